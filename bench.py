@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: Msamples/s (input f32 values) of the 128-tap polyphase FIR,
+2 ch 44.1 kHz -> 48 kHz (BASELINE.json configs[1]), inputs resident in HBM.
+
+A step = one pass of the hot path over one batch: `--streams` independent 2-channel streams, each
+a fresh 2^20-frame sine sweep (reset + the reference's bulk driver loop with 512-value chunks,
+resample/src/main.rs:226-254), all streams in ONE launch of the periodic FIR kernel.  One stream
+alone is 8 MiB in / 8.7 MiB out -- microseconds of HBM time -- so the single-GPU workload is a
+batch of them (weak scaling: every rank owns `--streams` streams; no data-path collective).
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (fir_periodic_kernel),
+timed with HIP events on the launch stream inside the library (rsmp_fir_set_profiling);
+`cpu_baseline` is the oracle's AVX+FMA restatement of the reference path on one host core.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+IN_HZ, OUT_HZ, CHANNELS = 44100, 48000, 2
+
+
+def cpu_baseline(frames: int, seconds: float):
+    """Oracle (port of the reference AVX+FMA path, fir/avx.rs + resampler_fir.rs) on ONE core:
+    the same 2 ch 44.1k->48k 128-tap sweep, 512-value chunks, repeated for ~`seconds`."""
+    from oracle import pyoracle as orc
+    from resampler_amd import synth
+    kind = orc.CONVOLVE_AVX_FMA if orc.have_avx_fma() else orc.CONVOLVE_SCALAR
+    r = orc.OracleFir(CHANNELS, IN_HZ, OUT_HZ, 128, 90, kind)
+    x = synth.sweep(frames, CHANNELS, float(IN_HZ))
+    r.resample_all(x[: 2 * 65536], 512)          # warm caches / page in
+    t0 = time.perf_counter()
+    values = 0
+    passes = 0
+    while True:
+        r.resample_all(x, 512)
+        values += x.size
+        passes += 1
+        if time.perf_counter() - t0 >= seconds:
+            break
+    dt = time.perf_counter() - t0
+    return {
+        "value": round(values / dt / 1e6, 3),
+        "unit": "Msamples/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"{passes} passes of one {frames}-frame 2ch sweep, 512-value calls, "
+                  f"{'AVX+FMA' if kind == orc.CONVOLVE_AVX_FMA else 'scalar'} convolve, {dt:.1f} s",
+    }
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--streams", type=int, default=64, help="streams per GPU")
+    ap.add_argument("--frames", type=int, default=1 << 20, help="input frames per stream per step")
+    ap.add_argument("--chunk", type=int, default=512, help="reference call size in f32 values")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--kernel", choices=["auto", "generic", "periodic"], default="auto")
+    args = ap.parse_args()
+
+    import torch
+    import resampler_amd as ra
+    from resampler_amd import synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    if not torch.cuda.is_available() or ra.device_count() < 1:
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device(f"cuda:{local_rank}")
+
+    S, N = args.streams, args.frames
+    kernel = {"auto": ra.FirKernel.Auto, "generic": ra.FirKernel.Generic,
+              "periodic": ra.FirKernel.Periodic}[args.kernel]
+    handles = []
+    for _ in range(S):
+        h = ra.ResamplerFir.new(CHANNELS, ra.SampleRate.Hz44100, ra.SampleRate.Hz48000,
+                                ra.Latency.Sample64, ra.Attenuation.Db90, device=local_rank)
+        h.set_kernel(kernel)
+        handles.append(h)
+    # Synthetic input: the sweep, a different gain per stream so every stream has its own buffer.
+    base = torch.from_numpy(synth.sweep(N, CHANNELS, float(IN_HZ))).to(dev)
+    gains = torch.linspace(0.5, 1.0, S, device=dev)
+    d_in = [(base * gains[i]).contiguous() for i in range(S)]
+    cap = handles[0].bulk_output_bound(CHANNELS * N, args.chunk)
+    d_out = [torch.empty(cap, device=dev, dtype=torch.float32) for _ in range(S)]
+    batch = ra.FirBatch(handles)
+    batch.bind(d_in, d_out)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        for h in handles:
+            h.reset()                     # a fresh stream per step (a new file)
+        return batch.resample_bulk_device(args.chunk, stream)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    t_plan0 = time.perf_counter()
+    consumed, produced = step()          # first step also builds the plan / class table
+    torch.cuda.synchronize()
+    plan_cold_ms = (time.perf_counter() - t_plan0) * 1e3
+    assert all(c == CHANNELS * N for c in consumed), "bulk call must consume every frame"
+    for _ in range(max(0, args.warmup - 1)):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # Dominant-kernel time: HIP events around the convolution launch on its own stream.
+    handles[0].set_profiling(True)
+    kernel_ms = []
+    for _ in range(min(10, max(3, args.steps))):
+        step()
+        kernel_ms.append(handles[0].last_kernel_ms())
+    handles[0].set_profiling(False)
+    torch.cuda.synchronize()
+    k_ms = float(np.mean(kernel_ms))
+
+    values_in_per_step = S * CHANNELS * N            # per rank
+    values_out_per_step = sum(produced)
+    alg_bytes = 4.0 * (values_in_per_step + values_out_per_step) + 4.0 * 1024 * 128
+    achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    if rank == 0:
+        total_values = values_in_per_step * world * args.steps
+        line = {
+            "metric": "Msamples/s (in) 44.1k->48k FIR 128-tap",
+            "value": round(total_values / dt / 1e6, 1),
+            "unit": "Msamples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"ResamplerFir 2ch interleaved 44100->48000, 128-tap (Sample64/Db90), "
+                            f"{S} streams/GPU x {N}-frame sine sweep per step, bulk driver loop "
+                            f"with {args.chunk}-value calls, one launch per step",
+                "streams_per_gpu": S,
+                "frames_per_stream": N,
+                "kernel": args.kernel,
+                "out_values_per_step": int(values_out_per_step),
+                "plan_cold_ms": round(plan_cold_ms, 2),
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "fir_periodic_kernel" if args.kernel != "generic" else "fir_generic_kernel",
+                "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": traffic,
+                "kernel_ms": round(k_ms, 4),
+                "algorithmic_bytes": int(alg_bytes),
+                "valu_fma_per_s": round(values_out_per_step * 128 / (k_ms * 1e-3) / 1e12, 2),
+            },
+        }
+        if not args.no_cpu:
+            line["cpu_baseline"] = cpu_baseline(N, args.cpu_seconds)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

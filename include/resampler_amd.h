@@ -1,0 +1,150 @@
+/*
+ * resampler_amd.h -- C ABI of the MI355X-native resampling engine (libresampler_amd.so).
+ *
+ * Drop-in boundary for the hot path of hasenbanck/resampler v0.5.1: each entry point names the
+ * reference interface it replaces (file:line relative to the reference repository).  Plain
+ * pointers and sizes only; all buffers are interleaved f32 frames, all counts are numbers of f32
+ * values across all channels exactly as in the reference (src/resampler_fir.rs:617-620).
+ *
+ * Pointers named `in`/`out` are HOST pointers; pointers named `d_in`/`d_out` are DEVICE (HBM)
+ * pointers on the handle's device.  `stream` is a hipStream_t passed as void* (NULL = the
+ * handle's own stream).  Device entry points are asynchronous on `stream`; the returned counts
+ * are exact and available immediately (they come from the host-side mirror of the reference
+ * state machine, not from the GPU).
+ *
+ * There is no CPU fallback: every compute entry point fails with RSMP_ERR_NO_DEVICE when no HIP
+ * device is present.  The rsmp_*_plan_* / rsmp_design_* entry points are host-only (filter
+ * design, FFT planning, and the (consumed, produced) state machine) and work without a GPU.
+ */
+#ifndef RESAMPLER_AMD_H
+#define RESAMPLER_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes: 1 and 2 are ResampleError (src/error.rs:3-8) ------------------------------- */
+enum {
+    RSMP_OK = 0,
+    RSMP_ERR_INVALID_INPUT_BUFFER_SIZE = 1,  /* ResampleError::InvalidInputBufferSize  */
+    RSMP_ERR_INVALID_OUTPUT_BUFFER_SIZE = 2, /* ResampleError::InvalidOutputBufferSize */
+    RSMP_ERR_INVALID_ARGUMENT = 3,           /* where the reference panics (resampler_fir.rs:302-309) */
+    RSMP_ERR_NO_DEVICE = 4,
+    RSMP_ERR_HIP = 5,
+    RSMP_ERR_CAPACITY = 6                    /* caller-provided array too small (bulk/plan calls) */
+};
+
+/* enum SampleRate (src/lib.rs:167-188), same order as the reference. */
+enum {
+    RSMP_HZ22050 = 0, RSMP_HZ16000, RSMP_HZ32000, RSMP_HZ44100, RSMP_HZ48000,
+    RSMP_HZ88200, RSMP_HZ96000, RSMP_HZ176400, RSMP_HZ192000, RSMP_HZ384000
+};
+/* enum Latency (src/resampler_fir.rs:139-149): taps = 16, 32, 64, 128. */
+enum { RSMP_LATENCY_SAMPLE8 = 0, RSMP_LATENCY_SAMPLE16, RSMP_LATENCY_SAMPLE32, RSMP_LATENCY_SAMPLE64 };
+/* enum Attenuation (src/resampler_fir.rs:102-110): Kaiser beta = 7, 10, 13. */
+enum { RSMP_ATTENUATION_DB60 = 0, RSMP_ATTENUATION_DB90, RSMP_ATTENUATION_DB120 };
+
+/* FIR kernel selection (rsmp_fir_set_kernel).  AUTO picks PERIODIC when the rate pair reduces to
+ * a small rational and the launch is long enough, GENERIC otherwise. */
+enum { RSMP_FIR_KERNEL_AUTO = 0, RSMP_FIR_KERNEL_GENERIC = 1, RSMP_FIR_KERNEL_PERIODIC = 2 };
+
+const char* rsmp_last_error(void);          /* thread-local message of the last failing call */
+int rsmp_device_count(void);                /* number of HIP devices, 0 when there is none   */
+const char* rsmp_version(void);
+/* impl From<SampleRate> for u32 (src/lib.rs:219-236); 0 for an invalid enum value. */
+uint32_t rsmp_sample_rate_hz(int sample_rate);
+
+/* ============================ ResamplerFir (src/resampler_fir.rs) =============================== */
+typedef struct rsmp_fir rsmp_fir;
+
+/* ResamplerFir::new (resampler_fir.rs:252-266).  NULL + rsmp_last_error() on failure. */
+rsmp_fir* rsmp_fir_new(size_t channels, int input_rate, int output_rate, int latency,
+                       int attenuation, int device);
+/* ResamplerFir::new_from_hz (resampler_fir.rs:295-404); zero rates -> NULL (reference panics). */
+rsmp_fir* rsmp_fir_new_from_hz(size_t channels, uint32_t input_rate_hz, uint32_t output_rate_hz,
+                               int latency, int attenuation, int device);
+/* Drop (resampler_fir.rs:61-67 et al.). */
+void rsmp_fir_free(rsmp_fir* r);
+/* ResamplerFir::buffer_size_output (resampler_fir.rs:456-465). */
+size_t rsmp_fir_buffer_size_output(const rsmp_fir* r);
+/* ResamplerFir::delay (resampler_fir.rs:630-632). */
+size_t rsmp_fir_delay(const rsmp_fir* r);
+/* ResamplerFir::reset (resampler_fir.rs:638-642). */
+void rsmp_fir_reset(rsmp_fir* r);
+/* fmt::Debug fields (resampler_fir.rs:203-211). */
+size_t rsmp_fir_channels(const rsmp_fir* r);
+size_t rsmp_fir_taps(const rsmp_fir* r);
+size_t rsmp_fir_phases(const rsmp_fir* r);
+int rsmp_fir_set_kernel(rsmp_fir* r, int kernel);
+/* Measurement hook: when enabled, the convolution launch(es) of every call made through this
+ * handle (the first handle of a batch call) are bracketed by HIP events on the launch stream;
+ * rsmp_fir_last_kernel_ms waits for the last one and returns its duration. */
+int rsmp_fir_set_profiling(rsmp_fir* r, int enable);
+int rsmp_fir_last_kernel_ms(rsmp_fir* r, float* ms);
+
+/* ResamplerFir::resample (resampler_fir.rs:509-621): one call, host buffers, synchronous. */
+int rsmp_fir_resample(rsmp_fir* r, const float* in, size_t in_len, float* out, size_t out_len,
+                      size_t* consumed, size_t* produced);
+/* Same call with HBM-resident buffers, asynchronous on `stream`. */
+int rsmp_fir_resample_device(rsmp_fir* r, const float* d_in, size_t in_len, float* d_out,
+                             size_t out_len, size_t* consumed, size_t* produced, void* stream);
+
+/* Bulk form: the result is DEFINED as what the reference driver loop resample_batch_fir
+ * (resample/src/main.rs:226-254) returns when it feeds `chunk_len`-value slices (the CLI uses
+ * 512) through resample() with a buffer_size_output() scratch: same output values, same total
+ * count, same per-call (consumed, produced) pairs (written to calls[2*i], calls[2*i+1] for the
+ * first max_calls calls; calls may be NULL).  One kernel launch for the whole buffer.
+ * out_cap must hold every produced value (RSMP_ERR_CAPACITY otherwise; use
+ * rsmp_fir_bulk_output_bound). */
+size_t rsmp_fir_bulk_output_bound(const rsmp_fir* r, size_t in_len, size_t chunk_len);
+int rsmp_fir_resample_bulk(rsmp_fir* r, const float* in, size_t in_len, size_t chunk_len,
+                           float* out, size_t out_cap, size_t* consumed, size_t* produced,
+                           size_t* calls, size_t max_calls, size_t* n_calls);
+int rsmp_fir_resample_bulk_device(rsmp_fir* r, const float* d_in, size_t in_len, size_t chunk_len,
+                                  float* d_out, size_t out_cap, size_t* consumed, size_t* produced,
+                                  size_t* calls, size_t max_calls, size_t* n_calls, void* stream);
+
+/* Batch form: n independent resampler instances (all on the same device), stream i processing
+ * d_in[i] -> d_out[i] with bulk semantics, all in ONE launch per kernel flavour.  This is the
+ * unit that is sharded across GPUs (one process per GPU, a contiguous range of streams each). */
+int rsmp_fir_batch_resample_bulk_device(rsmp_fir* const* rs, size_t n, const float* const* d_in,
+                                        const size_t* in_lens, size_t chunk_len,
+                                        float* const* d_out, const size_t* out_caps,
+                                        size_t* consumed, size_t* produced, void* stream);
+
+/* ---- host-only: filter design and the (consumed, produced) state machine ----------------------- */
+/* make_sincs_for_kaiser table exactly as ResamplerFir::create_fir_coeffs lays it out
+ * (resampler_fir.rs:406-422, window.rs:17-55): out[1024][taps]. */
+int rsmp_design_fir_coeffs(uint32_t input_rate_hz, uint32_t output_rate_hz, int latency,
+                           int attenuation, float* out, size_t out_len);
+/* calculate_cutoff_kaiser (window.rs:114-131). */
+double rsmp_design_cutoff_kaiser(size_t sample_count, double beta);
+
+typedef struct rsmp_fir_plan rsmp_fir_plan;   /* host mirror of {read_position, available_frames, position} */
+typedef struct {
+    uint32_t out_start;   /* index of the first output frame of the run inside the launch      */
+    uint32_t count;       /* output frames in the run                                          */
+    int64_t in_base;      /* input frame (relative to the first buffered frame at launch start) */
+                          /* that local position 0.0 refers to                                  */
+    double p0;            /* position of the run's first frame (resampler_fir.rs:544)          */
+    double inc;           /* exact position increment inside the run: p_k = p0 + k*inc         */
+} rsmp_fir_segment;
+
+rsmp_fir_plan* rsmp_fir_plan_new(uint32_t input_rate_hz, uint32_t output_rate_hz, int latency);
+void rsmp_fir_plan_free(rsmp_fir_plan* p);
+void rsmp_fir_plan_reset(rsmp_fir_plan* p);
+void rsmp_fir_plan_state(const rsmp_fir_plan* p, size_t* read_position, size_t* available_frames,
+                         double* position);
+/* One reference resample() call in frames: how many input frames are accepted, how many output
+ * frames are produced, and the exact position runs (segs may be NULL). */
+int rsmp_fir_plan_call(rsmp_fir_plan* p, size_t input_frames, size_t output_capacity_frames,
+                       size_t* frames_accepted, size_t* frames_produced, rsmp_fir_segment* segs,
+                       size_t max_segs, size_t* n_segs);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

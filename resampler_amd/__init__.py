@@ -1,0 +1,402 @@
+"""resampler_amd -- MI355X-native audio resampling engine (host-side mirror of the reference API).
+
+The product is the C-ABI shared library ``libresampler_amd.so`` (HIP kernels for gfx950 + C++ host
+runtime, see ``include/resampler_amd.h``).  This module is the thin Python binding the tests and
+the bench use; class and method names follow the reference crate (``ResamplerFir::new``,
+``new_from_hz``, ``buffer_size_output``, ``resample``, ``delay``, ``reset`` --
+src/resampler_fir.rs:252-642; ``ResamplerFft::new``, ``chunk_size_input``, ``chunk_size_output``,
+``delay``, ``resample`` -- src/resampler_fft.rs:75-240).
+
+There is no CPU compute path in here: if the library is missing, or there is no HIP device, the
+constructors raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import enum
+import os
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libresampler_amd.so")
+
+
+class ResampleError(Exception):
+    """ResampleError (src/error.rs:3-8) plus the argument / device errors of the C ABI."""
+
+    def __init__(self, code: int, message: str):
+        super().__init__(f"[{code}] {message}")
+        self.code = code
+
+
+class InvalidInputBufferSize(ResampleError):
+    pass
+
+
+class InvalidOutputBufferSize(ResampleError):
+    pass
+
+
+class SampleRate(enum.IntEnum):
+    """enum SampleRate (src/lib.rs:167-188), same order."""
+    Hz22050 = 0
+    Hz16000 = 1
+    Hz32000 = 2
+    Hz44100 = 3
+    Hz48000 = 4
+    Hz88200 = 5
+    Hz96000 = 6
+    Hz176400 = 7
+    Hz192000 = 8
+    Hz384000 = 9
+
+    @property
+    def hz(self) -> int:
+        return lib().rsmp_sample_rate_hz(int(self))
+
+
+class Latency(enum.IntEnum):
+    """enum Latency (src/resampler_fir.rs:139-149)."""
+    Sample8 = 0
+    Sample16 = 1
+    Sample32 = 2
+    Sample64 = 3
+
+    def taps(self) -> int:
+        return (16, 32, 64, 128)[int(self)]
+
+
+class Attenuation(enum.IntEnum):
+    """enum Attenuation (src/resampler_fir.rs:102-110)."""
+    Db60 = 0
+    Db90 = 1
+    Db120 = 2
+
+
+class FirKernel(enum.IntEnum):
+    Auto = 0
+    Generic = 1
+    Periodic = 2
+
+
+RSMP_OK = 0
+_f32p = C.POINTER(C.c_float)
+_szp = C.POINTER(C.c_size_t)
+
+
+class _Segment(C.Structure):
+    _fields_ = [("out_start", C.c_uint32), ("count", C.c_uint32), ("in_base", C.c_int64),
+                ("p0", C.c_double), ("inc", C.c_double)]
+
+
+_lib = None
+
+# Every symbol include/resampler_amd.h declares: (name, restype, argtypes).
+_SIGNATURES = [
+    ("rsmp_last_error", C.c_char_p, []),
+    ("rsmp_device_count", C.c_int, []),
+    ("rsmp_version", C.c_char_p, []),
+    ("rsmp_sample_rate_hz", C.c_uint32, [C.c_int]),
+    ("rsmp_fir_new", C.c_void_p, [C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    ("rsmp_fir_new_from_hz", C.c_void_p, [C.c_size_t, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_int]),
+    ("rsmp_fir_free", None, [C.c_void_p]),
+    ("rsmp_fir_buffer_size_output", C.c_size_t, [C.c_void_p]),
+    ("rsmp_fir_delay", C.c_size_t, [C.c_void_p]),
+    ("rsmp_fir_reset", None, [C.c_void_p]),
+    ("rsmp_fir_channels", C.c_size_t, [C.c_void_p]),
+    ("rsmp_fir_taps", C.c_size_t, [C.c_void_p]),
+    ("rsmp_fir_phases", C.c_size_t, [C.c_void_p]),
+    ("rsmp_fir_set_kernel", C.c_int, [C.c_void_p, C.c_int]),
+    ("rsmp_fir_set_profiling", C.c_int, [C.c_void_p, C.c_int]),
+    ("rsmp_fir_last_kernel_ms", C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    ("rsmp_fir_resample", C.c_int, [C.c_void_p, _f32p, C.c_size_t, _f32p, C.c_size_t, _szp, _szp]),
+    ("rsmp_fir_resample_device", C.c_int,
+     [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, _szp, _szp, C.c_void_p]),
+    ("rsmp_fir_bulk_output_bound", C.c_size_t, [C.c_void_p, C.c_size_t, C.c_size_t]),
+    ("rsmp_fir_resample_bulk", C.c_int,
+     [C.c_void_p, _f32p, C.c_size_t, C.c_size_t, _f32p, C.c_size_t, _szp, _szp, _szp, C.c_size_t, _szp]),
+    ("rsmp_fir_resample_bulk_device", C.c_int,
+     [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, _szp, _szp, _szp,
+      C.c_size_t, _szp, C.c_void_p]),
+    ("rsmp_fir_batch_resample_bulk_device", C.c_int,
+     [C.POINTER(C.c_void_p), C.c_size_t, C.POINTER(C.c_void_p), _szp, C.c_size_t,
+      C.POINTER(C.c_void_p), _szp, _szp, _szp, C.c_void_p]),
+    ("rsmp_design_fir_coeffs", C.c_int, [C.c_uint32, C.c_uint32, C.c_int, C.c_int, _f32p, C.c_size_t]),
+    ("rsmp_design_cutoff_kaiser", C.c_double, [C.c_size_t, C.c_double]),
+    ("rsmp_fir_plan_new", C.c_void_p, [C.c_uint32, C.c_uint32, C.c_int]),
+    ("rsmp_fir_plan_free", None, [C.c_void_p]),
+    ("rsmp_fir_plan_reset", None, [C.c_void_p]),
+    ("rsmp_fir_plan_state", None, [C.c_void_p, _szp, _szp, C.POINTER(C.c_double)]),
+    ("rsmp_fir_plan_call", C.c_int,
+     [C.c_void_p, C.c_size_t, C.c_size_t, _szp, _szp, C.POINTER(_Segment), C.c_size_t, _szp]),
+]
+
+
+def declared_symbols() -> Sequence[str]:
+    return [s[0] for s in _SIGNATURES]
+
+
+def lib() -> C.CDLL:
+    """Loads libresampler_amd.so (built by __graft_entry__.build / make -C resampler_amd/csrc)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(there is no Python/CPU fallback for the HIP path)")
+    L = C.CDLL(LIB_PATH)
+    for name, restype, argtypes in _SIGNATURES:
+        fn = getattr(L, name)
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = L
+    return L
+
+
+def last_error() -> str:
+    return lib().rsmp_last_error().decode()
+
+
+def device_count() -> int:
+    return lib().rsmp_device_count()
+
+
+def _check(rc: int) -> None:
+    if rc == RSMP_OK:
+        return
+    msg = last_error()
+    if rc == 1:
+        raise InvalidInputBufferSize(rc, msg)
+    if rc == 2:
+        raise InvalidOutputBufferSize(rc, msg)
+    raise ResampleError(rc, msg)
+
+
+def _np_f32(a) -> np.ndarray:
+    a = np.asarray(a)
+    if a.dtype != np.float32 or not a.flags["C_CONTIGUOUS"]:
+        a = np.ascontiguousarray(a, np.float32)
+    return a
+
+
+def _ptr(a: np.ndarray):
+    return a.ctypes.data_as(_f32p)
+
+
+def _dev_ptr(t) -> int:
+    """Device pointer of a torch CUDA tensor (float32, contiguous)."""
+    assert t.is_cuda and t.is_contiguous() and str(t.dtype) == "torch.float32"
+    return t.data_ptr()
+
+
+class ResamplerFir:
+    """GPU-backed ResamplerFir (src/resampler_fir.rs:179-643)."""
+
+    def __init__(self, channels: int, input_rate, output_rate, latency: Latency = Latency.Sample64,
+                 attenuation: Attenuation = Attenuation.Db120, device: int = 0, *, _from_hz=False):
+        L = lib()
+        if _from_hz:
+            h = L.rsmp_fir_new_from_hz(channels, int(input_rate), int(output_rate), int(latency),
+                                       int(attenuation), device)
+        else:
+            h = L.rsmp_fir_new(channels, int(SampleRate(input_rate)), int(SampleRate(output_rate)),
+                               int(latency), int(attenuation), device)
+        if not h:
+            raise ResampleError(3, last_error())
+        self._h = C.c_void_p(h)
+        self.device = device
+
+    # ResamplerFir::new / new_from_hz -------------------------------------------------------------
+    @classmethod
+    def new(cls, channels, input_rate: SampleRate, output_rate: SampleRate,
+            latency: Latency = Latency.Sample64, attenuation: Attenuation = Attenuation.Db120,
+            device: int = 0) -> "ResamplerFir":
+        return cls(channels, input_rate, output_rate, latency, attenuation, device)
+
+    @classmethod
+    def new_from_hz(cls, channels, input_rate_hz: int, output_rate_hz: int,
+                    latency: Latency = Latency.Sample64, attenuation: Attenuation = Attenuation.Db120,
+                    device: int = 0) -> "ResamplerFir":
+        if input_rate_hz < 0 or output_rate_hz < 0:
+            raise ValueError("sample rates are u32")
+        return cls(channels, input_rate_hz, output_rate_hz, latency, attenuation, device, _from_hz=True)
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            lib().rsmp_fir_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __repr__(self) -> str:  # fmt::Debug, resampler_fir.rs:203-211
+        return f"ResamplerFir {{ channels: {self.channels}, taps: {self.taps}, phases: {self.phases}, .. }}"
+
+    @property
+    def channels(self) -> int:
+        return lib().rsmp_fir_channels(self._h)
+
+    @property
+    def taps(self) -> int:
+        return lib().rsmp_fir_taps(self._h)
+
+    @property
+    def phases(self) -> int:
+        return lib().rsmp_fir_phases(self._h)
+
+    def buffer_size_output(self) -> int:
+        return lib().rsmp_fir_buffer_size_output(self._h)
+
+    def delay(self) -> int:
+        return lib().rsmp_fir_delay(self._h)
+
+    def reset(self) -> None:
+        lib().rsmp_fir_reset(self._h)
+
+    def set_kernel(self, kernel: FirKernel) -> None:
+        _check(lib().rsmp_fir_set_kernel(self._h, int(kernel)))
+
+    def set_profiling(self, enable: bool) -> None:
+        _check(lib().rsmp_fir_set_profiling(self._h, 1 if enable else 0))
+
+    def last_kernel_ms(self) -> float:
+        ms = C.c_float()
+        _check(lib().rsmp_fir_last_kernel_ms(self._h, C.byref(ms)))
+        return ms.value
+
+    # ResamplerFir::resample (host slices) --------------------------------------------------------
+    def resample(self, input, output: np.ndarray) -> Tuple[int, int]:
+        """Returns (consumed, produced) in f32 values; raises ResampleError like Err(..)."""
+        inp = _np_f32(input)
+        assert output.dtype == np.float32 and output.flags["C_CONTIGUOUS"]
+        c, p = C.c_size_t(), C.c_size_t()
+        _check(lib().rsmp_fir_resample(self._h, _ptr(inp), inp.size, _ptr(output), output.size,
+                                       C.byref(c), C.byref(p)))
+        return c.value, p.value
+
+    def resample_device(self, d_in, d_out, stream: Optional[int] = None) -> Tuple[int, int]:
+        """Same call on HBM-resident torch tensors (async on `stream`, a hipStream_t value)."""
+        c, p = C.c_size_t(), C.c_size_t()
+        _check(lib().rsmp_fir_resample_device(self._h, _dev_ptr(d_in), d_in.numel(), _dev_ptr(d_out),
+                                              d_out.numel(), C.byref(c), C.byref(p),
+                                              C.c_void_p(stream or 0)))
+        return c.value, p.value
+
+    # Bulk: the CLI driver loop (resample/src/main.rs:226-254) in one launch ------------------------
+    def bulk_output_bound(self, in_len: int, chunk_len: int = 512) -> int:
+        return lib().rsmp_fir_bulk_output_bound(self._h, in_len, chunk_len)
+
+    def resample_bulk(self, input, chunk_len: int = 512, want_calls: bool = False):
+        """Returns (output[:produced], consumed) or (output, consumed, calls[n,2])."""
+        inp = _np_f32(input)
+        cap = self.bulk_output_bound(inp.size, chunk_len)
+        out = np.empty(cap, np.float32)
+        c, p, nc = C.c_size_t(), C.c_size_t(), C.c_size_t()
+        max_calls = (inp.size // max(1, chunk_len) + 2) if want_calls else 0
+        calls = np.zeros(2 * max(1, max_calls), np.uintp)
+        _check(lib().rsmp_fir_resample_bulk(self._h, _ptr(inp), inp.size, chunk_len, _ptr(out), cap,
+                                            C.byref(c), C.byref(p),
+                                            calls.ctypes.data_as(_szp) if want_calls else None,
+                                            max_calls, C.byref(nc)))
+        if want_calls:
+            k = min(nc.value, max_calls)
+            return out[:p.value], c.value, calls[:2 * k].reshape(k, 2).astype(np.int64)
+        return out[:p.value], c.value
+
+    def resample_bulk_device(self, d_in, d_out, chunk_len: int = 512, stream: Optional[int] = None,
+                             in_len: Optional[int] = None) -> Tuple[int, int]:
+        c, p, nc = C.c_size_t(), C.c_size_t(), C.c_size_t()
+        n_in = d_in.numel() if in_len is None else in_len
+        _check(lib().rsmp_fir_resample_bulk_device(self._h, _dev_ptr(d_in), n_in, chunk_len,
+                                                   _dev_ptr(d_out), d_out.numel(), C.byref(c),
+                                                   C.byref(p), None, 0, C.byref(nc),
+                                                   C.c_void_p(stream or 0)))
+        return c.value, p.value
+
+
+class FirBatch:
+    """N independent ResamplerFir instances on one device processed in one launch per step
+    (rsmp_fir_batch_resample_bulk_device) -- the unit sharded across GPUs."""
+
+    def __init__(self, resamplers: Sequence[ResamplerFir]):
+        self.resamplers = list(resamplers)
+        n = len(self.resamplers)
+        self._handles = (C.c_void_p * n)(*[r._h for r in self.resamplers])
+        self._in = (C.c_void_p * n)()
+        self._out = (C.c_void_p * n)()
+        self._in_lens = (C.c_size_t * n)()
+        self._out_caps = (C.c_size_t * n)()
+        self._consumed = (C.c_size_t * n)()
+        self._produced = (C.c_size_t * n)()
+
+    def bind(self, d_ins, d_outs) -> None:
+        """Binds one input and one output tensor per stream (kept until the next bind)."""
+        self._keep = (list(d_ins), list(d_outs))
+        for i, (a, b) in enumerate(zip(d_ins, d_outs)):
+            self._in[i] = _dev_ptr(a)
+            self._out[i] = _dev_ptr(b)
+            self._in_lens[i] = a.numel()
+            self._out_caps[i] = b.numel()
+
+    def resample_bulk_device(self, chunk_len: int = 512, stream: Optional[int] = None):
+        n = len(self.resamplers)
+        _check(lib().rsmp_fir_batch_resample_bulk_device(
+            self._handles, n, self._in, self._in_lens, chunk_len, self._out, self._out_caps,
+            self._consumed, self._produced, C.c_void_p(stream or 0)))
+        return list(self._consumed), list(self._produced)
+
+
+# ---- host-only helpers (no GPU needed) -----------------------------------------------------------
+def design_fir_coeffs(input_rate_hz: int, output_rate_hz: int, latency: Latency,
+                      attenuation: Attenuation) -> np.ndarray:
+    taps = Latency(latency).taps()
+    out = np.empty((1024, taps), np.float32)
+    _check(lib().rsmp_design_fir_coeffs(input_rate_hz, output_rate_hz, int(latency), int(attenuation),
+                                        _ptr(out), out.size))
+    return out
+
+
+def design_cutoff_kaiser(sample_count: int, beta: float) -> float:
+    return lib().rsmp_design_cutoff_kaiser(sample_count, beta)
+
+
+class FirPlan:
+    """Host mirror of the ResamplerFir state machine (counts and exact positions, no samples)."""
+
+    def __init__(self, input_rate_hz: int, output_rate_hz: int, latency: Latency = Latency.Sample64):
+        h = lib().rsmp_fir_plan_new(input_rate_hz, output_rate_hz, int(latency))
+        if not h:
+            raise ResampleError(3, last_error())
+        self._h = C.c_void_p(h)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().rsmp_fir_plan_free(self._h)
+            self._h = None
+
+    def reset(self) -> None:
+        lib().rsmp_fir_plan_reset(self._h)
+
+    def state(self):
+        rp, av, pos = C.c_size_t(), C.c_size_t(), C.c_double()
+        lib().rsmp_fir_plan_state(self._h, C.byref(rp), C.byref(av), C.byref(pos))
+        return rp.value, av.value, pos.value
+
+    def call(self, input_frames: int, output_capacity_frames: int, want_segments: bool = False):
+        """One resample() call in frames -> (accepted, produced[, segments])."""
+        a, p, ns = C.c_size_t(), C.c_size_t(), C.c_size_t()
+        max_segs = 8192 if want_segments else 0
+        segs = (_Segment * max(1, max_segs))()
+        _check(lib().rsmp_fir_plan_call(self._h, input_frames, output_capacity_frames, C.byref(a),
+                                        C.byref(p), segs if want_segments else None, max_segs,
+                                        C.byref(ns)))
+        if want_segments:
+            return a.value, p.value, [(s.out_start, s.count, s.in_base, s.p0, s.inc)
+                                      for s in segs[:ns.value]]
+        return a.value, p.value

@@ -1,0 +1,709 @@
+// fir_api.cpp -- ResamplerFir front-end on the GPU: handles, state, launch assembly, C ABI.
+//
+// Mirrors src/resampler_fir.rs of the reference: construction (:295-404), buffer_size_output
+// (:456-465), resample (:509-621), delay (:630-632), reset (:638-642).  The per-call control
+// flow (how many frames are accepted / produced / retired) runs on the host in FirMirror; the
+// arithmetic runs in one launch of fir_generic / fir_periodic per call, bulk buffer or batch.
+//
+// Device-side stream state: instead of the reference's planar double-size ring
+// (input_buffers, :187, :329) each stream keeps only the frames still buffered
+// (available_frames <= 4096) as an interleaved `hist` array, ping-ponged between two HBM
+// buffers; a launch reads the virtual concatenation [hist | new input] and a small tail-copy
+// kernel writes the next hist.  There is no CPU fallback anywhere in this file.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <vector>
+
+#include "common.h"
+#include "device_util.h"
+#include "filter_design.h"
+#include "fir_kernels.h"
+#include "fir_periodic.h"
+#include "fir_plan.h"
+
+using rsmp::DeviceBuffer;
+using rsmp::DeviceGuard;
+using rsmp::FirMirror;
+using rsmp::FirStreamDesc;
+using rsmp::PinnedBuffer;
+
+namespace {
+
+// Per-device cache of uploaded polyphase tables (the device-side half of the reference's
+// FIR_CACHE, resampler_fir.rs:164-166): key = (device, host table identity).
+struct DeviceTableCache {
+    std::mutex mu;
+    std::map<std::pair<int, const void*>, float*> tables;
+    // Keeps host tables alive for as long as their device copies are cached.
+    std::vector<std::shared_ptr<const std::vector<float>>> pins;
+};
+DeviceTableCache& table_cache() {
+    static DeviceTableCache* c = new DeviceTableCache;  // leaked on purpose (process lifetime)
+    return *c;
+}
+
+int upload_table(int device, const std::shared_ptr<const std::vector<float>>& host, float** out) {
+    DeviceTableCache& c = table_cache();
+    std::lock_guard<std::mutex> lock(c.mu);
+    const auto key = std::make_pair(device, static_cast<const void*>(host.get()));
+    auto it = c.tables.find(key);
+    if (it != c.tables.end()) { *out = it->second; return RSMP_OK; }
+    float* d = nullptr;
+    RSMP_HIP_CHECK(hipMalloc(&d, host->size() * sizeof(float)));
+    RSMP_HIP_CHECK(hipMemcpy(d, host->data(), host->size() * sizeof(float), hipMemcpyHostToDevice));
+    c.tables.emplace(key, d);
+    c.pins.push_back(host);
+    *out = d;
+    return RSMP_OK;
+}
+
+}  // namespace
+
+struct rsmp_fir {
+    int device = 0;
+    size_t channels = 0;
+    size_t taps = 0;
+    int attenuation = 0;
+    uint32_t in_hz = 0, out_hz = 0;
+    int kernel_mode = RSMP_FIR_KERNEL_AUTO;
+    FirMirror mirror;
+    std::shared_ptr<const std::vector<float>> table;
+    float* d_coeffs = nullptr;
+    float* d_hist[2] = {nullptr, nullptr};  // kInputCapacity * channels floats each
+    int cur = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t plan_copied = nullptr;
+    bool plan_pending = false;
+    // launch workspace (descs + runs + tile index), host-pinned and device
+    PinnedBuffer h_plan;
+    DeviceBuffer d_plan;
+    // staging for the host-pointer entry points
+    DeviceBuffer d_stage_in, d_stage_out;
+    rsmp::PeriodicState periodic;
+    // optional timing of the main convolution launch(es) (rsmp_fir_set_profiling)
+    bool profiling = false;
+    hipEvent_t prof_start = nullptr, prof_stop = nullptr;
+    bool prof_valid = false;
+
+    rsmp_fir(uint32_t i, uint32_t o, size_t t) : mirror(i, o, t) {}
+};
+
+namespace {
+
+rsmp_fir* fir_create(size_t channels, uint32_t in_hz, uint32_t out_hz, int latency,
+                     int attenuation, int device) {
+    const size_t taps = rsmp::latency_taps(latency);
+    const double beta = rsmp::attenuation_beta(attenuation);
+    if (channels == 0 || channels > 4096 || taps == 0 || beta < 0.0) {
+        rsmp::fail(RSMP_ERR_INVALID_ARGUMENT, "ResamplerFir: invalid channels/latency/attenuation");
+        return nullptr;
+    }
+    if (in_hz == 0) {  // resampler_fir.rs:302-305 panics
+        rsmp::fail(RSMP_ERR_INVALID_ARGUMENT, "input sample rate must be greater than zero");
+        return nullptr;
+    }
+    if (out_hz == 0) {  // resampler_fir.rs:306-309 panics
+        rsmp::fail(RSMP_ERR_INVALID_ARGUMENT, "output sample rate must be greater than zero");
+        return nullptr;
+    }
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) {
+        rsmp::fail(RSMP_ERR_NO_DEVICE, "ResamplerFir: no HIP device (this engine has no CPU path)");
+        return nullptr;
+    }
+    if (device < 0 || device >= n_dev) {
+        rsmp::fail(RSMP_ERR_INVALID_ARGUMENT, "ResamplerFir: device %d out of range (%d devices)",
+                   device, n_dev);
+        return nullptr;
+    }
+    DeviceGuard guard(device);
+    std::unique_ptr<rsmp_fir> r(new rsmp_fir(in_hz, out_hz, taps));
+    r->device = device;
+    r->channels = channels;
+    r->taps = taps;
+    r->attenuation = attenuation;
+    r->in_hz = in_hz;
+    r->out_hz = out_hz;
+    const rsmp::FirDesign design = rsmp::fir_design(in_hz, out_hz, taps, beta);
+    r->table = rsmp::get_or_create_fir_coeffs(design.cutoff, taps, attenuation);
+    if (upload_table(device, r->table, &r->d_coeffs) != RSMP_OK) return nullptr;
+    const size_t hist_bytes = rsmp::kInputCapacity * channels * sizeof(float);
+    for (int i = 0; i < 2; ++i) {
+        if (hipMalloc(&r->d_hist[i], hist_bytes) != hipSuccess ||
+            hipMemset(r->d_hist[i], 0, hist_bytes) != hipSuccess) {
+            rsmp::fail(RSMP_ERR_HIP, "ResamplerFir: cannot allocate stream state");
+            for (int j = 0; j <= i; ++j) if (r->d_hist[j]) (void)hipFree(r->d_hist[j]);
+            return nullptr;
+        }
+    }
+    if (hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&r->plan_copied, hipEventDisableTiming) != hipSuccess) {
+        rsmp::fail(RSMP_ERR_HIP, "ResamplerFir: cannot create stream/event");
+        return nullptr;
+    }
+    return r.release();
+}
+
+// The host-side result of replaying a reference call sequence: shared between the streams of a
+// batch that are in the same state and are fed the same amount of input (their control flow is
+// data independent, so one replay serves all of them).
+struct Plan {
+    FirMirror planned;                      // mirror state after the launch
+    std::vector<rsmp_fir_segment> segs;     // generic kernel: exact position runs
+    std::vector<uint32_t> wraps;            // periodic kernel: row-1023 fix-ups
+    std::vector<size_t> calls;              // (consumed, produced) per reference call, in values
+    size_t accepted_frames = 0;
+    size_t produced_frames = 0;
+    size_t consumed_frames = 0;
+    size_t hist_frames = 0;
+    bool periodic = false;
+    // workspace offsets (filled by launch_jobs)
+    size_t seg_off = 0, tile_off = 0, wrap_off = 0;
+    bool placed = false;
+    explicit Plan(const FirMirror& m) : planned(m) {}
+};
+
+struct PlanKey {
+    uint32_t in_hz, out_hz;
+    size_t taps, channels, read_position, available;
+    uint64_t position_bits, abs_out, abs_consumed;
+    size_t in_len, out_cap_or_zero, chunk_len;
+    int kernel_mode;
+    bool operator==(const PlanKey& o) const { return std::memcmp(this, &o, sizeof o) == 0; }
+};
+
+// One stream's part of a launch.
+struct Job {
+    rsmp_fir* r;
+    const float* d_in;
+    size_t in_len;     // f32 values offered
+    float* d_out;
+    size_t out_cap;    // f32 values of room
+    size_t chunk_len;  // 0: one reference call with output capacity out_cap; else bulk loop
+    std::shared_ptr<Plan> plan;
+    size_t consumed() const { return plan->accepted_frames * r->channels; }
+    size_t produced() const { return plan->produced_frames * r->channels; }
+};
+
+PlanKey make_key(const Job& j) {
+    PlanKey k;
+    std::memset(&k, 0, sizeof k);
+    const rsmp_fir* r = j.r;
+    k.in_hz = r->in_hz;
+    k.out_hz = r->out_hz;
+    k.taps = r->taps;
+    k.channels = r->channels;
+    k.read_position = r->mirror.read_position();
+    k.available = r->mirror.available();
+    const double pos = r->mirror.position();
+    std::memcpy(&k.position_bits, &pos, sizeof pos);
+    k.abs_out = r->mirror.abs_out();
+    k.abs_consumed = r->mirror.abs_consumed();
+    k.in_len = j.in_len;
+    k.out_cap_or_zero = j.chunk_len == 0 ? j.out_cap : 0;
+    k.chunk_len = j.chunk_len;
+    k.kernel_mode = r->kernel_mode;
+    return k;
+}
+
+// Process-wide plan cache.  A plan is a pure function of (configuration, stream state, amount of
+// input, chunking) -- no sample values -- so, like an FFT plan, it is built once and reused: a
+// service converting many files replays the same few plans over and over (every fresh stream
+// of a given length starts in the same state).  Bounded; oldest entry evicted first.
+struct PlanCache {
+    std::mutex mu;
+    std::vector<std::pair<PlanKey, std::shared_ptr<Plan>>> entries;
+    size_t next_evict = 0;
+    static constexpr size_t kMaxEntries = 64;
+
+    std::shared_ptr<Plan> find(const PlanKey& k) {
+        std::lock_guard<std::mutex> lock(mu);
+        for (auto& e : entries) if (e.first == k) return e.second;
+        return nullptr;
+    }
+    void insert(const PlanKey& k, const std::shared_ptr<Plan>& p) {
+        std::lock_guard<std::mutex> lock(mu);
+        if (entries.size() < kMaxEntries) { entries.emplace_back(k, p); return; }
+        entries[next_evict] = std::make_pair(k, p);
+        next_evict = (next_evict + 1) % kMaxEntries;
+    }
+};
+PlanCache& plan_cache() {
+    static PlanCache* c = new PlanCache;
+    return *c;
+}
+
+// Replays the reference call sequence on a copy of the mirror (committed only on success).
+int plan_job_uncached(Job& j, bool with_segments) {
+    rsmp_fir* r = j.r;
+    const size_t ch = r->channels;
+    if (j.in_len % ch != 0)
+        return rsmp::fail(RSMP_ERR_INVALID_INPUT_BUFFER_SIZE, "Input buffer size is invalid");
+    auto plan = std::make_shared<Plan>(r->mirror);
+    Plan& pl = *plan;
+    pl.hist_frames = pl.planned.available();
+    const bool want_periodic =
+        !with_segments && rsmp::periodic_supported(pl.planned, ch, r->taps, r->kernel_mode);
+    std::vector<uint32_t>* wraps = want_periodic ? &pl.wraps : nullptr;
+    std::vector<rsmp_fir_segment>* segs = want_periodic ? nullptr : &pl.segs;
+    const size_t in_frames_total = j.in_len / ch;
+    if (j.chunk_len == 0) {
+        if (j.out_cap % ch != 0)
+            return rsmp::fail(RSMP_ERR_INVALID_OUTPUT_BUFFER_SIZE, "Output buffer size is invalid");
+        const rsmp::FirCallResult c = pl.planned.call(in_frames_total, j.out_cap / ch, 0, 0, segs, wraps);
+        pl.accepted_frames = c.accepted;
+        pl.produced_frames = c.produced;
+        pl.consumed_frames = c.consumed;
+        pl.calls.push_back(c.accepted * ch);
+        pl.calls.push_back(c.produced * ch);
+    } else {
+        // resample/src/main.rs:226-254 with CHUNK_SIZE = chunk_len values
+        if (j.chunk_len % ch != 0)
+            return rsmp::fail(RSMP_ERR_INVALID_INPUT_BUFFER_SIZE,
+                              "Input buffer size is invalid (chunk_len not a multiple of channels)");
+        const size_t chunk_frames = j.chunk_len / ch;
+        const size_t cap_frames = pl.planned.buffer_size_output_frames();
+        size_t offset = 0;
+        while (offset < in_frames_total) {
+            const size_t remaining = in_frames_total - offset;
+            const size_t take = remaining < chunk_frames ? remaining : chunk_frames;
+            if (pl.produced_frames > 0xFFFFFFFFull - cap_frames)
+                return rsmp::fail(RSMP_ERR_CAPACITY, "bulk launch exceeds 2^32 output frames");
+            const rsmp::FirCallResult c =
+                pl.planned.call(take, cap_frames, static_cast<int64_t>(pl.consumed_frames),
+                                static_cast<uint32_t>(pl.produced_frames), segs, wraps);
+            pl.calls.push_back(c.accepted * ch);
+            pl.calls.push_back(c.produced * ch);
+            pl.produced_frames += c.produced;
+            pl.consumed_frames += c.consumed;
+            pl.accepted_frames += c.accepted;
+            offset += c.accepted;
+            if (c.accepted == 0) break;
+        }
+        if (pl.produced_frames * ch > j.out_cap)
+            return rsmp::fail(RSMP_ERR_CAPACITY, "bulk output needs %zu values, room for %zu",
+                              pl.produced_frames * ch, j.out_cap);
+    }
+    if (want_periodic) {
+        if (!pl.planned.periodic_ok() ||
+            !rsmp::periodic_worthwhile(pl.planned, pl.produced_frames, r->kernel_mode))
+            return plan_job_uncached(j, true);  // replay once more, keeping the position runs
+        pl.periodic = true;
+    }
+    j.plan = plan;
+    return RSMP_OK;
+}
+
+int plan_job(Job& j) {
+    if (j.chunk_len == 0) return plan_job_uncached(j, false);  // one call: cheaper than a lookup
+    const PlanKey key = make_key(j);
+    if (auto hit = plan_cache().find(key)) {
+        if (hit->produced_frames * j.r->channels > j.out_cap)
+            return rsmp::fail(RSMP_ERR_CAPACITY, "bulk output needs %zu values, room for %zu",
+                              hit->produced_frames * j.r->channels, j.out_cap);
+        j.plan = hit;
+        return RSMP_OK;
+    }
+    const int rc = plan_job_uncached(j, false);
+    if (rc == RSMP_OK) plan_cache().insert(key, j.plan);
+    return rc;
+}
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// Assembles and enqueues the launches for a set of planned jobs on one device / stream.
+// `leader` owns the launch workspace.
+int launch_jobs(rsmp_fir* leader, std::vector<Job>& jobs, hipStream_t stream) {
+    // Plans are shared objects carrying per-launch placement scratch: one assembly at a time.
+    static std::mutex assembly_mu;
+    std::lock_guard<std::mutex> assembly_lock(assembly_mu);
+    const size_t n = jobs.size();
+    // Bind class tables first (may upload), then order: generic jobs, then periodic jobs grouped
+    // by geometry (one launch per geometry).
+    std::vector<size_t> order;
+    size_t n_generic = 0;
+    for (size_t i = 0; i < n; ++i)
+        if (!jobs[i].plan->periodic) { order.push_back(i); ++n_generic; }
+    struct Group { rsmp::PeriodicGeometry geo; std::vector<size_t> members; };
+    std::vector<Group> groups;
+    for (size_t i = 0; i < n; ++i) {
+        Job& j = jobs[i];
+        if (!j.plan->periodic) continue;
+        const int rc = rsmp::periodic_bind(j.r->periodic, j.r->device, *j.r->table, j.plan->planned,
+                                           static_cast<uint32_t>(j.r->channels), stream);
+        if (rc != RSMP_OK) return rc;
+        bool found = false;
+        for (Group& g : groups)
+            if (g.geo == j.r->periodic.geo) { g.members.push_back(i); found = true; break; }
+        if (!found) groups.push_back(Group{j.r->periodic.geo, {i}});
+    }
+    for (const Group& g : groups) for (size_t i : g.members) order.push_back(i);
+
+    // Workspace layout: [descs] then per distinct plan: [runs][tile index] or [wraps].
+    size_t bytes = align_up(n * sizeof(FirStreamDesc), 256);
+    for (Job& j : jobs) j.plan->placed = false;
+    for (Job& j : jobs) {
+        Plan& pl = *j.plan;
+        if (pl.placed) continue;
+        pl.placed = true;
+        if (!pl.periodic) {
+            pl.seg_off = bytes;
+            bytes = align_up(bytes + pl.segs.size() * sizeof(rsmp_fir_segment), 256);
+            pl.tile_off = bytes;
+            const size_t tiles = (pl.produced_frames + rsmp::kFirTile - 1) / rsmp::kFirTile;
+            bytes = align_up(bytes + tiles * sizeof(uint32_t), 256);
+        } else {
+            pl.wrap_off = bytes;
+            bytes = align_up(bytes + pl.wraps.size() * sizeof(uint32_t), 256);
+        }
+    }
+    if (leader->plan_pending) {  // the previous launch's plan upload must have left pinned memory
+        RSMP_HIP_CHECK(hipEventSynchronize(leader->plan_copied));
+        leader->plan_pending = false;
+    }
+    RSMP_HIP_CHECK(leader->h_plan.reserve(bytes));
+    if (bytes > leader->d_plan.capacity()) {
+        RSMP_HIP_CHECK(hipStreamSynchronize(stream));
+        RSMP_HIP_CHECK(leader->d_plan.reserve(bytes));
+    }
+    char* h = leader->h_plan.as<char>();
+    char* d = leader->d_plan.as<char>();
+    FirStreamDesc* descs = reinterpret_cast<FirStreamDesc*>(h);
+
+    for (Job& j : jobs) j.plan->placed = false;
+    uint32_t max_out_generic = 0, max_tail_values = 0, max_wraps = 0;
+    for (size_t slot = 0; slot < n; ++slot) {
+        Job& j = jobs[order[slot]];
+        Plan& pl = *j.plan;
+        rsmp_fir* r = j.r;
+        const uint32_t ch = static_cast<uint32_t>(r->channels);
+        FirStreamDesc& ds = descs[slot];
+        std::memset(&ds, 0, sizeof ds);
+        ds.in = j.d_in;
+        ds.hist = r->d_hist[r->cur];
+        ds.hist_next = r->d_hist[r->cur ^ 1];
+        ds.out = j.d_out;
+        ds.coeffs = r->d_coeffs;
+        ds.n_out = static_cast<uint32_t>(pl.produced_frames);
+        ds.hist_frames = static_cast<uint32_t>(pl.hist_frames);
+        ds.in_frames = static_cast<uint32_t>(pl.accepted_frames);
+        ds.tail_start = static_cast<uint32_t>(pl.consumed_frames);
+        ds.tail_frames = static_cast<uint32_t>(pl.planned.available());
+        ds.channels = ch;
+        ds.taps = static_cast<uint32_t>(r->taps);
+        ds.num = static_cast<uint32_t>(r->mirror.num());
+        ds.den = static_cast<uint32_t>(r->mirror.den());
+        ds.abs_out = r->mirror.abs_out();
+        ds.abs_consumed = r->mirror.abs_consumed();
+        if (ds.tail_frames * ch > max_tail_values) max_tail_values = ds.tail_frames * ch;
+        if (!pl.periodic) {
+            ds.segs = reinterpret_cast<const rsmp_fir_segment*>(d + pl.seg_off);
+            ds.n_segs = static_cast<uint32_t>(pl.segs.size());
+            ds.tile_seg = reinterpret_cast<const uint32_t*>(d + pl.tile_off);
+            if (!pl.placed) {
+                std::memcpy(h + pl.seg_off, pl.segs.data(), pl.segs.size() * sizeof(rsmp_fir_segment));
+                uint32_t* ts = reinterpret_cast<uint32_t*>(h + pl.tile_off);
+                size_t s = 0;
+                for (size_t t = 0; t * rsmp::kFirTile < pl.produced_frames; ++t) {
+                    const size_t first = t * rsmp::kFirTile;
+                    while (first >= static_cast<size_t>(pl.segs[s].out_start) + pl.segs[s].count) ++s;
+                    ts[t] = static_cast<uint32_t>(s);
+                }
+            }
+            if (ds.n_out > max_out_generic) max_out_generic = ds.n_out;
+        } else {
+            ds.wraps = reinterpret_cast<const uint32_t*>(d + pl.wrap_off);
+            ds.n_wraps = static_cast<uint32_t>(pl.wraps.size());
+            ds.mixed = r->periodic.d_table;
+            if (!pl.placed)
+                std::memcpy(h + pl.wrap_off, pl.wraps.data(), pl.wraps.size() * sizeof(uint32_t));
+            if (ds.n_wraps > max_wraps) max_wraps = ds.n_wraps;
+        }
+        pl.placed = true;
+    }
+    RSMP_HIP_CHECK(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, stream));
+    RSMP_HIP_CHECK(hipEventRecord(leader->plan_copied, stream));
+    leader->plan_pending = true;
+
+    const FirStreamDesc* d_descs = reinterpret_cast<const FirStreamDesc*>(d);
+    if (leader->profiling) RSMP_HIP_CHECK(hipEventRecord(leader->prof_start, stream));
+    if (n_generic)
+        RSMP_HIP_CHECK(rsmp::launch_fir_generic(d_descs, static_cast<uint32_t>(n_generic),
+                                                max_out_generic, 0, stream));
+    size_t first = n_generic;
+    for (const Group& g : groups) {
+        uint32_t max_blocks = 0;
+        for (size_t i : g.members) {
+            const uint32_t b = rsmp::periodic_blocks(g.geo, jobs[i].r->mirror.abs_out(),
+                                                     static_cast<uint32_t>(jobs[i].plan->produced_frames));
+            if (b > max_blocks) max_blocks = b;
+        }
+        RSMP_HIP_CHECK(rsmp::launch_fir_periodic(d_descs + first,
+                                                 static_cast<uint32_t>(g.members.size()), g.geo,
+                                                 max_blocks, stream));
+        first += g.members.size();
+    }
+    if (leader->profiling) {
+        RSMP_HIP_CHECK(hipEventRecord(leader->prof_stop, stream));
+        leader->prof_valid = true;
+    }
+    if (n > n_generic)
+        RSMP_HIP_CHECK(rsmp::launch_fir_wrap_fixup(d_descs + n_generic,
+                                                   static_cast<uint32_t>(n - n_generic), max_wraps,
+                                                   stream));
+    RSMP_HIP_CHECK(rsmp::launch_fir_tail_copy(d_descs, static_cast<uint32_t>(n), max_tail_values,
+                                              stream));
+    // Commit: the mirrors advance, the hist buffers swap.
+    for (Job& j : jobs) {
+        j.r->mirror = j.plan->planned;
+        j.r->cur ^= 1;
+    }
+    return RSMP_OK;
+}
+
+void report_calls(const Plan& pl, size_t* calls, size_t max_calls, size_t* n_calls) {
+    const size_t nc = pl.calls.size() / 2;
+    if (n_calls) *n_calls = nc;
+    if (calls)
+        for (size_t i = 0; i < nc && i < max_calls; ++i) {
+            calls[2 * i] = pl.calls[2 * i];
+            calls[2 * i + 1] = pl.calls[2 * i + 1];
+        }
+}
+
+int run_single(rsmp_fir* r, const float* d_in, size_t in_len, float* d_out, size_t out_cap,
+               size_t chunk_len, size_t* consumed, size_t* produced, size_t* calls,
+               size_t max_calls, size_t* n_calls, hipStream_t stream) {
+    std::vector<Job> jobs;
+    jobs.push_back(Job{r, d_in, in_len, d_out, out_cap, chunk_len, nullptr});
+    int rc = plan_job(jobs[0]);
+    if (rc != RSMP_OK) return rc;
+    rc = launch_jobs(r, jobs, stream);
+    if (rc != RSMP_OK) return rc;
+    if (consumed) *consumed = jobs[0].consumed();
+    if (produced) *produced = jobs[0].produced();
+    report_calls(*jobs[0].plan, calls, max_calls, n_calls);
+    return RSMP_OK;
+}
+
+}  // namespace
+
+// ================================ C ABI ==========================================================
+extern "C" int rsmp_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" rsmp_fir* rsmp_fir_new_from_hz(size_t channels, uint32_t input_rate_hz,
+                                          uint32_t output_rate_hz, int latency, int attenuation,
+                                          int device) {
+    return fir_create(channels, input_rate_hz, output_rate_hz, latency, attenuation, device);
+}
+
+extern "C" rsmp_fir* rsmp_fir_new(size_t channels, int input_rate, int output_rate, int latency,
+                                  int attenuation, int device) {
+    const uint32_t in_hz = rsmp_sample_rate_hz(input_rate);
+    const uint32_t out_hz = rsmp_sample_rate_hz(output_rate);
+    if (!in_hz || !out_hz) {
+        rsmp::fail(RSMP_ERR_INVALID_ARGUMENT, "ResamplerFir::new: invalid SampleRate value");
+        return nullptr;
+    }
+    return fir_create(channels, in_hz, out_hz, latency, attenuation, device);
+}
+
+extern "C" void rsmp_fir_free(rsmp_fir* r) {
+    if (!r) return;
+    DeviceGuard guard(r->device);
+    if (r->stream) (void)hipStreamSynchronize(r->stream);
+    (void)hipDeviceSynchronize();
+    for (int i = 0; i < 2; ++i) if (r->d_hist[i]) (void)hipFree(r->d_hist[i]);
+    if (r->plan_copied) (void)hipEventDestroy(r->plan_copied);
+    if (r->prof_start) (void)hipEventDestroy(r->prof_start);
+    if (r->prof_stop) (void)hipEventDestroy(r->prof_stop);
+    if (r->stream) (void)hipStreamDestroy(r->stream);
+    delete r;
+}
+
+extern "C" size_t rsmp_fir_buffer_size_output(const rsmp_fir* r) {
+    return r->mirror.buffer_size_output_frames() * r->channels;
+}
+extern "C" size_t rsmp_fir_delay(const rsmp_fir* r) { return r->taps / 2; }
+extern "C" size_t rsmp_fir_channels(const rsmp_fir* r) { return r->channels; }
+extern "C" size_t rsmp_fir_taps(const rsmp_fir* r) { return r->taps; }
+extern "C" size_t rsmp_fir_phases(const rsmp_fir* r) { (void)r; return rsmp::kPhases; }
+
+extern "C" void rsmp_fir_reset(rsmp_fir* r) {
+    // resampler_fir.rs:638-642: only the three scalars; stale frames are unreachable.
+    r->mirror.reset();
+}
+
+extern "C" int rsmp_fir_set_kernel(rsmp_fir* r, int kernel) {
+    if (kernel < RSMP_FIR_KERNEL_AUTO || kernel > RSMP_FIR_KERNEL_PERIODIC)
+        return rsmp::fail(RSMP_ERR_INVALID_ARGUMENT, "rsmp_fir_set_kernel: unknown kernel %d", kernel);
+    r->kernel_mode = kernel;
+    return RSMP_OK;
+}
+
+extern "C" int rsmp_fir_set_profiling(rsmp_fir* r, int enable) {
+    DeviceGuard guard(r->device);
+    if (enable && !r->prof_start) {
+        RSMP_HIP_CHECK(hipEventCreate(&r->prof_start));
+        RSMP_HIP_CHECK(hipEventCreate(&r->prof_stop));
+    }
+    r->profiling = enable != 0;
+    r->prof_valid = false;
+    return RSMP_OK;
+}
+
+extern "C" int rsmp_fir_last_kernel_ms(rsmp_fir* r, float* ms) {
+    DeviceGuard guard(r->device);
+    if (!r->prof_valid || !ms)
+        return rsmp::fail(RSMP_ERR_INVALID_ARGUMENT, "rsmp_fir_last_kernel_ms: no profiled launch");
+    RSMP_HIP_CHECK(hipEventSynchronize(r->prof_stop));
+    RSMP_HIP_CHECK(hipEventElapsedTime(ms, r->prof_start, r->prof_stop));
+    return RSMP_OK;
+}
+
+extern "C" int rsmp_fir_resample_device(rsmp_fir* r, const float* d_in, size_t in_len, float* d_out,
+                                        size_t out_len, size_t* consumed, size_t* produced,
+                                        void* stream) {
+    DeviceGuard guard(r->device);
+    // resampler_fir.rs:514-519: input is validated before output.
+    if (in_len % r->channels != 0)
+        return rsmp::fail(RSMP_ERR_INVALID_INPUT_BUFFER_SIZE, "Input buffer size is invalid");
+    if (out_len % r->channels != 0)
+        return rsmp::fail(RSMP_ERR_INVALID_OUTPUT_BUFFER_SIZE, "Output buffer size is invalid");
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : r->stream;
+    return run_single(r, d_in, in_len, d_out, out_len, 0, consumed, produced, nullptr, 0, nullptr, s);
+}
+
+extern "C" int rsmp_fir_resample(rsmp_fir* r, const float* in, size_t in_len, float* out,
+                                 size_t out_len, size_t* consumed, size_t* produced) {
+    DeviceGuard guard(r->device);
+    if (in_len % r->channels != 0)
+        return rsmp::fail(RSMP_ERR_INVALID_INPUT_BUFFER_SIZE, "Input buffer size is invalid");
+    if (out_len % r->channels != 0)
+        return rsmp::fail(RSMP_ERR_INVALID_OUTPUT_BUFFER_SIZE, "Output buffer size is invalid");
+    // At most INPUT_CAPACITY frames can be accepted and buffer_size_output-ish produced per
+    // call, so the staging buffers are bounded no matter how large the caller's slices are.
+    const size_t max_in = rsmp::kInputCapacity * r->channels;
+    const size_t stage_in = in_len < max_in ? in_len : max_in;
+    const size_t max_out =
+        (static_cast<size_t>(static_cast<double>(rsmp::kInputCapacity) / r->mirror.ratio()) + 8) *
+        r->channels;
+    const size_t stage_out = out_len < max_out ? out_len : max_out;
+    RSMP_HIP_CHECK(hipStreamSynchronize(r->stream));
+    RSMP_HIP_CHECK(r->d_stage_in.reserve((stage_in + 4) * sizeof(float)));
+    RSMP_HIP_CHECK(r->d_stage_out.reserve((stage_out + 4) * sizeof(float)));
+    if (stage_in)
+        RSMP_HIP_CHECK(hipMemcpyAsync(r->d_stage_in.get(), in, stage_in * sizeof(float),
+                                      hipMemcpyHostToDevice, r->stream));
+    size_t c = 0, p = 0;
+    const int rc = run_single(r, r->d_stage_in.as<float>(), stage_in, r->d_stage_out.as<float>(),
+                              stage_out, 0, &c, &p, nullptr, 0, nullptr, r->stream);
+    if (rc != RSMP_OK) return rc;
+    if (p)
+        RSMP_HIP_CHECK(hipMemcpyAsync(out, r->d_stage_out.get(), p * sizeof(float),
+                                      hipMemcpyDeviceToHost, r->stream));
+    RSMP_HIP_CHECK(hipStreamSynchronize(r->stream));
+    if (consumed) *consumed = c;
+    if (produced) *produced = p;
+    return RSMP_OK;
+}
+
+extern "C" size_t rsmp_fir_bulk_output_bound(const rsmp_fir* r, size_t in_len, size_t chunk_len) {
+    (void)chunk_len;
+    // Everything buffered plus everything offered, resampled, plus one frame of slack per call
+    // boundary effect; generous but O(in_len).
+    const size_t frames = in_len / r->channels + r->mirror.available();
+    const size_t out_frames = static_cast<size_t>(static_cast<double>(frames) / r->mirror.ratio()) + 8;
+    return out_frames * r->channels;
+}
+
+extern "C" int rsmp_fir_resample_bulk_device(rsmp_fir* r, const float* d_in, size_t in_len,
+                                             size_t chunk_len, float* d_out, size_t out_cap,
+                                             size_t* consumed, size_t* produced, size_t* calls,
+                                             size_t max_calls, size_t* n_calls, void* stream) {
+    DeviceGuard guard(r->device);
+    if (chunk_len == 0)
+        return rsmp::fail(RSMP_ERR_INVALID_ARGUMENT, "rsmp_fir_resample_bulk: chunk_len must be > 0");
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : r->stream;
+    return run_single(r, d_in, in_len, d_out, out_cap, chunk_len, consumed, produced, calls,
+                      max_calls, n_calls, s);
+}
+
+extern "C" int rsmp_fir_resample_bulk(rsmp_fir* r, const float* in, size_t in_len, size_t chunk_len,
+                                      float* out, size_t out_cap, size_t* consumed, size_t* produced,
+                                      size_t* calls, size_t max_calls, size_t* n_calls) {
+    DeviceGuard guard(r->device);
+    if (chunk_len == 0)
+        return rsmp::fail(RSMP_ERR_INVALID_ARGUMENT, "rsmp_fir_resample_bulk: chunk_len must be > 0");
+    RSMP_HIP_CHECK(hipStreamSynchronize(r->stream));
+    RSMP_HIP_CHECK(r->d_stage_in.reserve((in_len + 4) * sizeof(float)));
+    RSMP_HIP_CHECK(r->d_stage_out.reserve((out_cap + 4) * sizeof(float)));
+    if (in_len)
+        RSMP_HIP_CHECK(hipMemcpyAsync(r->d_stage_in.get(), in, in_len * sizeof(float),
+                                      hipMemcpyHostToDevice, r->stream));
+    size_t c = 0, p = 0;
+    const int rc = run_single(r, r->d_stage_in.as<float>(), in_len, r->d_stage_out.as<float>(),
+                              out_cap, chunk_len, &c, &p, calls, max_calls, n_calls, r->stream);
+    if (rc != RSMP_OK) return rc;
+    if (p)
+        RSMP_HIP_CHECK(hipMemcpyAsync(out, r->d_stage_out.get(), p * sizeof(float),
+                                      hipMemcpyDeviceToHost, r->stream));
+    RSMP_HIP_CHECK(hipStreamSynchronize(r->stream));
+    if (consumed) *consumed = c;
+    if (produced) *produced = p;
+    return RSMP_OK;
+}
+
+extern "C" int rsmp_fir_batch_resample_bulk_device(rsmp_fir* const* rs, size_t n,
+                                                   const float* const* d_in, const size_t* in_lens,
+                                                   size_t chunk_len, float* const* d_out,
+                                                   const size_t* out_caps, size_t* consumed,
+                                                   size_t* produced, void* stream) {
+    if (n == 0) return RSMP_OK;
+    if (!rs || !d_in || !in_lens || !d_out || !out_caps || chunk_len == 0)
+        return rsmp::fail(RSMP_ERR_INVALID_ARGUMENT, "rsmp_fir_batch_resample_bulk_device: null/zero argument");
+    for (size_t i = 0; i < n; ++i) {
+        if (!rs[i] || rs[i]->device != rs[0]->device)
+            return rsmp::fail(RSMP_ERR_INVALID_ARGUMENT, "batch streams must share one device");
+        for (size_t k = 0; k < i; ++k)
+            if (rs[k] == rs[i])
+                return rsmp::fail(RSMP_ERR_INVALID_ARGUMENT, "batch lists the same stream twice");
+    }
+    DeviceGuard guard(rs[0]->device);
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : rs[0]->stream;
+    std::vector<Job> jobs;
+    jobs.reserve(n);
+    // Streams in the same state that are fed the same amount share one replay of the reference
+    // call sequence (the control flow does not depend on the sample values).
+    std::vector<std::pair<PlanKey, std::shared_ptr<Plan>>> memo;
+    for (size_t i = 0; i < n; ++i) {
+        jobs.push_back(Job{rs[i], d_in[i], in_lens[i], d_out[i], out_caps[i], chunk_len, nullptr});
+        Job& j = jobs.back();
+        const PlanKey key = make_key(j);
+        for (auto& kv : memo)
+            if (kv.first == key && kv.second->produced_frames * rs[i]->channels <= out_caps[i]) {
+                j.plan = kv.second;
+                break;
+            }
+        if (!j.plan) {
+            const int rc = plan_job(j);
+            if (rc != RSMP_OK) return rc;
+            memo.emplace_back(key, j.plan);
+        }
+    }
+    const int rc = launch_jobs(rs[0], jobs, s);
+    if (rc != RSMP_OK) return rc;
+    for (size_t i = 0; i < n; ++i) {
+        if (consumed) consumed[i] = jobs[i].consumed();
+        if (produced) produced[i] = jobs[i].produced();
+    }
+    return RSMP_OK;
+}

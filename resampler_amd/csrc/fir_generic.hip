@@ -1,0 +1,142 @@
+// fir_generic.hip -- generic polyphase FIR kernel for gfx950 (any rate pair, any call pattern).
+//
+// Replaces the reference's per-output-frame loop body (src/resampler_fir.rs:542-590) and its
+// convolution leaf (src/fir/avx.rs:5-61).  One launch covers every output frame of every call
+// the host mirror planned: each frame recovers its exact f64 position from its run descriptor
+// (p = p0 + k*inc, one FMA, exact -- see fir_plan.h), derives input offset / phase rows / frac
+// exactly as :544-565, and computes the dual-row dot product + per-lane lerp.
+//
+// Mapping: 8 lanes share one output frame (lane g owns float4 chunks g, g+8, ... of both phase
+// rows, so one row read is a fully coalesced 512-byte burst at 128 taps), partial sums are lerped
+// per lane like the reference's SIMD lanes (avx.rs:41-45) and reduced with three DPP butterfly
+// steps.  A wave therefore produces 8 frames at a time; a 256-thread workgroup walks a tile of
+// 256 consecutive output frames.  Samples come straight from [hist|in] in HBM/L2 (each lane
+// reads 16-byte-contiguous frames); this kernel is the correctness backbone and the latency
+// path -- the throughput path for rational rate pairs is fir_periodic.hip.
+#include "fir_kernels.h"
+
+namespace rsmp {
+
+namespace {
+
+constexpr int kLanesPerFrame = 8;
+constexpr int kBlock = 256;
+constexpr int kFramesPerPass = kBlock / kLanesPerFrame;  // 32
+
+__device__ __forceinline__ float group_sum8(float v) {
+    v += __shfl_xor(v, 4, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 1, 64);
+    return v;
+}
+
+// Sample `c` of virtual frame v of [hist|in].
+__device__ __forceinline__ float load_sample(const FirStreamDesc& d, int64_t v, uint32_t c) {
+    return v < static_cast<int64_t>(d.hist_frames)
+               ? d.hist[static_cast<size_t>(v) * d.channels + c]
+               : d.in[static_cast<size_t>(v - d.hist_frames) * d.channels + c];
+}
+
+__global__ __launch_bounds__(kBlock) void fir_generic_kernel(const FirStreamDesc* __restrict__ descs) {
+    const FirStreamDesc d = descs[blockIdx.y];
+    const uint32_t tile = blockIdx.x;
+    const uint32_t tile_first = tile * kFirTile;
+    if (tile_first >= d.n_out) return;
+
+    const int g = threadIdx.x & (kLanesPerFrame - 1);
+    const int slot = threadIdx.x / kLanesPerFrame;
+    const uint32_t taps = d.taps;
+    const uint32_t channels = d.channels;
+
+    uint32_t seg_idx = d.tile_seg[tile];
+
+    for (uint32_t base = tile_first; base < tile_first + kFirTile; base += kFramesPerPass) {
+        const uint32_t n = base + slot;
+        const bool live = n < d.n_out;
+        // Exact position of frame n: walk forward to its run (runs are sorted by out_start).
+        double p0 = 0.0, inc = 0.0;
+        int64_t in_base = 0;
+        uint32_t k = 0;
+        if (live) {
+            uint32_t s = seg_idx;
+            rsmp_fir_segment sg = d.segs[s];
+            while (n >= sg.out_start + sg.count) sg = d.segs[++s];
+            seg_idx = s;
+            p0 = sg.p0;
+            inc = sg.inc;
+            in_base = sg.in_base;
+            k = n - sg.out_start;
+        }
+        const double p = fma(static_cast<double>(k), inc, p0);
+        const double fl = floor(p);                                   // :544
+        const double fract = p - fl;                                  // :558 (p >= 0)
+        double phase_f = fract * 1024.0;                              // :562
+        phase_f = phase_f < 1023.0 ? phase_f : 1023.0;
+        const uint32_t phase1 = static_cast<uint32_t>(phase_f);       // :563
+        const uint32_t phase2 = phase1 + 1 < 1023u ? phase1 + 1 : 1023u;  // :564
+        const float frac = static_cast<float>(phase_f - static_cast<double>(phase1));  // :565
+        const int64_t v0 = in_base + static_cast<int64_t>(fl);
+        const float4* __restrict__ row1 =
+            reinterpret_cast<const float4*>(d.coeffs + static_cast<size_t>(phase1) * taps);
+        const float4* __restrict__ row2 =
+            reinterpret_cast<const float4*>(d.coeffs + static_cast<size_t>(phase2) * taps);
+        const float one_minus_frac = 1.0f - frac;                     // avx.rs:42
+
+        for (uint32_t c = 0; c < channels; ++c) {
+            float a1 = 0.0f, a2 = 0.0f;
+            if (live) {
+                for (uint32_t q = g; q < taps / 4; q += kLanesPerFrame) {
+                    const float4 k1 = row1[q];
+                    const float4 k2 = row2[q];
+                    const int64_t v = v0 + 4 * static_cast<int64_t>(q);
+                    const float x0 = load_sample(d, v, c);
+                    const float x1 = load_sample(d, v + 1, c);
+                    const float x2 = load_sample(d, v + 2, c);
+                    const float x3 = load_sample(d, v + 3, c);
+                    a1 = fmaf(k1.x, x0, a1); a2 = fmaf(k2.x, x0, a2);
+                    a1 = fmaf(k1.y, x1, a1); a2 = fmaf(k2.y, x1, a2);
+                    a1 = fmaf(k1.z, x2, a1); a2 = fmaf(k2.z, x2, a2);
+                    a1 = fmaf(k1.w, x3, a1); a2 = fmaf(k2.w, x3, a2);
+                }
+            }
+            // per-lane lerp, then horizontal sum (avx.rs:41-58)
+            const float part = a1 * one_minus_frac + a2 * frac;
+            const float y = group_sum8(part);
+            if (live && g == 0) d.out[static_cast<size_t>(n) * channels + c] = y;
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void fir_tail_copy_kernel(const FirStreamDesc* __restrict__ descs) {
+    const FirStreamDesc d = descs[blockIdx.y];
+    const size_t total = static_cast<size_t>(d.tail_frames) * d.channels;
+    const size_t first = static_cast<size_t>(d.tail_start) * d.channels;
+    const size_t hist_values = static_cast<size_t>(d.hist_frames) * d.channels;
+    for (size_t i = blockIdx.x * static_cast<size_t>(kBlock) + threadIdx.x; i < total;
+         i += static_cast<size_t>(gridDim.x) * kBlock) {
+        const size_t src = first + i;
+        d.hist_next[i] = src < hist_values ? d.hist[src] : d.in[src - hist_values];
+    }
+}
+
+}  // namespace
+
+hipError_t launch_fir_generic(const FirStreamDesc* d_descs, uint32_t n_streams, uint32_t max_out,
+                              uint32_t /*max_channels*/, hipStream_t stream) {
+    if (n_streams == 0 || max_out == 0) return hipSuccess;
+    const dim3 grid((max_out + kFirTile - 1) / kFirTile, n_streams);
+    hipLaunchKernelGGL(fir_generic_kernel, grid, dim3(kBlock), 0, stream, d_descs);
+    return hipGetLastError();
+}
+
+hipError_t launch_fir_tail_copy(const FirStreamDesc* d_descs, uint32_t n_streams,
+                                uint32_t max_tail_values, hipStream_t stream) {
+    if (n_streams == 0 || max_tail_values == 0) return hipSuccess;
+    uint32_t blocks = (max_tail_values + kBlock - 1) / kBlock;
+    if (blocks > 64) blocks = 64;
+    hipLaunchKernelGGL(fir_tail_copy_kernel, dim3(blocks, n_streams), dim3(kBlock), 0, stream,
+                       d_descs);
+    return hipGetLastError();
+}
+
+}  // namespace rsmp

@@ -1,0 +1,51 @@
+// fir_kernels.h -- device-side work descriptors and launch wrappers of the FIR path.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "../../include/resampler_amd.h"
+
+namespace rsmp {
+
+// One stream's share of a launch.  A launch covers `n_out` output frames of every stream in the
+// batch; the input of a stream is the virtual concatenation [hist | in]: `hist_frames` frames
+// that were already buffered inside the resampler when the launch started (the reference's
+// input_buffers[read_position .. read_position+available_frames], resampler_fir.rs:187-191)
+// followed by the frames accepted during the launch.  Everything is interleaved f32.
+struct FirStreamDesc {
+    const float* in;               // frames accepted in this launch (device)
+    const float* hist;             // frames buffered before the launch (device)
+    float* out;                    // output frames (device)
+    const float* coeffs;           // [1024][taps] polyphase table (device)
+    const rsmp_fir_segment* segs;  // exact position runs, sorted by out_start (device)
+    const uint32_t* tile_seg;      // index of the run containing output frame tile*kFirTile
+    float* hist_next;              // receives the frames still buffered after the launch
+    const float* mixed;            // periodic kernel: pre-mixed class table (device)
+    const uint32_t* wraps;         // periodic kernel: outputs needing the row-1023 fix-up
+    uint32_t n_out;                // output frames in this launch
+    uint32_t n_segs;
+    uint32_t hist_frames;
+    uint32_t in_frames;            // frames accepted in this launch
+    uint32_t tail_start;           // first frame of [hist|in] that stays buffered afterwards
+    uint32_t tail_frames;          // how many stay buffered
+    uint32_t n_wraps;
+    uint32_t channels;
+    uint32_t taps;
+    // periodic kernel: in_hz/out_hz = num/den reduced, absolute counters at launch start
+    uint32_t num, den;
+    uint64_t abs_out;              // output frames produced since reset, before this launch
+    uint64_t abs_consumed;         // input frames retired since reset, before this launch
+};
+
+constexpr uint32_t kFirTile = 256;  // output frames per workgroup tile (generic kernel)
+
+// Generic kernel: any ratio, reference-form two-row interpolation; grid = (max tiles, streams).
+hipError_t launch_fir_generic(const FirStreamDesc* d_descs, uint32_t n_streams, uint32_t max_out,
+                              uint32_t max_channels, hipStream_t stream);
+// Copies the still-buffered tail of [hist|in] into hist_next; grid = (blocks, streams).
+hipError_t launch_fir_tail_copy(const FirStreamDesc* d_descs, uint32_t n_streams,
+                                uint32_t max_tail_values, hipStream_t stream);
+
+}  // namespace rsmp

@@ -1,0 +1,206 @@
+"""GPU parity tests of the FIR path: everything goes through the C ABI (libresampler_amd.so) and is
+compared with the CPU oracle on the same inputs.  Gate (BASELINE.json north_star): output within
+1e-6 RMS of the CPU path, identical (consumed, produced) counts."""
+import numpy as np
+import pytest
+
+import resampler_amd as ra
+from oracle import pyoracle as o
+from resampler_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+RMS_TOL = 1e-6   # north_star tolerance
+ATT_DB = {ra.Attenuation.Db60: 60, ra.Attenuation.Db90: 90, ra.Attenuation.Db120: 120}
+
+
+def rms(a, b):
+    if a.size == 0:
+        return 0.0
+    return float(np.sqrt(np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2)))
+
+
+def make_pair(ch, in_hz, out_hz, lat=ra.Latency.Sample64, att=ra.Attenuation.Db90, kernel=None):
+    g = ra.ResamplerFir.new_from_hz(ch, in_hz, out_hz, lat, att)
+    if kernel is not None:
+        g.set_kernel(kernel)
+    r = o.OracleFir(ch, in_hz, out_hz, lat.taps(), ATT_DB[att])
+    return g, r
+
+
+def stream_compare(g, r, x, chunks, out_caps=None):
+    """Feeds the same slices to both and compares every call."""
+    ch = g.channels
+    og = np.zeros(g.buffer_size_output(), np.float32)
+    orr = np.zeros(r.buffer_size_output(), np.float32)
+    off = 0
+    worst = 0.0
+    i = 0
+    while off < x.size:
+        n = chunks[i % len(chunks)] * ch
+        cap = og.size if out_caps is None else min(og.size, out_caps[i % len(out_caps)] * ch)
+        sl = x[off:off + n]
+        cg, pg = g.resample(sl, og[:cap])
+        rc, cr, pr = r.resample(sl, orr[:cap])
+        assert rc == 0
+        assert (cg, pg) == (cr, pr), (i, (cg, pg), (cr, pr))
+        worst = max(worst, rms(og[:pg], orr[:pr]))
+        off += cg
+        i += 1
+        if cg == 0 and pg == 0:
+            break
+    return worst
+
+
+def test_c1_plumbing_config_on_gpu():
+    # BASELINE config 1 shape: 1 ch 48000 -> 44100, Sample64 / Db90, 512-sample chunks.
+    g, r = make_pair(1, 48000, 44100)
+    x = synth.sweep(1 << 16, 1, 48000.0)
+    assert g.buffer_size_output() == r.buffer_size_output() == 3648
+    assert g.delay() == r.delay() == 64
+    assert stream_compare(g, r, x, [512]) <= RMS_TOL
+
+
+@pytest.mark.parametrize("ch,in_hz,out_hz,lat,att", [
+    (2, 44100, 48000, ra.Latency.Sample64, ra.Attenuation.Db90),
+    (2, 48000, 44100, ra.Latency.Sample64, ra.Attenuation.Db120),
+    (8, 96000, 44100, ra.Latency.Sample64, ra.Attenuation.Db120),
+    (3, 44100, 96000, ra.Latency.Sample32, ra.Attenuation.Db60),
+    (1, 24000, 16000, ra.Latency.Sample16, ra.Attenuation.Db60),
+    (2, 44100, 48001, ra.Latency.Sample8, ra.Attenuation.Db90),
+    (5, 384000, 16000, ra.Latency.Sample64, ra.Attenuation.Db90),
+])
+def test_streaming_calls_match_oracle(ch, in_hz, out_hz, lat, att):
+    g, r = make_pair(ch, in_hz, out_hz, lat, att)
+    x = synth.fast_noise(ch * 30000, seed=ch)
+    # ragged chunk sizes incl. empty and > INPUT_CAPACITY, and small output buffers
+    worst = stream_compare(g, r, x, [256, 1, 0, 4096, 5000, 17, 512],
+                           out_caps=[100000, 100000, 64, 100000, 7, 100000])
+    assert worst <= RMS_TOL
+    # reset(): same behaviour afterwards
+    g.reset()
+    r.reset()
+    assert stream_compare(g, r, x[: ch * 5000], [333]) <= RMS_TOL
+
+
+def test_error_codes_match_reference():
+    g, r = make_pair(3, 44100, 48000)
+    out = np.zeros(g.buffer_size_output(), np.float32)
+    with pytest.raises(ra.InvalidInputBufferSize):
+        g.resample(np.zeros(100, np.float32), out)
+    with pytest.raises(ra.InvalidOutputBufferSize):
+        g.resample(np.zeros(99, np.float32), out[:100])
+    # input is validated first (resampler_fir.rs:514-519)
+    with pytest.raises(ra.InvalidInputBufferSize):
+        g.resample(np.zeros(100, np.float32), out[:100])
+    assert g.resample(np.zeros(0, np.float32), out[:0]) == (0, 0)
+
+
+@pytest.mark.parametrize("kernel", [ra.FirKernel.Generic, ra.FirKernel.Periodic])
+@pytest.mark.parametrize("ch,in_hz,out_hz,att", [
+    (2, 44100, 48000, ra.Attenuation.Db90),
+    (2, 48000, 44100, ra.Attenuation.Db90),
+    (1, 44100, 96000, ra.Attenuation.Db120),
+    (2, 96000, 44100, ra.Attenuation.Db120),
+    (2, 48000, 96000, ra.Attenuation.Db90),
+    (2, 96000, 48000, ra.Attenuation.Db90),
+    (8, 96000, 44100, ra.Attenuation.Db120),
+    (4, 22050, 48000, ra.Attenuation.Db60),
+])
+def test_bulk_matches_reference_driver_loop(kernel, ch, in_hz, out_hz, att):
+    g, r = make_pair(ch, in_hz, out_hz, att=att, kernel=kernel)
+    x = synth.sweep(60000, ch, float(in_hz))
+    chunk = 512 - (512 % ch)
+    yg, consumed, calls_g = g.resample_bulk(x, chunk, want_calls=True)
+    yr, calls_r = r.resample_all(x, chunk)
+    assert consumed == int(calls_r[:, 0].sum())
+    assert np.array_equal(calls_g, calls_r)
+    assert yg.size == yr.size
+    assert rms(yg, yr) <= RMS_TOL
+    # the stream continues seamlessly: per-call API after a bulk launch, then bulk again
+    x2 = synth.fast_noise(ch * 9000, seed=5)
+    assert stream_compare(g, r, x2[: ch * 3000], [700]) <= RMS_TOL
+    yg2, _ = g.resample_bulk(x2[ch * 3000:], chunk)
+    yr2, _ = r.resample_all(x2[ch * 3000:], chunk)
+    assert yg2.size == yr2.size and rms(yg2, yr2) <= RMS_TOL
+
+
+@pytest.mark.parametrize("taps_lat", [ra.Latency.Sample8, ra.Latency.Sample16, ra.Latency.Sample32])
+def test_bulk_periodic_other_tap_counts(taps_lat):
+    g, r = make_pair(2, 44100, 48000, lat=taps_lat, kernel=ra.FirKernel.Periodic)
+    x = synth.sweep(50000, 2, 44100.0)
+    yg, _ = g.resample_bulk(x, 512)
+    yr, _ = r.resample_all(x, 512)
+    assert yg.size == yr.size and rms(yg, yr) <= RMS_TOL
+
+
+def test_c2_full_size_bulk_parity_and_max_abs():
+    # BASELINE config 2: 2 ch interleaved 44100 -> 48000, 128 taps, 2^20-frame sine sweep.
+    g, r = make_pair(2, 44100, 48000)
+    x = synth.sweep(1 << 20, 2, 44100.0)
+    yg, consumed, calls_g = g.resample_bulk(x, 512, want_calls=True)
+    yr, calls_r = r.resample_all(x, 512)
+    assert consumed == x.size
+    assert np.array_equal(calls_g, calls_r)
+    assert yg.size == yr.size
+    assert rms(yg, yr) <= RMS_TOL
+    assert float(np.max(np.abs(yg.astype(np.float64) - yr))) < 2e-5
+
+
+def test_device_resident_api_and_batch():
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda:0")
+    n_streams = 7
+    pairs = [(44100, 48000), (48000, 44100), (44100, 96000)]
+    gs, rs, xs = [], [], []
+    for i in range(n_streams):
+        in_hz, out_hz = pairs[i % len(pairs)]
+        g, r = make_pair(2, in_hz, out_hz)
+        gs.append(g)
+        rs.append(r)
+        xs.append(synth.fast_noise(2 * (30000 + 1000 * (i % 2)), seed=100 + i))
+    batch = ra.FirBatch(gs)
+    for step in range(2):
+        d_in = [torch.from_numpy(x).to(dev) for x in xs]
+        d_out = [torch.zeros(g.bulk_output_bound(x.size, 512), device=dev) for g, x in zip(gs, xs)]
+        batch.bind(d_in, d_out)
+        consumed, produced = batch.resample_bulk_device(512, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        for i in range(n_streams):
+            yr, calls = rs[i].resample_all(xs[i], 512)
+            assert consumed[i] == xs[i].size and produced[i] == yr.size
+            assert rms(d_out[i][: produced[i]].cpu().numpy(), yr) <= RMS_TOL
+    # single-stream device call
+    g, r = make_pair(2, 44100, 48000)
+    x = synth.fast_noise(2 * 2000, seed=9)
+    d_x = torch.from_numpy(x).to(dev)
+    d_y = torch.zeros(g.buffer_size_output(), device=dev)
+    c, p = g.resample_device(d_x, d_y, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    orr = np.zeros(r.buffer_size_output(), np.float32)
+    rc, cr, pr = r.resample(x, orr)
+    assert (c, p) == (cr, pr) and rms(d_y[:p].cpu().numpy(), orr[:pr]) <= RMS_TOL
+
+
+def test_linearity_and_shift_properties_at_full_size():
+    # Size-independent properties on a large launch: linearity, and identical channels in ->
+    # identical channels out.
+    g1 = ra.ResamplerFir.new(2, ra.SampleRate.Hz44100, ra.SampleRate.Hz48000, ra.Latency.Sample64,
+                             ra.Attenuation.Db90)
+    g2 = ra.ResamplerFir.new(2, ra.SampleRate.Hz44100, ra.SampleRate.Hz48000, ra.Latency.Sample64,
+                             ra.Attenuation.Db90)
+    g3 = ra.ResamplerFir.new(2, ra.SampleRate.Hz44100, ra.SampleRate.Hz48000, ra.Latency.Sample64,
+                             ra.Attenuation.Db90)
+    n = 1 << 19
+    a = synth.fast_noise(2 * n, seed=1)
+    b = synth.fast_noise(2 * n, seed=2)
+    ya, _ = g1.resample_bulk(a, 512)
+    yb, _ = g2.resample_bulk(b, 512)
+    yab, _ = g3.resample_bulk((a + b).astype(np.float32), 512)
+    assert ya.size == yb.size == yab.size
+    assert rms(yab, ya + yb) <= 2e-6
+    mono = synth.fast_noise(n, seed=3)
+    st = np.repeat(mono, 2)
+    g4 = ra.ResamplerFir.new(2, ra.SampleRate.Hz44100, ra.SampleRate.Hz48000)
+    y, _ = g4.resample_bulk(st, 512)
+    assert np.array_equal(y[0::2], y[1::2])
