@@ -147,6 +147,14 @@ def lib() -> C.CDLL:
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(there is no Python/CPU fallback for the HIP path)")
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7 / libhsa-runtime64;
+    # if /opt/rocm's copy gets loaded first, torch later loads a second runtime that finds no
+    # GPU.  Importing torch first makes the dynamic loader bind this library to torch's copy
+    # (same SONAME).  Without torch installed the system runtime is used.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     for name, restype, argtypes in _SIGNATURES:
         fn = getattr(L, name)
