@@ -358,7 +358,13 @@ int launch_jobs(rsmp_fir* leader, std::vector<Job>& jobs, hipStream_t stream) {
             bytes = align_up(bytes + tiles * sizeof(uint32_t), 256);
         } else {
             pl.wrap_off = bytes;
-            bytes = align_up(bytes + pl.wraps.size() * sizeof(uint32_t), 256);
+            const rsmp::PeriodicGeometry& geo = j.r->periodic.geo;
+            const size_t words = geo.inline_wraps
+                                     ? rsmp::periodic_wrap_words(j.r->mirror.abs_out(),
+                                                                 static_cast<uint32_t>(pl.produced_frames),
+                                                                 geo.den)
+                                     : pl.wraps.size();
+            bytes = align_up(bytes + words * sizeof(uint32_t), 256);
         }
     }
     if (leader->plan_pending) {  // the previous launch's plan upload must have left pinned memory
@@ -416,12 +422,25 @@ int launch_jobs(rsmp_fir* leader, std::vector<Job>& jobs, hipStream_t stream) {
             }
             if (ds.n_out > max_out_generic) max_out_generic = ds.n_out;
         } else {
-            ds.wraps = reinterpret_cast<const uint32_t*>(d + pl.wrap_off);
-            ds.n_wraps = static_cast<uint32_t>(pl.wraps.size());
-            ds.mixed = r->periodic.d_table;
-            if (!pl.placed)
-                std::memcpy(h + pl.wrap_off, pl.wraps.data(), pl.wraps.size() * sizeof(uint32_t));
-            if (ds.n_wraps > max_wraps) max_wraps = ds.n_wraps;
+            const rsmp::PeriodicGeometry& geo = r->periodic.geo;
+            ds.class_coef = r->periodic.table.d_coef;
+            ds.class_wrap_coef = r->periodic.table.d_wrap_coef;
+            ds.class_meta = r->periodic.table.d_meta;
+            if (geo.inline_wraps) {
+                ds.wrap_bits = reinterpret_cast<const uint32_t*>(d + pl.wrap_off);
+                ds.wrap_k0 = r->mirror.abs_out() / geo.den;
+                if (!pl.placed) {
+                    const size_t words = rsmp::periodic_wrap_words(r->mirror.abs_out(), ds.n_out, geo.den);
+                    rsmp::periodic_fill_wrap_bits(pl.wraps, r->mirror.abs_out(), geo.den,
+                                                  reinterpret_cast<uint32_t*>(h + pl.wrap_off), words);
+                }
+            } else {
+                ds.wraps = reinterpret_cast<const uint32_t*>(d + pl.wrap_off);
+                ds.n_wraps = static_cast<uint32_t>(pl.wraps.size());
+                if (!pl.placed)
+                    std::memcpy(h + pl.wrap_off, pl.wraps.data(), pl.wraps.size() * sizeof(uint32_t));
+                if (ds.n_wraps > max_wraps) max_wraps = ds.n_wraps;
+            }
         }
         pl.placed = true;
     }
@@ -451,7 +470,7 @@ int launch_jobs(rsmp_fir* leader, std::vector<Job>& jobs, hipStream_t stream) {
         RSMP_HIP_CHECK(hipEventRecord(leader->prof_stop, stream));
         leader->prof_valid = true;
     }
-    if (n > n_generic)
+    if (n > n_generic && max_wraps > 0)
         RSMP_HIP_CHECK(rsmp::launch_fir_wrap_fixup(d_descs + n_generic,
                                                    static_cast<uint32_t>(n - n_generic), max_wraps,
                                                    stream));

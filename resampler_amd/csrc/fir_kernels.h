@@ -22,8 +22,11 @@ struct FirStreamDesc {
     const rsmp_fir_segment* segs;  // exact position runs, sorted by out_start (device)
     const uint32_t* tile_seg;      // index of the run containing output frame tile*kFirTile
     float* hist_next;              // receives the frames still buffered after the launch
-    const float* mixed;            // periodic kernel: pre-mixed class table (device)
-    const uint32_t* wraps;         // periodic kernel: outputs needing the row-1023 fix-up
+    const float* class_coef;       // periodic kernel: class table [tile][row_len][8] (device)
+    const float* class_wrap_coef;  // periodic kernel: wrap-variant coefficients [tile][row_len]
+    const void* class_meta;        // periodic kernel: TileMeta[tile]
+    const uint32_t* wrap_bits;     // periodic kernel: bitmap of outputs taking the wrap variant
+    const uint32_t* wraps;         // fix-up kernel: outputs needing the row-1023 variant
     uint32_t n_out;                // output frames in this launch
     uint32_t n_segs;
     uint32_t hist_frames;
@@ -37,6 +40,7 @@ struct FirStreamDesc {
     uint32_t num, den;
     uint64_t abs_out;              // output frames produced since reset, before this launch
     uint64_t abs_consumed;         // input frames retired since reset, before this launch
+    uint64_t wrap_k0;              // wrap_bits bit K <-> absolute output (wrap_k0 + K) * den
 };
 
 constexpr uint32_t kFirTile = 256;  // output frames per workgroup tile (generic kernel)

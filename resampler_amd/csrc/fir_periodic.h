@@ -15,7 +15,9 @@
 //     wave-uniform and arrive through the scalar cache (s_load) while the samples come from LDS;
 //   * the only outputs whose discrete choices depend on the sign of the f64 drift are those with
 //     m*num/den integer: position just below the integer picks the previous frame and row 1023
-//     (:562-564).  FirMirror lists them (`wraps`) and a fix-up kernel recomputes them.
+//     (:562-564).  FirMirror lists them (`wraps`); the kernel carries a 9th accumulator for that
+//     variant in the tiles that contain such a class and selects per lane from a bitmap
+//     (den >= 8), or a fix-up kernel recomputes them (den < 8).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -33,28 +35,52 @@ constexpr uint32_t kClassTile = 8;
 struct PeriodicGeometry {
     bool ok = false;
     uint32_t a = 0, b = 0;       // super period: a input frames -> b output frames
+    uint32_t den = 0;            // true period of the phase pattern (b = r * den)
     uint32_t taps = 0;
     uint32_t row_len = 0;        // taps + max in-tile shift, rounded up to a multiple of 4
     uint32_t n_tiles = 0;        // ceil(b / 8)
     uint32_t cg = 0;             // channels per lane (1 or 2)
     uint32_t lp = 0;             // lanes per period = channels / cg
     uint32_t pw = 0;             // periods per workgroup (<= 64 / lp)
-    uint32_t row_stride = 0;     // LDS dwords between period rows (padded: conflict-free)
+    uint32_t row_stride = 0;     // LDS dwords between period rows (odd frame count: conflict-free)
     uint32_t waves = 0;          // waves per workgroup
     uint32_t lds_bytes = 0;
+    bool inline_wraps = false;   // den >= 8: wrap variant computed inside the kernel
     bool operator==(const PeriodicGeometry& o) const {
-        return a == o.a && b == o.b && taps == o.taps && row_len == o.row_len && cg == o.cg &&
-               lp == o.lp && pw == o.pw && row_stride == o.row_stride && waves == o.waves;
+        return a == o.a && b == o.b && den == o.den && taps == o.taps && row_len == o.row_len &&
+               cg == o.cg && lp == o.lp && pw == o.pw && row_stride == o.row_stride &&
+               waves == o.waves;
     }
 };
 
 PeriodicGeometry periodic_geometry(uint64_t num, uint64_t den, uint32_t taps, uint32_t channels);
 
+// Per class tile: where its window starts and what its wrap variant (if any) needs.
+struct TileMeta {
+    uint32_t base;         // first input frame of the tile's window, relative to the period start
+    int32_t wrap_col;      // column (0..7) whose class has an integer exact position, or -1
+    uint32_t wrap_jd;      // (class index of that column) / den
+    int32_t extra_col;     // frame (relative to the period start, may be -1) of the one sample
+                           // the wrap window has in front of the tile window; -2 = none
+    float extra_coef;      // its coefficient (row 1023, tap 0)
+    uint32_t pad[3];
+};
+static_assert(sizeof(TileMeta) == 32, "TileMeta is read with one s_load_dwordx8");
+
+// Device image of one class table: [tile][row_len][8] coefficients, [tile][row_len] wrap-variant
+// coefficients, [tile] TileMeta.
+struct ClassTable {
+    const float* d_coef = nullptr;
+    const float* d_wrap_coef = nullptr;
+    const TileMeta* d_meta = nullptr;
+};
+
 // Per-handle periodic state: the class table currently bound to the stream.
 struct PeriodicState {
     PeriodicGeometry geo;
     bool geo_valid = false;
-    const float* d_table = nullptr;  // device class table (owned by the global cache)
+    ClassTable table;
+    bool table_valid = false;
     double table_drift = 0.0;
 };
 
@@ -67,18 +93,30 @@ bool periodic_worthwhile(const FirMirror& planned, size_t produced_frames, int k
 int periodic_bind(PeriodicState& st, int device, const std::vector<float>& table,
                   const FirMirror& planned, uint32_t channels, hipStream_t stream);
 
+// Bitmap of wrapped outputs for one launch: bit K <-> the output with absolute index
+// (abs_out / den + K) * den.  Returns the number of 32-bit words.
+size_t periodic_wrap_words(uint64_t abs_out, uint32_t n_out, uint64_t den);
+void periodic_fill_wrap_bits(const std::vector<uint32_t>& wraps, uint64_t abs_out, uint64_t den,
+                             uint32_t* words, size_t n_words);
+
 // One launch per geometry: d_descs[0..n_streams) all use `geo`; grid = (max_blocks, n_streams).
 hipError_t launch_fir_periodic(const FirStreamDesc* d_descs, uint32_t n_streams,
                                const PeriodicGeometry& geo, uint32_t max_blocks,
                                hipStream_t stream);
-// Recomputes the outputs listed in each stream's `wraps` with row 1023 / previous frame.
+// Recomputes the outputs listed in each stream's `wraps` with row 1023 / previous frame
+// (only for geometries without inline wraps).
 hipError_t launch_fir_wrap_fixup(const FirStreamDesc* d_descs, uint32_t n_streams,
                                  uint32_t max_wraps, hipStream_t stream);
 // Number of period blocks (grid.x) a stream's launch needs.
 uint32_t periodic_blocks(const PeriodicGeometry& geo, uint64_t abs_out, uint32_t n_out);
 
-// Host build of the class table (exposed for tests): layout [tile][row_len][8].
-std::vector<float> build_class_table(const std::vector<float>& coeffs, const PeriodicGeometry& g,
-                                     uint64_t den, double drift);
+// Host build of the class table (exposed for tests).
+struct HostClassTable {
+    std::vector<float> coef;       // [tile][row_len][8]
+    std::vector<float> wrap_coef;  // [tile][row_len]
+    std::vector<TileMeta> meta;    // [tile]
+};
+HostClassTable build_class_table(const std::vector<float>& coeffs, const PeriodicGeometry& g,
+                                 double drift);
 
 }  // namespace rsmp

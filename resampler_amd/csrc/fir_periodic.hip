@@ -3,19 +3,26 @@
 // (src/resampler_fir.rs:542-590 + src/fir/avx.rs:5-61) for launches long enough to fill waves
 // with whole periods.
 //
-// Workgroup = `waves` wave64s sharing one staged input span of `pw` periods:
-//   stage   : [hist|in] frames (q0*a ... (q0+pw)*a + row_len) -> LDS, one padded row per period
-//             (row stride == lanes-per-period mod 32 read units -> the strided per-lane reads below
-//             are bank-conflict free), zero filled outside the stream;
+// Workgroup = `waves` wave64s sharing one staged input span of `pw` periods (two workgroups per
+// CU: one stages / stores while the other computes):
+//   stage   : [hist|in] frames (q0*a ... (q0+pw)*a + row_len) -> LDS, one row per period with an
+//             odd frame stride (the per-lane strided reads below are then bank-conflict free),
+//             zero filled outside the stream; branch-free so the loads of a row are all in flight;
 //   compute : wave w takes class tiles w, w+waves, ...; lane = (period, channel group).  Per tap:
 //             one ds_read of the lane's sample(s), 8 wave-uniform coefficients through the scalar
-//             cache, 8 x CG v_fma with an SGPR operand.  No cross-lane traffic at all;
-//   store   : each lane writes its 8 consecutive output frames (interleaved), masked to the launch.
+//             cache (s_load_dwordx16 = 2 taps), 8 v_pk_fma_f32 with an SGPR operand (packed fp32
+//             is the only way to the 128 FMA/clk/CU peak on gfx950).  No cross-lane traffic;
+//   wrap    : tiles holding a class whose exact position is an integer carry a 9th accumulator
+//             (row 1023, previous frame) and pick per lane from the launch's wrap bitmap;
+//   store   : a 4x4 DPP transpose inside each lane quad turns "lane = period, 64 B of output
+//             each" into 64 B-contiguous quads, so one store instruction issues 16 x 64 B requests
+//             instead of 64 x 16 B (L2 request rate, not bytes, limits scattered stores).
 // HBM traffic = input span once per workgroup (+ row_len halo) + output once; the class table
 // (<= a few hundred KB) stays in L2 / scalar cache.
 #include "fir_periodic.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -28,61 +35,107 @@ namespace rsmp {
 
 namespace {
 
+constexpr uint32_t kLdsTwoPerCu = 80 * 1024;   // two workgroups per CU
+constexpr uint32_t kLdsMax = 160 * 1024;
+
 struct GeoArgs {
-    uint32_t a, b, row_len, n_tiles, lp, pw, row_stride, waves, channels, taps;
+    uint32_t a, b, r, row_len, n_tiles, lp, pw, row_stride, waves, channels, xprev_len;
+    uint32_t inline_wraps;
+    uint32_t debug;  // RSMP_FIR_DEBUG: bit0 skip staging, bit1 skip the tap loops (timing only)
 };
 
-typedef const float __attribute__((address_space(4)))* const_f32_ptr;
+typedef const float __attribute__((address_space(4)))* const_f32_ptr;   // scalar-cache loads
+typedef const float __attribute__((address_space(1)))* gconst_f32_ptr;  // global (not flat) loads
+typedef float __attribute__((address_space(1)))* g_f32_ptr;
+typedef const uint32_t __attribute__((address_space(1)))* gconst_u32_ptr;
+typedef const uint32_t __attribute__((address_space(4)))* const_u32_ptr;
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
 
-template <int CG> struct Acc { float v[kClassTile][CG]; };
+// Copies a wave-uniform, read-only POD through the scalar cache (s_load) into registers.
+template <class T>
+__device__ __forceinline__ T load_uniform(const T* p) {
+    static_assert(sizeof(T) % 4 == 0, "dword-sized PODs only");
+    T v;
+    const_u32_ptr src = (const_u32_ptr)p;
+    uint32_t* dst = reinterpret_cast<uint32_t*>(&v);
+#pragma unroll
+    for (size_t i = 0; i < sizeof(T) / 4; ++i) dst[i] = src[i];
+    return v;
+}
+
+template <int CG> struct Acc {
+    float v[kClassTile][CG];
+    float w[CG];  // wrap variant of one column
+};
+
+template <int CG>
+__device__ __forceinline__ void load_x(float (&xs)[CG], const float* p) {
+    if constexpr (CG == 2) {
+        const float2 t = *reinterpret_cast<const float2*>(p);
+        xs[0] = t.x;
+        xs[1] = t.y;
+    } else {
+        xs[0] = p[0];
+    }
+}
 
 // `count` taps: sample(s) from LDS (stride `cstride` dwords per frame), 8 coefficients per tap
-// from the class table through scalar loads.
-template <int CG>
+// (+1 for the wrap variant) from the class table through scalar loads.
+template <int CG, bool WRAP>
 __device__ __forceinline__ void accumulate(Acc<CG>& acc, const float* __restrict__ x,
-                                           uint32_t cstride, const_f32_ptr g, uint32_t count) {
+                                           uint32_t cstride, const_f32_ptr g, const_f32_ptr gw,
+                                           uint32_t count) {
     uint32_t m = 0;
     for (; m + 4 <= count; m += 4) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             float xs[CG];
-            if constexpr (CG == 2) {
-                const float2 t = *reinterpret_cast<const float2*>(x + (m + u) * cstride);
-                xs[0] = t.x;
-                xs[1] = t.y;
-            } else {
-                xs[0] = x[(m + u) * cstride];
-            }
+            load_x<CG>(xs, x + (m + u) * cstride);
 #pragma unroll
             for (int i = 0; i < (int)kClassTile; ++i) {
                 const float c = g[(m + u) * kClassTile + i];
 #pragma unroll
                 for (int k = 0; k < CG; ++k) acc.v[i][k] = fmaf(c, xs[k], acc.v[i][k]);
             }
+            if constexpr (WRAP) {
+                const float c = gw[m + u];
+#pragma unroll
+                for (int k = 0; k < CG; ++k) acc.w[k] = fmaf(c, xs[k], acc.w[k]);
+            }
         }
     }
     for (; m < count; ++m) {
         float xs[CG];
-        if constexpr (CG == 2) {
-            const float2 t = *reinterpret_cast<const float2*>(x + m * cstride);
-            xs[0] = t.x;
-            xs[1] = t.y;
-        } else {
-            xs[0] = x[m * cstride];
-        }
+        load_x<CG>(xs, x + m * cstride);
 #pragma unroll
         for (int i = 0; i < (int)kClassTile; ++i) {
             const float c = g[m * kClassTile + i];
 #pragma unroll
             for (int k = 0; k < CG; ++k) acc.v[i][k] = fmaf(c, xs[k], acc.v[i][k]);
         }
+        if constexpr (WRAP) {
+            const float c = gw[m];
+#pragma unroll
+            for (int k = 0; k < CG; ++k) acc.w[k] = fmaf(c, xs[k], acc.w[k]);
+        }
     }
 }
 
+__device__ __forceinline__ float dpp_quad_xor1(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float dpp_quad_xor2(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));
+}
+
+// 640 threads = 10 waves; two workgroups per CU -> 5 waves per SIMD -> at most 96 VGPRs.
 template <int CG>
-__global__ void fir_periodic_kernel(const FirStreamDesc* __restrict__ descs, GeoArgs geo) {
+__global__ __launch_bounds__(640, 5) void fir_periodic_kernel(const FirStreamDesc* __restrict__ descs,
+                                                              GeoArgs geo) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const FirStreamDesc& d = descs[blockIdx.y];
+    // The descriptor is wave-uniform and read-only: fetch it through the scalar cache.
+    const FirStreamDesc d = load_uniform(descs + blockIdx.y);
     const uint32_t n_out = d.n_out;
     if (n_out == 0) return;
     const uint64_t abs_out = d.abs_out;
@@ -94,49 +147,62 @@ __global__ void fir_periodic_kernel(const FirStreamDesc* __restrict__ descs, Geo
     const uint32_t C = geo.channels;
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* __restrict__ xprev = lds;                   // [pw][C]: the frame in front of each period
+    float* __restrict__ rows = lds + geo.xprev_len;    // [pw + 1][row_stride]
 
     // ---- stage ---------------------------------------------------------------------------------
-    {
-        const int64_t hist_frames = d.hist_frames;
-        const int64_t total_frames = hist_frames + d.in_frames;
-        const float* __restrict__ hist = d.hist;
-        const float* __restrict__ in = d.in;
-        // virtual index of the span's first frame: absolute frame q0*a minus frames retired so far
-        const int64_t v_span = static_cast<int64_t>(q0 * geo.a) - static_cast<int64_t>(d.abs_consumed);
+    // LDS-DMA (global_load_lds, 4 B per lane): the rows region is filled 256 B per wave
+    // instruction straight from [hist|in] with no VGPR round trip, so every piece of a wave
+    // (~30) is in flight at once and the other resident workgroup computes meanwhile.  Source
+    // addresses are clamped into the stream; an edge workgroup zeroes the out-of-stream part
+    // afterwards.
+    if (!(geo.debug & 1)) {
+        const int64_t hist_values = static_cast<int64_t>(d.hist_frames) * C;
+        const int64_t total_values = hist_values + static_cast<int64_t>(d.in_frames) * C;  // > 0
+        gconst_f32_ptr hist = (gconst_f32_ptr)d.hist;
+        gconst_f32_ptr in = (gconst_f32_ptr)d.in;
+        // virtual value index of the span's first sample: absolute frame q0*a minus the frames
+        // retired before this launch, times C
+        const int64_t w_span =
+            (static_cast<int64_t>(q0 * geo.a) - static_cast<int64_t>(d.abs_consumed)) * C;
         const uint32_t row_values = geo.a * C;
-        for (uint32_t p = wave; p <= geo.pw; p += geo.waves) {
-            const uint32_t values = (p < geo.pw) ? row_values
-                                                 : (geo.row_len < geo.a ? geo.row_len : geo.a) * C;
-            const int64_t v_row = v_span + static_cast<int64_t>(p) * geo.a;
-            float* __restrict__ dst = lds + static_cast<size_t>(p) * geo.row_stride;
-            if ((C & 1) == 0) {
-                // frames are 8-byte aligned: move float2 units
-                const uint32_t half_c = C >> 1;
-                for (uint32_t e = lane; e < values / 2; e += 64) {
-                    const int64_t v = v_row + (half_c == 1 ? e : e / half_c);
-                    const uint32_t within = half_c == 1 ? 0u : (e % half_c) * 2u;
-                    float2 val = make_float2(0.f, 0.f);
-                    if (v >= 0 && v < total_frames) {
-                        const float* src = v < hist_frames
-                                               ? hist + static_cast<size_t>(v) * C + within
-                                               : in + static_cast<size_t>(v - hist_frames) * C + within;
-                        val = *reinterpret_cast<const float2*>(src);
-                    }
-                    *reinterpret_cast<float2*>(dst + 2 * e) = val;
-                }
-            } else {
-                for (uint32_t e = lane; e < values; e += 64) {
-                    const int64_t v = v_row + (C == 1 ? e : e / C);
-                    const uint32_t within = C == 1 ? 0u : e % C;
-                    float val = 0.f;
-                    if (v >= 0 && v < total_frames)
-                        val = v < hist_frames ? hist[static_cast<size_t>(v) * C + within]
-                                              : in[static_cast<size_t>(v - hist_frames) * C + within];
-                    dst[e] = val;
-                }
+        const bool flat = geo.row_stride == row_values;   // odd a: rows are back to back
+        const uint32_t region = (geo.pw + 1) * geo.row_stride;
+        // virtual value index feeding LDS dword L of the rows region (pad dwords of even-a rows
+        // re-read the next row's first frame; they are never used)
+        auto w_of = [&](uint32_t L) -> int64_t {
+            if (flat) return w_span + L;
+            const uint32_t p = L / geo.row_stride;
+            return w_span + static_cast<int64_t>(p) * row_values + (L - p * geo.row_stride);
+        };
+        auto src_of = [&](int64_t w) -> gconst_f32_ptr {
+            const int64_t wc = w < 0 ? 0 : (w >= total_values ? total_values - 1 : w);
+            return wc < hist_values ? hist + wc : in + (wc - hist_values);
+        };
+        typedef __attribute__((address_space(3))) void* lds_void_ptr;
+        for (uint32_t base = wave * 64; base < region; base += geo.waves * 64) {
+            const uint32_t L = base + lane;
+            if (L < region)
+                __builtin_amdgcn_global_load_lds(src_of(w_of(L)), (lds_void_ptr)(rows + base), 4, 0, 0);
+        }
+        for (uint32_t e = threadIdx.x; e < geo.pw * C; e += blockDim.x) {
+            const uint32_t p = C == 1 ? e : e / C;
+            const int64_t w = w_span + static_cast<int64_t>(p) * row_values - C + (e - p * C);
+            float val = *src_of(w);
+            if (w < 0 || w >= total_values) val = 0.f;
+            xprev[e] = val;
+        }
+        const bool edge = w_span < 0 || w_span + static_cast<int64_t>(geo.pw + 1) * row_values > total_values;
+        if (edge) {   // workgroup-uniform
+            __builtin_amdgcn_s_waitcnt(0);   // own DMA pieces have landed
+            __syncthreads();
+            for (uint32_t L = threadIdx.x; L < region; L += blockDim.x) {
+                const int64_t w = w_of(L);
+                if (w < 0 || w >= total_values) rows[L] = 0.f;
             }
         }
     }
+    __builtin_amdgcn_s_waitcnt(0);   // vmcnt(0): LDS-DMA is tracked by vmcnt
     __syncthreads();
 
     // ---- compute -------------------------------------------------------------------------------
@@ -144,37 +210,123 @@ __global__ void fir_periodic_kernel(const FirStreamDesc* __restrict__ descs, Geo
     const uint32_t gi = lane - pl * geo.lp;      // channel group of this lane
     const bool lane_on = pl < geo.pw;
     const uint32_t pl_c = lane_on ? pl : 0;      // idle lanes shadow lane 0 (no stores)
-    const uint32_t lane_base = pl_c * geo.row_stride + gi * CG;
-    const_f32_ptr table = (const_f32_ptr)(d.mixed);
-    float* __restrict__ out = d.out;
+    const float* __restrict__ lane_row = rows + pl_c * geo.row_stride + gi * CG;
+    const_f32_ptr table = (const_f32_ptr)(d.class_coef);
+    const_f32_ptr wtable = (const_f32_ptr)(d.class_wrap_coef);
+    const TileMeta* metas = static_cast<const TileMeta*>(d.class_meta);
+    gconst_u32_ptr wrap_bits = (gconst_u32_ptr)d.wrap_bits;
+    g_f32_ptr out = (g_f32_ptr)d.out;
     const uint64_t q = q0 + pl_c;
 
     for (uint32_t t = wave; t < geo.n_tiles; t += geo.waves) {
         const uint32_t j0 = t * kClassTile;
-        const uint32_t ob = static_cast<uint32_t>((static_cast<uint64_t>(j0) * geo.a) / geo.b);
+        const TileMeta tm = load_uniform(metas + t);
+        const uint32_t ob = tm.base;
         const_f32_ptr g = table + static_cast<size_t>(t) * geo.row_len * kClassTile;
+        const_f32_ptr gw = wtable + static_cast<size_t>(t) * geo.row_len;
+        const bool has_wrap = geo.inline_wraps && tm.wrap_col >= 0;
         Acc<CG> acc;
 #pragma unroll
         for (int i = 0; i < (int)kClassTile; ++i)
 #pragma unroll
             for (int k = 0; k < CG; ++k) acc.v[i][k] = 0.f;
+#pragma unroll
+        for (int k = 0; k < CG; ++k) acc.w[k] = 0.f;
 
         // window [ob, ob+row_len) of the lane's period row, spilling into the next row
         const uint32_t n1 = geo.a - ob < geo.row_len ? geo.a - ob : geo.row_len;
-        accumulate<CG>(acc, lds + lane_base + ob * C, C, g, n1);
-        if (n1 < geo.row_len)
-            accumulate<CG>(acc, lds + lane_base + geo.row_stride, C, g + n1 * kClassTile,
-                           geo.row_len - n1);
+        if (!(geo.debug & 2)) {
+            if (has_wrap) {
+                accumulate<CG, true>(acc, lane_row + ob * C, C, g, gw, n1);
+                if (n1 < geo.row_len)
+                    accumulate<CG, true>(acc, lane_row + geo.row_stride, C, g + n1 * kClassTile,
+                                         gw + n1, geo.row_len - n1);
+            } else {
+                accumulate<CG, false>(acc, lane_row + ob * C, C, g, gw, n1);
+                if (n1 < geo.row_len)
+                    accumulate<CG, false>(acc, lane_row + geo.row_stride, C, g + n1 * kClassTile,
+                                          gw + n1, geo.row_len - n1);
+            }
+        }
 
-        if (lane_on) {
-            const uint64_t m0 = q * geo.b + j0;
+        const uint64_t m0 = q * geo.b + j0;
+        if (has_wrap) {
+            if (tm.extra_col != -2) {
+                float xs[CG];
+                load_x<CG>(xs, tm.extra_col >= 0 ? lane_row + tm.extra_col * C
+                                                 : xprev + pl_c * C + gi * CG);
+#pragma unroll
+                for (int k = 0; k < CG; ++k) acc.w[k] = fmaf(tm.extra_coef, xs[k], acc.w[k]);
+            }
+            const uint64_t m = m0 + tm.wrap_col;
+            bool take = false;
+            if (m >= abs_out && m < m_end) {
+                const uint64_t K = q * geo.r + tm.wrap_jd - d.wrap_k0;
+                take = (wrap_bits[K >> 5] >> (K & 31)) & 1u;
+            }
+#pragma unroll
+            for (int i = 0; i < (int)kClassTile; ++i)
+                if (i == tm.wrap_col && take) {
+#pragma unroll
+                    for (int k = 0; k < CG; ++k) acc.v[i][k] = acc.w[k];
+                }
+        }
+
+        // ---- store ---------------------------------------------------------------------------
+        bool done = false;
+        if constexpr (CG == 2) {
+            if (C == 2) {
+                // Quad transpose: lane r of a quad ends up with quarter r (2 frames = 16 B) of the
+                // four periods of the quad; store s then covers period quad_base + s contiguously.
+                const bool full_tile = j0 + kClassTile <= geo.b;
+                const bool mine_full = m0 >= abs_out && m0 + kClassTile <= m_end;
+                const bool mine_none = m0 >= m_end || m0 + kClassTile <= abs_out || !lane_on;
+                const bool partial = !(mine_full || mine_none);
+                if (full_tile && !__any(partial)) {
+                    float4 B[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        B[k] = make_float4(acc.v[2 * k][0], acc.v[2 * k][1], acc.v[2 * k + 1][0],
+                                           acc.v[2 * k + 1][1]);
+                    const bool odd = lane & 1, hi = lane & 2;
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) {
+                        const float4 s = odd ? B[2 * p] : B[2 * p + 1];
+                        const float4 r4 = make_float4(dpp_quad_xor1(s.x), dpp_quad_xor1(s.y),
+                                                      dpp_quad_xor1(s.z), dpp_quad_xor1(s.w));
+                        if (odd) B[2 * p] = r4; else B[2 * p + 1] = r4;
+                    }
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const float4 s = hi ? B[k] : B[k + 2];
+                        const float4 r4 = make_float4(dpp_quad_xor2(s.x), dpp_quad_xor2(s.y),
+                                                      dpp_quad_xor2(s.z), dpp_quad_xor2(s.w));
+                        if (hi) B[k] = r4; else B[k + 2] = r4;
+                    }
+                    const uint32_t quad_base = lane & ~3u, r = lane & 3u;
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        const uint32_t ps = quad_base + s;
+                        const uint64_t ms = (q0 + ps) * geo.b + j0;
+                        if (ps < geo.pw && ms >= abs_out && ms + kClassTile <= m_end) {
+                            typedef v4f __attribute__((address_space(1), aligned(8)))* g_f4a8_ptr;
+                            *((g_f4a8_ptr)(out + (ms - abs_out) * 2 + r * 4)) =
+                                v4f{B[s].x, B[s].y, B[s].z, B[s].w};
+                        }
+                    }
+                    done = true;
+                }
+            }
+        }
+        if (!done && lane_on) {
 #pragma unroll
             for (int i = 0; i < (int)kClassTile; ++i) {
                 const uint64_t m = m0 + i;
                 if (j0 + i < geo.b && m >= abs_out && m < m_end) {
-                    float* o = out + (m - abs_out) * C + gi * CG;
+                    g_f32_ptr o = out + (m - abs_out) * C + gi * CG;
                     if constexpr (CG == 2) {
-                        *reinterpret_cast<float2*>(o) = make_float2(acc.v[i][0], acc.v[i][1]);
+                        typedef v2f __attribute__((address_space(1)))* g_f2_ptr;
+                        *((g_f2_ptr)o) = v2f{acc.v[i][0], acc.v[i][1]};
                     } else {
                         o[0] = acc.v[i][0];
                     }
@@ -185,7 +337,8 @@ __global__ void fir_periodic_kernel(const FirStreamDesc* __restrict__ descs, Geo
 }
 
 // Outputs whose f64 position fell just below an integer: previous frame, row 1023, frac 0
-// (resampler_fir.rs:544, :562-565).  8 lanes per output, as fir_generic.
+// (resampler_fir.rs:544, :562-565).  8 lanes per output, as fir_generic.  Used only when the
+// geometry cannot take the wrap variant inline (den < 8).
 __global__ __launch_bounds__(256) void fir_wrap_fixup_kernel(const FirStreamDesc* __restrict__ descs) {
     const FirStreamDesc& d = descs[blockIdx.y];
     const uint32_t g = threadIdx.x & 7;
@@ -222,8 +375,16 @@ __global__ __launch_bounds__(256) void fir_wrap_fixup_kernel(const FirStreamDesc
     }
 }
 
-GeoArgs to_args(const PeriodicGeometry& g, uint32_t channels) {
-    return GeoArgs{g.a, g.b, g.row_len, g.n_tiles, g.lp, g.pw, g.row_stride, g.waves, channels, g.taps};
+uint32_t xprev_len_of(uint32_t pw, uint32_t channels) { return (pw * channels + 3) / 4 * 4; }
+
+GeoArgs to_args(const PeriodicGeometry& g) {
+    static const uint32_t debug = [] {
+        const char* e = getenv("RSMP_FIR_DEBUG");
+        return e ? static_cast<uint32_t>(atoi(e)) : 0u;
+    }();
+    const uint32_t channels = g.lp * g.cg;
+    return GeoArgs{g.a, g.b, g.b / g.den, g.row_len, g.n_tiles, g.lp, g.pw, g.row_stride, g.waves,
+                   channels, xprev_len_of(g.pw, channels), g.inline_wraps ? 1u : 0u, debug};
 }
 
 // Device class tables, shared by every stream on a device with the same polyphase table, rate
@@ -231,8 +392,7 @@ GeoArgs to_args(const PeriodicGeometry& g, uint32_t channels) {
 struct ClassTableKey {
     int device;
     const void* table;
-    uint64_t den;
-    uint32_t a, b, row_len;
+    uint32_t den, a, b, row_len;
     uint64_t drift_bits;
     bool operator<(const ClassTableKey& o) const {
         return std::tie(device, table, den, a, b, row_len, drift_bits) <
@@ -241,7 +401,7 @@ struct ClassTableKey {
 };
 struct ClassTableCache {
     std::mutex mu;
-    std::map<ClassTableKey, float*> tables;
+    std::map<ClassTableKey, ClassTable> tables;
 };
 ClassTableCache& class_cache() {
     static ClassTableCache* c = new ClassTableCache;
@@ -250,25 +410,20 @@ ClassTableCache& class_cache() {
 
 constexpr double kDriftQuantum = 2e-9;  // positions this close share a class table
 
+inline uint32_t class_offset(const PeriodicGeometry& g, uint32_t j) {
+    return static_cast<uint32_t>((static_cast<uint64_t>(j) * g.a) / g.b);
+}
+
 }  // namespace
 
 PeriodicGeometry periodic_geometry(uint64_t num, uint64_t den, uint32_t taps, uint32_t channels) {
     PeriodicGeometry g;
     if (num == 0 || den == 0 || channels == 0 || channels > 64) return g;
     if (num > (1u << 20) || den > (1u << 20)) return g;
-    // max in-tile shift: off(j) = floor(j*num/den); classes of a tile share the first one's base
-    // (the pattern repeats every den classes, and tiles of the super period start at multiples
-    // of 8, so scanning lcm-many tiles covers all of them; den*8 classes always do).
-    uint32_t shift = 0;
-    const uint64_t scan = den * kClassTile;
-    for (uint64_t j0 = 0; j0 < scan; j0 += kClassTile) {
-        const uint64_t s = ((j0 + kClassTile - 1) * num) / den - (j0 * num) / den;
-        if (s > shift) shift = static_cast<uint32_t>(s);
-        if (j0 > (1u << 16)) break;  // long enough: the bound ceil(7*num/den) is reached early
-    }
-    const uint32_t bound = static_cast<uint32_t>((7 * num + den - 1) / den);
-    if (shift < bound) shift = bound;
+    // max in-tile shift: off(j) = floor(j*num/den); tiles start at multiples of 8.
+    const uint32_t shift = static_cast<uint32_t>((7 * num + den - 1) / den);
     g.taps = taps;
+    g.den = static_cast<uint32_t>(den);
     g.row_len = (taps + shift + 3) / 4 * 4;
     // super period: a >= row_len (a window spans at most two rows) and b >= 8
     uint64_t r = (g.row_len + num - 1) / num;
@@ -278,36 +433,35 @@ PeriodicGeometry periodic_geometry(uint64_t num, uint64_t den, uint32_t taps, ui
     g.a = static_cast<uint32_t>(a);
     g.b = static_cast<uint32_t>(b);
     g.n_tiles = (g.b + kClassTile - 1) / kClassTile;
+    g.inline_wraps = den >= kClassTile;
 
-    constexpr uint32_t kLdsTwoPerCu = 80 * 1024;   // two workgroups per CU
-    constexpr uint32_t kLdsMax = 160 * 1024;
     auto fit = [&](uint32_t cg) -> bool {
         if (channels % cg != 0) return false;
         const uint32_t lp = channels / cg;
         if (lp > 64) return false;
         const uint32_t pw_max = 64 / lp;
-        uint32_t units = g.a * lp;  // read units (cg dwords) per period row
-        units += ((lp + 32 - units % 32) % 32);  // units == lp (mod 32): conflict-free lane stride
-        const uint32_t stride = units * cg;
+        // odd number of frames per row: the lane stride then hits every LDS bank once
+        const uint32_t stride = (g.a | 1u) * channels;
         const uint32_t row_bytes = stride * 4;
-        uint32_t pw = kLdsTwoPerCu / row_bytes;
-        pw = pw > 0 ? pw - 1 : 0;
-        if (pw * 4 < pw_max * 3) {  // < 75% of the lanes: take the whole LDS instead
-            pw = kLdsMax / row_bytes;
-            pw = pw > 0 ? pw - 1 : 0;
-        }
+        const uint32_t fixed = (64 * channels + 16) * 4;  // xprev
+        auto rows_in = [&](uint32_t budget) -> uint32_t {
+            if (budget <= fixed + 2 * row_bytes) return 0;
+            return (budget - fixed) / row_bytes - 1;
+        };
+        uint32_t pw = rows_in(kLdsTwoPerCu);
+        if (pw * 4 < pw_max * 3) pw = rows_in(kLdsMax);  // < 75% of the lanes: use the whole LDS
         if (pw > pw_max) pw = pw_max;
         if (pw * 2 < pw_max || pw == 0) return false;
         g.cg = cg;
         g.lp = lp;
         g.pw = pw;
         g.row_stride = stride;
-        g.lds_bytes = (pw + 1) * row_bytes;
+        g.lds_bytes = (xprev_len_of(pw, channels) + (pw + 1) * stride) * 4;
         return true;
     };
     if (!fit(2) && !fit(1)) return g;
     // waves per workgroup: balance the class tiles, keep >= 4 waves
-    const uint32_t max_waves = g.lds_bytes > kLdsTwoPerCu ? 16 : 10;
+    const uint32_t max_waves = 10;  // __launch_bounds__(640, 5) of fir_periodic_kernel
     uint32_t best = 4;
     double best_cost = 1e9;
     for (uint32_t w = 4; w <= max_waves; ++w) {
@@ -340,35 +494,77 @@ uint32_t periodic_blocks(const PeriodicGeometry& geo, uint64_t abs_out, uint32_t
     return static_cast<uint32_t>((q_last - q_first) / geo.pw + 1);
 }
 
-std::vector<float> build_class_table(const std::vector<float>& coeffs, const PeriodicGeometry& g,
-                                     uint64_t den, double drift) {
-    const uint32_t taps = g.taps;
-    std::vector<float> tab(static_cast<size_t>(g.n_tiles) * g.row_len * kClassTile, 0.0f);
-    std::vector<float> mixed(taps);
-    for (uint32_t j = 0; j < g.b; ++j) {
-        // exact fractional position of class j, plus the stream's current f64 drift
-        const uint64_t rem = (static_cast<uint64_t>(j) * g.a) % g.b;
-        double fract = static_cast<double>(rem) / static_cast<double>(g.b) + drift;
-        if (j % den == 0) fract = drift > 0.0 ? drift : 0.0;  // below-integer cases: fix-up kernel
-        if (fract < 0.0) fract = 0.0;
-        // resampler_fir.rs:562-565
-        double phase_f = fract * static_cast<double>(kPhases);
-        if (phase_f > static_cast<double>(kPhases - 1)) phase_f = static_cast<double>(kPhases - 1);
-        const size_t phase1 = static_cast<size_t>(phase_f);
-        const size_t phase2 = phase1 + 1 < kPhases - 1 ? phase1 + 1 : kPhases - 1;
-        const float frac = static_cast<float>(phase_f - static_cast<double>(phase1));
-        const float* c1 = coeffs.data() + phase1 * taps;
-        const float* c2 = coeffs.data() + phase2 * taps;
-        const float omf = 1.0f - frac;
-        for (uint32_t k = 0; k < taps; ++k) mixed[k] = c1[k] * omf + c2[k] * frac;  // avx.rs:41-45
-        const uint32_t t = j / kClassTile, i = j % kClassTile;
-        const uint32_t j0 = t * kClassTile;
-        const uint32_t shift = static_cast<uint32_t>((static_cast<uint64_t>(j) * g.a) / g.b -
-                                                     (static_cast<uint64_t>(j0) * g.a) / g.b);
-        float* base = tab.data() + static_cast<size_t>(t) * g.row_len * kClassTile;
-        for (uint32_t k = 0; k < taps; ++k) base[(k + shift) * kClassTile + i] = mixed[k];
+size_t periodic_wrap_words(uint64_t abs_out, uint32_t n_out, uint64_t den) {
+    if (n_out == 0) return 1;
+    const uint64_t k0 = abs_out / den, k1 = (abs_out + n_out - 1) / den;
+    return static_cast<size_t>((k1 - k0) / 32 + 1);
+}
+
+void periodic_fill_wrap_bits(const std::vector<uint32_t>& wraps, uint64_t abs_out, uint64_t den,
+                             uint32_t* words, size_t n_words) {
+    std::memset(words, 0, n_words * sizeof(uint32_t));
+    const uint64_t k0 = abs_out / den;
+    for (uint32_t n : wraps) {
+        const uint64_t k = (abs_out + n) / den - k0;
+        words[k >> 5] |= 1u << (k & 31);
     }
-    return tab;
+}
+
+HostClassTable build_class_table(const std::vector<float>& coeffs, const PeriodicGeometry& g,
+                                 double drift) {
+    const uint32_t taps = g.taps;
+    HostClassTable out;
+    out.coef.assign(static_cast<size_t>(g.n_tiles) * g.row_len * kClassTile, 0.0f);
+    out.wrap_coef.assign(static_cast<size_t>(g.n_tiles) * g.row_len, 0.0f);
+    out.meta.resize(g.n_tiles);
+    std::vector<float> mixed(taps);
+    const float* row1023 = coeffs.data() + (kPhases - 1) * taps;
+    for (uint32_t t = 0; t < g.n_tiles; ++t) {
+        TileMeta& tm = out.meta[t];
+        std::memset(&tm, 0, sizeof tm);
+        const uint32_t j0 = t * kClassTile;
+        tm.base = class_offset(g, j0);
+        tm.wrap_col = -1;
+        tm.extra_col = -2;
+        float* base = out.coef.data() + static_cast<size_t>(t) * g.row_len * kClassTile;
+        for (uint32_t i = 0; i < kClassTile && j0 + i < g.b; ++i) {
+            const uint32_t j = j0 + i;
+            // exact fractional position of class j, plus the stream's current f64 drift
+            const uint64_t rem = (static_cast<uint64_t>(j) * g.a) % g.b;
+            double fract = static_cast<double>(rem) / static_cast<double>(g.b) + drift;
+            if (j % g.den == 0) fract = drift > 0.0 ? drift : 0.0;  // below-integer: wrap variant
+            if (fract < 0.0) fract = 0.0;
+            // resampler_fir.rs:562-565
+            double phase_f = fract * static_cast<double>(kPhases);
+            if (phase_f > static_cast<double>(kPhases - 1)) phase_f = static_cast<double>(kPhases - 1);
+            const size_t phase1 = static_cast<size_t>(phase_f);
+            const size_t phase2 = phase1 + 1 < kPhases - 1 ? phase1 + 1 : kPhases - 1;
+            const float frac = static_cast<float>(phase_f - static_cast<double>(phase1));
+            const float* c1 = coeffs.data() + phase1 * taps;
+            const float* c2 = coeffs.data() + phase2 * taps;
+            const float omf = 1.0f - frac;
+            for (uint32_t k = 0; k < taps; ++k) mixed[k] = c1[k] * omf + c2[k] * frac;  // avx.rs:41-45
+            const uint32_t shift = class_offset(g, j) - tm.base;
+            for (uint32_t k = 0; k < taps; ++k) base[(k + shift) * kClassTile + i] = mixed[k];
+
+            if (g.inline_wraps && j % g.den == 0) {
+                // wrap variant of class j: row 1023 on the window one frame earlier (:544, :562-564)
+                tm.wrap_col = static_cast<int32_t>(i);
+                tm.wrap_jd = j / g.den;
+                float* wc = out.wrap_coef.data() + static_cast<size_t>(t) * g.row_len;
+                const int64_t w = static_cast<int64_t>(class_offset(g, j)) - 1;
+                if (w >= static_cast<int64_t>(tm.base)) {
+                    const uint32_t ws = static_cast<uint32_t>(w - tm.base);
+                    for (uint32_t k = 0; k < taps; ++k) wc[k + ws] = row1023[k];
+                } else {  // one sample in front of the tile window
+                    for (uint32_t k = 1; k < taps; ++k) wc[k - 1] = row1023[k];
+                    tm.extra_col = static_cast<int32_t>(tm.base) - 1;
+                    tm.extra_coef = row1023[0];
+                }
+            }
+        }
+    }
+    return out;
 }
 
 int periodic_bind(PeriodicState& st, int device, const std::vector<float>& table,
@@ -378,27 +574,37 @@ int periodic_bind(PeriodicState& st, int device, const std::vector<float>& table
         st.geo = periodic_geometry(planned.num(), planned.den(), static_cast<uint32_t>(planned.taps()),
                                    channels);
         st.geo_valid = true;
-        st.d_table = nullptr;
+        st.table_valid = false;
     }
     if (!st.geo.ok) return fail(RSMP_ERR_INVALID_ARGUMENT, "periodic kernel: unsupported geometry");
     const double drift = std::round(planned.drift() / kDriftQuantum) * kDriftQuantum;
-    if (st.d_table && drift == st.table_drift) return RSMP_OK;
+    if (st.table_valid && drift == st.table_drift) return RSMP_OK;
     ClassTableCache& cache = class_cache();
     std::lock_guard<std::mutex> lock(cache.mu);
     uint64_t bits;
     std::memcpy(&bits, &drift, sizeof bits);
-    const ClassTableKey key{device, table.data(), planned.den(), st.geo.a, st.geo.b,
-                            st.geo.row_len, bits};
+    const ClassTableKey key{device, table.data(), st.geo.den, st.geo.a, st.geo.b, st.geo.row_len, bits};
     auto it = cache.tables.find(key);
     if (it == cache.tables.end()) {
-        const std::vector<float> host = build_class_table(table, st.geo, planned.den(), drift);
-        float* dptr = nullptr;
-        RSMP_HIP_CHECK(hipMalloc(&dptr, host.size() * sizeof(float)));
-        RSMP_HIP_CHECK(hipMemcpy(dptr, host.data(), host.size() * sizeof(float),
+        const HostClassTable host = build_class_table(table, st.geo, drift);
+        const size_t coef_bytes = host.coef.size() * sizeof(float);
+        const size_t wrap_bytes = host.wrap_coef.size() * sizeof(float);
+        const size_t meta_bytes = host.meta.size() * sizeof(TileMeta);
+        char* dptr = nullptr;
+        RSMP_HIP_CHECK(hipMalloc(&dptr, coef_bytes + wrap_bytes + meta_bytes));
+        RSMP_HIP_CHECK(hipMemcpy(dptr, host.coef.data(), coef_bytes, hipMemcpyHostToDevice));
+        RSMP_HIP_CHECK(hipMemcpy(dptr + coef_bytes, host.wrap_coef.data(), wrap_bytes,
                                  hipMemcpyHostToDevice));
-        it = cache.tables.emplace(key, dptr).first;
+        RSMP_HIP_CHECK(hipMemcpy(dptr + coef_bytes + wrap_bytes, host.meta.data(), meta_bytes,
+                                 hipMemcpyHostToDevice));
+        ClassTable ct;
+        ct.d_coef = reinterpret_cast<const float*>(dptr);
+        ct.d_wrap_coef = reinterpret_cast<const float*>(dptr + coef_bytes);
+        ct.d_meta = reinterpret_cast<const TileMeta*>(dptr + coef_bytes + wrap_bytes);
+        it = cache.tables.emplace(key, ct).first;
     }
-    st.d_table = it->second;
+    st.table = it->second;
+    st.table_valid = true;
     st.table_drift = drift;
     return RSMP_OK;
 }
@@ -409,19 +615,28 @@ hipError_t launch_fir_periodic(const FirStreamDesc* d_descs, uint32_t n_streams,
     if (n_streams == 0 || max_blocks == 0) return hipSuccess;
     const dim3 grid(max_blocks, n_streams);
     const dim3 block(geo.waves * 64);
-    const GeoArgs args = to_args(geo, geo.lp * geo.cg);
-    hipError_t e;
-    if (geo.cg == 2) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(fir_periodic_kernel<2>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, geo.lds_bytes);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(fir_periodic_kernel<2>, grid, block, geo.lds_bytes, stream, d_descs, args);
-    } else {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(fir_periodic_kernel<1>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, geo.lds_bytes);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(fir_periodic_kernel<1>, grid, block, geo.lds_bytes, stream, d_descs, args);
+    const GeoArgs args = to_args(geo);
+    // Dynamic LDS above 64 KiB must be opted into, once per kernel and device.
+    static std::mutex mu;
+    static std::map<std::pair<int, int>, bool> granted;
+    int device = 0;
+    hipError_t e = hipGetDevice(&device);
+    if (e != hipSuccess) return e;
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        bool& have = granted[{device, static_cast<int>(geo.cg)}];
+        if (!have) {
+            const void* fn = geo.cg == 2 ? reinterpret_cast<const void*>(fir_periodic_kernel<2>)
+                                         : reinterpret_cast<const void*>(fir_periodic_kernel<1>);
+            e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMax);
+            if (e != hipSuccess) return e;
+            have = true;
+        }
     }
+    if (geo.cg == 2)
+        hipLaunchKernelGGL(fir_periodic_kernel<2>, grid, block, geo.lds_bytes, stream, d_descs, args);
+    else
+        hipLaunchKernelGGL(fir_periodic_kernel<1>, grid, block, geo.lds_bytes, stream, d_descs, args);
     return hipGetLastError();
 }
 
