@@ -271,8 +271,8 @@ int plan_job_uncached(Job& j, bool with_segments) {
         while (offset < in_frames_total) {
             const size_t remaining = in_frames_total - offset;
             const size_t take = remaining < chunk_frames ? remaining : chunk_frames;
-            if (pl.produced_frames > 0xFFFFFFFFull - cap_frames)
-                return rsmp::fail(RSMP_ERR_CAPACITY, "bulk launch exceeds 2^32 output frames");
+            if (pl.produced_frames > 0x7FF00000ull - cap_frames)
+                return rsmp::fail(RSMP_ERR_CAPACITY, "bulk launch exceeds 2^31 output frames");
             const rsmp::FirCallResult c =
                 pl.planned.call(take, cap_frames, static_cast<int64_t>(pl.consumed_frames),
                                 static_cast<uint32_t>(pl.produced_frames), segs, wraps);

@@ -42,6 +42,7 @@ struct GeoArgs {
     uint32_t a, b, r, row_len, n_tiles, lp, pw, row_stride, waves, channels, xprev_len;
     uint32_t inline_wraps;
     uint32_t debug;  // RSMP_FIR_DEBUG: bit0 skip staging, bit1 skip the tap loops (timing only)
+    uint32_t stagger_ticks;  // one-time start delay of the second workgroup slot (100 MHz ticks)
 };
 
 typedef const float __attribute__((address_space(4)))* const_f32_ptr;   // scalar-cache loads
@@ -129,8 +130,82 @@ __device__ __forceinline__ float dpp_quad_xor2(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));
 }
 
+// ---- fast path (2 channels, both per lane): packed-FMA chunks of 8 taps ---------------------------
+typedef const v2f __attribute__((address_space(4)))* const_v2f_ptr;
+
+// acc[2p] += c_p.lo * x, acc[2p+1] += c_p.hi * x for the four coefficient pairs of one tap: src0 is
+// an SGPR pair whose low / high half is broadcast to both lanes of the packed FMA by op_sel.
+__device__ __forceinline__ void pk_fma8(v2f (&acc)[8], v2f c0, v2f c1, v2f c2, v2f c3, v2f x) {
+    asm("v_pk_fma_f32 %0, %8, %12, %0 op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 %1, %8, %12, %1 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+        "v_pk_fma_f32 %2, %9, %12, %2 op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 %3, %9, %12, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+        "v_pk_fma_f32 %4, %10, %12, %4 op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 %5, %10, %12, %5 op_sel:[1,0,0] op_sel_hi:[1,1,1]\n\t"
+        "v_pk_fma_f32 %6, %11, %12, %6 op_sel_hi:[0,1,1]\n\t"
+        "v_pk_fma_f32 %7, %11, %12, %7 op_sel:[1,0,0] op_sel_hi:[1,1,1]"
+        : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]),
+          "+v"(acc[6]), "+v"(acc[7])
+        : "s"(c0), "s"(c1), "s"(c2), "s"(c3), "v"(x));
+}
+
+// 8 taps: 32 coefficient pairs (4 x s_load_dwordx16 = 256 B of the class table) against 8 frames.
+// One wait covers 64 packed FMAs (256 issue cycles), which is what lets a handful of waves per
+// SIMD hide the scalar-cache miss latency: each line of the table is touched by one wave only.
+template <bool WRAP>
+__device__ __forceinline__ void taps8(v2f (&acc)[8], v2f& accw, const v2f (&x)[8],
+                                      const_v2f_ptr gc, const_f32_ptr gwc) {
+    v2f c[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) c[i] = gc[i];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        pk_fma8(acc, c[4 * u], c[4 * u + 1], c[4 * u + 2], c[4 * u + 3], x[u]);
+        if constexpr (WRAP) {
+            const float w = gwc[u];
+            accw.x = fmaf(w, x[u].x, accw.x);
+            accw.y = fmaf(w, x[u].y, accw.y);
+        }
+    }
+}
+
+template <bool WRAP>
+__device__ __forceinline__ void tile_taps_c2(v2f (&acc)[8], v2f& accw, const float* rowA,
+                                             const float* rowB, uint32_t n1, uint32_t row_len,
+                                             const_f32_ptr g, const_f32_ptr gw) {
+    const uint32_t n_chunks = row_len >> 3;
+    const uint32_t chunks_a = n1 >> 3;          // chunks entirely inside the lane's own row
+    const_v2f_ptr gc = (const_v2f_ptr)g;
+    uint32_t c = 0;
+    for (; c < chunks_a; ++c) {
+        v2f x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x[u] = *reinterpret_cast<const v2f*>(rowA + 16 * c + 2 * u);
+        taps8<WRAP>(acc, accw, x, gc + 32 * c, gw + 8 * c);
+    }
+    if (c < n_chunks && (n1 & 7u)) {            // the chunk that straddles the two rows
+        v2f x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const uint32_t m = 8 * c + u;
+            const float* px = m < n1 ? rowA + 2 * m : rowB + 2 * (m - n1);
+            x[u] = *reinterpret_cast<const v2f*>(px);
+        }
+        taps8<WRAP>(acc, accw, x, gc + 32 * c, gw + 8 * c);
+        ++c;
+    }
+    for (; c < n_chunks; ++c) {
+        const float* pb = rowB + 2 * (8 * c - n1);
+        v2f x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x[u] = *reinterpret_cast<const v2f*>(pb + 2 * u);
+        taps8<WRAP>(acc, accw, x, gc + 32 * c, gw + 8 * c);
+    }
+}
+
 // 640 threads = 10 waves; two workgroups per CU -> 5 waves per SIMD -> at most 96 VGPRs.
-template <int CG>
+// C2 = true: exactly two channels, both handled by one lane (CG == 2) -- the headline config.
+template <int CG, bool C2>
 __global__ __launch_bounds__(640, 5) void fir_periodic_kernel(const FirStreamDesc* __restrict__ descs,
                                                               GeoArgs geo) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -141,10 +216,24 @@ __global__ __launch_bounds__(640, 5) void fir_periodic_kernel(const FirStreamDes
     const uint64_t abs_out = d.abs_out;
     const uint64_t q_first = abs_out / geo.b;
     const uint64_t q0 = q_first + static_cast<uint64_t>(blockIdx.x) * geo.pw;
-    const uint64_t m_end = abs_out + n_out;  // one past the last absolute output index
-    if (q0 * geo.b >= m_end) return;
+    if (q0 * geo.b >= abs_out + n_out) return;
+    // launch-relative index of output (period q0, class 0); fits int32 (n_out < 2^31)
+    const int32_t n_block0 = static_cast<int32_t>(static_cast<int64_t>(q0 * geo.b) -
+                                                  static_cast<int64_t>(abs_out));
 
-    const uint32_t C = geo.channels;
+    // All workgroups start together and take equally long, so the two workgroups sharing a CU
+    // would stage (HBM busy, VALU idle) and compute (VALU busy, HBM idle) in lockstep.  Delaying
+    // the second dispatch round once puts the pairs out of phase for the rest of the launch:
+    // one streams while the other computes.  Dispatch order only affects speed, never results.
+    if (geo.stagger_ticks) {
+        const uint32_t lin = blockIdx.x + gridDim.x * blockIdx.y;
+        if (lin >= 256 && lin < 512) {
+            const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+            while (__builtin_amdgcn_s_memrealtime() - t0 < geo.stagger_ticks) __builtin_amdgcn_s_sleep(16);
+        }
+    }
+
+    const uint32_t C = C2 ? 2u : geo.channels;
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float* __restrict__ xprev = lds;                   // [pw][C]: the frame in front of each period
@@ -180,10 +269,20 @@ __global__ __launch_bounds__(640, 5) void fir_periodic_kernel(const FirStreamDes
             return wc < hist_values ? hist + wc : in + (wc - hist_values);
         };
         typedef __attribute__((address_space(3))) void* lds_void_ptr;
-        for (uint32_t base = wave * 64; base < region; base += geo.waves * 64) {
-            const uint32_t L = base + lane;
-            if (L < region)
-                __builtin_amdgcn_global_load_lds(src_of(w_of(L)), (lds_void_ptr)(rows + base), 4, 0, 0);
+        const int64_t span_values = static_cast<int64_t>(geo.pw + 1) * row_values;
+        const bool edge = w_span < 0 || w_span + span_values > total_values;
+        if (flat && w_span >= hist_values && !edge) {
+            // interior workgroup: the span is one contiguous piece of `in`
+            gconst_f32_ptr src = in + (w_span - hist_values) + lane;
+            for (uint32_t base = wave * 64; base < region; base += geo.waves * 64)
+                if (base + lane < region)
+                    __builtin_amdgcn_global_load_lds(src + base, (lds_void_ptr)(rows + base), 4, 0, 0);
+        } else {
+            for (uint32_t base = wave * 64; base < region; base += geo.waves * 64) {
+                const uint32_t L = base + lane;
+                if (L < region)
+                    __builtin_amdgcn_global_load_lds(src_of(w_of(L)), (lds_void_ptr)(rows + base), 4, 0, 0);
+            }
         }
         for (uint32_t e = threadIdx.x; e < geo.pw * C; e += blockDim.x) {
             const uint32_t p = C == 1 ? e : e / C;
@@ -192,7 +291,6 @@ __global__ __launch_bounds__(640, 5) void fir_periodic_kernel(const FirStreamDes
             if (w < 0 || w >= total_values) val = 0.f;
             xprev[e] = val;
         }
-        const bool edge = w_span < 0 || w_span + static_cast<int64_t>(geo.pw + 1) * row_values > total_values;
         if (edge) {   // workgroup-uniform
             __builtin_amdgcn_s_waitcnt(0);   // own DMA pieces have landed
             __syncthreads();
@@ -206,17 +304,19 @@ __global__ __launch_bounds__(640, 5) void fir_periodic_kernel(const FirStreamDes
     __syncthreads();
 
     // ---- compute -------------------------------------------------------------------------------
-    const uint32_t pl = lane / geo.lp;           // period of this lane inside the block
-    const uint32_t gi = lane - pl * geo.lp;      // channel group of this lane
+    const uint32_t pl = C2 ? lane : lane / geo.lp;   // period of this lane inside the block
+    const uint32_t gi = C2 ? 0u : lane - pl * geo.lp;  // channel group of this lane
     const bool lane_on = pl < geo.pw;
-    const uint32_t pl_c = lane_on ? pl : 0;      // idle lanes shadow lane 0 (no stores)
+    const uint32_t pl_c = lane_on ? pl : 0;          // idle lanes shadow lane 0 (no stores)
     const float* __restrict__ lane_row = rows + pl_c * geo.row_stride + gi * CG;
     const_f32_ptr table = (const_f32_ptr)(d.class_coef);
     const_f32_ptr wtable = (const_f32_ptr)(d.class_wrap_coef);
     const TileMeta* metas = static_cast<const TileMeta*>(d.class_meta);
     gconst_u32_ptr wrap_bits = (gconst_u32_ptr)d.wrap_bits;
     g_f32_ptr out = (g_f32_ptr)d.out;
-    const uint64_t q = q0 + pl_c;
+    // bit index of (period q0, class 0) in the wrap bitmap
+    const int32_t k_block0 = static_cast<int32_t>(static_cast<int64_t>(q0 * geo.r) -
+                                                  static_cast<int64_t>(d.wrap_k0));
 
     for (uint32_t t = wave; t < geo.n_tiles; t += geo.waves) {
         const uint32_t j0 = t * kClassTile;
@@ -225,110 +325,133 @@ __global__ __launch_bounds__(640, 5) void fir_periodic_kernel(const FirStreamDes
         const_f32_ptr g = table + static_cast<size_t>(t) * geo.row_len * kClassTile;
         const_f32_ptr gw = wtable + static_cast<size_t>(t) * geo.row_len;
         const bool has_wrap = geo.inline_wraps && tm.wrap_col >= 0;
-        Acc<CG> acc;
-#pragma unroll
-        for (int i = 0; i < (int)kClassTile; ++i)
-#pragma unroll
-            for (int k = 0; k < CG; ++k) acc.v[i][k] = 0.f;
-#pragma unroll
-        for (int k = 0; k < CG; ++k) acc.w[k] = 0.f;
-
         // window [ob, ob+row_len) of the lane's period row, spilling into the next row
         const uint32_t n1 = geo.a - ob < geo.row_len ? geo.a - ob : geo.row_len;
-        if (!(geo.debug & 2)) {
-            if (has_wrap) {
-                accumulate<CG, true>(acc, lane_row + ob * C, C, g, gw, n1);
-                if (n1 < geo.row_len)
-                    accumulate<CG, true>(acc, lane_row + geo.row_stride, C, g + n1 * kClassTile,
-                                         gw + n1, geo.row_len - n1);
-            } else {
-                accumulate<CG, false>(acc, lane_row + ob * C, C, g, gw, n1);
-                if (n1 < geo.row_len)
-                    accumulate<CG, false>(acc, lane_row + geo.row_stride, C, g + n1 * kClassTile,
-                                          gw + n1, geo.row_len - n1);
+        const int32_t n_lane0 = n_block0 + static_cast<int32_t>(pl_c * geo.b + j0);  // class j0
+        const int32_t n_limit = static_cast<int32_t>(n_out);
+
+        float av[kClassTile][CG];
+        float aw[CG];
+        if constexpr (C2) {
+            v2f acc[8], accw = {0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = v2f{0.f, 0.f};
+            if (!(geo.debug & 2)) {
+                if (has_wrap)
+                    tile_taps_c2<true>(acc, accw, lane_row + ob * 2, lane_row + geo.row_stride, n1,
+                                       geo.row_len, g, gw);
+                else
+                    tile_taps_c2<false>(acc, accw, lane_row + ob * 2, lane_row + geo.row_stride, n1,
+                                        geo.row_len, g, gw);
             }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { av[i][0] = acc[i].x; av[i][1] = acc[i].y; }
+            aw[0] = accw.x;
+            aw[1] = accw.y;
+        } else {
+            Acc<CG> acc;
+#pragma unroll
+            for (int i = 0; i < (int)kClassTile; ++i)
+#pragma unroll
+                for (int k = 0; k < CG; ++k) acc.v[i][k] = 0.f;
+#pragma unroll
+            for (int k = 0; k < CG; ++k) acc.w[k] = 0.f;
+            if (!(geo.debug & 2)) {
+                if (has_wrap) {
+                    accumulate<CG, true>(acc, lane_row + ob * C, C, g, gw, n1);
+                    if (n1 < geo.row_len)
+                        accumulate<CG, true>(acc, lane_row + geo.row_stride, C, g + n1 * kClassTile,
+                                             gw + n1, geo.row_len - n1);
+                } else {
+                    accumulate<CG, false>(acc, lane_row + ob * C, C, g, gw, n1);
+                    if (n1 < geo.row_len)
+                        accumulate<CG, false>(acc, lane_row + geo.row_stride, C, g + n1 * kClassTile,
+                                              gw + n1, geo.row_len - n1);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < (int)kClassTile; ++i)
+#pragma unroll
+                for (int k = 0; k < CG; ++k) av[i][k] = acc.v[i][k];
+#pragma unroll
+            for (int k = 0; k < CG; ++k) aw[k] = acc.w[k];
         }
 
-        const uint64_t m0 = q * geo.b + j0;
         if (has_wrap) {
             if (tm.extra_col != -2) {
                 float xs[CG];
                 load_x<CG>(xs, tm.extra_col >= 0 ? lane_row + tm.extra_col * C
                                                  : xprev + pl_c * C + gi * CG);
 #pragma unroll
-                for (int k = 0; k < CG; ++k) acc.w[k] = fmaf(tm.extra_coef, xs[k], acc.w[k]);
+                for (int k = 0; k < CG; ++k) aw[k] = fmaf(tm.extra_coef, xs[k], aw[k]);
             }
-            const uint64_t m = m0 + tm.wrap_col;
+            const int32_t nw = n_lane0 + tm.wrap_col;
             bool take = false;
-            if (m >= abs_out && m < m_end) {
-                const uint64_t K = q * geo.r + tm.wrap_jd - d.wrap_k0;
+            if (nw >= 0 && nw < n_limit) {
+                const uint32_t K = static_cast<uint32_t>(k_block0 + static_cast<int32_t>(pl_c * geo.r + tm.wrap_jd));
                 take = (wrap_bits[K >> 5] >> (K & 31)) & 1u;
             }
 #pragma unroll
             for (int i = 0; i < (int)kClassTile; ++i)
                 if (i == tm.wrap_col && take) {
 #pragma unroll
-                    for (int k = 0; k < CG; ++k) acc.v[i][k] = acc.w[k];
+                    for (int k = 0; k < CG; ++k) av[i][k] = aw[k];
                 }
         }
 
         // ---- store ---------------------------------------------------------------------------
         bool done = false;
-        if constexpr (CG == 2) {
-            if (C == 2) {
-                // Quad transpose: lane r of a quad ends up with quarter r (2 frames = 16 B) of the
-                // four periods of the quad; store s then covers period quad_base + s contiguously.
-                const bool full_tile = j0 + kClassTile <= geo.b;
-                const bool mine_full = m0 >= abs_out && m0 + kClassTile <= m_end;
-                const bool mine_none = m0 >= m_end || m0 + kClassTile <= abs_out || !lane_on;
-                const bool partial = !(mine_full || mine_none);
-                if (full_tile && !__any(partial)) {
-                    float4 B[4];
+        if constexpr (C2) {
+            // Quad transpose: lane r of a quad ends up with quarter r (2 frames = 16 B) of the four
+            // periods of the quad; store s then covers period quad_base + s contiguously.
+            const bool full_tile = j0 + kClassTile <= geo.b;
+            const bool mine_full = n_lane0 >= 0 && n_lane0 + (int32_t)kClassTile <= n_limit;
+            const bool mine_none = n_lane0 >= n_limit || n_lane0 + (int32_t)kClassTile <= 0 || !lane_on;
+            const bool partial = !(mine_full || mine_none);
+            if (full_tile && !__any(partial)) {
+                v4f B[4];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        B[k] = make_float4(acc.v[2 * k][0], acc.v[2 * k][1], acc.v[2 * k + 1][0],
-                                           acc.v[2 * k + 1][1]);
-                    const bool odd = lane & 1, hi = lane & 2;
+                for (int k = 0; k < 4; ++k)
+                    B[k] = v4f{av[2 * k][0], av[2 * k][1], av[2 * k + 1][0], av[2 * k + 1][1]};
+                const bool odd = lane & 1, hi = lane & 2;
 #pragma unroll
-                    for (int p = 0; p < 2; ++p) {
-                        const float4 s = odd ? B[2 * p] : B[2 * p + 1];
-                        const float4 r4 = make_float4(dpp_quad_xor1(s.x), dpp_quad_xor1(s.y),
-                                                      dpp_quad_xor1(s.z), dpp_quad_xor1(s.w));
-                        if (odd) B[2 * p] = r4; else B[2 * p + 1] = r4;
-                    }
-#pragma unroll
-                    for (int k = 0; k < 2; ++k) {
-                        const float4 s = hi ? B[k] : B[k + 2];
-                        const float4 r4 = make_float4(dpp_quad_xor2(s.x), dpp_quad_xor2(s.y),
-                                                      dpp_quad_xor2(s.z), dpp_quad_xor2(s.w));
-                        if (hi) B[k] = r4; else B[k + 2] = r4;
-                    }
-                    const uint32_t quad_base = lane & ~3u, r = lane & 3u;
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) {
-                        const uint32_t ps = quad_base + s;
-                        const uint64_t ms = (q0 + ps) * geo.b + j0;
-                        if (ps < geo.pw && ms >= abs_out && ms + kClassTile <= m_end) {
-                            typedef v4f __attribute__((address_space(1), aligned(8)))* g_f4a8_ptr;
-                            *((g_f4a8_ptr)(out + (ms - abs_out) * 2 + r * 4)) =
-                                v4f{B[s].x, B[s].y, B[s].z, B[s].w};
-                        }
-                    }
-                    done = true;
+                for (int p = 0; p < 2; ++p) {
+                    const v4f s = odd ? B[2 * p] : B[2 * p + 1];
+                    const v4f r4 = v4f{dpp_quad_xor1(s.x), dpp_quad_xor1(s.y), dpp_quad_xor1(s.z),
+                                       dpp_quad_xor1(s.w)};
+                    if (odd) B[2 * p] = r4; else B[2 * p + 1] = r4;
                 }
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const v4f s = hi ? B[k] : B[k + 2];
+                    const v4f r4 = v4f{dpp_quad_xor2(s.x), dpp_quad_xor2(s.y), dpp_quad_xor2(s.z),
+                                       dpp_quad_xor2(s.w)};
+                    if (hi) B[k] = r4; else B[k + 2] = r4;
+                }
+                const uint32_t quad_base = lane & ~3u, r = lane & 3u;
+                const int32_t n_quad0 = n_block0 + static_cast<int32_t>(quad_base * geo.b + j0);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const int32_t ns = n_quad0 + s * static_cast<int32_t>(geo.b);
+                    if (quad_base + s < geo.pw && ns >= 0 && ns + (int32_t)kClassTile <= n_limit) {
+                        typedef v4f __attribute__((address_space(1), aligned(8)))* g_f4a8_ptr;
+                        *((g_f4a8_ptr)(out + static_cast<size_t>(ns) * 2 + r * 4)) = B[s];
+                    }
+                }
+                done = true;
             }
         }
         if (!done && lane_on) {
 #pragma unroll
             for (int i = 0; i < (int)kClassTile; ++i) {
-                const uint64_t m = m0 + i;
-                if (j0 + i < geo.b && m >= abs_out && m < m_end) {
-                    g_f32_ptr o = out + (m - abs_out) * C + gi * CG;
+                const int32_t n = n_lane0 + i;
+                if (j0 + i < geo.b && n >= 0 && n < n_limit) {
+                    g_f32_ptr o = out + static_cast<size_t>(n) * C + gi * CG;
                     if constexpr (CG == 2) {
                         typedef v2f __attribute__((address_space(1)))* g_f2_ptr;
-                        *((g_f2_ptr)o) = v2f{acc.v[i][0], acc.v[i][1]};
+                        *((g_f2_ptr)o) = v2f{av[i][0], av[i][1]};
                     } else {
-                        o[0] = acc.v[i][0];
+                        o[0] = av[i][0];
                     }
                 }
             }
@@ -382,9 +505,13 @@ GeoArgs to_args(const PeriodicGeometry& g) {
         const char* e = getenv("RSMP_FIR_DEBUG");
         return e ? static_cast<uint32_t>(atoi(e)) : 0u;
     }();
+    static const uint32_t stagger = [] {
+        const char* e = getenv("RSMP_FIR_STAGGER_US");
+        return static_cast<uint32_t>((e ? atof(e) : 12.0) * 100.0);
+    }();
     const uint32_t channels = g.lp * g.cg;
     return GeoArgs{g.a, g.b, g.b / g.den, g.row_len, g.n_tiles, g.lp, g.pw, g.row_stride, g.waves,
-                   channels, xprev_len_of(g.pw, channels), g.inline_wraps ? 1u : 0u, debug};
+                   channels, xprev_len_of(g.pw, channels), g.inline_wraps ? 1u : 0u, debug, stagger};
 }
 
 // Device class tables, shared by every stream on a device with the same polyphase table, rate
@@ -424,7 +551,7 @@ PeriodicGeometry periodic_geometry(uint64_t num, uint64_t den, uint32_t taps, ui
     const uint32_t shift = static_cast<uint32_t>((7 * num + den - 1) / den);
     g.taps = taps;
     g.den = static_cast<uint32_t>(den);
-    g.row_len = (taps + shift + 3) / 4 * 4;
+    g.row_len = (taps + shift + 7) / 8 * 8;   // whole 8-tap chunks (fir_periodic_kernel)
     // super period: a >= row_len (a window spans at most two rows) and b >= 8
     uint64_t r = (g.row_len + num - 1) / num;
     if (den * r < kClassTile) r = (kClassTile + den - 1) / den;
@@ -622,21 +749,36 @@ hipError_t launch_fir_periodic(const FirStreamDesc* d_descs, uint32_t n_streams,
     int device = 0;
     hipError_t e = hipGetDevice(&device);
     if (e != hipSuccess) return e;
+    const int variant = geo.cg == 2 ? (geo.lp == 1 ? 0 : 1) : 2;
+    const void* fns[3] = {reinterpret_cast<const void*>(fir_periodic_kernel<2, true>),
+                          reinterpret_cast<const void*>(fir_periodic_kernel<2, false>),
+                          reinterpret_cast<const void*>(fir_periodic_kernel<1, false>)};
     {
         std::lock_guard<std::mutex> lock(mu);
-        bool& have = granted[{device, static_cast<int>(geo.cg)}];
+        bool& have = granted[{device, variant}];
         if (!have) {
-            const void* fn = geo.cg == 2 ? reinterpret_cast<const void*>(fir_periodic_kernel<2>)
-                                         : reinterpret_cast<const void*>(fir_periodic_kernel<1>);
-            e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMax);
+            e = hipFuncSetAttribute(fns[variant], hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMax);
             if (e != hipSuccess) return e;
             have = true;
         }
     }
-    if (geo.cg == 2)
-        hipLaunchKernelGGL(fir_periodic_kernel<2>, grid, block, geo.lds_bytes, stream, d_descs, args);
+    static const bool verbose = getenv("RSMP_FIR_VERBOSE") != nullptr;
+    if (verbose) {
+        int blocks = -1;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, fns[variant], geo.waves * 64,
+                                                           geo.lds_bytes);
+        fprintf(stderr,
+                "[rsmp] periodic launch: a=%u b=%u row_len=%u tiles=%u cg=%u lp=%u pw=%u stride=%u "
+                "waves=%u lds=%u grid=(%u,%u) occupancy=%d blocks/CU\n",
+                geo.a, geo.b, geo.row_len, geo.n_tiles, geo.cg, geo.lp, geo.pw, geo.row_stride,
+                geo.waves, geo.lds_bytes, max_blocks, n_streams, blocks);
+    }
+    if (variant == 0)
+        hipLaunchKernelGGL((fir_periodic_kernel<2, true>), grid, block, geo.lds_bytes, stream, d_descs, args);
+    else if (variant == 1)
+        hipLaunchKernelGGL((fir_periodic_kernel<2, false>), grid, block, geo.lds_bytes, stream, d_descs, args);
     else
-        hipLaunchKernelGGL(fir_periodic_kernel<1>, grid, block, geo.lds_bytes, stream, d_descs, args);
+        hipLaunchKernelGGL((fir_periodic_kernel<1, false>), grid, block, geo.lds_bytes, stream, d_descs, args);
     return hipGetLastError();
 }
 
