@@ -1,0 +1,157 @@
+"""Pins the CPU oracle's FFT half against the known answers and properties the reference's own
+tests hold: planner tables (src/fft/planner.rs:248-443), optimizer lists
+(src/fft/optimizer.rs:72-165), FFT properties (src/fft/radix_fft.rs:723-1486) and the
+ResamplerFft amplitude tests (src/resampler_fft.rs:439-566)."""
+import numpy as np
+import pytest
+
+from oracle import pyoracle as o
+
+# (factors for RadixFFT::new) as used by the reference's multi-stage tests plus the production plans
+FACTOR_LISTS = [
+    [2], [4], [8], [2, 2], [2, 3], [2, 5], [2, 7], [4, 3], [8, 3], [2, 2, 2], [4, 4], [8, 8],
+    [2, 3, 5], [2, 3, 7], [2, 5, 7], [4, 3, 5], [2, 2, 3, 3], [8, 3, 5, 7], [2, 2, 2, 2, 2, 2, 2],
+    [4, 4, 4, 3, 2], [3, 4, 7, 7, 2, 2], [4, 4, 4, 4, 5, 2], [2, 3, 3, 7, 7, 2], [2, 4, 4, 4, 5, 2],
+    [4, 4, 4, 4, 5, 2, 2], [3, 4, 7, 7, 2, 8, 2],
+]
+
+
+def test_planner_known_configs():          # planner.rs:252-348
+    cases = {
+        (48000, 96000): (2, 4), (48000, 192000): (2, 8), (22050, 48000): (588, 1280),
+        (16000, 48000): (64, 192), (16000, 44100): (640, 1764), (44100, 48000): (1176, 1280),
+        (44100, 96000): (1176, 2560),
+    }
+    for (i, out), (si, so) in cases.items():
+        fi, fo, _, _ = o.fft_plan(i, out, scale=False)
+        assert (fi, fo) == (si, so)
+    assert o.fft_plan(44100, 48000, scale=False)[2:] == ([3, 4, 7, 7, 2], [4, 4, 4, 4, 5])
+    assert o.fft_plan(44100, 96000, scale=False)[2:] == ([3, 4, 7, 7, 2], [4, 4, 4, 4, 5, 2])
+
+
+def test_planner_throughput_scaling():      # planner.rs:350-442 and SURVEY 8a7
+    assert o.fft_plan(22050, 48000) == (588, 1280, [3, 4, 7, 7], [4, 4, 4, 4, 5])
+    assert o.fft_plan(44100, 48000) == (1176, 1280, [3, 4, 7, 7, 2], [4, 4, 4, 4, 5])
+    fi, fo, a, b = o.fft_plan(48000, 96000)
+    assert (fi, fo) == (512, 1024) and int(np.prod(a)) == 512 and int(np.prod(b)) == 1024
+    fi, fo, a, b = o.fft_plan(16000, 48000)
+    assert (fi, fo) == (512, 1536) and int(np.prod(a)) == 512 and int(np.prod(b)) == 1536
+    with pytest.raises(ValueError):
+        o.fft_plan(24000, 48000)
+
+
+def test_optimizer_known_lists():           # optimizer.rs:72-165
+    assert o.optimize_factors([2, 2]) == [4]
+    assert o.optimize_factors([2, 2, 4, 2, 2]) == [8, 8]
+    assert o.optimize_factors([2, 4, 4, 4, 4, 2]) == [2, 8, 8, 8]
+    assert o.optimize_factors([4, 4, 4, 4, 5]) == [4, 5, 8, 8]
+    assert o.optimize_factors([2, 4, 4, 4]) == [2, 8, 8]
+    assert o.optimize_factors([4, 4, 8, 8]) == [2, 8, 8, 8]
+
+
+def test_production_stage_lists():          # 44.1k -> 48k
+    assert o.OracleRfft([3, 4, 7, 7, 2, 2]).stage_factors() == [3, 7, 7, 8]
+    assert o.OracleRfft([4, 4, 4, 4, 5, 2], inverse=True).stage_factors() == [4, 5, 8, 8]
+
+
+@pytest.mark.parametrize("factors", FACTOR_LISTS)
+def test_fft_properties(factors):           # radix_fft.rs:773-1486
+    F = o.OracleRfft(factors)
+    I = o.OracleRfft(factors, inverse=True)
+    n = F.n
+    tol = 1e-5 * n
+    # DC
+    X = F.forward(np.ones(n, np.float32))
+    assert abs(X[0] - n) < tol and np.abs(X[1:]).max() < tol
+    # impulse
+    x = np.zeros(n, np.float32)
+    x[0] = 1.0
+    assert np.abs(F.forward(x) - 1.0).max() < 1e-5
+    rng = np.random.default_rng(n)
+    a = rng.standard_normal(n).astype(np.float32)
+    b = rng.standard_normal(n).astype(np.float32)
+    A, B = F.forward(a), F.forward(b)
+    # vs naive DFT (numpy in f64)
+    ref = np.fft.rfft(a.astype(np.float64))
+    assert np.abs(A - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())
+    # linearity
+    AB = F.forward((2 * a + 3 * b).astype(np.float32))
+    assert np.abs(AB - (2 * A + 3 * B)).max() < 1e-4 * max(1.0, np.abs(AB).max())
+    # Parseval (real FFT: DC and Nyquist once, the rest twice)
+    e_time = float(np.sum(a.astype(np.float64) ** 2))
+    mag = np.abs(A.astype(np.complex128)) ** 2
+    e_freq = (mag[0] + mag[-1] + 2 * mag[1:-1].sum()) / n
+    assert abs(e_time - e_freq) < 1e-4 * e_time
+    # DC / Nyquist bins are real
+    assert abs(A[0].imag) < 1e-6 and abs(A[-1].imag) < 1e-6
+    # single cosine bin
+    if n >= 8:
+        k = 1 if n < 16 else 3
+        c = np.cos(2 * np.pi * k * np.arange(n) / n).astype(np.float32)
+        Cx = F.forward(c)
+        assert abs(Cx[k] - n / 2) < tol
+        Cx[k] = 0
+        assert np.abs(Cx).max() < tol
+    # forward + inverse = n * x
+    y = I.inverse_transform(A)
+    assert np.abs(y / n - a).max() < 1e-5 * max(1.0, np.abs(a).max()) * np.log2(n + 1)
+
+
+DC_CASES = [(48000, 44100), (44100, 48000), (48000, 32000), (32000, 48000), (96000, 48000), (48000, 96000)]
+
+
+@pytest.mark.parametrize("in_hz,out_hz", DC_CASES)
+def test_resampler_dc_amplitude(in_hz, out_hz):        # resampler_fft.rs:439-480
+    r = o.OracleFft(1, in_hz, out_hz)
+    x = np.full(r.chunk_size_input(), 0.5, np.float32)
+    out = np.zeros(r.chunk_size_output(), np.float32)
+    for _ in range(5):
+        assert r.resample(x, out) == 0
+    start = min(r.delay(), out.size // 4)
+    assert np.abs(out[start:out.size * 3 // 4] - 0.5).max() < 0.02
+
+
+@pytest.mark.parametrize("in_hz,out_hz", DC_CASES[:3])
+def test_resampler_sine_amplitude(in_hz, out_hz):      # resampler_fft.rs:482-526
+    r = o.OracleFft(1, in_hz, out_hz)
+    n = r.chunk_size_input()
+    inc = np.float32(2.0 * np.pi * 1000.0 / in_hz)
+    phase = np.float32(0.0)
+    x = np.empty(n, np.float32)
+    for i in range(n):
+        x[i] = np.float32(0.5) * np.sin(phase)
+        phase = np.float32(phase + inc)
+    out = np.zeros(r.chunk_size_output(), np.float32)
+    for _ in range(5):
+        r.resample(x, out)
+    start = min(r.delay(), out.size // 4)
+    assert abs(np.abs(out[start:out.size * 3 // 4]).max() - 0.5) < 0.02
+
+
+def test_resampler_stereo_dc():                         # resampler_fft.rs:528-566
+    r = o.OracleFft(2, 48000, 44100)
+    n = r.chunk_size_input()
+    x = np.zeros(n, np.float32)
+    x[0::2] = 0.3
+    x[1::2] = 0.6
+    out = np.zeros(r.chunk_size_output(), np.float32)
+    for _ in range(5):
+        r.resample(x, out)
+    start = min(r.delay(), out.size // 8) * 2
+    end = out.size * 3 // 4
+    assert np.abs(out[start:end:2] - 0.3).max() < 0.02
+    assert np.abs(out[start + 1:end:2] - 0.6).max() < 0.02
+
+
+def test_resampler_sizes_and_errors():
+    r = o.OracleFft(2, 44100, 48000)
+    assert (r.chunk_size_input(), r.chunk_size_output(), r.delay()) == (2352, 2560, 588)
+    assert r.filter_spectrum().size == 1177
+    out = np.zeros(2560, np.float32)
+    assert r.resample(np.zeros(2351, np.float32), out) == 1
+    assert r.resample(np.zeros(2352, np.float32), out[:2559]) == 2
+    assert r.resample(np.zeros(5000, np.float32), np.zeros(4000, np.float32)) == 0   # >= is enough
+    # the reference's channel scratch quirk: stereo 32k -> 16k indexes out of range
+    q = o.OracleFft(2, 32000, 16000)
+    assert q.resample(np.zeros(q.chunk_size_input(), np.float32),
+                      np.zeros(q.chunk_size_output(), np.float32)) in (0, 3)
