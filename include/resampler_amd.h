@@ -144,6 +144,43 @@ int rsmp_fir_plan_call(rsmp_fir_plan* p, size_t input_frames, size_t output_capa
                        size_t* frames_accepted, size_t* frames_produced, rsmp_fir_segment* segs,
                        size_t max_segs, size_t* n_segs);
 
+/* ============================ ResamplerFft (src/resampler_fft.rs) =============================== */
+typedef struct rsmp_fft rsmp_fft;
+
+/* ResamplerFft::new (resampler_fft.rs:75-119); rates are SampleRate enum values.  NULL on
+ * failure.  Channels are processed independently ("reference quirks"). */
+rsmp_fft* rsmp_fft_new(size_t channels, int input_rate, int output_rate, int device);
+void rsmp_fft_free(rsmp_fft* r);
+/* ResamplerFft::chunk_size_input / chunk_size_output (resampler_fft.rs:135-145). */
+size_t rsmp_fft_chunk_size_input(const rsmp_fft* r);
+size_t rsmp_fft_chunk_size_output(const rsmp_fft* r);
+/* ResamplerFft::delay (resampler_fft.rs:151-153). */
+size_t rsmp_fft_delay(const rsmp_fft* r);
+size_t rsmp_fft_channels(const rsmp_fft* r);
+int rsmp_fft_set_profiling(rsmp_fft* r, int enable);
+int rsmp_fft_last_kernel_ms(rsmp_fft* r, float* ms);
+
+/* ResamplerFft::resample (resampler_fft.rs:182-240): one chunk; in_len >= chunk_size_input and
+ * out_len >= chunk_size_output, extra values ignored (:186-192).  Host buffers, synchronous. */
+int rsmp_fft_resample(rsmp_fft* r, const float* in, size_t in_len, float* out, size_t out_len);
+int rsmp_fft_resample_device(rsmp_fft* r, const float* d_in, size_t in_len, float* d_out,
+                             size_t out_len, void* stream);
+/* n_chunks back-to-back chunks == n_chunks consecutive resample() calls (the whole-chunk loop of
+ * resample_batch, resample/src/main.rs:276-289), one launch. */
+int rsmp_fft_resample_bulk(rsmp_fft* r, const float* in, size_t in_len, float* out, size_t out_len,
+                           size_t n_chunks);
+int rsmp_fft_resample_bulk_device(rsmp_fft* r, const float* d_in, size_t in_len, float* d_out,
+                                  size_t out_len, size_t n_chunks, void* stream);
+/* n instances with the same rate pair on one device, one launch. */
+int rsmp_fft_batch_resample_bulk_device(rsmp_fft* const* rs, size_t n, const float* const* d_in,
+                                        float* const* d_out, const size_t* n_chunks, void* stream);
+
+/* host-only: block sizes and the N/2-point Stockham stage lists for a rate pair
+ * (planner.rs:35-245, optimizer.rs:6-64, radix_fft.rs:222-246). */
+int rsmp_fft_plan_sizes(uint32_t input_rate_hz, uint32_t output_rate_hz, size_t* fft_size_input,
+                        size_t* fft_size_output, int* forward_stages, size_t* n_forward_stages,
+                        int* inverse_stages, size_t* n_inverse_stages, size_t max_stages);
+
 #ifdef __cplusplus
 }
 #endif

@@ -131,6 +131,24 @@ _SIGNATURES = [
     ("rsmp_fir_plan_state", None, [C.c_void_p, _szp, _szp, C.POINTER(C.c_double)]),
     ("rsmp_fir_plan_call", C.c_int,
      [C.c_void_p, C.c_size_t, C.c_size_t, _szp, _szp, C.POINTER(_Segment), C.c_size_t, _szp]),
+    ("rsmp_fft_new", C.c_void_p, [C.c_size_t, C.c_int, C.c_int, C.c_int]),
+    ("rsmp_fft_free", None, [C.c_void_p]),
+    ("rsmp_fft_chunk_size_input", C.c_size_t, [C.c_void_p]),
+    ("rsmp_fft_chunk_size_output", C.c_size_t, [C.c_void_p]),
+    ("rsmp_fft_delay", C.c_size_t, [C.c_void_p]),
+    ("rsmp_fft_channels", C.c_size_t, [C.c_void_p]),
+    ("rsmp_fft_set_profiling", C.c_int, [C.c_void_p, C.c_int]),
+    ("rsmp_fft_last_kernel_ms", C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    ("rsmp_fft_resample", C.c_int, [C.c_void_p, _f32p, C.c_size_t, _f32p, C.c_size_t]),
+    ("rsmp_fft_resample_device", C.c_int,
+     [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]),
+    ("rsmp_fft_resample_bulk", C.c_int, [C.c_void_p, _f32p, C.c_size_t, _f32p, C.c_size_t, C.c_size_t]),
+    ("rsmp_fft_resample_bulk_device", C.c_int,
+     [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p]),
+    ("rsmp_fft_batch_resample_bulk_device", C.c_int,
+     [C.POINTER(C.c_void_p), C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _szp, C.c_void_p]),
+    ("rsmp_fft_plan_sizes", C.c_int,
+     [C.c_uint32, C.c_uint32, _szp, _szp, C.POINTER(C.c_int), _szp, C.POINTER(C.c_int), _szp, C.c_size_t]),
 ]
 
 
@@ -358,6 +376,118 @@ class FirBatch:
             self._handles, n, self._in, self._in_lens, chunk_len, self._out, self._out_caps,
             self._consumed, self._produced, C.c_void_p(stream or 0)))
         return list(self._consumed), list(self._produced)
+
+
+class ResamplerFft:
+    """GPU-backed ResamplerFft (src/resampler_fft.rs:43-240)."""
+
+    def __init__(self, channels: int, sample_rate_input: SampleRate, sample_rate_output: SampleRate,
+                 device: int = 0):
+        h = lib().rsmp_fft_new(channels, int(SampleRate(sample_rate_input)),
+                               int(SampleRate(sample_rate_output)), device)
+        if not h:
+            raise ResampleError(3, last_error())
+        self._h = C.c_void_p(h)
+        self.device = device
+
+    @classmethod
+    def new(cls, channels, sample_rate_input: SampleRate, sample_rate_output: SampleRate,
+            device: int = 0) -> "ResamplerFft":
+        return cls(channels, sample_rate_input, sample_rate_output, device)
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            lib().rsmp_fft_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __repr__(self) -> str:  # fmt::Debug, resampler_fft.rs:56-66
+        ch = self.channels
+        return (f"ResamplerFft {{ channels: {ch}, chunk_size_input: {self.chunk_size_input()}, "
+                f"chunk_size_output: {self.chunk_size_output()}, fft_size_input: "
+                f"{self.chunk_size_input() // ch}, fft_size_output: {self.chunk_size_output() // ch}, .. }}")
+
+    @property
+    def channels(self) -> int:
+        return lib().rsmp_fft_channels(self._h)
+
+    def chunk_size_input(self) -> int:
+        return lib().rsmp_fft_chunk_size_input(self._h)
+
+    def chunk_size_output(self) -> int:
+        return lib().rsmp_fft_chunk_size_output(self._h)
+
+    def delay(self) -> int:
+        return lib().rsmp_fft_delay(self._h)
+
+    def set_profiling(self, enable: bool) -> None:
+        _check(lib().rsmp_fft_set_profiling(self._h, 1 if enable else 0))
+
+    def last_kernel_ms(self) -> float:
+        ms = C.c_float()
+        _check(lib().rsmp_fft_last_kernel_ms(self._h, C.byref(ms)))
+        return ms.value
+
+    def resample(self, input, output: np.ndarray) -> None:
+        """One chunk; raises InvalidInputBufferSize / InvalidOutputBufferSize like Err(..)."""
+        inp = _np_f32(input)
+        assert output.dtype == np.float32 and output.flags["C_CONTIGUOUS"]
+        _check(lib().rsmp_fft_resample(self._h, _ptr(inp), inp.size, _ptr(output), output.size))
+
+    def resample_bulk(self, input, n_chunks: int) -> np.ndarray:
+        inp = _np_f32(input)
+        out = np.empty(n_chunks * self.chunk_size_output(), np.float32)
+        _check(lib().rsmp_fft_resample_bulk(self._h, _ptr(inp), inp.size, _ptr(out), out.size, n_chunks))
+        return out
+
+    def resample_device(self, d_in, d_out, stream: Optional[int] = None) -> None:
+        _check(lib().rsmp_fft_resample_device(self._h, _dev_ptr(d_in), d_in.numel(), _dev_ptr(d_out),
+                                              d_out.numel(), C.c_void_p(stream or 0)))
+
+    def resample_bulk_device(self, d_in, d_out, n_chunks: int, stream: Optional[int] = None) -> None:
+        _check(lib().rsmp_fft_resample_bulk_device(self._h, _dev_ptr(d_in), d_in.numel(),
+                                                   _dev_ptr(d_out), d_out.numel(), n_chunks,
+                                                   C.c_void_p(stream or 0)))
+
+
+class FftBatch:
+    """N ResamplerFft instances with one rate pair on one device, one launch per step."""
+
+    def __init__(self, resamplers: Sequence[ResamplerFft]):
+        self.resamplers = list(resamplers)
+        n = len(self.resamplers)
+        self._handles = (C.c_void_p * n)(*[r._h for r in self.resamplers])
+        self._in = (C.c_void_p * n)()
+        self._out = (C.c_void_p * n)()
+        self._chunks = (C.c_size_t * n)()
+
+    def bind(self, d_ins, d_outs, n_chunks: Sequence[int]) -> None:
+        self._keep = (list(d_ins), list(d_outs))
+        for i, (a, b, k) in enumerate(zip(d_ins, d_outs, n_chunks)):
+            r = self.resamplers[i]
+            assert a.numel() >= k * r.chunk_size_input() and b.numel() >= k * r.chunk_size_output()
+            self._in[i] = _dev_ptr(a)
+            self._out[i] = _dev_ptr(b)
+            self._chunks[i] = k
+
+    def resample_bulk_device(self, stream: Optional[int] = None) -> None:
+        _check(lib().rsmp_fft_batch_resample_bulk_device(self._handles, len(self.resamplers), self._in,
+                                                         self._out, self._chunks, C.c_void_p(stream or 0)))
+
+
+def fft_plan_sizes(input_rate_hz: int, output_rate_hz: int):
+    """(fft_size_input, fft_size_output, forward stage radices, inverse stage radices)."""
+    fi, fo, nf, ni = C.c_size_t(), C.c_size_t(), C.c_size_t(), C.c_size_t()
+    a = (C.c_int * 16)()
+    b = (C.c_int * 16)()
+    _check(lib().rsmp_fft_plan_sizes(input_rate_hz, output_rate_hz, C.byref(fi), C.byref(fo), a,
+                                     C.byref(nf), b, C.byref(ni), 16))
+    return fi.value, fo.value, list(a[:nf.value]), list(b[:ni.value])
 
 
 # ---- host-only helpers (no GPU needed) -----------------------------------------------------------

@@ -1,0 +1,327 @@
+// fft_api.cpp -- ResamplerFft front-end on the GPU: handles, state, launch assembly, C ABI.
+//
+// Mirrors src/resampler_fft.rs of the reference: ResamplerFft::new (:75-119), chunk_size_input /
+// chunk_size_output (:135-145), delay (:151-153), resample (:182-240).  Stream state is the
+// per-channel overlap row (`overlaps`, :51), resident in HBM; everything else the reference keeps
+// per instance (scratch pads, spectra) lives in LDS for the duration of a block.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <vector>
+
+#include "common.h"
+#include "device_util.h"
+#include "fft_kernels.h"
+#include "fft_plan.h"
+
+using rsmp::DeviceBuffer;
+using rsmp::DeviceGuard;
+using rsmp::FftPlanDev;
+using rsmp::FftStreamDesc;
+using rsmp::PinnedBuffer;
+
+namespace {
+
+// Device-side half of the reference's FFT_CACHE (resampler_fft.rs:35-36, :306-318): one plan
+// image per (device, rate pair), shared by every instance.
+struct DevicePlan {
+    rsmp::FftResamplerPlan host;
+    FftPlanDev dev;
+};
+struct PlanCache {
+    std::mutex mu;
+    std::map<std::tuple<int, uint32_t, uint32_t>, std::shared_ptr<DevicePlan>> plans;
+};
+PlanCache& plan_cache() {
+    static PlanCache* c = new PlanCache;
+    return *c;
+}
+
+template <class T>
+int upload(const std::vector<T>& v, const T** out) {
+    T* d = nullptr;
+    const size_t bytes = (v.empty() ? 1 : v.size()) * sizeof(T);
+    RSMP_HIP_CHECK(hipMalloc(&d, bytes));
+    if (!v.empty()) RSMP_HIP_CHECK(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    *out = d;
+    return RSMP_OK;
+}
+
+int get_plan(int device, uint32_t in_hz, uint32_t out_hz, std::shared_ptr<DevicePlan>* out) {
+    PlanCache& c = plan_cache();
+    std::lock_guard<std::mutex> lock(c.mu);
+    const auto key = std::make_tuple(device, in_hz, out_hz);
+    auto it = c.plans.find(key);
+    if (it != c.plans.end()) { *out = it->second; return RSMP_OK; }
+    auto p = std::make_shared<DevicePlan>();
+    p->host = rsmp::make_fft_resampler_plan(in_hz, out_hz);
+    if (!p->host.ok)
+        return rsmp::fail(RSMP_ERR_INVALID_ARGUMENT, "ResamplerFft: unsupported rate pair %u -> %u", in_hz, out_hz);
+    const rsmp::FftResamplerPlan& h = p->host;
+    if (h.forward.stages.size() > rsmp::kMaxFftStages || h.inverse.stages.size() > rsmp::kMaxFftStages)
+        return rsmp::fail(RSMP_ERR_INVALID_ARGUMENT, "ResamplerFft: too many FFT stages");
+    FftPlanDev& d = p->dev;
+    std::memset(&d, 0, sizeof d);
+    d.fft_in = static_cast<uint32_t>(h.fft_in);
+    d.fft_out = static_cast<uint32_t>(h.fft_out);
+    d.n_stages_f = static_cast<uint32_t>(h.forward.stages.size());
+    d.n_stages_i = static_cast<uint32_t>(h.inverse.stages.size());
+    for (size_t s = 0; s < h.forward.stages.size(); ++s) {
+        d.radix_f[s] = static_cast<uint32_t>(h.forward.stages[s]);
+        d.tw_off_f[s] = h.forward.stage_twiddle_offset[s];
+    }
+    for (size_t s = 0; s < h.inverse.stages.size(); ++s) {
+        d.radix_i[s] = static_cast<uint32_t>(h.inverse.stages[s]);
+        d.tw_off_i[s] = h.inverse.stage_twiddle_offset[s];
+    }
+    static_assert(sizeof(rsmp::Complex32) == sizeof(float2), "Complex32 is float2");
+    int rc;
+    const rsmp::Complex32* ptr = nullptr;
+    if ((rc = upload(h.forward.stage_twiddles, &ptr)) != RSMP_OK) return rc;
+    d.tw_f = reinterpret_cast<const float2*>(ptr);
+    if ((rc = upload(h.inverse.stage_twiddles, &ptr)) != RSMP_OK) return rc;
+    d.tw_i = reinterpret_cast<const float2*>(ptr);
+    if ((rc = upload(h.forward.rc_twiddles, &ptr)) != RSMP_OK) return rc;
+    d.rc_f = reinterpret_cast<const float2*>(ptr);
+    if ((rc = upload(h.inverse.rc_twiddles, &ptr)) != RSMP_OK) return rc;
+    d.rc_i = reinterpret_cast<const float2*>(ptr);
+    d.n_rc_f = static_cast<uint32_t>(h.forward.rc_twiddles.size());
+    d.n_rc_i = static_cast<uint32_t>(h.inverse.rc_twiddles.size());
+    d.new_length = static_cast<uint32_t>(h.new_length);
+    d.lds_complex = static_cast<uint32_t>((h.fft_in > h.fft_out ? h.fft_in : h.fft_out) + 1);
+    if (rsmp::fft_ola_lds_bytes(d, 1) > 160 * 1024)
+        return rsmp::fail(RSMP_ERR_INVALID_ARGUMENT,
+                          "ResamplerFft: blocks of %zu -> %zu frames do not fit the 160 KiB LDS",
+                          h.fft_in, h.fft_out);
+    // Filter spectrum = forward transform of the windowed sinc, by the same device transform the
+    // resampler uses (resampler_fft.rs:361-376).
+    const float* d_time = nullptr;
+    if ((rc = upload(h.filter_time, &d_time)) != RSMP_OK) return rc;
+    float2* d_spec = nullptr;
+    RSMP_HIP_CHECK(hipMalloc(&d_spec, (h.fft_in + 1) * sizeof(float2)));
+    RSMP_HIP_CHECK(rsmp::launch_fft_filter_spectrum(d, d_time, d_spec, nullptr));
+    RSMP_HIP_CHECK(hipDeviceSynchronize());
+    RSMP_HIP_CHECK(hipFree(const_cast<float*>(d_time)));
+    d.filter = d_spec;
+    c.plans.emplace(key, p);
+    *out = p;
+    return RSMP_OK;
+}
+
+}  // namespace
+
+struct rsmp_fft {
+    int device = 0;
+    size_t channels = 0;
+    uint32_t in_hz = 0, out_hz = 0;
+    std::shared_ptr<DevicePlan> plan;
+    float* d_overlap = nullptr;   // [channels][fft_out], zero at construction (:81)
+    hipStream_t stream = nullptr;
+    hipEvent_t desc_copied = nullptr;
+    bool desc_pending = false;
+    PinnedBuffer h_desc;
+    DeviceBuffer d_desc;
+    DeviceBuffer d_stage_in, d_stage_out;
+    bool profiling = false;
+    hipEvent_t prof_start = nullptr, prof_stop = nullptr;
+    bool prof_valid = false;
+};
+
+namespace {
+
+struct FftJob {
+    rsmp_fft* r;
+    const float* d_in;
+    float* d_out;
+    size_t n_blocks;
+};
+
+int launch_fft_jobs(rsmp_fft* leader, const std::vector<FftJob>& jobs, hipStream_t stream) {
+    const size_t n = jobs.size();
+    const size_t bytes = n * sizeof(FftStreamDesc);
+    if (leader->desc_pending) {
+        RSMP_HIP_CHECK(hipEventSynchronize(leader->desc_copied));
+        leader->desc_pending = false;
+    }
+    RSMP_HIP_CHECK(leader->h_desc.reserve(bytes));
+    if (bytes > leader->d_desc.capacity()) {
+        RSMP_HIP_CHECK(hipStreamSynchronize(stream));
+        RSMP_HIP_CHECK(leader->d_desc.reserve(bytes));
+    }
+    FftStreamDesc* h = leader->h_desc.as<FftStreamDesc>();
+    uint32_t max_blocks = 0, max_channels = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const FftJob& j = jobs[i];
+        h[i].in = j.d_in;
+        h[i].out = j.d_out;
+        h[i].overlap = j.r->d_overlap;
+        h[i].n_blocks = static_cast<uint32_t>(j.n_blocks);
+        h[i].channels = static_cast<uint32_t>(j.r->channels);
+        if (h[i].n_blocks > max_blocks) max_blocks = h[i].n_blocks;
+        if (h[i].channels > max_channels) max_channels = h[i].channels;
+    }
+    RSMP_HIP_CHECK(hipMemcpyAsync(leader->d_desc.get(), h, bytes, hipMemcpyHostToDevice, stream));
+    RSMP_HIP_CHECK(hipEventRecord(leader->desc_copied, stream));
+    leader->desc_pending = true;
+    if (leader->profiling) RSMP_HIP_CHECK(hipEventRecord(leader->prof_start, stream));
+    RSMP_HIP_CHECK(rsmp::launch_fft_ola(leader->plan->dev, leader->d_desc.as<FftStreamDesc>(),
+                                        static_cast<uint32_t>(n), max_blocks, max_channels, stream));
+    if (leader->profiling) {
+        RSMP_HIP_CHECK(hipEventRecord(leader->prof_stop, stream));
+        leader->prof_valid = true;
+    }
+    return RSMP_OK;
+}
+
+int check_lds(const rsmp_fft* r) {
+    if (rsmp::fft_ola_lds_bytes(r->plan->dev, static_cast<uint32_t>(r->channels)) > 160 * 1024)
+        return rsmp::fail(RSMP_ERR_INVALID_ARGUMENT, "ResamplerFft: %zu channels of this block size exceed the LDS",
+                          r->channels);
+    return RSMP_OK;
+}
+
+}  // namespace
+
+// ================================ C ABI ==========================================================
+extern "C" rsmp_fft* rsmp_fft_new(size_t channels, int input_rate, int output_rate, int device) {
+    const uint32_t in_hz = rsmp_sample_rate_hz(input_rate), out_hz = rsmp_sample_rate_hz(output_rate);
+    if (!in_hz || !out_hz || channels == 0 || channels > 4096) {
+        rsmp::fail(RSMP_ERR_INVALID_ARGUMENT, "ResamplerFft::new: invalid channels / SampleRate");
+        return nullptr;
+    }
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) {
+        rsmp::fail(RSMP_ERR_NO_DEVICE, "ResamplerFft: no HIP device (this engine has no CPU path)");
+        return nullptr;
+    }
+    if (device < 0 || device >= n_dev) {
+        rsmp::fail(RSMP_ERR_INVALID_ARGUMENT, "ResamplerFft: device %d out of range", device);
+        return nullptr;
+    }
+    DeviceGuard guard(device);
+    std::unique_ptr<rsmp_fft> r(new rsmp_fft);
+    r->device = device;
+    r->channels = channels;
+    r->in_hz = in_hz;
+    r->out_hz = out_hz;
+    if (get_plan(device, in_hz, out_hz, &r->plan) != RSMP_OK) return nullptr;
+    if (check_lds(r.get()) != RSMP_OK) return nullptr;
+    const size_t ov_bytes = channels * r->plan->host.fft_out * sizeof(float);
+    if (hipMalloc(&r->d_overlap, ov_bytes) != hipSuccess || hipMemset(r->d_overlap, 0, ov_bytes) != hipSuccess ||
+        hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&r->desc_copied, hipEventDisableTiming) != hipSuccess) {
+        rsmp::fail(RSMP_ERR_HIP, "ResamplerFft: cannot allocate stream state");
+        if (r->d_overlap) (void)hipFree(r->d_overlap);
+        return nullptr;
+    }
+    return r.release();
+}
+
+extern "C" void rsmp_fft_free(rsmp_fft* r) {
+    if (!r) return;
+    DeviceGuard guard(r->device);
+    (void)hipDeviceSynchronize();
+    if (r->d_overlap) (void)hipFree(r->d_overlap);
+    if (r->desc_copied) (void)hipEventDestroy(r->desc_copied);
+    if (r->prof_start) (void)hipEventDestroy(r->prof_start);
+    if (r->prof_stop) (void)hipEventDestroy(r->prof_stop);
+    if (r->stream) (void)hipStreamDestroy(r->stream);
+    delete r;
+}
+
+extern "C" size_t rsmp_fft_chunk_size_input(const rsmp_fft* r) { return r->plan->host.fft_in * r->channels; }
+extern "C" size_t rsmp_fft_chunk_size_output(const rsmp_fft* r) { return r->plan->host.fft_out * r->channels; }
+extern "C" size_t rsmp_fft_delay(const rsmp_fft* r) { return r->plan->host.fft_in / 2; }
+extern "C" size_t rsmp_fft_channels(const rsmp_fft* r) { return r->channels; }
+
+extern "C" int rsmp_fft_set_profiling(rsmp_fft* r, int enable) {
+    DeviceGuard guard(r->device);
+    if (enable && !r->prof_start) {
+        RSMP_HIP_CHECK(hipEventCreate(&r->prof_start));
+        RSMP_HIP_CHECK(hipEventCreate(&r->prof_stop));
+    }
+    r->profiling = enable != 0;
+    r->prof_valid = false;
+    return RSMP_OK;
+}
+
+extern "C" int rsmp_fft_last_kernel_ms(rsmp_fft* r, float* ms) {
+    DeviceGuard guard(r->device);
+    if (!r->prof_valid || !ms)
+        return rsmp::fail(RSMP_ERR_INVALID_ARGUMENT, "rsmp_fft_last_kernel_ms: no profiled launch");
+    RSMP_HIP_CHECK(hipEventSynchronize(r->prof_stop));
+    RSMP_HIP_CHECK(hipEventElapsedTime(ms, r->prof_start, r->prof_stop));
+    return RSMP_OK;
+}
+
+// n_chunks consecutive chunks == n_chunks calls of ResamplerFft::resample (resampler_fft.rs:182-240).
+extern "C" int rsmp_fft_resample_bulk_device(rsmp_fft* r, const float* d_in, size_t in_len,
+                                             float* d_out, size_t out_len, size_t n_chunks,
+                                             void* stream) {
+    DeviceGuard guard(r->device);
+    if (n_chunks == 0) return RSMP_OK;
+    // :186-192 -- `>=`, extra values are ignored
+    if (in_len < n_chunks * rsmp_fft_chunk_size_input(r))
+        return rsmp::fail(RSMP_ERR_INVALID_INPUT_BUFFER_SIZE, "Input buffer size is invalid");
+    if (out_len < n_chunks * rsmp_fft_chunk_size_output(r))
+        return rsmp::fail(RSMP_ERR_INVALID_OUTPUT_BUFFER_SIZE, "Output buffer size is invalid");
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : r->stream;
+    std::vector<FftJob> jobs{FftJob{r, d_in, d_out, n_chunks}};
+    return launch_fft_jobs(r, jobs, s);
+}
+
+extern "C" int rsmp_fft_resample_device(rsmp_fft* r, const float* d_in, size_t in_len, float* d_out,
+                                        size_t out_len, void* stream) {
+    return rsmp_fft_resample_bulk_device(r, d_in, in_len, d_out, out_len, 1, stream);
+}
+
+extern "C" int rsmp_fft_resample_bulk(rsmp_fft* r, const float* in, size_t in_len, float* out,
+                                      size_t out_len, size_t n_chunks) {
+    DeviceGuard guard(r->device);
+    const size_t need_in = n_chunks * rsmp_fft_chunk_size_input(r);
+    const size_t need_out = n_chunks * rsmp_fft_chunk_size_output(r);
+    if (in_len < need_in)
+        return rsmp::fail(RSMP_ERR_INVALID_INPUT_BUFFER_SIZE, "Input buffer size is invalid");
+    if (out_len < need_out)
+        return rsmp::fail(RSMP_ERR_INVALID_OUTPUT_BUFFER_SIZE, "Output buffer size is invalid");
+    if (n_chunks == 0) return RSMP_OK;
+    RSMP_HIP_CHECK(hipStreamSynchronize(r->stream));
+    RSMP_HIP_CHECK(r->d_stage_in.reserve(need_in * sizeof(float)));
+    RSMP_HIP_CHECK(r->d_stage_out.reserve(need_out * sizeof(float)));
+    RSMP_HIP_CHECK(hipMemcpyAsync(r->d_stage_in.get(), in, need_in * sizeof(float),
+                                  hipMemcpyHostToDevice, r->stream));
+    const int rc = rsmp_fft_resample_bulk_device(r, r->d_stage_in.as<float>(), need_in,
+                                                 r->d_stage_out.as<float>(), need_out, n_chunks,
+                                                 r->stream);
+    if (rc != RSMP_OK) return rc;
+    RSMP_HIP_CHECK(hipMemcpyAsync(out, r->d_stage_out.get(), need_out * sizeof(float),
+                                  hipMemcpyDeviceToHost, r->stream));
+    RSMP_HIP_CHECK(hipStreamSynchronize(r->stream));
+    return RSMP_OK;
+}
+
+extern "C" int rsmp_fft_resample(rsmp_fft* r, const float* in, size_t in_len, float* out,
+                                 size_t out_len) {
+    return rsmp_fft_resample_bulk(r, in, in_len, out, out_len, 1);
+}
+
+extern "C" int rsmp_fft_batch_resample_bulk_device(rsmp_fft* const* rs, size_t n,
+                                                   const float* const* d_in, float* const* d_out,
+                                                   const size_t* n_chunks, void* stream) {
+    if (n == 0) return RSMP_OK;
+    if (!rs || !d_in || !d_out || !n_chunks)
+        return rsmp::fail(RSMP_ERR_INVALID_ARGUMENT, "rsmp_fft_batch_resample_bulk_device: null argument");
+    for (size_t i = 0; i < n; ++i)
+        if (!rs[i] || rs[i]->device != rs[0]->device || rs[i]->plan != rs[0]->plan)
+            return rsmp::fail(RSMP_ERR_INVALID_ARGUMENT,
+                              "batch streams must share one device and one rate pair");
+    DeviceGuard guard(rs[0]->device);
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : rs[0]->stream;
+    std::vector<FftJob> jobs;
+    jobs.reserve(n);
+    for (size_t i = 0; i < n; ++i) jobs.push_back(FftJob{rs[i], d_in[i], d_out[i], n_chunks[i]});
+    return launch_fft_jobs(rs[0], jobs, s);
+}

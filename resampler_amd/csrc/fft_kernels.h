@@ -1,0 +1,49 @@
+// fft_kernels.h -- device-side descriptors and launch wrappers of the FFT overlap-add path.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace rsmp {
+
+constexpr int kMaxFftStages = 8;
+
+// Device image of one FftResamplerPlan (fft_plan.h).  All pointers are HBM pointers.
+struct FftPlanDev {
+    uint32_t fft_in, fft_out;            // frames per block = complex FFT lengths (N/2 trick)
+    uint32_t n_stages_f, n_stages_i;
+    uint32_t radix_f[kMaxFftStages], radix_i[kMaxFftStages];
+    uint32_t tw_off_f[kMaxFftStages], tw_off_i[kMaxFftStages];
+    const float2* tw_f;                  // forward stage twiddles (unique per column)
+    const float2* tw_i;                  // inverse stage twiddles
+    const float2* rc_f;                  // real-FFT expansion twiddles (x0.5)
+    const float2* rc_i;                  // real-FFT reduction twiddles (conjugated)
+    uint32_t n_rc_f, n_rc_i;
+    const float2* filter;                // fft_in + 1 bins
+    uint32_t new_length;                 // bins multiplied by the filter, the rest are zero
+    uint32_t lds_complex;                // max(fft_in, fft_out) + 1
+};
+
+// One stream's share of a launch: n_blocks consecutive blocks of all its channels.
+struct FftStreamDesc {
+    const float* in;      // interleaved, n_blocks * fft_in * channels values
+    float* out;           // interleaved, n_blocks * fft_out * channels values
+    float* overlap;       // stream state: [channels][fft_out] (resampler_fft.rs:51)
+    uint32_t n_blocks;
+    uint32_t channels;
+};
+
+// Blocks a workgroup walks in sequence (carrying the overlap on chip); the first block of a run
+// that does not start the launch recomputes its predecessor as halo.
+constexpr uint32_t kFftRun = 16;
+
+hipError_t launch_fft_ola(const FftPlanDev& plan, const FftStreamDesc* d_descs, uint32_t n_streams,
+                          uint32_t max_blocks, uint32_t max_channels, hipStream_t stream);
+// filter_spectrum[0 .. fft_in] = forward real FFT of d_filter_time[0 .. 2*fft_in)
+// (resampler_fft.rs:375-376); plan.filter is ignored.
+hipError_t launch_fft_filter_spectrum(const FftPlanDev& plan, const float* d_filter_time,
+                                      float2* d_filter_spectrum, hipStream_t stream);
+size_t fft_ola_lds_bytes(const FftPlanDev& plan, uint32_t channels);
+
+}  // namespace rsmp

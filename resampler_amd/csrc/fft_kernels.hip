@@ -1,0 +1,336 @@
+// fft_kernels.hip -- ResamplerFft block pipeline for gfx950, entirely in LDS.
+//
+// Replaces FftResampler::resample (src/resampler_fft.rs:385-424) and everything below it:
+// RadixFFT::process forward / inverse (src/fft/radix_fft.rs:476-670), the Stockham stage loop
+// (src/fft/stockham_autosort.rs:169-247), the radix-2/3/4/5/7/8 butterflies
+// (src/fft/butterflies/butterflyN/mod.rs, scalar specs) and the real<->complex passes
+// (src/fft/real_complex/mod.rs:37-114), plus the deinterleave / interleave copies of
+// ResamplerFft::resample (resampler_fft.rs:197-202, :232-237), which disappear into the first
+// load and the last store.
+//
+// One workgroup = one stream x a run of consecutive blocks; per block and channel:
+//   load (zero padded, 2 reals = 1 complex) -> forward Stockham stages ping-ponging between two
+//   LDS arrays -> real-FFT post-process -> x filter spectrum, truncate / zero-extend ->
+//   inverse-real pre-process + conjugate -> inverse Stockham stages -> conjugate, overlap-add with
+//   the carry kept in LDS, interleaved store.
+// HBM traffic is the algorithmic minimum: fft_in reads + fft_out writes per block-channel (the
+// overlap row only at the ends of a launch); twiddles and the filter spectrum (~30 KB) stay in L2.
+// Channels are computed independently (what the reference yields per channel when its scratch
+// regions do not collide).
+#include "fft_kernels.h"
+
+namespace rsmp {
+
+namespace {
+
+constexpr int kFftThreads = 256;
+
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+// Complex32::mul (fft/mod.rs:52-57)
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+    return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+
+// r-point DFT of t[0..R) (t[0] untwiddled), scalar-spec arithmetic of butterflyN/mod.rs.
+template <int R> __device__ __forceinline__ void dft(const float2 (&t)[R], float2 (&o)[R]);
+
+template <> __device__ __forceinline__ void dft<2>(const float2 (&t)[2], float2 (&o)[2]) {
+    o[0] = cadd(t[0], t[1]);                                   // butterfly2/mod.rs:263-265
+    o[1] = csub(t[0], t[1]);
+}
+template <> __device__ __forceinline__ void dft<3>(const float2 (&t)[3], float2 (&o)[3]) {
+    const float SQRT3_2 = 0.8660254f;                          // butterfly3/mod.rs:47
+    const float2 sum_t = cadd(t[1], t[2]), diff_t = csub(t[1], t[2]);
+    o[0] = cadd(t[0], sum_t);
+    const float re_part = t[0].x - 0.5f * sum_t.x, im_part = t[0].y - 0.5f * sum_t.y;
+    const float sre = SQRT3_2 * diff_t.y, sim = -SQRT3_2 * diff_t.x;
+    o[1] = make_float2(re_part + sre, im_part + sim);
+    o[2] = make_float2(re_part - sre, im_part - sim);
+}
+template <> __device__ __forceinline__ void dft<4>(const float2 (&t)[4], float2 (&o)[4]) {
+    const float2 a0 = cadd(t[0], t[2]), a1 = csub(t[0], t[2]), a2 = cadd(t[1], t[3]);   // butterfly4/mod.rs:309-320
+    const float a3_re = t[1].y - t[3].y, a3_im = t[3].x - t[1].x;
+    o[0] = cadd(a0, a2);
+    o[2] = csub(a0, a2);
+    o[1] = make_float2(a1.x + a3_re, a1.y + a3_im);
+    o[3] = make_float2(a1.x - a3_re, a1.y - a3_im);
+}
+template <> __device__ __forceinline__ void dft<5>(const float2 (&t)[5], float2 (&o)[5]) {
+    const float C1 = 0.309017f, S1 = 0.95105654f, C2 = -0.809017f, S2 = 0.58778524f;   // butterfly5/mod.rs:47-50
+    const float2 sum_all = cadd(cadd(cadd(t[1], t[2]), t[3]), t[4]);
+    const float2 a1 = cadd(t[1], t[4]), a2 = cadd(t[2], t[3]);
+    const float b1_re = t[1].y - t[4].y, b1_im = t[4].x - t[1].x;
+    const float b2_re = t[2].y - t[3].y, b2_im = t[3].x - t[2].x;
+    const float c1_re = t[0].x + C1 * a1.x + C2 * a2.x, c1_im = t[0].y + C1 * a1.y + C2 * a2.y;
+    const float c2_re = t[0].x + C2 * a1.x + C1 * a2.x, c2_im = t[0].y + C2 * a1.y + C1 * a2.y;
+    const float d1_re = S1 * b1_re + S2 * b2_re, d1_im = S1 * b1_im + S2 * b2_im;
+    const float d2_re = S2 * b1_re - S1 * b2_re, d2_im = S2 * b1_im - S1 * b2_im;
+    o[0] = cadd(t[0], sum_all);
+    o[1] = make_float2(c1_re + d1_re, c1_im + d1_im);
+    o[2] = make_float2(c2_re + d2_re, c2_im + d2_im);
+    o[3] = make_float2(c2_re - d2_re, c2_im - d2_im);
+    o[4] = make_float2(c1_re - d1_re, c1_im - d1_im);
+}
+template <> __device__ __forceinline__ void dft<7>(const float2 (&t)[7], float2 (&o)[7]) {
+    const float C[3] = {0.6234898f, -0.22252093f, -0.90096885f};   // butterfly7/mod.rs:47-52
+    const float S[3] = {0.7818315f, 0.9749279f, 0.43388373f};
+    const float2 sum_all = cadd(cadd(cadd(cadd(cadd(t[1], t[2]), t[3]), t[4]), t[5]), t[6]);
+    const float2 a1 = cadd(t[1], t[6]), a2 = cadd(t[2], t[5]), a3 = cadd(t[3], t[4]);
+    const float b1_re = t[1].y - t[6].y, b1_im = t[6].x - t[1].x;
+    const float b2_re = t[2].y - t[5].y, b2_im = t[5].x - t[2].x;
+    const float b3_re = t[3].y - t[4].y, b3_im = t[4].x - t[3].x;
+    o[0] = cadd(t[0], sum_all);
+    // (cos1, sin1, cos2, sin2, cos3, sin3) per output, butterfly7/mod.rs:416-436
+#define RSMP_R7(idx, c1, s1, c2, s2, c3, s3)                                                     \
+    {                                                                                            \
+        const float c_re = t[0].x + (c1) * a1.x + (c2) * a2.x + (c3) * a3.x;                     \
+        const float c_im = t[0].y + (c1) * a1.y + (c2) * a2.y + (c3) * a3.y;                     \
+        const float d_re = (s1) * b1_re + (s2) * b2_re + (s3) * b3_re;                           \
+        const float d_im = (s1) * b1_im + (s2) * b2_im + (s3) * b3_im;                           \
+        o[idx] = make_float2(c_re + d_re, c_im + d_im);                                          \
+    }
+    RSMP_R7(1, C[0], S[0], C[1], S[1], C[2], S[2])
+    RSMP_R7(2, C[1], S[1], C[2], -S[2], C[0], -S[0])
+    RSMP_R7(3, C[2], S[2], C[0], -S[0], C[1], S[1])
+    RSMP_R7(4, C[2], -S[2], C[0], S[0], C[1], -S[1])
+    RSMP_R7(5, C[1], -S[1], C[2], S[2], C[0], S[0])
+    RSMP_R7(6, C[0], -S[0], C[1], -S[1], C[2], -S[2])
+#undef RSMP_R7
+}
+template <> __device__ __forceinline__ void dft<8>(const float2 (&t)[8], float2 (&o)[8]) {
+    const float H = 0.70710678118654752440f;                   // butterfly8/mod.rs:299
+    const float2 ea0 = cadd(t[0], t[4]), ea1 = csub(t[0], t[4]), ea2 = cadd(t[2], t[6]);
+    const float ea3_re = t[2].y - t[6].y, ea3_im = t[6].x - t[2].x;
+    const float2 xe0 = cadd(ea0, ea2), xe2 = csub(ea0, ea2);
+    const float2 xe1 = make_float2(ea1.x + ea3_re, ea1.y + ea3_im);
+    const float2 xe3 = make_float2(ea1.x - ea3_re, ea1.y - ea3_im);
+    const float2 oa0 = cadd(t[1], t[5]), oa1 = csub(t[1], t[5]), oa2 = cadd(t[3], t[7]);
+    const float oa3_re = t[3].y - t[7].y, oa3_im = t[7].x - t[3].x;
+    const float2 xo0 = cadd(oa0, oa2), xo2 = csub(oa0, oa2);
+    const float2 xo1 = make_float2(oa1.x + oa3_re, oa1.y + oa3_im);
+    const float2 xo3 = make_float2(oa1.x - oa3_re, oa1.y - oa3_im);
+    o[0] = cadd(xe0, xo0);
+    o[4] = csub(xe0, xo0);
+    const float2 w1 = make_float2(H * (xo1.x + xo1.y), H * (xo1.y - xo1.x));
+    o[1] = cadd(xe1, w1);
+    o[5] = csub(xe1, w1);
+    const float2 w2 = make_float2(xo2.y, -xo2.x);
+    o[2] = cadd(xe2, w2);
+    o[6] = csub(xe2, w2);
+    const float2 w3 = make_float2(H * (xo3.y - xo3.x), -H * (xo3.x + xo3.y));
+    o[3] = cadd(xe3, w3);
+    o[7] = csub(xe3, w3);
+}
+
+// One out-of-place Stockham stage: butterfly i reads src[i + q*m], twiddles inputs 1..R-1 with
+// w[(i mod stride)*(R-1) + q-1] (none when stride == 1) and writes dst[R*i - (R-1)*k + q*stride]
+// (butterfly4/mod.rs:316-320 etc.).
+template <int R>
+__device__ __forceinline__ void stage(const float2* __restrict__ src, float2* __restrict__ dst,
+                                      uint32_t n, uint32_t stride, const float2* __restrict__ tw) {
+    const uint32_t m = n / R;
+    for (uint32_t i = threadIdx.x; i < m; i += kFftThreads) {
+        const uint32_t k = stride == 1 ? 0u : i % stride;
+        float2 t[R], o[R];
+#pragma unroll
+        for (int q = 0; q < R; ++q) t[q] = src[i + q * m];
+        if (stride != 1) {
+            const float2* w = tw + k * (R - 1);
+#pragma unroll
+            for (int q = 1; q < R; ++q) t[q] = cmul(w[q - 1], t[q]);
+        }
+        dft<R>(t, o);
+        float2* d = dst + R * i - (R - 1) * k;
+#pragma unroll
+        for (int q = 0; q < R; ++q) d[q * stride] = o[q];
+    }
+}
+
+// stockham_autosort (stockham_autosort.rs:169-247): returns the buffer holding the result.
+__device__ float2* stockham(float2* a, float2* b, uint32_t n, uint32_t n_stages,
+                            const uint32_t* radix, const uint32_t* tw_off,
+                            const float2* __restrict__ tw) {
+    uint32_t stride = 1;
+    for (uint32_t s = 0; s < n_stages; ++s) {
+        const uint32_t r = radix[s];
+        const float2* w = tw + tw_off[s];
+        switch (r) {
+            case 2: stage<2>(a, b, n, stride, w); break;
+            case 3: stage<3>(a, b, n, stride, w); break;
+            case 4: stage<4>(a, b, n, stride, w); break;
+            case 5: stage<5>(a, b, n, stride, w); break;
+            case 7: stage<7>(a, b, n, stride, w); break;
+            default: stage<8>(a, b, n, stride, w); break;
+        }
+        __syncthreads();
+        float2* tmp = a; a = b; b = tmp;
+        stride *= r;
+    }
+    return a;
+}
+
+// postprocess_fft (radix_fft.rs:500-537 + real_complex/mod.rs:37-74), in place on x[0 .. n2].
+__device__ void postprocess_forward(float2* x, uint32_t n2, const float2* __restrict__ rc, uint32_t n_rc) {
+    const uint32_t len = n2 + 1, split = len / 2;
+    uint32_t iters = split - 1;                       // left middle
+    const uint32_t rm_len = len - split - 1;          // right middle
+    if (rm_len < iters) iters = rm_len;
+    if (n_rc < iters) iters = n_rc;
+    if (threadIdx.x == 0) {
+        const float2 z0 = x[0];
+        x[0] = make_float2(z0.x + z0.y, 0.0f);
+        x[n2] = make_float2(z0.x - z0.y, 0.0f);
+    }
+    for (uint32_t i = threadIdx.x; i < iters; i += kFftThreads) {
+        const uint32_t l = 1 + i, rr = n2 - 1 - i;
+        const float2 o = x[l], orv = x[rr], tw = rc[i];
+        const float2 sum = cadd(o, orv), diff = csub(o, orv);
+        const float half_sum_real = 0.5f * sum.x, half_diff_imag = 0.5f * diff.y;
+        const float real = sum.y * tw.x + diff.x * tw.y;
+        const float imag = sum.y * tw.y - diff.x * tw.x;
+        x[l] = make_float2(half_sum_real + real, half_diff_imag + imag);
+        x[rr] = make_float2(half_sum_real - real, imag - half_diff_imag);
+    }
+    if ((len & 1u) && threadIdx.x == 32) x[len / 2].y = -x[len / 2].y;
+}
+
+// preprocess_ifft (radix_fft.rs:592-624 + real_complex/mod.rs:84-114) followed by the input
+// conjugation of process_inverse_complex (:634-637), in place on y[0 .. n2].
+__device__ void preprocess_inverse(float2* y, uint32_t n2, const float2* __restrict__ rc, uint32_t n_rc) {
+    const uint32_t len = n2 + 1, split = len / 2;
+    uint32_t iters = split - 1;
+    const uint32_t rm_len = len - split - 1;
+    if (rm_len < iters) iters = rm_len;
+    if (n_rc < iters) iters = n_rc;
+    if (threadIdx.x == 0) {
+        const float2 a = y[0], b = y[n2];
+        const float2 first_sum = cadd(a, b), first_diff = csub(a, b);
+        y[0] = make_float2(first_sum.x - first_sum.y, first_diff.x - first_diff.y);
+    }
+    for (uint32_t i = threadIdx.x; i < iters; i += kFftThreads) {
+        const uint32_t l = 1 + i, rr = n2 - 1 - i;
+        const float2 a = y[l], b = y[rr], tw = rc[i];
+        const float2 sum = cadd(a, b), diff = csub(a, b);
+        const float real = sum.y * tw.x + diff.x * tw.y;
+        const float imag = sum.y * tw.y - diff.x * tw.x;
+        y[l] = make_float2(sum.x - real, diff.y - imag);
+        y[rr] = make_float2(sum.x + real, -imag - diff.y);
+    }
+    if ((len & 1u) && threadIdx.x == 32) {
+        const float2 c = y[len / 2];
+        const float2 dbl = cadd(c, c);
+        y[len / 2] = make_float2(dbl.x, -dbl.y);
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < n2; i += kFftThreads) y[i].y = -y[i].y;
+}
+
+__global__ __launch_bounds__(kFftThreads) void fft_ola_kernel(FftPlanDev plan,
+                                                              const FftStreamDesc* __restrict__ descs) {
+    extern __shared__ __attribute__((aligned(16))) float2 lds2[];
+    const FftStreamDesc d = descs[blockIdx.y];
+    const uint32_t first = blockIdx.x * kFftRun;
+    if (first >= d.n_blocks) return;
+    const uint32_t last = first + kFftRun < d.n_blocks ? first + kFftRun : d.n_blocks;  // exclusive
+    const uint32_t C = d.channels, fi = plan.fft_in, fo = plan.fft_out;
+    float2* bufA = lds2;
+    float2* bufB = lds2 + plan.lds_complex;
+    float* carry = reinterpret_cast<float*>(lds2 + 2 * plan.lds_complex);   // [C][fo]
+
+    // overlap carried into the run: the stream state, or the predecessor block recomputed
+    if (first == 0)
+        for (uint32_t e = threadIdx.x; e < C * fo; e += kFftThreads) carry[e] = d.overlap[e];
+    const int64_t b_begin = first == 0 ? 0 : static_cast<int64_t>(first) - 1;
+    __syncthreads();
+
+    for (int64_t b = b_begin; b < static_cast<int64_t>(last); ++b) {
+        const bool emit = b >= static_cast<int64_t>(first);
+        const float* __restrict__ xin = d.in + static_cast<size_t>(b) * fi * C;
+        float* __restrict__ xout = d.out + static_cast<size_t>(b) * fo * C;
+        for (uint32_t c = 0; c < C; ++c) {
+            // resampler_fft.rs:387-388: fi reals + fi zeros, viewed as fi complexes (radix_fft.rs:552-554)
+            for (uint32_t i = threadIdx.x; i < fi; i += kFftThreads) {
+                float2 v = make_float2(0.f, 0.f);
+                if (2 * i + 1 < fi) v = make_float2(xin[(2 * i) * C + c], xin[(2 * i + 1) * C + c]);
+                else if (2 * i < fi) v = make_float2(xin[(2 * i) * C + c], 0.f);
+                bufA[i] = v;
+            }
+            __syncthreads();
+            float2* X = stockham(bufA, bufB, fi, plan.n_stages_f, plan.radix_f, plan.tw_off_f, plan.tw_f);
+            float2* Y = X == bufA ? bufB : bufA;
+            postprocess_forward(X, fi, plan.rc_f, plan.n_rc_f);
+            __syncthreads();
+            // resampler_fft.rs:401-408: multiply new_length bins, zero the rest up to fo
+            for (uint32_t k = threadIdx.x; k <= fo; k += kFftThreads)
+                Y[k] = k < plan.new_length ? cmul(X[k], plan.filter[k]) : make_float2(0.f, 0.f);
+            __syncthreads();
+            preprocess_inverse(Y, fo, plan.rc_i, plan.n_rc_i);
+            __syncthreads();
+            float2* Z = stockham(Y, X, fo, plan.n_stages_i, plan.radix_i, plan.tw_off_i, plan.tw_i);
+            // output conjugation (radix_fft.rs:656-669), reals 2i, 2i+1 <- Z[i]; overlap-add (:416-423)
+            float* ov = carry + c * fo;
+            if (emit)
+                for (uint32_t t = threadIdx.x; t < fo; t += kFftThreads) {
+                    const float2 z = Z[t >> 1];
+                    const float y = (t & 1u) ? -z.y : z.x;
+                    xout[t * C + c] = y + ov[t];
+                }
+            __syncthreads();
+            for (uint32_t t = threadIdx.x; t < fo; t += kFftThreads) {
+                const float2 z = Z[(t + fo) >> 1];
+                ov[t] = ((t + fo) & 1u) ? -z.y : z.x;
+            }
+            __syncthreads();
+        }
+    }
+    if (last == d.n_blocks)
+        for (uint32_t e = threadIdx.x; e < C * fo; e += kFftThreads) d.overlap[e] = carry[e];
+}
+
+__global__ __launch_bounds__(kFftThreads) void fft_filter_kernel(FftPlanDev plan,
+                                                                 const float* __restrict__ filter_time,
+                                                                 float2* __restrict__ spectrum) {
+    extern __shared__ __attribute__((aligned(16))) float2 lds2[];
+    float2* bufA = lds2;
+    float2* bufB = lds2 + plan.lds_complex;
+    const uint32_t fi = plan.fft_in;
+    for (uint32_t i = threadIdx.x; i < fi; i += kFftThreads)
+        bufA[i] = make_float2(filter_time[2 * i], filter_time[2 * i + 1]);
+    __syncthreads();
+    float2* X = stockham(bufA, bufB, fi, plan.n_stages_f, plan.radix_f, plan.tw_off_f, plan.tw_f);
+    postprocess_forward(X, fi, plan.rc_f, plan.n_rc_f);
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k <= fi; k += kFftThreads) spectrum[k] = X[k];
+}
+
+}  // namespace
+
+size_t fft_ola_lds_bytes(const FftPlanDev& plan, uint32_t channels) {
+    return 2 * static_cast<size_t>(plan.lds_complex) * sizeof(float2) +
+           static_cast<size_t>(channels) * plan.fft_out * sizeof(float);
+}
+
+hipError_t launch_fft_ola(const FftPlanDev& plan, const FftStreamDesc* d_descs, uint32_t n_streams,
+                          uint32_t max_blocks, uint32_t max_channels, hipStream_t stream) {
+    if (n_streams == 0 || max_blocks == 0) return hipSuccess;
+    const size_t lds = fft_ola_lds_bytes(plan, max_channels);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fft_ola_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+    }
+    const dim3 grid((max_blocks + kFftRun - 1) / kFftRun, n_streams);
+    hipLaunchKernelGGL(fft_ola_kernel, grid, dim3(kFftThreads), lds, stream, plan, d_descs);
+    return hipGetLastError();
+}
+
+hipError_t launch_fft_filter_spectrum(const FftPlanDev& plan, const float* d_filter_time,
+                                      float2* d_filter_spectrum, hipStream_t stream) {
+    const size_t lds = 2 * static_cast<size_t>(plan.lds_complex) * sizeof(float2);
+    hipLaunchKernelGGL(fft_filter_kernel, dim3(1), dim3(kFftThreads), lds, stream, plan,
+                       d_filter_time, d_filter_spectrum);
+    return hipGetLastError();
+}
+
+}  // namespace rsmp

@@ -1,0 +1,164 @@
+"""FFT path: host-side planning parity (CPU) and GPU parity of ResamplerFft against the oracle.
+Gate (BASELINE.json north_star): output within 1e-6 RMS of the CPU path."""
+import itertools
+
+import numpy as np
+import pytest
+
+import resampler_amd as ra
+from oracle import pyoracle as o
+from resampler_amd import synth
+
+RMS_TOL = 1e-6
+RATES = [22050, 16000, 32000, 44100, 48000, 88200, 96000, 176400, 192000, 384000]
+
+
+def rms(a, b):
+    return float(np.sqrt(np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2)))
+
+
+def sr(hz):
+    return ra.SampleRate(RATES.index(hz))
+
+
+# ---- CPU: planning ------------------------------------------------------------------------------
+def test_plan_matches_oracle_for_every_rate_pair():
+    for i, out in itertools.product(RATES, RATES):
+        fi, fo, a, b = o.fft_plan(i, out)
+        mi, mo, fwd, inv = ra.fft_plan_sizes(i, out)
+        assert (mi, mo) == (fi, fo)
+        assert fwd == o.OracleRfft(a + [2]).stage_factors()
+        assert inv == o.OracleRfft(b + [2], inverse=True).stage_factors()
+    assert ra.fft_plan_sizes(44100, 48000) == (1176, 1280, [3, 7, 7, 8], [4, 5, 8, 8])
+    with pytest.raises(ra.ResampleError):
+        ra.fft_plan_sizes(24000, 48000)
+
+
+# ---- GPU ----------------------------------------------------------------------------------------
+def consistent(ch, in_hz, out_hz):
+    """Rate pairs / channel counts where the reference's per-channel scratch regions do not collide
+    (SURVEY 7.3 item 6): channel c's block lives at c*fft_in*(ch+1) in a scratch of
+    fft_out*(ch+1)*ch values."""
+    fi, fo, _, _ = o.fft_plan(in_hz, out_hz)
+    stride = fi * (ch + 1)
+    return ch == 1 or (fo <= stride and (ch - 1) * stride + fo <= fo * (ch + 1) * ch)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ch,in_hz,out_hz", [
+    (2, 44100, 48000),      # BASELINE config 3
+    (2, 48000, 44100),
+    (1, 48000, 32000),
+    (1, 32000, 48000),
+    (1, 96000, 48000),
+    (2, 48000, 96000),
+    (1, 16000, 44100),
+    (1, 22050, 16000),
+    (3, 44100, 48000),
+    (1, 44100, 44100),
+    (1, 22050, 48000),
+    (2, 88200, 96000),
+])
+def test_per_call_resample_matches_oracle(ch, in_hz, out_hz):
+    assert consistent(ch, in_hz, out_hz)
+    g = ra.ResamplerFft.new(ch, sr(in_hz), sr(out_hz))
+    r = o.OracleFft(ch, in_hz, out_hz)
+    n_in, n_out = g.chunk_size_input(), g.chunk_size_output()
+    assert (n_in, n_out, g.delay()) == (r.chunk_size_input(), r.chunk_size_output(), r.delay())
+    blocks = 6
+    x = synth.sweep(blocks * n_in // ch, ch, float(in_hz))
+    og = np.zeros(n_out, np.float32)
+    orr = np.zeros(n_out, np.float32)
+    for b in range(blocks):
+        g.resample(x[b * n_in:(b + 1) * n_in], og)
+        assert r.resample(x[b * n_in:(b + 1) * n_in], orr) == 0
+        assert rms(og, orr) <= RMS_TOL, b
+
+
+@pytest.mark.gpu
+def test_error_codes_and_oversized_buffers():
+    g = ra.ResamplerFft.new(2, ra.SampleRate.Hz44100, ra.SampleRate.Hz48000)
+    r = o.OracleFft(2, 44100, 48000)
+    out = np.zeros(2560, np.float32)
+    with pytest.raises(ra.InvalidInputBufferSize):
+        g.resample(np.zeros(2351, np.float32), out)
+    with pytest.raises(ra.InvalidOutputBufferSize):
+        g.resample(np.zeros(2352, np.float32), out[:2559])
+    # `>=` is enough; extra values are ignored (resampler_fft.rs:186-192)
+    x = synth.fast_noise(3000, seed=4)
+    og = np.zeros(3000, np.float32)
+    orr = np.zeros(3000, np.float32)
+    g.resample(x, og)
+    assert r.resample(x, orr) == 0
+    assert rms(og[:2560], orr[:2560]) <= RMS_TOL and not og[2560:].any()
+    with pytest.raises((ValueError, ra.ResampleError)):
+        ra.ResamplerFft(2, 99, 4)
+    assert not ra.lib().rsmp_fft_new(2, 99, 4, 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ch,in_hz,out_hz,blocks", [(2, 44100, 48000, 37), (1, 48000, 44100, 50),
+                                                    (2, 48000, 96000, 20)])
+def test_bulk_equals_consecutive_calls(ch, in_hz, out_hz, blocks):
+    g = ra.ResamplerFft.new(ch, sr(in_hz), sr(out_hz))
+    r = o.OracleFft(ch, in_hz, out_hz)
+    n_in, n_out = g.chunk_size_input(), g.chunk_size_output()
+    x = synth.fast_noise(blocks * n_in, seed=blocks)
+    # a few per-call chunks first so the bulk launch starts from a non-zero overlap
+    og = np.zeros(n_out, np.float32)
+    ref = np.zeros((blocks, n_out), np.float32)
+    for b in range(blocks):
+        assert r.resample(x[b * n_in:(b + 1) * n_in], ref[b]) == 0
+    for b in range(3):
+        g.resample(x[b * n_in:(b + 1) * n_in], og)
+        assert rms(og, ref[b]) <= RMS_TOL
+    y = g.resample_bulk(x[3 * n_in:], blocks - 3)     # > kFftRun blocks: exercises the halo recompute
+    assert rms(y, ref[3:].reshape(-1)) <= RMS_TOL
+    assert float(np.max(np.abs(y - ref[3:].reshape(-1)))) < 1e-5
+
+
+@pytest.mark.gpu
+def test_c3_full_size_and_batch_device_api():
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda:0")
+    # BASELINE config 3: 2 ch 44100 -> 48000, 892 blocks of 1176 frames (~2^20 frames).
+    blocks = 892
+    n_streams = 3
+    gs = [ra.ResamplerFft.new(2, ra.SampleRate.Hz44100, ra.SampleRate.Hz48000) for _ in range(n_streams)]
+    n_in, n_out = gs[0].chunk_size_input(), gs[0].chunk_size_output()
+    xs = [synth.sweep(blocks * n_in // 2, 2, 44100.0) * np.float32(1.0 - 0.1 * i) for i in range(n_streams)]
+    d_in = [torch.from_numpy(x).to(dev) for x in xs]
+    d_out = [torch.zeros(blocks * n_out, device=dev) for _ in range(n_streams)]
+    batch = ra.FftBatch(gs)
+    batch.bind(d_in, d_out, [blocks] * n_streams)
+    batch.resample_bulk_device(torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    for i in range(n_streams):
+        r = o.OracleFft(2, 44100, 48000)
+        ref = np.zeros((blocks, n_out), np.float32)
+        for b in range(blocks):
+            assert r.resample(xs[i][b * n_in:(b + 1) * n_in], ref[b]) == 0
+        assert rms(d_out[i].cpu().numpy(), ref.reshape(-1)) <= RMS_TOL
+
+
+@pytest.mark.gpu
+def test_reference_amplitude_properties_on_gpu():
+    # resampler_fft.rs:439-566 run against the GPU path itself.
+    for in_hz, out_hz in [(48000, 44100), (44100, 48000), (48000, 32000), (32000, 48000),
+                          (96000, 48000), (48000, 96000)]:
+        g = ra.ResamplerFft.new(1, sr(in_hz), sr(out_hz))
+        x = np.full(g.chunk_size_input(), 0.5, np.float32)
+        out = np.zeros(g.chunk_size_output(), np.float32)
+        for _ in range(5):
+            g.resample(x, out)
+        start = min(g.delay(), out.size // 4)
+        assert np.abs(out[start:out.size * 3 // 4] - 0.5).max() < 0.02
+    g = ra.ResamplerFft.new(2, ra.SampleRate.Hz48000, ra.SampleRate.Hz44100)
+    x = np.zeros(g.chunk_size_input(), np.float32)
+    x[0::2], x[1::2] = 0.3, 0.6
+    out = np.zeros(g.chunk_size_output(), np.float32)
+    for _ in range(5):
+        g.resample(x, out)
+    start = min(g.delay(), out.size // 8) * 2
+    end = out.size * 3 // 4
+    assert np.abs(out[start:end:2] - 0.3).max() < 0.02 and np.abs(out[start + 1:end:2] - 0.6).max() < 0.02
