@@ -1,0 +1,154 @@
+//! Drop-in replacement for the public API of hasenbanck/resampler v0.5.1 (`ResamplerFir`,
+//! `ResamplerFft`, `SampleRate`, `Latency`, `Attenuation`, `ResampleError`; reference
+//! src/lib.rs:160-188) on top of the C ABI of libresampler_amd.so (include/resampler_amd.h).
+//!
+//! SOURCE ONLY -- never compiled in the build image (no rustc).  Same names, argument meaning and
+//! error behaviour as the reference; where the reference panics (zero rates) this shim panics too.
+use std::os::raw::{c_int, c_void};
+
+#[derive(Copy, Clone, Hash, PartialEq, Eq, PartialOrd, Ord, Debug)]
+pub enum ResampleError {
+    InvalidInputBufferSize,
+    InvalidOutputBufferSize,
+}
+
+impl core::fmt::Display for ResampleError {
+    fn fmt(&self, f: &mut core::fmt::Formatter<'_>) -> core::fmt::Result {
+        match self {
+            Self::InvalidInputBufferSize => "Input buffer size is invalid".fmt(f),
+            Self::InvalidOutputBufferSize => "Output buffer size is invalid".fmt(f),
+        }
+    }
+}
+impl std::error::Error for ResampleError {}
+
+/// Same variant order as the reference (src/lib.rs:167-188) == RSMP_HZ* of the C ABI.
+#[repr(i32)]
+#[derive(Debug, Copy, Clone, PartialOrd, PartialEq, Ord, Eq, Hash)]
+pub enum SampleRate {
+    Hz22050 = 0, Hz16000, Hz32000, Hz44100, Hz48000, Hz88200, Hz96000, Hz176400, Hz192000, Hz384000,
+}
+
+#[repr(i32)]
+#[derive(Default, Debug, Copy, Clone, PartialEq, Eq, Hash)]
+pub enum Latency { Sample8 = 0, Sample16, Sample32, #[default] Sample64 }
+
+#[repr(i32)]
+#[derive(Default, Debug, Copy, Clone, PartialEq, Eq, Hash)]
+pub enum Attenuation { Db60 = 0, Db90, #[default] Db120 }
+
+#[allow(non_camel_case_types)]
+type rsmp_fir = c_void;
+#[allow(non_camel_case_types)]
+type rsmp_fft = c_void;
+
+extern "C" {
+    fn rsmp_fir_new(channels: usize, input_rate: c_int, output_rate: c_int, latency: c_int,
+                    attenuation: c_int, device: c_int) -> *mut rsmp_fir;
+    fn rsmp_fir_new_from_hz(channels: usize, in_hz: u32, out_hz: u32, latency: c_int,
+                            attenuation: c_int, device: c_int) -> *mut rsmp_fir;
+    fn rsmp_fir_free(r: *mut rsmp_fir);
+    fn rsmp_fir_buffer_size_output(r: *const rsmp_fir) -> usize;
+    fn rsmp_fir_delay(r: *const rsmp_fir) -> usize;
+    fn rsmp_fir_reset(r: *mut rsmp_fir);
+    fn rsmp_fir_resample(r: *mut rsmp_fir, input: *const f32, in_len: usize, output: *mut f32,
+                         out_len: usize, consumed: *mut usize, produced: *mut usize) -> c_int;
+    fn rsmp_fft_new(channels: usize, input_rate: c_int, output_rate: c_int, device: c_int) -> *mut rsmp_fft;
+    fn rsmp_fft_free(r: *mut rsmp_fft);
+    fn rsmp_fft_chunk_size_input(r: *const rsmp_fft) -> usize;
+    fn rsmp_fft_chunk_size_output(r: *const rsmp_fft) -> usize;
+    fn rsmp_fft_delay(r: *const rsmp_fft) -> usize;
+    fn rsmp_fft_resample(r: *mut rsmp_fft, input: *const f32, in_len: usize, output: *mut f32,
+                         out_len: usize) -> c_int;
+    fn rsmp_last_error() -> *const std::os::raw::c_char;
+}
+
+fn device() -> c_int {
+    std::env::var("RESAMPLER_AMD_DEVICE").ok().and_then(|v| v.parse().ok()).unwrap_or(0)
+}
+
+fn last_error() -> String {
+    unsafe { std::ffi::CStr::from_ptr(rsmp_last_error()).to_string_lossy().into_owned() }
+}
+
+fn status(rc: c_int) -> Result<(), ResampleError> {
+    match rc {
+        0 => Ok(()),
+        1 => Err(ResampleError::InvalidInputBufferSize),
+        2 => Err(ResampleError::InvalidOutputBufferSize),
+        _ => panic!("resampler_amd: {}", last_error()),
+    }
+}
+
+/// src/resampler_fir.rs:179-643
+pub struct ResamplerFir { handle: *mut rsmp_fir }
+unsafe impl Send for ResamplerFir {}
+unsafe impl Sync for ResamplerFir {}
+
+impl ResamplerFir {
+    pub fn new(channels: usize, input_rate: SampleRate, output_rate: SampleRate, latency: Latency,
+               attenuation: Attenuation) -> Self {
+        let handle = unsafe {
+            rsmp_fir_new(channels, input_rate as c_int, output_rate as c_int, latency as c_int,
+                         attenuation as c_int, device())
+        };
+        assert!(!handle.is_null(), "{}", last_error());
+        Self { handle }
+    }
+
+    pub fn new_from_hz(channels: usize, input_rate_hz: u32, output_rate_hz: u32, latency: Latency,
+                       attenuation: Attenuation) -> Self {
+        assert!(input_rate_hz > 0, "input sample rate must be greater than zero");
+        assert!(output_rate_hz > 0, "output sample rate must be greater than zero");
+        let handle = unsafe {
+            rsmp_fir_new_from_hz(channels, input_rate_hz, output_rate_hz, latency as c_int,
+                                 attenuation as c_int, device())
+        };
+        assert!(!handle.is_null(), "{}", last_error());
+        Self { handle }
+    }
+
+    pub fn buffer_size_output(&self) -> usize { unsafe { rsmp_fir_buffer_size_output(self.handle) } }
+    pub fn delay(&self) -> usize { unsafe { rsmp_fir_delay(self.handle) } }
+    pub fn reset(&mut self) { unsafe { rsmp_fir_reset(self.handle) } }
+
+    pub fn resample(&mut self, input: &[f32], output: &mut [f32]) -> Result<(usize, usize), ResampleError> {
+        let (mut consumed, mut produced) = (0usize, 0usize);
+        let rc = unsafe {
+            rsmp_fir_resample(self.handle, input.as_ptr(), input.len(), output.as_mut_ptr(),
+                              output.len(), &mut consumed, &mut produced)
+        };
+        status(rc).map(|_| (consumed, produced))
+    }
+}
+
+impl Drop for ResamplerFir {
+    fn drop(&mut self) { unsafe { rsmp_fir_free(self.handle) } }
+}
+
+/// src/resampler_fft.rs:43-240
+pub struct ResamplerFft { handle: *mut rsmp_fft }
+unsafe impl Send for ResamplerFft {}
+unsafe impl Sync for ResamplerFft {}
+
+impl ResamplerFft {
+    pub fn new(channels: usize, sample_rate_input: SampleRate, sample_rate_output: SampleRate) -> Self {
+        let handle = unsafe {
+            rsmp_fft_new(channels, sample_rate_input as c_int, sample_rate_output as c_int, device())
+        };
+        assert!(!handle.is_null(), "{}", last_error());
+        Self { handle }
+    }
+    pub fn chunk_size_input(&self) -> usize { unsafe { rsmp_fft_chunk_size_input(self.handle) } }
+    pub fn chunk_size_output(&self) -> usize { unsafe { rsmp_fft_chunk_size_output(self.handle) } }
+    pub fn delay(&self) -> usize { unsafe { rsmp_fft_delay(self.handle) } }
+    pub fn resample(&mut self, input: &[f32], output: &mut [f32]) -> Result<(), ResampleError> {
+        status(unsafe {
+            rsmp_fft_resample(self.handle, input.as_ptr(), input.len(), output.as_mut_ptr(), output.len())
+        })
+    }
+}
+
+impl Drop for ResamplerFft {
+    fn drop(&mut self) { unsafe { rsmp_fft_free(self.handle) } }
+}
