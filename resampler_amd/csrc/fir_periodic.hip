@@ -43,6 +43,8 @@ struct GeoArgs {
     uint32_t inline_wraps;
     uint32_t debug;  // RSMP_FIR_DEBUG: bit0 skip staging, bit1 skip the tap loops (timing only)
     uint32_t stagger_ticks;  // one-time start delay of the second workgroup slot (100 MHz ticks)
+    unsigned long long* trace;  // RSMP_FIR_TRACE diagnostic build only: 6 u64 per workgroup
+    uint32_t blocks_per_stream, total_items;
 };
 
 typedef const float __attribute__((address_space(4)))* const_f32_ptr;   // scalar-cache loads
@@ -203,41 +205,51 @@ __device__ __forceinline__ void tile_taps_c2(v2f (&acc)[8], v2f& accw, const flo
     }
 }
 
-// 640 threads = 10 waves; two workgroups per CU -> 5 waves per SIMD -> at most 96 VGPRs.
+// Up to 768 threads = 12 waves (3 per SIMD); two workgroups per CU -> 6 waves per SIMD -> at
+// most 80 VGPRs.
 // C2 = true: exactly two channels, both handled by one lane (CG == 2) -- the headline config.
 template <int CG, bool C2>
-__global__ __launch_bounds__(640, 5) void fir_periodic_kernel(const FirStreamDesc* __restrict__ descs,
+__global__ __launch_bounds__(768, 6) void fir_periodic_kernel(const FirStreamDesc* __restrict__ descs,
                                                               GeoArgs geo) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    // The descriptor is wave-uniform and read-only: fetch it through the scalar cache.
-    const FirStreamDesc d = load_uniform(descs + blockIdx.y);
-    const uint32_t n_out = d.n_out;
-    if (n_out == 0) return;
-    const uint64_t abs_out = d.abs_out;
-    const uint64_t q_first = abs_out / geo.b;
-    const uint64_t q0 = q_first + static_cast<uint64_t>(blockIdx.x) * geo.pw;
-    if (q0 * geo.b >= abs_out + n_out) return;
-    // launch-relative index of output (period q0, class 0); fits int32 (n_out < 2^31)
-    const int32_t n_block0 = static_cast<int32_t>(static_cast<int64_t>(q0 * geo.b) -
-                                                  static_cast<int64_t>(abs_out));
-
+    // Persistent workgroups: the grid is two workgroups per CU and each walks the launch's work
+    // items (stream, period block) with the grid as stride.  A fresh dispatch per block cost
+    // ~10 us of empty LDS slot between workgroups (measured with RSMP_FIR_TRACE) -- a third of
+    // each slot's time.
+    //
     // All workgroups start together and take equally long, so the two workgroups sharing a CU
     // would stage (HBM busy, VALU idle) and compute (VALU busy, HBM idle) in lockstep.  Delaying
     // the second dispatch round once puts the pairs out of phase for the rest of the launch:
     // one streams while the other computes.  Dispatch order only affects speed, never results.
-    if (geo.stagger_ticks) {
-        const uint32_t lin = blockIdx.x + gridDim.x * blockIdx.y;
-        if (lin >= 256 && lin < 512) {
-            const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
-            while (__builtin_amdgcn_s_memrealtime() - t0 < geo.stagger_ticks) __builtin_amdgcn_s_sleep(16);
-        }
+    unsigned long long t_trace[4] = {0, 0, 0, 0};
+    if (geo.trace) t_trace[0] = __builtin_amdgcn_s_memrealtime();
+    if (geo.stagger_ticks && blockIdx.x >= gridDim.x / 2) {
+        const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+        while (__builtin_amdgcn_s_memrealtime() - t0 < geo.stagger_ticks) __builtin_amdgcn_s_sleep(16);
     }
 
     const uint32_t C = C2 ? 2u : geo.channels;
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    float* __restrict__ xprev = lds;                   // [pw][C]: the frame in front of each period
+    uint32_t* tile_counter = reinterpret_cast<uint32_t*>(lds);   // next unclaimed class tile
+    float* __restrict__ xprev = lds + 4;               // [pw][C]: the frame in front of each period
     float* __restrict__ rows = lds + geo.xprev_len;    // [pw + 1][row_stride]
+
+  for (uint32_t item = blockIdx.x; item < geo.total_items; item += gridDim.x) {
+    const uint32_t stream_idx = item / geo.blocks_per_stream;
+    const uint32_t block_idx = item - stream_idx * geo.blocks_per_stream;
+    // The descriptor is wave-uniform and read-only: fetch it through the scalar cache.
+    const FirStreamDesc d = load_uniform(descs + stream_idx);
+    const uint32_t n_out = d.n_out;
+    if (n_out == 0) continue;
+    const uint64_t abs_out = d.abs_out;
+    const uint64_t q_first = abs_out / geo.b;
+    const uint64_t q0 = q_first + static_cast<uint64_t>(block_idx) * geo.pw;
+    if (q0 * geo.b >= abs_out + n_out) continue;
+    // launch-relative index of output (period q0, class 0); fits int32 (n_out < 2^31)
+    const int32_t n_block0 = static_cast<int32_t>(static_cast<int64_t>(q0 * geo.b) -
+                                                  static_cast<int64_t>(abs_out));
+    __syncthreads();   // every wave is done reading the previous item's LDS image
 
     // ---- stage ---------------------------------------------------------------------------------
     // LDS-DMA (global_load_lds, 4 B per lane): the rows region is filled 256 B per wave
@@ -300,9 +312,11 @@ __global__ __launch_bounds__(640, 5) void fir_periodic_kernel(const FirStreamDes
             }
         }
     }
+    if (threadIdx.x == 0) *tile_counter = 0;
     __builtin_amdgcn_s_waitcnt(0);   // vmcnt(0): LDS-DMA is tracked by vmcnt
     __syncthreads();
 
+    if (geo.trace) t_trace[1] = __builtin_amdgcn_s_memrealtime();
     // ---- compute -------------------------------------------------------------------------------
     const uint32_t pl = C2 ? lane : lane / geo.lp;   // period of this lane inside the block
     const uint32_t gi = C2 ? 0u : lane - pl * geo.lp;  // channel group of this lane
@@ -318,7 +332,14 @@ __global__ __launch_bounds__(640, 5) void fir_periodic_kernel(const FirStreamDes
     const int32_t k_block0 = static_cast<int32_t>(static_cast<int64_t>(q0 * geo.r) -
                                                   static_cast<int64_t>(d.wrap_k0));
 
-    for (uint32_t t = wave; t < geo.n_tiles; t += geo.waves) {
+    // Class tiles are claimed dynamically: a workgroup's waves are spread unevenly over the four
+    // SIMDs (and share them with the other resident workgroup), so a static split leaves the
+    // least loaded SIMD idle while the most loaded one finishes.
+    for (;;) {
+        uint32_t t = 0;
+        if (lane == 0) t = atomicAdd(tile_counter, 1u);
+        t = __builtin_amdgcn_readfirstlane(t);
+        if (t >= geo.n_tiles) break;
         const uint32_t j0 = t * kClassTile;
         const TileMeta tm = load_uniform(metas + t);
         const uint32_t ob = tm.base;
@@ -457,6 +478,20 @@ __global__ __launch_bounds__(640, 5) void fir_periodic_kernel(const FirStreamDes
             }
         }
     }
+  }   // items
+    if (geo.trace) {
+        t_trace[2] = __builtin_amdgcn_s_memrealtime();
+        __builtin_amdgcn_s_waitcnt(0);   // stores acknowledged
+        t_trace[3] = __builtin_amdgcn_s_memrealtime();
+        if (threadIdx.x == 0) {
+            unsigned long long* rec = geo.trace + 6ull * blockIdx.x;
+            unsigned hw_id, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            rec[0] = t_trace[0]; rec[1] = t_trace[1]; rec[2] = t_trace[2]; rec[3] = t_trace[3];
+            rec[4] = hw_id; rec[5] = xcc;
+        }
+    }
 }
 
 // Outputs whose f64 position fell just below an integer: previous frame, row 1023, frac 0
@@ -498,7 +533,8 @@ __global__ __launch_bounds__(256) void fir_wrap_fixup_kernel(const FirStreamDesc
     }
 }
 
-uint32_t xprev_len_of(uint32_t pw, uint32_t channels) { return (pw * channels + 3) / 4 * 4; }
+// LDS prefix: [4 dwords: dynamic tile counter] [pw][C] previous-frame samples, 16-byte multiple.
+uint32_t xprev_len_of(uint32_t pw, uint32_t channels) { return 4 + (pw * channels + 3) / 4 * 4; }
 
 GeoArgs to_args(const PeriodicGeometry& g) {
     static const uint32_t debug = [] {
@@ -511,7 +547,7 @@ GeoArgs to_args(const PeriodicGeometry& g) {
     }();
     const uint32_t channels = g.lp * g.cg;
     return GeoArgs{g.a, g.b, g.b / g.den, g.row_len, g.n_tiles, g.lp, g.pw, g.row_stride, g.waves,
-                   channels, xprev_len_of(g.pw, channels), g.inline_wraps ? 1u : 0u, debug, stagger};
+                   channels, xprev_len_of(g.pw, channels), g.inline_wraps ? 1u : 0u, debug, stagger, nullptr, 0u, 0u};
 }
 
 // Device class tables, shared by every stream on a device with the same polyphase table, rate
@@ -587,14 +623,9 @@ PeriodicGeometry periodic_geometry(uint64_t num, uint64_t den, uint32_t taps, ui
         return true;
     };
     if (!fit(2) && !fit(1)) return g;
-    // waves per workgroup: balance the class tiles, keep >= 4 waves
-    const uint32_t max_waves = 10;  // __launch_bounds__(640, 5) of fir_periodic_kernel
-    uint32_t best = 4;
-    double best_cost = 1e9;
-    for (uint32_t w = 4; w <= max_waves; ++w) {
-        const double cost = static_cast<double>((g.n_tiles + w - 1) / w * w) / g.n_tiles;
-        if (cost <= best_cost + 1e-9) { best_cost = cost; best = w; }
-    }
+    // waves per workgroup: a multiple of the 4 SIMDs, at most 12 (__launch_bounds__(768, 6));
+    // tiles are claimed dynamically, so the count need not divide n_tiles
+    const uint32_t best = g.n_tiles >= 12 ? 12u : (g.n_tiles >= 8 ? 8u : 4u);
     g.waves = best;
     g.ok = true;
     return g;
@@ -740,15 +771,41 @@ hipError_t launch_fir_periodic(const FirStreamDesc* d_descs, uint32_t n_streams,
                                const PeriodicGeometry& geo, uint32_t max_blocks,
                                hipStream_t stream) {
     if (n_streams == 0 || max_blocks == 0) return hipSuccess;
-    const dim3 grid(max_blocks, n_streams);
     const dim3 block(geo.waves * 64);
-    const GeoArgs args = to_args(geo);
-    // Dynamic LDS above 64 KiB must be opted into, once per kernel and device.
-    static std::mutex mu;
-    static std::map<std::pair<int, int>, bool> granted;
+    GeoArgs args = to_args(geo);
+    args.blocks_per_stream = max_blocks;
+    args.total_items = max_blocks * n_streams;
     int device = 0;
     hipError_t e = hipGetDevice(&device);
     if (e != hipSuccess) return e;
+    static std::map<int, uint32_t> cu_count;
+    static std::mutex cu_mu;
+    uint32_t cus;
+    {
+        std::lock_guard<std::mutex> lock(cu_mu);
+        uint32_t& c = cu_count[device];
+        if (c == 0) {
+            int v = 0;
+            e = hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device);
+            if (e != hipSuccess) return e;
+            c = static_cast<uint32_t>(v > 0 ? v : 256);
+        }
+        cus = c;
+    }
+    const uint32_t slots = cus * (geo.lds_bytes > kLdsTwoPerCu ? 1u : 2u);
+    const dim3 grid(args.total_items < slots ? args.total_items : slots);
+    static const char* trace_path = getenv("RSMP_FIR_TRACE");
+    static unsigned long long* d_trace = nullptr;
+    const size_t trace_words = 6ull * grid.x;
+    if (trace_path) {
+        if (d_trace) (void)hipFree(d_trace);
+        if (hipMalloc(&d_trace, trace_words * 8) != hipSuccess) return hipErrorOutOfMemory;
+        (void)hipMemset(d_trace, 0, trace_words * 8);
+        args.trace = d_trace;
+    }
+    // Dynamic LDS above 64 KiB must be opted into, once per kernel and device.
+    static std::mutex mu;
+    static std::map<std::pair<int, int>, bool> granted;
     const int variant = geo.cg == 2 ? (geo.lp == 1 ? 0 : 1) : 2;
     const void* fns[3] = {reinterpret_cast<const void*>(fir_periodic_kernel<2, true>),
                           reinterpret_cast<const void*>(fir_periodic_kernel<2, false>),
@@ -779,6 +836,17 @@ hipError_t launch_fir_periodic(const FirStreamDesc* d_descs, uint32_t n_streams,
         hipLaunchKernelGGL((fir_periodic_kernel<2, false>), grid, block, geo.lds_bytes, stream, d_descs, args);
     else
         hipLaunchKernelGGL((fir_periodic_kernel<1, false>), grid, block, geo.lds_bytes, stream, d_descs, args);
+    if (trace_path) {
+        (void)hipStreamSynchronize(stream);
+        std::vector<unsigned long long> h(trace_words);
+        (void)hipMemcpy(h.data(), d_trace, trace_words * 8, hipMemcpyDeviceToHost);
+        if (FILE* f = fopen(trace_path, "w")) {
+            for (size_t i = 0; i < trace_words / 6; ++i)
+                fprintf(f, "%zu %llu %llu %llu %llu %llu %llu\n", i, h[6 * i], h[6 * i + 1], h[6 * i + 2],
+                        h[6 * i + 3], h[6 * i + 4], h[6 * i + 5]);
+            fclose(f);
+        }
+    }
     return hipGetLastError();
 }
 
