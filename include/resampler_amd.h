@@ -115,6 +115,9 @@ int rsmp_fir_batch_resample_bulk_device(rsmp_fir* const* rs, size_t n, const flo
                                         float* const* d_out, const size_t* out_caps,
                                         size_t* consumed, size_t* produced, void* stream);
 
+/* reset() for every stream of a batch. */
+void rsmp_fir_batch_reset(rsmp_fir* const* rs, size_t n);
+
 /* ---- host-only: filter design and the (consumed, produced) state machine ----------------------- */
 /* make_sincs_for_kaiser table exactly as ResamplerFir::create_fir_coeffs lays it out
  * (resampler_fir.rs:406-422, window.rs:17-55): out[1024][taps]. */

@@ -123,6 +123,7 @@ _SIGNATURES = [
     ("rsmp_fir_batch_resample_bulk_device", C.c_int,
      [C.POINTER(C.c_void_p), C.c_size_t, C.POINTER(C.c_void_p), _szp, C.c_size_t,
       C.POINTER(C.c_void_p), _szp, _szp, _szp, C.c_void_p]),
+    ("rsmp_fir_batch_reset", None, [C.POINTER(C.c_void_p), C.c_size_t]),
     ("rsmp_design_fir_coeffs", C.c_int, [C.c_uint32, C.c_uint32, C.c_int, C.c_int, _f32p, C.c_size_t]),
     ("rsmp_design_cutoff_kaiser", C.c_double, [C.c_size_t, C.c_double]),
     ("rsmp_fir_plan_new", C.c_void_p, [C.c_uint32, C.c_uint32, C.c_int]),
@@ -369,6 +370,9 @@ class FirBatch:
             self._out[i] = _dev_ptr(b)
             self._in_lens[i] = a.numel()
             self._out_caps[i] = b.numel()
+
+    def reset(self) -> None:
+        lib().rsmp_fir_batch_reset(self._handles, len(self.resamplers))
 
     def resample_bulk_device(self, chunk_len: int = 512, stream: Optional[int] = None):
         n = len(self.resamplers)

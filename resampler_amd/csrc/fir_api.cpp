@@ -76,10 +76,14 @@ struct rsmp_fir {
     float* d_hist[2] = {nullptr, nullptr};  // kInputCapacity * channels floats each
     int cur = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t plan_copied = nullptr;
-    bool plan_pending = false;
+    // Launch plans travel through a small ring of pinned buffers so the host can enqueue several
+    // launches ahead of the GPU (a slot is reused only after its upload has left host memory).
+    static constexpr int kPlanSlots = 4;
+    hipEvent_t plan_copied[kPlanSlots] = {nullptr, nullptr, nullptr, nullptr};
+    bool plan_pending[kPlanSlots] = {false, false, false, false};
+    int plan_slot = 0;
     // launch workspace (descs + runs + tile index), host-pinned and device
-    PinnedBuffer h_plan;
+    PinnedBuffer h_plan[kPlanSlots];
     DeviceBuffer d_plan;
     // staging for the host-pointer entry points
     DeviceBuffer d_stage_in, d_stage_out;
@@ -141,7 +145,10 @@ rsmp_fir* fir_create(size_t channels, uint32_t in_hz, uint32_t out_hz, int laten
         }
     }
     if (hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&r->plan_copied, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&r->plan_copied[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&r->plan_copied[1], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&r->plan_copied[2], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&r->plan_copied[3], hipEventDisableTiming) != hipSuccess) {
         rsmp::fail(RSMP_ERR_HIP, "ResamplerFir: cannot create stream/event");
         return nullptr;
     }
@@ -367,16 +374,18 @@ int launch_jobs(rsmp_fir* leader, std::vector<Job>& jobs, hipStream_t stream) {
             bytes = align_up(bytes + words * sizeof(uint32_t), 256);
         }
     }
-    if (leader->plan_pending) {  // the previous launch's plan upload must have left pinned memory
-        RSMP_HIP_CHECK(hipEventSynchronize(leader->plan_copied));
-        leader->plan_pending = false;
+    const int slot = leader->plan_slot;
+    leader->plan_slot = (slot + 1) % rsmp_fir::kPlanSlots;
+    if (leader->plan_pending[slot]) {  // this slot's previous upload must have left pinned memory
+        RSMP_HIP_CHECK(hipEventSynchronize(leader->plan_copied[slot]));
+        leader->plan_pending[slot] = false;
     }
-    RSMP_HIP_CHECK(leader->h_plan.reserve(bytes));
+    RSMP_HIP_CHECK(leader->h_plan[slot].reserve(bytes));
     if (bytes > leader->d_plan.capacity()) {
         RSMP_HIP_CHECK(hipStreamSynchronize(stream));
         RSMP_HIP_CHECK(leader->d_plan.reserve(bytes));
     }
-    char* h = leader->h_plan.as<char>();
+    char* h = leader->h_plan[slot].as<char>();
     char* d = leader->d_plan.as<char>();
     FirStreamDesc* descs = reinterpret_cast<FirStreamDesc*>(h);
 
@@ -445,8 +454,8 @@ int launch_jobs(rsmp_fir* leader, std::vector<Job>& jobs, hipStream_t stream) {
         pl.placed = true;
     }
     RSMP_HIP_CHECK(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, stream));
-    RSMP_HIP_CHECK(hipEventRecord(leader->plan_copied, stream));
-    leader->plan_pending = true;
+    RSMP_HIP_CHECK(hipEventRecord(leader->plan_copied[slot], stream));
+    leader->plan_pending[slot] = true;
 
     const FirStreamDesc* d_descs = reinterpret_cast<const FirStreamDesc*>(d);
     if (leader->profiling) RSMP_HIP_CHECK(hipEventRecord(leader->prof_start, stream));
@@ -541,7 +550,7 @@ extern "C" void rsmp_fir_free(rsmp_fir* r) {
     if (r->stream) (void)hipStreamSynchronize(r->stream);
     (void)hipDeviceSynchronize();
     for (int i = 0; i < 2; ++i) if (r->d_hist[i]) (void)hipFree(r->d_hist[i]);
-    if (r->plan_copied) (void)hipEventDestroy(r->plan_copied);
+    for (hipEvent_t e : r->plan_copied) if (e) (void)hipEventDestroy(e);
     if (r->prof_start) (void)hipEventDestroy(r->prof_start);
     if (r->prof_stop) (void)hipEventDestroy(r->prof_stop);
     if (r->stream) (void)hipStreamDestroy(r->stream);
@@ -559,6 +568,10 @@ extern "C" size_t rsmp_fir_phases(const rsmp_fir* r) { (void)r; return rsmp::kPh
 extern "C" void rsmp_fir_reset(rsmp_fir* r) {
     // resampler_fir.rs:638-642: only the three scalars; stale frames are unreachable.
     r->mirror.reset();
+}
+
+extern "C" void rsmp_fir_batch_reset(rsmp_fir* const* rs, size_t n) {
+    for (size_t i = 0; i < n; ++i) rs[i]->mirror.reset();
 }
 
 extern "C" int rsmp_fir_set_kernel(rsmp_fir* r, int kernel) {

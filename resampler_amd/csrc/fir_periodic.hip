@@ -625,7 +625,11 @@ PeriodicGeometry periodic_geometry(uint64_t num, uint64_t den, uint32_t taps, ui
     if (!fit(2) && !fit(1)) return g;
     // waves per workgroup: a multiple of the 4 SIMDs, at most 12 (__launch_bounds__(768, 6));
     // tiles are claimed dynamically, so the count need not divide n_tiles
-    const uint32_t best = g.n_tiles >= 12 ? 12u : (g.n_tiles >= 8 ? 8u : 4u);
+    uint32_t best = g.n_tiles >= 12 ? 12u : (g.n_tiles >= 8 ? 8u : 4u);
+    if (const char* e = getenv("RSMP_FIR_WAVES")) {   // tuning knob (4..12)
+        const int w = atoi(e);
+        if (w >= 1 && w <= 12) best = static_cast<uint32_t>(w);
+    }
     g.waves = best;
     g.ok = true;
     return g;
