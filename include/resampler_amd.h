@@ -84,6 +84,9 @@ int rsmp_fir_set_kernel(rsmp_fir* r, int kernel);
  * rsmp_fir_last_kernel_ms waits for the last one and returns its duration. */
 int rsmp_fir_set_profiling(rsmp_fir* r, int enable);
 int rsmp_fir_last_kernel_ms(rsmp_fir* r, float* ms);
+/* Mean over the (up to 64) most recent launches made since profiling was enabled; no host sync
+ * happens between those launches, so this is the kernel's duration inside a timed region. */
+int rsmp_fir_mean_kernel_ms(rsmp_fir* r, float* ms, size_t* launches);
 
 /* ResamplerFir::resample (resampler_fir.rs:509-621): one call, host buffers, synchronous. */
 int rsmp_fir_resample(rsmp_fir* r, const float* in, size_t in_len, float* out, size_t out_len,

@@ -111,6 +111,7 @@ _SIGNATURES = [
     ("rsmp_fir_set_kernel", C.c_int, [C.c_void_p, C.c_int]),
     ("rsmp_fir_set_profiling", C.c_int, [C.c_void_p, C.c_int]),
     ("rsmp_fir_last_kernel_ms", C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    ("rsmp_fir_mean_kernel_ms", C.c_int, [C.c_void_p, C.POINTER(C.c_float), _szp]),
     ("rsmp_fir_resample", C.c_int, [C.c_void_p, _f32p, C.c_size_t, _f32p, C.c_size_t, _szp, _szp]),
     ("rsmp_fir_resample_device", C.c_int,
      [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, _szp, _szp, C.c_void_p]),
@@ -296,6 +297,11 @@ class ResamplerFir:
         ms = C.c_float()
         _check(lib().rsmp_fir_last_kernel_ms(self._h, C.byref(ms)))
         return ms.value
+
+    def mean_kernel_ms(self) -> Tuple[float, int]:
+        ms, n = C.c_float(), C.c_size_t()
+        _check(lib().rsmp_fir_mean_kernel_ms(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
 
     # ResamplerFir::resample (host slices) --------------------------------------------------------
     def resample(self, input, output: np.ndarray) -> Tuple[int, int]:
