@@ -59,8 +59,83 @@ def cpu_baseline(frames: int, seconds: float):
     }
 
 
+def bench_fft(args) -> None:
+    """Secondary line (`--path fft`): ResamplerFft 2 ch 44.1k -> 48k (BASELINE config 3), a batch of
+    `--streams` streams x 892 blocks of 1176 frames per step, one launch of fft_ola_kernel."""
+    import torch
+    import resampler_amd as ra
+    from resampler_amd import synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device(f"cuda:{local_rank}")
+    S, blocks = args.streams, 892
+    hs = [ra.ResamplerFft.new(CHANNELS, ra.SampleRate.Hz44100, ra.SampleRate.Hz48000, device=local_rank)
+          for _ in range(S)]
+    n_in, n_out = hs[0].chunk_size_input(), hs[0].chunk_size_output()
+    base = torch.from_numpy(synth.sweep(blocks * n_in // CHANNELS, CHANNELS, float(IN_HZ))).to(dev)
+    gains = torch.linspace(0.5, 1.0, S, device=dev)
+    d_in = [(base * gains[i]).contiguous() for i in range(S)]
+    d_out = [torch.empty(blocks * n_out, device=dev, dtype=torch.float32) for _ in range(S)]
+    batch = ra.FftBatch(hs)
+    batch.bind(d_in, d_out, [blocks] * S)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(1, args.warmup)):
+        batch.resample_bulk_device(stream)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        batch.resample_bulk_device(stream)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    hs[0].set_profiling(True)
+    k = []
+    for _ in range(5):
+        batch.resample_bulk_device(stream)
+        k.append(hs[0].last_kernel_ms())
+    hs[0].set_profiling(False)
+    k_ms = float(np.mean(k))
+    values_in = S * blocks * n_in
+    alg_bytes = 4.0 * S * blocks * (n_in + n_out)
+    if rank == 0:
+        achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+        print(json.dumps({
+            "metric": "Msamples/s (in) 44.1k->48k FFT overlap-add",
+            "value": round(values_in * world * args.steps / dt / 1e6, 1), "unit": "Msamples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"ResamplerFft 2ch 44100->48000, {S} streams/GPU x {blocks} blocks of "
+                                   f"1176 frames per step, one launch per step"},
+            "roofline": {"bound": "hbm", "kernel": "fft_ola_kernel", "achieved": round(achieved, 1),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "traffic": None, "kernel_ms": round(k_ms, 4), "algorithmic_bytes": int(alg_bytes)},
+        }), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
+    ap.add_argument("--path", choices=["fir", "fft"], default="fir",
+                    help="fir = headline metric (default); fft = secondary ResamplerFft line")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
@@ -71,6 +146,9 @@ def main() -> None:
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--kernel", choices=["auto", "generic", "periodic"], default="auto")
     args = ap.parse_args()
+    if args.path == "fft":
+        bench_fft(args)
+        return
 
     import torch
     import resampler_amd as ra

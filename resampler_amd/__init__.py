@@ -455,6 +455,18 @@ class ResamplerFft:
         _check(lib().rsmp_fft_resample_bulk(self._h, _ptr(inp), inp.size, _ptr(out), out.size, n_chunks))
         return out
 
+    def resample_batch(self, input) -> np.ndarray:
+        """The CLI's whole-file driver `resample_batch` (resample/src/main.rs:256-313): complete
+        chunks, then the zero-padded partial chunk, trimmed to ceil(len * out / in) values."""
+        inp = _np_f32(input)
+        n_in, n_out = self.chunk_size_input(), self.chunk_size_output()
+        total = -(-inp.size // n_in)
+        padded = np.zeros(total * n_in, np.float32)
+        padded[:inp.size] = inp
+        out = self.resample_bulk(padded, total) if total else np.zeros(0, np.float32)
+        expected = int(np.ceil(float(inp.size) * float(n_out) / float(n_in)))
+        return out[:expected]
+
     def resample_device(self, d_in, d_out, stream: Optional[int] = None) -> None:
         _check(lib().rsmp_fft_resample_device(self._h, _dev_ptr(d_in), d_in.numel(), _dev_ptr(d_out),
                                               d_out.numel(), C.c_void_p(stream or 0)))

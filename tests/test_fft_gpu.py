@@ -162,3 +162,23 @@ def test_reference_amplitude_properties_on_gpu():
     start = min(g.delay(), out.size // 8) * 2
     end = out.size * 3 // 4
     assert np.abs(out[start:end:2] - 0.3).max() < 0.02 and np.abs(out[start + 1:end:2] - 0.6).max() < 0.02
+
+
+@pytest.mark.gpu
+def test_whole_file_driver_matches_reference_loop():
+    # resample_batch (resample/src/main.rs:256-313) -- zero-padded tail chunk and
+    # ceil(len * out / in) trim -- replayed on the oracle chunk by chunk.
+    g = ra.ResamplerFft.new(2, ra.SampleRate.Hz44100, ra.SampleRate.Hz48000)
+    r = o.OracleFft(2, 44100, 48000)
+    n_in, n_out = g.chunk_size_input(), g.chunk_size_output()
+    x = synth.sweep((7 * n_in + 1000) // 2, 2, 44100.0)
+    y = g.resample_batch(x)
+    total = -(-x.size // n_in)
+    padded = np.zeros(total * n_in, np.float32)
+    padded[:x.size] = x
+    ref = np.zeros((total, n_out), np.float32)
+    for b in range(total):
+        assert r.resample(padded[b * n_in:(b + 1) * n_in], ref[b]) == 0
+    expected = int(np.ceil(x.size * n_out / n_in))
+    assert y.size == expected
+    assert rms(y, ref.reshape(-1)[:expected]) <= RMS_TOL

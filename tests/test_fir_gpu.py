@@ -204,3 +204,27 @@ def test_linearity_and_shift_properties_at_full_size():
     g4 = ra.ResamplerFir.new(2, ra.SampleRate.Hz44100, ra.SampleRate.Hz48000)
     y, _ = g4.resample_bulk(st, 512)
     assert np.array_equal(y[0::2], y[1::2])
+
+
+@pytest.mark.parametrize("in_hz,out_hz", [(22050, 44100), (22050, 48000)])
+def test_stopband_attenuation_on_gpu(in_hz, out_hz):
+    # the reference's own quality gate (resampler_fir.rs:693-815) run through the
+    # GPU path: impulse in 256-value calls, >= 90 dB between pass band and stop band.
+    n = int(np.float32(in_hz) * np.float32(5.0))
+    x = np.zeros(n, np.float32)
+    x[min(int(n * 0.5), n - 1)] = 1.0
+    g = ra.ResamplerFir.new_from_hz(1, in_hz, out_hz, ra.Latency.Sample64, ra.Attenuation.Db90)
+    y, consumed = g.resample_bulk(x, 256)
+    assert consumed == n
+    peak = int(np.argmax(np.abs(y)))
+    win = int(np.float32(out_hz) * np.float32(0.1))
+    start = max(0, peak - win // 2)
+    seg = y[start:min(start + win, len(y))][:8192]
+    mag_db = 20.0 * np.log10(np.maximum(np.abs(np.fft.rfft(seg.astype(np.float64), 8192)), 1e-10))
+
+    def to_bin(f):
+        return int(round(f * 8192 / out_hz))
+    nyq = in_hz / 2.0
+    pass_max = mag_db[to_bin(20.0):to_bin(nyq * 0.9) + 1].max()
+    stop_max = mag_db[to_bin(nyq * 1.1):min(len(mag_db) - 10, to_bin(out_hz / 2.0 * 0.95)) + 1].max()
+    assert pass_max - stop_max >= 90.0
