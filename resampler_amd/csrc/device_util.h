@@ -57,7 +57,8 @@ public:
         }
         size_t want = bytes + bytes / 2;
         if (want < 4096) want = 4096;
-        hipError_t e = hipHostMalloc(&ptr_, want, hipHostMallocDefault);
+        // mapped + coherent: small launch plans are read by the kernels straight from this memory
+        hipError_t e = hipHostMalloc(&ptr_, want, hipHostMallocMapped | hipHostMallocCoherent);
         if (e != hipSuccess) { ptr_ = nullptr; return e; }
         cap_ = want;
         return hipSuccess;

@@ -380,7 +380,17 @@ int launch_jobs(rsmp_fir* leader, std::vector<Job>& jobs, hipStream_t stream) {
     }
     const int slot = leader->plan_slot;
     leader->plan_slot = (slot + 1) % rsmp_fir::kPlanSlots;
-    if (bytes > leader->d_plan[slot].capacity()) {
+    // Small plans (a single call, a handful of streams) are not uploaded at all: the kernels read
+    // them from mapped, coherent host memory.  That removes a copy-engine operation and its
+    // cross-queue synchronisation (~50 us) from every streaming call.
+    const bool direct = bytes <= 16 * 1024;
+    if (direct) {
+        if (leader->plan_pending[slot]) {  // kernels of the slot's previous launch are done with it
+            RSMP_HIP_CHECK(hipEventSynchronize(leader->plan_copied[slot]));
+            leader->plan_pending[slot] = false;
+        }
+        RSMP_HIP_CHECK(leader->h_plan[slot].reserve(16 * 1024));
+    } else if (bytes > leader->d_plan[slot].capacity()) {
         RSMP_HIP_CHECK(hipStreamSynchronize(stream));
         RSMP_HIP_CHECK(leader->d_plan[slot].reserve(bytes));
         leader->plan_image[slot].clear();
@@ -390,11 +400,11 @@ int launch_jobs(rsmp_fir* leader, std::vector<Job>& jobs, hipStream_t stream) {
     // of equally long files) finds its image already in HBM and skips the upload.
     leader->plan_scratch.assign(bytes, 0);
     char* h = leader->plan_scratch.data();
-    char* d = leader->d_plan[slot].as<char>();
+    char* d = direct ? leader->h_plan[slot].as<char>() : leader->d_plan[slot].as<char>();
     FirStreamDesc* descs = reinterpret_cast<FirStreamDesc*>(h);
 
     for (Job& j : jobs) j.plan->placed = false;
-    uint32_t max_out_generic = 0, max_tail_values = 0, max_wraps = 0;
+    uint32_t max_out_generic = 0, max_ch_generic = 0, max_tail_values = 0, max_wraps = 0;
     for (size_t slot = 0; slot < n; ++slot) {
         Job& j = jobs[order[slot]];
         Plan& pl = *j.plan;
@@ -434,6 +444,7 @@ int launch_jobs(rsmp_fir* leader, std::vector<Job>& jobs, hipStream_t stream) {
                 }
             }
             if (ds.n_out > max_out_generic) max_out_generic = ds.n_out;
+            if (ch > max_ch_generic) max_ch_generic = ch;
         } else {
             const rsmp::PeriodicGeometry& geo = r->periodic.geo;
             ds.class_coef = r->periodic.table.d_coef;
@@ -457,7 +468,9 @@ int launch_jobs(rsmp_fir* leader, std::vector<Job>& jobs, hipStream_t stream) {
         }
         pl.placed = true;
     }
-    if (leader->plan_image[slot] != leader->plan_scratch) {
+    if (direct) {
+        std::memcpy(d, h, bytes);
+    } else if (leader->plan_image[slot] != leader->plan_scratch) {
         if (leader->plan_pending[slot]) {  // this slot's previous upload must have left pinned memory
             RSMP_HIP_CHECK(hipEventSynchronize(leader->plan_copied[slot]));
             leader->plan_pending[slot] = false;
@@ -475,7 +488,7 @@ int launch_jobs(rsmp_fir* leader, std::vector<Job>& jobs, hipStream_t stream) {
         RSMP_HIP_CHECK(hipEventRecord(leader->prof_start[leader->prof_count % rsmp_fir::kProfRing], stream));
     if (n_generic)
         RSMP_HIP_CHECK(rsmp::launch_fir_generic(d_descs, static_cast<uint32_t>(n_generic),
-                                                max_out_generic, 0, stream));
+                                                max_out_generic, max_ch_generic, stream));
     size_t first = n_generic;
     for (const Group& g : groups) {
         uint32_t max_blocks = 0;
@@ -499,6 +512,11 @@ int launch_jobs(rsmp_fir* leader, std::vector<Job>& jobs, hipStream_t stream) {
                                                    stream));
     RSMP_HIP_CHECK(rsmp::launch_fir_tail_copy(d_descs, static_cast<uint32_t>(n), max_tail_values,
                                               stream));
+    if (direct) {   // the slot may be rewritten once these kernels have read it
+        RSMP_HIP_CHECK(hipEventRecord(leader->plan_copied[slot], stream));
+        leader->plan_pending[slot] = true;
+        leader->plan_image[slot].clear();
+    }
     // Commit: the mirrors advance, the hist buffers swap.
     for (Job& j : jobs) {
         j.r->mirror = j.plan->planned;

@@ -21,7 +21,8 @@ namespace {
 
 constexpr int kLanesPerFrame = 8;
 constexpr int kBlock = 256;
-constexpr int kFramesPerPass = kBlock / kLanesPerFrame;  // 32
+constexpr int kFramesPerPass = kBlock / kLanesPerFrame;  // 32 == kFirTile
+constexpr uint32_t kChannelsPerBlock = 2;
 
 __device__ __forceinline__ float group_sum8(float v) {
     v += __shfl_xor(v, 4, 64);
@@ -49,6 +50,11 @@ __global__ __launch_bounds__(kBlock) void fir_generic_kernel(const FirStreamDesc
     const uint32_t channels = d.channels;
 
     uint32_t seg_idx = d.tile_seg[tile];
+    // blockIdx.z splits the channels (2 per workgroup): short calls with many channels are
+    // latency bound, so they get parallel workgroups instead of a serial channel loop.
+    const uint32_t c_begin = blockIdx.z * kChannelsPerBlock;
+    if (c_begin >= channels) return;
+    const uint32_t c_end = c_begin + kChannelsPerBlock < channels ? c_begin + kChannelsPerBlock : channels;
 
     for (uint32_t base = tile_first; base < tile_first + kFirTile; base += kFramesPerPass) {
         const uint32_t n = base + slot;
@@ -82,7 +88,7 @@ __global__ __launch_bounds__(kBlock) void fir_generic_kernel(const FirStreamDesc
             reinterpret_cast<const float4*>(d.coeffs + static_cast<size_t>(phase2) * taps);
         const float one_minus_frac = 1.0f - frac;                     // avx.rs:42
 
-        for (uint32_t c = 0; c < channels; ++c) {
+        for (uint32_t c = c_begin; c < c_end; ++c) {
             float a1 = 0.0f, a2 = 0.0f;
             if (live) {
                 for (uint32_t q = g; q < taps / 4; q += kLanesPerFrame) {
@@ -122,9 +128,10 @@ __global__ __launch_bounds__(kBlock) void fir_tail_copy_kernel(const FirStreamDe
 }  // namespace
 
 hipError_t launch_fir_generic(const FirStreamDesc* d_descs, uint32_t n_streams, uint32_t max_out,
-                              uint32_t /*max_channels*/, hipStream_t stream) {
+                              uint32_t max_channels, hipStream_t stream) {
     if (n_streams == 0 || max_out == 0) return hipSuccess;
-    const dim3 grid((max_out + kFirTile - 1) / kFirTile, n_streams);
+    const uint32_t cz = (max_channels + kChannelsPerBlock - 1) / kChannelsPerBlock;
+    const dim3 grid((max_out + kFirTile - 1) / kFirTile, n_streams, cz ? cz : 1);
     hipLaunchKernelGGL(fir_generic_kernel, grid, dim3(kBlock), 0, stream, d_descs);
     return hipGetLastError();
 }

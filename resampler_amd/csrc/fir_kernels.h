@@ -43,7 +43,7 @@ struct FirStreamDesc {
     uint64_t wrap_k0;              // wrap_bits bit K <-> absolute output (wrap_k0 + K) * den
 };
 
-constexpr uint32_t kFirTile = 256;  // output frames per workgroup tile (generic kernel)
+constexpr uint32_t kFirTile = 32;   // output frames per workgroup tile (generic kernel): one pass of 32 x 8 lanes
 
 // Generic kernel: any ratio, reference-form two-row interpolation; grid = (max tiles, streams).
 hipError_t launch_fir_generic(const FirStreamDesc* d_descs, uint32_t n_streams, uint32_t max_out,
