@@ -90,6 +90,8 @@ struct rsmp_fir {
     // staging for the host-pointer entry points
     DeviceBuffer d_stage_in, d_stage_out;
     rsmp::PeriodicState periodic;
+    unsigned long long* d_work_counter = nullptr;   // periodic kernel's item queue (leader only)
+    unsigned long long work_base = 0;
     // optional timing of the main convolution launch(es) (rsmp_fir_set_profiling)
     bool profiling = false;
     // ring of event pairs: launches made while profiling is on are timed without any host sync
@@ -497,9 +499,15 @@ int launch_jobs(rsmp_fir* leader, std::vector<Job>& jobs, hipStream_t stream) {
                                                      static_cast<uint32_t>(jobs[i].plan->produced_frames));
             if (b > max_blocks) max_blocks = b;
         }
+        if (!leader->d_work_counter) {
+            RSMP_HIP_CHECK(hipMalloc(&leader->d_work_counter, sizeof(unsigned long long)));
+            RSMP_HIP_CHECK(hipMemset(leader->d_work_counter, 0, sizeof(unsigned long long)));
+            leader->work_base = 0;
+        }
         RSMP_HIP_CHECK(rsmp::launch_fir_periodic(d_descs + first,
                                                  static_cast<uint32_t>(g.members.size()), g.geo,
-                                                 max_blocks, stream));
+                                                 max_blocks, leader->d_work_counter,
+                                                 &leader->work_base, stream));
         first += g.members.size();
     }
     if (leader->profiling) {
@@ -582,6 +590,7 @@ extern "C" void rsmp_fir_free(rsmp_fir* r) {
     if (r->stream) (void)hipStreamSynchronize(r->stream);
     (void)hipDeviceSynchronize();
     for (int i = 0; i < 2; ++i) if (r->d_hist[i]) (void)hipFree(r->d_hist[i]);
+    if (r->d_work_counter) (void)hipFree(r->d_work_counter);
     for (hipEvent_t e : r->plan_copied) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : r->prof_start) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : r->prof_stop) if (e) (void)hipEventDestroy(e);
