@@ -271,7 +271,7 @@ def main() -> None:
                 "valu_fma_per_s": round(values_out_per_step * 128 / (k_ms * 1e-3) / 1e12, 2),
             },
         }
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:   # rank 0 at N = 1 only
             line["cpu_baseline"] = cpu_baseline(N, args.cpu_seconds)
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -385,7 +385,9 @@ class FirBatch:
         _check(lib().rsmp_fir_batch_resample_bulk_device(
             self._handles, n, self._in, self._in_lens, chunk_len, self._out, self._out_caps,
             self._consumed, self._produced, C.c_void_p(stream or 0)))
-        return list(self._consumed), list(self._produced)
+        # zero-copy views (valid until the next call): converting 2 x n ctypes words to Python
+        # ints costs more than the launch for batches of a thousand streams
+        return (np.ctypeslib.as_array(self._consumed), np.ctypeslib.as_array(self._produced))
 
 
 class ResamplerFft:
