@@ -44,10 +44,13 @@ struct GeoArgs {
     uint32_t debug;  // RSMP_FIR_DEBUG: bit0 skip staging, bit1 skip the tap loops (timing only)
     uint32_t stagger_ticks;  // one-time start delay of the second workgroup slot (100 MHz ticks)
     unsigned long long* trace;  // RSMP_FIR_TRACE diagnostic build only: 6 u64 per workgroup
+    unsigned long long* wtrace; // RSMP_FIR_WTRACE: kWtraceSlots timestamped events per wave
     uint32_t blocks_per_stream, total_items;
     unsigned long long* work_counter;   // launch-wide item queue (monotonic)
     unsigned long long work_base;       // its value before this launch
 };
+
+constexpr uint32_t kWtraceSlots = 160, kWtraceWaves = 12;
 
 typedef const float __attribute__((address_space(4)))* const_f32_ptr;   // scalar-cache loads
 typedef const float __attribute__((address_space(1)))* gconst_f32_ptr;  // global (not flat) loads
@@ -153,17 +156,19 @@ __device__ __forceinline__ void pk_fma8(v2f (&acc)[8], v2f c0, v2f c1, v2f c2, v
         : "s"(c0), "s"(c1), "s"(c2), "s"(c3), "v"(x));
 }
 
-// 8 taps: 32 coefficient pairs (4 x s_load_dwordx16 = 256 B of the class table) against 8 frames.
-// One wait covers 64 packed FMAs (256 issue cycles), which is what lets a handful of waves per
-// SIMD hide the scalar-cache miss latency: each line of the table is touched by one wave only.
-template <bool WRAP>
-__device__ __forceinline__ void taps8(v2f (&acc)[8], v2f& accw, const v2f (&x)[8],
-                                      const_v2f_ptr gc, const_f32_ptr gwc) {
-    v2f c[32];
+// NT taps (8 or 4): 4*NT coefficient pairs (NT/2 x s_load_dwordx16) against NT frames.  One wait
+// covers 8*NT packed FMAs; that is what lets a handful of waves per SIMD hide the scalar-cache miss
+// latency (each line of the table is touched by one wave only).  NT = 8 needs 64 SGPRs for the
+// coefficients (12-wave workgroups, 6 waves per SIMD); NT = 4 halves that and leaves room for
+// 16-wave workgroups at 8 waves per SIMD.
+template <bool WRAP, int NT>
+__device__ __forceinline__ void taps(v2f (&acc)[8], v2f& accw, const v2f (&x)[NT],
+                                     const_v2f_ptr gc, const_f32_ptr gwc) {
+    v2f c[4 * NT];
 #pragma unroll
-    for (int i = 0; i < 32; ++i) c[i] = gc[i];
+    for (int i = 0; i < 4 * NT; ++i) c[i] = gc[i];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < NT; ++u) {
         pk_fma8(acc, c[4 * u], c[4 * u + 1], c[4 * u + 2], c[4 * u + 3], x[u]);
         if constexpr (WRAP) {
             const float w = gwc[u];
@@ -173,45 +178,45 @@ __device__ __forceinline__ void taps8(v2f (&acc)[8], v2f& accw, const v2f (&x)[8
     }
 }
 
-template <bool WRAP>
+template <bool WRAP, int NT>
 __device__ __forceinline__ void tile_taps_c2(v2f (&acc)[8], v2f& accw, const float* rowA,
                                              const float* rowB, uint32_t n1, uint32_t row_len,
                                              const_f32_ptr g, const_f32_ptr gw) {
-    const uint32_t n_chunks = row_len >> 3;
-    const uint32_t chunks_a = n1 >> 3;          // chunks entirely inside the lane's own row
+    const uint32_t n_chunks = row_len / NT;
+    const uint32_t chunks_a = n1 / NT;          // chunks entirely inside the lane's own row
     const_v2f_ptr gc = (const_v2f_ptr)g;
     uint32_t c = 0;
     for (; c < chunks_a; ++c) {
-        v2f x[8];
+        v2f x[NT];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) x[u] = *reinterpret_cast<const v2f*>(rowA + 16 * c + 2 * u);
-        taps8<WRAP>(acc, accw, x, gc + 32 * c, gw + 8 * c);
+        for (int u = 0; u < NT; ++u) x[u] = *reinterpret_cast<const v2f*>(rowA + 2 * NT * c + 2 * u);
+        taps<WRAP, NT>(acc, accw, x, gc + 4 * NT * c, gw + NT * c);
     }
-    if (c < n_chunks && (n1 & 7u)) {            // the chunk that straddles the two rows
-        v2f x[8];
+    if (c < n_chunks && (n1 % NT)) {            // the chunk that straddles the two rows
+        v2f x[NT];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const uint32_t m = 8 * c + u;
+        for (int u = 0; u < NT; ++u) {
+            const uint32_t m = NT * c + u;
             const float* px = m < n1 ? rowA + 2 * m : rowB + 2 * (m - n1);
             x[u] = *reinterpret_cast<const v2f*>(px);
         }
-        taps8<WRAP>(acc, accw, x, gc + 32 * c, gw + 8 * c);
+        taps<WRAP, NT>(acc, accw, x, gc + 4 * NT * c, gw + NT * c);
         ++c;
     }
     for (; c < n_chunks; ++c) {
-        const float* pb = rowB + 2 * (8 * c - n1);
-        v2f x[8];
+        const float* pb = rowB + 2 * (NT * c - n1);
+        v2f x[NT];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) x[u] = *reinterpret_cast<const v2f*>(pb + 2 * u);
-        taps8<WRAP>(acc, accw, x, gc + 32 * c, gw + 8 * c);
+        for (int u = 0; u < NT; ++u) x[u] = *reinterpret_cast<const v2f*>(pb + 2 * u);
+        taps<WRAP, NT>(acc, accw, x, gc + 4 * NT * c, gw + NT * c);
     }
 }
 
 // Up to 768 threads = 12 waves (3 per SIMD); two workgroups per CU -> 6 waves per SIMD -> at
 // most 80 VGPRs.
 // C2 = true: exactly two channels, both handled by one lane (CG == 2) -- the headline config.
-template <int CG, bool C2>
-__global__ __launch_bounds__(768, 6) void fir_periodic_kernel(const FirStreamDesc* __restrict__ descs,
+template <int CG, bool C2, int NT>
+__global__ __launch_bounds__(NT == 8 ? 768 : 1024, NT == 8 ? 6 : 8) void fir_periodic_kernel(const FirStreamDesc* __restrict__ descs,
                                                               GeoArgs geo) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     // Persistent workgroups: the grid is two workgroups per CU and each walks the launch's work
@@ -233,6 +238,16 @@ __global__ __launch_bounds__(768, 6) void fir_periodic_kernel(const FirStreamDes
     const uint32_t C = C2 ? 2u : geo.channels;
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // RSMP_FIR_WTRACE (diagnostic): per-wave event log, (100 MHz timestamp << 8) | tag
+    uint32_t ev_cursor = 0;
+    auto event = [&](uint32_t tag) {
+        if (geo.wtrace && ev_cursor < kWtraceSlots && wave < kWtraceWaves) {
+            const unsigned long long v = (__builtin_amdgcn_s_memrealtime() << 8) | tag;
+            if (lane == 0)
+                geo.wtrace[(static_cast<size_t>(blockIdx.x) * kWtraceWaves + wave) * kWtraceSlots + ev_cursor] = v;
+            ++ev_cursor;
+        }
+    };
     uint32_t* tile_counter = reinterpret_cast<uint32_t*>(lds);   // next unclaimed class tile
     float* __restrict__ xprev = lds + 4;               // [pw][C]: the frame in front of each period
     float* __restrict__ rows = lds + geo.xprev_len;    // [pw + 1][row_stride]
@@ -263,7 +278,9 @@ __global__ __launch_bounds__(768, 6) void fir_periodic_kernel(const FirStreamDes
     // launch-relative index of output (period q0, class 0); fits int32 (n_out < 2^31)
     const int32_t n_block0 = static_cast<int32_t>(static_cast<int64_t>(q0 * geo.b) -
                                                   static_cast<int64_t>(abs_out));
+    event(1);          // item begins (waiting for the other waves)
     __syncthreads();   // every wave has read `item` and is done with the previous LDS image
+    event(2);
     if (threadIdx.x == 0) *next_item = claim();
     if (!valid) {      // padding item of a ragged batch
         __syncthreads();
@@ -333,8 +350,11 @@ __global__ __launch_bounds__(768, 6) void fir_periodic_kernel(const FirStreamDes
         }
     }
     if (threadIdx.x == 0) *tile_counter = 0;
+    event(3);          // staging issued
     __builtin_amdgcn_s_waitcnt(0);   // vmcnt(0): LDS-DMA is tracked by vmcnt
+    event(4);          // own pieces landed
     __syncthreads();
+    event(5);          // everyone's pieces landed
 
     if (geo.trace) t_trace[1] = __builtin_amdgcn_s_memrealtime();
     // ---- compute -------------------------------------------------------------------------------
@@ -355,15 +375,19 @@ __global__ __launch_bounds__(768, 6) void fir_periodic_kernel(const FirStreamDes
     // Class tiles are claimed dynamically: a workgroup's waves are spread unevenly over the four
     // SIMDs (and share them with the other resident workgroup), so a static split leaves the
     // least loaded SIMD idle while the most loaded one finishes.
-    for (;;) {
-        uint32_t t = 0;
-        if (lane == 0) t = atomicAdd(tile_counter, 1u);
-        t = __builtin_amdgcn_readfirstlane(t);
-        if (t >= geo.n_tiles) break;
+    // The claim of the next tile (an LDS atomic) and the fetch of its descriptor are issued while
+    // the current tile computes, so a tile switch exposes neither latency.
+    uint32_t t_claim = 0;
+    if (lane == 0) t_claim = atomicAdd(tile_counter, 1u);
+    uint32_t t = __builtin_amdgcn_readfirstlane(t_claim);
+    TileMeta tm_cur = load_uniform(metas + (t < geo.n_tiles ? t : 0));
+    while (t < geo.n_tiles) {
+        event(6);      // tile begins
+        if (lane == 0) t_claim = atomicAdd(tile_counter, 1u);   // next tile, consumed at the bottom
         const uint32_t j0 = t * kClassTile;
-        const TileMeta tm = load_uniform(metas + t);
+        const TileMeta tm = tm_cur;
         const uint32_t ob = tm.base;
-        const_f32_ptr g = table + static_cast<size_t>(t) * geo.row_len * kClassTile;
+        const_f32_ptr g = table + static_cast<size_t>((geo.debug & 32) ? 0 : t) * geo.row_len * kClassTile;
         const_f32_ptr gw = wtable + static_cast<size_t>(t) * geo.row_len;
         const bool has_wrap = geo.inline_wraps && tm.wrap_col >= 0;
         // window [ob, ob+row_len) of the lane's period row, spilling into the next row
@@ -379,10 +403,10 @@ __global__ __launch_bounds__(768, 6) void fir_periodic_kernel(const FirStreamDes
             for (int i = 0; i < 8; ++i) acc[i] = v2f{0.f, 0.f};
             if (!(geo.debug & 2)) {
                 if (has_wrap)
-                    tile_taps_c2<true>(acc, accw, lane_row + ob * 2, lane_row + geo.row_stride, n1,
+                    tile_taps_c2<true, NT>(acc, accw, lane_row + ob * 2, lane_row + geo.row_stride, n1,
                                        geo.row_len, g, gw);
                 else
-                    tile_taps_c2<false>(acc, accw, lane_row + ob * 2, lane_row + geo.row_stride, n1,
+                    tile_taps_c2<false, NT>(acc, accw, lane_row + ob * 2, lane_row + geo.row_stride, n1,
                                         geo.row_len, g, gw);
             }
 #pragma unroll
@@ -418,6 +442,9 @@ __global__ __launch_bounds__(768, 6) void fir_periodic_kernel(const FirStreamDes
             for (int k = 0; k < CG; ++k) aw[k] = acc.w[k];
         }
 
+        event(7);      // taps done
+        const uint32_t t_next = __builtin_amdgcn_readfirstlane(t_claim);
+        const TileMeta tm_next = load_uniform(metas + (t_next < geo.n_tiles ? t_next : 0));
         if (has_wrap) {
             if (tm.extra_col != -2) {
                 float xs[CG];
@@ -506,6 +533,9 @@ __global__ __launch_bounds__(768, 6) void fir_periodic_kernel(const FirStreamDes
                 }
             }
         }
+        t = t_next;
+        tm_cur = tm_next;
+        event(8);      // stores issued
     }
     item = *next_item;   // written before the barrier that preceded the tile loop
   }   // items
@@ -577,7 +607,7 @@ GeoArgs to_args(const PeriodicGeometry& g) {
     }();
     const uint32_t channels = g.lp * g.cg;
     return GeoArgs{g.a, g.b, g.b / g.den, g.row_len, g.n_tiles, g.lp, g.pw, g.row_stride, g.waves,
-                   channels, xprev_len_of(g.pw, channels), g.inline_wraps ? 1u : 0u, debug, stagger, nullptr, 0u, 0u, nullptr, 0ull};
+                   channels, xprev_len_of(g.pw, channels), g.inline_wraps ? 1u : 0u, debug, stagger, nullptr, nullptr, 0u, 0u, nullptr, 0ull};
 }
 
 // Device class tables, shared by every stream on a device with the same polyphase table, rate
@@ -841,13 +871,25 @@ hipError_t launch_fir_periodic(const FirStreamDesc* d_descs, uint32_t n_streams,
         (void)hipMemset(d_trace, 0, trace_words * 8);
         args.trace = d_trace;
     }
+    static const char* wtrace_path = getenv("RSMP_FIR_WTRACE");
+    static unsigned long long* d_wtrace = nullptr;
+    const size_t wtrace_words = static_cast<size_t>(grid.x) * kWtraceWaves * kWtraceSlots;
+    if (wtrace_path) {
+        if (d_wtrace) (void)hipFree(d_wtrace);
+        if (hipMalloc(&d_wtrace, wtrace_words * 8) != hipSuccess) return hipErrorOutOfMemory;
+        (void)hipMemset(d_wtrace, 0, wtrace_words * 8);
+        args.wtrace = d_wtrace;
+    }
     // Dynamic LDS above 64 KiB must be opted into, once per kernel and device.
     static std::mutex mu;
     static std::map<std::pair<int, int>, bool> granted;
+    // variants: 0 = two channels, one lane per period; 1 = CG 2, any even channel count; 2 = CG 1.
+    // (4-tap chunks with 16-wave workgroups at 8 waves per SIMD measured 13 % slower than 8-tap
+    // chunks with 12 waves: the 64-VGPR cap spills.)
     const int variant = geo.cg == 2 ? (geo.lp == 1 ? 0 : 1) : 2;
-    const void* fns[3] = {reinterpret_cast<const void*>(fir_periodic_kernel<2, true>),
-                          reinterpret_cast<const void*>(fir_periodic_kernel<2, false>),
-                          reinterpret_cast<const void*>(fir_periodic_kernel<1, false>)};
+    const void* fns[3] = {reinterpret_cast<const void*>(fir_periodic_kernel<2, true, 8>),
+                          reinterpret_cast<const void*>(fir_periodic_kernel<2, false, 8>),
+                          reinterpret_cast<const void*>(fir_periodic_kernel<1, false, 8>)};
     {
         std::lock_guard<std::mutex> lock(mu);
         bool& have = granted[{device, variant}];
@@ -864,16 +906,16 @@ hipError_t launch_fir_periodic(const FirStreamDesc* d_descs, uint32_t n_streams,
                                                            geo.lds_bytes);
         fprintf(stderr,
                 "[rsmp] periodic launch: a=%u b=%u row_len=%u tiles=%u cg=%u lp=%u pw=%u stride=%u "
-                "waves=%u lds=%u grid=(%u,%u) occupancy=%d blocks/CU\n",
+                "waves=%u lds=%u items=%u grid=%u occupancy=%d blocks/CU\n",
                 geo.a, geo.b, geo.row_len, geo.n_tiles, geo.cg, geo.lp, geo.pw, geo.row_stride,
-                geo.waves, geo.lds_bytes, max_blocks, n_streams, blocks);
+                geo.waves, geo.lds_bytes, args.total_items, grid.x, blocks);
     }
     if (variant == 0)
-        hipLaunchKernelGGL((fir_periodic_kernel<2, true>), grid, block, geo.lds_bytes, stream, d_descs, args);
+        hipLaunchKernelGGL((fir_periodic_kernel<2, true, 8>), grid, block, geo.lds_bytes, stream, d_descs, args);
     else if (variant == 1)
-        hipLaunchKernelGGL((fir_periodic_kernel<2, false>), grid, block, geo.lds_bytes, stream, d_descs, args);
+        hipLaunchKernelGGL((fir_periodic_kernel<2, false, 8>), grid, block, geo.lds_bytes, stream, d_descs, args);
     else
-        hipLaunchKernelGGL((fir_periodic_kernel<1, false>), grid, block, geo.lds_bytes, stream, d_descs, args);
+        hipLaunchKernelGGL((fir_periodic_kernel<1, false, 8>), grid, block, geo.lds_bytes, stream, d_descs, args);
     if (trace_path) {
         (void)hipStreamSynchronize(stream);
         std::vector<unsigned long long> h(trace_words);
@@ -882,6 +924,20 @@ hipError_t launch_fir_periodic(const FirStreamDesc* d_descs, uint32_t n_streams,
             for (size_t i = 0; i < trace_words / 6; ++i)
                 fprintf(f, "%zu %llu %llu %llu %llu %llu %llu\n", i, h[6 * i], h[6 * i + 1], h[6 * i + 2],
                         h[6 * i + 3], h[6 * i + 4], h[6 * i + 5]);
+            fclose(f);
+        }
+    }
+    if (wtrace_path) {   // one line per wave: block wave event...
+        (void)hipStreamSynchronize(stream);
+        std::vector<unsigned long long> h(wtrace_words);
+        (void)hipMemcpy(h.data(), d_wtrace, wtrace_words * 8, hipMemcpyDeviceToHost);
+        if (FILE* f = fopen(wtrace_path, "w")) {
+            for (size_t w = 0; w < wtrace_words / kWtraceSlots; ++w) {
+                fprintf(f, "%zu %zu", w / kWtraceWaves, w % kWtraceWaves);
+                for (uint32_t i = 0; i < kWtraceSlots && h[w * kWtraceSlots + i]; ++i)
+                    fprintf(f, " %llu:%llu", h[w * kWtraceSlots + i] >> 8, h[w * kWtraceSlots + i] & 255);
+                fprintf(f, "\n");
+            }
             fclose(f);
         }
     }
