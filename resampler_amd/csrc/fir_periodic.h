@@ -31,25 +31,29 @@
 namespace rsmp {
 
 constexpr uint32_t kClassTile = 8;
+constexpr uint32_t kMfmaClassTile = 16;   // classes per tile of the matrix-core kernel (M of 16x16x4)
 
 struct PeriodicGeometry {
     bool ok = false;
     uint32_t a = 0, b = 0;       // super period: a input frames -> b output frames
     uint32_t den = 0;            // true period of the phase pattern (b = r * den)
     uint32_t taps = 0;
-    uint32_t row_len = 0;        // taps + max in-tile shift, rounded up to a multiple of 4
-    uint32_t n_tiles = 0;        // ceil(b / 8)
+    uint32_t row_len = 0;        // taps + max in-tile shift, rounded up to whole chunks (8; mfma 16)
+    uint32_t n_tiles = 0;        // ceil(b / class tile); class tile = 8 (vector kernels) or 16 (mfma)
     uint32_t cg = 0;             // channels per lane (1 or 2)
     uint32_t lp = 0;             // lanes per period = channels / cg
     uint32_t pw = 0;             // periods per workgroup (<= 64 / lp)
     uint32_t row_stride = 0;     // LDS dwords between period rows (odd frame count: conflict-free)
     uint32_t waves = 0;          // waves per workgroup
+    uint32_t producers = 0;      // > 0: double-buffered kernel, this many waves only stage
+    uint32_t mfma = 0;           // > 0: matrix-core kernel (16-class tiles); period groups of 16 per work unit
+    uint32_t n_units = 0;        // work units per item: n_tiles (vector kernels) or tiles x unit splits (mfma)
     uint32_t lds_bytes = 0;
     bool inline_wraps = false;   // den >= 8: wrap variant computed inside the kernel
     bool operator==(const PeriodicGeometry& o) const {
         return a == o.a && b == o.b && den == o.den && taps == o.taps && row_len == o.row_len &&
                cg == o.cg && lp == o.lp && pw == o.pw && row_stride == o.row_stride &&
-               waves == o.waves;
+               waves == o.waves && producers == o.producers && mfma == o.mfma;
     }
 };
 
@@ -115,7 +119,7 @@ uint32_t periodic_blocks(const PeriodicGeometry& geo, uint64_t abs_out, uint32_t
 
 // Host build of the class table (exposed for tests).
 struct HostClassTable {
-    std::vector<float> coef;       // [tile][row_len][8]
+    std::vector<float> coef;       // [tile][row_len][8]; mfma: [tile][row_len / 16][64 lanes][4 steps]
     std::vector<float> wrap_coef;  // [tile][row_len]
     std::vector<TileMeta> meta;    // [tile]
 };

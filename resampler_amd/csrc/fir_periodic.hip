@@ -40,6 +40,7 @@ constexpr uint32_t kLdsMax = 160 * 1024;
 
 struct GeoArgs {
     uint32_t a, b, r, row_len, n_tiles, lp, pw, row_stride, waves, channels, xprev_len;
+    uint32_t producers;   // double-buffered kernel: waves that only stage
     uint32_t inline_wraps;
     uint32_t debug;  // RSMP_FIR_DEBUG: bit0 skip staging, bit1 skip the tap loops (timing only)
     uint32_t stagger_ticks;  // one-time start delay of the second workgroup slot (100 MHz ticks)
@@ -50,7 +51,7 @@ struct GeoArgs {
     unsigned long long work_base;       // its value before this launch
 };
 
-constexpr uint32_t kWtraceSlots = 160, kWtraceWaves = 12;
+constexpr uint32_t kWtraceSlots = 160, kWtraceWaves = 16;
 
 typedef const float __attribute__((address_space(4)))* const_f32_ptr;   // scalar-cache loads
 typedef const float __attribute__((address_space(1)))* gconst_f32_ptr;  // global (not flat) loads
@@ -215,19 +216,321 @@ __device__ __forceinline__ void tile_taps_c2(v2f (&acc)[8], v2f& accw, const flo
 // Up to 768 threads = 12 waves (3 per SIMD); two workgroups per CU -> 6 waves per SIMD -> at
 // most 80 VGPRs.
 // C2 = true: exactly two channels, both handled by one lane (CG == 2) -- the headline config.
+// Per-item state of a wave: what a class tile needs beyond its own index.
+struct ItemCtx {
+    const_f32_ptr table, wtable;      // class table, wrap rows
+    const TileMeta* metas;
+    gconst_u32_ptr wrap_bits;
+    g_f32_ptr out;
+    int32_t n_block0;                 // launch-relative output index of (period q0, class 0)
+    int32_t k_block0;                 // wrap-bitmap index of (period q0, class 0)
+    int32_t n_limit;                  // outputs in this launch
+    const float* lane_row;            // LDS: first sample of the lane's period row (+ channel group)
+    const float* xprev;               // LDS: frame in front of each period
+    uint32_t pl_c, gi, lane;
+    bool lane_on;
+};
+
+struct ItemGeom {                     // wave-uniform placement of a work item
+    uint64_t q0;
+    int32_t n_block0, k_block0;
+    bool valid;
+};
+
+__device__ __forceinline__ ItemGeom item_geom(const GeoArgs& geo, const FirStreamDesc& d,
+                                              uint32_t block_idx) {
+    ItemGeom ig;
+    const uint64_t q_first = d.abs_out / geo.b;
+    ig.q0 = q_first + static_cast<uint64_t>(block_idx) * geo.pw;
+    ig.valid = d.n_out != 0 && ig.q0 * geo.b < d.abs_out + d.n_out;
+    // launch-relative index of output (period q0, class 0); fits int32 (n_out < 2^31)
+    ig.n_block0 = static_cast<int32_t>(static_cast<int64_t>(ig.q0 * geo.b) -
+                                       static_cast<int64_t>(d.abs_out));
+    // bit index of (period q0, class 0) in the wrap bitmap
+    ig.k_block0 = static_cast<int32_t>(static_cast<int64_t>(ig.q0 * geo.r) -
+                                       static_cast<int64_t>(d.wrap_k0));
+    return ig;
+}
+
+template <int CG, bool C2>
+__device__ __forceinline__ ItemCtx item_ctx(const GeoArgs& geo, const FirStreamDesc& d,
+                                            const ItemGeom& ig, const float* rows, const float* xprev,
+                                            uint32_t lane) {
+    ItemCtx cx;
+    const uint32_t pl = C2 ? lane : lane / geo.lp;     // period of this lane inside the block
+    cx.gi = C2 ? 0u : lane - pl * geo.lp;              // channel group of this lane
+    cx.lane_on = pl < geo.pw;
+    cx.pl_c = cx.lane_on ? pl : 0;                     // idle lanes shadow lane 0 (no stores)
+    cx.lane = lane;
+    cx.lane_row = rows + cx.pl_c * geo.row_stride + cx.gi * CG;
+    cx.xprev = xprev;
+    cx.table = (const_f32_ptr)(d.class_coef);
+    cx.wtable = (const_f32_ptr)(d.class_wrap_coef);
+    cx.metas = static_cast<const TileMeta*>(d.class_meta);
+    cx.wrap_bits = (gconst_u32_ptr)d.wrap_bits;
+    cx.out = (g_f32_ptr)d.out;
+    cx.n_block0 = ig.n_block0;
+    cx.k_block0 = ig.k_block0;
+    cx.n_limit = static_cast<int32_t>(d.n_out);
+    return cx;
+}
+
+// ---- stage -----------------------------------------------------------------------------------------
+// LDS-DMA (global_load_lds, 4 B per lane): the rows region is filled 256 B per wave instruction
+// straight from [hist|in] with no VGPR round trip.  Wave `part` of `parts` takes every parts-th
+// 64-dword piece.  Source addresses are clamped into the stream; the wave then zeroes the
+// out-of-stream dwords of its own pieces (after they have landed), so stagers never wait for one
+// another.  Returns with the wave's DMA possibly still in flight unless the span touches a stream
+// edge; the caller waits (vmcnt) before publishing the image.
+__device__ __forceinline__ void stage_image(const GeoArgs& geo, const FirStreamDesc& d, uint64_t q0,
+                                            uint32_t C, float* rows, float* xprev, uint32_t part,
+                                            uint32_t parts, uint32_t lane) {
+    const int64_t hist_values = static_cast<int64_t>(d.hist_frames) * C;
+    const int64_t total_values = hist_values + static_cast<int64_t>(d.in_frames) * C;  // > 0
+    gconst_f32_ptr hist = (gconst_f32_ptr)d.hist;
+    gconst_f32_ptr in = (gconst_f32_ptr)d.in;
+    // virtual value index of the span's first sample: absolute frame q0*a minus the frames
+    // retired before this launch, times C
+    const int64_t w_span = (static_cast<int64_t>(q0 * geo.a) - static_cast<int64_t>(d.abs_consumed)) * C;
+    const uint32_t row_values = geo.a * C;
+    const bool flat = geo.row_stride == row_values;   // odd a: rows are back to back
+    const uint32_t region = (geo.pw + 1) * geo.row_stride;
+    // virtual value index feeding LDS dword L of the rows region (pad dwords of even-a rows
+    // re-read the next row's first frame; they are never used)
+    auto w_of = [&](uint32_t L) -> int64_t {
+        if (flat) return w_span + L;
+        const uint32_t p = L / geo.row_stride;
+        return w_span + static_cast<int64_t>(p) * row_values + (L - p * geo.row_stride);
+    };
+    auto src_of = [&](int64_t w) -> gconst_f32_ptr {
+        const int64_t wc = w < 0 ? 0 : (w >= total_values ? total_values - 1 : w);
+        return wc < hist_values ? hist + wc : in + (wc - hist_values);
+    };
+    typedef __attribute__((address_space(3))) void* lds_void_ptr;
+    const int64_t span_values = static_cast<int64_t>(geo.pw + 1) * row_values;
+    const bool edge = w_span < 0 || w_span + span_values > total_values;
+    if (flat && w_span >= hist_values && !edge) {
+        // interior item: the span is one contiguous piece of `in`.  16 bytes per lane: 1 KB per wave
+        // instruction, a quarter of the instructions (the vector memory pipe is shared with the
+        // consumers' loads and stores).  The last, partial piece goes dword-wise.
+        const uint32_t whole = region & ~255u;
+        gconst_f32_ptr src = in + (w_span - hist_values);
+        for (uint32_t base = part * 256; base < whole; base += parts * 256)
+            __builtin_amdgcn_global_load_lds(src + base + lane * 4, (lds_void_ptr)(rows + base), 16, 0, 0);
+        for (uint32_t base = whole + part * 64; base < region; base += parts * 64)
+            if (base + lane < region)
+                __builtin_amdgcn_global_load_lds(src + base + lane, (lds_void_ptr)(rows + base), 4, 0, 0);
+    } else {
+        for (uint32_t base = part * 64; base < region; base += parts * 64) {
+            const uint32_t L = base + lane;
+            if (L < region)
+                __builtin_amdgcn_global_load_lds(src_of(w_of(L)), (lds_void_ptr)(rows + base), 4, 0, 0);
+        }
+    }
+    for (uint32_t e = part * 64 + lane; e < geo.pw * C; e += parts * 64) {
+        const uint32_t p = C == 1 ? e : e / C;
+        const int64_t w = w_span + static_cast<int64_t>(p) * row_values - C + (e - p * C);
+        float val = *src_of(w);
+        if (w < 0 || w >= total_values) val = 0.f;
+        xprev[e] = val;
+    }
+    if (edge) {   // wave-uniform
+        __builtin_amdgcn_s_waitcnt(0);   // own DMA pieces have landed
+        for (uint32_t base = part * 64; base < region; base += parts * 64) {
+            const uint32_t L = base + lane;
+            if (L < region) {
+                const int64_t w = w_of(L);
+                if (w < 0 || w >= total_values) rows[L] = 0.f;
+            }
+        }
+    }
+}
+
+// ---- one class tile: taps, wrap pick, transposed stores -----------------------------------------
 template <int CG, bool C2, int NT>
-__global__ __launch_bounds__(NT == 8 ? 768 : 1024, NT == 8 ? 6 : 8) void fir_periodic_kernel(const FirStreamDesc* __restrict__ descs,
+__device__ __forceinline__ void process_tile(const GeoArgs& geo, const ItemCtx& cx, uint32_t t,
+                                             const TileMeta& tm) {
+    const uint32_t C = C2 ? 2u : geo.channels;
+    const uint32_t j0 = t * kClassTile;
+    const uint32_t ob = tm.base;
+    const_f32_ptr g = cx.table + static_cast<size_t>((geo.debug & 32) ? 0 : t) * geo.row_len * kClassTile;
+    const_f32_ptr gw = cx.wtable + static_cast<size_t>(t) * geo.row_len;
+    const bool has_wrap = geo.inline_wraps && tm.wrap_col >= 0;
+    // window [ob, ob+row_len) of the lane's period row, spilling into the next row
+    const uint32_t n1 = geo.a - ob < geo.row_len ? geo.a - ob : geo.row_len;
+    const int32_t n_lane0 = cx.n_block0 + static_cast<int32_t>(cx.pl_c * geo.b + j0);  // class j0
+    const int32_t n_limit = cx.n_limit;
+    const float* lane_row = cx.lane_row;
+
+    float av[kClassTile][CG];
+    float aw[CG];
+    if constexpr (C2) {
+        v2f acc[8], accw = {0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = v2f{0.f, 0.f};
+        if (!(geo.debug & 2)) {
+            if (has_wrap)
+                tile_taps_c2<true, NT>(acc, accw, lane_row + ob * 2, lane_row + geo.row_stride, n1,
+                                       geo.row_len, g, gw);
+            else
+                tile_taps_c2<false, NT>(acc, accw, lane_row + ob * 2, lane_row + geo.row_stride, n1,
+                                        geo.row_len, g, gw);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { av[i][0] = acc[i].x; av[i][1] = acc[i].y; }
+        aw[0] = accw.x;
+        aw[1] = accw.y;
+    } else {
+        Acc<CG> acc;
+#pragma unroll
+        for (int i = 0; i < (int)kClassTile; ++i)
+#pragma unroll
+            for (int k = 0; k < CG; ++k) acc.v[i][k] = 0.f;
+#pragma unroll
+        for (int k = 0; k < CG; ++k) acc.w[k] = 0.f;
+        if (!(geo.debug & 2)) {
+            if (has_wrap) {
+                accumulate<CG, true>(acc, lane_row + ob * C, C, g, gw, n1);
+                if (n1 < geo.row_len)
+                    accumulate<CG, true>(acc, lane_row + geo.row_stride, C, g + n1 * kClassTile,
+                                         gw + n1, geo.row_len - n1);
+            } else {
+                accumulate<CG, false>(acc, lane_row + ob * C, C, g, gw, n1);
+                if (n1 < geo.row_len)
+                    accumulate<CG, false>(acc, lane_row + geo.row_stride, C, g + n1 * kClassTile,
+                                          gw + n1, geo.row_len - n1);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < (int)kClassTile; ++i)
+#pragma unroll
+            for (int k = 0; k < CG; ++k) av[i][k] = acc.v[i][k];
+#pragma unroll
+        for (int k = 0; k < CG; ++k) aw[k] = acc.w[k];
+    }
+
+    if (has_wrap) {
+        if (tm.extra_col != -2) {
+            float xs[CG];
+            load_x<CG>(xs, tm.extra_col >= 0 ? lane_row + tm.extra_col * C
+                                             : cx.xprev + cx.pl_c * C + cx.gi * CG);
+#pragma unroll
+            for (int k = 0; k < CG; ++k) aw[k] = fmaf(tm.extra_coef, xs[k], aw[k]);
+        }
+        const int32_t nw = n_lane0 + tm.wrap_col;
+        bool take = false;
+        if (nw >= 0 && nw < n_limit) {
+            const uint32_t K = static_cast<uint32_t>(cx.k_block0 + static_cast<int32_t>(cx.pl_c * geo.r + tm.wrap_jd));
+            take = (cx.wrap_bits[K >> 5] >> (K & 31)) & 1u;
+        }
+#pragma unroll
+        for (int i = 0; i < (int)kClassTile; ++i)
+            if (i == tm.wrap_col && take) {
+#pragma unroll
+                for (int k = 0; k < CG; ++k) av[i][k] = aw[k];
+            }
+    }
+
+    // ---- store -------------------------------------------------------------------------------
+    g_f32_ptr out = cx.out;
+    const uint32_t lane = cx.lane;
+    bool done = false;
+    if (geo.debug & 16) {   // timing only: keep the sums alive with one conditional store
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < (int)kClassTile; ++i)
+#pragma unroll
+            for (int k = 0; k < CG; ++k) s += av[i][k];
+        if (s == 12345.678f) out[0] = s;
+        done = true;
+    }
+    if constexpr (C2) {
+        // Quad transpose: lane r of a quad ends up with quarter r (2 frames = 16 B) of the four
+        // periods of the quad; store s then covers period quad_base + s contiguously.
+        const bool full_tile = j0 + kClassTile <= geo.b;
+        const bool mine_full = n_lane0 >= 0 && n_lane0 + (int32_t)kClassTile <= n_limit;
+        const bool mine_none = n_lane0 >= n_limit || n_lane0 + (int32_t)kClassTile <= 0 || !cx.lane_on;
+        const bool partial = !(mine_full || mine_none);
+        if (!done && full_tile && !__any(partial)) {
+            v4f B[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                B[k] = v4f{av[2 * k][0], av[2 * k][1], av[2 * k + 1][0], av[2 * k + 1][1]};
+            const bool odd = lane & 1, hi = lane & 2;
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const v4f s = odd ? B[2 * p] : B[2 * p + 1];
+                const v4f r4 = v4f{dpp_quad_xor1(s.x), dpp_quad_xor1(s.y), dpp_quad_xor1(s.z),
+                                   dpp_quad_xor1(s.w)};
+                if (odd) B[2 * p] = r4; else B[2 * p + 1] = r4;
+            }
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const v4f s = hi ? B[k] : B[k + 2];
+                const v4f r4 = v4f{dpp_quad_xor2(s.x), dpp_quad_xor2(s.y), dpp_quad_xor2(s.z),
+                                   dpp_quad_xor2(s.w)};
+                if (hi) B[k] = r4; else B[k + 2] = r4;
+            }
+            const uint32_t quad_base = lane & ~3u, r = lane & 3u;
+            const int32_t n_quad0 = cx.n_block0 + static_cast<int32_t>(quad_base * geo.b + j0);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int32_t ns = n_quad0 + s * static_cast<int32_t>(geo.b);
+                if (quad_base + s < geo.pw && ns >= 0 && ns + (int32_t)kClassTile <= n_limit) {
+                    typedef v4f __attribute__((address_space(1), aligned(8)))* g_f4a8_ptr;
+                    *((g_f4a8_ptr)(out + static_cast<size_t>(ns) * 2 + r * 4)) = B[s];
+                }
+            }
+            done = true;
+        }
+    }
+    if (!done && cx.lane_on) {
+#pragma unroll
+        for (int i = 0; i < (int)kClassTile; ++i) {
+            const int32_t n = n_lane0 + i;
+            if (j0 + i < geo.b && n >= 0 && n < n_limit) {
+                g_f32_ptr o = out + static_cast<size_t>(n) * C + cx.gi * CG;
+                if constexpr (CG == 2) {
+                    typedef v2f __attribute__((address_space(1)))* g_f2_ptr;
+                    *((g_f2_ptr)o) = v2f{av[i][0], av[i][1]};
+                } else {
+                    o[0] = av[i][0];
+                }
+            }
+        }
+    }
+}
+
+// Diagnostic per-wave event log (RSMP_FIR_WTRACE): (100 MHz timestamp << 8) | tag.
+struct WaveTrace {
+    unsigned long long* base;
+    uint32_t cursor;
+    __device__ __forceinline__ void init(const GeoArgs& geo, uint32_t wave) {
+        base = (geo.wtrace && wave < kWtraceWaves)
+                   ? geo.wtrace + (static_cast<size_t>(blockIdx.x) * kWtraceWaves + wave) * kWtraceSlots
+                   : nullptr;
+        cursor = 0;
+    }
+    __device__ __forceinline__ void event(uint32_t tag) {
+        if (base && cursor < kWtraceSlots) {
+            const unsigned long long v = (__builtin_amdgcn_s_memrealtime() << 8) | tag;
+            if ((threadIdx.x & 63) == 0) base[cursor] = v;
+            ++cursor;
+        }
+    }
+};
+
+// ---- single-image kernel ---------------------------------------------------------------------------
+// One staged image per workgroup, barriers between stage and compute; two workgroups per CU overlap
+// each other's phases.  Used when two images do not fit the 160 KB of LDS (long periods) -- the
+// double-buffered kernel below is the fast path.
+template <int CG, bool C2, int NT>
+__global__ __launch_bounds__(768, 6) void fir_periodic_kernel(const FirStreamDesc* __restrict__ descs,
                                                               GeoArgs geo) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     // Persistent workgroups: the grid is two workgroups per CU and each walks the launch's work
-    // items (stream, period block) with the grid as stride.  A fresh dispatch per block cost
-    // ~10 us of empty LDS slot between workgroups (measured with RSMP_FIR_TRACE) -- a third of
-    // each slot's time.
-    //
-    // All workgroups start together and take equally long, so the two workgroups sharing a CU
-    // would stage (HBM busy, VALU idle) and compute (VALU busy, HBM idle) in lockstep.  Delaying
-    // the second dispatch round once puts the pairs out of phase for the rest of the launch:
-    // one streams while the other computes.  Dispatch order only affects speed, never results.
+    // items (stream, period block).  A fresh dispatch per block cost ~10 us of empty LDS slot
+    // between workgroups (measured with RSMP_FIR_TRACE) -- a third of each slot's time.
     unsigned long long t_trace[4] = {0, 0, 0, 0};
     if (geo.trace) t_trace[0] = __builtin_amdgcn_s_memrealtime();
     if (geo.stagger_ticks && blockIdx.x >= gridDim.x / 2) {
@@ -238,307 +541,69 @@ __global__ __launch_bounds__(NT == 8 ? 768 : 1024, NT == 8 ? 6 : 8) void fir_per
     const uint32_t C = C2 ? 2u : geo.channels;
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // RSMP_FIR_WTRACE (diagnostic): per-wave event log, (100 MHz timestamp << 8) | tag
-    uint32_t ev_cursor = 0;
-    auto event = [&](uint32_t tag) {
-        if (geo.wtrace && ev_cursor < kWtraceSlots && wave < kWtraceWaves) {
-            const unsigned long long v = (__builtin_amdgcn_s_memrealtime() << 8) | tag;
-            if (lane == 0)
-                geo.wtrace[(static_cast<size_t>(blockIdx.x) * kWtraceWaves + wave) * kWtraceSlots + ev_cursor] = v;
-            ++ev_cursor;
-        }
-    };
+    WaveTrace wt;
+    wt.init(geo, wave);
     uint32_t* tile_counter = reinterpret_cast<uint32_t*>(lds);   // next unclaimed class tile
     float* __restrict__ xprev = lds + 4;               // [pw][C]: the frame in front of each period
     float* __restrict__ rows = lds + geo.xprev_len;    // [pw + 1][row_stride]
 
-  // Work items are claimed from a launch-wide queue (one 64-bit counter that only ever grows; the
-  // host passes the value it had before this launch).  Static striding left the younger of the
-  // two workgroups of a CU -- which loses VALU arbitration to the older one -- with a third of
-  // its items still to do after its neighbour had finished.  The claim for the next item is made
-  // while the current one is being staged, so it is never on the critical path.
-  uint32_t* next_item = reinterpret_cast<uint32_t*>(lds) + 1;
-  auto claim = [&]() -> uint32_t {
-      const unsigned long long t = atomicAdd(geo.work_counter, 1ull) - geo.work_base;
-      return t < geo.total_items ? static_cast<uint32_t>(t) : 0xFFFFFFFFu;
-  };
-  if (threadIdx.x == 0) *next_item = claim();
-  __syncthreads();
-  uint32_t item = *next_item;
-  while (item != 0xFFFFFFFFu) {
-    const uint32_t stream_idx = item / geo.blocks_per_stream;
-    const uint32_t block_idx = item - stream_idx * geo.blocks_per_stream;
-    // The descriptor is wave-uniform and read-only: fetch it through the scalar cache.
-    const FirStreamDesc d = load_uniform(descs + stream_idx);
-    const uint32_t n_out = d.n_out;
-    const uint64_t abs_out = d.abs_out;
-    const uint64_t q_first = abs_out / geo.b;
-    const uint64_t q0 = q_first + static_cast<uint64_t>(block_idx) * geo.pw;
-    const bool valid = n_out != 0 && q0 * geo.b < abs_out + n_out;
-    // launch-relative index of output (period q0, class 0); fits int32 (n_out < 2^31)
-    const int32_t n_block0 = static_cast<int32_t>(static_cast<int64_t>(q0 * geo.b) -
-                                                  static_cast<int64_t>(abs_out));
-    event(1);          // item begins (waiting for the other waves)
-    __syncthreads();   // every wave has read `item` and is done with the previous LDS image
-    event(2);
+    // Work items are claimed from a launch-wide queue (one 64-bit counter that only ever grows; the
+    // host passes the value it had before this launch).  Static striding left the younger of the
+    // two workgroups of a CU -- which loses VALU arbitration to the older one -- with a third of
+    // its items still to do after its neighbour had finished.  The claim for the next item is made
+    // while the current one is being staged, so it is never on the critical path.
+    uint32_t* next_item = reinterpret_cast<uint32_t*>(lds) + 1;
+    auto claim = [&]() -> uint32_t {
+        const unsigned long long t = atomicAdd(geo.work_counter, 1ull) - geo.work_base;
+        return t < geo.total_items ? static_cast<uint32_t>(t) : 0xFFFFFFFFu;
+    };
     if (threadIdx.x == 0) *next_item = claim();
-    if (!valid) {      // padding item of a ragged batch
-        __syncthreads();
-        item = *next_item;
-        continue;
-    }
-
-    // ---- stage ---------------------------------------------------------------------------------
-    // LDS-DMA (global_load_lds, 4 B per lane): the rows region is filled 256 B per wave
-    // instruction straight from [hist|in] with no VGPR round trip, so every piece of a wave
-    // (~30) is in flight at once and the other resident workgroup computes meanwhile.  Source
-    // addresses are clamped into the stream; an edge workgroup zeroes the out-of-stream part
-    // afterwards.
-    if (!(geo.debug & 1)) {
-        const int64_t hist_values = static_cast<int64_t>(d.hist_frames) * C;
-        const int64_t total_values = hist_values + static_cast<int64_t>(d.in_frames) * C;  // > 0
-        gconst_f32_ptr hist = (gconst_f32_ptr)d.hist;
-        gconst_f32_ptr in = (gconst_f32_ptr)d.in;
-        // virtual value index of the span's first sample: absolute frame q0*a minus the frames
-        // retired before this launch, times C
-        const int64_t w_span =
-            (static_cast<int64_t>(q0 * geo.a) - static_cast<int64_t>(d.abs_consumed)) * C;
-        const uint32_t row_values = geo.a * C;
-        const bool flat = geo.row_stride == row_values;   // odd a: rows are back to back
-        const uint32_t region = (geo.pw + 1) * geo.row_stride;
-        // virtual value index feeding LDS dword L of the rows region (pad dwords of even-a rows
-        // re-read the next row's first frame; they are never used)
-        auto w_of = [&](uint32_t L) -> int64_t {
-            if (flat) return w_span + L;
-            const uint32_t p = L / geo.row_stride;
-            return w_span + static_cast<int64_t>(p) * row_values + (L - p * geo.row_stride);
-        };
-        auto src_of = [&](int64_t w) -> gconst_f32_ptr {
-            const int64_t wc = w < 0 ? 0 : (w >= total_values ? total_values - 1 : w);
-            return wc < hist_values ? hist + wc : in + (wc - hist_values);
-        };
-        typedef __attribute__((address_space(3))) void* lds_void_ptr;
-        const int64_t span_values = static_cast<int64_t>(geo.pw + 1) * row_values;
-        const bool edge = w_span < 0 || w_span + span_values > total_values;
-        if (flat && w_span >= hist_values && !edge) {
-            // interior workgroup: the span is one contiguous piece of `in`
-            gconst_f32_ptr src = in + (w_span - hist_values) + lane;
-            for (uint32_t base = wave * 64; base < region; base += geo.waves * 64)
-                if (base + lane < region)
-                    __builtin_amdgcn_global_load_lds(src + base, (lds_void_ptr)(rows + base), 4, 0, 0);
-        } else {
-            for (uint32_t base = wave * 64; base < region; base += geo.waves * 64) {
-                const uint32_t L = base + lane;
-                if (L < region)
-                    __builtin_amdgcn_global_load_lds(src_of(w_of(L)), (lds_void_ptr)(rows + base), 4, 0, 0);
-            }
-        }
-        for (uint32_t e = threadIdx.x; e < geo.pw * C; e += blockDim.x) {
-            const uint32_t p = C == 1 ? e : e / C;
-            const int64_t w = w_span + static_cast<int64_t>(p) * row_values - C + (e - p * C);
-            float val = *src_of(w);
-            if (w < 0 || w >= total_values) val = 0.f;
-            xprev[e] = val;
-        }
-        if (edge) {   // workgroup-uniform
-            __builtin_amdgcn_s_waitcnt(0);   // own DMA pieces have landed
-            __syncthreads();
-            for (uint32_t L = threadIdx.x; L < region; L += blockDim.x) {
-                const int64_t w = w_of(L);
-                if (w < 0 || w >= total_values) rows[L] = 0.f;
-            }
-        }
-    }
-    if (threadIdx.x == 0) *tile_counter = 0;
-    event(3);          // staging issued
-    __builtin_amdgcn_s_waitcnt(0);   // vmcnt(0): LDS-DMA is tracked by vmcnt
-    event(4);          // own pieces landed
     __syncthreads();
-    event(5);          // everyone's pieces landed
-
-    if (geo.trace) t_trace[1] = __builtin_amdgcn_s_memrealtime();
-    // ---- compute -------------------------------------------------------------------------------
-    const uint32_t pl = C2 ? lane : lane / geo.lp;   // period of this lane inside the block
-    const uint32_t gi = C2 ? 0u : lane - pl * geo.lp;  // channel group of this lane
-    const bool lane_on = pl < geo.pw;
-    const uint32_t pl_c = lane_on ? pl : 0;          // idle lanes shadow lane 0 (no stores)
-    const float* __restrict__ lane_row = rows + pl_c * geo.row_stride + gi * CG;
-    const_f32_ptr table = (const_f32_ptr)(d.class_coef);
-    const_f32_ptr wtable = (const_f32_ptr)(d.class_wrap_coef);
-    const TileMeta* metas = static_cast<const TileMeta*>(d.class_meta);
-    gconst_u32_ptr wrap_bits = (gconst_u32_ptr)d.wrap_bits;
-    g_f32_ptr out = (g_f32_ptr)d.out;
-    // bit index of (period q0, class 0) in the wrap bitmap
-    const int32_t k_block0 = static_cast<int32_t>(static_cast<int64_t>(q0 * geo.r) -
-                                                  static_cast<int64_t>(d.wrap_k0));
-
-    // Class tiles are claimed dynamically: a workgroup's waves are spread unevenly over the four
-    // SIMDs (and share them with the other resident workgroup), so a static split leaves the
-    // least loaded SIMD idle while the most loaded one finishes.
-    // The claim of the next tile (an LDS atomic) and the fetch of its descriptor are issued while
-    // the current tile computes, so a tile switch exposes neither latency.
-    uint32_t t_claim = 0;
-    if (lane == 0) t_claim = atomicAdd(tile_counter, 1u);
-    uint32_t t = __builtin_amdgcn_readfirstlane(t_claim);
-    TileMeta tm_cur = load_uniform(metas + (t < geo.n_tiles ? t : 0));
-    while (t < geo.n_tiles) {
-        event(6);      // tile begins
-        if (lane == 0) t_claim = atomicAdd(tile_counter, 1u);   // next tile, consumed at the bottom
-        const uint32_t j0 = t * kClassTile;
-        const TileMeta tm = tm_cur;
-        const uint32_t ob = tm.base;
-        const_f32_ptr g = table + static_cast<size_t>((geo.debug & 32) ? 0 : t) * geo.row_len * kClassTile;
-        const_f32_ptr gw = wtable + static_cast<size_t>(t) * geo.row_len;
-        const bool has_wrap = geo.inline_wraps && tm.wrap_col >= 0;
-        // window [ob, ob+row_len) of the lane's period row, spilling into the next row
-        const uint32_t n1 = geo.a - ob < geo.row_len ? geo.a - ob : geo.row_len;
-        const int32_t n_lane0 = n_block0 + static_cast<int32_t>(pl_c * geo.b + j0);  // class j0
-        const int32_t n_limit = static_cast<int32_t>(n_out);
-
-        float av[kClassTile][CG];
-        float aw[CG];
-        if constexpr (C2) {
-            v2f acc[8], accw = {0.f, 0.f};
-#pragma unroll
-            for (int i = 0; i < 8; ++i) acc[i] = v2f{0.f, 0.f};
-            if (!(geo.debug & 2)) {
-                if (has_wrap)
-                    tile_taps_c2<true, NT>(acc, accw, lane_row + ob * 2, lane_row + geo.row_stride, n1,
-                                       geo.row_len, g, gw);
-                else
-                    tile_taps_c2<false, NT>(acc, accw, lane_row + ob * 2, lane_row + geo.row_stride, n1,
-                                        geo.row_len, g, gw);
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) { av[i][0] = acc[i].x; av[i][1] = acc[i].y; }
-            aw[0] = accw.x;
-            aw[1] = accw.y;
-        } else {
-            Acc<CG> acc;
-#pragma unroll
-            for (int i = 0; i < (int)kClassTile; ++i)
-#pragma unroll
-                for (int k = 0; k < CG; ++k) acc.v[i][k] = 0.f;
-#pragma unroll
-            for (int k = 0; k < CG; ++k) acc.w[k] = 0.f;
-            if (!(geo.debug & 2)) {
-                if (has_wrap) {
-                    accumulate<CG, true>(acc, lane_row + ob * C, C, g, gw, n1);
-                    if (n1 < geo.row_len)
-                        accumulate<CG, true>(acc, lane_row + geo.row_stride, C, g + n1 * kClassTile,
-                                             gw + n1, geo.row_len - n1);
-                } else {
-                    accumulate<CG, false>(acc, lane_row + ob * C, C, g, gw, n1);
-                    if (n1 < geo.row_len)
-                        accumulate<CG, false>(acc, lane_row + geo.row_stride, C, g + n1 * kClassTile,
-                                              gw + n1, geo.row_len - n1);
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < (int)kClassTile; ++i)
-#pragma unroll
-                for (int k = 0; k < CG; ++k) av[i][k] = acc.v[i][k];
-#pragma unroll
-            for (int k = 0; k < CG; ++k) aw[k] = acc.w[k];
+    uint32_t item = *next_item;
+    while (item != 0xFFFFFFFFu) {
+        const uint32_t stream_idx = item / geo.blocks_per_stream;
+        const uint32_t block_idx = item - stream_idx * geo.blocks_per_stream;
+        // The descriptor is wave-uniform and read-only: fetch it through the scalar cache.
+        const FirStreamDesc d = load_uniform(descs + stream_idx);
+        const ItemGeom ig = item_geom(geo, d, block_idx);
+        wt.event(1);          // item begins (waiting for the other waves)
+        __syncthreads();      // every wave has read `item` and is done with the previous LDS image
+        wt.event(2);
+        if (threadIdx.x == 0) *next_item = claim();
+        if (!ig.valid) {      // padding item of a ragged batch
+            __syncthreads();
+            item = *next_item;
+            continue;
         }
+        if (!(geo.debug & 1)) stage_image(geo, d, ig.q0, C, rows, xprev, wave, geo.waves, lane);
+        if (threadIdx.x == 0) *tile_counter = 0;
+        wt.event(3);          // staging issued
+        __builtin_amdgcn_s_waitcnt(0);   // vmcnt(0): LDS-DMA is tracked by vmcnt
+        wt.event(4);          // own pieces landed
+        __syncthreads();
+        wt.event(5);          // everyone's pieces landed
+        if (geo.trace) t_trace[1] = __builtin_amdgcn_s_memrealtime();
 
-        event(7);      // taps done
-        const uint32_t t_next = __builtin_amdgcn_readfirstlane(t_claim);
-        const TileMeta tm_next = load_uniform(metas + (t_next < geo.n_tiles ? t_next : 0));
-        if (has_wrap) {
-            if (tm.extra_col != -2) {
-                float xs[CG];
-                load_x<CG>(xs, tm.extra_col >= 0 ? lane_row + tm.extra_col * C
-                                                 : xprev + pl_c * C + gi * CG);
-#pragma unroll
-                for (int k = 0; k < CG; ++k) aw[k] = fmaf(tm.extra_coef, xs[k], aw[k]);
-            }
-            const int32_t nw = n_lane0 + tm.wrap_col;
-            bool take = false;
-            if (nw >= 0 && nw < n_limit) {
-                const uint32_t K = static_cast<uint32_t>(k_block0 + static_cast<int32_t>(pl_c * geo.r + tm.wrap_jd));
-                take = (wrap_bits[K >> 5] >> (K & 31)) & 1u;
-            }
-#pragma unroll
-            for (int i = 0; i < (int)kClassTile; ++i)
-                if (i == tm.wrap_col && take) {
-#pragma unroll
-                    for (int k = 0; k < CG; ++k) av[i][k] = aw[k];
-                }
+        const ItemCtx cx = item_ctx<CG, C2>(geo, d, ig, rows, xprev, lane);
+        // Class tiles are claimed dynamically: a workgroup's waves are spread unevenly over the
+        // four SIMDs (and share them with the other resident workgroup), so a static split leaves
+        // the least loaded SIMD idle while the most loaded one finishes.  The claim of the next
+        // tile (an LDS atomic) and the fetch of its descriptor are issued while the current tile
+        // computes, so a tile switch exposes neither latency.
+        uint32_t t_claim = 0;
+        if (lane == 0) t_claim = atomicAdd(tile_counter, 1u);
+        uint32_t t = __builtin_amdgcn_readfirstlane(t_claim);
+        TileMeta tm_cur = load_uniform(cx.metas + (t < geo.n_tiles ? t : 0));
+        while (t < geo.n_tiles) {
+            wt.event(6);      // tile begins
+            if (lane == 0) t_claim = atomicAdd(tile_counter, 1u);   // next tile, consumed below
+            process_tile<CG, C2, NT>(geo, cx, t, tm_cur);
+            wt.event(7);      // tile done (stores issued)
+            t = __builtin_amdgcn_readfirstlane(t_claim);
+            tm_cur = load_uniform(cx.metas + (t < geo.n_tiles ? t : 0));
         }
-
-        // ---- store ---------------------------------------------------------------------------
-        bool done = false;
-        if (geo.debug & 16) {   // timing only: keep the sums alive with one conditional store
-            float s = 0.f;
-#pragma unroll
-            for (int i = 0; i < (int)kClassTile; ++i)
-#pragma unroll
-                for (int k = 0; k < CG; ++k) s += av[i][k];
-            if (s == 12345.678f) out[0] = s;
-            done = true;
-        }
-        if constexpr (C2) {
-            // Quad transpose: lane r of a quad ends up with quarter r (2 frames = 16 B) of the four
-            // periods of the quad; store s then covers period quad_base + s contiguously.
-            const bool full_tile = j0 + kClassTile <= geo.b;
-            const bool mine_full = n_lane0 >= 0 && n_lane0 + (int32_t)kClassTile <= n_limit;
-            const bool mine_none = n_lane0 >= n_limit || n_lane0 + (int32_t)kClassTile <= 0 || !lane_on;
-            const bool partial = !(mine_full || mine_none);
-            if (full_tile && !__any(partial)) {
-                v4f B[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k)
-                    B[k] = v4f{av[2 * k][0], av[2 * k][1], av[2 * k + 1][0], av[2 * k + 1][1]};
-                const bool odd = lane & 1, hi = lane & 2;
-#pragma unroll
-                for (int p = 0; p < 2; ++p) {
-                    const v4f s = odd ? B[2 * p] : B[2 * p + 1];
-                    const v4f r4 = v4f{dpp_quad_xor1(s.x), dpp_quad_xor1(s.y), dpp_quad_xor1(s.z),
-                                       dpp_quad_xor1(s.w)};
-                    if (odd) B[2 * p] = r4; else B[2 * p + 1] = r4;
-                }
-#pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    const v4f s = hi ? B[k] : B[k + 2];
-                    const v4f r4 = v4f{dpp_quad_xor2(s.x), dpp_quad_xor2(s.y), dpp_quad_xor2(s.z),
-                                       dpp_quad_xor2(s.w)};
-                    if (hi) B[k] = r4; else B[k + 2] = r4;
-                }
-                const uint32_t quad_base = lane & ~3u, r = lane & 3u;
-                const int32_t n_quad0 = n_block0 + static_cast<int32_t>(quad_base * geo.b + j0);
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const int32_t ns = n_quad0 + s * static_cast<int32_t>(geo.b);
-                    if (quad_base + s < geo.pw && ns >= 0 && ns + (int32_t)kClassTile <= n_limit) {
-                        typedef v4f __attribute__((address_space(1), aligned(8)))* g_f4a8_ptr;
-                        *((g_f4a8_ptr)(out + static_cast<size_t>(ns) * 2 + r * 4)) = B[s];
-                    }
-                }
-                done = true;
-            }
-        }
-        if (!done && lane_on && !(geo.debug & 16)) {
-#pragma unroll
-            for (int i = 0; i < (int)kClassTile; ++i) {
-                const int32_t n = n_lane0 + i;
-                if (j0 + i < geo.b && n >= 0 && n < n_limit) {
-                    g_f32_ptr o = out + static_cast<size_t>(n) * C + gi * CG;
-                    if constexpr (CG == 2) {
-                        typedef v2f __attribute__((address_space(1)))* g_f2_ptr;
-                        *((g_f2_ptr)o) = v2f{av[i][0], av[i][1]};
-                    } else {
-                        o[0] = av[i][0];
-                    }
-                }
-            }
-        }
-        t = t_next;
-        tm_cur = tm_next;
-        event(8);      // stores issued
-    }
-    item = *next_item;   // written before the barrier that preceded the tile loop
-  }   // items
+        item = *next_item;   // written before the barrier that preceded the tile loop
+    }   // items
     if (geo.trace) {
         t_trace[2] = __builtin_amdgcn_s_memrealtime();
         __builtin_amdgcn_s_waitcnt(0);   // stores acknowledged
@@ -551,6 +616,366 @@ __global__ __launch_bounds__(NT == 8 ? 768 : 1024, NT == 8 ? 6 : 8) void fir_per
             rec[0] = t_trace[0]; rec[1] = t_trace[1]; rec[2] = t_trace[2]; rec[3] = t_trace[3];
             rec[4] = hw_id; rec[5] = xcc;
         }
+    }
+}
+
+// ---- matrix-core work unit -----------------------------------------------------------------------
+// The polyphase sum of one 16-class tile over 16 periods of one channel is a 16 x K x 16 product
+// (classes x window taps x periods): D = A * B with A[class][tap] the tile's shifted, zero-padded,
+// phase-mixed coefficients and B[tap][period] the period rows in LDS.  v_mfma_f32_16x16x4_f32 does
+// 1024 exact f32 FMAs (bitwise an fmaf chain over the 4 taps) in 32 SIMD cycles -- the packed-FMA
+// peak, but issued by ONE instruction instead of eight, with operands from VGPRs instead of the
+// scalar cache, so two waves per SIMD keep the pipe full where the vector kernel needs six and still
+// stalls.  Operand layout of the instruction (lane l): A = coef[class l % 16][tap 4c + l / 16],
+// B = x[tap 4c + l / 16][period l % 16], D = 4 registers = classes 4 * (l / 16) + 0..3 of period
+// l % 16 -- four consecutive output frames, i.e. with both channels 32 contiguous bytes per lane and
+// 128 per period: the stores need no transpose.
+//   A: the class table is stored in operand order [tile][step][lane] -> one coalesced 256-byte
+//      global load per step, L2 resident (92 KB), prefetched 4-8 steps ahead;
+//   B: one ds_read_b64 (both channels of a frame) per 16-period group and step feeds two MFMAs.
+// A work unit = one tile x G groups of 16 periods (G = 2: 20 units per 160-class item).
+// Wrapped outputs (exact position an integer, f64 position just below) are left to
+// fir_wrap_fixup_kernel, as for every geometry without the inline wrap variant.
+typedef __attribute__((address_space(1))) const float* gptr_f32;
+
+// A-operand registers of a consumer wave: three sets of four steps.  The coefficient stream runs
+// 8-12 steps ahead of the MFMAs and straight across unit boundaries (the next unit is claimed
+// while the current one runs), so a unit never starts by waiting for its first coefficients.  A set
+// is refilled right after its last use and needed again two blocks later.  The window length is
+// padded to a multiple of three blocks (48 taps, zero coefficients), so every unit starts on set 0
+// and the loop body is one branch-free basic block: no register copies (which would have to wait
+// for the youngest load) and exact s_waitcnt counts from the compiler.
+struct MfmaPipe {
+    float a[3][4];
+    bool primed;      // sets 0, 1, 2 hold blocks 0, 1, 2 of the unit about to run
+};
+
+// FLAT: period rows are back to back in LDS (odd a), so a window that runs past its row simply
+// continues in the next one and a step's LDS offset is a compile-time immediate.
+template <int G, bool FLAT, int DBG>
+__device__ __forceinline__ void process_unit_mfma(const GeoArgs& geo, const ItemCtx& cx,
+                                                  const float* rows, uint32_t unit, uint32_t ob,
+                                                  MfmaPipe& pipe, uint32_t unit_next, bool has_next,
+                                                  WaveTrace& wt) {
+    constexpr uint32_t H = 4 / G;                      // units per tile
+    const uint32_t T = unit / H, h = unit - T * H;
+    const uint32_t lane = cx.lane;
+    const uint32_t k = lane >> 4, pi = lane & 15;
+    const uint32_t n_steps = geo.row_len >> 2, n_blocks = n_steps >> 2;   // a multiple of 3
+    // taps of the window that lie in the lane's own period row; the rest continue in the next row
+    const uint32_t n1 = geo.a - ob < geo.row_len ? geo.a - ob : geo.row_len;
+    const uint32_t jump = geo.row_stride - geo.a * 2;  // dwords skipped between two period rows
+    // first step at which this lane's tap (4c + k) has crossed into the next row
+    const uint32_t c_jump = n1 > k ? (n1 - k + 3) >> 2 : 0;
+
+    const float* xbase[G];
+    bool p_on[G];
+    uint32_t p_idx[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const uint32_t pl = 16 * (G * h + g) + pi;
+        p_on[g] = pl < geo.pw;
+        p_idx[g] = pl;
+        xbase[g] = rows + (p_on[g] ? pl : 0) * geo.row_stride + 2 * (ob + k);
+    }
+    // Coefficients: wave-uniform base pointer (SGPR pair) + lane offset; the stream moves on to the
+    // next unit's table when this one's blocks are exhausted.
+    gptr_f32 tab = (gptr_f32)(cx.table);
+    const uint32_t tile_floats = n_steps * 64;
+    gptr_f32 a_ptr = tab + static_cast<size_t>(T) * tile_floats;
+    gptr_f32 a_next = has_next ? tab + static_cast<size_t>(unit_next / H) * tile_floats : a_ptr;
+    uint32_t a_blk = 0;   // block the stream pointer stands at
+    auto load_a = [&](float (&dst)[4]) {
+        if constexpr (DBG & 1) {   // timing experiment: one hot 256-byte line
+#pragma unroll
+            for (uint32_t s = 0; s < 4; ++s) dst[s] = tab[lane];
+            return;
+        }
+        typedef const v4f __attribute__((address_space(1)))* gptr_v4f;
+        const v4f v = ((gptr_v4f)a_ptr)[lane];   // four steps of this lane: one 1 KB wave load
+        dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+        ++a_blk;
+        a_ptr = a_blk == n_blocks ? a_next : a_ptr + 256;
+    };
+
+    v4f acc[G][2];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        acc[g][0] = v4f{0.f, 0.f, 0.f, 0.f};
+        acc[g][1] = v4f{0.f, 0.f, 0.f, 0.f};
+    }
+    // samples of step c (c may run up to three steps past the window: those values are never used;
+    // the image is padded so that the reads stay inside it)
+    auto load_b = [&](v2f (&x)[G], uint32_t c_var, uint32_t c_imm) {
+        if constexpr (DBG & 2) {   // timing experiment: no LDS reads
+#pragma unroll
+            for (int g = 0; g < G; ++g) x[g] = v2f{1.f + c_imm, 2.f};
+            return;
+        }
+        if constexpr (FLAT) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) x[g] = *reinterpret_cast<const v2f*>(xbase[g] + 8 * c_imm);
+        } else {
+            const uint32_t c = c_var + c_imm;
+            const uint32_t off = 8 * c + (c >= c_jump ? jump : 0);
+#pragma unroll
+            for (int g = 0; g < G; ++g) x[g] = *reinterpret_cast<const v2f*>(xbase[g] + off);
+        }
+    };
+    if (pipe.primed) {
+        a_blk = 3;
+        a_ptr += 3 * 256;
+        if (n_blocks == 3) a_ptr = a_next;
+    } else {
+        load_a(pipe.a[0]);
+        load_a(pipe.a[1]);
+        load_a(pipe.a[2]);
+    }
+    // samples: a ring of four steps, loaded three steps ahead of their MFMAs; four steps per block,
+    // so the ring position of a step is static as well
+    v2f x[4][G];
+    load_b(x[0], 0, 0);
+    load_b(x[1], 0, 1);
+    load_b(x[2], 0, 2);
+    wt.event(20);   // operands requested
+    for (uint32_t blk = 0; blk < n_blocks; blk += 3) {
+#pragma unroll
+        for (uint32_t u = 0; u < 3; ++u) {
+#pragma unroll
+            for (uint32_t s = 0; s < 4; ++s) {
+                load_b(x[(s + 3) & 3], 4 * blk, 4 * u + s + 3);
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    acc[g][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(pipe.a[u][s], x[s][g].x, acc[g][0], 0, 0, 0);
+                    acc[g][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(pipe.a[u][s], x[s][g].y, acc[g][1], 0, 0, 0);
+                }
+            }
+            // keep the refill here: the scheduler otherwise sinks all twelve loads to the loop end,
+            // where the next iteration immediately waits for them
+            __builtin_amdgcn_sched_barrier(0);
+            load_a(pipe.a[u]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (FLAT) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) xbase[g] += 96;   // 12 steps x 4 frames x 2 channels
+        }
+    }
+    pipe.primed = has_next;
+    wt.event(21);   // MFMAs issued
+
+    // ---- store: lane = (period, 4 consecutive classes), both channels -> 32 contiguous bytes -------
+    g_f32_ptr out = cx.out;
+    const uint32_t j0 = T * kMfmaClassTile + 4 * k;
+    if (geo.debug & 16) {
+        float s = 0.f;
+#pragma unroll
+        for (int g = 0; g < G; ++g) s += acc[g][0].x + acc[g][1].y + acc[g][0].z + acc[g][1].w;
+        if (s == 12345.678f) out[0] = s;
+        return;
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        if (!p_on[g]) continue;
+        const int32_t n0 = cx.n_block0 + static_cast<int32_t>(p_idx[g] * geo.b + j0);
+        const v4f lo = v4f{acc[g][0].x, acc[g][1].x, acc[g][0].y, acc[g][1].y};
+        const v4f hi = v4f{acc[g][0].z, acc[g][1].z, acc[g][0].w, acc[g][1].w};
+        if (j0 + 4 <= geo.b && n0 >= 0 && n0 + 4 <= cx.n_limit) {
+            typedef v4f __attribute__((address_space(1), aligned(8)))* g_f4a8_ptr;
+            g_f4a8_ptr o = (g_f4a8_ptr)(out + static_cast<size_t>(n0) * 2);
+            o[0] = lo;
+            o[1] = hi;
+        } else {
+            const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int32_t n = n0 + r;
+                if (j0 + r < geo.b && n >= 0 && n < cx.n_limit) {
+                    typedef v2f __attribute__((address_space(1)))* g_f2_ptr;
+                    *((g_f2_ptr)(out + static_cast<size_t>(n) * 2)) = v2f{v[2 * r], v[2 * r + 1]};
+                }
+            }
+        }
+    }
+}
+
+// ---- double-buffered kernel ------------------------------------------------------------------------
+// One 16-wave workgroup per CU owning two LDS images.  The first `producers` waves only stage:
+// wait until every consumer has left an image, claim the next work item, DMA it in, publish it.
+// The other waves only compute: class tiles of the published image are claimed one at a time, and
+// a wave that finds none left moves straight on to the other image -- no workgroup barrier anywhere,
+// so staging, the uneven progress of the waves (the SIMD arbiter favours the oldest) and the tile
+// count not dividing the wave count cost nothing as long as an image is staged (~4-7 us) faster
+// than its tiles are consumed (~14 us).
+//
+// LDS control words (u32): [0..1] tile_counter per image, [2..3] consumers that have left the
+// image (cumulative over its uses), [4..5] sequence number + 1 of the item the image holds,
+// [6..7] its work item (or kNoItem), [8..9] producers finished staging (cumulative),
+// [10..11] sequence + 1 of the item whose id has been posted (for the other producers).
+constexpr uint32_t kNoItem = 0xFFFFFFFFu;
+constexpr uint32_t kDbCtrlWords = 16;
+// floats per image (frame-before-period block + rows), a 16-byte multiple
+__host__ __device__ inline uint32_t db_image_len(uint32_t xprev_len, uint32_t pw, uint32_t row_stride) {
+    // + 32: the matrix-core units prefetch up to three steps (24 dwords) past a window's end
+    return (xprev_len + (pw + 1) * row_stride + 32 + 3) / 4 * 4;
+}
+
+__device__ __forceinline__ uint32_t lds_load_acquire(uint32_t* p) {
+    return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void lds_store_release(uint32_t* p, uint32_t v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+template <int CG, bool C2, int NT, int MF>
+__global__ __launch_bounds__(1024) void fir_periodic_db_kernel(const FirStreamDesc* __restrict__ descs,
+                                                               GeoArgs geo) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const uint32_t C = C2 ? 2u : geo.channels;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    WaveTrace wt;
+    wt.init(geo, wave);
+    uint32_t* ctrl = reinterpret_cast<uint32_t*>(lds);
+    uint32_t* tile_counter = ctrl, *left = ctrl + 2, *ready = ctrl + 4, *item_id = ctrl + 6;
+    uint32_t* staged = ctrl + 8, *posted = ctrl + 10;
+    const uint32_t image_len = db_image_len(geo.xprev_len, geo.pw, geo.row_stride);
+    if (threadIdx.x < kDbCtrlWords) ctrl[threadIdx.x] = 0;
+    __syncthreads();   // the only workgroup barrier
+
+    const uint32_t producers = geo.producers, consumers = geo.waves - geo.producers;
+    if (wave < producers) {
+        // ---- producer ----------------------------------------------------------------------------
+        __builtin_amdgcn_s_setprio(3);   // mostly asleep; when it has work, that work gates everyone
+        for (uint32_t s = 0;; ++s) {
+            const uint32_t b = s & 1;
+            float* xprev = lds + kDbCtrlWords + b * image_len;
+            float* rows = xprev + geo.xprev_len;
+            wt.event(11);
+            // every consumer has left the image's previous use (s - 2)
+            while (lds_load_acquire(left + b) != consumers * (s >> 1)) __builtin_amdgcn_s_sleep(8);
+            wt.event(12);
+            uint32_t item = kNoItem;
+            FirStreamDesc d;
+            ItemGeom ig;
+            if (wave == 0) {
+                // claim work items until one is real (ragged batches pad with empty ones)
+                for (;;) {
+                    unsigned long long tkt = 0;
+                    if (lane == 0) tkt = atomicAdd(geo.work_counter, 1ull) - geo.work_base;
+                    const uint32_t lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(tkt));
+                    const uint32_t hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(tkt >> 32));
+                    if (hi != 0 || lo >= geo.total_items) { item = kNoItem; break; }
+                    item = lo;
+                    const uint32_t stream_idx = item / geo.blocks_per_stream;
+                    d = load_uniform(descs + stream_idx);
+                    ig = item_geom(geo, d, item - stream_idx * geo.blocks_per_stream);
+                    if (ig.valid) break;
+                }
+                if (lane == 0) {
+                    item_id[b] = item;
+                    tile_counter[b] = 0;
+                }
+                lds_store_release(posted + b, s + 1);
+            } else {
+                while (lds_load_acquire(posted + b) != s + 1) __builtin_amdgcn_s_sleep(2);
+                item = __builtin_amdgcn_readfirstlane(item_id[b]);
+                if (item != kNoItem) {
+                    const uint32_t stream_idx = item / geo.blocks_per_stream;
+                    d = load_uniform(descs + stream_idx);
+                    ig = item_geom(geo, d, item - stream_idx * geo.blocks_per_stream);
+                }
+            }
+            if (item != kNoItem && !(geo.debug & 1))
+                stage_image(geo, d, ig.q0, C, rows, xprev, wave, producers, lane);
+            wt.event(13);
+            __builtin_amdgcn_s_waitcnt(0);   // DMA (vmcnt) and LDS stores (lgkmcnt) of this wave are done
+            wt.event(14);
+            uint32_t n = 0;
+            if (lane == 0) n = __hip_atomic_fetch_add(staged + b, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+            n = __builtin_amdgcn_readfirstlane(n);
+            if (n + 1 == producers * ((s >> 1) + 1)) lds_store_release(ready + b, s + 1);   // last one publishes
+            if (item == kNoItem) break;
+        }
+        return;
+    }
+
+    // ---- consumer --------------------------------------------------------------------------------
+    for (uint32_t s = 0;; ++s) {
+        const uint32_t b = s & 1;
+        const float* xprev = lds + kDbCtrlWords + b * image_len;
+        const float* rows = xprev + geo.xprev_len;
+        wt.event(1);
+        while (lds_load_acquire(ready + b) != s + 1) __builtin_amdgcn_s_sleep(2);
+        wt.event(2);
+        const uint32_t item = __builtin_amdgcn_readfirstlane(item_id[b]);
+        if (item == kNoItem) break;
+        const uint32_t stream_idx = item / geo.blocks_per_stream;
+        const FirStreamDesc d = load_uniform(descs + stream_idx);
+        const ItemGeom ig = item_geom(geo, d, item - stream_idx * geo.blocks_per_stream);
+        const ItemCtx cx = item_ctx<CG, C2>(geo, d, ig, rows, xprev, lane);
+        if constexpr (MF == 0) {
+            uint32_t t_claim = 0;
+            if (lane == 0) t_claim = atomicAdd(tile_counter + b, 1u);
+            uint32_t t = __builtin_amdgcn_readfirstlane(t_claim);
+            TileMeta tm_cur = load_uniform(cx.metas + (t < geo.n_tiles ? t : 0));
+            while (t < geo.n_tiles) {
+                wt.event(6);
+                // The image is free again only when its last tile is done, and the SIMD arbiter
+                // serves the oldest wave first: a young wave that picks up one of the last tiles
+                // would hold the image for several tile times while everyone else has moved on.
+                // Late tiles therefore run at raised priority (the later, the higher); the next
+                // image's first tiles yield.
+                const uint32_t from_end = geo.n_tiles - 1 - t;
+                if (from_end < 3) __builtin_amdgcn_s_setprio(3);
+                else if (from_end < 6) __builtin_amdgcn_s_setprio(2);
+                else if (from_end < 9) __builtin_amdgcn_s_setprio(1);
+                else __builtin_amdgcn_s_setprio(0);
+                if (lane == 0) t_claim = atomicAdd(tile_counter + b, 1u);   // next tile, consumed below
+                process_tile<CG, C2, NT>(geo, cx, t, tm_cur);
+                wt.event(7);
+                t = __builtin_amdgcn_readfirstlane(t_claim);
+                tm_cur = load_uniform(cx.metas + (t < geo.n_tiles ? t : 0));
+            }
+            __builtin_amdgcn_s_setprio(0);
+        } else {
+            // Matrix-core units.  Two claims are kept in flight: the unit after the current one must
+            // be known when the current one starts (its first coefficients are requested by the
+            // current unit's last blocks), and the claim's LDS round trip should never be waited for.
+            constexpr uint32_t H = 4 / (MF & 15);
+            uint32_t c1 = 0, c2 = 0;
+            if (lane == 0) {
+                c1 = atomicAdd(tile_counter + b, 1u);
+                c2 = atomicAdd(tile_counter + b, 1u);
+            }
+            uint32_t t = __builtin_amdgcn_readfirstlane(c1);
+            uint32_t t_next = __builtin_amdgcn_readfirstlane(c2);
+            uint32_t ob = t < geo.n_tiles ? load_uniform(cx.metas + t / H).base : 0;
+            MfmaPipe pipe;
+            pipe.primed = false;
+            while (t < geo.n_tiles) {
+                wt.event(6);
+                const uint32_t from_end = geo.n_tiles - 1 - t;   // see above
+                if (from_end < 3) __builtin_amdgcn_s_setprio(3);
+                else if (from_end < 6) __builtin_amdgcn_s_setprio(2);
+                else if (from_end < 9) __builtin_amdgcn_s_setprio(1);
+                else __builtin_amdgcn_s_setprio(0);
+                if (lane == 0) c2 = atomicAdd(tile_counter + b, 1u);   // the unit after the next
+                const bool more = t_next < geo.n_tiles;
+                const uint32_t ob_next = more ? load_uniform(cx.metas + t_next / H).base : 0;
+                if (geo.row_stride == 2 * geo.a)
+                    process_unit_mfma<(MF & 15), true, (MF >> 4)>(geo, cx, rows, t, ob, pipe, t_next, more, wt);
+                else
+                    process_unit_mfma<(MF & 15), false, (MF >> 4)>(geo, cx, rows, t, ob, pipe, t_next, more, wt);
+                wt.event(7);
+                t = t_next;
+                ob = ob_next;
+                t_next = __builtin_amdgcn_readfirstlane(c2);
+            }
+            __builtin_amdgcn_s_setprio(0);
+        }
+        // this wave's reads of image b have all returned (their values were consumed above)
+        if (lane == 0) __hip_atomic_fetch_add(left + b, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
 }
 
@@ -606,8 +1031,8 @@ GeoArgs to_args(const PeriodicGeometry& g) {
         return static_cast<uint32_t>((e ? atof(e) : 12.0) * 100.0);
     }();
     const uint32_t channels = g.lp * g.cg;
-    return GeoArgs{g.a, g.b, g.b / g.den, g.row_len, g.n_tiles, g.lp, g.pw, g.row_stride, g.waves,
-                   channels, xprev_len_of(g.pw, channels), g.inline_wraps ? 1u : 0u, debug, stagger, nullptr, nullptr, 0u, 0u, nullptr, 0ull};
+    return GeoArgs{g.a, g.b, g.b / g.den, g.row_len, g.mfma ? g.n_units : g.n_tiles, g.lp, g.pw, g.row_stride, g.waves,
+                   channels, xprev_len_of(g.pw, channels), g.producers, g.inline_wraps ? 1u : 0u, debug, stagger, nullptr, nullptr, 0u, 0u, nullptr, 0ull};
 }
 
 // Device class tables, shared by every stream on a device with the same polyphase table, rate
@@ -615,11 +1040,11 @@ GeoArgs to_args(const PeriodicGeometry& g) {
 struct ClassTableKey {
     int device;
     const void* table;
-    uint32_t den, a, b, row_len;
+    uint32_t den, a, b, row_len, mfma;
     uint64_t drift_bits;
     bool operator<(const ClassTableKey& o) const {
-        return std::tie(device, table, den, a, b, row_len, drift_bits) <
-               std::tie(o.device, o.table, o.den, o.a, o.b, o.row_len, o.drift_bits);
+        return std::tie(device, table, den, a, b, row_len, mfma, drift_bits) <
+               std::tie(o.device, o.table, o.den, o.a, o.b, o.row_len, o.mfma, o.drift_bits);
     }
 };
 struct ClassTableCache {
@@ -639,31 +1064,53 @@ inline uint32_t class_offset(const PeriodicGeometry& g, uint32_t j) {
 
 }  // namespace
 
-PeriodicGeometry periodic_geometry(uint64_t num, uint64_t den, uint32_t taps, uint32_t channels) {
+namespace {
+// RSMP_FIR_MFMA: 0 = vector kernels only, 2 / 4 = matrix-core kernel with that many 16-period
+// groups per work unit.  Two interleaved channels only.  Off by default until the wrap variant
+// is computed inside the kernel (the fix-up launch costs more than the kernel gains).
+int mfma_knob() {
+    static const int knob = [] {
+        const char* e = getenv("RSMP_FIR_MFMA");
+        return e ? atoi(e) : 0;
+    }();
+    return knob;
+}
+
+PeriodicGeometry geometry_for(uint64_t num, uint64_t den, uint32_t taps, uint32_t channels,
+                              bool want_mfma) {
     PeriodicGeometry g;
     if (num == 0 || den == 0 || channels == 0 || channels > 64) return g;
     if (num > (1u << 20) || den > (1u << 20)) return g;
-    // max in-tile shift: off(j) = floor(j*num/den); tiles start at multiples of 8.
-    const uint32_t shift = static_cast<uint32_t>((7 * num + den - 1) / den);
+    const int knob_mfma = mfma_knob();
+    const uint32_t ct = want_mfma ? kMfmaClassTile : kClassTile;
+    // max in-tile shift: off(j) = floor(j*num/den); tiles start at multiples of the class tile.
+    const uint32_t shift = static_cast<uint32_t>(((ct - 1) * num + den - 1) / den);
     g.taps = taps;
     g.den = static_cast<uint32_t>(den);
-    g.row_len = (taps + shift + 7) / 8 * 8;   // whole 8-tap chunks (fir_periodic_kernel)
-    // super period: a >= row_len (a window spans at most two rows) and b >= 8
+    // whole 8-tap chunks (fir_periodic_kernel) / three blocks of four 4-tap MFMA steps
+    g.row_len = want_mfma ? (taps + shift + 47) / 48 * 48 : (taps + shift + 7) / 8 * 8;
+    // super period: a >= row_len (a window spans at most two rows) and b >= one class tile
     uint64_t r = (g.row_len + num - 1) / num;
-    if (den * r < kClassTile) r = (kClassTile + den - 1) / den;
+    if (den * r < ct) r = (ct + den - 1) / den;
     const uint64_t a = num * r, b = den * r;
     if (a > 4096 || b > (1u << 16)) return g;
     g.a = static_cast<uint32_t>(a);
     g.b = static_cast<uint32_t>(b);
-    g.n_tiles = (g.b + kClassTile - 1) / kClassTile;
-    g.inline_wraps = den >= kClassTile;
+    g.n_tiles = (g.b + ct - 1) / ct;
+    g.n_units = g.n_tiles;
+    g.inline_wraps = !want_mfma && den >= kClassTile;
 
+    static const int knob_db = [] {   // RSMP_FIR_PRODUCERS: 0 = single-image kernel, n = n producers
+        const char* e = getenv("RSMP_FIR_PRODUCERS");
+        return e ? atoi(e) : -1;
+    }();
     auto fit = [&](uint32_t cg) -> bool {
         if (channels % cg != 0) return false;
         const uint32_t lp = channels / cg;
         if (lp > 64) return false;
         const uint32_t pw_max = 64 / lp;
-        // odd number of frames per row: the lane stride then hits every LDS bank once
+        // odd number of frames per row: the lane stride then hits every LDS bank once (and with two
+        // channels per lane, 2 * odd dwords keeps every lane's ds_read_b64 8-byte aligned)
         const uint32_t stride = (g.a | 1u) * channels;
         const uint32_t row_bytes = stride * 4;
         const uint32_t fixed = (64 * channels + 16) * 4;  // xprev
@@ -671,28 +1118,62 @@ PeriodicGeometry periodic_geometry(uint64_t num, uint64_t den, uint32_t taps, ui
             if (budget <= fixed + 2 * row_bytes) return 0;
             return (budget - fixed) / row_bytes - 1;
         };
-        uint32_t pw = rows_in(kLdsTwoPerCu);
+        g.cg = cg;
+        g.lp = lp;
+        g.row_stride = stride;
+        // Fast path: two images in one workgroup (fir_periodic_db_kernel), if that keeps >= 75 % of
+        // the lanes busy.
+        uint32_t pw = rows_in((kLdsMax - kDbCtrlWords * 4) / 2 - 16);
+        if (pw > pw_max) pw = pw_max;
+        if ((knob_db != 0 || want_mfma) && pw * 4 >= pw_max * 3) {
+            g.pw = pw;
+            g.producers = knob_db > 0 && knob_db < 8 ? static_cast<uint32_t>(knob_db) : 4u;
+            g.lds_bytes = (kDbCtrlWords + 2 * db_image_len(xprev_len_of(pw, channels), pw, stride)) * 4;
+            if (want_mfma) {
+                // two consumer waves per SIMD keep the matrix pipe busy; more only add arbitration
+                static const int knob_consumers = [] {
+                    const char* e = getenv("RSMP_FIR_MFMA_CONSUMERS");
+                    const int v = e ? atoi(e) : 8;
+                    return v >= 1 && v <= 12 ? v : 8;
+                }();
+                g.mfma = static_cast<uint32_t>(knob_mfma);
+                g.n_units = g.n_tiles * (4 / g.mfma);
+                g.waves = g.producers + static_cast<uint32_t>(knob_consumers);
+            } else {
+                g.waves = 16;
+            }
+            return true;
+        }
+        if (want_mfma) return false;   // periodic_geometry() retries with the vector kernels
+        pw = rows_in(kLdsTwoPerCu);
         if (pw * 4 < pw_max * 3) pw = rows_in(kLdsMax);  // < 75% of the lanes: use the whole LDS
         if (pw > pw_max) pw = pw_max;
         if (pw * 2 < pw_max || pw == 0) return false;
-        g.cg = cg;
-        g.lp = lp;
         g.pw = pw;
-        g.row_stride = stride;
+        g.producers = 0;
         g.lds_bytes = (xprev_len_of(pw, channels) + (pw + 1) * stride) * 4;
+        // waves per workgroup: a multiple of the 4 SIMDs, at most 12 (__launch_bounds__(768, 6));
+        // tiles are claimed dynamically, so the count need not divide n_tiles
+        g.waves = g.n_tiles >= 12 ? 12u : (g.n_tiles >= 8 ? 8u : 4u);
+        if (const char* e = getenv("RSMP_FIR_WAVES")) {   // tuning knob (4..12)
+            const int w = atoi(e);
+            if (w >= 1 && w <= 12) g.waves = static_cast<uint32_t>(w);
+        }
         return true;
     };
     if (!fit(2) && !fit(1)) return g;
-    // waves per workgroup: a multiple of the 4 SIMDs, at most 12 (__launch_bounds__(768, 6));
-    // tiles are claimed dynamically, so the count need not divide n_tiles
-    uint32_t best = g.n_tiles >= 12 ? 12u : (g.n_tiles >= 8 ? 8u : 4u);
-    if (const char* e = getenv("RSMP_FIR_WAVES")) {   // tuning knob (4..12)
-        const int w = atoi(e);
-        if (w >= 1 && w <= 12) best = static_cast<uint32_t>(w);
-    }
-    g.waves = best;
     g.ok = true;
     return g;
+}
+}  // namespace
+
+PeriodicGeometry periodic_geometry(uint64_t num, uint64_t den, uint32_t taps, uint32_t channels) {
+    const int knob = mfma_knob();
+    if (channels == 2 && (knob == 2 || knob == 4)) {
+        const PeriodicGeometry g = geometry_for(num, den, taps, channels, true);
+        if (g.ok) return g;   // else: two images do not fit the LDS for this rate pair
+    }
+    return geometry_for(num, den, taps, channels, false);
 }
 
 bool periodic_supported(const FirMirror& m, size_t channels, size_t taps, int kernel_mode) {
@@ -735,8 +1216,9 @@ void periodic_fill_wrap_bits(const std::vector<uint32_t>& wraps, uint64_t abs_ou
 HostClassTable build_class_table(const std::vector<float>& coeffs, const PeriodicGeometry& g,
                                  double drift) {
     const uint32_t taps = g.taps;
+    const uint32_t ct = g.mfma ? kMfmaClassTile : kClassTile;
     HostClassTable out;
-    out.coef.assign(static_cast<size_t>(g.n_tiles) * g.row_len * kClassTile, 0.0f);
+    out.coef.assign(static_cast<size_t>(g.n_tiles) * g.row_len * ct, 0.0f);
     out.wrap_coef.assign(static_cast<size_t>(g.n_tiles) * g.row_len, 0.0f);
     out.meta.resize(g.n_tiles);
     std::vector<float> mixed(taps);
@@ -744,12 +1226,12 @@ HostClassTable build_class_table(const std::vector<float>& coeffs, const Periodi
     for (uint32_t t = 0; t < g.n_tiles; ++t) {
         TileMeta& tm = out.meta[t];
         std::memset(&tm, 0, sizeof tm);
-        const uint32_t j0 = t * kClassTile;
+        const uint32_t j0 = t * ct;
         tm.base = class_offset(g, j0);
         tm.wrap_col = -1;
         tm.extra_col = -2;
-        float* base = out.coef.data() + static_cast<size_t>(t) * g.row_len * kClassTile;
-        for (uint32_t i = 0; i < kClassTile && j0 + i < g.b; ++i) {
+        float* base = out.coef.data() + static_cast<size_t>(t) * g.row_len * ct;
+        for (uint32_t i = 0; i < ct && j0 + i < g.b; ++i) {
             const uint32_t j = j0 + i;
             // exact fractional position of class j, plus the stream's current f64 drift
             const uint64_t rem = (static_cast<uint64_t>(j) * g.a) % g.b;
@@ -767,6 +1249,15 @@ HostClassTable build_class_table(const std::vector<float>& coeffs, const Periodi
             const float omf = 1.0f - frac;
             for (uint32_t k = 0; k < taps; ++k) mixed[k] = c1[k] * omf + c2[k] * frac;  // avx.rs:41-45
             const uint32_t shift = class_offset(g, j) - tm.base;
+            if (g.mfma) {
+                // A-operand order of v_mfma_f32_16x16x4_f32 (lane = 16 * (tap % 4) + class), four
+                // steps of a lane adjacent: [block = tap / 16][lane][step = (tap / 4) % 4]
+                for (uint32_t k = 0; k < taps; ++k) {
+                    const uint32_t m = k + shift;
+                    base[(m >> 4) * 256 + ((m & 3) * 16 + i) * 4 + ((m >> 2) & 3)] = mixed[k];
+                }
+                continue;
+            }
             for (uint32_t k = 0; k < taps; ++k) base[(k + shift) * kClassTile + i] = mixed[k];
 
             if (g.inline_wraps && j % g.den == 0) {
@@ -805,7 +1296,8 @@ int periodic_bind(PeriodicState& st, int device, const std::vector<float>& table
     std::lock_guard<std::mutex> lock(cache.mu);
     uint64_t bits;
     std::memcpy(&bits, &drift, sizeof bits);
-    const ClassTableKey key{device, table.data(), st.geo.den, st.geo.a, st.geo.b, st.geo.row_len, bits};
+    const ClassTableKey key{device, table.data(), st.geo.den, st.geo.a, st.geo.b, st.geo.row_len,
+                            st.geo.mfma ? 1u : 0u, bits};
     auto it = cache.tables.find(key);
     if (it == cache.tables.end()) {
         const HostClassTable host = build_class_table(table, st.geo, drift);
@@ -857,7 +1349,7 @@ hipError_t launch_fir_periodic(const FirStreamDesc* d_descs, uint32_t n_streams,
         }
         cus = c;
     }
-    const uint32_t slots = cus * (geo.lds_bytes > kLdsTwoPerCu ? 1u : 2u);
+    const uint32_t slots = cus * (geo.lds_bytes > kLdsTwoPerCu ? 1u : 2u);   // workgroups that fit
     const dim3 grid(args.total_items < slots ? args.total_items : slots);
     args.work_counter = d_work_counter;
     args.work_base = *work_base;
@@ -883,13 +1375,28 @@ hipError_t launch_fir_periodic(const FirStreamDesc* d_descs, uint32_t n_streams,
     // Dynamic LDS above 64 KiB must be opted into, once per kernel and device.
     static std::mutex mu;
     static std::map<std::pair<int, int>, bool> granted;
-    // variants: 0 = two channels, one lane per period; 1 = CG 2, any even channel count; 2 = CG 1.
+    // variants: 0 = two channels, one lane per period; 1 = CG 2, any even channel count; 2 = CG 1;
+    // +3 for the double-buffered kernel; 6 / 7 = matrix-core consumers (2 / 4 period groups per unit).
     // (4-tap chunks with 16-wave workgroups at 8 waves per SIMD measured 13 % slower than 8-tap
-    // chunks with 12 waves: the 64-VGPR cap spills.)
-    const int variant = geo.cg == 2 ? (geo.lp == 1 ? 0 : 1) : 2;
-    const void* fns[3] = {reinterpret_cast<const void*>(fir_periodic_kernel<2, true, 8>),
+    // chunks: the 64-VGPR cap spills.)
+    static const int mfma_dbg = [] {   // RSMP_FIR_MFMA_DBG: 1 hot coefficient line, 2 no LDS reads, 3 both
+        const char* e = getenv("RSMP_FIR_MFMA_DBG");
+        const int v = e ? atoi(e) : 0;
+        return v >= 0 && v <= 3 ? v : 0;
+    }();
+    const int variant = geo.mfma ? (geo.mfma == 2 ? (mfma_dbg ? 7 + mfma_dbg : 6) : 7)
+                                 : (geo.cg == 2 ? (geo.lp == 1 ? 0 : 1) : 2) + (geo.producers ? 3 : 0);
+    const void* fns[11] = {reinterpret_cast<const void*>(fir_periodic_kernel<2, true, 8>),
                           reinterpret_cast<const void*>(fir_periodic_kernel<2, false, 8>),
-                          reinterpret_cast<const void*>(fir_periodic_kernel<1, false, 8>)};
+                          reinterpret_cast<const void*>(fir_periodic_kernel<1, false, 8>),
+                          reinterpret_cast<const void*>(fir_periodic_db_kernel<2, true, 8, 0>),
+                          reinterpret_cast<const void*>(fir_periodic_db_kernel<2, false, 8, 0>),
+                          reinterpret_cast<const void*>(fir_periodic_db_kernel<1, false, 8, 0>),
+                          reinterpret_cast<const void*>(fir_periodic_db_kernel<2, true, 8, 2>),
+                          reinterpret_cast<const void*>(fir_periodic_db_kernel<2, true, 8, 4>),
+                          reinterpret_cast<const void*>(fir_periodic_db_kernel<2, true, 8, 2 + 16>),
+                          reinterpret_cast<const void*>(fir_periodic_db_kernel<2, true, 8, 2 + 32>),
+                          reinterpret_cast<const void*>(fir_periodic_db_kernel<2, true, 8, 2 + 48>)};
     {
         std::lock_guard<std::mutex> lock(mu);
         bool& have = granted[{device, variant}];
@@ -910,12 +1417,9 @@ hipError_t launch_fir_periodic(const FirStreamDesc* d_descs, uint32_t n_streams,
                 geo.a, geo.b, geo.row_len, geo.n_tiles, geo.cg, geo.lp, geo.pw, geo.row_stride,
                 geo.waves, geo.lds_bytes, args.total_items, grid.x, blocks);
     }
-    if (variant == 0)
-        hipLaunchKernelGGL((fir_periodic_kernel<2, true, 8>), grid, block, geo.lds_bytes, stream, d_descs, args);
-    else if (variant == 1)
-        hipLaunchKernelGGL((fir_periodic_kernel<2, false, 8>), grid, block, geo.lds_bytes, stream, d_descs, args);
-    else
-        hipLaunchKernelGGL((fir_periodic_kernel<1, false, 8>), grid, block, geo.lds_bytes, stream, d_descs, args);
+    void* kargs[2] = {&d_descs, &args};
+    e = hipLaunchKernel(fns[variant], grid, block, kargs, geo.lds_bytes, stream);
+    if (e != hipSuccess) return e;
     if (trace_path) {
         (void)hipStreamSynchronize(stream);
         std::vector<unsigned long long> h(trace_words);

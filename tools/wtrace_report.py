@@ -2,8 +2,9 @@
 """Summarise an RSMP_FIR_WTRACE dump of fir_periodic_kernel (diagnostic; not part of the product).
 
 Each line of the dump is `block wave t:tag ...` with 100 MHz timestamps.  Tags: 1 item begins,
-2 first barrier passed, 3 staging issued, 4 own DMA landed, 5 staging barrier passed, 6 tile
-begins, 7 taps done, 8 stores issued.  Prints where the wave time goes.
+2 first barrier passed / image ready, 3 staging issued, 4 own DMA landed, 5 staging barrier
+passed, 6 tile begins, 7 tile done; producers of the double-buffered kernel: 11 wait for a free
+image, 12 free, 13 DMA issued, 14 landed.  Prints where the wave time goes.
 """
 import sys
 from collections import defaultdict
@@ -20,6 +21,16 @@ NAMES = {
     (8, 1): "item switch",
     (2, 1): "padding item",
     (5, 1): "item without tile",
+    (7, 6): "tile switch",
+    (7, 1): "item switch",
+    (2, 6): "item setup",
+    (6, 20): "unit setup",
+    (20, 21): "unit MFMA loop",
+    (21, 7): "unit epilogue",
+    (11, 12): "producer: wait image free",
+    (12, 13): "producer: claim + issue DMA",
+    (13, 14): "producer: wait landed",
+    (14, 11): "producer: publish",
 }
 
 
