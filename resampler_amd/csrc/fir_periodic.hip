@@ -41,6 +41,7 @@ constexpr uint32_t kLdsMax = 160 * 1024;
 struct GeoArgs {
     uint32_t a, b, r, row_len, n_tiles, lp, pw, row_stride, waves, channels, xprev_len;
     uint32_t producers;   // double-buffered kernel: waves that only stage
+    uint32_t den;         // true period of the phase pattern (b = r * den)
     uint32_t inline_wraps;
     uint32_t debug;  // RSMP_FIR_DEBUG: bit0 skip staging, bit1 skip the tap loops (timing only)
     uint32_t stagger_ticks;  // one-time start delay of the second workgroup slot (100 MHz ticks)
@@ -227,6 +228,7 @@ struct ItemCtx {
     int32_t n_limit;                  // outputs in this launch
     const float* lane_row;            // LDS: first sample of the lane's period row (+ channel group)
     const float* xprev;               // LDS: frame in front of each period
+    uint32_t wrap_tag;                // matrix-core path: image index | (item sequence + 1) << 1
     uint32_t pl_c, gi, lane;
     bool lane_on;
 };
@@ -264,6 +266,7 @@ __device__ __forceinline__ ItemCtx item_ctx(const GeoArgs& geo, const FirStreamD
     cx.lane = lane;
     cx.lane_row = rows + cx.pl_c * geo.row_stride + cx.gi * CG;
     cx.xprev = xprev;
+    cx.wrap_tag = 0;
     cx.table = (const_f32_ptr)(d.class_coef);
     cx.wtable = (const_f32_ptr)(d.class_wrap_coef);
     cx.metas = static_cast<const TileMeta*>(d.class_meta);
@@ -638,6 +641,45 @@ __global__ __launch_bounds__(768, 6) void fir_periodic_kernel(const FirStreamDes
 // fir_wrap_fixup_kernel, as for every geometry without the inline wrap variant.
 typedef __attribute__((address_space(1))) const float* gptr_f32;
 
+// ---- store of a matrix-core unit: lane = (period, 4 consecutive classes), both channels -> 32
+// contiguous bytes per lane, 128 per period: no transpose ------------------------------------------
+template <int G>
+__device__ __forceinline__ void mfma_store_unit(const GeoArgs& geo, const ItemCtx& cx,
+                                                const v4f (&acc)[G][2], const bool (&p_on)[G],
+                                                const uint32_t (&p_idx)[G], uint32_t j0) {
+    g_f32_ptr out = cx.out;
+    if (geo.debug & 16) {
+        float s = 0.f;
+#pragma unroll
+        for (int g = 0; g < G; ++g) s += acc[g][0].x + acc[g][1].y + acc[g][0].z + acc[g][1].w;
+        if (s == 12345.678f) out[0] = s;
+        return;
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        if (!p_on[g]) continue;
+        const int32_t n0 = cx.n_block0 + static_cast<int32_t>(p_idx[g] * geo.b + j0);
+        const v4f lo = v4f{acc[g][0].x, acc[g][1].x, acc[g][0].y, acc[g][1].y};
+        const v4f hi = v4f{acc[g][0].z, acc[g][1].z, acc[g][0].w, acc[g][1].w};
+        if (j0 + 4 <= geo.b && n0 >= 0 && n0 + 4 <= cx.n_limit) {
+            typedef v4f __attribute__((address_space(1), aligned(8)))* g_f4a8_ptr;
+            g_f4a8_ptr o = (g_f4a8_ptr)(out + static_cast<size_t>(n0) * 2);
+            o[0] = lo;
+            o[1] = hi;
+        } else {
+            const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int32_t n = n0 + r;
+                if (j0 + r < geo.b && n >= 0 && n < cx.n_limit) {
+                    typedef v2f __attribute__((address_space(1)))* g_f2_ptr;
+                    *((g_f2_ptr)(out + static_cast<size_t>(n) * 2)) = v2f{v[2 * r], v[2 * r + 1]};
+                }
+            }
+        }
+    }
+}
+
 // A-operand registers of a consumer wave: three sets of four steps.  The coefficient stream runs
 // 8-12 steps ahead of the MFMAs and straight across unit boundaries (the next unit is claimed
 // while the current one runs), so a unit never starts by waiting for its first coefficients.  A set
@@ -764,39 +806,294 @@ __device__ __forceinline__ void process_unit_mfma(const GeoArgs& geo, const Item
     pipe.primed = has_next;
     wt.event(21);   // MFMAs issued
 
-    // ---- store: lane = (period, 4 consecutive classes), both channels -> 32 contiguous bytes -------
-    g_f32_ptr out = cx.out;
-    const uint32_t j0 = T * kMfmaClassTile + 4 * k;
-    if (geo.debug & 16) {
-        float s = 0.f;
+    mfma_store_unit<G>(geo, cx, acc, p_on, p_idx, T * kMfmaClassTile + 4 * k);
+}
+
+constexpr uint32_t kNoItem = 0xFFFFFFFFu;
+constexpr uint32_t kDbCtrlWords = 32;   // 16 control words + two item posts
+// floats per image (frame-before-period block + rows), a 16-byte multiple
+__host__ __device__ inline uint32_t db_image_len(uint32_t xprev_len, uint32_t pw, uint32_t row_stride) {
+    // + 96: the matrix-core units prefetch up to 11 steps (88 dwords) past a window's end
+    return (xprev_len + (pw + 1) * row_stride + 96 + 3) / 4 * 4;
+}
+
+__device__ __forceinline__ uint32_t lds_load_acquire(uint32_t* p) {
+    return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void lds_store_release(uint32_t* p, uint32_t v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// Sample ring of the pipelined matrix-core units: kRing steps, loaded kRing - 1 steps ahead of their
+// MFMAs.  Must divide 12 (the window is a multiple of 12 steps) so that a step's ring slot is the
+// same in every unit.
+constexpr uint32_t kRing = 4;
+// Wrap classes per super period the matrix-core path handles inside the kernel (b = r * den, r <= this).
+constexpr uint32_t kMfmaWrapMax = 2;
+constexpr uint32_t kMfmaWrapWords = kMfmaWrapMax * 64 * 4;   // per image: {ch0, ch1, take, -} per period
+
+// Everything about a unit that can be computed ahead of its MFMAs.
+template <int G>
+struct MfmaUnit {
+    const float* xbase[G];   // LDS: the lane's sample of step 0 (tap k of period pi of group g)
+    g_f32_ptr out[G];        // where the lane's 4 frames x 2 channels go
+    uint32_t mode[G];        // 0 nothing to store, 1 all four frames in range, 2 some of them
+    int32_t n0[G];           // launch-relative index of the lane's first output frame
+    uint32_t j0;             // first of the lane's four classes
+    uint32_t c_jump;         // (padded rows only) first step at which the lane's tap is in the next row
+    uint32_t tile, unit;
+    // 0, or for a tile holding a wrap class: 1 | image << 1 | wrap index << 2 | class-in-tile << 4 |
+    // (item sequence + 1) << 8 -- where a producer leaves the wrap results and how to tell they are there
+    uint32_t wrap;
+    bool fast;               // wave-uniform: every lane stores all four frames of every group
+    gptr_f32 table;          // the item's class table (streams of one launch may differ in drift)
+    int32_t n_limit;         // outputs of the item's stream in this launch
+};
+
+// The addressing of a unit, in three pieces so that it can be spread over several MFMA gaps.
+template <int G>
+__device__ __forceinline__ void mfma_unit_setup_common(MfmaUnit<G>& u, const GeoArgs& geo,
+                                                       const ItemCtx& cx, uint32_t unit,
+                                                       uint32_t& ob, uint32_t& h) {
+    constexpr uint32_t H = 4 / G;                      // units per tile
+    const uint32_t T = unit / H;
+    h = unit - T * H;
+    const uint32_t k = cx.lane >> 4;
+    // first frame of the tile's window: floor(16 T a / b), < 2^16 * 2^12 (32-bit math)
+    ob = (T * kMfmaClassTile * geo.a) / geo.b;
+    // taps of the window that lie in the lane's own period row; the rest continue in the next row
+    const uint32_t n1 = geo.a - ob < geo.row_len ? geo.a - ob : geo.row_len;
+    u.c_jump = n1 > k ? (n1 - k + 3) >> 2 : 0;
+    u.tile = T;
+    u.unit = unit;
+    u.fast = true;
+    // classes i * den (i < r <= kMfmaWrapMax) have an integer exact position: their outputs may take
+    // the wrap variant, which a producer wave has left in LDS (den >= 16: at most one per tile)
+    u.wrap = 0;
+    if (geo.inline_wraps && !(geo.debug & 2048)) {
 #pragma unroll
-        for (int g = 0; g < G; ++g) s += acc[g][0].x + acc[g][1].y + acc[g][0].z + acc[g][1].w;
-        if (s == 12345.678f) out[0] = s;
+        for (uint32_t i = 0; i < kMfmaWrapMax; ++i) {
+            const uint32_t jw = i * geo.den;
+            if (i < geo.r && jw / kMfmaClassTile == T)
+                u.wrap = 1u | (cx.wrap_tag & 1u) << 1 | i << 2 | (jw % kMfmaClassTile) << 4 | (cx.wrap_tag >> 1) << 8;
+        }
+    }
+    u.table = (gptr_f32)(cx.table);
+    u.n_limit = cx.n_limit;
+    u.j0 = T * kMfmaClassTile + 4 * k;
+}
+
+template <int G>
+__device__ __forceinline__ void mfma_unit_setup_group(MfmaUnit<G>& u, int g, const GeoArgs& geo,
+                                                      const ItemCtx& cx, const float* rows, uint32_t ob,
+                                                      uint32_t h) {
+    const uint32_t k = cx.lane >> 4, pi = cx.lane & 15;
+    const uint32_t pl = 16 * (G * h + g) + pi;
+    const bool on = pl < geo.pw;
+    u.xbase[g] = rows + (on ? pl : 0) * geo.row_stride + 2 * (ob + k);
+    const int32_t n0 = cx.n_block0 + static_cast<int32_t>(pl * geo.b + u.j0);
+    u.n0[g] = n0;
+    u.out[g] = cx.out + static_cast<int64_t>(n0) * 2;
+    const bool all = u.j0 + 4 <= geo.b && n0 >= 0 && n0 + 4 <= cx.n_limit;
+    const bool none = u.j0 >= geo.b || n0 + 4 <= 0 || n0 >= cx.n_limit;
+    u.mode[g] = !on || none ? 0u : (all ? 1u : 2u);
+    u.fast = u.fast && __all(u.mode[g] == 1);
+}
+
+template <int G>
+__device__ __forceinline__ MfmaUnit<G> mfma_unit_setup(const GeoArgs& geo, const ItemCtx& cx,
+                                                      const float* rows, uint32_t unit) {
+    MfmaUnit<G> u;
+    uint32_t ob, h;
+    mfma_unit_setup_common<G>(u, geo, cx, unit, ob, h);
+#pragma unroll
+    for (int g = 0; g < G; ++g) mfma_unit_setup_group<G>(u, g, geo, cx, rows, ob, h);
+    return u;
+}
+
+// Sums of a finished unit waiting to be stored: the stores (a 4 x 2 register shuffle and two
+// dwordx4 per group) are issued inside the NEXT unit's MFMA stream.
+template <int G>
+struct MfmaPending {
+    v4f acc[G][2];
+    MfmaUnit<G> unit;
+    bool valid;
+};
+
+// lane = (period, 4 consecutive classes), both channels -> 32 contiguous bytes per lane, 128 per
+// period: no transpose
+// Inside an MFMA stream every taken branch costs an instruction refetch during which the wave issues
+// nothing (about 50 cycles; fifteen of them per unit cost 20 % of the pipe).  The common case -- every
+// lane of the wave stores all its frames -- is therefore one predictable, not-taken test and
+// straight-line stores; stream edges take the slow path.
+template <int G>
+__device__ __forceinline__ void mfma_store_pending_group(const GeoArgs& geo, const MfmaPending<G>& pend, int g) {
+    const MfmaUnit<G>& u = pend.unit;
+    if (__builtin_expect(pend.valid && u.fast && !u.wrap && !(geo.debug & 16), 1)) {
+        const v4f a0 = pend.acc[g][0], a1 = pend.acc[g][1];
+        typedef v4f __attribute__((address_space(1), aligned(8)))* g_f4a8_ptr;
+        g_f4a8_ptr o = (g_f4a8_ptr)(u.out[g]);
+        o[0] = v4f{a0.x, a1.x, a0.y, a1.y};
+        o[1] = v4f{a0.z, a1.z, a0.w, a1.w};
         return;
     }
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-        if (!p_on[g]) continue;
-        const int32_t n0 = cx.n_block0 + static_cast<int32_t>(p_idx[g] * geo.b + j0);
-        const v4f lo = v4f{acc[g][0].x, acc[g][1].x, acc[g][0].y, acc[g][1].y};
-        const v4f hi = v4f{acc[g][0].z, acc[g][1].z, acc[g][0].w, acc[g][1].w};
-        if (j0 + 4 <= geo.b && n0 >= 0 && n0 + 4 <= cx.n_limit) {
-            typedef v4f __attribute__((address_space(1), aligned(8)))* g_f4a8_ptr;
-            g_f4a8_ptr o = (g_f4a8_ptr)(out + static_cast<size_t>(n0) * 2);
-            o[0] = lo;
-            o[1] = hi;
-        } else {
-            const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int32_t n = n0 + r;
-                if (j0 + r < geo.b && n >= 0 && n < cx.n_limit) {
-                    typedef v2f __attribute__((address_space(1)))* g_f2_ptr;
-                    *((g_f2_ptr)(out + static_cast<size_t>(n) * 2)) = v2f{v[2 * r], v[2 * r + 1]};
-                }
+    if (!pend.valid) return;
+    if (geo.debug & 16) {
+        const float s = pend.acc[g][0].x + pend.acc[g][1].y + pend.acc[g][0].z + pend.acc[g][1].w;
+        if (s == 12345.678f) u.out[0][0] = s;
+        return;
+    }
+    v4f a0 = pend.acc[g][0], a1 = pend.acc[g][1];
+    if (u.wrap) {   // wave-uniform: this tile holds a class whose outputs may take the wrap variant
+        // (computed by a producer after it published the image; long done by now as a rule)
+        extern __shared__ __attribute__((aligned(16))) float lds_base[];
+        const uint32_t wb = (u.wrap >> 1) & 1, wi = (u.wrap >> 2) & 3, wc = (u.wrap >> 4) & 15, wseq = u.wrap >> 8;
+        uint32_t* flag = reinterpret_cast<uint32_t*>(lds_base) + 12 + wb;
+        while ((lds_load_acquire(flag) & 0xFFFFFFu) != wseq) __builtin_amdgcn_s_sleep(1);
+        const float* wv = lds_base + kDbCtrlWords + 2 * db_image_len(geo.xprev_len, geo.pw, geo.row_stride) +
+                          wb * kMfmaWrapWords + wi * (64 * 4);
+        const uint32_t lane = threadIdx.x & 63;
+        constexpr uint32_t H = 4 / G;
+        const uint32_t pl = 16 * (G * (u.unit % H) + g) + (lane & 15);   // the lane's period in the image
+        if ((lane >> 4) == (wc >> 2) && u.mode[g] != 0) {
+            const v4f w = *reinterpret_cast<const v4f*>(wv + pl * 4);
+            if (__float_as_uint(w.z) != 0u) {
+                const uint32_t wr = wc & 3;
+                if (wr == 0) { a0.x = w.x; a1.x = w.y; }
+                else if (wr == 1) { a0.y = w.x; a1.y = w.y; }
+                else if (wr == 2) { a0.z = w.x; a1.z = w.y; }
+                else { a0.w = w.x; a1.w = w.y; }
             }
         }
     }
+    const v4f lo = v4f{a0.x, a1.x, a0.y, a1.y};
+    const v4f hi = v4f{a0.z, a1.z, a0.w, a1.w};
+    if (u.mode[g] == 1) {
+        typedef v4f __attribute__((address_space(1), aligned(8)))* g_f4a8_ptr;
+        g_f4a8_ptr o = (g_f4a8_ptr)(u.out[g]);
+        o[0] = lo;
+        o[1] = hi;
+    } else if (u.mode[g] == 2) {
+        const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int32_t n = u.n0[g] + r;
+            if (u.j0 + r < geo.b && n >= 0 && n < u.n_limit) {
+                typedef v2f __attribute__((address_space(1)))* g_f2_ptr;
+                *((g_f2_ptr)(u.out[g] + 2 * r)) = v2f{v[2 * r], v[2 * r + 1]};
+            }
+        }
+    }
+}
+
+template <int G>
+__device__ __forceinline__ void mfma_store_pending(const GeoArgs& geo, MfmaPending<G>& pend) {
+#pragma unroll
+    for (int g = 0; g < G; ++g) mfma_store_pending_group<G>(geo, pend, g);
+    pend.valid = false;
+}
+
+// Register-resident, software-pipelined variant for windows of 12 * NB3 steps (<= 192 taps).
+//  * The whole coefficient tile of a unit (3 * NB3 dwordx4 per lane) sits in registers.  As soon as
+//    a block has been used, its register is refilled with the same block of the NEXT unit's tile --
+//    requested a full unit time (2-5 us) before its first use.  The vector memory pipe is shared
+//    with the producers' LDS-DMA (HBM misses) and with the output stores (vmcnt is in order: a load
+//    issued after a store also waits for that store), so a ring that runs only ~1000 cycles ahead
+//    stalls on both; here every coefficient load is older than the stores that precede its use.
+//  * The next unit's addressing (an integer division, LDS and output addresses, range checks) and
+//    its first three sample loads are issued INSIDE this unit's MFMA stream.  While one wave of a
+//    SIMD streams MFMAs, the other wave's vector instructions hardly get issued (measured: its
+//    "setup" lasted exactly as long as the partner's MFMA burst), so work left between two
+//    bursts is not hidden by the partner; inside the burst it rides in the MFMAs' own shadow.
+template <int NB3>
+struct MfmaTileRegs {
+    v4f a[3 * NB3];
+    bool primed;      // a[] holds (or is about to receive) the tile of the unit about to run
+};
+
+template <int G, bool FLAT, int NB3>
+__device__ __forceinline__ void mfma_unit_run(const GeoArgs& geo, const ItemCtx& cx, const float* rows,
+                                              const MfmaUnit<G>& cur, MfmaUnit<G>& nxt,
+                                              v2f (&x)[kRing][G], MfmaTileRegs<NB3>& regs,
+                                              MfmaPending<G>& pend, uint32_t unit_next, bool has_next,
+                                              WaveTrace& wt) {
+    constexpr uint32_t H = 4 / G;
+    constexpr uint32_t kBlocks = 3 * NB3, kSteps = 4 * kBlocks;
+    typedef const v4f __attribute__((address_space(1)))* gptr_v4f;
+    const uint32_t jump = geo.row_stride - geo.a * 2;  // dwords skipped between two period rows
+    // `cx` and `rows` are those of the NEXT unit's item (the same as this one's except across an
+    // item boundary); everything about the current unit is in `cur`.
+    if (!regs.primed) {
+        gptr_v4f src = (gptr_v4f)(cur.table + static_cast<size_t>(cur.tile) * (kSteps * 64)) + cx.lane;
+#pragma unroll
+        for (uint32_t j = 0; j < kBlocks; ++j) regs.a[j] = src[j * 64];
+    }
+    // refill source: the next unit's tile (this one's again if there is none: harmless)
+    gptr_v4f nsrc = has_next ? (gptr_v4f)((gptr_f32)(cx.table) + static_cast<size_t>(unit_next / H) * (kSteps * 64)) + cx.lane
+                             : (gptr_v4f)(cur.table + static_cast<size_t>(cur.tile) * (kSteps * 64)) + cx.lane;
+    regs.primed = has_next;
+
+    // samples of step c of unit `u` (c may run up to three steps past the window of the last unit of
+    // an image: those values are never used; the image is padded so that the reads stay inside it)
+    auto load_b = [&](v2f (&dst)[G], const MfmaUnit<G>& u, uint32_t c) {
+        if constexpr (FLAT) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) dst[g] = *reinterpret_cast<const v2f*>(u.xbase[g] + 8 * c);
+        } else {
+            const uint32_t off = 8 * c + (c >= u.c_jump ? jump : 0);
+#pragma unroll
+            for (int g = 0; g < G; ++g) dst[g] = *reinterpret_cast<const v2f*>(u.xbase[g] + off);
+        }
+    };
+    v4f acc[G][2];
+    uint32_t nxt_ob = 0, nxt_h = 0;
+    wt.event(20);
+#pragma unroll
+    for (uint32_t c = 0; c < kSteps; ++c) {
+        // samples run kRing - 1 steps ahead, straight into the next unit
+        constexpr uint32_t kAhead = kRing - 1;
+        if (c + kAhead < kSteps) load_b(x[(c + kAhead) % kRing], cur, c + kAhead);
+        else load_b(x[(c + kAhead) % kRing], nxt, c + kAhead - kSteps);
+        const v4f av = regs.a[c >> 2];
+        const float a = (c & 3) == 0 ? av.x : (c & 3) == 1 ? av.y : (c & 3) == 2 ? av.z : av.w;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const v4f z = v4f{0.f, 0.f, 0.f, 0.f};
+            acc[g][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, x[c % kRing][g].x, c == 0 ? z : acc[g][0], 0, 0, 0);
+            acc[g][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, x[c % kRing][g].y, c == 0 ? z : acc[g][1], 0, 0, 0);
+        }
+        // the loop is straight-line code: without a fence per step the scheduler hoists dozens of
+        // LDS reads to the top (and sinks the refills to the bottom)
+        __builtin_amdgcn_sched_barrier(0);
+        // The next unit's addressing and the previous unit's stores ride in the shadow of this
+        // unit's MFMAs, a piece per step (a gap between two MFMAs hides about five instructions).
+        if (c == 1) {   // without a next unit: this unit's own index again (results unused)
+            mfma_unit_setup_common<G>(nxt, geo, cx, has_next ? unit_next : cur.unit, nxt_ob, nxt_h);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (c >= 2 && c < 2 + G) {
+            mfma_unit_setup_group<G>(nxt, c - 2, geo, cx, rows, nxt_ob, nxt_h);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (c >= 2 + G && c < 2 + 2 * G) {
+            mfma_store_pending_group<G>(geo, pend, c - 2 - G);
+            if (c == 1 + 2 * G) pend.valid = false;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if ((c & 3) == 3) {
+            regs.a[c >> 2] = nsrc[(c >> 2) * 64];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    wt.event(21);   // MFMAs issued
+    // hand the sums to the next unit's stream (or to the caller's flush at the end of the item)
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        pend.acc[g][0] = acc[g][0];
+        pend.acc[g][1] = acc[g][1];
+    }
+    pend.unit = cur;
+    pend.valid = true;
 }
 
 // ---- double-buffered kernel ------------------------------------------------------------------------
@@ -812,23 +1109,138 @@ __device__ __forceinline__ void process_unit_mfma(const GeoArgs& geo, const Item
 // image (cumulative over its uses), [4..5] sequence number + 1 of the item the image holds,
 // [6..7] its work item (or kNoItem), [8..9] producers finished staging (cumulative),
 // [10..11] sequence + 1 of the item whose id has been posted (for the other producers).
-constexpr uint32_t kNoItem = 0xFFFFFFFFu;
-constexpr uint32_t kDbCtrlWords = 16;
-// floats per image (frame-before-period block + rows), a 16-byte multiple
-__host__ __device__ inline uint32_t db_image_len(uint32_t xprev_len, uint32_t pw, uint32_t row_stride) {
-    // + 32: the matrix-core units prefetch up to three steps (24 dwords) past a window's end
-    return (xprev_len + (pw + 1) * row_stride + 32 + 3) / 4 * 4;
+
+
+// Per-image item post (written by producer 0 before it publishes the image): what a matrix-core
+// consumer needs to know about the item, so that moving on to the next item costs a few LDS reads
+// instead of a descriptor fetch and 64-bit divisions.
+constexpr uint32_t kPostWords = 8;   // out (2), class table (2), n_block0, n_limit, 2 spare
+struct ItemPost {
+    unsigned long long out, table;
+    int32_t n_block0, n_limit;
+    uint32_t spare[2];
+};
+static_assert(sizeof(ItemPost) == kPostWords * 4, "ItemPost layout");
+
+__device__ __forceinline__ ItemCtx ctx_from_post(const uint32_t* post, uint32_t wrap_tag, uint32_t lane) {
+    ItemCtx cx;
+    uint32_t w[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) w[i] = __builtin_amdgcn_readfirstlane(post[i]);
+    cx.out = (g_f32_ptr)(static_cast<unsigned long long>(w[0]) | (static_cast<unsigned long long>(w[1]) << 32));
+    cx.table = (const_f32_ptr)(static_cast<unsigned long long>(w[2]) | (static_cast<unsigned long long>(w[3]) << 32));
+    cx.wtable = cx.table;
+    cx.metas = nullptr;
+    cx.wrap_bits = nullptr;
+    cx.n_block0 = static_cast<int32_t>(w[4]);
+    cx.k_block0 = 0;
+    cx.n_limit = static_cast<int32_t>(w[5]);
+    cx.lane_row = nullptr;
+    cx.xprev = nullptr;
+    cx.wrap_tag = wrap_tag;
+    cx.pl_c = 0;
+    cx.gi = 0;
+    cx.lane = lane;
+    cx.lane_on = true;
+    return cx;
 }
 
-__device__ __forceinline__ uint32_t lds_load_acquire(uint32_t* p) {
-    return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-__device__ __forceinline__ void lds_store_release(uint32_t* p, uint32_t v) {
-    __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+// Consumer wave of the register-resident matrix-core path: ONE MFMA stream over (item, unit) pairs.
+// Units are claimed two ahead; when the claims on the current image run out and the next image is
+// already published (the normal case: producers are an item ahead), the claim stream simply moves
+// on to it, so the last unit of an item prefetches the first unit of the next and the pipe never
+// drains between items.  Only when the next image is not ready does the wave flush and wait.
+template <int G, bool FLAT, int NB3>
+__device__ __forceinline__ void mfma_consumer_stream(const GeoArgs& geo, float* lds, uint32_t image_len,
+                                                     uint32_t lane, WaveTrace& wt) {
+    uint32_t* ctrl = reinterpret_cast<uint32_t*>(lds);
+    uint32_t* tile_counter = ctrl, *left = ctrl + 2, *ready = ctrl + 4, *item_id = ctrl + 6;
+    const uint32_t* posts = ctrl + 16;
+    const uint32_t n_units = geo.n_tiles;
+    auto rows_of = [&](uint32_t b) -> const float* {
+        return lds + kDbCtrlWords + b * image_len + geo.xprev_len;
+    };
+    auto claim2 = [&](uint32_t b, uint32_t& first, uint32_t& in_flight) {
+        uint32_t c1 = 0;
+        if (lane == 0) {
+            c1 = atomicAdd(tile_counter + b, 1u);
+            in_flight = atomicAdd(tile_counter + b, 1u);
+        }
+        first = __builtin_amdgcn_readfirstlane(c1);
+    };
+    auto leave = [&](uint32_t b) {
+        if (lane == 0) __hip_atomic_fetch_add(left + b, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    MfmaTileRegs<NB3> regs;
+    MfmaPending<G> pend;
+    pend.valid = false;
+    uint32_t s = 0;
+    for (;;) {
+        // ---- (re)start the stream on item s: blocking -------------------------------------------
+        uint32_t b = s & 1;
+        wt.event(1);
+        while (lds_load_acquire(ready + b) != s + 1) __builtin_amdgcn_s_sleep(2);
+        wt.event(2);
+        if (static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(item_id[b])) == kNoItem) return;
+        ItemCtx cx = ctx_from_post(posts + kPostWords * b, b | ((s + 1) & 0xFFFFFFu) << 1, lane);
+        uint32_t c2 = 0, t, t_next;
+        claim2(b, t, c2);
+        t_next = __builtin_amdgcn_readfirstlane(c2);
+        if (t >= n_units) {   // every unit of this item is taken already
+            leave(b);
+            ++s;
+            continue;
+        }
+        MfmaUnit<G> cur = mfma_unit_setup<G>(geo, cx, rows_of(b), t), nxt = cur;
+        regs.primed = false;
+        v2f x[kRing][G];
+#pragma unroll
+        for (uint32_t c = 0; c + 1 < kRing; ++c) {
+            const uint32_t off = 8 * c + (!FLAT && c >= cur.c_jump ? geo.row_stride - 2 * geo.a : 0);
+#pragma unroll
+            for (int g = 0; g < G; ++g) x[c][g] = *reinterpret_cast<const v2f*>(cur.xbase[g] + off);
+        }
+        // claim side of the stream: item sn, image bn (ahead of the running side by at most one item)
+        uint32_t sn = s, bn = b;
+        ItemCtx cxn = cx;
+        for (;;) {
+            wt.event(6);
+            bool more = t_next < n_units;
+            if (!more && sn == s && lds_load_acquire(ready + (b ^ 1)) == s + 2 &&
+                static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(item_id[b ^ 1])) != kNoItem) {
+                // image b is exhausted and the next item is already there: move the claims over
+                sn = s + 1;
+                bn = b ^ 1;
+                cxn = ctx_from_post(posts + kPostWords * bn, bn | ((sn + 1) & 0xFFFFFFu) << 1, lane);
+                claim2(bn, t_next, c2);
+                more = t_next < n_units;
+            } else if (more) {
+                if (lane == 0) c2 = atomicAdd(tile_counter + bn, 1u);   // the unit after the next
+            }
+            mfma_unit_run<G, FLAT, NB3>(geo, cxn, rows_of(bn), cur, nxt, x, regs, pend, t_next, more, wt);
+            wt.event(7);
+            if (!more) break;
+            if (sn != s) {   // the unit just run was this wave's last on image b
+                leave(b);
+                s = sn;
+                b = bn;
+            }
+            cur = nxt;
+            t_next = __builtin_amdgcn_readfirstlane(c2);
+        }
+        // no next unit in reach: drain, leave, and start over on the following item
+        mfma_store_pending<G>(geo, pend);
+        leave(b);
+        if (sn != s) {   // the claim stream had moved on but found the next item fully claimed
+            leave(bn);
+            s = sn;
+        }
+        ++s;
+    }
 }
 
 template <int CG, bool C2, int NT, int MF>
-__global__ __launch_bounds__(1024) void fir_periodic_db_kernel(const FirStreamDesc* __restrict__ descs,
+__global__ __launch_bounds__(MF ? 768 : 1024) void fir_periodic_db_kernel(const FirStreamDesc* __restrict__ descs,
                                                                GeoArgs geo) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const uint32_t C = C2 ? 2u : geo.channels;
@@ -875,6 +1287,13 @@ __global__ __launch_bounds__(1024) void fir_periodic_db_kernel(const FirStreamDe
                 if (lane == 0) {
                     item_id[b] = item;
                     tile_counter[b] = 0;
+                    if (item != kNoItem) {
+                        ItemPost* post = reinterpret_cast<ItemPost*>(ctrl + 16 + kPostWords * b);
+                        post->out = reinterpret_cast<unsigned long long>(d.out);
+                        post->table = reinterpret_cast<unsigned long long>(d.class_coef);
+                        post->n_block0 = ig.n_block0;
+                        post->n_limit = static_cast<int32_t>(d.n_out);
+                    }
                 }
                 lds_store_release(posted + b, s + 1);
             } else {
@@ -894,13 +1313,86 @@ __global__ __launch_bounds__(1024) void fir_periodic_db_kernel(const FirStreamDe
             uint32_t n = 0;
             if (lane == 0) n = __hip_atomic_fetch_add(staged + b, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
             n = __builtin_amdgcn_readfirstlane(n);
-            if (n + 1 == producers * ((s >> 1) + 1)) lds_store_release(ready + b, s + 1);   // last one publishes
+            if (n + 1 == producers * ((s >> 1) + 1)) {   // the last one to arrive publishes the image
+                lds_store_release(ready + b, s + 1);
+                if constexpr (MF != 0) {
+                    // ... and then computes the wrap variant of the item's wrap classes from the staged
+                    // image (row 1023 on the window one frame earlier, resampler_fir.rs:544, :562-565):
+                    // lane = period, 2 channels.  It is 0.5 % of the item's arithmetic; the consumers
+                    // only pick the result up in their store path.
+                    if (geo.inline_wraps && item != kNoItem) {
+                        float* wv = lds + kDbCtrlWords + 2 * image_len + b * kMfmaWrapWords;
+                        const_f32_ptr wrow = (const_f32_ptr)(d.coeffs) + static_cast<size_t>(1023) * d.taps;
+                        gconst_u32_ptr wrap_bits = (gconst_u32_ptr)d.wrap_bits;
+                        const uint32_t num = geo.a / geo.r, jump = geo.row_stride - 2 * geo.a;
+                        const uint32_t p = lane < geo.pw ? lane : 0;
+                        const float* row = rows + p * geo.row_stride;
+                        for (uint32_t i = 0; i < geo.r && i < kMfmaWrapMax && !(geo.debug & 1024); ++i) {
+                            const int32_t ws = static_cast<int32_t>(i * num) - 1;   // first frame of the window
+                            v2f acc = v2f{0.f, 0.f};
+                            uint32_t m = 0;
+                            if (ws < 0) {   // i == 0: the first tap falls on the frame in front of the period
+                                const v2f xv = *reinterpret_cast<const v2f*>(xprev + p * 2);
+                                const float w = wrow[0];
+                                acc.x = w * xv.x;
+                                acc.y = w * xv.y;
+                                m = 1;
+                            }
+                            // the remaining taps are consecutive frames: up to the end of the period row,
+                            // then on in the next row
+                            const uint32_t f0 = static_cast<uint32_t>(ws + static_cast<int32_t>(m));
+                            const uint32_t in_row = f0 < geo.a ? (geo.a - f0 < d.taps - m ? geo.a - f0 : d.taps - m) : 0;
+                            const float* px = row + 2 * f0;
+                            const_f32_ptr pw_ = wrow + m;
+                            auto run = [&](uint32_t count) {
+                                uint32_t q = 0;
+                                for (; q + 8 <= count; q += 8) {
+                                    v2f xv[8];
+#pragma unroll
+                                    for (int e = 0; e < 8; ++e) xv[e] = *reinterpret_cast<const v2f*>(px + 2 * (q + e));
+#pragma unroll
+                                    for (int e = 0; e < 8; ++e) {
+                                        const float w = pw_[q + e];
+                                        acc.x = fmaf(w, xv[e].x, acc.x);
+                                        acc.y = fmaf(w, xv[e].y, acc.y);
+                                    }
+                                }
+                                for (; q < count; ++q) {
+                                    const v2f x1 = *reinterpret_cast<const v2f*>(px + 2 * q);
+                                    const float w = pw_[q];
+                                    acc.x = fmaf(w, x1.x, acc.x);
+                                    acc.y = fmaf(w, x1.y, acc.y);
+                                }
+                                px += 2 * count;
+                                pw_ += count;
+                            };
+                            run(in_row);
+                            px += jump;
+                            run(d.taps - m - in_row);
+                            const int32_t nw = ig.n_block0 + static_cast<int32_t>(p * geo.b + i * geo.den);
+                            uint32_t take = 0;
+                            if (lane < geo.pw && nw >= 0 && nw < static_cast<int32_t>(d.n_out)) {
+                                const uint32_t K = static_cast<uint32_t>(ig.k_block0 + static_cast<int32_t>(p * geo.r + i));
+                                take = (wrap_bits[K >> 5] >> (K & 31)) & 1u;
+                            }
+                            *reinterpret_cast<v4f*>(wv + (i * 64 + lane) * 4) =
+                                v4f{acc.x, acc.y, __uint_as_float(take), 0.f};
+                        }
+                        __builtin_amdgcn_s_waitcnt(0);
+                        lds_store_release(ctrl + 12 + b, s + 1);
+                    }
+                }
+            }
             if (item == kNoItem) break;
         }
         return;
     }
 
     // ---- consumer --------------------------------------------------------------------------------
+    if constexpr (MF != 0 && ((MF >> 6) & 7) != 0) {
+        mfma_consumer_stream<(MF & 15), ((MF >> 9) & 1) != 0, ((MF >> 6) & 7)>(geo, lds, image_len, lane, wt);
+        return;
+    }
     for (uint32_t s = 0;; ++s) {
         const uint32_t b = s & 1;
         const float* xprev = lds + kDbCtrlWords + b * image_len;
@@ -940,9 +1432,10 @@ __global__ __launch_bounds__(1024) void fir_periodic_db_kernel(const FirStreamDe
             __builtin_amdgcn_s_setprio(0);
         } else {
             // Matrix-core units.  Two claims are kept in flight: the unit after the current one must
-            // be known when the current one starts (its first coefficients are requested by the
-            // current unit's last blocks), and the claim's LDS round trip should never be waited for.
-            constexpr uint32_t H = 4 / (MF & 15);
+            // be known when the current one starts (its coefficients and addressing are requested
+            // then), and the claim's LDS round trip should never be waited for.
+            constexpr int G = MF & 15, DBG = (MF >> 4) & 3, NB3 = (MF >> 6) & 7;
+            constexpr uint32_t H = 4 / G;
             uint32_t c1 = 0, c2 = 0;
             if (lane == 0) {
                 c1 = atomicAdd(tile_counter + b, 1u);
@@ -950,27 +1443,29 @@ __global__ __launch_bounds__(1024) void fir_periodic_db_kernel(const FirStreamDe
             }
             uint32_t t = __builtin_amdgcn_readfirstlane(c1);
             uint32_t t_next = __builtin_amdgcn_readfirstlane(c2);
-            uint32_t ob = t < geo.n_tiles ? load_uniform(cx.metas + t / H).base : 0;
-            MfmaPipe pipe;
-            pipe.primed = false;
-            while (t < geo.n_tiles) {
-                wt.event(6);
-                const uint32_t from_end = geo.n_tiles - 1 - t;   // see above
-                if (from_end < 3) __builtin_amdgcn_s_setprio(3);
-                else if (from_end < 6) __builtin_amdgcn_s_setprio(2);
-                else if (from_end < 9) __builtin_amdgcn_s_setprio(1);
+            // Late units of an image outrank the rest (see the vector consumer above).
+            auto set_priority = [&](uint32_t unit) {
+                if (geo.n_tiles - 1 - unit < 4) __builtin_amdgcn_s_setprio(2);
                 else __builtin_amdgcn_s_setprio(0);
-                if (lane == 0) c2 = atomicAdd(tile_counter + b, 1u);   // the unit after the next
-                const bool more = t_next < geo.n_tiles;
-                const uint32_t ob_next = more ? load_uniform(cx.metas + t_next / H).base : 0;
-                if (geo.row_stride == 2 * geo.a)
-                    process_unit_mfma<(MF & 15), true, (MF >> 4)>(geo, cx, rows, t, ob, pipe, t_next, more, wt);
-                else
-                    process_unit_mfma<(MF & 15), false, (MF >> 4)>(geo, cx, rows, t, ob, pipe, t_next, more, wt);
-                wt.event(7);
-                t = t_next;
-                ob = ob_next;
-                t_next = __builtin_amdgcn_readfirstlane(c2);
+            };
+            if constexpr (NB3 == 0) {
+                // first frame of a tile's window: floor(16 T a / b), < 2^16 * 2^12 (32-bit math)
+                auto base_of = [&](uint32_t unit) { return (unit / H * kMfmaClassTile * geo.a) / geo.b; };
+                const bool flat = geo.row_stride == 2 * geo.a;
+                MfmaPipe pipe;
+                pipe.primed = false;
+                while (t < geo.n_tiles) {
+                    wt.event(6);
+                    set_priority(t);
+                    if (lane == 0) c2 = atomicAdd(tile_counter + b, 1u);   // the unit after the next
+                    const bool more = t_next < geo.n_tiles;
+                    const uint32_t ob = base_of(t);
+                    if (flat) process_unit_mfma<G, true, DBG>(geo, cx, rows, t, ob, pipe, t_next, more, wt);
+                    else process_unit_mfma<G, false, DBG>(geo, cx, rows, t, ob, pipe, t_next, more, wt);
+                    wt.event(7);
+                    t = t_next;
+                    t_next = __builtin_amdgcn_readfirstlane(c2);
+                }
             }
             __builtin_amdgcn_s_setprio(0);
         }
@@ -1032,7 +1527,7 @@ GeoArgs to_args(const PeriodicGeometry& g) {
     }();
     const uint32_t channels = g.lp * g.cg;
     return GeoArgs{g.a, g.b, g.b / g.den, g.row_len, g.mfma ? g.n_units : g.n_tiles, g.lp, g.pw, g.row_stride, g.waves,
-                   channels, xprev_len_of(g.pw, channels), g.producers, g.inline_wraps ? 1u : 0u, debug, stagger, nullptr, nullptr, 0u, 0u, nullptr, 0ull};
+                   channels, xprev_len_of(g.pw, channels), g.producers, g.den, g.inline_wraps ? 1u : 0u, debug, stagger, nullptr, nullptr, 0u, 0u, nullptr, 0ull};
 }
 
 // Device class tables, shared by every stream on a device with the same polyphase table, rate
@@ -1066,12 +1561,11 @@ inline uint32_t class_offset(const PeriodicGeometry& g, uint32_t j) {
 
 namespace {
 // RSMP_FIR_MFMA: 0 = vector kernels only, 2 / 4 = matrix-core kernel with that many 16-period
-// groups per work unit.  Two interleaved channels only.  Off by default until the wrap variant
-// is computed inside the kernel (the fix-up launch costs more than the kernel gains).
+// groups per work unit (default 2).  Two interleaved channels only.
 int mfma_knob() {
     static const int knob = [] {
         const char* e = getenv("RSMP_FIR_MFMA");
-        return e ? atoi(e) : 0;
+        return e ? atoi(e) : 2;
     }();
     return knob;
 }
@@ -1098,9 +1592,18 @@ PeriodicGeometry geometry_for(uint64_t num, uint64_t den, uint32_t taps, uint32_
     g.b = static_cast<uint32_t>(b);
     g.n_tiles = (g.b + ct - 1) / ct;
     g.n_units = g.n_tiles;
-    g.inline_wraps = !want_mfma && den >= kClassTile;
+    // wrap variant inside the kernel: vector kernels den >= 8 (one wrap class per 8-class tile at
+    // most); matrix-core path den >= 16 and at most kMfmaWrapMax wrap classes per super period
+    // (only the register-resident variant picks the results up: windows <= 192 taps, 2 groups/unit)
+    static const bool ring_forced = getenv("RSMP_FIR_MFMA_RING") != nullptr;
+    static const bool nowrap = getenv("RSMP_FIR_MFMA_NOWRAP") != nullptr;   // A/B: wraps by the fix-up launch
+    const bool mfma_regs = want_mfma && knob_mfma == 2 && g.row_len <= 192 && !ring_forced && !nowrap;
+    g.inline_wraps = want_mfma ? (mfma_regs && den >= kMfmaClassTile && r <= kMfmaWrapMax) : den >= kClassTile;
 
-    static const int knob_db = [] {   // RSMP_FIR_PRODUCERS: 0 = single-image kernel, n = n producers
+    // RSMP_FIR_PRODUCERS = n: n producer waves; for the vector kernels it also selects the
+    // double-buffered workgroup (measured slower than two single-image workgroups per CU: 12
+    // consumer waves cannot hide the scalar-cache latency that 24 can)
+    static const int knob_db = [] {
         const char* e = getenv("RSMP_FIR_PRODUCERS");
         return e ? atoi(e) : -1;
     }();
@@ -1123,9 +1626,10 @@ PeriodicGeometry geometry_for(uint64_t num, uint64_t den, uint32_t taps, uint32_
         g.row_stride = stride;
         // Fast path: two images in one workgroup (fir_periodic_db_kernel), if that keeps >= 75 % of
         // the lanes busy.
-        uint32_t pw = rows_in((kLdsMax - kDbCtrlWords * 4) / 2 - 16);
+        // per image: + 96 floats of read-ahead padding; matrix-core path: + the wrap results
+        uint32_t pw = rows_in((kLdsMax - kDbCtrlWords * 4 - (want_mfma ? 2 * kMfmaWrapWords * 4 : 0)) / 2 - 400);
         if (pw > pw_max) pw = pw_max;
-        if ((knob_db != 0 || want_mfma) && pw * 4 >= pw_max * 3) {
+        if ((knob_db > 0 || want_mfma) && pw * 4 >= pw_max * 3) {
             g.pw = pw;
             g.producers = knob_db > 0 && knob_db < 8 ? static_cast<uint32_t>(knob_db) : 4u;
             g.lds_bytes = (kDbCtrlWords + 2 * db_image_len(xprev_len_of(pw, channels), pw, stride)) * 4;
@@ -1138,6 +1642,7 @@ PeriodicGeometry geometry_for(uint64_t num, uint64_t den, uint32_t taps, uint32_
                 }();
                 g.mfma = static_cast<uint32_t>(knob_mfma);
                 g.n_units = g.n_tiles * (4 / g.mfma);
+                g.lds_bytes += 2 * kMfmaWrapWords * 4;   // wrap results of the two images
                 g.waves = g.producers + static_cast<uint32_t>(knob_consumers);
             } else {
                 g.waves = 16;
@@ -1161,7 +1666,11 @@ PeriodicGeometry geometry_for(uint64_t num, uint64_t den, uint32_t taps, uint32_
         }
         return true;
     };
-    if (!fit(2) && !fit(1)) return g;
+    if (want_mfma) {   // the matrix-core kernel is written for two channels per lane group
+        if (!fit(2)) return g;
+    } else if (!fit(2) && !fit(1)) {
+        return g;
+    }
     g.ok = true;
     return g;
 }
@@ -1384,19 +1893,33 @@ hipError_t launch_fir_periodic(const FirStreamDesc* d_descs, uint32_t n_streams,
         const int v = e ? atoi(e) : 0;
         return v >= 0 && v <= 3 ? v : 0;
     }();
-    const int variant = geo.mfma ? (geo.mfma == 2 ? (mfma_dbg ? 7 + mfma_dbg : 6) : 7)
-                                 : (geo.cg == 2 ? (geo.lp == 1 ? 0 : 1) : 2) + (geo.producers ? 3 : 0);
-    const void* fns[11] = {reinterpret_cast<const void*>(fir_periodic_kernel<2, true, 8>),
-                          reinterpret_cast<const void*>(fir_periodic_kernel<2, false, 8>),
-                          reinterpret_cast<const void*>(fir_periodic_kernel<1, false, 8>),
-                          reinterpret_cast<const void*>(fir_periodic_db_kernel<2, true, 8, 0>),
-                          reinterpret_cast<const void*>(fir_periodic_db_kernel<2, false, 8, 0>),
-                          reinterpret_cast<const void*>(fir_periodic_db_kernel<1, false, 8, 0>),
-                          reinterpret_cast<const void*>(fir_periodic_db_kernel<2, true, 8, 2>),
-                          reinterpret_cast<const void*>(fir_periodic_db_kernel<2, true, 8, 4>),
-                          reinterpret_cast<const void*>(fir_periodic_db_kernel<2, true, 8, 2 + 16>),
-                          reinterpret_cast<const void*>(fir_periodic_db_kernel<2, true, 8, 2 + 32>),
-                          reinterpret_cast<const void*>(fir_periodic_db_kernel<2, true, 8, 2 + 48>)};
+    static const bool mfma_ring = getenv("RSMP_FIR_MFMA_RING") != nullptr;   // force the ring variant
+    // matrix-core variants: 6 / 7 = coefficient ring (any window length), 2 / 4 period groups per
+    // unit; 8..10 = ring timing experiments; 11..18 = coefficient tile in registers, windows of
+    // 48 / 96 / 144 / 192 taps (2 groups per unit), padded (11..14) or back-to-back (15..18) rows
+    const uint32_t nb3 = geo.row_len % 48 == 0 && geo.row_len <= 192 ? geo.row_len / 48 : 0;
+    const bool flat_rows = geo.row_stride == 2 * geo.a;
+    int variant;
+    if (!geo.mfma) variant = (geo.cg == 2 ? (geo.lp == 1 ? 0 : 1) : 2) + (geo.producers ? 3 : 0);
+    else if (geo.mfma == 4) variant = 7;
+    else if (mfma_dbg) variant = 7 + mfma_dbg;
+    else if (nb3 && !mfma_ring) variant = 10 + static_cast<int>(nb3) + (flat_rows ? 4 : 0);
+    else variant = 6;
+#define RSMP_MF(nb3v, flatv) reinterpret_cast<const void*>(fir_periodic_db_kernel<2, true, 8, 2 + 64 * (nb3v) + 512 * (flatv)>)
+    const void* fns[19] = {reinterpret_cast<const void*>(fir_periodic_kernel<2, true, 8>),
+                           reinterpret_cast<const void*>(fir_periodic_kernel<2, false, 8>),
+                           reinterpret_cast<const void*>(fir_periodic_kernel<1, false, 8>),
+                           reinterpret_cast<const void*>(fir_periodic_db_kernel<2, true, 8, 0>),
+                           reinterpret_cast<const void*>(fir_periodic_db_kernel<2, false, 8, 0>),
+                           reinterpret_cast<const void*>(fir_periodic_db_kernel<1, false, 8, 0>),
+                           reinterpret_cast<const void*>(fir_periodic_db_kernel<2, true, 8, 2>),
+                           reinterpret_cast<const void*>(fir_periodic_db_kernel<2, true, 8, 4>),
+                           reinterpret_cast<const void*>(fir_periodic_db_kernel<2, true, 8, 2 + 16>),
+                           reinterpret_cast<const void*>(fir_periodic_db_kernel<2, true, 8, 2 + 32>),
+                           reinterpret_cast<const void*>(fir_periodic_db_kernel<2, true, 8, 2 + 48>),
+                           RSMP_MF(1, 0), RSMP_MF(2, 0), RSMP_MF(3, 0), RSMP_MF(4, 0),
+                           RSMP_MF(1, 1), RSMP_MF(2, 1), RSMP_MF(3, 1), RSMP_MF(4, 1)};
+#undef RSMP_MF
     {
         std::lock_guard<std::mutex> lock(mu);
         bool& have = granted[{device, variant}];
