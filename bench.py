@@ -8,7 +8,8 @@ resample/src/main.rs:226-254), all streams in ONE launch of the periodic FIR ker
 alone is 8 MiB in / 8.7 MiB out -- microseconds of HBM time -- so the single-GPU workload is a
 batch of them (weak scaling: every rank owns `--streams` streams; no data-path collective).
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (fir_periodic_kernel),
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (fir_periodic_db_kernel, the
+matrix-core periodic FIR kernel, unless another one is forced with --kernel / RSMP_FIR_MFMA=0),
 timed with HIP events on the launch stream inside the library (rsmp_fir_set_profiling);
 `cpu_baseline` is the oracle's AVX+FMA restatement of the reference path on one host core.
 """
@@ -232,6 +233,9 @@ def main() -> None:
         except Exception:
             traffic = None
 
+    variant = handles[0].kernel_variant()
+    kernel_name = {0: "fir_generic_kernel", 1: "fir_periodic_kernel", 2: "fir_periodic_db_kernel (vector)",
+                   3: "fir_periodic_db_kernel (f32 MFMA)"}.get(variant, "?")
     if rank == 0:
         total_values = values_in_per_step * world * args.steps
         line = {
@@ -260,7 +264,7 @@ def main() -> None:
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "fir_periodic_kernel" if args.kernel != "generic" else "fir_generic_kernel",
+                "kernel": kernel_name,
                 "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
@@ -268,7 +272,9 @@ def main() -> None:
                 "traffic": traffic,
                 "kernel_ms": round(k_ms, 4),
                 "algorithmic_bytes": int(alg_bytes),
-                "valu_fma_per_s": round(values_out_per_step * 128 / (k_ms * 1e-3) / 1e12, 2),
+                # useful f32 FMAs (128 taps per output value), T/s: the pipe this kernel is bound by
+                # (f32 MFMA = packed-FMA VALU peak: 78.6 T/s at 2.4 GHz)
+                "fma_per_s": round(values_out_per_step * 128 / (k_ms * 1e-3) / 1e12, 2),
             },
         }
         if not args.no_cpu and world == 1:   # rank 0 at N = 1 only

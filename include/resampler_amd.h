@@ -87,6 +87,10 @@ int rsmp_fir_last_kernel_ms(rsmp_fir* r, float* ms);
 /* Mean over the (up to 64) most recent launches made since profiling was enabled; no host sync
  * happens between those launches, so this is the kernel's duration inside a timed region. */
 int rsmp_fir_mean_kernel_ms(rsmp_fir* r, float* ms, size_t* launches);
+/* Which kernel the handle's last launch used (diagnostic, for benchmark reports): 0 generic
+ * (any ratio), 1 periodic vector kernel, 2 periodic vector kernel with double-buffered
+ * workgroups, 3 periodic matrix-core kernel; negative: invalid handle. */
+int rsmp_fir_kernel_variant(const rsmp_fir* r);
 
 /* ResamplerFir::resample (resampler_fir.rs:509-621): one call, host buffers, synchronous. */
 int rsmp_fir_resample(rsmp_fir* r, const float* in, size_t in_len, float* out, size_t out_len,

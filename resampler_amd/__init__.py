@@ -112,6 +112,7 @@ _SIGNATURES = [
     ("rsmp_fir_set_profiling", C.c_int, [C.c_void_p, C.c_int]),
     ("rsmp_fir_last_kernel_ms", C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     ("rsmp_fir_mean_kernel_ms", C.c_int, [C.c_void_p, C.POINTER(C.c_float), _szp]),
+    ("rsmp_fir_kernel_variant", C.c_int, [C.c_void_p]),
     ("rsmp_fir_resample", C.c_int, [C.c_void_p, _f32p, C.c_size_t, _f32p, C.c_size_t, _szp, _szp]),
     ("rsmp_fir_resample_device", C.c_int,
      [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, _szp, _szp, C.c_void_p]),
@@ -302,6 +303,10 @@ class ResamplerFir:
         ms, n = C.c_float(), C.c_size_t()
         _check(lib().rsmp_fir_mean_kernel_ms(self._h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def kernel_variant(self) -> int:
+        """0 generic, 1 periodic vector, 2 periodic vector (double-buffered), 3 periodic matrix-core."""
+        return int(lib().rsmp_fir_kernel_variant(self._h))
 
     # ResamplerFir::resample (host slices) --------------------------------------------------------
     def resample(self, input, output: np.ndarray) -> Tuple[int, int]:

@@ -90,6 +90,7 @@ struct rsmp_fir {
     // staging for the host-pointer entry points
     DeviceBuffer d_stage_in, d_stage_out;
     rsmp::PeriodicState periodic;
+    bool last_periodic = false;   // the handle's last launch went through a periodic kernel
     unsigned long long* d_work_counter = nullptr;   // periodic kernel's item queue (leader only)
     unsigned long long work_base = 0;
     // optional timing of the main convolution launch(es) (rsmp_fir_set_profiling)
@@ -527,6 +528,7 @@ int launch_jobs(rsmp_fir* leader, std::vector<Job>& jobs, hipStream_t stream) {
     }
     // Commit: the mirrors advance, the hist buffers swap.
     for (Job& j : jobs) {
+        j.r->last_periodic = j.plan->periodic;
         j.r->mirror = j.plan->planned;
         j.r->cur ^= 1;
     }
@@ -642,6 +644,13 @@ extern "C" int rsmp_fir_last_kernel_ms(rsmp_fir* r, float* ms) {
     RSMP_HIP_CHECK(hipEventSynchronize(r->prof_stop[i]));
     RSMP_HIP_CHECK(hipEventElapsedTime(ms, r->prof_start[i], r->prof_stop[i]));
     return RSMP_OK;
+}
+
+extern "C" int rsmp_fir_kernel_variant(const rsmp_fir* r) {
+    if (!r) return -1;
+    if (!r->last_periodic || !r->periodic.geo_valid || !r->periodic.geo.ok) return 0;
+    const rsmp::PeriodicGeometry& g = r->periodic.geo;
+    return g.mfma ? 3 : (g.producers ? 2 : 1);
 }
 
 extern "C" int rsmp_fir_mean_kernel_ms(rsmp_fir* r, float* ms, size_t* launches) {
