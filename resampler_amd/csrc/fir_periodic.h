@@ -46,6 +46,7 @@ struct PeriodicGeometry {
     uint32_t row_stride = 0;     // LDS dwords between period rows (odd frame count: conflict-free)
     uint32_t waves = 0;          // waves per workgroup
     uint32_t producers = 0;      // > 0: double-buffered kernel, this many waves only stage
+    uint32_t images = 0;         // double-buffered kernels: LDS images in the ring (2 or 4)
     uint32_t mfma = 0;           // > 0: matrix-core kernel (16-class tiles); period groups of 16 per work unit
     uint32_t n_units = 0;        // work units per item: n_tiles (vector kernels) or tiles x unit splits (mfma)
     uint32_t lds_bytes = 0;
@@ -53,7 +54,7 @@ struct PeriodicGeometry {
     bool operator==(const PeriodicGeometry& o) const {
         return a == o.a && b == o.b && den == o.den && taps == o.taps && row_len == o.row_len &&
                cg == o.cg && lp == o.lp && pw == o.pw && row_stride == o.row_stride &&
-               waves == o.waves && producers == o.producers && mfma == o.mfma;
+               waves == o.waves && producers == o.producers && mfma == o.mfma && images == o.images;
     }
 };
 

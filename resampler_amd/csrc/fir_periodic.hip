@@ -42,6 +42,8 @@ struct GeoArgs {
     uint32_t a, b, r, row_len, n_tiles, lp, pw, row_stride, waves, channels, xprev_len;
     uint32_t producers;   // double-buffered kernel: waves that only stage
     uint32_t den;         // true period of the phase pattern (b = r * den)
+    uint32_t images;      // double-buffered kernel: LDS images in the ring (2 or 4)
+    uint32_t unit_shift;  // matrix-core path: log2(work units per class tile)
     uint32_t inline_wraps;
     uint32_t debug;  // RSMP_FIR_DEBUG: bit0 skip staging, bit1 skip the tap loops (timing only)
     uint32_t stagger_ticks;  // one-time start delay of the second workgroup slot (100 MHz ticks)
@@ -228,7 +230,7 @@ struct ItemCtx {
     int32_t n_limit;                  // outputs in this launch
     const float* lane_row;            // LDS: first sample of the lane's period row (+ channel group)
     const float* xprev;               // LDS: frame in front of each period
-    uint32_t wrap_tag;                // matrix-core path: image index | (item sequence + 1) << 1
+    uint32_t wrap_tag;                // matrix-core path: image index | (item sequence + 1) << 2
     uint32_t pl_c, gi, lane;
     bool lane_on;
 };
@@ -699,8 +701,8 @@ __device__ __forceinline__ void process_unit_mfma(const GeoArgs& geo, const Item
                                                   const float* rows, uint32_t unit, uint32_t ob,
                                                   MfmaPipe& pipe, uint32_t unit_next, bool has_next,
                                                   WaveTrace& wt) {
-    constexpr uint32_t H = 4 / G;                      // units per tile
-    const uint32_t T = unit / H, h = unit - T * H;
+    const uint32_t hs = geo.unit_shift;                // log2(units per tile)
+    const uint32_t T = unit >> hs, h = unit & ((1u << hs) - 1);
     const uint32_t lane = cx.lane;
     const uint32_t k = lane >> 4, pi = lane & 15;
     const uint32_t n_steps = geo.row_len >> 2, n_blocks = n_steps >> 2;   // a multiple of 3
@@ -725,7 +727,7 @@ __device__ __forceinline__ void process_unit_mfma(const GeoArgs& geo, const Item
     gptr_f32 tab = (gptr_f32)(cx.table);
     const uint32_t tile_floats = n_steps * 64;
     gptr_f32 a_ptr = tab + static_cast<size_t>(T) * tile_floats;
-    gptr_f32 a_next = has_next ? tab + static_cast<size_t>(unit_next / H) * tile_floats : a_ptr;
+    gptr_f32 a_next = has_next ? tab + static_cast<size_t>(unit_next >> hs) * tile_floats : a_ptr;
     uint32_t a_blk = 0;   // block the stream pointer stands at
     auto load_a = [&](float (&dst)[4]) {
         if constexpr (DBG & 1) {   // timing experiment: one hot 256-byte line
@@ -810,7 +812,11 @@ __device__ __forceinline__ void process_unit_mfma(const GeoArgs& geo, const Item
 }
 
 constexpr uint32_t kNoItem = 0xFFFFFFFFu;
-constexpr uint32_t kDbCtrlWords = 32;   // 16 control words + two item posts
+constexpr uint32_t kDbMaxImages = 4;
+static_assert(kDbMaxImages * 7 <= 32, "control arrays end where the item posts begin");
+// control words: seven arrays of kDbMaxImages (see fir_periodic_db_kernel) + one item post per image
+constexpr uint32_t kDbPostBase = 32;   // kDbMaxImages posts of kPostWords words follow
+constexpr uint32_t kDbCtrlWords = 64;
 // floats per image (frame-before-period block + rows), a 16-byte multiple
 __host__ __device__ inline uint32_t db_image_len(uint32_t xprev_len, uint32_t pw, uint32_t row_stride) {
     // + 96: the matrix-core units prefetch up to 11 steps (88 dwords) past a window's end
@@ -830,7 +836,8 @@ __device__ __forceinline__ void lds_store_release(uint32_t* p, uint32_t v) {
 constexpr uint32_t kRing = 4;
 // Wrap classes per super period the matrix-core path handles inside the kernel (b = r * den, r <= this).
 constexpr uint32_t kMfmaWrapMax = 2;
-constexpr uint32_t kMfmaWrapWords = kMfmaWrapMax * 64 * 4;   // per image: {ch0, ch1, take, -} per period
+// per image: {ch0, ch1, take, -} per period and wrap class
+__host__ __device__ inline uint32_t mfma_wrap_words(uint32_t pw) { return kMfmaWrapMax * ((pw + 15) / 16 * 16) * 4; }
 
 // Everything about a unit that can be computed ahead of its MFMAs.
 template <int G>
@@ -842,7 +849,7 @@ struct MfmaUnit {
     uint32_t j0;             // first of the lane's four classes
     uint32_t c_jump;         // (padded rows only) first step at which the lane's tap is in the next row
     uint32_t tile, unit;
-    // 0, or for a tile holding a wrap class: 1 | image << 1 | wrap index << 2 | class-in-tile << 4 |
+    // 0, or for a tile holding a wrap class: 1 | image << 1 | wrap index << 3 | class-in-tile << 4 |
     // (item sequence + 1) << 8 -- where a producer leaves the wrap results and how to tell they are there
     uint32_t wrap;
     bool fast;               // wave-uniform: every lane stores all four frames of every group
@@ -855,9 +862,8 @@ template <int G>
 __device__ __forceinline__ void mfma_unit_setup_common(MfmaUnit<G>& u, const GeoArgs& geo,
                                                        const ItemCtx& cx, uint32_t unit,
                                                        uint32_t& ob, uint32_t& h) {
-    constexpr uint32_t H = 4 / G;                      // units per tile
-    const uint32_t T = unit / H;
-    h = unit - T * H;
+    const uint32_t T = unit >> geo.unit_shift;         // 1 or 2 units per tile
+    h = unit & ((1u << geo.unit_shift) - 1);
     const uint32_t k = cx.lane >> 4;
     // first frame of the tile's window: floor(16 T a / b), < 2^16 * 2^12 (32-bit math)
     ob = (T * kMfmaClassTile * geo.a) / geo.b;
@@ -875,7 +881,7 @@ __device__ __forceinline__ void mfma_unit_setup_common(MfmaUnit<G>& u, const Geo
         for (uint32_t i = 0; i < kMfmaWrapMax; ++i) {
             const uint32_t jw = i * geo.den;
             if (i < geo.r && jw / kMfmaClassTile == T)
-                u.wrap = 1u | (cx.wrap_tag & 1u) << 1 | i << 2 | (jw % kMfmaClassTile) << 4 | (cx.wrap_tag >> 1) << 8;
+                u.wrap = 1u | (cx.wrap_tag & 3u) << 1 | i << 3 | (jw % kMfmaClassTile) << 4 | (cx.wrap_tag >> 2) << 8;
         }
     }
     u.table = (gptr_f32)(cx.table);
@@ -947,14 +953,13 @@ __device__ __forceinline__ void mfma_store_pending_group(const GeoArgs& geo, con
     if (u.wrap) {   // wave-uniform: this tile holds a class whose outputs may take the wrap variant
         // (computed by a producer after it published the image; long done by now as a rule)
         extern __shared__ __attribute__((aligned(16))) float lds_base[];
-        const uint32_t wb = (u.wrap >> 1) & 1, wi = (u.wrap >> 2) & 3, wc = (u.wrap >> 4) & 15, wseq = u.wrap >> 8;
-        uint32_t* flag = reinterpret_cast<uint32_t*>(lds_base) + 12 + wb;
+        const uint32_t wb = (u.wrap >> 1) & 3, wi = (u.wrap >> 3) & 1, wc = (u.wrap >> 4) & 15, wseq = u.wrap >> 8;
+        uint32_t* flag = reinterpret_cast<uint32_t*>(lds_base) + 24 + wb;
         while ((lds_load_acquire(flag) & 0xFFFFFFu) != wseq) __builtin_amdgcn_s_sleep(1);
-        const float* wv = lds_base + kDbCtrlWords + 2 * db_image_len(geo.xprev_len, geo.pw, geo.row_stride) +
-                          wb * kMfmaWrapWords + wi * (64 * 4);
+        const float* wv = lds_base + kDbCtrlWords + geo.images * db_image_len(geo.xprev_len, geo.pw, geo.row_stride) +
+                          wb * mfma_wrap_words(geo.pw) + wi * (mfma_wrap_words(geo.pw) / kMfmaWrapMax);
         const uint32_t lane = threadIdx.x & 63;
-        constexpr uint32_t H = 4 / G;
-        const uint32_t pl = 16 * (G * (u.unit % H) + g) + (lane & 15);   // the lane's period in the image
+        const uint32_t pl = 16 * (G * (u.unit & ((1u << geo.unit_shift) - 1)) + g) + (lane & 15);   // the lane's period in the image
         if ((lane >> 4) == (wc >> 2) && u.mode[g] != 0) {
             const v4f w = *reinterpret_cast<const v4f*>(wv + pl * 4);
             if (__float_as_uint(w.z) != 0u) {
@@ -1017,7 +1022,6 @@ __device__ __forceinline__ void mfma_unit_run(const GeoArgs& geo, const ItemCtx&
                                               v2f (&x)[kRing][G], MfmaTileRegs<NB3>& regs,
                                               MfmaPending<G>& pend, uint32_t unit_next, bool has_next,
                                               WaveTrace& wt) {
-    constexpr uint32_t H = 4 / G;
     constexpr uint32_t kBlocks = 3 * NB3, kSteps = 4 * kBlocks;
     typedef const v4f __attribute__((address_space(1)))* gptr_v4f;
     const uint32_t jump = geo.row_stride - geo.a * 2;  // dwords skipped between two period rows
@@ -1029,7 +1033,7 @@ __device__ __forceinline__ void mfma_unit_run(const GeoArgs& geo, const ItemCtx&
         for (uint32_t j = 0; j < kBlocks; ++j) regs.a[j] = src[j * 64];
     }
     // refill source: the next unit's tile (this one's again if there is none: harmless)
-    gptr_v4f nsrc = has_next ? (gptr_v4f)((gptr_f32)(cx.table) + static_cast<size_t>(unit_next / H) * (kSteps * 64)) + cx.lane
+    gptr_v4f nsrc = has_next ? (gptr_v4f)((gptr_f32)(cx.table) + static_cast<size_t>(unit_next >> geo.unit_shift) * (kSteps * 64)) + cx.lane
                              : (gptr_v4f)(cur.table + static_cast<size_t>(cur.tile) * (kSteps * 64)) + cx.lane;
     regs.primed = has_next;
 
@@ -1154,8 +1158,9 @@ template <int G, bool FLAT, int NB3>
 __device__ __forceinline__ void mfma_consumer_stream(const GeoArgs& geo, float* lds, uint32_t image_len,
                                                      uint32_t lane, WaveTrace& wt) {
     uint32_t* ctrl = reinterpret_cast<uint32_t*>(lds);
-    uint32_t* tile_counter = ctrl, *left = ctrl + 2, *ready = ctrl + 4, *item_id = ctrl + 6;
-    const uint32_t* posts = ctrl + 16;
+    uint32_t* tile_counter = ctrl, *left = ctrl + 4, *ready = ctrl + 8, *item_id = ctrl + 12;
+    const uint32_t* posts = ctrl + kDbPostBase;
+    const uint32_t imask = geo.images - 1;   // images: 2 or 4
     const uint32_t n_units = geo.n_tiles;
     auto rows_of = [&](uint32_t b) -> const float* {
         return lds + kDbCtrlWords + b * image_len + geo.xprev_len;
@@ -1177,12 +1182,12 @@ __device__ __forceinline__ void mfma_consumer_stream(const GeoArgs& geo, float* 
     uint32_t s = 0;
     for (;;) {
         // ---- (re)start the stream on item s: blocking -------------------------------------------
-        uint32_t b = s & 1;
+        uint32_t b = s & imask;
         wt.event(1);
         while (lds_load_acquire(ready + b) != s + 1) __builtin_amdgcn_s_sleep(2);
         wt.event(2);
         if (static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(item_id[b])) == kNoItem) return;
-        ItemCtx cx = ctx_from_post(posts + kPostWords * b, b | ((s + 1) & 0xFFFFFFu) << 1, lane);
+        ItemCtx cx = ctx_from_post(posts + kPostWords * b, b | ((s + 1) & 0xFFFFFFu) << 2, lane);
         uint32_t c2 = 0, t, t_next;
         claim2(b, t, c2);
         t_next = __builtin_amdgcn_readfirstlane(c2);
@@ -1206,12 +1211,13 @@ __device__ __forceinline__ void mfma_consumer_stream(const GeoArgs& geo, float* 
         for (;;) {
             wt.event(6);
             bool more = t_next < n_units;
-            if (!more && sn == s && lds_load_acquire(ready + (b ^ 1)) == s + 2 &&
-                static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(item_id[b ^ 1])) != kNoItem) {
+            const uint32_t b1 = (b + 1) & imask;
+            if (!more && sn == s && lds_load_acquire(ready + b1) == s + 2 &&
+                static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(item_id[b1])) != kNoItem) {
                 // image b is exhausted and the next item is already there: move the claims over
                 sn = s + 1;
-                bn = b ^ 1;
-                cxn = ctx_from_post(posts + kPostWords * bn, bn | ((sn + 1) & 0xFFFFFFu) << 1, lane);
+                bn = b1;
+                cxn = ctx_from_post(posts + kPostWords * bn, bn | ((sn + 1) & 0xFFFFFFu) << 2, lane);
                 claim2(bn, t_next, c2);
                 more = t_next < n_units;
             } else if (more) {
@@ -1249,8 +1255,9 @@ __global__ __launch_bounds__(MF ? 768 : 1024) void fir_periodic_db_kernel(const 
     WaveTrace wt;
     wt.init(geo, wave);
     uint32_t* ctrl = reinterpret_cast<uint32_t*>(lds);
-    uint32_t* tile_counter = ctrl, *left = ctrl + 2, *ready = ctrl + 4, *item_id = ctrl + 6;
-    uint32_t* staged = ctrl + 8, *posted = ctrl + 10;
+    uint32_t* tile_counter = ctrl, *left = ctrl + 4, *ready = ctrl + 8, *item_id = ctrl + 12;
+    uint32_t* staged = ctrl + 16, *posted = ctrl + 20, *wflag = ctrl + 24;
+    const uint32_t imask = geo.images - 1, ishift = geo.images == 4 ? 2 : 1;
     const uint32_t image_len = db_image_len(geo.xprev_len, geo.pw, geo.row_stride);
     if (threadIdx.x < kDbCtrlWords) ctrl[threadIdx.x] = 0;
     __syncthreads();   // the only workgroup barrier
@@ -1259,18 +1266,27 @@ __global__ __launch_bounds__(MF ? 768 : 1024) void fir_periodic_db_kernel(const 
     if (wave < producers) {
         // ---- producer ----------------------------------------------------------------------------
         __builtin_amdgcn_s_setprio(3);   // mostly asleep; when it has work, that work gates everyone
-        for (uint32_t s = 0;; ++s) {
-            const uint32_t b = s & 1;
+        // With as many producers as images each producer owns an image (sequence numbers wave,
+        // wave + images, ...) and stages it alone: several images are in flight at once, and nothing
+        // is waited for between producers except the turn to claim (claims stay in sequence order
+        // so that the first failed claim is also the last item).  Otherwise the producers stage
+        // every image together.
+        const bool own_image = producers == geo.images && MF != 0;
+        uint32_t* claim_turn = ctrl + 28;
+        for (uint32_t s = own_image ? wave : 0;; s += own_image ? geo.images : 1) {
+            const uint32_t b = s & imask;
             float* xprev = lds + kDbCtrlWords + b * image_len;
             float* rows = xprev + geo.xprev_len;
             wt.event(11);
             // every consumer has left the image's previous use (s - 2)
-            while (lds_load_acquire(left + b) != consumers * (s >> 1)) __builtin_amdgcn_s_sleep(8);
+            while (lds_load_acquire(left + b) != consumers * (s >> ishift)) __builtin_amdgcn_s_sleep(8);
             wt.event(12);
             uint32_t item = kNoItem;
             FirStreamDesc d;
             ItemGeom ig;
-            if (wave == 0) {
+            if (wave == 0 || own_image) {
+                if (own_image)
+                    while (lds_load_acquire(claim_turn) != s) __builtin_amdgcn_s_sleep(2);
                 // claim work items until one is real (ragged batches pad with empty ones)
                 for (;;) {
                     unsigned long long tkt = 0;
@@ -1284,11 +1300,12 @@ __global__ __launch_bounds__(MF ? 768 : 1024) void fir_periodic_db_kernel(const 
                     ig = item_geom(geo, d, item - stream_idx * geo.blocks_per_stream);
                     if (ig.valid) break;
                 }
+                if (own_image) lds_store_release(claim_turn, s + 1);
                 if (lane == 0) {
                     item_id[b] = item;
                     tile_counter[b] = 0;
                     if (item != kNoItem) {
-                        ItemPost* post = reinterpret_cast<ItemPost*>(ctrl + 16 + kPostWords * b);
+                        ItemPost* post = reinterpret_cast<ItemPost*>(ctrl + kDbPostBase + kPostWords * b);
                         post->out = reinterpret_cast<unsigned long long>(d.out);
                         post->table = reinterpret_cast<unsigned long long>(d.class_coef);
                         post->n_block0 = ig.n_block0;
@@ -1306,14 +1323,16 @@ __global__ __launch_bounds__(MF ? 768 : 1024) void fir_periodic_db_kernel(const 
                 }
             }
             if (item != kNoItem && !(geo.debug & 1))
-                stage_image(geo, d, ig.q0, C, rows, xprev, wave, producers, lane);
+                stage_image(geo, d, ig.q0, C, rows, xprev, own_image ? 0 : wave, own_image ? 1 : producers, lane);
             wt.event(13);
             __builtin_amdgcn_s_waitcnt(0);   // DMA (vmcnt) and LDS stores (lgkmcnt) of this wave are done
             wt.event(14);
             uint32_t n = 0;
-            if (lane == 0) n = __hip_atomic_fetch_add(staged + b, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
-            n = __builtin_amdgcn_readfirstlane(n);
-            if (n + 1 == producers * ((s >> 1) + 1)) {   // the last one to arrive publishes the image
+            if (!own_image) {
+                if (lane == 0) n = __hip_atomic_fetch_add(staged + b, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+                n = __builtin_amdgcn_readfirstlane(n);
+            }
+            if (own_image || n + 1 == producers * ((s >> ishift) + 1)) {   // the last one to arrive publishes the image
                 lds_store_release(ready + b, s + 1);
                 if constexpr (MF != 0) {
                     // ... and then computes the wrap variant of the item's wrap classes from the staged
@@ -1321,7 +1340,8 @@ __global__ __launch_bounds__(MF ? 768 : 1024) void fir_periodic_db_kernel(const 
                     // lane = period, 2 channels.  It is 0.5 % of the item's arithmetic; the consumers
                     // only pick the result up in their store path.
                     if (geo.inline_wraps && item != kNoItem) {
-                        float* wv = lds + kDbCtrlWords + 2 * image_len + b * kMfmaWrapWords;
+                        float* wv = lds + kDbCtrlWords + geo.images * image_len + b * mfma_wrap_words(geo.pw);
+                        const uint32_t wstride = mfma_wrap_words(geo.pw) / kMfmaWrapMax;   // floats per wrap class
                         const_f32_ptr wrow = (const_f32_ptr)(d.coeffs) + static_cast<size_t>(1023) * d.taps;
                         gconst_u32_ptr wrap_bits = (gconst_u32_ptr)d.wrap_bits;
                         const uint32_t num = geo.a / geo.r, jump = geo.row_stride - 2 * geo.a;
@@ -1375,11 +1395,12 @@ __global__ __launch_bounds__(MF ? 768 : 1024) void fir_periodic_db_kernel(const 
                                 const uint32_t K = static_cast<uint32_t>(ig.k_block0 + static_cast<int32_t>(p * geo.r + i));
                                 take = (wrap_bits[K >> 5] >> (K & 31)) & 1u;
                             }
-                            *reinterpret_cast<v4f*>(wv + (i * 64 + lane) * 4) =
-                                v4f{acc.x, acc.y, __uint_as_float(take), 0.f};
+                            if (lane * 4 < wstride)
+                                *reinterpret_cast<v4f*>(wv + i * wstride + lane * 4) =
+                                    v4f{acc.x, acc.y, __uint_as_float(take), 0.f};
                         }
                         __builtin_amdgcn_s_waitcnt(0);
-                        lds_store_release(ctrl + 12 + b, s + 1);
+                        lds_store_release(wflag + b, s + 1);
                     }
                 }
             }
@@ -1394,7 +1415,7 @@ __global__ __launch_bounds__(MF ? 768 : 1024) void fir_periodic_db_kernel(const 
         return;
     }
     for (uint32_t s = 0;; ++s) {
-        const uint32_t b = s & 1;
+        const uint32_t b = s & imask;
         const float* xprev = lds + kDbCtrlWords + b * image_len;
         const float* rows = xprev + geo.xprev_len;
         wt.event(1);
@@ -1435,7 +1456,6 @@ __global__ __launch_bounds__(MF ? 768 : 1024) void fir_periodic_db_kernel(const 
             // be known when the current one starts (its coefficients and addressing are requested
             // then), and the claim's LDS round trip should never be waited for.
             constexpr int G = MF & 15, DBG = (MF >> 4) & 3, NB3 = (MF >> 6) & 7;
-            constexpr uint32_t H = 4 / G;
             uint32_t c1 = 0, c2 = 0;
             if (lane == 0) {
                 c1 = atomicAdd(tile_counter + b, 1u);
@@ -1450,7 +1470,7 @@ __global__ __launch_bounds__(MF ? 768 : 1024) void fir_periodic_db_kernel(const 
             };
             if constexpr (NB3 == 0) {
                 // first frame of a tile's window: floor(16 T a / b), < 2^16 * 2^12 (32-bit math)
-                auto base_of = [&](uint32_t unit) { return (unit / H * kMfmaClassTile * geo.a) / geo.b; };
+                auto base_of = [&](uint32_t unit) { return ((unit >> geo.unit_shift) * kMfmaClassTile * geo.a) / geo.b; };
                 const bool flat = geo.row_stride == 2 * geo.a;
                 MfmaPipe pipe;
                 pipe.primed = false;
@@ -1527,7 +1547,8 @@ GeoArgs to_args(const PeriodicGeometry& g) {
     }();
     const uint32_t channels = g.lp * g.cg;
     return GeoArgs{g.a, g.b, g.b / g.den, g.row_len, g.mfma ? g.n_units : g.n_tiles, g.lp, g.pw, g.row_stride, g.waves,
-                   channels, xprev_len_of(g.pw, channels), g.producers, g.den, g.inline_wraps ? 1u : 0u, debug, stagger, nullptr, nullptr, 0u, 0u, nullptr, 0ull};
+                   channels, xprev_len_of(g.pw, channels), g.producers, g.den, g.images ? g.images : 2u,
+                   g.mfma && g.n_units == 2 * g.n_tiles ? 1u : 0u, g.inline_wraps ? 1u : 0u, debug, stagger, nullptr, nullptr, 0u, 0u, nullptr, 0ull};
 }
 
 // Device class tables, shared by every stream on a device with the same polyphase table, rate
@@ -1626,13 +1647,40 @@ PeriodicGeometry geometry_for(uint64_t num, uint64_t den, uint32_t taps, uint32_
         g.row_stride = stride;
         // Fast path: two images in one workgroup (fir_periodic_db_kernel), if that keeps >= 75 % of
         // the lanes busy.
-        // per image: + 96 floats of read-ahead padding; matrix-core path: + the wrap results
-        uint32_t pw = rows_in((kLdsMax - kDbCtrlWords * 4 - (want_mfma ? 2 * kMfmaWrapWords * 4 : 0)) / 2 - 400);
-        if (pw > pw_max) pw = pw_max;
-        if ((knob_db > 0 || want_mfma) && pw * 4 >= pw_max * 3) {
+        // Fast path: several images in one workgroup (fir_periodic_db_kernel).  Per image: + 96 floats of
+        // read-ahead padding; matrix-core path: + the wrap results.  RSMP_FIR_IMAGES=4 selects a ring of
+        // four 32-period images, one per producer, instead of two 64-period ones (producers up to three
+        // items ahead; measured equal: the doubled per-item work eats what the extra slack gains).
+        static const int knob_images = [] {
+            const char* e = getenv("RSMP_FIR_IMAGES");
+            return e ? atoi(e) : 0;
+        }();
+        auto db_fit = [&](uint32_t images, uint32_t pw_cap, uint32_t& pw_out, uint32_t& bytes_out) -> bool {
+            if (pw_cap > pw_max) pw_cap = pw_max;
+            for (uint32_t pw = pw_cap; pw * 4 >= pw_cap * 3 && pw > 0; --pw) {
+                const uint32_t bytes = (kDbCtrlWords + images * db_image_len(xprev_len_of(pw, channels), pw, stride) +
+                                        (want_mfma ? images * mfma_wrap_words(pw) : 0)) * 4;
+                if (bytes <= kLdsMax) {
+                    pw_out = pw;
+                    bytes_out = bytes;
+                    return true;
+                }
+            }
+            return false;
+        };
+        uint32_t pw = 0, bytes = 0;
+        bool have_db = false;
+        if (want_mfma && knob_mfma == 2 && knob_images == 4 && pw_max == 64 && db_fit(4, 32, pw, bytes) && pw == 32) {
+            g.images = 4;
+            have_db = true;
+        } else if ((knob_db > 0 || want_mfma) && db_fit(2, 64, pw, bytes)) {
+            g.images = 2;
+            have_db = true;
+        }
+        if (have_db) {
             g.pw = pw;
             g.producers = knob_db > 0 && knob_db < 8 ? static_cast<uint32_t>(knob_db) : 4u;
-            g.lds_bytes = (kDbCtrlWords + 2 * db_image_len(xprev_len_of(pw, channels), pw, stride)) * 4;
+            g.lds_bytes = bytes;
             if (want_mfma) {
                 // two consumer waves per SIMD keep the matrix pipe busy; more only add arbitration
                 static const int knob_consumers = [] {
@@ -1641,8 +1689,9 @@ PeriodicGeometry geometry_for(uint64_t num, uint64_t den, uint32_t taps, uint32_
                     return v >= 1 && v <= 12 ? v : 8;
                 }();
                 g.mfma = static_cast<uint32_t>(knob_mfma);
-                g.n_units = g.n_tiles * (4 / g.mfma);
-                g.lds_bytes += 2 * kMfmaWrapWords * 4;   // wrap results of the two images
+                // a work unit spans knob_mfma groups of 16 periods
+                const uint32_t groups = (pw + 15) / 16;
+                g.n_units = g.n_tiles * ((groups + g.mfma - 1) / g.mfma);
                 g.waves = g.producers + static_cast<uint32_t>(knob_consumers);
             } else {
                 g.waves = 16;
@@ -1862,7 +1911,10 @@ hipError_t launch_fir_periodic(const FirStreamDesc* d_descs, uint32_t n_streams,
     const dim3 grid(args.total_items < slots ? args.total_items : slots);
     args.work_counter = d_work_counter;
     args.work_base = *work_base;
-    *work_base += args.total_items + grid.x;   // every workgroup makes exactly one failing claim
+    // every claiming wave makes exactly one failing claim: one per workgroup, or one per producer when
+    // each producer owns an image
+    const bool own_image = geo.mfma && geo.producers == geo.images;
+    *work_base += args.total_items + static_cast<unsigned long long>(grid.x) * (own_image ? geo.images : 1u);
     static const char* trace_path = getenv("RSMP_FIR_TRACE");
     static unsigned long long* d_trace = nullptr;
     const size_t trace_words = 6ull * grid.x;
