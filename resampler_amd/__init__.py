@@ -20,7 +20,7 @@ from typing import Optional, Sequence, Tuple
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libresampler_amd.so")
+LIB_PATH = os.environ.get("RSMP_AMD_LIB") or os.path.join(_HERE, "libresampler_amd.so")   # override: A/B builds
 
 
 class ResampleError(Exception):

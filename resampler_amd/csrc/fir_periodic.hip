@@ -1,23 +1,21 @@
-// fir_periodic.hip -- throughput FIR kernel for rational rate pairs on gfx950 (see fir_periodic.h
-// for the idea).  Replaces the same reference code as fir_generic.hip
-// (src/resampler_fir.rs:542-590 + src/fir/avx.rs:5-61) for launches long enough to fill waves
-// with whole periods.
+// fir_periodic.hip -- throughput FIR kernels for rational rate pairs on gfx950 (see fir_periodic.h
+// for the idea; DESIGN.md section 4.1 for the measurements).  They replace the same reference code
+// as fir_generic.hip (src/resampler_fir.rs:542-590 + src/fir/avx.rs:5-61) for launches long enough
+// to work in whole periods.  Three kernels share the staging, geometry and class-table code:
 //
-// Workgroup = `waves` wave64s sharing one staged input span of `pw` periods (two workgroups per
-// CU: one stages / stores while the other computes):
-//   stage   : [hist|in] frames (q0*a ... (q0+pw)*a + row_len) -> LDS, one row per period with an
-//             odd frame stride (the per-lane strided reads below are then bank-conflict free),
-//             zero filled outside the stream; branch-free so the loads of a row are all in flight;
-//   compute : wave w takes class tiles w, w+waves, ...; lane = (period, channel group).  Per tap:
-//             one ds_read of the lane's sample(s), 8 wave-uniform coefficients through the scalar
-//             cache (s_load_dwordx16 = 2 taps), 8 v_pk_fma_f32 with an SGPR operand (packed fp32
-//             is the only way to the 128 FMA/clk/CU peak on gfx950).  No cross-lane traffic;
-//   wrap    : tiles holding a class whose exact position is an integer carry a 9th accumulator
-//             (row 1023, previous frame) and pick per lane from the launch's wrap bitmap;
-//   store   : a 4x4 DPP transpose inside each lane quad turns "lane = period, 64 B of output
-//             each" into 64 B-contiguous quads, so one store instruction issues 16 x 64 B requests
-//             instead of 64 x 16 B (L2 request rate, not bytes, limits scattered stores).
-// HBM traffic = input span once per workgroup (+ row_len halo) + output once; the class table
+//   fir_periodic_db_kernel<.., MF != 0>   matrix-core consumers (default for 2 channels): one
+//       workgroup per CU owning two (or four) LDS images; producer waves stage with LDS-DMA,
+//       consumer waves run v_mfma_f32_16x16x4_f32 streams over 16-class tiles (exact f32), the
+//       coefficient tile in registers, samples from LDS, stores without any transpose; the wrap
+//       variant is computed by a producer from the staged image;
+//   fir_periodic_db_kernel<.., 0>         the same producer / consumer skeleton around the vector
+//       tile code (RSMP_FIR_PRODUCERS=n; measured slower than the next one);
+//   fir_periodic_kernel                   vector kernel, two workgroups per CU alternating between
+//       staging and computing: lane = period, the 8 coefficients of a tap wave-uniform through the
+//       scalar cache into the SGPR operand of v_pk_fma_f32, 4x4 DPP transposes before the stores,
+//       a 9th accumulator for the wrap variant.  Any channel count, any period length.
+//
+// HBM traffic = input span once per work item (+ row_len halo) + output once; the class table
 // (<= a few hundred KB) stays in L2 / scalar cache.
 #include "fir_periodic.h"
 
