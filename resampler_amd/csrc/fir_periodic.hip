@@ -1277,7 +1277,7 @@ __global__ __launch_bounds__(MF ? 768 : 1024) void fir_periodic_db_kernel(const 
             float* rows = xprev + geo.xprev_len;
             wt.event(11);
             // every consumer has left the image's previous use (s - 2)
-            while (lds_load_acquire(left + b) != consumers * (s >> ishift)) __builtin_amdgcn_s_sleep(8);
+            while (lds_load_acquire(left + b) != consumers * (s >> ishift)) __builtin_amdgcn_s_sleep(2);
             wt.event(12);
             uint32_t item = kNoItem;
             FirStreamDesc d;

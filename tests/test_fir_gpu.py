@@ -182,6 +182,41 @@ def test_device_resident_api_and_batch():
     assert (c, p) == (cr, pr) and rms(d_y[:p].cpu().numpy(), orr[:pr]) <= RMS_TOL
 
 
+def test_matrix_core_kernel_ragged_batch_and_edges():
+    """The default kernel for 2-channel rational rate pairs is the matrix-core periodic kernel
+    (DESIGN.md 4.1): check that it is the one that runs, on a ragged batch whose streams are
+    shorter than a period, one frame past a period block, and long; then a second launch on the
+    carried state (wrap bitmap, class-table drift and hist/in junction all in play)."""
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda:0")
+    frames = [1, 50, 147, 148, 9408, 9409, 20000, 64 * 147 * 3 + 77, 123457]
+    gs, rs, xs = [], [], []
+    for i, n in enumerate(frames):
+        g, r = make_pair(2, 44100, 48000, kernel=ra.FirKernel.Periodic)
+        gs.append(g)
+        rs.append(r)
+        xs.append(synth.fast_noise(2 * n, seed=300 + i))
+    batch = ra.FirBatch(gs)
+    for step in range(2):
+        d_in = [torch.from_numpy(x).to(dev) for x in xs]
+        d_out = [torch.zeros(g.bulk_output_bound(x.size, 512), device=dev) for g, x in zip(gs, xs)]
+        batch.bind(d_in, d_out)
+        consumed, produced = batch.resample_bulk_device(512, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        for i in range(len(frames)):
+            yr, _ = rs[i].resample_all(xs[i], 512)
+            assert consumed[i] == xs[i].size and produced[i] == yr.size, (step, i)
+            assert rms(d_out[i][: produced[i]].cpu().numpy(), yr) <= RMS_TOL, (step, i)
+    assert gs[-1].kernel_variant() == 3   # periodic matrix-core kernel
+    # other even rate pairs on the same path: 44.1 -> 96 k (20 class tiles), 16 / 32 / 64 taps above
+    g, r = make_pair(2, 44100, 96000, kernel=ra.FirKernel.Periodic)
+    x = synth.sweep(70001, 2, 44100.0)
+    yg, _ = g.resample_bulk(x, 512)
+    yr, _ = r.resample_all(x, 512)
+    assert yg.size == yr.size and rms(yg, yr) <= RMS_TOL
+    assert g.kernel_variant() == 3
+
+
 def test_linearity_and_shift_properties_at_full_size():
     # Size-independent properties on a large launch: linearity, and identical channels in ->
     # identical channels out.
