@@ -814,7 +814,8 @@ constexpr uint32_t kDbMaxImages = 4;
 static_assert(kDbMaxImages * 7 <= 32, "control arrays end where the item posts begin");
 // control words: seven arrays of kDbMaxImages (see fir_periodic_db_kernel) + one item post per image
 constexpr uint32_t kDbPostBase = 32;   // kDbMaxImages posts of kPostWords words follow
-constexpr uint32_t kDbCtrlWords = 64;
+constexpr uint32_t kDbMailBase = 64;   // producer 0 -> other producers: the claimed item, one slot per s & 3
+constexpr uint32_t kDbCtrlWords = 80;
 // floats per image (frame-before-period block + rows), a 16-byte multiple
 __host__ __device__ inline uint32_t db_image_len(uint32_t xprev_len, uint32_t pw, uint32_t row_stride) {
     // + 96: the matrix-core units prefetch up to 11 steps (88 dwords) past a window's end
@@ -1275,10 +1276,14 @@ __global__ __launch_bounds__(MF ? 768 : 1024) void fir_periodic_db_kernel(const 
             const uint32_t b = s & imask;
             float* xprev = lds + kDbCtrlWords + b * image_len;
             float* rows = xprev + geo.xprev_len;
-            wt.event(11);
-            // every consumer has left the image's previous use (s - 2)
-            while (lds_load_acquire(left + b) != consumers * (s >> ishift)) __builtin_amdgcn_s_sleep(2);
-            wt.event(12);
+            // The next item is claimed, and its descriptor fetched and placed, BEFORE waiting for the
+            // image: the global atomic, the descriptor load and the 64-bit divisions (~1-2 us) then
+            // overlap the wait instead of extending the time between "image free" and "image ready",
+            // which the consumers are waiting for.
+            // mailbox from producer 0 to the others, indexed by s & 3 like `posted`: producer 0 cannot be
+            // four items ahead of a producer that has not yet arrived for item s + 1
+            uint32_t* next_item = ctrl + kDbMailBase + (s & 3u);
+            uint32_t* posted_s = posted + (s & 3u);
             uint32_t item = kNoItem;
             FirStreamDesc d;
             ItemGeom ig;
@@ -1298,26 +1303,34 @@ __global__ __launch_bounds__(MF ? 768 : 1024) void fir_periodic_db_kernel(const 
                     ig = item_geom(geo, d, item - stream_idx * geo.blocks_per_stream);
                     if (ig.valid) break;
                 }
-                if (own_image) lds_store_release(claim_turn, s + 1);
-                if (lane == 0) {
-                    item_id[b] = item;
-                    tile_counter[b] = 0;
-                    if (item != kNoItem) {
-                        ItemPost* post = reinterpret_cast<ItemPost*>(ctrl + kDbPostBase + kPostWords * b);
-                        post->out = reinterpret_cast<unsigned long long>(d.out);
-                        post->table = reinterpret_cast<unsigned long long>(d.class_coef);
-                        post->n_block0 = ig.n_block0;
-                        post->n_limit = static_cast<int32_t>(d.n_out);
-                    }
+                if (own_image) {
+                    lds_store_release(claim_turn, s + 1);
+                } else {
+                    if (lane == 0) next_item[0] = item;
+                    lds_store_release(posted_s, s + 1);
                 }
-                lds_store_release(posted + b, s + 1);
             } else {
-                while (lds_load_acquire(posted + b) != s + 1) __builtin_amdgcn_s_sleep(2);
-                item = __builtin_amdgcn_readfirstlane(item_id[b]);
+                while (lds_load_acquire(posted_s) != s + 1) __builtin_amdgcn_s_sleep(2);
+                item = __builtin_amdgcn_readfirstlane(next_item[0]);
                 if (item != kNoItem) {
                     const uint32_t stream_idx = item / geo.blocks_per_stream;
                     d = load_uniform(descs + stream_idx);
                     ig = item_geom(geo, d, item - stream_idx * geo.blocks_per_stream);
+                }
+            }
+            wt.event(11);
+            // every consumer has left the image's previous use (s - images)
+            while (lds_load_acquire(left + b) != consumers * (s >> ishift)) __builtin_amdgcn_s_sleep(2);
+            wt.event(12);
+            if ((wave == 0 || own_image) && lane == 0) {
+                item_id[b] = item;
+                tile_counter[b] = 0;
+                if (item != kNoItem) {
+                    ItemPost* post = reinterpret_cast<ItemPost*>(ctrl + kDbPostBase + kPostWords * b);
+                    post->out = reinterpret_cast<unsigned long long>(d.out);
+                    post->table = reinterpret_cast<unsigned long long>(d.class_coef);
+                    post->n_block0 = ig.n_block0;
+                    post->n_limit = static_cast<int32_t>(d.n_out);
                 }
             }
             if (item != kNoItem && !(geo.debug & 1))
