@@ -1559,7 +1559,8 @@ GeoArgs to_args(const PeriodicGeometry& g) {
     const uint32_t channels = g.lp * g.cg;
     return GeoArgs{g.a, g.b, g.b / g.den, g.row_len, g.mfma ? g.n_units : g.n_tiles, g.lp, g.pw, g.row_stride, g.waves,
                    channels, xprev_len_of(g.pw, channels), g.producers, g.den, g.images ? g.images : 2u,
-                   g.mfma && g.n_units == 2 * g.n_tiles ? 1u : 0u, g.inline_wraps ? 1u : 0u, debug, stagger, nullptr, nullptr, 0u, 0u, nullptr, 0ull};
+                   g.mfma ? (g.n_units == 4 * g.n_tiles ? 2u : (g.n_units == 2 * g.n_tiles ? 1u : 0u)) : 0u,
+                   g.inline_wraps ? 1u : 0u, debug, stagger, nullptr, nullptr, 0u, 0u, nullptr, 0ull};
 }
 
 // Device class tables, shared by every stream on a device with the same polyphase table, rate
@@ -1592,7 +1593,7 @@ inline uint32_t class_offset(const PeriodicGeometry& g, uint32_t j) {
 }  // namespace
 
 namespace {
-// RSMP_FIR_MFMA: 0 = vector kernels only, 2 / 4 = matrix-core kernel with that many 16-period
+// RSMP_FIR_MFMA: 0 = vector kernels only, 1 / 2 / 4 = matrix-core kernel with that many 16-period
 // groups per work unit (default 2).  Two interleaved channels only.
 int mfma_knob() {
     static const int knob = [] {
@@ -1629,7 +1630,7 @@ PeriodicGeometry geometry_for(uint64_t num, uint64_t den, uint32_t taps, uint32_
     // (only the register-resident variant picks the results up: windows <= 192 taps, 2 groups/unit)
     static const bool ring_forced = getenv("RSMP_FIR_MFMA_RING") != nullptr;
     static const bool nowrap = getenv("RSMP_FIR_MFMA_NOWRAP") != nullptr;   // A/B: wraps by the fix-up launch
-    const bool mfma_regs = want_mfma && knob_mfma == 2 && g.row_len <= 192 && !ring_forced && !nowrap;
+    const bool mfma_regs = want_mfma && knob_mfma <= 2 && g.row_len <= 192 && !ring_forced && !nowrap;
     g.inline_wraps = want_mfma ? (mfma_regs && den >= kMfmaClassTile && r <= kMfmaWrapMax) : den >= kClassTile;
 
     // RSMP_FIR_PRODUCERS = n: n producer waves; for the vector kernels it also selects the
@@ -1704,6 +1705,7 @@ PeriodicGeometry geometry_for(uint64_t num, uint64_t den, uint32_t taps, uint32_
                 const uint32_t groups = (pw + 15) / 16;
                 g.n_units = g.n_tiles * ((groups + g.mfma - 1) / g.mfma);
                 g.waves = g.producers + static_cast<uint32_t>(knob_consumers);
+                if (g.waves > 12) g.waves = 12;   // __launch_bounds__(768) of the matrix-core kernels
             } else {
                 g.waves = 16;
             }
@@ -1738,7 +1740,7 @@ PeriodicGeometry geometry_for(uint64_t num, uint64_t den, uint32_t taps, uint32_
 
 PeriodicGeometry periodic_geometry(uint64_t num, uint64_t den, uint32_t taps, uint32_t channels) {
     const int knob = mfma_knob();
-    if (channels == 2 && (knob == 2 || knob == 4)) {
+    if (channels == 2 && (knob == 1 || knob == 2 || knob == 4)) {
         const PeriodicGeometry g = geometry_for(num, den, taps, channels, true);
         if (g.ok) return g;   // else: two images do not fit the LDS for this rate pair
     }
@@ -1965,11 +1967,14 @@ hipError_t launch_fir_periodic(const FirStreamDesc* d_descs, uint32_t n_streams,
     int variant;
     if (!geo.mfma) variant = (geo.cg == 2 ? (geo.lp == 1 ? 0 : 1) : 2) + (geo.producers ? 3 : 0);
     else if (geo.mfma == 4) variant = 7;
+    else if (geo.mfma == 1 && (!nb3 || mfma_ring)) return hipErrorInvalidValue;   // G = 1 exists only register-resident
     else if (mfma_dbg) variant = 7 + mfma_dbg;
+    else if (nb3 && !mfma_ring && geo.mfma == 1) variant = 18 + static_cast<int>(nb3) + (flat_rows ? 4 : 0);
     else if (nb3 && !mfma_ring) variant = 10 + static_cast<int>(nb3) + (flat_rows ? 4 : 0);
     else variant = 6;
 #define RSMP_MF(nb3v, flatv) reinterpret_cast<const void*>(fir_periodic_db_kernel<2, true, 8, 2 + 64 * (nb3v) + 512 * (flatv)>)
-    const void* fns[19] = {reinterpret_cast<const void*>(fir_periodic_kernel<2, true, 8>),
+#define RSMP_MF1(nb3v, flatv) reinterpret_cast<const void*>(fir_periodic_db_kernel<2, true, 8, 1 + 64 * (nb3v) + 512 * (flatv)>)
+    const void* fns[27] = {reinterpret_cast<const void*>(fir_periodic_kernel<2, true, 8>),
                            reinterpret_cast<const void*>(fir_periodic_kernel<2, false, 8>),
                            reinterpret_cast<const void*>(fir_periodic_kernel<1, false, 8>),
                            reinterpret_cast<const void*>(fir_periodic_db_kernel<2, true, 8, 0>),
@@ -1981,8 +1986,11 @@ hipError_t launch_fir_periodic(const FirStreamDesc* d_descs, uint32_t n_streams,
                            reinterpret_cast<const void*>(fir_periodic_db_kernel<2, true, 8, 2 + 32>),
                            reinterpret_cast<const void*>(fir_periodic_db_kernel<2, true, 8, 2 + 48>),
                            RSMP_MF(1, 0), RSMP_MF(2, 0), RSMP_MF(3, 0), RSMP_MF(4, 0),
-                           RSMP_MF(1, 1), RSMP_MF(2, 1), RSMP_MF(3, 1), RSMP_MF(4, 1)};
+                           RSMP_MF(1, 1), RSMP_MF(2, 1), RSMP_MF(3, 1), RSMP_MF(4, 1),
+                           RSMP_MF1(1, 0), RSMP_MF1(2, 0), RSMP_MF1(3, 0), RSMP_MF1(4, 0),
+                           RSMP_MF1(1, 1), RSMP_MF1(2, 1), RSMP_MF1(3, 1), RSMP_MF1(4, 1)};
 #undef RSMP_MF
+#undef RSMP_MF1
     {
         std::lock_guard<std::mutex> lock(mu);
         bool& have = granted[{device, variant}];
