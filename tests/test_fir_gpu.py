@@ -217,6 +217,32 @@ def test_matrix_core_kernel_ragged_batch_and_edges():
     assert g.kernel_variant() == 3
 
 
+def test_fuzz_periodic_kernels_against_oracle():
+    """Seeded sweep over audio rate pairs, tap counts, channel counts, lengths and chunk sizes on the
+    periodic kernels (matrix-core for 2 channels where two images fit, vector otherwise): counts
+    identical, output within the gate, and a second launch continuing each stream."""
+    rates = [8000, 11025, 16000, 22050, 32000, 44100, 48000, 88200, 96000, 176400, 192000]
+    lats = [ra.Latency.Sample8, ra.Latency.Sample16, ra.Latency.Sample32, ra.Latency.Sample64]
+    rng = np.random.default_rng(20240607)
+    variants = set()
+    for case in range(28):
+        in_hz, out_hz = (int(v) for v in rng.choice(rates, 2, replace=False))
+        ch = int(rng.choice([1, 2, 2, 2, 3, 4]))
+        lat = lats[int(rng.integers(len(lats)))]
+        g, r = make_pair(ch, in_hz, out_hz, lat=lat, kernel=ra.FirKernel.Periodic)
+        chunk = int(rng.integers(1, 300)) * ch
+        for part in range(2):
+            frames = int(rng.integers(1, 40000))
+            x = synth.fast_noise(ch * frames, seed=1000 + 10 * case + part)
+            yg, consumed, calls_g = g.resample_bulk(x, chunk, want_calls=True)
+            yr, calls_r = r.resample_all(x, chunk)
+            assert np.array_equal(calls_g, calls_r), (case, part, in_hz, out_hz, ch)
+            assert yg.size == yr.size, (case, part)
+            assert rms(yg, yr) <= RMS_TOL, (case, part, in_hz, out_hz, ch, lat)
+        variants.add(g.kernel_variant())
+    assert 3 in variants and 1 in variants   # both the matrix-core and the vector kernel were exercised
+
+
 def test_linearity_and_shift_properties_at_full_size():
     # Size-independent properties on a large launch: linearity, and identical channels in ->
     # identical channels out.
