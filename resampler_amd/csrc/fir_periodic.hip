@@ -1226,6 +1226,11 @@ __device__ __forceinline__ void mfma_consumer_stream(const GeoArgs& geo, float* 
             wt.event(7);
             if (!more) break;
             if (sn != s) {   // the unit just run was this wave's last on image b
+                // Its stores are still pending (they ride in the next unit's stream).  If they pick up
+                // wrap results, those live in image b's LDS area and are announced by image b's flag:
+                // once this wave has left, a producer may restage b and overwrite both (the wave would
+                // then wait for a flag value that is gone).  Store now in that case.
+                if (pend.valid && pend.unit.wrap) mfma_store_pending<G>(geo, pend);
                 leave(b);
                 s = sn;
                 b = bn;
