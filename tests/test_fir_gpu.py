@@ -1,6 +1,8 @@
 """GPU parity tests of the FIR path: everything goes through the C ABI (libresampler_amd.so) and is
 compared with the CPU oracle on the same inputs.  Gate (BASELINE.json north_star): output within
 1e-6 RMS of the CPU path, identical (consumed, produced) counts."""
+import os
+
 import numpy as np
 import pytest
 
@@ -207,14 +209,49 @@ def test_matrix_core_kernel_ragged_batch_and_edges():
             yr, _ = rs[i].resample_all(xs[i], 512)
             assert consumed[i] == xs[i].size and produced[i] == yr.size, (step, i)
             assert rms(d_out[i][: produced[i]].cpu().numpy(), yr) <= RMS_TOL, (step, i)
-    assert gs[-1].kernel_variant() == 3   # periodic matrix-core kernel
+    mfma_on = os.environ.get("RSMP_FIR_MFMA", "2") != "0"
+    assert gs[-1].kernel_variant() == (3 if mfma_on else 1)   # periodic matrix-core kernel by default
     # other even rate pairs on the same path: 44.1 -> 96 k (20 class tiles), 16 / 32 / 64 taps above
     g, r = make_pair(2, 44100, 96000, kernel=ra.FirKernel.Periodic)
     x = synth.sweep(70001, 2, 44100.0)
     yg, _ = g.resample_bulk(x, 512)
     yr, _ = r.resample_all(x, 512)
     assert yg.size == yr.size and rms(yg, yr) <= RMS_TOL
-    assert g.kernel_variant() == 3
+    assert g.kernel_variant() == (3 if mfma_on else 1)
+
+
+def test_repeated_launches_are_bit_identical():
+    """The periodic kernels are full of dynamic scheduling (work queues, claims, producer / consumer
+    flags): whatever the interleaving, a launch must produce the same bits.  40 launches of a
+    16-stream batch, each compared with the first one (which is checked against the oracle)."""
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda:0")
+    n_streams, frames = 16, 150001
+    gs, xs = [], []
+    for i in range(n_streams):
+        gs.append(ra.ResamplerFir.new_from_hz(2, 44100, 48000, ra.Latency.Sample64, ra.Attenuation.Db90))
+        xs.append(synth.fast_noise(2 * frames, seed=700 + i))
+    d_in = [torch.from_numpy(x).to(dev) for x in xs]
+    d_out = [torch.zeros(gs[0].bulk_output_bound(2 * frames, 512), device=dev) for _ in range(n_streams)]
+    batch = ra.FirBatch(gs)
+    batch.bind(d_in, d_out)
+    stream = torch.cuda.current_stream().cuda_stream
+    first = None
+    for launch in range(40):
+        for o_ in d_out:
+            o_.fill_(float("nan"))
+        batch.reset()
+        consumed, produced = batch.resample_bulk_device(512, stream)
+        torch.cuda.synchronize()
+        got = [d_out[i][: produced[i]].clone() for i in range(n_streams)]
+        if first is None:
+            first = got
+            r = o.OracleFir(2, 44100, 48000, 128, 90)
+            yr, _ = r.resample_all(xs[0], 512)
+            assert produced[0] == yr.size and rms(first[0].cpu().numpy(), yr) <= RMS_TOL
+        else:
+            for i in range(n_streams):
+                assert torch.equal(got[i], first[i]), (launch, i)
 
 
 def test_fuzz_periodic_kernels_against_oracle():
@@ -240,7 +277,9 @@ def test_fuzz_periodic_kernels_against_oracle():
             assert yg.size == yr.size, (case, part)
             assert rms(yg, yr) <= RMS_TOL, (case, part, in_hz, out_hz, ch, lat)
         variants.add(g.kernel_variant())
-    assert 3 in variants and 1 in variants   # both the matrix-core and the vector kernel were exercised
+    assert 1 in variants                      # the vector kernel was exercised ...
+    if os.environ.get("RSMP_FIR_MFMA", "2") != "0":
+        assert 3 in variants                  # ... and so was the matrix-core kernel (unless switched off)
 
 
 def test_linearity_and_shift_properties_at_full_size():
