@@ -19,6 +19,8 @@
 // regions do not collide).
 #include "fft_kernels.h"
 
+#include <cstdlib>
+
 namespace rsmp {
 
 namespace {
@@ -288,6 +290,221 @@ __global__ __launch_bounds__(kFftThreads) void fft_ola_kernel(FftPlanDev plan,
         for (uint32_t e = threadIdx.x; e < C * fo; e += kFftThreads) d.overlap[e] = carry[e];
 }
 
+// ---- plan-specialised kernel -----------------------------------------------------------------------
+// The same pipeline with the transform lengths and stage radices as template parameters: trip
+// counts, strides, divisors and twiddle offsets fold into immediates and the stage loop disappears.
+// The generic kernel above issues one instruction per 4 cycles per SIMD, 30 % of them scalar loop /
+// dispatch / spill traffic -- it is bound by instruction issue, not by LDS, HBM or the ALUs -- so
+// what a plan-specific build removes is exactly what it is short of.  Instantiated for the
+// 44.1 <-> 48 kHz family (1176 = 3.7.7.8 and 1280 = 4.5.8.8 complex points); every other plan runs
+// on the generic kernel.  Arithmetic, operation order and tables are identical.
+template <int N, int R, int STRIDE>
+__device__ __forceinline__ void stage_ct(const float2* __restrict__ src, float2* __restrict__ dst,
+                                         const float2* __restrict__ tw) {
+    constexpr int M = N / R;
+    constexpr int ITER = (M + kFftThreads - 1) / kFftThreads;
+#pragma unroll 1   // unrolled, the two butterflies of a 2-trip stage cost a workgroup per CU in registers
+    for (int it = 0; it < ITER; ++it) {
+        const int i = static_cast<int>(threadIdx.x) + it * kFftThreads;
+        if ((it + 1) * kFftThreads <= M || i < M) {
+            const int k = STRIDE == 1 ? 0 : i % STRIDE;
+            float2 t[R], o[R];
+#pragma unroll
+            for (int q = 0; q < R; ++q) t[q] = src[i + q * M];
+            if constexpr (STRIDE != 1) {
+                const float2* w = tw + k * (R - 1);
+#pragma unroll
+                for (int q = 1; q < R; ++q) t[q] = cmul(w[q - 1], t[q]);
+            }
+            dft<R>(t, o);
+            float2* d = dst + R * i - (R - 1) * k;
+#pragma unroll
+            for (int q = 0; q < R; ++q) d[q * STRIDE] = o[q];
+        }
+    }
+}
+
+template <int N, int STRIDE, int TWOFF, int R, int... Rest>
+struct StagesCt {
+    static __device__ __forceinline__ float2* run(float2* a, float2* b, const float2* __restrict__ tw) {
+        stage_ct<N, R, STRIDE>(a, b, tw + TWOFF);
+        __syncthreads();
+        if constexpr (sizeof...(Rest) == 0) {
+            return b;
+        } else {
+            return StagesCt<N, STRIDE * R, TWOFF + (STRIDE == 1 ? 0 : STRIDE * (R - 1)), Rest...>::run(b, a, tw);
+        }
+    }
+};
+template <int N, int... Rs> struct PlanCt {
+    static constexpr int kN = N;
+    static constexpr int kStages = sizeof...(Rs);
+    static __device__ __forceinline__ float2* run(float2* a, float2* b, const float2* __restrict__ tw) {
+        return StagesCt<N, 1, 0, Rs...>::run(a, b, tw);
+    }
+    static bool matches(uint32_t n, uint32_t n_stages, const uint32_t* radix) {
+        const uint32_t want[] = {static_cast<uint32_t>(Rs)...};
+        if (n != static_cast<uint32_t>(N) || n_stages != sizeof...(Rs)) return false;
+        for (uint32_t s = 0; s < n_stages; ++s)
+            if (radix[s] != want[s]) return false;
+        return true;
+    }
+};
+
+// postprocess_forward / preprocess_inverse with the length known (every plan the resampler builds
+// has n2 / 2 - 1 twiddles: the pair loop covers all bins)
+template <int N2>
+__device__ __forceinline__ void postprocess_forward_ct(float2* x, const float2* __restrict__ rc) {
+    constexpr int LEN = N2 + 1, SPLIT = LEN / 2, ITERS = SPLIT - 1;
+    constexpr int TRIPS = (ITERS + kFftThreads - 1) / kFftThreads;
+    if (threadIdx.x == 0) {
+        const float2 z0 = x[0];
+        x[0] = make_float2(z0.x + z0.y, 0.0f);
+        x[N2] = make_float2(z0.x - z0.y, 0.0f);
+    }
+#pragma unroll
+    for (int it = 0; it < TRIPS; ++it) {
+                if (it > 0) __builtin_amdgcn_sched_barrier(0);
+        const int i = static_cast<int>(threadIdx.x) + it * kFftThreads;
+        if (i < ITERS) {
+            const int l = 1 + i, rr = N2 - 1 - i;
+            const float2 o = x[l], orv = x[rr], tw = rc[i];
+            const float2 sum = cadd(o, orv), diff = csub(o, orv);
+            const float half_sum_real = 0.5f * sum.x, half_diff_imag = 0.5f * diff.y;
+            const float real = sum.y * tw.x + diff.x * tw.y;
+            const float imag = sum.y * tw.y - diff.x * tw.x;
+            x[l] = make_float2(half_sum_real + real, half_diff_imag + imag);
+            x[rr] = make_float2(half_sum_real - real, imag - half_diff_imag);
+        }
+    }
+    if ((LEN & 1) && threadIdx.x == 32) x[LEN / 2].y = -x[LEN / 2].y;
+}
+
+template <int N2>
+__device__ __forceinline__ void preprocess_inverse_ct(float2* y, const float2* __restrict__ rc) {
+    constexpr int LEN = N2 + 1, SPLIT = LEN / 2, ITERS = SPLIT - 1;
+    constexpr int TRIPS = (ITERS + kFftThreads - 1) / kFftThreads;
+    if (threadIdx.x == 0) {
+        const float2 a = y[0], b = y[N2];
+        const float2 first_sum = cadd(a, b), first_diff = csub(a, b);
+        y[0] = make_float2(first_sum.x - first_sum.y, first_diff.x - first_diff.y);
+    }
+#pragma unroll
+    for (int it = 0; it < TRIPS; ++it) {
+                if (it > 0) __builtin_amdgcn_sched_barrier(0);
+        const int i = static_cast<int>(threadIdx.x) + it * kFftThreads;
+        if (i < ITERS) {
+            const int l = 1 + i, rr = N2 - 1 - i;
+            const float2 a = y[l], b = y[rr], tw = rc[i];
+            const float2 sum = cadd(a, b), diff = csub(a, b);
+            const float real = sum.y * tw.x + diff.x * tw.y;
+            const float imag = sum.y * tw.y - diff.x * tw.x;
+            y[l] = make_float2(sum.x - real, diff.y - imag);
+            y[rr] = make_float2(sum.x + real, -imag - diff.y);
+        }
+    }
+    if ((LEN & 1) && threadIdx.x == 32) {
+        const float2 c = y[LEN / 2];
+        const float2 dbl = cadd(c, c);
+        y[LEN / 2] = make_float2(dbl.x, -dbl.y);
+    }
+    __syncthreads();
+    constexpr int T2 = (N2 + kFftThreads - 1) / kFftThreads;
+#pragma unroll
+    for (int it = 0; it < T2; ++it) {
+                if (it > 0) __builtin_amdgcn_sched_barrier(0);
+        const int i = static_cast<int>(threadIdx.x) + it * kFftThreads;
+        if (i < N2) y[i].y = -y[i].y;
+    }
+}
+
+template <class FWD, class INV>
+__global__ __launch_bounds__(kFftThreads) void fft_ola_kernel_ct(FftPlanDev plan,
+                                                                 const FftStreamDesc* __restrict__ descs) {
+    extern __shared__ __attribute__((aligned(16))) float2 lds2[];
+    constexpr int FI = FWD::kN, FO = INV::kN;
+    constexpr int LDSC = (FI > FO ? FI : FO) + 1;
+    const FftStreamDesc d = descs[blockIdx.y];
+    const uint32_t first = blockIdx.x * kFftRun;
+    if (first >= d.n_blocks) return;
+    const uint32_t last = first + kFftRun < d.n_blocks ? first + kFftRun : d.n_blocks;  // exclusive
+    const uint32_t C = d.channels;
+    float2* bufA = lds2;
+    float2* bufB = lds2 + LDSC;
+    float* carry = reinterpret_cast<float*>(lds2 + 2 * LDSC);   // [C][FO]
+
+    if (first == 0)
+        for (uint32_t e = threadIdx.x; e < C * FO; e += kFftThreads) carry[e] = d.overlap[e];
+    const int64_t b_begin = first == 0 ? 0 : static_cast<int64_t>(first) - 1;
+    __syncthreads();
+
+    for (int64_t b = b_begin; b < static_cast<int64_t>(last); ++b) {
+        const bool emit = b >= static_cast<int64_t>(first);
+        const float* __restrict__ xin = d.in + static_cast<size_t>(b) * FI * C;
+        float* __restrict__ xout = d.out + static_cast<size_t>(b) * FO * C;
+        for (uint32_t c = 0; c < C; ++c) {
+            constexpr int TI = (FI + kFftThreads - 1) / kFftThreads;
+#pragma unroll
+            for (int it = 0; it < TI; ++it) {
+                if (it > 0) __builtin_amdgcn_sched_barrier(0);
+                const int i = static_cast<int>(threadIdx.x) + it * kFftThreads;
+                if (i < FI) {
+                    float2 v = make_float2(0.f, 0.f);
+                    if (2 * i + 1 < FI) v = make_float2(xin[(2 * i) * C + c], xin[(2 * i + 1) * C + c]);
+                    else if (2 * i < FI) v = make_float2(xin[(2 * i) * C + c], 0.f);
+                    bufA[i] = v;
+                }
+            }
+            __syncthreads();
+            float2* X = FWD::run(bufA, bufB, plan.tw_f);
+            float2* Y = X == bufA ? bufB : bufA;
+            postprocess_forward_ct<FI>(X, plan.rc_f);
+            __syncthreads();
+            constexpr int TK = (FO + 1 + kFftThreads - 1) / kFftThreads;
+#pragma unroll
+            for (int it = 0; it < TK; ++it) {
+                if (it > 0) __builtin_amdgcn_sched_barrier(0);
+                const uint32_t k = threadIdx.x + it * kFftThreads;
+                if (k <= FO) Y[k] = k < plan.new_length ? cmul(X[k], plan.filter[k]) : make_float2(0.f, 0.f);
+            }
+            __syncthreads();
+            preprocess_inverse_ct<FO>(Y, plan.rc_i);
+            __syncthreads();
+            float2* Z = INV::run(Y, X, plan.tw_i);
+            float* ov = carry + c * FO;
+            constexpr int TO = (FO + kFftThreads - 1) / kFftThreads;
+            if (emit) {
+#pragma unroll
+                for (int it = 0; it < TO; ++it) {
+                if (it > 0) __builtin_amdgcn_sched_barrier(0);
+                    const uint32_t t = threadIdx.x + it * kFftThreads;
+                    if (t < FO) {
+                        const float2 z = Z[t >> 1];
+                        const float y = (t & 1u) ? -z.y : z.x;
+                        xout[t * C + c] = y + ov[t];
+                    }
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < TO; ++it) {
+                if (it > 0) __builtin_amdgcn_sched_barrier(0);
+                const uint32_t t = threadIdx.x + it * kFftThreads;
+                if (t < FO) {
+                    const float2 z = Z[(t + FO) >> 1];
+                    ov[t] = ((t + FO) & 1u) ? -z.y : z.x;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (last == d.n_blocks)
+        for (uint32_t e = threadIdx.x; e < C * FO; e += kFftThreads) d.overlap[e] = carry[e];
+}
+
+typedef PlanCt<1176, 3, 7, 7, 8> Plan1176;
+typedef PlanCt<1280, 4, 5, 8, 8> Plan1280;
+
 __global__ __launch_bounds__(kFftThreads) void fft_filter_kernel(FftPlanDev plan,
                                                                  const float* __restrict__ filter_time,
                                                                  float2* __restrict__ spectrum) {
@@ -321,7 +538,17 @@ hipError_t launch_fft_ola(const FftPlanDev& plan, const FftStreamDesc* d_descs, 
         if (e != hipSuccess) return e;
     }
     const dim3 grid((max_blocks + kFftRun - 1) / kFftRun, n_streams);
-    hipLaunchKernelGGL(fft_ola_kernel, grid, dim3(kFftThreads), lds, stream, plan, d_descs);
+    static const bool generic_only = getenv("RSMP_FFT_GENERIC") != nullptr;   // A/B: skip the specialised builds
+    const bool rc_full = plan.n_rc_f == plan.fft_in / 2 - 1 && plan.n_rc_i == plan.fft_out / 2 - 1;
+    if (!generic_only && rc_full && Plan1176::matches(plan.fft_in, plan.n_stages_f, plan.radix_f) &&
+        Plan1280::matches(plan.fft_out, plan.n_stages_i, plan.radix_i)) {
+        hipLaunchKernelGGL((fft_ola_kernel_ct<Plan1176, Plan1280>), grid, dim3(kFftThreads), lds, stream, plan, d_descs);
+    } else if (!generic_only && rc_full && Plan1280::matches(plan.fft_in, plan.n_stages_f, plan.radix_f) &&
+               Plan1176::matches(plan.fft_out, plan.n_stages_i, plan.radix_i)) {
+        hipLaunchKernelGGL((fft_ola_kernel_ct<Plan1280, Plan1176>), grid, dim3(kFftThreads), lds, stream, plan, d_descs);
+    } else {
+        hipLaunchKernelGGL(fft_ola_kernel, grid, dim3(kFftThreads), lds, stream, plan, d_descs);
+    }
     return hipGetLastError();
 }
 
