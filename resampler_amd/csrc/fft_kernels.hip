@@ -19,6 +19,8 @@
 // regions do not collide).
 #include "fft_kernels.h"
 
+#include <cmath>
+
 #include <cstdlib>
 
 namespace rsmp {
@@ -229,12 +231,13 @@ __device__ void preprocess_inverse(float2* y, uint32_t n2, const float2* __restr
 }
 
 __global__ __launch_bounds__(kFftThreads) void fft_ola_kernel(FftPlanDev plan,
-                                                              const FftStreamDesc* __restrict__ descs) {
+                                                              const FftStreamDesc* __restrict__ descs,
+                                                              uint32_t run) {
     extern __shared__ __attribute__((aligned(16))) float2 lds2[];
     const FftStreamDesc d = descs[blockIdx.y];
-    const uint32_t first = blockIdx.x * kFftRun;
+    const uint32_t first = blockIdx.x * run;
     if (first >= d.n_blocks) return;
-    const uint32_t last = first + kFftRun < d.n_blocks ? first + kFftRun : d.n_blocks;  // exclusive
+    const uint32_t last = first + run < d.n_blocks ? first + run : d.n_blocks;  // exclusive
     const uint32_t C = d.channels, fi = plan.fft_in, fo = plan.fft_out;
     float2* bufA = lds2;
     float2* bufB = lds2 + plan.lds_complex;
@@ -420,14 +423,15 @@ __device__ __forceinline__ void preprocess_inverse_ct(float2* y, const float2* _
 
 template <class FWD, class INV>
 __global__ __launch_bounds__(kFftThreads) void fft_ola_kernel_ct(FftPlanDev plan,
-                                                                 const FftStreamDesc* __restrict__ descs) {
+                                                                 const FftStreamDesc* __restrict__ descs,
+                                                                 uint32_t run) {
     extern __shared__ __attribute__((aligned(16))) float2 lds2[];
     constexpr int FI = FWD::kN, FO = INV::kN;
     constexpr int LDSC = (FI > FO ? FI : FO) + 1;
     const FftStreamDesc d = descs[blockIdx.y];
-    const uint32_t first = blockIdx.x * kFftRun;
+    const uint32_t first = blockIdx.x * run;
     if (first >= d.n_blocks) return;
-    const uint32_t last = first + kFftRun < d.n_blocks ? first + kFftRun : d.n_blocks;  // exclusive
+    const uint32_t last = first + run < d.n_blocks ? first + run : d.n_blocks;  // exclusive
     const uint32_t C = d.channels;
     float2* bufA = lds2;
     float2* bufB = lds2 + LDSC;
@@ -537,18 +541,43 @@ hipError_t launch_fft_ola(const FftPlanDev& plan, const FftStreamDesc* d_descs, 
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
     }
-    const dim3 grid((max_blocks + kFftRun - 1) / kFftRun, n_streams);
     static const bool generic_only = getenv("RSMP_FFT_GENERIC") != nullptr;   // A/B: skip the specialised builds
     const bool rc_full = plan.n_rc_f == plan.fft_in / 2 - 1 && plan.n_rc_i == plan.fft_out / 2 - 1;
+    typedef void (*Kernel)(FftPlanDev, const FftStreamDesc*, uint32_t);
+    Kernel fn = fft_ola_kernel;
     if (!generic_only && rc_full && Plan1176::matches(plan.fft_in, plan.n_stages_f, plan.radix_f) &&
-        Plan1280::matches(plan.fft_out, plan.n_stages_i, plan.radix_i)) {
-        hipLaunchKernelGGL((fft_ola_kernel_ct<Plan1176, Plan1280>), grid, dim3(kFftThreads), lds, stream, plan, d_descs);
-    } else if (!generic_only && rc_full && Plan1280::matches(plan.fft_in, plan.n_stages_f, plan.radix_f) &&
-               Plan1176::matches(plan.fft_out, plan.n_stages_i, plan.radix_i)) {
-        hipLaunchKernelGGL((fft_ola_kernel_ct<Plan1280, Plan1176>), grid, dim3(kFftThreads), lds, stream, plan, d_descs);
-    } else {
-        hipLaunchKernelGGL(fft_ola_kernel, grid, dim3(kFftThreads), lds, stream, plan, d_descs);
+        Plan1280::matches(plan.fft_out, plan.n_stages_i, plan.radix_i))
+        fn = fft_ola_kernel_ct<Plan1176, Plan1280>;
+    else if (!generic_only && rc_full && Plan1280::matches(plan.fft_in, plan.n_stages_f, plan.radix_f) &&
+             Plan1176::matches(plan.fft_out, plan.n_stages_i, plan.radix_i))
+        fn = fft_ola_kernel_ct<Plan1280, Plan1176>;
+    // Blocks per workgroup: every run after a stream's first recomputes its predecessor block (1 / run
+    // extra work), and the launch ends with a partly filled round of workgroups unless their number
+    // is close to a multiple of what the chip holds at once.  Pick the run length (8..64) that
+    // maximises useful work per occupied slot.
+    uint32_t run = kFftRun;
+    {
+        int dev = 0, cus = 256, per_cu = 4;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(fn), kFftThreads, lds) != hipSuccess ||
+            per_cu < 1)
+            per_cu = 4;
+        const double slots = static_cast<double>(cus) * per_cu;
+        double best = -1.0;
+        for (uint32_t cand = 8; cand <= 64; ++cand) {
+            const double runs = static_cast<double>((max_blocks + cand - 1) / cand);
+            const double wgs = runs * n_streams;
+            const double rounds = std::ceil(wgs / slots);
+            const double useful = static_cast<double>(max_blocks) / (max_blocks + runs - 1.0);   // halo blocks
+            const double score = wgs / (rounds * slots) * useful;
+            if (score > best + 1e-9) { best = score; run = cand; }
+        }
+        static const char* knob = getenv("RSMP_FFT_RUN");
+        if (knob && atoi(knob) > 0) run = static_cast<uint32_t>(atoi(knob));
     }
+    const dim3 grid((max_blocks + run - 1) / run, n_streams);
+    hipLaunchKernelGGL(fn, grid, dim3(kFftThreads), lds, stream, plan, d_descs, run);
     return hipGetLastError();
 }
 
