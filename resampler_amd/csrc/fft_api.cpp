@@ -152,7 +152,7 @@ int launch_fft_jobs(rsmp_fft* leader, const std::vector<FftJob>& jobs, hipStream
         RSMP_HIP_CHECK(leader->d_desc.reserve(bytes));
     }
     FftStreamDesc* h = leader->h_desc.as<FftStreamDesc>();
-    uint32_t max_blocks = 0, max_channels = 0;
+    uint32_t max_blocks = 0, max_channels = 0, min_channels = 0xFFFFFFFFu;
     for (size_t i = 0; i < n; ++i) {
         const FftJob& j = jobs[i];
         h[i].in = j.d_in;
@@ -162,13 +162,14 @@ int launch_fft_jobs(rsmp_fft* leader, const std::vector<FftJob>& jobs, hipStream
         h[i].channels = static_cast<uint32_t>(j.r->channels);
         if (h[i].n_blocks > max_blocks) max_blocks = h[i].n_blocks;
         if (h[i].channels > max_channels) max_channels = h[i].channels;
+        if (h[i].channels < min_channels) min_channels = h[i].channels;
     }
     RSMP_HIP_CHECK(hipMemcpyAsync(leader->d_desc.get(), h, bytes, hipMemcpyHostToDevice, stream));
     RSMP_HIP_CHECK(hipEventRecord(leader->desc_copied, stream));
     leader->desc_pending = true;
     if (leader->profiling) RSMP_HIP_CHECK(hipEventRecord(leader->prof_start, stream));
     RSMP_HIP_CHECK(rsmp::launch_fft_ola(leader->plan->dev, leader->d_desc.as<FftStreamDesc>(),
-                                        static_cast<uint32_t>(n), max_blocks, max_channels, stream));
+                                        static_cast<uint32_t>(n), max_blocks, max_channels, min_channels, stream));
     if (leader->profiling) {
         RSMP_HIP_CHECK(hipEventRecord(leader->prof_stop, stream));
         leader->prof_valid = true;

@@ -39,7 +39,8 @@ struct FftStreamDesc {
 constexpr uint32_t kFftRun = 16;
 
 hipError_t launch_fft_ola(const FftPlanDev& plan, const FftStreamDesc* d_descs, uint32_t n_streams,
-                          uint32_t max_blocks, uint32_t max_channels, hipStream_t stream);
+                          uint32_t max_blocks, uint32_t max_channels, uint32_t min_channels,
+                          hipStream_t stream);
 // filter_spectrum[0 .. fft_in] = forward real FFT of d_filter_time[0 .. 2*fft_in)
 // (resampler_fft.rs:375-376); plan.filter is ignored.
 hipError_t launch_fft_filter_spectrum(const FftPlanDev& plan, const float* d_filter_time,

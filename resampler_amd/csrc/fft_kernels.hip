@@ -506,6 +506,163 @@ __global__ __launch_bounds__(kFftThreads) void fft_ola_kernel_ct(FftPlanDev plan
         for (uint32_t e = threadIdx.x; e < C * FO; e += kFftThreads) d.overlap[e] = carry[e];
 }
 
+// ---- two channels per phase --------------------------------------------------------------------------
+// A barrier-separated phase of this pipeline costs about a microsecond however little it computes
+// (per-wave trace), so the stereo build does the work of both channels between two barriers: half
+// the barriers per transform, two independent butterflies per thread to overlap, and the
+// interleaved frames are loaded and stored as whole float4 (two frames x two channels) instead of
+// channel-strided scalars.  Arithmetic per channel is unchanged.
+template <int N, int STRIDE, int TWOFF, int R, int... Rest>
+struct StagesCt2 {
+    static __device__ __forceinline__ bool run(float2* a0, float2* b0, float2* a1, float2* b1,
+                                               const float2* __restrict__ tw) {
+        stage_ct<N, R, STRIDE>(a0, b0, tw + TWOFF);
+        stage_ct<N, R, STRIDE>(a1, b1, tw + TWOFF);
+        __syncthreads();
+        if constexpr (sizeof...(Rest) == 0) {
+            return true;   // result in the b buffers
+        } else {
+            return !StagesCt2<N, STRIDE * R, TWOFF + (STRIDE == 1 ? 0 : STRIDE * (R - 1)), Rest...>::run(b0, a0, b1, a1, tw);
+        }
+    }
+};
+
+template <int N2>
+__device__ __forceinline__ void conj_ct(float2* y) {
+    constexpr int T2 = (N2 + kFftThreads - 1) / kFftThreads;
+#pragma unroll
+    for (int it = 0; it < T2; ++it) {
+        const int i = static_cast<int>(threadIdx.x) + it * kFftThreads;
+        if (i < N2) y[i].y = -y[i].y;
+    }
+}
+
+// preprocess_inverse_ct without its trailing barrier + conjugation (the caller runs both channels, then
+// one barrier, then conj_ct on both)
+template <int N2>
+__device__ __forceinline__ void preprocess_inverse_head_ct(float2* y, const float2* __restrict__ rc) {
+    constexpr int LEN = N2 + 1, SPLIT = LEN / 2, ITERS = SPLIT - 1;
+    constexpr int TRIPS = (ITERS + kFftThreads - 1) / kFftThreads;
+    if (threadIdx.x == 0) {
+        const float2 a = y[0], b = y[N2];
+        const float2 first_sum = cadd(a, b), first_diff = csub(a, b);
+        y[0] = make_float2(first_sum.x - first_sum.y, first_diff.x - first_diff.y);
+    }
+#pragma unroll
+    for (int it = 0; it < TRIPS; ++it) {
+        const int i = static_cast<int>(threadIdx.x) + it * kFftThreads;
+        if (i < ITERS) {
+            const int l = 1 + i, rr = N2 - 1 - i;
+            const float2 a = y[l], b = y[rr], tw = rc[i];
+            const float2 sum = cadd(a, b), diff = csub(a, b);
+            const float real = sum.y * tw.x + diff.x * tw.y;
+            const float imag = sum.y * tw.y - diff.x * tw.x;
+            y[l] = make_float2(sum.x - real, diff.y - imag);
+            y[rr] = make_float2(sum.x + real, -imag - diff.y);
+        }
+    }
+    if ((LEN & 1) && threadIdx.x == 32) {
+        const float2 c = y[LEN / 2];
+        const float2 dbl = cadd(c, c);
+        y[LEN / 2] = make_float2(dbl.x, -dbl.y);
+    }
+}
+
+template <class P> struct Stages2Of;
+template <int N, int... Rs> struct Stages2Of<PlanCt<N, Rs...>> { typedef StagesCt2<N, 1, 0, Rs...> type; };
+
+template <class FWD, class INV>
+__global__ __launch_bounds__(kFftThreads) void fft_ola_kernel_ct2(FftPlanDev plan,
+                                                                  const FftStreamDesc* __restrict__ descs,
+                                                                  uint32_t run) {
+    extern __shared__ __attribute__((aligned(16))) float2 lds2[];
+    constexpr int FI = FWD::kN, FO = INV::kN;
+    constexpr int LDSC = (FI > FO ? FI : FO) + 1;
+    static_assert(FI % 2 == 0 && FO % 2 == 0, "frame pairs");
+    const FftStreamDesc d = descs[blockIdx.y];   // d.channels == 2
+    const uint32_t first = blockIdx.x * run;
+    if (first >= d.n_blocks) return;
+    const uint32_t last = first + run < d.n_blocks ? first + run : d.n_blocks;  // exclusive
+    float2* A0 = lds2;
+    float2* B0 = lds2 + LDSC;
+    float2* A1 = lds2 + 2 * LDSC;
+    float2* B1 = lds2 + 3 * LDSC;
+    float* carry = reinterpret_cast<float*>(lds2 + 4 * LDSC);   // [2][FO]
+
+    if (first == 0)
+        for (uint32_t e = threadIdx.x; e < 2 * FO; e += kFftThreads) carry[e] = d.overlap[e];
+    const int64_t b_begin = first == 0 ? 0 : static_cast<int64_t>(first) - 1;
+    __syncthreads();
+
+    for (int64_t b = b_begin; b < static_cast<int64_t>(last); ++b) {
+        const bool emit = b >= static_cast<int64_t>(first);
+        const float4* __restrict__ xin4 = reinterpret_cast<const float4*>(d.in + static_cast<size_t>(b) * FI * 2);
+        float4* __restrict__ xout4 = reinterpret_cast<float4*>(d.out + static_cast<size_t>(b) * FO * 2);
+        // resampler_fft.rs:387-388: FI reals + FI zeros per channel, viewed as FI complexes; complex i =
+        // frames 2i, 2i+1 (i < FI / 2), zero beyond.  One float4 = both frames of both channels.
+        constexpr int TI = (FI + kFftThreads - 1) / kFftThreads;
+#pragma unroll
+        for (int it = 0; it < TI; ++it) {
+            const int i = static_cast<int>(threadIdx.x) + it * kFftThreads;
+            if (i < FI) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (i < FI / 2) v = xin4[i];
+                A0[i] = make_float2(v.x, v.z);
+                A1[i] = make_float2(v.y, v.w);
+            }
+        }
+        __syncthreads();
+        const bool in_b = Stages2Of<FWD>::type::run(A0, B0, A1, B1, plan.tw_f);
+        float2* X0 = in_b ? B0 : A0;
+        float2* X1 = in_b ? B1 : A1;
+        float2* Y0 = in_b ? A0 : B0;
+        float2* Y1 = in_b ? A1 : B1;
+        postprocess_forward_ct<FI>(X0, plan.rc_f);
+        postprocess_forward_ct<FI>(X1, plan.rc_f);
+        __syncthreads();
+        constexpr int TK = (FO + 1 + kFftThreads - 1) / kFftThreads;
+#pragma unroll
+        for (int it = 0; it < TK; ++it) {
+            const uint32_t k = threadIdx.x + it * kFftThreads;
+            if (k <= FO) {
+                const bool on = k < plan.new_length;
+                const float2 f = on ? plan.filter[k] : make_float2(0.f, 0.f);
+                Y0[k] = on ? cmul(X0[k], f) : make_float2(0.f, 0.f);
+                Y1[k] = on ? cmul(X1[k], f) : make_float2(0.f, 0.f);
+            }
+        }
+        __syncthreads();
+        preprocess_inverse_head_ct<FO>(Y0, plan.rc_i);
+        preprocess_inverse_head_ct<FO>(Y1, plan.rc_i);
+        __syncthreads();
+        conj_ct<FO>(Y0);
+        conj_ct<FO>(Y1);
+        __syncthreads();
+        const bool z_in_x = Stages2Of<INV>::type::run(Y0, X0, Y1, X1, plan.tw_i);
+        const float2* Z0 = z_in_x ? X0 : Y0;
+        const float2* Z1 = z_in_x ? X1 : Y1;
+        // output conjugation (radix_fft.rs:656-669), reals 2i, 2i+1 <- Z[i]; the first FO reals of a
+        // channel are overlap-added and stored, the second FO become its next overlap (:416-423).
+        float2* ov0 = reinterpret_cast<float2*>(carry);
+        float2* ov1 = reinterpret_cast<float2*>(carry + FO);
+        constexpr int TO = (FO / 2 + kFftThreads - 1) / kFftThreads;
+#pragma unroll
+        for (int it = 0; it < TO; ++it) {
+            const uint32_t i = threadIdx.x + it * kFftThreads;
+            if (i < FO / 2) {
+                const float2 z0 = Z0[i], z1 = Z1[i], n0 = Z0[i + FO / 2], n1 = Z1[i + FO / 2];
+                const float2 o0 = ov0[i], o1 = ov1[i];
+                if (emit) xout4[i] = make_float4(z0.x + o0.x, z1.x + o1.x, -z0.y + o0.y, -z1.y + o1.y);
+                ov0[i] = make_float2(n0.x, -n0.y);
+                ov1[i] = make_float2(n1.x, -n1.y);
+            }
+        }
+        __syncthreads();
+    }
+    if (last == d.n_blocks)
+        for (uint32_t e = threadIdx.x; e < 2 * FO; e += kFftThreads) d.overlap[e] = carry[e];
+}
+
 typedef PlanCt<1176, 3, 7, 7, 8> Plan1176;
 typedef PlanCt<1280, 4, 5, 8, 8> Plan1280;
 
@@ -533,24 +690,33 @@ size_t fft_ola_lds_bytes(const FftPlanDev& plan, uint32_t channels) {
 }
 
 hipError_t launch_fft_ola(const FftPlanDev& plan, const FftStreamDesc* d_descs, uint32_t n_streams,
-                          uint32_t max_blocks, uint32_t max_channels, hipStream_t stream) {
+                          uint32_t max_blocks, uint32_t max_channels, uint32_t min_channels,
+                          hipStream_t stream) {
     if (n_streams == 0 || max_blocks == 0) return hipSuccess;
-    const size_t lds = fft_ola_lds_bytes(plan, max_channels);
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fft_ola_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-    }
+    size_t lds = fft_ola_lds_bytes(plan, max_channels);
+    bool all_stereo = max_channels == 2 && min_channels == 2;
     static const bool generic_only = getenv("RSMP_FFT_GENERIC") != nullptr;   // A/B: skip the specialised builds
     const bool rc_full = plan.n_rc_f == plan.fft_in / 2 - 1 && plan.n_rc_i == plan.fft_out / 2 - 1;
     typedef void (*Kernel)(FftPlanDev, const FftStreamDesc*, uint32_t);
     Kernel fn = fft_ola_kernel;
+    static const bool no_stereo = getenv("RSMP_FFT_NO_STEREO") != nullptr;   // A/B
+    const bool stereo = all_stereo && !no_stereo;
     if (!generic_only && rc_full && Plan1176::matches(plan.fft_in, plan.n_stages_f, plan.radix_f) &&
         Plan1280::matches(plan.fft_out, plan.n_stages_i, plan.radix_i))
-        fn = fft_ola_kernel_ct<Plan1176, Plan1280>;
+        fn = stereo ? fft_ola_kernel_ct2<Plan1176, Plan1280> : fft_ola_kernel_ct<Plan1176, Plan1280>;
     else if (!generic_only && rc_full && Plan1280::matches(plan.fft_in, plan.n_stages_f, plan.radix_f) &&
              Plan1176::matches(plan.fft_out, plan.n_stages_i, plan.radix_i))
-        fn = fft_ola_kernel_ct<Plan1280, Plan1176>;
+        fn = stereo ? fft_ola_kernel_ct2<Plan1280, Plan1176> : fft_ola_kernel_ct<Plan1280, Plan1176>;
+    else
+        all_stereo = false;
+    if (fn == static_cast<Kernel>(fft_ola_kernel_ct2<Plan1176, Plan1280>) ||
+        fn == static_cast<Kernel>(fft_ola_kernel_ct2<Plan1280, Plan1176>))
+        lds = 4 * static_cast<size_t>(plan.lds_complex) * sizeof(float2) + 2 * static_cast<size_t>(plan.fft_out) * sizeof(float);
+    if (lds > 64 * 1024) {   // dynamic LDS above 64 KiB must be opted into
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+    }
     // Blocks per workgroup: every run after a stream's first recomputes its predecessor block (1 / run
     // extra work), and the launch ends with a partly filled round of workgroups unless their number
     // is close to a multiple of what the chip holds at once.  Pick the run length (8..64) that
