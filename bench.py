@@ -142,7 +142,7 @@ def bench_fft(args) -> None:
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"ResamplerFft 2ch 44100->48000, {S} streams/GPU x {blocks} blocks of "
                                    f"1176 frames per step, one launch per step"},
-            "roofline": {"bound": "hbm", "kernel": "fft_ola_kernel", "achieved": round(achieved, 1),
+            "roofline": {"bound": "hbm", "kernel": "fft_ola_kernel_ct2 (plan-specialised; fft_ola_kernel for other plans)", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": None, "kernel_ms": round(k_ms, 4), "algorithmic_bytes": int(alg_bytes)},
         }), flush=True)
