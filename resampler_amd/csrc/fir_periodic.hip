@@ -1632,10 +1632,11 @@ PeriodicGeometry geometry_for(uint64_t num, uint64_t den, uint32_t taps, uint32_
     g.n_units = g.n_tiles;
     // wrap variant inside the kernel: vector kernels den >= 8 (one wrap class per 8-class tile at
     // most); matrix-core path den >= 16 and at most kMfmaWrapMax wrap classes per super period
-    // (only the register-resident variant picks the results up: windows <= 192 taps, 2 groups/unit)
+    // (only the register-resident variant picks the results up: windows <= 144 taps, 1-2 groups/unit)
     static const bool ring_forced = getenv("RSMP_FIR_MFMA_RING") != nullptr;
     static const bool nowrap = getenv("RSMP_FIR_MFMA_NOWRAP") != nullptr;   // A/B: wraps by the fix-up launch
-    const bool mfma_regs = want_mfma && knob_mfma <= 2 && g.row_len <= 192 && !ring_forced && !nowrap;
+    // (144 taps at most: with a 192-tap tile in registers the register-resident build spills)
+    const bool mfma_regs = want_mfma && knob_mfma <= 2 && g.row_len <= 144 && !ring_forced && !nowrap;
     g.inline_wraps = want_mfma ? (mfma_regs && den >= kMfmaClassTile && r <= kMfmaWrapMax) : den >= kClassTile;
 
     // RSMP_FIR_PRODUCERS = n: n producer waves; for the vector kernels it also selects the
@@ -1967,7 +1968,7 @@ hipError_t launch_fir_periodic(const FirStreamDesc* d_descs, uint32_t n_streams,
     // matrix-core variants: 6 / 7 = coefficient ring (any window length), 2 / 4 period groups per
     // unit; 8..10 = ring timing experiments; 11..18 = coefficient tile in registers, windows of
     // 48 / 96 / 144 / 192 taps (2 groups per unit), padded (11..14) or back-to-back (15..18) rows
-    const uint32_t nb3 = geo.row_len % 48 == 0 && geo.row_len <= 192 ? geo.row_len / 48 : 0;
+    const uint32_t nb3 = geo.row_len % 48 == 0 && geo.row_len <= 144 ? geo.row_len / 48 : 0;
     const bool flat_rows = geo.row_stride == 2 * geo.a;
     int variant;
     if (!geo.mfma) variant = (geo.cg == 2 ? (geo.lp == 1 ? 0 : 1) : 2) + (geo.producers ? 3 : 0);
