@@ -166,7 +166,7 @@ def main() -> None:
                     help="untimed steps run before the --warmup steps until this much time has passed: "
                          "the clock governor needs ~50 ms of load to leave its idle state (0 = off)")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--kernel", choices=["auto", "generic", "periodic"], default="auto")
+    ap.add_argument("--kernel", choices=["auto", "generic", "periodic", "periodic-vector"], default="auto")
     args = ap.parse_args()
     if args.path == "fft":
         bench_fft(args)
@@ -189,7 +189,7 @@ def main() -> None:
 
     S, N = args.streams, args.frames
     kernel = {"auto": ra.FirKernel.Auto, "generic": ra.FirKernel.Generic,
-              "periodic": ra.FirKernel.Periodic}[args.kernel]
+              "periodic": ra.FirKernel.Periodic, "periodic-vector": ra.FirKernel.PeriodicVector}[args.kernel]
     handles = []
     for _ in range(S):
         h = ra.ResamplerFir.new(CHANNELS, ra.SampleRate.Hz44100, ra.SampleRate.Hz48000,

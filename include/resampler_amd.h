@@ -48,8 +48,12 @@ enum { RSMP_LATENCY_SAMPLE8 = 0, RSMP_LATENCY_SAMPLE16, RSMP_LATENCY_SAMPLE32, R
 enum { RSMP_ATTENUATION_DB60 = 0, RSMP_ATTENUATION_DB90, RSMP_ATTENUATION_DB120 };
 
 /* FIR kernel selection (rsmp_fir_set_kernel).  AUTO picks PERIODIC when the rate pair reduces to
- * a small rational and the launch is long enough, GENERIC otherwise. */
-enum { RSMP_FIR_KERNEL_AUTO = 0, RSMP_FIR_KERNEL_GENERIC = 1, RSMP_FIR_KERNEL_PERIODIC = 2 };
+ * a small rational and the launch is long enough, GENERIC otherwise.  PERIODIC runs 2-channel
+ * streams on the matrix cores (exact f32 MFMA) where the geometry allows; PERIODIC_VECTOR forces the
+ * packed-FMA vector kernel for every channel count.  All produce the same results within the 1e-6
+ * RMS gate. */
+enum { RSMP_FIR_KERNEL_AUTO = 0, RSMP_FIR_KERNEL_GENERIC = 1, RSMP_FIR_KERNEL_PERIODIC = 2,
+       RSMP_FIR_KERNEL_PERIODIC_VECTOR = 3 };
 
 const char* rsmp_last_error(void);          /* thread-local message of the last failing call */
 int rsmp_device_count(void);                /* number of HIP devices, 0 when there is none   */

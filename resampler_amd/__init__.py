@@ -79,6 +79,7 @@ class FirKernel(enum.IntEnum):
     Auto = 0
     Generic = 1
     Periodic = 2
+    PeriodicVector = 3   # the packed-FMA vector kernel, no matrix cores
 
 
 RSMP_OK = 0

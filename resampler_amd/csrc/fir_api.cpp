@@ -347,7 +347,7 @@ int launch_jobs(rsmp_fir* leader, std::vector<Job>& jobs, hipStream_t stream) {
     for (size_t i = 0; i < n; ++i) {
         Job& j = jobs[i];
         if (!j.plan->periodic) continue;
-        const int rc = rsmp::periodic_bind(j.r->periodic, j.r->device, *j.r->table, j.plan->planned,
+        const int rc = rsmp::periodic_bind(j.r->periodic, j.r->device, *j.r->table, j.r->kernel_mode, j.plan->planned,
                                            static_cast<uint32_t>(j.r->channels), stream);
         if (rc != RSMP_OK) return rc;
         bool found = false;
@@ -618,7 +618,7 @@ extern "C" void rsmp_fir_batch_reset(rsmp_fir* const* rs, size_t n) {
 }
 
 extern "C" int rsmp_fir_set_kernel(rsmp_fir* r, int kernel) {
-    if (kernel < RSMP_FIR_KERNEL_AUTO || kernel > RSMP_FIR_KERNEL_PERIODIC)
+    if (kernel < RSMP_FIR_KERNEL_AUTO || kernel > RSMP_FIR_KERNEL_PERIODIC_VECTOR)
         return rsmp::fail(RSMP_ERR_INVALID_ARGUMENT, "rsmp_fir_set_kernel: unknown kernel %d", kernel);
     r->kernel_mode = kernel;
     return RSMP_OK;

@@ -58,7 +58,9 @@ struct PeriodicGeometry {
     }
 };
 
-PeriodicGeometry periodic_geometry(uint64_t num, uint64_t den, uint32_t taps, uint32_t channels);
+// allow_matrix = false: vector kernels only (RSMP_FIR_KERNEL_PERIODIC_VECTOR)
+PeriodicGeometry periodic_geometry(uint64_t num, uint64_t den, uint32_t taps, uint32_t channels,
+                                   bool allow_matrix = true);
 
 // Per class tile: where its window starts and what its wrap variant (if any) needs.
 struct TileMeta {
@@ -84,6 +86,7 @@ struct ClassTable {
 struct PeriodicState {
     PeriodicGeometry geo;
     bool geo_valid = false;
+    bool geo_matrix = true;      // geo was derived with the matrix-core path allowed
     ClassTable table;
     bool table_valid = false;
     double table_drift = 0.0;
@@ -95,7 +98,7 @@ bool periodic_worthwhile(const FirMirror& planned, size_t produced_frames, int k
 // Makes sure `st` holds the geometry and the device class table matching the stream's rate pair
 // and its current f64 drift (host build + one upload, cached per device and shared by every
 // stream with the same polyphase table, rate pair and drift).
-int periodic_bind(PeriodicState& st, int device, const std::vector<float>& table,
+int periodic_bind(PeriodicState& st, int device, const std::vector<float>& table, int kernel_mode,
                   const FirMirror& planned, uint32_t channels, hipStream_t stream);
 
 // Bitmap of wrapped outputs for one launch: bit K <-> the output with absolute index

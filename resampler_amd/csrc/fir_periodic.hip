@@ -1744,9 +1744,10 @@ PeriodicGeometry geometry_for(uint64_t num, uint64_t den, uint32_t taps, uint32_
 }
 }  // namespace
 
-PeriodicGeometry periodic_geometry(uint64_t num, uint64_t den, uint32_t taps, uint32_t channels) {
+PeriodicGeometry periodic_geometry(uint64_t num, uint64_t den, uint32_t taps, uint32_t channels,
+                                   bool allow_matrix) {
     const int knob = mfma_knob();
-    if (channels == 2 && (knob == 1 || knob == 2 || knob == 4)) {
+    if (allow_matrix && channels == 2 && (knob == 1 || knob == 2 || knob == 4)) {
         const PeriodicGeometry g = geometry_for(num, den, taps, channels, true);
         if (g.ok) return g;   // else: two images do not fit the LDS for this rate pair
     }
@@ -1756,12 +1757,13 @@ PeriodicGeometry periodic_geometry(uint64_t num, uint64_t den, uint32_t taps, ui
 bool periodic_supported(const FirMirror& m, size_t channels, size_t taps, int kernel_mode) {
     if (kernel_mode == RSMP_FIR_KERNEL_GENERIC) return false;
     if (!m.periodic_ok()) return false;
-    return periodic_geometry(m.num(), m.den(), static_cast<uint32_t>(taps),
-                             static_cast<uint32_t>(channels)).ok;
+    return periodic_geometry(m.num(), m.den(), static_cast<uint32_t>(taps), static_cast<uint32_t>(channels),
+                             kernel_mode != RSMP_FIR_KERNEL_PERIODIC_VECTOR).ok;
 }
 
 bool periodic_worthwhile(const FirMirror& planned, size_t produced_frames, int kernel_mode) {
-    if (kernel_mode == RSMP_FIR_KERNEL_PERIODIC) return produced_frames > 0;
+    if (kernel_mode == RSMP_FIR_KERNEL_PERIODIC || kernel_mode == RSMP_FIR_KERNEL_PERIODIC_VECTOR)
+        return produced_frames > 0;
     // AUTO: a launch shorter than a few workgroup spans leaves most lanes idle.
     (void)planned;
     return produced_frames >= 16384;
@@ -1857,13 +1859,15 @@ HostClassTable build_class_table(const std::vector<float>& coeffs, const Periodi
     return out;
 }
 
-int periodic_bind(PeriodicState& st, int device, const std::vector<float>& table,
+int periodic_bind(PeriodicState& st, int device, const std::vector<float>& table, int kernel_mode,
                   const FirMirror& planned, uint32_t channels, hipStream_t stream) {
     (void)stream;
-    if (!st.geo_valid) {
+    const bool allow_matrix = kernel_mode != RSMP_FIR_KERNEL_PERIODIC_VECTOR;
+    if (!st.geo_valid || st.geo_matrix != allow_matrix) {   // (rsmp_fir_set_kernel may switch between them)
         st.geo = periodic_geometry(planned.num(), planned.den(), static_cast<uint32_t>(planned.taps()),
-                                   channels);
+                                   channels, allow_matrix);
         st.geo_valid = true;
+        st.geo_matrix = allow_matrix;
         st.table_valid = false;
     }
     if (!st.geo.ok) return fail(RSMP_ERR_INVALID_ARGUMENT, "periodic kernel: unsupported geometry");

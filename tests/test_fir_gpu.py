@@ -98,7 +98,7 @@ def test_error_codes_match_reference():
     assert g.resample(np.zeros(0, np.float32), out[:0]) == (0, 0)
 
 
-@pytest.mark.parametrize("kernel", [ra.FirKernel.Generic, ra.FirKernel.Periodic])
+@pytest.mark.parametrize("kernel", [ra.FirKernel.Generic, ra.FirKernel.Periodic, ra.FirKernel.PeriodicVector])
 @pytest.mark.parametrize("ch,in_hz,out_hz,att", [
     (2, 44100, 48000, ra.Attenuation.Db90),
     (2, 48000, 44100, ra.Attenuation.Db90),
@@ -125,6 +125,10 @@ def test_bulk_matches_reference_driver_loop(kernel, ch, in_hz, out_hz, att):
     yg2, _ = g.resample_bulk(x2[ch * 3000:], chunk)
     yr2, _ = r.resample_all(x2[ch * 3000:], chunk)
     assert yg2.size == yr2.size and rms(yg2, yr2) <= RMS_TOL
+    if kernel == ra.FirKernel.PeriodicVector:
+        assert g.kernel_variant() in (1, 2)   # never the matrix-core kernel
+    if kernel == ra.FirKernel.Generic:
+        assert g.kernel_variant() == 0
 
 
 @pytest.mark.parametrize("taps_lat", [ra.Latency.Sample8, ra.Latency.Sample16, ra.Latency.Sample32])
