@@ -47,7 +47,8 @@ struct PeriodicGeometry {
     uint32_t waves = 0;          // waves per workgroup
     uint32_t producers = 0;      // > 0: double-buffered kernel, this many waves only stage
     uint32_t images = 0;         // double-buffered kernels: LDS images in the ring (2 or 4)
-    uint32_t mfma = 0;           // > 0: matrix-core kernel (16-class tiles); period groups of 16 per work unit
+    uint32_t mfma = 0;           // > 0: matrix-core kernel (16-class tiles); period groups of 16 per work unit;
+                                 // 3: split-bf16 kernel (fir_split.hip)
     uint32_t n_units = 0;        // work units per item: n_tiles (vector kernels) or tiles x unit splits (mfma)
     uint32_t lds_bytes = 0;
     bool inline_wraps = false;   // den >= 8: wrap variant computed inside the kernel
@@ -120,6 +121,15 @@ hipError_t launch_fir_wrap_fixup(const FirStreamDesc* d_descs, uint32_t n_stream
                                  uint32_t max_wraps, hipStream_t stream);
 // Number of period blocks (grid.x) a stream's launch needs.
 uint32_t periodic_blocks(const PeriodicGeometry& geo, uint64_t abs_out, uint32_t n_out);
+
+// Split-bf16 matrix kernel (fir_split.hip): geometry (mfma == 3; row_stride = rows of an LDS image),
+// class-table image and launch.
+PeriodicGeometry split_geometry(uint64_t num, uint64_t den, uint32_t taps, uint32_t channels);
+size_t split_table_floats(const PeriodicGeometry& g);
+void split_store_class(std::vector<float>& coef, const PeriodicGeometry& g, uint32_t tile, uint32_t m,
+                       uint32_t shift, const std::vector<float>& mixed);
+hipError_t launch_fir_split(const FirStreamDesc* d_descs, uint32_t n_streams, const PeriodicGeometry& geo,
+                            uint32_t max_blocks, uint32_t cus, hipStream_t stream);
 
 // Host build of the class table (exposed for tests).
 struct HostClassTable {

@@ -1613,7 +1613,7 @@ PeriodicGeometry geometry_for(uint64_t num, uint64_t den, uint32_t taps, uint32_
     PeriodicGeometry g;
     if (num == 0 || den == 0 || channels == 0 || channels > 64) return g;
     if (num > (1u << 20) || den > (1u << 20)) return g;
-    const int knob_mfma = mfma_knob();
+    const int knob_mfma = mfma_knob() == 3 ? 2 : mfma_knob();   // 3: this is the fallback of the split kernel
     const uint32_t ct = want_mfma ? kMfmaClassTile : kClassTile;
     // max in-tile shift: off(j) = floor(j*num/den); tiles start at multiples of the class tile.
     const uint32_t shift = static_cast<uint32_t>(((ct - 1) * num + den - 1) / den);
@@ -1746,7 +1746,12 @@ PeriodicGeometry geometry_for(uint64_t num, uint64_t den, uint32_t taps, uint32_
 
 PeriodicGeometry periodic_geometry(uint64_t num, uint64_t den, uint32_t taps, uint32_t channels,
                                    bool allow_matrix) {
-    const int knob = mfma_knob();
+    int knob = mfma_knob();
+    if (allow_matrix && knob == 3) {   // split-bf16 matrix kernel where its geometry exists
+        const PeriodicGeometry g = split_geometry(num, den, taps, channels);
+        if (g.ok) return g;
+        knob = 2;
+    }
     if (allow_matrix && channels == 2 && (knob == 1 || knob == 2 || knob == 4)) {
         const PeriodicGeometry g = geometry_for(num, den, taps, channels, true);
         if (g.ok) return g;   // else: two images do not fit the LDS for this rate pair
@@ -1797,7 +1802,7 @@ HostClassTable build_class_table(const std::vector<float>& coeffs, const Periodi
     const uint32_t taps = g.taps;
     const uint32_t ct = g.mfma ? kMfmaClassTile : kClassTile;
     HostClassTable out;
-    out.coef.assign(static_cast<size_t>(g.n_tiles) * g.row_len * ct, 0.0f);
+    out.coef.assign(g.mfma == 3 ? split_table_floats(g) : static_cast<size_t>(g.n_tiles) * g.row_len * ct, 0.0f);
     out.wrap_coef.assign(static_cast<size_t>(g.n_tiles) * g.row_len, 0.0f);
     out.meta.resize(g.n_tiles);
     std::vector<float> mixed(taps);
@@ -1828,6 +1833,10 @@ HostClassTable build_class_table(const std::vector<float>& coeffs, const Periodi
             const float omf = 1.0f - frac;
             for (uint32_t k = 0; k < taps; ++k) mixed[k] = c1[k] * omf + c2[k] * frac;  // avx.rs:41-45
             const uint32_t shift = class_offset(g, j) - tm.base;
+            if (g.mfma == 3) {
+                split_store_class(out.coef, g, t, i, shift, mixed);
+                continue;
+            }
             if (g.mfma) {
                 // A-operand order of v_mfma_f32_16x16x4_f32 (lane = 16 * (tap % 4) + class), four
                 // steps of a lane adjacent: [block = tap / 16][lane][step = (tap / 4) % 4]
@@ -1878,7 +1887,7 @@ int periodic_bind(PeriodicState& st, int device, const std::vector<float>& table
     uint64_t bits;
     std::memcpy(&bits, &drift, sizeof bits);
     const ClassTableKey key{device, table.data(), st.geo.den, st.geo.a, st.geo.b, st.geo.row_len,
-                            st.geo.mfma ? 1u : 0u, bits};
+                            st.geo.mfma == 3 ? 3u : (st.geo.mfma ? 1u : 0u), bits};
     auto it = cache.tables.find(key);
     if (it == cache.tables.end()) {
         const HostClassTable host = build_class_table(table, st.geo, drift);
@@ -1930,6 +1939,7 @@ hipError_t launch_fir_periodic(const FirStreamDesc* d_descs, uint32_t n_streams,
         }
         cus = c;
     }
+    if (geo.mfma == 3) return launch_fir_split(d_descs, n_streams, geo, max_blocks, cus, stream);
     const uint32_t slots = cus * (geo.lds_bytes > kLdsTwoPerCu ? 1u : 2u);   // workgroups that fit
     const dim3 grid(args.total_items < slots ? args.total_items : slots);
     args.work_counter = d_work_counter;

@@ -213,8 +213,10 @@ def test_matrix_core_kernel_ragged_batch_and_edges():
             yr, _ = rs[i].resample_all(xs[i], 512)
             assert consumed[i] == xs[i].size and produced[i] == yr.size, (step, i)
             assert rms(d_out[i][: produced[i]].cpu().numpy(), yr) <= RMS_TOL, (step, i)
-    mfma_on = os.environ.get("RSMP_FIR_MFMA", "2") != "0"
-    assert gs[-1].kernel_variant() == (3 if mfma_on else 1)   # periodic matrix-core kernel by default
+    knob = os.environ.get("RSMP_FIR_MFMA", "2")
+    mfma_on = knob != "0"
+    # periodic matrix-core kernel by default (4 = the split-bf16 one, RSMP_FIR_MFMA=3)
+    assert gs[-1].kernel_variant() == ((4 if knob == "3" else 3) if mfma_on else 1)
     # other even rate pairs on the same path: 44.1 -> 96 k (20 class tiles), 16 / 32 / 64 taps above
     g, r = make_pair(2, 44100, 96000, kernel=ra.FirKernel.Periodic)
     x = synth.sweep(70001, 2, 44100.0)
