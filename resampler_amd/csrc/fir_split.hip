@@ -40,15 +40,36 @@ namespace rsmp {
 
 namespace {
 
-constexpr uint32_t kProducers = 2, kConsumers = 10, kWaves = kProducers + kConsumers;
-constexpr uint32_t kCtrlBytes = 256;                 // staged[2], done[2], wflag[2]
+constexpr uint32_t kProducers = 6, kConsumers = 10, kWaves = kProducers + kConsumers;
+constexpr uint32_t kCtrlBytes = 256;                 // staged[2], done[2]
 constexpr uint32_t kWrapBytes = 2 * 16 * 16;         // two slots x 16 periods x (ch0, ch1, take, -)
 constexpr uint32_t kImageBase = kCtrlBytes + kWrapBytes;
 constexpr uint32_t kLdsLimit = 160 * 1024;
-constexpr int kBatch = 8;                            // (row block, period pair) combos in flight per producer
+constexpr int kWrapTaps = 8;                         // taps of the wrap variant per lane (16 lanes per period)
+constexpr int kMaxCombos = 7;                           // (row block, period pair) combos in flight per producer
 
 struct SplitArgs {
     uint32_t a, b, taps, n_tiles, rows, blocks_per_stream, total_items, debug;
+    unsigned long long* wtrace;   // RSMP_FIR_WTRACE: kWtraceSlots timestamped events per wave
+};
+
+constexpr uint32_t kWtraceSlots = 160;
+
+// Diagnostic per-wave event log: (100 MHz timestamp << 8) | tag, read by tools/wtrace_report.py.
+struct WaveTrace {
+    unsigned long long* base;
+    uint32_t cursor;
+    __device__ __forceinline__ void init(const SplitArgs& g, uint32_t wave) {
+        base = g.wtrace ? g.wtrace + (static_cast<size_t>(blockIdx.x) * 16 + wave) * kWtraceSlots : nullptr;
+        cursor = 0;
+    }
+    __device__ __forceinline__ void event(uint32_t tag) {
+        if (base && cursor < kWtraceSlots) {
+            const unsigned long long v = (__builtin_amdgcn_s_memrealtime() << 8) | tag;
+            if ((threadIdx.x & 63) == 0) base[cursor] = v;
+            ++cursor;
+        }
+    }
 };
 
 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -66,9 +87,6 @@ typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
 
 __device__ __forceinline__ uint32_t lds_load_acquire(uint32_t* p) {
     return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-__device__ __forceinline__ void lds_store_release(uint32_t* p, uint32_t v) {
-    __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 // One count per WAVE (a wave-wide atomic would add one per active lane): everything the wave did in
 // LDS before is complete when the count becomes visible.
@@ -88,10 +106,18 @@ struct StreamCtx {
     const uint32_t* wrap_bits;
     uint32_t n_out, hist_frames, in_frames;
     uint64_t abs_out, abs_consumed, wrap_k0;
+    uint64_t q_first;     // abs_out / b: the period holding the launch's first output
 };
 
-__device__ __forceinline__ StreamCtx load_stream(const FirStreamDesc* descs, uint32_t s) {
-    const FirStreamDesc& d = descs[s];
+// Through the scalar cache (constant address space): the descriptors do not change during the launch,
+// and scalar loads are counted by lgkmcnt -- vector loads here would sit in the producers' vmcnt queue.
+__device__ __forceinline__ StreamCtx load_stream(const FirStreamDesc* descs, uint32_t s, uint32_t b) {
+    typedef const uint32_t __attribute__((address_space(4)))* const_u32_ptr;
+    FirStreamDesc d;
+    const_u32_ptr src = (const_u32_ptr)(descs + s);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(&d);
+#pragma unroll
+    for (size_t i = 0; i < sizeof(FirStreamDesc) / 4; ++i) dst[i] = src[i];
     StreamCtx c;
     c.in = d.in;
     c.hist = d.hist;
@@ -105,6 +131,7 @@ __device__ __forceinline__ StreamCtx load_stream(const FirStreamDesc* descs, uin
     c.abs_out = d.abs_out;
     c.abs_consumed = d.abs_consumed;
     c.wrap_k0 = d.wrap_k0;
+    c.q_first = d.abs_out / b;   // (64-bit division: once per stream, not per item)
     return c;
 }
 
@@ -117,7 +144,7 @@ struct Item {
 
 __device__ __forceinline__ Item item_of(const SplitArgs& g, const StreamCtx& d, uint32_t block) {
     Item it;
-    it.q0 = d.abs_out / g.b + static_cast<uint64_t>(block) * 16u;
+    it.q0 = d.q_first + static_cast<uint64_t>(block) * 16u;
     it.valid = d.n_out != 0 && it.q0 * g.b < d.abs_out + d.n_out;
     it.n_block0 = static_cast<int32_t>(static_cast<int64_t>(it.q0 * g.b) - static_cast<int64_t>(d.abs_out));
     it.k_block0 = static_cast<int32_t>(static_cast<int64_t>(it.q0) - static_cast<int64_t>(d.wrap_k0));
@@ -138,18 +165,55 @@ __device__ __forceinline__ uint32_t pack_hi16(uint32_t hi, uint32_t lo) {
     return __builtin_amdgcn_perm(hi, lo, 0x07060302u);
 }
 
+// Loads the compiler does not see: issued by inline asm and awaited with an explicit vmcnt, so that a
+// producer can keep the NEXT item's loads in flight across the loop back edge.  (With plain loads the
+// compiler's own wait insertion falls back to vmcnt(0) in this loop -- every store waited for the
+// loads just issued, i.e. the full HBM latency seven times per item.)  vmcnt is in order: waiting
+// until at most N operations are outstanding completes everything older than the N youngest.
+__device__ __forceinline__ const void* uniform_ptr(const void* p) {   // into scalar registers, whatever the compiler thought
+    const uint64_t v = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v));
+    const uint32_t hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v >> 32));
+    return reinterpret_cast<const void*>(static_cast<uint64_t>(hi) << 32 | lo);
+}
+__device__ __forceinline__ void gload2(v2f& dst, uint32_t byte_off, const void* base) {
+    asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(dst) : "v"(byte_off), "s"(base) : "memory");
+}
+__device__ __forceinline__ void gload1(uint32_t& dst, uint32_t byte_off, const void* base) {
+    asm volatile("global_load_dword %0, %1, %2" : "=v"(dst) : "v"(byte_off), "s"(base) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_loads(v2f& a, v2f& b) {
+    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory");
+}
+
 struct Combo {
     v2f x0, x1;   // (ch0, ch1) of row k in periods 2pp and 2pp + 1
 };
 
+// A producer's view of a work item (wave-uniform).
+struct PItem {
+    uint32_t item;        // index in the launch; item_end = none
+    Item it;
+    int64_t f0;           // frame index of (period q0, row 0) in [hist|in]
+    bool interior;        // the image and its wrap windows lie inside `in`, below 2^28 frames
+    uint32_t off0;        // interior: f0 - hist_frames
+};
+
+// Wave roles.  A workgroup's waves go to the four SIMDs cyclically, so waves w and w + 4 share one:
+// producers 0-3 sit one per SIMD, producers 4 and 5 join SIMDs 2 and 3, which get two consumers
+// each; SIMDs 0 and 1 get three consumers.
+__device__ __forceinline__ bool wave_is_producer(uint32_t w) { return w < 4 || w == 6 || w == 7; }
+__device__ __forceinline__ uint32_t producer_index(uint32_t w) { return w < 4 ? w : w - 2; }
+__device__ __forceinline__ uint32_t consumer_index(uint32_t w) { return w < 6 ? w - 4 : w - 6; }
+
 template <int NK>
-__global__ __launch_bounds__(768) void fir_split_kernel(const FirStreamDesc* __restrict__ descs,
-                                                        const SplitArgs g) {
+__global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __restrict__ descs,
+                                                         const SplitArgs g) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     uint32_t* ctrl = reinterpret_cast<uint32_t*>(lds);
     uint32_t* staged = ctrl;        // [slot]: producers that finished staging, cumulative
     uint32_t* done = ctrl + 2;      // [slot]: consumers that finished reading, cumulative
-    uint32_t* wflag = ctrl + 4;     // [slot]: round + 1 whose wrap results are in the wrap area
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (threadIdx.x < kCtrlBytes / 4) ctrl[threadIdx.x] = 0;
@@ -162,156 +226,248 @@ __global__ __launch_bounds__(768) void fir_split_kernel(const FirStreamDesc* __r
     const uint32_t item_end = static_cast<uint32_t>(static_cast<uint64_t>(blockIdx.x + 1) * g.total_items / gridDim.x);
     if (item_begin == item_end) return;
 
-    uint32_t cur_stream = 0xFFFFFFFFu;
-    StreamCtx d{};
     uint32_t rnd = 0;
+    WaveTrace wt;
+    wt.init(g, wave);
 
-    if (wave < kProducers) {
+    if (wave_is_producer(wave)) {
         // ---- producer ------------------------------------------------------------------------------
-        const uint32_t n_rb = (R + 63) / 64;                       // 64-row blocks
-        const uint32_t n_combos = n_rb * 8;                        // x 8 period pairs
-        const uint32_t mine = (n_combos - wave + kProducers - 1) / kProducers;   // combos wave, wave + P, ...
-        for (uint32_t item = item_begin; item < item_end; ++item) {
-            const uint32_t stream = item / g.blocks_per_stream;
-            if (stream != cur_stream) {
-                d = load_stream(descs, stream);
-                cur_stream = stream;
+        // An image is R rows x 8 period pairs; a combo = 64 rows of one pair; producer P takes combos
+        // P, P + 6, ...  The loads of the NEXT item's combos are issued in place as soon as a combo of
+        // the current item has been written: HBM latency is hidden across items, not within one.
+        const uint32_t P = producer_index(wave);
+        const uint32_t n_combos = (R / 64) * 8;   // R is a whole number of 64-row blocks
+        // every producer handles exactly kMaxCombos combos, unconditionally (straight-line code lets the
+        // compiler count the loads in flight); surplus slots repeat another producer's combo
+        // wrap variant of class 0: producers 0-3 take 4 periods each; lane = (8 taps, period)
+        const bool wrapper = P < 4;   // (P & 3 below: producers 4 and 5 shadow 0 and 1)
+        // (the lane id behind an optimisation barrier per item: otherwise every combo's loop-invariant
+        // addressing is hoisted out of the item loop, spilled, and each reload from scratch waits for
+        // ALL the prefetches in flight -- scratch loads share the in-order vmcnt)
+        uint32_t ln = lane;
+        #define RSMP_WP (4 * (P & 3) + (ln & 3))
+        #define RSMP_WPART (ln >> 2)
+        float wcoef[kWrapTaps];
+        const float* cur_coeffs = nullptr;
+
+        StreamCtx d{}, dn{};
+        uint32_t sid = 0xFFFFFFFFu, sidn = 0xFFFFFFFFu;
+        auto find = [&](uint32_t item, StreamCtx& c, uint32_t& s) -> PItem {
+            PItem r;
+            r.item = item_end;
+            r.it = Item{};
+            r.f0 = 0;
+            r.interior = false;
+            r.off0 = 0;
+            for (; item < item_end; ++item) {
+                const uint32_t stream = item / g.blocks_per_stream;
+                if (stream != s) {
+                    c = load_stream(descs, stream, g.b);
+                    s = stream;
+                }
+                const Item it = item_of(g, c, item - stream * g.blocks_per_stream);
+                if (!it.valid) continue;
+                r.item = item;
+                r.it = it;
+                r.f0 = static_cast<int64_t>(it.q0 * g.a) - static_cast<int64_t>(c.abs_consumed);
+                const int64_t hf = c.hist_frames;
+                r.interior = r.f0 > hf && r.f0 + static_cast<int64_t>(15u * g.a + R) <= hf + static_cast<int64_t>(c.in_frames) &&
+                             c.in_frames < (1u << 28);
+                r.off0 = static_cast<uint32_t>(r.f0 - hf);
+                break;
             }
-            const Item it = item_of(g, d, item - stream * g.blocks_per_stream);
-            if (!it.valid) continue;
+            return r;
+        };
+        // row block / pair of this producer's m-th combo
+        auto combo_of = [&](uint32_t m) {
+            const uint32_t c = P + m * kProducers;
+            return c < n_combos ? c : c - n_combos;
+        };
+        auto combo_rb = [&](uint32_t m) { return combo_of(m) >> 3; };
+        auto combo_pp = [&](uint32_t m) { return combo_of(m) & 7; };
+        // real = false: a dummy load of the first bytes of the descriptor array (always mapped), so that
+        // every pass through the loop issues the same number of loads
+        auto load_combo = [&](Combo& cb, bool real, const PItem& pi, const void* base, uint32_t m) {
+            const uint32_t k = combo_rb(m) * 64 + ln;
+            // interior items have 32-bit byte offsets (see find): scalar base + one VGPR offset per load
+            const uint32_t off = real ? (pi.off0 + (2 * combo_pp(m)) * g.a + k) * 8u : 0u;
+            gload2(cb.x0, off, base);
+            gload2(cb.x1, real ? off + g.a * 8u : 0u, base);
+        };
+        auto fetch_edge = [&](const StreamCtx& c, int64_t f) -> v2f {
+            const int64_t hf = c.hist_frames, total = hf + static_cast<int64_t>(c.in_frames);
+            const bool ok = f >= 0 && f < total;
+            const int64_t fc = f < 0 ? 0 : (f >= total ? total - 1 : f);
+            v2f v = fc < hf ? ((gconst_f2_ptr)c.hist)[fc] : ((gconst_f2_ptr)c.in)[fc - hf];
+            if (!ok) v = v2f{0.f, 0.f};
+            return v;
+        };
+        auto store_combo = [&](char* img, uint32_t m, const Combo& cb) {
+            const uint32_t pp = combo_pp(m);
+            const uint32_t k = combo_rb(m) * 64 + ln;
+            uint32_t a1, a2, a3, b1, b2, b3;
+            char* row = img + k * 32 + ((((pp >> 1) ^ ((k >> 2) & 3)) << 3) | ((pp & 1) << 2));
+            split3(cb.x0.x, a1, a2, a3);   // channel 0
+            split3(cb.x1.x, b1, b2, b3);
+            *reinterpret_cast<uint32_t*>(row) = pack_hi16(b1, a1);
+            *reinterpret_cast<uint32_t*>(row + R * 32) = pack_hi16(b2, a2);
+            *reinterpret_cast<uint32_t*>(row + 2 * R * 32) = pack_hi16(b3, a3);
+            split3(cb.x0.y, a1, a2, a3);   // channel 1
+            split3(cb.x1.y, b1, b2, b3);
+            *reinterpret_cast<uint32_t*>(row + 3 * R * 32) = pack_hi16(b1, a1);
+            *reinterpret_cast<uint32_t*>(row + 4 * R * 32) = pack_hi16(b2, a2);
+            *reinterpret_cast<uint32_t*>(row + 5 * R * 32) = pack_hi16(b3, a3);
+        };
+        // wrap variant (row 1023 on the window one frame earlier, resampler_fir.rs:544, :562-565):
+        // this lane's 8 frames of period wp, and whether that period's class-0 output takes it
+        // 9 loads: this lane's 8 frames of period wp and the bitmap word holding that period's take bit
+        auto load_wrap = [&](bool real, const PItem& pi, const StreamCtx& c, v2f (&wx)[kWrapTaps], uint32_t& word) {
+            const void* base = uniform_ptr(real ? static_cast<const void*>(c.in) : static_cast<const void*>(descs));
+            const uint32_t off = real ? (pi.off0 + RSMP_WP * g.a - 1 + RSMP_WPART * kWrapTaps) * 8u : 0u;
+#pragma unroll
+            for (int i = 0; i < kWrapTaps; ++i) gload2(wx[i], real ? off + i * 8u : 0u, base);
+            const int32_t nw = pi.it.n_block0 + static_cast<int32_t>(RSMP_WP * g.b);
+            const bool in_launch = real && nw >= 0 && nw < static_cast<int32_t>(c.n_out);
+            const uint32_t K = in_launch ? static_cast<uint32_t>(pi.it.k_block0 + static_cast<int32_t>(RSMP_WP)) : 0u;
+            gload1(word, (K >> 5) * 4u, uniform_ptr(real ? static_cast<const void*>(c.wrap_bits) : static_cast<const void*>(descs)));
+        };
+        auto take_of = [&](const PItem& pi, const StreamCtx& c, uint32_t word) -> uint32_t {
+            const int32_t nw = pi.it.n_block0 + static_cast<int32_t>(RSMP_WP * g.b);
+            const bool in_launch = nw >= 0 && nw < static_cast<int32_t>(c.n_out);
+            const uint32_t K = static_cast<uint32_t>(pi.it.k_block0 + static_cast<int32_t>(RSMP_WP));
+            return in_launch ? (word >> (K & 31)) & 1u : 0u;
+        };
+        auto load_wrap_edge = [&](const PItem& pi, const StreamCtx& c, v2f (&wx)[kWrapTaps], uint32_t& word) {
+            const int64_t fw = pi.f0 + static_cast<int64_t>(RSMP_WP * g.a) - 1 + RSMP_WPART * kWrapTaps;
+#pragma unroll
+            for (int i = 0; i < kWrapTaps; ++i) wx[i] = fetch_edge(c, fw + i);
+            const int32_t nw = pi.it.n_block0 + static_cast<int32_t>(RSMP_WP * g.b);
+            const bool in_launch = nw >= 0 && nw < static_cast<int32_t>(c.n_out);
+            const uint32_t K = in_launch ? static_cast<uint32_t>(pi.it.k_block0 + static_cast<int32_t>(RSMP_WP)) : 0u;
+            word = ((gconst_u32_ptr)c.wrap_bits)[K >> 5];
+        };
+        constexpr int kItemLoads = 2 * kMaxCombos + kWrapTaps + 1;   // loads a producer issues per item
+
+        // One static instance of every asm load: the first pass (no current item yet) only issues the
+        // first item's loads, every later pass writes the current item and issues the next one's into
+        // the same registers.  (A separate prologue would make the compiler copy registers that are
+        // still in flight where its values meet the loop's.)
+        PItem cur;
+        cur.item = item_end;
+        cur.it = Item{};
+        cur.f0 = 0;
+        cur.interior = false;
+        cur.off0 = 0;
+        PItem nxt = find(item_begin, dn, sidn);
+        Combo x[kMaxCombos];
+        v2f wx[kWrapTaps];
+        uint32_t word = 0;
+        bool loaded = false;   // cur's loads are in flight (cur is an interior item)
+        for (;;) {
+            const bool have = cur.item != item_end;
+            const bool more = nxt.item != item_end;
+            if (!have && !more) break;
+            const bool pre = more && nxt.interior;   // the next item's loads can be issued ahead
+            asm volatile("" : "+v"(ln));
             const uint32_t slot = rnd & 1, use = rnd >> 1;
             char* img = lds + kImageBase + slot * image_bytes;
-            const int64_t f0 = static_cast<int64_t>(it.q0 * g.a) - static_cast<int64_t>(d.abs_consumed);
-            const int64_t hist_frames = d.hist_frames;
-            const int64_t total = hist_frames + static_cast<int64_t>(d.in_frames);
-            const bool interior = f0 >= hist_frames && f0 + static_cast<int64_t>(15u * g.a + R) <= total;
-            gconst_f2_ptr in2 = (gconst_f2_ptr)d.in;
-            gconst_f2_ptr hist2 = (gconst_f2_ptr)d.hist;
-
-            auto store_combo = [&](uint32_t c, const Combo& cb) {
-                const uint32_t rb = c >> 3, pp = c & 7;
-                const uint32_t k = rb * 64 + lane;
-                if (k >= R) return;
-                uint32_t a1, a2, a3, b1, b2, b3;
-                char* row = img + k * 32 + ((((pp >> 1) ^ ((k >> 2) & 3)) << 3) | ((pp & 1) << 2));
-                // channel 0
-                split3(cb.x0.x, a1, a2, a3);
-                split3(cb.x1.x, b1, b2, b3);
-                *reinterpret_cast<uint32_t*>(row) = pack_hi16(b1, a1);
-                *reinterpret_cast<uint32_t*>(row + R * 32) = pack_hi16(b2, a2);
-                *reinterpret_cast<uint32_t*>(row + 2 * R * 32) = pack_hi16(b3, a3);
-                // channel 1
-                split3(cb.x0.y, a1, a2, a3);
-                split3(cb.x1.y, b1, b2, b3);
-                *reinterpret_cast<uint32_t*>(row + 3 * R * 32) = pack_hi16(b1, a1);
-                *reinterpret_cast<uint32_t*>(row + 4 * R * 32) = pack_hi16(b2, a2);
-                *reinterpret_cast<uint32_t*>(row + 5 * R * 32) = pack_hi16(b3, a3);
-            };
-            if (interior) {
-                // the whole image lies inside `in`: batches of loads in flight, the first two before the
-                // slot is known to be free
-                gconst_f2_ptr src = in2 + (f0 - hist_frames) + (lane < R ? lane : 0);
-                auto load_combo = [&](uint32_t c) -> Combo {
-                    const uint32_t rb = c >> 3, pp = c & 7;
-                    uint32_t k = rb * 64;
-                    if (k + lane >= R) k = 0;   // rows past the image: any valid address (not stored)
-                    gconst_f2_ptr s0 = src + ((2 * pp) * g.a + k);
-                    Combo cb;
-                    cb.x0 = s0[0];
-                    cb.x1 = s0[g.a];
-                    return cb;
-                };
-                Combo xa[kBatch], xb[kBatch];
-                const uint32_t n_batches = (mine + kBatch - 1) / kBatch;
-                auto load_batch = [&](Combo (&x)[kBatch], uint32_t bt) {
+            if (have && !loaded) asm volatile("s_waitcnt vmcnt(0)" : : : "memory");   // dummies: done with the registers
+            if (have && d.coeffs != cur_coeffs) {   // this lane's taps of row 1023 (rare: compiler-visible loads)
+                asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+                cur_coeffs = d.coeffs;
+                gconst_f32_ptr wrow = (gconst_f32_ptr)d.coeffs + static_cast<size_t>(1023) * g.taps;
 #pragma unroll
-                    for (int i = 0; i < kBatch; ++i) {
-                        const uint32_t m = bt * kBatch + i;
-                        if (m < mine) x[i] = load_combo(wave + m * kProducers);
-                    }
-                };
-                auto store_batch = [&](const Combo (&x)[kBatch], uint32_t bt) {
-#pragma unroll
-                    for (int i = 0; i < kBatch; ++i) {
-                        const uint32_t m = bt * kBatch + i;
-                        if (m < mine) store_combo(wave + m * kProducers, x[i]);
-                    }
-                };
-                load_batch(xa, 0);
-                if (n_batches > 1) load_batch(xb, 1);
-                while (lds_load_acquire(done + slot) < n_active * use) __builtin_amdgcn_s_sleep(1);
-                for (uint32_t bt = 0; bt < n_batches; bt += 2) {
-                    store_batch(xa, bt);
-                    if (bt + 2 < n_batches) load_batch(xa, bt + 2);
-                    if (bt + 1 < n_batches) store_batch(xb, bt + 1);
-                    if (bt + 3 < n_batches) load_batch(xb, bt + 3);
+                for (int i = 0; i < kWrapTaps; ++i) {
+                    const uint32_t t = RSMP_WPART * kWrapTaps + i;
+                    wcoef[i] = t < g.taps ? wrow[t] : 0.f;
                 }
-            } else {
-                // stream edges: frames outside [hist|in] read as zero; one combo at a time
+                // have them land here: a compiler-inserted wait at their use would also wait for every
+                // prefetch issued in between
+#pragma unroll
+                for (int i = 0; i < kWrapTaps; ++i) asm volatile("" : "+v"(wcoef[i]));
+            }
+            if (have) {
+                wt.event(11);
                 while (lds_load_acquire(done + slot) < n_active * use) __builtin_amdgcn_s_sleep(1);
-                for (uint32_t m = 0; m < mine; ++m) {
-                    const uint32_t c = wave + m * kProducers;
-                    const uint32_t rb = c >> 3, pp = c & 7;
-                    uint32_t k = rb * 64 + lane;
-                    if (k >= R) k = R - 1;
-                    auto fetch = [&](int64_t f) -> v2f {
-                        const bool ok = f >= 0 && f < total;
-                        const int64_t fc = f < 0 ? 0 : (f >= total ? total - 1 : f);
-                        v2f v = fc < hist_frames ? hist2[fc] : in2[fc - hist_frames];
-                        if (!ok) v = v2f{0.f, 0.f};
-                        return v;
-                    };
-                    const int64_t f = f0 + static_cast<int64_t>((2 * pp) * g.a + k);
+                wt.event(12);
+            }
+            if (have && !loaded) {
+                // stream edges: frames outside [hist|in] read as zero; one combo at a time, plain loads
+                for (uint32_t m = 0; m < kMaxCombos; ++m) {
+                    const uint32_t k = combo_rb(m) * 64 + ln;
+                    const int64_t f = cur.f0 + static_cast<int64_t>((2 * combo_pp(m)) * g.a + k);
                     Combo cb;
-                    cb.x0 = fetch(f);
-                    cb.x1 = fetch(f + g.a);
-                    store_combo(c, cb);
+                    cb.x0 = fetch_edge(d, f);
+                    cb.x1 = fetch_edge(d, f + g.a);
+                    store_combo(img, m, cb);
                 }
             }
-            lds_signal(staged + slot);
-
-            // wrap variant of class 0 for the 16 periods: row 1023 on the window one frame earlier
-            // (resampler_fir.rs:544, :562-565), f32 FMA from global memory; lane = (quarter of the taps, period)
-            if (wave == kProducers - 1) {
-                const uint32_t p = lane & 15, part = lane >> 4;
-                const int32_t nw = it.n_block0 + static_cast<int32_t>(p * g.b);
-                uint32_t take = 0;
-                if (nw >= 0 && nw < static_cast<int32_t>(d.n_out)) {
-                    const uint32_t K = static_cast<uint32_t>(it.k_block0 + static_cast<int32_t>(p));
-                    take = (((gconst_u32_ptr)d.wrap_bits)[K >> 5] >> (K & 31)) & 1u;
+            const void* nbase = uniform_ptr(pre ? static_cast<const void*>(dn.in) : static_cast<const void*>(descs));
+            const bool stage = have && loaded && !(g.debug & 1);
+#pragma unroll
+            for (int m = 0; m < kMaxCombos; ++m) {
+                if (have && loaded) {
+                    // x[m]'s loads are older than the kItemLoads - 2 issued since
+                    wait_loads<kItemLoads - 2>(x[m].x0, x[m].x1);
+                    if (stage) store_combo(img, m, x[m]);
+                }
+                load_combo(x[m], pre, nxt, nbase, m);
+            }
+            // wrap variant of class 0 for this producer's periods (the two paths share no registers: a value
+            // merged from a plain load and an asm load would make the compiler wait for everything)
+            auto wrap_out = [&](const v2f (&w)[kWrapTaps], uint32_t take) {
+                v2f acc = v2f{0.f, 0.f};
+                if (wrapper && !(g.debug & 1024)) {
+#pragma unroll
+                    for (int i = 0; i < kWrapTaps; ++i) {
+                        acc.x = fmaf(wcoef[i], w[i].x, acc.x);
+                        acc.y = fmaf(wcoef[i], w[i].y, acc.y);
+                    }
+#pragma unroll
+                    for (int sh = 4; sh < 64; sh *= 2) {
+                        acc.x += __shfl_xor(acc.x, sh, 64);
+                        acc.y += __shfl_xor(acc.y, sh, 64);
+                    }
                 }
                 float* wv = reinterpret_cast<float*>(lds + kCtrlBytes + slot * (kWrapBytes / 2));
-                v2f acc = v2f{0.f, 0.f};
-                if (__any(take != 0) && !(g.debug & 1024)) {
-                    gconst_f32_ptr wrow = (gconst_f32_ptr)d.coeffs + static_cast<size_t>(1023) * g.taps;
-                    const uint32_t per = (g.taps + 3) / 4;
-                    const uint32_t t0 = part * per, t1 = t0 + per < g.taps ? t0 + per : g.taps;
-                    const int64_t fw = f0 + static_cast<int64_t>(p * g.a) - 1;
-                    for (uint32_t t = t0; t < t1; ++t) {
-                        const int64_t f = fw + t;
-                        const bool ok = f >= 0 && f < total;
-                        const int64_t fc = f < 0 ? 0 : (f >= total ? total - 1 : f);
-                        v2f v = fc < hist_frames ? hist2[fc] : in2[fc - hist_frames];
-                        if (!ok) v = v2f{0.f, 0.f};
-                        const float w = wrow[t];
-                        acc.x = fmaf(w, v.x, acc.x);
-                        acc.y = fmaf(w, v.y, acc.y);
-                    }
-                    acc.x += __shfl_xor(acc.x, 16, 64);
-                    acc.y += __shfl_xor(acc.y, 16, 64);
-                    acc.x += __shfl_xor(acc.x, 32, 64);
-                    acc.y += __shfl_xor(acc.y, 32, 64);
-                }
-                if (lane < 16) *reinterpret_cast<v4f*>(wv + lane * 4) = v4f{acc.x, acc.y, __uint_as_float(take), 0.f};
-                lds_store_release(wflag + slot, rnd + 1);
+                if (wrapper && lane < 4)
+                    *reinterpret_cast<v4f*>(wv + RSMP_WP * 4) = v4f{acc.x, acc.y, __uint_as_float(take), 0.f};
+            };
+            if (have) wt.event(13);
+            if (have && loaded) {
+                // the wrap loads of this item: older than the 2 * kMaxCombos combo loads just issued
+                asm volatile("s_waitcnt vmcnt(%0)" : : "n"(2 * kMaxCombos) : "memory");
+#pragma unroll
+                for (int i = 0; i < kWrapTaps; ++i) asm volatile("" : "+v"(wx[i]));
+                asm volatile("" : "+v"(word));
+                wrap_out(wx, take_of(cur, d, word));
+            } else if (have) {
+                v2f we[kWrapTaps];
+                uint32_t w2;
+                load_wrap_edge(cur, d, we, w2);
+                wrap_out(we, take_of(cur, d, w2));
             }
-            ++rnd;
+            // (producers 4 and 5 issue the same loads as 0 and 1 and drop them: one code path)
+            load_wrap(pre, nxt, dn, wx, word);
+            if (have) {
+                lds_signal(staged + slot);
+                wt.event(14);
+                ++rnd;
+            }
+            cur = nxt;
+            d = dn;
+            sid = sidn;
+            loaded = pre;
+            if (more) nxt = find(cur.item + 1, dn, sidn);
         }
+        asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+        #undef RSMP_WP
+        #undef RSMP_WPART
         return;
     }
 
     // ---- consumer ----------------------------------------------------------------------------------
-    const uint32_t T = wave - kProducers;
+    const uint32_t T = consumer_index(wave);
     if (T >= g.n_tiles) return;
     const uint32_t grp = lane >> 4, q = (lane >> 2) & 3, pc = lane & 3;
     const uint32_t ob = (T * 16u * g.a) / g.b;        // first frame of the tile's window
@@ -322,11 +478,13 @@ __global__ __launch_bounds__(768) void fir_split_kernel(const FirStreamDesc* __r
 
     bf16x8 A[NK][3];
     const float* cur_table = nullptr;
+    uint32_t cur_stream = 0xFFFFFFFFu;
+    StreamCtx d{};
 
     for (uint32_t item = item_begin; item < item_end; ++item) {
         const uint32_t stream = item / g.blocks_per_stream;
         if (stream != cur_stream) {
-            d = load_stream(descs, stream);
+            d = load_stream(descs, stream, g.b);
             cur_stream = stream;
         }
         const Item it = item_of(g, d, item - stream * g.blocks_per_stream);
@@ -341,7 +499,9 @@ __global__ __launch_bounds__(768) void fir_split_kernel(const FirStreamDesc* __r
         }
         const uint32_t slot = rnd & 1, use = rnd >> 1;
         const uint32_t base = kImageBase + slot * image_bytes + lane_off;
+        wt.event(1);
         while (lds_load_acquire(staged + slot) < kProducers * (use + 1)) __builtin_amdgcn_s_sleep(1);
+        wt.event(2);
 
         v4f acc0 = v4f{0.f, 0.f, 0.f, 0.f}, acc1 = v4f{0.f, 0.f, 0.f, 0.f};
         auto frag = [&](uint32_t plane_ch, int s) -> bf16x8 {
@@ -351,6 +511,7 @@ __global__ __launch_bounds__(768) void fir_split_kernel(const FirStreamDesc* __r
             const s16x8 t = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
             return __builtin_bit_cast(bf16x8, t);
         };
+        if (!(g.debug & 2))
 #pragma unroll
         for (int s = 0; s < NK; ++s) {
             const bf16x8 x1 = frag(0, s), x2 = frag(1, s), x3 = frag(2, s);
@@ -369,15 +530,15 @@ __global__ __launch_bounds__(768) void fir_split_kernel(const FirStreamDesc* __r
             acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[s][0], x1, acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[s][0], y1, acc1, 0, 0, 0);
         }
-        // class 0 may take the wrap variant a producer computed (tile 0, D row 0)
+        // class 0 may take the wrap variant the producers left with the image (tile 0, D row 0)
         if (T == 0) {
-            while (lds_load_acquire(wflag + slot) != rnd + 1) __builtin_amdgcn_s_sleep(1);
             const v4f w = *reinterpret_cast<const v4f*>(lds + kCtrlBytes + slot * (kWrapBytes / 2) + pl * 16);
             if (grp == 0 && __float_as_uint(w.z) != 0u && !(g.debug & 2048)) {
                 acc0.x = w.x;
                 acc1.x = w.y;
             }
         }
+        wt.event(7);
         lds_signal(done + slot);
 
         // lane = (period, 4 consecutive classes), both channels: 32 contiguous bytes
@@ -403,6 +564,7 @@ __global__ __launch_bounds__(768) void fir_split_kernel(const FirStreamDesc* __r
                 }
             }
         }
+        wt.event(8);
         ++rnd;
     }
 }
@@ -431,8 +593,9 @@ PeriodicGeometry split_geometry(uint64_t num, uint64_t den, uint32_t taps, uint3
         }
     }
     const uint32_t kpad = (taps + shift + 31) / 32 * 32;
-    if (kpad / 32 < 1 || kpad / 32 > 5) return g;
-    const uint32_t rows = ob_max + kpad;
+    if (kpad / 32 < 1 || kpad / 32 > 5 || taps > 16 * kWrapTaps) return g;
+    const uint32_t rows = (ob_max + kpad + 63) / 64 * 64;   // whole 64-row blocks: producers store unconditionally
+    if (rows / 64 * 8 > kMaxCombos * kProducers) return g;
     const uint32_t lds = kImageBase + 2u * 6u * rows * 32u;
     if (lds > kLdsLimit) return g;
     g.a = a;
@@ -503,7 +666,7 @@ hipError_t launch_fir_split(const FirStreamDesc* d_descs, uint32_t n_streams, co
         const char* e = getenv("RSMP_FIR_DEBUG");
         return e ? static_cast<uint32_t>(atoi(e)) : 0u;
     }();
-    SplitArgs args{geo.a, geo.b, geo.taps, geo.n_tiles, geo.row_stride, max_blocks, max_blocks * n_streams, debug};
+    SplitArgs args{geo.a, geo.b, geo.taps, geo.n_tiles, geo.row_stride, max_blocks, max_blocks * n_streams, debug, nullptr};
     const void* fns[5] = {reinterpret_cast<const void*>(fir_split_kernel<1>),
                           reinterpret_cast<const void*>(fir_split_kernel<2>),
                           reinterpret_cast<const void*>(fir_split_kernel<3>),
@@ -530,9 +693,32 @@ hipError_t launch_fir_split(const FirStreamDesc* d_descs, uint32_t n_streams, co
     if (verbose)
         fprintf(stderr, "[rsmp] split launch: a=%u b=%u window=%u tiles=%u rows=%u lds=%u items=%u grid=%u\n",
                 geo.a, geo.b, geo.row_len, geo.n_tiles, geo.row_stride, geo.lds_bytes, args.total_items, grid.x);
+    static const char* wtrace_path = getenv("RSMP_FIR_WTRACE");
+    static unsigned long long* d_wtrace = nullptr;
+    const size_t wtrace_words = static_cast<size_t>(grid.x) * 16 * kWtraceSlots;
+    if (wtrace_path) {
+        if (d_wtrace) (void)hipFree(d_wtrace);
+        if (hipMalloc(&d_wtrace, wtrace_words * 8) != hipSuccess) return hipErrorOutOfMemory;
+        (void)hipMemset(d_wtrace, 0, wtrace_words * 8);
+        args.wtrace = d_wtrace;
+    }
     void* kargs[2] = {&d_descs, &args};
     e = hipLaunchKernel(fns[nk - 1], grid, dim3(kWaves * 64), kargs, geo.lds_bytes, stream);
     if (e != hipSuccess) return e;
+    if (wtrace_path) {   // one line per wave: block wave event...
+        (void)hipStreamSynchronize(stream);
+        std::vector<unsigned long long> h(wtrace_words);
+        (void)hipMemcpy(h.data(), d_wtrace, wtrace_words * 8, hipMemcpyDeviceToHost);
+        if (FILE* f = fopen(wtrace_path, "w")) {
+            for (size_t w = 0; w < wtrace_words / kWtraceSlots; ++w) {
+                fprintf(f, "%zu %zu", w / 16, w % 16);
+                for (uint32_t i = 0; i < kWtraceSlots && h[w * kWtraceSlots + i]; ++i)
+                    fprintf(f, " %llu:%llu", h[w * kWtraceSlots + i] >> 8, h[w * kWtraceSlots + i] & 255);
+                fprintf(f, "\n");
+            }
+            fclose(f);
+        }
+    }
     return hipGetLastError();
 }
 

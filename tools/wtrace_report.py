@@ -27,6 +27,14 @@ NAMES = {
     (6, 20): "unit setup",
     (20, 21): "unit MFMA loop",
     (21, 7): "unit epilogue",
+    (2, 7): "consumer: MFMA stream",
+    (7, 8): "consumer: signal + stores",
+    (8, 1): "consumer: next item",
+    (1, 2): "wait: image staged",
+    (12, 14): "producer: stage + signal",
+    (12, 13): "producer: stage",
+    (13, 14): "producer: wrap + signal",
+    (14, 11): "producer: next item",
     (11, 12): "producer: wait image free",
     (12, 13): "producer: claim + issue DMA",
     (13, 14): "producer: wait landed",
