@@ -43,10 +43,12 @@ namespace {
 constexpr uint32_t kProducers = 6, kConsumers = 10, kWaves = kProducers + kConsumers;
 constexpr uint32_t kCtrlBytes = 256;                 // staged[2], done[2]
 constexpr uint32_t kWrapBytes = 2 * 16 * 16;         // two slots x 16 periods x (ch0, ch1, take, -)
-constexpr uint32_t kImageBase = kCtrlBytes + kWrapBytes;
+constexpr uint32_t kTouchBytes = 3 * 256;              // landing zone of the consumers' L2 prefetch touches
+constexpr uint32_t kImageBase = kCtrlBytes + kWrapBytes + kTouchBytes;
+constexpr uint32_t kTouchAhead = 3;                    // items between a touch and the producers' loads of the same frames
 constexpr uint32_t kLdsLimit = 160 * 1024;
 constexpr int kWrapTaps = 8;                         // taps of the wrap variant per lane (16 lanes per period)
-constexpr int kMaxCombos = 7;                           // (row block, period pair) combos in flight per producer
+constexpr int kTaskSlots = 2;                          // (row block, period pair) combos in flight per producer
 
 struct SplitArgs {
     uint32_t a, b, taps, n_tiles, rows, blocks_per_stream, total_items, debug;
@@ -187,6 +189,19 @@ __device__ __forceinline__ void wait_loads(v2f& a, v2f& b) {
     asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory");
 }
 
+// Sum over the 16 lanes of a DPP row (every lane gets the total).
+__device__ __forceinline__ float row_sum16(float v) {
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, false));   // row_ror:8
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xf, 0xf, false));   // row_ror:4
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x122, 0xf, 0xf, false));   // row_ror:2
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121, 0xf, 0xf, false));   // row_ror:1
+    return v;
+}
+
+struct Quint {
+    v2f x[5];     // (ch0, ch1) of frame k in five consecutive periods
+};
+
 struct Combo {
     v2f x0, x1;   // (ch0, ch1) of row k in periods 2pp and 2pp + 1
 };
@@ -232,67 +247,84 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
 
     if (wave_is_producer(wave)) {
         // ---- producer ------------------------------------------------------------------------------
-        // An image is R rows x 8 period pairs; a combo = 64 rows of one pair; producer P takes combos
-        // P, P + 6, ...  The loads of the NEXT item's combos are issued in place as soon as a combo of
-        // the current item has been written: HBM latency is hidden across items, not within one.
+        // A lane task = frame k of five consecutive periods 4Q .. 4Q+4 (both channels): it writes the
+        // four periods 4Q..4Q+3 of row k (one 8-byte chunk per plane) and, because row k + a repeats row
+        // k of the NEXT period, the chunk of row k + a from the periods 4Q+1..4Q+4 -- every frame is
+        // split once and written twice.  4a lane tasks per image, 64 per wave task; producer P takes wave
+        // tasks P and P + 6.  The loads of the NEXT item are issued in place as soon as a task of the
+        // current item has been written: HBM latency is hidden across items, not within one.
         const uint32_t P = producer_index(wave);
-        const uint32_t n_combos = (R / 64) * 8;   // R is a whole number of 64-row blocks
-        // every producer handles exactly kMaxCombos combos, unconditionally (straight-line code lets the
-        // compiler count the loads in flight); surplus slots repeat another producer's combo
-        // wrap variant of class 0: producers 0-3 take 4 periods each; lane = (8 taps, period)
-        const bool wrapper = P < 4;   // (P & 3 below: producers 4 and 5 shadow 0 and 1)
-        // (the lane id behind an optimisation barrier per item: otherwise every combo's loop-invariant
-        // addressing is hoisted out of the item loop, spilled, and each reload from scratch waits for
-        // ALL the prefetches in flight -- scratch loads share the in-order vmcnt)
+        const uint32_t n_lane_tasks = 4 * g.a;
+        const uint32_t n_tasks = (n_lane_tasks + 63) / 64;   // <= kTaskSlots * kProducers (split_geometry)
+        // wrap variant of class 0: producers 2-5 take 4 periods each; lane = (period, 8 of the taps)
+        const bool wrapper = P >= 2;
+        // (the lane id behind an optimisation barrier per item: otherwise loop-invariant addressing is
+        // hoisted out of the item loop, spilled, and each reload from scratch waits for ALL the
+        // prefetches in flight -- scratch loads share the in-order vmcnt)
         uint32_t ln = lane;
-        #define RSMP_WP (4 * (P & 3) + (ln & 3))
-        #define RSMP_WPART (ln >> 2)
+        #define RSMP_WP (4 * ((P + 2) & 3) + (ln >> 4))
+        #define RSMP_WPART (ln & 15)
         float wcoef[kWrapTaps];
         const float* cur_coeffs = nullptr;
 
         StreamCtx d{}, dn{};
-        uint32_t sid = 0xFFFFFFFFu, sidn = 0xFFFFFFFFu;
-        auto find = [&](uint32_t item, StreamCtx& c, uint32_t& s) -> PItem {
+        uint32_t sidn = 0xFFFFFFFFu;
+        // items are visited in order: (stream, block) advance without a division
+        uint32_t f_stream = item_begin / g.blocks_per_stream, f_block = item_begin - f_stream * g.blocks_per_stream;
+        uint32_t f_item = item_begin;
+        auto find_next = [&]() -> PItem {   // the next valid item at or after f_item, in dn
             PItem r;
             r.item = item_end;
             r.it = Item{};
             r.f0 = 0;
             r.interior = false;
             r.off0 = 0;
-            for (; item < item_end; ++item) {
-                const uint32_t stream = item / g.blocks_per_stream;
-                if (stream != s) {
-                    c = load_stream(descs, stream, g.b);
-                    s = stream;
+            while (f_item < item_end) {
+                if (f_stream != sidn) {
+                    dn = load_stream(descs, f_stream, g.b);
+                    sidn = f_stream;
                 }
-                const Item it = item_of(g, c, item - stream * g.blocks_per_stream);
+                const Item it = item_of(g, dn, f_block);
+                const uint32_t this_item = f_item;
+                ++f_item;
+                if (++f_block == g.blocks_per_stream) {
+                    f_block = 0;
+                    ++f_stream;
+                }
                 if (!it.valid) continue;
-                r.item = item;
+                r.item = this_item;
                 r.it = it;
-                r.f0 = static_cast<int64_t>(it.q0 * g.a) - static_cast<int64_t>(c.abs_consumed);
-                const int64_t hf = c.hist_frames;
-                r.interior = r.f0 > hf && r.f0 + static_cast<int64_t>(15u * g.a + R) <= hf + static_cast<int64_t>(c.in_frames) &&
-                             c.in_frames < (1u << 28);
+                r.f0 = static_cast<int64_t>(it.q0 * g.a) - static_cast<int64_t>(dn.abs_consumed);
+                const int64_t hf = dn.hist_frames;
+                r.interior = r.f0 > hf && r.f0 + static_cast<int64_t>(17u * g.a) <= hf + static_cast<int64_t>(dn.in_frames) &&
+                             dn.in_frames < (1u << 28);
                 r.off0 = static_cast<uint32_t>(r.f0 - hf);
                 break;
             }
             return r;
         };
-        // row block / pair of this producer's m-th combo
-        auto combo_of = [&](uint32_t m) {
-            const uint32_t c = P + m * kProducers;
-            return c < n_combos ? c : c - n_combos;
+        // lane task of slot j: (Q, k); surplus lanes repeat the last lane task, surplus slots are idle
+        uint32_t tq[kTaskSlots], tk[kTaskSlots];   // (one division per slot for the whole launch)
+#pragma unroll
+        for (int j = 0; j < kTaskSlots; ++j) {
+            uint32_t t = (P + j * kProducers) * 64 + lane;
+            if (t >= n_lane_tasks) t = n_lane_tasks - 1;
+            tq[j] = t / g.a;
+            tk[j] = t - tq[j] * g.a;
+        }
+        auto task_of = [&](int j, uint32_t& Q, uint32_t& k) -> bool {
+            Q = tq[j];
+            k = tk[j];
+            return P + j * kProducers < n_tasks;
         };
-        auto combo_rb = [&](uint32_t m) { return combo_of(m) >> 3; };
-        auto combo_pp = [&](uint32_t m) { return combo_of(m) & 7; };
-        // real = false: a dummy load of the first bytes of the descriptor array (always mapped), so that
-        // every pass through the loop issues the same number of loads
-        auto load_combo = [&](Combo& cb, bool real, const PItem& pi, const void* base, uint32_t m) {
-            const uint32_t k = combo_rb(m) * 64 + ln;
-            // interior items have 32-bit byte offsets (see find): scalar base + one VGPR offset per load
-            const uint32_t off = real ? (pi.off0 + (2 * combo_pp(m)) * g.a + k) * 8u : 0u;
-            gload2(cb.x0, off, base);
-            gload2(cb.x1, real ? off + g.a * 8u : 0u, base);
+        auto load_task = [&](Quint& v, bool real, const PItem& pi, const void* base, int j) {
+            uint32_t Q, k;
+            (void)task_of(j, Q, k);
+            // interior items have 32-bit byte offsets (see find_next): scalar base + one VGPR offset per load
+            const uint32_t off = real ? (pi.off0 + 4 * Q * g.a + k) * 8u : 0u;
+            const uint32_t step = real ? g.a * 8u : 0u;
+#pragma unroll
+            for (int i = 0; i < 5; ++i) gload2(v.x[i], off + i * step, base);
         };
         auto fetch_edge = [&](const StreamCtx& c, int64_t f) -> v2f {
             const int64_t hf = c.hist_frames, total = hf + static_cast<int64_t>(c.in_frames);
@@ -302,24 +334,30 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
             if (!ok) v = v2f{0.f, 0.f};
             return v;
         };
-        auto store_combo = [&](char* img, uint32_t m, const Combo& cb) {
-            const uint32_t pp = combo_pp(m);
-            const uint32_t k = combo_rb(m) * 64 + ln;
-            uint32_t a1, a2, a3, b1, b2, b3;
-            char* row = img + k * 32 + ((((pp >> 1) ^ ((k >> 2) & 3)) << 3) | ((pp & 1) << 2));
-            split3(cb.x0.x, a1, a2, a3);   // channel 0
-            split3(cb.x1.x, b1, b2, b3);
-            *reinterpret_cast<uint32_t*>(row) = pack_hi16(b1, a1);
-            *reinterpret_cast<uint32_t*>(row + R * 32) = pack_hi16(b2, a2);
-            *reinterpret_cast<uint32_t*>(row + 2 * R * 32) = pack_hi16(b3, a3);
-            split3(cb.x0.y, a1, a2, a3);   // channel 1
-            split3(cb.x1.y, b1, b2, b3);
-            *reinterpret_cast<uint32_t*>(row + 3 * R * 32) = pack_hi16(b1, a1);
-            *reinterpret_cast<uint32_t*>(row + 4 * R * 32) = pack_hi16(b2, a2);
-            *reinterpret_cast<uint32_t*>(row + 5 * R * 32) = pack_hi16(b3, a3);
+        auto store_task = [&](char* img, int j, const Quint& v) {
+            uint32_t Q, k;
+            if (!task_of(j, Q, k)) return;   // wave-uniform
+            typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+            char* prim = img + k * 32 + ((Q ^ ((k >> 2) & 3)) << 3);
+            const uint32_t kd = k + g.a;
+            const bool dup = kd < R;
+            char* dupp = img + kd * 32 + ((Q ^ ((kd >> 2) & 3)) << 3);
+            uint32_t pl[3][5];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) split3(v.x[i].x, pl[0][i], pl[1][i], pl[2][i]);   // channel 0
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                *reinterpret_cast<u2*>(prim + p * R * 32) = u2{pack_hi16(pl[p][1], pl[p][0]), pack_hi16(pl[p][3], pl[p][2])};
+                if (dup) *reinterpret_cast<u2*>(dupp + p * R * 32) = u2{pack_hi16(pl[p][2], pl[p][1]), pack_hi16(pl[p][4], pl[p][3])};
+            }
+#pragma unroll
+            for (int i = 0; i < 5; ++i) split3(v.x[i].y, pl[0][i], pl[1][i], pl[2][i]);   // channel 1
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                *reinterpret_cast<u2*>(prim + (3 + p) * R * 32) = u2{pack_hi16(pl[p][1], pl[p][0]), pack_hi16(pl[p][3], pl[p][2])};
+                if (dup) *reinterpret_cast<u2*>(dupp + (3 + p) * R * 32) = u2{pack_hi16(pl[p][2], pl[p][1]), pack_hi16(pl[p][4], pl[p][3])};
+            }
         };
-        // wrap variant (row 1023 on the window one frame earlier, resampler_fir.rs:544, :562-565):
-        // this lane's 8 frames of period wp, and whether that period's class-0 output takes it
         // 9 loads: this lane's 8 frames of period wp and the bitmap word holding that period's take bit
         auto load_wrap = [&](bool real, const PItem& pi, const StreamCtx& c, v2f (&wx)[kWrapTaps], uint32_t& word) {
             const void* base = uniform_ptr(real ? static_cast<const void*>(c.in) : static_cast<const void*>(descs));
@@ -346,7 +384,7 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
             const uint32_t K = in_launch ? static_cast<uint32_t>(pi.it.k_block0 + static_cast<int32_t>(RSMP_WP)) : 0u;
             word = ((gconst_u32_ptr)c.wrap_bits)[K >> 5];
         };
-        constexpr int kItemLoads = 2 * kMaxCombos + kWrapTaps + 1;   // loads a producer issues per item
+        constexpr int kItemLoads = 5 * kTaskSlots + kWrapTaps + 1;   // loads a producer issues per item
 
         // One static instance of every asm load: the first pass (no current item yet) only issues the
         // first item's loads, every later pass writes the current item and issues the next one's into
@@ -358,8 +396,8 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
         cur.f0 = 0;
         cur.interior = false;
         cur.off0 = 0;
-        PItem nxt = find(item_begin, dn, sidn);
-        Combo x[kMaxCombos];
+        PItem nxt = find_next();
+        Quint x[kTaskSlots];
         v2f wx[kWrapTaps];
         uint32_t word = 0;
         bool loaded = false;   // cur's loads are in flight (cur is an interior item)
@@ -367,12 +405,14 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
             const bool have = cur.item != item_end;
             const bool more = nxt.item != item_end;
             if (!have && !more) break;
-            const bool pre = more && nxt.interior;   // the next item's loads can be issued ahead
+            const bool pre = more && nxt.interior && !(g.debug & 8192);   // the next item's loads can be issued ahead
             asm volatile("" : "+v"(ln));
+#pragma unroll
+            for (int j = 0; j < kTaskSlots; ++j) asm volatile("" : "+v"(tq[j]), "+v"(tk[j]));
             const uint32_t slot = rnd & 1, use = rnd >> 1;
             char* img = lds + kImageBase + slot * image_bytes;
             if (have && !loaded) asm volatile("s_waitcnt vmcnt(0)" : : : "memory");   // dummies: done with the registers
-            if (have && d.coeffs != cur_coeffs) {   // this lane's taps of row 1023 (rare: compiler-visible loads)
+            if (have && wrapper && d.coeffs != cur_coeffs) {   // this lane's taps of row 1023 (rare: compiler-visible loads)
                 asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
                 cur_coeffs = d.coeffs;
                 gconst_f32_ptr wrow = (gconst_f32_ptr)d.coeffs + static_cast<size_t>(1023) * g.taps;
@@ -392,63 +432,63 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
                 wt.event(12);
             }
             if (have && !loaded) {
-                // stream edges: frames outside [hist|in] read as zero; one combo at a time, plain loads
-                for (uint32_t m = 0; m < kMaxCombos; ++m) {
-                    const uint32_t k = combo_rb(m) * 64 + ln;
-                    const int64_t f = cur.f0 + static_cast<int64_t>((2 * combo_pp(m)) * g.a + k);
-                    Combo cb;
-                    cb.x0 = fetch_edge(d, f);
-                    cb.x1 = fetch_edge(d, f + g.a);
-                    store_combo(img, m, cb);
+                // stream edges: frames outside [hist|in] read as zero; one task at a time, plain loads
+                for (int j = 0; j < kTaskSlots; ++j) {
+                    uint32_t Q, k;
+                    if (!task_of(j, Q, k)) continue;
+                    Quint e;
+#pragma unroll
+                    for (int i = 0; i < 5; ++i)
+                        e.x[i] = fetch_edge(d, cur.f0 + static_cast<int64_t>((4 * Q + i) * g.a + k));
+                    store_task(img, j, e);
                 }
             }
             const void* nbase = uniform_ptr(pre ? static_cast<const void*>(dn.in) : static_cast<const void*>(descs));
             const bool stage = have && loaded && !(g.debug & 1);
 #pragma unroll
-            for (int m = 0; m < kMaxCombos; ++m) {
+            for (int j = 0; j < kTaskSlots; ++j) {
                 if (have && loaded) {
-                    // x[m]'s loads are older than the kItemLoads - 2 issued since
-                    wait_loads<kItemLoads - 2>(x[m].x0, x[m].x1);
-                    if (stage) store_combo(img, m, x[m]);
+                    // x[j]'s loads are older than the kItemLoads - 5 issued since
+                    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(kItemLoads - 5) : "memory");
+#pragma unroll
+                    for (int i = 0; i < 5; ++i) asm volatile("" : "+v"(x[j].x[i]));
+                    if (stage) store_task(img, j, x[j]);
                 }
-                load_combo(x[m], pre, nxt, nbase, m);
+                if (!(g.debug & 8192)) load_task(x[j], pre, nxt, nbase, j);
             }
             // wrap variant of class 0 for this producer's periods (the two paths share no registers: a value
             // merged from a plain load and an asm load would make the compiler wait for everything)
             auto wrap_out = [&](const v2f (&w)[kWrapTaps], uint32_t take) {
                 v2f acc = v2f{0.f, 0.f};
-                if (wrapper && !(g.debug & 1024)) {
+                if (!(g.debug & 1024)) {
 #pragma unroll
                     for (int i = 0; i < kWrapTaps; ++i) {
                         acc.x = fmaf(wcoef[i], w[i].x, acc.x);
                         acc.y = fmaf(wcoef[i], w[i].y, acc.y);
                     }
-#pragma unroll
-                    for (int sh = 4; sh < 64; sh *= 2) {
-                        acc.x += __shfl_xor(acc.x, sh, 64);
-                        acc.y += __shfl_xor(acc.y, sh, 64);
-                    }
+                    acc.x = row_sum16(acc.x);
+                    acc.y = row_sum16(acc.y);
                 }
                 float* wv = reinterpret_cast<float*>(lds + kCtrlBytes + slot * (kWrapBytes / 2));
-                if (wrapper && lane < 4)
+                if ((lane & 15) == 0)
                     *reinterpret_cast<v4f*>(wv + RSMP_WP * 4) = v4f{acc.x, acc.y, __uint_as_float(take), 0.f};
             };
             if (have) wt.event(13);
             if (have && loaded) {
-                // the wrap loads of this item: older than the 2 * kMaxCombos combo loads just issued
-                asm volatile("s_waitcnt vmcnt(%0)" : : "n"(2 * kMaxCombos) : "memory");
+                // the wrap loads of this item: older than the 5 * kTaskSlots task loads just issued
+                asm volatile("s_waitcnt vmcnt(%0)" : : "n"(5 * kTaskSlots) : "memory");
 #pragma unroll
                 for (int i = 0; i < kWrapTaps; ++i) asm volatile("" : "+v"(wx[i]));
                 asm volatile("" : "+v"(word));
-                wrap_out(wx, take_of(cur, d, word));
-            } else if (have) {
+                if (wrapper) wrap_out(wx, take_of(cur, d, word));
+            } else if (have && wrapper) {
                 v2f we[kWrapTaps];
                 uint32_t w2;
                 load_wrap_edge(cur, d, we, w2);
                 wrap_out(we, take_of(cur, d, w2));
             }
-            // (producers 4 and 5 issue the same loads as 0 and 1 and drop them: one code path)
-            load_wrap(pre, nxt, dn, wx, word);
+            // (producers 0 and 1 issue dummies here: one code path, one load count)
+            if (!(g.debug & 8192)) load_wrap(pre && wrapper, nxt, dn, wx, word);
             if (have) {
                 lds_signal(staged + slot);
                 wt.event(14);
@@ -456,9 +496,8 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
             }
             cur = nxt;
             d = dn;
-            sid = sidn;
             loaded = pre;
-            if (more) nxt = find(cur.item + 1, dn, sidn);
+            if (more) nxt = find_next();
         }
         asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
         #undef RSMP_WP
@@ -499,8 +538,22 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
         }
         const uint32_t slot = rnd & 1, use = rnd >> 1;
         const uint32_t base = kImageBase + slot * image_bytes + lane_off;
+        // L2 prefetch for the producers: the frames of the item kTouchAhead items on (same stream assumed),
+        // one dword per 128-byte line by LDS-DMA into a landing zone nobody reads.  The producers' own
+        // loads, issued one item ahead, would otherwise each pay the full HBM latency -- longer than an item.
+        if (T < 3 && d.in_frames != 0 && !(g.debug & 4096)) {
+            int64_t f = static_cast<int64_t>(it.q0 * g.a) - static_cast<int64_t>(d.abs_consumed) -
+                        static_cast<int64_t>(d.hist_frames) + static_cast<int64_t>(kTouchAhead * 16u * g.a) +
+                        static_cast<int64_t>((T * 64 + lane) * 16u);
+            if (f < 0) f = 0;
+            if (f >= static_cast<int64_t>(d.in_frames)) f = static_cast<int64_t>(d.in_frames) - 1;
+            typedef __attribute__((address_space(3))) void* lds_void_ptr;
+            __builtin_amdgcn_global_load_lds((gconst_f32_ptr)d.in + f * 2,
+                                             (lds_void_ptr)(lds + kCtrlBytes + kWrapBytes + T * 256), 4, 0, 0);
+        }
         wt.event(1);
-        while (lds_load_acquire(staged + slot) < kProducers * (use + 1)) __builtin_amdgcn_s_sleep(1);
+        if (!(g.debug & 16384))
+            while (lds_load_acquire(staged + slot) < kProducers * (use + 1)) __builtin_amdgcn_s_sleep(1);
         wt.event(2);
 
         v4f acc0 = v4f{0.f, 0.f, 0.f, 0.f}, acc1 = v4f{0.f, 0.f, 0.f, 0.f};
@@ -594,8 +647,8 @@ PeriodicGeometry split_geometry(uint64_t num, uint64_t den, uint32_t taps, uint3
     }
     const uint32_t kpad = (taps + shift + 31) / 32 * 32;
     if (kpad / 32 < 1 || kpad / 32 > 5 || taps > 16 * kWrapTaps) return g;
-    const uint32_t rows = (ob_max + kpad + 63) / 64 * 64;   // whole 64-row blocks: producers store unconditionally
-    if (rows / 64 * 8 > kMaxCombos * kProducers) return g;
+    const uint32_t rows = ob_max + kpad;
+    if ((4 * a + 63) / 64 > kTaskSlots * kProducers || rows < a || rows > 2 * a) return g;   // (rows beyond a repeat the next period)
     const uint32_t lds = kImageBase + 2u * 6u * rows * 32u;
     if (lds > kLdsLimit) return g;
     g.a = a;
@@ -699,7 +752,7 @@ hipError_t launch_fir_split(const FirStreamDesc* d_descs, uint32_t n_streams, co
     if (wtrace_path) {
         if (d_wtrace) (void)hipFree(d_wtrace);
         if (hipMalloc(&d_wtrace, wtrace_words * 8) != hipSuccess) return hipErrorOutOfMemory;
-        (void)hipMemset(d_wtrace, 0, wtrace_words * 8);
+        (void)hipMemsetAsync(d_wtrace, 0, wtrace_words * 8, stream);
         args.wtrace = d_wtrace;
     }
     void* kargs[2] = {&d_descs, &args};

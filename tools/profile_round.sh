@@ -39,7 +39,7 @@ out = sys.argv[1]
 tot = collections.defaultdict(list)
 for f in glob.glob(out + '/pmc_*/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
-        if 'fir_periodic' in r['Kernel_Name']:
+        if 'fir_periodic' in r['Kernel_Name'] or 'fir_split' in r['Kernel_Name']:
             tot[r['Counter_Name']].append(float(r['Counter_Value']))
 mean = {k: sum(v) / len(v) for k, v in tot.items()}
 bench = json.loads(open(out + '/bench_n1.json').read().strip().splitlines()[-1])
