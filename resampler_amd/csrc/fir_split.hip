@@ -42,7 +42,7 @@ namespace {
 
 constexpr uint32_t kProducers = 6, kConsumers = 10, kWaves = kProducers + kConsumers;
 constexpr uint32_t kCtrlBytes = 256;                 // staged[2], done[2]
-constexpr uint32_t kWrapBytes = 2 * 16 * 16;         // two slots x 16 periods x (ch0, ch1, take, -)
+constexpr uint32_t kWrapBytes = 4 * 16 * 16;         // up to four slots x 16 periods x (ch0, ch1, take, -)
 constexpr uint32_t kTouchBytes = 3 * 256;              // landing zone of the consumers' L2 prefetch touches
 constexpr uint32_t kImageBase = kCtrlBytes + kWrapBytes + kTouchBytes;
 constexpr uint32_t kTouchAhead = 3;                    // items between a touch and the producers' loads of the same frames
@@ -51,25 +51,40 @@ constexpr int kWrapTaps = 8;                         // taps of the wrap variant
 constexpr int kTaskSlots = 2;                          // (row block, period pair) combos in flight per producer
 
 struct SplitArgs {
-    uint32_t a, b, taps, n_tiles, rows, blocks_per_stream, total_items, debug;
+    uint32_t a, b, taps, n_tiles, rows, slots, lds_bytes, blocks_per_stream, total_items, debug;
     unsigned long long* wtrace;   // RSMP_FIR_WTRACE: kWtraceSlots timestamped events per wave
 };
 
-constexpr uint32_t kWtraceSlots = 160;
+constexpr uint32_t kWtraceSlots = 16;
 
-// Diagnostic per-wave event log: (100 MHz timestamp << 8) | tag, read by tools/wtrace_report.py.
+// Diagnostic per-wave phase clock (RSMP_FIR_WTRACE): event(tag) adds the shader-clock cycles since the
+// wave's previous event to the bucket of the previous tag (in LDS, 16 buckets per wave, written out at
+// the end).  Cheap enough not to change what it measures: one s_memtime and one LDS add per event.
 struct WaveTrace {
-    unsigned long long* base;
-    uint32_t cursor;
-    __device__ __forceinline__ void init(const SplitArgs& g, uint32_t wave) {
-        base = g.wtrace ? g.wtrace + (static_cast<size_t>(blockIdx.x) * 16 + wave) * kWtraceSlots : nullptr;
-        cursor = 0;
+    unsigned long long* out;
+    unsigned long long* acc;     // LDS
+    unsigned long long last;
+    uint32_t prev;
+    __device__ __forceinline__ void init(const SplitArgs& g, char* lds, uint32_t wave) {
+        out = g.wtrace ? g.wtrace + (static_cast<size_t>(blockIdx.x) * 16 + wave) * kWtraceSlots : nullptr;
+        acc = reinterpret_cast<unsigned long long*>(lds + g.lds_bytes) + wave * kWtraceSlots;
+        last = 0;
+        prev = 0;
     }
     __device__ __forceinline__ void event(uint32_t tag) {
-        if (base && cursor < kWtraceSlots) {
-            const unsigned long long v = (__builtin_amdgcn_s_memrealtime() << 8) | tag;
-            if ((threadIdx.x & 63) == 0) base[cursor] = v;
-            ++cursor;
+        if (out) {
+            const unsigned long long now = __builtin_amdgcn_s_memtime();
+            if (last != 0 && (threadIdx.x & 63) == 0)
+                (void)__hip_atomic_fetch_add(acc + prev, now - last, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            last = now;
+            prev = tag & 15;
+        }
+    }
+    __device__ __forceinline__ void flush() {
+        if (out) {
+            __builtin_amdgcn_s_waitcnt(0);
+            const uint32_t l = threadIdx.x & 63;
+            if (l < kWtraceSlots) out[l] = acc[l];
         }
     }
 };
@@ -153,6 +168,59 @@ __device__ __forceinline__ Item item_of(const SplitArgs& g, const StreamCtx& d, 
     return it;
 }
 
+// Walks a workgroup's items in order without per-item divisions or 64-bit multiplications: the item
+// values of a stream advance by constants from one block to the next.
+struct Cursor {
+    uint32_t item, stream, block;   // the next item to look at
+    bool fresh;                     // `c` and the values below belong to (stream, block)
+    StreamCtx c;
+    uint64_t q0, q_limit;           // valid iff q0 < q_limit
+    int32_t n_block0, k_block0;
+    int64_t f0;                     // frame index of (period q0, row 0) in [hist|in]
+    __device__ __forceinline__ void init(const SplitArgs& g, uint32_t first) {
+        item = first;
+        stream = first / g.blocks_per_stream;
+        block = first - stream * g.blocks_per_stream;
+        fresh = false;
+        c = StreamCtx{};
+        q0 = q_limit = 0;
+        n_block0 = k_block0 = 0;
+        f0 = 0;
+    }
+    // Finds the next valid item before `end`; returns false when there is none.  On success the values
+    // (c, q0, n_block0, k_block0, f0) describe it and `found` is its index.
+    __device__ __forceinline__ bool next(const SplitArgs& g, const FirStreamDesc* descs, uint32_t end, uint32_t& found) {
+        while (item < end) {
+            if (!fresh) {
+                c = load_stream(descs, stream, g.b);
+                q0 = c.q_first + static_cast<uint64_t>(block) * 16u;
+                q_limit = c.n_out != 0 ? (c.abs_out + c.n_out + g.b - 1) / g.b : 0;
+                n_block0 = static_cast<int32_t>(static_cast<int64_t>(q0 * g.b) - static_cast<int64_t>(c.abs_out));
+                k_block0 = static_cast<int32_t>(static_cast<int64_t>(q0) - static_cast<int64_t>(c.wrap_k0));
+                f0 = static_cast<int64_t>(q0 * g.a) - static_cast<int64_t>(c.abs_consumed);
+                fresh = true;
+            } else {
+                q0 += 16;
+                n_block0 += static_cast<int32_t>(16u * g.b);
+                k_block0 += 16;
+                f0 += 16u * g.a;
+            }
+            found = item;
+            const bool valid = q0 < q_limit;
+            ++item;
+            if (++block == g.blocks_per_stream) {
+                block = 0;
+                ++stream;
+                fresh = false;
+            } else if (!valid) {
+                // past the stream's last period: skip the rest of its blocks
+            }
+            if (valid) return true;
+        }
+        return false;
+    }
+};
+
 // f32 -> three bf16 planes by truncation: x == p1 + p2 + p3 exactly (24 significant bits = 8 + 8 + 8;
 // both subtractions are exact).  Returned as f32 bit patterns whose low halves are don't-care.
 __device__ __forceinline__ void split3(float x, uint32_t& p1, uint32_t& p2, uint32_t& p3) {
@@ -228,10 +296,11 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
     extern __shared__ __attribute__((aligned(16))) char lds[];
     uint32_t* ctrl = reinterpret_cast<uint32_t*>(lds);
     uint32_t* staged = ctrl;        // [slot]: producers that finished staging, cumulative
-    uint32_t* done = ctrl + 2;      // [slot]: consumers that finished reading, cumulative
+    uint32_t* done = ctrl + 4;      // [slot]: consumers that finished reading, cumulative
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (threadIdx.x < kCtrlBytes / 4) ctrl[threadIdx.x] = 0;
+    for (uint32_t i = threadIdx.x; i < (g.lds_bytes + (g.wtrace ? 16 * kWtraceSlots * 8 : 0)) / 4; i += blockDim.x)
+        ctrl[i] = 0;   // counters; finite image rows
     __syncthreads();
 
     const uint32_t R = g.rows;
@@ -241,9 +310,9 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
     const uint32_t item_end = static_cast<uint32_t>(static_cast<uint64_t>(blockIdx.x + 1) * g.total_items / gridDim.x);
     if (item_begin == item_end) return;
 
-    uint32_t rnd = 0;
+    uint32_t slot = 0, use = 0;   // ring position of the current item: image slot, times the slot was used before
     WaveTrace wt;
-    wt.init(g, wave);
+    wt.init(g, lds, wave);
 
     if (wave_is_producer(wave)) {
         // ---- producer ------------------------------------------------------------------------------
@@ -254,6 +323,9 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
         // tasks P and P + 6.  The loads of the NEXT item are issued in place as soon as a task of the
         // current item has been written: HBM latency is hidden across items, not within one.
         const uint32_t P = producer_index(wave);
+        // The producers are the critical path (the consumers have slack): let the SIMD's arbiter take their
+        // instructions first whenever they are ready, between the consumers' MFMAs.
+        if (!(g.debug & 32768)) __builtin_amdgcn_s_setprio(3);
         const uint32_t n_lane_tasks = 4 * g.a;
         const uint32_t n_tasks = (n_lane_tasks + 63) / 64;   // <= kTaskSlots * kProducers (split_geometry)
         // wrap variant of class 0: producers 2-5 take 4 periods each; lane = (period, 8 of the taps)
@@ -267,43 +339,31 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
         float wcoef[kWrapTaps];
         const float* cur_coeffs = nullptr;
 
-        StreamCtx d{}, dn{};
-        uint32_t sidn = 0xFFFFFFFFu;
-        // items are visited in order: (stream, block) advance without a division
-        uint32_t f_stream = item_begin / g.blocks_per_stream, f_block = item_begin - f_stream * g.blocks_per_stream;
-        uint32_t f_item = item_begin;
-        auto find_next = [&]() -> PItem {   // the next valid item at or after f_item, in dn
+        StreamCtx d{};
+        Cursor cu;
+        cu.init(g, item_begin);
+        auto find_next = [&]() -> PItem {   // the next valid item; its stream context is cu.c
             PItem r;
             r.item = item_end;
             r.it = Item{};
             r.f0 = 0;
             r.interior = false;
             r.off0 = 0;
-            while (f_item < item_end) {
-                if (f_stream != sidn) {
-                    dn = load_stream(descs, f_stream, g.b);
-                    sidn = f_stream;
-                }
-                const Item it = item_of(g, dn, f_block);
-                const uint32_t this_item = f_item;
-                ++f_item;
-                if (++f_block == g.blocks_per_stream) {
-                    f_block = 0;
-                    ++f_stream;
-                }
-                if (!it.valid) continue;
-                r.item = this_item;
-                r.it = it;
-                r.f0 = static_cast<int64_t>(it.q0 * g.a) - static_cast<int64_t>(dn.abs_consumed);
-                const int64_t hf = dn.hist_frames;
-                r.interior = r.f0 > hf && r.f0 + static_cast<int64_t>(17u * g.a) <= hf + static_cast<int64_t>(dn.in_frames) &&
-                             dn.in_frames < (1u << 28);
+            uint32_t found;
+            if (cu.next(g, descs, item_end, found)) {
+                r.item = found;
+                r.it.q0 = cu.q0;
+                r.it.n_block0 = cu.n_block0;
+                r.it.k_block0 = cu.k_block0;
+                r.it.valid = true;
+                r.f0 = cu.f0;
+                const int64_t hf = cu.c.hist_frames;
+                r.interior = r.f0 > hf && r.f0 + static_cast<int64_t>(17u * g.a) <= hf + static_cast<int64_t>(cu.c.in_frames) &&
+                             cu.c.in_frames < (1u << 28);
                 r.off0 = static_cast<uint32_t>(r.f0 - hf);
-                break;
             }
             return r;
         };
-        // lane task of slot j: (Q, k); surplus lanes repeat the last lane task, surplus slots are idle
         uint32_t tq[kTaskSlots], tk[kTaskSlots];   // (one division per slot for the whole launch)
 #pragma unroll
         for (int j = 0; j < kTaskSlots; ++j) {
@@ -407,9 +467,10 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
             if (!have && !more) break;
             const bool pre = more && nxt.interior && !(g.debug & 8192);   // the next item's loads can be issued ahead
             asm volatile("" : "+v"(ln));
+            if (g.debug & 65536) {
 #pragma unroll
-            for (int j = 0; j < kTaskSlots; ++j) asm volatile("" : "+v"(tq[j]), "+v"(tk[j]));
-            const uint32_t slot = rnd & 1, use = rnd >> 1;
+                for (int j = 0; j < kTaskSlots; ++j) asm volatile("" : "+v"(tq[j]), "+v"(tk[j]));
+            }
             char* img = lds + kImageBase + slot * image_bytes;
             if (have && !loaded) asm volatile("s_waitcnt vmcnt(0)" : : : "memory");   // dummies: done with the registers
             if (have && wrapper && d.coeffs != cur_coeffs) {   // this lane's taps of row 1023 (rare: compiler-visible loads)
@@ -443,7 +504,7 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
                     store_task(img, j, e);
                 }
             }
-            const void* nbase = uniform_ptr(pre ? static_cast<const void*>(dn.in) : static_cast<const void*>(descs));
+            const void* nbase = uniform_ptr(pre ? static_cast<const void*>(cu.c.in) : static_cast<const void*>(descs));
             const bool stage = have && loaded && !(g.debug & 1);
 #pragma unroll
             for (int j = 0; j < kTaskSlots; ++j) {
@@ -469,7 +530,7 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
                     acc.x = row_sum16(acc.x);
                     acc.y = row_sum16(acc.y);
                 }
-                float* wv = reinterpret_cast<float*>(lds + kCtrlBytes + slot * (kWrapBytes / 2));
+                float* wv = reinterpret_cast<float*>(lds + kCtrlBytes + slot * 256);
                 if ((lane & 15) == 0)
                     *reinterpret_cast<v4f*>(wv + RSMP_WP * 4) = v4f{acc.x, acc.y, __uint_as_float(take), 0.f};
             };
@@ -488,18 +549,22 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
                 wrap_out(we, take_of(cur, d, w2));
             }
             // (producers 0 and 1 issue dummies here: one code path, one load count)
-            if (!(g.debug & 8192)) load_wrap(pre && wrapper, nxt, dn, wx, word);
+            if (!(g.debug & 8192)) load_wrap(pre && wrapper, nxt, cu.c, wx, word);
             if (have) {
                 lds_signal(staged + slot);
                 wt.event(14);
-                ++rnd;
+                if (++slot == g.slots) {
+                    slot = 0;
+                    ++use;
+                }
             }
             cur = nxt;
-            d = dn;
+            d = cu.c;
             loaded = pre;
             if (more) nxt = find_next();
         }
         asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+        wt.flush();
         #undef RSMP_WP
         #undef RSMP_WPART
         return;
@@ -517,17 +582,16 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
 
     bf16x8 A[NK][3];
     const float* cur_table = nullptr;
-    uint32_t cur_stream = 0xFFFFFFFFu;
-    StreamCtx d{};
-
-    for (uint32_t item = item_begin; item < item_end; ++item) {
-        const uint32_t stream = item / g.blocks_per_stream;
-        if (stream != cur_stream) {
-            d = load_stream(descs, stream, g.b);
-            cur_stream = stream;
-        }
-        const Item it = item_of(g, d, item - stream * g.blocks_per_stream);
-        if (!it.valid) continue;
+    Cursor cu;
+    cu.init(g, item_begin);
+    uint32_t item;
+    while (cu.next(g, descs, item_end, item)) {
+        const StreamCtx& d = cu.c;
+        Item it;
+        it.q0 = cu.q0;
+        it.n_block0 = cu.n_block0;
+        it.k_block0 = cu.k_block0;
+        it.valid = true;
         if (d.class_coef != cur_table) {   // streams of one launch may differ in drift
             cur_table = d.class_coef;
             gconst_u4_ptr tp = (gconst_u4_ptr)(cur_table) + static_cast<size_t>(T) * (NK * 3 * 64) + lane;
@@ -536,14 +600,12 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
 #pragma unroll
                 for (int p = 0; p < 3; ++p) A[s][p] = __builtin_bit_cast(bf16x8, tp[(s * 3 + p) * 64]);
         }
-        const uint32_t slot = rnd & 1, use = rnd >> 1;
         const uint32_t base = kImageBase + slot * image_bytes + lane_off;
         // L2 prefetch for the producers: the frames of the item kTouchAhead items on (same stream assumed),
         // one dword per 128-byte line by LDS-DMA into a landing zone nobody reads.  The producers' own
         // loads, issued one item ahead, would otherwise each pay the full HBM latency -- longer than an item.
         if (T < 3 && d.in_frames != 0 && !(g.debug & 4096)) {
-            int64_t f = static_cast<int64_t>(it.q0 * g.a) - static_cast<int64_t>(d.abs_consumed) -
-                        static_cast<int64_t>(d.hist_frames) + static_cast<int64_t>(kTouchAhead * 16u * g.a) +
+            int64_t f = cu.f0 - static_cast<int64_t>(d.hist_frames) + static_cast<int64_t>(kTouchAhead * 16u * g.a) +
                         static_cast<int64_t>((T * 64 + lane) * 16u);
             if (f < 0) f = 0;
             if (f >= static_cast<int64_t>(d.in_frames)) f = static_cast<int64_t>(d.in_frames) - 1;
@@ -585,7 +647,7 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
         }
         // class 0 may take the wrap variant the producers left with the image (tile 0, D row 0)
         if (T == 0) {
-            const v4f w = *reinterpret_cast<const v4f*>(lds + kCtrlBytes + slot * (kWrapBytes / 2) + pl * 16);
+            const v4f w = *reinterpret_cast<const v4f*>(lds + kCtrlBytes + slot * 256 + pl * 16);
             if (grp == 0 && __float_as_uint(w.z) != 0u && !(g.debug & 2048)) {
                 acc0.x = w.x;
                 acc1.x = w.y;
@@ -618,8 +680,12 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
             }
         }
         wt.event(8);
-        ++rnd;
+        if (++slot == g.slots) {
+            slot = 0;
+            ++use;
+        }
     }
+    wt.flush();
 }
 
 inline uint32_t split_class_offset(uint32_t a, uint32_t b, uint32_t j) {
@@ -647,10 +713,16 @@ PeriodicGeometry split_geometry(uint64_t num, uint64_t den, uint32_t taps, uint3
     }
     const uint32_t kpad = (taps + shift + 31) / 32 * 32;
     if (kpad / 32 < 1 || kpad / 32 > 5 || taps > 16 * kWrapTaps) return g;
-    const uint32_t rows = ob_max + kpad;
+    // Rows a plane really needs: the last tile's window ends at ob_max + taps + shift.  The MFMA steps read
+    // on to ob_max + kpad with zero coefficients -- into the rows that follow in LDS (the next plane, the next
+    // image, the pad after the last image: always finite values, the whole LDS is zeroed at the start).
+    const uint32_t rows = ob_max + taps + shift;
     if ((4 * a + 63) / 64 > kTaskSlots * kProducers || rows < a || rows > 2 * a) return g;   // (rows beyond a repeat the next period)
-    const uint32_t lds = kImageBase + 2u * 6u * rows * 32u;
-    if (lds > kLdsLimit) return g;
+    const uint32_t pad = (kpad - (taps + shift)) * 32u;
+    uint32_t slots = (kLdsLimit - kImageBase - pad) / (6u * rows * 32u);   // ring of images: slack between producers and consumers
+    if (slots > 4) slots = 4;
+    if (slots < 2) return g;
+    const uint32_t lds = kImageBase + slots * 6u * rows * 32u + pad;
     g.a = a;
     g.b = b;
     g.den = b;
@@ -664,7 +736,7 @@ PeriodicGeometry split_geometry(uint64_t num, uint64_t den, uint32_t taps, uint3
     g.row_stride = rows;       // rows of an image (frames of a period + window reach)
     g.waves = kWaves;
     g.producers = kProducers;
-    g.images = 2;
+    g.images = slots;
     g.mfma = 3;
     g.lds_bytes = lds;
     g.inline_wraps = true;
@@ -719,7 +791,7 @@ hipError_t launch_fir_split(const FirStreamDesc* d_descs, uint32_t n_streams, co
         const char* e = getenv("RSMP_FIR_DEBUG");
         return e ? static_cast<uint32_t>(atoi(e)) : 0u;
     }();
-    SplitArgs args{geo.a, geo.b, geo.taps, geo.n_tiles, geo.row_stride, max_blocks, max_blocks * n_streams, debug, nullptr};
+    SplitArgs args{geo.a, geo.b, geo.taps, geo.n_tiles, geo.row_stride, geo.images, geo.lds_bytes, max_blocks, max_blocks * n_streams, debug, nullptr};
     const void* fns[5] = {reinterpret_cast<const void*>(fir_split_kernel<1>),
                           reinterpret_cast<const void*>(fir_split_kernel<2>),
                           reinterpret_cast<const void*>(fir_split_kernel<3>),
@@ -756,7 +828,8 @@ hipError_t launch_fir_split(const FirStreamDesc* d_descs, uint32_t n_streams, co
         args.wtrace = d_wtrace;
     }
     void* kargs[2] = {&d_descs, &args};
-    e = hipLaunchKernel(fns[nk - 1], grid, dim3(kWaves * 64), kargs, geo.lds_bytes, stream);
+    e = hipLaunchKernel(fns[nk - 1], grid, dim3(kWaves * 64), kargs,
+                        geo.lds_bytes + (wtrace_path ? 16 * kWtraceSlots * 8 : 0), stream);
     if (e != hipSuccess) return e;
     if (wtrace_path) {   // one line per wave: block wave event...
         (void)hipStreamSynchronize(stream);
@@ -765,8 +838,7 @@ hipError_t launch_fir_split(const FirStreamDesc* d_descs, uint32_t n_streams, co
         if (FILE* f = fopen(wtrace_path, "w")) {
             for (size_t w = 0; w < wtrace_words / kWtraceSlots; ++w) {
                 fprintf(f, "%zu %zu", w / 16, w % 16);
-                for (uint32_t i = 0; i < kWtraceSlots && h[w * kWtraceSlots + i]; ++i)
-                    fprintf(f, " %llu:%llu", h[w * kWtraceSlots + i] >> 8, h[w * kWtraceSlots + i] & 255);
+                for (uint32_t i = 0; i < kWtraceSlots; ++i) fprintf(f, " %llu", h[w * kWtraceSlots + i]);
                 fprintf(f, "\n");
             }
             fclose(f);
