@@ -45,6 +45,9 @@ constexpr uint32_t kCtrlBytes = 256;                 // staged[2], done[2]
 constexpr uint32_t kWrapBytes = 4 * 16 * 16;         // up to four slots x 16 periods x (ch0, ch1, take, -)
 constexpr uint32_t kTouchBytes = 3 * 256;              // landing zone of the consumers' L2 prefetch touches
 constexpr uint32_t kImageBase = kCtrlBytes + kWrapBytes + kTouchBytes;
+constexpr uint32_t kRowBytes = 7 * 32;                 // an image row: six 32-byte plane rows (3 planes x 2 channels) + 32 bytes
+                                                       // of padding: 56 dwords = 7 mod 8 bank groups, so the eight rows a
+                                                       // transposed read touches per 32 lanes fall on distinct banks
 constexpr uint32_t kTouchAhead = 3;                    // items between a touch and the producers' loads of the same frames
 constexpr uint32_t kLdsLimit = 160 * 1024;
 constexpr int kWrapTaps = 8;                         // taps of the wrap variant per lane (16 lanes per period)
@@ -304,7 +307,7 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
     __syncthreads();
 
     const uint32_t R = g.rows;
-    const uint32_t image_bytes = 6u * R * 32u;
+    const uint32_t image_bytes = R * kRowBytes;
     const uint32_t n_active = g.n_tiles < kConsumers ? g.n_tiles : kConsumers;
     const uint32_t item_begin = static_cast<uint32_t>(static_cast<uint64_t>(blockIdx.x) * g.total_items / gridDim.x);
     const uint32_t item_end = static_cast<uint32_t>(static_cast<uint64_t>(blockIdx.x + 1) * g.total_items / gridDim.x);
@@ -398,24 +401,25 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
             uint32_t Q, k;
             if (!task_of(j, Q, k)) return;   // wave-uniform
             typedef uint32_t u2 __attribute__((ext_vector_type(2)));
-            char* prim = img + k * 32 + ((Q ^ ((k >> 2) & 3)) << 3);
+            char* prim = img + k * kRowBytes + ((Q ^ ((k >> 2) & 3)) << 3);
             const uint32_t kd = k + g.a;
-            const bool dup = kd < R;
-            char* dupp = img + kd * 32 + ((Q ^ ((kd >> 2) & 3)) << 3);
+            // rows past the image (two of the 147): their copies go to the touch landing zone instead -- an
+            // unconditional store is cheaper than a predicated one
+            char* dupp = kd < R ? img + kd * kRowBytes + ((Q ^ ((kd >> 2) & 3)) << 3) : lds + kCtrlBytes + kWrapBytes;
             uint32_t pl[3][5];
 #pragma unroll
             for (int i = 0; i < 5; ++i) split3(v.x[i].x, pl[0][i], pl[1][i], pl[2][i]);   // channel 0
 #pragma unroll
             for (int p = 0; p < 3; ++p) {
-                *reinterpret_cast<u2*>(prim + p * R * 32) = u2{pack_hi16(pl[p][1], pl[p][0]), pack_hi16(pl[p][3], pl[p][2])};
-                if (dup) *reinterpret_cast<u2*>(dupp + p * R * 32) = u2{pack_hi16(pl[p][2], pl[p][1]), pack_hi16(pl[p][4], pl[p][3])};
+                *reinterpret_cast<u2*>(prim + p * 32) = u2{pack_hi16(pl[p][1], pl[p][0]), pack_hi16(pl[p][3], pl[p][2])};
+                *reinterpret_cast<u2*>(dupp + p * 32) = u2{pack_hi16(pl[p][2], pl[p][1]), pack_hi16(pl[p][4], pl[p][3])};
             }
 #pragma unroll
             for (int i = 0; i < 5; ++i) split3(v.x[i].y, pl[0][i], pl[1][i], pl[2][i]);   // channel 1
 #pragma unroll
             for (int p = 0; p < 3; ++p) {
-                *reinterpret_cast<u2*>(prim + (3 + p) * R * 32) = u2{pack_hi16(pl[p][1], pl[p][0]), pack_hi16(pl[p][3], pl[p][2])};
-                if (dup) *reinterpret_cast<u2*>(dupp + (3 + p) * R * 32) = u2{pack_hi16(pl[p][2], pl[p][1]), pack_hi16(pl[p][4], pl[p][3])};
+                *reinterpret_cast<u2*>(prim + (3 + p) * 32) = u2{pack_hi16(pl[p][1], pl[p][0]), pack_hi16(pl[p][3], pl[p][2])};
+                *reinterpret_cast<u2*>(dupp + (3 + p) * 32) = u2{pack_hi16(pl[p][2], pl[p][1]), pack_hi16(pl[p][4], pl[p][3])};
             }
         };
         // 9 loads: this lane's 8 frames of period wp and the bitmap word holding that period's take bit
@@ -450,43 +454,30 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
         // first item's loads, every later pass writes the current item and issues the next one's into
         // the same registers.  (A separate prologue would make the compiler copy registers that are
         // still in flight where its values meet the loop's.)
-        PItem cur;
-        cur.item = item_end;
-        cur.it = Item{};
-        cur.f0 = 0;
-        cur.interior = false;
-        cur.off0 = 0;
+        // State carried from one pass to the next: whether there is a current item, whether its loads are
+        // in flight, and -- only for an edge item -- its description (an interior item needs none: its
+        // data sits in the registers, its take bit in `word` / `wsel`).
+        bool have = false, loaded = false;
         PItem nxt = find_next();
+        PItem ecur = nxt;
+        StreamCtx ectx = cu.c;
         Quint x[kTaskSlots];
         v2f wx[kWrapTaps];
-        uint32_t word = 0;
-        bool loaded = false;   // cur's loads are in flight (cur is an interior item)
+        uint32_t word = 0, wsel = 32;   // wsel: bit of `word` that says whether this lane's period takes the wrap variant; 32 = none
+        // load_wrap + the selector of the take bit
+        auto load_wrap_sel = [&](bool real, const PItem& pi, const StreamCtx& c) {
+            load_wrap(real, pi, c, wx, word);
+            const int32_t nw = pi.it.n_block0 + static_cast<int32_t>(RSMP_WP * g.b);
+            const bool in_launch = real && nw >= 0 && nw < static_cast<int32_t>(c.n_out);
+            wsel = in_launch ? static_cast<uint32_t>(pi.it.k_block0 + static_cast<int32_t>(RSMP_WP)) & 31u : 32u;
+        };
         for (;;) {
-            const bool have = cur.item != item_end;
             const bool more = nxt.item != item_end;
             if (!have && !more) break;
             const bool pre = more && nxt.interior && !(g.debug & 8192);   // the next item's loads can be issued ahead
             asm volatile("" : "+v"(ln));
-            if (g.debug & 65536) {
-#pragma unroll
-                for (int j = 0; j < kTaskSlots; ++j) asm volatile("" : "+v"(tq[j]), "+v"(tk[j]));
-            }
             char* img = lds + kImageBase + slot * image_bytes;
             if (have && !loaded) asm volatile("s_waitcnt vmcnt(0)" : : : "memory");   // dummies: done with the registers
-            if (have && wrapper && d.coeffs != cur_coeffs) {   // this lane's taps of row 1023 (rare: compiler-visible loads)
-                asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
-                cur_coeffs = d.coeffs;
-                gconst_f32_ptr wrow = (gconst_f32_ptr)d.coeffs + static_cast<size_t>(1023) * g.taps;
-#pragma unroll
-                for (int i = 0; i < kWrapTaps; ++i) {
-                    const uint32_t t = RSMP_WPART * kWrapTaps + i;
-                    wcoef[i] = t < g.taps ? wrow[t] : 0.f;
-                }
-                // have them land here: a compiler-inserted wait at their use would also wait for every
-                // prefetch issued in between
-#pragma unroll
-                for (int i = 0; i < kWrapTaps; ++i) asm volatile("" : "+v"(wcoef[i]));
-            }
             if (have) {
                 wt.event(11);
                 while (lds_load_acquire(done + slot) < n_active * use) __builtin_amdgcn_s_sleep(1);
@@ -500,7 +491,7 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
                     Quint e;
 #pragma unroll
                     for (int i = 0; i < 5; ++i)
-                        e.x[i] = fetch_edge(d, cur.f0 + static_cast<int64_t>((4 * Q + i) * g.a + k));
+                        e.x[i] = fetch_edge(ectx, ecur.f0 + static_cast<int64_t>((4 * Q + i) * g.a + k));
                     store_task(img, j, e);
                 }
             }
@@ -541,15 +532,29 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
 #pragma unroll
                 for (int i = 0; i < kWrapTaps; ++i) asm volatile("" : "+v"(wx[i]));
                 asm volatile("" : "+v"(word));
-                if (wrapper) wrap_out(wx, take_of(cur, d, word));
+                if (wrapper) wrap_out(wx, wsel < 32 ? (word >> wsel) & 1u : 0u);
             } else if (have && wrapper) {
                 v2f we[kWrapTaps];
                 uint32_t w2;
-                load_wrap_edge(cur, d, we, w2);
-                wrap_out(we, take_of(cur, d, w2));
+                load_wrap_edge(ecur, ectx, we, w2);
+                wrap_out(we, take_of(ecur, ectx, w2));
+            }
+            if (more && wrapper && cu.c.coeffs != cur_coeffs) {   // the next item's taps of row 1023 (rare: compiler-visible loads)
+                asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+                cur_coeffs = cu.c.coeffs;
+                gconst_f32_ptr wrow = (gconst_f32_ptr)cu.c.coeffs + static_cast<size_t>(1023) * g.taps;
+#pragma unroll
+                for (int i = 0; i < kWrapTaps; ++i) {
+                    const uint32_t t = RSMP_WPART * kWrapTaps + i;
+                    wcoef[i] = t < g.taps ? wrow[t] : 0.f;
+                }
+                // have them land here: a compiler-inserted wait at their use would also wait for every
+                // prefetch issued in between
+#pragma unroll
+                for (int i = 0; i < kWrapTaps; ++i) asm volatile("" : "+v"(wcoef[i]));
             }
             // (producers 0 and 1 issue dummies here: one code path, one load count)
-            if (!(g.debug & 8192)) load_wrap(pre && wrapper, nxt, cu.c, wx, word);
+            if (!(g.debug & 8192)) load_wrap_sel(pre && wrapper, nxt, cu.c);
             if (have) {
                 lds_signal(staged + slot);
                 wt.event(14);
@@ -558,9 +563,12 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
                     ++use;
                 }
             }
-            cur = nxt;
-            d = cu.c;
+            have = more;
             loaded = pre;
+            if (more && !pre) {   // an edge item comes next: keep its description
+                ecur = nxt;
+                ectx = cu.c;
+            }
             if (more) nxt = find_next();
         }
         asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
@@ -576,7 +584,7 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
     const uint32_t grp = lane >> 4, q = (lane >> 2) & 3, pc = lane & 3;
     const uint32_t ob = (T * 16u * g.a) / g.b;        // first frame of the tile's window
     const uint32_t row0 = ob + 4 * grp + q;
-    const uint32_t lane_off = row0 * 32 + ((pc ^ ((row0 >> 2) & 3)) << 3);
+    const uint32_t lane_off = row0 * kRowBytes + ((pc ^ ((row0 >> 2) & 3)) << 3);
     const uint32_t j0 = T * 16u + 4 * grp;             // the lane's four classes (D rows)
     const uint32_t pl = lane & 15;                     // the lane's period (D column)
 
@@ -620,9 +628,9 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
 
         v4f acc0 = v4f{0.f, 0.f, 0.f, 0.f}, acc1 = v4f{0.f, 0.f, 0.f, 0.f};
         auto frag = [&](uint32_t plane_ch, int s) -> bf16x8 {
-            const uint32_t addr = base + plane_ch * (R * 32u);
-            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(lds + addr + s * 1024));
-            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(lds + addr + s * 1024 + 512));
+            const uint32_t addr = base + plane_ch * 32u;   // (everything but `base` is an immediate offset)
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(lds + addr + s * (32 * kRowBytes)));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(lds + addr + s * (32 * kRowBytes) + 16 * kRowBytes));
             const s16x8 t = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
             return __builtin_bit_cast(bf16x8, t);
         };
@@ -718,11 +726,11 @@ PeriodicGeometry split_geometry(uint64_t num, uint64_t den, uint32_t taps, uint3
     // image, the pad after the last image: always finite values, the whole LDS is zeroed at the start).
     const uint32_t rows = ob_max + taps + shift;
     if ((4 * a + 63) / 64 > kTaskSlots * kProducers || rows < a || rows > 2 * a) return g;   // (rows beyond a repeat the next period)
-    const uint32_t pad = (kpad - (taps + shift)) * 32u;
-    uint32_t slots = (kLdsLimit - kImageBase - pad) / (6u * rows * 32u);   // ring of images: slack between producers and consumers
+    const uint32_t pad = (kpad - (taps + shift)) * kRowBytes;
+    uint32_t slots = (kLdsLimit - kImageBase - pad) / (rows * kRowBytes);   // ring of images: slack between producers and consumers
     if (slots > 4) slots = 4;
     if (slots < 2) return g;
-    const uint32_t lds = kImageBase + slots * 6u * rows * 32u + pad;
+    const uint32_t lds = kImageBase + slots * rows * kRowBytes + pad;
     g.a = a;
     g.b = b;
     g.den = b;
