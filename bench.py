@@ -166,7 +166,7 @@ def main() -> None:
                     help="untimed steps run before the --warmup steps until this much time has passed: "
                          "the clock governor needs ~50 ms of load to leave its idle state (0 = off)")
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--kernel", choices=["auto", "generic", "periodic", "periodic-vector"], default="auto")
+    ap.add_argument("--kernel", choices=["auto", "generic", "periodic", "periodic-vector", "periodic-f32"], default="auto")
     args = ap.parse_args()
     if args.path == "fft":
         bench_fft(args)
@@ -189,7 +189,8 @@ def main() -> None:
 
     S, N = args.streams, args.frames
     kernel = {"auto": ra.FirKernel.Auto, "generic": ra.FirKernel.Generic,
-              "periodic": ra.FirKernel.Periodic, "periodic-vector": ra.FirKernel.PeriodicVector}[args.kernel]
+              "periodic": ra.FirKernel.Periodic, "periodic-vector": ra.FirKernel.PeriodicVector,
+              "periodic-f32": ra.FirKernel.PeriodicF32}[args.kernel]
     handles = []
     for _ in range(S):
         h = ra.ResamplerFir.new(CHANNELS, ra.SampleRate.Hz44100, ra.SampleRate.Hz48000,
@@ -257,7 +258,7 @@ def main() -> None:
 
     variant = handles[0].kernel_variant()
     kernel_name = {0: "fir_generic_kernel", 1: "fir_periodic_kernel", 2: "fir_periodic_db_kernel (vector)",
-                   3: "fir_periodic_db_kernel (f32 MFMA)"}.get(variant, "?")
+                   3: "fir_periodic_db_kernel (f32 MFMA)", 4: "fir_split_kernel (bf16x3 MFMA)"}.get(variant, "?")
     if rank == 0:
         total_values = values_in_per_step * world * args.steps
         line = {

@@ -49,11 +49,14 @@ enum { RSMP_ATTENUATION_DB60 = 0, RSMP_ATTENUATION_DB90, RSMP_ATTENUATION_DB120 
 
 /* FIR kernel selection (rsmp_fir_set_kernel).  AUTO picks PERIODIC when the rate pair reduces to
  * a small rational and the launch is long enough, GENERIC otherwise.  PERIODIC runs 2-channel
- * streams on the matrix cores (exact f32 MFMA) where the geometry allows; PERIODIC_VECTOR forces the
- * packed-FMA vector kernel for every channel count.  All produce the same results within the 1e-6
- * RMS gate. */
+ * streams on the matrix cores where the geometry allows: the split-bf16 kernel (every f32 operand as
+ * the exact sum of three bf16 values, six bf16 MFMA products accumulated in f32) for rate pairs with
+ * 16..160 classes such as 44.1 <-> 48 kHz, the exact-f32 MFMA kernel otherwise.  PERIODIC_F32 keeps
+ * every product in f32 (exact-f32 MFMA or vector kernels, never the split one); PERIODIC_VECTOR forces
+ * the packed-FMA vector kernel for every channel count.  All produce the same results within the
+ * 1e-6 RMS gate (measured against the CPU path: about 1.2e-7 RMS each). */
 enum { RSMP_FIR_KERNEL_AUTO = 0, RSMP_FIR_KERNEL_GENERIC = 1, RSMP_FIR_KERNEL_PERIODIC = 2,
-       RSMP_FIR_KERNEL_PERIODIC_VECTOR = 3 };
+       RSMP_FIR_KERNEL_PERIODIC_VECTOR = 3, RSMP_FIR_KERNEL_PERIODIC_F32 = 4 };
 
 const char* rsmp_last_error(void);          /* thread-local message of the last failing call */
 int rsmp_device_count(void);                /* number of HIP devices, 0 when there is none   */

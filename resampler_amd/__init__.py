@@ -80,6 +80,7 @@ class FirKernel(enum.IntEnum):
     Generic = 1
     Periodic = 2
     PeriodicVector = 3   # the packed-FMA vector kernel, no matrix cores
+    PeriodicF32 = 4      # periodic kernels that keep every product in f32 (never the split-bf16 one)
 
 
 RSMP_OK = 0
@@ -306,7 +307,8 @@ class ResamplerFir:
         return ms.value, n.value
 
     def kernel_variant(self) -> int:
-        """0 generic, 1 periodic vector, 2 periodic vector (double-buffered), 3 periodic matrix-core."""
+        """0 generic, 1 periodic vector, 2 periodic vector (double-buffered), 3 periodic f32 matrix-core,
+        4 periodic split-bf16 matrix-core."""
         return int(lib().rsmp_fir_kernel_variant(self._h))
 
     # ResamplerFir::resample (host slices) --------------------------------------------------------

@@ -618,7 +618,7 @@ extern "C" void rsmp_fir_batch_reset(rsmp_fir* const* rs, size_t n) {
 }
 
 extern "C" int rsmp_fir_set_kernel(rsmp_fir* r, int kernel) {
-    if (kernel < RSMP_FIR_KERNEL_AUTO || kernel > RSMP_FIR_KERNEL_PERIODIC_VECTOR)
+    if (kernel < RSMP_FIR_KERNEL_AUTO || kernel > RSMP_FIR_KERNEL_PERIODIC_F32)
         return rsmp::fail(RSMP_ERR_INVALID_ARGUMENT, "rsmp_fir_set_kernel: unknown kernel %d", kernel);
     r->kernel_mode = kernel;
     return RSMP_OK;

@@ -59,9 +59,10 @@ struct PeriodicGeometry {
     }
 };
 
-// allow_matrix = false: vector kernels only (RSMP_FIR_KERNEL_PERIODIC_VECTOR)
+// allow_matrix = false: vector kernels only (RSMP_FIR_KERNEL_PERIODIC_VECTOR); allow_split = false:
+// never the split-bf16 kernel (RSMP_FIR_KERNEL_PERIODIC_F32)
 PeriodicGeometry periodic_geometry(uint64_t num, uint64_t den, uint32_t taps, uint32_t channels,
-                                   bool allow_matrix = true);
+                                   bool allow_matrix = true, bool allow_split = true);
 
 // Per class tile: where its window starts and what its wrap variant (if any) needs.
 struct TileMeta {
@@ -87,7 +88,7 @@ struct ClassTable {
 struct PeriodicState {
     PeriodicGeometry geo;
     bool geo_valid = false;
-    bool geo_matrix = true;      // geo was derived with the matrix-core path allowed
+    int geo_mode = -1;           // kernel mode the geometry was derived for
     ClassTable table;
     bool table_valid = false;
     double table_drift = 0.0;

@@ -1598,12 +1598,13 @@ inline uint32_t class_offset(const PeriodicGeometry& g, uint32_t j) {
 }  // namespace
 
 namespace {
-// RSMP_FIR_MFMA: 0 = vector kernels only, 1 / 2 / 4 = matrix-core kernel with that many 16-period
-// groups per work unit (default 2).  Two interleaved channels only.
+// RSMP_FIR_MFMA: 0 = vector kernels only; 1 / 2 / 4 = exact-f32 matrix-core kernel with that many 16-period
+// groups per work unit; 3 (default) = split-bf16 matrix kernel (fir_split.hip) where its geometry exists,
+// else as 2.  Two interleaved channels only.
 int mfma_knob() {
     static const int knob = [] {
         const char* e = getenv("RSMP_FIR_MFMA");
-        return e ? atoi(e) : 2;
+        return e ? atoi(e) : 3;
     }();
     return knob;
 }
@@ -1745,11 +1746,13 @@ PeriodicGeometry geometry_for(uint64_t num, uint64_t den, uint32_t taps, uint32_
 }  // namespace
 
 PeriodicGeometry periodic_geometry(uint64_t num, uint64_t den, uint32_t taps, uint32_t channels,
-                                   bool allow_matrix) {
+                                   bool allow_matrix, bool allow_split) {
     int knob = mfma_knob();
-    if (allow_matrix && knob == 3) {   // split-bf16 matrix kernel where its geometry exists
-        const PeriodicGeometry g = split_geometry(num, den, taps, channels);
-        if (g.ok) return g;
+    if (knob == 3) {   // split-bf16 matrix kernel where its geometry exists
+        if (allow_matrix && allow_split) {
+            const PeriodicGeometry g = split_geometry(num, den, taps, channels);
+            if (g.ok) return g;
+        }
         knob = 2;
     }
     if (allow_matrix && channels == 2 && (knob == 1 || knob == 2 || knob == 4)) {
@@ -1763,11 +1766,13 @@ bool periodic_supported(const FirMirror& m, size_t channels, size_t taps, int ke
     if (kernel_mode == RSMP_FIR_KERNEL_GENERIC) return false;
     if (!m.periodic_ok()) return false;
     return periodic_geometry(m.num(), m.den(), static_cast<uint32_t>(taps), static_cast<uint32_t>(channels),
-                             kernel_mode != RSMP_FIR_KERNEL_PERIODIC_VECTOR).ok;
+                             kernel_mode != RSMP_FIR_KERNEL_PERIODIC_VECTOR,
+                             kernel_mode != RSMP_FIR_KERNEL_PERIODIC_F32).ok;
 }
 
 bool periodic_worthwhile(const FirMirror& planned, size_t produced_frames, int kernel_mode) {
-    if (kernel_mode == RSMP_FIR_KERNEL_PERIODIC || kernel_mode == RSMP_FIR_KERNEL_PERIODIC_VECTOR)
+    if (kernel_mode == RSMP_FIR_KERNEL_PERIODIC || kernel_mode == RSMP_FIR_KERNEL_PERIODIC_VECTOR ||
+        kernel_mode == RSMP_FIR_KERNEL_PERIODIC_F32)
         return produced_frames > 0;
     // AUTO: a launch shorter than a few workgroup spans leaves most lanes idle.
     (void)planned;
@@ -1872,11 +1877,11 @@ int periodic_bind(PeriodicState& st, int device, const std::vector<float>& table
                   const FirMirror& planned, uint32_t channels, hipStream_t stream) {
     (void)stream;
     const bool allow_matrix = kernel_mode != RSMP_FIR_KERNEL_PERIODIC_VECTOR;
-    if (!st.geo_valid || st.geo_matrix != allow_matrix) {   // (rsmp_fir_set_kernel may switch between them)
+    if (!st.geo_valid || st.geo_mode != kernel_mode) {   // (rsmp_fir_set_kernel may switch between them)
         st.geo = periodic_geometry(planned.num(), planned.den(), static_cast<uint32_t>(planned.taps()),
-                                   channels, allow_matrix);
+                                   channels, allow_matrix, kernel_mode != RSMP_FIR_KERNEL_PERIODIC_F32);
         st.geo_valid = true;
-        st.geo_matrix = allow_matrix;
+        st.geo_mode = kernel_mode;
         st.table_valid = false;
     }
     if (!st.geo.ok) return fail(RSMP_ERR_INVALID_ARGUMENT, "periodic kernel: unsupported geometry");

@@ -162,15 +162,6 @@ struct Item {
     bool valid;
 };
 
-__device__ __forceinline__ Item item_of(const SplitArgs& g, const StreamCtx& d, uint32_t block) {
-    Item it;
-    it.q0 = d.q_first + static_cast<uint64_t>(block) * 16u;
-    it.valid = d.n_out != 0 && it.q0 * g.b < d.abs_out + d.n_out;
-    it.n_block0 = static_cast<int32_t>(static_cast<int64_t>(it.q0 * g.b) - static_cast<int64_t>(d.abs_out));
-    it.k_block0 = static_cast<int32_t>(static_cast<int64_t>(it.q0) - static_cast<int64_t>(d.wrap_k0));
-    return it;
-}
-
 // Walks a workgroup's items in order without per-item divisions or 64-bit multiplications: the item
 // values of a stream advance by constants from one block to the next.
 struct Cursor {
@@ -255,10 +246,6 @@ __device__ __forceinline__ void gload2(v2f& dst, uint32_t byte_off, const void* 
 __device__ __forceinline__ void gload1(uint32_t& dst, uint32_t byte_off, const void* base) {
     asm volatile("global_load_dword %0, %1, %2" : "=v"(dst) : "v"(byte_off), "s"(base) : "memory");
 }
-template <int N>
-__device__ __forceinline__ void wait_loads(v2f& a, v2f& b) {
-    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory");
-}
 
 // Sum over the 16 lanes of a DPP row (every lane gets the total).
 __device__ __forceinline__ float row_sum16(float v) {
@@ -273,9 +260,6 @@ struct Quint {
     v2f x[5];     // (ch0, ch1) of frame k in five consecutive periods
 };
 
-struct Combo {
-    v2f x0, x1;   // (ch0, ch1) of row k in periods 2pp and 2pp + 1
-};
 
 // A producer's view of a work item (wave-uniform).
 struct PItem {
@@ -342,7 +326,6 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
         float wcoef[kWrapTaps];
         const float* cur_coeffs = nullptr;
 
-        StreamCtx d{};
         Cursor cu;
         cu.init(g, item_begin);
         auto find_next = [&]() -> PItem {   // the next valid item; its stream context is cu.c
@@ -532,6 +515,7 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
 #pragma unroll
                 for (int i = 0; i < kWrapTaps; ++i) asm volatile("" : "+v"(wx[i]));
                 asm volatile("" : "+v"(word));
+                wt.event(3);
                 if (wrapper) wrap_out(wx, wsel < 32 ? (word >> wsel) & 1u : 0u);
             } else if (have && wrapper) {
                 v2f we[kWrapTaps];
@@ -556,6 +540,7 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
             // (producers 0 and 1 issue dummies here: one code path, one load count)
             if (!(g.debug & 8192)) load_wrap_sel(pre && wrapper, nxt, cu.c);
             if (have) {
+                wt.event(4);
                 lds_signal(staged + slot);
                 wt.event(14);
                 if (++slot == g.slots) {
@@ -570,6 +555,7 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
                 ectx = cu.c;
             }
             if (more) nxt = find_next();
+            if (have) wt.event(5);
         }
         asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
         wt.flush();

@@ -98,7 +98,8 @@ def test_error_codes_match_reference():
     assert g.resample(np.zeros(0, np.float32), out[:0]) == (0, 0)
 
 
-@pytest.mark.parametrize("kernel", [ra.FirKernel.Generic, ra.FirKernel.Periodic, ra.FirKernel.PeriodicVector])
+@pytest.mark.parametrize("kernel", [ra.FirKernel.Generic, ra.FirKernel.Periodic, ra.FirKernel.PeriodicVector,
+                                    ra.FirKernel.PeriodicF32])
 @pytest.mark.parametrize("ch,in_hz,out_hz,att", [
     (2, 44100, 48000, ra.Attenuation.Db90),
     (2, 48000, 44100, ra.Attenuation.Db90),
@@ -127,6 +128,8 @@ def test_bulk_matches_reference_driver_loop(kernel, ch, in_hz, out_hz, att):
     assert yg2.size == yr2.size and rms(yg2, yr2) <= RMS_TOL
     if kernel == ra.FirKernel.PeriodicVector:
         assert g.kernel_variant() in (1, 2)   # never the matrix-core kernel
+    if kernel == ra.FirKernel.PeriodicF32:
+        assert g.kernel_variant() in (1, 2, 3)   # never the split-bf16 kernel
     if kernel == ra.FirKernel.Generic:
         assert g.kernel_variant() == 0
 
@@ -188,9 +191,11 @@ def test_device_resident_api_and_batch():
     assert (c, p) == (cr, pr) and rms(d_y[:p].cpu().numpy(), orr[:pr]) <= RMS_TOL
 
 
-def test_matrix_core_kernel_ragged_batch_and_edges():
-    """The default kernel for 2-channel rational rate pairs is the matrix-core periodic kernel
-    (DESIGN.md 4.1): check that it is the one that runs, on a ragged batch whose streams are
+@pytest.mark.parametrize("kernel", [ra.FirKernel.Periodic, ra.FirKernel.PeriodicF32])
+def test_matrix_core_kernel_ragged_batch_and_edges(kernel):
+    """The default kernels for 2-channel rational rate pairs are the matrix-core periodic kernels
+    (split-bf16 for 44.1 <-> 48 kHz, exact f32 when asked for or elsewhere): check that
+    the right one runs, on a ragged batch whose streams are
     shorter than a period, one frame past a period block, and long; then a second launch on the
     carried state (wrap bitmap, class-table drift and hist/in junction all in play)."""
     torch = pytest.importorskip("torch")
@@ -198,7 +203,7 @@ def test_matrix_core_kernel_ragged_batch_and_edges():
     frames = [1, 50, 147, 148, 9408, 9409, 20000, 64 * 147 * 3 + 77, 123457]
     gs, rs, xs = [], [], []
     for i, n in enumerate(frames):
-        g, r = make_pair(2, 44100, 48000, kernel=ra.FirKernel.Periodic)
+        g, r = make_pair(2, 44100, 48000, kernel=kernel)
         gs.append(g)
         rs.append(r)
         xs.append(synth.fast_noise(2 * n, seed=300 + i))
@@ -213,12 +218,13 @@ def test_matrix_core_kernel_ragged_batch_and_edges():
             yr, _ = rs[i].resample_all(xs[i], 512)
             assert consumed[i] == xs[i].size and produced[i] == yr.size, (step, i)
             assert rms(d_out[i][: produced[i]].cpu().numpy(), yr) <= RMS_TOL, (step, i)
-    knob = os.environ.get("RSMP_FIR_MFMA", "2")
+    knob = os.environ.get("RSMP_FIR_MFMA", "3")
     mfma_on = knob != "0"
     # periodic matrix-core kernel by default (4 = the split-bf16 one, RSMP_FIR_MFMA=3)
-    assert gs[-1].kernel_variant() == ((4 if knob == "3" else 3) if mfma_on else 1)
+    split = knob == "3" and kernel == ra.FirKernel.Periodic
+    assert gs[-1].kernel_variant() == ((4 if split else 3) if mfma_on else 1)
     # other even rate pairs on the same path: 44.1 -> 96 k (20 class tiles), 16 / 32 / 64 taps above
-    g, r = make_pair(2, 44100, 96000, kernel=ra.FirKernel.Periodic)
+    g, r = make_pair(2, 44100, 96000, kernel=kernel)
     x = synth.sweep(70001, 2, 44100.0)
     yg, _ = g.resample_bulk(x, 512)
     yr, _ = r.resample_all(x, 512)
@@ -284,8 +290,8 @@ def test_fuzz_periodic_kernels_against_oracle():
             assert rms(yg, yr) <= RMS_TOL, (case, part, in_hz, out_hz, ch, lat)
         variants.add(g.kernel_variant())
     assert 1 in variants                      # the vector kernel was exercised ...
-    if os.environ.get("RSMP_FIR_MFMA", "2") != "0":
-        assert 3 in variants                  # ... and so was the matrix-core kernel (unless switched off)
+    if os.environ.get("RSMP_FIR_MFMA", "3") != "0":
+        assert variants & {3, 4}              # ... and so were the matrix-core kernels (unless switched off)
 
 
 def test_linearity_and_shift_properties_at_full_size():
