@@ -252,7 +252,10 @@ def main() -> None:
     tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            tj = json.load(open(tpath))
+            traffic = tj.get("hbm_bytes_per_launch")
+            if tj.get("variant") is not None and tj["variant"] != handles[0].kernel_variant():
+                traffic = None   # the counters were collected for another kernel
         except Exception:
             traffic = None
 
