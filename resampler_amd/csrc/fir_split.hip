@@ -40,7 +40,7 @@ namespace rsmp {
 
 namespace {
 
-constexpr uint32_t kProducers = 6, kConsumers = 10, kWaves = kProducers + kConsumers;
+constexpr uint32_t kProducers = 5, kConsumers = 10, kWaves = 16;   // (wave 7 idles: roles are tied to SIMDs)
 constexpr uint32_t kCtrlBytes = 256;                 // staged[2], done[2]
 constexpr uint32_t kWrapBytes = 4 * 16 * 16;         // up to four slots x 16 periods x (ch0, ch1, take, -)
 constexpr uint32_t kTouchBytes = 3 * 256;              // landing zone of the consumers' L2 prefetch touches
@@ -51,7 +51,7 @@ constexpr uint32_t kRowBytes = 7 * 32;                 // an image row: six 32-b
 constexpr uint32_t kTouchAhead = 3;                    // items between a touch and the producers' loads of the same frames
 constexpr uint32_t kLdsLimit = 160 * 1024;
 constexpr int kWrapTaps = 8;                         // taps of the wrap variant per lane (16 lanes per period)
-constexpr int kTaskSlots = 2;                          // (row block, period pair) combos in flight per producer
+constexpr uint32_t kStagers = kProducers;                          // (row block, period pair) combos in flight per producer
 
 struct SplitArgs {
     uint32_t a, b, taps, n_tiles, rows, slots, lds_bytes, blocks_per_stream, total_items, debug;
@@ -243,6 +243,9 @@ __device__ __forceinline__ const void* uniform_ptr(const void* p) {   // into sc
 __device__ __forceinline__ void gload2(v2f& dst, uint32_t byte_off, const void* base) {
     asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(dst) : "v"(byte_off), "s"(base) : "memory");
 }
+__device__ __forceinline__ void gload4(v4f& dst, uint32_t byte_off, const void* base) {
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(byte_off), "s"(base) : "memory");
+}
 __device__ __forceinline__ void gload1(uint32_t& dst, uint32_t byte_off, const void* base) {
     asm volatile("global_load_dword %0, %1, %2" : "=v"(dst) : "v"(byte_off), "s"(base) : "memory");
 }
@@ -273,7 +276,7 @@ struct PItem {
 // Wave roles.  A workgroup's waves go to the four SIMDs cyclically, so waves w and w + 4 share one:
 // producers 0-3 sit one per SIMD, producers 4 and 5 join SIMDs 2 and 3, which get two consumers
 // each; SIMDs 0 and 1 get three consumers.
-__device__ __forceinline__ bool wave_is_producer(uint32_t w) { return w < 4 || w == 6 || w == 7; }
+__device__ __forceinline__ bool wave_is_producer(uint32_t w) { return w < 4 || w == 6; }
 __device__ __forceinline__ uint32_t producer_index(uint32_t w) { return w < 4 ? w : w - 2; }
 __device__ __forceinline__ uint32_t consumer_index(uint32_t w) { return w < 6 ? w - 4 : w - 6; }
 
@@ -301,30 +304,24 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
     WaveTrace wt;
     wt.init(g, lds, wave);
 
+    if (wave == 7) return;   // (five producers: this wave slot stays empty)
     if (wave_is_producer(wave)) {
-        // ---- producer ------------------------------------------------------------------------------
-        // A lane task = frame k of five consecutive periods 4Q .. 4Q+4 (both channels): it writes the
-        // four periods 4Q..4Q+3 of row k (one 8-byte chunk per plane) and, because row k + a repeats row
-        // k of the NEXT period, the chunk of row k + a from the periods 4Q+1..4Q+4 -- every frame is
-        // split once and written twice.  4a lane tasks per image, 64 per wave task; producer P takes wave
-        // tasks P and P + 6.  The loads of the NEXT item are issued in place as soon as a task of the
-        // current item has been written: HBM latency is hidden across items, not within one.
+        // ---- producers -----------------------------------------------------------------------------
+        // Producers 0-4 stage the image, producer 5 computes the wrap variant of class 0.
+        // A lane task = frames 2K and 2K+1 of five consecutive periods 4Q .. 4Q+4 (both channels, five
+        // 16-byte loads): it writes the four periods 4Q..4Q+3 of rows 2K and 2K+1 (one 8-byte chunk per
+        // plane and row) and, because row k + a repeats row k of the NEXT period, the chunks of rows
+        // 2K+a and 2K+1+a from the periods 4Q+1..4Q+4 -- every frame is split once and written twice.
+        // 4 * ceil(a/2) lane tasks per image, 64 per producer.  The loads of the NEXT item are issued
+        // into the same registers as soon as the current item has been written: HBM latency is hidden
+        // across items.  A global load costs a wave ~100 cycles to issue here, whatever its width: few, wide.
         const uint32_t P = producer_index(wave);
-        // The producers are the critical path (the consumers have slack): let the SIMD's arbiter take their
-        // instructions first whenever they are ready, between the consumers' MFMAs.
-        if (!(g.debug & 32768)) __builtin_amdgcn_s_setprio(3);
-        const uint32_t n_lane_tasks = 4 * g.a;
-        const uint32_t n_tasks = (n_lane_tasks + 63) / 64;   // <= kTaskSlots * kProducers (split_geometry)
-        // wrap variant of class 0: producers 2-5 take 4 periods each; lane = (period, 8 of the taps)
-        const bool wrapper = P >= 2;
+        const uint32_t half_a = (g.a + 1) / 2;
+        const uint32_t n_lane_tasks = 4 * half_a;   // <= 64 * kStagers (split_geometry)
         // (the lane id behind an optimisation barrier per item: otherwise loop-invariant addressing is
         // hoisted out of the item loop, spilled, and each reload from scratch waits for ALL the
         // prefetches in flight -- scratch loads share the in-order vmcnt)
         uint32_t ln = lane;
-        #define RSMP_WP (4 * ((P + 2) & 3) + (ln >> 4))
-        #define RSMP_WPART (ln & 15)
-        float wcoef[kWrapTaps];
-        const float* cur_coeffs = nullptr;
 
         Cursor cu;
         cu.init(g, item_begin);
@@ -344,33 +341,11 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
                 r.it.valid = true;
                 r.f0 = cu.f0;
                 const int64_t hf = cu.c.hist_frames;
-                r.interior = r.f0 > hf && r.f0 + static_cast<int64_t>(17u * g.a) <= hf + static_cast<int64_t>(cu.c.in_frames) &&
-                             cu.c.in_frames < (1u << 28);
+                r.interior = r.f0 > hf && r.f0 + static_cast<int64_t>(17u * g.a + 2u) <= hf + static_cast<int64_t>(cu.c.in_frames) &&
+                             cu.c.in_frames < (1u << 27);
                 r.off0 = static_cast<uint32_t>(r.f0 - hf);
             }
             return r;
-        };
-        uint32_t tq[kTaskSlots], tk[kTaskSlots];   // (one division per slot for the whole launch)
-#pragma unroll
-        for (int j = 0; j < kTaskSlots; ++j) {
-            uint32_t t = (P + j * kProducers) * 64 + lane;
-            if (t >= n_lane_tasks) t = n_lane_tasks - 1;
-            tq[j] = t / g.a;
-            tk[j] = t - tq[j] * g.a;
-        }
-        auto task_of = [&](int j, uint32_t& Q, uint32_t& k) -> bool {
-            Q = tq[j];
-            k = tk[j];
-            return P + j * kProducers < n_tasks;
-        };
-        auto load_task = [&](Quint& v, bool real, const PItem& pi, const void* base, int j) {
-            uint32_t Q, k;
-            (void)task_of(j, Q, k);
-            // interior items have 32-bit byte offsets (see find_next): scalar base + one VGPR offset per load
-            const uint32_t off = real ? (pi.off0 + 4 * Q * g.a + k) * 8u : 0u;
-            const uint32_t step = real ? g.a * 8u : 0u;
-#pragma unroll
-            for (int i = 0; i < 5; ++i) gload2(v.x[i], off + i * step, base);
         };
         auto fetch_edge = [&](const StreamCtx& c, int64_t f) -> v2f {
             const int64_t hf = c.hist_frames, total = hf + static_cast<int64_t>(c.in_frames);
@@ -380,119 +355,84 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
             if (!ok) v = v2f{0.f, 0.f};
             return v;
         };
-        auto store_task = [&](char* img, int j, const Quint& v) {
-            uint32_t Q, k;
-            if (!task_of(j, Q, k)) return;   // wave-uniform
-            typedef uint32_t u2 __attribute__((ext_vector_type(2)));
-            char* prim = img + k * kRowBytes + ((Q ^ ((k >> 2) & 3)) << 3);
-            const uint32_t kd = k + g.a;
-            // rows past the image (two of the 147): their copies go to the touch landing zone instead -- an
-            // unconditional store is cheaper than a predicated one
-            char* dupp = kd < R ? img + kd * kRowBytes + ((Q ^ ((kd >> 2) & 3)) << 3) : lds + kCtrlBytes + kWrapBytes;
-            uint32_t pl[3][5];
-#pragma unroll
-            for (int i = 0; i < 5; ++i) split3(v.x[i].x, pl[0][i], pl[1][i], pl[2][i]);   // channel 0
-#pragma unroll
-            for (int p = 0; p < 3; ++p) {
-                *reinterpret_cast<u2*>(prim + p * 32) = u2{pack_hi16(pl[p][1], pl[p][0]), pack_hi16(pl[p][3], pl[p][2])};
-                *reinterpret_cast<u2*>(dupp + p * 32) = u2{pack_hi16(pl[p][2], pl[p][1]), pack_hi16(pl[p][4], pl[p][3])};
-            }
-#pragma unroll
-            for (int i = 0; i < 5; ++i) split3(v.x[i].y, pl[0][i], pl[1][i], pl[2][i]);   // channel 1
-#pragma unroll
-            for (int p = 0; p < 3; ++p) {
-                *reinterpret_cast<u2*>(prim + (3 + p) * 32) = u2{pack_hi16(pl[p][1], pl[p][0]), pack_hi16(pl[p][3], pl[p][2])};
-                *reinterpret_cast<u2*>(dupp + (3 + p) * 32) = u2{pack_hi16(pl[p][2], pl[p][1]), pack_hi16(pl[p][4], pl[p][3])};
-            }
-        };
-        // 9 loads: this lane's 8 frames of period wp and the bitmap word holding that period's take bit
-        auto load_wrap = [&](bool real, const PItem& pi, const StreamCtx& c, v2f (&wx)[kWrapTaps], uint32_t& word) {
-            const void* base = uniform_ptr(real ? static_cast<const void*>(c.in) : static_cast<const void*>(descs));
-            const uint32_t off = real ? (pi.off0 + RSMP_WP * g.a - 1 + RSMP_WPART * kWrapTaps) * 8u : 0u;
-#pragma unroll
-            for (int i = 0; i < kWrapTaps; ++i) gload2(wx[i], real ? off + i * 8u : 0u, base);
-            const int32_t nw = pi.it.n_block0 + static_cast<int32_t>(RSMP_WP * g.b);
-            const bool in_launch = real && nw >= 0 && nw < static_cast<int32_t>(c.n_out);
-            const uint32_t K = in_launch ? static_cast<uint32_t>(pi.it.k_block0 + static_cast<int32_t>(RSMP_WP)) : 0u;
-            gload1(word, (K >> 5) * 4u, uniform_ptr(real ? static_cast<const void*>(c.wrap_bits) : static_cast<const void*>(descs)));
-        };
-        auto take_of = [&](const PItem& pi, const StreamCtx& c, uint32_t word) -> uint32_t {
-            const int32_t nw = pi.it.n_block0 + static_cast<int32_t>(RSMP_WP * g.b);
-            const bool in_launch = nw >= 0 && nw < static_cast<int32_t>(c.n_out);
-            const uint32_t K = static_cast<uint32_t>(pi.it.k_block0 + static_cast<int32_t>(RSMP_WP));
-            return in_launch ? (word >> (K & 31)) & 1u : 0u;
-        };
-        auto load_wrap_edge = [&](const PItem& pi, const StreamCtx& c, v2f (&wx)[kWrapTaps], uint32_t& word) {
-            const int64_t fw = pi.f0 + static_cast<int64_t>(RSMP_WP * g.a) - 1 + RSMP_WPART * kWrapTaps;
-#pragma unroll
-            for (int i = 0; i < kWrapTaps; ++i) wx[i] = fetch_edge(c, fw + i);
-            const int32_t nw = pi.it.n_block0 + static_cast<int32_t>(RSMP_WP * g.b);
-            const bool in_launch = nw >= 0 && nw < static_cast<int32_t>(c.n_out);
-            const uint32_t K = in_launch ? static_cast<uint32_t>(pi.it.k_block0 + static_cast<int32_t>(RSMP_WP)) : 0u;
-            word = ((gconst_u32_ptr)c.wrap_bits)[K >> 5];
-        };
-        constexpr int kItemLoads = 5 * kTaskSlots + kWrapTaps + 1;   // loads a producer issues per item
-
-        // One static instance of every asm load: the first pass (no current item yet) only issues the
-        // first item's loads, every later pass writes the current item and issues the next one's into
-        // the same registers.  (A separate prologue would make the compiler copy registers that are
-        // still in flight where its values meet the loop's.)
         // State carried from one pass to the next: whether there is a current item, whether its loads are
         // in flight, and -- only for an edge item -- its description (an interior item needs none: its
-        // data sits in the registers, its take bit in `word` / `wsel`).
+        // data sits in the registers).  One static instance of every asm load: the first pass (no
+        // current item yet) only issues the first item's loads; a separate prologue would make the
+        // compiler copy registers that are still in flight where its values meet the loop's.  All the
+        // loads of an item are issued together and nothing else is in flight when they are used: the
+        // wait is a plain vmcnt(0).
         bool have = false, loaded = false;
         PItem nxt = find_next();
         PItem ecur = nxt;
         StreamCtx ectx = cu.c;
-        Quint x[kTaskSlots];
-        v2f wx[kWrapTaps];
-        uint32_t word = 0, wsel = 32;   // wsel: bit of `word` that says whether this lane's period takes the wrap variant; 32 = none
-        // load_wrap + the selector of the take bit
-        auto load_wrap_sel = [&](bool real, const PItem& pi, const StreamCtx& c) {
-            load_wrap(real, pi, c, wx, word);
-            const int32_t nw = pi.it.n_block0 + static_cast<int32_t>(RSMP_WP * g.b);
-            const bool in_launch = real && nw >= 0 && nw < static_cast<int32_t>(c.n_out);
-            wsel = in_launch ? static_cast<uint32_t>(pi.it.k_block0 + static_cast<int32_t>(RSMP_WP)) & 31u : 32u;
-        };
-        for (;;) {
-            const bool more = nxt.item != item_end;
-            if (!have && !more) break;
-            const bool pre = more && nxt.interior && !(g.debug & 8192);   // the next item's loads can be issued ahead
-            asm volatile("" : "+v"(ln));
-            char* img = lds + kImageBase + slot * image_bytes;
-            if (have && !loaded) asm volatile("s_waitcnt vmcnt(0)" : : : "memory");   // dummies: done with the registers
-            if (have) {
-                wt.event(11);
-                while (lds_load_acquire(done + slot) < n_active * use) __builtin_amdgcn_s_sleep(1);
-                wt.event(12);
-            }
-            if (have && !loaded) {
-                // stream edges: frames outside [hist|in] read as zero; one task at a time, plain loads
-                for (int j = 0; j < kTaskSlots; ++j) {
-                    uint32_t Q, k;
-                    if (!task_of(j, Q, k)) continue;
-                    Quint e;
+
+        {
+            // ---- staging (all producers) + one pass of the wrap variant (producers 0-3) ---------------
+            uint32_t t = P * 64 + lane;   // (one division for the whole launch)
+            const bool real_task = P * 64 < n_lane_tasks;
+            if (t >= n_lane_tasks) t = n_lane_tasks - 1;   // surplus lanes repeat the last lane task
+            uint32_t tQ = t / half_a;
+            uint32_t tK = t - tQ * half_a;
+            // real = false: dummy loads of the first bytes of the descriptor array (always mapped), so that
+            // every pass through the loop issues the same loads
+            auto load_task = [&](v4f (&v)[5], bool real, const PItem& pi, const void* base) {
+                const uint32_t off = real ? (pi.off0 + 4 * tQ * g.a + 2 * tK) * 8u : 0u;
+                const uint32_t step = real ? g.a * 8u : 0u;
 #pragma unroll
-                    for (int i = 0; i < 5; ++i)
-                        e.x[i] = fetch_edge(ectx, ecur.f0 + static_cast<int64_t>((4 * Q + i) * g.a + k));
-                    store_task(img, j, e);
+                for (int i = 0; i < 5; ++i) gload4(v[i], off + i * step, base);
+            };
+            // v[i] = (ch0, ch1) of frame 2K and (ch0, ch1) of frame 2K+1 in period 4Q+i
+            auto store_task = [&](char* img, const v4f (&v)[5]) {
+                typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+                const uint32_t k0 = 2 * tK;   // rows k0 and k0 + 1 share a swizzle (k0 is even)
+                char* prim = img + k0 * kRowBytes + ((tQ ^ ((k0 >> 2) & 3)) << 3);
+                // rows past the image: their copies go to the touch landing zone instead -- an unconditional
+                // store is cheaper than a predicated one
+                char* land = lds + kCtrlBytes + kWrapBytes;
+                const uint32_t kd0 = k0 + g.a, kd1 = k0 + 1 + g.a;
+                char* dup0 = kd0 < R ? img + kd0 * kRowBytes + ((tQ ^ ((kd0 >> 2) & 3)) << 3) : land;
+                char* dup1 = kd1 < R ? img + kd1 * kRowBytes + ((tQ ^ ((kd1 >> 2) & 3)) << 3) : land;
+                char* prim1 = k0 + 1 < R ? prim + kRowBytes : land;
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {          // channel
+#pragma unroll
+                    for (int fr = 0; fr < 2; ++fr) {   // frame 2K + fr
+                        uint32_t pl[3][5];
+#pragma unroll
+                        for (int i = 0; i < 5; ++i) split3(v[i][2 * fr + c], pl[0][i], pl[1][i], pl[2][i]);
+                        char* pr = fr ? prim1 : prim;
+                        char* du = fr ? dup1 : dup0;
+#pragma unroll
+                        for (int p = 0; p < 3; ++p) {
+                            *reinterpret_cast<u2*>(pr + (3 * c + p) * 32) =
+                                u2{pack_hi16(pl[p][1], pl[p][0]), pack_hi16(pl[p][3], pl[p][2])};
+                            *reinterpret_cast<u2*>(du + (3 * c + p) * 32) =
+                                u2{pack_hi16(pl[p][2], pl[p][1]), pack_hi16(pl[p][4], pl[p][3])};
+                        }
+                    }
                 }
-            }
-            const void* nbase = uniform_ptr(pre ? static_cast<const void*>(cu.c.in) : static_cast<const void*>(descs));
-            const bool stage = have && loaded && !(g.debug & 1);
+            };
+            // wrap variant of class 0 (row 1023 on the window one frame earlier, resampler_fir.rs:544,
+            // :562-565), f32 from global memory: producer P < 4 takes periods 4P .. 4P+3; lane = (period, 8 taps)
+            const bool wrapper = P < 4;
+            #define wpart (ln & 15)
+            #define wper (4 * P + (ln >> 4))
+            float wcoef[kWrapTaps];
+            const float* cur_coeffs = nullptr;
+            v4f wx[kWrapTaps / 2];
+            uint32_t wword = 0, wsel = 32;   // the bitmap word with this lane's period's take bit, the bit (32 = none)
+            auto load_wrap = [&](const PItem& pi, const StreamCtx& c) {
+                const void* base = uniform_ptr(c.in);
+                const uint32_t off = (pi.off0 + wper * g.a - 1 + wpart * kWrapTaps) * 8u;
 #pragma unroll
-            for (int j = 0; j < kTaskSlots; ++j) {
-                if (have && loaded) {
-                    // x[j]'s loads are older than the kItemLoads - 5 issued since
-                    asm volatile("s_waitcnt vmcnt(%0)" : : "n"(kItemLoads - 5) : "memory");
-#pragma unroll
-                    for (int i = 0; i < 5; ++i) asm volatile("" : "+v"(x[j].x[i]));
-                    if (stage) store_task(img, j, x[j]);
-                }
-                if (!(g.debug & 8192)) load_task(x[j], pre, nxt, nbase, j);
-            }
-            // wrap variant of class 0 for this producer's periods (the two paths share no registers: a value
-            // merged from a plain load and an asm load would make the compiler wait for everything)
+                for (int i = 0; i < kWrapTaps / 2; ++i) gload4(wx[i], off + i * 16u, base);
+                const int32_t nw = pi.it.n_block0 + static_cast<int32_t>(wper * g.b);
+                const bool in_launch = nw >= 0 && nw < static_cast<int32_t>(c.n_out);
+                const uint32_t K = in_launch ? static_cast<uint32_t>(pi.it.k_block0) + wper : 0u;   // (word 0 always exists)
+                gload1(wword, (K >> 5) * 4u, uniform_ptr(c.wrap_bits));
+                wsel = in_launch ? K & 31u : 32u;
+            };
             auto wrap_out = [&](const v2f (&w)[kWrapTaps], uint32_t take) {
                 v2f acc = v2f{0.f, 0.f};
                 if (!(g.debug & 1024)) {
@@ -505,62 +445,102 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
                     acc.y = row_sum16(acc.y);
                 }
                 float* wv = reinterpret_cast<float*>(lds + kCtrlBytes + slot * 256);
-                if ((lane & 15) == 0)
-                    *reinterpret_cast<v4f*>(wv + RSMP_WP * 4) = v4f{acc.x, acc.y, __uint_as_float(take), 0.f};
+                if (wpart == 0) *reinterpret_cast<v4f*>(wv + wper * 4) = v4f{acc.x, acc.y, __uint_as_float(take), 0.f};
             };
-            if (have) wt.event(13);
-            if (have && loaded) {
-                // the wrap loads of this item: older than the 5 * kTaskSlots task loads just issued
-                asm volatile("s_waitcnt vmcnt(%0)" : : "n"(5 * kTaskSlots) : "memory");
-#pragma unroll
-                for (int i = 0; i < kWrapTaps; ++i) asm volatile("" : "+v"(wx[i]));
-                asm volatile("" : "+v"(word));
-                wt.event(3);
-                if (wrapper) wrap_out(wx, wsel < 32 ? (word >> wsel) & 1u : 0u);
-            } else if (have && wrapper) {
-                v2f we[kWrapTaps];
-                uint32_t w2;
-                load_wrap_edge(ecur, ectx, we, w2);
-                wrap_out(we, take_of(ecur, ectx, w2));
-            }
-            if (more && wrapper && cu.c.coeffs != cur_coeffs) {   // the next item's taps of row 1023 (rare: compiler-visible loads)
-                asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
-                cur_coeffs = cu.c.coeffs;
-                gconst_f32_ptr wrow = (gconst_f32_ptr)cu.c.coeffs + static_cast<size_t>(1023) * g.taps;
-#pragma unroll
-                for (int i = 0; i < kWrapTaps; ++i) {
-                    const uint32_t t = RSMP_WPART * kWrapTaps + i;
-                    wcoef[i] = t < g.taps ? wrow[t] : 0.f;
+            v4f x[5];
+            for (;;) {
+                const bool more = nxt.item != item_end;
+                if (!have && !more) break;
+                const bool pre = more && nxt.interior && !(g.debug & 8192);   // the next item's loads can be issued ahead
+                asm volatile("" : "+v"(ln), "+v"(tQ), "+v"(tK));
+                char* img = lds + kImageBase + slot * image_bytes;
+                if (have) {
+                    wt.event(11);
+                    while (lds_load_acquire(done + slot) < n_active * use) __builtin_amdgcn_s_sleep(1);
+                    wt.event(12);
                 }
-                // have them land here: a compiler-inserted wait at their use would also wait for every
-                // prefetch issued in between
+                asm volatile("s_waitcnt vmcnt(0)" : : : "memory");   // the current item's loads (or dummies)
 #pragma unroll
-                for (int i = 0; i < kWrapTaps; ++i) asm volatile("" : "+v"(wcoef[i]));
-            }
-            // (producers 0 and 1 issue dummies here: one code path, one load count)
-            if (!(g.debug & 8192)) load_wrap_sel(pre && wrapper, nxt, cu.c);
-            if (have) {
-                wt.event(4);
-                lds_signal(staged + slot);
-                wt.event(14);
-                if (++slot == g.slots) {
-                    slot = 0;
-                    ++use;
+                for (int i = 0; i < 5; ++i) asm volatile("" : "+v"(x[i]));
+#pragma unroll
+                for (int i = 0; i < kWrapTaps / 2; ++i) asm volatile("" : "+v"(wx[i]));
+                asm volatile("" : "+v"(wword));
+                if (have && real_task && !(g.debug & 1)) {
+                    if (loaded) {
+                        store_task(img, x);
+                    } else {
+                        // stream edges: frames outside [hist|in] read as zero; plain loads
+                        v4f e[5];
+#pragma unroll
+                        for (int i = 0; i < 5; ++i) {
+                            const int64_t f = ecur.f0 + static_cast<int64_t>((4 * tQ + i) * g.a + 2 * tK);
+                            const v2f lo = fetch_edge(ectx, f), hi = fetch_edge(ectx, f + 1);
+                            e[i] = v4f{lo.x, lo.y, hi.x, hi.y};
+                        }
+                        store_task(img, e);
+                    }
                 }
+                if (have && wrapper) {
+                    wt.event(13);
+                    v2f w[kWrapTaps];
+                    if (loaded) {
+#pragma unroll
+                        for (int i = 0; i < kWrapTaps / 2; ++i) {
+                            w[2 * i] = v2f{wx[i].x, wx[i].y};
+                            w[2 * i + 1] = v2f{wx[i].z, wx[i].w};
+                        }
+                        wrap_out(w, wsel < 32 ? (wword >> wsel) & 1u : 0u);
+                    } else {
+                        const int64_t fw = ecur.f0 + static_cast<int64_t>(wper * g.a) - 1 + wpart * kWrapTaps;
+#pragma unroll
+                        for (int i = 0; i < kWrapTaps; ++i) w[i] = fetch_edge(ectx, fw + i);
+                        const int32_t nw = ecur.it.n_block0 + static_cast<int32_t>(wper * g.b);
+                        const bool in_launch = nw >= 0 && nw < static_cast<int32_t>(ectx.n_out);
+                        const uint32_t K = in_launch ? static_cast<uint32_t>(ecur.it.k_block0) + wper : 0u;
+                        const uint32_t word = ((gconst_u32_ptr)ectx.wrap_bits)[K >> 5];
+                        wrap_out(w, in_launch ? (word >> (K & 31)) & 1u : 0u);
+                    }
+                }
+                if (more && wrapper && cu.c.coeffs != cur_coeffs) {   // the next item's taps of row 1023 (rare: compiler-visible loads)
+                    cur_coeffs = cu.c.coeffs;
+                    gconst_f32_ptr wrow = (gconst_f32_ptr)cu.c.coeffs + static_cast<size_t>(1023) * g.taps;
+#pragma unroll
+                    for (int i = 0; i < kWrapTaps; ++i) {
+                        const uint32_t tt = wpart * kWrapTaps + i;
+                        wcoef[i] = tt < g.taps ? wrow[tt] : 0.f;
+                    }
+                    // have them land here: a compiler-inserted wait at their use would also wait for every
+                    // prefetch issued in between
+#pragma unroll
+                    for (int i = 0; i < kWrapTaps; ++i) asm volatile("" : "+v"(wcoef[i]));
+                }
+                if (pre) {
+                    load_task(x, true, nxt, uniform_ptr(cu.c.in));
+                    if (wrapper) load_wrap(nxt, cu.c);
+                }
+                if (have) {
+                    wt.event(4);
+                    lds_signal(staged + slot);
+                    wt.event(14);
+                    if (++slot == g.slots) {
+                        slot = 0;
+                        ++use;
+                    }
+                }
+                have = more;
+                loaded = pre;
+                if (more && !pre) {   // an edge item comes next: keep its description
+                    ecur = nxt;
+                    ectx = cu.c;
+                }
+                if (more) nxt = find_next();
+                if (have) wt.event(5);
             }
-            have = more;
-            loaded = pre;
-            if (more && !pre) {   // an edge item comes next: keep its description
-                ecur = nxt;
-                ectx = cu.c;
-            }
-            if (more) nxt = find_next();
-            if (have) wt.event(5);
+            #undef wpart
+            #undef wper
         }
         asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
         wt.flush();
-        #undef RSMP_WP
-        #undef RSMP_WPART
         return;
     }
 
@@ -711,7 +691,7 @@ PeriodicGeometry split_geometry(uint64_t num, uint64_t den, uint32_t taps, uint3
     // on to ob_max + kpad with zero coefficients -- into the rows that follow in LDS (the next plane, the next
     // image, the pad after the last image: always finite values, the whole LDS is zeroed at the start).
     const uint32_t rows = ob_max + taps + shift;
-    if ((4 * a + 63) / 64 > kTaskSlots * kProducers || rows < a || rows > 2 * a) return g;   // (rows beyond a repeat the next period)
+    if (4 * ((a + 1) / 2) > 64 * kStagers || rows < a || rows > 2 * a) return g;   // (rows beyond a repeat the next period)
     const uint32_t pad = (kpad - (taps + shift)) * kRowBytes;
     uint32_t slots = (kLdsLimit - kImageBase - pad) / (rows * kRowBytes);   // ring of images: slack between producers and consumers
     if (slots > 4) slots = 4;
