@@ -50,6 +50,9 @@ constexpr uint32_t kRowBytes = 7 * 32;                 // an image row: six 32-b
                                                        // transposed read touches per 32 lanes fall on distinct banks
 constexpr uint32_t kTouchAhead = 3;                    // items between a touch and the producers' loads of the same frames
 constexpr uint32_t kLdsLimit = 160 * 1024;
+#ifndef RSMP_POLL_SLEEP
+#define RSMP_POLL_SLEEP 1   // s_sleep units (64 cycles) between two polls of an LDS counter
+#endif
 constexpr int kWrapTaps = 8;                         // taps of the wrap variant per lane (16 lanes per period)
 constexpr uint32_t kStagers = kProducers;                          // (row block, period pair) combos in flight per producer
 
@@ -456,7 +459,7 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
                 char* img = lds + kImageBase + slot * image_bytes;
                 if (have) {
                     wt.event(11);
-                    while (lds_load_acquire(done + slot) < n_active * use) __builtin_amdgcn_s_sleep(1);
+                    while (lds_load_acquire(done + slot) < n_active * use) __builtin_amdgcn_s_sleep(RSMP_POLL_SLEEP);
                     wt.event(12);
                 }
                 asm volatile("s_waitcnt vmcnt(0)" : : : "memory");   // the current item's loads (or dummies)
@@ -589,7 +592,7 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
         }
         wt.event(1);
         if (!(g.debug & 16384))
-            while (lds_load_acquire(staged + slot) < kProducers * (use + 1)) __builtin_amdgcn_s_sleep(1);
+            while (lds_load_acquire(staged + slot) < kProducers * (use + 1)) __builtin_amdgcn_s_sleep(RSMP_POLL_SLEEP);
         wt.event(2);
 
         v4f acc0 = v4f{0.f, 0.f, 0.f, 0.f}, acc1 = v4f{0.f, 0.f, 0.f, 0.f};
