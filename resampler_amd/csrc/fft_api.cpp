@@ -212,6 +212,7 @@ extern "C" rsmp_fft* rsmp_fft_new(size_t channels, int input_rate, int output_ra
     if (check_lds(r.get()) != RSMP_OK) return nullptr;
     const size_t ov_bytes = channels * r->plan->host.fft_out * sizeof(float);
     if (hipMalloc(&r->d_overlap, ov_bytes) != hipSuccess || hipMemset(r->d_overlap, 0, ov_bytes) != hipSuccess ||
+        hipStreamSynchronize(nullptr) != hipSuccess ||   // (the handle's stream is non-blocking: no implicit order)
         hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&r->desc_copied, hipEventDisableTiming) != hipSuccess) {
         rsmp::fail(RSMP_ERR_HIP, "ResamplerFft: cannot allocate stream state");

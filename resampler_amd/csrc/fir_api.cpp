@@ -145,7 +145,8 @@ rsmp_fir* fir_create(size_t channels, uint32_t in_hz, uint32_t out_hz, int laten
     const size_t hist_bytes = rsmp::kInputCapacity * channels * sizeof(float);
     for (int i = 0; i < 2; ++i) {
         if (hipMalloc(&r->d_hist[i], hist_bytes) != hipSuccess ||
-            hipMemset(r->d_hist[i], 0, hist_bytes) != hipSuccess) {
+            hipMemset(r->d_hist[i], 0, hist_bytes) != hipSuccess ||
+            hipStreamSynchronize(nullptr) != hipSuccess) {   // (the handle's stream is non-blocking: no implicit order)
             rsmp::fail(RSMP_ERR_HIP, "ResamplerFir: cannot allocate stream state");
             for (int j = 0; j <= i; ++j) if (r->d_hist[j]) (void)hipFree(r->d_hist[j]);
             return nullptr;
@@ -502,7 +503,10 @@ int launch_jobs(rsmp_fir* leader, std::vector<Job>& jobs, hipStream_t stream) {
         }
         if (!leader->d_work_counter) {
             RSMP_HIP_CHECK(hipMalloc(&leader->d_work_counter, sizeof(unsigned long long)));
-            RSMP_HIP_CHECK(hipMemset(leader->d_work_counter, 0, sizeof(unsigned long long)));
+            // on the launch stream: a null-stream memset is not ordered with a non-blocking stream and
+            // could land after the first kernel had started claiming (host and device counts then
+            // disagree for good and later launches find no work)
+            RSMP_HIP_CHECK(hipMemsetAsync(leader->d_work_counter, 0, sizeof(unsigned long long), stream));
             leader->work_base = 0;
         }
         RSMP_HIP_CHECK(rsmp::launch_fir_periodic(d_descs + first,

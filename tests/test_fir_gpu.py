@@ -46,7 +46,12 @@ def stream_compare(g, r, x, chunks, out_caps=None):
         rc, cr, pr = r.resample(sl, orr[:cap])
         assert rc == 0
         assert (cg, pg) == (cr, pr), (i, (cg, pg), (cr, pr))
-        worst = max(worst, rms(og[:pg], orr[:pr]))
+        e = rms(og[:pg], orr[:pr])
+        if e > RMS_TOL:   # diagnostic for the failure report
+            bad = np.flatnonzero(np.abs(og[:pg].astype(np.float64) - orr[:pr]) > 1e-4)
+            print(f"stream_compare: call {i} consumed {cg} produced {pg} rms {e:.3e} bad values {bad.size}: "
+                  f"{bad[:8]} ... {bad[-4:]} got {og[bad[:4]]} want {orr[bad[:4]]}")
+        worst = max(worst, e)
         off += cg
         i += 1
         if cg == 0 and pg == 0:
