@@ -246,9 +246,6 @@ __device__ __forceinline__ const void* uniform_ptr(const void* p) {   // into sc
     const uint32_t hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v >> 32));
     return reinterpret_cast<const void*>(static_cast<uint64_t>(hi) << 32 | lo);
 }
-__device__ __forceinline__ void gload2(v2f& dst, uint32_t byte_off, const void* base) {
-    asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(dst) : "v"(byte_off), "s"(base) : "memory");
-}
 __device__ __forceinline__ void gload4(v4f& dst, uint32_t byte_off, const void* base) {
     asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(byte_off), "s"(base) : "memory");
 }
@@ -265,9 +262,6 @@ __device__ __forceinline__ float row_sum16(float v) {
     return v;
 }
 
-struct Quint {
-    v2f x[5];     // (ch0, ch1) of frame k in five consecutive periods
-};
 
 
 // A producer's view of a work item (wave-uniform).
