@@ -43,7 +43,7 @@ namespace rsmp {
 
 namespace {
 
-constexpr uint32_t kProducers = 5, kConsumers = 10, kWaves = 16;   // (wave 7 idles: roles are tied to SIMDs)
+constexpr uint32_t kProducers = 6, kConsumers = 10, kWaves = 16;   // five stagers + one wrap-only producer
 constexpr uint32_t kCtrlBytes = 256;                 // staged[2], done[2]
 constexpr uint32_t kWrapBytes = 4 * 16 * 16;         // up to four slots x 16 periods x (ch0, ch1, take, -)
 constexpr uint32_t kTouchBytes = 3 * 256;              // landing zone of the consumers' L2 prefetch touches
@@ -57,7 +57,7 @@ constexpr uint32_t kLdsLimit = 160 * 1024;
 #define RSMP_POLL_SLEEP 1   // s_sleep units (64 cycles) between two polls of an LDS counter
 #endif
 constexpr int kWrapTaps = 8;                         // taps of the wrap variant per lane (16 lanes per period)
-constexpr uint32_t kStagers = kProducers;                          // (row block, period pair) combos in flight per producer
+constexpr uint32_t kStagers = 5;                          // (row block, period pair) combos in flight per producer
 
 struct SplitArgs {
     uint32_t a, b, taps, n_tiles, rows, slots, lds_bytes, blocks_per_stream, total_items, debug;
@@ -278,8 +278,8 @@ struct PItem {
 // SIMD 3 (11, 15).  Five producers: one beside SIMD 1's consumers (wave 1), two each on SIMDs 2 and 3
 // (waves 2, 6 and 3, 7); wave 0 exits, so SIMD 0's three consumers have their SIMD to themselves
 // (measured 1.5 % faster than a producer there and an empty slot on SIMD 3).
-__device__ __forceinline__ bool wave_is_producer(uint32_t w) { return (w >= 1 && w < 4) || w == 6 || w == 7; }
-__device__ __forceinline__ uint32_t producer_index(uint32_t w) { return w < 4 ? w - 1 : w - 3; }
+__device__ __forceinline__ bool wave_is_producer(uint32_t w) { return w < 4 || w == 6 || w == 7; }
+__device__ __forceinline__ uint32_t producer_index(uint32_t w) { return w == 0 ? 5 : (w < 4 ? w - 1 : w - 3); }
 __device__ __forceinline__ uint32_t consumer_index(uint32_t w) { return w < 6 ? w - 4 : w - 6; }
 
 template <int NK>
@@ -306,7 +306,6 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
     WaveTrace wt;
     wt.init(g, lds, wave);
 
-    if (wave == 0) return;   // (five producers: SIMD 0 keeps its three consumers to itself)
     if (wave_is_producer(wave)) {
         // ---- producers -----------------------------------------------------------------------------
         // Producers 0-4 stage the image, producer 5 computes the wrap variant of class 0.
@@ -416,26 +415,30 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
                 }
             };
             // wrap variant of class 0 (row 1023 on the window one frame earlier, resampler_fir.rs:544,
-            // :562-565), f32 from global memory: producer P < 4 takes periods 4P .. 4P+3; lane = (period, 8 taps)
-            const bool wrapper = P < 4;
+            // :562-565), f32 from global memory, in passes of four periods; lane = (period, 8 taps).  The
+            // wrap-only producer (index 5, the wave beside SIMD 0's three consumers) takes passes 0 and 1,
+            // the two stagers with most slack (indices 1 and 2) passes 2 and 3.
+            const uint32_t n_pass = P == 5 ? 2u : (P == 1 || P == 2 ? 1u : 0u);
+            const uint32_t pass0 = P == 5 ? 0u : P + 1;
+            const bool wrapper = n_pass != 0;
             #define wpart (ln & 15)
-            #define wper (4 * P + (ln >> 4))
             float wcoef[kWrapTaps];
             const float* cur_coeffs = nullptr;
-            v4f wx[kWrapTaps / 2];
-            uint32_t wword = 0, wsel = 32;   // the bitmap word with this lane's period's take bit, the bit (32 = none)
-            auto load_wrap = [&](const PItem& pi, const StreamCtx& c) {
+            v4f wx[2][kWrapTaps / 2];
+            uint32_t wword[2] = {0, 0}, wsel[2] = {32, 32};   // the bitmap word with this lane's period's take bit, the bit (32 = none)
+            auto load_wrap = [&](int ps, const PItem& pi, const StreamCtx& c) {
+                const uint32_t wper = 4 * (pass0 + ps) + (ln >> 4);
                 const void* base = uniform_ptr(c.in);
                 const uint32_t off = (pi.off0 + wper * g.a - 1 + wpart * kWrapTaps) * 8u;
 #pragma unroll
-                for (int i = 0; i < kWrapTaps / 2; ++i) gload4(wx[i], off + i * 16u, base);
+                for (int i = 0; i < kWrapTaps / 2; ++i) gload4(wx[ps][i], off + i * 16u, base);
                 const int32_t nw = pi.it.n_block0 + static_cast<int32_t>(wper * g.b);
                 const bool in_launch = nw >= 0 && nw < static_cast<int32_t>(c.n_out);
                 const uint32_t K = in_launch ? static_cast<uint32_t>(pi.it.k_block0) + wper : 0u;   // (word 0 always exists)
-                gload1(wword, (K >> 5) * 4u, uniform_ptr(c.wrap_bits));
-                wsel = in_launch ? K & 31u : 32u;
+                gload1(wword[ps], (K >> 5) * 4u, uniform_ptr(c.wrap_bits));
+                wsel[ps] = in_launch ? K & 31u : 32u;
             };
-            auto wrap_out = [&](const v2f (&w)[kWrapTaps], uint32_t take) {
+            auto wrap_out = [&](const v2f (&w)[kWrapTaps], uint32_t wper, uint32_t take) {
                 v2f acc = v2f{0.f, 0.f};
                 if (!(g.debug & 1024)) {
 #pragma unroll
@@ -465,8 +468,11 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
 #pragma unroll
                 for (int i = 0; i < 5; ++i) asm volatile("" : "+v"(x[i]));
 #pragma unroll
-                for (int i = 0; i < kWrapTaps / 2; ++i) asm volatile("" : "+v"(wx[i]));
-                asm volatile("" : "+v"(wword));
+                for (int ps = 0; ps < 2; ++ps) {
+#pragma unroll
+                    for (int i = 0; i < kWrapTaps / 2; ++i) asm volatile("" : "+v"(wx[ps][i]));
+                    asm volatile("" : "+v"(wword[ps]));
+                }
                 if (have && real_task && !(g.debug & 1)) {
                     if (loaded) {
                         store_task(img, x);
@@ -484,23 +490,28 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
                 }
                 if (have && wrapper) {
                     wt.event(13);
-                    v2f w[kWrapTaps];
-                    if (loaded) {
 #pragma unroll
-                        for (int i = 0; i < kWrapTaps / 2; ++i) {
-                            w[2 * i] = v2f{wx[i].x, wx[i].y};
-                            w[2 * i + 1] = v2f{wx[i].z, wx[i].w};
+                    for (int ps = 0; ps < 2; ++ps) {
+                        if (static_cast<uint32_t>(ps) >= n_pass) continue;
+                        const uint32_t wper = 4 * (pass0 + ps) + (ln >> 4);
+                        v2f w[kWrapTaps];
+                        if (loaded) {
+#pragma unroll
+                            for (int i = 0; i < kWrapTaps / 2; ++i) {
+                                w[2 * i] = v2f{wx[ps][i].x, wx[ps][i].y};
+                                w[2 * i + 1] = v2f{wx[ps][i].z, wx[ps][i].w};
+                            }
+                            wrap_out(w, wper, wsel[ps] < 32 ? (wword[ps] >> wsel[ps]) & 1u : 0u);
+                        } else {
+                            const int64_t fw = ecur.f0 + static_cast<int64_t>(wper * g.a) - 1 + wpart * kWrapTaps;
+#pragma unroll
+                            for (int i = 0; i < kWrapTaps; ++i) w[i] = fetch_edge(ectx, fw + i);
+                            const int32_t nw = ecur.it.n_block0 + static_cast<int32_t>(wper * g.b);
+                            const bool in_launch = nw >= 0 && nw < static_cast<int32_t>(ectx.n_out);
+                            const uint32_t K = in_launch ? static_cast<uint32_t>(ecur.it.k_block0) + wper : 0u;
+                            const uint32_t word = ((gconst_u32_ptr)ectx.wrap_bits)[K >> 5];
+                            wrap_out(w, wper, in_launch ? (word >> (K & 31)) & 1u : 0u);
                         }
-                        wrap_out(w, wsel < 32 ? (wword >> wsel) & 1u : 0u);
-                    } else {
-                        const int64_t fw = ecur.f0 + static_cast<int64_t>(wper * g.a) - 1 + wpart * kWrapTaps;
-#pragma unroll
-                        for (int i = 0; i < kWrapTaps; ++i) w[i] = fetch_edge(ectx, fw + i);
-                        const int32_t nw = ecur.it.n_block0 + static_cast<int32_t>(wper * g.b);
-                        const bool in_launch = nw >= 0 && nw < static_cast<int32_t>(ectx.n_out);
-                        const uint32_t K = in_launch ? static_cast<uint32_t>(ecur.it.k_block0) + wper : 0u;
-                        const uint32_t word = ((gconst_u32_ptr)ectx.wrap_bits)[K >> 5];
-                        wrap_out(w, in_launch ? (word >> (K & 31)) & 1u : 0u);
                     }
                 }
                 if (more && wrapper && cu.c.coeffs != cur_coeffs) {   // the next item's taps of row 1023 (rare: compiler-visible loads)
@@ -517,8 +528,10 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
                     for (int i = 0; i < kWrapTaps; ++i) asm volatile("" : "+v"(wcoef[i]));
                 }
                 if (pre) {
-                    load_task(x, true, nxt, uniform_ptr(cu.c.in));
-                    if (wrapper) load_wrap(nxt, cu.c);
+                    if (real_task) load_task(x, true, nxt, uniform_ptr(cu.c.in));
+#pragma unroll
+                    for (int ps = 0; ps < 2; ++ps)
+                        if (static_cast<uint32_t>(ps) < n_pass) load_wrap(ps, nxt, cu.c);
                 }
                 if (have) {
                     wt.event(4);
@@ -539,7 +552,6 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
                 if (have) wt.event(5);
             }
             #undef wpart
-            #undef wper
         }
         asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
         wt.flush();
