@@ -651,7 +651,12 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
         const v4f lo = v4f{acc0.x, acc1.x, acc0.y, acc1.y};
         const v4f hi = v4f{acc0.z, acc1.z, acc0.w, acc1.w};
         if (!(g.debug & 16)) {
-            if (j0 + 4 <= g.b && n0 >= 0 && n0 + 4 <= n_limit) {
+            const bool full = j0 + 4 <= g.b && n0 >= 0 && n0 + 4 <= n_limit;
+            if (__builtin_expect(__all(full), 1)) {   // the whole wave inside the launch: straight-line stores
+                typedef v4f __attribute__((address_space(1), aligned(8)))* g_f4a8_ptr;
+                ((g_f4a8_ptr)o)[0] = lo;
+                ((g_f4a8_ptr)o)[1] = hi;
+            } else if (full) {
                 typedef v4f __attribute__((address_space(1), aligned(8)))* g_f4a8_ptr;
                 ((g_f4a8_ptr)o)[0] = lo;
                 ((g_f4a8_ptr)o)[1] = hi;
