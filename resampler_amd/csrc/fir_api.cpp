@@ -494,6 +494,7 @@ int launch_jobs(rsmp_fir* leader, std::vector<Job>& jobs, hipStream_t stream) {
         RSMP_HIP_CHECK(rsmp::launch_fir_generic(d_descs, static_cast<uint32_t>(n_generic),
                                                 max_out_generic, max_ch_generic, stream));
     size_t first = n_generic;
+    bool tail_fused = false;
     for (const Group& g : groups) {
         uint32_t max_blocks = 0;
         for (size_t i : g.members) {
@@ -509,10 +510,13 @@ int launch_jobs(rsmp_fir* leader, std::vector<Job>& jobs, hipStream_t stream) {
             RSMP_HIP_CHECK(hipMemsetAsync(leader->d_work_counter, 0, sizeof(unsigned long long), stream));
             leader->work_base = 0;
         }
+        // a launch made of split-kernel streams only lets that kernel copy the tails as well
+        tail_fused = n_generic == 0 && groups.size() == 1 && g.geo.mfma == 3 && max_blocks != 0 &&
+                     getenv("RSMP_FIR_NO_FUSED_TAIL") == nullptr;
         RSMP_HIP_CHECK(rsmp::launch_fir_periodic(d_descs + first,
                                                  static_cast<uint32_t>(g.members.size()), g.geo,
                                                  max_blocks, leader->d_work_counter,
-                                                 &leader->work_base, stream));
+                                                 &leader->work_base, stream, tail_fused));
         first += g.members.size();
     }
     if (leader->profiling) {
@@ -523,8 +527,9 @@ int launch_jobs(rsmp_fir* leader, std::vector<Job>& jobs, hipStream_t stream) {
         RSMP_HIP_CHECK(rsmp::launch_fir_wrap_fixup(d_descs + n_generic,
                                                    static_cast<uint32_t>(n - n_generic), max_wraps,
                                                    stream));
-    RSMP_HIP_CHECK(rsmp::launch_fir_tail_copy(d_descs, static_cast<uint32_t>(n), max_tail_values,
-                                              stream));
+    if (!tail_fused)
+        RSMP_HIP_CHECK(rsmp::launch_fir_tail_copy(d_descs, static_cast<uint32_t>(n), max_tail_values,
+                                                  stream));
     if (direct) {   // the slot may be rewritten once these kernels have read it
         RSMP_HIP_CHECK(hipEventRecord(leader->plan_copied[slot], stream));
         leader->plan_pending[slot] = true;

@@ -115,7 +115,7 @@ void periodic_fill_wrap_bits(const std::vector<uint32_t>& wraps, uint64_t abs_ou
 hipError_t launch_fir_periodic(const FirStreamDesc* d_descs, uint32_t n_streams,
                                const PeriodicGeometry& geo, uint32_t max_blocks,
                                unsigned long long* d_work_counter, unsigned long long* work_base,
-                               hipStream_t stream);
+                               hipStream_t stream, bool fuse_tail = false);
 // Recomputes the outputs listed in each stream's `wraps` with row 1023 / previous frame
 // (only for geometries without inline wraps).
 hipError_t launch_fir_wrap_fixup(const FirStreamDesc* d_descs, uint32_t n_streams,
@@ -129,8 +129,9 @@ PeriodicGeometry split_geometry(uint64_t num, uint64_t den, uint32_t taps, uint3
 size_t split_table_floats(const PeriodicGeometry& g);
 void split_store_class(std::vector<float>& coef, const PeriodicGeometry& g, uint32_t tile, uint32_t m,
                        uint32_t shift, const std::vector<float>& mixed);
+// fuse_tail: the kernel also copies every stream's still-buffered tail into hist_next (no tail-copy launch)
 hipError_t launch_fir_split(const FirStreamDesc* d_descs, uint32_t n_streams, const PeriodicGeometry& geo,
-                            uint32_t max_blocks, uint32_t cus, hipStream_t stream);
+                            uint32_t max_blocks, uint32_t cus, bool fuse_tail, hipStream_t stream);
 
 // Host build of the class table (exposed for tests).
 struct HostClassTable {

@@ -1921,7 +1921,7 @@ int periodic_bind(PeriodicState& st, int device, const std::vector<float>& table
 hipError_t launch_fir_periodic(const FirStreamDesc* d_descs, uint32_t n_streams,
                                const PeriodicGeometry& geo, uint32_t max_blocks,
                                unsigned long long* d_work_counter, unsigned long long* work_base,
-                               hipStream_t stream) {
+                               hipStream_t stream, bool fuse_tail) {
     if (n_streams == 0 || max_blocks == 0) return hipSuccess;
     const dim3 block(geo.waves * 64);
     GeoArgs args = to_args(geo);
@@ -1944,7 +1944,7 @@ hipError_t launch_fir_periodic(const FirStreamDesc* d_descs, uint32_t n_streams,
         }
         cus = c;
     }
-    if (geo.mfma == 3) return launch_fir_split(d_descs, n_streams, geo, max_blocks, cus, stream);
+    if (geo.mfma == 3) return launch_fir_split(d_descs, n_streams, geo, max_blocks, cus, fuse_tail, stream);
     const uint32_t slots = cus * (geo.lds_bytes > kLdsTwoPerCu ? 1u : 2u);   // workgroups that fit
     const dim3 grid(args.total_items < slots ? args.total_items : slots);
     args.work_counter = d_work_counter;

@@ -61,6 +61,7 @@ constexpr uint32_t kStagers = 5;                          // (row block, period 
 
 struct SplitArgs {
     uint32_t a, b, taps, n_tiles, rows, slots, lds_bytes, blocks_per_stream, total_items, debug;
+    uint32_t n_streams, fuse_tail;   // fuse_tail: also copy every stream's still-buffered tail into hist_next
     unsigned long long* wtrace;   // RSMP_FIR_WTRACE: kWtraceSlots timestamped events per wave
 };
 
@@ -300,6 +301,23 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
     const uint32_t n_active = g.n_tiles < kConsumers ? g.n_tiles : kConsumers;
     const uint32_t item_begin = static_cast<uint32_t>(static_cast<uint64_t>(blockIdx.x) * g.total_items / gridDim.x);
     const uint32_t item_end = static_cast<uint32_t>(static_cast<uint64_t>(blockIdx.x + 1) * g.total_items / gridDim.x);
+    // The frames that stay buffered after the launch move to hist_next (what fir_tail_copy_kernel does in
+    // launches that mix kernels): nobody in this launch reads hist_next, the wave with most slack does it.
+    if (g.fuse_tail && wave == 0) {
+        typedef const uint32_t __attribute__((address_space(4)))* const_u32_ptr;
+        for (uint32_t sidx = blockIdx.x; sidx < g.n_streams; sidx += gridDim.x) {
+            FirStreamDesc d;
+            const_u32_ptr src = (const_u32_ptr)(descs + sidx);
+            uint32_t* dst = reinterpret_cast<uint32_t*>(&d);
+#pragma unroll
+            for (size_t i = 0; i < sizeof(FirStreamDesc) / 4; ++i) dst[i] = src[i];
+            const uint32_t total = d.tail_frames * 2u, first = d.tail_start * 2u, hist_values = d.hist_frames * 2u;
+            for (uint32_t i = lane; i < total; i += 64) {
+                const uint32_t sv = first + i;
+                d.hist_next[i] = sv < hist_values ? d.hist[sv] : d.in[sv - hist_values];
+            }
+        }
+    }
     if (item_begin == item_end) return;
 
     uint32_t slot = 0, use = 0;   // ring position of the current item: image slot, times the slot was used before
@@ -779,12 +797,12 @@ size_t split_table_floats(const PeriodicGeometry& g) {
 }
 
 hipError_t launch_fir_split(const FirStreamDesc* d_descs, uint32_t n_streams, const PeriodicGeometry& geo,
-                            uint32_t max_blocks, uint32_t cus, hipStream_t stream) {
+                            uint32_t max_blocks, uint32_t cus, bool fuse_tail, hipStream_t stream) {
     static const uint32_t debug = [] {
         const char* e = getenv("RSMP_FIR_DEBUG");
         return e ? static_cast<uint32_t>(atoi(e)) : 0u;
     }();
-    SplitArgs args{geo.a, geo.b, geo.taps, geo.n_tiles, geo.row_stride, geo.images, geo.lds_bytes, max_blocks, max_blocks * n_streams, debug, nullptr};
+    SplitArgs args{geo.a, geo.b, geo.taps, geo.n_tiles, geo.row_stride, geo.images, geo.lds_bytes, max_blocks, max_blocks * n_streams, debug, n_streams, fuse_tail ? 1u : 0u, nullptr};
     const void* fns[5] = {reinterpret_cast<const void*>(fir_split_kernel<1>),
                           reinterpret_cast<const void*>(fir_split_kernel<2>),
                           reinterpret_cast<const void*>(fir_split_kernel<3>),
