@@ -492,6 +492,7 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
                     wt.event(12);
                 }
                 asm volatile("s_waitcnt vmcnt(0)" : : : "memory");   // the current item's loads (or dummies)
+                if (have) wt.event(6);
 #pragma unroll
                 for (int i = 0; i < 5; ++i) asm volatile("" : "+v"(x[i]));
 #pragma unroll
