@@ -237,6 +237,34 @@ def test_matrix_core_kernel_ragged_batch_and_edges(kernel):
     assert g.kernel_variant() == (3 if mfma_on else 1)
 
 
+def test_batch_with_two_rate_pairs_and_mixed_kernels():
+    """One batch launch holding streams of both split-kernel rate pairs (44.1 -> 48 k and 48 -> 44.1 k: two
+    kernel groups, so the tails are copied by the separate launch) plus a 44.1 -> 96 k stream (f32 matrix-core
+    kernel) and a mono stream (vector kernel); two launches so that the carried state is exercised too."""
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda:0")
+    spec = [(2, 44100, 48000, 30011), (2, 48000, 44100, 41000), (2, 44100, 48000, 5000),
+            (2, 44100, 96000, 20000), (1, 48000, 44100, 33000), (2, 48000, 44100, 160 * 16 * 3)]
+    gs, rs, xs = [], [], []
+    for i, (ch, a, b, n) in enumerate(spec):
+        g, r = make_pair(ch, a, b, kernel=ra.FirKernel.Periodic)
+        gs.append(g)
+        rs.append(r)
+        xs.append(synth.fast_noise(ch * n, seed=900 + i))
+    batch = ra.FirBatch(gs)
+    for step in range(2):
+        d_in = [torch.from_numpy(x).to(dev) for x in xs]
+        d_out = [torch.zeros(g.bulk_output_bound(x.size, 512), device=dev) for g, x in zip(gs, xs)]
+        batch.bind(d_in, d_out)
+        consumed, produced = batch.resample_bulk_device(512, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        for i in range(len(spec)):
+            chunk = 512 - 512 % spec[i][0]
+            yr, _ = rs[i].resample_all(xs[i], chunk)
+            assert consumed[i] == xs[i].size and produced[i] == yr.size, (step, i)
+            assert rms(d_out[i][: produced[i]].cpu().numpy(), yr) <= RMS_TOL, (step, i)
+
+
 def test_repeated_launches_are_bit_identical():
     """The periodic kernels are full of dynamic scheduling (work queues, claims, producer / consumer
     flags): whatever the interleaving, a launch must produce the same bits.  40 launches of a
