@@ -598,6 +598,20 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
 
     bf16x8 A[NK][3];
     const float* cur_table = nullptr;
+    // The sums of an item whose wave lies wholly inside the launch are stored inside the NEXT item's MFMA
+    // stream (the wave mostly waits for the matrix pipe there); only that wave-uniform straight-line case:
+    // a divergent store path inside the stream would issue MFMAs under a partial EXEC mask.
+    v4f pend_lo = v4f{0.f, 0.f, 0.f, 0.f}, pend_hi = v4f{0.f, 0.f, 0.f, 0.f};
+    g_f32_ptr pend_o = nullptr;
+    bool pend = false;
+    auto flush_pending = [&]() {
+        if (pend) {   // wave-uniform
+            typedef v4f __attribute__((address_space(1), aligned(8)))* g_f4a8_ptr;
+            ((g_f4a8_ptr)pend_o)[0] = pend_lo;
+            ((g_f4a8_ptr)pend_o)[1] = pend_hi;
+            pend = false;
+        }
+    };
     Cursor cu;
     cu.init(g, item_begin);
     uint32_t item;
@@ -660,7 +674,13 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
             acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[s][1], y1, acc1, 0, 0, 0);
             acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[s][0], x1, acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[s][0], y1, acc1, 0, 0, 0);
+            if (s == 0 && !(g.debug & 131072)) {
+                __builtin_amdgcn_sched_barrier(0);
+                flush_pending();
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
+        flush_pending();   // (no MFMA loop ran, or the experiment switch above)
         // class 0 may take the wrap variant the producers left with the image (tile 0, D row 0)
         if (T == 0) {
             const v4f w = *reinterpret_cast<const v4f*>(lds + kCtrlBytes + slot * 256 + pl * 16);
@@ -680,10 +700,11 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
         const v4f hi = v4f{acc0.z, acc1.z, acc0.w, acc1.w};
         if (!(g.debug & 16)) {
             const bool full = j0 + 4 <= g.b && n0 >= 0 && n0 + 4 <= n_limit;
-            if (__builtin_expect(__all(full), 1)) {   // the whole wave inside the launch: straight-line stores
-                typedef v4f __attribute__((address_space(1), aligned(8)))* g_f4a8_ptr;
-                ((g_f4a8_ptr)o)[0] = lo;
-                ((g_f4a8_ptr)o)[1] = hi;
+            if (__builtin_expect(__all(full), 1)) {   // the whole wave inside the launch: stored inside the next item's stream
+                pend_lo = lo;
+                pend_hi = hi;
+                pend_o = o;
+                pend = true;
             } else if (full) {
                 typedef v4f __attribute__((address_space(1), aligned(8)))* g_f4a8_ptr;
                 ((g_f4a8_ptr)o)[0] = lo;
@@ -706,6 +727,7 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
             ++use;
         }
     }
+    flush_pending();
     wt.flush();
 }
 
