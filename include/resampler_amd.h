@@ -85,6 +85,9 @@ void rsmp_fir_reset(rsmp_fir* r);
 size_t rsmp_fir_channels(const rsmp_fir* r);
 size_t rsmp_fir_taps(const rsmp_fir* r);
 size_t rsmp_fir_phases(const rsmp_fir* r);
+/* The reference's private streaming state (resampler_fir.rs:189-192: read_position, available_frames,
+ * position), for tests and checkpoints: it must equal the reference's after the same calls. */
+void rsmp_fir_state(const rsmp_fir* r, size_t* read_position, size_t* available_frames, double* position);
 int rsmp_fir_set_kernel(rsmp_fir* r, int kernel);
 /* Measurement hook: when enabled, the convolution launch(es) of every call made through this
  * handle (the first handle of a batch call) are bracketed by HIP events on the launch stream;
@@ -96,7 +99,8 @@ int rsmp_fir_last_kernel_ms(rsmp_fir* r, float* ms);
 int rsmp_fir_mean_kernel_ms(rsmp_fir* r, float* ms, size_t* launches);
 /* Which kernel the handle's last launch used (diagnostic, for benchmark reports): 0 generic
  * (any ratio), 1 periodic vector kernel, 2 periodic vector kernel with double-buffered
- * workgroups, 3 periodic matrix-core kernel; negative: invalid handle. */
+ * workgroups, 3 periodic exact-f32 matrix-core kernel, 4 periodic split-bf16 matrix-core kernel;
+ * negative: invalid handle. */
 int rsmp_fir_kernel_variant(const rsmp_fir* r);
 
 /* ResamplerFir::resample (resampler_fir.rs:509-621): one call, host buffers, synchronous. */
@@ -131,6 +135,37 @@ int rsmp_fir_batch_resample_bulk_device(rsmp_fir* const* rs, size_t n, const flo
 
 /* reset() for every stream of a batch. */
 void rsmp_fir_batch_reset(rsmp_fir* const* rs, size_t n);
+
+/* ---- lock-step batch: a fixed set of streams, ONE resample() call per stream and step ------------
+ * BASELINE config 4 (1024 mixed-rate streams, one 512-frame chunk each per step).  Per stream a step
+ * is exactly ResamplerFir::resample (resampler_fir.rs:509-621) on d_in[i] + in_offset_frames*channels_i
+ * (in_frames frames) into d_out[i] (or, with `append`, behind what the earlier steps wrote there): same
+ * frames accepted, same output, same frames kept.  Unlike the calls above the reference's state
+ * (read_position / available_frames / position, :189-192) lives in HBM and the control flow runs inside
+ * the kernel, one lane per stream: a step is a single launch with constant arguments and no per-stream
+ * host work, whatever states the streams are in.  Consequently the (consumed, produced) counts of a step
+ * are device data: rsmp_fir_lockstep_counts waits for the last step and copies them out.
+ * While a batch exists its streams must not be used through other entry points; rsmp_fir_lockstep_sync
+ * (and _free) write the device state back into the handles.  out_caps[i] must be at least
+ * rsmp_fir_buffer_size_output (the reference's documented sizing).  Steps of one batch are ordered. */
+typedef struct rsmp_fir_lockstep rsmp_fir_lockstep;
+rsmp_fir_lockstep* rsmp_fir_lockstep_new(rsmp_fir* const* rs, size_t n, size_t max_step_frames);
+void rsmp_fir_lockstep_free(rsmp_fir_lockstep* ls);
+size_t rsmp_fir_lockstep_size(const rsmp_fir_lockstep* ls);
+size_t rsmp_fir_lockstep_workgroups(const rsmp_fir_lockstep* ls);   /* diagnostic: workgroups per step */
+int rsmp_fir_lockstep_bind(rsmp_fir_lockstep* ls, const float* const* d_in, float* const* d_out,
+                           const size_t* out_caps);
+/* d_in_frames: optional DEVICE array of frames offered per stream (in the order of `rs`; NULL = in_frames
+ * for every stream; entries above max_step_frames are clamped). */
+int rsmp_fir_lockstep_step(rsmp_fir_lockstep* ls, size_t in_frames, size_t in_offset_frames,
+                           const uint32_t* d_in_frames, int append, void* stream);
+int rsmp_fir_lockstep_counts(rsmp_fir_lockstep* ls, size_t* consumed, size_t* produced);
+/* Sticky per-stream flags: 1 = more position runs in one step than the kernel keeps (outputs of that step
+ * undefined; never observed), 2 = a step saw non-finite samples and was evaluated in the reference's
+ * two-row form, 4 = the f64 position drifted out of the class tables' tolerance (reference form from then on). */
+int rsmp_fir_lockstep_status(rsmp_fir_lockstep* ls, uint32_t* status);
+int rsmp_fir_lockstep_sync(rsmp_fir_lockstep* ls);
+int rsmp_fir_lockstep_reset(rsmp_fir_lockstep* ls);   /* reset() of every stream (resampler_fir.rs:638-642) */
 
 /* ---- host-only: filter design and the (consumed, produced) state machine ----------------------- */
 /* make_sincs_for_kaiser table exactly as ResamplerFir::create_fir_coeffs lays it out

@@ -110,6 +110,7 @@ _SIGNATURES = [
     ("rsmp_fir_channels", C.c_size_t, [C.c_void_p]),
     ("rsmp_fir_taps", C.c_size_t, [C.c_void_p]),
     ("rsmp_fir_phases", C.c_size_t, [C.c_void_p]),
+    ("rsmp_fir_state", None, [C.c_void_p, _szp, _szp, C.POINTER(C.c_double)]),
     ("rsmp_fir_set_kernel", C.c_int, [C.c_void_p, C.c_int]),
     ("rsmp_fir_set_profiling", C.c_int, [C.c_void_p, C.c_int]),
     ("rsmp_fir_last_kernel_ms", C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
@@ -128,6 +129,16 @@ _SIGNATURES = [
      [C.POINTER(C.c_void_p), C.c_size_t, C.POINTER(C.c_void_p), _szp, C.c_size_t,
       C.POINTER(C.c_void_p), _szp, _szp, _szp, C.c_void_p]),
     ("rsmp_fir_batch_reset", None, [C.POINTER(C.c_void_p), C.c_size_t]),
+    ("rsmp_fir_lockstep_new", C.c_void_p, [C.POINTER(C.c_void_p), C.c_size_t, C.c_size_t]),
+    ("rsmp_fir_lockstep_free", None, [C.c_void_p]),
+    ("rsmp_fir_lockstep_size", C.c_size_t, [C.c_void_p]),
+    ("rsmp_fir_lockstep_workgroups", C.c_size_t, [C.c_void_p]),
+    ("rsmp_fir_lockstep_bind", C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _szp]),
+    ("rsmp_fir_lockstep_step", C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p]),
+    ("rsmp_fir_lockstep_counts", C.c_int, [C.c_void_p, _szp, _szp]),
+    ("rsmp_fir_lockstep_status", C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
+    ("rsmp_fir_lockstep_sync", C.c_int, [C.c_void_p]),
+    ("rsmp_fir_lockstep_reset", C.c_int, [C.c_void_p]),
     ("rsmp_design_fir_coeffs", C.c_int, [C.c_uint32, C.c_uint32, C.c_int, C.c_int, _f32p, C.c_size_t]),
     ("rsmp_design_cutoff_kaiser", C.c_double, [C.c_size_t, C.c_double]),
     ("rsmp_fir_plan_new", C.c_void_p, [C.c_uint32, C.c_uint32, C.c_int]),
@@ -290,6 +301,12 @@ class ResamplerFir:
     def reset(self) -> None:
         lib().rsmp_fir_reset(self._h)
 
+    def state(self):
+        """(read_position, available_frames, position) -- resampler_fir.rs:189-192."""
+        rp, av, pos = C.c_size_t(), C.c_size_t(), C.c_double()
+        lib().rsmp_fir_state(self._h, C.byref(rp), C.byref(av), C.byref(pos))
+        return rp.value, av.value, pos.value
+
     def set_kernel(self, kernel: FirKernel) -> None:
         _check(lib().rsmp_fir_set_kernel(self._h, int(kernel)))
 
@@ -396,6 +413,83 @@ class FirBatch:
         # zero-copy views (valid until the next call): converting 2 x n ctypes words to Python
         # ints costs more than the launch for batches of a thousand streams
         return (np.ctypeslib.as_array(self._consumed), np.ctypeslib.as_array(self._produced))
+
+
+class FirLockstep:
+    """A fixed set of ResamplerFir streams stepped together, one resample() call per stream and step
+    (rsmp_fir_lockstep_*): the streams' state lives in HBM, a step is one kernel launch and no
+    per-stream host work.  BASELINE config 4's shape."""
+
+    def __init__(self, resamplers: Sequence[ResamplerFir], max_step_frames: int = 512):
+        self.resamplers = list(resamplers)
+        n = len(self.resamplers)
+        self._handles = (C.c_void_p * n)(*[r._h for r in self.resamplers])
+        h = lib().rsmp_fir_lockstep_new(self._handles, n, max_step_frames)
+        if not h:
+            raise ResampleError(3, last_error())
+        self._h = C.c_void_p(h)
+        self._in = (C.c_void_p * n)()
+        self._out = (C.c_void_p * n)()
+        self._out_caps = (C.c_size_t * n)()
+        self._consumed = (C.c_size_t * n)()
+        self._produced = (C.c_size_t * n)()
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            lib().rsmp_fir_lockstep_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def workgroups(self) -> int:
+        return lib().rsmp_fir_lockstep_workgroups(self._h)
+
+    def bind(self, d_ins, d_outs) -> None:
+        self._keep = (list(d_ins), list(d_outs))
+        for i, (a, b) in enumerate(zip(d_ins, d_outs)):
+            self._in[i] = _dev_ptr(a)
+            self._out[i] = _dev_ptr(b)
+            self._out_caps[i] = b.numel()
+        _check(lib().rsmp_fir_lockstep_bind(self._h, self._in, self._out, self._out_caps))
+
+    def bind_caps(self, d_ins, d_outs, out_caps: Sequence[int]) -> None:
+        """Like bind, with an explicit per-step output capacity (append mode: the tensors are longer)."""
+        self._keep = (list(d_ins), list(d_outs))
+        for i, (a, b, k) in enumerate(zip(d_ins, d_outs, out_caps)):
+            self._in[i] = _dev_ptr(a)
+            self._out[i] = _dev_ptr(b)
+            self._out_caps[i] = k
+        _check(lib().rsmp_fir_lockstep_bind(self._h, self._in, self._out, self._out_caps))
+
+    def step(self, in_frames: int, in_offset_frames: int = 0, append: bool = False,
+             stream: Optional[int] = None, d_in_frames=None) -> None:
+        ptr = None
+        if d_in_frames is not None:
+            assert d_in_frames.is_cuda and str(d_in_frames.dtype) == "torch.int32"
+            ptr = C.c_void_p(d_in_frames.data_ptr())
+        _check(lib().rsmp_fir_lockstep_step(self._h, in_frames, in_offset_frames, ptr, 1 if append else 0,
+                                            C.c_void_p(stream or 0)))
+
+    def counts(self):
+        """(consumed, produced) of the last step per stream, in f32 values (waits for the step)."""
+        _check(lib().rsmp_fir_lockstep_counts(self._h, self._consumed, self._produced))
+        return (np.ctypeslib.as_array(self._consumed).astype(np.int64),
+                np.ctypeslib.as_array(self._produced).astype(np.int64))
+
+    def status(self) -> np.ndarray:
+        st = (C.c_uint32 * len(self.resamplers))()
+        _check(lib().rsmp_fir_lockstep_status(self._h, st))
+        return np.ctypeslib.as_array(st).copy()
+
+    def sync(self) -> None:
+        _check(lib().rsmp_fir_lockstep_sync(self._h))
+
+    def reset(self) -> None:
+        _check(lib().rsmp_fir_lockstep_reset(self._h))
 
 
 class ResamplerFft:

@@ -1,0 +1,92 @@
+// fir_lockstep.h -- lock-step batch of ResamplerFir streams with DEVICE-resident state.
+//
+// BASELINE config 4 (a thousand independent streams of mixed rate pairs, each fed one 512-frame
+// chunk per step) is microseconds of GPU work per step: any per-stream host work -- replaying the
+// state machine, assembling descriptors, uploading them -- costs more than the arithmetic.  A lock-step
+// batch therefore keeps everything a step needs in HBM: the streams' reference state
+// (read_position / available_frames / position, resampler_fir.rs:189-192), their buffered frames, their
+// buffer pointers.  One step is ONE kernel launch with constant arguments; the kernel runs the
+// reference's control flow itself (fir_mirror_core.h, one lane per stream), stages every stream's
+// [buffered | new] frames in LDS, computes the outputs on the f32 matrix cores with "row = stream"
+// (the 16 columns of a tile are (stream, period) pairs, so short steps of many streams fill the
+// tiles), retires the consumed frames and writes (consumed, produced) per stream to HBM.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <vector>
+
+#include "fir_mirror_core.h"
+#include "fir_periodic.h"
+
+namespace rsmp {
+
+constexpr uint32_t kLsWaves = 10;             // waves per workgroup
+constexpr uint32_t kLsMaxSlots = 16;          // streams per workgroup
+constexpr uint32_t kLsSegCap = 40;            // exact position runs kept per stream and step
+constexpr uint32_t kLsLdsLimit = 160 * 1024;
+
+struct LockstepStream {        // per bound stream, constant between binds (HBM)
+    const float* in;           // a step reads in + in_offset, in_frames frames
+    float* out;
+    float* hist;               // frames buffered between steps (interleaved), updated in place
+    const float* coeffs;       // [1024][taps] polyphase table
+    uint64_t out_cap_frames;   // room of `out` per step, in frames
+};
+
+struct LockstepGroup {         // one workgroup's share: `count` streams of one geometry (HBM)
+    uint32_t first, count;     // streams [first, first + count) of the batch's internal order
+    uint32_t channels, taps;
+    uint32_t periodic;         // 0: every output in the reference's two-row form (any ratio)
+    uint32_t num, den;         // in_hz / out_hz reduced
+    uint32_t a, b;             // super period: a = r * num input frames -> b = r * den outputs
+    uint32_t row_len, n_tiles; // padded window of a 16-class tile; tiles per super period
+    uint32_t guard_frames;     // zeroed frames in front of a stream's span in LDS (>= a)
+    uint32_t span_frames;      // capacity of the span itself (buffered + new frames)
+    uint32_t region_frames;    // guard + span + zeroed tail (>= a + row_len)
+    uint32_t max_out;          // output frames one step can produce
+    uint32_t wrap_words;       // bitmap words per stream: ceil(max_out / 32)
+    uint32_t wrap_cap;         // wrap list entries per stream
+    uint32_t max_cols;         // column table entries
+    const float* class_coef;   // [tile][row_len / 16][64 lanes][4 steps] (A-operand order)
+    const TileMeta* class_meta;
+    uint32_t lds_bytes;        // what this group needs
+    uint32_t slots;            // streams per workgroup the LDS layout is sized for (>= count)
+};
+
+struct LockstepArgs {
+    const LockstepGroup* groups;
+    const LockstepStream* streams;
+    FirMirrorState* states;
+    uint64_t* out_cursor;                 // f32 values appended so far per stream (append mode)
+    uint64_t* counts;                     // [n][2]: (consumed, produced) of the step, in f32 values
+    uint32_t* status;                     // sticky per-stream flags (kLsStatus*)
+    const uint32_t* order;                // internal stream index -> index in the caller's order
+    const uint32_t* in_frames_per_stream; // optional: frames offered per stream, in the caller's order
+    uint64_t in_offset;                   // frames added to every stream's `in`
+    uint32_t in_frames;                   // frames offered to every stream (when the array is null)
+    uint32_t append;                      // 1: a step's output goes to out + out_cursor; 0: to out
+};
+
+constexpr uint32_t kLsStatusRunOverflow = 1;   // more than kLsSegCap position runs in one step
+constexpr uint32_t kLsStatusNonFinite = 2;     // a step saw non-finite samples (reference-form path taken)
+constexpr uint32_t kLsStatusAperiodic = 4;     // the f64 drift left the class tables' tolerance
+
+// Geometry of one (rate pair, taps, channels, step size) combination.
+struct LockstepGeometry {
+    bool periodic = false;
+    uint32_t num = 0, den = 0, r = 0, a = 0, b = 0, taps = 0, row_len = 0, n_tiles = 0;
+    uint32_t guard_frames = 0, span_frames = 0, region_frames = 0, max_out = 0, cols_per_stream = 0;
+    uint32_t slots = 1;        // streams per workgroup
+    uint32_t wrap_words = 0, wrap_cap = 0, max_cols = 0, lds_bytes = 0;
+};
+LockstepGeometry lockstep_geometry(uint64_t num, uint64_t den, double ratio, uint32_t taps,
+                                   uint32_t channels, uint32_t step_frames);
+// The PeriodicGeometry view of it that build_class_table understands (f32 matrix-core layout).
+PeriodicGeometry lockstep_class_geometry(const LockstepGeometry& g);
+
+hipError_t launch_fir_lockstep(const LockstepArgs& args, uint32_t n_groups, uint32_t max_lds_bytes,
+                               hipStream_t stream);
+
+}  // namespace rsmp

@@ -1,0 +1,534 @@
+// fir_lockstep.hip -- one kernel launch = one lock-step step of a batch of ResamplerFir streams
+// (see fir_lockstep.h).  Per stream and step it is exactly one reference resample() call
+// (src/resampler_fir.rs:509-621): same frames accepted, same outputs, same frames retired.
+//
+// A workgroup owns a few streams of one rate pair:
+//   A  wave 0, one lane per stream: the reference's control flow (fir_mirror_core.h) -> n_out, frames
+//      consumed, the outputs that take the row-1023 variant, the exact position runs; meanwhile the
+//      other waves stage [buffered | new] frames of every stream into LDS (zeroed guards around them);
+//   B  the buffered tail is written back in place from LDS; then the outputs: D[16 classes][16 columns]
+//      += A[class][tap] * B[tap][column] with v_mfma_f32_16x16x4_f32 (exact f32, an fmaf chain over the
+//      taps), a column being one (stream, super period) pair -- "row = stream": the window of class j
+//      of period q starts at frame q*a + off(j) of ITS stream, wherever that stream stands;
+//      coefficients are the class tables of fir_periodic.h (the two phase rows pre-mixed with the
+//      class's frac, shifted to the tile's common window, zero padded) in A-operand order;
+//   C  outputs whose f64 position fell just below an integer (previous frame, row 1023, :562-564);
+//   D  streams that cannot use class tables (irrational ratio, drifted position) and streams whose
+//      step saw a non-finite sample are evaluated in the reference's own form (two phase rows, eight
+//      partial sums lerped per lane, src/fir/avx.rs:25-58): a zero padding coefficient times an
+//      infinity would otherwise turn finite reference outputs into NaN.
+#include "fir_lockstep.h"
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <map>
+#include <mutex>
+
+#include "common.h"
+
+namespace rsmp {
+
+namespace {
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef const float __attribute__((address_space(1)))* gconst_f32_ptr;
+typedef const v4f __attribute__((address_space(1)))* gconst_f4_ptr;
+typedef float __attribute__((address_space(1)))* g_f32_ptr;
+typedef const uint32_t __attribute__((address_space(4)))* const_u32_ptr;
+
+template <class T>
+__device__ __forceinline__ T load_uniform(const T* p) {   // wave-uniform POD through the scalar cache
+    static_assert(sizeof(T) % 4 == 0, "dword-sized PODs only");
+    T v;
+    const_u32_ptr src = (const_u32_ptr)p;
+    uint32_t* dst = reinterpret_cast<uint32_t*>(&v);
+#pragma unroll
+    for (size_t i = 0; i < sizeof(T) / 4; ++i) dst[i] = src[i];
+    return v;
+}
+
+constexpr uint32_t kFlagNonFinite = 1, kFlagReference = 2, kFlagRunOverflow = 4;
+
+struct PlanLds {             // one stream's step, in LDS
+    uint32_t n_out;          // output frames of the step
+    uint32_t hist_frames;    // frames buffered before the step
+    uint32_t accepted;       // frames taken from `in`
+    uint32_t consumed;       // frames retired by the step
+    uint32_t tail_frames;    // frames buffered after it
+    uint32_t n_segs, n_wraps;
+    uint32_t flags;
+    uint64_t abs_out, abs_consumed;   // absolute counters before the step
+    float* out;              // where the step's first output frame goes
+    uint64_t pad;
+};
+static_assert(sizeof(PlanLds) == 64, "PlanLds layout");
+
+struct ColLds {              // one column of the matrix product: super period q of a stream
+    int32_t frame0;          // span-relative frame of absolute input frame q * a
+    int32_t n0;              // step-relative output index of (period q, class 0); may be negative
+    uint32_t slot;
+    uint32_t pad;
+};
+
+struct SegLds {
+    uint32_t first, count;
+    double p0, inc;
+};
+
+struct LsLayout {
+    uint32_t cols, segs, wbits, wlist, spans, total;   // byte offsets
+};
+__host__ __device__ inline LsLayout ls_layout(uint32_t slots, uint32_t max_cols, uint32_t wrap_words,
+                                              uint32_t wrap_cap, uint32_t region_frames, uint32_t channels) {
+    LsLayout l;
+    l.cols = kLsMaxSlots * 64 + 16;                               // PlanLds[16], n_cols + 3 spare words
+    l.segs = (l.cols + max_cols * 16 + 7) & ~7u;
+    l.wbits = l.segs + slots * kLsSegCap * 24;
+    l.wlist = l.wbits + slots * wrap_words * 4;
+    l.spans = (l.wlist + slots * wrap_cap * 4 + 15) & ~15u;
+    l.total = l.spans + slots * region_frames * channels * 4;
+    return l;
+}
+
+// mirror_call sink writing into LDS.
+struct LdsSink {
+    SegLds* segs;
+    uint32_t* bits;
+    uint32_t* list;
+    uint32_t n_segs, n_wraps, wrap_cap;
+    bool periodic, overflow;
+    __host__ __device__ bool want_wraps() const { return periodic; }
+    __host__ __device__ void run(uint64_t first, uint64_t count, double p0, double inc) {
+        if (n_segs < kLsSegCap) {
+            segs[n_segs].first = static_cast<uint32_t>(first);
+            segs[n_segs].count = static_cast<uint32_t>(count);
+            segs[n_segs].p0 = p0;
+            segs[n_segs].inc = inc;
+            ++n_segs;
+        } else {
+            overflow = true;
+        }
+    }
+    __host__ __device__ void wrap(uint64_t index) {
+        bits[index >> 5] |= 1u << (index & 31);
+        if (n_wraps < wrap_cap) list[n_wraps] = static_cast<uint32_t>(index);
+        ++n_wraps;
+    }
+};
+
+__device__ __forceinline__ float group_sum8(float v) {
+    v += __shfl_xor(v, 4, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 1, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(kLsWaves * 64) void fir_lockstep_kernel(LockstepArgs args) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const LockstepGroup g = load_uniform(args.groups + blockIdx.x);
+    const uint32_t C = g.channels;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const LsLayout lay = ls_layout(g.slots, g.max_cols, g.wrap_words, g.wrap_cap, g.region_frames, C);
+    PlanLds* plan = reinterpret_cast<PlanLds*>(lds);
+    uint32_t* n_cols_p = reinterpret_cast<uint32_t*>(lds + kLsMaxSlots * 64);
+    ColLds* cols = reinterpret_cast<ColLds*>(lds + lay.cols);
+    SegLds* segs = reinterpret_cast<SegLds*>(lds + lay.segs);
+    uint32_t* wbits = reinterpret_cast<uint32_t*>(lds + lay.wbits);
+    uint32_t* wlist = reinterpret_cast<uint32_t*>(lds + lay.wlist);
+    float* spans = reinterpret_cast<float*>(lds + lay.spans);
+    const uint32_t region_dw = g.region_frames * C;
+
+    // ---- A: plan (wave 0) | stage (waves 1..) ---------------------------------------------------
+    FirMirrorState st;          // wave 0, lanes < count
+    uint32_t plan_flags = 0;
+    if (wave == 0) {
+        if (lane < g.count) {
+            const uint32_t gs = g.first + lane;
+            st = args.states[gs];
+            const LockstepStream ls = args.streams[gs];
+            uint32_t in_fr = args.in_frames_per_stream ? args.in_frames_per_stream[args.order[gs]] : args.in_frames;
+            const uint32_t room = g.span_frames > st.available ? g.span_frames - static_cast<uint32_t>(st.available) : 0u;
+            if (in_fr > room) in_fr = room;   // (cannot happen when out_cap >= buffer_size_output: available < taps)
+            uint32_t* bits = wbits + lane * g.wrap_words;
+            for (uint32_t w = 0; w < g.wrap_words; ++w) bits[w] = 0;
+            LdsSink sink{segs + lane * kLsSegCap, bits, wlist + lane * g.wrap_cap, 0u, 0u, g.wrap_cap,
+                         g.periodic != 0 && st.periodic_ok != 0, false};
+            PlanLds pl;
+            pl.hist_frames = static_cast<uint32_t>(st.available);
+            pl.abs_out = st.abs_out;
+            pl.abs_consumed = st.abs_consumed;
+            const FirCallCounts c = mirror_call(st, in_fr, ls.out_cap_frames, sink);
+            pl.n_out = static_cast<uint32_t>(c.produced);
+            pl.accepted = static_cast<uint32_t>(c.accepted);
+            pl.consumed = static_cast<uint32_t>(c.consumed);
+            pl.tail_frames = static_cast<uint32_t>(st.available);
+            pl.n_segs = sink.n_segs;
+            pl.n_wraps = sink.n_wraps < g.wrap_cap ? sink.n_wraps : g.wrap_cap;
+            pl.flags = (sink.periodic && st.periodic_ok != 0 ? 0u : kFlagReference) |
+                       (sink.overflow ? kFlagRunOverflow : 0u);
+            uint64_t cursor = 0;
+            if (args.append) {
+                cursor = args.out_cursor[gs];
+                args.out_cursor[gs] = cursor + c.produced * C;
+            }
+            pl.out = ls.out + cursor;
+            pl.pad = 0;
+            plan[lane] = pl;
+            plan_flags = pl.flags;
+            args.counts[2 * gs] = c.accepted * C;
+            args.counts[2 * gs + 1] = c.produced * C;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (lane == 0) {   // the column table: every (stream, super period) pair with outputs in this step
+            uint32_t nc = 0;
+            if (g.periodic)
+                for (uint32_t s = 0; s < g.count; ++s) {
+                    const PlanLds& pl = plan[s];
+                    if (pl.n_out == 0 || (pl.flags & kFlagReference)) continue;
+                    const uint64_t q_first = pl.abs_out / g.b;
+                    const uint64_t q_last = (pl.abs_out + pl.n_out - 1) / g.b;
+                    for (uint64_t q = q_first; q <= q_last && nc < g.max_cols; ++q) {
+                        cols[nc].frame0 = static_cast<int32_t>(static_cast<int64_t>(q * g.a) -
+                                                               static_cast<int64_t>(pl.abs_consumed));
+                        cols[nc].n0 = static_cast<int32_t>(static_cast<int64_t>(q * g.b) -
+                                                           static_cast<int64_t>(pl.abs_out));
+                        cols[nc].slot = s;
+                        cols[nc].pad = 0;
+                        ++nc;
+                    }
+                }
+            *n_cols_p = nc;
+        }
+    } else {
+        // Stage [buffered | new] of every stream; everything else of the region is zero (the guards are
+        // read by masked columns and by zero padding coefficients: they must be finite).
+        const uint32_t t0 = threadIdx.x - 64;
+        const uint32_t nt = (kLsWaves - 1) * 64;
+        for (uint32_t s = 0; s < g.count; ++s) {
+            const uint32_t gs = g.first + s;
+            // wave-uniform: the frames this step accepts (the first lines of mirror_call)
+            const uint64_t avail = args.states[gs].available;
+            const uint64_t readp = args.states[gs].read_position;
+            uint32_t in_fr = args.in_frames_per_stream ? args.in_frames_per_stream[args.order[gs]] : args.in_frames;
+            const uint32_t room = g.span_frames > avail ? g.span_frames - static_cast<uint32_t>(avail) : 0u;
+            if (in_fr > room) in_fr = room;
+            const uint64_t wp = readp + avail;
+            const uint64_t rem = kMirrorBufferSize > wp ? kMirrorBufferSize - wp : 0;
+            uint64_t acc = in_fr < rem ? in_fr : rem;
+            if (acc > kMirrorInputCapacity - avail) acc = kMirrorInputCapacity - avail;
+            const uint32_t hist_dw = static_cast<uint32_t>(avail) * C;
+            const uint32_t span_dw = hist_dw + static_cast<uint32_t>(acc) * C;
+            const uint32_t guard_dw = g.guard_frames * C;
+            gconst_f32_ptr hist = (gconst_f32_ptr)args.streams[gs].hist;
+            gconst_f32_ptr in = (gconst_f32_ptr)(args.streams[gs].in + args.in_offset * C);
+            float* region = spans + s * region_dw;
+            for (uint32_t i = t0; i < region_dw; i += nt) {
+                float v = 0.f;
+                if (i >= guard_dw && i < guard_dw + span_dw) {
+                    const uint32_t k = i - guard_dw;
+                    v = k < hist_dw ? hist[k] : in[k - hist_dw];
+                }
+                region[i] = v;
+            }
+        }
+    }
+    __syncthreads();
+    if (wave == 0 && lane < g.count) args.states[g.first + lane] = st;   // every reader of the old state is past the barrier
+
+    // ---- B: retire (tail back to HBM, in place) -------------------------------------------------
+    for (uint32_t s = 0; s < g.count; ++s) {
+        const PlanLds& pl = plan[s];
+        const uint32_t tail_dw = pl.tail_frames * C;
+        const float* src = spans + s * region_dw + (g.guard_frames + pl.consumed) * C;
+        g_f32_ptr dst = (g_f32_ptr)args.streams[g.first + s].hist;
+        for (uint32_t i = threadIdx.x; i < tail_dw; i += kLsWaves * 64) dst[i] = src[i];
+    }
+
+    // ---- B: matrix-core units (16 columns x one 16-class tile) ------------------------------------
+    const uint32_t n_cols = *n_cols_p;
+    if (n_cols) {
+        const uint32_t n_chunks = (n_cols + 15) / 16;
+        const uint32_t n_units = n_chunks * g.n_tiles;
+        const uint32_t nblk = g.row_len / 16;
+        const bool pair_ok = (C & 1u) == 0;   // both channels of a frame with one 8-byte LDS read
+        for (uint32_t u = wave; u < n_units; u += kLsWaves) {
+            const uint32_t chunk = u / g.n_tiles;
+            const uint32_t t = u - chunk * g.n_tiles;
+            const TileMeta tm = load_uniform(g.class_meta + t);
+            const uint32_t col = chunk * 16 + (lane & 15);
+            const bool on = col < n_cols;
+            const ColLds cl = cols[on ? col : chunk * 16];
+            const uint32_t n_out = plan[cl.slot].n_out;
+            float* out = plan[cl.slot].out;
+            const uint32_t* bits = wbits + cl.slot * g.wrap_words;
+            const float* xb = spans + cl.slot * region_dw +
+                              static_cast<int32_t>(static_cast<int32_t>(g.guard_frames) + cl.frame0 +
+                                                   static_cast<int32_t>(tm.base) + static_cast<int32_t>(lane >> 4)) *
+                                  static_cast<int32_t>(C);
+            gconst_f4_ptr gA = (gconst_f4_ptr)(g.class_coef + static_cast<size_t>(t) * nblk * 256) + lane;
+            const uint32_t j = t * 16 + 4 * (lane >> 4);          // first of the lane's four classes
+            const uint32_t jw = (t * 16 + g.den - 1) / g.den * g.den;   // first class of the tile at an integer position
+            for (uint32_t c0 = 0; c0 < C; c0 += 2) {
+                const bool two = c0 + 1 < C;
+                v4f acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+                v4f a_cur = gA[0];
+                v4f a_n1 = gA[(nblk > 1 ? 1u : 0u) * 64];
+                for (uint32_t blk = 0; blk < nblk; ++blk) {
+                    const v4f a_n2 = gA[(blk + 2 < nblk ? blk + 2 : blk) * 64];   // two blocks (8-16 MFMAs) ahead
+                    const float* xp = xb + 16 * blk * C + c0;
+                    const float av[4] = {a_cur.x, a_cur.y, a_cur.z, a_cur.w};
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        float x0, x1 = 0.f;
+                        if (two && pair_ok) {
+                            const v2f x = *reinterpret_cast<const v2f*>(xp + 4 * s * C);
+                            x0 = x.x;
+                            x1 = x.y;
+                        } else {
+                            x0 = xp[4 * s * C];
+                            if (two) x1 = xp[4 * s * C + 1];
+                        }
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], x0, acc0, 0, 0, 0);
+                        if (two) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], x1, acc1, 0, 0, 0);
+                    }
+                    a_cur = a_n1;
+                    a_n1 = a_n2;
+                }
+                // a non-finite sum anywhere in the tile: the stream's step is redone in reference form
+                const float chk = (acc0.x + acc0.y) + (acc0.z + acc0.w) + (acc1.x + acc1.y) + (acc1.z + acc1.w);
+                if (on && !(fabsf(chk) <= FLT_MAX))
+                    (void)__hip_atomic_fetch_or(&plan[cl.slot].flags, kFlagNonFinite, __ATOMIC_RELAXED,
+                                                __HIP_MEMORY_SCOPE_WORKGROUP);
+                const float v0[4] = {acc0.x, acc0.y, acc0.z, acc0.w};
+                const float v1[4] = {acc1.x, acc1.y, acc1.z, acc1.w};
+                bool ok[4];
+                bool all = on;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const uint32_t jr = j + r;
+                    const int32_t n = cl.n0 + static_cast<int32_t>(jr);
+                    bool valid = on && jr < g.b && n >= 0 && n < static_cast<int32_t>(n_out);
+                    if (valid) {
+                        const bool at_integer = g.den >= 16 ? jr == jw : jr % g.den == 0;
+                        if (at_integer && ((bits[static_cast<uint32_t>(n) >> 5] >> (n & 31)) & 1u)) valid = false;   // phase C
+                    }
+                    ok[r] = valid;
+                    all = all && valid;
+                }
+                const int32_t nl = cl.n0 + static_cast<int32_t>(j);
+                if (all && C == 2) {
+                    typedef v4f __attribute__((address_space(1), aligned(8)))* g_f4a8_ptr;
+                    g_f4a8_ptr o = (g_f4a8_ptr)(out + static_cast<size_t>(nl) * 2);
+                    o[0] = v4f{v0[0], v1[0], v0[1], v1[1]};
+                    o[1] = v4f{v0[2], v1[2], v0[3], v1[3]};
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (ok[r]) {
+                            g_f32_ptr o = (g_f32_ptr)(out + static_cast<size_t>(nl + r) * C + c0);
+                            o[0] = v0[r];
+                            if (two) o[1] = v1[r];
+                        }
+                }
+            }
+        }
+    }
+
+    // ---- C: outputs just below an integer position: previous frame, row 1023, frac 0 ----------------
+    {
+        const uint32_t grp = threadIdx.x >> 3, ngrp = kLsWaves * 8, gl = threadIdx.x & 7;
+        for (uint32_t s = 0; s < g.count; ++s) {
+            const PlanLds& pl = plan[s];
+            if (pl.flags & kFlagReference) continue;
+            const uint32_t nw = pl.n_wraps;
+            if (nw == 0) continue;
+            const float4* row = reinterpret_cast<const float4*>(args.streams[g.first + s].coeffs +
+                                                                static_cast<size_t>(1023) * g.taps);
+            const float* span = spans + s * region_dw + g.guard_frames * C;
+            for (uint32_t e = grp; e < (nw + ngrp - 1) / ngrp * ngrp; e += ngrp) {
+                const bool live = e < nw;
+                const uint32_t n = live ? wlist[s * g.wrap_cap + e] : 0;
+                const uint64_t m = pl.abs_out + n;
+                const int64_t v0 = static_cast<int64_t>((m / g.den) * g.num) - 1 -
+                                   static_cast<int64_t>(pl.abs_consumed);
+                for (uint32_t c = 0; c < C; ++c) {
+                    float a = 0.f;
+                    if (live)
+                        for (uint32_t q = gl; q < g.taps / 4; q += 8) {
+                            const float4 k = row[q];
+                            const float* x = span + (v0 + 4 * q) * static_cast<int64_t>(C) + c;
+                            a = fmaf(k.x, x[0], a);
+                            a = fmaf(k.y, x[C], a);
+                            a = fmaf(k.z, x[2 * C], a);
+                            a = fmaf(k.w, x[3 * C], a);
+                        }
+                    a = group_sum8(a);
+                    if (live && gl == 0) pl.out[static_cast<size_t>(n) * C + c] = a;
+                }
+            }
+        }
+    }
+
+    // ---- D: reference form for the streams that need it -------------------------------------------
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // phase B/C stores are acknowledged before D overwrites
+    __syncthreads();
+    {
+        const uint32_t grp = threadIdx.x >> 3, ngrp = kLsWaves * 8, gl = threadIdx.x & 7;
+        for (uint32_t s = 0; s < g.count; ++s) {
+            const PlanLds& pl = plan[s];
+            if (!(pl.flags & (kFlagReference | kFlagNonFinite)) || pl.n_out == 0) continue;
+            const float* coeffs = args.streams[g.first + s].coeffs;
+            const float* span = spans + s * region_dw + g.guard_frames * C;
+            const SegLds* sg = segs + s * kLsSegCap;
+            const uint32_t n_round = (pl.n_out + ngrp - 1) / ngrp * ngrp;
+            for (uint32_t n = grp; n < n_round; n += ngrp) {
+                const bool live = n < pl.n_out;
+                double p = 0.0;
+                if (live) {
+                    uint32_t i = 0;
+                    while (i + 1 < pl.n_segs && n >= sg[i].first + sg[i].count) ++i;
+                    p = fma(static_cast<double>(n - sg[i].first), sg[i].inc, sg[i].p0);
+                }
+                const double fl = floor(p);                                   // resampler_fir.rs:544
+                const double fract = p - fl;                                  // :558
+                double phase_f = fract * 1024.0;                              // :562
+                phase_f = phase_f < 1023.0 ? phase_f : 1023.0;
+                const uint32_t phase1 = static_cast<uint32_t>(phase_f);       // :563
+                const uint32_t phase2 = phase1 + 1 < 1023u ? phase1 + 1 : 1023u;  // :564
+                const float frac = static_cast<float>(phase_f - static_cast<double>(phase1));  // :565
+                const float omf = 1.0f - frac;                                // avx.rs:42
+                const int64_t v0 = static_cast<int64_t>(fl);
+                const float4* row1 = reinterpret_cast<const float4*>(coeffs + static_cast<size_t>(phase1) * g.taps);
+                const float4* row2 = reinterpret_cast<const float4*>(coeffs + static_cast<size_t>(phase2) * g.taps);
+                for (uint32_t c = 0; c < C; ++c) {
+                    float a1 = 0.f, a2 = 0.f;
+                    if (live)
+                        for (uint32_t q = gl; q < g.taps / 4; q += 8) {
+                            const float4 k1 = row1[q];
+                            const float4 k2 = row2[q];
+                            const float* x = span + (v0 + 4 * q) * static_cast<int64_t>(C) + c;
+                            const float x0 = x[0], x1 = x[C], x2 = x[2 * C], x3 = x[3 * C];
+                            a1 = fmaf(k1.x, x0, a1); a2 = fmaf(k2.x, x0, a2);
+                            a1 = fmaf(k1.y, x1, a1); a2 = fmaf(k2.y, x1, a2);
+                            a1 = fmaf(k1.z, x2, a1); a2 = fmaf(k2.z, x2, a2);
+                            a1 = fmaf(k1.w, x3, a1); a2 = fmaf(k2.w, x3, a2);
+                        }
+                    const float part = a1 * omf + a2 * frac;                   // per-lane lerp (avx.rs:41-45)
+                    const float y = group_sum8(part);
+                    if (live && gl == 0) pl.out[static_cast<size_t>(n) * C + c] = y;
+                }
+            }
+        }
+    }
+    if (wave == 0 && lane < g.count) {
+        const uint32_t f = plan[lane].flags;   // (phase B may have added the non-finite flag)
+        const uint32_t status = ((f & kFlagRunOverflow) ? kLsStatusRunOverflow : 0u) |
+                                ((f & kFlagNonFinite) ? kLsStatusNonFinite : 0u) |
+                                (((f & kFlagReference) && g.periodic) ? kLsStatusAperiodic : 0u);
+        if (status) args.status[g.first + lane] |= status;
+        (void)plan_flags;
+    }
+}
+
+}  // namespace
+
+LockstepGeometry lockstep_geometry(uint64_t num, uint64_t den, double ratio, uint32_t taps,
+                                   uint32_t channels, uint32_t step_frames) {
+    LockstepGeometry g;
+    g.taps = taps;
+    g.num = static_cast<uint32_t>(num);
+    g.den = static_cast<uint32_t>(den);
+    // With out_cap >= buffer_size_output a step never leaves more than taps - 1 frames buffered, and
+    // it produces at most (buffered + new - taps + 1) / ratio + 1 frames.
+    g.span_frames = taps + step_frames + 8;
+    g.max_out = static_cast<uint32_t>(std::ceil(static_cast<double>(step_frames + 8) / ratio)) + 2;
+    g.wrap_words = (g.max_out + 31) / 32;
+    auto finish = [&](bool periodic) -> bool {
+        g.periodic = periodic;
+        if (!periodic) {
+            g.r = g.a = 0;
+            g.b = 1;
+            g.row_len = g.n_tiles = 0;
+            g.guard_frames = 0;
+            g.region_frames = g.span_frames;
+            g.cols_per_stream = 1;
+            g.wrap_cap = 1;
+        }
+        const uint32_t want = periodic ? std::max(1u, 16u / g.cols_per_stream) : 4u;
+        for (uint32_t s = std::min(want, kLsMaxSlots); s >= 1; --s) {
+            const uint32_t bytes = ls_layout(s, s * g.cols_per_stream, g.wrap_words, g.wrap_cap,
+                                             g.region_frames, channels).total;
+            if (bytes <= (s > 1 ? 64u * 1024u : kLsLdsLimit)) {
+                g.slots = s;
+                g.max_cols = s * g.cols_per_stream;
+                g.lds_bytes = bytes;
+                return true;
+            }
+        }
+        return false;
+    };
+    if (num != 0 && den != 0 && num <= (1u << 20) && den <= (1u << 20)) {
+        const uint32_t shift = static_cast<uint32_t>((15 * num + den - 1) / den);
+        g.row_len = (taps + shift + 15) / 16 * 16;
+        uint64_t r = (96 + den - 1) / den;
+        if (r == 0) r = 1;
+        const uint64_t a = num * r, b = den * r;
+        if (a <= 8192 && b <= 65536 && g.row_len <= 1024) {
+            g.r = static_cast<uint32_t>(r);
+            g.a = static_cast<uint32_t>(a);
+            g.b = static_cast<uint32_t>(b);
+            g.n_tiles = (g.b + 15) / 16;
+            g.guard_frames = g.a + (g.a & 1u);
+            g.region_frames = g.guard_frames + g.span_frames + g.a + g.row_len;
+            g.region_frames += g.region_frames & 1u;
+            g.cols_per_stream = (g.max_out - 1) / g.b + 2;
+            g.wrap_cap = g.max_out / g.den + 2;
+            if (finish(true)) return g;
+        }
+    }
+    if (!finish(false)) g.lds_bytes = 0;   // caller reports the failure
+    return g;
+}
+
+PeriodicGeometry lockstep_class_geometry(const LockstepGeometry& g) {
+    PeriodicGeometry p;
+    p.ok = g.periodic;
+    p.a = g.a;
+    p.b = g.b;
+    p.den = g.den;
+    p.taps = g.taps;
+    p.row_len = g.row_len;
+    p.n_tiles = g.n_tiles;
+    p.mfma = 1;             // A-operand order of v_mfma_f32_16x16x4_f32
+    p.inline_wraps = false;
+    return p;
+}
+
+hipError_t launch_fir_lockstep(const LockstepArgs& args, uint32_t n_groups, uint32_t max_lds_bytes,
+                               hipStream_t stream) {
+    if (n_groups == 0) return hipSuccess;
+    int device = 0;
+    hipError_t e = hipGetDevice(&device);
+    if (e != hipSuccess) return e;
+    static std::mutex mu;
+    static std::map<int, bool> granted;
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        bool& have = granted[device];
+        if (!have) {
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(fir_lockstep_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, kLsLdsLimit);
+            if (e != hipSuccess) return e;
+            have = true;
+        }
+    }
+    hipLaunchKernelGGL(fir_lockstep_kernel, dim3(n_groups), dim3(kLsWaves * 64), max_lds_bytes, stream, args);
+    return hipGetLastError();
+}
+
+}  // namespace rsmp

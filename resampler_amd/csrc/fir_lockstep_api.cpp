@@ -1,0 +1,298 @@
+// fir_lockstep_api.cpp -- C ABI of the lock-step batch (rsmp_fir_lockstep_*): BASELINE config 4's
+// shape, a fixed set of ResamplerFir instances (src/resampler_fir.rs:179-643) that are each fed one
+// chunk per step.  Creation sorts the streams by rate pair / table, builds the per-workgroup groups
+// and moves the streams' reference state to HBM; a step is one launch of fir_lockstep_kernel with
+// constant arguments -- no per-stream host work, no upload, no host-side state machine.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <tuple>
+#include <vector>
+
+#include "common.h"
+#include "device_util.h"
+#include "fir_handle.h"
+#include "fir_lockstep.h"
+
+using rsmp::DeviceBuffer;
+using rsmp::DeviceGuard;
+using rsmp::FirMirrorState;
+using rsmp::LockstepGroup;
+using rsmp::LockstepStream;
+
+struct rsmp_fir_lockstep {
+    int device = 0;
+    uint32_t step_frames = 0;
+    std::vector<rsmp_fir*> rs;        // caller order
+    std::vector<uint32_t> order;      // internal index -> caller index
+    std::vector<LockstepGroup> groups;
+    std::vector<LockstepStream> streams;   // internal order
+    std::vector<uint32_t> channels;        // internal order
+    DeviceBuffer d_groups, d_streams, d_states, d_cursor, d_counts, d_status, d_order;
+    uint32_t max_lds = 0;
+    bool bound = false;
+    hipStream_t last_stream = nullptr;
+    hipStream_t own_stream = nullptr;
+    std::vector<uint64_t> h_counts;
+    std::vector<FirMirrorState> h_states;
+};
+
+namespace {
+
+int upload_states(rsmp_fir_lockstep* ls) {
+    const size_t n = ls->rs.size();
+    ls->h_states.resize(n);
+    for (size_t k = 0; k < n; ++k) ls->h_states[k] = ls->rs[ls->order[k]]->mirror.state();
+    RSMP_HIP_CHECK(hipMemcpy(ls->d_states.get(), ls->h_states.data(), n * sizeof(FirMirrorState),
+                             hipMemcpyHostToDevice));
+    return RSMP_OK;
+}
+
+}  // namespace
+
+extern "C" rsmp_fir_lockstep* rsmp_fir_lockstep_new(rsmp_fir* const* rs, size_t n, size_t step_frames) {
+    if (!rs || n == 0 || step_frames == 0 || step_frames > rsmp::kMirrorInputCapacity) {
+        rsmp::fail(RSMP_ERR_INVALID_ARGUMENT, "rsmp_fir_lockstep_new: need streams and 1..4096 frames per step");
+        return nullptr;
+    }
+    for (size_t i = 0; i < n; ++i)
+        if (!rs[i] || rs[i]->device != rs[0]->device) {
+            rsmp::fail(RSMP_ERR_INVALID_ARGUMENT, "lock-step streams must share one device");
+            return nullptr;
+        }
+    {
+        std::vector<rsmp_fir*> sorted(rs, rs + n);
+        std::sort(sorted.begin(), sorted.end());
+        if (std::adjacent_find(sorted.begin(), sorted.end()) != sorted.end()) {
+            rsmp::fail(RSMP_ERR_INVALID_ARGUMENT, "lock-step batch lists the same stream twice");
+            return nullptr;
+        }
+    }
+    DeviceGuard guard(rs[0]->device);
+    std::unique_ptr<rsmp_fir_lockstep> ls(new rsmp_fir_lockstep);
+    ls->device = rs[0]->device;
+    ls->step_frames = static_cast<uint32_t>(step_frames);
+    ls->rs.assign(rs, rs + n);
+    // Streams that share a polyphase table, a rate pair and a channel count share a class table and
+    // a geometry: they become neighbours, then workgroups of `slots` streams.
+    typedef std::tuple<const void*, uint32_t, uint32_t, size_t, size_t> Key;
+    auto key_of = [](const rsmp_fir* r) {
+        return Key(static_cast<const void*>(r->table.get()), r->in_hz, r->out_hz, r->channels, r->taps);
+    };
+    ls->order.resize(n);
+    for (size_t i = 0; i < n; ++i) ls->order[i] = static_cast<uint32_t>(i);
+    std::stable_sort(ls->order.begin(), ls->order.end(),
+                     [&](uint32_t x, uint32_t y) { return key_of(rs[x]) < key_of(rs[y]); });
+    ls->streams.resize(n);
+    ls->channels.resize(n);
+    size_t k = 0;
+    while (k < n) {
+        const rsmp_fir* r0 = rs[ls->order[k]];
+        size_t e = k;
+        while (e < n && key_of(rs[ls->order[e]]) == key_of(r0)) ++e;
+        const rsmp::LockstepGeometry geo =
+            rsmp::lockstep_geometry(r0->mirror.num(), r0->mirror.den(), r0->mirror.ratio(),
+                                    static_cast<uint32_t>(r0->taps), static_cast<uint32_t>(r0->channels),
+                                    ls->step_frames);
+        if (geo.lds_bytes == 0) {
+            rsmp::fail(RSMP_ERR_INVALID_ARGUMENT,
+                       "lock-step batch: %zu channels x %zu frames per step do not fit the LDS", r0->channels,
+                       step_frames);
+            return nullptr;
+        }
+        rsmp::ClassTable ct;
+        if (geo.periodic) {
+            if (rsmp::class_table_for(ls->device, *r0->table, rsmp::lockstep_class_geometry(geo), 0.0, &ct) != RSMP_OK)
+                return nullptr;
+        }
+        for (size_t first = k; first < e; first += geo.slots) {
+            LockstepGroup g;
+            std::memset(&g, 0, sizeof g);
+            g.first = static_cast<uint32_t>(first);
+            g.count = static_cast<uint32_t>(std::min<size_t>(geo.slots, e - first));
+            g.channels = static_cast<uint32_t>(r0->channels);
+            g.taps = static_cast<uint32_t>(r0->taps);
+            g.periodic = geo.periodic ? 1u : 0u;
+            g.num = geo.num;
+            g.den = geo.den ? geo.den : 1u;
+            g.a = geo.a;
+            g.b = geo.b ? geo.b : 1u;
+            g.row_len = geo.row_len;
+            g.n_tiles = geo.n_tiles;
+            g.guard_frames = geo.guard_frames;
+            g.span_frames = geo.span_frames;
+            g.region_frames = geo.region_frames;
+            g.max_out = geo.max_out;
+            g.wrap_words = geo.wrap_words;
+            g.wrap_cap = geo.wrap_cap;
+            g.max_cols = geo.max_cols;
+            g.class_coef = ct.d_coef;
+            g.class_meta = ct.d_meta;
+            g.lds_bytes = geo.lds_bytes;
+            g.slots = geo.slots;
+            ls->groups.push_back(g);
+            if (geo.lds_bytes > ls->max_lds) ls->max_lds = geo.lds_bytes;
+        }
+        for (size_t i = k; i < e; ++i) {
+            const rsmp_fir* r = rs[ls->order[i]];
+            if (r->mirror.available() >= r->taps + 8) {
+                rsmp::fail(RSMP_ERR_INVALID_ARGUMENT,
+                           "lock-step batch: stream %u holds %zu buffered frames (an output-capped call left "
+                           "them); drain it first", ls->order[i], r->mirror.available());
+                return nullptr;
+            }
+            ls->channels[i] = static_cast<uint32_t>(r->channels);
+        }
+        k = e;
+    }
+    if (ls->d_groups.reserve(ls->groups.size() * sizeof(LockstepGroup)) != hipSuccess ||
+        ls->d_streams.reserve(n * sizeof(LockstepStream)) != hipSuccess ||
+        ls->d_states.reserve(n * sizeof(FirMirrorState)) != hipSuccess ||
+        ls->d_cursor.reserve(n * sizeof(uint64_t)) != hipSuccess ||
+        ls->d_counts.reserve(2 * n * sizeof(uint64_t)) != hipSuccess ||
+        ls->d_status.reserve(n * sizeof(uint32_t)) != hipSuccess ||
+        ls->d_order.reserve(n * sizeof(uint32_t)) != hipSuccess ||
+        hipStreamCreateWithFlags(&ls->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        rsmp::fail(RSMP_ERR_HIP, "lock-step batch: cannot allocate device state");
+        return nullptr;
+    }
+    // every stream's earlier launches (which wrote its buffered frames) must be complete
+    for (size_t i = 0; i < n; ++i) (void)hipStreamSynchronize(rs[i]->stream);
+    if (hipMemcpy(ls->d_groups.get(), ls->groups.data(), ls->groups.size() * sizeof(LockstepGroup),
+                  hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(ls->d_order.get(), ls->order.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemset(ls->d_cursor.get(), 0, n * sizeof(uint64_t)) != hipSuccess ||
+        hipMemset(ls->d_counts.get(), 0, 2 * n * sizeof(uint64_t)) != hipSuccess ||
+        hipMemset(ls->d_status.get(), 0, n * sizeof(uint32_t)) != hipSuccess ||
+        upload_states(ls.get()) != RSMP_OK) {
+        rsmp::fail(RSMP_ERR_HIP, "lock-step batch: cannot initialise device state");
+        return nullptr;
+    }
+    return ls.release();
+}
+
+extern "C" void rsmp_fir_lockstep_free(rsmp_fir_lockstep* ls) {
+    if (!ls) return;
+    DeviceGuard guard(ls->device);
+    (void)rsmp_fir_lockstep_sync(ls);
+    if (ls->own_stream) (void)hipStreamDestroy(ls->own_stream);
+    delete ls;
+}
+
+extern "C" size_t rsmp_fir_lockstep_size(const rsmp_fir_lockstep* ls) { return ls ? ls->rs.size() : 0; }
+extern "C" size_t rsmp_fir_lockstep_workgroups(const rsmp_fir_lockstep* ls) { return ls ? ls->groups.size() : 0; }
+
+extern "C" int rsmp_fir_lockstep_bind(rsmp_fir_lockstep* ls, const float* const* d_in, float* const* d_out,
+                                      const size_t* out_caps) {
+    if (!ls || !d_in || !d_out || !out_caps)
+        return rsmp::fail(RSMP_ERR_INVALID_ARGUMENT, "rsmp_fir_lockstep_bind: null argument");
+    DeviceGuard guard(ls->device);
+    const size_t n = ls->rs.size();
+    for (size_t k = 0; k < n; ++k) {
+        const uint32_t i = ls->order[k];
+        const rsmp_fir* r = ls->rs[i];
+        if (out_caps[i] % r->channels != 0)
+            return rsmp::fail(RSMP_ERR_INVALID_OUTPUT_BUFFER_SIZE, "Output buffer size is invalid");
+        // the reference's documented sizing (resampler_fir.rs:456-465); with it a step never leaves more
+        // than taps - 1 frames buffered, which is what bounds a stream's LDS span
+        if (out_caps[i] < rsmp_fir_buffer_size_output(r))
+            return rsmp::fail(RSMP_ERR_INVALID_OUTPUT_BUFFER_SIZE,
+                              "lock-step batch: stream %u needs room for buffer_size_output() = %zu values per step",
+                              i, rsmp_fir_buffer_size_output(r));
+        LockstepStream& s = ls->streams[k];
+        s.in = d_in[i];
+        s.out = d_out[i];
+        s.hist = r->d_hist[r->cur];
+        s.coeffs = r->d_coeffs;
+        s.out_cap_frames = out_caps[i] / r->channels;
+    }
+    if (ls->last_stream) RSMP_HIP_CHECK(hipStreamSynchronize(ls->last_stream));
+    RSMP_HIP_CHECK(hipMemcpy(ls->d_streams.get(), ls->streams.data(), n * sizeof(LockstepStream),
+                             hipMemcpyHostToDevice));
+    ls->bound = true;
+    return RSMP_OK;
+}
+
+extern "C" int rsmp_fir_lockstep_step(rsmp_fir_lockstep* ls, size_t in_frames, size_t in_offset_frames,
+                                      const uint32_t* d_in_frames, int append, void* stream) {
+    if (!ls || !ls->bound)
+        return rsmp::fail(RSMP_ERR_INVALID_ARGUMENT, "rsmp_fir_lockstep_step: bind buffers first");
+    if (in_frames > ls->step_frames)
+        return rsmp::fail(RSMP_ERR_INVALID_INPUT_BUFFER_SIZE,
+                          "lock-step batch: %zu frames offered, created for %u per step", in_frames,
+                          ls->step_frames);
+    DeviceGuard guard(ls->device);
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : ls->own_stream;
+    if (ls->last_stream && ls->last_stream != s) {
+        // steps of one batch are ordered: a change of stream waits for the previous step
+        RSMP_HIP_CHECK(hipStreamSynchronize(ls->last_stream));
+    }
+    rsmp::LockstepArgs a;
+    a.groups = ls->d_groups.as<LockstepGroup>();
+    a.streams = ls->d_streams.as<LockstepStream>();
+    a.states = ls->d_states.as<FirMirrorState>();
+    a.out_cursor = ls->d_cursor.as<uint64_t>();
+    a.counts = ls->d_counts.as<uint64_t>();
+    a.status = ls->d_status.as<uint32_t>();
+    a.order = ls->d_order.as<uint32_t>();
+    a.in_frames_per_stream = d_in_frames;
+    a.in_offset = in_offset_frames;
+    a.in_frames = static_cast<uint32_t>(in_frames);
+    a.append = append ? 1u : 0u;
+    RSMP_HIP_CHECK(rsmp::launch_fir_lockstep(a, static_cast<uint32_t>(ls->groups.size()), ls->max_lds, s));
+    ls->last_stream = s;
+    return RSMP_OK;
+}
+
+extern "C" int rsmp_fir_lockstep_counts(rsmp_fir_lockstep* ls, size_t* consumed, size_t* produced) {
+    if (!ls) return rsmp::fail(RSMP_ERR_INVALID_ARGUMENT, "rsmp_fir_lockstep_counts: null batch");
+    DeviceGuard guard(ls->device);
+    const size_t n = ls->rs.size();
+    if (ls->last_stream) RSMP_HIP_CHECK(hipStreamSynchronize(ls->last_stream));
+    ls->h_counts.resize(2 * n);
+    RSMP_HIP_CHECK(hipMemcpy(ls->h_counts.data(), ls->d_counts.get(), 2 * n * sizeof(uint64_t),
+                             hipMemcpyDeviceToHost));
+    for (size_t k = 0; k < n; ++k) {
+        const uint32_t i = ls->order[k];
+        if (consumed) consumed[i] = static_cast<size_t>(ls->h_counts[2 * k]);
+        if (produced) produced[i] = static_cast<size_t>(ls->h_counts[2 * k + 1]);
+    }
+    return RSMP_OK;
+}
+
+extern "C" int rsmp_fir_lockstep_status(rsmp_fir_lockstep* ls, uint32_t* status) {
+    if (!ls || !status) return rsmp::fail(RSMP_ERR_INVALID_ARGUMENT, "rsmp_fir_lockstep_status: null argument");
+    DeviceGuard guard(ls->device);
+    const size_t n = ls->rs.size();
+    if (ls->last_stream) RSMP_HIP_CHECK(hipStreamSynchronize(ls->last_stream));
+    std::vector<uint32_t> h(n);
+    RSMP_HIP_CHECK(hipMemcpy(h.data(), ls->d_status.get(), n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    for (size_t k = 0; k < n; ++k) status[ls->order[k]] = h[k];
+    return RSMP_OK;
+}
+
+extern "C" int rsmp_fir_lockstep_sync(rsmp_fir_lockstep* ls) {
+    if (!ls) return rsmp::fail(RSMP_ERR_INVALID_ARGUMENT, "rsmp_fir_lockstep_sync: null batch");
+    DeviceGuard guard(ls->device);
+    const size_t n = ls->rs.size();
+    if (ls->last_stream) RSMP_HIP_CHECK(hipStreamSynchronize(ls->last_stream));
+    ls->h_states.resize(n);
+    RSMP_HIP_CHECK(hipMemcpy(ls->h_states.data(), ls->d_states.get(), n * sizeof(FirMirrorState),
+                             hipMemcpyDeviceToHost));
+    for (size_t k = 0; k < n; ++k) ls->rs[ls->order[k]]->mirror.set_state(ls->h_states[k]);
+    return RSMP_OK;
+}
+
+extern "C" int rsmp_fir_lockstep_reset(rsmp_fir_lockstep* ls) {
+    if (!ls) return rsmp::fail(RSMP_ERR_INVALID_ARGUMENT, "rsmp_fir_lockstep_reset: null batch");
+    DeviceGuard guard(ls->device);
+    const size_t n = ls->rs.size();
+    if (ls->last_stream) RSMP_HIP_CHECK(hipStreamSynchronize(ls->last_stream));
+    for (rsmp_fir* r : ls->rs) r->mirror.reset();   // resampler_fir.rs:638-642
+    RSMP_HIP_CHECK(hipMemset(ls->d_cursor.get(), 0, n * sizeof(uint64_t)));
+    RSMP_HIP_CHECK(hipMemset(ls->d_status.get(), 0, n * sizeof(uint32_t)));
+    return upload_states(ls);
+}

@@ -103,6 +103,10 @@ bool periodic_worthwhile(const FirMirror& planned, size_t produced_frames, int k
 int periodic_bind(PeriodicState& st, int device, const std::vector<float>& table, int kernel_mode,
                   const FirMirror& planned, uint32_t channels, hipStream_t stream);
 
+// Device class table for a geometry and drift (built on the host once, cached per device).
+int class_table_for(int device, const std::vector<float>& table, const PeriodicGeometry& g, double drift,
+                    ClassTable* out);
+
 // Bitmap of wrapped outputs for one launch: bit K <-> the output with absolute index
 // (abs_out / den + K) * den.  Returns the number of 32-bit words.
 size_t periodic_wrap_words(uint64_t abs_out, uint32_t n_out, uint64_t den);

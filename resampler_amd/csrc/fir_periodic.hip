@@ -1873,29 +1873,17 @@ HostClassTable build_class_table(const std::vector<float>& coeffs, const Periodi
     return out;
 }
 
-int periodic_bind(PeriodicState& st, int device, const std::vector<float>& table, int kernel_mode,
-                  const FirMirror& planned, uint32_t channels, hipStream_t stream) {
-    (void)stream;
-    const bool allow_matrix = kernel_mode != RSMP_FIR_KERNEL_PERIODIC_VECTOR;
-    if (!st.geo_valid || st.geo_mode != kernel_mode) {   // (rsmp_fir_set_kernel may switch between them)
-        st.geo = periodic_geometry(planned.num(), planned.den(), static_cast<uint32_t>(planned.taps()),
-                                   channels, allow_matrix, kernel_mode != RSMP_FIR_KERNEL_PERIODIC_F32);
-        st.geo_valid = true;
-        st.geo_mode = kernel_mode;
-        st.table_valid = false;
-    }
-    if (!st.geo.ok) return fail(RSMP_ERR_INVALID_ARGUMENT, "periodic kernel: unsupported geometry");
-    const double drift = std::round(planned.drift() / kDriftQuantum) * kDriftQuantum;
-    if (st.table_valid && drift == st.table_drift) return RSMP_OK;
+int class_table_for(int device, const std::vector<float>& table, const PeriodicGeometry& g, double drift,
+                    ClassTable* out) {
     ClassTableCache& cache = class_cache();
     std::lock_guard<std::mutex> lock(cache.mu);
     uint64_t bits;
     std::memcpy(&bits, &drift, sizeof bits);
-    const ClassTableKey key{device, table.data(), st.geo.den, st.geo.a, st.geo.b, st.geo.row_len,
-                            st.geo.mfma == 3 ? 3u : (st.geo.mfma ? 1u : 0u), bits};
+    const ClassTableKey key{device, table.data(), g.den, g.a, g.b, g.row_len,
+                            g.mfma == 3 ? 3u : (g.mfma ? 1u : 0u), bits};
     auto it = cache.tables.find(key);
     if (it == cache.tables.end()) {
-        const HostClassTable host = build_class_table(table, st.geo, drift);
+        const HostClassTable host = build_class_table(table, g, drift);
         const size_t coef_bytes = host.coef.size() * sizeof(float);
         const size_t wrap_bytes = host.wrap_coef.size() * sizeof(float);
         const size_t meta_bytes = host.meta.size() * sizeof(TileMeta);
@@ -1912,7 +1900,28 @@ int periodic_bind(PeriodicState& st, int device, const std::vector<float>& table
         ct.d_meta = reinterpret_cast<const TileMeta*>(dptr + coef_bytes + wrap_bytes);
         it = cache.tables.emplace(key, ct).first;
     }
-    st.table = it->second;
+    *out = it->second;
+    return RSMP_OK;
+}
+
+int periodic_bind(PeriodicState& st, int device, const std::vector<float>& table, int kernel_mode,
+                  const FirMirror& planned, uint32_t channels, hipStream_t stream) {
+    (void)stream;
+    const bool allow_matrix = kernel_mode != RSMP_FIR_KERNEL_PERIODIC_VECTOR;
+    if (!st.geo_valid || st.geo_mode != kernel_mode) {   // (rsmp_fir_set_kernel may switch between them)
+        st.geo = periodic_geometry(planned.num(), planned.den(), static_cast<uint32_t>(planned.taps()),
+                                   channels, allow_matrix, kernel_mode != RSMP_FIR_KERNEL_PERIODIC_F32);
+        st.geo_valid = true;
+        st.geo_mode = kernel_mode;
+        st.table_valid = false;
+    }
+    if (!st.geo.ok) return fail(RSMP_ERR_INVALID_ARGUMENT, "periodic kernel: unsupported geometry");
+    const double drift = std::round(planned.drift() / kDriftQuantum) * kDriftQuantum;
+    if (st.table_valid && drift == st.table_drift) return RSMP_OK;
+    ClassTable ct;
+    const int rc = class_table_for(device, table, st.geo, drift, &ct);
+    if (rc != RSMP_OK) return rc;
+    st.table = ct;
     st.table_valid = true;
     st.table_drift = drift;
     return RSMP_OK;

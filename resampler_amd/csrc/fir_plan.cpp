@@ -13,125 +13,57 @@
 
 namespace rsmp {
 
-FirMirror::FirMirror(uint32_t in_hz, uint32_t out_hz, size_t taps)
-    : ratio_(static_cast<double>(in_hz) / static_cast<double>(out_hz)), taps_(taps) {
+FirMirror::FirMirror(uint32_t in_hz, uint32_t out_hz, size_t taps) {
+    st_ = FirMirrorState{};
+    st_.ratio = static_cast<double>(in_hz) / static_cast<double>(out_hz);
+    st_.taps = taps;
     const uint64_t g = std::gcd<uint64_t>(in_hz, out_hz);
-    num_ = in_hz / g;
-    den_ = out_hz / g;
+    st_.num = in_hz / g;
+    st_.den = out_hz / g;
+    st_.periodic_ok = 1;
 }
 
 void FirMirror::reset() {
-    read_position_ = 0;
-    available_ = 0;
-    position_ = 0.0;
-    abs_out_ = 0;
-    abs_consumed_ = 0;
-    periodic_ok_ = true;
-    drift_ = 0.0;
+    st_.read_position = 0;
+    st_.available = 0;
+    st_.position = 0.0;
+    st_.abs_out = 0;
+    st_.abs_consumed = 0;
+    st_.periodic_ok = 1;
+    st_.drift = 0.0;
 }
 
 size_t FirMirror::buffer_size_output_frames() const {
-    const double max_usable = static_cast<double>(kInputCapacity - taps_);
-    return static_cast<size_t>(std::ceil(max_usable / ratio_)) + 2;
+    const double max_usable = static_cast<double>(kInputCapacity - st_.taps);
+    return static_cast<size_t>(std::ceil(max_usable / st_.ratio)) + 2;
 }
 
 namespace {
 
-// Largest k >= 0 with p0 + k*inc < bound, given p0 < bound, inc > 0 and every p0 + k*inc up to
-// the bound exactly representable.
-inline uint64_t last_below(double p0, double inc, double bound) {
-    double est = std::floor((bound - p0) / inc);
-    if (est < 0.0) est = 0.0;
-    uint64_t k = static_cast<uint64_t>(est);
-    while (k > 0 && std::fma(static_cast<double>(k), inc, p0) >= bound) --k;
-    while (std::fma(static_cast<double>(k + 1), inc, p0) < bound) ++k;
-    return k;
-}
+// Host sink of mirror_call: appends runs / wraps to the caller's vectors.
+struct VectorSink {
+    std::vector<rsmp_fir_segment>* segs;
+    std::vector<uint32_t>* wraps;
+    int64_t in_base;
+    uint32_t out_start;
+    bool want_wraps() const { return wraps != nullptr; }
+    void run(uint64_t first, uint64_t count, double p0, double inc) {
+        if (segs)
+            segs->push_back(rsmp_fir_segment{out_start + static_cast<uint32_t>(first),
+                                             static_cast<uint32_t>(count), in_base, p0, inc});
+    }
+    void wrap(uint64_t index) { wraps->push_back(out_start + static_cast<uint32_t>(index)); }
+};
 
 }  // namespace
 
 FirCallResult FirMirror::call(size_t input_frames, size_t output_capacity, int64_t in_base,
                               uint32_t out_start, std::vector<rsmp_fir_segment>* segs,
                               std::vector<uint32_t>* wraps) {
-    // resampler_fir.rs:524-528
-    const size_t write_position = read_position_ + available_;
-    const size_t remaining_capacity = kBufferSize > write_position ? kBufferSize - write_position : 0;
-    size_t accepted = input_frames < remaining_capacity ? input_frames : remaining_capacity;
-    if (accepted > kInputCapacity - available_) accepted = kInputCapacity - available_;
-    available_ += accepted;
-
-    // Output loop (:542-590): frames are produced while floor(pos) + taps <= available, i.e.
-    // while pos < available - taps + 1, and while the output has room.
-    size_t count = 0;
-    double pos = position_;
-    const bool any = available_ >= taps_;
-    const double limit = any ? static_cast<double>(available_ - taps_) + 1.0 : 0.0;
-    const bool rational = wraps != nullptr && periodic_ok_;
-
-    auto note_wraps = [&](double p0, double inc, size_t n, size_t first_count) {
-        // Outputs whose exact position n_abs*num/den is an integer: the rounded f64 position is
-        // that integer +- drift.  Below it, floor() picks the previous input frame and the phase
-        // clamps to row 1023 (:562-564) instead of row 0 -- a 1/1024-sample step the periodic
-        // kernel must reproduce per output.
-        const uint64_t first_abs = abs_out_ + first_count;
-        uint64_t k = (den_ - first_abs % den_) % den_;
-        for (; k < n; k += den_) {
-            const double p = std::fma(static_cast<double>(k), inc, p0);
-            const double fr = p - std::floor(p);
-            const double dist = fr > 0.5 ? 1.0 - fr : fr;
-            drift_ = fr > 0.5 ? fr - 1.0 : fr;
-            if (dist > 1e-5) periodic_ok_ = false;
-            if (fr > 0.5) wraps->push_back(out_start + static_cast<uint32_t>(first_count + k));
-        }
-    };
-
-    while (any && count < output_capacity && pos < limit) {
-        size_t run = 0;
-        double inc = 0.0;
-        if (pos > 0.0) {
-            int e;
-            (void)std::frexp(pos, &e);
-            const double top = std::ldexp(1.0, e);  // pos in [top/2, top)
-            const double p1 = pos + ratio_;
-            if (p1 < top) {
-                inc = p1 - pos;  // exact: same binade
-                const double p2 = p1 + ratio_;
-                // Equal consecutive increments: RN(ratio) on this binade's grid, with the
-                // round-half-even parity (if ratio is a tie on this grid) already settled.
-                if (p2 < top && (p2 - p1) == inc) {
-                    uint64_t n = last_below(pos, inc, top);  // p_n < top: steps 0..n regular
-                    const uint64_t n_valid = last_below(pos, inc, limit) + 1;  // p_k < limit
-                    if (n_valid < n) n = n_valid;
-                    const uint64_t room = output_capacity - count;
-                    if (room < n) n = room;
-                    run = static_cast<size_t>(n);
-                }
-            }
-        }
-        if (run == 0) {
-            run = 1;
-            inc = 0.0;
-        }
-        if (segs)
-            segs->push_back(rsmp_fir_segment{out_start + static_cast<uint32_t>(count),
-                                             static_cast<uint32_t>(run), in_base, pos, inc});
-        if (rational) note_wraps(pos, inc, run, count);
-        pos = (inc == 0.0) ? pos + ratio_ : std::fma(static_cast<double>(run), inc, pos);
-        count += run;
-    }
-
-    // :596-602
-    size_t consumed = static_cast<size_t>(std::floor(pos));
-    if (consumed > available_) consumed = available_;
-    read_position_ += consumed;
-    available_ -= consumed;
-    position_ = pos - static_cast<double>(consumed);
-    // :605-615 (the device keeps no ring; only the index bookkeeping matters for `accepted`)
-    if (read_position_ > kInputCapacity) read_position_ = 0;
-
-    abs_out_ += count;
-    abs_consumed_ += consumed;
-    return FirCallResult{accepted, count, consumed};
+    VectorSink sink{segs, wraps, in_base, out_start};
+    const FirCallCounts c = mirror_call(st_, input_frames, output_capacity, sink);
+    return FirCallResult{static_cast<size_t>(c.accepted), static_cast<size_t>(c.produced),
+                         static_cast<size_t>(c.consumed)};
 }
 
 }  // namespace rsmp

@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "../../include/resampler_amd.h"
+#include "fir_mirror_core.h"
 
 namespace rsmp {
 
@@ -42,35 +43,30 @@ public:
 
     size_t buffer_size_output_frames() const;  // resampler_fir.rs:456-465, per channel
 
-    double ratio() const { return ratio_; }
-    size_t taps() const { return taps_; }
-    size_t read_position() const { return read_position_; }
-    size_t available() const { return available_; }
-    double position() const { return position_; }
+    double ratio() const { return st_.ratio; }
+    size_t taps() const { return st_.taps; }
+    size_t read_position() const { return st_.read_position; }
+    size_t available() const { return st_.available; }
+    double position() const { return st_.position; }
 
     // Rational view in_hz/out_hz = num/den (reduced) and absolute counters since reset().
-    uint64_t num() const { return num_; }
-    uint64_t den() const { return den_; }
-    uint64_t abs_out() const { return abs_out_; }
-    uint64_t abs_consumed() const { return abs_consumed_; }
+    uint64_t num() const { return st_.num; }
+    uint64_t den() const { return st_.den; }
+    uint64_t abs_out() const { return st_.abs_out; }
+    uint64_t abs_consumed() const { return st_.abs_consumed; }
     // False once the f64 position has drifted further from n*num/den than the periodic kernel
     // tolerates (never observed; the generic kernel is used from then on).
-    bool periodic_ok() const { return periodic_ok_; }
+    bool periodic_ok() const { return st_.periodic_ok != 0; }
     // Signed distance (f64 position - exact rational position) seen at the most recent output
     // whose exact position is an integer.
-    double drift() const { return drift_; }
+    double drift() const { return st_.drift; }
+
+    // The plain-data state (shared with the device-side planner, fir_mirror_core.h).
+    const FirMirrorState& state() const { return st_; }
+    void set_state(const FirMirrorState& s) { st_ = s; }
 
 private:
-    double ratio_;
-    size_t taps_;
-    uint64_t num_, den_;
-    size_t read_position_ = 0;
-    size_t available_ = 0;
-    double position_ = 0.0;
-    uint64_t abs_out_ = 0;
-    uint64_t abs_consumed_ = 0;
-    bool periodic_ok_ = true;
-    double drift_ = 0.0;
+    FirMirrorState st_;
 };
 
 }  // namespace rsmp

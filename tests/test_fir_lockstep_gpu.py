@@ -1,0 +1,240 @@
+"""GPU parity tests of the lock-step batch (rsmp_fir_lockstep_*, BASELINE config 4): per stream and step
+exactly one reference resample() call (src/resampler_fir.rs:509-621) -- identical (consumed, produced),
+output within 1e-6 RMS of the CPU oracle -- with the streams' state resident in HBM and the control flow
+run inside the kernel."""
+import numpy as np
+import pytest
+
+import resampler_amd as ra
+from oracle import pyoracle as o
+from resampler_amd import sharding, synth
+
+pytestmark = pytest.mark.gpu
+
+RMS_TOL = 1e-6   # north_star tolerance
+ATT_DB = {ra.Attenuation.Db60: 60, ra.Attenuation.Db90: 90, ra.Attenuation.Db120: 120}
+
+
+def rms(a, b):
+    if a.size == 0:
+        return 0.0
+    return float(np.sqrt(np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2)))
+
+
+def run_lockstep(specs, steps, frames, seed=0, lat=ra.Latency.Sample64, att=ra.Attenuation.Db90,
+                 prefeed=None, in_frames_per_stream=None, x_override=None, append=True):
+    """Runs `steps` lock-step steps of `frames` frames over the streams in `specs` on the GPU and the same
+    calls through one OracleFir per stream.  Returns the worst RMS error over the streams; asserts equal
+    counts at every step.  prefeed[i]: frames pushed through stream i with ordinary resample() calls
+    beforehand, so that the streams are in different states."""
+    import torch
+    dev = torch.device("cuda:0")
+    n = len(specs)
+    hs = [ra.ResamplerFir.new_from_hz(s.channels, s.in_hz, s.out_hz, lat, att) for s in specs]
+    refs = [o.OracleFir(s.channels, s.in_hz, s.out_hz, lat.taps(), ATT_DB[att]) for s in specs]
+    rng = np.random.default_rng(seed)
+    if prefeed is not None:
+        for i, (h, r) in enumerate(zip(hs, refs)):
+            if prefeed[i] == 0:
+                continue
+            x = (rng.random(prefeed[i] * specs[i].channels, dtype=np.float32) * 2 - 1).astype(np.float32)
+            og = np.zeros(h.buffer_size_output(), np.float32)
+            orr = np.zeros(r.buffer_size_output(), np.float32)
+            off = 0
+            while off < x.size:
+                cg, pg = h.resample(x[off:off + 300 * specs[i].channels], og)
+                rc, cr, pr = r.resample(x[off:off + 300 * specs[i].channels], orr)
+                assert rc == 0 and (cg, pg) == (cr, pr)
+                off += cg
+    xs = []
+    for i, s in enumerate(specs):
+        if x_override is not None:
+            xs.append(x_override[i])
+        else:
+            xs.append((rng.random(steps * frames * s.channels, dtype=np.float32) * 2 - 1).astype(np.float32))
+    d_in = [torch.from_numpy(x).to(dev) for x in xs]
+    caps = [h.buffer_size_output() for h in hs]
+    d_out = [torch.zeros(steps * c if append else c, device=dev, dtype=torch.float32) for c in caps]
+    ls = ra.FirLockstep(hs, frames)
+    ls.bind_caps(d_in, d_out, caps)
+    d_fr = None
+    if in_frames_per_stream is not None:
+        d_fr = torch.tensor(in_frames_per_stream, dtype=torch.int32, device=dev)
+    ref_out = [[] for _ in range(n)]
+    gpu_step_out = [[] for _ in range(n)]
+    orr = [np.zeros(r.buffer_size_output(), np.float32) for r in refs]
+    for k in range(steps):
+        ls.step(frames, k * frames, append=append, d_in_frames=d_fr)
+        cons, prod = ls.counts()
+        for i, s in enumerate(specs):
+            fr = frames if in_frames_per_stream is None else min(frames, in_frames_per_stream[i])
+            sl = xs[i][k * frames * s.channels:(k * frames + fr) * s.channels]
+            rc, cr, pr = refs[i].resample(sl, orr[i])
+            assert rc == 0
+            assert (int(cons[i]), int(prod[i])) == (cr, pr), (k, i, (cons[i], prod[i]), (cr, pr))
+            ref_out[i].append(orr[i][:pr].copy())
+            if not append:
+                gpu_step_out[i].append(d_out[i][:pr].cpu().numpy())
+    worst = 0.0
+    for i in range(n):
+        want = np.concatenate(ref_out[i]) if ref_out[i] else np.zeros(0, np.float32)
+        got = d_out[i][:want.size].cpu().numpy() if append else np.concatenate(gpu_step_out[i])
+        e = rms(got, want)
+        if e > RMS_TOL:
+            bad = np.flatnonzero(~(np.abs(got.astype(np.float64) - want) <= 1e-4))
+            print(f"lockstep: stream {i} {specs[i]} rms {e:.3e} bad {bad.size}: {bad[:8]} got {got[bad[:4]]} "
+                  f"want {want[bad[:4]]}")
+        worst = max(worst, e)
+    return worst, ls, hs, refs
+
+
+def test_c4_shape_1024_streams_six_pairs_16_steps():
+    # BASELINE config 4: 1024 streams, stream i = ordered pair i mod 6 of the 44.1k / 48k / 96k
+    # conversions, 2 ch, 128 taps, Db90, lock-step steps of 512 frames on carried state.
+    specs = sharding.mixed_rate_batch(1024, 2, 512)
+    worst, ls, hs, refs = run_lockstep(specs, steps=16, frames=512, seed=4)
+    assert worst <= RMS_TOL, worst
+    assert not ls.status().any()
+    # the device state written back into the handles equals the oracle's state machine, bit for bit
+    ls.sync()
+    for h, r in zip(hs, refs):
+        assert h.state() == r.state()
+    x = synth.fast_noise(2 * 300, seed=9)
+    ls.close()
+    for i in (0, 1, 2, 3, 4, 5, 1023):   # the handles carry on through the ordinary API
+        g_out = np.zeros(hs[i].buffer_size_output(), np.float32)
+        r_out = np.zeros(refs[i].buffer_size_output(), np.float32)
+        cg, pg = hs[i].resample(x, g_out)
+        rc, cr, pr = refs[i].resample(x, r_out)
+        assert rc == 0 and (cg, pg) == (cr, pr)
+        assert rms(g_out[:pg], r_out[:pr]) <= RMS_TOL
+
+
+def test_streams_in_different_states():
+    # every stream has been running for a different time: different positions, buffered frames, phases
+    specs = sharding.mixed_rate_batch(96, 2, 512)
+    prefeed = [(37 * i) % 1500 for i in range(96)]
+    worst, ls, _, _ = run_lockstep(specs, steps=6, frames=512, seed=5, prefeed=prefeed)
+    assert worst <= RMS_TOL, worst
+    assert not ls.status().any()
+
+
+@pytest.mark.parametrize("channels", [1, 3, 8])
+def test_channel_counts(channels):
+    pairs = [(44100, 48000), (96000, 44100), (48000, 96000)]
+    specs = [sharding.StreamSpec(channels, *pairs[i % 3], 128, 256) for i in range(9)]
+    worst, ls, _, _ = run_lockstep(specs, steps=5, frames=256, seed=6 + channels)
+    assert worst <= RMS_TOL, worst
+
+
+@pytest.mark.parametrize("lat", [ra.Latency.Sample8, ra.Latency.Sample16, ra.Latency.Sample32])
+def test_tap_counts_and_other_rates(lat):
+    pairs = [(22050, 48000), (48000, 32000), (32000, 48000), (16000, 44100), (192000, 48000), (48000, 192000)]
+    specs = [sharding.StreamSpec(2, *pairs[i % 6], lat.taps(), 200) for i in range(12)]
+    worst, ls, _, _ = run_lockstep(specs, steps=7, frames=200, seed=11, lat=lat, att=ra.Attenuation.Db60)
+    assert worst <= RMS_TOL, worst
+
+
+def test_irrational_and_huge_ratios_use_the_reference_form():
+    # no usable period: every output is evaluated in the reference's two-row form inside the same kernel
+    specs = [sharding.StreamSpec(2, 44100, 44101, 128, 384), sharding.StreamSpec(2, 48000, 47999, 128, 384),
+             sharding.StreamSpec(1, 12345, 54321, 128, 384), sharding.StreamSpec(2, 44100, 48000, 128, 384)]
+    worst, ls, _, _ = run_lockstep(specs, steps=6, frames=384, seed=12)
+    assert worst <= RMS_TOL, worst
+
+
+def test_per_stream_step_sizes_and_call_semantics():
+    # ragged steps (a device array of frames per stream, including empty ones), output written at the
+    # start of `out` every step like the reference call
+    specs = sharding.mixed_rate_batch(18, 2, 512)
+    fr = [0, 1, 17, 128, 511, 512] * 3
+    worst, ls, _, _ = run_lockstep(specs, steps=5, frames=512, seed=13, in_frames_per_stream=fr, append=False)
+    assert worst <= RMS_TOL, worst
+
+
+def test_non_finite_samples_match_the_reference():
+    # Inf / NaN at a stream start, in the middle of a period, at a step edge, in one channel and in both:
+    # the outputs the reference leaves finite stay finite and equal, the others are non-finite in both.
+    import torch
+    specs = sharding.mixed_rate_batch(12, 2, 512)
+    steps, frames = 4, 512
+    rng = np.random.default_rng(21)
+    xs = [(rng.random(steps * frames * 2, dtype=np.float32) * 2 - 1).astype(np.float32) for _ in specs]
+    xs[0][0] = np.inf                       # first sample of the stream, channel 0
+    xs[1][2 * 700 + 1] = -np.inf            # mid stream, channel 1
+    xs[2][2 * 511] = np.nan                 # last frame of step 0
+    xs[2][2 * 511 + 1] = np.nan
+    xs[3][2 * 512] = np.inf                 # first frame of step 1
+    xs[4][2 * 1000] = np.inf
+    xs[4][2 * 1003] = -np.inf               # +inf and -inf inside one window
+    xs[5][2 * 1500 + 1] = np.nan
+    dev = torch.device("cuda:0")
+    hs = [ra.ResamplerFir.new_from_hz(2, s.in_hz, s.out_hz, ra.Latency.Sample64, ra.Attenuation.Db90) for s in specs]
+    refs = [o.OracleFir(2, s.in_hz, s.out_hz, 128, 90, o.CONVOLVE_AVX_FMA if o.have_avx_fma() else o.CONVOLVE_SCALAR)
+            for s in specs]
+    caps = [h.buffer_size_output() for h in hs]
+    d_in = [torch.from_numpy(x).to(dev) for x in xs]
+    d_out = [torch.zeros(steps * c, device=dev) for c in caps]
+    ls = ra.FirLockstep(hs, frames)
+    ls.bind_caps(d_in, d_out, caps)
+    want = [[] for _ in specs]
+    orr = [np.zeros(c, np.float32) for c in caps]
+    for k in range(steps):
+        ls.step(frames, k * frames, append=True)
+        cons, prod = ls.counts()
+        for i in range(len(specs)):
+            rc, cr, pr = refs[i].resample(xs[i][k * frames * 2:(k + 1) * frames * 2], orr[i])
+            assert rc == 0 and (int(cons[i]), int(prod[i])) == (cr, pr)
+            want[i].append(orr[i][:pr].copy())
+    for i in range(len(specs)):
+        w = np.concatenate(want[i])
+        g = d_out[i][:w.size].cpu().numpy()
+        fin = np.isfinite(w)
+        assert np.array_equal(np.isfinite(g), fin), (i, np.flatnonzero(np.isfinite(g) != fin)[:10])
+        assert np.array_equal(np.isnan(g), np.isnan(w)), i
+        inf = np.isinf(w)
+        assert np.array_equal(g[inf], w[inf]), i          # same signed infinities
+        assert rms(g[fin], w[fin]) <= RMS_TOL
+        if i <= 5:
+            assert (~fin).any()
+    st = ls.status()
+    assert all(st[i] & 2 for i in range(6)) and not any(st[6:])
+
+
+def test_reset_and_rebind():
+    import torch
+    specs = sharding.mixed_rate_batch(12, 2, 256)
+    worst, ls, hs, refs = run_lockstep(specs, steps=3, frames=256, seed=31)
+    assert worst <= RMS_TOL
+    ls.reset()
+    for r in refs:
+        r.reset()
+    dev = torch.device("cuda:0")
+    x = synth.fast_noise(2 * 256, seed=32)
+    d_in = [torch.from_numpy(x).to(dev) for _ in specs]
+    d_out = [torch.zeros(h.buffer_size_output(), device=dev) for h in hs]
+    ls.bind(d_in, d_out)
+    ls.step(256)
+    cons, prod = ls.counts()
+    for i, r in enumerate(refs):
+        out = np.zeros(r.buffer_size_output(), np.float32)
+        rc, cr, pr = r.resample(x, out)
+        assert rc == 0 and (int(cons[i]), int(prod[i])) == (cr, pr)
+        assert rms(d_out[i][:pr].cpu().numpy(), out[:pr]) <= RMS_TOL
+
+
+def test_rejects_small_output_and_busy_streams():
+    import torch
+    dev = torch.device("cuda:0")
+    h = ra.ResamplerFir.new_from_hz(2, 44100, 48000, ra.Latency.Sample64, ra.Attenuation.Db90)
+    ls = ra.FirLockstep([h], 512)
+    d_in = [torch.zeros(1024, device=dev)]
+    with pytest.raises(ra.InvalidOutputBufferSize):
+        ls.bind(d_in, [torch.zeros(64, device=dev)])
+    with pytest.raises(ra.ResampleError):
+        ls.step(512)            # nothing bound
+    ls.bind(d_in, [torch.zeros(h.buffer_size_output(), device=dev)])
+    with pytest.raises(ra.InvalidInputBufferSize):
+        ls.step(513)            # more than the batch was created for
+    with pytest.raises(ra.ResampleError):
+        ra.FirLockstep([h, h], 512)
