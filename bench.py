@@ -2,23 +2,34 @@
 """bench.py -- headline benchmark: Msamples/s (input f32 values) of the 128-tap polyphase FIR,
 2 ch 44.1 kHz -> 48 kHz (BASELINE.json configs[1]), inputs resident in HBM.
 
+  python bench.py [--gpus N] [--steps K] [--warmup W]            headline (FIR, weak scaling)
+  python bench.py --config c4 [--gpus N]                         BASELINE config 4 (strong scaling)
+  python bench.py --path fft                                     ResamplerFft line alone
+
 A step = one pass of the hot path over one batch: `--streams` independent 2-channel streams, each
 a fresh 2^20-frame sine sweep (reset + the reference's bulk driver loop with 512-value chunks,
 resample/src/main.rs:226-254), all streams in ONE launch of the periodic FIR kernel.  One stream
 alone is 8 MiB in / 8.7 MiB out -- microseconds of HBM time -- so the single-GPU workload is a
 batch of them (weak scaling: every rank owns `--streams` streams; no data-path collective).
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (fir_periodic_db_kernel, the
-matrix-core periodic FIR kernel, unless another one is forced with --kernel / RSMP_FIR_MFMA=0),
-timed with HIP events on the launch stream inside the library (rsmp_fir_set_profiling);
-`cpu_baseline` is the oracle's AVX+FMA restatement of the reference path on one host core.
+--gpus N > 1 without a launcher spawns N fresh rank processes (one per GPU, RCCL group over
+127.0.0.1) BEFORE anything touches the GPU and prints rank 0's line; under
+`python -m torch.distributed.run` (RANK / WORLD_SIZE in the environment) the process is one rank.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel, timed with HIP events on the
+launch stream inside the library (rsmp_fir_set_profiling); `cpu_baseline` is the oracle's AVX+FMA
+restatement of the reference path on the host cores; `secondary` (N = 1 only) carries the FFT
+path, the exact-f32 and vector FIR kernels, the cold-plan / distinct-state FIR step and config 4.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
+import threading
 import time
 
 import numpy as np
@@ -29,288 +40,608 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 IN_HZ, OUT_HZ, CHANNELS = 44100, 48000, 2
+FIR_DTYPE = "f32 (bf16x3-split products, f32 accumulate)"
+KERNEL_NAMES = {0: "fir_generic_kernel", 1: "fir_periodic_kernel (vector)", 2: "fir_periodic_db_kernel (vector)",
+                3: "fir_periodic_db_kernel (exact-f32 MFMA)", 4: "fir_split_kernel (bf16x3 MFMA)"}
 
 
-def spinup(step, torch, seconds: float) -> int:
+# ------------------------------------------------------------------------------------------------
+# process layout
+# ------------------------------------------------------------------------------------------------
+def spawn_ranks(args) -> int:
+    """--gpus N without a launcher: start N rank processes of this script (one per GPU) before this
+    process has initialised HIP, wait for them, and pass rank 0's JSON line through."""
+    import torch
+    have = torch.cuda.device_count()      # does not initialise the GPU on this image
+    if have < args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) are visible", file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    for p in procs[1:]:
+        p.wait()
+        rc = rc or p.returncode
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    return rc
+
+
+class Ctx:
+    """One rank: device, process group, barrier, max-over-ranks timing."""
+
+    def __init__(self, args):
+        import torch
+        self.torch = torch
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if self.world != max(1, args.gpus) and self.rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={self.world}; using WORLD_SIZE", file=sys.stderr)
+        self.dist = None
+        if self.world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{self.local_rank}"))
+            self.dist = dist
+        import resampler_amd as ra
+        if not torch.cuda.is_available() or ra.device_count() <= self.local_rank:
+            raise SystemExit("bench.py needs a HIP device per rank (no CPU fallback)")
+        torch.cuda.set_device(self.local_rank)
+        self.dev = torch.device(f"cuda:{self.local_rank}")
+        self.stream = torch.cuda.current_stream().cuda_stream
+
+    def barrier(self):
+        self.torch.cuda.synchronize()
+        if self.dist:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def max_over_ranks(self, dt: float) -> float:
+        if not self.dist:
+            return dt
+        t = self.torch.tensor([dt], device=self.dev, dtype=self.torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def sum_over_ranks(self, v: float) -> float:
+        if not self.dist:
+            return v
+        t = self.torch.tensor([v], device=self.dev, dtype=self.torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return float(t.item())
+
+    def close(self):
+        if self.dist:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
+def timed(ctx: Ctx, step, steps: int, warmup: int):
+    """W untimed steps, then exactly K steps bracketed by barrier + synchronize; max over ranks."""
+    for _ in range(warmup):
+        step()
+    ctx.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    host_dt = time.perf_counter() - t0
+    ctx.barrier()
+    dt = time.perf_counter() - t0
+    return ctx.max_over_ranks(dt), host_dt
+
+
+def spinup(ctx: Ctx, step, seconds: float) -> None:
     """Untimed steps of the same workload until `seconds` have passed, before the contract's warmup
     steps.  Measured on the pool's MI355X: the first ~100 launches after idle run ~18 % slower than
-    the steady state (0.52 vs 0.44 ms per kernel) -- a 20-step run never leaves the governor's ramp,
-    so without this the line reports the ramp, not the kernel.  The timed region is unchanged."""
-    n = 0
+    the steady state -- a 20-step run never leaves the governor's ramp, so without this the line
+    reports the ramp, not the kernel.  The timed region is unchanged."""
     if seconds <= 0:
-        return n
+        return
     t0 = time.perf_counter()
     while time.perf_counter() - t0 < seconds:
         for _ in range(20):
             step()
-        torch.cuda.synchronize()
-        n += 20
-    return n
+        ctx.torch.cuda.synchronize()
 
 
-def cpu_baseline(frames: int, seconds: float):
-    """Oracle (port of the reference AVX+FMA path, fir/avx.rs + resampler_fir.rs) on ONE core:
-    the same 2 ch 44.1k->48k 128-tap sweep, 512-value chunks, repeated for ~`seconds`."""
+# ------------------------------------------------------------------------------------------------
+# CPU baselines (oracle = port of the reference; test infrastructure, used here only as `cpu_baseline`)
+# ------------------------------------------------------------------------------------------------
+def cpu_info():
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("model name"):
+                    model = ln.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    return model, cores
+
+
+def _fir_cpu_worker(x, seconds, chunk, out, idx, specs=(CHANNELS, IN_HZ, OUT_HZ, 128, 90)):
     from oracle import pyoracle as orc
-    from resampler_amd import synth
     kind = orc.CONVOLVE_AVX_FMA if orc.have_avx_fma() else orc.CONVOLVE_SCALAR
-    r = orc.OracleFir(CHANNELS, IN_HZ, OUT_HZ, 128, 90, kind)
-    x = synth.sweep(frames, CHANNELS, float(IN_HZ))
-    r.resample_all(x[: 2 * 65536], 512)          # warm caches / page in
+    r = orc.OracleFir(specs[0], specs[1], specs[2], specs[3], specs[4], kind)
+    r.resample_all(x[: 2 * 65536], chunk)          # warm caches / page in
     t0 = time.perf_counter()
     values = 0
-    passes = 0
     while True:
-        r.resample_all(x, 512)
+        r.reset()
+        r.resample_all(x, chunk)                   # (ctypes releases the GIL for the call)
         values += x.size
-        passes += 1
         if time.perf_counter() - t0 >= seconds:
             break
-    dt = time.perf_counter() - t0
-    return {
-        "value": round(values / dt / 1e6, 3),
-        "unit": "Msamples/s",
-        "cores": 1,
-        "kind": "port",
-        "sample": f"{passes} passes of one {frames}-frame 2ch sweep, 512-value calls, "
-                  f"{'AVX+FMA' if kind == orc.CONVOLVE_AVX_FMA else 'scalar'} convolve, {dt:.1f} s",
+    out[idx] = (values, time.perf_counter() - t0)
+
+
+def cpu_baseline_fir(frames: int, seconds: float, all_cores_seconds: float):
+    """Oracle (port of the reference AVX+FMA path, fir/avx.rs + resampler_fir.rs): the same 2 ch
+    44.1k->48k 128-tap sweep in 512-value calls, repeated for ~`seconds` on ONE core; then one
+    stream per core on all host cores (the reference is single-threaded per instance)."""
+    from oracle import pyoracle as orc
+    from resampler_amd import synth
+    model, cores = cpu_info()
+    x = synth.sweep(frames, CHANNELS, float(IN_HZ))
+    res = [None]
+    _fir_cpu_worker(x, seconds, 512, res, 0)
+    one = res[0][0] / res[0][1] / 1e6
+    line = {
+        "value": round(one, 3), "unit": "Msamples/s", "cores": 1, "kind": "port", "model": model,
+        "host_cores": cores,
+        "sample": f"{res[0][0] // x.size} passes of one {frames}-frame 2ch sweep, 512-value calls, "
+                  f"{'AVX+FMA' if orc.have_avx_fma() else 'scalar'} convolve, {res[0][1]:.1f} s",
     }
+    if all_cores_seconds > 0 and cores > 1:
+        n = min(cores, 256)
+        xs = x[: 2 * (1 << 18)]                    # a quarter of the sweep per thread: bounded sample
+        res = [None] * n
+        ths = [threading.Thread(target=_fir_cpu_worker, args=(xs, all_cores_seconds, 512, res, i)) for i in range(n)]
+        t0 = time.perf_counter()
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        wall = time.perf_counter() - t0
+        line["all_cores"] = {"value": round(sum(r[0] for r in res) / wall / 1e6, 1), "unit": "Msamples/s",
+                             "cores": n, "sample": f"one stream per core, 2^18-frame sweeps, {wall:.1f} s"}
+    return line
 
 
-def bench_fft(args) -> None:
-    """Secondary line (`--path fft`): ResamplerFft 2 ch 44.1k -> 48k (BASELINE config 3), a batch of
-    `--streams` streams x 892 blocks of 1176 frames per step, one launch of fft_ola_kernel."""
-    import torch
+def cpu_baseline_fft(seconds: float):
+    """OracleFft (port of resampler_fft.rs:182-240 + src/fft, scalar butterflies) on one core."""
+    from oracle import pyoracle as orc
+    from resampler_amd import synth
+    model, cores = cpu_info()
+    r = orc.OracleFft(CHANNELS, IN_HZ, OUT_HZ)
+    n_in, n_out = r.chunk_size_input(), r.chunk_size_output()
+    blocks = 256
+    x = synth.sweep(blocks * n_in // CHANNELS, CHANNELS, float(IN_HZ))
+    out = np.zeros(n_out, np.float32)
+    t0 = time.perf_counter()
+    values = 0
+    while time.perf_counter() - t0 < seconds:
+        for b in range(blocks):
+            r.resample(x[b * n_in:(b + 1) * n_in], out)
+        values += blocks * n_in
+    dt = time.perf_counter() - t0
+    return {"value": round(values / dt / 1e6, 3), "unit": "Msamples/s", "cores": 1, "kind": "port",
+            "model": model, "sample": f"{values // n_in} blocks of 1176 frames, scalar butterflies, {dt:.1f} s"}
+
+
+# ------------------------------------------------------------------------------------------------
+# GPU workloads
+# ------------------------------------------------------------------------------------------------
+def traffic_from_profiles(name: str, variant=None):
+    """HBM bytes per launch from the committed PMC passes (profiles/traffic_latest.json is written by
+    tools/profile_round.sh on the GPU box; this run does not collect counters itself)."""
+    tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    try:
+        tj = json.load(open(tpath))
+    except Exception:
+        return None
+    ent = tj.get(name) if isinstance(tj.get(name), dict) else (tj if name == "fir" else None)
+    if not ent:
+        return None
+    if variant is not None and ent.get("variant") is not None and ent["variant"] != variant:
+        return None
+    return ent.get("hbm_bytes_per_launch")
+
+
+def make_fir_batch(ctx: Ctx, ra, S: int, N: int, chunk: int, kernel, distinct_states: bool = False):
+    from resampler_amd import synth
+    torch = ctx.torch
+    handles = []
+    for _ in range(S):
+        h = ra.ResamplerFir.new(CHANNELS, ra.SampleRate.Hz44100, ra.SampleRate.Hz48000,
+                                ra.Latency.Sample64, ra.Attenuation.Db90, device=ctx.local_rank)
+        h.set_kernel(kernel)
+        handles.append(h)
+    if distinct_states:   # every stream has already run for a different time
+        warm = np.zeros(CHANNELS * 4096, np.float32)
+        for i, h in enumerate(handles):
+            h.resample_bulk(warm[: CHANNELS * (64 + 37 * i)], chunk)
+    base = torch.from_numpy(synth.sweep(N, CHANNELS, float(IN_HZ))).to(ctx.dev)
+    gains = torch.linspace(0.5, 1.0, S, device=ctx.dev)
+    d_in = [(base * gains[i]).contiguous() for i in range(S)]
+    cap = max(h.bulk_output_bound(CHANNELS * N, chunk) for h in handles)
+    d_out = [torch.empty(cap, device=ctx.dev, dtype=torch.float32) for _ in range(S)]
+    batch = ra.FirBatch(handles)
+    batch.bind(d_in, d_out)
+    return handles, batch
+
+
+def fir_kernel_point(ctx: Ctx, ra, args, kernel, steps: int):
+    """Kernel time / roofline fraction of one FIR kernel flavour on the headline workload."""
+    S, N = args.streams, args.frames
+    handles, batch = make_fir_batch(ctx, ra, S, N, args.chunk, kernel)
+
+    def step():
+        batch.reset()
+        return batch.resample_bulk_device(args.chunk, ctx.stream)
+    consumed, produced = step()
+    out_values = int(sum(produced))
+    spinup(ctx, step, 0.5)
+    handles[0].set_profiling(True)
+    for _ in range(steps):
+        step()
+    k_ms, _ = handles[0].mean_kernel_ms()
+    handles[0].set_profiling(False)
+    alg = 4.0 * (S * CHANNELS * N + out_values) + 4.0 * 1024 * 128
+    ach = alg / (k_ms * 1e-3) / 1e9
+    return {"kernel": KERNEL_NAMES.get(handles[0].kernel_variant(), "?"), "kernel_ms": round(k_ms, 4),
+            "achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4),
+            "Msamples_in_per_s_kernel": round(S * CHANNELS * N / (k_ms * 1e-3) / 1e6, 1)}
+
+
+def bench_fft(ctx: Ctx, args, steps: int, warmup: int, with_cpu: bool):
+    """ResamplerFft 2 ch 44.1k -> 48k (BASELINE config 3): a batch of `--streams` streams x 892 blocks
+    of 1176 frames per step, one launch of the overlap-add FFT kernel."""
     import resampler_amd as ra
     from resampler_amd import synth
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device(f"cuda:{local_rank}")
+    torch = ctx.torch
     S, blocks = args.streams, 892
-    hs = [ra.ResamplerFft.new(CHANNELS, ra.SampleRate.Hz44100, ra.SampleRate.Hz48000, device=local_rank)
+    hs = [ra.ResamplerFft.new(CHANNELS, ra.SampleRate.Hz44100, ra.SampleRate.Hz48000, device=ctx.local_rank)
           for _ in range(S)]
     n_in, n_out = hs[0].chunk_size_input(), hs[0].chunk_size_output()
-    base = torch.from_numpy(synth.sweep(blocks * n_in // CHANNELS, CHANNELS, float(IN_HZ))).to(dev)
-    gains = torch.linspace(0.5, 1.0, S, device=dev)
+    base = torch.from_numpy(synth.sweep(blocks * n_in // CHANNELS, CHANNELS, float(IN_HZ))).to(ctx.dev)
+    gains = torch.linspace(0.5, 1.0, S, device=ctx.dev)
     d_in = [(base * gains[i]).contiguous() for i in range(S)]
-    d_out = [torch.empty(blocks * n_out, device=dev, dtype=torch.float32) for _ in range(S)]
+    d_out = [torch.empty(blocks * n_out, device=ctx.dev, dtype=torch.float32) for _ in range(S)]
     batch = ra.FftBatch(hs)
     batch.bind(d_in, d_out, [blocks] * S)
-    stream = torch.cuda.current_stream().cuda_stream
 
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    spinup(lambda: batch.resample_bulk_device(stream), torch, args.spinup_seconds)
-    for _ in range(max(1, args.warmup)):
-        batch.resample_bulk_device(stream)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        batch.resample_bulk_device(stream)
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    def step():
+        batch.resample_bulk_device(ctx.stream)
+    step()
+    spinup(ctx, step, args.spinup_seconds)
+    dt, _ = timed(ctx, step, steps, max(1, warmup))
     hs[0].set_profiling(True)
     k = []
-    for _ in range(5):
-        batch.resample_bulk_device(stream)
+    for _ in range(8):
+        step()
         k.append(hs[0].last_kernel_ms())
     hs[0].set_profiling(False)
     k_ms = float(np.mean(k))
     values_in = S * blocks * n_in
     alg_bytes = 4.0 * S * blocks * (n_in + n_out)
-    if rank == 0:
-        achieved = alg_bytes / (k_ms * 1e-3) / 1e9
-        print(json.dumps({
-            "metric": "Msamples/s (in) 44.1k->48k FFT overlap-add",
-            "value": round(values_in * world * args.steps / dt / 1e6, 1), "unit": "Msamples/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"ResamplerFft 2ch 44100->48000, {S} streams/GPU x {blocks} blocks of "
-                                   f"1176 frames per step, one launch per step"},
-            "roofline": {"bound": "hbm", "kernel": "fft_ola_kernel_ct2 (plan-specialised; fft_ola_kernel for other plans)", "achieved": round(achieved, 1),
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": None, "kernel_ms": round(k_ms, 4), "algorithmic_bytes": int(alg_bytes)},
-        }), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+    line = {
+        "metric": "Msamples/s (in) 44.1k->48k FFT overlap-add",
+        "value": round(values_in * ctx.world * steps / dt / 1e6, 1), "unit": "Msamples/s",
+        "n_gpus": ctx.world, "steps": steps, "warmup": warmup,
+        "ms_per_step": round(dt / steps * 1e3, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"ResamplerFft 2ch 44100->48000, {S} streams/GPU x {blocks} blocks of "
+                               f"1176 frames per step, one launch per step"},
+        "roofline": {"bound": "hbm", "kernel": "fft_ola kernel (plan-specialised build for 1176/1280)",
+                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic_from_profiles("fft"),
+                     "kernel_ms": round(k_ms, 4), "algorithmic_bytes": int(alg_bytes)},
+    }
+    if with_cpu:
+        line["cpu_baseline"] = cpu_baseline_fft(min(args.cpu_seconds, 6.0))
+    return line
 
 
-def main() -> None:
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--path", choices=["fir", "fft"], default="fir",
-                    help="fir = headline metric (default); fft = secondary ResamplerFft line")
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--streams", type=int, default=64, help="streams per GPU")
-    ap.add_argument("--frames", type=int, default=1 << 20, help="input frames per stream per step")
-    ap.add_argument("--chunk", type=int, default=512, help="reference call size in f32 values")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--spinup-seconds", type=float, default=1.0,
-                    help="untimed steps run before the --warmup steps until this much time has passed: "
-                         "the clock governor needs ~50 ms of load to leave its idle state (0 = off)")
-    ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--kernel", choices=["auto", "generic", "periodic", "periodic-vector", "periodic-f32"], default="auto")
-    args = ap.parse_args()
-    if args.path == "fft":
-        bench_fft(args)
-        return
-
-    import torch
+def bench_c4(ctx: Ctx, args, steps: int, warmup: int):
+    """BASELINE config 4: `--c4-streams` independent 2-channel ResamplerFir streams, stream i = ordered
+    pair i mod 6 of the 44.1k / 48k / 96k conversions, lock-step steps of 512 frames; the batch is
+    partitioned over the ranks by predicted work (strong scaling: the batch is fixed, the ranks share
+    it).  A step = one 512-frame chunk for every stream = one launch of fir_lockstep_kernel per GPU.
+    --feed rccl: the chunks of a step sit on GPU 0 and travel to their GPU by RCCL send/recv
+    (scatter-v), the outputs travel back (gather-v); default: chunks are resident on their GPU."""
     import resampler_amd as ra
-    from resampler_amd import synth
+    from resampler_amd import sharding, synth
+    torch = ctx.torch
+    n, frames = args.c4_streams, 512
+    specs = sharding.mixed_rate_batch(n, CHANNELS, frames)
+    lo, hi = sharding.shard(specs, ctx.rank, ctx.world)
+    mine = specs[lo:hi]
+    hs = [ra.ResamplerFir.new_from_hz(s.channels, s.in_hz, s.out_hz, ra.Latency.Sample64,
+                                      ra.Attenuation.Db90, device=ctx.local_rank) for s in mine]
+    ring = 8                                        # chunks of input resident per stream, cycled
+    x = torch.from_numpy(synth.fast_noise(ring * frames * CHANNELS, seed=1 + ctx.rank)).to(ctx.dev)
+    gains = torch.linspace(0.5, 1.0, max(1, len(mine)), device=ctx.dev)
+    d_in = [(x * gains[i]).contiguous() for i in range(len(mine))]
+    caps = [h.buffer_size_output() for h in hs]
+    d_out = [torch.empty(c, device=ctx.dev, dtype=torch.float32) for c in caps]
+    ls = ra.FirLockstep(hs, frames) if hs else None
+    if ls:
+        ls.bind_caps(d_in, d_out, caps)
+    feed = None
+    if args.feed == "rccl" and ctx.dist:
+        feed = RcclFeed(ctx, specs, frames, d_in, d_out)
+    k = [0]
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
-    if not torch.cuda.is_available() or ra.device_count() < 1:
-        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device(f"cuda:{local_rank}")
+    def step():
+        if feed:
+            feed.scatter(k[0] % ring)
+        if ls:
+            ls.step(frames, (k[0] % ring) * frames, append=False, stream=ctx.stream)
+        if feed:
+            feed.gather()
+        k[0] += 1
+    step()
+    spinup(ctx, step, args.spinup_seconds)
+    dt, host_dt = timed(ctx, step, steps, warmup)
+    k_ms = 0.0
+    out_values = 0
+    if ls:
+        ls.set_profiling(True)
+        for _ in range(32):
+            step()
+        k_ms, _ = ls.mean_kernel_ms()
+        ls.set_profiling(False)
+        _, prod = ls.counts()
+        out_values = int(prod.sum())
+    k_ms = ctx.max_over_ranks(k_ms)
+    out_values_all = ctx.sum_over_ranks(float(out_values))
+    values_in = n * CHANNELS * frames
+    # algorithmic bytes of one step: every input value read once, every output value written once
+    alg = 4.0 * (values_in + out_values_all)
+    ach = alg / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+    return {
+        "metric": "Msamples/s (in) config 4: 1024 mixed-rate FIR streams, 512-frame lock-step steps",
+        "value": round(values_in * steps / dt / 1e6, 1), "unit": "Msamples/s", "n_gpus": ctx.world,
+        "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 5),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32 (exact-f32 MFMA)", "data": "synthetic",
+        "config": {"workload": f"{n} ResamplerFir streams 2ch 128-tap (Sample64/Db90), pairs 44.1/48/96 kHz "
+                               f"(6 ordered), {frames}-frame lock-step steps on carried state, one launch per "
+                               f"step and GPU, streams partitioned by predicted work",
+                   "streams_this_rank": len(mine), "workgroups_this_rank": ls.workgroups() if ls else 0,
+                   "feed": "rccl scatter-v/gather-v from GPU 0" if feed else "resident per GPU",
+                   "host_enqueue_ms_per_step": round(host_dt / steps * 1e3, 5)},
+        "roofline": {"bound": "hbm", "kernel": "fir_lockstep_kernel (exact-f32 MFMA, row = stream)",
+                     "achieved": round(ach, 1), "peak": HBM_PEAK_GBS * ctx.world, "unit": "GB/s",
+                     "frac": round(ach / (HBM_PEAK_GBS * ctx.world), 4), "traffic": traffic_from_profiles("c4"),
+                     "kernel_ms": round(k_ms, 5), "algorithmic_bytes": int(alg)},
+    }
 
+
+class RcclFeed:
+    """Scatter-v of a step's input chunks from GPU 0 and gather-v of its outputs back, as one RCCL
+    group of send/recv pairs per direction (torch.distributed.batch_isend_irecv = ncclGroupStart +
+    ncclSend / ncclRecv).  The only exchange the path has; optional."""
+
+    def __init__(self, ctx: Ctx, specs, frames, d_in, d_out):
+        from resampler_amd import sharding
+        torch = ctx.torch
+        self.ctx = ctx
+        self.frames = frames
+        self.parts = sharding.partition([s.work() for s in specs], ctx.world)
+        self.d_in, self.d_out = d_in, d_out
+        self.chunk = frames * CHANNELS
+        lo, hi = self.parts[ctx.rank]
+        self.n_mine = hi - lo
+        self.in_flat = torch.empty(self.n_mine * self.chunk, device=ctx.dev)
+        self.out_cap = max([t.numel() for t in d_out], default=0)
+        self.out_cap = int(ctx.max_over_ranks(float(self.out_cap)))
+        self.out_flat = torch.empty(self.n_mine * self.out_cap, device=ctx.dev)
+        if ctx.rank == 0:   # the staging copies on GPU 0: every rank's chunks / outputs
+            self.stage_in = [torch.rand((b - a) * self.chunk, device=ctx.dev) * 2 - 1 for a, b in self.parts]
+            self.stage_out = [torch.empty((b - a) * self.out_cap, device=ctx.dev) for a, b in self.parts]
+
+    def scatter(self, slot: int):
+        dist, ctx = self.ctx.dist, self.ctx
+        ops = []
+        if ctx.rank == 0:
+            for r in range(1, ctx.world):
+                if self.stage_in[r].numel():
+                    ops.append(dist.P2POp(dist.isend, self.stage_in[r], r))
+            self.in_flat.copy_(self.stage_in[0])
+        elif self.n_mine:
+            ops.append(dist.P2POp(dist.irecv, self.in_flat, 0))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        for i in range(self.n_mine):   # into the slot the step reads
+            self.d_in[i][slot * self.chunk:(slot + 1) * self.chunk].copy_(self.in_flat[i * self.chunk:(i + 1) * self.chunk])
+
+    def gather(self):
+        dist, ctx = self.ctx.dist, self.ctx
+        for i in range(self.n_mine):
+            self.out_flat[i * self.out_cap:i * self.out_cap + self.d_out[i].numel()].copy_(self.d_out[i])
+        ops = []
+        if ctx.rank == 0:
+            for r in range(1, ctx.world):
+                if self.stage_out[r].numel():
+                    ops.append(dist.P2POp(dist.irecv, self.stage_out[r], r))
+            self.stage_out[0].copy_(self.out_flat)
+        elif self.n_mine:
+            ops.append(dist.P2POp(dist.isend, self.out_flat, 0))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+
+
+def bench_fir(ctx: Ctx, args):
+    import resampler_amd as ra
     S, N = args.streams, args.frames
     kernel = {"auto": ra.FirKernel.Auto, "generic": ra.FirKernel.Generic,
               "periodic": ra.FirKernel.Periodic, "periodic-vector": ra.FirKernel.PeriodicVector,
               "periodic-f32": ra.FirKernel.PeriodicF32}[args.kernel]
-    handles = []
-    for _ in range(S):
-        h = ra.ResamplerFir.new(CHANNELS, ra.SampleRate.Hz44100, ra.SampleRate.Hz48000,
-                                ra.Latency.Sample64, ra.Attenuation.Db90, device=local_rank)
-        h.set_kernel(kernel)
-        handles.append(h)
-    # Synthetic input: the sweep, a different gain per stream so every stream has its own buffer.
-    base = torch.from_numpy(synth.sweep(N, CHANNELS, float(IN_HZ))).to(dev)
-    gains = torch.linspace(0.5, 1.0, S, device=dev)
-    d_in = [(base * gains[i]).contiguous() for i in range(S)]
-    cap = handles[0].bulk_output_bound(CHANNELS * N, args.chunk)
-    d_out = [torch.empty(cap, device=dev, dtype=torch.float32) for _ in range(S)]
-    batch = ra.FirBatch(handles)
-    batch.bind(d_in, d_out)
-    stream = torch.cuda.current_stream().cuda_stream
+    handles, batch = make_fir_batch(ctx, ra, S, N, args.chunk, kernel)
 
     def step():
         batch.reset()                     # a fresh stream per step (a new file)
-        return batch.resample_bulk_device(args.chunk, stream)
-
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+        return batch.resample_bulk_device(args.chunk, ctx.stream)
 
     t_plan0 = time.perf_counter()
     consumed, produced = step()          # first step also builds the plan / class table
-    torch.cuda.synchronize()
+    ctx.torch.cuda.synchronize()
     plan_cold_ms = (time.perf_counter() - t_plan0) * 1e3
     assert all(c == CHANNELS * N for c in consumed), "bulk call must consume every frame"
-    spinup(step, torch, args.spinup_seconds)
-    for _ in range(max(0, args.warmup - 1)):
-        step()
+    produced = np.array(produced).copy()
+    spinup(ctx, step, args.spinup_seconds)
     # HIP events bracket the convolution launch of every timed step on the launch stream (recorded
     # inside the library, no host sync between steps): roofline.achieved uses their mean.
-    handles[0].set_profiling(True)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(max(0, args.warmup - 1)):
         step()
-    host_dt = time.perf_counter() - t0      # host-side enqueue time (launches are asynchronous)
-    barrier()
-    dt = time.perf_counter() - t0
+    handles[0].set_profiling(True)
+    dt, host_dt = timed(ctx, step, args.steps, 1 if args.warmup > 0 else 0)
     k_ms, k_launches = handles[0].mean_kernel_ms()
     handles[0].set_profiling(False)
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-
 
     values_in_per_step = S * CHANNELS * N            # per rank
-    values_out_per_step = sum(produced)
+    values_out_per_step = int(produced.sum())
     alg_bytes = 4.0 * (values_in_per_step + values_out_per_step) + 4.0 * 1024 * 128
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9
-
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-    if os.path.exists(tpath):
-        try:
-            tj = json.load(open(tpath))
-            traffic = tj.get("hbm_bytes_per_launch")
-            if tj.get("variant") is not None and tj["variant"] != handles[0].kernel_variant():
-                traffic = None   # the counters were collected for another kernel
-        except Exception:
-            traffic = None
-
     variant = handles[0].kernel_variant()
-    kernel_name = {0: "fir_generic_kernel", 1: "fir_periodic_kernel", 2: "fir_periodic_db_kernel (vector)",
-                   3: "fir_periodic_db_kernel (f32 MFMA)", 4: "fir_split_kernel (bf16x3 MFMA)"}.get(variant, "?")
-    if rank == 0:
-        total_values = values_in_per_step * world * args.steps
-        line = {
-            "metric": "Msamples/s (in) 44.1k->48k FIR 128-tap",
-            "value": round(total_values / dt / 1e6, 1),
-            "unit": "Msamples/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 4),
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f32",
-            "data": "synthetic",
-            "config": {
-                "workload": f"ResamplerFir 2ch interleaved 44100->48000, 128-tap (Sample64/Db90), "
-                            f"{S} streams/GPU x {N}-frame sine sweep per step, bulk driver loop "
-                            f"with {args.chunk}-value calls, one launch per step",
-                "streams_per_gpu": S,
-                "frames_per_stream": N,
-                "kernel": args.kernel,
-                "out_values_per_step": int(values_out_per_step),
-                "plan_cold_ms": round(plan_cold_ms, 2),
-                "spinup_s": args.spinup_seconds,
-                "host_enqueue_ms_per_step": round(host_dt / args.steps * 1e3, 4),
-            },
-            "roofline": {
-                "bound": "hbm",
-                "kernel": kernel_name,
-                "achieved": round(achieved, 1),
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": traffic,
-                "kernel_ms": round(k_ms, 4),
-                "algorithmic_bytes": int(alg_bytes),
-                # useful f32 FMAs (128 taps per output value), T/s: the pipe this kernel is bound by
-                # (f32 MFMA = packed-FMA VALU peak: 78.6 T/s at 2.4 GHz)
-                "fma_per_s": round(values_out_per_step * 128 / (k_ms * 1e-3) / 1e12, 2),
-            },
-        }
-        if not args.no_cpu and world == 1:   # rank 0 at N = 1 only
-            line["cpu_baseline"] = cpu_baseline(N, args.cpu_seconds)
+    line = {
+        "metric": "Msamples/s (in) 44.1k->48k FIR 128-tap",
+        "value": round(values_in_per_step * ctx.world * args.steps / dt / 1e6, 1),
+        "unit": "Msamples/s",
+        "n_gpus": ctx.world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": FIR_DTYPE if variant == 4 else "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": f"ResamplerFir 2ch interleaved 44100->48000, 128-tap (Sample64/Db90), "
+                        f"{S} streams/GPU x {N}-frame sine sweep per step, bulk driver loop "
+                        f"with {args.chunk}-value calls, one launch per step",
+            "streams_per_gpu": S,
+            "frames_per_stream": N,
+            "kernel": args.kernel,
+            "out_values_per_step": values_out_per_step,
+            "plan_cold_ms": round(plan_cold_ms, 2),
+            "spinup_s": args.spinup_seconds,
+            "host_enqueue_ms_per_step": round(host_dt / args.steps * 1e3, 4),
+            "feed": "resident per GPU (no data-path collective)",
+        },
+        "roofline": {
+            "bound": "hbm",
+            "kernel": KERNEL_NAMES.get(variant, "?"),
+            "achieved": round(achieved, 1),
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4),
+            "traffic": traffic_from_profiles("fir", variant),
+            "kernel_ms": round(k_ms, 4),
+            "kernel_launches_timed": int(k_launches),
+            "algorithmic_bytes": int(alg_bytes),
+            # useful f32 FMAs (128 taps per output value), T/s
+            "fma_per_s": round(values_out_per_step * 128 / (k_ms * 1e-3) / 1e12, 2),
+        },
+    }
+    del batch, handles
+    return line
+
+
+def secondary_lines(ctx: Ctx, args):
+    """N = 1 only: the other figures the headline line is read against."""
+    import resampler_amd as ra
+    sec = {}
+    fft = bench_fft(ctx, args, steps=min(args.steps, 20), warmup=2, with_cpu=not args.no_cpu)
+    sec["fft"] = {"metric": fft["metric"], "value": fft["value"], "unit": fft["unit"],
+                  "ms_per_step": fft["ms_per_step"], "workload": fft["config"]["workload"],
+                  "roofline": fft["roofline"], "cpu_baseline": fft.get("cpu_baseline")}
+    sec["fir_exact_f32"] = fir_kernel_point(ctx, ra, args, ra.FirKernel.PeriodicF32, 16)
+    sec["fir_vector_no_mfma"] = fir_kernel_point(ctx, ra, args, ra.FirKernel.PeriodicVector, 16)
+    # the same launch with every stream in a different state: nothing shares a plan
+    t0 = time.perf_counter()
+    handles, batch = make_fir_batch(ctx, ra, args.streams, args.frames, args.chunk, ra.FirKernel.Auto,
+                                    distinct_states=True)
+    t1 = time.perf_counter()
+    batch.resample_bulk_device(args.chunk, ctx.stream)
+    ctx.torch.cuda.synchronize()
+    cold = (time.perf_counter() - t1) * 1e3
+    sec["fir_distinct_states"] = {
+        "what": f"{args.streams} streams in {args.streams} different states, first launch (every stream "
+                f"replays its own control flow on the host, then one launch)",
+        "step_ms_cold": round(cold, 2), "setup_s": round(t1 - t0, 2)}
+    del batch, handles
+    c4 = bench_c4(ctx, args, steps=256, warmup=8)
+    sec["config4"] = {k: c4[k] for k in ("metric", "value", "unit", "ms_per_step", "scaling", "dtype", "config", "roofline")}
+    return sec
+
+
+def main() -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--path", choices=["fir", "fft"], default="fir",
+                    help="fir = headline metric (default); fft = the ResamplerFft line alone")
+    ap.add_argument("--config", choices=["c2", "c4"], default="c2",
+                    help="c2 = headline workload (weak scaling); c4 = 1024 mixed-rate lock-step streams (strong)")
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--streams", type=int, default=64, help="streams per GPU (c2 / fft)")
+    ap.add_argument("--c4-streams", type=int, default=1024, help="streams of the whole config-4 batch")
+    ap.add_argument("--frames", type=int, default=1 << 20, help="input frames per stream per step")
+    ap.add_argument("--chunk", type=int, default=512, help="reference call size in f32 values")
+    ap.add_argument("--feed", choices=["resident", "rccl"], default="resident",
+                    help="c4: rccl = a step's chunks are scattered from GPU 0 and outputs gathered back (RCCL send/recv)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-all-cores-seconds", type=float, default=6.0)
+    ap.add_argument("--spinup-seconds", type=float, default=1.0,
+                    help="untimed steps run before the --warmup steps until this much time has passed: "
+                         "the clock governor needs ~50 ms of load to leave its idle state (0 = off)")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--kernel", choices=["auto", "generic", "periodic", "periodic-vector", "periodic-f32"], default="auto")
+    args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return spawn_ranks(args)       # nothing below has run: this process never touches the GPU
+
+    ctx = Ctx(args)
+    if args.path == "fft":
+        line = bench_fft(ctx, args, args.steps, args.warmup, with_cpu=(not args.no_cpu and ctx.world == 1))
+    elif args.config == "c4":
+        line = bench_c4(ctx, args, args.steps, args.warmup)
+    else:
+        line = bench_fir(ctx, args)
+        if ctx.world == 1 and ctx.rank == 0:
+            if not args.no_cpu:
+                line["cpu_baseline"] = cpu_baseline_fir(args.frames, args.cpu_seconds, args.cpu_all_cores_seconds)
+            if not args.no_secondary:
+                line["secondary"] = secondary_lines(ctx, args)
+    if ctx.rank == 0:
         print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    ctx.close()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

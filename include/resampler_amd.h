@@ -165,6 +165,10 @@ int rsmp_fir_lockstep_counts(rsmp_fir_lockstep* ls, size_t* consumed, size_t* pr
  * two-row form, 4 = the f64 position drifted out of the class tables' tolerance (reference form from then on). */
 int rsmp_fir_lockstep_status(rsmp_fir_lockstep* ls, uint32_t* status);
 int rsmp_fir_lockstep_sync(rsmp_fir_lockstep* ls);
+/* Measurement hooks, as rsmp_fir_set_profiling / rsmp_fir_mean_kernel_ms: HIP events on the launch stream
+ * around every step while enabled; the mean covers the (up to 64) most recent steps. */
+int rsmp_fir_lockstep_set_profiling(rsmp_fir_lockstep* ls, int enable);
+int rsmp_fir_lockstep_mean_kernel_ms(rsmp_fir_lockstep* ls, float* ms, size_t* launches);
 int rsmp_fir_lockstep_reset(rsmp_fir_lockstep* ls);   /* reset() of every stream (resampler_fir.rs:638-642) */
 
 /* ---- host-only: filter design and the (consumed, produced) state machine ----------------------- */

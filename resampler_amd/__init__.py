@@ -139,6 +139,8 @@ _SIGNATURES = [
     ("rsmp_fir_lockstep_status", C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
     ("rsmp_fir_lockstep_sync", C.c_int, [C.c_void_p]),
     ("rsmp_fir_lockstep_reset", C.c_int, [C.c_void_p]),
+    ("rsmp_fir_lockstep_set_profiling", C.c_int, [C.c_void_p, C.c_int]),
+    ("rsmp_fir_lockstep_mean_kernel_ms", C.c_int, [C.c_void_p, C.POINTER(C.c_float), _szp]),
     ("rsmp_design_fir_coeffs", C.c_int, [C.c_uint32, C.c_uint32, C.c_int, C.c_int, _f32p, C.c_size_t]),
     ("rsmp_design_cutoff_kaiser", C.c_double, [C.c_size_t, C.c_double]),
     ("rsmp_fir_plan_new", C.c_void_p, [C.c_uint32, C.c_uint32, C.c_int]),
@@ -487,6 +489,14 @@ class FirLockstep:
 
     def sync(self) -> None:
         _check(lib().rsmp_fir_lockstep_sync(self._h))
+
+    def set_profiling(self, enable: bool) -> None:
+        _check(lib().rsmp_fir_lockstep_set_profiling(self._h, 1 if enable else 0))
+
+    def mean_kernel_ms(self) -> Tuple[float, int]:
+        ms, n = C.c_float(), C.c_size_t()
+        _check(lib().rsmp_fir_lockstep_mean_kernel_ms(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
 
     def reset(self) -> None:
         _check(lib().rsmp_fir_lockstep_reset(self._h))

@@ -22,9 +22,10 @@
 
 namespace rsmp {
 
-constexpr uint32_t kLsWaves = 10;             // waves per workgroup
+constexpr uint32_t kLsWaves = 8;              // waves per workgroup (two workgroups per CU: <= 128 VGPRs)
 constexpr uint32_t kLsMaxSlots = 16;          // streams per workgroup
 constexpr uint32_t kLsSegCap = 40;            // exact position runs kept per stream and step
+constexpr uint32_t kLsMaxBlk = 12;            // 16-tap blocks of a tile window held in registers (row_len <= 192)
 constexpr uint32_t kLsLdsLimit = 160 * 1024;
 
 struct LockstepStream {        // per bound stream, constant between binds (HBM)
@@ -67,6 +68,7 @@ struct LockstepArgs {
     uint64_t in_offset;                   // frames added to every stream's `in`
     uint32_t in_frames;                   // frames offered to every stream (when the array is null)
     uint32_t append;                      // 1: a step's output goes to out + out_cursor; 0: to out
+    unsigned long long* trace;            // diagnostic instantiation only (RSMP_LS_TRACE), else null
 };
 
 constexpr uint32_t kLsStatusRunOverflow = 1;   // more than kLsSegCap position runs in one step

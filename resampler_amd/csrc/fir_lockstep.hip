@@ -22,6 +22,8 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <map>
 #include <mutex>
 
@@ -65,6 +67,8 @@ struct PlanLds {             // one stream's step, in LDS
 };
 static_assert(sizeof(PlanLds) == 64, "PlanLds layout");
 
+static_assert(sizeof(FirMirrorState) <= 96, "state stash slots are 96 bytes");
+
 struct ColLds {              // one column of the matrix product: super period q of a stream
     int32_t frame0;          // span-relative frame of absolute input frame q * a
     int32_t n0;              // step-relative output index of (period q, class 0); may be negative
@@ -83,7 +87,7 @@ struct LsLayout {
 __host__ __device__ inline LsLayout ls_layout(uint32_t slots, uint32_t max_cols, uint32_t wrap_words,
                                               uint32_t wrap_cap, uint32_t region_frames, uint32_t channels) {
     LsLayout l;
-    l.cols = kLsMaxSlots * 64 + 16;                               // PlanLds[16], n_cols + 3 spare words
+    l.cols = kLsMaxSlots * 64 + 16 + kLsMaxSlots * 96;            // PlanLds[16], n_cols + 3 spare words, state stash[16]
     l.segs = (l.cols + max_cols * 16 + 7) & ~7u;
     l.wbits = l.segs + slots * kLsSegCap * 24;
     l.wlist = l.wbits + slots * wrap_words * 4;
@@ -125,8 +129,44 @@ __device__ __forceinline__ float group_sum8(float v) {
     return v;
 }
 
-__global__ __launch_bounds__(kLsWaves * 64) void fir_lockstep_kernel(LockstepArgs args) {
+// The MFMA stream of one unit and one channel pair (NCH = 2: both channels of a frame with one 8-byte
+// LDS read) or single channel (NCH = 1): the B operands of block b + 1 are read while block b's MFMAs
+// issue; the A operands (the tile's coefficients) are already in registers.
+template <int NCH>
+__device__ __forceinline__ void unit_mfma(const v4f (&a_reg)[kLsMaxBlk], uint32_t nblk, const float* xb,
+                                          uint32_t C, v4f& acc0, v4f& acc1) {
+    v2f xc[4], xn[4];
+    auto load4 = [&](v2f (&x)[4], const float* p) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            if constexpr (NCH == 2) x[s] = *reinterpret_cast<const v2f*>(p + 4 * s * C);
+            else x[s] = v2f{p[4 * s * C], 0.f};
+        }
+    };
+    load4(xc, xb);
+#pragma unroll
+    for (uint32_t blk = 0; blk < kLsMaxBlk; ++blk) {
+        if (blk < nblk) {
+            load4(xn, xb + 16 * (blk + 1 < nblk ? blk + 1 : blk) * C);
+            const float av[4] = {a_reg[blk].x, a_reg[blk].y, a_reg[blk].z, a_reg[blk].w};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], xc[s].x, acc0, 0, 0, 0);
+                if constexpr (NCH == 2) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], xc[s].y, acc1, 0, 0, 0);
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) xc[s] = xn[s];
+        }
+    }
+}
+
+// TRACE: diagnostic instantiation (RSMP_LS_TRACE=path): per workgroup the shader clock at the phase
+// boundaries of wave 0 and of wave 1 goes to args.trace; the shipping instantiation has no trace code.
+template <bool TRACE>
+__global__ __launch_bounds__(kLsWaves * 64, kLsWaves / 2) void fir_lockstep_kernel(LockstepArgs args) {   // two workgroups per CU
     extern __shared__ __attribute__((aligned(16))) char lds[];
+    unsigned long long tr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if constexpr (TRACE) tr[0] = __builtin_amdgcn_s_memtime();
     const LockstepGroup g = load_uniform(args.groups + blockIdx.x);
     const uint32_t C = g.channels;
     const uint32_t lane = threadIdx.x & 63;
@@ -134,6 +174,7 @@ __global__ __launch_bounds__(kLsWaves * 64) void fir_lockstep_kernel(LockstepArg
     const LsLayout lay = ls_layout(g.slots, g.max_cols, g.wrap_words, g.wrap_cap, g.region_frames, C);
     PlanLds* plan = reinterpret_cast<PlanLds*>(lds);
     uint32_t* n_cols_p = reinterpret_cast<uint32_t*>(lds + kLsMaxSlots * 64);
+    FirMirrorState* stash = reinterpret_cast<FirMirrorState*>(lds + kLsMaxSlots * 64 + 16);   // new states until every reader of the old ones is done
     ColLds* cols = reinterpret_cast<ColLds*>(lds + lay.cols);
     SegLds* segs = reinterpret_cast<SegLds*>(lds + lay.segs);
     uint32_t* wbits = reinterpret_cast<uint32_t*>(lds + lay.wbits);
@@ -141,13 +182,24 @@ __global__ __launch_bounds__(kLsWaves * 64) void fir_lockstep_kernel(LockstepArg
     float* spans = reinterpret_cast<float*>(lds + lay.spans);
     const uint32_t region_dw = g.region_frames * C;
 
+    // The coefficient tile of a unit (row_len / 16 blocks of 1 KB, L2 resident) is fetched whole into
+    // registers before the unit's first MFMA: one L2 round trip per unit.  (Requesting a wave's first
+    // tile before the planning phase would hide that too, but keeps 48 registers live across the
+    // planner: it spilled under the 128-register cap that two workgroups per CU need.)
+    const uint32_t nblk = g.row_len / 16;
+    v4f a_reg[kLsMaxBlk];
+    auto fetch_tile = [&](uint32_t t) {
+        gconst_f4_ptr gA = (gconst_f4_ptr)(g.class_coef + static_cast<size_t>(t) * nblk * 256) + lane;
+#pragma unroll
+        for (uint32_t b = 0; b < kLsMaxBlk; ++b)
+            if (b < nblk) a_reg[b] = gA[b * 64];
+    };
+
     // ---- A: plan (wave 0) | stage (waves 1..) ---------------------------------------------------
-    FirMirrorState st;          // wave 0, lanes < count
-    uint32_t plan_flags = 0;
     if (wave == 0) {
         if (lane < g.count) {
             const uint32_t gs = g.first + lane;
-            st = args.states[gs];
+            FirMirrorState st = args.states[gs];
             const LockstepStream ls = args.streams[gs];
             uint32_t in_fr = args.in_frames_per_stream ? args.in_frames_per_stream[args.order[gs]] : args.in_frames;
             const uint32_t room = g.span_frames > st.available ? g.span_frames - static_cast<uint32_t>(st.available) : 0u;
@@ -177,41 +229,59 @@ __global__ __launch_bounds__(kLsWaves * 64) void fir_lockstep_kernel(LockstepArg
             pl.out = ls.out + cursor;
             pl.pad = 0;
             plan[lane] = pl;
-            plan_flags = pl.flags;
+            stash[lane] = st;
             args.counts[2 * gs] = c.accepted * C;
             args.counts[2 * gs + 1] = c.produced * C;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        if (lane == 0) {   // the column table: every (stream, super period) pair with outputs in this step
-            uint32_t nc = 0;
-            if (g.periodic)
-                for (uint32_t s = 0; s < g.count; ++s) {
-                    const PlanLds& pl = plan[s];
-                    if (pl.n_out == 0 || (pl.flags & kFlagReference)) continue;
-                    const uint64_t q_first = pl.abs_out / g.b;
-                    const uint64_t q_last = (pl.abs_out + pl.n_out - 1) / g.b;
-                    for (uint64_t q = q_first; q <= q_last && nc < g.max_cols; ++q) {
-                        cols[nc].frame0 = static_cast<int32_t>(static_cast<int64_t>(q * g.a) -
-                                                               static_cast<int64_t>(pl.abs_consumed));
-                        cols[nc].n0 = static_cast<int32_t>(static_cast<int64_t>(q * g.b) -
-                                                           static_cast<int64_t>(pl.abs_out));
-                        cols[nc].slot = s;
-                        cols[nc].pad = 0;
-                        ++nc;
-                    }
-                }
-            *n_cols_p = nc;
+        if constexpr (TRACE) tr[1] = __builtin_amdgcn_s_memtime();   // planned
+        // The column table: every (stream, super period) pair with outputs in this step.  Each planner
+        // lane places its own stream's columns behind those of the lanes before it.
+        uint32_t my_cols = 0;
+        uint64_t q_first = 0;
+        if (lane < g.count && g.periodic) {
+            const PlanLds& pl = plan[lane];
+            if (pl.n_out != 0 && !(pl.flags & kFlagReference)) {
+                q_first = pl.abs_out / g.b;
+                my_cols = static_cast<uint32_t>((pl.abs_out + pl.n_out - 1) / g.b - q_first) + 1;
+            }
         }
+        uint32_t before = 0, total = 0;
+        for (uint32_t s = 0; s < g.count; ++s) {
+            const uint32_t n = __shfl(my_cols, s, 64);
+            if (s < lane) before += n;
+            total += n;
+        }
+        if (lane < g.count) {
+            const PlanLds& pl = plan[lane];
+            for (uint32_t i = 0; i < my_cols && before + i < g.max_cols; ++i) {
+                const uint64_t q = q_first + i;
+                ColLds cl;
+                cl.frame0 = static_cast<int32_t>(static_cast<int64_t>(q * g.a) - static_cast<int64_t>(pl.abs_consumed));
+                cl.n0 = static_cast<int32_t>(static_cast<int64_t>(q * g.b) - static_cast<int64_t>(pl.abs_out));
+                cl.slot = lane;
+                cl.pad = 0;
+                cols[before + i] = cl;
+            }
+        }
+        if (lane == 0) *n_cols_p = total < g.max_cols ? total : g.max_cols;
     } else {
-        // Stage [buffered | new] of every stream; everything else of the region is zero (the guards are
-        // read by masked columns and by zero padding coefficients: they must be finite).
+        // Stage [buffered | new] of every stream with LDS-DMA (global_load_lds, 256 B per wave instruction,
+        // no VGPR round trip: every piece of every stream is in flight at once); everything else of the
+        // region is zeroed (the guards are read by masked columns and by zero padding coefficients: they
+        // must be finite).  The dwords a stream's last, partial piece writes beyond its span are zeroed by
+        // the wave that issued it, after the piece has landed.
+        typedef __attribute__((address_space(3))) void* lds_void_ptr;
         const uint32_t t0 = threadIdx.x - 64;
         const uint32_t nt = (kLsWaves - 1) * 64;
-        for (uint32_t s = 0; s < g.count; ++s) {
-            const uint32_t gs = g.first + s;
-            // wave-uniform: the frames this step accepts (the first lines of mirror_call)
+        // lane s of every staging wave fetches stream s's parameters: one round trip for all streams
+        uint32_t my_hist_dw = 0, my_span_dw = 0;
+        unsigned long long my_hist = 0, my_in = 0;
+        if (lane < g.count) {
+            const uint32_t gs = g.first + lane;
+            // the frames this step accepts (the first lines of mirror_call)
             const uint64_t avail = args.states[gs].available;
             const uint64_t readp = args.states[gs].read_position;
             uint32_t in_fr = args.in_frames_per_stream ? args.in_frames_per_stream[args.order[gs]] : args.in_frames;
@@ -221,24 +291,42 @@ __global__ __launch_bounds__(kLsWaves * 64) void fir_lockstep_kernel(LockstepArg
             const uint64_t rem = kMirrorBufferSize > wp ? kMirrorBufferSize - wp : 0;
             uint64_t acc = in_fr < rem ? in_fr : rem;
             if (acc > kMirrorInputCapacity - avail) acc = kMirrorInputCapacity - avail;
-            const uint32_t hist_dw = static_cast<uint32_t>(avail) * C;
-            const uint32_t span_dw = hist_dw + static_cast<uint32_t>(acc) * C;
-            const uint32_t guard_dw = g.guard_frames * C;
-            gconst_f32_ptr hist = (gconst_f32_ptr)args.streams[gs].hist;
-            gconst_f32_ptr in = (gconst_f32_ptr)(args.streams[gs].in + args.in_offset * C);
+            my_hist_dw = static_cast<uint32_t>(avail) * C;
+            my_span_dw = my_hist_dw + static_cast<uint32_t>(acc) * C;
+            my_hist = reinterpret_cast<unsigned long long>(args.streams[gs].hist);
+            my_in = reinterpret_cast<unsigned long long>(args.streams[gs].in + args.in_offset * C);
+        }
+        const uint32_t guard_dw = g.guard_frames * C;
+        for (uint32_t s = 0; s < g.count; ++s) {
+            const uint32_t hist_dw = __shfl(my_hist_dw, s, 64);
+            const uint32_t span_dw = __shfl(my_span_dw, s, 64);
+            gconst_f32_ptr hist = (gconst_f32_ptr) reinterpret_cast<const float*>(__shfl(my_hist, s, 64));
+            gconst_f32_ptr in = (gconst_f32_ptr) reinterpret_cast<const float*>(__shfl(my_in, s, 64));
             float* region = spans + s * region_dw;
-            for (uint32_t i = t0; i < region_dw; i += nt) {
-                float v = 0.f;
-                if (i >= guard_dw && i < guard_dw + span_dw) {
-                    const uint32_t k = i - guard_dw;
-                    v = k < hist_dw ? hist[k] : in[k - hist_dw];
-                }
-                region[i] = v;
+            const uint32_t pieces = (span_dw + 63) / 64;
+            for (uint32_t p = wave - 1; p < pieces; p += kLsWaves - 1) {
+                const uint32_t k = p * 64 + lane;
+                const uint32_t kc = k < span_dw ? k : span_dw - 1;
+                gconst_f32_ptr src = kc < hist_dw ? hist + kc : in + (kc - hist_dw);
+                __builtin_amdgcn_global_load_lds(src, (lds_void_ptr)(region + guard_dw + p * 64), 4, 0, 0);
+            }
+            for (uint32_t i = t0; i < guard_dw; i += nt) region[i] = 0.f;
+            for (uint32_t i = guard_dw + pieces * 64 + t0; i < region_dw; i += nt) region[i] = 0.f;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own pieces have landed
+        for (uint32_t s = 0; s < g.count; ++s) {
+            const uint32_t span_dw = __shfl(my_span_dw, s, 64);
+            const uint32_t pieces = (span_dw + 63) / 64;
+            if (pieces != 0 && (pieces - 1) % (kLsWaves - 1) == wave - 1) {   // this wave issued the last piece
+                const uint32_t k = (pieces - 1) * 64 + lane;
+                if (k >= span_dw) spans[s * region_dw + guard_dw + k] = 0.f;
             }
         }
     }
+    if constexpr (TRACE) tr[2] = __builtin_amdgcn_s_memtime();   // wave 0: columns built; others: staged
     __syncthreads();
-    if (wave == 0 && lane < g.count) args.states[g.first + lane] = st;   // every reader of the old state is past the barrier
+    if constexpr (TRACE) tr[3] = __builtin_amdgcn_s_memtime();
+    if (wave == 0 && lane < g.count) args.states[g.first + lane] = stash[lane];   // every reader of the old state is past the barrier
 
     // ---- B: retire (tail back to HBM, in place) -------------------------------------------------
     for (uint32_t s = 0; s < g.count; ++s) {
@@ -254,7 +342,6 @@ __global__ __launch_bounds__(kLsWaves * 64) void fir_lockstep_kernel(LockstepArg
     if (n_cols) {
         const uint32_t n_chunks = (n_cols + 15) / 16;
         const uint32_t n_units = n_chunks * g.n_tiles;
-        const uint32_t nblk = g.row_len / 16;
         const bool pair_ok = (C & 1u) == 0;   // both channels of a frame with one 8-byte LDS read
         for (uint32_t u = wave; u < n_units; u += kLsWaves) {
             const uint32_t chunk = u / g.n_tiles;
@@ -270,34 +357,18 @@ __global__ __launch_bounds__(kLsWaves * 64) void fir_lockstep_kernel(LockstepArg
                               static_cast<int32_t>(static_cast<int32_t>(g.guard_frames) + cl.frame0 +
                                                    static_cast<int32_t>(tm.base) + static_cast<int32_t>(lane >> 4)) *
                                   static_cast<int32_t>(C);
-            gconst_f4_ptr gA = (gconst_f4_ptr)(g.class_coef + static_cast<size_t>(t) * nblk * 256) + lane;
+            fetch_tile(t);
             const uint32_t j = t * 16 + 4 * (lane >> 4);          // first of the lane's four classes
             const uint32_t jw = (t * 16 + g.den - 1) / g.den * g.den;   // first class of the tile at an integer position
             for (uint32_t c0 = 0; c0 < C; c0 += 2) {
                 const bool two = c0 + 1 < C;
                 v4f acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-                v4f a_cur = gA[0];
-                v4f a_n1 = gA[(nblk > 1 ? 1u : 0u) * 64];
-                for (uint32_t blk = 0; blk < nblk; ++blk) {
-                    const v4f a_n2 = gA[(blk + 2 < nblk ? blk + 2 : blk) * 64];   // two blocks (8-16 MFMAs) ahead
-                    const float* xp = xb + 16 * blk * C + c0;
-                    const float av[4] = {a_cur.x, a_cur.y, a_cur.z, a_cur.w};
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) {
-                        float x0, x1 = 0.f;
-                        if (two && pair_ok) {
-                            const v2f x = *reinterpret_cast<const v2f*>(xp + 4 * s * C);
-                            x0 = x.x;
-                            x1 = x.y;
-                        } else {
-                            x0 = xp[4 * s * C];
-                            if (two) x1 = xp[4 * s * C + 1];
-                        }
-                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], x0, acc0, 0, 0, 0);
-                        if (two) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], x1, acc1, 0, 0, 0);
-                    }
-                    a_cur = a_n1;
-                    a_n1 = a_n2;
+                if (two && pair_ok) {
+                    unit_mfma<2>(a_reg, nblk, xb + c0, C, acc0, acc1);
+                } else {
+                    v4f unused = {0.f, 0.f, 0.f, 0.f};
+                    unit_mfma<1>(a_reg, nblk, xb + c0, C, acc0, unused);
+                    if (two) unit_mfma<1>(a_reg, nblk, xb + c0 + 1, C, acc1, unused);
                 }
                 // a non-finite sum anywhere in the tile: the stream's step is redone in reference form
                 const float chk = (acc0.x + acc0.y) + (acc0.z + acc0.w) + (acc1.x + acc1.y) + (acc1.z + acc1.w);
@@ -339,6 +410,7 @@ __global__ __launch_bounds__(kLsWaves * 64) void fir_lockstep_kernel(LockstepArg
         }
     }
 
+    if constexpr (TRACE) tr[4] = __builtin_amdgcn_s_memtime();   // units done
     // ---- C: outputs just below an integer position: previous frame, row 1023, frac 0 ----------------
     {
         const uint32_t grp = threadIdx.x >> 3, ngrp = kLsWaves * 8, gl = threadIdx.x & 7;
@@ -375,8 +447,10 @@ __global__ __launch_bounds__(kLsWaves * 64) void fir_lockstep_kernel(LockstepArg
     }
 
     // ---- D: reference form for the streams that need it -------------------------------------------
+    if constexpr (TRACE) tr[5] = __builtin_amdgcn_s_memtime();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // phase B/C stores are acknowledged before D overwrites
     __syncthreads();
+    if constexpr (TRACE) tr[6] = __builtin_amdgcn_s_memtime();
     {
         const uint32_t grp = threadIdx.x >> 3, ngrp = kLsWaves * 8, gl = threadIdx.x & 7;
         for (uint32_t s = 0; s < g.count; ++s) {
@@ -431,7 +505,11 @@ __global__ __launch_bounds__(kLsWaves * 64) void fir_lockstep_kernel(LockstepArg
                                 ((f & kFlagNonFinite) ? kLsStatusNonFinite : 0u) |
                                 (((f & kFlagReference) && g.periodic) ? kLsStatusAperiodic : 0u);
         if (status) args.status[g.first + lane] |= status;
-        (void)plan_flags;
+    }
+    if constexpr (TRACE) {
+        tr[7] = __builtin_amdgcn_s_memtime();
+        if (args.trace && wave < 2 && lane == 0)
+            for (int i = 0; i < 8; ++i) args.trace[(static_cast<size_t>(blockIdx.x) * 2 + wave) * 8 + i] = tr[i];
     }
 }
 
@@ -455,7 +533,7 @@ LockstepGeometry lockstep_geometry(uint64_t num, uint64_t den, double ratio, uin
             g.b = 1;
             g.row_len = g.n_tiles = 0;
             g.guard_frames = 0;
-            g.region_frames = g.span_frames;
+            g.region_frames = g.span_frames + 64;   // (the last staging piece may run 63 dwords past the span)
             g.cols_per_stream = 1;
             g.wrap_cap = 1;
         }
@@ -478,7 +556,7 @@ LockstepGeometry lockstep_geometry(uint64_t num, uint64_t den, double ratio, uin
         uint64_t r = (96 + den - 1) / den;
         if (r == 0) r = 1;
         const uint64_t a = num * r, b = den * r;
-        if (a <= 8192 && b <= 65536 && g.row_len <= 1024) {
+        if (a <= 8192 && b <= 65536 && g.row_len <= 16 * kLsMaxBlk) {
             g.r = static_cast<uint32_t>(r);
             g.a = static_cast<uint32_t>(a);
             g.b = static_cast<uint32_t>(b);
@@ -521,13 +599,40 @@ hipError_t launch_fir_lockstep(const LockstepArgs& args, uint32_t n_groups, uint
         std::lock_guard<std::mutex> lock(mu);
         bool& have = granted[device];
         if (!have) {
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(fir_lockstep_kernel),
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(fir_lockstep_kernel<false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, kLsLdsLimit);
+            if (e != hipSuccess) return e;
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(fir_lockstep_kernel<true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, kLsLdsLimit);
             if (e != hipSuccess) return e;
             have = true;
         }
     }
-    hipLaunchKernelGGL(fir_lockstep_kernel, dim3(n_groups), dim3(kLsWaves * 64), max_lds_bytes, stream, args);
+    static const char* trace_path = getenv("RSMP_LS_TRACE");
+    if (trace_path) {   // diagnostic: one synchronous traced step, phase clocks written to the file
+        LockstepArgs a = args;
+        const size_t words = static_cast<size_t>(n_groups) * 16;
+        unsigned long long* d = nullptr;
+        if (hipMalloc(&d, words * 8) != hipSuccess) return hipErrorOutOfMemory;
+        (void)hipMemset(d, 0, words * 8);
+        a.trace = d;
+        hipLaunchKernelGGL(fir_lockstep_kernel<true>, dim3(n_groups), dim3(kLsWaves * 64), max_lds_bytes, stream, a);
+        (void)hipStreamSynchronize(stream);
+        std::vector<unsigned long long> h(words);
+        (void)hipMemcpy(h.data(), d, words * 8, hipMemcpyDeviceToHost);
+        (void)hipFree(d);
+        if (FILE* f = fopen(trace_path, "a")) {
+            for (uint32_t b = 0; b < n_groups; ++b) {
+                fprintf(f, "%u", b);
+                for (int w = 0; w < 2; ++w)
+                    for (int i = 1; i < 8; ++i) fprintf(f, " %lld", (long long)(h[(b * 2 + w) * 8 + i] - h[(b * 2 + w) * 8]));
+                fprintf(f, "\n");
+            }
+            fclose(f);
+        }
+        return hipGetLastError();
+    }
+    hipLaunchKernelGGL(fir_lockstep_kernel<false>, dim3(n_groups), dim3(kLsWaves * 64), max_lds_bytes, stream, args);
     return hipGetLastError();
 }
 

@@ -38,6 +38,11 @@ struct rsmp_fir_lockstep {
     hipStream_t own_stream = nullptr;
     std::vector<uint64_t> h_counts;
     std::vector<FirMirrorState> h_states;
+    // optional timing of the step launches (rsmp_fir_lockstep_set_profiling): ring of event pairs
+    static constexpr int kProfRing = 64;
+    bool profiling = false;
+    hipEvent_t prof_start[kProfRing] = {}, prof_stop[kProfRing] = {};
+    size_t prof_count = 0;
 };
 
 namespace {
@@ -179,6 +184,8 @@ extern "C" void rsmp_fir_lockstep_free(rsmp_fir_lockstep* ls) {
     DeviceGuard guard(ls->device);
     (void)rsmp_fir_lockstep_sync(ls);
     if (ls->own_stream) (void)hipStreamDestroy(ls->own_stream);
+    for (hipEvent_t e : ls->prof_start) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ls->prof_stop) if (e) (void)hipEventDestroy(e);
     delete ls;
 }
 
@@ -242,7 +249,14 @@ extern "C" int rsmp_fir_lockstep_step(rsmp_fir_lockstep* ls, size_t in_frames, s
     a.in_offset = in_offset_frames;
     a.in_frames = static_cast<uint32_t>(in_frames);
     a.append = append ? 1u : 0u;
+    a.trace = nullptr;
+    if (ls->profiling)
+        RSMP_HIP_CHECK(hipEventRecord(ls->prof_start[ls->prof_count % rsmp_fir_lockstep::kProfRing], s));
     RSMP_HIP_CHECK(rsmp::launch_fir_lockstep(a, static_cast<uint32_t>(ls->groups.size()), ls->max_lds, s));
+    if (ls->profiling) {
+        RSMP_HIP_CHECK(hipEventRecord(ls->prof_stop[ls->prof_count % rsmp_fir_lockstep::kProfRing], s));
+        ++ls->prof_count;
+    }
     ls->last_stream = s;
     return RSMP_OK;
 }
@@ -295,4 +309,36 @@ extern "C" int rsmp_fir_lockstep_reset(rsmp_fir_lockstep* ls) {
     RSMP_HIP_CHECK(hipMemset(ls->d_cursor.get(), 0, n * sizeof(uint64_t)));
     RSMP_HIP_CHECK(hipMemset(ls->d_status.get(), 0, n * sizeof(uint32_t)));
     return upload_states(ls);
+}
+
+extern "C" int rsmp_fir_lockstep_set_profiling(rsmp_fir_lockstep* ls, int enable) {
+    if (!ls) return rsmp::fail(RSMP_ERR_INVALID_ARGUMENT, "rsmp_fir_lockstep_set_profiling: null batch");
+    DeviceGuard guard(ls->device);
+    if (enable && !ls->prof_start[0])
+        for (int i = 0; i < rsmp_fir_lockstep::kProfRing; ++i) {
+            RSMP_HIP_CHECK(hipEventCreate(&ls->prof_start[i]));
+            RSMP_HIP_CHECK(hipEventCreate(&ls->prof_stop[i]));
+        }
+    ls->profiling = enable != 0;
+    ls->prof_count = 0;
+    return RSMP_OK;
+}
+
+extern "C" int rsmp_fir_lockstep_mean_kernel_ms(rsmp_fir_lockstep* ls, float* ms, size_t* launches) {
+    if (!ls || !ms || ls->prof_count == 0)
+        return rsmp::fail(RSMP_ERR_INVALID_ARGUMENT, "rsmp_fir_lockstep_mean_kernel_ms: no profiled step");
+    DeviceGuard guard(ls->device);
+    const size_t ring = rsmp_fir_lockstep::kProfRing;
+    const size_t n = ls->prof_count < ring ? ls->prof_count : ring;
+    RSMP_HIP_CHECK(hipEventSynchronize(ls->prof_stop[(ls->prof_count - 1) % ring]));
+    double sum = 0.0;
+    for (size_t k = 0; k < n; ++k) {
+        const size_t i = (ls->prof_count - 1 - k) % ring;
+        float t = 0.f;
+        RSMP_HIP_CHECK(hipEventElapsedTime(&t, ls->prof_start[i], ls->prof_stop[i]));
+        sum += t;
+    }
+    *ms = static_cast<float>(sum / static_cast<double>(n));
+    if (launches) *launches = n;
+    return RSMP_OK;
 }

@@ -7,8 +7,8 @@
 // reference's f64 recurrence `position += ratio` (:589) bit for bit -- it decides the (consumed,
 // produced) counts and, next to integer positions, the window / phase row of an output -- so the
 // arithmetic below is restricted to operations that are exact or correctly rounded on both sides
-// (f64 add / sub / fma / floor / frexp / ldexp; the one division only seeds a search that is then
-// corrected with exact fma tests).  Build with -ffp-contract=off.
+// (f64 add / sub / fma / floor and exponent-field arithmetic; the one division and the multiply
+// by its result only seed a search that is then corrected with exact fma tests).  Build with -ffp-contract=off.
 //
 // Closed form: inside one binade [2^e, 2^(e+1)) every rounded add moves the position by the same
 // multiple of the binade's ulp, so a run of outputs is p_k = p0 + k*inc with p0, inc and every p_k
@@ -39,7 +39,8 @@ struct FirMirrorState {
     uint64_t abs_consumed;    // input frames retired since reset
     double drift;             // f64 position minus exact rational position at the last integer-position output
     uint32_t periodic_ok;     // 0 once |drift| exceeded what the class tables tolerate
-    uint32_t pad;
+    uint32_t next_int;        // outputs until the next one whose exact position is an integer:
+                              // (den - abs_out % den) % den (den < 2^32: the rates are u32)
 };
 
 struct FirCallCounts {
@@ -48,15 +49,25 @@ struct FirCallCounts {
     uint64_t consumed;   // frames retired from the front of the buffer (:596)
 };
 
-// Largest k >= 0 with p0 + k*inc < bound, given p0 < bound, inc > 0 and every p0 + k*inc up to
-// the bound exactly representable.
-__host__ __device__ inline uint64_t mirror_last_below(double p0, double inc, double bound) {
-    double est = floor((bound - p0) / inc);
-    if (est < 0.0) est = 0.0;
-    uint64_t k = static_cast<uint64_t>(est);
+// Largest k >= 0 with p0 + k*inc < bound, given p0 < bound, inc > 0, every p0 + k*inc up to the bound
+// exactly representable, and a seed `est` (any value; the two loops make the answer exact).
+template <class Idx>
+__host__ __device__ inline Idx mirror_refine_last_below(double p0, double inc, double bound, double est) {
+    Idx k = est >= 1.0 ? static_cast<Idx>(est) : Idx(0);
     while (k > 0 && fma(static_cast<double>(k), inc, p0) >= bound) --k;
     while (fma(static_cast<double>(k + 1), inc, p0) < bound) ++k;
     return k;
+}
+
+__host__ __device__ inline uint64_t mirror_bits(double v) {
+    union { double d; uint64_t u; } x;
+    x.d = v;
+    return x.u;
+}
+__host__ __device__ inline double mirror_from_bits(uint64_t u) {
+    union { double d; uint64_t u; } x;
+    x.u = u;
+    return x.d;
 }
 
 // One reference resample() call in frames.  `Sink` receives the exact position runs
@@ -66,6 +77,102 @@ __host__ __device__ inline uint64_t mirror_last_below(double p0, double inc, dou
 //   sink.wrap(out_index)
 // (floor() then picks the previous input frame and the phase clamps to row 1023, :562-564, instead
 // of row 0 of the next frame -- the one discrete choice that depends on the sign of the f64 drift).
+// The output loop of one call (:542-590) in closed form.  Idx = uint32_t when the output capacity
+// is below 2^31 (32-bit integer and conversion instructions on the device), uint64_t otherwise.
+template <class Idx, class Sink>
+__host__ __device__ inline uint64_t mirror_output_loop(FirMirrorState& st, Idx output_capacity, double limit,
+                                                       double& pos_io, Sink& sink) {
+    Idx count = 0;
+    double pos = pos_io;
+    const bool rational = sink.want_wraps() && st.periodic_ok != 0;
+    const double inv_ratio = 1.0 / st.ratio;   // seeds the run-length searches only (they are then made exact)
+    Idx next_int = static_cast<Idx>(st.next_int);
+    const Idx den = static_cast<Idx>(st.den);   // (only used when rational: den < 2^32)
+    const double den_d = static_cast<double>(st.den);
+    while (count < output_capacity && pos < limit) {
+        Idx run = 0;
+        double inc = 0.0;
+        const uint64_t pbits = mirror_bits(pos);
+        if (pos > 0.0 && (pbits >> 52) != 0) {   // positive and normal
+            const double top = mirror_from_bits(((pbits >> 52) + 1) << 52);  // pos in [top/2, top)
+            const double p1 = pos + st.ratio;
+            if (p1 < top) {
+                inc = p1 - pos;  // exact: same binade
+                const double p2 = p1 + st.ratio;
+                // Equal consecutive increments: RN(ratio) on this binade's grid, with the
+                // round-half-even parity (if ratio is a tie on this grid) already settled.
+                if (p2 < top && (p2 - p1) == inc) {
+                    // n = the largest k with p_k < top: the outputs at p_0 .. p_n lie on this binade's
+                    // grid (n + 1 of them); the add after p_n crosses into the next binade and rounds there.
+                    const Idx room = output_capacity - count;
+                    const double est = floor((top - pos) * inv_ratio);
+                    Idx m;   // outputs of this run
+                    if (est > static_cast<double>(room) + 4.0) {
+                        m = room;
+                    } else {
+                        m = mirror_refine_last_below<Idx>(pos, inc, top, est) + 1;
+                        if (room < m) m = room;
+                    }
+                    if (!(fma(static_cast<double>(m - 1), inc, pos) < limit))   // p_(m-1) must be below the limit
+                        m = mirror_refine_last_below<Idx>(pos, inc, limit, floor((limit - pos) * inv_ratio)) + 1;
+                    run = m;
+                }
+            }
+        }
+        if (run == 0) {
+            run = 1;
+            inc = 0.0;
+        }
+        sink.run(count, run, pos, inc);
+        if (rational && next_int < run) {
+            // Outputs of the run whose exact position n_abs*num/den is an integer (k = next_int,
+            // next_int + den, ...): the rounded f64 position is that integer + d_k with |d_k| tiny,
+            // and d_k moves LINEARLY with k inside a run (every p_k is exact), so its sign changes at
+            // most once: evaluate the two ends, search the change if there is one.
+            const Idx n_int = (run - 1 - next_int) / den + 1;
+            const double next_d = static_cast<double>(next_int);
+            auto dev = [&](Idx i) -> double {   // signed distance of the i-th such position from its integer
+                const double p = fma(fma(static_cast<double>(i), den_d, next_d), inc, pos);
+                const double fr = p - floor(p);
+                return fr > 0.5 ? fr - 1.0 : fr;
+            };
+            const double d_first = dev(0), d_last = n_int > 1 ? dev(n_int - 1) : d_first;
+            st.drift = d_last;
+            if ((d_first < 0.0 ? -d_first : d_first) > 1e-5 || (d_last < 0.0 ? -d_last : d_last) > 1e-5)
+                st.periodic_ok = 0;
+            // wrapped = below the integer (d < 0): floor() picks the previous frame
+            Idx w_begin = 0, w_end = 0;   // [w_begin, w_end) of the n_int positions
+            if (d_first < 0.0 && d_last < 0.0) {
+                w_end = n_int;
+            } else if (d_first < 0.0 || d_last < 0.0) {
+                Idx lo = 0, hi = n_int - 1;   // the sign at lo differs from the sign at hi
+                while (hi - lo > 1) {
+                    const Idx mid = lo + (hi - lo) / 2;
+                    if ((dev(mid) < 0.0) == (d_first < 0.0)) lo = mid; else hi = mid;
+                }
+                if (d_first < 0.0) { w_begin = 0; w_end = hi; } else { w_begin = hi; w_end = n_int; }
+            }
+            for (Idx i = w_begin; i < w_end; ++i)
+                sink.wrap(static_cast<uint64_t>(count) + next_int + static_cast<uint64_t>(i) * st.den);
+            next_int = static_cast<Idx>(static_cast<uint64_t>(next_int) + static_cast<uint64_t>(n_int) * st.den - run);
+        } else if (rational) {
+            next_int -= run;
+        }
+        // next position: p_(run-1) + ratio, one rounded add -- exact (= p_run) while it stays inside the
+        // binade, the reference's rounding when it crosses into the next one
+        pos = fma(static_cast<double>(run - 1), inc, pos) + st.ratio;
+        count += run;
+    }
+    if (rational) {
+        st.next_int = static_cast<uint32_t>(next_int);
+    } else if (count != 0) {   // not tracked run by run: one modulo per call
+        const uint64_t ph = (st.abs_out + count) % st.den;
+        st.next_int = static_cast<uint32_t>(ph ? st.den - ph : 0);
+    }
+    pos_io = pos;
+    return count;
+}
+
 template <class Sink>
 __host__ __device__ inline FirCallCounts mirror_call(FirMirrorState& st, uint64_t input_frames,
                                                      uint64_t output_capacity, Sink& sink) {
@@ -80,54 +187,11 @@ __host__ __device__ inline FirCallCounts mirror_call(FirMirrorState& st, uint64_
     // while pos < available - taps + 1, and while the output has room.
     uint64_t count = 0;
     double pos = st.position;
-    const bool any = st.available >= st.taps;
-    const double limit = any ? static_cast<double>(st.available - st.taps) + 1.0 : 0.0;
-    const bool rational = sink.want_wraps() && st.periodic_ok != 0;
-
-    while (any && count < output_capacity && pos < limit) {
-        uint64_t run = 0;
-        double inc = 0.0;
-        if (pos > 0.0) {
-            int e;
-            (void)frexp(pos, &e);
-            const double top = ldexp(1.0, e);  // pos in [top/2, top)
-            const double p1 = pos + st.ratio;
-            if (p1 < top) {
-                inc = p1 - pos;  // exact: same binade
-                const double p2 = p1 + st.ratio;
-                // Equal consecutive increments: RN(ratio) on this binade's grid, with the
-                // round-half-even parity (if ratio is a tie on this grid) already settled.
-                if (p2 < top && (p2 - p1) == inc) {
-                    uint64_t n = mirror_last_below(pos, inc, top);  // p_n < top: steps 0..n regular
-                    const uint64_t n_valid = mirror_last_below(pos, inc, limit) + 1;  // p_k < limit
-                    if (n_valid < n) n = n_valid;
-                    const uint64_t room = output_capacity - count;
-                    if (room < n) n = room;
-                    run = n;
-                }
-            }
-        }
-        if (run == 0) {
-            run = 1;
-            inc = 0.0;
-        }
-        sink.run(count, run, pos, inc);
-        if (rational) {
-            // Outputs whose exact position n_abs*num/den is an integer: the rounded f64 position is
-            // that integer +- drift.
-            const uint64_t first_abs = st.abs_out + count;
-            uint64_t k = (st.den - first_abs % st.den) % st.den;
-            for (; k < run; k += st.den) {
-                const double p = fma(static_cast<double>(k), inc, pos);
-                const double fr = p - floor(p);
-                const double dist = fr > 0.5 ? 1.0 - fr : fr;
-                st.drift = fr > 0.5 ? fr - 1.0 : fr;
-                if (dist > 1e-5) st.periodic_ok = 0;
-                if (fr > 0.5) sink.wrap(count + k);
-            }
-        }
-        pos = (inc == 0.0) ? pos + st.ratio : fma(static_cast<double>(run), inc, pos);
-        count += run;
+    if (st.available >= st.taps) {
+        const double limit = static_cast<double>(st.available - st.taps) + 1.0;
+        count = output_capacity < 0x7FFFFFF0ull
+                    ? mirror_output_loop<uint32_t>(st, static_cast<uint32_t>(output_capacity), limit, pos, sink)
+                    : mirror_output_loop<uint64_t>(st, output_capacity, limit, pos, sink);
     }
 
     // :596-602

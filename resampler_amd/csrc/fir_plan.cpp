@@ -31,6 +31,7 @@ void FirMirror::reset() {
     st_.abs_consumed = 0;
     st_.periodic_ok = 1;
     st_.drift = 0.0;
+    st_.next_int = 0;
 }
 
 size_t FirMirror::buffer_size_output_frames() const {

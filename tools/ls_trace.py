@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""Phase clocks of fir_lockstep_kernel (diagnostic instantiation, RSMP_LS_TRACE): one traced step of config 4.
+Columns per workgroup: wave 0 = planned, columns built, past barrier, units done, wraps done, past barrier 2, end;
+wave 1 = (unused), staged, past barrier, units done, ...  (shader-clock cycles since kernel entry)."""
+import os, sys, json
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+path = os.path.join(ROOT, "gpurun_out", "ls_trace.txt")
+if os.path.exists(path):
+    os.remove(path)
+import torch
+import resampler_amd as ra
+from resampler_amd import sharding, synth
+dev = torch.device("cuda:0")
+specs = sharding.mixed_rate_batch(1024, 2, 512)
+hs = [ra.ResamplerFir.new_from_hz(2, s.in_hz, s.out_hz, ra.Latency.Sample64, ra.Attenuation.Db90) for s in specs]
+x = torch.from_numpy(synth.fast_noise(8 * 512 * 2, seed=1)).to(dev)
+d_in = [x.clone() for _ in specs]
+caps = [h.buffer_size_output() for h in hs]
+d_out = [torch.empty(c, device=dev) for c in caps]
+ls = ra.FirLockstep(hs, 512)
+ls.bind_caps(d_in, d_out, caps)
+for k in range(4):
+    ls.step(512, (k % 8) * 512)
+ls.counts()
+rows = np.loadtxt(path)
+rows = rows[-ls.workgroups():]          # the last traced step
+names = ["planned", "cols", "barrier1", "units", "wraps", "barrier2", "end"]
+print("workgroups", rows.shape[0])
+for w in range(2):
+    blk = rows[:, 1 + 7 * w: 8 + 7 * w]
+    print(f"wave {w}: " + "  ".join(f"{n} p50 {np.percentile(blk[:, i], 50):.0f} max {blk[:, i].max():.0f}" for i, n in enumerate(names)))
+# by geometry: group rows by their 'end'
+order = np.argsort(rows[:, 7])
+print("slowest workgroups:", rows[order[-5:], 0].astype(int), rows[order[-5:], 7])
