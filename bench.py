@@ -374,27 +374,41 @@ def bench_c4(ctx: Ctx, args, steps: int, warmup: int):
     mine = specs[lo:hi]
     hs = [ra.ResamplerFir.new_from_hz(s.channels, s.in_hz, s.out_hz, ra.Latency.Sample64,
                                       ra.Attenuation.Db90, device=ctx.local_rank) for s in mine]
-    ring = 8                                        # chunks of input resident per stream, cycled
-    x = torch.from_numpy(synth.fast_noise(ring * frames * CHANNELS, seed=1 + ctx.rank)).to(ctx.dev)
-    gains = torch.linspace(0.5, 1.0, max(1, len(mine)), device=ctx.dev)
-    d_in = [(x * gains[i]).contiguous() for i in range(len(mine))]
-    caps = [h.buffer_size_output() for h in hs]
-    d_out = [torch.empty(c, device=ctx.dev, dtype=torch.float32) for c in caps]
+    caps_all = [sharding.buffer_size_output(s) for s in specs]
+    caps = caps_all[lo:hi]
+    assert all(c == h.buffer_size_output() for c, h in zip(caps, hs))
     ls = ra.FirLockstep(hs, frames) if hs else None
+    feed = None
+    ring = 8                                        # chunks of input resident per stream, cycled
+    if args.feed == "rccl":
+        # a step's chunks arrive from GPU 0 and its outputs return there: the streams are bound straight
+        # to their slices of the exchange buffers
+        parts = sharding.partition([s.work() for s in specs], ctx.world)
+        feed = sharding.StepFeed(ctx.dist, ctx.rank, ctx.world, parts, [frames * CHANNELS] * n, caps_all, ctx.dev)
+        stage_in = stage_out = None
+        if ctx.rank == 0:
+            stage_in = [torch.from_numpy(synth.fast_noise(n * frames * CHANNELS, seed=10 + j)).to(ctx.dev) for j in range(ring)]
+            stage_out = torch.empty(sum(caps_all), device=ctx.dev, dtype=torch.float32)
+        d_in = [feed.local_in_view(i) for i in range(lo, hi)]
+        d_out = [feed.local_out_view(i) for i in range(lo, hi)]
+        ring_frames = 0
+    else:
+        x = torch.from_numpy(synth.fast_noise(ring * frames * CHANNELS, seed=1 + ctx.rank)).to(ctx.dev)
+        gains = torch.linspace(0.5, 1.0, max(1, len(mine)), device=ctx.dev)
+        d_in = [(x * gains[i]).contiguous() for i in range(len(mine))]
+        d_out = [torch.empty(c, device=ctx.dev, dtype=torch.float32) for c in caps]
+        ring_frames = frames
     if ls:
         ls.bind_caps(d_in, d_out, caps)
-    feed = None
-    if args.feed == "rccl" and ctx.dist:
-        feed = RcclFeed(ctx, specs, frames, d_in, d_out)
     k = [0]
 
     def step():
         if feed:
-            feed.scatter(k[0] % ring)
+            feed.scatter(stage_in[k[0] % ring] if ctx.rank == 0 else None)
         if ls:
-            ls.step(frames, (k[0] % ring) * frames, append=False, stream=ctx.stream)
+            ls.step(frames, (k[0] % ring) * ring_frames, append=False, stream=ctx.stream)
         if feed:
-            feed.gather()
+            feed.gather(stage_out)
         k[0] += 1
     step()
     spinup(ctx, step, args.spinup_seconds)
@@ -425,69 +439,14 @@ def bench_c4(ctx: Ctx, args, steps: int, warmup: int):
                                f"(6 ordered), {frames}-frame lock-step steps on carried state, one launch per "
                                f"step and GPU, streams partitioned by predicted work",
                    "streams_this_rank": len(mine), "workgroups_this_rank": ls.workgroups() if ls else 0,
-                   "feed": "rccl scatter-v/gather-v from GPU 0" if feed else "resident per GPU",
+                   "feed": "rccl send/recv scatter-v + gather-v through GPU 0, inside the timed step" if feed
+                           else "resident per GPU (no data-path collective)",
                    "host_enqueue_ms_per_step": round(host_dt / steps * 1e3, 5)},
         "roofline": {"bound": "hbm", "kernel": "fir_lockstep_kernel (exact-f32 MFMA, row = stream)",
                      "achieved": round(ach, 1), "peak": HBM_PEAK_GBS * ctx.world, "unit": "GB/s",
                      "frac": round(ach / (HBM_PEAK_GBS * ctx.world), 4), "traffic": traffic_from_profiles("c4"),
                      "kernel_ms": round(k_ms, 5), "algorithmic_bytes": int(alg)},
     }
-
-
-class RcclFeed:
-    """Scatter-v of a step's input chunks from GPU 0 and gather-v of its outputs back, as one RCCL
-    group of send/recv pairs per direction (torch.distributed.batch_isend_irecv = ncclGroupStart +
-    ncclSend / ncclRecv).  The only exchange the path has; optional."""
-
-    def __init__(self, ctx: Ctx, specs, frames, d_in, d_out):
-        from resampler_amd import sharding
-        torch = ctx.torch
-        self.ctx = ctx
-        self.frames = frames
-        self.parts = sharding.partition([s.work() for s in specs], ctx.world)
-        self.d_in, self.d_out = d_in, d_out
-        self.chunk = frames * CHANNELS
-        lo, hi = self.parts[ctx.rank]
-        self.n_mine = hi - lo
-        self.in_flat = torch.empty(self.n_mine * self.chunk, device=ctx.dev)
-        self.out_cap = max([t.numel() for t in d_out], default=0)
-        self.out_cap = int(ctx.max_over_ranks(float(self.out_cap)))
-        self.out_flat = torch.empty(self.n_mine * self.out_cap, device=ctx.dev)
-        if ctx.rank == 0:   # the staging copies on GPU 0: every rank's chunks / outputs
-            self.stage_in = [torch.rand((b - a) * self.chunk, device=ctx.dev) * 2 - 1 for a, b in self.parts]
-            self.stage_out = [torch.empty((b - a) * self.out_cap, device=ctx.dev) for a, b in self.parts]
-
-    def scatter(self, slot: int):
-        dist, ctx = self.ctx.dist, self.ctx
-        ops = []
-        if ctx.rank == 0:
-            for r in range(1, ctx.world):
-                if self.stage_in[r].numel():
-                    ops.append(dist.P2POp(dist.isend, self.stage_in[r], r))
-            self.in_flat.copy_(self.stage_in[0])
-        elif self.n_mine:
-            ops.append(dist.P2POp(dist.irecv, self.in_flat, 0))
-        if ops:
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()
-        for i in range(self.n_mine):   # into the slot the step reads
-            self.d_in[i][slot * self.chunk:(slot + 1) * self.chunk].copy_(self.in_flat[i * self.chunk:(i + 1) * self.chunk])
-
-    def gather(self):
-        dist, ctx = self.ctx.dist, self.ctx
-        for i in range(self.n_mine):
-            self.out_flat[i * self.out_cap:i * self.out_cap + self.d_out[i].numel()].copy_(self.d_out[i])
-        ops = []
-        if ctx.rank == 0:
-            for r in range(1, ctx.world):
-                if self.stage_out[r].numel():
-                    ops.append(dist.P2POp(dist.irecv, self.stage_out[r], r))
-            self.stage_out[0].copy_(self.out_flat)
-        elif self.n_mine:
-            ops.append(dist.P2POp(dist.isend, self.out_flat, 0))
-        if ops:
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()
 
 
 def bench_fir(ctx: Ctx, args):

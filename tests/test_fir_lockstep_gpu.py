@@ -238,3 +238,36 @@ def test_rejects_small_output_and_busy_streams():
         ls.step(513)            # more than the batch was created for
     with pytest.raises(ra.ResampleError):
         ra.FirLockstep([h, h], 512)
+
+
+def test_sharded_step_feed_on_device():
+    # The per-rank device path of the multi-GPU form (bench.py --config c4 --feed rccl) at world size 1:
+    # a step's chunks arrive through sharding.StepFeed's exchange buffers, the streams are bound straight
+    # to their slices of them, the outputs leave through the gather side.  (World 2 moves the same
+    # buffers over gloo in tests/test_sharding_gloo.py.)
+    import torch
+    dev = torch.device("cuda:0")
+    n, frames, steps = 30, 512, 5
+    specs = sharding.mixed_rate_batch(n, 2, frames)
+    parts = sharding.partition([s.work() for s in specs], 1)
+    caps = [sharding.buffer_size_output(s) for s in specs]
+    hs = [ra.ResamplerFir.new_from_hz(2, s.in_hz, s.out_hz, ra.Latency.Sample64, ra.Attenuation.Db90) for s in specs]
+    assert caps == [h.buffer_size_output() for h in hs]
+    refs = [o.OracleFir(2, s.in_hz, s.out_hz, 128, 90) for s in specs]
+    feed = sharding.StepFeed(None, 0, 1, parts, [frames * 2] * n, caps, dev)
+    ls = ra.FirLockstep(hs, frames)
+    ls.bind_caps([feed.local_in_view(i) for i in range(n)], [feed.local_out_view(i) for i in range(n)], caps)
+    stage_out = torch.zeros(sum(caps), device=dev)
+    rng = np.random.default_rng(77)
+    for k in range(steps):
+        x = (rng.random(n * frames * 2, dtype=np.float32) * 2 - 1).astype(np.float32)
+        feed.scatter(torch.from_numpy(x).to(dev))
+        ls.step(frames, 0, stream=torch.cuda.current_stream().cuda_stream)
+        feed.gather(stage_out)
+        cons, prod = ls.counts()
+        got = stage_out.cpu().numpy()
+        for i in range(n):
+            out = np.zeros(caps[i], np.float32)
+            rc, c, p = refs[i].resample(x[i * frames * 2:(i + 1) * frames * 2], out)
+            assert rc == 0 and (int(cons[i]), int(prod[i])) == (c, p)
+            assert rms(got[feed.out_off[i]:feed.out_off[i] + p], out[:p]) <= RMS_TOL
