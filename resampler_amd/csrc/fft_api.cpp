@@ -118,7 +118,8 @@ struct rsmp_fft {
     size_t channels = 0;
     uint32_t in_hz = 0, out_hz = 0;
     std::shared_ptr<DevicePlan> plan;
-    float* d_overlap = nullptr;   // [channels][fft_out], zero at construction (:81)
+    float* d_overlap = nullptr;   // 2 x [channels][fft_out] (ping-pong per launch), zero at construction (:81)
+    int cur = 0;
     hipStream_t stream = nullptr;
     hipEvent_t desc_copied = nullptr;
     bool desc_pending = false;
@@ -157,7 +158,9 @@ int launch_fft_jobs(rsmp_fft* leader, const std::vector<FftJob>& jobs, hipStream
         const FftJob& j = jobs[i];
         h[i].in = j.d_in;
         h[i].out = j.d_out;
-        h[i].overlap = j.r->d_overlap;
+        const size_t ov = j.r->channels * j.r->plan->host.fft_out;
+        h[i].overlap = j.r->d_overlap + j.r->cur * ov;
+        h[i].overlap_next = j.r->d_overlap + (j.r->cur ^ 1) * ov;
         h[i].n_blocks = static_cast<uint32_t>(j.n_blocks);
         h[i].channels = static_cast<uint32_t>(j.r->channels);
         if (h[i].n_blocks > max_blocks) max_blocks = h[i].n_blocks;
@@ -174,6 +177,8 @@ int launch_fft_jobs(rsmp_fft* leader, const std::vector<FftJob>& jobs, hipStream
         RSMP_HIP_CHECK(hipEventRecord(leader->prof_stop, stream));
         leader->prof_valid = true;
     }
+    for (const FftJob& j : jobs)
+        if (j.n_blocks != 0) j.r->cur ^= 1;   // (a stream without blocks in this launch keeps its state where it is)
     return RSMP_OK;
 }
 
@@ -210,7 +215,7 @@ extern "C" rsmp_fft* rsmp_fft_new(size_t channels, int input_rate, int output_ra
     r->out_hz = out_hz;
     if (get_plan(device, in_hz, out_hz, &r->plan) != RSMP_OK) return nullptr;
     if (check_lds(r.get()) != RSMP_OK) return nullptr;
-    const size_t ov_bytes = channels * r->plan->host.fft_out * sizeof(float);
+    const size_t ov_bytes = 2 * channels * r->plan->host.fft_out * sizeof(float);
     if (hipMalloc(&r->d_overlap, ov_bytes) != hipSuccess || hipMemset(r->d_overlap, 0, ov_bytes) != hipSuccess ||
         hipStreamSynchronize(nullptr) != hipSuccess ||   // (the handle's stream is non-blocking: no implicit order)
         hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking) != hipSuccess ||

@@ -29,7 +29,9 @@ struct FftPlanDev {
 struct FftStreamDesc {
     const float* in;      // interleaved, n_blocks * fft_in * channels values
     float* out;           // interleaved, n_blocks * fft_out * channels values
-    float* overlap;       // stream state: [channels][fft_out] (resampler_fft.rs:51)
+    const float* overlap; // stream state before the launch: [channels][fft_out] (resampler_fft.rs:51)
+    float* overlap_next;  // receives the state after the launch (another buffer: the workgroup that reads
+                          // the old state and the one that writes the new one are not ordered)
     uint32_t n_blocks;
     uint32_t channels;
 };
@@ -41,6 +43,11 @@ constexpr uint32_t kFftRun = 16;
 hipError_t launch_fft_ola(const FftPlanDev& plan, const FftStreamDesc* d_descs, uint32_t n_streams,
                           uint32_t max_blocks, uint32_t max_channels, uint32_t min_channels,
                           hipStream_t stream);
+// Wave-per-transform build (fft_wave.hip) for the plans it is instantiated for; hipErrorNotSupported
+// otherwise (launch_fft_ola then falls back to the workgroup kernels by itself).
+hipError_t launch_fft_ola_wave(const FftPlanDev& plan, const FftStreamDesc* d_descs, uint32_t n_streams,
+                               uint32_t max_blocks, uint32_t max_channels, uint32_t min_channels,
+                               hipStream_t stream);
 // filter_spectrum[0 .. fft_in] = forward real FFT of d_filter_time[0 .. 2*fft_in)
 // (resampler_fft.rs:375-376); plan.filter is ignored.
 hipError_t launch_fft_filter_spectrum(const FftPlanDev& plan, const float* d_filter_time,

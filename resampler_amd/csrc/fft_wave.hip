@@ -1,0 +1,387 @@
+// fft_wave.hip -- ResamplerFft block pipeline, ONE WAVE per transform (gfx950).
+//
+// Replaces the same reference code as fft_kernels.hip (FftResampler::resample, src/resampler_fft.rs:385-424;
+// RadixFFT forward / inverse, src/fft/radix_fft.rs:476-670; the Stockham stages and butterflies; the
+// real<->complex passes, src/fft/real_complex/mod.rs:37-114) for the plans it is instantiated for.
+//
+// Why another mapping: with a workgroup per transform every one of the ~14 phases of a block ends in a
+// workgroup barrier and costs about a microsecond however little it computes (43 % of the wave time at
+// barriers).  Here a wave owns a (stream, channel) and walks a run of its blocks alone:
+//   * the 1176 / 1280 complex points live in ONE private LDS buffer (10 KB per wave); a Stockham stage
+//     reads all of the wave's butterflies into registers, then writes the results back in place -- the LDS
+//     executes a wave's operations in order, so no barrier or fence exists anywhere in the kernel;
+//   * the first forward stage takes its inputs straight from HBM (the zero padding never exists), the
+//     last inverse stage leaves its outputs in registers, where the overlap carry of the (stream, channel)
+//     also lives for the whole run: conjugation, overlap-add and the interleaved store happen there;
+//   * real-FFT post-process, filter multiply, truncate / zero-extend, inverse pre-process and the input
+//     conjugation of the inverse transform are two in-place passes over bin pairs;
+//   (Requesting the next block's samples ahead of the transform costs 28 registers and spilled under the
+//   168-register cap of three waves per SIMD; the other eleven waves of the CU cover the load latency.)
+// Arithmetic, operation order and tables are those of fft_kernels.hip (and of the reference's scalar
+// specs): results are bit-identical to the workgroup kernels.
+// The two (or C) waves of a block's channels sit in one workgroup, so their half-line stores of the
+// interleaved output meet in the same L2.
+#include <cmath>
+#include <cstdlib>
+
+#ifdef RSMP_FFT_WAVE_FMA
+#pragma clang fp contract(fast)
+#endif
+
+#include "fft_butterflies.h"
+#include "fft_kernels.h"
+
+namespace rsmp {
+
+namespace {
+
+constexpr int kWavesPerGroup = 4;
+
+// Lanes of a wave exchange data through the wave's LDS buffer without any barrier: the hardware executes a
+// wave's LDS operations in issue order.  The COMPILER, however, reasons per thread and may move a thread's
+// store above its own loads of provably different addresses -- which are other lanes' data here (it did,
+// in the radix-4 stage).  This pins the program order of memory operations; it emits no instruction.
+__device__ __forceinline__ void lds_order() { asm volatile("" ::: "memory"); }
+
+template <int N_, int... Rs> struct WavePlan;
+template <int N_, int R0, int R1, int R2, int R3>
+struct WavePlan<N_, R0, R1, R2, R3> {
+    static constexpr int N = N_;
+    static constexpr int kR[4] = {R0, R1, R2, R3};
+    static_assert(R0 * R1 * R2 * R3 == N_, "radices");
+    static bool matches(uint32_t n, uint32_t n_stages, const uint32_t* radix) {
+        return n == static_cast<uint32_t>(N_) && n_stages == 4 && radix[0] == R0 && radix[1] == R1 &&
+               radix[2] == R2 && radix[3] == R3;
+    }
+};
+
+// One Stockham stage in place in the wave's LDS buffer: butterfly i reads buf[i + q*M], twiddles inputs
+// 1..R-1 with w[(i mod STRIDE)*(R-1) + q-1] and writes buf[R*i - (R-1)*k + q*STRIDE]
+// (butterfly4/mod.rs:316-320 etc.).  Every read of the stage is issued before its first write.
+template <int N, int R, int STRIDE>
+__device__ __forceinline__ void wave_stage(float2* buf, const float2* __restrict__ tw, int lane) {
+    constexpr int M = N / R;
+    constexpr int ITER = (M + 63) / 64;
+    float2 t[ITER][R];
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+        const int i = lane + 64 * it;
+        if ((it + 1) * 64 <= M || i < M) {
+#pragma unroll
+            for (int q = 0; q < R; ++q) t[it][q] = buf[i + q * M];
+        }
+    }
+    lds_order();
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+        const int i = lane + 64 * it;
+        if ((it + 1) * 64 <= M || i < M) {
+            const int k = i % STRIDE;
+            const float2* w = tw + k * (R - 1);
+#pragma unroll
+            for (int q = 1; q < R; ++q) t[it][q] = cmul(w[q - 1], t[it][q]);
+            float2 o[R];
+            dft<R>(t[it], o);
+            float2* d = buf + R * i - (R - 1) * k;
+#pragma unroll
+            for (int q = 0; q < R; ++q) d[q * STRIDE] = o[q];
+        }
+        lds_order();   // (also keeps the scheduler from hoisting every iteration's twiddle loads: registers)
+    }
+}
+
+// postprocess_fft (radix_fft.rs:500-537 + real_complex/mod.rs:37-74), in place on x[0 .. N2].
+template <int N2>
+__device__ __forceinline__ void wave_postprocess(float2* x, const float2* __restrict__ rc, int lane) {
+    constexpr int ITERS = (N2 + 1) / 2 - 1;
+    constexpr int TRIPS = (ITERS + 63) / 64;
+    if (lane == 0) {
+        const float2 z0 = x[0];
+        x[0] = make_float2(z0.x + z0.y, 0.0f);
+        x[N2] = make_float2(z0.x - z0.y, 0.0f);
+    }
+#pragma unroll
+    for (int it = 0; it < TRIPS; ++it) {
+        const int i = lane + 64 * it;
+        if (i < ITERS) {
+            const int l = 1 + i, rr = N2 - 1 - i;
+            const float2 o = x[l], orv = x[rr], tw = rc[i];
+            const float2 sum = cadd(o, orv), diff = csub(o, orv);
+            const float half_sum_real = 0.5f * sum.x, half_diff_imag = 0.5f * diff.y;
+            const float real = sum.y * tw.x + diff.x * tw.y;
+            const float imag = sum.y * tw.y - diff.x * tw.x;
+            x[l] = make_float2(half_sum_real + real, half_diff_imag + imag);
+            x[rr] = make_float2(half_sum_real - real, imag - half_diff_imag);
+        }
+        if (it & 1) lds_order();   // two trips in flight at a time (bounds the registers the scheduler spends on hoisted loads)
+    }
+    if (((N2 + 1) & 1) && lane == 32) x[(N2 + 1) / 2].y = -x[(N2 + 1) / 2].y;
+    lds_order();
+}
+
+// resampler_fft.rs:401-408 (multiply new_length bins by the filter spectrum, zero the rest up to FO),
+// preprocess_ifft (radix_fft.rs:592-624 + real_complex/mod.rs:84-114) and the input conjugation of
+// process_inverse_complex (:634-637), fused over the bin pairs (l, FO - l), in place.
+template <int FO>
+__device__ __forceinline__ void wave_filter_preprocess(float2* y, const float2* __restrict__ filter,
+                                                       uint32_t new_length, const float2* __restrict__ rc, int lane) {
+    constexpr int ITERS = (FO + 1) / 2 - 1;
+    constexpr int TRIPS = (ITERS + 63) / 64;
+    auto bin = [&](int k) -> float2 {
+        return static_cast<uint32_t>(k) < new_length ? cmul(y[k], filter[k]) : make_float2(0.f, 0.f);
+    };
+    float2 first = make_float2(0.f, 0.f), mid = make_float2(0.f, 0.f);
+    if (lane == 0) {
+        const float2 a = bin(0), b = bin(FO);
+        const float2 first_sum = cadd(a, b), first_diff = csub(a, b);
+        first = make_float2(first_sum.x - first_sum.y, first_diff.x - first_diff.y);
+    }
+    if (((FO + 1) & 1) && lane == 32) {
+        const float2 c = bin((FO + 1) / 2);
+        const float2 dbl = cadd(c, c);
+        mid = make_float2(dbl.x, -dbl.y);
+    }
+#pragma unroll
+    for (int it = 0; it < TRIPS; ++it) {
+        const int i = lane + 64 * it;
+        if (i < ITERS) {
+            const int l = 1 + i, rr = FO - 1 - i;
+            const float2 a = bin(l), b = bin(rr), tw = rc[i];
+            const float2 sum = cadd(a, b), diff = csub(a, b);
+            const float real = sum.y * tw.x + diff.x * tw.y;
+            const float imag = sum.y * tw.y - diff.x * tw.x;
+            y[l] = make_float2(sum.x - real, -(diff.y - imag));
+            y[rr] = make_float2(sum.x + real, -(-imag - diff.y));
+        }
+        if (it & 1) lds_order();
+    }
+    if (lane == 0) y[0] = make_float2(first.x, -first.y);
+    if (((FO + 1) & 1) && lane == 32) y[(FO + 1) / 2] = make_float2(mid.x, -mid.y);
+    lds_order();
+}
+
+// OCC: waves per SIMD the register allocation aims at (2: ~205 registers, no scratch; 3: 168 registers).
+template <class FWD, class INV, bool C2, int OCC>
+__global__ __launch_bounds__(kWavesPerGroup * 64, OCC) void fft_ola_wave_kernel(FftPlanDev plan,
+                                                                              const FftStreamDesc* __restrict__ descs,
+                                                                              uint32_t run, uint32_t runs_per_stream,
+                                                                              uint32_t total_waves) {
+    extern __shared__ __attribute__((aligned(16))) float2 lds2[];
+    constexpr int FI = FWD::N, FO = INV::N;
+    constexpr int LDSC = (FI > FO ? FI : FO) + 2;
+    constexpr int R1 = FWD::kR[0], M1 = FI / R1, ITER1 = (M1 + 63) / 64, QV = (R1 + 1) / 2;
+    constexpr int RL = INV::kR[3], ML = FO / RL, ITERL = (ML + 63) / 64, HL = RL / 2;
+    static_assert(RL % 2 == 0, "the last inverse stage splits its outputs into output half and carry half");
+    static_assert(FI % 2 == 0 && FO % 2 == 0, "frame pairs");
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t gw = blockIdx.x * kWavesPerGroup + wave;
+    if (gw >= total_waves) return;      // (no barrier anywhere: waves are independent)
+    float2* buf = lds2 + wave * LDSC;
+
+    // wave -> (stream, run of blocks, channel); the channels of a run are neighbouring waves
+    const uint32_t stream_idx = gw / (runs_per_stream * (C2 ? 2u : descs[0].channels));
+    const FftStreamDesc d = descs[stream_idx];
+    const uint32_t C = C2 ? 2u : d.channels;
+    const uint32_t in_stream = gw - stream_idx * runs_per_stream * C;
+    const uint32_t run_idx = in_stream / C;
+    const uint32_t ch = in_stream - run_idx * C;
+    const uint32_t first = run_idx * run;
+    if (first >= d.n_blocks) return;
+    const uint32_t last = first + run < d.n_blocks ? first + run : d.n_blocks;  // exclusive
+
+    // overlap carried into the run: the stream state, or the predecessor block recomputed (not emitted)
+    float2 carry[ITERL][HL];
+#pragma unroll
+    for (int it = 0; it < ITERL; ++it) {
+        const int i = lane + 64 * it;
+#pragma unroll
+        for (int q = 0; q < HL; ++q) {
+            carry[it][q] = make_float2(0.f, 0.f);
+            if (first == 0 && i < ML) {
+                const int c = i + q * ML;   // complex index = reals 2c, 2c + 1 of the channel's overlap row
+                carry[it][q] = make_float2(d.overlap[ch * FO + 2 * c], d.overlap[ch * FO + 2 * c + 1]);
+            }
+        }
+    }
+    const int64_t b_begin = first == 0 ? 0 : static_cast<int64_t>(first) - 1;
+
+    // complex j of the block's channel = frames 2j, 2j + 1 (j < FI / 2), zero beyond (resampler_fft.rs:387-388)
+    auto load_block = [&](int64_t b, float2 (&x)[ITER1][QV]) {
+        const float* xin = d.in + static_cast<size_t>(b) * FI * C;
+#pragma unroll
+        for (int it = 0; it < ITER1; ++it) {
+            const int i = lane + 64 * it;
+#pragma unroll
+            for (int q = 0; q < QV; ++q) {
+                const int j = i + q * M1;
+                float2 v = make_float2(0.f, 0.f);
+                if (i < M1 && j < FI / 2) {
+                    if constexpr (C2) {
+                        const float4 f = reinterpret_cast<const float4*>(xin)[j];
+                        v = ch == 0 ? make_float2(f.x, f.z) : make_float2(f.y, f.w);
+                    } else {
+                        v = make_float2(xin[static_cast<size_t>(2 * j) * C + ch], xin[static_cast<size_t>(2 * j + 1) * C + ch]);
+                    }
+                }
+                x[it][q] = v;
+            }
+        }
+    };
+
+    for (int64_t b = b_begin; b < static_cast<int64_t>(last); ++b) {
+        const bool emit = b >= static_cast<int64_t>(first);
+        float2 xcur[ITER1][QV];
+        load_block(b, xcur);
+        // ---- forward stage 1 (stride 1, no twiddles) straight from the loaded samples
+#pragma unroll
+        for (int it = 0; it < ITER1; ++it) {
+            const int i = lane + 64 * it;
+            if ((it + 1) * 64 <= M1 || i < M1) {
+                float2 t[R1], o[R1];
+#pragma unroll
+                for (int q = 0; q < R1; ++q) t[q] = q < QV ? xcur[it][q] : make_float2(0.f, 0.f);
+                dft<R1>(t, o);
+#pragma unroll
+                for (int q = 0; q < R1; ++q) buf[R1 * i + q] = o[q];
+            }
+        }
+        lds_order();
+
+        constexpr int S1 = R1, S2 = S1 * FWD::kR[1], S3 = S2 * FWD::kR[2];
+        constexpr int T1 = 0, T2 = T1 + S1 * (FWD::kR[1] - 1), T3 = T2 + S2 * (FWD::kR[2] - 1);
+        wave_stage<FI, FWD::kR[1], S1>(buf, plan.tw_f + T1, lane);
+        wave_stage<FI, FWD::kR[2], S2>(buf, plan.tw_f + T2, lane);
+        wave_stage<FI, FWD::kR[3], S3>(buf, plan.tw_f + T3, lane);
+        wave_postprocess<FI>(buf, plan.rc_f, lane);
+        wave_filter_preprocess<FO>(buf, plan.filter, plan.new_length, plan.rc_i, lane);
+
+        constexpr int IS1 = INV::kR[0], IS2 = IS1 * INV::kR[1];
+        constexpr int IT1 = 0, IT2 = IT1 + IS1 * (INV::kR[1] - 1), IT3 = IT2 + IS2 * (INV::kR[2] - 1);
+        {   // inverse stage 1: stride 1, no twiddles
+            constexpr int R = INV::kR[0], M = FO / R, ITER = (M + 63) / 64;
+            float2 t[ITER][R];
+#pragma unroll
+            for (int it = 0; it < ITER; ++it) {
+                const int i = lane + 64 * it;
+                if ((it + 1) * 64 <= M || i < M) {
+#pragma unroll
+                    for (int q = 0; q < R; ++q) t[it][q] = buf[i + q * M];
+                }
+            }
+            lds_order();
+#pragma unroll
+            for (int it = 0; it < ITER; ++it) {
+                const int i = lane + 64 * it;
+                if ((it + 1) * 64 <= M || i < M) {
+                    float2 o[R];
+                    dft<R>(t[it], o);
+#pragma unroll
+                    for (int q = 0; q < R; ++q) buf[R * i + q] = o[q];
+                }
+            }
+            lds_order();
+        }
+        wave_stage<FO, INV::kR[1], IS1>(buf, plan.tw_i + IT1, lane);
+        wave_stage<FO, INV::kR[2], IS2>(buf, plan.tw_i + IT2, lane);
+        // ---- last inverse stage: outputs stay in registers.  Butterfly i (k = i) yields Z[i + q*ML]; the
+        // output conjugation (radix_fft.rs:656-669) makes reals 2c, 2c + 1 of the channel out of Z[c]; the
+        // first FO reals are overlap-added and stored, the second FO become the next overlap (:416-423).
+        float* xout = d.out + static_cast<size_t>(b) * FO * C;
+#pragma unroll
+        for (int it = 0; it < ITERL; ++it) {
+            const int i = lane + 64 * it;
+            if ((it + 1) * 64 <= ML || i < ML) {
+                float2 t[RL], o[RL];
+#pragma unroll
+                for (int q = 0; q < RL; ++q) t[q] = buf[i + q * ML];
+                const float2* w = plan.tw_i + IT3 + i * (RL - 1);
+#pragma unroll
+                for (int q = 1; q < RL; ++q) t[q] = cmul(w[q - 1], t[q]);
+                dft<RL>(t, o);
+#pragma unroll
+                for (int q = 0; q < HL; ++q) {
+                    const int c = i + q * ML;
+                    if (emit) {
+                        xout[static_cast<size_t>(2 * c) * C + ch] = o[q].x + carry[it][q].x;
+                        xout[static_cast<size_t>(2 * c + 1) * C + ch] = -o[q].y + carry[it][q].y;
+                    }
+                    carry[it][q] = make_float2(o[q + HL].x, -o[q + HL].y);
+                }
+            }
+        }
+        lds_order();
+    }
+    if (last == d.n_blocks) {
+#pragma unroll
+        for (int it = 0; it < ITERL; ++it) {
+            const int i = lane + 64 * it;
+            if (i < ML) {
+#pragma unroll
+                for (int q = 0; q < HL; ++q) {
+                    const int c = i + q * ML;
+                    d.overlap_next[ch * FO + 2 * c] = carry[it][q].x;
+                    d.overlap_next[ch * FO + 2 * c + 1] = carry[it][q].y;
+                }
+            }
+        }
+    }
+}
+
+typedef WavePlan<1176, 3, 7, 7, 8> W1176;
+typedef WavePlan<1280, 4, 5, 8, 8> W1280;
+
+}  // namespace
+
+// Wave-per-transform kernels exist for the 44.1 <-> 48 kHz family (both directions).  Returns
+// hipErrorNotSupported when the plan is another one (the caller then uses the workgroup kernels).
+hipError_t launch_fft_ola_wave(const FftPlanDev& plan, const FftStreamDesc* d_descs, uint32_t n_streams,
+                               uint32_t max_blocks, uint32_t max_channels, uint32_t min_channels,
+                               hipStream_t stream) {
+    if (max_channels != min_channels) return hipErrorNotSupported;   // one wave layout per launch
+    if (plan.n_rc_f != plan.fft_in / 2 - 1 || plan.n_rc_i != plan.fft_out / 2 - 1) return hipErrorNotSupported;
+    const bool up = W1176::matches(plan.fft_in, plan.n_stages_f, plan.radix_f) &&
+                    W1280::matches(plan.fft_out, plan.n_stages_i, plan.radix_i);
+    const bool down = W1280::matches(plan.fft_in, plan.n_stages_f, plan.radix_f) &&
+                      W1176::matches(plan.fft_out, plan.n_stages_i, plan.radix_i);
+    if (!up && !down) return hipErrorNotSupported;
+    const uint32_t C = max_channels;
+    typedef void (*Kernel)(FftPlanDev, const FftStreamDesc*, uint32_t, uint32_t, uint32_t);
+    Kernel fn;
+    static const int occ = [] { const char* e = getenv("RSMP_FFT_WAVE_OCC"); return e && atoi(e) == 3 ? 3 : 2; }();
+    if (occ == 3) {
+        if (up) fn = C == 2 ? fft_ola_wave_kernel<W1176, W1280, true, 3> : fft_ola_wave_kernel<W1176, W1280, false, 3>;
+        else fn = C == 2 ? fft_ola_wave_kernel<W1280, W1176, true, 3> : fft_ola_wave_kernel<W1280, W1176, false, 3>;
+    } else {
+        if (up) fn = C == 2 ? fft_ola_wave_kernel<W1176, W1280, true, 2> : fft_ola_wave_kernel<W1176, W1280, false, 2>;
+        else fn = C == 2 ? fft_ola_wave_kernel<W1280, W1176, true, 2> : fft_ola_wave_kernel<W1280, W1176, false, 2>;
+    }
+    const size_t lds = static_cast<size_t>(kWavesPerGroup) * (1280 + 2) * sizeof(float2);
+    // Blocks per wave: every run after a stream's first recomputes its predecessor block (1 / run extra
+    // work), and the launch ends with a partly filled round unless the number of waves is close to a
+    // multiple of what the chip holds at once (3 workgroups of 4 waves per CU).
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const double slots = static_cast<double>(cus) * occ * kWavesPerGroup;
+    uint32_t run = 16;
+    double best = -1.0;
+    for (uint32_t cand = 6; cand <= 64; ++cand) {
+        const double runs = static_cast<double>((max_blocks + cand - 1) / cand);
+        const double waves = runs * n_streams * C;
+        const double rounds = std::ceil(waves / slots);
+        const double useful = static_cast<double>(max_blocks) / (max_blocks + runs - 1.0);   // halo blocks
+        const double score = waves / (rounds * slots) * useful;
+        if (score > best + 1e-9) { best = score; run = cand; }
+    }
+    static const char* knob = getenv("RSMP_FFT_RUN");
+    if (knob && atoi(knob) > 0) run = static_cast<uint32_t>(atoi(knob));
+    const uint32_t runs_per_stream = (max_blocks + run - 1) / run;
+    const uint32_t total_waves = runs_per_stream * n_streams * C;
+    const dim3 grid((total_waves + kWavesPerGroup - 1) / kWavesPerGroup);
+    hipLaunchKernelGGL(fn, grid, dim3(kWavesPerGroup * 64), lds, stream, plan, d_descs, run, runs_per_stream,
+                       total_waves);
+    return hipGetLastError();
+}
+
+}  // namespace rsmp
