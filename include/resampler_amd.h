@@ -54,7 +54,16 @@ enum { RSMP_ATTENUATION_DB60 = 0, RSMP_ATTENUATION_DB90, RSMP_ATTENUATION_DB120 
  * 16..160 classes such as 44.1 <-> 48 kHz, the exact-f32 MFMA kernel otherwise.  PERIODIC_F32 keeps
  * every product in f32 (exact-f32 MFMA or vector kernels, never the split one); PERIODIC_VECTOR forces
  * the packed-FMA vector kernel for every channel count.  All produce the same results within the
- * 1e-6 RMS gate (measured against the CPU path: about 1.2e-7 RMS each). */
+ * 1e-6 RMS gate (measured against the CPU path: about 1.2e-7 RMS each).
+ * Non-finite input (+-inf, NaN): GENERIC -- and the lock-step batch below -- evaluate the affected outputs
+ * in the reference's own form (two phase rows, per-lane lerp, src/fir/avx.rs:25-58): the same outputs are
+ * finite, +inf, -inf or NaN as in the reference.  The PERIODIC kernels pre-mix the two phase rows and
+ * multiply up to 16 samples next to an output's true window by zero padding coefficients (0 * inf = NaN),
+ * and the split-bf16 kernel splits an infinity into (inf, NaN, NaN): every output the reference makes
+ * non-finite is non-finite there too (as NaN, possibly where the reference has +-inf), and at most the
+ * outputs within 32 output frames of such an output are NaN in addition; all other outputs are unaffected.
+ * Callers that must reproduce the reference's inf / NaN pattern select GENERIC
+ * (tests/test_fir_gpu.py::test_non_finite_input_contract). */
 enum { RSMP_FIR_KERNEL_AUTO = 0, RSMP_FIR_KERNEL_GENERIC = 1, RSMP_FIR_KERNEL_PERIODIC = 2,
        RSMP_FIR_KERNEL_PERIODIC_VECTOR = 3, RSMP_FIR_KERNEL_PERIODIC_F32 = 4 };
 

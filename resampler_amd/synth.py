@@ -49,3 +49,16 @@ def fast_noise(n_values: int, seed: int = 0) -> np.ndarray:
     """Uniform [-1, 1) f32 noise from numpy's PCG64 (for large buffers)."""
     rng = np.random.default_rng(seed)
     return (rng.random(n_values, dtype=np.float32) * np.float32(2.0) - np.float32(1.0))
+
+
+def hash_noise(n_values: int, seed: int = 0) -> np.ndarray:
+    """Uniform [-1, 1) f32 noise from a counter-based generator (splitmix64 of seed + index, top 24 bits):
+    pure integer arithmetic, so the committed golden fixtures do not depend on a numpy version."""
+    with np.errstate(over="ignore"):
+        z = (np.arange(n_values, dtype=np.uint64) + np.uint64(seed) * np.uint64(0x9E3779B97F4A7C15)
+             + np.uint64(0x9E3779B97F4A7C15))
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    top = (z >> np.uint64(40)).astype(np.float64)          # 24 bits
+    return (top / float(1 << 23) - 1.0).astype(np.float32)

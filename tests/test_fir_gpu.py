@@ -393,3 +393,48 @@ def test_stopband_attenuation_on_gpu(in_hz, out_hz):
     pass_max = mag_db[to_bin(20.0):to_bin(nyq * 0.9) + 1].max()
     stop_max = mag_db[to_bin(nyq * 1.1):min(len(mag_db) - 10, to_bin(out_hz / 2.0 * 0.95)) + 1].max()
     assert pass_max - stop_max >= 90.0
+
+
+@pytest.mark.parametrize("kernel", [ra.FirKernel.Generic, ra.FirKernel.Periodic, ra.FirKernel.PeriodicF32,
+                                    ra.FirKernel.PeriodicVector])
+def test_non_finite_input_contract(kernel):
+    """Inf / NaN samples (stream start, mid tile, tile edge, one channel and both).  Contract of the bulk
+    kernels, as documented in include/resampler_amd.h (rsmp_fir_set_kernel):
+      * GENERIC evaluates every output in the reference's form: the same outputs are finite, the same are
+        +inf / -inf / NaN (src/fir/avx.rs:25-58);
+      * the PERIODIC kernels multiply a few samples next to an output's true window by zero padding
+        coefficients (0 * inf = NaN) and, in the split kernel, split an infinity into (inf, NaN, NaN): every
+        output the reference makes non-finite is non-finite here too, and additionally at most the outputs
+        within one class tile (16 output frames + the tile's window shift) of such an output; everything else
+        is finite and within the 1e-6 RMS gate."""
+    g, r = make_pair(2, 44100, 48000, kernel=kernel)
+    r = o.OracleFir(2, 44100, 48000, 128, 90, o.CONVOLVE_AVX_FMA if o.have_avx_fma() else o.CONVOLVE_SCALAR)
+    n = 60000
+    x = synth.fast_noise(2 * n, seed=77)
+    x[0] = np.inf                      # first sample of the stream, channel 0
+    x[2 * 5000 + 1] = -np.inf          # channel 1
+    x[2 * 11760] = np.nan              # frame 11760 = 80 input periods of 147: a period edge
+    x[2 * 11760 + 1] = np.nan
+    x[2 * 30007] = np.inf
+    x[2 * 30011] = -np.inf             # +inf and -inf inside one window
+    x[2 * 47040 - 2] = np.inf          # last frame of a 16-period item (16 * 147 * 20 = 47040)
+    yg, consumed = g.resample_bulk(x, 512)
+    yr, _ = r.resample_all(x, 512)
+    assert consumed == x.size and yg.size == yr.size
+    fin_r, fin_g = np.isfinite(yr), np.isfinite(yg)
+    assert not fin_g[~fin_r].any()                      # never finite where the reference is not
+    if kernel == ra.FirKernel.Generic:
+        assert np.array_equal(fin_g, fin_r)
+        assert np.array_equal(np.isnan(yg), np.isnan(yr))
+        inf = np.isinf(yr)
+        assert np.array_equal(yg[inf], yr[inf])
+    else:
+        # extra non-finite outputs only next to reference-non-finite ones: within 16 + 16 output frames
+        bad_frames_r = np.unique(np.flatnonzero(~fin_r) // 2)
+        extra = np.unique(np.flatnonzero(~fin_g & fin_r) // 2)
+        if extra.size:
+            dist = np.min(np.abs(extra[:, None] - bad_frames_r[None, :]), axis=1)
+            assert dist.max() <= 32, dist.max()
+    both = fin_r & fin_g
+    assert both.sum() > 0.95 * yr.size
+    assert rms(yg[both], yr[both]) <= RMS_TOL

@@ -1,0 +1,173 @@
+"""Golden fixtures of the five BASELINE configs (tests/golden/config_fixtures.json, written by
+tests/golden/make_fixtures.py from the CPU oracle in the build container).  The reference pins no
+end-to-end sample or count sequence, so these freeze the oracle: a box whose libm moves the
+design tables, or an oracle edit that changes a rounding, fails here -- and the HIP path is checked against
+the frozen values, not only against an oracle running beside it."""
+import base64
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import resampler_amd as ra
+from oracle import pyoracle as o
+from resampler_amd import sharding, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RMS_TOL = 1e-6   # north_star tolerance
+
+
+@pytest.fixture(scope="module")
+def fx():
+    with open(os.path.join(ROOT, "tests", "golden", "config_fixtures.json")) as f:
+        return json.load(f)
+
+
+def unpack(s):
+    return np.frombuffer(base64.b64decode(s), "<f4")
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a, np.float32).tobytes()).hexdigest()
+
+
+def rms(a, b):
+    return float(np.sqrt(np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2)))
+
+
+def expand(rle):
+    out = []
+    for c, p, k in rle:
+        out += [[c, p]] * k
+    return np.array(out, np.int64)
+
+
+def fir_input(name):
+    if name == "c1":
+        return synth.sweep(1 << 20, 1, 48000.0)
+    if name == "c2":
+        return synth.sweep(1 << 20, 2, 44100.0)
+    return synth.hash_noise(64 * 512 * 8, seed=5)
+
+
+def check_oracle(fx):
+    for name in ("c1", "c2", "c5"):
+        c = fx[name]
+        r = o.OracleFir(c["channels"], c["in_hz"], c["out_hz"], c["taps"], c["attenuation_db"])
+        assert sha(r.coeffs()) == c["table_sha256"], name       # the polyphase table, bit for bit
+        y, calls = r.resample_all(fir_input(name), c["chunk_values"])
+        assert y.size == c["out_values"] and np.array_equal(calls, expand(c["calls_rle"])), name
+        assert sha(y) == c["sha256"], name
+        assert list(r.state()) == c["final_state"], name
+    c3 = fx["c3"]
+    f = o.OracleFft(2, 44100, 48000)
+    assert sha(f.filter_spectrum().view(np.float32)) == c3["filter_spectrum_sha256"]
+    n_in, n_out = f.chunk_size_input(), f.chunk_size_output()
+    assert (n_in, n_out) == (c3["chunk_size_input"], c3["chunk_size_output"])
+    x = synth.sweep(c3["blocks"] * n_in // 2, 2, 44100.0)
+    y = np.zeros(c3["blocks"] * n_out, np.float32)
+    blk = np.zeros(n_out, np.float32)
+    for b in range(c3["blocks"]):
+        assert f.resample(x[b * n_in:(b + 1) * n_in], blk) == 0
+        y[b * n_out:(b + 1) * n_out] = blk
+    assert sha(y) == c3["sha256"]
+    c4 = fx["c4"]
+    specs = sharding.mixed_rate_batch(c4["streams"], 2, c4["frames_per_step"])
+    all_hash = hashlib.sha256()
+    detail = {d["index"]: d for d in c4["detail"]}
+    for i, s in enumerate(specs):
+        r = o.OracleFir(2, s.in_hz, s.out_hz, 128, 90)
+        x = synth.hash_noise(c4["steps"] * 1024, seed=i)
+        out = np.zeros(r.buffer_size_output(), np.float32)
+        ys, counts = [], []
+        for k in range(c4["steps"]):
+            rc, c, p = r.resample(x[k * 1024:(k + 1) * 1024], out)
+            assert rc == 0
+            counts.append([c, p])
+            ys.append(out[:p].copy())
+        digest = sha(np.concatenate(ys))
+        all_hash.update(bytes.fromhex(digest))
+        if i in detail:
+            assert counts == detail[i]["counts"] and digest == detail[i]["sha256"], i
+    assert all_hash.hexdigest() == c4["sha256_of_stream_sha256s"]
+
+
+def test_oracle_reproduces_the_golden_configs(fx):
+    check_oracle(fx)
+
+
+def test_product_tables_match_the_golden_hashes(fx):
+    # host-only design path of the product (no GPU): the same 128-tap tables, bit for bit
+    for name, att in (("c1", ra.Attenuation.Db90), ("c2", ra.Attenuation.Db90), ("c5", ra.Attenuation.Db120)):
+        c = fx[name]
+        t = ra.design_fir_coeffs(c["in_hz"], c["out_hz"], ra.Latency.Sample64, att)
+        assert sha(t) == c["table_sha256"], name
+
+
+@pytest.mark.gpu
+def test_oracle_reproduces_the_golden_configs_on_the_gpu_box(fx):
+    check_oracle(fx)
+
+
+@pytest.mark.gpu
+def test_hip_path_against_the_golden_configs(fx):
+    att = {90: ra.Attenuation.Db90, 120: ra.Attenuation.Db120}
+    # C1 / C2 / C5 through the bulk driver (the reference loop with the config's call size)
+    for name in ("c1", "c2", "c5"):
+        c = fx[name]
+        g = ra.ResamplerFir.new_from_hz(c["channels"], c["in_hz"], c["out_hz"], ra.Latency.Sample64, att[c["attenuation_db"]])
+        assert g.buffer_size_output() == c["buffer_size_output"]
+        y, consumed, calls = g.resample_bulk(fir_input(name), c["chunk_values"], want_calls=True)
+        assert consumed == c["in_values"] and y.size == c["out_values"], name
+        assert np.array_equal(calls, expand(c["calls_rle"])), name
+        assert list(g.state()) == c["final_state"], name
+        head, tail = unpack(c["head"]), unpack(c["tail"])
+        assert rms(y[:head.size], head) <= RMS_TOL and rms(y[-tail.size:], tail) <= RMS_TOL, name
+    # C1 also call by call (the drop-in form): counts of every call
+    c = fx["c1"]
+    g = ra.ResamplerFir.new_from_hz(1, 48000, 44100, ra.Latency.Sample64, ra.Attenuation.Db90)
+    x = fir_input("c1")
+    out = np.zeros(g.buffer_size_output(), np.float32)
+    want = expand(c["calls_rle"])
+    got_head = []
+    for k in range(64):
+        cg, pg = g.resample(x[k * 512:(k + 1) * 512], out)
+        assert [cg, pg] == want[k].tolist(), k
+        got_head.append(out[:pg].copy())
+    got_head = np.concatenate(got_head)
+    head = unpack(c["head"])
+    m = min(head.size, got_head.size)
+    assert rms(got_head[:m], head[:m]) <= RMS_TOL
+    # C3
+    c3 = fx["c3"]
+    f = ra.ResamplerFft.new(2, ra.SampleRate.Hz44100, ra.SampleRate.Hz48000)
+    x = synth.sweep(c3["blocks"] * c3["chunk_size_input"] // 2, 2, 44100.0)
+    y = f.resample_bulk(x, c3["blocks"])
+    head, tail = unpack(c3["head"]), unpack(c3["tail"])
+    assert rms(y[:head.size], head) <= RMS_TOL and rms(y[-tail.size:], tail) <= RMS_TOL
+    # C4: the lock-step batch at the config's full shape
+    import torch
+    dev = torch.device("cuda:0")
+    c4 = fx["c4"]
+    specs = sharding.mixed_rate_batch(c4["streams"], 2, c4["frames_per_step"])
+    hs = [ra.ResamplerFir.new_from_hz(2, s.in_hz, s.out_hz, ra.Latency.Sample64, ra.Attenuation.Db90) for s in specs]
+    d_in = [torch.from_numpy(synth.hash_noise(c4["steps"] * 1024, seed=i)).to(dev) for i in range(len(specs))]
+    caps = [h.buffer_size_output() for h in hs]
+    d_out = [torch.zeros(c4["steps"] * cap, device=dev) for cap in caps]
+    ls = ra.FirLockstep(hs, c4["frames_per_step"])
+    ls.bind_caps(d_in, d_out, caps)
+    detail = {d["index"]: d for d in c4["detail"]}
+    counts = {i: [] for i in detail}
+    for k in range(c4["steps"]):
+        ls.step(c4["frames_per_step"], k * c4["frames_per_step"], append=True)
+        cons, prod = ls.counts()
+        for i in detail:
+            counts[i].append([int(cons[i]), int(prod[i])])
+    for i, d in detail.items():
+        assert counts[i] == d["counts"], i
+        total = sum(p for _, p in d["counts"])
+        y = d_out[i][:total].cpu().numpy()
+        head, tail = unpack(d["head"]), unpack(d["tail"])
+        assert rms(y[:head.size], head) <= RMS_TOL and rms(y[-tail.size:], tail) <= RMS_TOL, i
