@@ -66,6 +66,21 @@ int upload_table(int device, const std::shared_ptr<const std::vector<float>>& ho
 
 namespace {
 
+// Releases everything a (possibly half-built) handle owns.
+void fir_destroy(rsmp_fir* r) {
+    if (!r) return;
+    DeviceGuard guard(r->device);
+    if (r->stream) (void)hipStreamSynchronize(r->stream);
+    (void)hipDeviceSynchronize();
+    for (int i = 0; i < 2; ++i) if (r->d_hist[i]) (void)hipFree(r->d_hist[i]);
+    if (r->d_work_counter) (void)hipFree(r->d_work_counter);
+    for (hipEvent_t e : r->plan_copied) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : r->prof_start) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : r->prof_stop) if (e) (void)hipEventDestroy(e);
+    if (r->stream) (void)hipStreamDestroy(r->stream);
+    delete r;
+}
+
 rsmp_fir* fir_create(size_t channels, uint32_t in_hz, uint32_t out_hz, int latency,
                      int attenuation, int device) {
     const size_t taps = rsmp::latency_taps(latency);
@@ -109,7 +124,7 @@ rsmp_fir* fir_create(size_t channels, uint32_t in_hz, uint32_t out_hz, int laten
             hipMemset(r->d_hist[i], 0, hist_bytes) != hipSuccess ||
             hipStreamSynchronize(nullptr) != hipSuccess) {   // (the handle's stream is non-blocking: no implicit order)
             rsmp::fail(RSMP_ERR_HIP, "ResamplerFir: cannot allocate stream state");
-            for (int j = 0; j <= i; ++j) if (r->d_hist[j]) (void)hipFree(r->d_hist[j]);
+            fir_destroy(r.release());
             return nullptr;
         }
     }
@@ -119,6 +134,7 @@ rsmp_fir* fir_create(size_t channels, uint32_t in_hz, uint32_t out_hz, int laten
         hipEventCreateWithFlags(&r->plan_copied[2], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&r->plan_copied[3], hipEventDisableTiming) != hipSuccess) {
         rsmp::fail(RSMP_ERR_HIP, "ResamplerFir: cannot create stream/event");
+        fir_destroy(r.release());
         return nullptr;
     }
     return r.release();
@@ -137,9 +153,6 @@ struct Plan {
     size_t consumed_frames = 0;
     size_t hist_frames = 0;
     bool periodic = false;
-    // workspace offsets (filled by launch_jobs)
-    size_t seg_off = 0, tile_off = 0, wrap_off = 0;
-    bool placed = false;
     explicit Plan(const FirMirror& m) : planned(m) {}
 };
 
@@ -294,10 +307,23 @@ size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 // Assembles and enqueues the launches for a set of planned jobs on one device / stream.
 // `leader` owns the launch workspace.
 int launch_jobs(rsmp_fir* leader, std::vector<Job>& jobs, hipStream_t stream) {
-    // Plans are shared objects carrying per-launch placement scratch: one assembly at a time.
-    static std::mutex assembly_mu;
-    std::lock_guard<std::mutex> assembly_lock(assembly_mu);
+    // Plans are shared, immutable once built; where a plan's arrays sit in THIS launch's workspace is
+    // launch-local (streams of a batch that share a plan share its arrays too).
+    struct Placement { size_t seg_off = 0, tile_off = 0, wrap_off = 0; bool written = false; };
+    std::map<const Plan*, Placement> place;
     const size_t n = jobs.size();
+    // Launches that touch a handle (its buffered frames, its plan slots, the leader's item queue) are
+    // ordered: the ABI lets every call name a stream, so a handle that was last used on another stream
+    // waits for that stream first (rare; a caller that keeps one stream per handle never blocks here).
+    auto order_after = [&](rsmp_fir* h) -> int {
+        if (h->last_stream_valid && h->last_stream != stream) RSMP_HIP_CHECK(hipStreamSynchronize(h->last_stream));
+        h->last_stream = stream;
+        h->last_stream_valid = true;
+        return RSMP_OK;
+    };
+    if (int rc = order_after(leader)) return rc;
+    for (Job& j : jobs)
+        if (int rc = order_after(j.r)) return rc;
     // Bind class tables first (may upload), then order: generic jobs, then periodic jobs grouped
     // by geometry (one launch per geometry).
     std::vector<size_t> order;
@@ -321,19 +347,18 @@ int launch_jobs(rsmp_fir* leader, std::vector<Job>& jobs, hipStream_t stream) {
 
     // Workspace layout: [descs] then per distinct plan: [runs][tile index] or [wraps].
     size_t bytes = align_up(n * sizeof(FirStreamDesc), 256);
-    for (Job& j : jobs) j.plan->placed = false;
     for (Job& j : jobs) {
-        Plan& pl = *j.plan;
-        if (pl.placed) continue;
-        pl.placed = true;
+        const Plan& pl = *j.plan;
+        if (place.count(&pl)) continue;
+        Placement& pp = place[&pl];
         if (!pl.periodic) {
-            pl.seg_off = bytes;
+            pp.seg_off = bytes;
             bytes = align_up(bytes + pl.segs.size() * sizeof(rsmp_fir_segment), 256);
-            pl.tile_off = bytes;
+            pp.tile_off = bytes;
             const size_t tiles = (pl.produced_frames + rsmp::kFirTile - 1) / rsmp::kFirTile;
             bytes = align_up(bytes + tiles * sizeof(uint32_t), 256);
         } else {
-            pl.wrap_off = bytes;
+            pp.wrap_off = bytes;
             const rsmp::PeriodicGeometry& geo = j.r->periodic.geo;
             const size_t words = geo.inline_wraps
                                      ? rsmp::periodic_wrap_words(j.r->mirror.abs_out(),
@@ -368,11 +393,11 @@ int launch_jobs(rsmp_fir* leader, std::vector<Job>& jobs, hipStream_t stream) {
     char* d = direct ? leader->h_plan[slot].as<char>() : leader->d_plan[slot].as<char>();
     FirStreamDesc* descs = reinterpret_cast<FirStreamDesc*>(h);
 
-    for (Job& j : jobs) j.plan->placed = false;
     uint32_t max_out_generic = 0, max_ch_generic = 0, max_tail_values = 0, max_wraps = 0;
     for (size_t slot = 0; slot < n; ++slot) {
         Job& j = jobs[order[slot]];
-        Plan& pl = *j.plan;
+        const Plan& pl = *j.plan;
+        Placement& pp = place[&pl];
         rsmp_fir* r = j.r;
         const uint32_t ch = static_cast<uint32_t>(r->channels);
         FirStreamDesc& ds = descs[slot];
@@ -395,12 +420,12 @@ int launch_jobs(rsmp_fir* leader, std::vector<Job>& jobs, hipStream_t stream) {
         ds.abs_consumed = r->mirror.abs_consumed();
         if (ds.tail_frames * ch > max_tail_values) max_tail_values = ds.tail_frames * ch;
         if (!pl.periodic) {
-            ds.segs = reinterpret_cast<const rsmp_fir_segment*>(d + pl.seg_off);
+            ds.segs = reinterpret_cast<const rsmp_fir_segment*>(d + pp.seg_off);
             ds.n_segs = static_cast<uint32_t>(pl.segs.size());
-            ds.tile_seg = reinterpret_cast<const uint32_t*>(d + pl.tile_off);
-            if (!pl.placed) {
-                std::memcpy(h + pl.seg_off, pl.segs.data(), pl.segs.size() * sizeof(rsmp_fir_segment));
-                uint32_t* ts = reinterpret_cast<uint32_t*>(h + pl.tile_off);
+            ds.tile_seg = reinterpret_cast<const uint32_t*>(d + pp.tile_off);
+            if (!pp.written) {
+                std::memcpy(h + pp.seg_off, pl.segs.data(), pl.segs.size() * sizeof(rsmp_fir_segment));
+                uint32_t* ts = reinterpret_cast<uint32_t*>(h + pp.tile_off);
                 size_t s = 0;
                 for (size_t t = 0; t * rsmp::kFirTile < pl.produced_frames; ++t) {
                     const size_t first = t * rsmp::kFirTile;
@@ -416,22 +441,22 @@ int launch_jobs(rsmp_fir* leader, std::vector<Job>& jobs, hipStream_t stream) {
             ds.class_wrap_coef = r->periodic.table.d_wrap_coef;
             ds.class_meta = r->periodic.table.d_meta;
             if (geo.inline_wraps) {
-                ds.wrap_bits = reinterpret_cast<const uint32_t*>(d + pl.wrap_off);
+                ds.wrap_bits = reinterpret_cast<const uint32_t*>(d + pp.wrap_off);
                 ds.wrap_k0 = r->mirror.abs_out() / geo.den;
-                if (!pl.placed) {
+                if (!pp.written) {
                     const size_t words = rsmp::periodic_wrap_words(r->mirror.abs_out(), ds.n_out, geo.den);
                     rsmp::periodic_fill_wrap_bits(pl.wraps, r->mirror.abs_out(), geo.den,
-                                                  reinterpret_cast<uint32_t*>(h + pl.wrap_off), words);
+                                                  reinterpret_cast<uint32_t*>(h + pp.wrap_off), words);
                 }
             } else {
-                ds.wraps = reinterpret_cast<const uint32_t*>(d + pl.wrap_off);
+                ds.wraps = reinterpret_cast<const uint32_t*>(d + pp.wrap_off);
                 ds.n_wraps = static_cast<uint32_t>(pl.wraps.size());
-                if (!pl.placed)
-                    std::memcpy(h + pl.wrap_off, pl.wraps.data(), pl.wraps.size() * sizeof(uint32_t));
+                if (!pp.written)
+                    std::memcpy(h + pp.wrap_off, pl.wraps.data(), pl.wraps.size() * sizeof(uint32_t));
                 if (ds.n_wraps > max_wraps) max_wraps = ds.n_wraps;
             }
         }
-        pl.placed = true;
+        pp.written = true;
     }
     if (direct) {
         std::memcpy(d, h, bytes);
@@ -469,15 +494,13 @@ int launch_jobs(rsmp_fir* leader, std::vector<Job>& jobs, hipStream_t stream) {
             // could land after the first kernel had started claiming (host and device counts then
             // disagree for good and later launches find no work)
             RSMP_HIP_CHECK(hipMemsetAsync(leader->d_work_counter, 0, sizeof(unsigned long long), stream));
-            leader->work_base = 0;
         }
         // a launch made of split-kernel streams only lets that kernel copy the tails as well
         tail_fused = n_generic == 0 && groups.size() == 1 && g.geo.mfma == 3 && max_blocks != 0 &&
                      getenv("RSMP_FIR_NO_FUSED_TAIL") == nullptr;
         RSMP_HIP_CHECK(rsmp::launch_fir_periodic(d_descs + first,
                                                  static_cast<uint32_t>(g.members.size()), g.geo,
-                                                 max_blocks, leader->d_work_counter,
-                                                 &leader->work_base, stream, tail_fused));
+                                                 max_blocks, leader->d_work_counter, stream, tail_fused));
         first += g.members.size();
     }
     if (leader->profiling) {
@@ -556,19 +579,7 @@ extern "C" rsmp_fir* rsmp_fir_new(size_t channels, int input_rate, int output_ra
     return fir_create(channels, in_hz, out_hz, latency, attenuation, device);
 }
 
-extern "C" void rsmp_fir_free(rsmp_fir* r) {
-    if (!r) return;
-    DeviceGuard guard(r->device);
-    if (r->stream) (void)hipStreamSynchronize(r->stream);
-    (void)hipDeviceSynchronize();
-    for (int i = 0; i < 2; ++i) if (r->d_hist[i]) (void)hipFree(r->d_hist[i]);
-    if (r->d_work_counter) (void)hipFree(r->d_work_counter);
-    for (hipEvent_t e : r->plan_copied) if (e) (void)hipEventDestroy(e);
-    for (hipEvent_t e : r->prof_start) if (e) (void)hipEventDestroy(e);
-    for (hipEvent_t e : r->prof_stop) if (e) (void)hipEventDestroy(e);
-    if (r->stream) (void)hipStreamDestroy(r->stream);
-    delete r;
-}
+extern "C" void rsmp_fir_free(rsmp_fir* r) { fir_destroy(r); }
 
 extern "C" size_t rsmp_fir_buffer_size_output(const rsmp_fir* r) {
     return r->mirror.buffer_size_output_frames() * r->channels;

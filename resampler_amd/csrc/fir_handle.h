@@ -39,8 +39,9 @@ struct rsmp_fir {
     rsmp::DeviceBuffer d_stage_in, d_stage_out;
     rsmp::PeriodicState periodic;
     bool last_periodic = false;   // the handle's last launch went through a periodic kernel
-    unsigned long long* d_work_counter = nullptr;   // periodic kernel's item queue (leader only)
-    unsigned long long work_base = 0;
+    unsigned long long* d_work_counter = nullptr;   // periodic kernel's item queue (leader only), zero between launches
+    hipStream_t last_stream = nullptr;              // the stream of the handle's most recent launch
+    bool last_stream_valid = false;
     // optional timing of the main convolution launch(es) (rsmp_fir_set_profiling)
     bool profiling = false;
     // ring of event pairs: launches made while profiling is on are timed without any host sync

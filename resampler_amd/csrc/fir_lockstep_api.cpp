@@ -165,7 +165,10 @@ extern "C" rsmp_fir_lockstep* rsmp_fir_lockstep_new(rsmp_fir* const* rs, size_t 
         return nullptr;
     }
     // every stream's earlier launches (which wrote its buffered frames) must be complete
-    for (size_t i = 0; i < n; ++i) (void)hipStreamSynchronize(rs[i]->stream);
+    for (size_t i = 0; i < n; ++i) {
+        (void)hipStreamSynchronize(rs[i]->stream);
+        if (rs[i]->last_stream_valid) (void)hipStreamSynchronize(rs[i]->last_stream);
+    }
     if (hipMemcpy(ls->d_groups.get(), ls->groups.data(), ls->groups.size() * sizeof(LockstepGroup),
                   hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(ls->d_order.get(), ls->order.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess ||

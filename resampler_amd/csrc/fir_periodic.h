@@ -114,12 +114,12 @@ void periodic_fill_wrap_bits(const std::vector<uint32_t>& wraps, uint64_t abs_ou
                              uint32_t* words, size_t n_words);
 
 // One launch per geometry: d_descs[0..n_streams) all use `geo`; grid = (max_blocks, n_streams).
-// `d_work_counter` is a zero-initialised 64-bit device word owned by the caller and used only by
-// launches on one stream; `work_base` is the host's copy of its value (advanced by this call).
+// `d_work_counter` is a zero-initialised 64-bit device word owned by the caller; the kernel leaves it
+// at zero again (launches sharing it must be ordered, which launch_jobs enforces per handle).
 hipError_t launch_fir_periodic(const FirStreamDesc* d_descs, uint32_t n_streams,
                                const PeriodicGeometry& geo, uint32_t max_blocks,
-                               unsigned long long* d_work_counter, unsigned long long* work_base,
-                               hipStream_t stream, bool fuse_tail = false);
+                               unsigned long long* d_work_counter, hipStream_t stream,
+                               bool fuse_tail = false);
 // Recomputes the outputs listed in each stream's `wraps` with row 1023 / previous frame
 // (only for geometries without inline wraps).
 hipError_t launch_fir_wrap_fixup(const FirStreamDesc* d_descs, uint32_t n_streams,

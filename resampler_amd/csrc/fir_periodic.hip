@@ -48,11 +48,21 @@ struct GeoArgs {
     unsigned long long* trace;  // RSMP_FIR_TRACE diagnostic build only: 6 u64 per workgroup
     unsigned long long* wtrace; // RSMP_FIR_WTRACE: kWtraceSlots timestamped events per wave
     uint32_t blocks_per_stream, total_items;
-    unsigned long long* work_counter;   // launch-wide item queue (monotonic)
-    unsigned long long work_base;       // its value before this launch
+    unsigned long long* work_counter;   // launch-wide item queue: zero between launches
+    uint32_t n_claimers;                // waves that claim from it; each ends on exactly one failing claim
 };
 
 constexpr uint32_t kWtraceSlots = 160, kWtraceWaves = 16;
+
+// One ticket of the launch-wide item queue.  Every claimer stops at its first failing claim, so the
+// launch's last ticket is total_items + n_claimers - 1: whoever draws it puts the counter back to zero.
+// The queue is thereby self-contained per launch: nothing on the host predicts its value, and a launch
+// that fails to start leaves it untouched.
+__device__ __forceinline__ unsigned long long queue_claim(const GeoArgs& geo) {
+    const unsigned long long t = atomicAdd(geo.work_counter, 1ull);
+    if (t == static_cast<unsigned long long>(geo.total_items) + geo.n_claimers - 1ull) (void)atomicExch(geo.work_counter, 0ull);
+    return t;
+}
 
 typedef const float __attribute__((address_space(4)))* const_f32_ptr;   // scalar-cache loads
 typedef const float __attribute__((address_space(1)))* gconst_f32_ptr;  // global (not flat) loads
@@ -557,7 +567,7 @@ __global__ __launch_bounds__(768, 6) void fir_periodic_kernel(const FirStreamDes
     // while the current one is being staged, so it is never on the critical path.
     uint32_t* next_item = reinterpret_cast<uint32_t*>(lds) + 1;
     auto claim = [&]() -> uint32_t {
-        const unsigned long long t = atomicAdd(geo.work_counter, 1ull) - geo.work_base;
+        const unsigned long long t = queue_claim(geo);
         return t < geo.total_items ? static_cast<uint32_t>(t) : 0xFFFFFFFFu;
     };
     if (threadIdx.x == 0) *next_item = claim();
@@ -1298,7 +1308,7 @@ __global__ __launch_bounds__(MF ? 768 : 1024) void fir_periodic_db_kernel(const 
                 // claim work items until one is real (ragged batches pad with empty ones)
                 for (;;) {
                     unsigned long long tkt = 0;
-                    if (lane == 0) tkt = atomicAdd(geo.work_counter, 1ull) - geo.work_base;
+                    if (lane == 0) tkt = queue_claim(geo);
                     const uint32_t lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(tkt));
                     const uint32_t hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(tkt >> 32));
                     if (hi != 0 || lo >= geo.total_items) { item = kNoItem; break; }
@@ -1565,7 +1575,7 @@ GeoArgs to_args(const PeriodicGeometry& g) {
     return GeoArgs{g.a, g.b, g.b / g.den, g.row_len, g.mfma ? g.n_units : g.n_tiles, g.lp, g.pw, g.row_stride, g.waves,
                    channels, xprev_len_of(g.pw, channels), g.producers, g.den, g.images ? g.images : 2u,
                    g.mfma ? (g.n_units == 4 * g.n_tiles ? 2u : (g.n_units == 2 * g.n_tiles ? 1u : 0u)) : 0u,
-                   g.inline_wraps ? 1u : 0u, debug, stagger, nullptr, nullptr, 0u, 0u, nullptr, 0ull};
+                   g.inline_wraps ? 1u : 0u, debug, stagger, nullptr, nullptr, 0u, 0u, nullptr, 0u};
 }
 
 // Device class tables, shared by every stream on a device with the same polyphase table, rate
@@ -1929,8 +1939,7 @@ int periodic_bind(PeriodicState& st, int device, const std::vector<float>& table
 
 hipError_t launch_fir_periodic(const FirStreamDesc* d_descs, uint32_t n_streams,
                                const PeriodicGeometry& geo, uint32_t max_blocks,
-                               unsigned long long* d_work_counter, unsigned long long* work_base,
-                               hipStream_t stream, bool fuse_tail) {
+                               unsigned long long* d_work_counter, hipStream_t stream, bool fuse_tail) {
     if (n_streams == 0 || max_blocks == 0) return hipSuccess;
     const dim3 block(geo.waves * 64);
     GeoArgs args = to_args(geo);
@@ -1957,11 +1966,10 @@ hipError_t launch_fir_periodic(const FirStreamDesc* d_descs, uint32_t n_streams,
     const uint32_t slots = cus * (geo.lds_bytes > kLdsTwoPerCu ? 1u : 2u);   // workgroups that fit
     const dim3 grid(args.total_items < slots ? args.total_items : slots);
     args.work_counter = d_work_counter;
-    args.work_base = *work_base;
     // every claiming wave makes exactly one failing claim: one per workgroup, or one per producer when
     // each producer owns an image
     const bool own_image = geo.mfma && geo.producers == geo.images;
-    *work_base += args.total_items + static_cast<unsigned long long>(grid.x) * (own_image ? geo.images : 1u);
+    args.n_claimers = grid.x * (own_image ? geo.images : 1u);
     static const char* trace_path = getenv("RSMP_FIR_TRACE");
     static unsigned long long* d_trace = nullptr;
     const size_t trace_words = 6ull * grid.x;
