@@ -15,8 +15,8 @@ pub enum ResampleError {
 impl core::fmt::Display for ResampleError {
     fn fmt(&self, f: &mut core::fmt::Formatter<'_>) -> core::fmt::Result {
         match self {
-            Self::InvalidInputBufferSize => "Input buffer size is invalid".fmt(f),
-            Self::InvalidOutputBufferSize => "Output buffer size is invalid".fmt(f),
+            Self::InvalidInputBufferSize => f.write_str("Input buffer size is invalid"),
+            Self::InvalidOutputBufferSize => f.write_str("Output buffer size is invalid"),
         }
     }
 }
@@ -27,6 +27,25 @@ impl std::error::Error for ResampleError {}
 #[derive(Debug, Copy, Clone, PartialOrd, PartialEq, Ord, Eq, Hash)]
 pub enum SampleRate {
     Hz22050 = 0, Hz16000, Hz32000, Hz44100, Hz48000, Hz88200, Hz96000, Hz176400, Hz192000, Hz384000,
+}
+
+const ALL_RATES: [SampleRate; 10] = [
+    SampleRate::Hz22050, SampleRate::Hz16000, SampleRate::Hz32000, SampleRate::Hz44100, SampleRate::Hz48000,
+    SampleRate::Hz88200, SampleRate::Hz96000, SampleRate::Hz176400, SampleRate::Hz192000, SampleRate::Hz384000,
+];
+
+/// impl From<SampleRate> for u32 (src/lib.rs:219-236): the table lives in the library
+/// (rsmp_sample_rate_hz), so the shim cannot drift from it.
+impl From<SampleRate> for u32 {
+    fn from(value: SampleRate) -> Self { unsafe { rsmp_sample_rate_hz(value as c_int) } }
+}
+
+/// impl TryFrom<u32> for SampleRate (src/lib.rs:238-257): `Err(())` for a rate that is not in the enum.
+impl TryFrom<u32> for SampleRate {
+    type Error = ();
+    fn try_from(value: u32) -> Result<Self, Self::Error> {
+        ALL_RATES.iter().copied().find(|r| u32::from(*r) == value).ok_or(())
+    }
 }
 
 #[repr(i32)]
@@ -61,6 +80,11 @@ extern "C" {
     fn rsmp_fft_resample(r: *mut rsmp_fft, input: *const f32, in_len: usize, output: *mut f32,
                          out_len: usize) -> c_int;
     fn rsmp_last_error() -> *const std::os::raw::c_char;
+    fn rsmp_sample_rate_hz(sample_rate: c_int) -> u32;
+    fn rsmp_fir_channels(r: *const rsmp_fir) -> usize;
+    fn rsmp_fir_taps(r: *const rsmp_fir) -> usize;
+    fn rsmp_fir_phases(r: *const rsmp_fir) -> usize;
+    fn rsmp_fft_channels(r: *const rsmp_fft) -> usize;
 }
 
 fn device() -> c_int {
@@ -122,6 +146,20 @@ impl ResamplerFir {
     }
 }
 
+/// impl fmt::Debug for ResamplerFir (src/resampler_fir.rs:203-211): channels, taps, phases, `..`
+impl core::fmt::Debug for ResamplerFir {
+    fn fmt(&self, f: &mut core::fmt::Formatter<'_>) -> core::fmt::Result {
+        let (channels, taps, phases) = unsafe {
+            (rsmp_fir_channels(self.handle), rsmp_fir_taps(self.handle), rsmp_fir_phases(self.handle))
+        };
+        f.debug_struct("ResamplerFir")
+            .field("channels", &channels)
+            .field("taps", &taps)
+            .field("phases", &phases)
+            .finish_non_exhaustive()
+    }
+}
+
 impl Drop for ResamplerFir {
     fn drop(&mut self) { unsafe { rsmp_fir_free(self.handle) } }
 }
@@ -146,6 +184,20 @@ impl ResamplerFft {
         status(unsafe {
             rsmp_fft_resample(self.handle, input.as_ptr(), input.len(), output.as_mut_ptr(), output.len())
         })
+    }
+}
+
+/// impl fmt::Debug for ResamplerFft (src/resampler_fft.rs:56-66)
+impl core::fmt::Debug for ResamplerFft {
+    fn fmt(&self, f: &mut core::fmt::Formatter<'_>) -> core::fmt::Result {
+        let channels = unsafe { rsmp_fft_channels(self.handle) };
+        f.debug_struct("ResamplerFft")
+            .field("channels", &channels)
+            .field("chunk_size_input", &self.chunk_size_input())
+            .field("chunk_size_output", &self.chunk_size_output())
+            .field("fft_size_input", &(self.chunk_size_input() / channels))
+            .field("fft_size_output", &(self.chunk_size_output() / channels))
+            .finish_non_exhaustive()
     }
 }
 

@@ -209,6 +209,21 @@ int rsmp_fir_plan_call(rsmp_fir_plan* p, size_t input_frames, size_t output_capa
                        size_t* frames_accepted, size_t* frames_produced, rsmp_fir_segment* segs,
                        size_t max_segs, size_t* n_segs);
 
+/* ============================ CLI helpers around the path (resample/src) ========================== */
+/* InterpolationResampler (resample/src/interpolation_resampler.rs:41-126): the comparison interpolators of
+ * the reference's command-line tool, whole buffer in, ceil(frames * out / in) frames out. */
+enum { RSMP_INTERP_LINEAR = 0, RSMP_INTERP_HERMITE = 1 };
+size_t rsmp_interp_output_len(size_t channels, uint32_t in_hz, uint32_t out_hz, size_t in_len);   /* in f32 values */
+int rsmp_interp_resample(int mode, size_t channels, uint32_t in_hz, uint32_t out_hz, const float* in,
+                         size_t in_len, float* out, size_t out_cap, size_t* produced);
+int rsmp_interp_resample_device(int mode, size_t channels, uint32_t in_hz, uint32_t out_hz, const float* d_in,
+                                size_t in_len, float* d_out, size_t out_cap, size_t* produced, void* stream);
+/* WAV sample conversion of the tool (resample/src/main.rs:128-156): little-endian integer PCM (16, packed
+ * 24, 32 bits) -> f32 = s / 2^(bits-1), mono duplicated to both channels; d_out holds n_samples values
+ * (2 channels in) or 2 * n_samples (1 channel in).  Device pointers, asynchronous on `stream`. */
+int rsmp_pcm_to_stereo_f32_device(const void* d_pcm, int bits, int channels, size_t n_samples, float* d_out,
+                                  void* stream);
+
 /* ============================ ResamplerFft (src/resampler_fft.rs) =============================== */
 typedef struct rsmp_fft rsmp_fft;
 

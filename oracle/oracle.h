@@ -104,6 +104,15 @@ int orc_fft_resample(orc_fft_resampler* r, const float* in, size_t in_len, float
                      size_t out_len);                                     /* :182-240 */
 const orc_c32* orc_fft_filter_spectrum(const orc_fft_resampler* r, size_t* len);
 
+/* ---- resample/src (CLI helpers around the path) --------------------------------------------- */
+/* interpolation_resampler.rs:41-126; return output frames (0 when out_cap is too small). */
+size_t orc_interp_linear(size_t channels, uint32_t in_hz, uint32_t out_hz, const float* input, size_t in_len,
+                         float* output, size_t out_cap);
+size_t orc_interp_hermite(size_t channels, uint32_t in_hz, uint32_t out_hz, const float* input, size_t in_len,
+                          float* output, size_t out_cap);
+/* main.rs:128-156: integer PCM -> f32, mono duplicated to stereo. */
+size_t orc_pcm_to_stereo_f32(const uint8_t* pcm, int bits, int channels, size_t n_samples, float* out);
+
 #ifdef __cplusplus
 }
 #endif

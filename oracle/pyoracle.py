@@ -97,6 +97,12 @@ def lib() -> C.CDLL:
         L.orc_fft_resample.argtypes = [C.c_void_p, f32p, C.c_size_t, f32p, C.c_size_t]
         L.orc_fft_filter_spectrum.restype = f32p
         L.orc_fft_filter_spectrum.argtypes = [C.c_void_p, szp]
+    for name in ("orc_interp_linear", "orc_interp_hermite"):
+        fn = getattr(L, name)
+        fn.restype = C.c_size_t
+        fn.argtypes = [C.c_size_t, C.c_uint32, C.c_uint32, f32p, C.c_size_t, f32p, C.c_size_t]
+    L.orc_pcm_to_stereo_f32.restype = C.c_size_t
+    L.orc_pcm_to_stereo_f32.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_size_t, f32p]
     _lib = L
     return L
 
@@ -296,3 +302,23 @@ class OracleFft:
     def resample(self, inp: np.ndarray, out: np.ndarray) -> int:
         inp = np.ascontiguousarray(inp, np.float32)
         return lib().orc_fft_resample(self._h, _f32p(inp), inp.size, _f32p(out), out.size)
+
+
+# ---- resample/src: interpolators and WAV sample conversion ----------------------------------------
+def interpolate(mode: str, channels: int, in_hz: int, out_hz: int, x: np.ndarray) -> np.ndarray:
+    """InterpolationResampler::resample (interpolation_resampler.rs:41-126); mode 'linear' | 'hermite'."""
+    x = np.ascontiguousarray(x, np.float32)
+    frames = x.size // channels
+    cap = (int(np.ceil(frames * (out_hz / in_hz))) + 2) * channels
+    out = np.zeros(cap, np.float32)
+    fn = lib().orc_interp_linear if mode == "linear" else lib().orc_interp_hermite
+    n = fn(channels, in_hz, out_hz, _f32p(x), x.size, _f32p(out), cap)
+    return out[:n * channels].copy()
+
+
+def pcm_to_stereo_f32(pcm: bytes, bits: int, channels: int) -> np.ndarray:
+    """main.rs:128-156."""
+    n = len(pcm) // (bits // 8)
+    out = np.zeros(n * (2 if channels == 1 else 1), np.float32)
+    w = lib().orc_pcm_to_stereo_f32(pcm, bits, channels, n, _f32p(out))
+    return out[:w]

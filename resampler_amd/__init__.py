@@ -149,6 +149,12 @@ _SIGNATURES = [
     ("rsmp_fir_plan_state", None, [C.c_void_p, _szp, _szp, C.POINTER(C.c_double)]),
     ("rsmp_fir_plan_call", C.c_int,
      [C.c_void_p, C.c_size_t, C.c_size_t, _szp, _szp, C.POINTER(_Segment), C.c_size_t, _szp]),
+    ("rsmp_interp_output_len", C.c_size_t, [C.c_size_t, C.c_uint32, C.c_uint32, C.c_size_t]),
+    ("rsmp_interp_resample", C.c_int,
+     [C.c_int, C.c_size_t, C.c_uint32, C.c_uint32, _f32p, C.c_size_t, _f32p, C.c_size_t, _szp]),
+    ("rsmp_interp_resample_device", C.c_int,
+     [C.c_int, C.c_size_t, C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, _szp, C.c_void_p]),
+    ("rsmp_pcm_to_stereo_f32_device", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p]),
     ("rsmp_fft_new", C.c_void_p, [C.c_size_t, C.c_int, C.c_int, C.c_int]),
     ("rsmp_fft_free", None, [C.c_void_p]),
     ("rsmp_fft_chunk_size_input", C.c_size_t, [C.c_void_p]),
@@ -614,6 +620,40 @@ class FftBatch:
     def resample_bulk_device(self, stream: Optional[int] = None) -> None:
         _check(lib().rsmp_fft_batch_resample_bulk_device(self._handles, len(self.resamplers), self._in,
                                                          self._out, self._chunks, C.c_void_p(stream or 0)))
+
+
+class InterpolationMode(enum.IntEnum):
+    """enum InterpolationMode (resample/src/interpolation_resampler.rs:4-10)."""
+    Linear = 0
+    Hermite = 1
+
+
+class InterpolationResampler:
+    """The CLI's comparison interpolators (resample/src/interpolation_resampler.rs:12-127) on the GPU."""
+
+    def __init__(self, channels: int, input_rate: SampleRate, output_rate: SampleRate, mode: InterpolationMode):
+        self.channels = channels
+        self.in_hz = SampleRate(input_rate).hz
+        self.out_hz = SampleRate(output_rate).hz
+        self.mode = InterpolationMode(mode)
+
+    def resample(self, input) -> np.ndarray:
+        inp = _np_f32(input)
+        cap = lib().rsmp_interp_output_len(self.channels, self.in_hz, self.out_hz, inp.size)
+        out = np.empty(max(cap, 1), np.float32)
+        p = C.c_size_t()
+        _check(lib().rsmp_interp_resample(int(self.mode), self.channels, self.in_hz, self.out_hz, _ptr(inp),
+                                          inp.size, _ptr(out), cap, C.byref(p)))
+        return out[:p.value]
+
+
+def pcm_to_stereo_f32_device(d_pcm, bits: int, channels: int, d_out, stream: Optional[int] = None) -> None:
+    """WAV sample conversion (resample/src/main.rs:128-156) on HBM-resident torch tensors: d_pcm = uint8
+    bytes of little-endian samples, d_out = float32 (mono input: two values per sample)."""
+    n = d_pcm.numel() // (bits // 8)
+    assert d_out.numel() >= n * (2 if channels == 1 else 1)
+    _check(lib().rsmp_pcm_to_stereo_f32_device(C.c_void_p(d_pcm.data_ptr()), bits, channels, n,
+                                               C.c_void_p(d_out.data_ptr()), C.c_void_p(stream or 0)))
 
 
 def fft_plan_sizes(input_rate_hz: int, output_rate_hz: int):

@@ -1,0 +1,80 @@
+"""the reference CLI's helpers around the hot path -- the linear / Hermite comparison
+interpolators (resample/src/interpolation_resampler.rs:41-126) and the WAV sample conversion with mono
+duplication (resample/src/main.rs:128-156) -- on the GPU, bit for bit against the C restatement."""
+import numpy as np
+import pytest
+
+import resampler_amd as ra
+from oracle import pyoracle as o
+from resampler_amd import synth
+
+RATES = {ra.SampleRate.Hz44100: 44100, ra.SampleRate.Hz48000: 48000, ra.SampleRate.Hz96000: 96000,
+         ra.SampleRate.Hz16000: 16000, ra.SampleRate.Hz22050: 22050}
+
+
+def test_oracle_interpolators_known_points():
+    # linear: halfway between two samples at 1:2; last frame repeats (interpolation_resampler.rs:55-62)
+    x = np.array([0.0, 1.0, 4.0], np.float32)
+    y = o.interpolate("linear", 1, 48000, 96000, x)
+    assert np.array_equal(y, np.array([0.0, 0.5, 1.0, 2.5, 4.0, 4.0], np.float32))
+    # Hermite reproduces a straight line exactly in the interior
+    x = np.arange(16, dtype=np.float32)
+    y = o.interpolate("hermite", 1, 48000, 96000, x)
+    assert np.allclose(y[2:26], np.arange(2, 26) * 0.5, atol=1e-6)
+    assert y.size == 32
+    # 16-bit PCM: s / 32768, mono duplicated
+    pcm = np.array([0, 16384, -32768, 32767], "<i2").tobytes()
+    assert np.array_equal(o.pcm_to_stereo_f32(pcm, 16, 1),
+                          np.repeat(np.array([0, 0.5, -1.0, 32767 / 32768], np.float32), 2))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["linear", "hermite"])
+@pytest.mark.parametrize("ch,rin,rout", [(2, ra.SampleRate.Hz44100, ra.SampleRate.Hz48000),
+                                         (2, ra.SampleRate.Hz96000, ra.SampleRate.Hz44100),
+                                         (1, ra.SampleRate.Hz16000, ra.SampleRate.Hz48000),
+                                         (3, ra.SampleRate.Hz48000, ra.SampleRate.Hz22050)])
+def test_interpolators_match_the_reference_form(mode, ch, rin, rout):
+    x = synth.hash_noise(ch * 50001, seed=3)
+    g = ra.InterpolationResampler(ch, rin, rout, ra.InterpolationMode.Linear if mode == "linear" else ra.InterpolationMode.Hermite)
+    y = g.resample(x)
+    w = o.interpolate(mode, ch, RATES[rin], RATES[rout], x)
+    assert y.size == w.size
+    assert np.array_equal(y, w)          # same f64 position, same f32 operations in the same order
+    assert g.resample(np.zeros(0, np.float32)).size == 0
+    one = g.resample(x[:ch])             # a single frame: every output repeats it
+    assert np.array_equal(one, np.tile(x[:ch], one.size // ch))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bits", [16, 24, 32])
+@pytest.mark.parametrize("channels", [1, 2])
+def test_pcm_conversion_matches_the_reference_form(bits, channels):
+    import torch
+    rng = np.random.default_rng(bits * 10 + channels)
+    n = 100003 if channels == 1 else 100002
+    lo, hi = -(1 << (bits - 1)), (1 << (bits - 1)) - 1
+    s = rng.integers(lo, hi + 1, n, dtype=np.int64)
+    s[:4] = [lo, hi, 0, -1]
+    if bits == 16:
+        pcm = s.astype("<i2").tobytes()
+    elif bits == 32:
+        pcm = s.astype("<i4").tobytes()
+    else:
+        b = s.astype("<i4").view(np.uint8).reshape(-1, 4)[:, :3]
+        pcm = np.ascontiguousarray(b).tobytes()
+    want = o.pcm_to_stereo_f32(pcm, bits, channels)
+    dev = torch.device("cuda:0")
+    d_pcm = torch.frombuffer(bytearray(pcm), dtype=torch.uint8).to(dev)
+    d_out = torch.zeros(want.size, device=dev)
+    ra.pcm_to_stereo_f32_device(d_pcm, bits, channels, d_out)
+    assert np.array_equal(d_out.cpu().numpy(), want)
+    # ... and straight into the resampler: the decoded file is resampled without a host round trip
+    if bits == 16 and channels == 1:
+        g = ra.ResamplerFir.new(2, ra.SampleRate.Hz44100, ra.SampleRate.Hz48000, ra.Latency.Sample64, ra.Attenuation.Db90)
+        r = o.OracleFir(2, 44100, 48000, 128, 90)
+        d_y = torch.zeros(g.bulk_output_bound(want.size, 512), device=dev)
+        c, p = g.resample_bulk_device(d_out, d_y, 512)
+        yr, _ = r.resample_all(want, 512)
+        assert c == want.size and p == yr.size
+        assert float(np.sqrt(np.mean((d_y[:p].cpu().numpy().astype(np.float64) - yr) ** 2))) <= 1e-6
