@@ -40,9 +40,10 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 IN_HZ, OUT_HZ, CHANNELS = 44100, 48000, 2
-FIR_DTYPE = "f32 (bf16x3-split products, f32 accumulate)"
+FIR_DTYPE = {4: "f32 (bf16x3-split products, f32 accumulate)", 5: "f32 (fp16x2-split products, f32 accumulate)"}
 KERNEL_NAMES = {0: "fir_generic_kernel", 1: "fir_periodic_kernel (vector)", 2: "fir_periodic_db_kernel (vector)",
-                3: "fir_periodic_db_kernel (exact-f32 MFMA)", 4: "fir_split_kernel (bf16x3 MFMA)"}
+                3: "fir_periodic_db_kernel (exact-f32 MFMA)", 4: "fir_split_kernel (bf16x3 MFMA)",
+                5: "fir_split_kernel (fp16x2 MFMA)"}
 
 
 # ------------------------------------------------------------------------------------------------
@@ -493,7 +494,7 @@ def bench_fir(ctx: Ctx, args):
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": FIR_DTYPE if variant == 4 else "f32",
+        "dtype": FIR_DTYPE.get(variant, "f32"),
         "data": "synthetic",
         "config": {
             "workload": f"ResamplerFir 2ch interleaved 44100->48000, 128-tap (Sample64/Db90), "

@@ -333,7 +333,7 @@ class ResamplerFir:
 
     def kernel_variant(self) -> int:
         """0 generic, 1 periodic vector, 2 periodic vector (double-buffered), 3 periodic f32 matrix-core,
-        4 periodic split-bf16 matrix-core."""
+        4 periodic split matrix-core with three bf16 planes, 5 with two fp16 planes (default)."""
         return int(lib().rsmp_fir_kernel_variant(self._h))
 
     # ResamplerFir::resample (host slices) --------------------------------------------------------

@@ -638,7 +638,7 @@ extern "C" int rsmp_fir_kernel_variant(const rsmp_fir* r) {
     if (!r) return -1;
     if (!r->last_periodic || !r->periodic.geo_valid || !r->periodic.geo.ok) return 0;
     const rsmp::PeriodicGeometry& g = r->periodic.geo;
-    return g.mfma == 3 ? 4 : (g.mfma ? 3 : (g.producers ? 2 : 1));
+    return g.mfma == 3 ? (g.planes == 3 ? 4 : 5) : (g.mfma ? 3 : (g.producers ? 2 : 1));
 }
 
 extern "C" int rsmp_fir_mean_kernel_ms(rsmp_fir* r, float* ms, size_t* launches) {

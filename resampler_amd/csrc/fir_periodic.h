@@ -48,14 +48,16 @@ struct PeriodicGeometry {
     uint32_t producers = 0;      // > 0: double-buffered kernel, this many waves only stage
     uint32_t images = 0;         // double-buffered kernels: LDS images in the ring (2 or 4)
     uint32_t mfma = 0;           // > 0: matrix-core kernel (16-class tiles); period groups of 16 per work unit;
-                                 // 3: split-bf16 kernel (fir_split.hip)
+                                 // 3: split kernel (fir_split.hip)
+    uint32_t planes = 0;         // split kernel: 16-bit planes per f32 operand (3: bf16, exact; 2: fp16)
     uint32_t n_units = 0;        // work units per item: n_tiles (vector kernels) or tiles x unit splits (mfma)
     uint32_t lds_bytes = 0;
     bool inline_wraps = false;   // den >= 8: wrap variant computed inside the kernel
     bool operator==(const PeriodicGeometry& o) const {
         return a == o.a && b == o.b && den == o.den && taps == o.taps && row_len == o.row_len &&
                cg == o.cg && lp == o.lp && pw == o.pw && row_stride == o.row_stride &&
-               waves == o.waves && producers == o.producers && mfma == o.mfma && images == o.images;
+               waves == o.waves && producers == o.producers && mfma == o.mfma && images == o.images &&
+               planes == o.planes;
     }
 };
 

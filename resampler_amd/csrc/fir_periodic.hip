@@ -1890,7 +1890,7 @@ int class_table_for(int device, const std::vector<float>& table, const PeriodicG
     uint64_t bits;
     std::memcpy(&bits, &drift, sizeof bits);
     const ClassTableKey key{device, table.data(), g.den, g.a, g.b, g.row_len,
-                            g.mfma == 3 ? 3u : (g.mfma ? 1u : 0u), bits};
+                            g.mfma == 3 ? 8u + g.planes : (g.mfma ? 1u : 0u), bits};
     auto it = cache.tables.find(key);
     if (it == cache.tables.end()) {
         const HostClassTable host = build_class_table(table, g, drift);

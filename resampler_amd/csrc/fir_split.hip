@@ -35,6 +35,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <type_traits>
 #include <mutex>
 
 #include "common.h"
@@ -48,9 +49,17 @@ constexpr uint32_t kCtrlBytes = 256;                 // staged[2], done[2]
 constexpr uint32_t kWrapBytes = 4 * 16 * 16;         // up to four slots x 16 periods x (ch0, ch1, take, -)
 constexpr uint32_t kTouchBytes = 3 * 256;              // landing zone of the consumers' L2 prefetch touches
 constexpr uint32_t kImageBase = kCtrlBytes + kWrapBytes + kTouchBytes;
-constexpr uint32_t kRowBytes = 7 * 32;                 // an image row: six 32-byte plane rows (3 planes x 2 channels) + 32 bytes
-                                                       // of padding: 56 dwords = 7 mod 8 bank groups, so the eight rows a
-                                                       // transposed read touches per 32 lanes fall on distinct banks
+// An image row: per channel and plane one 32-byte plane row (16 periods x 16 bits), + 32 bytes of padding.
+// In 32-byte units the stride is 7 (three bf16 planes) or 5 (two fp16 planes): odd, so the eight rows a
+// transposed read touches per 32 lanes fall on distinct bank groups (64 banks x 4 B = 8 units).
+__host__ __device__ constexpr uint32_t row_bytes(int planes) { return planes == 3 ? 7u * 32u : 5u * 32u; }
+// Two-plane split: the operands are scaled by powers of two before they are cut into fp16 planes, so that
+// samples down to 2^-26 and taps down to 2^-27 keep their full relative precision (fp16 normals start at
+// 2^-14); samples of magnitude >= 16 overflow to infinity there -- the launch's non-finite check then has
+// the item recomputed in the reference's f32 form.
+constexpr float kXScale = 4096.0f;        // 2^12
+constexpr float kCScale = 8192.0f;        // 2^13
+constexpr float kOutScale = 1.0f / (4096.0f * 8192.0f);
 constexpr uint32_t kTouchAhead = 3;                    // items between a touch and the producers' loads of the same frames
 constexpr uint32_t kLdsLimit = 160 * 1024;
 #ifndef RSMP_POLL_SLEEP
@@ -105,6 +114,8 @@ typedef uint32_t v4u __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef const float __attribute__((address_space(1)))* gconst_f32_ptr;
 typedef const v2f __attribute__((address_space(1)))* gconst_f2_ptr;
 typedef const v4u __attribute__((address_space(1)))* gconst_u4_ptr;
@@ -240,6 +251,13 @@ __device__ __forceinline__ void split3(float x, uint32_t& p1, uint32_t& p2, uint
     const float r2 = r1 - __uint_as_float(p2 & 0xFFFF0000u);
     p3 = __float_as_uint(r2);
 }
+// f32 pair -> fp16 pair (round to nearest, one v_cvt_pk_f16_f32): low half = a, high half = b
+__device__ __forceinline__ uint32_t cvt_pk_f16(float a, float b) {
+    const v2f v = v2f{a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2));
+}
+__device__ __forceinline__ float f16_lo(uint32_t w) { return static_cast<float>(__builtin_bit_cast(f16x2, w)[0]); }
+__device__ __forceinline__ float f16_hi(uint32_t w) { return static_cast<float>(__builtin_bit_cast(f16x2, w)[1]); }
 // (high half of hi) : (high half of lo)
 __device__ __forceinline__ uint32_t pack_hi16(uint32_t hi, uint32_t lo) {
     return __builtin_amdgcn_perm(hi, lo, 0x07060302u);
@@ -292,9 +310,10 @@ __device__ __forceinline__ bool wave_is_producer(uint32_t w) { return w < 4 || w
 __device__ __forceinline__ uint32_t producer_index(uint32_t w) { return w == 0 ? 5 : (w < 4 ? w - 1 : w - 3); }
 __device__ __forceinline__ uint32_t consumer_index(uint32_t w) { return w < 6 ? w - 4 : w - 6; }
 
-template <int NK>
+template <int NK, int PLANES>
 __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __restrict__ descs,
                                                          const SplitArgs g) {
+    constexpr uint32_t kRowBytes = row_bytes(PLANES);
     extern __shared__ __attribute__((aligned(16))) char lds[];
     uint32_t* ctrl = reinterpret_cast<uint32_t*>(lds);
     uint32_t* staged = ctrl;        // [slot]: producers that finished staging, cumulative
@@ -426,17 +445,35 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
                 for (int c = 0; c < 2; ++c) {          // channel
 #pragma unroll
                     for (int fr = 0; fr < 2; ++fr) {   // frame 2K + fr
-                        uint32_t pl[3][5];
-#pragma unroll
-                        for (int i = 0; i < 5; ++i) split3(v[i][2 * fr + c], pl[0][i], pl[1][i], pl[2][i]);
                         char* pr = fr ? prim1 : prim;
                         char* du = fr ? dup1 : dup0;
+                        if constexpr (PLANES == 3) {
+                            uint32_t pl[3][5];
 #pragma unroll
-                        for (int p = 0; p < 3; ++p) {
-                            *reinterpret_cast<u2*>(pr + (3 * c + p) * 32) =
-                                u2{pack_hi16(pl[p][1], pl[p][0]), pack_hi16(pl[p][3], pl[p][2])};
-                            *reinterpret_cast<u2*>(du + (3 * c + p) * 32) =
-                                u2{pack_hi16(pl[p][2], pl[p][1]), pack_hi16(pl[p][4], pl[p][3])};
+                            for (int i = 0; i < 5; ++i) split3(v[i][2 * fr + c], pl[0][i], pl[1][i], pl[2][i]);
+#pragma unroll
+                            for (int p = 0; p < 3; ++p) {
+                                *reinterpret_cast<u2*>(pr + (3 * c + p) * 32) =
+                                    u2{pack_hi16(pl[p][1], pl[p][0]), pack_hi16(pl[p][3], pl[p][2])};
+                                *reinterpret_cast<u2*>(du + (3 * c + p) * 32) =
+                                    u2{pack_hi16(pl[p][2], pl[p][1]), pack_hi16(pl[p][4], pl[p][3])};
+                            }
+                        } else {
+                            // two fp16 planes: h1 = RN16(s), h2 = RN16(s - h1) with s = 2^12 x (s - h1 is exact)
+                            float s[5];
+#pragma unroll
+                            for (int i = 0; i < 5; ++i) s[i] = v[i][2 * fr + c] * kXScale;
+                            const uint32_t a01 = cvt_pk_f16(s[0], s[1]), a23 = cvt_pk_f16(s[2], s[3]), a4 = cvt_pk_f16(s[4], s[4]);
+                            const uint32_t b01 = cvt_pk_f16(s[0] - f16_lo(a01), s[1] - f16_hi(a01));
+                            const uint32_t b23 = cvt_pk_f16(s[2] - f16_lo(a23), s[3] - f16_hi(a23));
+                            const uint32_t b4 = cvt_pk_f16(s[4] - f16_lo(a4), 0.f);
+                            // periods (4Q, 4Q+1), (4Q+2, 4Q+3) to row k; (4Q+1, 4Q+2), (4Q+3, 4Q+4) to row k + a
+                            *reinterpret_cast<u2*>(pr + (2 * c) * 32) = u2{a01, a23};
+                            *reinterpret_cast<u2*>(pr + (2 * c + 1) * 32) = u2{b01, b23};
+                            *reinterpret_cast<u2*>(du + (2 * c) * 32) =
+                                u2{__builtin_amdgcn_alignbyte(a23, a01, 2), __builtin_amdgcn_alignbyte(a4, a23, 2)};
+                            *reinterpret_cast<u2*>(du + (2 * c + 1) * 32) =
+                                u2{__builtin_amdgcn_alignbyte(b23, b01, 2), __builtin_amdgcn_alignbyte(b4, b23, 2)};
                         }
                     }
                 }
@@ -596,7 +633,8 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
     const uint32_t j0 = T * 16u + 4 * grp;             // the lane's four classes (D rows)
     const uint32_t pl = lane & 15;                     // the lane's period (D column)
 
-    bf16x8 A[NK][3];
+    typedef typename std::conditional<PLANES == 3, bf16x8, f16x8>::type frag_t;
+    frag_t A[NK][PLANES];
     const float* cur_table = nullptr;
     // The sums of an item whose wave lies wholly inside the launch are stored inside the NEXT item's MFMA
     // stream (the wave mostly waits for the matrix pipe there); only that wave-uniform straight-line case:
@@ -624,11 +662,11 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
         it.valid = true;
         if (d.class_coef != cur_table) {   // streams of one launch may differ in drift
             cur_table = d.class_coef;
-            gconst_u4_ptr tp = (gconst_u4_ptr)(cur_table) + static_cast<size_t>(T) * (NK * 3 * 64) + lane;
+            gconst_u4_ptr tp = (gconst_u4_ptr)(cur_table) + static_cast<size_t>(T) * (NK * PLANES * 64) + lane;
 #pragma unroll
             for (int s = 0; s < NK; ++s)
 #pragma unroll
-                for (int p = 0; p < 3; ++p) A[s][p] = __builtin_bit_cast(bf16x8, tp[(s * 3 + p) * 64]);
+                for (int p = 0; p < PLANES; ++p) A[s][p] = __builtin_bit_cast(frag_t, tp[(s * PLANES + p) * 64]);
         }
         const uint32_t base = kImageBase + slot * image_bytes + lane_off;
         // L2 prefetch for the producers: the frames of the item kTouchAhead items on (same stream assumed),
@@ -649,36 +687,52 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
         wt.event(2);
 
         v4f acc0 = v4f{0.f, 0.f, 0.f, 0.f}, acc1 = v4f{0.f, 0.f, 0.f, 0.f};
-        auto frag = [&](uint32_t plane_ch, int s) -> bf16x8 {
+        auto frag = [&](uint32_t plane_ch, int s) -> frag_t {
             const uint32_t addr = base + plane_ch * 32u;   // (everything but `base` is an immediate offset)
             const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(lds + addr + s * (32 * kRowBytes)));
             const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(lds + addr + s * (32 * kRowBytes) + 16 * kRowBytes));
             const s16x8 t = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-            return __builtin_bit_cast(bf16x8, t);
+            return __builtin_bit_cast(frag_t, t);
         };
         if (!(g.debug & 2))
 #pragma unroll
         for (int s = 0; s < NK; ++s) {
-            const bf16x8 x1 = frag(0, s), x2 = frag(1, s), x3 = frag(2, s);
-            const bf16x8 y1 = frag(3, s), y2 = frag(4, s), y3 = frag(5, s);
-            // smallest products first
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[s][0], x3, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[s][0], y3, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[s][1], x2, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[s][1], y2, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[s][2], x1, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[s][2], y1, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[s][0], x2, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[s][0], y2, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[s][1], x1, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[s][1], y1, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[s][0], x1, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[s][0], y1, acc1, 0, 0, 0);
+            if constexpr (PLANES == 3) {
+                const bf16x8 x1 = frag(0, s), x2 = frag(1, s), x3 = frag(2, s);
+                const bf16x8 y1 = frag(3, s), y2 = frag(4, s), y3 = frag(5, s);
+                // smallest products first
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[s][0], x3, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[s][0], y3, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[s][1], x2, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[s][1], y2, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[s][2], x1, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[s][2], y1, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[s][0], x2, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[s][0], y2, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[s][1], x1, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[s][1], y1, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[s][0], x1, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[s][0], y1, acc1, 0, 0, 0);
+            } else {
+                const f16x8 x1 = frag(0, s), x2 = frag(1, s);
+                const f16x8 y1 = frag(2, s), y2 = frag(3, s);
+                // c1 x2 + c2 x1 + c1 x1 (c2 x2 is below 2^-22 of a product), smallest first
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[s][0], x2, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[s][0], y2, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[s][1], x1, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[s][1], y1, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[s][0], x1, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[s][0], y1, acc1, 0, 0, 0);
+            }
             if (s == 0 && !(g.debug & 131072)) {
                 __builtin_amdgcn_sched_barrier(0);
                 flush_pending();
                 __builtin_amdgcn_sched_barrier(0);
             }
+        }
+        if constexpr (PLANES == 2) {
+            acc0 *= kOutScale;
+            acc1 *= kOutScale;
         }
         flush_pending();   // (no MFMA loop ran, or the experiment switch above)
         // class 0 may take the wrap variant the producers left with the image (tile 0, D row 0)
@@ -740,8 +794,20 @@ inline uint32_t split_class_offset(uint32_t a, uint32_t b, uint32_t j) {
 // Geometry of the split-bf16 kernel for num/den, or !ok: two channels, one true period per class
 // pattern (b = den: 16..160 classes = at most one tile per consumer wave), window of <= 160 taps,
 // two images within the LDS.
+// RSMP_FIR_SPLIT_PLANES = 3 selects the three-plane bf16 split (every f32 operand exactly), default 2: two
+// fp16 planes per operand, three matrix products instead of six.
+static uint32_t split_planes_knob() {
+    static const uint32_t v = [] {
+        const char* e = getenv("RSMP_FIR_SPLIT_PLANES");
+        return e && atoi(e) == 3 ? 3u : 2u;
+    }();
+    return v;
+}
+
 PeriodicGeometry split_geometry(uint64_t num, uint64_t den, uint32_t taps, uint32_t channels) {
     PeriodicGeometry g;
+    const uint32_t planes = split_planes_knob();
+    const uint32_t kRowBytes = row_bytes(static_cast<int>(planes));
     if (channels != 2 || num == 0 || num > 4096 || den < 16 || den > 16 * kConsumers) return g;
     const uint32_t a = static_cast<uint32_t>(num), b = static_cast<uint32_t>(den);
     const uint32_t n_tiles = (b + 15) / 16;
@@ -781,18 +847,21 @@ PeriodicGeometry split_geometry(uint64_t num, uint64_t den, uint32_t taps, uint3
     g.producers = kProducers;
     g.images = slots;
     g.mfma = 3;
+    g.planes = planes;
     g.lds_bytes = lds;
     g.inline_wraps = true;
     g.ok = true;
     return g;
 }
 
-// Class-table image for the split kernel: [tile][k step][plane][lane][8 bf16]; lane (class m =
+// Class-table image for the split kernel: [tile][k step][plane][lane][8 x 16 bit]; lane (class m =
 // lane & 15, k group = lane >> 4) element j holds window position 32 s + 16 (j >> 2) + 4 (lane >> 4) +
-// (j & 3) -- the order in which the transposed LDS reads deliver the frames.
+// (j & 3) -- the order in which the transposed LDS reads deliver the frames.  Three planes: bf16 by
+// truncation (c == p1 + p2 + p3 exactly); two planes: fp16, round to nearest, of 2^13 c.
 void split_store_class(std::vector<float>& coef, const PeriodicGeometry& g, uint32_t tile, uint32_t m,
                        uint32_t shift, const std::vector<float>& mixed) {
     const uint32_t nk = g.row_len / 32;
+    const uint32_t planes = g.planes;
     uint32_t* words = reinterpret_cast<uint32_t*>(coef.data());
     for (uint32_t s = 0; s < nk; ++s)
         for (uint32_t grp = 0; grp < 4; ++grp)
@@ -800,24 +869,35 @@ void split_store_class(std::vector<float>& coef, const PeriodicGeometry& g, uint
                 const uint32_t pos = 32 * s + 16 * (j >> 2) + 4 * grp + (j & 3);
                 float c = 0.f;
                 if (pos >= shift && pos - shift < g.taps) c = mixed[pos - shift];
-                uint32_t p[3];
-                uint32_t u;
-                std::memcpy(&u, &c, 4);
-                p[0] = u >> 16;
-                float h;
-                uint32_t hu = u & 0xFFFF0000u;
-                std::memcpy(&h, &hu, 4);
-                const float r1 = c - h;
-                std::memcpy(&u, &r1, 4);
-                p[1] = u >> 16;
-                hu = u & 0xFFFF0000u;
-                std::memcpy(&h, &hu, 4);
-                const float r2 = r1 - h;
-                std::memcpy(&u, &r2, 4);
-                p[2] = u >> 16;
+                uint32_t p[3] = {0, 0, 0};
+                if (planes == 3) {
+                    uint32_t u;
+                    std::memcpy(&u, &c, 4);
+                    p[0] = u >> 16;
+                    float h;
+                    uint32_t hu = u & 0xFFFF0000u;
+                    std::memcpy(&h, &hu, 4);
+                    const float r1 = c - h;
+                    std::memcpy(&u, &r1, 4);
+                    p[1] = u >> 16;
+                    hu = u & 0xFFFF0000u;
+                    std::memcpy(&h, &hu, 4);
+                    const float r2 = r1 - h;
+                    std::memcpy(&u, &r2, 4);
+                    p[2] = u >> 16;
+                } else {
+                    const float sc = c * kCScale;
+                    const _Float16 h1 = static_cast<_Float16>(sc);
+                    const _Float16 h2 = static_cast<_Float16>(sc - static_cast<float>(h1));
+                    uint16_t b1, b2;
+                    std::memcpy(&b1, &h1, 2);
+                    std::memcpy(&b2, &h2, 2);
+                    p[0] = b1;
+                    p[1] = b2;
+                }
                 const uint32_t lane = 16 * grp + m;
-                for (uint32_t pl = 0; pl < 3; ++pl) {
-                    const size_t dword = ((((static_cast<size_t>(tile) * nk + s) * 3 + pl) * 64 + lane) * 4) + (j >> 1);
+                for (uint32_t pl = 0; pl < planes; ++pl) {
+                    const size_t dword = ((((static_cast<size_t>(tile) * nk + s) * planes + pl) * 64 + lane) * 4) + (j >> 1);
                     const uint32_t sh = (j & 1) * 16;
                     words[dword] = (words[dword] & ~(0xFFFFu << sh)) | (p[pl] << sh);
                 }
@@ -825,7 +905,7 @@ void split_store_class(std::vector<float>& coef, const PeriodicGeometry& g, uint
 }
 
 size_t split_table_floats(const PeriodicGeometry& g) {
-    return static_cast<size_t>(g.n_tiles) * (g.row_len / 32) * 3 * 64 * 4;
+    return static_cast<size_t>(g.n_tiles) * (g.row_len / 32) * g.planes * 64 * 4;
 }
 
 hipError_t launch_fir_split(const FirStreamDesc* d_descs, uint32_t n_streams, const PeriodicGeometry& geo,
@@ -835,11 +915,17 @@ hipError_t launch_fir_split(const FirStreamDesc* d_descs, uint32_t n_streams, co
         return e ? static_cast<uint32_t>(atoi(e)) : 0u;
     }();
     SplitArgs args{geo.a, geo.b, geo.taps, geo.n_tiles, geo.row_stride, geo.images, geo.lds_bytes, max_blocks, max_blocks * n_streams, debug, n_streams, fuse_tail ? 1u : 0u, nullptr};
-    const void* fns[5] = {reinterpret_cast<const void*>(fir_split_kernel<1>),
-                          reinterpret_cast<const void*>(fir_split_kernel<2>),
-                          reinterpret_cast<const void*>(fir_split_kernel<3>),
-                          reinterpret_cast<const void*>(fir_split_kernel<4>),
-                          reinterpret_cast<const void*>(fir_split_kernel<5>)};
+    const void* fns3[5] = {reinterpret_cast<const void*>(fir_split_kernel<1, 3>),
+                           reinterpret_cast<const void*>(fir_split_kernel<2, 3>),
+                           reinterpret_cast<const void*>(fir_split_kernel<3, 3>),
+                           reinterpret_cast<const void*>(fir_split_kernel<4, 3>),
+                           reinterpret_cast<const void*>(fir_split_kernel<5, 3>)};
+    const void* fns2[5] = {reinterpret_cast<const void*>(fir_split_kernel<1, 2>),
+                           reinterpret_cast<const void*>(fir_split_kernel<2, 2>),
+                           reinterpret_cast<const void*>(fir_split_kernel<3, 2>),
+                           reinterpret_cast<const void*>(fir_split_kernel<4, 2>),
+                           reinterpret_cast<const void*>(fir_split_kernel<5, 2>)};
+    const void* const* fns = geo.planes == 3 ? fns3 : fns2;
     const uint32_t nk = geo.row_len / 32;
     if (nk < 1 || nk > 5) return hipErrorInvalidValue;
     int device = 0;
@@ -849,7 +935,7 @@ hipError_t launch_fir_split(const FirStreamDesc* d_descs, uint32_t n_streams, co
     static std::map<std::pair<int, uint32_t>, bool> granted;
     {
         std::lock_guard<std::mutex> lock(mu);
-        bool& have = granted[{device, nk}];
+        bool& have = granted[{device, nk * 8 + geo.planes}];
         if (!have) {
             e = hipFuncSetAttribute(fns[nk - 1], hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit);
             if (e != hipSuccess) return e;

@@ -13,6 +13,7 @@ from resampler_amd import synth
 pytestmark = pytest.mark.gpu
 
 RMS_TOL = 1e-6   # north_star tolerance
+SPLIT_VARIANT = 4 if os.environ.get("RSMP_FIR_SPLIT_PLANES") == "3" else 5   # bf16x3 or (default) fp16x2 split kernel
 ATT_DB = {ra.Attenuation.Db60: 60, ra.Attenuation.Db90: 90, ra.Attenuation.Db120: 120}
 
 
@@ -160,7 +161,7 @@ def test_c2_full_size_bulk_parity_and_max_abs():
     assert rms(yg, yr) <= RMS_TOL
     assert float(np.max(np.abs(yg.astype(np.float64) - yr))) < 2e-5
     if os.environ.get("RSMP_FIR_MFMA", "3") == "3":
-        assert g.kernel_variant() == 4   # the full-size config runs on the split-bf16 matrix kernel (the bench's kernel)
+        assert g.kernel_variant() == SPLIT_VARIANT   # the full-size config runs on the split matrix kernel (the bench's kernel)
 
 
 def test_device_resident_api_and_batch():
@@ -229,7 +230,7 @@ def test_matrix_core_kernel_ragged_batch_and_edges(kernel):
     mfma_on = knob != "0"
     # periodic matrix-core kernel by default (4 = the split-bf16 one, RSMP_FIR_MFMA=3)
     split = knob == "3" and kernel == ra.FirKernel.Periodic
-    assert gs[-1].kernel_variant() == ((4 if split else 3) if mfma_on else 1)
+    assert gs[-1].kernel_variant() == ((SPLIT_VARIANT if split else 3) if mfma_on else 1)
     # other even rate pairs on the same path: 44.1 -> 96 k (20 class tiles), 16 / 32 / 64 taps above
     g, r = make_pair(2, 44100, 96000, kernel=kernel)
     x = synth.sweep(70001, 2, 44100.0)

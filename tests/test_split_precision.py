@@ -52,3 +52,36 @@ def test_six_products_match_an_f32_chain():
     rms = lambda e: float(np.sqrt(np.mean(e ** 2)))
     assert rms(six - ref) <= 1.0e-7 and rms(six - ref) <= 1.5 * rms(chain - ref)
     assert rms(three - ref) > 1.0e-6                                # bf16x2 would fail the north-star tolerance
+
+
+def split_f16(v):
+    a = v.astype(np.float16).astype(np.float32)
+    b = (v - a).astype(np.float32).astype(np.float16).astype(np.float32)
+    return a, b
+
+
+def test_two_fp16_planes_with_three_products_stay_inside_the_gate():
+    # the default split kernel: operands scaled by 2^12 / 2^13, two fp16 planes each (round to nearest),
+    # products c1 x2 + c2 x1 + c1 x1 accumulated in f32 per 32-tap block like v_mfma_f32_16x16x32_f16
+    rng = np.random.default_rng(2)
+    taps, n = 128, 4000
+    k = np.arange(taps) - 63.3
+    h = (np.sinc(k * 0.9) * np.kaiser(taps, 10)).astype(np.float32)
+    h = (h / h.sum()).astype(np.float32)
+    idx = np.arange(n)[:, None] + np.arange(taps)[None, :]
+    rms = lambda e: float(np.sqrt(np.mean(e ** 2)))
+    for scale in (0.99, 0.3, 1e-3, 1e-6):
+        x = np.clip(rng.standard_normal(n + taps) * scale, -1, 1).astype(np.float32)
+        ref = x[idx].astype(np.float64) @ h.astype(np.float64)
+        h1, h2 = split_f16((h * np.float32(8192.0)).astype(np.float32))
+        x1, x2 = split_f16((x * np.float32(4096.0)).astype(np.float32))
+        got = blockwise([(h1, x2), (h2, x1), (h1, x1)], idx, taps, n) * np.float32(1.0 / (4096.0 * 8192.0))
+        chain = np.zeros(n, np.float32)
+        for t in range(taps):
+            chain = np.float32(chain + x[idx[:, t]] * h[t])
+        assert rms(got - ref) <= 1.0e-7                                         # far inside the 1e-6 gate (6e-8 at full scale)
+        if scale >= 1e-3:
+            assert rms(got - ref) <= rms(chain - ref)                           # at least as close as an f32 FMA chain
+        assert rms(got - ref) <= 1e-5 * rms(ref)                                # quiet signals keep their relative precision (-100 dB)
+    # samples of magnitude >= 16 overflow the scaled fp16 plane: the kernel's non-finite check takes over
+    assert not np.isfinite(np.float16(np.float32(16.0) * np.float32(4096.0)))
