@@ -49,21 +49,22 @@ enum { RSMP_ATTENUATION_DB60 = 0, RSMP_ATTENUATION_DB90, RSMP_ATTENUATION_DB120 
 
 /* FIR kernel selection (rsmp_fir_set_kernel).  AUTO picks PERIODIC when the rate pair reduces to
  * a small rational and the launch is long enough, GENERIC otherwise.  PERIODIC runs 2-channel
- * streams on the matrix cores where the geometry allows: the split-bf16 kernel (every f32 operand as
- * the exact sum of three bf16 values, six bf16 MFMA products accumulated in f32) for rate pairs with
+ * streams on the matrix cores where the geometry allows: the split kernel (every f32 operand as the sum
+ * of two fp16 values of the scaled operand, three fp16 MFMA products accumulated in f32; RSMP_FIR_SPLIT_PLANES=3
+ * selects three bf16 planes / six products, exact in every bit) for rate pairs with
  * 16..160 classes such as 44.1 <-> 48 kHz, the exact-f32 MFMA kernel otherwise.  PERIODIC_F32 keeps
  * every product in f32 (exact-f32 MFMA or vector kernels, never the split one); PERIODIC_VECTOR forces
  * the packed-FMA vector kernel for every channel count.  All produce the same results within the
  * 1e-6 RMS gate (measured against the CPU path: about 1.2e-7 RMS each).
- * Non-finite input (+-inf, NaN): GENERIC -- and the lock-step batch below -- evaluate the affected outputs
- * in the reference's own form (two phase rows, per-lane lerp, src/fir/avx.rs:25-58): the same outputs are
- * finite, +inf, -inf or NaN as in the reference.  The PERIODIC kernels pre-mix the two phase rows and
- * multiply up to 16 samples next to an output's true window by zero padding coefficients (0 * inf = NaN),
- * and the split-bf16 kernel splits an infinity into (inf, NaN, NaN): every output the reference makes
- * non-finite is non-finite there too (as NaN, possibly where the reference has +-inf), and at most the
- * outputs within 32 output frames of such an output are NaN in addition; all other outputs are unaffected.
- * Callers that must reproduce the reference's inf / NaN pattern select GENERIC
- * (tests/test_fir_gpu.py::test_non_finite_input_contract). */
+ * Non-finite and out-of-range input: every kernel gives the reference's answer -- the same outputs are
+ * finite, +inf, -inf or NaN (src/fir/avx.rs:25-58).  The PERIODIC kernels check the sums they store; a
+ * launch that saw a non-finite sum (an inf / NaN sample, or in the split kernel a sample of magnitude
+ * >= 16, beyond its fp16 planes) is followed by a repair launch that re-evaluates the affected 1024-frame
+ * chunks in the reference's own two-row form (tests/test_fir_gpu.py::
+ * test_non_finite_and_huge_input_match_the_reference).  One residue: at outputs whose exact position is a
+ * multiple of 1/1024 frame the reference's inf-versus-NaN depends on the sign of an ~1e-12 rounding residue
+ * of its f64 position; the repair pass may say NaN where the reference says inf or vice versa (GENERIC, which
+ * replays the exact f64 positions, does not).  Clean audio never takes the repair path. */
 enum { RSMP_FIR_KERNEL_AUTO = 0, RSMP_FIR_KERNEL_GENERIC = 1, RSMP_FIR_KERNEL_PERIODIC = 2,
        RSMP_FIR_KERNEL_PERIODIC_VECTOR = 3, RSMP_FIR_KERNEL_PERIODIC_F32 = 4 };
 

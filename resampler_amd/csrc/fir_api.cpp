@@ -437,6 +437,7 @@ int launch_jobs(rsmp_fir* leader, std::vector<Job>& jobs, hipStream_t stream) {
             if (ch > max_ch_generic) max_ch_generic = ch;
         } else {
             const rsmp::PeriodicGeometry& geo = r->periodic.geo;
+            ds.drift = r->periodic.table_drift;
             ds.class_coef = r->periodic.table.d_coef;
             ds.class_wrap_coef = r->periodic.table.d_wrap_coef;
             ds.class_meta = r->periodic.table.d_meta;
@@ -498,9 +499,27 @@ int launch_jobs(rsmp_fir* leader, std::vector<Job>& jobs, hipStream_t stream) {
         // a launch made of split-kernel streams only lets that kernel copy the tails as well
         tail_fused = n_generic == 0 && groups.size() == 1 && g.geo.mfma == 3 && max_blocks != 0 &&
                      getenv("RSMP_FIR_NO_FUSED_TAIL") == nullptr;
+        // where the launch marks non-finite sums: one bit per stream and 1024-frame chunk (fir_nonfinite.h)
+        uint32_t max_out = 0;
+        for (size_t i : g.members)
+            if (jobs[i].plan->produced_frames > max_out) max_out = static_cast<uint32_t>(jobs[i].plan->produced_frames);
+        rsmp::NfArgs nf;
+        nf.chunks = (max_out >> rsmp::kNfChunkShift) + 1;
+        const size_t nf_words = 1 + (g.members.size() * nf.chunks + 31) / 32;
+        if (nf_words * sizeof(uint32_t) > leader->d_nf.capacity()) {
+            RSMP_HIP_CHECK(hipStreamSynchronize(stream));
+            RSMP_HIP_CHECK(leader->d_nf.reserve(nf_words * sizeof(uint32_t)));
+            RSMP_HIP_CHECK(hipMemsetAsync(leader->d_nf.get(), 0, leader->d_nf.capacity(), stream));
+        }
+        nf.words = leader->d_nf.as<uint32_t>();
+        if (++leader->nf_tag == 0) leader->nf_tag = 1;
+        nf.tag = leader->nf_tag;
         RSMP_HIP_CHECK(rsmp::launch_fir_periodic(d_descs + first,
                                                  static_cast<uint32_t>(g.members.size()), g.geo,
-                                                 max_blocks, leader->d_work_counter, stream, tail_fused));
+                                                 max_blocks, leader->d_work_counter, nf, stream, tail_fused));
+        static const bool no_repair = getenv("RSMP_FIR_NO_REPAIR") != nullptr;   // A/B timing only
+        if (!no_repair)
+            RSMP_HIP_CHECK(rsmp::launch_fir_repair(d_descs + first, static_cast<uint32_t>(g.members.size()), nf, stream));
         first += g.members.size();
     }
     if (leader->profiling) {

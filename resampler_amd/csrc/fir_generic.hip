@@ -125,7 +125,90 @@ __global__ __launch_bounds__(kBlock) void fir_tail_copy_kernel(const FirStreamDe
     }
 }
 
+// Chunks of 1024 output frames that a periodic launch marked (fir_nonfinite.h), re-evaluated in the
+// reference's form.  The position of output m is the exact rational m * num / den plus the drift the
+// stream's class table was built for -- the same phase rows and frac the periodic kernel pre-mixed -- and
+// outputs at an integer position take the previous frame and row 1023 where the wrap bitmap says so
+// (resampler_fir.rs:544, :562-565).
+__global__ __launch_bounds__(kBlock) void fir_repair_kernel(const FirStreamDesc* __restrict__ descs,
+                                                            uint32_t n_streams, NfArgs nf) {
+    if (__hip_atomic_load(nf.words, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != nf.tag) return;
+    const int g = threadIdx.x & (kLanesPerFrame - 1);
+    const uint32_t slot = threadIdx.x / kLanesPerFrame;
+    const uint32_t total = n_streams * nf.chunks;
+    for (uint32_t idx = blockIdx.x; idx < total; idx += gridDim.x) {
+        const uint32_t word = __hip_atomic_load(nf.words + 1 + (idx >> 5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!((word >> (idx & 31)) & 1u)) continue;
+        const uint32_t s = idx / nf.chunks, chunk = idx - s * nf.chunks;
+        const FirStreamDesc d = descs[s];
+        const uint32_t n_begin = chunk << kNfChunkShift;
+        const uint32_t n_end = n_begin + (1u << kNfChunkShift) < d.n_out ? n_begin + (1u << kNfChunkShift) : d.n_out;
+        const uint32_t taps = d.taps, channels = d.channels;
+        for (uint32_t base = n_begin; base < n_end; base += kFramesPerPass) {
+            const uint32_t n = base + slot;
+            const bool live = n < n_end;
+            const uint64_t m = d.abs_out + (live ? n : n_begin);
+            const uint64_t t = m * d.num;
+            const uint64_t off = t / d.den, rem = t - off * d.den;
+            double fract = static_cast<double>(rem) / static_cast<double>(d.den) + d.drift;
+            bool wrapped = false;
+            if (rem == 0) {
+                fract = d.drift > 0.0 ? d.drift : 0.0;
+                if (d.wrap_bits) {
+                    const uint64_t K = m / d.den - d.wrap_k0;
+                    wrapped = (d.wrap_bits[K >> 5] >> (K & 31)) & 1u;
+                }
+            }
+            if (fract < 0.0) fract = 0.0;
+            double phase_f = fract * 1024.0;                              // :562
+            phase_f = phase_f < 1023.0 ? phase_f : 1023.0;
+            uint32_t phase1 = static_cast<uint32_t>(phase_f);             // :563
+            uint32_t phase2 = phase1 + 1 < 1023u ? phase1 + 1 : 1023u;    // :564
+            float frac = static_cast<float>(phase_f - static_cast<double>(phase1));  // :565
+            int64_t v0 = static_cast<int64_t>(off) - static_cast<int64_t>(d.abs_consumed);
+            if (wrapped) {   // the f64 position was just below the integer: previous frame, row 1023, frac 0
+                v0 -= 1;
+                phase1 = phase2 = 1023u;
+                frac = 0.0f;
+            }
+            const float4* __restrict__ row1 = reinterpret_cast<const float4*>(d.coeffs + static_cast<size_t>(phase1) * taps);
+            const float4* __restrict__ row2 = reinterpret_cast<const float4*>(d.coeffs + static_cast<size_t>(phase2) * taps);
+            const float one_minus_frac = 1.0f - frac;
+            for (uint32_t c = 0; c < channels; ++c) {
+                float a1 = 0.0f, a2 = 0.0f;
+                if (live) {
+                    for (uint32_t q = g; q < taps / 4; q += kLanesPerFrame) {
+                        const float4 k1 = row1[q];
+                        const float4 k2 = row2[q];
+                        const int64_t v = v0 + 4 * static_cast<int64_t>(q);
+                        const float x0 = load_sample(d, v, c);
+                        const float x1 = load_sample(d, v + 1, c);
+                        const float x2 = load_sample(d, v + 2, c);
+                        const float x3 = load_sample(d, v + 3, c);
+                        a1 = fmaf(k1.x, x0, a1); a2 = fmaf(k2.x, x0, a2);
+                        a1 = fmaf(k1.y, x1, a1); a2 = fmaf(k2.y, x1, a2);
+                        a1 = fmaf(k1.z, x2, a1); a2 = fmaf(k2.z, x2, a2);
+                        a1 = fmaf(k1.w, x3, a1); a2 = fmaf(k2.w, x3, a2);
+                    }
+                }
+                const float part = a1 * one_minus_frac + a2 * frac;
+                const float y = group_sum8(part);
+                if (live && g == 0) d.out[static_cast<size_t>(n) * channels + c] = y;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) (void)atomicAnd(nf.words + 1 + (idx >> 5), ~(1u << (idx & 31)));   // the bitmap is zero again for the next launch
+    }
+}
+
 }  // namespace
+
+hipError_t launch_fir_repair(const FirStreamDesc* d_descs, uint32_t n_streams, const NfArgs& nf, hipStream_t stream) {
+    if (n_streams == 0 || !nf.words || nf.chunks == 0) return hipSuccess;
+    const uint32_t total = n_streams * nf.chunks;
+    hipLaunchKernelGGL(fir_repair_kernel, dim3(total < 512 ? total : 512), dim3(kBlock), 0, stream, d_descs, n_streams, nf);
+    return hipGetLastError();
+}
 
 hipError_t launch_fir_generic(const FirStreamDesc* d_descs, uint32_t n_streams, uint32_t max_out,
                               uint32_t max_channels, hipStream_t stream) {

@@ -40,6 +40,8 @@ struct rsmp_fir {
     rsmp::PeriodicState periodic;
     bool last_periodic = false;   // the handle's last launch went through a periodic kernel
     unsigned long long* d_work_counter = nullptr;   // periodic kernel's item queue (leader only), zero between launches
+    rsmp::DeviceBuffer d_nf;                        // non-finite marks of the periodic launches (leader only)
+    uint32_t nf_tag = 0;
     hipStream_t last_stream = nullptr;              // the stream of the handle's most recent launch
     bool last_stream_valid = false;
     // optional timing of the main convolution launch(es) (rsmp_fir_set_profiling)

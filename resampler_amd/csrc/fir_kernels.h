@@ -6,6 +6,7 @@
 #include <cstdint>
 
 #include "../../include/resampler_amd.h"
+#include "fir_nonfinite.h"
 
 namespace rsmp {
 
@@ -41,6 +42,7 @@ struct FirStreamDesc {
     uint64_t abs_out;              // output frames produced since reset, before this launch
     uint64_t abs_consumed;         // input frames retired since reset, before this launch
     uint64_t wrap_k0;              // wrap_bits bit K <-> absolute output (wrap_k0 + K) * den
+    double drift;                  // periodic kernels: the f64 drift the stream's class table was built for
 };
 
 constexpr uint32_t kFirTile = 32;   // output frames per workgroup tile (generic kernel): one pass of 32 x 8 lanes
@@ -48,6 +50,9 @@ constexpr uint32_t kFirTile = 32;   // output frames per workgroup tile (generic
 // Generic kernel: any ratio, reference-form two-row interpolation; grid = (max tiles, streams).
 hipError_t launch_fir_generic(const FirStreamDesc* d_descs, uint32_t n_streams, uint32_t max_out,
                               uint32_t max_channels, hipStream_t stream);
+// Re-evaluates, in the reference's two-row form, the output chunks a periodic launch marked as non-finite
+// (fir_nonfinite.h); exits at once when the launch marked nothing.
+hipError_t launch_fir_repair(const FirStreamDesc* d_descs, uint32_t n_streams, const NfArgs& nf, hipStream_t stream);
 // Copies the still-buffered tail of [hist|in] into hist_next; grid = (blocks, streams).
 hipError_t launch_fir_tail_copy(const FirStreamDesc* d_descs, uint32_t n_streams,
                                 uint32_t max_tail_values, hipStream_t stream);

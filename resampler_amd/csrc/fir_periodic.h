@@ -118,9 +118,10 @@ void periodic_fill_wrap_bits(const std::vector<uint32_t>& wraps, uint64_t abs_ou
 // One launch per geometry: d_descs[0..n_streams) all use `geo`; grid = (max_blocks, n_streams).
 // `d_work_counter` is a zero-initialised 64-bit device word owned by the caller; the kernel leaves it
 // at zero again (launches sharing it must be ordered, which launch_jobs enforces per handle).
+// `nf`: where non-finite sums are marked (fir_nonfinite.h); the caller follows up with launch_fir_repair.
 hipError_t launch_fir_periodic(const FirStreamDesc* d_descs, uint32_t n_streams,
                                const PeriodicGeometry& geo, uint32_t max_blocks,
-                               unsigned long long* d_work_counter, hipStream_t stream,
+                               unsigned long long* d_work_counter, const NfArgs& nf, hipStream_t stream,
                                bool fuse_tail = false);
 // Recomputes the outputs listed in each stream's `wraps` with row 1023 / previous frame
 // (only for geometries without inline wraps).
@@ -137,7 +138,7 @@ void split_store_class(std::vector<float>& coef, const PeriodicGeometry& g, uint
                        uint32_t shift, const std::vector<float>& mixed);
 // fuse_tail: the kernel also copies every stream's still-buffered tail into hist_next (no tail-copy launch)
 hipError_t launch_fir_split(const FirStreamDesc* d_descs, uint32_t n_streams, const PeriodicGeometry& geo,
-                            uint32_t max_blocks, uint32_t cus, bool fuse_tail, hipStream_t stream);
+                            uint32_t max_blocks, uint32_t cus, bool fuse_tail, const NfArgs& nf, hipStream_t stream);
 
 // Host build of the class table (exposed for tests).
 struct HostClassTable {

@@ -50,6 +50,7 @@ struct GeoArgs {
     uint32_t blocks_per_stream, total_items;
     unsigned long long* work_counter;   // launch-wide item queue: zero between launches
     uint32_t n_claimers;                // waves that claim from it; each ends on exactly one failing claim
+    NfArgs nf;                          // non-finite sums are marked here (fir_nonfinite.h)
 };
 
 constexpr uint32_t kWtraceSlots = 160, kWtraceWaves = 16;
@@ -239,6 +240,7 @@ struct ItemCtx {
     const float* lane_row;            // LDS: first sample of the lane's period row (+ channel group)
     const float* xprev;               // LDS: frame in front of each period
     uint32_t wrap_tag;                // matrix-core path: image index | (item sequence + 1) << 2
+    uint32_t stream;                  // the stream's index in the launch (non-finite marks)
     uint32_t pl_c, gi, lane;
     bool lane_on;
 };
@@ -267,8 +269,9 @@ __device__ __forceinline__ ItemGeom item_geom(const GeoArgs& geo, const FirStrea
 template <int CG, bool C2>
 __device__ __forceinline__ ItemCtx item_ctx(const GeoArgs& geo, const FirStreamDesc& d,
                                             const ItemGeom& ig, const float* rows, const float* xprev,
-                                            uint32_t lane) {
+                                            uint32_t lane, uint32_t stream_idx) {
     ItemCtx cx;
+    cx.stream = stream_idx;
     const uint32_t pl = C2 ? lane : lane / geo.lp;     // period of this lane inside the block
     cx.gi = C2 ? 0u : lane - pl * geo.lp;              // channel group of this lane
     cx.lane_on = pl < geo.pw;
@@ -444,6 +447,15 @@ __device__ __forceinline__ void process_tile(const GeoArgs& geo, const ItemCtx& 
             }
     }
 
+    // ---- non-finite sums: the chunk is redone in the reference's form by the repair launch ---------
+    {
+        float chk = 0.f;
+#pragma unroll
+        for (int i = 0; i < (int)kClassTile; ++i)
+#pragma unroll
+            for (int k = 0; k < CG; ++k) chk += av[i][k];
+        nf_mark(geo.nf, cx.lane_on && nf_is_bad(chk), cx.stream, n_lane0, static_cast<int32_t>(kClassTile), n_limit);
+    }
     // ---- store -------------------------------------------------------------------------------
     g_f32_ptr out = cx.out;
     const uint32_t lane = cx.lane;
@@ -597,7 +609,7 @@ __global__ __launch_bounds__(768, 6) void fir_periodic_kernel(const FirStreamDes
         wt.event(5);          // everyone's pieces landed
         if (geo.trace) t_trace[1] = __builtin_amdgcn_s_memrealtime();
 
-        const ItemCtx cx = item_ctx<CG, C2>(geo, d, ig, rows, xprev, lane);
+        const ItemCtx cx = item_ctx<CG, C2>(geo, d, ig, rows, xprev, lane, stream_idx);
         // Class tiles are claimed dynamically: a workgroup's waves are spread unevenly over the
         // four SIMDs (and share them with the other resident workgroup), so a static split leaves
         // the least loaded SIMD idle while the most loaded one finishes.  The claim of the next
@@ -664,6 +676,12 @@ __device__ __forceinline__ void mfma_store_unit(const GeoArgs& geo, const ItemCt
         for (int g = 0; g < G; ++g) s += acc[g][0].x + acc[g][1].y + acc[g][0].z + acc[g][1].w;
         if (s == 12345.678f) out[0] = s;
         return;
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const v4f s0 = acc[g][0], s1 = acc[g][1];
+        nf_mark(geo.nf, p_on[g] && nf_is_bad(((s0.x + s0.y) + (s0.z + s0.w)) + ((s1.x + s1.y) + (s1.z + s1.w))), cx.stream,
+                cx.n_block0 + static_cast<int32_t>(p_idx[g] * geo.b + j0), 4, cx.n_limit);
     }
 #pragma unroll
     for (int g = 0; g < G; ++g) {
@@ -864,6 +882,7 @@ struct MfmaUnit {
     bool fast;               // wave-uniform: every lane stores all four frames of every group
     gptr_f32 table;          // the item's class table (streams of one launch may differ in drift)
     int32_t n_limit;         // outputs of the item's stream in this launch
+    uint32_t stream;         // the stream's index in the launch (non-finite marks)
 };
 
 // The addressing of a unit, in three pieces so that it can be spread over several MFMA gaps.
@@ -895,6 +914,7 @@ __device__ __forceinline__ void mfma_unit_setup_common(MfmaUnit<G>& u, const Geo
     }
     u.table = (gptr_f32)(cx.table);
     u.n_limit = cx.n_limit;
+    u.stream = cx.stream;
     u.j0 = T * kMfmaClassTile + 4 * k;
 }
 
@@ -944,6 +964,11 @@ struct MfmaPending {
 template <int G>
 __device__ __forceinline__ void mfma_store_pending_group(const GeoArgs& geo, const MfmaPending<G>& pend, int g) {
     const MfmaUnit<G>& u = pend.unit;
+    if (pend.valid) {
+        const v4f s0 = pend.acc[g][0], s1 = pend.acc[g][1];
+        nf_mark(geo.nf, u.mode[g] != 0 && nf_is_bad(((s0.x + s0.y) + (s0.z + s0.w)) + ((s1.x + s1.y) + (s1.z + s1.w))),
+                u.stream, u.n0[g], 4, u.n_limit);
+    }
     if (__builtin_expect(pend.valid && u.fast && !u.wrap && !(geo.debug & 16), 1)) {
         const v4f a0 = pend.acc[g][0], a1 = pend.acc[g][1];
         typedef v4f __attribute__((address_space(1), aligned(8)))* g_f4a8_ptr;
@@ -1131,15 +1156,16 @@ constexpr uint32_t kPostWords = 8;   // out (2), class table (2), n_block0, n_li
 struct ItemPost {
     unsigned long long out, table;
     int32_t n_block0, n_limit;
-    uint32_t spare[2];
+    uint32_t stream;      // the stream's index in the launch
+    uint32_t spare;
 };
 static_assert(sizeof(ItemPost) == kPostWords * 4, "ItemPost layout");
 
 __device__ __forceinline__ ItemCtx ctx_from_post(const uint32_t* post, uint32_t wrap_tag, uint32_t lane) {
     ItemCtx cx;
-    uint32_t w[6];
+    uint32_t w[7];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) w[i] = __builtin_amdgcn_readfirstlane(post[i]);
+    for (int i = 0; i < 7; ++i) w[i] = __builtin_amdgcn_readfirstlane(post[i]);
     cx.out = (g_f32_ptr)(static_cast<unsigned long long>(w[0]) | (static_cast<unsigned long long>(w[1]) << 32));
     cx.table = (const_f32_ptr)(static_cast<unsigned long long>(w[2]) | (static_cast<unsigned long long>(w[3]) << 32));
     cx.wtable = cx.table;
@@ -1151,6 +1177,7 @@ __device__ __forceinline__ ItemCtx ctx_from_post(const uint32_t* post, uint32_t 
     cx.lane_row = nullptr;
     cx.xprev = nullptr;
     cx.wrap_tag = wrap_tag;
+    cx.stream = w[6];
     cx.pl_c = 0;
     cx.gi = 0;
     cx.lane = lane;
@@ -1346,6 +1373,7 @@ __global__ __launch_bounds__(MF ? 768 : 1024) void fir_periodic_db_kernel(const 
                     post->table = reinterpret_cast<unsigned long long>(d.class_coef);
                     post->n_block0 = ig.n_block0;
                     post->n_limit = static_cast<int32_t>(d.n_out);
+                    post->stream = item / geo.blocks_per_stream;
                 }
             }
             if (item != kNoItem && !(geo.debug & 1))
@@ -1452,7 +1480,7 @@ __global__ __launch_bounds__(MF ? 768 : 1024) void fir_periodic_db_kernel(const 
         const uint32_t stream_idx = item / geo.blocks_per_stream;
         const FirStreamDesc d = load_uniform(descs + stream_idx);
         const ItemGeom ig = item_geom(geo, d, item - stream_idx * geo.blocks_per_stream);
-        const ItemCtx cx = item_ctx<CG, C2>(geo, d, ig, rows, xprev, lane);
+        const ItemCtx cx = item_ctx<CG, C2>(geo, d, ig, rows, xprev, lane, stream_idx);
         if constexpr (MF == 0) {
             uint32_t t_claim = 0;
             if (lane == 0) t_claim = atomicAdd(tile_counter + b, 1u);
@@ -1575,7 +1603,7 @@ GeoArgs to_args(const PeriodicGeometry& g) {
     return GeoArgs{g.a, g.b, g.b / g.den, g.row_len, g.mfma ? g.n_units : g.n_tiles, g.lp, g.pw, g.row_stride, g.waves,
                    channels, xprev_len_of(g.pw, channels), g.producers, g.den, g.images ? g.images : 2u,
                    g.mfma ? (g.n_units == 4 * g.n_tiles ? 2u : (g.n_units == 2 * g.n_tiles ? 1u : 0u)) : 0u,
-                   g.inline_wraps ? 1u : 0u, debug, stagger, nullptr, nullptr, 0u, 0u, nullptr, 0u};
+                   g.inline_wraps ? 1u : 0u, debug, stagger, nullptr, nullptr, 0u, 0u, nullptr, 0u, NfArgs{nullptr, 0u, 0u}};
 }
 
 // Device class tables, shared by every stream on a device with the same polyphase table, rate
@@ -1939,7 +1967,8 @@ int periodic_bind(PeriodicState& st, int device, const std::vector<float>& table
 
 hipError_t launch_fir_periodic(const FirStreamDesc* d_descs, uint32_t n_streams,
                                const PeriodicGeometry& geo, uint32_t max_blocks,
-                               unsigned long long* d_work_counter, hipStream_t stream, bool fuse_tail) {
+                               unsigned long long* d_work_counter, const NfArgs& nf, hipStream_t stream,
+                               bool fuse_tail) {
     if (n_streams == 0 || max_blocks == 0) return hipSuccess;
     const dim3 block(geo.waves * 64);
     GeoArgs args = to_args(geo);
@@ -1962,7 +1991,8 @@ hipError_t launch_fir_periodic(const FirStreamDesc* d_descs, uint32_t n_streams,
         }
         cus = c;
     }
-    if (geo.mfma == 3) return launch_fir_split(d_descs, n_streams, geo, max_blocks, cus, fuse_tail, stream);
+    if (geo.mfma == 3) return launch_fir_split(d_descs, n_streams, geo, max_blocks, cus, fuse_tail, nf, stream);
+    args.nf = nf;
     const uint32_t slots = cus * (geo.lds_bytes > kLdsTwoPerCu ? 1u : 2u);   // workgroups that fit
     const dim3 grid(args.total_items < slots ? args.total_items : slots);
     args.work_counter = d_work_counter;

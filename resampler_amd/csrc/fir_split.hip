@@ -72,6 +72,7 @@ struct SplitArgs {
     uint32_t a, b, taps, n_tiles, rows, slots, lds_bytes, blocks_per_stream, total_items, debug;
     uint32_t n_streams, fuse_tail;   // fuse_tail: also copy every stream's still-buffered tail into hist_next
     unsigned long long* wtrace;   // RSMP_FIR_WTRACE: kWtraceSlots timestamped events per wave
+    NfArgs nf;                    // non-finite sums are marked here (fir_nonfinite.h)
 };
 
 constexpr uint32_t kWtraceSlots = 16;
@@ -154,6 +155,7 @@ struct StreamCtx {
     uint32_t n_out, hist_frames, in_frames;
     uint64_t abs_out, abs_consumed, wrap_k0;
     uint64_t q_first;     // abs_out / b: the period holding the launch's first output
+    uint32_t sidx;        // the stream's index in the launch
 };
 
 // Through the scalar cache (constant address space): the descriptors do not change during the launch,
@@ -179,6 +181,7 @@ __device__ __forceinline__ StreamCtx load_stream(const FirStreamDesc* descs, uin
     c.abs_consumed = d.abs_consumed;
     c.wrap_k0 = d.wrap_k0;
     c.q_first = d.abs_out / b;   // (64-bit division: once per stream, not per item)
+    c.sidx = s;
     return c;
 }
 
@@ -749,6 +752,10 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
         // lane = (period, 4 consecutive classes), both channels: 32 contiguous bytes
         const int32_t n0 = it.n_block0 + static_cast<int32_t>(pl * g.b + j0);
         const int32_t n_limit = static_cast<int32_t>(d.n_out);
+        // a non-finite sum (inf / NaN sample, or one too large for the 16-bit planes): the chunk is redone
+        // in the reference's form by the repair launch
+        nf_mark(g.nf, nf_is_bad(((acc0.x + acc0.y) + (acc0.z + acc0.w)) + ((acc1.x + acc1.y) + (acc1.z + acc1.w))),
+                d.sidx, n0, 4, n_limit);
         g_f32_ptr o = (g_f32_ptr)d.out + static_cast<int64_t>(n0) * 2;
         const v4f lo = v4f{acc0.x, acc1.x, acc0.y, acc1.y};
         const v4f hi = v4f{acc0.z, acc1.z, acc0.w, acc1.w};
@@ -909,12 +916,12 @@ size_t split_table_floats(const PeriodicGeometry& g) {
 }
 
 hipError_t launch_fir_split(const FirStreamDesc* d_descs, uint32_t n_streams, const PeriodicGeometry& geo,
-                            uint32_t max_blocks, uint32_t cus, bool fuse_tail, hipStream_t stream) {
+                            uint32_t max_blocks, uint32_t cus, bool fuse_tail, const NfArgs& nf, hipStream_t stream) {
     static const uint32_t debug = [] {
         const char* e = getenv("RSMP_FIR_DEBUG");
         return e ? static_cast<uint32_t>(atoi(e)) : 0u;
     }();
-    SplitArgs args{geo.a, geo.b, geo.taps, geo.n_tiles, geo.row_stride, geo.images, geo.lds_bytes, max_blocks, max_blocks * n_streams, debug, n_streams, fuse_tail ? 1u : 0u, nullptr};
+    SplitArgs args{geo.a, geo.b, geo.taps, geo.n_tiles, geo.row_stride, geo.images, geo.lds_bytes, max_blocks, max_blocks * n_streams, debug, n_streams, fuse_tail ? 1u : 0u, nullptr, nf};
     const void* fns3[5] = {reinterpret_cast<const void*>(fir_split_kernel<1, 3>),
                            reinterpret_cast<const void*>(fir_split_kernel<2, 3>),
                            reinterpret_cast<const void*>(fir_split_kernel<3, 3>),

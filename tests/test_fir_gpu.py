@@ -398,17 +398,13 @@ def test_stopband_attenuation_on_gpu(in_hz, out_hz):
 
 @pytest.mark.parametrize("kernel", [ra.FirKernel.Generic, ra.FirKernel.Periodic, ra.FirKernel.PeriodicF32,
                                     ra.FirKernel.PeriodicVector])
-def test_non_finite_input_contract(kernel):
-    """Inf / NaN samples (stream start, mid tile, tile edge, one channel and both).  Contract of the bulk
-    kernels, as documented in include/resampler_amd.h (rsmp_fir_set_kernel):
-      * GENERIC evaluates every output in the reference's form: the same outputs are finite, the same are
-        +inf / -inf / NaN (src/fir/avx.rs:25-58);
-      * the PERIODIC kernels multiply a few samples next to an output's true window by zero padding
-        coefficients (0 * inf = NaN) and, in the split kernel, split an infinity into (inf, NaN, NaN): every
-        output the reference makes non-finite is non-finite here too, and additionally at most the outputs
-        within one class tile (16 output frames + the tile's window shift) of such an output; everything else
-        is finite and within the 1e-6 RMS gate."""
-    g, r = make_pair(2, 44100, 48000, kernel=kernel)
+def test_non_finite_and_huge_input_match_the_reference(kernel):
+    """Inf / NaN samples (stream start, mid tile, tile edge, one channel and both) and samples far outside the
+    audio range.  The periodic kernels pre-mix phase rows, pad windows with zero coefficients and (split
+    kernel) cut operands into 16-bit planes; every store path therefore checks its sums and a repair launch
+    re-evaluates the marked 1024-frame chunks in the reference's own form (fir_nonfinite.h).  Result: the same
+    outputs are finite, +inf, -inf or NaN as in the reference (src/fir/avx.rs:25-58), on every kernel."""
+    g, _ = make_pair(2, 44100, 48000, kernel=kernel)
     r = o.OracleFir(2, 44100, 48000, 128, 90, o.CONVOLVE_AVX_FMA if o.have_avx_fma() else o.CONVOLVE_SCALAR)
     n = 60000
     x = synth.fast_noise(2 * n, seed=77)
@@ -419,23 +415,29 @@ def test_non_finite_input_contract(kernel):
     x[2 * 30007] = np.inf
     x[2 * 30011] = -np.inf             # +inf and -inf inside one window
     x[2 * 47040 - 2] = np.inf          # last frame of a 16-period item (16 * 147 * 20 = 47040)
+    x[2 * 20000] = 1000.0              # finite, but beyond the range of the two-plane fp16 split
+    x[2 * 20001 + 1] = -3.0e30
+    x[2 * 25000] = 15.99               # just inside it
+    x[2 * 55000 + 1] = 1.0e-30         # and far below it
     yg, consumed = g.resample_bulk(x, 512)
     yr, _ = r.resample_all(x, 512)
     assert consumed == x.size and yg.size == yr.size
     fin_r, fin_g = np.isfinite(yr), np.isfinite(yg)
-    assert not fin_g[~fin_r].any()                      # never finite where the reference is not
+    assert np.array_equal(fin_g, fin_r), np.flatnonzero(fin_g != fin_r)[:10]
+    # inf versus NaN: identical, except -- on the periodic kernels -- at outputs whose exact position is a
+    # multiple of 1/1024 frame (every 5th output here): there the reference's frac is its f64 rounding
+    # residue (~1e-12) times 1024, i.e. 0 or not by the sign of that residue, and inf * frac is NaN or inf
+    # accordingly; the repair pass knows the position to the class table's 2e-9 drift quantum only.
+    kind = np.isnan(yg) != np.isnan(yr)
     if kernel == ra.FirKernel.Generic:
-        assert np.array_equal(fin_g, fin_r)
-        assert np.array_equal(np.isnan(yg), np.isnan(yr))
-        inf = np.isinf(yr)
-        assert np.array_equal(yg[inf], yr[inf])
+        assert not kind.any()
     else:
-        # extra non-finite outputs only next to reference-non-finite ones: within 16 + 16 output frames
-        bad_frames_r = np.unique(np.flatnonzero(~fin_r) // 2)
-        extra = np.unique(np.flatnonzero(~fin_g & fin_r) // 2)
-        if extra.size:
-            dist = np.min(np.abs(extra[:, None] - bad_frames_r[None, :]), axis=1)
-            assert dist.max() <= 32, dist.max()
-    both = fin_r & fin_g
-    assert both.sum() > 0.95 * yr.size
-    assert rms(yg[both], yr[both]) <= RMS_TOL
+        m = np.flatnonzero(kind) // 2
+        assert np.all((m * 147 * 1024) % 160 == 0), m[:10]
+    inf = np.isinf(yr) & np.isinf(yg)
+    assert inf.any() and np.array_equal(yg[inf], yr[inf])          # same signed infinities
+    # finite outputs: relative to the local magnitude (the 1e30 sample makes finite outputs of ~1e29)
+    big = fin_r & (np.abs(yr) > 1e3)
+    assert big.any() and np.all(np.abs(yg[big] - yr[big]) <= 1e-5 * np.abs(yr[big]))
+    small = fin_r & ~big
+    assert rms(yg[small], yr[small]) <= RMS_TOL
