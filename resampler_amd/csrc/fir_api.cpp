@@ -482,6 +482,30 @@ int launch_jobs(rsmp_fir* leader, std::vector<Job>& jobs, hipStream_t stream) {
                                                 max_out_generic, max_ch_generic, stream));
     size_t first = n_generic;
     bool tail_fused = false;
+    // Where the periodic launches mark non-finite sums: one bit per stream and 1024-frame chunk
+    // (fir_nonfinite.h), one region of the buffer per launch; the repair launches follow the timed ones.
+    struct Repair { size_t first; uint32_t count; rsmp::NfArgs nf; };
+    std::vector<Repair> repairs;
+    size_t nf_words_total = 0;
+    for (const Group& g : groups) {
+        uint32_t max_out = 0;
+        for (size_t i : g.members)
+            if (jobs[i].plan->produced_frames > max_out) max_out = static_cast<uint32_t>(jobs[i].plan->produced_frames);
+        Repair rp;
+        rp.first = 0;
+        rp.count = static_cast<uint32_t>(g.members.size());
+        rp.nf.chunks = (max_out >> rsmp::kNfChunkShift) + 1;
+        rp.nf.words = reinterpret_cast<uint32_t*>(nf_words_total * sizeof(uint32_t));   // offset for now
+        rp.nf.tag = 0;
+        nf_words_total += 1 + (static_cast<size_t>(rp.count) * rp.nf.chunks + 31) / 32;
+        repairs.push_back(rp);
+    }
+    if (nf_words_total * sizeof(uint32_t) > leader->d_nf.capacity()) {
+        RSMP_HIP_CHECK(hipStreamSynchronize(stream));
+        RSMP_HIP_CHECK(leader->d_nf.reserve(nf_words_total * sizeof(uint32_t)));
+        RSMP_HIP_CHECK(hipMemsetAsync(leader->d_nf.get(), 0, leader->d_nf.capacity(), stream));
+    }
+    size_t gi = 0;
     for (const Group& g : groups) {
         uint32_t max_blocks = 0;
         for (size_t i : g.members) {
@@ -492,40 +516,28 @@ int launch_jobs(rsmp_fir* leader, std::vector<Job>& jobs, hipStream_t stream) {
         if (!leader->d_work_counter) {
             RSMP_HIP_CHECK(hipMalloc(&leader->d_work_counter, sizeof(unsigned long long)));
             // on the launch stream: a null-stream memset is not ordered with a non-blocking stream and
-            // could land after the first kernel had started claiming (host and device counts then
-            // disagree for good and later launches find no work)
+            // could land after the first kernel had started claiming
             RSMP_HIP_CHECK(hipMemsetAsync(leader->d_work_counter, 0, sizeof(unsigned long long), stream));
         }
         // a launch made of split-kernel streams only lets that kernel copy the tails as well
         tail_fused = n_generic == 0 && groups.size() == 1 && g.geo.mfma == 3 && max_blocks != 0 &&
                      getenv("RSMP_FIR_NO_FUSED_TAIL") == nullptr;
-        // where the launch marks non-finite sums: one bit per stream and 1024-frame chunk (fir_nonfinite.h)
-        uint32_t max_out = 0;
-        for (size_t i : g.members)
-            if (jobs[i].plan->produced_frames > max_out) max_out = static_cast<uint32_t>(jobs[i].plan->produced_frames);
-        rsmp::NfArgs nf;
-        nf.chunks = (max_out >> rsmp::kNfChunkShift) + 1;
-        const size_t nf_words = 1 + (g.members.size() * nf.chunks + 31) / 32;
-        if (nf_words * sizeof(uint32_t) > leader->d_nf.capacity()) {
-            RSMP_HIP_CHECK(hipStreamSynchronize(stream));
-            RSMP_HIP_CHECK(leader->d_nf.reserve(nf_words * sizeof(uint32_t)));
-            RSMP_HIP_CHECK(hipMemsetAsync(leader->d_nf.get(), 0, leader->d_nf.capacity(), stream));
-        }
-        nf.words = leader->d_nf.as<uint32_t>();
+        Repair& rp = repairs[gi++];
+        rp.first = first;
+        rp.nf.words = leader->d_nf.as<uint32_t>() + reinterpret_cast<size_t>(rp.nf.words) / sizeof(uint32_t);
         if (++leader->nf_tag == 0) leader->nf_tag = 1;
-        nf.tag = leader->nf_tag;
+        rp.nf.tag = leader->nf_tag;
         RSMP_HIP_CHECK(rsmp::launch_fir_periodic(d_descs + first,
                                                  static_cast<uint32_t>(g.members.size()), g.geo,
-                                                 max_blocks, leader->d_work_counter, nf, stream, tail_fused));
-        static const bool no_repair = getenv("RSMP_FIR_NO_REPAIR") != nullptr;   // A/B timing only
-        if (!no_repair)
-            RSMP_HIP_CHECK(rsmp::launch_fir_repair(d_descs + first, static_cast<uint32_t>(g.members.size()), nf, stream));
+                                                 max_blocks, leader->d_work_counter, rp.nf, stream, tail_fused));
         first += g.members.size();
     }
     if (leader->profiling) {
         RSMP_HIP_CHECK(hipEventRecord(leader->prof_stop[leader->prof_count % rsmp_fir::kProfRing], stream));
         ++leader->prof_count;
     }
+    for (const Repair& rp : repairs)
+        RSMP_HIP_CHECK(rsmp::launch_fir_repair(d_descs + rp.first, rp.count, rp.nf, stream));
     if (n > n_generic && max_wraps > 0)
         RSMP_HIP_CHECK(rsmp::launch_fir_wrap_fixup(d_descs + n_generic,
                                                    static_cast<uint32_t>(n - n_generic), max_wraps,
