@@ -24,7 +24,11 @@
 #include <cmath>
 #include <cstdlib>
 
-#ifdef RSMP_FFT_WAVE_FMA
+// a*b + c may fuse in this file: one rounding fewer per fused pair.  The results then differ from the
+// reference's scalar arithmetic (which never fuses) in the last bits -- far inside the 1e-6 RMS gate (measured
+// against the oracle: tests/test_fft_gpu.py) -- and the kernel needs 10 % fewer vector instructions.
+// -DRSMP_FFT_WAVE_EXACT keeps the reference's operation-for-operation arithmetic (bit-identical to it).
+#ifndef RSMP_FFT_WAVE_EXACT
 #pragma clang fp contract(fast)
 #endif
 
@@ -35,7 +39,6 @@ namespace rsmp {
 
 namespace {
 
-constexpr int kWavesPerGroup = 4;
 
 // Lanes of a wave exchange data through the wave's LDS buffer without any barrier: the hardware executes a
 // wave's LDS operations in issue order.  The COMPILER, however, reasons per thread and may move a thread's
@@ -49,6 +52,9 @@ struct WavePlan<N_, R0, R1, R2, R3> {
     static constexpr int N = N_;
     static constexpr int kR[4] = {R0, R1, R2, R3};
     static_assert(R0 * R1 * R2 * R3 == N_, "radices");
+    // stage twiddles, unique per column: stage s (s >= 1) holds stride_s * (R_s - 1) of them
+    static constexpr int kTw = R0 * (R1 - 1) + R0 * R1 * (R2 - 1) + R0 * R1 * R2 * (R3 - 1);
+    static constexpr int kRc = N_ / 2 - 1;   // real <-> complex twiddles
     static bool matches(uint32_t n, uint32_t n_stages, const uint32_t* radix) {
         return n == static_cast<uint32_t>(N_) && n_stages == 4 && radix[0] == R0 && radix[1] == R1 &&
                radix[2] == R2 && radix[3] == R3;
@@ -160,13 +166,15 @@ __device__ __forceinline__ void wave_filter_preprocess(float2* y, const float2* 
     lds_order();
 }
 
-// OCC: waves per SIMD the register allocation aims at (2: ~205 registers, no scratch; 3: 168 registers).
+// OCC waves per SIMD: 2 = two workgroups of 4 waves per CU (80 KB of LDS each: the tables + 4 buffers),
+// 3 = one workgroup of 12 waves per CU (one copy of the tables + 12 buffers = 158 KB; <= 168 registers).
 template <class FWD, class INV, bool C2, int OCC>
-__global__ __launch_bounds__(kWavesPerGroup * 64, OCC) void fft_ola_wave_kernel(FftPlanDev plan,
+__global__ __launch_bounds__((OCC == 3 ? 12 : 4) * 64, OCC) void fft_ola_wave_kernel(FftPlanDev plan,
                                                                               const FftStreamDesc* __restrict__ descs,
                                                                               uint32_t run, uint32_t runs_per_stream,
                                                                               uint32_t total_waves) {
     extern __shared__ __attribute__((aligned(16))) float2 lds2[];
+    constexpr int kWavesPerGroup = OCC == 3 ? 12 : 4;
     constexpr int FI = FWD::N, FO = INV::N;
     constexpr int LDSC = (FI > FO ? FI : FO) + 2;
     constexpr int R1 = FWD::kR[0], M1 = FI / R1, ITER1 = (M1 + 63) / 64, QV = (R1 + 1) / 2;
@@ -176,8 +184,31 @@ __global__ __launch_bounds__(kWavesPerGroup * 64, OCC) void fft_ola_wave_kernel(
     const int lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t gw = blockIdx.x * kWavesPerGroup + wave;
-    if (gw >= total_waves) return;      // (no barrier anywhere: waves are independent)
-    float2* buf = lds2 + wave * LDSC;
+    // Every table of the plan (stage twiddles, real <-> complex twiddles, filter spectrum: 39 KB) is copied
+    // to LDS once per workgroup: the per-butterfly twiddle fetches were the kernel's main wait (48 % of the
+    // wave time at s_waitcnt, vector-memory instructions in flight 4x the LDS ones).  The only barrier of
+    // the kernel follows; after it the waves never meet again.
+    constexpr int kTabF = 0, kTabI = kTabF + FWD::kTw, kTabRcF = kTabI + INV::kTw, kTabRcI = kTabRcF + FWD::kRc,
+                  kTabFilter = kTabRcI + INV::kRc, kTabEnd = kTabFilter + FI + 1;
+    float2* tab = lds2;
+    {
+        auto copy = [&](float2* dst, const float2* __restrict__ src, int n) {
+            for (int i = threadIdx.x; i < n; i += kWavesPerGroup * 64) dst[i] = src[i];
+        };
+        copy(tab + kTabF, plan.tw_f, FWD::kTw);
+        copy(tab + kTabI, plan.tw_i, INV::kTw);
+        copy(tab + kTabRcF, plan.rc_f, FWD::kRc);
+        copy(tab + kTabRcI, plan.rc_i, INV::kRc);
+        copy(tab + kTabFilter, plan.filter, FI + 1);
+    }
+    __syncthreads();
+    if (gw >= total_waves) return;
+    float2* buf = lds2 + kTabEnd + wave * LDSC;
+    const float2* tw_f = tab + kTabF;
+    const float2* tw_i = tab + kTabI;
+    const float2* rc_f = tab + kTabRcF;
+    const float2* rc_i = tab + kTabRcI;
+    const float2* filter = tab + kTabFilter;
 
     // wave -> (stream, run of blocks, channel); the channels of a run are neighbouring waves
     const uint32_t stream_idx = gw / (runs_per_stream * (C2 ? 2u : descs[0].channels));
@@ -250,11 +281,11 @@ __global__ __launch_bounds__(kWavesPerGroup * 64, OCC) void fft_ola_wave_kernel(
 
         constexpr int S1 = R1, S2 = S1 * FWD::kR[1], S3 = S2 * FWD::kR[2];
         constexpr int T1 = 0, T2 = T1 + S1 * (FWD::kR[1] - 1), T3 = T2 + S2 * (FWD::kR[2] - 1);
-        wave_stage<FI, FWD::kR[1], S1>(buf, plan.tw_f + T1, lane);
-        wave_stage<FI, FWD::kR[2], S2>(buf, plan.tw_f + T2, lane);
-        wave_stage<FI, FWD::kR[3], S3>(buf, plan.tw_f + T3, lane);
-        wave_postprocess<FI>(buf, plan.rc_f, lane);
-        wave_filter_preprocess<FO>(buf, plan.filter, plan.new_length, plan.rc_i, lane);
+        wave_stage<FI, FWD::kR[1], S1>(buf, tw_f + T1, lane);
+        wave_stage<FI, FWD::kR[2], S2>(buf, tw_f + T2, lane);
+        wave_stage<FI, FWD::kR[3], S3>(buf, tw_f + T3, lane);
+        wave_postprocess<FI>(buf, rc_f, lane);
+        wave_filter_preprocess<FO>(buf, filter, plan.new_length, rc_i, lane);
 
         constexpr int IS1 = INV::kR[0], IS2 = IS1 * INV::kR[1];
         constexpr int IT1 = 0, IT2 = IT1 + IS1 * (INV::kR[1] - 1), IT3 = IT2 + IS2 * (INV::kR[2] - 1);
@@ -282,8 +313,8 @@ __global__ __launch_bounds__(kWavesPerGroup * 64, OCC) void fft_ola_wave_kernel(
             }
             lds_order();
         }
-        wave_stage<FO, INV::kR[1], IS1>(buf, plan.tw_i + IT1, lane);
-        wave_stage<FO, INV::kR[2], IS2>(buf, plan.tw_i + IT2, lane);
+        wave_stage<FO, INV::kR[1], IS1>(buf, tw_i + IT1, lane);
+        wave_stage<FO, INV::kR[2], IS2>(buf, tw_i + IT2, lane);
         // ---- last inverse stage: outputs stay in registers.  Butterfly i (k = i) yields Z[i + q*ML]; the
         // output conjugation (radix_fft.rs:656-669) makes reals 2c, 2c + 1 of the channel out of Z[c]; the
         // first FO reals are overlap-added and stored, the second FO become the next overlap (:416-423).
@@ -295,7 +326,7 @@ __global__ __launch_bounds__(kWavesPerGroup * 64, OCC) void fft_ola_wave_kernel(
                 float2 t[RL], o[RL];
 #pragma unroll
                 for (int q = 0; q < RL; ++q) t[q] = buf[i + q * ML];
-                const float2* w = plan.tw_i + IT3 + i * (RL - 1);
+                const float2* w = tw_i + IT3 + i * (RL - 1);
 #pragma unroll
                 for (int q = 1; q < RL; ++q) t[q] = cmul(w[q - 1], t[q]);
                 dft<RL>(t, o);
@@ -348,7 +379,7 @@ hipError_t launch_fft_ola_wave(const FftPlanDev& plan, const FftStreamDesc* d_de
     const uint32_t C = max_channels;
     typedef void (*Kernel)(FftPlanDev, const FftStreamDesc*, uint32_t, uint32_t, uint32_t);
     Kernel fn;
-    static const int occ = [] { const char* e = getenv("RSMP_FFT_WAVE_OCC"); return e && atoi(e) == 3 ? 3 : 2; }();
+    static const int occ = [] { const char* e = getenv("RSMP_FFT_WAVE_OCC"); return e && atoi(e) == 2 ? 2 : 3; }();
     if (occ == 3) {
         if (up) fn = C == 2 ? fft_ola_wave_kernel<W1176, W1280, true, 3> : fft_ola_wave_kernel<W1176, W1280, false, 3>;
         else fn = C == 2 ? fft_ola_wave_kernel<W1280, W1176, true, 3> : fft_ola_wave_kernel<W1280, W1176, false, 3>;
@@ -356,14 +387,17 @@ hipError_t launch_fft_ola_wave(const FftPlanDev& plan, const FftStreamDesc* d_de
         if (up) fn = C == 2 ? fft_ola_wave_kernel<W1176, W1280, true, 2> : fft_ola_wave_kernel<W1176, W1280, false, 2>;
         else fn = C == 2 ? fft_ola_wave_kernel<W1280, W1176, true, 2> : fft_ola_wave_kernel<W1280, W1176, false, 2>;
     }
-    const size_t lds = static_cast<size_t>(kWavesPerGroup) * (1280 + 2) * sizeof(float2);
+    // tables (stage twiddles 1173 + 1276, real <-> complex 587 + 639, filter spectrum fft_in + 1) + one buffer per wave
+    const uint32_t kWavesPerGroup = occ == 3 ? 12u : 4u;
+    const size_t lds = (static_cast<size_t>(1173 + 1276 + 587 + 639) + plan.fft_in + 1 +
+                        static_cast<size_t>(kWavesPerGroup) * (1280 + 2)) * sizeof(float2);
     // Blocks per wave: every run after a stream's first recomputes its predecessor block (1 / run extra
     // work), and the launch ends with a partly filled round unless the number of waves is close to a
     // multiple of what the chip holds at once (3 workgroups of 4 waves per CU).
     int dev = 0, cus = 256;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    const double slots = static_cast<double>(cus) * occ * kWavesPerGroup;
+    const double slots = static_cast<double>(cus) * occ * 4;
     uint32_t run = 16;
     double best = -1.0;
     for (uint32_t cand = 6; cand <= 64; ++cand) {
@@ -379,6 +413,11 @@ hipError_t launch_fft_ola_wave(const FftPlanDev& plan, const FftStreamDesc* d_de
     const uint32_t runs_per_stream = (max_blocks + run - 1) / run;
     const uint32_t total_waves = runs_per_stream * n_streams * C;
     const dim3 grid((total_waves + kWavesPerGroup - 1) / kWavesPerGroup);
+    if (lds > 64 * 1024) {   // dynamic LDS above 64 KiB must be opted into
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+    }
     hipLaunchKernelGGL(fn, grid, dim3(kWavesPerGroup * 64), lds, stream, plan, d_descs, run, runs_per_stream,
                        total_waves);
     return hipGetLastError();
