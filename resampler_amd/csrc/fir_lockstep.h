@@ -69,7 +69,27 @@ struct LockstepArgs {
     uint32_t in_frames;                   // frames offered to every stream (when the array is null)
     uint32_t append;                      // 1: a step's output goes to out + out_cursor; 0: to out
     unsigned long long* trace;            // diagnostic instantiation only (RSMP_LS_TRACE), else null
+    // Plans are computed one step AHEAD: while the other waves of a workgroup compute step k, its first
+    // wave runs the state machine for step k + 1 (assuming the same number of frames will be offered) and
+    // leaves the result in the stream's plan record; step k + 1 then starts from the record instead of
+    // ~20 k cycles of serial f64 arithmetic.  A record is used only if its epoch, step and frame count
+    // match; otherwise the step plans in line as before.
+    char* recs;                           // [2][n_streams] records of rec_stride bytes (parity = step & 1)
+    uint32_t rec_stride, n_streams;
+    uint32_t epoch, step;
 };
+
+struct LsPlanHeader {          // head of a plan record; followed by kLsSegCap runs (24 B each), then the wrap list
+    uint32_t epoch, step, in_frames, n_out;
+    uint32_t hist_frames, accepted, consumed, tail_frames;
+    uint32_t n_segs, n_wraps, flags, pad0;
+    uint64_t abs_out, abs_consumed;
+    FirMirrorState after;      // the stream's state after the step
+    uint64_t pad1;
+};
+static_assert(sizeof(LsPlanHeader) == 160, "plan record layout");
+constexpr uint32_t kLsRecSegs = 160, kLsRecWraps = kLsRecSegs + kLsSegCap * 24;
+inline uint32_t lockstep_rec_stride(uint32_t wrap_cap) { return (kLsRecWraps + 4 * wrap_cap + 15) / 16 * 16; }
 
 constexpr uint32_t kLsStatusRunOverflow = 1;   // more than kLsSegCap position runs in one step
 constexpr uint32_t kLsStatusNonFinite = 2;     // a step saw non-finite samples (reference-form path taken)

@@ -63,7 +63,7 @@ struct PlanLds {             // one stream's step, in LDS
     uint32_t flags;
     uint64_t abs_out, abs_consumed;   // absolute counters before the step
     float* out;              // where the step's first output frame goes
-    uint64_t pad;
+    const void* runs;        // the step's exact position runs (SegLds[n_segs]): in LDS, or in the plan record
 };
 static_assert(sizeof(PlanLds) == 64, "PlanLds layout");
 
@@ -116,7 +116,7 @@ struct LdsSink {
         }
     }
     __host__ __device__ void wrap(uint64_t index) {
-        bits[index >> 5] |= 1u << (index & 31);
+        if (bits) bits[index >> 5] |= 1u << (index & 31);
         if (n_wraps < wrap_cap) list[n_wraps] = static_cast<uint32_t>(index);
         ++n_wraps;
     }
@@ -166,6 +166,7 @@ template <bool TRACE>
 __global__ __launch_bounds__(kLsWaves * 64, kLsWaves / 2) void fir_lockstep_kernel(LockstepArgs args) {   // two workgroups per CU
     extern __shared__ __attribute__((aligned(16))) char lds[];
     unsigned long long tr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long ua[5] = {0, 0, 0, 0, 0};   // TRACE: unit setup, tile wait, MFMA stream, epilogue (cycles), units
     if constexpr (TRACE) tr[0] = __builtin_amdgcn_s_memtime();
     const LockstepGroup g = load_uniform(args.groups + blockIdx.x);
     const uint32_t C = g.channels;
@@ -196,42 +197,70 @@ __global__ __launch_bounds__(kLsWaves * 64, kLsWaves / 2) void fir_lockstep_kern
     };
 
     // ---- A: plan (wave 0) | stage (waves 1..) ---------------------------------------------------
+    uint32_t my_in_fr = 0;      // wave 0, lanes < count: frames offered to the lane's stream in this step
     if (wave == 0) {
         if (lane < g.count) {
             const uint32_t gs = g.first + lane;
-            FirMirrorState st = args.states[gs];
             const LockstepStream ls = args.streams[gs];
-            uint32_t in_fr = args.in_frames_per_stream ? args.in_frames_per_stream[args.order[gs]] : args.in_frames;
-            const uint32_t room = g.span_frames > st.available ? g.span_frames - static_cast<uint32_t>(st.available) : 0u;
-            if (in_fr > room) in_fr = room;   // (cannot happen when out_cap >= buffer_size_output: available < taps)
+            const uint32_t in_off = args.in_frames_per_stream ? args.in_frames_per_stream[args.order[gs]] : args.in_frames;
+            my_in_fr = in_off;
             uint32_t* bits = wbits + lane * g.wrap_words;
             for (uint32_t w = 0; w < g.wrap_words; ++w) bits[w] = 0;
-            LdsSink sink{segs + lane * kLsSegCap, bits, wlist + lane * g.wrap_cap, 0u, 0u, g.wrap_cap,
-                         g.periodic != 0 && st.periodic_ok != 0, false};
+            const char* rec = args.recs + (static_cast<size_t>(args.step & 1u) * args.n_streams + gs) * args.rec_stride;
+            const LsPlanHeader hd = *reinterpret_cast<const LsPlanHeader*>(rec);
             PlanLds pl;
-            pl.hist_frames = static_cast<uint32_t>(st.available);
-            pl.abs_out = st.abs_out;
-            pl.abs_consumed = st.abs_consumed;
-            const FirCallCounts c = mirror_call(st, in_fr, ls.out_cap_frames, sink);
-            pl.n_out = static_cast<uint32_t>(c.produced);
-            pl.accepted = static_cast<uint32_t>(c.accepted);
-            pl.consumed = static_cast<uint32_t>(c.consumed);
-            pl.tail_frames = static_cast<uint32_t>(st.available);
-            pl.n_segs = sink.n_segs;
-            pl.n_wraps = sink.n_wraps < g.wrap_cap ? sink.n_wraps : g.wrap_cap;
-            pl.flags = (sink.periodic && st.periodic_ok != 0 ? 0u : kFlagReference) |
-                       (sink.overflow ? kFlagRunOverflow : 0u);
+            FirMirrorState st;
+            if (hd.epoch == args.epoch && hd.step == args.step && hd.in_frames == in_off) {
+                // planned a step ahead: take the record
+                pl.n_out = hd.n_out;
+                pl.hist_frames = hd.hist_frames;
+                pl.accepted = hd.accepted;
+                pl.consumed = hd.consumed;
+                pl.tail_frames = hd.tail_frames;
+                pl.n_segs = hd.n_segs;
+                pl.n_wraps = hd.n_wraps;
+                pl.flags = hd.flags;
+                pl.abs_out = hd.abs_out;
+                pl.abs_consumed = hd.abs_consumed;
+                pl.runs = rec + kLsRecSegs;
+                st = hd.after;
+                const uint32_t* wl = reinterpret_cast<const uint32_t*>(rec + kLsRecWraps);
+                for (uint32_t i = 0; i < hd.n_wraps; ++i) {
+                    const uint32_t n = wl[i];
+                    wlist[lane * g.wrap_cap + i] = n;
+                    bits[n >> 5] |= 1u << (n & 31);
+                }
+            } else {
+                st = args.states[gs];
+                uint32_t in_fr = in_off;
+                const uint32_t room = g.span_frames > st.available ? g.span_frames - static_cast<uint32_t>(st.available) : 0u;
+                if (in_fr > room) in_fr = room;   // (cannot happen when out_cap >= buffer_size_output: available < taps)
+                LdsSink sink{segs + lane * kLsSegCap, bits, wlist + lane * g.wrap_cap, 0u, 0u, g.wrap_cap,
+                             g.periodic != 0 && st.periodic_ok != 0, false};
+                pl.hist_frames = static_cast<uint32_t>(st.available);
+                pl.abs_out = st.abs_out;
+                pl.abs_consumed = st.abs_consumed;
+                const FirCallCounts c = mirror_call(st, in_fr, ls.out_cap_frames, sink);
+                pl.n_out = static_cast<uint32_t>(c.produced);
+                pl.accepted = static_cast<uint32_t>(c.accepted);
+                pl.consumed = static_cast<uint32_t>(c.consumed);
+                pl.tail_frames = static_cast<uint32_t>(st.available);
+                pl.n_segs = sink.n_segs;
+                pl.n_wraps = sink.n_wraps < g.wrap_cap ? sink.n_wraps : g.wrap_cap;
+                pl.flags = (sink.periodic && st.periodic_ok != 0 ? 0u : kFlagReference) |
+                           (sink.overflow ? kFlagRunOverflow : 0u);
+                pl.runs = segs + lane * kLsSegCap;
+            }
             uint64_t cursor = 0;
             if (args.append) {
                 cursor = args.out_cursor[gs];
-                args.out_cursor[gs] = cursor + c.produced * C;
+                args.out_cursor[gs] = cursor + static_cast<uint64_t>(pl.n_out) * C;
             }
             pl.out = ls.out + cursor;
-            pl.pad = 0;
             plan[lane] = pl;
             stash[lane] = st;
-            args.counts[2 * gs] = c.accepted * C;
-            args.counts[2 * gs + 1] = c.produced * C;
+            args.counts[2 * gs] = static_cast<uint64_t>(pl.accepted) * C;
+            args.counts[2 * gs + 1] = static_cast<uint64_t>(pl.n_out) * C;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
@@ -266,7 +295,10 @@ __global__ __launch_bounds__(kLsWaves * 64, kLsWaves / 2) void fir_lockstep_kern
                 cols[before + i] = cl;
             }
         }
-        if (lane == 0) *n_cols_p = total < g.max_cols ? total : g.max_cols;
+        if (lane == 0) {
+            n_cols_p[0] = total < g.max_cols ? total : g.max_cols;
+            n_cols_p[1] = 0;   // unit counter
+        }
     } else {
         // Stage [buffered | new] of every stream with LDS-DMA (global_load_lds, 256 B per wave instruction,
         // no VGPR round trip: every piece of every stream is in flight at once); everything else of the
@@ -326,7 +358,37 @@ __global__ __launch_bounds__(kLsWaves * 64, kLsWaves / 2) void fir_lockstep_kern
     if constexpr (TRACE) tr[2] = __builtin_amdgcn_s_memtime();   // wave 0: columns built; others: staged
     __syncthreads();
     if constexpr (TRACE) tr[3] = __builtin_amdgcn_s_memtime();
-    if (wave == 0 && lane < g.count) args.states[g.first + lane] = stash[lane];   // every reader of the old state is past the barrier
+    if (wave == 0 && lane < g.count) {
+        const uint32_t gs = g.first + lane;
+        FirMirrorState st = stash[lane];
+        args.states[gs] = st;   // every reader of the old state is past the barrier
+        // ---- the NEXT step's plan, while the other waves compute this one ----------------------------
+        char* nrec = args.recs + (static_cast<size_t>((args.step + 1u) & 1u) * args.n_streams + gs) * args.rec_stride;
+        uint32_t in_fr = my_in_fr;
+        const uint32_t room = g.span_frames > st.available ? g.span_frames - static_cast<uint32_t>(st.available) : 0u;
+        if (in_fr > room) in_fr = room;
+        LdsSink sink{reinterpret_cast<SegLds*>(nrec + kLsRecSegs), nullptr, reinterpret_cast<uint32_t*>(nrec + kLsRecWraps),
+                     0u, 0u, g.wrap_cap, g.periodic != 0 && st.periodic_ok != 0, false};
+        LsPlanHeader hd;
+        hd.hist_frames = static_cast<uint32_t>(st.available);
+        hd.abs_out = st.abs_out;
+        hd.abs_consumed = st.abs_consumed;
+        const FirCallCounts c = mirror_call(st, in_fr, args.streams[gs].out_cap_frames, sink);
+        hd.epoch = args.epoch;
+        hd.step = args.step + 1u;
+        hd.in_frames = my_in_fr;
+        hd.n_out = static_cast<uint32_t>(c.produced);
+        hd.accepted = static_cast<uint32_t>(c.accepted);
+        hd.consumed = static_cast<uint32_t>(c.consumed);
+        hd.tail_frames = static_cast<uint32_t>(st.available);
+        hd.n_segs = sink.n_segs;
+        hd.n_wraps = sink.n_wraps < g.wrap_cap ? sink.n_wraps : g.wrap_cap;
+        hd.flags = (sink.periodic && st.periodic_ok != 0 ? 0u : kFlagReference) | (sink.overflow ? kFlagRunOverflow : 0u);
+        hd.pad0 = 0;
+        hd.pad1 = 0;
+        hd.after = st;
+        *reinterpret_cast<LsPlanHeader*>(nrec) = hd;
+    }
 
     // ---- B: retire (tail back to HBM, in place) -------------------------------------------------
     for (uint32_t s = 0; s < g.count; ++s) {
@@ -343,7 +405,14 @@ __global__ __launch_bounds__(kLsWaves * 64, kLsWaves / 2) void fir_lockstep_kern
         const uint32_t n_chunks = (n_cols + 15) / 16;
         const uint32_t n_units = n_chunks * g.n_tiles;
         const bool pair_ok = (C & 1u) == 0;   // both channels of a frame with one 8-byte LDS read
-        for (uint32_t u = wave; u < n_units; u += kLsWaves) {
+        // units are claimed from an LDS counter: the first wave joins late (it has planned the next step)
+        for (;;) {
+            uint32_t u_claim = 0;
+            if (lane == 0) u_claim = atomicAdd(n_cols_p + 1, 1u);
+            const uint32_t u = __builtin_amdgcn_readfirstlane(u_claim);
+            if (u >= n_units) break;
+            unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0;
+            if constexpr (TRACE) ts0 = __builtin_amdgcn_s_memtime();
             const uint32_t chunk = u / g.n_tiles;
             const uint32_t t = u - chunk * g.n_tiles;
             const TileMeta tm = load_uniform(g.class_meta + t);
@@ -358,6 +427,11 @@ __global__ __launch_bounds__(kLsWaves * 64, kLsWaves / 2) void fir_lockstep_kern
                                                    static_cast<int32_t>(tm.base) + static_cast<int32_t>(lane >> 4)) *
                                   static_cast<int32_t>(C);
             fetch_tile(t);
+            if constexpr (TRACE) {
+                ts1 = __builtin_amdgcn_s_memtime();
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                ts2 = __builtin_amdgcn_s_memtime();
+            }
             const uint32_t j = t * 16 + 4 * (lane >> 4);          // first of the lane's four classes
             const uint32_t jw = (t * 16 + g.den - 1) / g.den * g.den;   // first class of the tile at an integer position
             for (uint32_t c0 = 0; c0 < C; c0 += 2) {
@@ -369,6 +443,10 @@ __global__ __launch_bounds__(kLsWaves * 64, kLsWaves / 2) void fir_lockstep_kern
                     v4f unused = {0.f, 0.f, 0.f, 0.f};
                     unit_mfma<1>(a_reg, nblk, xb + c0, C, acc0, unused);
                     if (two) unit_mfma<1>(a_reg, nblk, xb + c0 + 1, C, acc1, unused);
+                }
+                if constexpr (TRACE) {
+                    asm volatile("" :: "v"(acc0), "v"(acc1));
+                    ts3 = __builtin_amdgcn_s_memtime();
                 }
                 // a non-finite sum anywhere in the tile: the stream's step is redone in reference form
                 const float chk = (acc0.x + acc0.y) + (acc0.z + acc0.w) + (acc1.x + acc1.y) + (acc1.z + acc1.w);
@@ -406,6 +484,10 @@ __global__ __launch_bounds__(kLsWaves * 64, kLsWaves / 2) void fir_lockstep_kern
                             if (two) o[1] = v1[r];
                         }
                 }
+            }
+            if constexpr (TRACE) {
+                const unsigned long long ts4 = __builtin_amdgcn_s_memtime();
+                ua[0] += ts1 - ts0; ua[1] += ts2 - ts1; ua[2] += ts3 - ts2; ua[3] += ts4 - ts3; ua[4] += 1;
             }
         }
     }
@@ -458,7 +540,7 @@ __global__ __launch_bounds__(kLsWaves * 64, kLsWaves / 2) void fir_lockstep_kern
             if (!(pl.flags & (kFlagReference | kFlagNonFinite)) || pl.n_out == 0) continue;
             const float* coeffs = args.streams[g.first + s].coeffs;
             const float* span = spans + s * region_dw + g.guard_frames * C;
-            const SegLds* sg = segs + s * kLsSegCap;
+            const SegLds* sg = static_cast<const SegLds*>(pl.runs);
             const uint32_t n_round = (pl.n_out + ngrp - 1) / ngrp * ngrp;
             for (uint32_t n = grp; n < n_round; n += ngrp) {
                 const bool live = n < pl.n_out;
@@ -508,8 +590,11 @@ __global__ __launch_bounds__(kLsWaves * 64, kLsWaves / 2) void fir_lockstep_kern
     }
     if constexpr (TRACE) {
         tr[7] = __builtin_amdgcn_s_memtime();
-        if (args.trace && wave < 2 && lane == 0)
+        if (args.trace && wave < 2 && lane == 0) {
             for (int i = 0; i < 8; ++i) args.trace[(static_cast<size_t>(blockIdx.x) * 2 + wave) * 8 + i] = tr[i];
+            if (wave == 1)   // wave 1's unit phases ride in the slots of wave 0 that are unused: after the stamps
+                for (int i = 0; i < 5; ++i) args.trace[static_cast<size_t>(gridDim.x) * 16 + static_cast<size_t>(blockIdx.x) * 5 + i] = ua[i];
+        }
     }
 }
 
@@ -611,7 +696,7 @@ hipError_t launch_fir_lockstep(const LockstepArgs& args, uint32_t n_groups, uint
     static const char* trace_path = getenv("RSMP_LS_TRACE");
     if (trace_path) {   // diagnostic: one synchronous traced step, phase clocks written to the file
         LockstepArgs a = args;
-        const size_t words = static_cast<size_t>(n_groups) * 16;
+        const size_t words = static_cast<size_t>(n_groups) * 21;
         unsigned long long* d = nullptr;
         if (hipMalloc(&d, words * 8) != hipSuccess) return hipErrorOutOfMemory;
         (void)hipMemset(d, 0, words * 8);
@@ -626,6 +711,7 @@ hipError_t launch_fir_lockstep(const LockstepArgs& args, uint32_t n_groups, uint
                 fprintf(f, "%u", b);
                 for (int w = 0; w < 2; ++w)
                     for (int i = 1; i < 8; ++i) fprintf(f, " %lld", (long long)(h[(b * 2 + w) * 8 + i] - h[(b * 2 + w) * 8]));
+                for (int i = 0; i < 5; ++i) fprintf(f, " %lld", (long long)h[static_cast<size_t>(n_groups) * 16 + b * 5 + i]);
                 fprintf(f, "\n");
             }
             fclose(f);

@@ -31,7 +31,8 @@ struct rsmp_fir_lockstep {
     std::vector<LockstepGroup> groups;
     std::vector<LockstepStream> streams;   // internal order
     std::vector<uint32_t> channels;        // internal order
-    DeviceBuffer d_groups, d_streams, d_states, d_cursor, d_counts, d_status, d_order;
+    DeviceBuffer d_groups, d_streams, d_states, d_cursor, d_counts, d_status, d_order, d_recs;
+    uint32_t rec_stride = 0, epoch = 1, step = 0;   // plan-ahead records (fir_lockstep.h)
     uint32_t max_lds = 0;
     bool bound = false;
     hipStream_t last_stream = nullptr;
@@ -140,6 +141,7 @@ extern "C" rsmp_fir_lockstep* rsmp_fir_lockstep_new(rsmp_fir* const* rs, size_t 
             g.slots = geo.slots;
             ls->groups.push_back(g);
             if (geo.lds_bytes > ls->max_lds) ls->max_lds = geo.lds_bytes;
+            if (rsmp::lockstep_rec_stride(geo.wrap_cap) > ls->rec_stride) ls->rec_stride = rsmp::lockstep_rec_stride(geo.wrap_cap);
         }
         for (size_t i = k; i < e; ++i) {
             const rsmp_fir* r = rs[ls->order[i]];
@@ -160,6 +162,7 @@ extern "C" rsmp_fir_lockstep* rsmp_fir_lockstep_new(rsmp_fir* const* rs, size_t 
         ls->d_counts.reserve(2 * n * sizeof(uint64_t)) != hipSuccess ||
         ls->d_status.reserve(n * sizeof(uint32_t)) != hipSuccess ||
         ls->d_order.reserve(n * sizeof(uint32_t)) != hipSuccess ||
+        ls->d_recs.reserve(2 * n * static_cast<size_t>(ls->rec_stride)) != hipSuccess ||
         hipStreamCreateWithFlags(&ls->own_stream, hipStreamNonBlocking) != hipSuccess) {
         rsmp::fail(RSMP_ERR_HIP, "lock-step batch: cannot allocate device state");
         return nullptr;
@@ -172,6 +175,7 @@ extern "C" rsmp_fir_lockstep* rsmp_fir_lockstep_new(rsmp_fir* const* rs, size_t 
     if (hipMemcpy(ls->d_groups.get(), ls->groups.data(), ls->groups.size() * sizeof(LockstepGroup),
                   hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(ls->d_order.get(), ls->order.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemset(ls->d_recs.get(), 0, 2 * n * static_cast<size_t>(ls->rec_stride)) != hipSuccess ||
         hipMemset(ls->d_cursor.get(), 0, n * sizeof(uint64_t)) != hipSuccess ||
         hipMemset(ls->d_counts.get(), 0, 2 * n * sizeof(uint64_t)) != hipSuccess ||
         hipMemset(ls->d_status.get(), 0, n * sizeof(uint32_t)) != hipSuccess ||
@@ -223,6 +227,7 @@ extern "C" int rsmp_fir_lockstep_bind(rsmp_fir_lockstep* ls, const float* const*
     RSMP_HIP_CHECK(hipMemcpy(ls->d_streams.get(), ls->streams.data(), n * sizeof(LockstepStream),
                              hipMemcpyHostToDevice));
     ls->bound = true;
+    ++ls->epoch;   // plans made ahead assumed the previous output capacities
     return RSMP_OK;
 }
 
@@ -253,6 +258,11 @@ extern "C" int rsmp_fir_lockstep_step(rsmp_fir_lockstep* ls, size_t in_frames, s
     a.in_frames = static_cast<uint32_t>(in_frames);
     a.append = append ? 1u : 0u;
     a.trace = nullptr;
+    a.recs = ls->d_recs.as<char>();
+    a.rec_stride = ls->rec_stride;
+    a.n_streams = static_cast<uint32_t>(ls->rs.size());
+    a.epoch = ls->epoch;
+    a.step = ls->step++;
     if (ls->profiling)
         RSMP_HIP_CHECK(hipEventRecord(ls->prof_start[ls->prof_count % rsmp_fir_lockstep::kProfRing], s));
     RSMP_HIP_CHECK(rsmp::launch_fir_lockstep(a, static_cast<uint32_t>(ls->groups.size()), ls->max_lds, s));
@@ -311,6 +321,7 @@ extern "C" int rsmp_fir_lockstep_reset(rsmp_fir_lockstep* ls) {
     for (rsmp_fir* r : ls->rs) r->mirror.reset();   // resampler_fir.rs:638-642
     RSMP_HIP_CHECK(hipMemset(ls->d_cursor.get(), 0, n * sizeof(uint64_t)));
     RSMP_HIP_CHECK(hipMemset(ls->d_status.get(), 0, n * sizeof(uint32_t)));
+    ++ls->epoch;   // plans made ahead belong to the old states
     return upload_states(ls);
 }
 

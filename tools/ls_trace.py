@@ -31,6 +31,10 @@ print("workgroups", rows.shape[0])
 for w in range(2):
     blk = rows[:, 1 + 7 * w: 8 + 7 * w]
     print(f"wave {w}: " + "  ".join(f"{n} p50 {np.percentile(blk[:, i], 50):.0f} max {blk[:, i].max():.0f}" for i, n in enumerate(names)))
+ua = rows[:, 15:20]
+n = np.maximum(ua[:, 4], 1)
+print("wave 1 per unit: units p50 %.1f | setup %.0f | tile wait %.0f | mfma %.0f | epilogue %.0f (cycles, p50 over workgroups)" % (
+    np.percentile(ua[:, 4], 50), np.percentile(ua[:, 0] / n, 50), np.percentile(ua[:, 1] / n, 50), np.percentile(ua[:, 2] / n, 50), np.percentile(ua[:, 3] / n, 50)))
 # by geometry: group rows by their 'end'
 order = np.argsort(rows[:, 7])
 print("slowest workgroups:", rows[order[-5:], 0].astype(int), rows[order[-5:], 7])
