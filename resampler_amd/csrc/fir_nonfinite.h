@@ -26,14 +26,17 @@ struct NfArgs {
     uint32_t chunks;    // chunks per stream
 };
 
-// `bad`: this lane holds a non-finite sum among its outputs n_first .. n_first + n_count - 1 (launch-relative
-// output frames of stream `stream`, of which [0, n_limit) exist).
+// `bad`: the sum this lane tested among its outputs n_first .. n_first + n_count - 1 (launch-relative output
+// frames of stream `stream`, of which [0, n_limit) exist) is not finite.  A lane tests ONE frame of its 4 or
+// 8 (both channels): a non-finite sample spoils a run of >= taps consecutive outputs, so every spoilt run
+// contains tested frames -- except possibly its first and last few, which is why the marked range is
+// widened by the lane's frame count on both sides.
 __device__ __forceinline__ void nf_mark(const NfArgs& nf, bool bad, uint32_t stream, int32_t n_first, int32_t n_count,
                                         int32_t n_limit) {
     if (__builtin_expect(__any(bad), 0)) {
         if (bad && nf.words) {
-            const int32_t a = n_first < 0 ? 0 : n_first;
-            int32_t b = n_first + n_count - 1;
+            const int32_t a = n_first - n_count < 0 ? 0 : n_first - n_count;
+            int32_t b = n_first + 2 * n_count - 1;
             if (b >= n_limit) b = n_limit - 1;
             if (a <= b) {
                 for (int32_t c = a >> kNfChunkShift; c <= (b >> kNfChunkShift); ++c) {

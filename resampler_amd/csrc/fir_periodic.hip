@@ -449,11 +449,9 @@ __device__ __forceinline__ void process_tile(const GeoArgs& geo, const ItemCtx& 
 
     // ---- non-finite sums: the chunk is redone in the reference's form by the repair launch ---------
     {
-        float chk = 0.f;
+        float chk = av[0][0];   // one frame of the lane's eight, every channel of the lane
 #pragma unroll
-        for (int i = 0; i < (int)kClassTile; ++i)
-#pragma unroll
-            for (int k = 0; k < CG; ++k) chk += av[i][k];
+        for (int k = 1; k < CG; ++k) chk += av[0][k];
         nf_mark(geo.nf, cx.lane_on && nf_is_bad(chk), cx.stream, n_lane0, static_cast<int32_t>(kClassTile), n_limit);
     }
     // ---- store -------------------------------------------------------------------------------
@@ -549,9 +547,18 @@ struct WaveTrace {
 // One staged image per workgroup, barriers between stage and compute; two workgroups per CU overlap
 // each other's phases.  Used when two images do not fit the 160 KB of LDS (long periods) -- the
 // double-buffered kernel below is the fast path.
-template <int CG, bool C2, int NT>
+// DIAG (here and in fir_periodic_db_kernel): the diagnostic instantiation honours RSMP_FIR_DEBUG (timing
+// experiments that switch parts of the kernel off) and the RSMP_FIR_TRACE / RSMP_FIR_WTRACE clocks; the
+// shipping instantiation sees them as constant zero / null and carries none of that code.
+template <int CG, bool C2, int NT, bool DIAG>
 __global__ __launch_bounds__(768, 6) void fir_periodic_kernel(const FirStreamDesc* __restrict__ descs,
-                                                              GeoArgs geo) {
+                                                              GeoArgs geo_arg) {
+    GeoArgs geo = geo_arg;
+    if constexpr (!DIAG) {
+        geo.debug = 0;
+        geo.trace = nullptr;
+        geo.wtrace = nullptr;
+    }
     extern __shared__ __attribute__((aligned(16))) float lds[];
     // Persistent workgroups: the grid is two workgroups per CU and each walks the launch's work
     // items (stream, period block).  A fresh dispatch per block cost ~10 us of empty LDS slot
@@ -680,7 +687,7 @@ __device__ __forceinline__ void mfma_store_unit(const GeoArgs& geo, const ItemCt
 #pragma unroll
     for (int g = 0; g < G; ++g) {
         const v4f s0 = acc[g][0], s1 = acc[g][1];
-        nf_mark(geo.nf, p_on[g] && nf_is_bad(((s0.x + s0.y) + (s0.z + s0.w)) + ((s1.x + s1.y) + (s1.z + s1.w))), cx.stream,
+        nf_mark(geo.nf, p_on[g] && nf_is_bad(s0.x + s1.x), cx.stream,
                 cx.n_block0 + static_cast<int32_t>(p_idx[g] * geo.b + j0), 4, cx.n_limit);
     }
 #pragma unroll
@@ -966,8 +973,7 @@ __device__ __forceinline__ void mfma_store_pending_group(const GeoArgs& geo, con
     const MfmaUnit<G>& u = pend.unit;
     if (pend.valid) {
         const v4f s0 = pend.acc[g][0], s1 = pend.acc[g][1];
-        nf_mark(geo.nf, u.mode[g] != 0 && nf_is_bad(((s0.x + s0.y) + (s0.z + s0.w)) + ((s1.x + s1.y) + (s1.z + s1.w))),
-                u.stream, u.n0[g], 4, u.n_limit);
+        nf_mark(geo.nf, u.mode[g] != 0 && nf_is_bad(s0.x + s1.x), u.stream, u.n0[g], 4, u.n_limit);
     }
     if (__builtin_expect(pend.valid && u.fast && !u.wrap && !(geo.debug & 16), 1)) {
         const v4f a0 = pend.acc[g][0], a1 = pend.acc[g][1];
@@ -1286,9 +1292,15 @@ __device__ __forceinline__ void mfma_consumer_stream(const GeoArgs& geo, float* 
     }
 }
 
-template <int CG, bool C2, int NT, int MF>
+template <int CG, bool C2, int NT, int MF, bool DIAG>
 __global__ __launch_bounds__(MF ? 768 : 1024) void fir_periodic_db_kernel(const FirStreamDesc* __restrict__ descs,
-                                                               GeoArgs geo) {
+                                                               GeoArgs geo_arg) {
+    GeoArgs geo = geo_arg;
+    if constexpr (!DIAG) {
+        geo.debug = 0;
+        geo.trace = nullptr;
+        geo.wtrace = nullptr;
+    }
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const uint32_t C = C2 ? 2u : geo.channels;
     const uint32_t lane = threadIdx.x & 63;
@@ -2044,28 +2056,30 @@ hipError_t launch_fir_periodic(const FirStreamDesc* d_descs, uint32_t n_streams,
     else if (nb3 && !mfma_ring && geo.mfma == 1) variant = 18 + static_cast<int>(nb3) + (flat_rows ? 4 : 0);
     else if (nb3 && !mfma_ring) variant = 10 + static_cast<int>(nb3) + (flat_rows ? 4 : 0);
     else variant = 6;
-#define RSMP_MF(nb3v, flatv) reinterpret_cast<const void*>(fir_periodic_db_kernel<2, true, 8, 2 + 64 * (nb3v) + 512 * (flatv)>)
-#define RSMP_MF1(nb3v, flatv) reinterpret_cast<const void*>(fir_periodic_db_kernel<2, true, 8, 1 + 64 * (nb3v) + 512 * (flatv)>)
-    const void* fns[27] = {reinterpret_cast<const void*>(fir_periodic_kernel<2, true, 8>),
-                           reinterpret_cast<const void*>(fir_periodic_kernel<2, false, 8>),
-                           reinterpret_cast<const void*>(fir_periodic_kernel<1, false, 8>),
-                           reinterpret_cast<const void*>(fir_periodic_db_kernel<2, true, 8, 0>),
-                           reinterpret_cast<const void*>(fir_periodic_db_kernel<2, false, 8, 0>),
-                           reinterpret_cast<const void*>(fir_periodic_db_kernel<1, false, 8, 0>),
-                           reinterpret_cast<const void*>(fir_periodic_db_kernel<2, true, 8, 2>),
-                           reinterpret_cast<const void*>(fir_periodic_db_kernel<2, true, 8, 4>),
-                           reinterpret_cast<const void*>(fir_periodic_db_kernel<2, true, 8, 2 + 16>),
-                           reinterpret_cast<const void*>(fir_periodic_db_kernel<2, true, 8, 2 + 32>),
-                           reinterpret_cast<const void*>(fir_periodic_db_kernel<2, true, 8, 2 + 48>),
-                           RSMP_MF(1, 0), RSMP_MF(2, 0), RSMP_MF(3, 0), RSMP_MF(4, 0),
-                           RSMP_MF(1, 1), RSMP_MF(2, 1), RSMP_MF(3, 1), RSMP_MF(4, 1),
-                           RSMP_MF1(1, 0), RSMP_MF1(2, 0), RSMP_MF1(3, 0), RSMP_MF1(4, 0),
-                           RSMP_MF1(1, 1), RSMP_MF1(2, 1), RSMP_MF1(3, 1), RSMP_MF1(4, 1)};
+static const char* trace_env = getenv("RSMP_FIR_TRACE");
+    static const char* wtrace_env = getenv("RSMP_FIR_WTRACE");
+    const bool diag = args.debug != 0 || trace_env != nullptr || wtrace_env != nullptr;
+#define RSMP_SK(cg, c2, D) reinterpret_cast<const void*>(fir_periodic_kernel<cg, c2, 8, D>)
+#define RSMP_DB(cg, c2, mf, D) reinterpret_cast<const void*>(fir_periodic_db_kernel<cg, c2, 8, mf, D>)
+#define RSMP_MF(nb3v, flatv, D) RSMP_DB(2, true, 2 + 64 * (nb3v) + 512 * (flatv), D)
+#define RSMP_MF1(nb3v, flatv, D) RSMP_DB(2, true, 1 + 64 * (nb3v) + 512 * (flatv), D)
+#define RSMP_FNS(D)                                                                                          \
+    {RSMP_SK(2, true, D), RSMP_SK(2, false, D), RSMP_SK(1, false, D), RSMP_DB(2, true, 0, D), RSMP_DB(2, false, 0, D), \
+     RSMP_DB(1, false, 0, D), RSMP_DB(2, true, 2, D), RSMP_DB(2, true, 4, D), RSMP_DB(2, true, 2 + 16, D),            \
+     RSMP_DB(2, true, 2 + 32, D), RSMP_DB(2, true, 2 + 48, D), RSMP_MF(1, 0, D), RSMP_MF(2, 0, D), RSMP_MF(3, 0, D), \
+     RSMP_MF(4, 0, D), RSMP_MF(1, 1, D), RSMP_MF(2, 1, D), RSMP_MF(3, 1, D), RSMP_MF(4, 1, D), RSMP_MF1(1, 0, D),    \
+     RSMP_MF1(2, 0, D), RSMP_MF1(3, 0, D), RSMP_MF1(4, 0, D), RSMP_MF1(1, 1, D), RSMP_MF1(2, 1, D),                  \
+     RSMP_MF1(3, 1, D), RSMP_MF1(4, 1, D)}
+    static const void* const fns_all[2][27] = {RSMP_FNS(false), RSMP_FNS(true)};
+    const void* const* fns = fns_all[diag ? 1 : 0];
+#undef RSMP_FNS
+#undef RSMP_SK
+#undef RSMP_DB
 #undef RSMP_MF
 #undef RSMP_MF1
     {
         std::lock_guard<std::mutex> lock(mu);
-        bool& have = granted[{device, variant}];
+        bool& have = granted[{device, variant * 2 + (diag ? 1 : 0)}];
         if (!have) {
             e = hipFuncSetAttribute(fns[variant], hipFuncAttributeMaxDynamicSharedMemorySize, kLdsMax);
             if (e != hipSuccess) return e;

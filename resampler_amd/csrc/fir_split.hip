@@ -1,34 +1,40 @@
-// fir_split.hip -- periodic FIR on the bf16 matrix cores with three-way split operands (gfx950).
+// fir_split.hip -- periodic FIR on the 16-bit matrix cores with split f32 operands (gfx950).
 //
 // Replaces the same reference code as the other periodic kernels (src/resampler_fir.rs:542-590 +
 // src/fir/avx.rs:5-61) for two-channel streams whose rate pair has 16..160 classes (44.1 <-> 48 kHz).
 //
 // Why: 128 taps per output value is 16.6 FMA per byte of HBM traffic, more than the f32 pipes can
 // retire per byte (78 TFMA/s vs 8 TB/s): an exact-f32 kernel cannot get past ~50 % of the HBM roofline.
-// The bf16 matrix pipe is 16x faster per product, and an f32 value is EXACTLY the sum of three bf16
-// values (8 + 8 + 8 significant bits, by truncation).  With x = x1 + x2 + x3 and c = c1 + c2 + c3 the
-// six products c1x1, c2x1, c3x1, c1x2, c2x2, c1x3 (each exact in f32, accumulated in f32 by the MFMA)
-// leave out only terms below 2^-24 of a product: the result is as close to the f64 sum as the
-// reference's own f32 FMA chain is (measured: DESIGN.md section 4.1).
+// The 16-bit matrix pipe is 16x faster per product, and an f32 operand can be cut into 16-bit planes:
+//   PLANES = 2 (default): x * 2^12 = h1 + h2 + r with h1, h2 fp16 (round to nearest) and |r| <= 2^-22 |x|;
+//     likewise c * 2^13.  Three products c1x1 + c2x1 + c1x2 (each exact in f32, accumulated in f32 by
+//     v_mfma_f32_16x16x32_f16, which keeps fp16 denormals -- tools/f16_mfma_probe.hip) are closer to the
+//     f64 sum than the reference's own f32 FMA chain at audio levels (6e-8 vs 1.4e-7 RMS at full scale,
+//     tests/test_split_precision.py).  Samples of magnitude >= 16 overflow the scaled plane; the launch's
+//     non-finite check (fir_nonfinite.h) then has the chunk recomputed in the reference's f32 form.
+//   PLANES = 3 (RSMP_FIR_SPLIT_PLANES=3): x = p1 + p2 + p3 EXACTLY with bf16 planes by truncation (8 + 8 +
+//     8 significant bits); six products c1x1, c2x1, c3x1, c1x2, c2x2, c1x3 leave out only terms below
+//     2^-24 of a product.  Twice the matrix work, any magnitude.
 //
 // Layout of the computation (same classes / tiles / shifted zero-padded windows as fir_periodic.h):
-//   D[class 16][period 16] += A[class][k 32] * B[k][period]      v_mfma_f32_16x16x32_bf16
-//   * one workgroup per CU, 15 active waves: 5 producers + 10 consumers; consumer T owns class tile T
-//     for the whole launch and keeps its coefficient tile -- 3 planes x window/32 steps x 4 registers --
-//     in VGPRs: the class table is read once per workgroup, not once per work unit;
-//   * an LDS image holds 16 periods of both channels as three bf16 planes, TRANSPOSED: row = frame
-//     inside the period (0 .. end of the last tile's window), per row six 32-byte plane rows (16
-//     periods side by side) + 32 bytes of padding.  Any window start is then a row address (no
-//     alignment constraint), and ds_read_b64_tr_b16 delivers the B operand -- 4 consecutive frames x
-//     16 periods per 16 lanes -- at the full 256 B/clk, every offset an immediate.  Rows beyond the
-//     period repeat the next period's first frames;
-//   * producers load frames from HBM (16 bytes per lane, coalesced along the frame index), split them
-//     into the three planes with 4 VALU operations per value, pack four periods into 8 bytes and write
-//     each chunk twice (row k, and row k + a of the previous period) with ds_write_b64, chunks
-//     XOR-swizzled by the row so that the writes spread over the banks; the next item's loads are in
-//     flight while the current one is written (inline-asm loads, explicit vmcnt);
+//   D[class 16][period 16] += A[class][k 32] * B[k][period]      v_mfma_f32_16x16x32_{f16,bf16}
+//   * one workgroup per CU, 16 waves: 6 producers (five stagers + one wrap-only) + 10 consumers; consumer T
+//     owns class tile T for the whole launch and keeps its coefficient tile -- planes x window/32 steps x 4
+//     registers -- in VGPRs: the class table is read once per workgroup, not once per work unit;
+//   * an LDS image holds 16 periods of both channels as 16-bit planes, TRANSPOSED: row = frame inside the
+//     period (0 .. end of the last tile's window), per row and (channel, plane) one 32-byte plane row (16
+//     periods side by side) + 32 bytes of padding (an odd number of 32-byte units per row: conflict-free
+//     transposed reads).  Any window start is then a row address (no alignment constraint), and
+//     ds_read_b64_tr_b16 delivers the B operand -- 4 consecutive frames x 16 periods per 16 lanes -- at the
+//     full 256 B/clk, every offset an immediate.  Rows beyond the period repeat the next period's first
+//     frames.  Two planes: 160-byte rows, three images in the ring; three planes: 224 bytes, two images;
+//   * producers load frames from HBM (16 bytes per lane, coalesced along the frame index), cut them into
+//     planes (fp16: one v_cvt_pk_f16_f32 per pair and plane), pack four periods into 8 bytes and write each
+//     chunk twice (row k, and row k + a of the previous period) with ds_write_b64, chunks XOR-swizzled by
+//     the row so that the writes spread over the banks; the next item's loads are in flight while the
+//     current one is written (inline-asm loads, explicit vmcnt);
 //   * ring of images, monotonic LDS counters instead of barriers; the wrap variant of class 0 (row 1023
-//     on the previous frame, :562-564) is computed by producers 0-3 in f32 from global memory.
+//     on the previous frame, :562-564) is computed by producers in f32 from global memory.
 #include "fir_periodic.h"
 
 #include <cstdio>
@@ -80,18 +86,20 @@ constexpr uint32_t kWtraceSlots = 16;
 // Diagnostic per-wave phase clock (RSMP_FIR_WTRACE): event(tag) adds the shader-clock cycles since the
 // wave's previous event to the bucket of the previous tag (in LDS, 16 buckets per wave, written out at
 // the end).  Cheap enough not to change what it measures: one s_memtime and one LDS add per event.
+template <bool DIAG>
 struct WaveTrace {
     unsigned long long* out;
     unsigned long long* acc;     // LDS
     unsigned long long last;
     uint32_t prev;
     __device__ __forceinline__ void init(const SplitArgs& g, char* lds, uint32_t wave) {
-        out = g.wtrace ? g.wtrace + (static_cast<size_t>(blockIdx.x) * 16 + wave) * kWtraceSlots : nullptr;
+        out = DIAG && g.wtrace ? g.wtrace + (static_cast<size_t>(blockIdx.x) * 16 + wave) * kWtraceSlots : nullptr;
         acc = reinterpret_cast<unsigned long long*>(lds + g.lds_bytes) + wave * kWtraceSlots;
         last = 0;
         prev = 0;
     }
     __device__ __forceinline__ void event(uint32_t tag) {
+        if constexpr (!DIAG) return;
         if (out) {
             const unsigned long long now = __builtin_amdgcn_s_memtime();
             if (last != 0 && (threadIdx.x & 63) == 0)
@@ -101,6 +109,7 @@ struct WaveTrace {
         }
     }
     __device__ __forceinline__ void flush() {
+        if constexpr (!DIAG) return;
         if (out) {
             __builtin_amdgcn_s_waitcnt(0);
             const uint32_t l = threadIdx.x & 63;
@@ -313,17 +322,20 @@ __device__ __forceinline__ bool wave_is_producer(uint32_t w) { return w < 4 || w
 __device__ __forceinline__ uint32_t producer_index(uint32_t w) { return w == 0 ? 5 : (w < 4 ? w - 1 : w - 3); }
 __device__ __forceinline__ uint32_t consumer_index(uint32_t w) { return w < 6 ? w - 4 : w - 6; }
 
-template <int NK, int PLANES>
+// DIAG: the diagnostic instantiation (RSMP_FIR_DEBUG switches for timing experiments, RSMP_FIR_WTRACE phase
+// clocks); in the shipping instantiation `dbg` is the constant 0 and every such test folds away.
+template <int NK, int PLANES, bool DIAG>
 __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __restrict__ descs,
                                                          const SplitArgs g) {
     constexpr uint32_t kRowBytes = row_bytes(PLANES);
+    const uint32_t dbg = DIAG ? g.debug : 0u;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     uint32_t* ctrl = reinterpret_cast<uint32_t*>(lds);
     uint32_t* staged = ctrl;        // [slot]: producers that finished staging, cumulative
     uint32_t* done = ctrl + 4;      // [slot]: consumers that finished reading, cumulative
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    for (uint32_t i = threadIdx.x; i < (g.lds_bytes + (g.wtrace ? 16 * kWtraceSlots * 8 : 0)) / 4; i += blockDim.x)
+    for (uint32_t i = threadIdx.x; i < (g.lds_bytes + (DIAG && g.wtrace ? 16 * kWtraceSlots * 8 : 0)) / 4; i += blockDim.x)
         ctrl[i] = 0;   // counters; finite image rows
     __syncthreads();
 
@@ -352,7 +364,7 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
     if (item_begin == item_end) return;
 
     uint32_t slot = 0, use = 0;   // ring position of the current item: image slot, times the slot was used before
-    WaveTrace wt;
+    WaveTrace<DIAG> wt;
     wt.init(g, lds, wave);
 
     if (wave_is_producer(wave)) {
@@ -507,7 +519,7 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
             };
             auto wrap_out = [&](const v2f (&w)[kWrapTaps], uint32_t wper, uint32_t take) {
                 v2f acc = v2f{0.f, 0.f};
-                if (!(g.debug & 1024)) {
+                if (!(dbg & 1024)) {
 #pragma unroll
                     for (int i = 0; i < kWrapTaps; ++i) {
                         acc.x = fmaf(wcoef[i], w[i].x, acc.x);
@@ -523,7 +535,7 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
             for (;;) {
                 const bool more = nxt.item != item_end;
                 if (!have && !more) break;
-                const bool pre = more && nxt.interior && !(g.debug & 8192);   // the next item's loads can be issued ahead
+                const bool pre = more && nxt.interior && !(dbg & 8192);   // the next item's loads can be issued ahead
                 asm volatile("" : "+v"(ln), "+v"(tQ), "+v"(tK));
                 char* img = lds + kImageBase + slot * image_bytes;
                 if (have) {
@@ -541,7 +553,7 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
                     for (int i = 0; i < kWrapTaps / 2; ++i) asm volatile("" : "+v"(wx[ps][i]));
                     asm volatile("" : "+v"(wword[ps]));
                 }
-                if (have && real_task && !(g.debug & 1)) {
+                if (have && real_task && !(dbg & 1)) {
                     if (loaded) {
                         store_task(img, x);
                     } else {
@@ -675,7 +687,7 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
         // L2 prefetch for the producers: the frames of the item kTouchAhead items on (same stream assumed),
         // one dword per 128-byte line by LDS-DMA into a landing zone nobody reads.  The producers' own
         // loads, issued one item ahead, would otherwise each pay the full HBM latency -- longer than an item.
-        if (T < 3 && d.in_frames != 0 && (g.debug & 4096)) {   // (off: measured 4 % slower than without)
+        if (T < 3 && d.in_frames != 0 && (dbg & 4096)) {   // (off: measured 4 % slower than without)
             int64_t f = cu.f0 - static_cast<int64_t>(d.hist_frames) + static_cast<int64_t>(kTouchAhead * 16u * g.a) +
                         static_cast<int64_t>((T * 64 + lane) * 16u);
             if (f < 0) f = 0;
@@ -685,7 +697,7 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
                                              (lds_void_ptr)(lds + kCtrlBytes + kWrapBytes + T * 256), 4, 0, 0);
         }
         wt.event(1);
-        if (!(g.debug & 16384))
+        if (!(dbg & 16384))
             while (lds_load_acquire(staged + slot) < kProducers * (use + 1)) __builtin_amdgcn_s_sleep(RSMP_POLL_SLEEP);
         wt.event(2);
 
@@ -697,7 +709,7 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
             const s16x8 t = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
             return __builtin_bit_cast(frag_t, t);
         };
-        if (!(g.debug & 2))
+        if (!(dbg & 2))
 #pragma unroll
         for (int s = 0; s < NK; ++s) {
             if constexpr (PLANES == 3) {
@@ -727,7 +739,7 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
                 acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[s][0], x1, acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[s][0], y1, acc1, 0, 0, 0);
             }
-            if (s == 0 && !(g.debug & 131072)) {
+            if (s == 0 && !(dbg & 131072)) {
                 __builtin_amdgcn_sched_barrier(0);
                 flush_pending();
                 __builtin_amdgcn_sched_barrier(0);
@@ -741,7 +753,7 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
         // class 0 may take the wrap variant the producers left with the image (tile 0, D row 0)
         if (T == 0) {
             const v4f w = *reinterpret_cast<const v4f*>(lds + kCtrlBytes + slot * 256 + pl * 16);
-            if (grp == 0 && __float_as_uint(w.z) != 0u && !(g.debug & 2048)) {
+            if (grp == 0 && __float_as_uint(w.z) != 0u && !(dbg & 2048)) {
                 acc0.x = w.x;
                 acc1.x = w.y;
             }
@@ -754,12 +766,11 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
         const int32_t n_limit = static_cast<int32_t>(d.n_out);
         // a non-finite sum (inf / NaN sample, or one too large for the 16-bit planes): the chunk is redone
         // in the reference's form by the repair launch
-        nf_mark(g.nf, nf_is_bad(((acc0.x + acc0.y) + (acc0.z + acc0.w)) + ((acc1.x + acc1.y) + (acc1.z + acc1.w))),
-                d.sidx, n0, 4, n_limit);
+        nf_mark(g.nf, nf_is_bad(acc0.x + acc1.x), d.sidx, n0, 4, n_limit);
         g_f32_ptr o = (g_f32_ptr)d.out + static_cast<int64_t>(n0) * 2;
         const v4f lo = v4f{acc0.x, acc1.x, acc0.y, acc1.y};
         const v4f hi = v4f{acc0.z, acc1.z, acc0.w, acc1.w};
-        if (!(g.debug & 16)) {
+        if (!(dbg & 16)) {
             const bool full = j0 + 4 <= g.b && n0 >= 0 && n0 + 4 <= n_limit;
             if (__builtin_expect(__all(full), 1)) {   // the whole wave inside the launch: stored inside the next item's stream
                 pend_lo = lo;
@@ -922,17 +933,16 @@ hipError_t launch_fir_split(const FirStreamDesc* d_descs, uint32_t n_streams, co
         return e ? static_cast<uint32_t>(atoi(e)) : 0u;
     }();
     SplitArgs args{geo.a, geo.b, geo.taps, geo.n_tiles, geo.row_stride, geo.images, geo.lds_bytes, max_blocks, max_blocks * n_streams, debug, n_streams, fuse_tail ? 1u : 0u, nullptr, nf};
-    const void* fns3[5] = {reinterpret_cast<const void*>(fir_split_kernel<1, 3>),
-                           reinterpret_cast<const void*>(fir_split_kernel<2, 3>),
-                           reinterpret_cast<const void*>(fir_split_kernel<3, 3>),
-                           reinterpret_cast<const void*>(fir_split_kernel<4, 3>),
-                           reinterpret_cast<const void*>(fir_split_kernel<5, 3>)};
-    const void* fns2[5] = {reinterpret_cast<const void*>(fir_split_kernel<1, 2>),
-                           reinterpret_cast<const void*>(fir_split_kernel<2, 2>),
-                           reinterpret_cast<const void*>(fir_split_kernel<3, 2>),
-                           reinterpret_cast<const void*>(fir_split_kernel<4, 2>),
-                           reinterpret_cast<const void*>(fir_split_kernel<5, 2>)};
-    const void* const* fns = geo.planes == 3 ? fns3 : fns2;
+    static const char* wtrace_path = getenv("RSMP_FIR_WTRACE");
+    const bool diag = debug != 0 || wtrace_path != nullptr;
+#define RSMP_SPLIT_FNS(P, D)                                                                              \
+    {reinterpret_cast<const void*>(fir_split_kernel<1, P, D>), reinterpret_cast<const void*>(fir_split_kernel<2, P, D>), \
+     reinterpret_cast<const void*>(fir_split_kernel<3, P, D>), reinterpret_cast<const void*>(fir_split_kernel<4, P, D>), \
+     reinterpret_cast<const void*>(fir_split_kernel<5, P, D>)}
+    static const void* const fns_all[2][2][5] = {{RSMP_SPLIT_FNS(2, false), RSMP_SPLIT_FNS(2, true)},
+                                                 {RSMP_SPLIT_FNS(3, false), RSMP_SPLIT_FNS(3, true)}};
+#undef RSMP_SPLIT_FNS
+    const void* const* fns = fns_all[geo.planes == 3 ? 1 : 0][diag ? 1 : 0];
     const uint32_t nk = geo.row_len / 32;
     if (nk < 1 || nk > 5) return hipErrorInvalidValue;
     int device = 0;
@@ -942,7 +952,7 @@ hipError_t launch_fir_split(const FirStreamDesc* d_descs, uint32_t n_streams, co
     static std::map<std::pair<int, uint32_t>, bool> granted;
     {
         std::lock_guard<std::mutex> lock(mu);
-        bool& have = granted[{device, nk * 8 + geo.planes}];
+        bool& have = granted[{device, (nk * 8 + geo.planes) * 2 + (diag ? 1u : 0u)}];
         if (!have) {
             e = hipFuncSetAttribute(fns[nk - 1], hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit);
             if (e != hipSuccess) return e;
@@ -954,7 +964,6 @@ hipError_t launch_fir_split(const FirStreamDesc* d_descs, uint32_t n_streams, co
     if (verbose)
         fprintf(stderr, "[rsmp] split launch: a=%u b=%u window=%u tiles=%u rows=%u lds=%u items=%u grid=%u\n",
                 geo.a, geo.b, geo.row_len, geo.n_tiles, geo.row_stride, geo.lds_bytes, args.total_items, grid.x);
-    static const char* wtrace_path = getenv("RSMP_FIR_WTRACE");
     static unsigned long long* d_wtrace = nullptr;
     const size_t wtrace_words = static_cast<size_t>(grid.x) * 16 * kWtraceSlots;
     if (wtrace_path) {
