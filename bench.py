@@ -247,19 +247,19 @@ def cpu_baseline_fft(seconds: float):
 # ------------------------------------------------------------------------------------------------
 # GPU workloads
 # ------------------------------------------------------------------------------------------------
-def traffic_from_profiles(name: str, variant=None):
-    """HBM bytes per launch from the committed PMC passes (profiles/traffic_latest.json is written by
-    tools/profile_round.sh on the GPU box; this run does not collect counters itself)."""
+def traffic_from_profiles(name: str, kernel_name=None):
+    """HBM bytes per launch of the workload's dominant kernel from the committed PMC passes
+    (profiles/traffic_latest.json, written by tools/profile_round.sh on the GPU box: separate FETCH_SIZE /
+    WRITE_SIZE passes with the guide's gfx950 corrections; this run does not collect counters itself)."""
     tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
     try:
-        tj = json.load(open(tpath))
+        ent = json.load(open(tpath)).get(name)
     except Exception:
         return None
-    ent = tj.get(name) if isinstance(tj.get(name), dict) else (tj if name == "fir" else None)
-    if not ent:
+    if not isinstance(ent, dict):
         return None
-    if variant is not None and ent.get("variant") is not None and ent["variant"] != variant:
-        return None
+    if kernel_name is not None and ent.get("kernel") not in (None, kernel_name):
+        return None   # the counters were collected for another kernel
     return ent.get("hbm_bytes_per_launch")
 
 
@@ -516,7 +516,7 @@ def bench_fir(ctx: Ctx, args):
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": traffic_from_profiles("fir", variant),
+            "traffic": traffic_from_profiles("fir", KERNEL_NAMES.get(variant)),
             "kernel_ms": round(k_ms, 4),
             "kernel_launches_timed": int(k_launches),
             "algorithmic_bytes": int(alg_bytes),
