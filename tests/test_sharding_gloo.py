@@ -181,3 +181,17 @@ def test_world2_gloo_scatter_compute_gather_moves_real_samples():
         off += n
         assert totals[i] == [c_tot, p_tot], i
         assert digests[i] == h.hexdigest(), i
+
+
+def test_bench_gpus_flag_spawns_or_fails_loudly():
+    # `bench.py --gpus N` must never quietly run one rank: without N visible GPUs it refuses (exit code 2, a
+    # message on stderr) before anything touches a device.
+    import subprocess
+    import torch
+    n = torch.cuda.device_count() + 2
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--no-cpu"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert p.returncode == 2, (p.returncode, p.stderr[-500:])
+    assert f"--gpus {n}" in p.stderr and "visible" in p.stderr
+    assert p.stdout.strip() == ""

@@ -6,7 +6,7 @@ import os, sys, json
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-path = os.path.join(ROOT, "gpurun_out", "ls_trace.txt")
+path = os.environ.get("RSMP_LS_TRACE") or os.path.join(ROOT, "gpurun_out", "ls_trace.txt")
 if os.path.exists(path):
     os.remove(path)
 import torch

@@ -19,6 +19,10 @@ cd /tmp && export TMPDIR=/tmp
 python3 "$R/bench.py" --steps 20 --warmup 3 > "$SUM/bench_n1.json" 2> "$OUT/bench_n1.err"
 python3 "$R/bench.py" --path fft --steps 20 --warmup 3 > "$SUM/bench_fft.json" 2> "$OUT/bench_fft.err"
 python3 "$R/bench.py" --config c4 --steps 256 --warmup 16 > "$SUM/bench_c4.json" 2> "$OUT/bench_c4.err"
+python3 "$R/tools/configs_bench.py" > "$SUM/bench_c5.json" 2> "$OUT/bench_c5.err"
+RSMP_LS_TRACE="$SUM/ls_trace_raw.txt" python3 "$R/tools/ls_trace.py" > "$SUM/ls_trace.txt" 2> "$OUT/ls_trace.err"; rm -f "$SUM/ls_trace_raw.txt"
+RSMP_FIR_WTRACE="$OUT/wtrace.txt" python3 "$R/bench.py" --no-cpu --no-secondary --steps 3 --warmup 1 --spinup-seconds 0 > /dev/null 2>&1
+python3 "$R/tools/wphase_report.py" "$OUT/wtrace.txt" 111.5 > "$SUM/wphase_split.txt" 2>/dev/null
 
 declare -A CMD
 CMD[fir]="--steps 20 --warmup 3 --no-cpu --no-secondary"
