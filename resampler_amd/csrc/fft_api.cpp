@@ -56,7 +56,17 @@ int get_plan(int device, uint32_t in_hz, uint32_t out_hz, std::shared_ptr<Device
     const auto key = std::make_tuple(device, in_hz, out_hz);
     auto it = c.plans.find(key);
     if (it != c.plans.end()) { *out = it->second; return RSMP_OK; }
-    auto p = std::make_shared<DevicePlan>();
+    // a plan that fails half way releases what it had uploaded (a cached plan lives for the process)
+    auto release = [](DevicePlan* dp) {
+        const FftPlanDev& dv = dp->dev;
+        for (const void* q : {static_cast<const void*>(dv.tw_f), static_cast<const void*>(dv.tw_i),
+                              static_cast<const void*>(dv.rc_f), static_cast<const void*>(dv.rc_i),
+                              static_cast<const void*>(dv.filter)})
+            if (q) (void)hipFree(const_cast<void*>(q));
+        delete dp;
+    };
+    std::shared_ptr<DevicePlan> p(new DevicePlan, release);
+    std::memset(&p->dev, 0, sizeof p->dev);
     p->host = rsmp::make_fft_resampler_plan(in_hz, out_hz);
     if (!p->host.ok)
         return rsmp::fail(RSMP_ERR_INVALID_ARGUMENT, "ResamplerFft: unsupported rate pair %u -> %u", in_hz, out_hz);
@@ -64,7 +74,6 @@ int get_plan(int device, uint32_t in_hz, uint32_t out_hz, std::shared_ptr<Device
     if (h.forward.stages.size() > rsmp::kMaxFftStages || h.inverse.stages.size() > rsmp::kMaxFftStages)
         return rsmp::fail(RSMP_ERR_INVALID_ARGUMENT, "ResamplerFft: too many FFT stages");
     FftPlanDev& d = p->dev;
-    std::memset(&d, 0, sizeof d);
     d.fft_in = static_cast<uint32_t>(h.fft_in);
     d.fft_out = static_cast<uint32_t>(h.fft_out);
     d.n_stages_f = static_cast<uint32_t>(h.forward.stages.size());
