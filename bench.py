@@ -477,6 +477,15 @@ def bench_fir(ctx: Ctx, args):
     dt, host_dt = timed(ctx, step, args.steps, 1 if args.warmup > 0 else 0)
     k_ms, k_launches = handles[0].mean_kernel_ms()
     handles[0].set_profiling(False)
+    # what a step costs the host when it does not wait for the GPU (in the timed loop the enqueue runs at
+    # most a launch or two ahead, so `host_enqueue_ms_per_step` there is mostly back-pressure)
+    host_idle = 0.0
+    for _ in range(10):
+        ctx.torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        step()
+        host_idle += time.perf_counter() - t1
+    ctx.torch.cuda.synchronize()
 
     values_in_per_step = S * CHANNELS * N            # per rank
     values_out_per_step = int(produced.sum())
@@ -507,6 +516,7 @@ def bench_fir(ctx: Ctx, args):
             "plan_cold_ms": round(plan_cold_ms, 2),
             "spinup_s": args.spinup_seconds,
             "host_enqueue_ms_per_step": round(host_dt / args.steps * 1e3, 4),
+            "host_cost_ms_per_step_gpu_idle": round(host_idle / 10 * 1e3, 4),
             "feed": "resident per GPU (no data-path collective)",
         },
         "roofline": {
