@@ -96,6 +96,57 @@ __device__ __forceinline__ void wave_stage(float2* buf, const float2* __restrict
     }
 }
 
+// Stages 0 (radix RA, stride 1, no twiddles) and 1 (radix RB, stride RA, twiddles W_(RA*RB)^(k q')) of a
+// transform in ONE register pass.  The three (RA) stage-1 butterflies 3j, 3j+1, 3j+2 consume exactly the
+// outputs of the seven (RB) stage-0 butterflies j + M2*q': unit j therefore takes the RA*RB points
+// j + M2*m (m = q' + RB*q), runs RB radix-RA butterflies, the twiddles and RA radix-RB butterflies in
+// registers, and writes the contiguous outputs RA*RB*j .. RA*RB*j + RA*RB - 1 -- what the two stages
+// would have left in LDS, with one LDS round trip and the stage-1 index arithmetic gone.  Same operations
+// on the same values as the separate stages (the unit twiddles of column k = 0 are skipped).
+// `load(index)` yields point `index` of the stage-0 input (LDS, or samples straight from HBM).
+template <int N, int RA, int RB, class Load>
+__device__ __forceinline__ void wave_fused_first(float2* dst, const float2* __restrict__ tw1, int lane, Load load) {
+    constexpr int M2 = N / (RA * RB);
+    constexpr int ITER = (M2 + 63) / 64;
+    float2 s[ITER][RB][RA];
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+        const int j = lane + 64 * it;
+        if ((it + 1) * 64 <= M2 || j < M2) {
+#pragma unroll
+            for (int qp = 0; qp < RB; ++qp)
+#pragma unroll
+                for (int q = 0; q < RA; ++q) s[it][qp][q] = load(j + M2 * (qp + RB * q));
+        }
+    }
+    lds_order();
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+        const int j = lane + 64 * it;
+        if ((it + 1) * 64 <= M2 || j < M2) {
+#pragma unroll
+            for (int qp = 0; qp < RB; ++qp) {
+                float2 o[RA];
+                dft<RA>(s[it][qp], o);
+#pragma unroll
+                for (int k = 0; k < RA; ++k) s[it][qp][k] = o[k];
+            }
+#pragma unroll
+            for (int k = 0; k < RA; ++k) {
+                float2 u[RB], o[RB];
+                u[0] = s[it][0][k];
+#pragma unroll
+                for (int qp = 1; qp < RB; ++qp)
+                    u[qp] = k == 0 ? s[it][qp][k] : cmul(tw1[k * (RB - 1) + qp - 1], s[it][qp][k]);
+                dft<RB>(u, o);
+#pragma unroll
+                for (int qq = 0; qq < RB; ++qq) dst[RA * RB * j + k + RA * qq] = o[qq];
+            }
+        }
+    }
+    lds_order();
+}
+
 // postprocess_fft (radix_fft.rs:500-537 + real_complex/mod.rs:37-74), in place on x[0 .. N2].
 template <int N2>
 __device__ __forceinline__ void wave_postprocess(float2* x, const float2* __restrict__ rc, int lane) {
@@ -177,7 +228,7 @@ __global__ __launch_bounds__((OCC == 3 ? 12 : 4) * 64, OCC) void fft_ola_wave_ke
     constexpr int kWavesPerGroup = OCC == 3 ? 12 : 4;
     constexpr int FI = FWD::N, FO = INV::N;
     constexpr int LDSC = (FI > FO ? FI : FO) + 2;
-    constexpr int R1 = FWD::kR[0], M1 = FI / R1, ITER1 = (M1 + 63) / 64, QV = (R1 + 1) / 2;
+    constexpr int R1 = FWD::kR[0];
     constexpr int RL = INV::kR[3], ML = FO / RL, ITERL = (ML + 63) / 64, HL = RL / 2;
     static_assert(RL % 2 == 0, "the last inverse stage splits its outputs into output half and carry half");
     static_assert(FI % 2 == 0 && FO % 2 == 0, "frame pairs");
@@ -237,17 +288,17 @@ __global__ __launch_bounds__((OCC == 3 ? 12 : 4) * 64, OCC) void fft_ola_wave_ke
     }
     const int64_t b_begin = first == 0 ? 0 : static_cast<int64_t>(first) - 1;
 
-    // complex j of the block's channel = frames 2j, 2j + 1 (j < FI / 2), zero beyond (resampler_fft.rs:387-388)
-    auto load_block = [&](int64_t b, float2 (&x)[ITER1][QV]) {
-        const float* xin = d.in + static_cast<size_t>(b) * FI * C;
-#pragma unroll
-        for (int it = 0; it < ITER1; ++it) {
-            const int i = lane + 64 * it;
-#pragma unroll
-            for (int q = 0; q < QV; ++q) {
-                const int j = i + q * M1;
+    for (int64_t b = b_begin; b < static_cast<int64_t>(last); ++b) {
+        const bool emit = b >= static_cast<int64_t>(first);
+        constexpr int S1 = R1, S2 = S1 * FWD::kR[1], S3 = S2 * FWD::kR[2];
+        constexpr int T1 = 0, T2 = T1 + S1 * (FWD::kR[1] - 1), T3 = T2 + S2 * (FWD::kR[2] - 1);
+        // ---- forward stages 1 + 2 in one register pass, inputs straight from HBM: complex j of the block's
+        // channel = frames 2j, 2j + 1 (j < FI / 2), zero beyond (resampler_fft.rs:387-388)
+        {
+            const float* xin = d.in + static_cast<size_t>(b) * FI * C;
+            auto sample = [&](int j) -> float2 {
                 float2 v = make_float2(0.f, 0.f);
-                if (i < M1 && j < FI / 2) {
+                if (j < FI / 2) {
                     if constexpr (C2) {
                         const float4 f = reinterpret_cast<const float4*>(xin)[j];
                         v = ch == 0 ? make_float2(f.x, f.z) : make_float2(f.y, f.w);
@@ -255,33 +306,10 @@ __global__ __launch_bounds__((OCC == 3 ? 12 : 4) * 64, OCC) void fft_ola_wave_ke
                         v = make_float2(xin[static_cast<size_t>(2 * j) * C + ch], xin[static_cast<size_t>(2 * j + 1) * C + ch]);
                     }
                 }
-                x[it][q] = v;
-            }
+                return v;
+            };
+            wave_fused_first<FI, FWD::kR[0], FWD::kR[1]>(buf, tw_f + T1, lane, sample);
         }
-    };
-
-    for (int64_t b = b_begin; b < static_cast<int64_t>(last); ++b) {
-        const bool emit = b >= static_cast<int64_t>(first);
-        float2 xcur[ITER1][QV];
-        load_block(b, xcur);
-        // ---- forward stage 1 (stride 1, no twiddles) straight from the loaded samples
-#pragma unroll
-        for (int it = 0; it < ITER1; ++it) {
-            const int i = lane + 64 * it;
-            if ((it + 1) * 64 <= M1 || i < M1) {
-                float2 t[R1], o[R1];
-#pragma unroll
-                for (int q = 0; q < R1; ++q) t[q] = q < QV ? xcur[it][q] : make_float2(0.f, 0.f);
-                dft<R1>(t, o);
-#pragma unroll
-                for (int q = 0; q < R1; ++q) buf[R1 * i + q] = o[q];
-            }
-        }
-        lds_order();
-
-        constexpr int S1 = R1, S2 = S1 * FWD::kR[1], S3 = S2 * FWD::kR[2];
-        constexpr int T1 = 0, T2 = T1 + S1 * (FWD::kR[1] - 1), T3 = T2 + S2 * (FWD::kR[2] - 1);
-        wave_stage<FI, FWD::kR[1], S1>(buf, tw_f + T1, lane);
         wave_stage<FI, FWD::kR[2], S2>(buf, tw_f + T2, lane);
         wave_stage<FI, FWD::kR[3], S3>(buf, tw_f + T3, lane);
         wave_postprocess<FI>(buf, rc_f, lane);
@@ -289,31 +317,8 @@ __global__ __launch_bounds__((OCC == 3 ? 12 : 4) * 64, OCC) void fft_ola_wave_ke
 
         constexpr int IS1 = INV::kR[0], IS2 = IS1 * INV::kR[1];
         constexpr int IT1 = 0, IT2 = IT1 + IS1 * (INV::kR[1] - 1), IT3 = IT2 + IS2 * (INV::kR[2] - 1);
-        {   // inverse stage 1: stride 1, no twiddles
-            constexpr int R = INV::kR[0], M = FO / R, ITER = (M + 63) / 64;
-            float2 t[ITER][R];
-#pragma unroll
-            for (int it = 0; it < ITER; ++it) {
-                const int i = lane + 64 * it;
-                if ((it + 1) * 64 <= M || i < M) {
-#pragma unroll
-                    for (int q = 0; q < R; ++q) t[it][q] = buf[i + q * M];
-                }
-            }
-            lds_order();
-#pragma unroll
-            for (int it = 0; it < ITER; ++it) {
-                const int i = lane + 64 * it;
-                if ((it + 1) * 64 <= M || i < M) {
-                    float2 o[R];
-                    dft<R>(t[it], o);
-#pragma unroll
-                    for (int q = 0; q < R; ++q) buf[R * i + q] = o[q];
-                }
-            }
-            lds_order();
-        }
-        wave_stage<FO, INV::kR[1], IS1>(buf, tw_i + IT1, lane);
+        // inverse stages 1 + 2 in one register pass, in place
+        wave_fused_first<FO, INV::kR[0], INV::kR[1]>(buf, tw_i + IT1, lane, [&](int j) -> float2 { return buf[j]; });
         wave_stage<FO, INV::kR[2], IS2>(buf, tw_i + IT2, lane);
         // ---- last inverse stage: outputs stay in registers.  Butterfly i (k = i) yields Z[i + q*ML]; the
         // output conjugation (radix_fft.rs:656-669) makes reals 2c, 2c + 1 of the channel out of Z[c]; the
