@@ -32,7 +32,7 @@
 #pragma clang fp contract(fast)
 #endif
 
-#include "fft_butterflies.h"
+#include "fft_butterflies_pk.h"
 #include "fft_kernels.h"
 
 namespace rsmp {
@@ -65,10 +65,10 @@ struct WavePlan<N_, R0, R1, R2, R3> {
 // 1..R-1 with w[(i mod STRIDE)*(R-1) + q-1] and writes buf[R*i - (R-1)*k + q*STRIDE]
 // (butterfly4/mod.rs:316-320 etc.).  Every read of the stage is issued before its first write.
 template <int N, int R, int STRIDE>
-__device__ __forceinline__ void wave_stage(float2* buf, const float2* __restrict__ tw, int lane) {
+__device__ __forceinline__ void wave_stage(cf* buf, const cf* __restrict__ tw, int lane) {
     constexpr int M = N / R;
     constexpr int ITER = (M + 63) / 64;
-    float2 t[ITER][R];
+    cf t[ITER][R];
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
         const int i = lane + 64 * it;
@@ -83,12 +83,12 @@ __device__ __forceinline__ void wave_stage(float2* buf, const float2* __restrict
         const int i = lane + 64 * it;
         if ((it + 1) * 64 <= M || i < M) {
             const int k = i % STRIDE;
-            const float2* w = tw + k * (R - 1);
+            const cf* w = tw + k * (R - 1);
 #pragma unroll
-            for (int q = 1; q < R; ++q) t[it][q] = cmul(w[q - 1], t[it][q]);
-            float2 o[R];
-            dft<R>(t[it], o);
-            float2* d = buf + R * i - (R - 1) * k;
+            for (int q = 1; q < R; ++q) t[it][q] = cf_mul(w[q - 1], t[it][q]);
+            cf o[R];
+            pdft<R>(t[it], o);
+            cf* d = buf + R * i - (R - 1) * k;
 #pragma unroll
             for (int q = 0; q < R; ++q) d[q * STRIDE] = o[q];
         }
@@ -105,10 +105,10 @@ __device__ __forceinline__ void wave_stage(float2* buf, const float2* __restrict
 // on the same values as the separate stages (the unit twiddles of column k = 0 are skipped).
 // `load(index)` yields point `index` of the stage-0 input (LDS, or samples straight from HBM).
 template <int N, int RA, int RB, class Load>
-__device__ __forceinline__ void wave_fused_first(float2* dst, const float2* __restrict__ tw1, int lane, Load load) {
+__device__ __forceinline__ void wave_fused_first(cf* dst, const cf* __restrict__ tw1, int lane, Load load) {
     constexpr int M2 = N / (RA * RB);
     constexpr int ITER = (M2 + 63) / 64;
-    float2 s[ITER][RB][RA];
+    cf s[ITER][RB][RA];
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
         const int j = lane + 64 * it;
@@ -126,19 +126,19 @@ __device__ __forceinline__ void wave_fused_first(float2* dst, const float2* __re
         if ((it + 1) * 64 <= M2 || j < M2) {
 #pragma unroll
             for (int qp = 0; qp < RB; ++qp) {
-                float2 o[RA];
-                dft<RA>(s[it][qp], o);
+                cf o[RA];
+                pdft<RA>(s[it][qp], o);
 #pragma unroll
                 for (int k = 0; k < RA; ++k) s[it][qp][k] = o[k];
             }
 #pragma unroll
             for (int k = 0; k < RA; ++k) {
-                float2 u[RB], o[RB];
+                cf u[RB], o[RB];
                 u[0] = s[it][0][k];
 #pragma unroll
                 for (int qp = 1; qp < RB; ++qp)
-                    u[qp] = k == 0 ? s[it][qp][k] : cmul(tw1[k * (RB - 1) + qp - 1], s[it][qp][k]);
-                dft<RB>(u, o);
+                    u[qp] = k == 0 ? s[it][qp][k] : cf_mul(tw1[k * (RB - 1) + qp - 1], s[it][qp][k]);
+                pdft<RB>(u, o);
 #pragma unroll
                 for (int qq = 0; qq < RB; ++qq) dst[RA * RB * j + k + RA * qq] = o[qq];
             }
@@ -149,26 +149,25 @@ __device__ __forceinline__ void wave_fused_first(float2* dst, const float2* __re
 
 // postprocess_fft (radix_fft.rs:500-537 + real_complex/mod.rs:37-74), in place on x[0 .. N2].
 template <int N2>
-__device__ __forceinline__ void wave_postprocess(float2* x, const float2* __restrict__ rc, int lane) {
+__device__ __forceinline__ void wave_postprocess(cf* x, const cf* __restrict__ rc, int lane) {
     constexpr int ITERS = (N2 + 1) / 2 - 1;
     constexpr int TRIPS = (ITERS + 63) / 64;
     if (lane == 0) {
-        const float2 z0 = x[0];
-        x[0] = make_float2(z0.x + z0.y, 0.0f);
-        x[N2] = make_float2(z0.x - z0.y, 0.0f);
+        const cf z0 = x[0];
+        x[0] = cf_make(z0.x + z0.y, 0.0f);
+        x[N2] = cf_make(z0.x - z0.y, 0.0f);
     }
 #pragma unroll
     for (int it = 0; it < TRIPS; ++it) {
         const int i = lane + 64 * it;
         if (i < ITERS) {
             const int l = 1 + i, rr = N2 - 1 - i;
-            const float2 o = x[l], orv = x[rr], tw = rc[i];
-            const float2 sum = cadd(o, orv), diff = csub(o, orv);
-            const float half_sum_real = 0.5f * sum.x, half_diff_imag = 0.5f * diff.y;
-            const float real = sum.y * tw.x + diff.x * tw.y;
-            const float imag = sum.y * tw.y - diff.x * tw.x;
-            x[l] = make_float2(half_sum_real + real, half_diff_imag + imag);
-            x[rr] = make_float2(half_sum_real - real, imag - half_diff_imag);
+            const cf o = x[l], orv = x[rr], tw = rc[i];
+            // o + conj(orv) = (sum.x, diff.y) and o - conj(orv) = (diff.x, sum.y) of real_complex/mod.rs:52-58
+            const cf half = 0.5f * cf_add_conj(o, orv);           // (half_sum_real, half_diff_imag)
+            const cf ri = cf_rc_rotate(cf_sub_conj(o, orv), tw);  // (real, imag)
+            x[l] = half + ri;
+            x[rr] = cf_conj_sub(half, ri);                        // (half_sum_real - real, imag - half_diff_imag)
         }
         if (it & 1) lds_order();   // two trips in flight at a time (bounds the registers the scheduler spends on hoisted loads)
     }
@@ -180,40 +179,43 @@ __device__ __forceinline__ void wave_postprocess(float2* x, const float2* __rest
 // preprocess_ifft (radix_fft.rs:592-624 + real_complex/mod.rs:84-114) and the input conjugation of
 // process_inverse_complex (:634-637), fused over the bin pairs (l, FO - l), in place.
 template <int FO>
-__device__ __forceinline__ void wave_filter_preprocess(float2* y, const float2* __restrict__ filter,
-                                                       uint32_t new_length, const float2* __restrict__ rc, int lane) {
+__device__ __forceinline__ void wave_filter_preprocess(cf* y, const cf* __restrict__ filter,
+                                                       uint32_t new_length, const cf* __restrict__ rc, int lane) {
     constexpr int ITERS = (FO + 1) / 2 - 1;
     constexpr int TRIPS = (ITERS + 63) / 64;
-    auto bin = [&](int k) -> float2 {
-        return static_cast<uint32_t>(k) < new_length ? cmul(y[k], filter[k]) : make_float2(0.f, 0.f);
+    auto bin = [&](int k) -> cf {
+        return static_cast<uint32_t>(k) < new_length ? cf_mul(y[k], filter[k]) : cf_make(0.f, 0.f);
     };
-    float2 first = make_float2(0.f, 0.f), mid = make_float2(0.f, 0.f);
+    cf first = cf_make(0.f, 0.f), mid = cf_make(0.f, 0.f);
     if (lane == 0) {
-        const float2 a = bin(0), b = bin(FO);
-        const float2 first_sum = cadd(a, b), first_diff = csub(a, b);
-        first = make_float2(first_sum.x - first_sum.y, first_diff.x - first_diff.y);
+        const cf a = bin(0), b = bin(FO);
+        const cf first_sum = a + b, first_diff = a - b;
+        first = cf_make(first_sum.x - first_sum.y, first_diff.x - first_diff.y);
     }
     if (((FO + 1) & 1) && lane == 32) {
-        const float2 c = bin((FO + 1) / 2);
-        const float2 dbl = cadd(c, c);
-        mid = make_float2(dbl.x, -dbl.y);
+        const cf c = bin((FO + 1) / 2);
+        const cf dbl = c + c;
+        mid = cf_make(dbl.x, -dbl.y);
     }
 #pragma unroll
     for (int it = 0; it < TRIPS; ++it) {
         const int i = lane + 64 * it;
         if (i < ITERS) {
             const int l = 1 + i, rr = FO - 1 - i;
-            const float2 a = bin(l), b = bin(rr), tw = rc[i];
-            const float2 sum = cadd(a, b), diff = csub(a, b);
-            const float real = sum.y * tw.x + diff.x * tw.y;
-            const float imag = sum.y * tw.y - diff.x * tw.x;
-            y[l] = make_float2(sum.x - real, -(diff.y - imag));
-            y[rr] = make_float2(sum.x + real, -(-imag - diff.y));
+            const cf a = bin(l), b = bin(rr), tw = rc[i];
+            const cf sd = cf_add_conj(a, b);                      // (sum.x, diff.y)
+            const cf ri = cf_rc_rotate(cf_sub_conj(a, b), tw);    // (real, imag)
+            y[l] = cf_conj_sub(sd, ri);                           // (sum.x - real, -(diff.y - imag))
+#ifdef RSMP_FFT_WAVE_EXACT
+            y[rr] = cf_conj(cf_conj_add_conj(sd, ri));            // (sum.x + real, -(-imag - diff.y)), zero signs included
+#else
+            y[rr] = sd + ri;
+#endif
         }
         if (it & 1) lds_order();
     }
-    if (lane == 0) y[0] = make_float2(first.x, -first.y);
-    if (((FO + 1) & 1) && lane == 32) y[(FO + 1) / 2] = make_float2(mid.x, -mid.y);
+    if (lane == 0) y[0] = cf_make(first.x, -first.y);
+    if (((FO + 1) & 1) && lane == 32) y[(FO + 1) / 2] = cf_make(mid.x, -mid.y);
     lds_order();
 }
 
@@ -224,7 +226,7 @@ __global__ __launch_bounds__((OCC == 3 ? 12 : 4) * 64, OCC) void fft_ola_wave_ke
                                                                               const FftStreamDesc* __restrict__ descs,
                                                                               uint32_t run, uint32_t runs_per_stream,
                                                                               uint32_t total_waves) {
-    extern __shared__ __attribute__((aligned(16))) float2 lds2[];
+    extern __shared__ __attribute__((aligned(16))) cf lds2[];
     constexpr int kWavesPerGroup = OCC == 3 ? 12 : 4;
     constexpr int FI = FWD::N, FO = INV::N;
     constexpr int LDSC = (FI > FO ? FI : FO) + 2;
@@ -241,25 +243,25 @@ __global__ __launch_bounds__((OCC == 3 ? 12 : 4) * 64, OCC) void fft_ola_wave_ke
     // the kernel follows; after it the waves never meet again.
     constexpr int kTabF = 0, kTabI = kTabF + FWD::kTw, kTabRcF = kTabI + INV::kTw, kTabRcI = kTabRcF + FWD::kRc,
                   kTabFilter = kTabRcI + INV::kRc, kTabEnd = kTabFilter + FI + 1;
-    float2* tab = lds2;
+    cf* tab = lds2;
     {
-        auto copy = [&](float2* dst, const float2* __restrict__ src, int n) {
+        auto copy = [&](cf* dst, const cf* __restrict__ src, int n) {
             for (int i = threadIdx.x; i < n; i += kWavesPerGroup * 64) dst[i] = src[i];
         };
-        copy(tab + kTabF, plan.tw_f, FWD::kTw);
-        copy(tab + kTabI, plan.tw_i, INV::kTw);
-        copy(tab + kTabRcF, plan.rc_f, FWD::kRc);
-        copy(tab + kTabRcI, plan.rc_i, INV::kRc);
-        copy(tab + kTabFilter, plan.filter, FI + 1);
+        copy(tab + kTabF, reinterpret_cast<const cf*>(plan.tw_f), FWD::kTw);
+        copy(tab + kTabI, reinterpret_cast<const cf*>(plan.tw_i), INV::kTw);
+        copy(tab + kTabRcF, reinterpret_cast<const cf*>(plan.rc_f), FWD::kRc);
+        copy(tab + kTabRcI, reinterpret_cast<const cf*>(plan.rc_i), INV::kRc);
+        copy(tab + kTabFilter, reinterpret_cast<const cf*>(plan.filter), FI + 1);
     }
     __syncthreads();
     if (gw >= total_waves) return;
-    float2* buf = lds2 + kTabEnd + wave * LDSC;
-    const float2* tw_f = tab + kTabF;
-    const float2* tw_i = tab + kTabI;
-    const float2* rc_f = tab + kTabRcF;
-    const float2* rc_i = tab + kTabRcI;
-    const float2* filter = tab + kTabFilter;
+    cf* buf = lds2 + kTabEnd + wave * LDSC;
+    const cf* tw_f = tab + kTabF;
+    const cf* tw_i = tab + kTabI;
+    const cf* rc_f = tab + kTabRcF;
+    const cf* rc_i = tab + kTabRcI;
+    const cf* filter = tab + kTabFilter;
 
     // wave -> (stream, run of blocks, channel); the channels of a run are neighbouring waves
     const uint32_t stream_idx = gw / (runs_per_stream * (C2 ? 2u : descs[0].channels));
@@ -272,17 +274,19 @@ __global__ __launch_bounds__((OCC == 3 ? 12 : 4) * 64, OCC) void fft_ola_wave_ke
     if (first >= d.n_blocks) return;
     const uint32_t last = first + run < d.n_blocks ? first + run : d.n_blocks;  // exclusive
 
-    // overlap carried into the run: the stream state, or the predecessor block recomputed (not emitted)
-    float2 carry[ITERL][HL];
+    // overlap carried into the run: the stream state, or the predecessor block recomputed (not emitted).
+    // Held as the unconjugated transform outputs (the conjugation of radix_fft.rs:656-669 is a modifier of
+    // the overlap-add below).
+    cf carry[ITERL][HL];
 #pragma unroll
     for (int it = 0; it < ITERL; ++it) {
         const int i = lane + 64 * it;
 #pragma unroll
         for (int q = 0; q < HL; ++q) {
-            carry[it][q] = make_float2(0.f, 0.f);
+            carry[it][q] = cf_make(0.f, 0.f);
             if (first == 0 && i < ML) {
                 const int c = i + q * ML;   // complex index = reals 2c, 2c + 1 of the channel's overlap row
-                carry[it][q] = make_float2(d.overlap[ch * FO + 2 * c], d.overlap[ch * FO + 2 * c + 1]);
+                carry[it][q] = cf_make(d.overlap[ch * FO + 2 * c], -d.overlap[ch * FO + 2 * c + 1]);
             }
         }
     }
@@ -296,14 +300,14 @@ __global__ __launch_bounds__((OCC == 3 ? 12 : 4) * 64, OCC) void fft_ola_wave_ke
         // channel = frames 2j, 2j + 1 (j < FI / 2), zero beyond (resampler_fft.rs:387-388)
         {
             const float* xin = d.in + static_cast<size_t>(b) * FI * C;
-            auto sample = [&](int j) -> float2 {
-                float2 v = make_float2(0.f, 0.f);
+            auto sample = [&](int j) -> cf {
+                cf v = cf_make(0.f, 0.f);
                 if (j < FI / 2) {
                     if constexpr (C2) {
                         const float4 f = reinterpret_cast<const float4*>(xin)[j];
-                        v = ch == 0 ? make_float2(f.x, f.z) : make_float2(f.y, f.w);
+                        v = ch == 0 ? cf_make(f.x, f.z) : cf_make(f.y, f.w);
                     } else {
-                        v = make_float2(xin[static_cast<size_t>(2 * j) * C + ch], xin[static_cast<size_t>(2 * j + 1) * C + ch]);
+                        v = cf_make(xin[static_cast<size_t>(2 * j) * C + ch], xin[static_cast<size_t>(2 * j + 1) * C + ch]);
                     }
                 }
                 return v;
@@ -318,7 +322,7 @@ __global__ __launch_bounds__((OCC == 3 ? 12 : 4) * 64, OCC) void fft_ola_wave_ke
         constexpr int IS1 = INV::kR[0], IS2 = IS1 * INV::kR[1];
         constexpr int IT1 = 0, IT2 = IT1 + IS1 * (INV::kR[1] - 1), IT3 = IT2 + IS2 * (INV::kR[2] - 1);
         // inverse stages 1 + 2 in one register pass, in place
-        wave_fused_first<FO, INV::kR[0], INV::kR[1]>(buf, tw_i + IT1, lane, [&](int j) -> float2 { return buf[j]; });
+        wave_fused_first<FO, INV::kR[0], INV::kR[1]>(buf, tw_i + IT1, lane, [&](int j) -> cf { return buf[j]; });
         wave_stage<FO, INV::kR[2], IS2>(buf, tw_i + IT2, lane);
         // ---- last inverse stage: outputs stay in registers.  Butterfly i (k = i) yields Z[i + q*ML]; the
         // output conjugation (radix_fft.rs:656-669) makes reals 2c, 2c + 1 of the channel out of Z[c]; the
@@ -328,21 +332,22 @@ __global__ __launch_bounds__((OCC == 3 ? 12 : 4) * 64, OCC) void fft_ola_wave_ke
         for (int it = 0; it < ITERL; ++it) {
             const int i = lane + 64 * it;
             if ((it + 1) * 64 <= ML || i < ML) {
-                float2 t[RL], o[RL];
+                cf t[RL], o[RL];
 #pragma unroll
                 for (int q = 0; q < RL; ++q) t[q] = buf[i + q * ML];
-                const float2* w = tw_i + IT3 + i * (RL - 1);
+                const cf* w = tw_i + IT3 + i * (RL - 1);
 #pragma unroll
-                for (int q = 1; q < RL; ++q) t[q] = cmul(w[q - 1], t[q]);
-                dft<RL>(t, o);
+                for (int q = 1; q < RL; ++q) t[q] = cf_mul(w[q - 1], t[q]);
+                pdft<RL>(t, o);
 #pragma unroll
                 for (int q = 0; q < HL; ++q) {
                     const int c = i + q * ML;
                     if (emit) {
-                        xout[static_cast<size_t>(2 * c) * C + ch] = o[q].x + carry[it][q].x;
-                        xout[static_cast<size_t>(2 * c + 1) * C + ch] = -o[q].y + carry[it][q].y;
+                        const cf v = cf_conj_add_conj(o[q], carry[it][q]);
+                        xout[static_cast<size_t>(2 * c) * C + ch] = v.x;
+                        xout[static_cast<size_t>(2 * c + 1) * C + ch] = v.y;
                     }
-                    carry[it][q] = make_float2(o[q + HL].x, -o[q + HL].y);
+                    carry[it][q] = o[q + HL];
                 }
             }
         }
@@ -357,7 +362,7 @@ __global__ __launch_bounds__((OCC == 3 ? 12 : 4) * 64, OCC) void fft_ola_wave_ke
                 for (int q = 0; q < HL; ++q) {
                     const int c = i + q * ML;
                     d.overlap_next[ch * FO + 2 * c] = carry[it][q].x;
-                    d.overlap_next[ch * FO + 2 * c + 1] = carry[it][q].y;
+                    d.overlap_next[ch * FO + 2 * c + 1] = -carry[it][q].y;
                 }
             }
         }
@@ -395,7 +400,7 @@ hipError_t launch_fft_ola_wave(const FftPlanDev& plan, const FftStreamDesc* d_de
     // tables (stage twiddles 1173 + 1276, real <-> complex 587 + 639, filter spectrum fft_in + 1) + one buffer per wave
     const uint32_t kWavesPerGroup = occ == 3 ? 12u : 4u;
     const size_t lds = (static_cast<size_t>(1173 + 1276 + 587 + 639) + plan.fft_in + 1 +
-                        static_cast<size_t>(kWavesPerGroup) * (1280 + 2)) * sizeof(float2);
+                        static_cast<size_t>(kWavesPerGroup) * (1280 + 2)) * sizeof(cf);
     // Blocks per wave: every run after a stream's first recomputes its predecessor block (1 / run extra
     // work), and the launch ends with a partly filled round unless the number of waves is close to a
     // multiple of what the chip holds at once (3 workgroups of 4 waves per CU).
