@@ -52,8 +52,13 @@ struct WavePlan<N_, R0, R1, R2, R3> {
     static constexpr int N = N_;
     static constexpr int kR[4] = {R0, R1, R2, R3};
     static_assert(R0 * R1 * R2 * R3 == N_, "radices");
-    // stage twiddles, unique per column: stage s (s >= 1) holds stride_s * (R_s - 1) of them
-    static constexpr int kTw = R0 * (R1 - 1) + R0 * R1 * (R2 - 1) + R0 * R1 * R2 * (R3 - 1);
+    // stage twiddles, unique per column: stage s (s >= 1) holds stride_s rows of R_s - 1.  In LDS the rows
+    // of stages 2 and 3 are (R - 1) | 1 values apart: lane k reads row k, and an even row length puts lanes
+    // 16 apart (radix 7: six values = 12 dwords) on the same banks.
+    static constexpr int row(int r) { return (r - 1) | 1; }
+    static constexpr int kT1 = 0, kT2 = kT1 + R0 * (R1 - 1), kT3 = kT2 + R0 * R1 * row(R2);
+    static constexpr int kTw = kT3 + R0 * R1 * R2 * row(R3);
+    static constexpr int kSrc2 = R0 * (R1 - 1), kSrc3 = kSrc2 + R0 * R1 * (R2 - 1);   // offsets in the plan's array
     static constexpr int kRc = N_ / 2 - 1;   // real <-> complex twiddles
     static bool matches(uint32_t n, uint32_t n_stages, const uint32_t* radix) {
         return n == static_cast<uint32_t>(N_) && n_stages == 4 && radix[0] == R0 && radix[1] == R1 &&
@@ -64,17 +69,24 @@ struct WavePlan<N_, R0, R1, R2, R3> {
 // One Stockham stage in place in the wave's LDS buffer: butterfly i reads buf[i + q*M], twiddles inputs
 // 1..R-1 with w[(i mod STRIDE)*(R-1) + q-1] and writes buf[R*i - (R-1)*k + q*STRIDE]
 // (butterfly4/mod.rs:316-320 etc.).  Every read of the stage is issued before its first write.
-template <int N, int R, int STRIDE>
+// QS: distance of a butterfly's inputs in the buffer (N / R, or more when the producer padded its rows).
+// OPAD: values of padding after every R * STRIDE outputs (one block of the next stage's columns).  With 21
+// columns a half wave of 32 lanes spans two blocks, and 147 values = 294 dwords put the second block's first
+// columns on the first block's last banks; two values more (298 = 42 mod 64) and every half wave of the
+// stage stores conflict-free.  The next stage then reads its inputs N / R' + OPAD apart (stage_out_pad).
+constexpr int stage_out_pad(int r, int stride) { return r == 7 && stride == 21 ? 2 : 0; }
+template <int N, int R, int STRIDE, int QS = N / R, int OPAD = stage_out_pad(R, STRIDE)>
 __device__ __forceinline__ void wave_stage(cf* buf, const cf* __restrict__ tw, int lane) {
     constexpr int M = N / R;
     constexpr int ITER = (M + 63) / 64;
+    constexpr int ROW = (R - 1) | 1;
     cf t[ITER][R];
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
         const int i = lane + 64 * it;
         if ((it + 1) * 64 <= M || i < M) {
 #pragma unroll
-            for (int q = 0; q < R; ++q) t[it][q] = buf[i + q * M];
+            for (int q = 0; q < R; ++q) t[it][q] = buf[i + q * QS];
         }
     }
     lds_order();
@@ -83,12 +95,12 @@ __device__ __forceinline__ void wave_stage(cf* buf, const cf* __restrict__ tw, i
         const int i = lane + 64 * it;
         if ((it + 1) * 64 <= M || i < M) {
             const int k = i % STRIDE;
-            const cf* w = tw + k * (R - 1);
+            const cf* w = tw + k * ROW;
 #pragma unroll
             for (int q = 1; q < R; ++q) t[it][q] = cf_mul(w[q - 1], t[it][q]);
             cf o[R];
             pdft<R>(t[it], o);
-            cf* d = buf + R * i - (R - 1) * k;
+            cf* d = buf + R * i - (R - 1) * k + (OPAD ? OPAD * (i / STRIDE) : 0);
 #pragma unroll
             for (int q = 0; q < R; ++q) d[q * STRIDE] = o[q];
         }
@@ -104,9 +116,19 @@ __device__ __forceinline__ void wave_stage(cf* buf, const cf* __restrict__ tw, i
 // would have left in LDS, with one LDS round trip and the stage-1 index arithmetic gone.  Same operations
 // on the same values as the separate stages (the unit twiddles of column k = 0 are skipped).
 // `load(index)` yields point `index` of the stage-0 input (LDS, or samples straight from HBM).
+// A unit's outputs are RA*RB values apart from the next lane's; when that is even (20 values = 40 dwords)
+// the 64 lanes of a store meet on 8 bank pairs, so one value of padding follows every fused_pad<>() values
+// (160: lanes 8 apart move on by a bank pair) and the next stage reads its inputs fused_qs<>() apart.
+template <int RA, int RB> constexpr int fused_pad() { return (RA * RB) % 2 == 0 ? 8 * RA * RB : 0; }
+template <int N, int R, int RA, int RB> constexpr int fused_qs() {
+    // inputs i + q * (N / R) of the next stage: the padding adds (i + q N/R) / pad, exact when N / R == pad
+    static_assert(fused_pad<RA, RB>() == 0 || N / R == fused_pad<RA, RB>(), "padding period = input distance");
+    return fused_pad<RA, RB>() ? N / R + 1 : N / R;
+}
 template <int N, int RA, int RB, class Load>
 __device__ __forceinline__ void wave_fused_first(cf* dst, const cf* __restrict__ tw1, int lane, Load load) {
     constexpr int M2 = N / (RA * RB);
+    constexpr int PADJ = fused_pad<RA, RB>() / (RA * RB);   // units per padding value
     constexpr int ITER = (M2 + 63) / 64;
     cf s[ITER][RB][RA];
 #pragma unroll
@@ -140,7 +162,7 @@ __device__ __forceinline__ void wave_fused_first(cf* dst, const cf* __restrict__
                     u[qp] = k == 0 ? s[it][qp][k] : cf_mul(tw1[k * (RB - 1) + qp - 1], s[it][qp][k]);
                 pdft<RB>(u, o);
 #pragma unroll
-                for (int qq = 0; qq < RB; ++qq) dst[RA * RB * j + k + RA * qq] = o[qq];
+                for (int qq = 0; qq < RB; ++qq) dst[RA * RB * j + (PADJ ? j / PADJ : 0) + k + RA * qq] = o[qq];
             }
         }
     }
@@ -229,7 +251,8 @@ __global__ __launch_bounds__((OCC == 3 ? 12 : 4) * 64, OCC) void fft_ola_wave_ke
     extern __shared__ __attribute__((aligned(16))) cf lds2[];
     constexpr int kWavesPerGroup = OCC == 3 ? 12 : 4;
     constexpr int FI = FWD::N, FO = INV::N;
-    constexpr int LDSC = (FI > FO ? FI : FO) + 2;
+    constexpr int LDSC = (FI > FO ? FI : FO) + 2 + 8;   // + the padding of a fused first pass (1280 + 8) or of a stage (1176 + 16)
+    static_assert(1176 + 16 <= LDSC, "stage padding");
     constexpr int R1 = FWD::kR[0];
     constexpr int RL = INV::kR[3], ML = FO / RL, ITERL = (ML + 63) / 64, HL = RL / 2;
     static_assert(RL % 2 == 0, "the last inverse stage splits its outputs into output half and carry half");
@@ -248,8 +271,19 @@ __global__ __launch_bounds__((OCC == 3 ? 12 : 4) * 64, OCC) void fft_ola_wave_ke
         auto copy = [&](cf* dst, const cf* __restrict__ src, int n) {
             for (int i = threadIdx.x; i < n; i += kWavesPerGroup * 64) dst[i] = src[i];
         };
-        copy(tab + kTabF, reinterpret_cast<const cf*>(plan.tw_f), FWD::kTw);
-        copy(tab + kTabI, reinterpret_cast<const cf*>(plan.tw_i), INV::kTw);
+        // stage twiddles: rows of stages 2 and 3 re-spaced (WavePlan::row)
+        auto rows = [&](cf* dst, const cf* __restrict__ src, int n_rows, int r) {
+            const int len = r - 1, pitch = (r - 1) | 1;
+            for (int i = threadIdx.x; i < n_rows * len; i += kWavesPerGroup * 64) dst[(i / len) * pitch + i % len] = src[i];
+        };
+        auto stage_tables = [&](cf* dst, const cf* __restrict__ src, auto P) {
+            typedef decltype(P) PL;
+            copy(dst + PL::kT1, src, PL::kSrc2);
+            rows(dst + PL::kT2, src + PL::kSrc2, PL::kR[0] * PL::kR[1], PL::kR[2]);
+            rows(dst + PL::kT3, src + PL::kSrc3, PL::kR[0] * PL::kR[1] * PL::kR[2], PL::kR[3]);
+        };
+        stage_tables(tab + kTabF, reinterpret_cast<const cf*>(plan.tw_f), FWD{});
+        stage_tables(tab + kTabI, reinterpret_cast<const cf*>(plan.tw_i), INV{});
         copy(tab + kTabRcF, reinterpret_cast<const cf*>(plan.rc_f), FWD::kRc);
         copy(tab + kTabRcI, reinterpret_cast<const cf*>(plan.rc_i), INV::kRc);
         copy(tab + kTabFilter, reinterpret_cast<const cf*>(plan.filter), FI + 1);
@@ -295,7 +329,7 @@ __global__ __launch_bounds__((OCC == 3 ? 12 : 4) * 64, OCC) void fft_ola_wave_ke
     for (int64_t b = b_begin; b < static_cast<int64_t>(last); ++b) {
         const bool emit = b >= static_cast<int64_t>(first);
         constexpr int S1 = R1, S2 = S1 * FWD::kR[1], S3 = S2 * FWD::kR[2];
-        constexpr int T1 = 0, T2 = T1 + S1 * (FWD::kR[1] - 1), T3 = T2 + S2 * (FWD::kR[2] - 1);
+        constexpr int T1 = FWD::kT1, T2 = FWD::kT2, T3 = FWD::kT3;
         // ---- forward stages 1 + 2 in one register pass, inputs straight from HBM: complex j of the block's
         // channel = frames 2j, 2j + 1 (j < FI / 2), zero beyond (resampler_fft.rs:387-388)
         {
@@ -314,16 +348,17 @@ __global__ __launch_bounds__((OCC == 3 ? 12 : 4) * 64, OCC) void fft_ola_wave_ke
             };
             wave_fused_first<FI, FWD::kR[0], FWD::kR[1]>(buf, tw_f + T1, lane, sample);
         }
-        wave_stage<FI, FWD::kR[2], S2>(buf, tw_f + T2, lane);
-        wave_stage<FI, FWD::kR[3], S3>(buf, tw_f + T3, lane);
+        wave_stage<FI, FWD::kR[2], S2, fused_qs<FI, FWD::kR[2], FWD::kR[0], FWD::kR[1]>()>(buf, tw_f + T2, lane);
+        static_assert(stage_out_pad(FWD::kR[2], S2) == 0 || FI / FWD::kR[3] == S3, "padding period = input distance");
+        wave_stage<FI, FWD::kR[3], S3, FI / FWD::kR[3] + stage_out_pad(FWD::kR[2], S2)>(buf, tw_f + T3, lane);
         wave_postprocess<FI>(buf, rc_f, lane);
         wave_filter_preprocess<FO>(buf, filter, plan.new_length, rc_i, lane);
 
         constexpr int IS1 = INV::kR[0], IS2 = IS1 * INV::kR[1];
-        constexpr int IT1 = 0, IT2 = IT1 + IS1 * (INV::kR[1] - 1), IT3 = IT2 + IS2 * (INV::kR[2] - 1);
+        constexpr int IT1 = INV::kT1, IT2 = INV::kT2, IT3 = INV::kT3;
         // inverse stages 1 + 2 in one register pass, in place
         wave_fused_first<FO, INV::kR[0], INV::kR[1]>(buf, tw_i + IT1, lane, [&](int j) -> cf { return buf[j]; });
-        wave_stage<FO, INV::kR[2], IS2>(buf, tw_i + IT2, lane);
+        wave_stage<FO, INV::kR[2], IS2, fused_qs<FO, INV::kR[2], INV::kR[0], INV::kR[1]>()>(buf, tw_i + IT2, lane);
         // ---- last inverse stage: outputs stay in registers.  Butterfly i (k = i) yields Z[i + q*ML]; the
         // output conjugation (radix_fft.rs:656-669) makes reals 2c, 2c + 1 of the channel out of Z[c]; the
         // first FO reals are overlap-added and stored, the second FO become the next overlap (:416-423).
@@ -334,8 +369,8 @@ __global__ __launch_bounds__((OCC == 3 ? 12 : 4) * 64, OCC) void fft_ola_wave_ke
             if ((it + 1) * 64 <= ML || i < ML) {
                 cf t[RL], o[RL];
 #pragma unroll
-                for (int q = 0; q < RL; ++q) t[q] = buf[i + q * ML];
-                const cf* w = tw_i + IT3 + i * (RL - 1);
+                for (int q = 0; q < RL; ++q) t[q] = buf[i + q * (ML + stage_out_pad(INV::kR[2], IS2))];
+                const cf* w = tw_i + IT3 + i * INV::row(RL);
 #pragma unroll
                 for (int q = 1; q < RL; ++q) t[q] = cf_mul(w[q - 1], t[q]);
                 pdft<RL>(t, o);
@@ -397,10 +432,10 @@ hipError_t launch_fft_ola_wave(const FftPlanDev& plan, const FftStreamDesc* d_de
         if (up) fn = C == 2 ? fft_ola_wave_kernel<W1176, W1280, true, 2> : fft_ola_wave_kernel<W1176, W1280, false, 2>;
         else fn = C == 2 ? fft_ola_wave_kernel<W1280, W1176, true, 2> : fft_ola_wave_kernel<W1280, W1176, false, 2>;
     }
-    // tables (stage twiddles 1173 + 1276, real <-> complex 587 + 639, filter spectrum fft_in + 1) + one buffer per wave
+    // tables (stage twiddles, real <-> complex twiddles, filter spectrum fft_in + 1) + one buffer per wave
     const uint32_t kWavesPerGroup = occ == 3 ? 12u : 4u;
-    const size_t lds = (static_cast<size_t>(1173 + 1276 + 587 + 639) + plan.fft_in + 1 +
-                        static_cast<size_t>(kWavesPerGroup) * (1280 + 2)) * sizeof(cf);
+    const size_t lds = (static_cast<size_t>(W1176::kTw + W1280::kTw + W1176::kRc + W1280::kRc) + plan.fft_in + 1 +
+                        static_cast<size_t>(kWavesPerGroup) * (1280 + 2 + 8)) * sizeof(cf);
     // Blocks per wave: every run after a stream's first recomputes its predecessor block (1 / run extra
     // work), and the launch ends with a partly filled round unless the number of waves is close to a
     // multiple of what the chip holds at once (3 workgroups of 4 waves per CU).
