@@ -46,6 +46,25 @@ namespace {
 // in the radix-4 stage).  This pins the program order of memory operations; it emits no instruction.
 __device__ __forceinline__ void lds_order() { asm volatile("" ::: "memory"); }
 
+// Stream pointers come out of a descriptor in memory, so the compiler knows no address space for them and
+// emits FLAT loads and stores -- which count on the LDS counter too, and so tie every wait for an LDS read to
+// the block's output stores.  Naming the global address space gives global_load / global_store.
+typedef __attribute__((address_space(1))) float GFloat;
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) f4 GFloat4;
+__device__ __forceinline__ const GFloat* as_global(const float* p) { return (const GFloat*)p; }
+__device__ __forceinline__ GFloat* as_global(float* p) { return (GFloat*)p; }
+
+// One LDS value by ds_read_b64, which the LDS serves at 256 B/clk.  Left to itself the compiler pairs
+// neighbouring loads into ds_read2_b64 / ds_read2st64_b64, which run at HALF that rate (8 LDS cycles for the
+// 16 bytes per lane against 2 + 2, MI355X_MICROARCH.md LDS table) in a kernel whose bound is the LDS; a
+// volatile access is never merged (and must name the LDS address space: address-space inference skips
+// volatile accesses, which would otherwise become flat loads).
+__device__ __forceinline__ cf lds_ld(const cf* p) {
+    typedef const volatile __attribute__((address_space(3))) cf* LdsPtr;
+    return *(LdsPtr)(p);
+}
+
 template <int N_, int... Rs> struct WavePlan;
 template <int N_, int R0, int R1, int R2, int R3>
 struct WavePlan<N_, R0, R1, R2, R3> {
@@ -69,6 +88,27 @@ struct WavePlan<N_, R0, R1, R2, R3> {
 // One Stockham stage in place in the wave's LDS buffer: butterfly i reads buf[i + q*M], twiddles inputs
 // 1..R-1 with w[(i mod STRIDE)*(R-1) + q-1] and writes buf[R*i - (R-1)*k + q*STRIDE]
 // (butterfly4/mod.rs:316-320 etc.).  Every read of the stage is issued before its first write.
+// The R - 1 twiddles of a butterfly are the powers w, w^2 .. w^(R-1) of one value.  The kernel is bound by
+// LDS traffic, of which the twiddle rows were a quarter: radix 7 and 8 fetch w, w^2 and w^4 and multiply
+// the others out (one or two roundings more on those twiddles; -DRSMP_FFT_WAVE_EXACT fetches all of them).
+template <int R>
+__device__ __forceinline__ void twiddle_row(const cf* __restrict__ w, cf (&tw)[R]) {
+#if !defined(RSMP_FFT_WAVE_EXACT) && !defined(RSMP_FFT_WAVE_ALL_TWIDDLES)
+    if constexpr (R == 7 || R == 8) {
+        tw[1] = lds_ld(w);
+        tw[2] = lds_ld(w + 1);
+        tw[4] = lds_ld(w + 3);
+        tw[3] = cf_mul(tw[1], tw[2]);
+        tw[5] = cf_mul(tw[1], tw[4]);
+        tw[6] = cf_mul(tw[2], tw[4]);
+        if constexpr (R == 8) tw[7] = cf_mul(tw[3], tw[4]);
+        return;
+    }
+#endif
+#pragma unroll
+    for (int q = 1; q < R; ++q) tw[q] = lds_ld(w + q - 1);
+}
+
 // QS: distance of a butterfly's inputs in the buffer (N / R, or more when the producer padded its rows).
 // OPAD: values of padding after every R * STRIDE outputs (one block of the next stage's columns).  With 21
 // columns a half wave of 32 lanes spans two blocks, and 147 values = 294 dwords put the second block's first
@@ -86,7 +126,7 @@ __device__ __forceinline__ void wave_stage(cf* buf, const cf* __restrict__ tw, i
         const int i = lane + 64 * it;
         if ((it + 1) * 64 <= M || i < M) {
 #pragma unroll
-            for (int q = 0; q < R; ++q) t[it][q] = buf[i + q * QS];
+            for (int q = 0; q < R; ++q) t[it][q] = lds_ld(buf + i + q * QS);
         }
     }
     lds_order();
@@ -96,8 +136,10 @@ __device__ __forceinline__ void wave_stage(cf* buf, const cf* __restrict__ tw, i
         if ((it + 1) * 64 <= M || i < M) {
             const int k = i % STRIDE;
             const cf* w = tw + k * ROW;
+            cf twr[R];
+            twiddle_row<R>(w, twr);
 #pragma unroll
-            for (int q = 1; q < R; ++q) t[it][q] = cf_mul(w[q - 1], t[it][q]);
+            for (int q = 1; q < R; ++q) t[it][q] = cf_mul(twr[q], t[it][q]);
             cf o[R];
             pdft<R>(t[it], o);
             cf* d = buf + R * i - (R - 1) * k + (OPAD ? OPAD * (i / STRIDE) : 0);
@@ -159,7 +201,7 @@ __device__ __forceinline__ void wave_fused_first(cf* dst, const cf* __restrict__
                 u[0] = s[it][0][k];
 #pragma unroll
                 for (int qp = 1; qp < RB; ++qp)
-                    u[qp] = k == 0 ? s[it][qp][k] : cf_mul(tw1[k * (RB - 1) + qp - 1], s[it][qp][k]);
+                    u[qp] = k == 0 ? s[it][qp][k] : cf_mul(lds_ld(tw1 + k * (RB - 1) + qp - 1), s[it][qp][k]);
                 pdft<RB>(u, o);
 #pragma unroll
                 for (int qq = 0; qq < RB; ++qq) dst[RA * RB * j + (PADJ ? j / PADJ : 0) + k + RA * qq] = o[qq];
@@ -184,7 +226,7 @@ __device__ __forceinline__ void wave_postprocess(cf* x, const cf* __restrict__ r
         const int i = lane + 64 * it;
         if (i < ITERS) {
             const int l = 1 + i, rr = N2 - 1 - i;
-            const cf o = x[l], orv = x[rr], tw = rc[i];
+            const cf o = lds_ld(x + l), orv = lds_ld(x + rr), tw = lds_ld(rc + i);
             // o + conj(orv) = (sum.x, diff.y) and o - conj(orv) = (diff.x, sum.y) of real_complex/mod.rs:52-58
             const cf half = 0.5f * cf_add_conj(o, orv);           // (half_sum_real, half_diff_imag)
             const cf ri = cf_rc_rotate(cf_sub_conj(o, orv), tw);  // (real, imag)
@@ -206,7 +248,7 @@ __device__ __forceinline__ void wave_filter_preprocess(cf* y, const cf* __restri
     constexpr int ITERS = (FO + 1) / 2 - 1;
     constexpr int TRIPS = (ITERS + 63) / 64;
     auto bin = [&](int k) -> cf {
-        return static_cast<uint32_t>(k) < new_length ? cf_mul(y[k], filter[k]) : cf_make(0.f, 0.f);
+        return static_cast<uint32_t>(k) < new_length ? cf_mul(lds_ld(y + k), lds_ld(filter + k)) : cf_make(0.f, 0.f);
     };
     cf first = cf_make(0.f, 0.f), mid = cf_make(0.f, 0.f);
     if (lane == 0) {
@@ -224,7 +266,7 @@ __device__ __forceinline__ void wave_filter_preprocess(cf* y, const cf* __restri
         const int i = lane + 64 * it;
         if (i < ITERS) {
             const int l = 1 + i, rr = FO - 1 - i;
-            const cf a = bin(l), b = bin(rr), tw = rc[i];
+            const cf a = bin(l), b = bin(rr), tw = lds_ld(rc + i);
             const cf sd = cf_add_conj(a, b);                      // (sum.x, diff.y)
             const cf ri = cf_rc_rotate(cf_sub_conj(a, b), tw);    // (real, imag)
             y[l] = cf_conj_sub(sd, ri);                           // (sum.x - real, -(diff.y - imag))
@@ -320,7 +362,8 @@ __global__ __launch_bounds__((OCC == 3 ? 12 : 4) * 64, OCC) void fft_ola_wave_ke
             carry[it][q] = cf_make(0.f, 0.f);
             if (first == 0 && i < ML) {
                 const int c = i + q * ML;   // complex index = reals 2c, 2c + 1 of the channel's overlap row
-                carry[it][q] = cf_make(d.overlap[ch * FO + 2 * c], -d.overlap[ch * FO + 2 * c + 1]);
+                const GFloat* ov = as_global(d.overlap);
+                carry[it][q] = cf_make(ov[ch * FO + 2 * c], -ov[ch * FO + 2 * c + 1]);
             }
         }
     }
@@ -333,12 +376,12 @@ __global__ __launch_bounds__((OCC == 3 ? 12 : 4) * 64, OCC) void fft_ola_wave_ke
         // ---- forward stages 1 + 2 in one register pass, inputs straight from HBM: complex j of the block's
         // channel = frames 2j, 2j + 1 (j < FI / 2), zero beyond (resampler_fft.rs:387-388)
         {
-            const float* xin = d.in + static_cast<size_t>(b) * FI * C;
+            const GFloat* xin = as_global(d.in) + static_cast<size_t>(b) * FI * C;
             auto sample = [&](int j) -> cf {
                 cf v = cf_make(0.f, 0.f);
                 if (j < FI / 2) {
                     if constexpr (C2) {
-                        const float4 f = reinterpret_cast<const float4*>(xin)[j];
+                        const f4 f = ((const GFloat4*)xin)[j];
                         v = ch == 0 ? cf_make(f.x, f.z) : cf_make(f.y, f.w);
                     } else {
                         v = cf_make(xin[static_cast<size_t>(2 * j) * C + ch], xin[static_cast<size_t>(2 * j + 1) * C + ch]);
@@ -357,22 +400,24 @@ __global__ __launch_bounds__((OCC == 3 ? 12 : 4) * 64, OCC) void fft_ola_wave_ke
         constexpr int IS1 = INV::kR[0], IS2 = IS1 * INV::kR[1];
         constexpr int IT1 = INV::kT1, IT2 = INV::kT2, IT3 = INV::kT3;
         // inverse stages 1 + 2 in one register pass, in place
-        wave_fused_first<FO, INV::kR[0], INV::kR[1]>(buf, tw_i + IT1, lane, [&](int j) -> cf { return buf[j]; });
+        wave_fused_first<FO, INV::kR[0], INV::kR[1]>(buf, tw_i + IT1, lane, [&](int j) -> cf { return lds_ld(buf + j); });
         wave_stage<FO, INV::kR[2], IS2, fused_qs<FO, INV::kR[2], INV::kR[0], INV::kR[1]>()>(buf, tw_i + IT2, lane);
         // ---- last inverse stage: outputs stay in registers.  Butterfly i (k = i) yields Z[i + q*ML]; the
         // output conjugation (radix_fft.rs:656-669) makes reals 2c, 2c + 1 of the channel out of Z[c]; the
         // first FO reals are overlap-added and stored, the second FO become the next overlap (:416-423).
-        float* xout = d.out + static_cast<size_t>(b) * FO * C;
+        GFloat* xout = as_global(d.out) + static_cast<size_t>(b) * FO * C;
 #pragma unroll
         for (int it = 0; it < ITERL; ++it) {
             const int i = lane + 64 * it;
             if ((it + 1) * 64 <= ML || i < ML) {
                 cf t[RL], o[RL];
 #pragma unroll
-                for (int q = 0; q < RL; ++q) t[q] = buf[i + q * (ML + stage_out_pad(INV::kR[2], IS2))];
+                for (int q = 0; q < RL; ++q) t[q] = lds_ld(buf + i + q * (ML + stage_out_pad(INV::kR[2], IS2)));
                 const cf* w = tw_i + IT3 + i * INV::row(RL);
+                cf twr[RL];
+                twiddle_row<RL>(w, twr);
 #pragma unroll
-                for (int q = 1; q < RL; ++q) t[q] = cf_mul(w[q - 1], t[q]);
+                for (int q = 1; q < RL; ++q) t[q] = cf_mul(twr[q], t[q]);
                 pdft<RL>(t, o);
 #pragma unroll
                 for (int q = 0; q < HL; ++q) {
@@ -396,8 +441,9 @@ __global__ __launch_bounds__((OCC == 3 ? 12 : 4) * 64, OCC) void fft_ola_wave_ke
 #pragma unroll
                 for (int q = 0; q < HL; ++q) {
                     const int c = i + q * ML;
-                    d.overlap_next[ch * FO + 2 * c] = carry[it][q].x;
-                    d.overlap_next[ch * FO + 2 * c + 1] = -carry[it][q].y;
+                    GFloat* ov = as_global(d.overlap_next);
+                    ov[ch * FO + 2 * c] = carry[it][q].x;
+                    ov[ch * FO + 2 * c + 1] = -carry[it][q].y;
                 }
             }
         }
