@@ -61,7 +61,13 @@ __device__ __forceinline__ cf cf_mul(cf a, cf b) {
 #ifdef RSMP_FFT_WAVE_EXACT
     return cf_mul_xx(a, b) + cf_mul_yy_rot(a, b);
 #else
-    return cf_fma_yy_rot(a, b, cf_mul_xx(a, b));
+    // one statement: before an asm statement that reads a register the previous instruction wrote, the
+    // compiler (which cannot see what kind of instruction it is) spends an s_nop
+    cf d;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
+        : "=&v"(d) : "v"(a), "v"(b));
+    return d;
 #endif
 }
 // (s.y t.x + d.x t.y, s.y t.y - d.x t.x) for m = (d.x, s.y): the rotation of the real <-> complex passes
@@ -70,7 +76,11 @@ __device__ __forceinline__ cf cf_rc_rotate(cf m, cf t) {
 #ifdef RSMP_FFT_WAVE_EXACT
     return cf_mul_yy(m, t) + cf_mul_xx_nrot(m, t);
 #else
-    return cf_fma_xx_nrot(m, t, cf_mul_yy(m, t));
+    cf d;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]\n\t"
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[0,0,1] neg_hi:[0,1,0]"
+        : "=&v"(d) : "v"(m), "v"(t));
+    return d;
 #endif
 }
 

@@ -91,22 +91,38 @@ struct WavePlan<N_, R0, R1, R2, R3> {
 // The R - 1 twiddles of a butterfly are the powers w, w^2 .. w^(R-1) of one value.  The kernel is bound by
 // LDS traffic, of which the twiddle rows were a quarter: radix 7 and 8 fetch w, w^2 and w^4 and multiply
 // the others out (one or two roundings more on those twiddles; -DRSMP_FFT_WAVE_EXACT fetches all of them).
-template <int R>
-__device__ __forceinline__ void twiddle_row(const cf* __restrict__ w, cf (&tw)[R]) {
+// A row is FETCHED (twiddle_fetch: kFetch<R> LDS reads, issued with the stage's data reads) and EXPANDED
+// when its butterfly runs.
 #if !defined(RSMP_FFT_WAVE_EXACT) && !defined(RSMP_FFT_WAVE_ALL_TWIDDLES)
-    if constexpr (R == 7 || R == 8) {
-        tw[1] = lds_ld(w);
-        tw[2] = lds_ld(w + 1);
-        tw[4] = lds_ld(w + 3);
+template <int R> constexpr int kFetch = (R == 7 || R == 8) ? 3 : R - 1;
+#else
+template <int R> constexpr int kFetch = R - 1;
+#endif
+template <int R>
+__device__ __forceinline__ void twiddle_fetch(const cf* __restrict__ w, cf (&raw)[kFetch<R>]) {
+    if constexpr (kFetch<R> != R - 1) {
+        raw[0] = lds_ld(w);
+        raw[1] = lds_ld(w + 1);
+        raw[2] = lds_ld(w + 3);
+    } else {
+#pragma unroll
+        for (int q = 0; q < R - 1; ++q) raw[q] = lds_ld(w + q);
+    }
+}
+template <int R>
+__device__ __forceinline__ void twiddle_expand(const cf (&raw)[kFetch<R>], cf (&tw)[R]) {
+    if constexpr (kFetch<R> != R - 1) {
+        tw[1] = raw[0];
+        tw[2] = raw[1];
+        tw[4] = raw[2];
         tw[3] = cf_mul(tw[1], tw[2]);
         tw[5] = cf_mul(tw[1], tw[4]);
         tw[6] = cf_mul(tw[2], tw[4]);
         if constexpr (R == 8) tw[7] = cf_mul(tw[3], tw[4]);
-        return;
-    }
-#endif
+    } else {
 #pragma unroll
-    for (int q = 1; q < R; ++q) tw[q] = lds_ld(w + q - 1);
+        for (int q = 1; q < R; ++q) tw[q] = raw[q - 1];
+    }
 }
 
 // QS: distance of a butterfly's inputs in the buffer (N / R, or more when the producer padded its rows).
@@ -120,13 +136,17 @@ __device__ __forceinline__ void wave_stage(cf* buf, const cf* __restrict__ tw, i
     constexpr int M = N / R;
     constexpr int ITER = (M + 63) / 64;
     constexpr int ROW = (R - 1) | 1;
-    cf t[ITER][R];
+    // Every LDS read of the stage -- data and twiddle rows, in the order of their use -- is issued before the
+    // first butterfly: the wave then waits for a read once per stage, not once per butterfly (LDS operations
+    // of a wave complete in order, so butterfly 0 runs while the later reads are still in flight).
+    cf t[ITER][R], raw[ITER][kFetch<R>];
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
         const int i = lane + 64 * it;
         if ((it + 1) * 64 <= M || i < M) {
 #pragma unroll
             for (int q = 0; q < R; ++q) t[it][q] = lds_ld(buf + i + q * QS);
+            twiddle_fetch<R>(tw + (i % STRIDE) * ROW, raw[it]);
         }
     }
     lds_order();
@@ -135,9 +155,8 @@ __device__ __forceinline__ void wave_stage(cf* buf, const cf* __restrict__ tw, i
         const int i = lane + 64 * it;
         if ((it + 1) * 64 <= M || i < M) {
             const int k = i % STRIDE;
-            const cf* w = tw + k * ROW;
             cf twr[R];
-            twiddle_row<R>(w, twr);
+            twiddle_expand<R>(raw[it], twr);
 #pragma unroll
             for (int q = 1; q < R; ++q) t[it][q] = cf_mul(twr[q], t[it][q]);
             cf o[R];
@@ -146,8 +165,8 @@ __device__ __forceinline__ void wave_stage(cf* buf, const cf* __restrict__ tw, i
 #pragma unroll
             for (int q = 0; q < R; ++q) d[q * STRIDE] = o[q];
         }
-        lds_order();   // (also keeps the scheduler from hoisting every iteration's twiddle loads: registers)
     }
+    lds_order();
 }
 
 // Stages 0 (radix RA, stride 1, no twiddles) and 1 (radix RB, stride RA, twiddles W_(RA*RB)^(k q')) of a
@@ -183,6 +202,11 @@ __device__ __forceinline__ void wave_fused_first(cf* dst, const cf* __restrict__
                 for (int q = 0; q < RA; ++q) s[it][qp][q] = load(j + M2 * (qp + RB * q));
         }
     }
+    cf w1[RA][RB];   // (the same for every lane: broadcast reads, fetched with the data)
+#pragma unroll
+    for (int k = 1; k < RA; ++k)
+#pragma unroll
+        for (int qp = 1; qp < RB; ++qp) w1[k][qp] = lds_ld(tw1 + k * (RB - 1) + qp - 1);
     lds_order();
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
@@ -201,7 +225,7 @@ __device__ __forceinline__ void wave_fused_first(cf* dst, const cf* __restrict__
                 u[0] = s[it][0][k];
 #pragma unroll
                 for (int qp = 1; qp < RB; ++qp)
-                    u[qp] = k == 0 ? s[it][qp][k] : cf_mul(lds_ld(tw1 + k * (RB - 1) + qp - 1), s[it][qp][k]);
+                    u[qp] = k == 0 ? s[it][qp][k] : cf_mul(w1[k][qp], s[it][qp][k]);
                 pdft<RB>(u, o);
 #pragma unroll
                 for (int qq = 0; qq < RB; ++qq) dst[RA * RB * j + (PADJ ? j / PADJ : 0) + k + RA * qq] = o[qq];
@@ -221,19 +245,33 @@ __device__ __forceinline__ void wave_postprocess(cf* x, const cf* __restrict__ r
         x[0] = cf_make(z0.x + z0.y, 0.0f);
         x[N2] = cf_make(z0.x - z0.y, 0.0f);
     }
+    // A pair (l, N2 - l) is read and written by one lane, so nothing orders the trips; GROUP trips' reads are
+    // issued together and the wave waits once per group.
+    constexpr int GROUP = 5;
 #pragma unroll
-    for (int it = 0; it < TRIPS; ++it) {
-        const int i = lane + 64 * it;
-        if (i < ITERS) {
-            const int l = 1 + i, rr = N2 - 1 - i;
-            const cf o = lds_ld(x + l), orv = lds_ld(x + rr), tw = lds_ld(rc + i);
-            // o + conj(orv) = (sum.x, diff.y) and o - conj(orv) = (diff.x, sum.y) of real_complex/mod.rs:52-58
-            const cf half = 0.5f * cf_add_conj(o, orv);           // (half_sum_real, half_diff_imag)
-            const cf ri = cf_rc_rotate(cf_sub_conj(o, orv), tw);  // (real, imag)
-            x[l] = half + ri;
-            x[rr] = cf_conj_sub(half, ri);                        // (half_sum_real - real, imag - half_diff_imag)
+    for (int g = 0; g < TRIPS; g += GROUP) {
+        cf o[GROUP], orv[GROUP], tw[GROUP];
+#pragma unroll
+        for (int u = 0; u < GROUP; ++u) {
+            const int i = lane + 64 * (g + u);
+            if (g + u < TRIPS && i < ITERS) {
+                o[u] = lds_ld(x + 1 + i);
+                orv[u] = lds_ld(x + N2 - 1 - i);
+                tw[u] = lds_ld(rc + i);
+            }
         }
-        if (it & 1) lds_order();   // two trips in flight at a time (bounds the registers the scheduler spends on hoisted loads)
+#pragma unroll
+        for (int u = 0; u < GROUP; ++u) {
+            const int i = lane + 64 * (g + u);
+            if (g + u < TRIPS && i < ITERS) {
+                // o + conj(orv) = (sum.x, diff.y) and o - conj(orv) = (diff.x, sum.y) of real_complex/mod.rs:52-58
+                const cf half = 0.5f * cf_add_conj(o[u], orv[u]);           // (half_sum_real, half_diff_imag)
+                const cf ri = cf_rc_rotate(cf_sub_conj(o[u], orv[u]), tw[u]);  // (real, imag)
+                x[1 + i] = half + ri;
+                x[N2 - 1 - i] = cf_conj_sub(half, ri);                      // (half_sum_real - real, imag - half_diff_imag)
+            }
+        }
+        lds_order();
     }
     if (((N2 + 1) & 1) && lane == 32) x[(N2 + 1) / 2].y = -x[(N2 + 1) / 2].y;
     lds_order();
@@ -242,13 +280,16 @@ __device__ __forceinline__ void wave_postprocess(cf* x, const cf* __restrict__ r
 // resampler_fft.rs:401-408 (multiply new_length bins by the filter spectrum, zero the rest up to FO),
 // preprocess_ifft (radix_fft.rs:592-624 + real_complex/mod.rs:84-114) and the input conjugation of
 // process_inverse_complex (:634-637), fused over the bin pairs (l, FO - l), in place.
-template <int FO>
+// NL = the plan's new_length (a constant of the two sizes: fft_in + 1 or fft_out, resampler_fft.rs:396-399),
+// FMAX = the last index of the filter table.
+template <int FO, int NL, int FMAX>
 __device__ __forceinline__ void wave_filter_preprocess(cf* y, const cf* __restrict__ filter,
-                                                       uint32_t new_length, const cf* __restrict__ rc, int lane) {
+                                                       const cf* __restrict__ rc, int lane) {
     constexpr int ITERS = (FO + 1) / 2 - 1;
     constexpr int TRIPS = (ITERS + 63) / 64;
+    static_assert(ITERS + 1 <= NL, "the low bin of every pair is multiplied by the filter");
     auto bin = [&](int k) -> cf {
-        return static_cast<uint32_t>(k) < new_length ? cf_mul(lds_ld(y + k), lds_ld(filter + k)) : cf_make(0.f, 0.f);
+        return k < NL ? cf_mul(lds_ld(y + k), lds_ld(filter + k)) : cf_make(0.f, 0.f);
     };
     cf first = cf_make(0.f, 0.f), mid = cf_make(0.f, 0.f);
     if (lane == 0) {
@@ -261,22 +302,51 @@ __device__ __forceinline__ void wave_filter_preprocess(cf* y, const cf* __restri
         const cf dbl = c + c;
         mid = cf_make(dbl.x, -dbl.y);
     }
+    // A pair (l, FO - l) is read and written by one lane: GROUP trips' reads are issued together.  Whether the
+    // high bins FO - 1 - i of a trip lie below NL is known per trip: all of them (no test), none (zeros, no
+    // reads) or some (the reads stay inside the tables, the product is dropped).
+    constexpr int GROUP = 3;
 #pragma unroll
-    for (int it = 0; it < TRIPS; ++it) {
-        const int i = lane + 64 * it;
-        if (i < ITERS) {
-            const int l = 1 + i, rr = FO - 1 - i;
-            const cf a = bin(l), b = bin(rr), tw = lds_ld(rc + i);
-            const cf sd = cf_add_conj(a, b);                      // (sum.x, diff.y)
-            const cf ri = cf_rc_rotate(cf_sub_conj(a, b), tw);    // (real, imag)
-            y[l] = cf_conj_sub(sd, ri);                           // (sum.x - real, -(diff.y - imag))
-#ifdef RSMP_FFT_WAVE_EXACT
-            y[rr] = cf_conj(cf_conj_add_conj(sd, ri));            // (sum.x + real, -(-imag - diff.y)), zero signs included
-#else
-            y[rr] = sd + ri;
-#endif
+    for (int g = 0; g < TRIPS; g += GROUP) {
+        cf ya[GROUP], fa[GROUP], yb[GROUP], fb[GROUP], tw[GROUP];
+#pragma unroll
+        for (int u = 0; u < GROUP; ++u) {
+            const int trip = g + u, i = lane + 64 * trip;
+            const bool none = FO - 1 - (64 * trip + 63) >= NL;
+            if (trip < TRIPS && ((trip + 1) * 64 <= ITERS || i < ITERS)) {
+                const int l = 1 + i, rr = FO - 1 - i;
+                ya[u] = lds_ld(y + l);
+                fa[u] = lds_ld(filter + l);
+                if (!none) {
+                    yb[u] = lds_ld(y + rr);
+                    fb[u] = lds_ld(filter + (rr < FMAX ? rr : FMAX));
+                }
+                tw[u] = lds_ld(rc + i);
+            }
         }
-        if (it & 1) lds_order();
+#pragma unroll
+        for (int u = 0; u < GROUP; ++u) {
+            const int trip = g + u, i = lane + 64 * trip;
+            const bool none = FO - 1 - (64 * trip + 63) >= NL, all = FO - 1 - 64 * trip < NL;
+            if (trip < TRIPS && ((trip + 1) * 64 <= ITERS || i < ITERS)) {
+                const int l = 1 + i, rr = FO - 1 - i;
+                const cf a = cf_mul(ya[u], fa[u]);
+                cf b = cf_make(0.f, 0.f);
+                if (!none) {
+                    b = cf_mul(yb[u], fb[u]);
+                    if (!all) b = rr < NL ? b : cf_make(0.f, 0.f);
+                }
+                const cf sd = cf_add_conj(a, b);                      // (sum.x, diff.y)
+                const cf ri = cf_rc_rotate(cf_sub_conj(a, b), tw[u]); // (real, imag)
+                y[l] = cf_conj_sub(sd, ri);                           // (sum.x - real, -(diff.y - imag))
+#ifdef RSMP_FFT_WAVE_EXACT
+                y[rr] = cf_conj(cf_conj_add_conj(sd, ri));            // (sum.x + real, -(-imag - diff.y)), zero signs included
+#else
+                y[rr] = sd + ri;
+#endif
+            }
+        }
+        lds_order();
     }
     if (lane == 0) y[0] = cf_make(first.x, -first.y);
     if (((FO + 1) & 1) && lane == 32) y[(FO + 1) / 2] = cf_make(mid.x, -mid.y);
@@ -395,7 +465,7 @@ __global__ __launch_bounds__((OCC == 3 ? 12 : 4) * 64, OCC) void fft_ola_wave_ke
         static_assert(stage_out_pad(FWD::kR[2], S2) == 0 || FI / FWD::kR[3] == S3, "padding period = input distance");
         wave_stage<FI, FWD::kR[3], S3, FI / FWD::kR[3] + stage_out_pad(FWD::kR[2], S2)>(buf, tw_f + T3, lane);
         wave_postprocess<FI>(buf, rc_f, lane);
-        wave_filter_preprocess<FO>(buf, filter, plan.new_length, rc_i, lane);
+        wave_filter_preprocess<FO, (FI < FO ? FI + 1 : FO), FI>(buf, filter, rc_i, lane);
 
         constexpr int IS1 = INV::kR[0], IS2 = IS1 * INV::kR[1];
         constexpr int IT1 = INV::kT1, IT2 = INV::kT2, IT3 = INV::kT3;
@@ -406,19 +476,28 @@ __global__ __launch_bounds__((OCC == 3 ? 12 : 4) * 64, OCC) void fft_ola_wave_ke
         // output conjugation (radix_fft.rs:656-669) makes reals 2c, 2c + 1 of the channel out of Z[c]; the
         // first FO reals are overlap-added and stored, the second FO become the next overlap (:416-423).
         GFloat* xout = as_global(d.out) + static_cast<size_t>(b) * FO * C;
+        // reads of butterfly it + 1 are issued before butterfly it runs (all of them at once do not fit the
+        // 168 registers of three waves per SIMD next to the carry)
+        cf tl[2][RL], rawl[2][kFetch<RL>];
+        auto fetch = [&](int it) {
+            const int i = lane + 64 * it;
+            if ((it + 1) * 64 <= ML || i < ML) {
+#pragma unroll
+                for (int q = 0; q < RL; ++q) tl[it & 1][q] = lds_ld(buf + i + q * (ML + stage_out_pad(INV::kR[2], IS2)));
+                twiddle_fetch<RL>(tw_i + IT3 + i * INV::row(RL), rawl[it & 1]);
+            }
+        };
+        fetch(0);
 #pragma unroll
         for (int it = 0; it < ITERL; ++it) {
             const int i = lane + 64 * it;
+            if (it + 1 < ITERL) fetch(it + 1);
             if ((it + 1) * 64 <= ML || i < ML) {
-                cf t[RL], o[RL];
+                cf o[RL], twr[RL];
+                twiddle_expand<RL>(rawl[it & 1], twr);
 #pragma unroll
-                for (int q = 0; q < RL; ++q) t[q] = lds_ld(buf + i + q * (ML + stage_out_pad(INV::kR[2], IS2)));
-                const cf* w = tw_i + IT3 + i * INV::row(RL);
-                cf twr[RL];
-                twiddle_row<RL>(w, twr);
-#pragma unroll
-                for (int q = 1; q < RL; ++q) t[q] = cf_mul(twr[q], t[q]);
-                pdft<RL>(t, o);
+                for (int q = 1; q < RL; ++q) tl[it & 1][q] = cf_mul(twr[q], tl[it & 1][q]);
+                pdft<RL>(tl[it & 1], o);
 #pragma unroll
                 for (int q = 0; q < HL; ++q) {
                     const int c = i + q * ML;
@@ -462,6 +541,7 @@ hipError_t launch_fft_ola_wave(const FftPlanDev& plan, const FftStreamDesc* d_de
                                hipStream_t stream) {
     if (max_channels != min_channels) return hipErrorNotSupported;   // one wave layout per launch
     if (plan.n_rc_f != plan.fft_in / 2 - 1 || plan.n_rc_i != plan.fft_out / 2 - 1) return hipErrorNotSupported;
+    if (plan.new_length != (plan.fft_in < plan.fft_out ? plan.fft_in + 1 : plan.fft_out)) return hipErrorNotSupported;
     const bool up = W1176::matches(plan.fft_in, plan.n_stages_f, plan.radix_f) &&
                     W1280::matches(plan.fft_out, plan.n_stages_i, plan.radix_i);
     const bool down = W1280::matches(plan.fft_in, plan.n_stages_f, plan.radix_f) &&
