@@ -129,19 +129,19 @@ template <> __device__ __forceinline__ void pdft<7>(const cf (&t)[7], cf (&o)[7]
     const cf a1 = t[1] + t[6], a2 = t[2] + t[5], a3 = t[3] + t[4];
     const cf b1 = t[1] - t[6], b2 = t[2] - t[5], b3 = t[3] - t[4];   // (rotated by -i in the last add)
     o[0] = t[0] + sum_all;
-    // (cos1, sin1, cos2, sin2, cos3, sin3) per output, butterfly7/mod.rs:416-436
+    // (cos1, sin1, cos2, sin2, cos3, sin3) per output, butterfly7/mod.rs:416-436.  Outputs idx and 7 - idx
+    // have the same cosines and the opposite sines: the second is c - d where the first is c + d, bit for bit
+    // what evaluating its own row gives ((-s) b = -(s b)).
 #define RSMP_R7(idx, c1, s1, c2, s2, c3, s3)                                \
     {                                                                       \
         const cf c = ((t[0] + (c1) * a1) + (c2) * a2) + (c3) * a3;          \
         const cf d = ((s1) * b1 + (s2) * b2) + (s3) * b3;                   \
         o[idx] = cf_add_nrot(c, d);                                         \
+        o[7 - idx] = cf_sub_nrot(c, d);                                     \
     }
     RSMP_R7(1, C[0], S[0], C[1], S[1], C[2], S[2])
     RSMP_R7(2, C[1], S[1], C[2], -S[2], C[0], -S[0])
     RSMP_R7(3, C[2], S[2], C[0], -S[0], C[1], S[1])
-    RSMP_R7(4, C[2], -S[2], C[0], S[0], C[1], -S[1])
-    RSMP_R7(5, C[1], -S[1], C[2], S[2], C[0], S[0])
-    RSMP_R7(6, C[0], -S[0], C[1], -S[1], C[2], -S[2])
 #undef RSMP_R7
 }
 template <> __device__ __forceinline__ void pdft<8>(const cf (&t)[8], cf (&o)[8]) {
