@@ -182,3 +182,46 @@ def test_whole_file_driver_matches_reference_loop():
     expected = int(np.ceil(x.size * n_out / n_in))
     assert y.size == expected
     assert rms(y, ref.reshape(-1)[:expected]) <= RMS_TOL
+
+
+@pytest.mark.gpu
+def test_exact_build_is_bit_identical_to_the_reference_arithmetic():
+    """libresampler_amd_fftexact.so = the same library with the wave kernel compiled without fused
+    multiply-adds and with every twiddle fetched (make -C resampler_amd/csrc): its output equals the CPU
+    path's bit for bit, both directions of the 44.1 / 48 kHz pair.  (One library per process: a child runs it.)"""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exact = os.path.join(root, "resampler_amd", "libresampler_amd_fftexact.so")
+    assert os.path.exists(exact), "build it: make -C resampler_amd/csrc"
+    code = r"""
+import numpy as np, torch
+import resampler_amd as ra
+from oracle import pyoracle as o
+from resampler_amd import synth
+assert ra.LIB_PATH.endswith("libresampler_amd_fftexact.so")
+blocks = 40
+for in_hz, out_hz, a, b in ((44100, 48000, ra.SampleRate.Hz44100, ra.SampleRate.Hz48000),
+                            (48000, 44100, ra.SampleRate.Hz48000, ra.SampleRate.Hz44100)):
+    g = ra.ResamplerFft.new(2, a, b)
+    n_in, n_out = g.chunk_size_input(), g.chunk_size_output()
+    x = synth.sweep(blocks * n_in // 2, 2, float(in_hz))
+    dev = torch.device("cuda:0")
+    d_in, d_out = [torch.from_numpy(x).to(dev)], [torch.zeros(blocks * n_out, device=dev)]
+    batch = ra.FftBatch([g])
+    batch.bind(d_in, d_out, [blocks])
+    batch.resample_bulk_device(torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    r = o.OracleFft(2, in_hz, out_hz)
+    ref = np.zeros((blocks, n_out), np.float32)
+    for k in range(blocks):
+        assert r.resample(x[k * n_in:(k + 1) * n_in], ref[k]) == 0
+    y = d_out[0].cpu().numpy()
+    assert np.array_equal(y, ref.reshape(-1)), (in_hz, float(np.abs(y - ref.reshape(-1)).max()))
+print("bit-identical")
+"""
+    env = dict(os.environ, RSMP_AMD_LIB=exact, PYTHONPATH=root)
+    out = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "bit-identical" in out.stdout, out.stdout + out.stderr
