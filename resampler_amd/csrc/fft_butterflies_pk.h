@@ -162,4 +162,32 @@ template <> __device__ __forceinline__ void pdft<8>(const cf (&t)[8], cf (&o)[8]
     o[7] = xe3 + w3;
 }
 
+// pdft<R> of inputs whose last NZ are zero (they are not read): what pdft computes with them, less the
+// operations whose operand is a zero (x + 0, x - 0, c * 0: equal in value; the sign of a zero result may
+// differ, which no later operation turns into a different value).
+template <int R, int NZ> __device__ __forceinline__ void pdft_tail(cf (&t)[R], cf (&o)[R]) {
+    if constexpr (NZ == 0) {
+        pdft<R>(t, o);
+    } else if constexpr (R == 3 && NZ == 1) {
+        const float SQRT3_2 = 0.8660254f;
+        o[0] = t[0] + t[1];
+        const cf part = t[0] - 0.5f * t[1];
+        const cf s = SQRT3_2 * t[1];
+        o[1] = cf_add_nrot(part, s);
+        o[2] = cf_sub_nrot(part, s);
+    } else if constexpr (R == 4 && NZ == 2) {
+        o[0] = t[0] + t[1];
+        o[2] = t[0] - t[1];
+        o[1] = cf_add_nrot(t[0], t[1]);
+        o[3] = cf_sub_nrot(t[0], t[1]);
+    } else if constexpr (NZ == R - 1) {
+#pragma unroll
+        for (int q = 0; q < R; ++q) o[q] = t[0];
+    } else {
+#pragma unroll
+        for (int q = R - NZ; q < R; ++q) t[q] = cf_make(0.f, 0.f);
+        pdft<R>(t, o);
+    }
+}
+
 }  // namespace rsmp

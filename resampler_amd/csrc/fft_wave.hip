@@ -23,6 +23,7 @@
 // interleaved output meet in the same L2.
 #include <cmath>
 #include <cstdlib>
+#include <type_traits>
 
 // a*b + c may fuse in this file: one rounding fewer per fused pair.  The results then differ from the
 // reference's scalar arithmetic (which never fuses) in the last bits -- far inside the 1e-6 RMS gate (measured
@@ -186,7 +187,17 @@ template <int N, int R, int RA, int RB> constexpr int fused_qs() {
     static_assert(fused_pad<RA, RB>() == 0 || N / R == fused_pad<RA, RB>(), "padding period = input distance");
     return fused_pad<RA, RB>() ? N / R + 1 : N / R;
 }
-template <int N, int RA, int RB, class Load>
+template <int I, int E, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < E) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, E>(f);
+    }
+}
+// NVALID: points at index >= NVALID of the stage-0 input are zero and are neither fetched nor computed with
+// (the zero padding of the forward transform: resampler_fft.rs:387-388).  Butterfly q' takes the points
+// j + M2 (q' + RB q): the last NZ of its RA inputs are padding for every j (pdft_tail).
+template <int N, int RA, int RB, int NVALID = N, class Load>
 __device__ __forceinline__ void wave_fused_first(cf* dst, const cf* __restrict__ tw1, int lane, Load load) {
     constexpr int M2 = N / (RA * RB);
     constexpr int PADJ = fused_pad<RA, RB>() / (RA * RB);   // units per padding value
@@ -196,10 +207,12 @@ __device__ __forceinline__ void wave_fused_first(cf* dst, const cf* __restrict__
     for (int it = 0; it < ITER; ++it) {
         const int j = lane + 64 * it;
         if ((it + 1) * 64 <= M2 || j < M2) {
-#pragma unroll
-            for (int qp = 0; qp < RB; ++qp)
-#pragma unroll
-                for (int q = 0; q < RA; ++q) s[it][qp][q] = load(j + M2 * (qp + RB * q));
+            static_for<0, RB>([&](auto qp_c) {
+                static_for<0, RA>([&](auto q_c) {
+                    constexpr int m = decltype(qp_c)::value + RB * decltype(q_c)::value;
+                    if constexpr (M2 * m < NVALID) s[it][decltype(qp_c)::value][decltype(q_c)::value] = load(j + M2 * m);
+                });
+            });
         }
     }
     cf w1[RA][RB];   // (the same for every lane: broadcast reads, fetched with the data)
@@ -212,13 +225,16 @@ __device__ __forceinline__ void wave_fused_first(cf* dst, const cf* __restrict__
     for (int it = 0; it < ITER; ++it) {
         const int j = lane + 64 * it;
         if ((it + 1) * 64 <= M2 || j < M2) {
-#pragma unroll
-            for (int qp = 0; qp < RB; ++qp) {
+            static_for<0, RB>([&](auto qp_c) {
+                constexpr int qp = decltype(qp_c)::value;
+                // inputs q with M2 (qp + RB q) >= NVALID are zero: count them from the end
+                constexpr int first_zero = M2 * qp >= NVALID ? 0 : (NVALID - M2 * qp + M2 * RB - 1) / (M2 * RB);
+                constexpr int NZ = first_zero >= RA ? 0 : RA - first_zero;
                 cf o[RA];
-                pdft<RA>(s[it][qp], o);
+                pdft_tail<RA, NZ>(s[it][qp], o);
 #pragma unroll
                 for (int k = 0; k < RA; ++k) s[it][qp][k] = o[k];
-            }
+            });
 #pragma unroll
             for (int k = 0; k < RA; ++k) {
                 cf u[RB], o[RB];
@@ -459,7 +475,7 @@ __global__ __launch_bounds__((OCC == 3 ? 12 : 4) * 64, OCC) void fft_ola_wave_ke
                 }
                 return v;
             };
-            wave_fused_first<FI, FWD::kR[0], FWD::kR[1]>(buf, tw_f + T1, lane, sample);
+            wave_fused_first<FI, FWD::kR[0], FWD::kR[1], FI / 2>(buf, tw_f + T1, lane, sample);
         }
         wave_stage<FI, FWD::kR[2], S2, fused_qs<FI, FWD::kR[2], FWD::kR[0], FWD::kR[1]>()>(buf, tw_f + T2, lane);
         static_assert(stage_out_pad(FWD::kR[2], S2) == 0 || FI / FWD::kR[3] == S3, "padding period = input distance");
