@@ -566,18 +566,98 @@ def secondary_lines(ctx: Ctx, args):
     return sec
 
 
+def device_hash_noise(torch, dev, start: int, n_values: int, seed: int = 0):
+    """synth.hash_noise (splitmix64 of the value's index in the stream) evaluated on the GPU for values
+    [start, start + n_values): every rank can produce its own span of one long stream."""
+    out = torch.empty(n_values, device=dev, dtype=torch.float32)
+    def i64(v):   # a 64-bit pattern as the int64 torch computes with (wrap-around arithmetic, as numpy's uint64)
+        v &= (1 << 64) - 1
+        return v - (1 << 64) if v >> 63 else v
+    c1, c2, c3 = i64((seed + 1) * 0x9E3779B97F4A7C15), i64(0xBF58476D1CE4E5B9), i64(0x94D049BB133111EB)
+    step = 1 << 26
+    for a in range(0, n_values, step):
+        b = min(n_values, a + step)
+        z = torch.arange(start + a, start + b, device=dev, dtype=torch.int64) + c1
+        z = (z ^ ((z >> 30) & ((1 << 34) - 1))) * c2
+        z = (z ^ ((z >> 27) & ((1 << 37) - 1))) * c3
+        z = z ^ ((z >> 31) & ((1 << 33) - 1))
+        top = (z >> 40) & ((1 << 24) - 1)
+        out[a:b] = top.to(torch.float32) / float(1 << 23) - 1.0
+    return out
+
+
+def bench_c5(ctx: Ctx, args, steps: int, warmup: int):
+    """BASELINE config 5: ONE 8-channel 96 kHz -> 44.1 kHz stream (Sample64 / Db120), `--c5-frames` input frames
+    (default 57.6 M = 10 minutes), 512-frame calls.  The stream is cut into one run of calls per rank
+    (sharding.fir_time_shards: the host mirror's exact state at every cut, the buffered frames as halo); a step =
+    every rank seeks its resampler to its cut and resamples its run in one bulk launch (strong scaling, no
+    data-path collective: a rank holds its span of the input and keeps its span of the output)."""
+    import resampler_amd as ra
+    from resampler_amd import sharding
+    torch = ctx.torch
+    ch, in_hz, out_hz, chunk = 8, 96000, 44100, 512
+    frames = args.c5_frames
+    t0 = time.perf_counter()
+    shards = sharding.fir_time_shards(in_hz, out_hz, ra.Latency.Sample64, frames, chunk, ctx.world)
+    plan_s = time.perf_counter() - t0
+    s = shards[ctx.rank]
+    h = ra.ResamplerFir.new_from_hz(ch, in_hz, out_hz, ra.Latency.Sample64, ra.Attenuation.Db120, device=ctx.local_rank)
+    first = s.in_offset - s.history_frames
+    d_span = device_hash_noise(torch, ctx.dev, first * ch, (s.history_frames + s.in_frames) * ch, seed=5)
+    d_hist, d_in = d_span[:s.history_frames * ch], d_span[s.history_frames * ch:]
+    d_out = torch.empty(max(1, s.out_frames) * ch + 64, device=ctx.dev, dtype=torch.float32)
+
+    def step():
+        h.seek(s.plan, d_hist, ctx.stream)
+        if s.in_frames:
+            c, p = h.resample_bulk_device(d_in, d_out, chunk * ch, ctx.stream)
+            assert (c, p) == (s.in_frames * ch, s.out_frames * ch)
+    step()
+    spinup(ctx, step, args.spinup_seconds)
+    dt, host_dt = timed(ctx, step, steps, warmup)
+    h.set_profiling(True)
+    for _ in range(8):
+        step()
+    k_ms, _ = h.mean_kernel_ms()
+    h.set_profiling(False)
+    k_ms = ctx.max_over_ranks(k_ms)
+    values_in = frames * ch
+    out_frames = sum(t.out_frames for t in shards)
+    alg = 4.0 * ch * (frames + out_frames)
+    ach = alg / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+    variant = {0: "fir_generic_kernel", 1: "fir_periodic_kernel (vector)", 2: "fir_periodic_db_kernel (vector)",
+               3: "fir_periodic_db_kernel (exact-f32 MFMA)", 4: "fir_split_kernel (bf16x3 MFMA)",
+               5: "fir_split_kernel (fp16x2 MFMA)"}.get(h.kernel_variant(), "?")
+    return {
+        "metric": "Msamples/s (in) config 5: one 8-channel 96k->44.1k FIR stream, time-sharded",
+        "value": round(values_in * steps / dt / 1e6, 1), "unit": "Msamples/s", "n_gpus": ctx.world,
+        "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"ResamplerFir 8ch 96000->44100 128-tap (Sample64/Db120), {frames} input frames in "
+                               f"{chunk}-frame calls, cut into {ctx.world} run(s) of calls at the host mirror's exact "
+                               f"state, each run one seek + one bulk launch on its GPU",
+                   "calls_this_rank": s.n_calls, "halo_frames_this_rank": s.history_frames,
+                   "shard_planning_s": round(plan_s, 3), "host_enqueue_ms_per_step": round(host_dt / steps * 1e3, 4)},
+        "roofline": {"bound": "hbm", "kernel": variant, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS * ctx.world,
+                     "unit": "GB/s", "frac": round(ach / (HBM_PEAK_GBS * ctx.world), 4), "traffic": None,
+                     "kernel_ms": round(k_ms, 4), "algorithmic_bytes": int(alg)},
+    }
+
+
 def main() -> int:
     ap = argparse.ArgumentParser()
     ap.add_argument("--path", choices=["fir", "fft"], default="fir",
                     help="fir = headline metric (default); fft = the ResamplerFft line alone")
-    ap.add_argument("--config", choices=["c2", "c4"], default="c2",
-                    help="c2 = headline workload (weak scaling); c4 = 1024 mixed-rate lock-step streams (strong)")
+    ap.add_argument("--config", choices=["c2", "c4", "c5"], default="c2",
+                    help="c2 = headline workload (weak scaling); c4 = 1024 mixed-rate lock-step streams (strong); "
+                         "c5 = one long 8-channel stream cut into time shards (strong)")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--streams", type=int, default=64, help="streams per GPU (c2 / fft)")
     ap.add_argument("--c4-streams", type=int, default=1024, help="streams of the whole config-4 batch")
     ap.add_argument("--frames", type=int, default=1 << 20, help="input frames per stream per step")
+    ap.add_argument("--c5-frames", type=int, default=57_600_000, help="input frames of the config-5 stream (10 min at 96 kHz)")
     ap.add_argument("--chunk", type=int, default=512, help="reference call size in f32 values")
     ap.add_argument("--feed", choices=["resident", "rccl"], default="resident",
                     help="c4: rccl = a step's chunks are scattered from GPU 0 and outputs gathered back (RCCL send/recv)")
@@ -600,6 +680,8 @@ def main() -> int:
         line = bench_fft(ctx, args, args.steps, args.warmup, with_cpu=(not args.no_cpu and ctx.world == 1))
     elif args.config == "c4":
         line = bench_c4(ctx, args, args.steps, args.warmup)
+    elif args.config == "c5":
+        line = bench_c5(ctx, args, args.steps, args.warmup)
     else:
         line = bench_fir(ctx, args)
         if ctx.world == 1 and ctx.rank == 0:

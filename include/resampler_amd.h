@@ -210,6 +210,21 @@ int rsmp_fir_plan_call(rsmp_fir_plan* p, size_t input_frames, size_t output_capa
                        size_t* frames_accepted, size_t* frames_produced, rsmp_fir_segment* segs,
                        size_t max_segs, size_t* n_segs);
 
+/* A copy of the plan (its state); NULL for NULL. */
+rsmp_fir_plan* rsmp_fir_plan_clone(const rsmp_fir_plan* p);
+/* The driver loop of resample/src/main.rs:226-254 on the plan alone: calls of min(chunk_frames, remaining)
+ * input frames with the full output capacity until in_frames are used up or max_calls calls were made
+ * (0 = no limit).  Totals in frames.  What rsmp_fir_resample_bulk would do to a stream in this state. */
+int rsmp_fir_plan_bulk(rsmp_fir_plan* p, size_t in_frames, size_t chunk_frames, size_t max_calls,
+                       size_t* frames_accepted, size_t* frames_produced, size_t* n_calls);
+/* Starts a resampler in the middle of a stream: the handle takes the plan's state (same rate pair and
+ * latency) and, as its buffered frames, the last available_frames * channels values of `history` -- the
+ * input that precedes the point (host or device memory).  A stream cut at call boundaries found with
+ * rsmp_fir_plan_bulk can so be resampled piece by piece, on different GPUs, with the output of one pass
+ * (the reference has no counterpart: its state is private, resampler_fir.rs:189-192). */
+int rsmp_fir_seek(rsmp_fir* r, const rsmp_fir_plan* p, const float* history, size_t history_len,
+                  int history_on_device, void* stream);
+
 /* ============================ CLI helpers around the path (resample/src) ========================== */
 /* InterpolationResampler (resample/src/interpolation_resampler.rs:41-126): the comparison interpolators of
  * the reference's command-line tool, whole buffer in, ceil(frames * out / in) frames out. */

@@ -139,6 +139,23 @@ void orc_fir_state(const orc_fir* r, size_t* read_position, size_t* available_fr
     if (position) *position = r->position;
 }
 
+/* Test support (no reference counterpart: the state is private, resampler_fir.rs:189-192): puts the three
+ * scalars where a run over the stream's earlier input left them and refills the planar ring with the
+ * `available_frames` interleaved frames that precede the point.  Lets the CPU tests run one piece of a
+ * stream on its own (tests/test_sharding_gloo.py). */
+int orc_fir_seek(orc_fir* r, size_t read_position, size_t available_frames, double position,
+                 const float* history, size_t history_len) {
+    size_t ch = r->channels;
+    if (read_position + available_frames > BUFFER_SIZE || history_len < available_frames * ch) return 1;
+    const float* h = history + (history_len - available_frames * ch);
+    for (size_t f = 0; f < available_frames; f++)
+        for (size_t c = 0; c < ch; c++) r->input_buffers[BUFFER_SIZE * c + read_position + f] = h[f * ch + c];
+    r->read_position = read_position;
+    r->available_frames = available_frames;
+    r->position = position;
+    return 0;
+}
+
 static size_t min_sz(size_t a, size_t b) { return a < b ? a : b; }
 
 /* resampler_fir.rs:509-621 */

@@ -63,6 +63,8 @@ int orc_fir_resample(orc_fir* r, const float* in, size_t in_len, float* out, siz
                      size_t* consumed, size_t* produced);                 /* :509-621 */
 const float* orc_fir_coeffs(const orc_fir* r);  /* [1024][taps] */
 double orc_fir_ratio(const orc_fir* r);
+int orc_fir_seek(orc_fir* r, size_t read_position, size_t available_frames, double position,
+                 const float* history, size_t history_len);   /* test support: start mid-stream */
 void orc_fir_state(const orc_fir* r, size_t* read_position, size_t* available_frames,
                    double* position);
 /* The CLI driver loop (resample/src/main.rs:226-254) with a caller-chosen chunk length (in f32

@@ -68,6 +68,8 @@ def lib() -> C.CDLL:
     L.orc_fir_ratio.restype = C.c_double
     L.orc_fir_ratio.argtypes = [C.c_void_p]
     L.orc_fir_state.argtypes = [C.c_void_p, szp, szp, C.POINTER(C.c_double)]
+    L.orc_fir_seek.restype = C.c_int
+    L.orc_fir_seek.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_double, C.POINTER(C.c_float), C.c_size_t]
     L.orc_fir_resample_all.restype = C.c_size_t
     L.orc_fir_resample_all.argtypes = [C.c_void_p, f32p, C.c_size_t, C.c_size_t, f32p, C.c_size_t,
                                        szp, C.c_size_t, szp]
@@ -190,6 +192,12 @@ class OracleFir:
         rp, av, pos = C.c_size_t(), C.c_size_t(), C.c_double()
         lib().orc_fir_state(self._h, C.byref(rp), C.byref(av), C.byref(pos))
         return rp.value, av.value, pos.value
+
+    def seek(self, state, history: np.ndarray) -> None:
+        """Test support: (read_position, available_frames, position) + the input preceding the point."""
+        h = np.ascontiguousarray(history, np.float32)
+        if lib().orc_fir_seek(self._h, state[0], state[1], state[2], _f32p(h), h.size) != 0:
+            raise ValueError("orc_fir_seek: history shorter than the buffered frames")
 
     def resample(self, inp: np.ndarray, out: np.ndarray):
         """Returns (status, consumed, produced); status 0/1/2 as error.rs:3-8."""

@@ -149,6 +149,9 @@ _SIGNATURES = [
     ("rsmp_fir_plan_state", None, [C.c_void_p, _szp, _szp, C.POINTER(C.c_double)]),
     ("rsmp_fir_plan_call", C.c_int,
      [C.c_void_p, C.c_size_t, C.c_size_t, _szp, _szp, C.POINTER(_Segment), C.c_size_t, _szp]),
+    ("rsmp_fir_plan_clone", C.c_void_p, [C.c_void_p]),
+    ("rsmp_fir_plan_bulk", C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, _szp, _szp, _szp]),
+    ("rsmp_fir_seek", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
     ("rsmp_interp_output_len", C.c_size_t, [C.c_size_t, C.c_uint32, C.c_uint32, C.c_size_t]),
     ("rsmp_interp_resample", C.c_int,
      [C.c_int, C.c_size_t, C.c_uint32, C.c_uint32, _f32p, C.c_size_t, _f32p, C.c_size_t, _szp]),
@@ -314,6 +317,16 @@ class ResamplerFir:
         rp, av, pos = C.c_size_t(), C.c_size_t(), C.c_double()
         lib().rsmp_fir_state(self._h, C.byref(rp), C.byref(av), C.byref(pos))
         return rp.value, av.value, pos.value
+
+    def seek(self, plan: "FirPlan", history, stream: Optional[int] = None) -> None:
+        """Starts this resampler where ``plan`` stands: its state, and as buffered frames the end of
+        ``history`` -- the input preceding the point (numpy array or CUDA tensor).  See sharding.fir_time_shards."""
+        if isinstance(history, np.ndarray):
+            h = _np_f32(history)
+            _check(lib().rsmp_fir_seek(self._h, plan._h, _ptr(h), h.size, 0, C.c_void_p(stream or 0)))
+        else:
+            _check(lib().rsmp_fir_seek(self._h, plan._h, C.c_void_p(_dev_ptr(history) if history.numel() else 0),
+                                       history.numel(), 1, C.c_void_p(stream or 0)))
 
     def set_kernel(self, kernel: FirKernel) -> None:
         _check(lib().rsmp_fir_set_kernel(self._h, int(kernel)))
@@ -690,7 +703,7 @@ class FirPlan:
         self._h = C.c_void_p(h)
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and lib is not None:   # (module globals are gone at interpreter exit)
             lib().rsmp_fir_plan_free(self._h)
             self._h = None
 
@@ -701,6 +714,19 @@ class FirPlan:
         rp, av, pos = C.c_size_t(), C.c_size_t(), C.c_double()
         lib().rsmp_fir_plan_state(self._h, C.byref(rp), C.byref(av), C.byref(pos))
         return rp.value, av.value, pos.value
+
+    def clone(self) -> "FirPlan":
+        c = FirPlan.__new__(FirPlan)
+        c._h = C.c_void_p(lib().rsmp_fir_plan_clone(self._h))
+        return c
+
+    def bulk(self, in_frames: int, chunk_frames: int, max_calls: int = 0):
+        """The CLI driver loop (resample/src/main.rs:226-254) on the plan alone: calls of ``chunk_frames``
+        until ``in_frames`` are used up or ``max_calls`` calls were made -> (accepted, produced, calls)."""
+        a, p, n = C.c_size_t(), C.c_size_t(), C.c_size_t()
+        _check(lib().rsmp_fir_plan_bulk(self._h, in_frames, chunk_frames, max_calls, C.byref(a), C.byref(p),
+                                        C.byref(n)))
+        return a.value, p.value, n.value
 
     def call(self, input_frames: int, output_capacity_frames: int, want_segments: bool = False):
         """One resample() call in frames -> (accepted, produced[, segments])."""

@@ -629,6 +629,35 @@ extern "C" void rsmp_fir_state(const rsmp_fir* r, size_t* read_position, size_t*
     if (position) *position = r->mirror.position();
 }
 
+// Puts the stream where a host-only plan stands: the plan's state becomes the handle's and the frames the
+// reference would hold buffered at that point (available_frames of them) are taken from the END of
+// `history`, the input that precedes the point.  With rsmp_fir_plan_bulk this starts a resampler in the
+// middle of a stream -- a long stream is cut at call boundaries and each piece runs on its own GPU with
+// the results of the unsharded run (exact position state from the host mirror plus a halo).
+extern "C" int rsmp_fir_seek(rsmp_fir* r, const rsmp_fir_plan* p, const float* history, size_t history_len,
+                             int history_on_device, void* stream_v) {
+    if (!r || !p) return rsmp::fail(RSMP_ERR_INVALID_ARGUMENT, "rsmp_fir_seek: null argument");
+    const rsmp::FirMirrorState& s = p->mirror.state();
+    if (s.num != r->mirror.num() || s.den != r->mirror.den() || s.taps != r->mirror.taps())
+        return rsmp::fail(RSMP_ERR_INVALID_ARGUMENT, "rsmp_fir_seek: the plan is for another rate pair or latency");
+    const size_t need = static_cast<size_t>(s.available) * r->channels;
+    if (history_len < need || (need && !history))
+        return rsmp::fail(RSMP_ERR_INVALID_INPUT_BUFFER_SIZE, "rsmp_fir_seek: %zu values buffered at this point, history holds %zu",
+                          need, history_len);
+    DeviceGuard guard(r->device);
+    hipStream_t stream = stream_v ? static_cast<hipStream_t>(stream_v) : r->stream;
+    if (r->last_stream_valid && r->last_stream != stream) RSMP_HIP_CHECK(hipStreamSynchronize(r->last_stream));
+    r->last_stream = stream;
+    r->last_stream_valid = true;
+    if (need) {
+        RSMP_HIP_CHECK(hipMemcpyAsync(r->d_hist[r->cur], history + (history_len - need), need * sizeof(float),
+                                      history_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, stream));
+        if (!history_on_device) RSMP_HIP_CHECK(hipStreamSynchronize(stream));   // the caller's buffer is free on return
+    }
+    r->mirror.set_state(s);
+    return RSMP_OK;
+}
+
 extern "C" void rsmp_fir_reset(rsmp_fir* r) {
     // resampler_fir.rs:638-642: only the three scalars; stale frames are unreachable.
     r->mirror.reset();

@@ -70,11 +70,6 @@ FirCallResult FirMirror::call(size_t input_frames, size_t output_capacity, int64
 }  // namespace rsmp
 
 // ---- C ABI: host-only plan handle -----------------------------------------------------------
-struct rsmp_fir_plan {
-    rsmp::FirMirror mirror;
-    explicit rsmp_fir_plan(uint32_t i, uint32_t o, size_t t) : mirror(i, o, t) {}
-};
-
 extern "C" rsmp_fir_plan* rsmp_fir_plan_new(uint32_t input_rate_hz, uint32_t output_rate_hz,
                                             int latency) {
     const size_t taps = rsmp::latency_taps(latency);
@@ -86,6 +81,7 @@ extern "C" rsmp_fir_plan* rsmp_fir_plan_new(uint32_t input_rate_hz, uint32_t out
 }
 
 extern "C" void rsmp_fir_plan_free(rsmp_fir_plan* p) { delete p; }
+extern "C" rsmp_fir_plan* rsmp_fir_plan_clone(const rsmp_fir_plan* p) { return p ? new rsmp_fir_plan(*p) : nullptr; }
 extern "C" void rsmp_fir_plan_reset(rsmp_fir_plan* p) { if (p) p->mirror.reset(); }
 
 extern "C" void rsmp_fir_plan_state(const rsmp_fir_plan* p, size_t* read_position,
@@ -114,3 +110,27 @@ extern "C" int rsmp_fir_plan_call(rsmp_fir_plan* p, size_t input_frames,
     }
     return RSMP_OK;
 }
+
+// The driver loop of resample/src/main.rs:226-254 on the mirror alone (what rsmp_fir_resample_bulk plans,
+// fir_api.cpp plan_job_uncached): every call offers min(chunk, remaining) frames and the full output
+// capacity; stops after max_calls calls (0 = no limit) or when the input is used up.
+extern "C" int rsmp_fir_plan_bulk(rsmp_fir_plan* p, size_t in_frames, size_t chunk_frames, size_t max_calls,
+                                  size_t* frames_accepted, size_t* frames_produced, size_t* n_calls) {
+    if (!p || chunk_frames == 0) return rsmp::fail(RSMP_ERR_INVALID_ARGUMENT, "rsmp_fir_plan_bulk: invalid argument");
+    const size_t cap_frames = p->mirror.buffer_size_output_frames();
+    size_t offset = 0, produced = 0, calls = 0;
+    while (offset < in_frames && (max_calls == 0 || calls < max_calls)) {
+        const size_t remaining = in_frames - offset;
+        const rsmp::FirCallResult c =
+            p->mirror.call(remaining < chunk_frames ? remaining : chunk_frames, cap_frames, 0, 0, nullptr, nullptr);
+        produced += c.produced;
+        offset += c.accepted;
+        ++calls;
+        if (c.accepted == 0) break;
+    }
+    if (frames_accepted) *frames_accepted = offset;
+    if (frames_produced) *frames_produced = produced;
+    if (n_calls) *n_calls = calls;
+    return RSMP_OK;
+}
+

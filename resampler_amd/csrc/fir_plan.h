@@ -70,3 +70,9 @@ private:
 };
 
 }  // namespace rsmp
+
+// The host-only plan handle of the C ABI (rsmp_fir_plan_*): a mirror without a device.
+struct rsmp_fir_plan {
+    rsmp::FirMirror mirror;
+    explicit rsmp_fir_plan(uint32_t i, uint32_t o, size_t t) : mirror(i, o, t) {}
+};

@@ -145,3 +145,85 @@ class StepFeed:
             ops.append(d.P2POp(d.isend, self.local_out, self.root))
         self._exchange(ops)
         return stage_out
+
+
+# ---- one long stream over several GPUs (time shards, block shards) -----------------------------
+
+@dataclass
+class TimeShard:
+    """A run of consecutive resample() calls of one ResamplerFir stream (frames, not values)."""
+    rank: int
+    first_call: int
+    n_calls: int
+    in_offset: int        # the shard's first input frame in the stream
+    in_frames: int
+    out_offset: int       # its first output frame in the stream's output
+    out_frames: int
+    history_frames: int   # frames the reference holds buffered when the shard starts: input[in_offset - h : in_offset]
+    plan: object          # FirPlan standing at the shard's start (ResamplerFir.seek)
+
+
+def fir_time_shards(in_hz: int, out_hz: int, latency, in_frames: int, chunk_frames: int, world: int) -> List[TimeShard]:
+    """Cuts the CLI driver loop (resample/src/main.rs:226-254) over ``in_frames`` of one stream into ``world``
+    runs of calls.  The host mirror (FirPlan: the reference's f64 position recurrence replayed exactly, no
+    samples) gives, for every cut, the state the reference is in, how much input it has consumed and how much
+    output it has produced; a rank starts its resampler there (``ResamplerFir.seek`` with the ``history_frames``
+    input frames before the cut as the halo) and produces exactly the outputs the single pass would.
+    Deterministic: every rank computes the same list."""
+    from . import FirPlan
+    if world <= 0 or chunk_frames <= 0:
+        raise ValueError("world and chunk_frames must be positive")
+    plan = FirPlan(in_hz, out_hz, latency)
+    _, _, total_calls = plan.clone().bulk(in_frames, chunk_frames)
+    shards: List[TimeShard] = []
+    in_off = out_off = 0
+    for r in range(world):
+        k0, k1 = (r * total_calls) // world, ((r + 1) * total_calls) // world
+        start = plan.clone()
+        hist = start.state()[1]
+        accepted = produced = calls = 0
+        if k1 > k0:
+            accepted, produced, calls = plan.bulk(in_frames - in_off, chunk_frames, k1 - k0)
+            if r + 1 < world and (calls != k1 - k0 or accepted != calls * chunk_frames):
+                raise ValueError("a call of the stream did not accept its whole chunk: cut it with a smaller chunk")
+        shards.append(TimeShard(r, k0, calls, in_off, accepted, out_off, produced, hist, start))
+        in_off += accepted
+        out_off += produced
+    return shards
+
+
+def run_fir_time_shard(handle, shard: TimeShard, d_stream, d_out, channels: int, chunk_frames: int,
+                       stream=None) -> Tuple[int, int]:
+    """Runs ``shard`` of the stream ``d_stream`` (a CUDA tensor holding at least the shard's input and the
+    ``history_frames`` before it, indexed from the start of the stream) on ``handle``'s GPU; the shard's outputs
+    go to ``d_out[0 : out_frames * channels]``.  Returns (consumed, produced) in values."""
+    c = channels
+    handle.seek(shard.plan, d_stream[(shard.in_offset - shard.history_frames) * c:shard.in_offset * c], stream)
+    if shard.in_frames == 0:
+        return 0, 0
+    return handle.resample_bulk_device(d_stream[shard.in_offset * c:(shard.in_offset + shard.in_frames) * c], d_out,
+                                       chunk_frames * c, stream)
+
+
+def fft_block_shards(n_blocks: int, world: int) -> List[Tuple[int, int]]:
+    """[first_block, end_block) per rank for one ResamplerFft stream.  A block's output needs the second half of
+    its predecessor's inverse transform (the overlap, resampler_fft.rs:416-423) and nothing older, so a rank
+    whose range does not start the stream recomputes ONE block before it and drops that block's output
+    (run_fft_block_shard)."""
+    if world <= 0:
+        raise ValueError("world must be positive")
+    return [((r * n_blocks) // world, ((r + 1) * n_blocks) // world) for r in range(world)]
+
+
+def run_fft_block_shard(handle, first: int, end: int, d_stream, d_work, stream=None):
+    """Blocks [first, end) of the stream ``d_stream`` (indexed from the start of the stream) on a FRESH
+    ``handle`` (zero overlap).  ``d_work`` holds ``end - first + 1`` output blocks: the halo block's output
+    lands in front and is dropped; returns the view of ``d_work`` with the shard's outputs (no copy, so nothing
+    has to be ordered against the launch, which is asynchronous on ``stream`` / the handle's stream)."""
+    n_in, n_out = handle.chunk_size_input(), handle.chunk_size_output()
+    if end <= first:
+        return d_work[:0]
+    halo = 1 if first > 0 else 0
+    n = end - first + halo
+    handle.resample_bulk_device(d_stream[(first - halo) * n_in:end * n_in], d_work[:n * n_out], n, stream)
+    return d_work[halo * n_out:n * n_out]

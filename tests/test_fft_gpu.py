@@ -225,3 +225,26 @@ print("bit-identical")
     env = dict(os.environ, RSMP_AMD_LIB=exact, PYTHONPATH=root)
     out = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "bit-identical" in out.stdout, out.stdout + out.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("in_hz,out_hz,blocks,world", [(44100, 48000, 101, 4), (48000, 44100, 37, 3)])
+def test_block_sharded_stream_equals_the_single_launch(in_hz, out_hz, blocks, world):
+    """block ranges of one FFT stream on fresh resamplers, each recomputing one block of halo
+    (sharding.run_fft_block_shard), equal the single bulk launch bit for bit."""
+    torch = pytest.importorskip("torch")
+    from resampler_amd import sharding
+    dev = torch.device("cuda:0")
+    mk = lambda: ra.ResamplerFft.new(2, sr(in_hz), sr(out_hz))
+    g = mk()
+    n_in, n_out = g.chunk_size_input(), g.chunk_size_output()
+    x = synth.sweep(blocks * n_in // 2, 2, float(in_hz))
+    d_x = torch.from_numpy(x).to(dev)
+    d_whole = torch.zeros(blocks * n_out, device=dev)
+    g.resample_bulk_device(d_x, d_whole, blocks)
+    for first, end in sharding.fft_block_shards(blocks, world):
+        d_work = torch.zeros((end - first + 1) * n_out, device=dev)
+        d_out = sharding.run_fft_block_shard(mk(), first, end, d_x, d_work)
+        torch.cuda.synchronize()
+        assert d_out.numel() == (end - first) * n_out
+        assert torch.equal(d_out, d_whole[first * n_out:end * n_out]), (first, end)

@@ -441,3 +441,53 @@ def test_non_finite_and_huge_input_match_the_reference(kernel):
     assert big.any() and np.all(np.abs(yg[big] - yr[big]) <= 1e-5 * np.abs(yr[big]))
     small = fin_r & ~big
     assert rms(yg[small], yr[small]) <= RMS_TOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ch,in_hz,out_hz,lat,att,frames,chunk,world", [
+    (8, 96000, 44100, "Sample64", "Db120", 600_000, 512, 4),     # BASELINE config 5's stream, shortened
+    (2, 44100, 48000, "Sample64", "Db90", 300_000, 512, 3),
+    (1, 48000, 44100, "Sample32", "Db90", 100_003, 500, 5),
+])
+def test_time_sharded_stream_equals_the_single_launch(ch, in_hz, out_hz, lat, att, frames, chunk, world):
+    """one long stream cut at call boundaries (sharding.fir_time_shards); every piece starts from the
+    host mirror's state with its halo (ResamplerFir.seek) on a handle of its own -- as it would on its own GPU.
+    Counts and states are those of the single bulk launch; the samples are the same up to the last bit or two
+    (a launch premixes its coefficient rows for the position drift it sees, so two launches over different
+    spans of a stream can round a coefficient differently) and within the 1e-6 RMS gate of the CPU path."""
+    torch = pytest.importorskip("torch")
+    from resampler_amd import sharding
+    dev = torch.device("cuda:0")
+    mk = lambda: ra.ResamplerFir.new_from_hz(ch, in_hz, out_hz, getattr(ra.Latency, lat), getattr(ra.Attenuation, att))
+    x = synth.sweep(frames, ch, float(in_hz))
+    d_x = torch.from_numpy(x).to(dev)
+    whole_h = mk()
+    d_whole = torch.zeros(whole_h.bulk_output_bound(x.size, chunk * ch), device=dev)
+    consumed, produced = whole_h.resample_bulk_device(d_x, d_whole, chunk * ch)
+    assert consumed == x.size
+    shards = sharding.fir_time_shards(in_hz, out_hz, getattr(ra.Latency, lat), frames, chunk, world)
+    assert sum(s.out_frames for s in shards) * ch == produced
+    pieces = []
+    for s in shards:
+        h = mk()
+        d_out = torch.zeros(max(1, s.out_frames) * ch + 64, device=dev)
+        c, p = sharding.run_fir_time_shard(h, s, d_x, d_out, ch, chunk)
+        assert (c, p) == (s.in_frames * ch, s.out_frames * ch), s.rank
+        torch.cuda.synchronize()
+        ref = d_whole[s.out_offset * ch:s.out_offset * ch + p]
+        assert float((d_out[:p] - ref).abs().max()) <= 6e-7, s.rank          # values are below 1: a couple of ulps
+        assert not d_out[p:].any()
+        pieces.append(d_out[:p].cpu().numpy())
+        if s.rank + 1 < world:
+            assert h.state() == shards[s.rank + 1].plan.state()
+        else:
+            assert h.state() == whole_h.state()
+    if ch * frames <= 700_000:   # the CPU path over the whole stream (kept to a few seconds)
+        orc = o.OracleFir(ch, in_hz, out_hz, {"Sample32": 64, "Sample64": 128}[lat], {"Db90": 90, "Db120": 120}[att])
+        y_ref, calls_ref = orc.resample_all(x, chunk * ch)
+        assert int(calls_ref[:, 1].sum()) == produced and y_ref.size == produced
+        assert rms(np.concatenate(pieces), y_ref) <= RMS_TOL
+    # a seek with too little history is refused
+    s = shards[-1]
+    with pytest.raises(ra.ResampleError):
+        mk().seek(s.plan, d_x[:max(0, s.history_frames - 1) * ch])
