@@ -566,7 +566,11 @@ hipError_t launch_fft_ola_wave(const FftPlanDev& plan, const FftStreamDesc* d_de
     const uint32_t C = max_channels;
     typedef void (*Kernel)(FftPlanDev, const FftStreamDesc*, uint32_t, uint32_t, uint32_t);
     Kernel fn;
-    static const int occ = [] { const char* e = getenv("RSMP_FFT_WAVE_OCC"); return e && atoi(e) == 2 ? 2 : 3; }();
+    // Three waves per SIMD (<= 168 registers) where the kernel fits them: the two-channel instantiation.  The
+    // any-channel-count one needs ~250 registers (strided sample addressing) and spilled 290 bytes per lane
+    // under the cap: two waves per SIMD run it 25-30 % faster (tools/fft_channels_bench.py).
+    static const int occ_env = [] { const char* e = getenv("RSMP_FFT_WAVE_OCC"); return e ? atoi(e) : 0; }();
+    const int occ = occ_env == 2 || occ_env == 3 ? occ_env : (C == 2 ? 3 : 2);
     if (occ == 3) {
         if (up) fn = C == 2 ? fft_ola_wave_kernel<W1176, W1280, true, 3> : fft_ola_wave_kernel<W1176, W1280, false, 3>;
         else fn = C == 2 ? fft_ola_wave_kernel<W1280, W1176, true, 3> : fft_ola_wave_kernel<W1280, W1176, false, 3>;
