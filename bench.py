@@ -435,7 +435,10 @@ def bench_c4(ctx: Ctx, args, steps: int, warmup: int):
         "value": round(values_in * steps / dt / 1e6, 1), "unit": "Msamples/s", "n_gpus": ctx.world,
         "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 5),
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": "f32 (exact-f32 MFMA)", "data": "synthetic",
+        "dtype": ("f32 (fp16x2-split products, f32 accumulate)" if ls and ls.split_workgroups() == ls.workgroups()
+                  else "f32 (fp16x2-split products, f32 accumulate; exact-f32 products for %d of %d workgroups)"
+                  % (ls.workgroups() - ls.split_workgroups(), ls.workgroups()) if ls and ls.split_workgroups()
+                  else "f32 (exact-f32 MFMA)"), "data": "synthetic",
         "config": {"workload": f"{n} ResamplerFir streams 2ch 128-tap (Sample64/Db90), pairs 44.1/48/96 kHz "
                                f"(6 ordered), {frames}-frame lock-step steps on carried state, one launch per "
                                f"step and GPU, streams partitioned by predicted work",
@@ -443,7 +446,8 @@ def bench_c4(ctx: Ctx, args, steps: int, warmup: int):
                    "feed": "rccl send/recv scatter-v + gather-v through GPU 0, inside the timed step" if feed
                            else "resident per GPU (no data-path collective)",
                    "host_enqueue_ms_per_step": round(host_dt / steps * 1e3, 5)},
-        "roofline": {"bound": "hbm", "kernel": "fir_lockstep_kernel (exact-f32 MFMA, row = stream)",
+        "roofline": {"bound": "hbm", "kernel": "fir_lockstep_kernel (%s, row = stream)" %
+                               ("fp16x2 MFMA" if ls and ls.split_workgroups() else "exact-f32 MFMA"),
                      "achieved": round(ach, 1), "peak": HBM_PEAK_GBS * ctx.world, "unit": "GB/s",
                      "frac": round(ach / (HBM_PEAK_GBS * ctx.world), 4), "traffic": traffic_from_profiles("c4"),
                      "kernel_ms": round(k_ms, 5), "algorithmic_bytes": int(alg)},

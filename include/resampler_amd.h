@@ -163,6 +163,10 @@ rsmp_fir_lockstep* rsmp_fir_lockstep_new(rsmp_fir* const* rs, size_t n, size_t m
 void rsmp_fir_lockstep_free(rsmp_fir_lockstep* ls);
 size_t rsmp_fir_lockstep_size(const rsmp_fir_lockstep* ls);
 size_t rsmp_fir_lockstep_workgroups(const rsmp_fir_lockstep* ls);   /* diagnostic: workgroups per step */
+/* ... and how many of them use split operands on the fp16 matrix cores (two-channel streams in
+ * RSMP_FIR_KERNEL_AUTO; the others keep every product in f32: other channel counts, streams set to another
+ * kernel mode with rsmp_fir_set_kernel before the batch was made, geometries whose image does not fit). */
+size_t rsmp_fir_lockstep_split_workgroups(const rsmp_fir_lockstep* ls);
 int rsmp_fir_lockstep_bind(rsmp_fir_lockstep* ls, const float* const* d_in, float* const* d_out,
                            const size_t* out_caps);
 /* d_in_frames: optional DEVICE array of frames offered per stream (in the order of `rs`; NULL = in_frames

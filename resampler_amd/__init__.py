@@ -137,6 +137,7 @@ _SIGNATURES = [
     ("rsmp_fir_lockstep_step", C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p]),
     ("rsmp_fir_lockstep_counts", C.c_int, [C.c_void_p, _szp, _szp]),
     ("rsmp_fir_lockstep_status", C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
+    ("rsmp_fir_lockstep_split_workgroups", C.c_size_t, [C.c_void_p]),
     ("rsmp_fir_lockstep_sync", C.c_int, [C.c_void_p]),
     ("rsmp_fir_lockstep_reset", C.c_int, [C.c_void_p]),
     ("rsmp_fir_lockstep_set_profiling", C.c_int, [C.c_void_p, C.c_int]),
@@ -468,6 +469,10 @@ class FirLockstep:
 
     def workgroups(self) -> int:
         return lib().rsmp_fir_lockstep_workgroups(self._h)
+
+    def split_workgroups(self) -> int:
+        """Workgroups per step that run on the fp16 matrix cores with split operands (two-channel streams)."""
+        return lib().rsmp_fir_lockstep_split_workgroups(self._h)
 
     def bind(self, d_ins, d_outs) -> None:
         self._keep = (list(d_ins), list(d_outs))

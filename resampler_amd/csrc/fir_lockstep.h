@@ -7,9 +7,12 @@
 // (read_position / available_frames / position, resampler_fir.rs:189-192), their buffered frames, their
 // buffer pointers.  One step is ONE kernel launch with constant arguments; the kernel runs the
 // reference's control flow itself (fir_mirror_core.h, one lane per stream), stages every stream's
-// [buffered | new] frames in LDS, computes the outputs on the f32 matrix cores with "row = stream"
+// [buffered | new] frames in LDS, computes the outputs on the matrix cores with "row = stream"
 // (the 16 columns of a tile are (stream, period) pairs, so short steps of many streams fill the
 // tiles), retires the consumed frames and writes (consumed, produced) per stream to HBM.
+// Two-channel streams use the arithmetic of fir_split.hip (operands cut into two fp16 planes, three
+// v_mfma_f32_16x16x32_f16 products per term, f32 accumulation): 5x less matrix-pipe time than exact f32
+// products, which stay available (rsmp_fir_set_kernel(.., RSMP_FIR_KERNEL_PERIODIC_F32), other channel counts).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -31,7 +34,8 @@ constexpr uint32_t kLsLdsLimit = 160 * 1024;
 struct LockstepStream {        // per bound stream, constant between binds (HBM)
     const float* in;           // a step reads in + in_offset, in_frames frames
     float* out;
-    float* hist;               // frames buffered between steps (interleaved), updated in place
+    float* hist;               // frames buffered between steps (interleaved): a step with an even index reads
+    float* hist_alt;           // `hist` and leaves its tail in `hist_alt`, an odd one the other way round
     const float* coeffs;       // [1024][taps] polyphase table
     uint64_t out_cap_frames;   // room of `out` per step, in frames
 };
@@ -54,6 +58,9 @@ struct LockstepGroup {         // one workgroup's share: `count` streams of one 
     const TileMeta* class_meta;
     uint32_t lds_bytes;        // what this group needs
     uint32_t slots;            // streams per workgroup the LDS layout is sized for (>= count)
+    uint32_t split;            // 1: two-channel streams on the fp16 matrix cores with split operands (fir_split.hip's
+                               //    arithmetic): class_coef is the split table, the LDS holds a transposed fp16 image
+    uint32_t rows;             // split: rows (frames) of the image: last tile's window start + row_len
 };
 
 struct LockstepArgs {
@@ -68,6 +75,7 @@ struct LockstepArgs {
     uint64_t in_offset;                   // frames added to every stream's `in`
     uint32_t in_frames;                   // frames offered to every stream (when the array is null)
     uint32_t append;                      // 1: a step's output goes to out + out_cursor; 0: to out
+    uint32_t in_aligned8;                 // every two-channel stream's `in` is 8-byte aligned (split variant: 8-byte loads)
     unsigned long long* trace;            // diagnostic instantiation only (RSMP_LS_TRACE), else null
     // Plans are computed one step AHEAD: while the other waves of a workgroup compute step k, its first
     // wave runs the state machine for step k + 1 (assuming the same number of frames will be offered) and
@@ -102,11 +110,16 @@ struct LockstepGeometry {
     uint32_t guard_frames = 0, span_frames = 0, region_frames = 0, max_out = 0, cols_per_stream = 0;
     uint32_t slots = 1;        // streams per workgroup
     uint32_t wrap_words = 0, wrap_cap = 0, max_cols = 0, lds_bytes = 0;
+    bool split = false;        // fp16x2 split operands (two-channel streams, unless exact f32 products are asked for)
+    uint32_t rows = 0;         // split: rows of the LDS image
 };
+// allow_split = false: exact-f32 products (RSMP_FIR_KERNEL_PERIODIC_F32 on the streams, or RSMP_LS_EXACT=1).
 LockstepGeometry lockstep_geometry(uint64_t num, uint64_t den, double ratio, uint32_t taps,
-                                   uint32_t channels, uint32_t step_frames);
-// The PeriodicGeometry view of it that build_class_table understands (f32 matrix-core layout).
+                                   uint32_t channels, uint32_t step_frames, bool allow_split = true);
+// The PeriodicGeometry view of it that build_class_table understands (f32 matrix-core layout, or the split
+// kernel's fp16x2 layout).
 PeriodicGeometry lockstep_class_geometry(const LockstepGeometry& g);
+constexpr uint32_t kLsImageRowBytes = 160;   // split image: (2 channels x 2 planes) x 32 B + 32 B of padding (fir_split.hip)
 
 hipError_t launch_fir_lockstep(const LockstepArgs& args, uint32_t n_groups, uint32_t max_lds_bytes,
                                hipStream_t stream);

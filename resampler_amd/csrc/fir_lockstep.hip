@@ -39,6 +39,18 @@ typedef const float __attribute__((address_space(1)))* gconst_f32_ptr;
 typedef const v4f __attribute__((address_space(1)))* gconst_f4_ptr;
 typedef float __attribute__((address_space(1)))* g_f32_ptr;
 typedef const uint32_t __attribute__((address_space(4)))* const_u32_ptr;
+// split variant (the operand types and scales of fir_split.hip)
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef const v4u __attribute__((address_space(1)))* gconst_u4_ptr;
+typedef const v2f __attribute__((address_space(1)))* gconst_f2_ptr;
+typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+constexpr float kLsXScale = 4096.0f;                               // samples: 2^12 (taps: 2^13, in the table)
+constexpr float kLsOutScale = 1.0f / (4096.0f * 8192.0f);
+constexpr uint32_t kLsMaxK32 = 6;                                  // 32-tap steps of a tile window (row_len <= 192)
 
 template <class T>
 __device__ __forceinline__ T load_uniform(const T* p) {   // wave-uniform POD through the scalar cache
@@ -82,18 +94,25 @@ struct SegLds {
 };
 
 struct LsLayout {
-    uint32_t cols, segs, wbits, wlist, spans, total;   // byte offsets
+    uint32_t ptrs, colsrc, cols, segs, wbits, wlist, spans, total;   // byte offsets
 };
+// data_bytes: the spans of the streams (slots x region_frames x channels f32) or the split image (rows x 160 B)
 __host__ __device__ inline LsLayout ls_layout(uint32_t slots, uint32_t max_cols, uint32_t wrap_words,
-                                              uint32_t wrap_cap, uint32_t region_frames, uint32_t channels) {
+                                              uint32_t wrap_cap, uint32_t data_bytes) {
     LsLayout l;
-    l.cols = kLsMaxSlots * 64 + 16 + kLsMaxSlots * 96;            // PlanLds[16], n_cols + 3 spare words, state stash[16]
+    l.ptrs = kLsMaxSlots * 64 + 16 + kLsMaxSlots * 96;            // PlanLds[16], n_cols + 3 words, state stash[16]
+    l.colsrc = l.ptrs + kLsMaxSlots * 32;                         // (hist, in, hist_next) pointers per slot
+    l.cols = l.colsrc + 16 * 32;                                  // split: where each of the 16 columns' frames come from
     l.segs = (l.cols + max_cols * 16 + 7) & ~7u;
     l.wbits = l.segs + slots * kLsSegCap * 24;
     l.wlist = l.wbits + slots * wrap_words * 4;
     l.spans = (l.wlist + slots * wrap_cap * 4 + 15) & ~15u;
-    l.total = l.spans + slots * region_frames * channels * 4;
+    l.total = l.spans + data_bytes;
     return l;
+}
+__host__ __device__ inline uint32_t ls_data_bytes(bool split, uint32_t rows, uint32_t slots, uint32_t region_frames,
+                                                  uint32_t channels) {
+    return split ? rows * kLsImageRowBytes : slots * region_frames * channels * 4u;
 }
 
 // mirror_call sink writing into LDS.
@@ -160,6 +179,73 @@ __device__ __forceinline__ void unit_mfma(const v4f (&a_reg)[kLsMaxBlk], uint32_
     }
 }
 
+// ---- split variant (two fp16 planes per f32 operand: fir_split.hip's arithmetic and image layout) --------
+// f32 pair -> fp16 pair (round to nearest, one v_cvt_pk_f16_f32): low half = a, high half = b
+__device__ __forceinline__ uint32_t ls_cvt_pk_f16(float a, float b) {
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v2f{a, b}, f16x2));
+}
+__device__ __forceinline__ float ls_f16_lo(uint32_t w) { return static_cast<float>(__builtin_bit_cast(f16x2, w)[0]); }
+__device__ __forceinline__ float ls_f16_hi(uint32_t w) { return static_cast<float>(__builtin_bit_cast(f16x2, w)[1]); }
+
+// The MFMA stream of one unit on the image: row r of the image holds frame r of every column (a column's
+// frame 0 is its super period's first frame), per row four 32-byte plane rows (channel 0 high / low plane,
+// channel 1 high / low plane: 16 columns x 16 bits, 8-byte chunks XOR-swizzled by the row) + 32 bytes of
+// padding.  A tile's window starts at row `base_row`: ds_read_b64_tr_b16 delivers 4 consecutive frames of
+// the lane's column, the B operand of v_mfma_f32_16x16x32_f16 being two of those (frames 32 s + 4 grp .. and
+// 32 s + 16 + 4 grp ..), in the order the split table (split_store_class) holds the taps.  Per 32 taps:
+// c1 x2 + c2 x1 + c1 x1, smallest products first (fir_split.hip).
+template <uint32_t NK>   // 32-tap steps of the tile window: compile-time, so that step s + 1's reads are in flight under step s's MFMAs
+__device__ __forceinline__ void unit_mfma_split_nk(const v4f (&a_reg)[kLsMaxBlk], char* lds, uint32_t image_off,
+                                                   uint32_t base_row, uint32_t lane, v4f& acc0, v4f& acc1) {
+    const uint32_t grp = lane >> 4, q = (lane >> 2) & 3, pc = lane & 3;
+    const uint32_t row0 = base_row + 4 * grp + q;
+    const uint32_t base = image_off + row0 * kLsImageRowBytes + ((pc ^ ((row0 >> 2) & 3)) << 3);
+    auto frag = [&](uint32_t plane_ch, uint32_t s) -> f16x8 {
+        const uint32_t addr = base + plane_ch * 32u + s * (32u * kLsImageRowBytes);
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(lds + addr));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(lds + addr + 16u * kLsImageRowBytes));
+        return __builtin_bit_cast(f16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+#pragma unroll
+    for (uint32_t s = 0; s < NK; ++s) {
+        const f16x8 c1 = __builtin_bit_cast(f16x8, a_reg[2 * s]), c2 = __builtin_bit_cast(f16x8, a_reg[2 * s + 1]);
+        const f16x8 x1 = frag(0, s), x2 = frag(1, s), y1 = frag(2, s), y2 = frag(3, s);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(c1, x2, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(c1, y2, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(c2, x1, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(c2, y1, acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(c1, x1, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(c1, y1, acc1, 0, 0, 0);
+    }
+    acc0 *= kLsOutScale;
+    acc1 *= kLsOutScale;
+}
+__device__ __forceinline__ void unit_mfma_split(const v4f (&a_reg)[kLsMaxBlk], uint32_t nk, char* lds, uint32_t image_off,
+                                                uint32_t base_row, uint32_t lane, v4f& acc0, v4f& acc1) {
+    switch (nk) {   // (workgroup-uniform)
+        case 1: unit_mfma_split_nk<1>(a_reg, lds, image_off, base_row, lane, acc0, acc1); break;
+        case 2: unit_mfma_split_nk<2>(a_reg, lds, image_off, base_row, lane, acc0, acc1); break;
+        case 3: unit_mfma_split_nk<3>(a_reg, lds, image_off, base_row, lane, acc0, acc1); break;
+        case 4: unit_mfma_split_nk<4>(a_reg, lds, image_off, base_row, lane, acc0, acc1); break;
+        case 5: unit_mfma_split_nk<5>(a_reg, lds, image_off, base_row, lane, acc0, acc1); break;
+        default: unit_mfma_split_nk<kLsMaxK32>(a_reg, lds, image_off, base_row, lane, acc0, acc1); break;
+    }
+}
+
+// Frame f (relative to the first buffered frame) of a stream's [buffered | new] frames, channel c: from the
+// LDS span (zeroed guards around it), or -- split variant, which keeps no f32 copy in LDS -- from HBM.
+struct SpanView {
+    const float* lds_span;       // f32 variant: frame 0 of the span in LDS
+    const float* hist;           // split variant
+    const float* in;
+    uint32_t hist_frames, span_frames, C;
+    __device__ __forceinline__ float at(int64_t f, uint32_t c) const {
+        if (lds_span) return lds_span[f * static_cast<int64_t>(C) + c];
+        if (f < 0 || f >= static_cast<int64_t>(span_frames)) return 0.f;
+        return f < static_cast<int64_t>(hist_frames) ? hist[f * C + c] : in[(f - hist_frames) * C + c];
+    }
+};
+
 // TRACE: diagnostic instantiation (RSMP_LS_TRACE=path): per workgroup the shader clock at the phase
 // boundaries of wave 0 and of wave 1 goes to args.trace; the shipping instantiation has no trace code.
 template <bool TRACE>
@@ -172,7 +258,13 @@ __global__ __launch_bounds__(kLsWaves * 64, kLsWaves / 2) void fir_lockstep_kern
     const uint32_t C = g.channels;
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const LsLayout lay = ls_layout(g.slots, g.max_cols, g.wrap_words, g.wrap_cap, g.region_frames, C);
+    const bool split = g.split != 0;   // (workgroup-uniform)
+    const LsLayout lay = ls_layout(g.slots, g.max_cols, g.wrap_words, g.wrap_cap,
+                                   ls_data_bytes(split, g.rows, g.slots, g.region_frames, C));
+    struct SlotPtrs { const float* hist; const float* in; float* hist_next; uint64_t pad; };   // this step's buffered frames, its new frames, where its tail goes
+    SlotPtrs* ptrs = reinterpret_cast<SlotPtrs*>(lds + lay.ptrs);   // split: the streams' frames are read from HBM
+    struct ColSrc { const float* hist; const float* in; int32_t frame0; uint32_t hist_frames, span_frames, pad; };   // 32 B
+    ColSrc* colsrc = reinterpret_cast<ColSrc*>(lds + lay.colsrc);
     PlanLds* plan = reinterpret_cast<PlanLds*>(lds);
     uint32_t* n_cols_p = reinterpret_cast<uint32_t*>(lds + kLsMaxSlots * 64);
     FirMirrorState* stash = reinterpret_cast<FirMirrorState*>(lds + kLsMaxSlots * 64 + 16);   // new states until every reader of the old ones is done
@@ -259,12 +351,15 @@ __global__ __launch_bounds__(kLsWaves * 64, kLsWaves / 2) void fir_lockstep_kern
             pl.out = ls.out + cursor;
             plan[lane] = pl;
             stash[lane] = st;
+            ptrs[lane] = SlotPtrs{(args.step & 1u) ? ls.hist_alt : ls.hist, ls.in + args.in_offset * C,
+                                  (args.step & 1u) ? ls.hist : ls.hist_alt, 0};
             args.counts[2 * gs] = static_cast<uint64_t>(pl.accepted) * C;
             args.counts[2 * gs + 1] = static_cast<uint64_t>(pl.n_out) * C;
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        // the lanes of this wave read each other's PlanLds next: LDS operations of a wave complete in order, so
+        // only the compiler has to keep the order (a release fence would also wait for the stores to HBM above)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         if constexpr (TRACE) tr[1] = __builtin_amdgcn_s_memtime();   // planned
         // The column table: every (stream, super period) pair with outputs in this step.  Each planner
         // lane places its own stream's columns behind those of the lanes before it.
@@ -283,6 +378,9 @@ __global__ __launch_bounds__(kLsWaves * 64, kLsWaves / 2) void fir_lockstep_kern
             if (s < lane) before += n;
             total += n;
         }
+        // (split: what the staging waves need per column goes to a flat table -- no chain of dependent LDS reads
+        // there; a column without a stream has no frames and a history pointer that can be dereferenced)
+        if (split && lane < 16) colsrc[lane] = ColSrc{ptrs[0].hist, ptrs[0].in, 0, 0u, 0u, 0u};
         if (lane < g.count) {
             const PlanLds& pl = plan[lane];
             for (uint32_t i = 0; i < my_cols && before + i < g.max_cols; ++i) {
@@ -293,13 +391,17 @@ __global__ __launch_bounds__(kLsWaves * 64, kLsWaves / 2) void fir_lockstep_kern
                 cl.slot = lane;
                 cl.pad = 0;
                 cols[before + i] = cl;
+                if (split)
+                    colsrc[before + i] = ColSrc{ptrs[lane].hist, ptrs[lane].in, cl.frame0, pl.hist_frames,
+                                                pl.hist_frames + pl.accepted, 0u};
             }
         }
         if (lane == 0) {
             n_cols_p[0] = total < g.max_cols ? total : g.max_cols;
             n_cols_p[1] = 0;   // unit counter
+            n_cols_p[2] = 0;   // split: waves that have written their share of the image
         }
-    } else {
+    } else if (!split) {
         // Stage [buffered | new] of every stream with LDS-DMA (global_load_lds, 256 B per wave instruction,
         // no VGPR round trip: every piece of every stream is in flight at once); everything else of the
         // region is zeroed (the guards are read by masked columns and by zero padding coefficients: they
@@ -325,7 +427,7 @@ __global__ __launch_bounds__(kLsWaves * 64, kLsWaves / 2) void fir_lockstep_kern
             if (acc > kMirrorInputCapacity - avail) acc = kMirrorInputCapacity - avail;
             my_hist_dw = static_cast<uint32_t>(avail) * C;
             my_span_dw = my_hist_dw + static_cast<uint32_t>(acc) * C;
-            my_hist = reinterpret_cast<unsigned long long>(args.streams[gs].hist);
+            my_hist = reinterpret_cast<unsigned long long>((args.step & 1u) ? args.streams[gs].hist_alt : args.streams[gs].hist);
             my_in = reinterpret_cast<unsigned long long>(args.streams[gs].in + args.in_offset * C);
         }
         const uint32_t guard_dw = g.guard_frames * C;
@@ -390,13 +492,95 @@ __global__ __launch_bounds__(kLsWaves * 64, kLsWaves / 2) void fir_lockstep_kern
         *reinterpret_cast<LsPlanHeader*>(nrec) = hd;
     }
 
-    // ---- B: retire (tail back to HBM, in place) -------------------------------------------------
+    // ---- split variant: the image (waves 1..; wave 0 is planning the next step) -----------------------
+    // Entry (row r, column c) = frame frame0(c) + r of the column's stream, cut into two fp16 planes of
+    // 2^12 x (x * 2^12 = h1 + h2 + r, |r| <= 2^-22 |x|); frames outside the stream's [buffered | new] span and
+    // unused columns are zero.  Lanes run along the rows: a wave instruction reads 64 consecutive frames.
+    const uint32_t image_off = lay.spans;
+    if (split && wave != 0 && *n_cols_p != 0) {
+        const bool aligned8 = args.in_aligned8 != 0;
+        uint32_t src[8];   // lane c < 16: column c's ColSrc
+        {
+            const uint32_t* cs = reinterpret_cast<const uint32_t*>(colsrc) + (lane & 15) * 8;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) src[k] = cs[k];
+            // pinned here, where every lane is active: v_readlane below reads lanes 0..15 whatever the loop's
+            // EXEC mask is, and a wave's last row block may have fewer than 16 rows (the compiler sank the loads
+            // into the loop: lanes without a row then never loaded their column)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) asm volatile("" : "+v"(src[k]));
+        }
+        for (uint32_t r = threadIdx.x - 64; r < g.rows; r += (kLsWaves - 1) * 64) {
+            // every column's frame of this row is requested before the first is converted: one memory
+            // latency per row block, not one per column
+            float x0[16], x1[16];
+            bool ok[16];
+#pragma unroll
+            for (uint32_t c = 0; c < 16; ++c) {
+                // branch-free: an entry outside its stream's frames (or of an unused column) loads the first
+                // buffered value instead and drops it -- a guarded load would end the run of loads in flight.
+                // Column c's description sits in lane c of `src` and is the same for every lane: scalar registers.
+                auto word = [&](int k) -> uint32_t { return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(src[k]), c)); };
+                gconst_f32_ptr hist = (gconst_f32_ptr) reinterpret_cast<const float*>((static_cast<uint64_t>(word(1)) << 32) | word(0));
+                gconst_f32_ptr in = (gconst_f32_ptr) reinterpret_cast<const float*>((static_cast<uint64_t>(word(3)) << 32) | word(2));
+                const int32_t frame0 = static_cast<int32_t>(word(4));
+                const uint32_t hist_fr = word(5), span_fr = word(6);
+                const int32_t f = frame0 + static_cast<int32_t>(r);
+                ok[c] = f >= 0 && static_cast<uint32_t>(f) < span_fr;
+                const uint32_t fu = ok[c] ? static_cast<uint32_t>(f) : 0u;
+                gconst_f32_ptr p = fu < hist_fr ? hist + 2 * fu : in + 2 * (fu - hist_fr);
+                if (!ok[c]) p = hist;   // (the history buffer always exists)
+                if (aligned8) {   // (uniform) one 8-byte load per frame: half the load instructions of the phase
+                    const v2f v = *(gconst_f2_ptr)p;
+                    x0[c] = v.x;
+                    x1[c] = v.y;
+                } else {
+                    x0[c] = p[0];
+                    x1[c] = p[1];
+                }
+            }
+#pragma unroll
+            for (uint32_t c = 0; c < 16; ++c) {
+                x0[c] = ok[c] ? x0[c] : 0.f;
+                x1[c] = ok[c] ? x1[c] : 0.f;
+            }
+            char* row = lds + image_off + r * kLsImageRowBytes;
+            const uint32_t sw = (r >> 2) & 3;
+#pragma unroll
+            for (uint32_t c = 0; c < 16; ++c) {
+                const float s0 = x0[c] * kLsXScale, s1 = x1[c] * kLsXScale;
+                const uint32_t hi = ls_cvt_pk_f16(s0, s1);
+                const uint32_t lo = ls_cvt_pk_f16(s0 - ls_f16_lo(hi), s1 - ls_f16_hi(hi));
+                char* e = row + ((((c >> 2) ^ sw) << 3) + (c & 3) * 2);
+                *reinterpret_cast<uint16_t*>(e) = static_cast<uint16_t>(hi);            // channel 0, high plane
+                *reinterpret_cast<uint16_t*>(e + 32) = static_cast<uint16_t>(lo);       // channel 0, low plane
+                *reinterpret_cast<uint16_t*>(e + 64) = static_cast<uint16_t>(hi >> 16);  // channel 1, high plane
+                *reinterpret_cast<uint16_t*>(e + 96) = static_cast<uint16_t>(lo >> 16);  // channel 1, low plane
+            }
+        }
+        // one count per wave: its share of the image is in LDS when the count becomes visible
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) (void)__hip_atomic_fetch_add(n_cols_p + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if constexpr (TRACE) tr[1] = __builtin_amdgcn_s_memtime();   // (staging waves: their share of the image written)
+    }
+
+    // ---- B: retire: the still-buffered tail goes to the front of the stream's OTHER history buffer (the
+    // next step reads that one: nothing of this step reads what is written here, so no ordering is needed)
     for (uint32_t s = 0; s < g.count; ++s) {
         const PlanLds& pl = plan[s];
         const uint32_t tail_dw = pl.tail_frames * C;
-        const float* src = spans + s * region_dw + (g.guard_frames + pl.consumed) * C;
-        g_f32_ptr dst = (g_f32_ptr)args.streams[g.first + s].hist;
-        for (uint32_t i = threadIdx.x; i < tail_dw; i += kLsWaves * 64) dst[i] = src[i];
+        g_f32_ptr dst = (g_f32_ptr)ptrs[s].hist_next;
+        if (!split) {
+            const float* src = spans + s * region_dw + (g.guard_frames + pl.consumed) * C;
+            for (uint32_t i = threadIdx.x; i < tail_dw; i += kLsWaves * 64) dst[i] = src[i];
+        } else {
+            const uint32_t hist_dw = pl.hist_frames * C, first = pl.consumed * C;
+            gconst_f32_ptr hist = (gconst_f32_ptr)ptrs[s].hist, in = (gconst_f32_ptr)ptrs[s].in;
+            for (uint32_t i = threadIdx.x; i < tail_dw; i += kLsWaves * 64) {
+                const uint32_t e = first + i;
+                dst[i] = e < hist_dw ? hist[e] : in[e - hist_dw];
+            }
+        }
     }
 
     // ---- B: matrix-core units (16 columns x one 16-class tile) ------------------------------------
@@ -405,6 +589,9 @@ __global__ __launch_bounds__(kLsWaves * 64, kLsWaves / 2) void fir_lockstep_kern
         const uint32_t n_chunks = (n_cols + 15) / 16;
         const uint32_t n_units = n_chunks * g.n_tiles;
         const bool pair_ok = (C & 1u) == 0;   // both channels of a frame with one 8-byte LDS read
+        if (split)   // the image is complete once the seven staging waves have counted in
+            while (__hip_atomic_load(n_cols_p + 2, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < kLsWaves - 1)
+                __builtin_amdgcn_s_sleep(1);
         // units are claimed from an LDS counter: the first wave joins late (it has planned the next step)
         for (;;) {
             uint32_t u_claim = 0;
@@ -415,7 +602,7 @@ __global__ __launch_bounds__(kLsWaves * 64, kLsWaves / 2) void fir_lockstep_kern
             if constexpr (TRACE) ts0 = __builtin_amdgcn_s_memtime();
             const uint32_t chunk = u / g.n_tiles;
             const uint32_t t = u - chunk * g.n_tiles;
-            const TileMeta tm = load_uniform(g.class_meta + t);
+            const uint32_t tile_base = static_cast<uint32_t>((static_cast<uint64_t>(t) * 16u * g.a) / g.b);   // TileMeta::base = class_offset(16 t)
             const uint32_t col = chunk * 16 + (lane & 15);
             const bool on = col < n_cols;
             const ColLds cl = cols[on ? col : chunk * 16];
@@ -424,7 +611,7 @@ __global__ __launch_bounds__(kLsWaves * 64, kLsWaves / 2) void fir_lockstep_kern
             const uint32_t* bits = wbits + cl.slot * g.wrap_words;
             const float* xb = spans + cl.slot * region_dw +
                               static_cast<int32_t>(static_cast<int32_t>(g.guard_frames) + cl.frame0 +
-                                                   static_cast<int32_t>(tm.base) + static_cast<int32_t>(lane >> 4)) *
+                                                   static_cast<int32_t>(tile_base) + static_cast<int32_t>(lane >> 4)) *
                                   static_cast<int32_t>(C);
             fetch_tile(t);
             if constexpr (TRACE) {
@@ -437,7 +624,9 @@ __global__ __launch_bounds__(kLsWaves * 64, kLsWaves / 2) void fir_lockstep_kern
             for (uint32_t c0 = 0; c0 < C; c0 += 2) {
                 const bool two = c0 + 1 < C;
                 v4f acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-                if (two && pair_ok) {
+                if (split) {
+                    unit_mfma_split(a_reg, g.row_len / 32, lds, image_off, tile_base, lane, acc0, acc1);
+                } else if (two && pair_ok) {
                     unit_mfma<2>(a_reg, nblk, xb + c0, C, acc0, acc1);
                 } else {
                     v4f unused = {0.f, 0.f, 0.f, 0.f};
@@ -494,7 +683,63 @@ __global__ __launch_bounds__(kLsWaves * 64, kLsWaves / 2) void fir_lockstep_kern
 
     if constexpr (TRACE) tr[4] = __builtin_amdgcn_s_memtime();   // units done
     // ---- C: outputs just below an integer position: previous frame, row 1023, frac 0 ----------------
-    {
+    if (split) {
+        // The frames come from HBM here: every load of an output (its 128 taps x 2 channels over 8 lanes) is
+        // requested before the first multiply, and the wraps of all streams form one list -- one memory
+        // latency for the whole phase.  Same sums in the same order as the f32 variant below.
+        const uint32_t grp = threadIdx.x >> 3, ngrp = kLsWaves * 8, gl = threadIdx.x & 7;
+        uint32_t total = 0;
+        for (uint32_t s = 0; s < g.count; ++s)
+            if (!(plan[s].flags & kFlagReference)) total += plan[s].n_wraps;
+        for (uint32_t item = grp; item < (total + ngrp - 1) / ngrp * ngrp; item += ngrp) {
+            const bool live = item < total;
+            uint32_t s = 0, e = live ? item : 0;
+            for (; s + 1 < g.count; ++s) {
+                const uint32_t nw = (plan[s].flags & kFlagReference) ? 0u : plan[s].n_wraps;
+                if (e < nw) break;
+                e -= nw;
+            }
+            const PlanLds& pl = plan[s];
+            const uint32_t n = live ? wlist[s * g.wrap_cap + e] : 0;
+            const uint64_t m = pl.abs_out + n;
+            const int64_t v0 = static_cast<int64_t>((m / g.den) * g.num) - 1 - static_cast<int64_t>(pl.abs_consumed);
+            const float4* row = reinterpret_cast<const float4*>(args.streams[g.first + s].coeffs + static_cast<size_t>(1023) * g.taps);
+            gconst_f32_ptr hist = (gconst_f32_ptr)ptrs[s].hist, in = (gconst_f32_ptr)ptrs[s].in;
+            const int64_t hist_fr = pl.hist_frames, span_fr = pl.hist_frames + pl.accepted;
+            float4 k[4];
+            float x[4][4][2];
+#pragma unroll
+            for (uint32_t it = 0; it < 4; ++it) {
+                const uint32_t q = gl + 8 * it;
+                const bool have = live && q < g.taps / 4;
+                k[it] = have ? row[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (uint32_t j = 0; j < 4; ++j) {
+                    const int64_t f = v0 + 4 * q + j;
+                    const bool ok = have && f >= 0 && f < span_fr;
+                    const int64_t fc = ok ? f : hist_fr;   // (a frame that exists whenever any does: in[0])
+                    gconst_f32_ptr p = fc < hist_fr ? hist + 2 * fc : in + 2 * (fc - hist_fr);
+                    const float a0 = ok ? p[0] : 0.f, a1 = ok ? p[1] : 0.f;
+                    x[it][j][0] = a0;
+                    x[it][j][1] = a1;
+                }
+            }
+#pragma unroll
+            for (uint32_t c = 0; c < 2; ++c) {
+                float a = 0.f;
+#pragma unroll
+                for (uint32_t it = 0; it < 4; ++it)
+                    if (gl + 8 * it < g.taps / 4) {
+                        a = fmaf(k[it].x, x[it][0][c], a);
+                        a = fmaf(k[it].y, x[it][1][c], a);
+                        a = fmaf(k[it].z, x[it][2][c], a);
+                        a = fmaf(k[it].w, x[it][3][c], a);
+                    }
+                a = group_sum8(a);
+                if (live && gl == 0) pl.out[static_cast<size_t>(n) * 2 + c] = a;
+            }
+        }
+    } else {
         const uint32_t grp = threadIdx.x >> 3, ngrp = kLsWaves * 8, gl = threadIdx.x & 7;
         for (uint32_t s = 0; s < g.count; ++s) {
             const PlanLds& pl = plan[s];
@@ -503,7 +748,8 @@ __global__ __launch_bounds__(kLsWaves * 64, kLsWaves / 2) void fir_lockstep_kern
             if (nw == 0) continue;
             const float4* row = reinterpret_cast<const float4*>(args.streams[g.first + s].coeffs +
                                                                 static_cast<size_t>(1023) * g.taps);
-            const float* span = spans + s * region_dw + g.guard_frames * C;
+            const SpanView sv{split ? nullptr : spans + s * region_dw + g.guard_frames * C, ptrs[s].hist, ptrs[s].in,
+                              pl.hist_frames, pl.hist_frames + pl.accepted, C};
             for (uint32_t e = grp; e < (nw + ngrp - 1) / ngrp * ngrp; e += ngrp) {
                 const bool live = e < nw;
                 const uint32_t n = live ? wlist[s * g.wrap_cap + e] : 0;
@@ -515,11 +761,11 @@ __global__ __launch_bounds__(kLsWaves * 64, kLsWaves / 2) void fir_lockstep_kern
                     if (live)
                         for (uint32_t q = gl; q < g.taps / 4; q += 8) {
                             const float4 k = row[q];
-                            const float* x = span + (v0 + 4 * q) * static_cast<int64_t>(C) + c;
-                            a = fmaf(k.x, x[0], a);
-                            a = fmaf(k.y, x[C], a);
-                            a = fmaf(k.z, x[2 * C], a);
-                            a = fmaf(k.w, x[3 * C], a);
+                            const int64_t f = v0 + 4 * q;
+                            a = fmaf(k.x, sv.at(f, c), a);
+                            a = fmaf(k.y, sv.at(f + 1, c), a);
+                            a = fmaf(k.z, sv.at(f + 2, c), a);
+                            a = fmaf(k.w, sv.at(f + 3, c), a);
                         }
                     a = group_sum8(a);
                     if (live && gl == 0) pl.out[static_cast<size_t>(n) * C + c] = a;
@@ -539,7 +785,8 @@ __global__ __launch_bounds__(kLsWaves * 64, kLsWaves / 2) void fir_lockstep_kern
             const PlanLds& pl = plan[s];
             if (!(pl.flags & (kFlagReference | kFlagNonFinite)) || pl.n_out == 0) continue;
             const float* coeffs = args.streams[g.first + s].coeffs;
-            const float* span = spans + s * region_dw + g.guard_frames * C;
+            const SpanView sv{split ? nullptr : spans + s * region_dw + g.guard_frames * C, ptrs[s].hist, ptrs[s].in,
+                              pl.hist_frames, pl.hist_frames + pl.accepted, C};
             const SegLds* sg = static_cast<const SegLds*>(pl.runs);
             const uint32_t n_round = (pl.n_out + ngrp - 1) / ngrp * ngrp;
             for (uint32_t n = grp; n < n_round; n += ngrp) {
@@ -567,8 +814,8 @@ __global__ __launch_bounds__(kLsWaves * 64, kLsWaves / 2) void fir_lockstep_kern
                         for (uint32_t q = gl; q < g.taps / 4; q += 8) {
                             const float4 k1 = row1[q];
                             const float4 k2 = row2[q];
-                            const float* x = span + (v0 + 4 * q) * static_cast<int64_t>(C) + c;
-                            const float x0 = x[0], x1 = x[C], x2 = x[2 * C], x3 = x[3 * C];
+                            const int64_t f = v0 + 4 * q;
+                            const float x0 = sv.at(f, c), x1 = sv.at(f + 1, c), x2 = sv.at(f + 2, c), x3 = sv.at(f + 3, c);
                             a1 = fmaf(k1.x, x0, a1); a2 = fmaf(k2.x, x0, a2);
                             a1 = fmaf(k1.y, x1, a1); a2 = fmaf(k2.y, x1, a2);
                             a1 = fmaf(k1.z, x2, a1); a2 = fmaf(k2.z, x2, a2);
@@ -601,7 +848,8 @@ __global__ __launch_bounds__(kLsWaves * 64, kLsWaves / 2) void fir_lockstep_kern
 }  // namespace
 
 LockstepGeometry lockstep_geometry(uint64_t num, uint64_t den, double ratio, uint32_t taps,
-                                   uint32_t channels, uint32_t step_frames) {
+                                   uint32_t channels, uint32_t step_frames, bool allow_split) {
+    static const bool exact_knob = [] { const char* e = getenv("RSMP_LS_EXACT"); return e && atoi(e) != 0; }();
     LockstepGeometry g;
     g.taps = taps;
     g.num = static_cast<uint32_t>(num);
@@ -625,8 +873,11 @@ LockstepGeometry lockstep_geometry(uint64_t num, uint64_t den, double ratio, uin
         const uint32_t want = periodic ? std::max(1u, 16u / g.cols_per_stream) : 4u;
         for (uint32_t s = std::min(want, kLsMaxSlots); s >= 1; --s) {
             const uint32_t bytes = ls_layout(s, s * g.cols_per_stream, g.wrap_words, g.wrap_cap,
-                                             g.region_frames, channels).total;
-            if (bytes <= (s > 1 ? 64u * 1024u : kLsLdsLimit)) {
+                                             ls_data_bytes(g.split, g.rows, s, g.region_frames, channels)).total;
+            // Two workgroups per CU: 64 KB each.  One dynamic LDS size serves the whole launch, so a group above
+            // that would halve the occupancy of every group: a split image that does not fit makes way for the
+            // exact-f32 layout (which drops to one stream per workgroup before it gives up on 64 KB).
+            if (bytes <= (s > 1 || g.split ? 64u * 1024u : kLsLdsLimit)) {
                 g.slots = s;
                 g.max_cols = s * g.cols_per_stream;
                 g.lds_bytes = bytes;
@@ -637,7 +888,8 @@ LockstepGeometry lockstep_geometry(uint64_t num, uint64_t den, double ratio, uin
     };
     if (num != 0 && den != 0 && num <= (1u << 20) && den <= (1u << 20)) {
         const uint32_t shift = static_cast<uint32_t>((15 * num + den - 1) / den);
-        g.row_len = (taps + shift + 15) / 16 * 16;
+        g.split = allow_split && !exact_knob && channels == 2;
+        g.row_len = g.split ? (taps + shift + 31) / 32 * 32 : (taps + shift + 15) / 16 * 16;
         uint64_t r = (96 + den - 1) / den;
         if (r == 0) r = 1;
         const uint64_t a = num * r, b = den * r;
@@ -651,9 +903,16 @@ LockstepGeometry lockstep_geometry(uint64_t num, uint64_t den, double ratio, uin
             g.region_frames += g.region_frames & 1u;
             g.cols_per_stream = (g.max_out - 1) / g.b + 2;
             g.wrap_cap = g.max_out / g.den + 2;
+            g.rows = static_cast<uint32_t>((static_cast<uint64_t>(g.n_tiles - 1) * 16 * g.a) / g.b) + g.row_len;
             if (finish(true)) return g;
+            if (g.split) {   // the image does not fit: exact-f32 layout
+                g.split = false;
+                g.row_len = (taps + shift + 15) / 16 * 16;
+                if (g.row_len <= 16 * kLsMaxBlk && finish(true)) return g;
+            }
         }
     }
+    g.split = false;
     if (!finish(false)) g.lds_bytes = 0;   // caller reports the failure
     return g;
 }
@@ -667,7 +926,8 @@ PeriodicGeometry lockstep_class_geometry(const LockstepGeometry& g) {
     p.taps = g.taps;
     p.row_len = g.row_len;
     p.n_tiles = g.n_tiles;
-    p.mfma = 1;             // A-operand order of v_mfma_f32_16x16x4_f32
+    p.mfma = g.split ? 3 : 1;   // A-operand order of v_mfma_f32_16x16x4_f32, or the split table of fir_split.hip
+    p.planes = g.split ? 2 : 0;
     p.inline_wraps = false;
     return p;
 }

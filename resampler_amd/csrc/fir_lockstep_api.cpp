@@ -31,6 +31,7 @@ struct rsmp_fir_lockstep {
     std::vector<LockstepGroup> groups;
     std::vector<LockstepStream> streams;   // internal order
     std::vector<uint32_t> channels;        // internal order
+    bool in_aligned8 = false;
     DeviceBuffer d_groups, d_streams, d_states, d_cursor, d_counts, d_status, d_order, d_recs;
     uint32_t rec_stride = 0, epoch = 1, step = 0;   // plan-ahead records (fir_lockstep.h)
     uint32_t max_lds = 0;
@@ -47,6 +48,18 @@ struct rsmp_fir_lockstep {
 };
 
 namespace {
+
+// A stream's buffered frames alternate between its two history buffers (fir_lockstep.h, LockstepStream):
+// the next step (index ls->step) reads `hist` when its index is even.  After any number of steps the handle's
+// `cur` is made to name the buffer that holds the frames.
+void refresh_history_index(rsmp_fir_lockstep* ls) {
+    if (!ls->bound) return;
+    for (size_t k = 0; k < ls->rs.size(); ++k) {
+        rsmp_fir* r = ls->rs[ls->order[k]];
+        const float* live = (ls->step & 1u) ? ls->streams[k].hist_alt : ls->streams[k].hist;
+        r->cur = live == r->d_hist[0] ? 0 : 1;
+    }
+}
 
 int upload_states(rsmp_fir_lockstep* ls) {
     const size_t n = ls->rs.size();
@@ -84,9 +97,11 @@ extern "C" rsmp_fir_lockstep* rsmp_fir_lockstep_new(rsmp_fir* const* rs, size_t 
     ls->rs.assign(rs, rs + n);
     // Streams that share a polyphase table, a rate pair and a channel count share a class table and
     // a geometry: they become neighbours, then workgroups of `slots` streams.
-    typedef std::tuple<const void*, uint32_t, uint32_t, size_t, size_t> Key;
-    auto key_of = [](const rsmp_fir* r) {
-        return Key(static_cast<const void*>(r->table.get()), r->in_hz, r->out_hz, r->channels, r->taps);
+    // (a stream set to RSMP_FIR_KERNEL_PERIODIC_F32 keeps every product in f32: its own groups)
+    typedef std::tuple<const void*, uint32_t, uint32_t, size_t, size_t, bool> Key;
+    auto exact_of = [](const rsmp_fir* r) { return r->kernel_mode != RSMP_FIR_KERNEL_AUTO; };
+    auto key_of = [&](const rsmp_fir* r) {
+        return Key(static_cast<const void*>(r->table.get()), r->in_hz, r->out_hz, r->channels, r->taps, exact_of(r));
     };
     ls->order.resize(n);
     for (size_t i = 0; i < n; ++i) ls->order[i] = static_cast<uint32_t>(i);
@@ -102,7 +117,7 @@ extern "C" rsmp_fir_lockstep* rsmp_fir_lockstep_new(rsmp_fir* const* rs, size_t 
         const rsmp::LockstepGeometry geo =
             rsmp::lockstep_geometry(r0->mirror.num(), r0->mirror.den(), r0->mirror.ratio(),
                                     static_cast<uint32_t>(r0->taps), static_cast<uint32_t>(r0->channels),
-                                    ls->step_frames);
+                                    ls->step_frames, !exact_of(r0));
         if (geo.lds_bytes == 0) {
             rsmp::fail(RSMP_ERR_INVALID_ARGUMENT,
                        "lock-step batch: %zu channels x %zu frames per step do not fit the LDS", r0->channels,
@@ -139,6 +154,8 @@ extern "C" rsmp_fir_lockstep* rsmp_fir_lockstep_new(rsmp_fir* const* rs, size_t 
             g.class_meta = ct.d_meta;
             g.lds_bytes = geo.lds_bytes;
             g.slots = geo.slots;
+            g.split = geo.split ? 1u : 0u;
+            g.rows = geo.rows;
             ls->groups.push_back(g);
             if (geo.lds_bytes > ls->max_lds) ls->max_lds = geo.lds_bytes;
             if (rsmp::lockstep_rec_stride(geo.wrap_cap) > ls->rec_stride) ls->rec_stride = rsmp::lockstep_rec_stride(geo.wrap_cap);
@@ -198,6 +215,11 @@ extern "C" void rsmp_fir_lockstep_free(rsmp_fir_lockstep* ls) {
 
 extern "C" size_t rsmp_fir_lockstep_size(const rsmp_fir_lockstep* ls) { return ls ? ls->rs.size() : 0; }
 extern "C" size_t rsmp_fir_lockstep_workgroups(const rsmp_fir_lockstep* ls) { return ls ? ls->groups.size() : 0; }
+extern "C" size_t rsmp_fir_lockstep_split_workgroups(const rsmp_fir_lockstep* ls) {
+    size_t n = 0;
+    if (ls) for (const LockstepGroup& g : ls->groups) n += g.split ? 1 : 0;
+    return n;
+}
 
 extern "C" int rsmp_fir_lockstep_bind(rsmp_fir_lockstep* ls, const float* const* d_in, float* const* d_out,
                                       const size_t* out_caps) {
@@ -205,6 +227,9 @@ extern "C" int rsmp_fir_lockstep_bind(rsmp_fir_lockstep* ls, const float* const*
         return rsmp::fail(RSMP_ERR_INVALID_ARGUMENT, "rsmp_fir_lockstep_bind: null argument");
     DeviceGuard guard(ls->device);
     const size_t n = ls->rs.size();
+    if (ls->last_stream) RSMP_HIP_CHECK(hipStreamSynchronize(ls->last_stream));
+    refresh_history_index(ls);
+    bool aligned8 = true;
     for (size_t k = 0; k < n; ++k) {
         const uint32_t i = ls->order[k];
         const rsmp_fir* r = ls->rs[i];
@@ -217,9 +242,11 @@ extern "C" int rsmp_fir_lockstep_bind(rsmp_fir_lockstep* ls, const float* const*
                               "lock-step batch: stream %u needs room for buffer_size_output() = %zu values per step",
                               i, rsmp_fir_buffer_size_output(r));
         LockstepStream& s = ls->streams[k];
+        if (reinterpret_cast<uintptr_t>(d_in[i]) % 8 != 0) aligned8 = false;
         s.in = d_in[i];
         s.out = d_out[i];
-        s.hist = r->d_hist[r->cur];
+        s.hist = r->d_hist[(ls->step & 1u) ? r->cur ^ 1 : r->cur];       // the next step reads the handle's current buffer
+        s.hist_alt = r->d_hist[(ls->step & 1u) ? r->cur : r->cur ^ 1];
         s.coeffs = r->d_coeffs;
         s.out_cap_frames = out_caps[i] / r->channels;
     }
@@ -227,6 +254,7 @@ extern "C" int rsmp_fir_lockstep_bind(rsmp_fir_lockstep* ls, const float* const*
     RSMP_HIP_CHECK(hipMemcpy(ls->d_streams.get(), ls->streams.data(), n * sizeof(LockstepStream),
                              hipMemcpyHostToDevice));
     ls->bound = true;
+    ls->in_aligned8 = aligned8;
     ++ls->epoch;   // plans made ahead assumed the previous output capacities
     return RSMP_OK;
 }
@@ -257,6 +285,7 @@ extern "C" int rsmp_fir_lockstep_step(rsmp_fir_lockstep* ls, size_t in_frames, s
     a.in_offset = in_offset_frames;
     a.in_frames = static_cast<uint32_t>(in_frames);
     a.append = append ? 1u : 0u;
+    a.in_aligned8 = ls->in_aligned8 ? 1u : 0u;
     a.trace = nullptr;
     a.recs = ls->d_recs.as<char>();
     a.rec_stride = ls->rec_stride;
@@ -310,6 +339,7 @@ extern "C" int rsmp_fir_lockstep_sync(rsmp_fir_lockstep* ls) {
     RSMP_HIP_CHECK(hipMemcpy(ls->h_states.data(), ls->d_states.get(), n * sizeof(FirMirrorState),
                              hipMemcpyDeviceToHost));
     for (size_t k = 0; k < n; ++k) ls->rs[ls->order[k]]->mirror.set_state(ls->h_states[k]);
+    refresh_history_index(ls);
     return RSMP_OK;
 }
 
