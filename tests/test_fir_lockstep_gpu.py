@@ -22,7 +22,7 @@ def rms(a, b):
 
 
 def run_lockstep(specs, steps, frames, seed=0, lat=ra.Latency.Sample64, att=ra.Attenuation.Db90,
-                 prefeed=None, in_frames_per_stream=None, x_override=None, append=True):
+                 prefeed=None, in_frames_per_stream=None, x_override=None, append=True, exact=None):
     """Runs `steps` lock-step steps of `frames` frames over the streams in `specs` on the GPU and the same
     calls through one OracleFir per stream.  Returns the worst RMS error over the streams; asserts equal
     counts at every step.  prefeed[i]: frames pushed through stream i with ordinary resample() calls
@@ -31,6 +31,10 @@ def run_lockstep(specs, steps, frames, seed=0, lat=ra.Latency.Sample64, att=ra.A
     dev = torch.device("cuda:0")
     n = len(specs)
     hs = [ra.ResamplerFir.new_from_hz(s.channels, s.in_hz, s.out_hz, lat, att) for s in specs]
+    if exact is not None:   # exact(i): stream i keeps every product in f32 (its own workgroups inside the batch)
+        for i, h in enumerate(hs):
+            if exact(i):
+                h.set_kernel(ra.FirKernel.PeriodicF32)
     refs = [o.OracleFir(s.channels, s.in_hz, s.out_hz, lat.taps(), ATT_DB[att]) for s in specs]
     rng = np.random.default_rng(seed)
     if prefeed is not None:
@@ -108,6 +112,61 @@ def test_c4_shape_1024_streams_six_pairs_16_steps():
         rc, cr, pr = refs[i].resample(x, r_out)
         assert rc == 0 and (cg, pg) == (cr, pr)
         assert rms(g_out[:pg], r_out[:pr]) <= RMS_TOL
+
+
+@pytest.mark.parametrize("which", ["all-exact", "mixed"])
+def test_exact_f32_products_on_request_and_mixed_batches(which):
+    # two-channel streams run on the fp16 matrix cores with split operands by default; a stream set to
+    # RSMP_FIR_KERNEL_PERIODIC_F32 keeps exact f32 products, also next to split streams of the same rate pair
+    specs = sharding.mixed_rate_batch(60, 2, 512)
+    exact = (lambda i: True) if which == "all-exact" else (lambda i: i % 5 < 2)
+    worst, ls, hs, refs = run_lockstep(specs, steps=5, frames=512, seed=21, exact=exact, prefeed=[(53 * i) % 900 for i in range(60)])
+    assert worst <= RMS_TOL, worst
+    assert not ls.status().any()
+    if which == "all-exact":
+        assert ls.split_workgroups() == 0
+    else:
+        assert 0 < ls.split_workgroups() < ls.workgroups()
+    ls.sync()
+    for h, r in zip(hs, refs):
+        assert h.state() == r.state()
+
+
+def test_default_two_channel_batch_runs_split_and_other_channel_counts_do_not():
+    import torch
+    dev = torch.device("cuda:0")
+    for ch, want_split in ((2, True), (1, False), (6, False)):
+        hs = [ra.ResamplerFir.new_from_hz(ch, 44100, 48000, ra.Latency.Sample64, ra.Attenuation.Db90) for _ in range(7)]
+        ls = ra.FirLockstep(hs, 256)
+        assert (ls.split_workgroups() == ls.workgroups()) == want_split, (ch, ls.split_workgroups(), ls.workgroups())
+        ls.close()
+
+
+def test_unaligned_input_pointers():
+    # the split variant reads frames with 8-byte loads only when every input pointer allows it
+    import torch
+    dev = torch.device("cuda:0")
+    specs = sharding.mixed_rate_batch(12, 2, 300)
+    steps, frames = 4, 300
+    hs = [ra.ResamplerFir.new_from_hz(2, s.in_hz, s.out_hz, ra.Latency.Sample64, ra.Attenuation.Db90) for s in specs]
+    refs = [o.OracleFir(2, s.in_hz, s.out_hz, 128, 90) for s in specs]
+    xs = [synth.fast_noise(steps * frames * 2, seed=40 + i) for i in range(12)]
+    store = [torch.zeros(steps * frames * 2 + 1, device=dev) for _ in range(12)]
+    d_in = []
+    for i in range(12):
+        store[i][1:] = torch.from_numpy(xs[i]).to(dev)
+        d_in.append(store[i][1:])                     # 4 bytes off an 8-byte boundary
+    assert all(t.data_ptr() % 8 == 4 for t in d_in)
+    caps = [h.buffer_size_output() for h in hs]
+    d_out = [torch.zeros(steps * c, device=dev) for c in caps]
+    ls = ra.FirLockstep(hs, frames)
+    ls.bind_caps(d_in, d_out, caps)
+    for k in range(steps):
+        ls.step(frames, k * frames, append=True)
+    ls.counts()
+    for i in range(12):
+        y, _ = refs[i].resample_all(xs[i], frames * 2)
+        assert rms(d_out[i][:y.size].cpu().numpy(), y) <= RMS_TOL, i
 
 
 def test_streams_in_different_states():
