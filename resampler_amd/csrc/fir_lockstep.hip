@@ -877,6 +877,7 @@ LockstepGeometry lockstep_geometry(uint64_t num, uint64_t den, double ratio, uin
             // Two workgroups per CU: 64 KB each.  One dynamic LDS size serves the whole launch, so a group above
             // that would halve the occupancy of every group: a split image that does not fit makes way for the
             // exact-f32 layout (which drops to one stream per workgroup before it gives up on 64 KB).
+            if (g.split && s * g.cols_per_stream > 16) continue;   // one image = 16 columns (a long step of a high ratio has more: f32 layout)
             if (bytes <= (s > 1 || g.split ? 64u * 1024u : kLsLdsLimit)) {
                 g.slots = s;
                 g.max_cols = s * g.cols_per_stream;

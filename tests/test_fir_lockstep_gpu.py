@@ -142,6 +142,15 @@ def test_default_two_channel_batch_runs_split_and_other_channel_counts_do_not():
         ls.close()
 
 
+def test_high_ratio_steps_with_more_columns_than_one_image():
+    # 8 kHz -> 192 kHz: a 200-frame step of one stream spans 54 super periods = 54 columns; the split variant
+    # holds 16 per workgroup, so this geometry keeps the f32 layout (found by tools/fuzz_lockstep.py)
+    specs = [sharding.StreamSpec(2, 8000, 192000, 16, 200) for _ in range(5)]
+    worst, ls, _, _ = run_lockstep(specs, steps=5, frames=200, seed=31, lat=ra.Latency.Sample8)
+    assert worst <= RMS_TOL, worst
+    assert ls.split_workgroups() == 0
+
+
 def test_unaligned_input_pointers():
     # the split variant reads frames with 8-byte loads only when every input pointer allows it
     import torch

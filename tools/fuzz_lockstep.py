@@ -32,6 +32,8 @@ def main():
         pairs = [(int(rng.choice(RATES)), int(rng.choice(RATES))) for _ in range(n_pairs)]
         chans = [int(rng.integers(1, 5)) for _ in range(n_pairs)]
         specs = [(chans[i % n_pairs],) + pairs[i % n_pairs] for i in range(n)]
+        if os.environ.get("RSMP_FUZZ_VERBOSE"):   # (a GPU fault kills the process: the last line names the round)
+            print("round", rounds, "n", n, "frames", frames, "steps", steps, lat, att, "pairs", pairs, "channels", chans, flush=True)
         hs, refs = [], []
         try:
             for ch, a, b in specs:
