@@ -374,7 +374,7 @@ __global__ __launch_bounds__(kLsWaves * 64, kLsWaves / 2) void fir_lockstep_kern
         }
         uint32_t before = 0, total = 0;
         for (uint32_t s = 0; s < g.count; ++s) {
-            const uint32_t n = __shfl(my_cols, s, 64);
+            const uint32_t n = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(my_cols), static_cast<int>(s)));   // (s is uniform: no LDS round trip)
             if (s < lane) before += n;
             total += n;
         }
