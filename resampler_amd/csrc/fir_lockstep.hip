@@ -288,8 +288,127 @@ __global__ __launch_bounds__(kLsWaves * 64, kLsWaves / 2) void fir_lockstep_kern
             if (b < nblk) a_reg[b] = gA[b * 64];
     };
 
+    // ---- split variant: the image -------------------------------------------------------------------
+    // Entry (row r, column c) = frame frame0(c) + r of the column's stream, cut into two fp16 planes of
+    // 2^12 x (x * 2^12 = h1 + h2 + r, |r| <= 2^-22 |x|); frames outside the stream's [buffered | new] span and
+    // unused columns are zero.  Lanes run along the rows: a wave instruction reads 64 consecutive frames.
+    // src: lane c < 16 holds column c's ColSrc (8 words).
+    const uint32_t image_off = lay.spans;
+    const bool aligned8 = args.in_aligned8 != 0;
+    auto write_image = [&](const uint32_t (&src)[8]) {
+        for (uint32_t r = threadIdx.x - 64; r < g.rows; r += (kLsWaves - 1) * 64) {
+            // every column's frame of this row is requested before the first is converted: one memory
+            // latency per row block, not one per column
+            float x0[16], x1[16];
+            bool ok[16];
+#pragma unroll
+            for (uint32_t c = 0; c < 16; ++c) {
+                // branch-free: an entry outside its stream's frames (or of an unused column) loads the first
+                // buffered value instead and drops it -- a guarded load would end the run of loads in flight.
+                // Column c's description sits in lane c of `src` and is the same for every lane: scalar registers.
+                auto word = [&](int k) -> uint32_t { return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(src[k]), c)); };
+                gconst_f32_ptr hist = (gconst_f32_ptr) reinterpret_cast<const float*>((static_cast<uint64_t>(word(1)) << 32) | word(0));
+                gconst_f32_ptr in = (gconst_f32_ptr) reinterpret_cast<const float*>((static_cast<uint64_t>(word(3)) << 32) | word(2));
+                const int32_t frame0 = static_cast<int32_t>(word(4));
+                const uint32_t hist_fr = word(5), span_fr = word(6);
+                const int32_t f = frame0 + static_cast<int32_t>(r);
+                ok[c] = f >= 0 && static_cast<uint32_t>(f) < span_fr;
+                const uint32_t fu = ok[c] ? static_cast<uint32_t>(f) : 0u;
+                gconst_f32_ptr p = fu < hist_fr ? hist + 2 * fu : in + 2 * (fu - hist_fr);
+                if (!ok[c]) p = hist;   // (the history buffer always exists)
+                if (aligned8) {   // (uniform) one 8-byte load per frame: half the load instructions of the phase
+                    const v2f v = *(gconst_f2_ptr)p;
+                    x0[c] = v.x;
+                    x1[c] = v.y;
+                } else {
+                    x0[c] = p[0];
+                    x1[c] = p[1];
+                }
+            }
+#pragma unroll
+            for (uint32_t c = 0; c < 16; ++c) {
+                x0[c] = ok[c] ? x0[c] : 0.f;
+                x1[c] = ok[c] ? x1[c] : 0.f;
+            }
+            char* row = lds + image_off + r * kLsImageRowBytes;
+            const uint32_t sw = (r >> 2) & 3;
+#pragma unroll
+            for (uint32_t c = 0; c < 16; ++c) {
+                const float s0 = x0[c] * kLsXScale, s1 = x1[c] * kLsXScale;
+                const uint32_t hi = ls_cvt_pk_f16(s0, s1);
+                const uint32_t lo = ls_cvt_pk_f16(s0 - ls_f16_lo(hi), s1 - ls_f16_hi(hi));
+                char* e = row + ((((c >> 2) ^ sw) << 3) + (c & 3) * 2);
+                *reinterpret_cast<uint16_t*>(e) = static_cast<uint16_t>(hi);            // channel 0, high plane
+                *reinterpret_cast<uint16_t*>(e + 32) = static_cast<uint16_t>(lo);       // channel 0, low plane
+                *reinterpret_cast<uint16_t*>(e + 64) = static_cast<uint16_t>(hi >> 16);  // channel 1, high plane
+                *reinterpret_cast<uint16_t*>(e + 96) = static_cast<uint16_t>(lo >> 16);  // channel 1, low plane
+            }
+        }
+    };
+
     // ---- A: plan (wave 0) | stage (waves 1..) ---------------------------------------------------
     uint32_t my_in_fr = 0;      // wave 0, lanes < count: frames offered to the lane's stream in this step
+    // Split variant, steady state: the staging waves do not wait for wave 0's column table.  Each reads the
+    // streams' plan records itself (the same few words wave 0 reads), derives the columns in registers and
+    // writes its share of the image while wave 0 is still planning: the units start right behind the barrier.
+    // (Not when a record is stale -- first step, changed frame count -- or frames are offered per stream: then
+    // the table wave 0 leaves in LDS is used, after the barrier.)
+    bool early = false;
+    if (split && wave != 0 && args.in_frames_per_stream == nullptr) {
+        bool valid = true;
+        uint32_t mc = 0, f_hist_fr = 0, f_span_fr = 0;
+        int32_t f_base = 0;             // frame0 of the stream's first column
+        uint64_t f_hist = 0, f_in = 0;
+        if (lane < g.count) {
+            const uint32_t gs = g.first + lane;
+            const LsPlanHeader* hd = reinterpret_cast<const LsPlanHeader*>(
+                args.recs + (static_cast<size_t>(args.step & 1u) * args.n_streams + gs) * args.rec_stride);
+            const uint32_t h_epoch = hd->epoch, h_step = hd->step, h_in = hd->in_frames, h_n_out = hd->n_out;
+            const uint32_t h_hist = hd->hist_frames, h_acc = hd->accepted, h_flags = hd->flags;
+            const uint64_t h_abs_out = hd->abs_out, h_abs_consumed = hd->abs_consumed;
+            const LockstepStream& ls = args.streams[gs];
+            f_hist = reinterpret_cast<uint64_t>((args.step & 1u) ? ls.hist_alt : ls.hist);
+            f_in = reinterpret_cast<uint64_t>(ls.in + args.in_offset * C);
+            valid = h_epoch == args.epoch && h_step == args.step && h_in == args.in_frames;
+            if (valid && h_n_out != 0 && !(h_flags & kFlagReference)) {
+                const uint64_t q_first = h_abs_out / g.b;
+                mc = static_cast<uint32_t>((h_abs_out + h_n_out - 1) / g.b - q_first) + 1;
+                f_base = static_cast<int32_t>(static_cast<int64_t>(q_first * g.a) - static_cast<int64_t>(h_abs_consumed));
+            }
+            f_hist_fr = h_hist;
+            f_span_fr = h_hist + h_acc;
+        }
+        if (__builtin_amdgcn_readfirstlane(__all(valid) ? 1 : 0)) {
+            // column c = lane c: find its stream, take that stream's fields
+            uint32_t src[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            uint32_t acc = 0;
+            const uint32_t hist0_lo = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(static_cast<uint32_t>(f_hist)), 0));
+            const uint32_t hist0_hi = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(static_cast<uint32_t>(f_hist >> 32)), 0));
+            src[0] = hist0_lo;   // a column without a stream: no frames, a pointer that can be dereferenced
+            src[1] = hist0_hi;
+            for (uint32_t s = 0; s < g.count; ++s) {
+                auto bc = [&](uint32_t v) { return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), static_cast<int>(s))); };
+                const uint32_t n = bc(mc);
+                const uint32_t room = g.max_cols > acc ? g.max_cols - acc : 0u;
+                const uint32_t take = n < room ? n : room;
+                const uint32_t w0 = bc(static_cast<uint32_t>(f_hist)), w1 = bc(static_cast<uint32_t>(f_hist >> 32));
+                const uint32_t w2 = bc(static_cast<uint32_t>(f_in)), w3 = bc(static_cast<uint32_t>(f_in >> 32));
+                const uint32_t w4 = bc(static_cast<uint32_t>(f_base)), w5 = bc(f_hist_fr), w6 = bc(f_span_fr);
+                if (lane >= acc && lane < acc + take) {
+                    src[0] = w0; src[1] = w1; src[2] = w2; src[3] = w3;
+                    src[4] = w4 + (lane - acc) * g.a;
+                    src[5] = w5; src[6] = w6;
+                }
+                acc += take;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) asm volatile("" : "+v"(src[k]));   // (defined under the full EXEC mask: see below)
+            early = true;
+            if (acc != 0) write_image(src);
+            if constexpr (TRACE) tr[1] = __builtin_amdgcn_s_memtime();
+        }
+    }
+    if (split && wave != 0 && lane == 0) n_cols_p[3] = early ? 1u : 0u;   // (every staging wave writes the same value, before the barrier)
     if (wave == 0) {
         if (lane < g.count) {
             const uint32_t gs = g.first + lane;
@@ -492,13 +611,8 @@ __global__ __launch_bounds__(kLsWaves * 64, kLsWaves / 2) void fir_lockstep_kern
         *reinterpret_cast<LsPlanHeader*>(nrec) = hd;
     }
 
-    // ---- split variant: the image (waves 1..; wave 0 is planning the next step) -----------------------
-    // Entry (row r, column c) = frame frame0(c) + r of the column's stream, cut into two fp16 planes of
-    // 2^12 x (x * 2^12 = h1 + h2 + r, |r| <= 2^-22 |x|); frames outside the stream's [buffered | new] span and
-    // unused columns are zero.  Lanes run along the rows: a wave instruction reads 64 consecutive frames.
-    const uint32_t image_off = lay.spans;
-    if (split && wave != 0 && *n_cols_p != 0) {
-        const bool aligned8 = args.in_aligned8 != 0;
+    // ---- split variant, records not usable: the image from the column table wave 0 left in LDS ----------
+    if (split && wave != 0 && *n_cols_p != 0 && !early) {
         uint32_t src[8];   // lane c < 16: column c's ColSrc
         {
             const uint32_t* cs = reinterpret_cast<const uint32_t*>(colsrc) + (lane & 15) * 8;
@@ -510,54 +624,7 @@ __global__ __launch_bounds__(kLsWaves * 64, kLsWaves / 2) void fir_lockstep_kern
 #pragma unroll
             for (int k = 0; k < 8; ++k) asm volatile("" : "+v"(src[k]));
         }
-        for (uint32_t r = threadIdx.x - 64; r < g.rows; r += (kLsWaves - 1) * 64) {
-            // every column's frame of this row is requested before the first is converted: one memory
-            // latency per row block, not one per column
-            float x0[16], x1[16];
-            bool ok[16];
-#pragma unroll
-            for (uint32_t c = 0; c < 16; ++c) {
-                // branch-free: an entry outside its stream's frames (or of an unused column) loads the first
-                // buffered value instead and drops it -- a guarded load would end the run of loads in flight.
-                // Column c's description sits in lane c of `src` and is the same for every lane: scalar registers.
-                auto word = [&](int k) -> uint32_t { return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(src[k]), c)); };
-                gconst_f32_ptr hist = (gconst_f32_ptr) reinterpret_cast<const float*>((static_cast<uint64_t>(word(1)) << 32) | word(0));
-                gconst_f32_ptr in = (gconst_f32_ptr) reinterpret_cast<const float*>((static_cast<uint64_t>(word(3)) << 32) | word(2));
-                const int32_t frame0 = static_cast<int32_t>(word(4));
-                const uint32_t hist_fr = word(5), span_fr = word(6);
-                const int32_t f = frame0 + static_cast<int32_t>(r);
-                ok[c] = f >= 0 && static_cast<uint32_t>(f) < span_fr;
-                const uint32_t fu = ok[c] ? static_cast<uint32_t>(f) : 0u;
-                gconst_f32_ptr p = fu < hist_fr ? hist + 2 * fu : in + 2 * (fu - hist_fr);
-                if (!ok[c]) p = hist;   // (the history buffer always exists)
-                if (aligned8) {   // (uniform) one 8-byte load per frame: half the load instructions of the phase
-                    const v2f v = *(gconst_f2_ptr)p;
-                    x0[c] = v.x;
-                    x1[c] = v.y;
-                } else {
-                    x0[c] = p[0];
-                    x1[c] = p[1];
-                }
-            }
-#pragma unroll
-            for (uint32_t c = 0; c < 16; ++c) {
-                x0[c] = ok[c] ? x0[c] : 0.f;
-                x1[c] = ok[c] ? x1[c] : 0.f;
-            }
-            char* row = lds + image_off + r * kLsImageRowBytes;
-            const uint32_t sw = (r >> 2) & 3;
-#pragma unroll
-            for (uint32_t c = 0; c < 16; ++c) {
-                const float s0 = x0[c] * kLsXScale, s1 = x1[c] * kLsXScale;
-                const uint32_t hi = ls_cvt_pk_f16(s0, s1);
-                const uint32_t lo = ls_cvt_pk_f16(s0 - ls_f16_lo(hi), s1 - ls_f16_hi(hi));
-                char* e = row + ((((c >> 2) ^ sw) << 3) + (c & 3) * 2);
-                *reinterpret_cast<uint16_t*>(e) = static_cast<uint16_t>(hi);            // channel 0, high plane
-                *reinterpret_cast<uint16_t*>(e + 32) = static_cast<uint16_t>(lo);       // channel 0, low plane
-                *reinterpret_cast<uint16_t*>(e + 64) = static_cast<uint16_t>(hi >> 16);  // channel 1, high plane
-                *reinterpret_cast<uint16_t*>(e + 96) = static_cast<uint16_t>(lo >> 16);  // channel 1, low plane
-            }
-        }
+        write_image(src);
         // one count per wave: its share of the image is in LDS when the count becomes visible
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (lane == 0) (void)__hip_atomic_fetch_add(n_cols_p + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -589,7 +656,8 @@ __global__ __launch_bounds__(kLsWaves * 64, kLsWaves / 2) void fir_lockstep_kern
         const uint32_t n_chunks = (n_cols + 15) / 16;
         const uint32_t n_units = n_chunks * g.n_tiles;
         const bool pair_ok = (C & 1u) == 0;   // both channels of a frame with one 8-byte LDS read
-        if (split)   // the image is complete once the seven staging waves have counted in
+        if (split && n_cols_p[3] == 0)   // (word 3: the image was written before the barrier)
+            // the image is complete once the seven staging waves have counted in
             while (__hip_atomic_load(n_cols_p + 2, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < kLsWaves - 1)
                 __builtin_amdgcn_s_sleep(1);
         // units are claimed from an LDS counter: the first wave joins late (it has planned the next step)
