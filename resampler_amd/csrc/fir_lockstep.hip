@@ -50,6 +50,9 @@ typedef const v2f __attribute__((address_space(1)))* gconst_f2_ptr;
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
 constexpr float kLsXScale = 4096.0f;                               // samples: 2^12 (taps: 2^13, in the table)
 constexpr float kLsOutScale = 1.0f / (4096.0f * 8192.0f);
+constexpr uint32_t kLsPlanner = kLsWaves - 1;                      // the wave that plans the next step
+constexpr uint32_t kLsStagers = kLsWaves - 2;                      // waves 1 .. kLsStagers stage the frames
+constexpr uint32_t kLsSyncBytes = 32;                              // n_cols, unit counter, image counter, early flag, ready counter
 constexpr uint32_t kLsMaxK32 = 6;                                  // 32-tap steps of a tile window (row_len <= 192)
 
 template <class T>
@@ -100,7 +103,7 @@ struct LsLayout {
 __host__ __device__ inline LsLayout ls_layout(uint32_t slots, uint32_t max_cols, uint32_t wrap_words,
                                               uint32_t wrap_cap, uint32_t data_bytes) {
     LsLayout l;
-    l.ptrs = kLsMaxSlots * 64 + 16 + kLsMaxSlots * 96;            // PlanLds[16], n_cols + 3 words, state stash[16]
+    l.ptrs = kLsMaxSlots * 64 + kLsSyncBytes + kLsMaxSlots * 96;  // PlanLds[16], sync words, state stash[16]
     l.colsrc = l.ptrs + kLsMaxSlots * 32;                         // (hist, in, hist_next) pointers per slot
     l.cols = l.colsrc + 16 * 32;                                  // split: where each of the 16 columns' frames come from
     l.segs = (l.cols + max_cols * 16 + 7) & ~7u;
@@ -267,7 +270,7 @@ __global__ __launch_bounds__(kLsWaves * 64, kLsWaves / 2) void fir_lockstep_kern
     ColSrc* colsrc = reinterpret_cast<ColSrc*>(lds + lay.colsrc);
     PlanLds* plan = reinterpret_cast<PlanLds*>(lds);
     uint32_t* n_cols_p = reinterpret_cast<uint32_t*>(lds + kLsMaxSlots * 64);
-    FirMirrorState* stash = reinterpret_cast<FirMirrorState*>(lds + kLsMaxSlots * 64 + 16);   // new states until every reader of the old ones is done
+    FirMirrorState* stash = reinterpret_cast<FirMirrorState*>(lds + kLsMaxSlots * 64 + kLsSyncBytes);   // new states until every reader of the old ones is done
     ColLds* cols = reinterpret_cast<ColLds*>(lds + lay.cols);
     SegLds* segs = reinterpret_cast<SegLds*>(lds + lay.segs);
     uint32_t* wbits = reinterpret_cast<uint32_t*>(lds + lay.wbits);
@@ -296,7 +299,7 @@ __global__ __launch_bounds__(kLsWaves * 64, kLsWaves / 2) void fir_lockstep_kern
     const uint32_t image_off = lay.spans;
     const bool aligned8 = args.in_aligned8 != 0;
     auto write_image = [&](const uint32_t (&src)[8]) {
-        for (uint32_t r = threadIdx.x - 64; r < g.rows; r += (kLsWaves - 1) * 64) {
+        for (uint32_t r = threadIdx.x - 64; r < g.rows; r += kLsStagers * 64) {
             // every column's frame of this row is requested before the first is converted: one memory
             // latency per row block, not one per column
             float x0[16], x1[16];
@@ -348,13 +351,60 @@ __global__ __launch_bounds__(kLsWaves * 64, kLsWaves / 2) void fir_lockstep_kern
 
     // ---- A: plan (wave 0) | stage (waves 1..) ---------------------------------------------------
     uint32_t my_in_fr = 0;      // wave 0, lanes < count: frames offered to the lane's stream in this step
+    bool from_record = false;   // ... and whether its plan came from the record (then the planner wave plans the next step)
+    // The sync words start at zero (unit counter, image counter, early flag, ready counter): the only
+    // workgroup barrier before the final one -- every wave is here at once.
+    if (threadIdx.x < kLsSyncBytes / 4) n_cols_p[threadIdx.x] = 0;
+    __syncthreads();
+
+    // The NEXT step's plan (the reference's control flow for step k + 1, ~20 k cycles of serial f64 arithmetic
+    // on one lane per stream) goes to the stream's plan record.  A wave of its own does that from the kernel's
+    // first cycle on -- the state it starts from is in the record of THIS step (`after`) -- and takes part in
+    // nothing else before the units: it used to sit on wave 0 behind the barrier, where it was the longest
+    // chain of the step.  (When this step has no usable record, wave 0 plans in line and then does it itself.)
+    auto plan_ahead = [&](uint32_t gs, FirMirrorState st, uint32_t offered) {
+        char* nrec = args.recs + (static_cast<size_t>((args.step + 1u) & 1u) * args.n_streams + gs) * args.rec_stride;
+        uint32_t in_fr = offered;
+        const uint32_t room = g.span_frames > st.available ? g.span_frames - static_cast<uint32_t>(st.available) : 0u;
+        if (in_fr > room) in_fr = room;
+        LdsSink sink{reinterpret_cast<SegLds*>(nrec + kLsRecSegs), nullptr, reinterpret_cast<uint32_t*>(nrec + kLsRecWraps),
+                     0u, 0u, g.wrap_cap, g.periodic != 0 && st.periodic_ok != 0, false};
+        LsPlanHeader hd;
+        hd.hist_frames = static_cast<uint32_t>(st.available);
+        hd.abs_out = st.abs_out;
+        hd.abs_consumed = st.abs_consumed;
+        const FirCallCounts c = mirror_call(st, in_fr, args.streams[gs].out_cap_frames, sink);
+        hd.epoch = args.epoch;
+        hd.step = args.step + 1u;
+        hd.in_frames = offered;
+        hd.n_out = static_cast<uint32_t>(c.produced);
+        hd.accepted = static_cast<uint32_t>(c.accepted);
+        hd.consumed = static_cast<uint32_t>(c.consumed);
+        hd.tail_frames = static_cast<uint32_t>(st.available);
+        hd.n_segs = sink.n_segs;
+        hd.n_wraps = sink.n_wraps < g.wrap_cap ? sink.n_wraps : g.wrap_cap;
+        hd.flags = (sink.periodic && st.periodic_ok != 0 ? 0u : kFlagReference) | (sink.overflow ? kFlagRunOverflow : 0u);
+        hd.pad0 = 0;
+        hd.pad1 = 0;
+        hd.after = st;
+        *reinterpret_cast<LsPlanHeader*>(nrec) = hd;
+    };
+    if (wave == kLsPlanner && lane < g.count) {
+        const uint32_t gs = g.first + lane;
+        const uint32_t offered = args.in_frames_per_stream ? args.in_frames_per_stream[args.order[gs]] : args.in_frames;
+        const LsPlanHeader* hd = reinterpret_cast<const LsPlanHeader*>(
+            args.recs + (static_cast<size_t>(args.step & 1u) * args.n_streams + gs) * args.rec_stride);
+        if (hd->epoch == args.epoch && hd->step == args.step && hd->in_frames == offered) plan_ahead(gs, hd->after, offered);
+    }
+
     // Split variant, steady state: the staging waves do not wait for wave 0's column table.  Each reads the
     // streams' plan records itself (the same few words wave 0 reads), derives the columns in registers and
     // writes its share of the image while wave 0 is still planning: the units start right behind the barrier.
     // (Not when a record is stale -- first step, changed frame count -- or frames are offered per stream: then
     // the table wave 0 leaves in LDS is used, after the barrier.)
     bool early = false;
-    if (split && wave != 0 && args.in_frames_per_stream == nullptr) {
+    const bool stager = wave >= 1 && wave <= kLsStagers;
+    if (split && stager && args.in_frames_per_stream == nullptr) {
         bool valid = true;
         uint32_t mc = 0, f_hist_fr = 0, f_span_fr = 0;
         int32_t f_base = 0;             // frame0 of the stream's first column
@@ -408,7 +458,7 @@ __global__ __launch_bounds__(kLsWaves * 64, kLsWaves / 2) void fir_lockstep_kern
             if constexpr (TRACE) tr[1] = __builtin_amdgcn_s_memtime();
         }
     }
-    if (split && wave != 0 && lane == 0) n_cols_p[3] = early ? 1u : 0u;   // (every staging wave writes the same value, before the barrier)
+    if (split && stager && lane == 0) n_cols_p[3] = early ? 1u : 0u;   // (every staging wave writes the same value, before the barrier)
     if (wave == 0) {
         if (lane < g.count) {
             const uint32_t gs = g.first + lane;
@@ -421,7 +471,8 @@ __global__ __launch_bounds__(kLsWaves * 64, kLsWaves / 2) void fir_lockstep_kern
             const LsPlanHeader hd = *reinterpret_cast<const LsPlanHeader*>(rec);
             PlanLds pl;
             FirMirrorState st;
-            if (hd.epoch == args.epoch && hd.step == args.step && hd.in_frames == in_off) {
+            from_record = hd.epoch == args.epoch && hd.step == args.step && hd.in_frames == in_off;
+            if (from_record) {
                 // planned a step ahead: take the record
                 pl.n_out = hd.n_out;
                 pl.hist_frames = hd.hist_frames;
@@ -517,10 +568,8 @@ __global__ __launch_bounds__(kLsWaves * 64, kLsWaves / 2) void fir_lockstep_kern
         }
         if (lane == 0) {
             n_cols_p[0] = total < g.max_cols ? total : g.max_cols;
-            n_cols_p[1] = 0;   // unit counter
-            n_cols_p[2] = 0;   // split: waves that have written their share of the image
         }
-    } else if (!split) {
+    } else if (!split && stager) {
         // Stage [buffered | new] of every stream with LDS-DMA (global_load_lds, 256 B per wave instruction,
         // no VGPR round trip: every piece of every stream is in flight at once); everything else of the
         // region is zeroed (the guards are read by masked columns and by zero padding coefficients: they
@@ -528,7 +577,7 @@ __global__ __launch_bounds__(kLsWaves * 64, kLsWaves / 2) void fir_lockstep_kern
         // the wave that issued it, after the piece has landed.
         typedef __attribute__((address_space(3))) void* lds_void_ptr;
         const uint32_t t0 = threadIdx.x - 64;
-        const uint32_t nt = (kLsWaves - 1) * 64;
+        const uint32_t nt = kLsStagers * 64;
         // lane s of every staging wave fetches stream s's parameters: one round trip for all streams
         uint32_t my_hist_dw = 0, my_span_dw = 0;
         unsigned long long my_hist = 0, my_in = 0;
@@ -557,7 +606,7 @@ __global__ __launch_bounds__(kLsWaves * 64, kLsWaves / 2) void fir_lockstep_kern
             gconst_f32_ptr in = (gconst_f32_ptr) reinterpret_cast<const float*>(__shfl(my_in, s, 64));
             float* region = spans + s * region_dw;
             const uint32_t pieces = (span_dw + 63) / 64;
-            for (uint32_t p = wave - 1; p < pieces; p += kLsWaves - 1) {
+            for (uint32_t p = wave - 1; p < pieces; p += kLsStagers) {
                 const uint32_t k = p * 64 + lane;
                 const uint32_t kc = k < span_dw ? k : span_dw - 1;
                 gconst_f32_ptr src = kc < hist_dw ? hist + kc : in + (kc - hist_dw);
@@ -570,49 +619,31 @@ __global__ __launch_bounds__(kLsWaves * 64, kLsWaves / 2) void fir_lockstep_kern
         for (uint32_t s = 0; s < g.count; ++s) {
             const uint32_t span_dw = __shfl(my_span_dw, s, 64);
             const uint32_t pieces = (span_dw + 63) / 64;
-            if (pieces != 0 && (pieces - 1) % (kLsWaves - 1) == wave - 1) {   // this wave issued the last piece
+            if (pieces != 0 && (pieces - 1) % kLsStagers == wave - 1) {   // this wave issued the last piece
                 const uint32_t k = (pieces - 1) * 64 + lane;
                 if (k >= span_dw) spans[s * region_dw + guard_dw + k] = 0.f;
             }
         }
     }
     if constexpr (TRACE) tr[2] = __builtin_amdgcn_s_memtime();   // wave 0: columns built; others: staged
-    __syncthreads();
+    // Wave 0 and the staging waves count in (their LDS writes first), every wave waits for the seven counts:
+    // a barrier the planner wave does not hold up.
+    if (wave == 0 || stager) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) (void)__hip_atomic_fetch_add(n_cols_p + 4, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // (LDS operations of a wave complete in order)
+    }
+    while (__hip_atomic_load(n_cols_p + 4, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < 1 + kLsStagers)
+        __builtin_amdgcn_s_sleep(1);
     if constexpr (TRACE) tr[3] = __builtin_amdgcn_s_memtime();
     if (wave == 0 && lane < g.count) {
         const uint32_t gs = g.first + lane;
-        FirMirrorState st = stash[lane];
-        args.states[gs] = st;   // every reader of the old state is past the barrier
-        // ---- the NEXT step's plan, while the other waves compute this one ----------------------------
-        char* nrec = args.recs + (static_cast<size_t>((args.step + 1u) & 1u) * args.n_streams + gs) * args.rec_stride;
-        uint32_t in_fr = my_in_fr;
-        const uint32_t room = g.span_frames > st.available ? g.span_frames - static_cast<uint32_t>(st.available) : 0u;
-        if (in_fr > room) in_fr = room;
-        LdsSink sink{reinterpret_cast<SegLds*>(nrec + kLsRecSegs), nullptr, reinterpret_cast<uint32_t*>(nrec + kLsRecWraps),
-                     0u, 0u, g.wrap_cap, g.periodic != 0 && st.periodic_ok != 0, false};
-        LsPlanHeader hd;
-        hd.hist_frames = static_cast<uint32_t>(st.available);
-        hd.abs_out = st.abs_out;
-        hd.abs_consumed = st.abs_consumed;
-        const FirCallCounts c = mirror_call(st, in_fr, args.streams[gs].out_cap_frames, sink);
-        hd.epoch = args.epoch;
-        hd.step = args.step + 1u;
-        hd.in_frames = my_in_fr;
-        hd.n_out = static_cast<uint32_t>(c.produced);
-        hd.accepted = static_cast<uint32_t>(c.accepted);
-        hd.consumed = static_cast<uint32_t>(c.consumed);
-        hd.tail_frames = static_cast<uint32_t>(st.available);
-        hd.n_segs = sink.n_segs;
-        hd.n_wraps = sink.n_wraps < g.wrap_cap ? sink.n_wraps : g.wrap_cap;
-        hd.flags = (sink.periodic && st.periodic_ok != 0 ? 0u : kFlagReference) | (sink.overflow ? kFlagRunOverflow : 0u);
-        hd.pad0 = 0;
-        hd.pad1 = 0;
-        hd.after = st;
-        *reinterpret_cast<LsPlanHeader*>(nrec) = hd;
+        const FirMirrorState st = stash[lane];
+        args.states[gs] = st;   // every reader of the old state has counted in
+        if (!from_record) plan_ahead(gs, st, my_in_fr);
     }
 
     // ---- split variant, records not usable: the image from the column table wave 0 left in LDS ----------
-    if (split && wave != 0 && *n_cols_p != 0 && !early) {
+    if (split && stager && *n_cols_p != 0 && !early) {
         uint32_t src[8];   // lane c < 16: column c's ColSrc
         {
             const uint32_t* cs = reinterpret_cast<const uint32_t*>(colsrc) + (lane & 15) * 8;
@@ -658,7 +689,7 @@ __global__ __launch_bounds__(kLsWaves * 64, kLsWaves / 2) void fir_lockstep_kern
         const bool pair_ok = (C & 1u) == 0;   // both channels of a frame with one 8-byte LDS read
         if (split && n_cols_p[3] == 0)   // (word 3: the image was written before the barrier)
             // the image is complete once the seven staging waves have counted in
-            while (__hip_atomic_load(n_cols_p + 2, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < kLsWaves - 1)
+            while (__hip_atomic_load(n_cols_p + 2, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < kLsStagers)
                 __builtin_amdgcn_s_sleep(1);
         // units are claimed from an LDS counter: the first wave joins late (it has planned the next step)
         for (;;) {
