@@ -61,6 +61,9 @@ struct LockstepGroup {         // one workgroup's share: `count` streams of one 
     uint32_t split;            // 1: two-channel streams on the fp16 matrix cores with split operands (fir_split.hip's
                                //    arithmetic): class_coef is the split table, the LDS holds a transposed fp16 image
     uint32_t rows;             // split: rows (frames) of the image: last tile's window start + row_len
+    uint32_t row_bytes;        // split: bytes per image row: 160 (32 B of padding: conflict-free transposed reads), or
+                               //        128 where only the unpadded image leaves room for two workgroups per CU
+    uint32_t pad0;
 };
 
 struct LockstepArgs {
@@ -112,6 +115,7 @@ struct LockstepGeometry {
     uint32_t wrap_words = 0, wrap_cap = 0, max_cols = 0, lds_bytes = 0;
     bool split = false;        // fp16x2 split operands (two-channel streams, unless exact f32 products are asked for)
     uint32_t rows = 0;         // split: rows of the LDS image
+    uint32_t row_bytes = 0;    // split: bytes per image row (160, or 128 without padding)
 };
 // allow_split = false: exact-f32 products (RSMP_FIR_KERNEL_PERIODIC_F32 on the streams, or RSMP_LS_EXACT=1).
 LockstepGeometry lockstep_geometry(uint64_t num, uint64_t den, double ratio, uint32_t taps,
@@ -120,6 +124,8 @@ LockstepGeometry lockstep_geometry(uint64_t num, uint64_t den, double ratio, uin
 // kernel's fp16x2 layout).
 PeriodicGeometry lockstep_class_geometry(const LockstepGeometry& g);
 constexpr uint32_t kLsImageRowBytes = 160;   // split image: (2 channels x 2 planes) x 32 B + 32 B of padding (fir_split.hip)
+constexpr uint32_t kLsImageRowBytesPacked = 128;   // ... without the padding
+constexpr uint32_t kLsLdsPerWorkgroup = 80 * 1024 - 512;   // two workgroups per CU (160 KB, less the allocation granule)
 
 hipError_t launch_fir_lockstep(const LockstepArgs& args, uint32_t n_groups, uint32_t max_lds_bytes,
                                hipStream_t stream);

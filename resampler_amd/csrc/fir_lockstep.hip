@@ -113,9 +113,9 @@ __host__ __device__ inline LsLayout ls_layout(uint32_t slots, uint32_t max_cols,
     l.total = l.spans + data_bytes;
     return l;
 }
-__host__ __device__ inline uint32_t ls_data_bytes(bool split, uint32_t rows, uint32_t slots, uint32_t region_frames,
-                                                  uint32_t channels) {
-    return split ? rows * kLsImageRowBytes : slots * region_frames * channels * 4u;
+__host__ __device__ inline uint32_t ls_data_bytes(bool split, uint32_t rows, uint32_t row_bytes, uint32_t slots,
+                                                  uint32_t region_frames, uint32_t channels) {
+    return split ? rows * row_bytes : slots * region_frames * channels * 4u;
 }
 
 // mirror_call sink writing into LDS.
@@ -197,16 +197,17 @@ __device__ __forceinline__ float ls_f16_hi(uint32_t w) { return static_cast<floa
 // the lane's column, the B operand of v_mfma_f32_16x16x32_f16 being two of those (frames 32 s + 4 grp .. and
 // 32 s + 16 + 4 grp ..), in the order the split table (split_store_class) holds the taps.  Per 32 taps:
 // c1 x2 + c2 x1 + c1 x1, smallest products first (fir_split.hip).
-template <uint32_t NK>   // 32-tap steps of the tile window: compile-time, so that step s + 1's reads are in flight under step s's MFMAs
+template <uint32_t NK, uint32_t ROWB>   // 32-tap steps of the tile window and the row pitch: compile-time, so that step s + 1's
+                                        // reads are in flight under step s's MFMAs and every offset is an immediate
 __device__ __forceinline__ void unit_mfma_split_nk(const v4f (&a_reg)[kLsMaxBlk], char* lds, uint32_t image_off,
                                                    uint32_t base_row, uint32_t lane, v4f& acc0, v4f& acc1) {
     const uint32_t grp = lane >> 4, q = (lane >> 2) & 3, pc = lane & 3;
     const uint32_t row0 = base_row + 4 * grp + q;
-    const uint32_t base = image_off + row0 * kLsImageRowBytes + ((pc ^ ((row0 >> 2) & 3)) << 3);
+    const uint32_t base = image_off + row0 * ROWB + ((pc ^ ((row0 >> 2) & 3)) << 3);
     auto frag = [&](uint32_t plane_ch, uint32_t s) -> f16x8 {
-        const uint32_t addr = base + plane_ch * 32u + s * (32u * kLsImageRowBytes);
+        const uint32_t addr = base + plane_ch * 32u + s * (32u * ROWB);
         const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(lds + addr));
-        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(lds + addr + 16u * kLsImageRowBytes));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(lds + addr + 16u * ROWB));
         return __builtin_bit_cast(f16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
     };
 #pragma unroll
@@ -223,16 +224,22 @@ __device__ __forceinline__ void unit_mfma_split_nk(const v4f (&a_reg)[kLsMaxBlk]
     acc0 *= kLsOutScale;
     acc1 *= kLsOutScale;
 }
-__device__ __forceinline__ void unit_mfma_split(const v4f (&a_reg)[kLsMaxBlk], uint32_t nk, char* lds, uint32_t image_off,
-                                                uint32_t base_row, uint32_t lane, v4f& acc0, v4f& acc1) {
+template <uint32_t ROWB>
+__device__ __forceinline__ void unit_mfma_split_rb(const v4f (&a_reg)[kLsMaxBlk], uint32_t nk, char* lds, uint32_t image_off,
+                                                   uint32_t base_row, uint32_t lane, v4f& acc0, v4f& acc1) {
     switch (nk) {   // (workgroup-uniform)
-        case 1: unit_mfma_split_nk<1>(a_reg, lds, image_off, base_row, lane, acc0, acc1); break;
-        case 2: unit_mfma_split_nk<2>(a_reg, lds, image_off, base_row, lane, acc0, acc1); break;
-        case 3: unit_mfma_split_nk<3>(a_reg, lds, image_off, base_row, lane, acc0, acc1); break;
-        case 4: unit_mfma_split_nk<4>(a_reg, lds, image_off, base_row, lane, acc0, acc1); break;
-        case 5: unit_mfma_split_nk<5>(a_reg, lds, image_off, base_row, lane, acc0, acc1); break;
-        default: unit_mfma_split_nk<kLsMaxK32>(a_reg, lds, image_off, base_row, lane, acc0, acc1); break;
+        case 1: unit_mfma_split_nk<1, ROWB>(a_reg, lds, image_off, base_row, lane, acc0, acc1); break;
+        case 2: unit_mfma_split_nk<2, ROWB>(a_reg, lds, image_off, base_row, lane, acc0, acc1); break;
+        case 3: unit_mfma_split_nk<3, ROWB>(a_reg, lds, image_off, base_row, lane, acc0, acc1); break;
+        case 4: unit_mfma_split_nk<4, ROWB>(a_reg, lds, image_off, base_row, lane, acc0, acc1); break;
+        case 5: unit_mfma_split_nk<5, ROWB>(a_reg, lds, image_off, base_row, lane, acc0, acc1); break;
+        default: unit_mfma_split_nk<kLsMaxK32, ROWB>(a_reg, lds, image_off, base_row, lane, acc0, acc1); break;
     }
+}
+__device__ __forceinline__ void unit_mfma_split(const v4f (&a_reg)[kLsMaxBlk], uint32_t nk, uint32_t row_bytes, char* lds,
+                                                uint32_t image_off, uint32_t base_row, uint32_t lane, v4f& acc0, v4f& acc1) {
+    if (row_bytes == kLsImageRowBytes) unit_mfma_split_rb<kLsImageRowBytes>(a_reg, nk, lds, image_off, base_row, lane, acc0, acc1);
+    else unit_mfma_split_rb<kLsImageRowBytesPacked>(a_reg, nk, lds, image_off, base_row, lane, acc0, acc1);
 }
 
 // Frame f (relative to the first buffered frame) of a stream's [buffered | new] frames, channel c: from the
@@ -263,7 +270,7 @@ __global__ __launch_bounds__(kLsWaves * 64, kLsWaves / 2) void fir_lockstep_kern
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const bool split = g.split != 0;   // (workgroup-uniform)
     const LsLayout lay = ls_layout(g.slots, g.max_cols, g.wrap_words, g.wrap_cap,
-                                   ls_data_bytes(split, g.rows, g.slots, g.region_frames, C));
+                                   ls_data_bytes(split, g.rows, g.row_bytes, g.slots, g.region_frames, C));
     struct SlotPtrs { const float* hist; const float* in; float* hist_next; uint64_t pad; };   // this step's buffered frames, its new frames, where its tail goes
     SlotPtrs* ptrs = reinterpret_cast<SlotPtrs*>(lds + lay.ptrs);   // split: the streams' frames are read from HBM
     struct ColSrc { const float* hist; const float* in; int32_t frame0; uint32_t hist_frames, span_frames, pad; };   // 32 B
@@ -333,7 +340,7 @@ __global__ __launch_bounds__(kLsWaves * 64, kLsWaves / 2) void fir_lockstep_kern
                 x0[c] = ok[c] ? x0[c] : 0.f;
                 x1[c] = ok[c] ? x1[c] : 0.f;
             }
-            char* row = lds + image_off + r * kLsImageRowBytes;
+            char* row = lds + image_off + r * g.row_bytes;
             const uint32_t sw = (r >> 2) & 3;
 #pragma unroll
             for (uint32_t c = 0; c < 16; ++c) {
@@ -724,7 +731,7 @@ __global__ __launch_bounds__(kLsWaves * 64, kLsWaves / 2) void fir_lockstep_kern
                 const bool two = c0 + 1 < C;
                 v4f acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
                 if (split) {
-                    unit_mfma_split(a_reg, g.row_len / 32, lds, image_off, tile_base, lane, acc0, acc1);
+                    unit_mfma_split(a_reg, g.row_len / 32, g.row_bytes, lds, image_off, tile_base, lane, acc0, acc1);
                 } else if (two && pair_ok) {
                     unit_mfma<2>(a_reg, nblk, xb + c0, C, acc0, acc1);
                 } else {
@@ -972,12 +979,12 @@ LockstepGeometry lockstep_geometry(uint64_t num, uint64_t den, double ratio, uin
         const uint32_t want = periodic ? std::max(1u, 16u / g.cols_per_stream) : 4u;
         for (uint32_t s = std::min(want, kLsMaxSlots); s >= 1; --s) {
             const uint32_t bytes = ls_layout(s, s * g.cols_per_stream, g.wrap_words, g.wrap_cap,
-                                             ls_data_bytes(g.split, g.rows, s, g.region_frames, channels)).total;
-            // Two workgroups per CU: 64 KB each.  One dynamic LDS size serves the whole launch, so a group above
+                                             ls_data_bytes(g.split, g.rows, g.row_bytes, s, g.region_frames, channels)).total;
+            // Two workgroups per CU: 80 KB each.  One dynamic LDS size serves the whole launch, so a group above
             // that would halve the occupancy of every group: a split image that does not fit makes way for the
-            // exact-f32 layout (which drops to one stream per workgroup before it gives up on 64 KB).
+            // exact-f32 layout (which drops to one stream per workgroup before it gives up on that).
             if (g.split && s * g.cols_per_stream > 16) continue;   // one image = 16 columns (a long step of a high ratio has more: f32 layout)
-            if (bytes <= (s > 1 || g.split ? 64u * 1024u : kLsLdsLimit)) {
+            if (bytes <= (s > 1 || g.split ? kLsLdsPerWorkgroup : kLsLdsLimit)) {
                 g.slots = s;
                 g.max_cols = s * g.cols_per_stream;
                 g.lds_bytes = bytes;
@@ -1004,7 +1011,12 @@ LockstepGeometry lockstep_geometry(uint64_t num, uint64_t den, double ratio, uin
             g.cols_per_stream = (g.max_out - 1) / g.b + 2;
             g.wrap_cap = g.max_out / g.den + 2;
             g.rows = static_cast<uint32_t>((static_cast<uint64_t>(g.n_tiles - 1) * 16 * g.a) / g.b) + g.row_len;
+            g.row_bytes = kLsImageRowBytes;
             if (finish(true)) return g;
+            if (g.split) {   // without the rows' padding (transposed reads then meet on banks: 2-4x the LDS time of a unit, still far below f32 products)
+                g.row_bytes = kLsImageRowBytesPacked;
+                if (finish(true)) return g;
+            }
             if (g.split) {   // the image does not fit: exact-f32 layout
                 g.split = false;
                 g.row_len = (taps + shift + 15) / 16 * 16;

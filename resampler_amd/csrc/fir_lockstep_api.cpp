@@ -156,6 +156,7 @@ extern "C" rsmp_fir_lockstep* rsmp_fir_lockstep_new(rsmp_fir* const* rs, size_t 
             g.slots = geo.slots;
             g.split = geo.split ? 1u : 0u;
             g.rows = geo.rows;
+            g.row_bytes = geo.row_bytes;
             ls->groups.push_back(g);
             if (geo.lds_bytes > ls->max_lds) ls->max_lds = geo.lds_bytes;
             if (rsmp::lockstep_rec_stride(geo.wrap_cap) > ls->rec_stride) ls->rec_stride = rsmp::lockstep_rec_stride(geo.wrap_cap);
