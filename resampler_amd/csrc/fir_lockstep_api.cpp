@@ -254,6 +254,7 @@ extern "C" int rsmp_fir_lockstep_bind(rsmp_fir_lockstep* ls, const float* const*
     if (ls->last_stream) RSMP_HIP_CHECK(hipStreamSynchronize(ls->last_stream));
     RSMP_HIP_CHECK(hipMemcpy(ls->d_streams.get(), ls->streams.data(), n * sizeof(LockstepStream),
                              hipMemcpyHostToDevice));
+    RSMP_HIP_CHECK(hipMemset(ls->d_cursor.get(), 0, n * sizeof(uint64_t)));   // nothing has been appended to the new buffers
     ls->bound = true;
     ls->in_aligned8 = aligned8;
     ++ls->epoch;   // plans made ahead assumed the previous output capacities

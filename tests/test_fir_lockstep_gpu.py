@@ -291,6 +291,60 @@ def test_reset_and_rebind():
         assert rms(d_out[i][:pr].cpu().numpy(), out[:pr]) <= RMS_TOL
 
 
+@pytest.mark.parametrize("steps_a,steps_b", [(1, 2), (3, 1), (4, 3)])
+def test_history_buffers_alternate_across_binds_batches_and_plain_calls(steps_a, steps_b):
+    """A stream's buffered frames move between its two history buffers every step.  Whatever the parity of the
+    step count: a rebind in the middle, the end of the batch, ordinary resample() calls on the handles and a
+    second batch over the same handles all continue the same streams (checked against one oracle per stream)."""
+    import torch
+    dev = torch.device("cuda:0")
+    specs = sharding.mixed_rate_batch(12, 2, 192) + [sharding.StreamSpec(3, 48000, 44100, 128, 192)]
+    frames = 192
+    hs = [ra.ResamplerFir.new_from_hz(s.channels, s.in_hz, s.out_hz, ra.Latency.Sample64, ra.Attenuation.Db90) for s in specs]
+    refs = [o.OracleFir(s.channels, s.in_hz, s.out_hz, 128, 90) for s in specs]
+    caps = [h.buffer_size_output() for h in hs]
+    rng = np.random.default_rng(77)
+    ref_buf = [np.zeros(c, np.float32) for c in caps]
+
+    def batch_steps(ls, n_steps):
+        xs = [(rng.random(n_steps * frames * s.channels, dtype=np.float32) * 2 - 1).astype(np.float32) for s in specs]
+        d_in = [torch.from_numpy(x).to(dev) for x in xs]
+        d_out = [torch.zeros(n_steps * c, device=dev) for c in caps]
+        ls.bind_caps(d_in, d_out, caps)
+        for k in range(n_steps):
+            ls.step(frames, k * frames, append=True)
+        ls.counts()
+        for i, s in enumerate(specs):
+            want = []
+            for k in range(n_steps):
+                rc, cr, pr = refs[i].resample(xs[i][k * frames * s.channels:(k + 1) * frames * s.channels], ref_buf[i])
+                assert rc == 0
+                want.append(ref_buf[i][:pr].copy())
+            want = np.concatenate(want)
+            assert rms(d_out[i][:want.size].cpu().numpy(), want) <= RMS_TOL, i
+
+    def plain_calls():
+        for i, s in enumerate(specs):
+            x = (rng.random(100 * s.channels, dtype=np.float32) * 2 - 1).astype(np.float32)
+            g_out = np.zeros(caps[i], np.float32)
+            cg, pg = hs[i].resample(x, g_out)
+            rc, cr, pr = refs[i].resample(x, ref_buf[i])
+            assert rc == 0 and (cg, pg) == (cr, pr)
+            assert rms(g_out[:pg], ref_buf[i][:pr]) <= RMS_TOL, i
+
+    ls = ra.FirLockstep(hs, frames)
+    batch_steps(ls, steps_a)
+    batch_steps(ls, steps_b)          # rebind inside the batch
+    ls.close()
+    for h, r in zip(hs, refs):
+        assert h.state() == r.state()
+    plain_calls()
+    ls2 = ra.FirLockstep(hs, frames)   # a second batch over the same handles
+    batch_steps(ls2, steps_a)
+    ls2.close()
+    plain_calls()
+
+
 def test_rejects_small_output_and_busy_streams():
     import torch
     dev = torch.device("cuda:0")
