@@ -167,7 +167,9 @@ size_t rsmp_fir_lockstep_workgroups(const rsmp_fir_lockstep* ls);   /* diagnosti
  * RSMP_FIR_KERNEL_AUTO; the others keep every product in f32: other channel counts, streams set to another
  * kernel mode with rsmp_fir_set_kernel before the batch was made, geometries whose image does not fit). */
 size_t rsmp_fir_lockstep_split_workgroups(const rsmp_fir_lockstep* ls);
-/* Binding (again) starts the `append` positions at the front of the new output buffers. */
+/* Binding (again) starts the `append` positions at the front of the new output buffers.  With `append` the
+ * caller sizes d_out[i] for all the steps it will run until the next bind (the kernel checks the room of one
+ * step, out_caps[i], not of the buffer). */
 int rsmp_fir_lockstep_bind(rsmp_fir_lockstep* ls, const float* const* d_in, float* const* d_out,
                            const size_t* out_caps);
 /* d_in_frames: optional DEVICE array of frames offered per stream (in the order of `rs`; NULL = in_frames
