@@ -1697,7 +1697,9 @@ PeriodicGeometry geometry_for(uint64_t num, uint64_t den, uint32_t taps, uint32_
         const char* e = getenv("RSMP_FIR_PRODUCERS");
         return e ? atoi(e) : -1;
     }();
+    bool two_per_cu = false;   // set by fit(): the single-image vector kernel with two workgroups per CU
     auto fit = [&](uint32_t cg) -> bool {
+        two_per_cu = false;
         if (channels % cg != 0) return false;
         const uint32_t lp = channels / cg;
         if (lp > 64) return false;
@@ -1770,7 +1772,8 @@ PeriodicGeometry geometry_for(uint64_t num, uint64_t den, uint32_t taps, uint32_
         }
         if (want_mfma) return false;   // periodic_geometry() retries with the vector kernels
         pw = rows_in(kLdsTwoPerCu);
-        if (pw * 4 < pw_max * 3) pw = rows_in(kLdsMax);  // < 75% of the lanes: use the whole LDS
+        two_per_cu = pw * 4 >= pw_max * 3;
+        if (!two_per_cu) pw = rows_in(kLdsMax);  // < 75% of the lanes: use the whole LDS
         if (pw > pw_max) pw = pw_max;
         if (pw * 2 < pw_max || pw == 0) return false;
         g.pw = pw;
@@ -1787,8 +1790,22 @@ PeriodicGeometry geometry_for(uint64_t num, uint64_t den, uint32_t taps, uint32_
     };
     if (want_mfma) {   // the matrix-core kernel is written for two channels per lane group
         if (!fit(2)) return g;
-    } else if (!fit(2) && !fit(1)) {
-        return g;
+    } else {
+        // Two channels per lane make every v_pk_fma_f32 count twice, but with many channels a period row is long
+        // and only one single-image workgroup fits a CU -- staging and arithmetic then take turns.  One channel per
+        // lane halves the periods per image: where that is what lets two workgroups share a CU it is faster
+        // (8 channels 96 -> 44.1 kHz: 0.73 -> 0.62 ms per 20 M frames).
+        static const int knob_cg = [] { const char* e = getenv("RSMP_FIR_CG"); return e ? atoi(e) : 0; }();   // tuning knob: 1 / 2 forces
+        bool ok = false;
+        if (knob_cg != 1) ok = fit(2);
+        if (knob_cg != 2 && (!ok || !two_per_cu)) {
+            const PeriodicGeometry g2 = g;
+            const bool ok2 = ok;
+            if (fit(1) && (two_per_cu || !ok2)) ok = true;
+            else if (ok2) { g = g2; ok = true; }
+            else ok = false;
+        }
+        if (!ok) return g;
     }
     g.ok = true;
     return g;
