@@ -625,6 +625,22 @@ def bench_c5(ctx: Ctx, args, steps: int, warmup: int):
     k_ms, _ = h.mean_kernel_ms()
     h.set_profiling(False)
     k_ms = ctx.max_over_ranks(k_ms)
+    # the same stream call by call (what a live 8-channel feed does): latency of one 512-frame resample() on
+    # HBM-resident buffers, call + wait, rank 0 only
+    lat = None
+    if ctx.rank == 0:
+        hl = ra.ResamplerFir.new_from_hz(ch, in_hz, out_hz, ra.Latency.Sample64, ra.Attenuation.Db120, device=ctx.local_rank)
+        d_chunk = d_span[:chunk * ch].contiguous() if d_span.numel() >= chunk * ch else torch.zeros(chunk * ch, device=ctx.dev)
+        d_y = torch.empty(hl.buffer_size_output(), device=ctx.dev, dtype=torch.float32)
+        ts = []
+        for i in range(520):
+            t1 = time.perf_counter()
+            hl.resample_device(d_chunk, d_y, ctx.stream)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t1)
+        ts = np.array(ts[20:]) * 1e6
+        lat = {"p50": round(float(np.percentile(ts, 50)), 1), "p99": round(float(np.percentile(ts, 99)), 1),
+               "chunk_frames": chunk, "realtime_factor_p50": round(chunk / in_hz / (float(np.percentile(ts, 50)) * 1e-6), 1)}
     values_in = frames * ch
     out_frames = sum(t.out_frames for t in shards)
     alg = 4.0 * ch * (frames + out_frames)
@@ -641,6 +657,7 @@ def bench_c5(ctx: Ctx, args, steps: int, warmup: int):
                                f"{chunk}-frame calls, cut into {ctx.world} run(s) of calls at the host mirror's exact "
                                f"state, each run one seek + one bulk launch on its GPU",
                    "calls_this_rank": s.n_calls, "halo_frames_this_rank": s.history_frames,
+                   "chunk_latency_us": lat, "algorithmic_GBps": round(alg * steps / dt / 1e9, 1),
                    "shard_planning_s": round(plan_s, 3), "host_enqueue_ms_per_step": round(host_dt / steps * 1e3, 4)},
         "roofline": {"bound": "hbm", "kernel": variant, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS * ctx.world,
                      "unit": "GB/s", "frac": round(ach / (HBM_PEAK_GBS * ctx.world), 4), "traffic": None,
