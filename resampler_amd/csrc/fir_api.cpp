@@ -479,11 +479,13 @@ int launch_jobs(rsmp_fir* leader, std::vector<Job>& jobs, hipStream_t stream) {
     const FirStreamDesc* d_descs = reinterpret_cast<const FirStreamDesc*>(d);
     if (leader->profiling)
         RSMP_HIP_CHECK(hipEventRecord(leader->prof_start[leader->prof_count % rsmp_fir::kProfRing], stream));
+    // a launch made of generic-kernel streams only (a streaming call, a batch of them) lets that kernel copy
+    // the tails as well: one launch per call instead of two
+    bool tail_fused = n_generic == n && max_out_generic != 0 && getenv("RSMP_FIR_NO_FUSED_TAIL") == nullptr;
     if (n_generic)
         RSMP_HIP_CHECK(rsmp::launch_fir_generic(d_descs, static_cast<uint32_t>(n_generic),
-                                                max_out_generic, max_ch_generic, stream));
+                                                max_out_generic, max_ch_generic, stream, tail_fused));
     size_t first = n_generic;
-    bool tail_fused = false;
     // Where the periodic launches mark non-finite sums: one bit per stream and 1024-frame chunk
     // (fir_nonfinite.h), one region of the buffer per launch; the repair launches follow the timed ones.
     struct Repair { size_t first; uint32_t count; rsmp::NfArgs nf; };

@@ -38,10 +38,21 @@ __device__ __forceinline__ float load_sample(const FirStreamDesc& d, int64_t v, 
                : d.in[static_cast<size_t>(v - d.hist_frames) * d.channels + c];
 }
 
-__global__ __launch_bounds__(kBlock) void fir_generic_kernel(const FirStreamDesc* __restrict__ descs) {
+// fuse_tail: the first workgroup of every stream also copies the stream's still-buffered frames into hist_next
+// (the job of fir_tail_copy_kernel: a second launch is a fifth of a streaming call's latency).
+__global__ __launch_bounds__(kBlock) void fir_generic_kernel(const FirStreamDesc* __restrict__ descs, uint32_t fuse_tail) {
     const FirStreamDesc d = descs[blockIdx.y];
     const uint32_t tile = blockIdx.x;
     const uint32_t tile_first = tile * kFirTile;
+    if (fuse_tail && tile == 0 && blockIdx.z == 0) {
+        const size_t total = static_cast<size_t>(d.tail_frames) * d.channels;
+        const size_t first = static_cast<size_t>(d.tail_start) * d.channels;
+        const size_t hist_values = static_cast<size_t>(d.hist_frames) * d.channels;
+        for (size_t i = threadIdx.x; i < total; i += kBlock) {
+            const size_t src = first + i;
+            d.hist_next[i] = src < hist_values ? d.hist[src] : d.in[src - hist_values];
+        }
+    }
     if (tile_first >= d.n_out) return;
 
     const int g = threadIdx.x & (kLanesPerFrame - 1);
@@ -211,11 +222,11 @@ hipError_t launch_fir_repair(const FirStreamDesc* d_descs, uint32_t n_streams, c
 }
 
 hipError_t launch_fir_generic(const FirStreamDesc* d_descs, uint32_t n_streams, uint32_t max_out,
-                              uint32_t max_channels, hipStream_t stream) {
+                              uint32_t max_channels, hipStream_t stream, bool fuse_tail) {
     if (n_streams == 0 || max_out == 0) return hipSuccess;
     const uint32_t cz = (max_channels + kChannelsPerBlock - 1) / kChannelsPerBlock;
     const dim3 grid((max_out + kFirTile - 1) / kFirTile, n_streams, cz ? cz : 1);
-    hipLaunchKernelGGL(fir_generic_kernel, grid, dim3(kBlock), 0, stream, d_descs);
+    hipLaunchKernelGGL(fir_generic_kernel, grid, dim3(kBlock), 0, stream, d_descs, fuse_tail ? 1u : 0u);
     return hipGetLastError();
 }
 

@@ -49,7 +49,7 @@ constexpr uint32_t kFirTile = 32;   // output frames per workgroup tile (generic
 
 // Generic kernel: any ratio, reference-form two-row interpolation; grid = (max tiles, streams).
 hipError_t launch_fir_generic(const FirStreamDesc* d_descs, uint32_t n_streams, uint32_t max_out,
-                              uint32_t max_channels, hipStream_t stream);
+                              uint32_t max_channels, hipStream_t stream, bool fuse_tail = false);
 // Re-evaluates, in the reference's two-row form, the output chunks a periodic launch marked as non-finite
 // (fir_nonfinite.h); exits at once when the launch marked nothing.
 hipError_t launch_fir_repair(const FirStreamDesc* d_descs, uint32_t n_streams, const NfArgs& nf, hipStream_t stream);
