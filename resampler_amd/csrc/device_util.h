@@ -47,7 +47,9 @@ public:
     PinnedBuffer& operator=(const PinnedBuffer&) = delete;
     ~PinnedBuffer() { if (ptr_) (void)hipHostFree(ptr_); }
 
-    hipError_t reserve(size_t bytes) {
+    // coherent = false: cached on the device like its own memory, visible to the other side at kernel
+    // boundaries (staging of small host-slice calls: the kernel reads every sample many times)
+    hipError_t reserve(size_t bytes, bool coherent = true) {
         if (bytes <= cap_) return hipSuccess;
         if (ptr_) {
             hipError_t e = hipHostFree(ptr_);
@@ -58,7 +60,7 @@ public:
         size_t want = bytes + bytes / 2;
         if (want < 4096) want = 4096;
         // mapped + coherent: small launch plans are read by the kernels straight from this memory
-        hipError_t e = hipHostMalloc(&ptr_, want, hipHostMallocMapped | hipHostMallocCoherent);
+        hipError_t e = hipHostMalloc(&ptr_, want, hipHostMallocMapped | (coherent ? hipHostMallocCoherent : hipHostMallocNonCoherent));
         if (e != hipSuccess) { ptr_ = nullptr; return e; }
         cap_ = want;
         return hipSuccess;

@@ -6,6 +6,7 @@
 // per instance (scratch pads, spectra) lives in LDS for the duration of a block.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -135,6 +136,7 @@ struct rsmp_fft {
     PinnedBuffer h_desc;
     DeviceBuffer d_desc;
     DeviceBuffer d_stage_in, d_stage_out;
+    rsmp::PinnedBuffer h_stage_in, h_stage_out;   // small calls: mapped host memory instead of copy-engine transfers
     bool profiling = false;
     hipEvent_t prof_start = nullptr, prof_stop = nullptr;
     bool prof_valid = false;
@@ -305,6 +307,25 @@ extern "C" int rsmp_fft_resample_bulk(rsmp_fft* r, const float* in, size_t in_le
         return rsmp::fail(RSMP_ERR_INVALID_OUTPUT_BUFFER_SIZE, "Output buffer size is invalid");
     if (n_chunks == 0) return RSMP_OK;
     RSMP_HIP_CHECK(hipStreamSynchronize(r->stream));
+    // (small calls through mapped host memory, as rsmp_fir_resample: fir_api.cpp)
+    static const size_t zero_copy_max = [] {
+        const char* e = getenv("RSMP_FIR_ZEROCOPY_MAX");
+        return e ? static_cast<size_t>(atoll(e)) : static_cast<size_t>(256 * 1024);
+    }();
+    if (need_in * sizeof(float) <= zero_copy_max && need_out * sizeof(float) <= zero_copy_max) {
+        RSMP_HIP_CHECK(r->h_stage_in.reserve(need_in * sizeof(float), false));
+        RSMP_HIP_CHECK(r->h_stage_out.reserve(need_out * sizeof(float), false));
+        std::memcpy(r->h_stage_in.get(), in, need_in * sizeof(float));
+        float* d_i = nullptr;
+        float* d_o = nullptr;
+        RSMP_HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&d_i), r->h_stage_in.get(), 0));
+        RSMP_HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&d_o), r->h_stage_out.get(), 0));
+        const int rc = rsmp_fft_resample_bulk_device(r, d_i, need_in, d_o, need_out, n_chunks, r->stream);
+        if (rc != RSMP_OK) return rc;
+        RSMP_HIP_CHECK(hipStreamSynchronize(r->stream));
+        std::memcpy(out, r->h_stage_out.get(), need_out * sizeof(float));
+        return RSMP_OK;
+    }
     RSMP_HIP_CHECK(r->d_stage_in.reserve(need_in * sizeof(float)));
     RSMP_HIP_CHECK(r->d_stage_out.reserve(need_out * sizeof(float)));
     RSMP_HIP_CHECK(hipMemcpyAsync(r->d_stage_in.get(), in, need_in * sizeof(float),

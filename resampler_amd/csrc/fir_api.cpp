@@ -752,19 +752,40 @@ extern "C" int rsmp_fir_resample(rsmp_fir* r, const float* in, size_t in_len, fl
         r->channels;
     const size_t stage_out = out_len < max_out ? out_len : max_out;
     RSMP_HIP_CHECK(hipStreamSynchronize(r->stream));
-    RSMP_HIP_CHECK(r->d_stage_in.reserve((stage_in + 4) * sizeof(float)));
-    RSMP_HIP_CHECK(r->d_stage_out.reserve((stage_out + 4) * sizeof(float)));
-    if (stage_in)
-        RSMP_HIP_CHECK(hipMemcpyAsync(r->d_stage_in.get(), in, stage_in * sizeof(float),
-                                      hipMemcpyHostToDevice, r->stream));
+    // A streaming call is a few kilobytes: two copy-engine transfers and their synchronisation cost more than
+    // the kernel.  Small calls therefore go through mapped host memory (cached on the device, visible at kernel
+    // boundaries): the CPU copies the caller's slice in, the kernel reads it over the link (once: re-reads hit
+    // L2) and writes the output back the same way.
+    static const size_t zero_copy_max = [] {
+        const char* e = getenv("RSMP_FIR_ZEROCOPY_MAX");   // bytes per direction; 0 disables
+        return e ? static_cast<size_t>(atoll(e)) : static_cast<size_t>(256 * 1024);
+    }();
+    const bool zero_copy = (stage_in + 4) * sizeof(float) <= zero_copy_max && (stage_out + 4) * sizeof(float) <= zero_copy_max;
+    float* d_in_stage = nullptr;
+    float* d_out_stage = nullptr;
+    if (zero_copy) {
+        RSMP_HIP_CHECK(r->h_stage_in.reserve((stage_in + 4) * sizeof(float), false));
+        RSMP_HIP_CHECK(r->h_stage_out.reserve((stage_out + 4) * sizeof(float), false));
+        if (stage_in) std::memcpy(r->h_stage_in.get(), in, stage_in * sizeof(float));
+        RSMP_HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&d_in_stage), r->h_stage_in.get(), 0));
+        RSMP_HIP_CHECK(hipHostGetDevicePointer(reinterpret_cast<void**>(&d_out_stage), r->h_stage_out.get(), 0));
+    } else {
+        RSMP_HIP_CHECK(r->d_stage_in.reserve((stage_in + 4) * sizeof(float)));
+        RSMP_HIP_CHECK(r->d_stage_out.reserve((stage_out + 4) * sizeof(float)));
+        if (stage_in)
+            RSMP_HIP_CHECK(hipMemcpyAsync(r->d_stage_in.get(), in, stage_in * sizeof(float),
+                                          hipMemcpyHostToDevice, r->stream));
+        d_in_stage = r->d_stage_in.as<float>();
+        d_out_stage = r->d_stage_out.as<float>();
+    }
     size_t c = 0, p = 0;
-    const int rc = run_single(r, r->d_stage_in.as<float>(), stage_in, r->d_stage_out.as<float>(),
-                              stage_out, 0, &c, &p, nullptr, 0, nullptr, r->stream);
+    const int rc = run_single(r, d_in_stage, stage_in, d_out_stage, stage_out, 0, &c, &p, nullptr, 0, nullptr, r->stream);
     if (rc != RSMP_OK) return rc;
-    if (p)
+    if (p && !zero_copy)
         RSMP_HIP_CHECK(hipMemcpyAsync(out, r->d_stage_out.get(), p * sizeof(float),
                                       hipMemcpyDeviceToHost, r->stream));
     RSMP_HIP_CHECK(hipStreamSynchronize(r->stream));
+    if (p && zero_copy) std::memcpy(out, r->h_stage_out.get(), p * sizeof(float));
     if (consumed) *consumed = c;
     if (produced) *produced = p;
     return RSMP_OK;

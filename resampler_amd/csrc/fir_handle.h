@@ -37,6 +37,7 @@ struct rsmp_fir {
     std::vector<char> plan_scratch;
     // staging for the host-pointer entry points
     rsmp::DeviceBuffer d_stage_in, d_stage_out;
+    rsmp::PinnedBuffer h_stage_in, h_stage_out;   // small calls: the kernels read / write mapped host memory, no copy engine
     rsmp::PeriodicState periodic;
     bool last_periodic = false;   // the handle's last launch went through a periodic kernel
     unsigned long long* d_work_counter = nullptr;   // periodic kernel's item queue (leader only), zero between launches
