@@ -567,6 +567,8 @@ def secondary_lines(ctx: Ctx, args):
     del batch, handles
     c4 = bench_c4(ctx, args, steps=256, warmup=8)
     sec["config4"] = {k: c4[k] for k in ("metric", "value", "unit", "ms_per_step", "scaling", "dtype", "config", "roofline")}
+    c5 = bench_c5(ctx, args, steps=10, warmup=2)
+    sec["config5"] = {k: c5[k] for k in ("metric", "value", "unit", "ms_per_step", "scaling", "dtype", "config", "roofline")}
     return sec
 
 
