@@ -2,21 +2,27 @@
 // (see fir_lockstep.h).  Per stream and step it is exactly one reference resample() call
 // (src/resampler_fir.rs:509-621): same frames accepted, same outputs, same frames retired.
 //
-// A workgroup owns a few streams of one rate pair:
-//   A  wave 0, one lane per stream: the reference's control flow (fir_mirror_core.h) -> n_out, frames
-//      consumed, the outputs that take the row-1023 variant, the exact position runs; meanwhile the
-//      other waves stage [buffered | new] frames of every stream into LDS (zeroed guards around them);
-//   B  the buffered tail is written back in place from LDS; then the outputs: D[16 classes][16 columns]
-//      += A[class][tap] * B[tap][column] with v_mfma_f32_16x16x4_f32 (exact f32, an fmaf chain over the
-//      taps), a column being one (stream, super period) pair -- "row = stream": the window of class j
-//      of period q starts at frame q*a + off(j) of ITS stream, wherever that stream stands;
-//      coefficients are the class tables of fir_periodic.h (the two phase rows pre-mixed with the
-//      class's frac, shifted to the tile's common window, zero padded) in A-operand order;
+// A workgroup (8 waves) owns a few streams of one rate pair:
+//   A  wave 0, one lane per stream: the step's plan -- from the stream's plan record (written one step ahead
+//      by wave 7, below) or, when the record is stale, the reference's control flow in line
+//      (fir_mirror_core.h) -> n_out, frames consumed, the outputs that take the row-1023 variant, the exact
+//      position runs -- and the column table.  Waves 1..6 stage the frames meanwhile: two-channel streams as
+//      a transposed fp16 image built straight from HBM (the split variant: operands cut into two fp16 planes,
+//      fir_split.hip's arithmetic; the columns derived from the plan records by the staging waves themselves),
+//      everything else as f32 spans by LDS-DMA (zeroed guards around them).  Wave 7 plans the NEXT step from the
+//      kernel's first cycle on and joins the units afterwards.  The barrier behind this phase is a count in LDS.
+//   B  the buffered tail goes to the stream's other history buffer (history alternates by step parity: no
+//      step reads what it writes); then the outputs: D[16 classes][16 columns] += A[class][tap] * B[tap][column]
+//      with v_mfma_f32_16x16x32_f16 on the image (three products per 32 taps) or v_mfma_f32_16x16x4_f32 on the
+//      spans (exact f32, an fmaf chain over the taps), a column being one (stream, super period) pair -- "row =
+//      stream": the window of class j of period q starts at frame q*a + off(j) of ITS stream, wherever that
+//      stream stands; coefficients are the class tables of fir_periodic.h (the two phase rows pre-mixed with
+//      the class's frac, shifted to the tile's common window, zero padded) in the operand order of the MFMA;
 //   C  outputs whose f64 position fell just below an integer (previous frame, row 1023, :562-564);
 //   D  streams that cannot use class tables (irrational ratio, drifted position) and streams whose
-//      step saw a non-finite sample are evaluated in the reference's own form (two phase rows, eight
-//      partial sums lerped per lane, src/fir/avx.rs:25-58): a zero padding coefficient times an
-//      infinity would otherwise turn finite reference outputs into NaN.
+//      step saw a non-finite sum (inf / NaN, or a sample beyond the fp16 planes' range) are evaluated in the
+//      reference's own form (two phase rows, eight partial sums lerped per lane, src/fir/avx.rs:25-58): a zero
+//      padding coefficient times an infinity would otherwise turn finite reference outputs into NaN.
 #include "fir_lockstep.h"
 
 #include <algorithm>
