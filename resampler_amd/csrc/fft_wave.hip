@@ -6,19 +6,23 @@
 //
 // Why another mapping: with a workgroup per transform every one of the ~14 phases of a block ends in a
 // workgroup barrier and costs about a microsecond however little it computes (43 % of the wave time at
-// barriers, DESIGN.md 4.3).  Here a wave owns a (stream, channel) and walks a run of its blocks alone:
-//   * the 1176 / 1280 complex points live in ONE private LDS buffer (10 KB per wave); a Stockham stage
-//     reads all of the wave's butterflies into registers, then writes the results back in place -- the LDS
-//     executes a wave's operations in order, so no barrier or fence exists anywhere in the kernel;
-//   * the first forward stage takes its inputs straight from HBM (the zero padding never exists), the
-//     last inverse stage leaves its outputs in registers, where the overlap carry of the (stream, channel)
-//     also lives for the whole run: conjugation, overlap-add and the interleaved store happen there;
-//   * real-FFT post-process, filter multiply, truncate / zero-extend, inverse pre-process and the input
-//     conjugation of the inverse transform are two in-place passes over bin pairs;
-//   (Requesting the next block's samples ahead of the transform costs 28 registers and spilled under the
-//   168-register cap of three waves per SIMD; the other eleven waves of the CU cover the load latency.)
-// Arithmetic, operation order and tables are those of fft_kernels.hip (and of the reference's scalar
-// specs): results are bit-identical to the workgroup kernels.
+// barriers, DESIGN.md 4.4).  Here a wave owns a (stream, channel) and walks a run of its blocks alone:
+//   * the 1176 / 1280 complex points live in ONE private LDS buffer (10 KB per wave); a pass reads all of the
+//     wave's inputs into registers, then writes the results back in place -- the LDS executes a wave's
+//     operations in order, so no barrier or fence exists anywhere in the block loop;
+//   * the first two stages of each transform are one register pass (radix 3x7 / 4x5: wave_fused_first); the
+//     forward one takes its inputs straight from HBM and skips the zero padding, the last inverse stage leaves
+//     its outputs in registers, where the overlap carry of the (stream, channel) also lives for the whole run:
+//     conjugation, overlap-add and the interleaved store happen there;
+//   * real-FFT post-process, and filter multiply + truncate / zero-extend + inverse pre-process + the input
+//     conjugation of the inverse transform, are two in-place passes over bin pairs;
+//   * complex values are a packed two-float vector type (fft_butterflies_pk.h): complex adds are single
+//     v_pk_*_f32 instructions, rotations / conjugations / complex multiplies carry op_sel / neg modifiers;
+//   * LDS rows are padded where a pass's lane stride would meet on banks, reads are ds_read_b64 only, all of a
+//     pass's reads are issued before its first butterfly, radix-7/8 twiddle rows fetch w, w^2, w^4 only.
+// Arithmetic: the reference's scalar specs, with a*b + c fused and some twiddles multiplied out (1.45e-7 RMS
+// from the CPU path); -DRSMP_FFT_WAVE_EXACT (libresampler_amd_fftexact.so) is operation for operation the
+// reference's and bit-identical to it (tests/test_fft_gpu.py).
 // The two (or C) waves of a block's channels sit in one workgroup, so their half-line stores of the
 // interleaved output meet in the same L2.
 #include <cmath>
