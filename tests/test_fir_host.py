@@ -27,6 +27,25 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(ra.declared_symbols()), declared ^ set(ra.declared_symbols())
 
 
+def test_rust_shim_binds_symbols_of_the_header_with_matching_arity():
+    """No rustc in the image: the source-only crate (bindings/rust) cannot be compiled here.  What can be checked:
+    every `fn rsmp_*` of its extern block names an entry point of the C header, with the same number of arguments,
+    and both libraries export it."""
+    src = open(os.path.join(ROOT, "bindings", "rust", "src", "lib.rs")).read()
+    header = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "resampler_amd.h")).read(), flags=re.S)
+    rust = {m.group(1): m.group(2) for m in re.finditer(r"fn (rsmp_[a-z0-9_]+)\s*\(([^)]*)\)", src, flags=re.S)}
+    assert len(rust) >= 19
+    lib = C.CDLL(ra.LIB_PATH)
+    for name, args in rust.items():
+        m = re.search(r"\b" + name + r"\s*\(([^)]*)\)", header, flags=re.S)
+        assert m, name
+        n_rust = len([a for a in args.split(",") if a.strip()])
+        c_args = m.group(1).strip()
+        n_c = 0 if c_args in ("", "void") else len(c_args.split(","))
+        assert n_rust == n_c, (name, args, c_args)
+        assert hasattr(lib, name), name
+
+
 def test_no_device_fails_loudly():
     if ra.device_count() > 0:
         pytest.skip("a GPU is present")
