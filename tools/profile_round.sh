@@ -32,7 +32,8 @@ declare -A CMD
 CMD[fir]="--steps 20 --warmup 3 --no-cpu --no-secondary"
 CMD[fft]="--path fft --steps 20 --warmup 3 --no-cpu"
 CMD[c4]="--config c4 --steps 256 --warmup 16"
-for w in fir fft c4; do
+CMD[c5]="--config c5 --steps 10 --warmup 2"
+for w in fir fft c4 c5; do
     rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_$w" -- python3 "$R/bench.py" ${CMD[$w]} \
         > "$SUM/bench_${w}_under_rocprofv3.json" 2> "$OUT/kt_$w.err"
     cp "$(find "$OUT/kt_$w" -name '*kernel_stats.csv' | head -1)" "$SUM/${w}_kernel_stats.csv" 2>/dev/null
