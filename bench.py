@@ -148,10 +148,15 @@ def spinup(ctx: Ctx, step, seconds: float) -> None:
     if seconds <= 0:
         return
     t0 = time.perf_counter()
-    while time.perf_counter() - t0 < seconds:
+    while True:
         for _ in range(20):
             step()
         ctx.torch.cuda.synchronize()
+        done = time.perf_counter() - t0 >= seconds
+        if ctx.dist:   # every rank runs the same number of steps (a step may contain collectives: --feed rccl)
+            done = ctx.max_over_ranks(1.0 if done else 0.0) > 0.0
+        if done:
+            break
 
 
 # ------------------------------------------------------------------------------------------------
