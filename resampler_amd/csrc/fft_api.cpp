@@ -102,7 +102,7 @@ int get_plan(int device, uint32_t in_hz, uint32_t out_hz, std::shared_ptr<Device
     d.n_rc_i = static_cast<uint32_t>(h.inverse.rc_twiddles.size());
     d.new_length = static_cast<uint32_t>(h.new_length);
     d.lds_complex = static_cast<uint32_t>((h.fft_in > h.fft_out ? h.fft_in : h.fft_out) + 1);
-    if (rsmp::fft_ola_lds_bytes(d, 1) > 160 * 1024)
+    if (rsmp::fft_ola_lds_bytes(d, 1) > 160 * 1024 && (rsmp::fft_big_lds_bytes(d) > 160 * 1024 || d.lds_complex > 12288 + 1))
         return rsmp::fail(RSMP_ERR_INVALID_ARGUMENT,
                           "ResamplerFft: blocks of %zu -> %zu frames do not fit the 160 KiB LDS",
                           h.fft_in, h.fft_out);
@@ -194,7 +194,9 @@ int launch_fft_jobs(rsmp_fft* leader, const std::vector<FftJob>& jobs, hipStream
 }
 
 int check_lds(const rsmp_fft* r) {
-    if (rsmp::fft_ola_lds_bytes(r->plan->dev, static_cast<uint32_t>(r->channels)) > 160 * 1024)
+    // (what does not fit the two-buffer kernels with the overlap rows in LDS runs on the one-buffer kernel)
+    if (rsmp::fft_ola_lds_bytes(r->plan->dev, static_cast<uint32_t>(r->channels)) > 160 * 1024 &&
+        (rsmp::fft_big_lds_bytes(r->plan->dev) > 160 * 1024 || r->plan->dev.lds_complex > 12288 + 1))
         return rsmp::fail(RSMP_ERR_INVALID_ARGUMENT, "ResamplerFft: %zu channels of this block size exceed the LDS",
                           r->channels);
     return RSMP_OK;

@@ -52,6 +52,7 @@ hipError_t launch_fft_ola_wave(const FftPlanDev& plan, const FftStreamDesc* d_de
 // (resampler_fft.rs:375-376); plan.filter is ignored.
 hipError_t launch_fft_filter_spectrum(const FftPlanDev& plan, const float* d_filter_time,
                                       float2* d_filter_spectrum, hipStream_t stream);
+size_t fft_big_lds_bytes(const FftPlanDev& plan);   // one-buffer kernel of the largest plans
 size_t fft_ola_lds_bytes(const FftPlanDev& plan, uint32_t channels);
 
 }  // namespace rsmp

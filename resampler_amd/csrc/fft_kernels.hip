@@ -78,6 +78,7 @@ __device__ float2* stockham(float2* a, float2* b, uint32_t n, uint32_t n_stages,
 }
 
 // postprocess_fft (radix_fft.rs:500-537 + real_complex/mod.rs:37-74), in place on x[0 .. n2].
+template <int THREADS = kFftThreads>
 __device__ void postprocess_forward(float2* x, uint32_t n2, const float2* __restrict__ rc, uint32_t n_rc) {
     const uint32_t len = n2 + 1, split = len / 2;
     uint32_t iters = split - 1;                       // left middle
@@ -89,7 +90,7 @@ __device__ void postprocess_forward(float2* x, uint32_t n2, const float2* __rest
         x[0] = make_float2(z0.x + z0.y, 0.0f);
         x[n2] = make_float2(z0.x - z0.y, 0.0f);
     }
-    for (uint32_t i = threadIdx.x; i < iters; i += kFftThreads) {
+    for (uint32_t i = threadIdx.x; i < iters; i += THREADS) {
         const uint32_t l = 1 + i, rr = n2 - 1 - i;
         const float2 o = x[l], orv = x[rr], tw = rc[i];
         const float2 sum = cadd(o, orv), diff = csub(o, orv);
@@ -104,6 +105,7 @@ __device__ void postprocess_forward(float2* x, uint32_t n2, const float2* __rest
 
 // preprocess_ifft (radix_fft.rs:592-624 + real_complex/mod.rs:84-114) followed by the input
 // conjugation of process_inverse_complex (:634-637), in place on y[0 .. n2].
+template <int THREADS = kFftThreads>
 __device__ void preprocess_inverse(float2* y, uint32_t n2, const float2* __restrict__ rc, uint32_t n_rc) {
     const uint32_t len = n2 + 1, split = len / 2;
     uint32_t iters = split - 1;
@@ -115,7 +117,7 @@ __device__ void preprocess_inverse(float2* y, uint32_t n2, const float2* __restr
         const float2 first_sum = cadd(a, b), first_diff = csub(a, b);
         y[0] = make_float2(first_sum.x - first_sum.y, first_diff.x - first_diff.y);
     }
-    for (uint32_t i = threadIdx.x; i < iters; i += kFftThreads) {
+    for (uint32_t i = threadIdx.x; i < iters; i += THREADS) {
         const uint32_t l = 1 + i, rr = n2 - 1 - i;
         const float2 a = y[l], b = y[rr], tw = rc[i];
         const float2 sum = cadd(a, b), diff = csub(a, b);
@@ -130,7 +132,7 @@ __device__ void preprocess_inverse(float2* y, uint32_t n2, const float2* __restr
         y[len / 2] = make_float2(dbl.x, -dbl.y);
     }
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < n2; i += kFftThreads) y[i].y = -y[i].y;
+    for (uint32_t i = threadIdx.x; i < n2; i += THREADS) y[i].y = -y[i].y;
 }
 
 __global__ __launch_bounds__(kFftThreads) void fft_ola_kernel(FftPlanDev plan,
@@ -585,7 +587,130 @@ __global__ __launch_bounds__(kFftThreads) void fft_filter_kernel(FftPlanDev plan
     for (uint32_t k = threadIdx.x; k <= fi; k += kFftThreads) spectrum[k] = X[k];
 }
 
+
+// ---- plans whose two transform buffers do not fit the LDS (blocks of 7056 .. 12288 frames: the rate pairs with
+// 384 kHz, or 176.4 kHz against 16 / 32 kHz) -------------------------------------------------------------------
+// ONE buffer: a Stockham stage reads all of its butterflies into registers, a barrier, then writes the results
+// back in place (1024 threads: at most 6 butterflies of 16 values per thread).  The overlap rows stay in HBM
+// (the stream's next-state rows serve as the carry: one workgroup walks a whole stream).  Same operations in
+// the same order as the kernels above.
+constexpr int kBigThreads = 1024;
+constexpr uint32_t kBigMaxN = 12288;
+
+template <int R>
+__device__ __forceinline__ void stage_inplace(float2* buf, uint32_t n, uint32_t stride, const float2* __restrict__ tw) {
+    constexpr int KMAX = (kBigMaxN / R + kBigThreads - 1) / kBigThreads;
+    const uint32_t m = n / R;
+    float2 t[KMAX][R];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        const uint32_t i = threadIdx.x + k * kBigThreads;
+        if (i < m) {
+#pragma unroll
+            for (int q = 0; q < R; ++q) t[k][q] = buf[i + q * m];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        const uint32_t i = threadIdx.x + k * kBigThreads;
+        if (i < m) {
+            const uint32_t kk = stride == 1 ? 0u : i % stride;
+            float2 o[R];
+            if (stride != 1) {
+                const float2* w = tw + kk * (R - 1);
+#pragma unroll
+                for (int q = 1; q < R; ++q) t[k][q] = cmul(w[q - 1], t[k][q]);
+            }
+            dft<R>(t[k], o);
+            float2* d = buf + R * i - (R - 1) * kk;
+#pragma unroll
+            for (int q = 0; q < R; ++q) d[q * stride] = o[q];
+        }
+    }
+    __syncthreads();
+}
+
+__device__ void stockham_inplace(float2* buf, uint32_t n, uint32_t n_stages, const uint32_t* radix,
+                                 const uint32_t* tw_off, const float2* __restrict__ tw) {
+    uint32_t stride = 1;
+    for (uint32_t s = 0; s < n_stages; ++s) {
+        const uint32_t r = radix[s];
+        const float2* w = tw + tw_off[s];
+        switch (r) {
+            case 2: stage_inplace<2>(buf, n, stride, w); break;
+            case 3: stage_inplace<3>(buf, n, stride, w); break;
+            case 4: stage_inplace<4>(buf, n, stride, w); break;
+            case 5: stage_inplace<5>(buf, n, stride, w); break;
+            case 7: stage_inplace<7>(buf, n, stride, w); break;
+            default: stage_inplace<8>(buf, n, stride, w); break;
+        }
+        stride *= r;
+    }
+}
+
+__global__ __launch_bounds__(kBigThreads) void fft_ola_big_kernel(FftPlanDev plan, const FftStreamDesc* __restrict__ descs) {
+    extern __shared__ __attribute__((aligned(16))) float2 lds2[];
+    const FftStreamDesc d = descs[blockIdx.x];
+    if (d.n_blocks == 0) return;
+    const uint32_t C = d.channels, fi = plan.fft_in, fo = plan.fft_out;
+    float2* buf = lds2;
+    float* carry = d.overlap_next;                       // [C][fo], in HBM
+    if (d.overlap_next != d.overlap)
+        for (uint32_t e = threadIdx.x; e < C * fo; e += kBigThreads) carry[e] = d.overlap[e];
+    __syncthreads();
+    for (uint32_t b = 0; b < d.n_blocks; ++b) {
+        const float* __restrict__ xin = d.in + static_cast<size_t>(b) * fi * C;
+        float* __restrict__ xout = d.out + static_cast<size_t>(b) * fo * C;
+        for (uint32_t c = 0; c < C; ++c) {
+            // resampler_fft.rs:387-388: fi reals + fi zeros, viewed as fi complexes (radix_fft.rs:552-554)
+            for (uint32_t i = threadIdx.x; i < fi; i += kBigThreads) {
+                float2 v = make_float2(0.f, 0.f);
+                if (2 * i + 1 < fi) v = make_float2(xin[(2 * i) * C + c], xin[(2 * i + 1) * C + c]);
+                else if (2 * i < fi) v = make_float2(xin[(2 * i) * C + c], 0.f);
+                buf[i] = v;
+            }
+            __syncthreads();
+            stockham_inplace(buf, fi, plan.n_stages_f, plan.radix_f, plan.tw_off_f, plan.tw_f);
+            postprocess_forward<kBigThreads>(buf, fi, plan.rc_f, plan.n_rc_f);
+            __syncthreads();
+            // resampler_fft.rs:401-408: multiply new_length bins, zero the rest up to fo
+            for (uint32_t k = threadIdx.x; k <= fo; k += kBigThreads)
+                buf[k] = k < plan.new_length ? cmul(buf[k], plan.filter[k]) : make_float2(0.f, 0.f);
+            __syncthreads();
+            preprocess_inverse<kBigThreads>(buf, fo, plan.rc_i, plan.n_rc_i);
+            __syncthreads();
+            stockham_inplace(buf, fo, plan.n_stages_i, plan.radix_i, plan.tw_off_i, plan.tw_i);
+            // output conjugation (radix_fft.rs:656-669), reals 2i, 2i+1 <- Z[i]; overlap-add (:416-423)
+            float* ov = carry + c * fo;
+            for (uint32_t t = threadIdx.x; t < fo; t += kBigThreads) {
+                const float2 z = buf[t >> 1];
+                const float y = (t & 1u) ? -z.y : z.x;
+                xout[t * C + c] = y + ov[t];
+                const float2 z2 = buf[(t + fo) >> 1];
+                ov[t] = ((t + fo) & 1u) ? -z2.y : z2.x;
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBigThreads) void fft_filter_big_kernel(FftPlanDev plan, const float* __restrict__ filter_time,
+                                                                     float2* __restrict__ spectrum) {
+    extern __shared__ __attribute__((aligned(16))) float2 lds2[];
+    float2* buf = lds2;
+    const uint32_t fi = plan.fft_in;
+    for (uint32_t i = threadIdx.x; i < fi; i += kBigThreads) buf[i] = make_float2(filter_time[2 * i], filter_time[2 * i + 1]);
+    __syncthreads();
+    stockham_inplace(buf, fi, plan.n_stages_f, plan.radix_f, plan.tw_off_f, plan.tw_f);
+    postprocess_forward<kBigThreads>(buf, fi, plan.rc_f, plan.n_rc_f);
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k <= fi; k += kBigThreads) spectrum[k] = buf[k];
+}
+
 }  // namespace
+
+size_t fft_big_lds_bytes(const FftPlanDev& plan) { return static_cast<size_t>(plan.lds_complex) * sizeof(float2); }
 
 size_t fft_ola_lds_bytes(const FftPlanDev& plan, uint32_t channels) {
     return 2 * static_cast<size_t>(plan.lds_complex) * sizeof(float2) +
@@ -602,6 +727,15 @@ hipError_t launch_fft_ola(const FftPlanDev& plan, const FftStreamDesc* d_descs, 
         if (e != hipErrorNotSupported) return e;
     }
     size_t lds = fft_ola_lds_bytes(plan, max_channels);
+    if (lds > 160 * 1024) {   // the two-buffer kernels do not fit: one buffer, in place, a workgroup per stream
+        const size_t big = fft_big_lds_bytes(plan);
+        if (big > 160 * 1024) return hipErrorInvalidValue;
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fft_ola_big_kernel),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(fft_ola_big_kernel, dim3(n_streams), dim3(kBigThreads), big, stream, plan, d_descs);
+        return hipGetLastError();
+    }
     bool all_stereo = max_channels == 2 && min_channels == 2;
     static const bool generic_only = getenv("RSMP_FFT_GENERIC") != nullptr;   // A/B: skip the specialised builds
     const bool rc_full = plan.n_rc_f == plan.fft_in / 2 - 1 && plan.n_rc_i == plan.fft_out / 2 - 1;
@@ -658,6 +792,19 @@ hipError_t launch_fft_ola(const FftPlanDev& plan, const FftStreamDesc* d_descs, 
 hipError_t launch_fft_filter_spectrum(const FftPlanDev& plan, const float* d_filter_time,
                                       float2* d_filter_spectrum, hipStream_t stream) {
     const size_t lds = 2 * static_cast<size_t>(plan.lds_complex) * sizeof(float2);
+    if (lds > 160 * 1024) {
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fft_filter_big_kernel),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(fft_filter_big_kernel, dim3(1), dim3(kBigThreads), fft_big_lds_bytes(plan), stream, plan,
+                           d_filter_time, d_filter_spectrum);
+        return hipGetLastError();
+    }
+    if (lds > 64 * 1024) {   // dynamic LDS above 64 KiB must be opted into
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fft_filter_kernel),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+    }
     hipLaunchKernelGGL(fft_filter_kernel, dim3(1), dim3(kFftThreads), lds, stream, plan,
                        d_filter_time, d_filter_spectrum);
     return hipGetLastError();

@@ -58,6 +58,13 @@ def consistent(ch, in_hz, out_hz):
     (1, 44100, 44100),
     (1, 22050, 48000),
     (2, 88200, 96000),
+    # blocks of 7056 .. 12288 frames: one transform buffer, in place (fft_ola_big_kernel)
+    (1, 44100, 384000),
+    (1, 384000, 44100),
+    (1, 16000, 384000),
+    (1, 176400, 384000),
+    (2, 176400, 384000),
+    (1, 32000, 176400),
 ])
 def test_per_call_resample_matches_oracle(ch, in_hz, out_hz):
     assert consistent(ch, in_hz, out_hz)
