@@ -255,3 +255,28 @@ def test_block_sharded_stream_equals_the_single_launch(in_hz, out_hz, blocks, wo
         torch.cuda.synchronize()
         assert d_out.numel() == (end - first) * n_out
         assert torch.equal(d_out, d_whole[first * n_out:end * n_out]), (first, end)
+
+
+@pytest.mark.gpu
+def test_every_rate_pair_of_the_reference_constructs_and_matches():
+    """All 90 ordered pairs of the reference's SampleRate (src/lib.rs:167-188), one channel, three blocks each
+    through the bulk entry: blocks from 64 to 12288 frames, every kernel flavour (wave, workgroup, one-buffer)."""
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda:0")
+    worst = 0.0
+    for a, b in itertools.permutations(RATES, 2):
+        g = ra.ResamplerFft.new(1, sr(a), sr(b))
+        r = o.OracleFft(1, a, b)
+        n_in, n_out = g.chunk_size_input(), g.chunk_size_output()
+        assert (n_in, n_out, g.delay()) == (r.chunk_size_input(), r.chunk_size_output(), r.delay()), (a, b)
+        blocks = 3
+        x = synth.fast_noise(blocks * n_in, seed=a % 977 + b % 13)
+        d_out = torch.zeros(blocks * n_out, device=dev)
+        g.resample_bulk_device(torch.from_numpy(x).to(dev), d_out, blocks)
+        ref = np.zeros((blocks, n_out), np.float32)
+        for k in range(blocks):
+            assert r.resample(x[k * n_in:(k + 1) * n_in], ref[k]) == 0
+        e = rms(d_out.cpu().numpy(), ref.reshape(-1))
+        assert e <= RMS_TOL, (a, b, e)
+        worst = max(worst, e)
+    assert worst > 0.0
