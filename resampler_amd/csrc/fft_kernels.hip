@@ -33,11 +33,11 @@ constexpr int kFftThreads = 256;
 // One out-of-place Stockham stage: butterfly i reads src[i + q*m], twiddles inputs 1..R-1 with
 // w[(i mod stride)*(R-1) + q-1] (none when stride == 1) and writes dst[R*i - (R-1)*k + q*stride]
 // (butterfly4/mod.rs:316-320 etc.).
-template <int R>
+template <int R, int THREADS = kFftThreads>
 __device__ __forceinline__ void stage(const float2* __restrict__ src, float2* __restrict__ dst,
                                       uint32_t n, uint32_t stride, const float2* __restrict__ tw) {
     const uint32_t m = n / R;
-    for (uint32_t i = threadIdx.x; i < m; i += kFftThreads) {
+    for (uint32_t i = threadIdx.x; i < m; i += THREADS) {
         const uint32_t k = stride == 1 ? 0u : i % stride;
         float2 t[R], o[R];
 #pragma unroll
@@ -55,6 +55,7 @@ __device__ __forceinline__ void stage(const float2* __restrict__ src, float2* __
 }
 
 // stockham_autosort (stockham_autosort.rs:169-247): returns the buffer holding the result.
+template <int THREADS = kFftThreads>
 __device__ float2* stockham(float2* a, float2* b, uint32_t n, uint32_t n_stages,
                             const uint32_t* radix, const uint32_t* tw_off,
                             const float2* __restrict__ tw) {
@@ -63,12 +64,12 @@ __device__ float2* stockham(float2* a, float2* b, uint32_t n, uint32_t n_stages,
         const uint32_t r = radix[s];
         const float2* w = tw + tw_off[s];
         switch (r) {
-            case 2: stage<2>(a, b, n, stride, w); break;
-            case 3: stage<3>(a, b, n, stride, w); break;
-            case 4: stage<4>(a, b, n, stride, w); break;
-            case 5: stage<5>(a, b, n, stride, w); break;
-            case 7: stage<7>(a, b, n, stride, w); break;
-            default: stage<8>(a, b, n, stride, w); break;
+            case 2: stage<2, THREADS>(a, b, n, stride, w); break;
+            case 3: stage<3, THREADS>(a, b, n, stride, w); break;
+            case 4: stage<4, THREADS>(a, b, n, stride, w); break;
+            case 5: stage<5, THREADS>(a, b, n, stride, w); break;
+            case 7: stage<7, THREADS>(a, b, n, stride, w); break;
+            default: stage<8, THREADS>(a, b, n, stride, w); break;
         }
         __syncthreads();
         float2* tmp = a; a = b; b = tmp;
@@ -135,22 +136,31 @@ __device__ void preprocess_inverse(float2* y, uint32_t n2, const float2* __restr
     for (uint32_t i = threadIdx.x; i < n2; i += THREADS) y[i].y = -y[i].y;
 }
 
-__global__ __launch_bounds__(kFftThreads) void fft_ola_kernel(FftPlanDev plan,
-                                                              const FftStreamDesc* __restrict__ descs,
-                                                              uint32_t run) {
+// THREADS = 256, PER_CHANNEL = false: a workgroup walks the channels of a block one after the other.
+// THREADS = 64, PER_CHANNEL = true: a one-wave workgroup per (stream, run of blocks, channel) -- its barriers cost
+// nothing, and as many of them share a CU as the LDS holds (blocks of 512 -> 256 frames: 16): transforms too small
+// to occupy 256 threads (64 radix-8 butterflies per stage) run up to twice as fast this way.
+template <int THREADS, bool PER_CHANNEL>
+__global__ __launch_bounds__(THREADS) void fft_ola_kernel(FftPlanDev plan,
+                                                          const FftStreamDesc* __restrict__ descs,
+                                                          uint32_t run) {
     extern __shared__ __attribute__((aligned(16))) float2 lds2[];
     const FftStreamDesc d = descs[blockIdx.y];
     const uint32_t first = blockIdx.x * run;
     if (first >= d.n_blocks) return;
     const uint32_t last = first + run < d.n_blocks ? first + run : d.n_blocks;  // exclusive
     const uint32_t C = d.channels, fi = plan.fft_in, fo = plan.fft_out;
+    if (PER_CHANNEL && blockIdx.z >= C) return;
+    const uint32_t c_begin = PER_CHANNEL ? blockIdx.z : 0u, c_end = PER_CHANNEL ? blockIdx.z + 1u : C;
     float2* bufA = lds2;
     float2* bufB = lds2 + plan.lds_complex;
-    float* carry = reinterpret_cast<float*>(lds2 + 2 * plan.lds_complex);   // [C][fo]
+    float* carry = reinterpret_cast<float*>(lds2 + 2 * plan.lds_complex);   // [C][fo], or [fo] of the workgroup's channel
+    const uint32_t carry_base = PER_CHANNEL ? c_begin * fo : 0u;           // index of carry[0] in the stream's overlap rows
+    const uint32_t carry_len = (c_end - c_begin) * fo;
 
     // overlap carried into the run: the stream state, or the predecessor block recomputed
     if (first == 0)
-        for (uint32_t e = threadIdx.x; e < C * fo; e += kFftThreads) carry[e] = d.overlap[e];
+        for (uint32_t e = threadIdx.x; e < carry_len; e += THREADS) carry[e] = d.overlap[carry_base + e];
     const int64_t b_begin = first == 0 ? 0 : static_cast<int64_t>(first) - 1;
     __syncthreads();
 
@@ -158,36 +168,36 @@ __global__ __launch_bounds__(kFftThreads) void fft_ola_kernel(FftPlanDev plan,
         const bool emit = b >= static_cast<int64_t>(first);
         const float* __restrict__ xin = d.in + static_cast<size_t>(b) * fi * C;
         float* __restrict__ xout = d.out + static_cast<size_t>(b) * fo * C;
-        for (uint32_t c = 0; c < C; ++c) {
+        for (uint32_t c = c_begin; c < c_end; ++c) {
             // resampler_fft.rs:387-388: fi reals + fi zeros, viewed as fi complexes (radix_fft.rs:552-554)
-            for (uint32_t i = threadIdx.x; i < fi; i += kFftThreads) {
+            for (uint32_t i = threadIdx.x; i < fi; i += THREADS) {
                 float2 v = make_float2(0.f, 0.f);
                 if (2 * i + 1 < fi) v = make_float2(xin[(2 * i) * C + c], xin[(2 * i + 1) * C + c]);
                 else if (2 * i < fi) v = make_float2(xin[(2 * i) * C + c], 0.f);
                 bufA[i] = v;
             }
             __syncthreads();
-            float2* X = stockham(bufA, bufB, fi, plan.n_stages_f, plan.radix_f, plan.tw_off_f, plan.tw_f);
+            float2* X = stockham<THREADS>(bufA, bufB, fi, plan.n_stages_f, plan.radix_f, plan.tw_off_f, plan.tw_f);
             float2* Y = X == bufA ? bufB : bufA;
-            postprocess_forward(X, fi, plan.rc_f, plan.n_rc_f);
+            postprocess_forward<THREADS>(X, fi, plan.rc_f, plan.n_rc_f);
             __syncthreads();
             // resampler_fft.rs:401-408: multiply new_length bins, zero the rest up to fo
-            for (uint32_t k = threadIdx.x; k <= fo; k += kFftThreads)
+            for (uint32_t k = threadIdx.x; k <= fo; k += THREADS)
                 Y[k] = k < plan.new_length ? cmul(X[k], plan.filter[k]) : make_float2(0.f, 0.f);
             __syncthreads();
-            preprocess_inverse(Y, fo, plan.rc_i, plan.n_rc_i);
+            preprocess_inverse<THREADS>(Y, fo, plan.rc_i, plan.n_rc_i);
             __syncthreads();
-            float2* Z = stockham(Y, X, fo, plan.n_stages_i, plan.radix_i, plan.tw_off_i, plan.tw_i);
+            float2* Z = stockham<THREADS>(Y, X, fo, plan.n_stages_i, plan.radix_i, plan.tw_off_i, plan.tw_i);
             // output conjugation (radix_fft.rs:656-669), reals 2i, 2i+1 <- Z[i]; overlap-add (:416-423)
-            float* ov = carry + c * fo;
+            float* ov = carry + (c - c_begin) * fo;
             if (emit)
-                for (uint32_t t = threadIdx.x; t < fo; t += kFftThreads) {
+                for (uint32_t t = threadIdx.x; t < fo; t += THREADS) {
                     const float2 z = Z[t >> 1];
                     const float y = (t & 1u) ? -z.y : z.x;
                     xout[t * C + c] = y + ov[t];
                 }
             __syncthreads();
-            for (uint32_t t = threadIdx.x; t < fo; t += kFftThreads) {
+            for (uint32_t t = threadIdx.x; t < fo; t += THREADS) {
                 const float2 z = Z[(t + fo) >> 1];
                 ov[t] = ((t + fo) & 1u) ? -z.y : z.x;
             }
@@ -195,7 +205,7 @@ __global__ __launch_bounds__(kFftThreads) void fft_ola_kernel(FftPlanDev plan,
         }
     }
     if (last == d.n_blocks)
-        for (uint32_t e = threadIdx.x; e < C * fo; e += kFftThreads) d.overlap_next[e] = carry[e];
+        for (uint32_t e = threadIdx.x; e < carry_len; e += THREADS) d.overlap_next[carry_base + e] = carry[e];
 }
 
 // ---- plan-specialised kernel -----------------------------------------------------------------------
@@ -740,7 +750,8 @@ hipError_t launch_fft_ola(const FftPlanDev& plan, const FftStreamDesc* d_descs, 
     static const bool generic_only = getenv("RSMP_FFT_GENERIC") != nullptr;   // A/B: skip the specialised builds
     const bool rc_full = plan.n_rc_f == plan.fft_in / 2 - 1 && plan.n_rc_i == plan.fft_out / 2 - 1;
     typedef void (*Kernel)(FftPlanDev, const FftStreamDesc*, uint32_t);
-    Kernel fn = fft_ola_kernel;
+    Kernel fn = fft_ola_kernel<kFftThreads, false>;
+    uint32_t threads = kFftThreads, grid_z = 1;
     static const bool no_stereo = getenv("RSMP_FFT_NO_STEREO") != nullptr;   // A/B
     const bool stereo = all_stereo && !no_stereo;
     if (!generic_only && rc_full && Plan1176::matches(plan.fft_in, plan.n_stages_f, plan.radix_f) &&
@@ -749,8 +760,21 @@ hipError_t launch_fft_ola(const FftPlanDev& plan, const FftStreamDesc* d_descs, 
     else if (!generic_only && rc_full && Plan1280::matches(plan.fft_in, plan.n_stages_f, plan.radix_f) &&
              Plan1176::matches(plan.fft_out, plan.n_stages_i, plan.radix_i))
         fn = stereo ? fft_ola_kernel_ct2<Plan1280, Plan1176> : fft_ola_kernel_ct<Plan1280, Plan1176>;
-    else
+    else {
         all_stereo = false;
+        // the generic pipeline: for blocks up to 512 frames (both sides) a one-wave workgroup per channel (see the
+        // kernel; 96 -> 48 kHz 1.56 -> 1.18 ms, 192 -> 48 kHz 1.48 -> 0.76 ms per 64 x 2^20 frames); above that the
+        // four-wave workgroups keep more waves on a CU for the same LDS and win (tools/fft_pairs_bench.py)
+        static const int wave_knob = [] { const char* e = getenv("RSMP_FFT_GENERIC_WAVE"); return e ? atoi(e) : -1; }();   // A/B: 0 / 1 forces
+        const size_t lds_wave = 2 * static_cast<size_t>(plan.lds_complex) * sizeof(float2) + static_cast<size_t>(plan.fft_out) * sizeof(float);
+        const bool per_channel = wave_knob >= 0 ? wave_knob != 0 : plan.lds_complex <= 513;
+        if (per_channel && lds_wave <= 160 * 1024) {
+            fn = fft_ola_kernel<64, true>;
+            threads = 64;
+            grid_z = max_channels;
+            lds = lds_wave;
+        }
+    }
     if (fn == static_cast<Kernel>(fft_ola_kernel_ct2<Plan1176, Plan1280>) ||
         fn == static_cast<Kernel>(fft_ola_kernel_ct2<Plan1280, Plan1176>))
         lds = 4 * static_cast<size_t>(plan.lds_complex) * sizeof(float2) + 2 * static_cast<size_t>(plan.fft_out) * sizeof(float);
@@ -768,14 +792,14 @@ hipError_t launch_fft_ola(const FftPlanDev& plan, const FftStreamDesc* d_descs, 
         int dev = 0, cus = 256, per_cu = 4;
         (void)hipGetDevice(&dev);
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(fn), kFftThreads, lds) != hipSuccess ||
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(fn), threads, lds) != hipSuccess ||
             per_cu < 1)
             per_cu = 4;
         const double slots = static_cast<double>(cus) * per_cu;
         double best = -1.0;
         for (uint32_t cand = 8; cand <= 64; ++cand) {
             const double runs = static_cast<double>((max_blocks + cand - 1) / cand);
-            const double wgs = runs * n_streams;
+            const double wgs = runs * n_streams * grid_z;
             const double rounds = std::ceil(wgs / slots);
             const double useful = static_cast<double>(max_blocks) / (max_blocks + runs - 1.0);   // halo blocks
             const double score = wgs / (rounds * slots) * useful;
@@ -784,8 +808,8 @@ hipError_t launch_fft_ola(const FftPlanDev& plan, const FftStreamDesc* d_descs, 
         static const char* knob = getenv("RSMP_FFT_RUN");
         if (knob && atoi(knob) > 0) run = static_cast<uint32_t>(atoi(knob));
     }
-    const dim3 grid((max_blocks + run - 1) / run, n_streams);
-    hipLaunchKernelGGL(fn, grid, dim3(kFftThreads), lds, stream, plan, d_descs, run);
+    const dim3 grid((max_blocks + run - 1) / run, n_streams, grid_z);
+    hipLaunchKernelGGL(fn, grid, dim3(threads), lds, stream, plan, d_descs, run);
     return hipGetLastError();
 }
 

@@ -1,0 +1,46 @@
+"""FFT bulk throughput for rate pairs other than the headline's (which run on the workgroup-per-transform
+kernels).  usage (GPU box): python tools/fft_pairs_bench.py"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+
+import torch
+
+import resampler_amd as ra
+from resampler_amd import synth
+
+R = [22050, 16000, 32000, 44100, 48000, 88200, 96000, 176400, 192000, 384000]
+
+
+def main():
+    dev = torch.device("cuda:0")
+    for a, b in ((44100, 48000), (48000, 44100), (48000, 96000), (96000, 48000), (44100, 96000), (32000, 48000), (16000, 48000),
+                 (22050, 44100), (88200, 96000), (192000, 48000), (44100, 384000)):
+        streams = 64
+        hs = [ra.ResamplerFft.new(2, ra.SampleRate(R.index(a)), ra.SampleRate(R.index(b))) for _ in range(streams)]
+        n_in, n_out = hs[0].chunk_size_input(), hs[0].chunk_size_output()
+        blocks = max(4, (1 << 21) // n_in)          # ~2^20 frames per stream
+        x = torch.from_numpy(synth.fast_noise(blocks * n_in, seed=3)).to(dev)
+        d_in = [x for _ in hs]
+        d_out = [torch.empty(blocks * n_out, device=dev) for _ in hs]
+        batch = ra.FftBatch(hs)
+        batch.bind(d_in, d_out, [blocks] * streams)
+        s = torch.cuda.current_stream().cuda_stream
+        for _ in range(3):
+            batch.resample_bulk_device(s)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n = 10
+        for _ in range(n):
+            batch.resample_bulk_device(s)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n
+        alg = 4.0 * (n_in + n_out) * blocks * streams
+        print(f"{a}->{b}: blocks of {n_in // 2}->{n_out // 2} frames x {blocks}: {dt * 1e3:.3f} ms, "
+              f"{streams * blocks * n_in / dt / 1e9:.1f} G samples/s in, {alg / dt / 8e12 * 100:.1f} % of 8 TB/s")
+
+
+if __name__ == "__main__":
+    main()
