@@ -70,23 +70,61 @@ __device__ __forceinline__ cf lds_ld(const cf* p) {
     return *(LdsPtr)(p);
 }
 
-template <int N_, int... Rs> struct WavePlan;
-template <int N_, int R0, int R1, int R2, int R3>
-struct WavePlan<N_, R0, R1, R2, R3> {
+// A transform of N complex points in `Rs...` Stockham stages (2 .. 4 of them), as the reference's planner orders
+// them (src/fft/optimizer.rs).  Where the first two radices multiply to at most 21 values per unit (and a third
+// stage exists) they run as one register pass (wave_fused_first); every later stage but the inverse's last is a
+// wave_stage; the twiddle tables of all stages sit in LDS.
+// With 21 columns a half wave of 32 lanes spans two blocks of a radix-7 stage's outputs, and 147 values = 294
+// dwords put the second block's first columns on the first block's last banks; two values more after every
+// block (298 = 42 mod 64) and every half wave of the stage stores conflict-free.
+constexpr int stage_out_pad(int r, int stride) { return r == 7 && stride == 21 ? 2 : 0; }
+template <int N_, int... Rs>
+struct WavePlan {
     static constexpr int N = N_;
-    static constexpr int kR[4] = {R0, R1, R2, R3};
-    static_assert(R0 * R1 * R2 * R3 == N_, "radices");
-    // stage twiddles, unique per column: stage s (s >= 1) holds stride_s rows of R_s - 1.  In LDS the rows
-    // of stages 2 and 3 are (R - 1) | 1 values apart: lane k reads row k, and an even row length puts lanes
-    // 16 apart (radix 7: six values = 12 dwords) on the same banks.
+    static constexpr int kStages = sizeof...(Rs);
+    static constexpr int kR[sizeof...(Rs)] = {Rs...};
+    static_assert(kStages >= 2 && kStages <= 4, "stages");
+    static constexpr int stride(int s) { int v = 1; for (int i = 0; i < s; ++i) v *= kR[i]; return v; }
+    static_assert(stride(kStages) == N_, "radices");
+    static constexpr bool kFused = kStages >= 3 && kR[0] * kR[1] <= 21;
+    // Stage twiddles, unique per column: stage s (s >= 1) holds stride(s) rows of R_s - 1.  In LDS the rows of a
+    // wave_stage are (R - 1) | 1 values apart: lane k reads row k, and an even row length puts lanes 16 apart
+    // (radix 7: six values = 12 dwords) on the same banks.  (The fused pass reads its rows by constant index.)
     static constexpr int row(int r) { return (r - 1) | 1; }
-    static constexpr int kT1 = 0, kT2 = kT1 + R0 * (R1 - 1), kT3 = kT2 + R0 * R1 * row(R2);
-    static constexpr int kTw = kT3 + R0 * R1 * R2 * row(R3);
-    static constexpr int kSrc2 = R0 * (R1 - 1), kSrc3 = kSrc2 + R0 * R1 * (R2 - 1);   // offsets in the plan's array
+    static constexpr int pitch(int s) { return kFused && s == 1 ? kR[1] - 1 : row(kR[s]); }
+    static constexpr int tab(int s) { int off = 0; for (int i = 1; i < s; ++i) off += stride(i) * pitch(i); return off; }   // LDS offset of stage s
+    static constexpr int src(int s) { int off = 0; for (int i = 1; i < s; ++i) off += stride(i) * (kR[i] - 1); return off; }   // offset in the plan's array
+    static constexpr int kTw = tab(kStages);
     static constexpr int kRc = N_ / 2 - 1;   // real <-> complex twiddles
+    // Padding between passes (LDS banks): after every fused_period() outputs of the fused pass one value, where
+    // its units are an even number of values apart and the next stage's input distance is that period; after
+    // the blocks of a radix-7 stage of stride 21 two values (stage_out_pad).  in_pad(s): what stage s's input
+    // distance N / R_s grows by.
+    static constexpr int fused_period() { return 8 * kR[0] * kR[1]; }
+    static constexpr bool kFusedPad = kFused && (kR[0] * kR[1]) % 2 == 0 && N_ / kR[2 < kStages ? 2 : 0] == fused_period();
+    static constexpr int out_pad(int s) {
+        if (s < 1 || s + 1 >= kStages || (kFused && s == 1)) return 0;
+        const int p = stage_out_pad(kR[s], stride(s));
+        return p != 0 && N_ / kR[s + 1] == stride(s + 1) ? p : 0;
+    }
+    static constexpr int in_pad(int s) {
+        if (kFused && s == 2) return kFusedPad ? 1 : 0;
+        return s >= 2 ? out_pad(s - 1) : 0;
+    }
+    static constexpr int buf_values() {   // what the wave's buffer needs: the points, bin N (real <-> complex passes), the widest padded layout
+        int pad = kFusedPad ? N_ / fused_period() : 0;
+        for (int s = 1; s + 1 < kStages; ++s) {
+            const int p = out_pad(s) * (N_ / stride(s + 1));
+            if (p > pad) pad = p;
+        }
+        return N_ + 2 + pad;
+    }
+    static constexpr int kBuf = buf_values();
     static bool matches(uint32_t n, uint32_t n_stages, const uint32_t* radix) {
-        return n == static_cast<uint32_t>(N_) && n_stages == 4 && radix[0] == R0 && radix[1] == R1 &&
-               radix[2] == R2 && radix[3] == R3;
+        if (n != static_cast<uint32_t>(N_) || n_stages != static_cast<uint32_t>(kStages)) return false;
+        for (int s = 0; s < kStages; ++s)
+            if (radix[s] != static_cast<uint32_t>(kR[s])) return false;
+        return true;
     }
 };
 
@@ -135,8 +173,7 @@ __device__ __forceinline__ void twiddle_expand(const cf (&raw)[kFetch<R>], cf (&
 // columns a half wave of 32 lanes spans two blocks, and 147 values = 294 dwords put the second block's first
 // columns on the first block's last banks; two values more (298 = 42 mod 64) and every half wave of the
 // stage stores conflict-free.  The next stage then reads its inputs N / R' + OPAD apart (stage_out_pad).
-constexpr int stage_out_pad(int r, int stride) { return r == 7 && stride == 21 ? 2 : 0; }
-template <int N, int R, int STRIDE, int QS = N / R, int OPAD = stage_out_pad(R, STRIDE)>
+template <int N, int R, int STRIDE, int QS = N / R, int OPAD = 0>
 __device__ __forceinline__ void wave_stage(cf* buf, const cf* __restrict__ tw, int lane) {
     constexpr int M = N / R;
     constexpr int ITER = (M + 63) / 64;
@@ -185,12 +222,6 @@ __device__ __forceinline__ void wave_stage(cf* buf, const cf* __restrict__ tw, i
 // A unit's outputs are RA*RB values apart from the next lane's; when that is even (20 values = 40 dwords)
 // the 64 lanes of a store meet on 8 bank pairs, so one value of padding follows every fused_pad<>() values
 // (160: lanes 8 apart move on by a bank pair) and the next stage reads its inputs fused_qs<>() apart.
-template <int RA, int RB> constexpr int fused_pad() { return (RA * RB) % 2 == 0 ? 8 * RA * RB : 0; }
-template <int N, int R, int RA, int RB> constexpr int fused_qs() {
-    // inputs i + q * (N / R) of the next stage: the padding adds (i + q N/R) / pad, exact when N / R == pad
-    static_assert(fused_pad<RA, RB>() == 0 || N / R == fused_pad<RA, RB>(), "padding period = input distance");
-    return fused_pad<RA, RB>() ? N / R + 1 : N / R;
-}
 template <int I, int E, class F>
 __device__ __forceinline__ void static_for(F&& f) {
     if constexpr (I < E) {
@@ -201,10 +232,11 @@ __device__ __forceinline__ void static_for(F&& f) {
 // NVALID: points at index >= NVALID of the stage-0 input are zero and are neither fetched nor computed with
 // (the zero padding of the forward transform: resampler_fft.rs:387-388).  Butterfly q' takes the points
 // j + M2 (q' + RB q): the last NZ of its RA inputs are padding for every j (pdft_tail).
-template <int N, int RA, int RB, int NVALID = N, class Load>
+// PAD: one value of padding after every 8 units (WavePlan::kFusedPad).
+template <int N, int RA, int RB, bool PAD, int NVALID = N, class Load>
 __device__ __forceinline__ void wave_fused_first(cf* dst, const cf* __restrict__ tw1, int lane, Load load) {
     constexpr int M2 = N / (RA * RB);
-    constexpr int PADJ = fused_pad<RA, RB>() / (RA * RB);   // units per padding value
+    constexpr int PADJ = PAD ? 8 : 0;   // units per padding value
     constexpr int ITER = (M2 + 63) / 64;
     cf s[ITER][RB][RA];
 #pragma unroll
@@ -250,6 +282,38 @@ __device__ __forceinline__ void wave_fused_first(cf* dst, const cf* __restrict__
 #pragma unroll
                 for (int qq = 0; qq < RB; ++qq) dst[RA * RB * j + (PADJ ? j / PADJ : 0) + k + RA * qq] = o[qq];
             }
+        }
+    }
+    lds_order();
+}
+
+// Stage 0 alone (stride 1, no twiddles) for the plans that do not fuse it with stage 1: butterfly i takes the
+// points i + q N / R through `load` (LDS, or samples straight from HBM; points at index >= NVALID are zero) and
+// writes R i + q.
+template <int N, int R, int NVALID = N, class Load>
+__device__ __forceinline__ void wave_first(cf* dst, int lane, Load load) {
+    constexpr int M = N / R;
+    constexpr int ITER = (M + 63) / 64;
+    constexpr int first_zero = (NVALID + M - 1) / M;            // inputs q >= first_zero are zero for every i
+    constexpr int NZ = first_zero >= R ? 0 : R - first_zero;
+    cf t[ITER][R];
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+        const int i = lane + 64 * it;
+        if ((it + 1) * 64 <= M || i < M) {
+#pragma unroll
+            for (int q = 0; q < R - NZ; ++q) t[it][q] = load(i + q * M);
+        }
+    }
+    lds_order();
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+        const int i = lane + 64 * it;
+        if ((it + 1) * 64 <= M || i < M) {
+            cf o[R];
+            pdft_tail<R, NZ>(t[it], o);
+#pragma unroll
+            for (int q = 0; q < R; ++q) dst[R * i + q] = o[q];
         }
     }
     lds_order();
@@ -307,7 +371,6 @@ __device__ __forceinline__ void wave_filter_preprocess(cf* y, const cf* __restri
                                                        const cf* __restrict__ rc, int lane) {
     constexpr int ITERS = (FO + 1) / 2 - 1;
     constexpr int TRIPS = (ITERS + 63) / 64;
-    static_assert(ITERS + 1 <= NL, "the low bin of every pair is multiplied by the filter");
     auto bin = [&](int k) -> cf {
         return k < NL ? cf_mul(lds_ld(y + k), lds_ld(filter + k)) : cf_make(0.f, 0.f);
     };
@@ -332,11 +395,14 @@ __device__ __forceinline__ void wave_filter_preprocess(cf* y, const cf* __restri
 #pragma unroll
         for (int u = 0; u < GROUP; ++u) {
             const int trip = g + u, i = lane + 64 * trip;
-            const bool none = FO - 1 - (64 * trip + 63) >= NL;
+            const bool none = FO - 1 - (64 * trip + 63) >= NL;   // high bins FO - 1 - i: none / all / some below NL
+            const bool lo_none = 1 + 64 * trip >= NL;             // low bins 1 + i likewise (a long up-sampling block)
             if (trip < TRIPS && ((trip + 1) * 64 <= ITERS || i < ITERS)) {
                 const int l = 1 + i, rr = FO - 1 - i;
-                ya[u] = lds_ld(y + l);
-                fa[u] = lds_ld(filter + l);
+                if (!lo_none) {
+                    ya[u] = lds_ld(y + l);
+                    fa[u] = lds_ld(filter + (l < FMAX ? l : FMAX));
+                }
                 if (!none) {
                     yb[u] = lds_ld(y + rr);
                     fb[u] = lds_ld(filter + (rr < FMAX ? rr : FMAX));
@@ -348,9 +414,14 @@ __device__ __forceinline__ void wave_filter_preprocess(cf* y, const cf* __restri
         for (int u = 0; u < GROUP; ++u) {
             const int trip = g + u, i = lane + 64 * trip;
             const bool none = FO - 1 - (64 * trip + 63) >= NL, all = FO - 1 - 64 * trip < NL;
+            const bool lo_none = 1 + 64 * trip >= NL, lo_all = 64 + 64 * trip < NL;
             if (trip < TRIPS && ((trip + 1) * 64 <= ITERS || i < ITERS)) {
                 const int l = 1 + i, rr = FO - 1 - i;
-                const cf a = cf_mul(ya[u], fa[u]);
+                cf a = cf_make(0.f, 0.f);
+                if (!lo_none) {
+                    a = cf_mul(ya[u], fa[u]);
+                    if (!lo_all) a = l < NL ? a : cf_make(0.f, 0.f);
+                }
                 cf b = cf_make(0.f, 0.f);
                 if (!none) {
                     b = cf_mul(yb[u], fb[u]);
@@ -383,10 +454,9 @@ __global__ __launch_bounds__((OCC == 3 ? 12 : 4) * 64, OCC) void fft_ola_wave_ke
     extern __shared__ __attribute__((aligned(16))) cf lds2[];
     constexpr int kWavesPerGroup = OCC == 3 ? 12 : 4;
     constexpr int FI = FWD::N, FO = INV::N;
-    constexpr int LDSC = (FI > FO ? FI : FO) + 2 + 8;   // + the padding of a fused first pass (1280 + 8) or of a stage (1176 + 16)
-    static_assert(1176 + 16 <= LDSC, "stage padding");
-    constexpr int R1 = FWD::kR[0];
-    constexpr int RL = INV::kR[3], ML = FO / RL, ITERL = (ML + 63) / 64, HL = RL / 2;
+    constexpr int LDSC = FWD::kBuf > INV::kBuf ? FWD::kBuf : INV::kBuf;   // (+ the padding of a fused first pass or of a stage)
+    constexpr int SF = FWD::kStages, SI = INV::kStages;
+    constexpr int RL = INV::kR[SI - 1], ML = FO / RL, ITERL = (ML + 63) / 64, HL = RL / 2;
     static_assert(RL % 2 == 0, "the last inverse stage splits its outputs into output half and carry half");
     static_assert(FI % 2 == 0 && FO % 2 == 0, "frame pairs");
     const int lane = threadIdx.x & 63;
@@ -403,16 +473,16 @@ __global__ __launch_bounds__((OCC == 3 ? 12 : 4) * 64, OCC) void fft_ola_wave_ke
         auto copy = [&](cf* dst, const cf* __restrict__ src, int n) {
             for (int i = threadIdx.x; i < n; i += kWavesPerGroup * 64) dst[i] = src[i];
         };
-        // stage twiddles: rows of stages 2 and 3 re-spaced (WavePlan::row)
-        auto rows = [&](cf* dst, const cf* __restrict__ src, int n_rows, int r) {
-            const int len = r - 1, pitch = (r - 1) | 1;
+        // stage twiddles: rows re-spaced to the pitch the stage reads them with (WavePlan::pitch)
+        auto rows = [&](cf* dst, const cf* __restrict__ src, int n_rows, int len, int pitch) {
             for (int i = threadIdx.x; i < n_rows * len; i += kWavesPerGroup * 64) dst[(i / len) * pitch + i % len] = src[i];
         };
         auto stage_tables = [&](cf* dst, const cf* __restrict__ src, auto P) {
             typedef decltype(P) PL;
-            copy(dst + PL::kT1, src, PL::kSrc2);
-            rows(dst + PL::kT2, src + PL::kSrc2, PL::kR[0] * PL::kR[1], PL::kR[2]);
-            rows(dst + PL::kT3, src + PL::kSrc3, PL::kR[0] * PL::kR[1] * PL::kR[2], PL::kR[3]);
+            static_for<1, PL::kStages>([&](auto s_c) {
+                constexpr int s = decltype(s_c)::value;
+                rows(dst + PL::tab(s), src + PL::src(s), PL::stride(s), PL::kR[s] - 1, PL::pitch(s));
+            });
         };
         stage_tables(tab + kTabF, reinterpret_cast<const cf*>(plan.tw_f), FWD{});
         stage_tables(tab + kTabI, reinterpret_cast<const cf*>(plan.tw_i), INV{});
@@ -461,9 +531,7 @@ __global__ __launch_bounds__((OCC == 3 ? 12 : 4) * 64, OCC) void fft_ola_wave_ke
 
     for (int64_t b = b_begin; b < static_cast<int64_t>(last); ++b) {
         const bool emit = b >= static_cast<int64_t>(first);
-        constexpr int S1 = R1, S2 = S1 * FWD::kR[1], S3 = S2 * FWD::kR[2];
-        constexpr int T1 = FWD::kT1, T2 = FWD::kT2, T3 = FWD::kT3;
-        // ---- forward stages 1 + 2 in one register pass, inputs straight from HBM: complex j of the block's
+        // ---- forward transform: the first pass takes its inputs straight from HBM: complex j of the block's
         // channel = frames 2j, 2j + 1 (j < FI / 2), zero beyond (resampler_fft.rs:387-388)
         {
             const GFloat* xin = as_global(d.in) + static_cast<size_t>(b) * FI * C;
@@ -479,19 +547,26 @@ __global__ __launch_bounds__((OCC == 3 ? 12 : 4) * 64, OCC) void fft_ola_wave_ke
                 }
                 return v;
             };
-            wave_fused_first<FI, FWD::kR[0], FWD::kR[1], FI / 2>(buf, tw_f + T1, lane, sample);
+            if constexpr (FWD::kFused) wave_fused_first<FI, FWD::kR[0], FWD::kR[1], FWD::kFusedPad, FI / 2>(buf, tw_f + FWD::tab(1), lane, sample);
+            else wave_first<FI, FWD::kR[0], FI / 2>(buf, lane, sample);
         }
-        wave_stage<FI, FWD::kR[2], S2, fused_qs<FI, FWD::kR[2], FWD::kR[0], FWD::kR[1]>()>(buf, tw_f + T2, lane);
-        static_assert(stage_out_pad(FWD::kR[2], S2) == 0 || FI / FWD::kR[3] == S3, "padding period = input distance");
-        wave_stage<FI, FWD::kR[3], S3, FI / FWD::kR[3] + stage_out_pad(FWD::kR[2], S2)>(buf, tw_f + T3, lane);
+        static_for<(FWD::kFused ? 2 : 1), SF>([&](auto s_c) {
+            constexpr int s = decltype(s_c)::value;
+            wave_stage<FI, FWD::kR[s], FWD::stride(s), FI / FWD::kR[s] + FWD::in_pad(s), FWD::out_pad(s)>(buf, tw_f + FWD::tab(s), lane);
+        });
         wave_postprocess<FI>(buf, rc_f, lane);
         wave_filter_preprocess<FO, (FI < FO ? FI + 1 : FO), FI>(buf, filter, rc_i, lane);
 
-        constexpr int IS1 = INV::kR[0], IS2 = IS1 * INV::kR[1];
-        constexpr int IT1 = INV::kT1, IT2 = INV::kT2, IT3 = INV::kT3;
-        // inverse stages 1 + 2 in one register pass, in place
-        wave_fused_first<FO, INV::kR[0], INV::kR[1]>(buf, tw_i + IT1, lane, [&](int j) -> cf { return lds_ld(buf + j); });
-        wave_stage<FO, INV::kR[2], IS2, fused_qs<FO, INV::kR[2], INV::kR[0], INV::kR[1]>()>(buf, tw_i + IT2, lane);
+        // ---- inverse transform, in place; its last stage below
+        {
+            auto from_lds = [&](int j) -> cf { return lds_ld(buf + j); };
+            if constexpr (INV::kFused) wave_fused_first<FO, INV::kR[0], INV::kR[1], INV::kFusedPad>(buf, tw_i + INV::tab(1), lane, from_lds);
+            else wave_first<FO, INV::kR[0]>(buf, lane, from_lds);
+        }
+        static_for<(INV::kFused ? 2 : 1), SI - 1>([&](auto s_c) {
+            constexpr int s = decltype(s_c)::value;
+            wave_stage<FO, INV::kR[s], INV::stride(s), FO / INV::kR[s] + INV::in_pad(s), INV::out_pad(s)>(buf, tw_i + INV::tab(s), lane);
+        });
         // ---- last inverse stage: outputs stay in registers.  Butterfly i (k = i) yields Z[i + q*ML]; the
         // output conjugation (radix_fft.rs:656-669) makes reals 2c, 2c + 1 of the channel out of Z[c]; the
         // first FO reals are overlap-added and stored, the second FO become the next overlap (:416-423).
@@ -503,8 +578,8 @@ __global__ __launch_bounds__((OCC == 3 ? 12 : 4) * 64, OCC) void fft_ola_wave_ke
             const int i = lane + 64 * it;
             if ((it + 1) * 64 <= ML || i < ML) {
 #pragma unroll
-                for (int q = 0; q < RL; ++q) tl[it & 1][q] = lds_ld(buf + i + q * (ML + stage_out_pad(INV::kR[2], IS2)));
-                twiddle_fetch<RL>(tw_i + IT3 + i * INV::row(RL), rawl[it & 1]);
+                for (int q = 0; q < RL; ++q) tl[it & 1][q] = lds_ld(buf + i + q * (ML + INV::in_pad(SI - 1)));
+                twiddle_fetch<RL>(tw_i + INV::tab(SI - 1) + i * INV::row(RL), rawl[it & 1]);
             }
         };
         fetch(0);
@@ -549,43 +624,69 @@ __global__ __launch_bounds__((OCC == 3 ? 12 : 4) * 64, OCC) void fft_ola_wave_ke
     }
 }
 
-typedef WavePlan<1176, 3, 7, 7, 8> W1176;
-typedef WavePlan<1280, 4, 5, 8, 8> W1280;
+typedef WavePlan<1176, 3, 7, 7, 8> W1176;   // 44.1 kHz side of the 44.1 <-> 48 kHz family
+typedef WavePlan<1280, 4, 5, 8, 8> W1280;   // 48 kHz side
+typedef WavePlan<512, 8, 8, 8> W512;        // the input block of the power-of-two families (x2, /2, x4, /4, x3, x1.5 ...)
+typedef WavePlan<1024, 2, 8, 8, 8> W1024;
+typedef WavePlan<256, 4, 8, 8> W256;
+typedef WavePlan<128, 2, 8, 8> W128;
+typedef WavePlan<64, 8, 8> W64;
+typedef WavePlan<768, 3, 4, 8, 8> W768;
+typedef WavePlan<1536, 3, 8, 8, 8> W1536;
+
+typedef void (*WaveKernel)(FftPlanDev, const FftStreamDesc*, uint32_t, uint32_t, uint32_t);
+struct WaveChoice {
+    WaveKernel fn = nullptr;
+    size_t lds = 0;          // bytes of a workgroup
+    uint32_t waves = 0;      // waves per workgroup
+    int occ = 0;
+};
+
+// The instantiation for (FWD, INV) if the plan is that pair; `occ` 3 = one 12-wave workgroup per CU (two-channel
+// streams: <= 168 registers), 2 = 4-wave workgroups.
+template <class FWD, class INV>
+bool wave_choice(const FftPlanDev& plan, uint32_t channels, int occ_env, WaveChoice* out) {
+    if (!FWD::matches(plan.fft_in, plan.n_stages_f, plan.radix_f) || !INV::matches(plan.fft_out, plan.n_stages_i, plan.radix_i))
+        return false;
+    constexpr size_t tables = static_cast<size_t>(FWD::kTw + INV::kTw + FWD::kRc + INV::kRc + FWD::N + 1);
+    constexpr size_t buf = FWD::kBuf > INV::kBuf ? FWD::kBuf : INV::kBuf;
+    // Three waves per SIMD (<= 168 registers) where the kernel fits them: the two-channel instantiation.  The
+    // any-channel-count one needs ~250 registers (strided sample addressing) and spilled 290 bytes per lane
+    // under the cap: two waves per SIMD run it 25-30 % faster (tools/fft_channels_bench.py).
+    int occ = occ_env == 2 || occ_env == 3 ? occ_env : (channels == 2 ? 3 : 2);
+    if (occ == 3 && (tables + 12 * buf) * sizeof(cf) > 160 * 1024) occ = 2;
+    if ((tables + 4 * buf) * sizeof(cf) > 160 * 1024) return false;
+    out->occ = occ;
+    out->waves = occ == 3 ? 12u : 4u;
+    out->lds = (tables + out->waves * buf) * sizeof(cf);
+    if (occ == 3) out->fn = channels == 2 ? fft_ola_wave_kernel<FWD, INV, true, 3> : fft_ola_wave_kernel<FWD, INV, false, 3>;
+    else out->fn = channels == 2 ? fft_ola_wave_kernel<FWD, INV, true, 2> : fft_ola_wave_kernel<FWD, INV, false, 2>;
+    return true;
+}
 
 }  // namespace
 
-// Wave-per-transform kernels exist for the 44.1 <-> 48 kHz family (both directions).  Returns
-// hipErrorNotSupported when the plan is another one (the caller then uses the workgroup kernels).
+// Wave-per-transform kernels exist for the 44.1 <-> 48 kHz family (both directions) and for the families whose
+// input block is 512 frames (x2, /2, /4, /8, x3, x1.5 ...).  Returns hipErrorNotSupported when the plan is another
+// one (the caller then uses the workgroup kernels).
 hipError_t launch_fft_ola_wave(const FftPlanDev& plan, const FftStreamDesc* d_descs, uint32_t n_streams,
                                uint32_t max_blocks, uint32_t max_channels, uint32_t min_channels,
                                hipStream_t stream) {
     if (max_channels != min_channels) return hipErrorNotSupported;   // one wave layout per launch
     if (plan.n_rc_f != plan.fft_in / 2 - 1 || plan.n_rc_i != plan.fft_out / 2 - 1) return hipErrorNotSupported;
     if (plan.new_length != (plan.fft_in < plan.fft_out ? plan.fft_in + 1 : plan.fft_out)) return hipErrorNotSupported;
-    const bool up = W1176::matches(plan.fft_in, plan.n_stages_f, plan.radix_f) &&
-                    W1280::matches(plan.fft_out, plan.n_stages_i, plan.radix_i);
-    const bool down = W1280::matches(plan.fft_in, plan.n_stages_f, plan.radix_f) &&
-                      W1176::matches(plan.fft_out, plan.n_stages_i, plan.radix_i);
-    if (!up && !down) return hipErrorNotSupported;
     const uint32_t C = max_channels;
-    typedef void (*Kernel)(FftPlanDev, const FftStreamDesc*, uint32_t, uint32_t, uint32_t);
-    Kernel fn;
-    // Three waves per SIMD (<= 168 registers) where the kernel fits them: the two-channel instantiation.  The
-    // any-channel-count one needs ~250 registers (strided sample addressing) and spilled 290 bytes per lane
-    // under the cap: two waves per SIMD run it 25-30 % faster (tools/fft_channels_bench.py).
     static const int occ_env = [] { const char* e = getenv("RSMP_FFT_WAVE_OCC"); return e ? atoi(e) : 0; }();
-    const int occ = occ_env == 2 || occ_env == 3 ? occ_env : (C == 2 ? 3 : 2);
-    if (occ == 3) {
-        if (up) fn = C == 2 ? fft_ola_wave_kernel<W1176, W1280, true, 3> : fft_ola_wave_kernel<W1176, W1280, false, 3>;
-        else fn = C == 2 ? fft_ola_wave_kernel<W1280, W1176, true, 3> : fft_ola_wave_kernel<W1280, W1176, false, 3>;
-    } else {
-        if (up) fn = C == 2 ? fft_ola_wave_kernel<W1176, W1280, true, 2> : fft_ola_wave_kernel<W1176, W1280, false, 2>;
-        else fn = C == 2 ? fft_ola_wave_kernel<W1280, W1176, true, 2> : fft_ola_wave_kernel<W1280, W1176, false, 2>;
-    }
-    // tables (stage twiddles, real <-> complex twiddles, filter spectrum fft_in + 1) + one buffer per wave
-    const uint32_t kWavesPerGroup = occ == 3 ? 12u : 4u;
-    const size_t lds = (static_cast<size_t>(W1176::kTw + W1280::kTw + W1176::kRc + W1280::kRc) + plan.fft_in + 1 +
-                        static_cast<size_t>(kWavesPerGroup) * (1280 + 2 + 8)) * sizeof(cf);
+    WaveChoice wc;
+    const bool found = wave_choice<W1176, W1280>(plan, C, occ_env, &wc) || wave_choice<W1280, W1176>(plan, C, occ_env, &wc) ||
+                       wave_choice<W512, W1024>(plan, C, occ_env, &wc) || wave_choice<W512, W256>(plan, C, occ_env, &wc) ||
+                       wave_choice<W512, W128>(plan, C, occ_env, &wc) || wave_choice<W512, W64>(plan, C, occ_env, &wc) ||
+                       wave_choice<W512, W768>(plan, C, occ_env, &wc) || wave_choice<W512, W1536>(plan, C, occ_env, &wc);
+    if (!found) return hipErrorNotSupported;
+    const uint32_t kWavesPerGroup = wc.waves;
+    const size_t lds = wc.lds;
+    const int occ = wc.occ;
+    WaveKernel fn = wc.fn;
     // Blocks per wave: every run after a stream's first recomputes its predecessor block (1 / run extra
     // work), and the launch ends with a partly filled round unless the number of waves is close to a
     // multiple of what the chip holds at once (3 workgroups of 4 waves per CU).
