@@ -83,7 +83,7 @@ struct WavePlan {
     static constexpr int N = N_;
     static constexpr int kStages = sizeof...(Rs);
     static constexpr int kR[sizeof...(Rs)] = {Rs...};
-    static_assert(kStages >= 2 && kStages <= 4, "stages");
+    static_assert(kStages >= 2 && kStages <= 5, "stages");
     static constexpr int stride(int s) { int v = 1; for (int i = 0; i < s; ++i) v *= kR[i]; return v; }
     static_assert(stride(kStages) == N_, "radices");
     static constexpr bool kFused = kStages >= 3 && kR[0] * kR[1] <= 21;
@@ -280,7 +280,7 @@ __device__ __forceinline__ void wave_fused_first(cf* dst, const cf* __restrict__
                     u[qp] = k == 0 ? s[it][qp][k] : cf_mul(w1[k][qp], s[it][qp][k]);
                 pdft<RB>(u, o);
 #pragma unroll
-                for (int qq = 0; qq < RB; ++qq) dst[RA * RB * j + (PADJ ? j / PADJ : 0) + k + RA * qq] = o[qq];
+                for (int qq = 0; qq < RB; ++qq) dst[RA * RB * j + (PADJ ? j / (PADJ ? PADJ : 1) : 0) + k + RA * qq] = o[qq];
             }
         }
     }
@@ -445,14 +445,17 @@ __device__ __forceinline__ void wave_filter_preprocess(cf* y, const cf* __restri
 }
 
 // OCC waves per SIMD: 2 = two workgroups of 4 waves per CU (80 KB of LDS each: the tables + 4 buffers),
-// 3 = one workgroup of 12 waves per CU (one copy of the tables + 12 buffers = 158 KB; <= 168 registers).
+// 3 = one workgroup of 12 waves per CU (one copy of the tables + 12 buffers = 158 KB; <= 168 registers),
+// 1 = one workgroup of as many waves (<= 8) as the CU's LDS holds buffers for (the long plans; the launch
+// decides).  (16 waves per CU for the short plans measured within 2 % of 12: the LDS is the bound, not latency.)
+constexpr int wave_group_threads(int occ) { return occ == 3 ? 768 : occ == 2 ? 256 : 512; }
 template <class FWD, class INV, bool C2, int OCC>
-__global__ __launch_bounds__((OCC == 3 ? 12 : 4) * 64, OCC) void fft_ola_wave_kernel(FftPlanDev plan,
+__global__ __launch_bounds__(wave_group_threads(OCC), OCC == 1 ? 2 : OCC) void fft_ola_wave_kernel(FftPlanDev plan,
                                                                               const FftStreamDesc* __restrict__ descs,
                                                                               uint32_t run, uint32_t runs_per_stream,
                                                                               uint32_t total_waves) {
     extern __shared__ __attribute__((aligned(16))) cf lds2[];
-    constexpr int kWavesPerGroup = OCC == 3 ? 12 : 4;
+    const int kWavesPerGroup = OCC == 1 ? static_cast<int>(blockDim.x >> 6) : wave_group_threads(OCC) / 64;
     constexpr int FI = FWD::N, FO = INV::N;
     constexpr int LDSC = FWD::kBuf > INV::kBuf ? FWD::kBuf : INV::kBuf;   // (+ the padding of a fused first pass or of a stage)
     constexpr int SF = FWD::kStages, SI = INV::kStages;
@@ -633,35 +636,58 @@ typedef WavePlan<128, 2, 8, 8> W128;
 typedef WavePlan<64, 8, 8> W64;
 typedef WavePlan<768, 3, 4, 8, 8> W768;
 typedef WavePlan<1536, 3, 8, 8, 8> W1536;
+typedef WavePlan<2048, 4, 8, 8, 8> W2048;
+typedef WavePlan<588, 3, 4, 7, 7> W588;     // 22.05 kHz against the 48 kHz family (input side: the inverse's last radix must be even)
+typedef WavePlan<882, 2, 3, 3, 7, 7> W882;
+typedef WavePlan<1764, 3, 3, 4, 7, 7> W1764;
+typedef WavePlan<2352, 2, 3, 7, 7, 8> W2352; // 88.2 kHz
+typedef WavePlan<2560, 5, 8, 8, 8> W2560;    // 96 kHz
+typedef WavePlan<640, 2, 5, 8, 8> W640;        // 16 kHz against the 44.1 kHz family
 
 typedef void (*WaveKernel)(FftPlanDev, const FftStreamDesc*, uint32_t, uint32_t, uint32_t);
 struct WaveChoice {
     WaveKernel fn = nullptr;
     size_t lds = 0;          // bytes of a workgroup
     uint32_t waves = 0;      // waves per workgroup
+    uint32_t resident = 0;   // waves a CU holds at once
     int occ = 0;
 };
 
-// The instantiation for (FWD, INV) if the plan is that pair; `occ` 3 = one 12-wave workgroup per CU (two-channel
-// streams: <= 168 registers), 2 = 4-wave workgroups.
+// The instantiation for (FWD, INV) if the plan is that pair.  Waves per CU, by what the CU's LDS holds (one copy
+// of the tables per workgroup + a buffer per wave) and what the registers allow: two-channel streams run 12
+// (<= 168 registers) or 2 x 4 waves; the any-channel-count build needs ~250 registers (strided
+// sample addressing; it spilled 290 bytes per lane under the 168 cap and ran 25-30 % slower,
+// tools/fft_channels_bench.py) and runs 2 x 4.  Plans too long for that run one workgroup of up to 8 waves.
 template <class FWD, class INV>
 bool wave_choice(const FftPlanDev& plan, uint32_t channels, int occ_env, WaveChoice* out) {
     if (!FWD::matches(plan.fft_in, plan.n_stages_f, plan.radix_f) || !INV::matches(plan.fft_out, plan.n_stages_i, plan.radix_i))
         return false;
     constexpr size_t tables = static_cast<size_t>(FWD::kTw + INV::kTw + FWD::kRc + INV::kRc + FWD::N + 1);
     constexpr size_t buf = FWD::kBuf > INV::kBuf ? FWD::kBuf : INV::kBuf;
-    // Three waves per SIMD (<= 168 registers) where the kernel fits them: the two-channel instantiation.  The
-    // any-channel-count one needs ~250 registers (strided sample addressing) and spilled 290 bytes per lane
-    // under the cap: two waves per SIMD run it 25-30 % faster (tools/fft_channels_bench.py).
-    int occ = occ_env == 2 || occ_env == 3 ? occ_env : (channels == 2 ? 3 : 2);
-    if (occ == 3 && (tables + 12 * buf) * sizeof(cf) > 160 * 1024) occ = 2;
-    if ((tables + 4 * buf) * sizeof(cf) > 160 * 1024) return false;
+    constexpr size_t kCu = 160 * 1024 / sizeof(cf);
+    constexpr bool fit12 = tables + 12 * buf <= kCu, fit4 = 2 * (tables + 4 * buf) <= kCu;
+    constexpr uint32_t wide = (kCu - tables) / buf < 8 ? static_cast<uint32_t>((kCu - tables) / buf) : 8u;
+    static_assert(fit4 || wide >= 4, "a plan this long belongs to the workgroup kernels");
+    int occ = channels == 2 ? (fit12 ? 3 : fit4 ? 2 : 1) : (fit4 ? 2 : 1);
+    if (channels == 2 && ((occ_env == 3 && fit12) || (occ_env == 2 && fit4))) occ = occ_env;
     out->occ = occ;
-    out->waves = occ == 3 ? 12u : 4u;
+    out->fn = nullptr;
+    if (channels == 2) {
+        if constexpr (fit12) if (occ == 3) out->fn = fft_ola_wave_kernel<FWD, INV, true, 3>;
+        if constexpr (fit4) if (occ == 2) out->fn = fft_ola_wave_kernel<FWD, INV, true, 2>;
+        if constexpr (!fit4) if (occ == 1) out->fn = fft_ola_wave_kernel<FWD, INV, true, 1>;
+    } else {
+        if constexpr (fit4) out->fn = fft_ola_wave_kernel<FWD, INV, false, 2>;
+        else out->fn = fft_ola_wave_kernel<FWD, INV, false, 1>;
+    }
+    out->waves = occ == 3 ? 12u : occ == 2 ? 4u : wide;
+    out->resident = occ == 2 ? 8u : out->waves;
     out->lds = (tables + out->waves * buf) * sizeof(cf);
-    if (occ == 3) out->fn = channels == 2 ? fft_ola_wave_kernel<FWD, INV, true, 3> : fft_ola_wave_kernel<FWD, INV, false, 3>;
-    else out->fn = channels == 2 ? fft_ola_wave_kernel<FWD, INV, true, 2> : fft_ola_wave_kernel<FWD, INV, false, 2>;
-    return true;
+    return out->fn != nullptr;
+}
+template <class FWD, class... INVS>
+bool wave_choices(const FftPlanDev& plan, uint32_t channels, int occ_env, WaveChoice* out) {
+    return (wave_choice<FWD, INVS>(plan, channels, occ_env, out) || ...);
 }
 
 }  // namespace
@@ -678,14 +704,17 @@ hipError_t launch_fft_ola_wave(const FftPlanDev& plan, const FftStreamDesc* d_de
     const uint32_t C = max_channels;
     static const int occ_env = [] { const char* e = getenv("RSMP_FFT_WAVE_OCC"); return e ? atoi(e) : 0; }();
     WaveChoice wc;
-    const bool found = wave_choice<W1176, W1280>(plan, C, occ_env, &wc) || wave_choice<W1280, W1176>(plan, C, occ_env, &wc) ||
-                       wave_choice<W512, W1024>(plan, C, occ_env, &wc) || wave_choice<W512, W256>(plan, C, occ_env, &wc) ||
-                       wave_choice<W512, W128>(plan, C, occ_env, &wc) || wave_choice<W512, W64>(plan, C, occ_env, &wc) ||
-                       wave_choice<W512, W768>(plan, C, occ_env, &wc) || wave_choice<W512, W1536>(plan, C, occ_env, &wc);
+    const bool found = wave_choices<W1176, W1280>(plan, C, occ_env, &wc) || wave_choices<W1280, W1176>(plan, C, occ_env, &wc) ||
+                       wave_choices<W512, W64, W128, W256, W768, W1024, W1536, W2048>(plan, C, occ_env, &wc) ||
+                       wave_choices<W768, W64, W128, W256, W512>(plan, C, occ_env, &wc) ||
+                       wave_choices<W1536, W64, W128>(plan, C, occ_env, &wc) ||
+                       wave_choices<W588, W1280, W2560>(plan, C, occ_env, &wc) || wave_choices<W882, W640, W1280>(plan, C, occ_env, &wc) ||
+                       wave_choices<W1764, W640, W1280>(plan, C, occ_env, &wc) || wave_choices<W2352, W1280, W2560>(plan, C, occ_env, &wc) ||
+                       wave_choice<W1176, W2560>(plan, C, occ_env, &wc) || wave_choice<W1280, W2352>(plan, C, occ_env, &wc) ||
+                       wave_choice<W2560, W2352>(plan, C, occ_env, &wc);
     if (!found) return hipErrorNotSupported;
     const uint32_t kWavesPerGroup = wc.waves;
     const size_t lds = wc.lds;
-    const int occ = wc.occ;
     WaveKernel fn = wc.fn;
     // Blocks per wave: every run after a stream's first recomputes its predecessor block (1 / run extra
     // work), and the launch ends with a partly filled round unless the number of waves is close to a
@@ -693,7 +722,7 @@ hipError_t launch_fft_ola_wave(const FftPlanDev& plan, const FftStreamDesc* d_de
     int dev = 0, cus = 256;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    const double slots = static_cast<double>(cus) * occ * 4;
+    const double slots = static_cast<double>(cus) * wc.resident;
     uint32_t run = 16;
     double best = -1.0;
     for (uint32_t cand = 6; cand <= 64; ++cand) {

@@ -1,5 +1,5 @@
 """FFT bulk throughput for rate pairs other than the headline's (which run on the workgroup-per-transform
-kernels).  usage (GPU box): python tools/fft_pairs_bench.py"""
+kernels).  usage (GPU box): python tools/fft_pairs_bench.py [--all | IN_HZ:OUT_HZ ...]"""
 import os
 import sys
 import time
@@ -16,8 +16,14 @@ R = [22050, 16000, 32000, 44100, 48000, 88200, 96000, 176400, 192000, 384000]
 
 def main():
     dev = torch.device("cuda:0")
-    for a, b in ((44100, 48000), (48000, 44100), (48000, 96000), (96000, 48000), (44100, 96000), (32000, 48000), (16000, 48000),
-                 (22050, 44100), (88200, 96000), (192000, 48000), (44100, 384000)):
+    pairs = [tuple(int(v) for v in arg.split(":")) for arg in sys.argv[1:] if ":" in arg]
+    if "--all" in sys.argv:
+        pairs = [(a, b) for a in R for b in R if a != b]
+    if not pairs:
+        pairs = [(44100, 48000), (48000, 44100), (48000, 96000), (96000, 48000), (44100, 96000), (32000, 48000), (16000, 48000),
+                 (22050, 44100), (88200, 96000), (192000, 48000), (44100, 384000), (48000, 192000), (48000, 16000),
+                 (48000, 32000), (384000, 32000), (384000, 48000)]
+    for a, b in pairs:
         streams = 64
         hs = [ra.ResamplerFft.new(2, ra.SampleRate(R.index(a)), ra.SampleRate(R.index(b))) for _ in range(streams)]
         n_in, n_out = hs[0].chunk_size_input(), hs[0].chunk_size_output()
