@@ -659,51 +659,58 @@ __device__ void stockham_inplace(float2* buf, uint32_t n, uint32_t n_stages, con
     }
 }
 
-__global__ __launch_bounds__(kBigThreads) void fft_ola_big_kernel(FftPlanDev plan, const FftStreamDesc* __restrict__ descs) {
+__global__ __launch_bounds__(kBigThreads) void fft_ola_big_kernel(FftPlanDev plan, const FftStreamDesc* __restrict__ descs,
+                                                                  uint32_t run) {
     extern __shared__ __attribute__((aligned(16))) float2 lds2[];
-    const FftStreamDesc d = descs[blockIdx.x];
-    if (d.n_blocks == 0) return;
-    const uint32_t C = d.channels, fi = plan.fft_in, fo = plan.fft_out;
+    const FftStreamDesc d = descs[blockIdx.y];
+    const uint32_t first = blockIdx.x * run;
+    if (first >= d.n_blocks) return;
+    const uint32_t last = first + run < d.n_blocks ? first + run : d.n_blocks;  // exclusive
+    const uint32_t C = d.channels, c = blockIdx.z, fi = plan.fft_in, fo = plan.fft_out;
+    if (c >= C) return;
     float2* buf = lds2;
-    float* carry = d.overlap_next;                       // [C][fo], in HBM
-    if (d.overlap_next != d.overlap)
-        for (uint32_t e = threadIdx.x; e < C * fo; e += kBigThreads) carry[e] = d.overlap[e];
+    float* carry = reinterpret_cast<float*>(lds2 + plan.lds_complex);   // [fo]: the channel's overlap
+    // overlap carried into the run: the stream state, or the predecessor block recomputed (not emitted)
+    if (first == 0)
+        for (uint32_t e = threadIdx.x; e < fo; e += kBigThreads) carry[e] = d.overlap[c * fo + e];
+    const int64_t b_begin = first == 0 ? 0 : static_cast<int64_t>(first) - 1;
     __syncthreads();
-    for (uint32_t b = 0; b < d.n_blocks; ++b) {
+    for (int64_t b = b_begin; b < static_cast<int64_t>(last); ++b) {
+        const bool emit = b >= static_cast<int64_t>(first);
         const float* __restrict__ xin = d.in + static_cast<size_t>(b) * fi * C;
         float* __restrict__ xout = d.out + static_cast<size_t>(b) * fo * C;
-        for (uint32_t c = 0; c < C; ++c) {
-            // resampler_fft.rs:387-388: fi reals + fi zeros, viewed as fi complexes (radix_fft.rs:552-554)
-            for (uint32_t i = threadIdx.x; i < fi; i += kBigThreads) {
-                float2 v = make_float2(0.f, 0.f);
-                if (2 * i + 1 < fi) v = make_float2(xin[(2 * i) * C + c], xin[(2 * i + 1) * C + c]);
-                else if (2 * i < fi) v = make_float2(xin[(2 * i) * C + c], 0.f);
-                buf[i] = v;
-            }
-            __syncthreads();
-            stockham_inplace(buf, fi, plan.n_stages_f, plan.radix_f, plan.tw_off_f, plan.tw_f);
-            postprocess_forward<kBigThreads>(buf, fi, plan.rc_f, plan.n_rc_f);
-            __syncthreads();
-            // resampler_fft.rs:401-408: multiply new_length bins, zero the rest up to fo
-            for (uint32_t k = threadIdx.x; k <= fo; k += kBigThreads)
-                buf[k] = k < plan.new_length ? cmul(buf[k], plan.filter[k]) : make_float2(0.f, 0.f);
-            __syncthreads();
-            preprocess_inverse<kBigThreads>(buf, fo, plan.rc_i, plan.n_rc_i);
-            __syncthreads();
-            stockham_inplace(buf, fo, plan.n_stages_i, plan.radix_i, plan.tw_off_i, plan.tw_i);
-            // output conjugation (radix_fft.rs:656-669), reals 2i, 2i+1 <- Z[i]; overlap-add (:416-423)
-            float* ov = carry + c * fo;
-            for (uint32_t t = threadIdx.x; t < fo; t += kBigThreads) {
-                const float2 z = buf[t >> 1];
-                const float y = (t & 1u) ? -z.y : z.x;
-                xout[t * C + c] = y + ov[t];
-                const float2 z2 = buf[(t + fo) >> 1];
-                ov[t] = ((t + fo) & 1u) ? -z2.y : z2.x;
-            }
-            __syncthreads();
+        // resampler_fft.rs:387-388: fi reals + fi zeros, viewed as fi complexes (radix_fft.rs:552-554)
+        for (uint32_t i = threadIdx.x; i < fi; i += kBigThreads) {
+            float2 v = make_float2(0.f, 0.f);
+            if (2 * i + 1 < fi) v = make_float2(xin[(2 * i) * C + c], xin[(2 * i + 1) * C + c]);
+            else if (2 * i < fi) v = make_float2(xin[(2 * i) * C + c], 0.f);
+            buf[i] = v;
         }
+        __syncthreads();
+        stockham_inplace(buf, fi, plan.n_stages_f, plan.radix_f, plan.tw_off_f, plan.tw_f);
+        postprocess_forward<kBigThreads>(buf, fi, plan.rc_f, plan.n_rc_f);
+        __syncthreads();
+        // resampler_fft.rs:401-408: multiply new_length bins, zero the rest up to fo
+        for (uint32_t k = threadIdx.x; k <= fo; k += kBigThreads)
+            buf[k] = k < plan.new_length ? cmul(buf[k], plan.filter[k]) : make_float2(0.f, 0.f);
+        __syncthreads();
+        preprocess_inverse<kBigThreads>(buf, fo, plan.rc_i, plan.n_rc_i);
+        __syncthreads();
+        stockham_inplace(buf, fo, plan.n_stages_i, plan.radix_i, plan.tw_off_i, plan.tw_i);
+        // output conjugation (radix_fft.rs:656-669), reals 2i, 2i+1 <- Z[i]; overlap-add (:416-423)
+        for (uint32_t t = threadIdx.x; t < fo; t += kBigThreads) {
+            const float2 z = buf[t >> 1];
+            const float y = (t & 1u) ? -z.y : z.x;
+            if (emit) xout[t * C + c] = y + carry[t];
+            const float2 z2 = buf[(t + fo) >> 1];
+            carry[t] = ((t + fo) & 1u) ? -z2.y : z2.x;
+        }
+        __syncthreads();
     }
+    if (last == d.n_blocks)
+        for (uint32_t e = threadIdx.x; e < fo; e += kBigThreads) d.overlap_next[c * fo + e] = carry[e];
 }
+
 
 __global__ __launch_bounds__(kBigThreads) void fft_filter_big_kernel(FftPlanDev plan, const float* __restrict__ filter_time,
                                                                      float2* __restrict__ spectrum) {
@@ -720,7 +727,10 @@ __global__ __launch_bounds__(kBigThreads) void fft_filter_big_kernel(FftPlanDev 
 
 }  // namespace
 
-size_t fft_big_lds_bytes(const FftPlanDev& plan) { return static_cast<size_t>(plan.lds_complex) * sizeof(float2); }
+// one buffer (the stages run in place) + the overlap row of the workgroup's channel
+size_t fft_big_lds_bytes(const FftPlanDev& plan) {
+    return static_cast<size_t>(plan.lds_complex) * sizeof(float2) + static_cast<size_t>(plan.fft_out) * sizeof(float);
+}
 
 size_t fft_ola_lds_bytes(const FftPlanDev& plan, uint32_t channels) {
     return 2 * static_cast<size_t>(plan.lds_complex) * sizeof(float2) +
@@ -736,14 +746,41 @@ hipError_t launch_fft_ola(const FftPlanDev& plan, const FftStreamDesc* d_descs, 
         const hipError_t e = launch_fft_ola_wave(plan, d_descs, n_streams, max_blocks, max_channels, min_channels, stream);
         if (e != hipErrorNotSupported) return e;
     }
+    // Blocks per workgroup: every run after a stream's first recomputes its predecessor block (1 / run
+    // extra work), and the launch ends with a partly filled round of workgroups unless their number
+    // is close to a multiple of what the chip holds at once.  Pick the run length (8..64) that
+    // maximises useful work per occupied slot.
+    auto pick_run = [&](const void* fn, uint32_t threads, size_t lds_bytes, uint32_t grid_z) {
+        uint32_t run = kFftRun;
+        int dev = 0, cus = 256, per_cu = 4;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, threads, lds_bytes) != hipSuccess || per_cu < 1) per_cu = 4;
+        const double slots = static_cast<double>(cus) * per_cu;
+        double best = -1.0;
+        for (uint32_t cand = 8; cand <= 64; ++cand) {
+            const double runs = static_cast<double>((max_blocks + cand - 1) / cand);
+            const double wgs = runs * n_streams * grid_z;
+            const double rounds = std::ceil(wgs / slots);
+            const double useful = static_cast<double>(max_blocks) / (max_blocks + runs - 1.0);   // halo blocks
+            const double score = wgs / (rounds * slots) * useful;
+            if (score > best + 1e-9) { best = score; run = cand; }
+        }
+        static const char* knob = getenv("RSMP_FFT_RUN");
+        if (knob && atoi(knob) > 0) run = static_cast<uint32_t>(atoi(knob));
+        return run;
+    };
     size_t lds = fft_ola_lds_bytes(plan, max_channels);
-    if (lds > 160 * 1024) {   // the two-buffer kernels do not fit: one buffer, in place, a workgroup per stream
+    static const int big_knob = [] { const char* e = getenv("RSMP_FFT_BIG_ABOVE"); return e ? atoi(e) : 160 * 1024; }();   // A/B
+    if (lds > static_cast<size_t>(big_knob)) {   // the two-buffer kernels do not fit: one buffer, in place, a workgroup per channel
         const size_t big = fft_big_lds_bytes(plan);
         if (big > 160 * 1024) return hipErrorInvalidValue;
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fft_ola_big_kernel),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(fft_ola_big_kernel, dim3(n_streams), dim3(kBigThreads), big, stream, plan, d_descs);
+        const uint32_t run = pick_run(reinterpret_cast<const void*>(fft_ola_big_kernel), kBigThreads, big, max_channels);
+        hipLaunchKernelGGL(fft_ola_big_kernel, dim3((max_blocks + run - 1) / run, n_streams, max_channels), dim3(kBigThreads), big,
+                           stream, plan, d_descs, run);
         return hipGetLastError();
     }
     bool all_stereo = max_channels == 2 && min_channels == 2;
@@ -768,11 +805,19 @@ hipError_t launch_fft_ola(const FftPlanDev& plan, const FftStreamDesc* d_descs, 
         static const int wave_knob = [] { const char* e = getenv("RSMP_FFT_GENERIC_WAVE"); return e ? atoi(e) : -1; }();   // A/B: 0 / 1 forces
         const size_t lds_wave = 2 * static_cast<size_t>(plan.lds_complex) * sizeof(float2) + static_cast<size_t>(plan.fft_out) * sizeof(float);
         const bool per_channel = wave_knob >= 0 ? wave_knob != 0 : plan.lds_complex <= 513;
+        static const int threads_knob = [] { const char* e = getenv("RSMP_FFT_GENERIC_THREADS"); return e ? atoi(e) : 0; }();   // A/B
         if (per_channel && lds_wave <= 160 * 1024) {
             fn = fft_ola_kernel<64, true>;
             threads = 64;
             grid_z = max_channels;
             lds = lds_wave;
+        } else if (threads_knob ? threads_knob == 1024 : lds > 80 * 1024) {
+            // the long plans: one workgroup per CU is all the LDS holds, so it is 16 waves wide, not 4
+            fn = fft_ola_kernel<1024, false>;
+            threads = 1024;
+        } else if (threads_knob ? threads_knob == 512 : lds > 160 * 1024 / 3) {
+            fn = fft_ola_kernel<512, false>;   // two workgroups per CU
+            threads = 512;
         }
     }
     if (fn == static_cast<Kernel>(fft_ola_kernel_ct2<Plan1176, Plan1280>) ||
@@ -783,31 +828,7 @@ hipError_t launch_fft_ola(const FftPlanDev& plan, const FftStreamDesc* d_descs, 
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
     }
-    // Blocks per workgroup: every run after a stream's first recomputes its predecessor block (1 / run
-    // extra work), and the launch ends with a partly filled round of workgroups unless their number
-    // is close to a multiple of what the chip holds at once.  Pick the run length (8..64) that
-    // maximises useful work per occupied slot.
-    uint32_t run = kFftRun;
-    {
-        int dev = 0, cus = 256, per_cu = 4;
-        (void)hipGetDevice(&dev);
-        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(fn), threads, lds) != hipSuccess ||
-            per_cu < 1)
-            per_cu = 4;
-        const double slots = static_cast<double>(cus) * per_cu;
-        double best = -1.0;
-        for (uint32_t cand = 8; cand <= 64; ++cand) {
-            const double runs = static_cast<double>((max_blocks + cand - 1) / cand);
-            const double wgs = runs * n_streams * grid_z;
-            const double rounds = std::ceil(wgs / slots);
-            const double useful = static_cast<double>(max_blocks) / (max_blocks + runs - 1.0);   // halo blocks
-            const double score = wgs / (rounds * slots) * useful;
-            if (score > best + 1e-9) { best = score; run = cand; }
-        }
-        static const char* knob = getenv("RSMP_FFT_RUN");
-        if (knob && atoi(knob) > 0) run = static_cast<uint32_t>(atoi(knob));
-    }
+    const uint32_t run = pick_run(reinterpret_cast<const void*>(fn), threads, lds, grid_z);
     const dim3 grid((max_blocks + run - 1) / run, n_streams, grid_z);
     hipLaunchKernelGGL(fn, grid, dim3(threads), lds, stream, plan, d_descs, run);
     return hipGetLastError();
