@@ -668,11 +668,12 @@ bool wave_choice(const FftPlanDev& plan, uint32_t channels, int occ_env, WaveCho
     constexpr bool fit12 = tables + 12 * buf <= kCu, fit4 = 2 * (tables + 4 * buf) <= kCu;
     constexpr uint32_t wide = (kCu - tables) / buf < 8 ? static_cast<uint32_t>((kCu - tables) / buf) : 8u;
     static_assert(fit4 || wide >= 4, "a plan this long belongs to the workgroup kernels");
-    int occ = channels == 2 ? (fit12 ? 3 : fit4 ? 2 : 1) : (fit4 ? 2 : 1);
+    static const bool no_c2 = getenv("RSMP_FFT_WAVE_NOC2") != nullptr;   // A/B: the any-channel-count build for two channels
+    int occ = channels == 2 && !no_c2 ? (fit12 ? 3 : fit4 ? 2 : 1) : (fit4 ? 2 : 1);
     if (channels == 2 && ((occ_env == 3 && fit12) || (occ_env == 2 && fit4))) occ = occ_env;
     out->occ = occ;
     out->fn = nullptr;
-    if (channels == 2) {
+    if (channels == 2 && !no_c2) {
         if constexpr (fit12) if (occ == 3) out->fn = fft_ola_wave_kernel<FWD, INV, true, 3>;
         if constexpr (fit4) if (occ == 2) out->fn = fft_ola_wave_kernel<FWD, INV, true, 2>;
         if constexpr (!fit4) if (occ == 1) out->fn = fft_ola_wave_kernel<FWD, INV, true, 1>;
@@ -680,7 +681,8 @@ bool wave_choice(const FftPlanDev& plan, uint32_t channels, int occ_env, WaveCho
         if constexpr (fit4) out->fn = fft_ola_wave_kernel<FWD, INV, false, 2>;
         else out->fn = fft_ola_wave_kernel<FWD, INV, false, 1>;
     }
-    out->waves = occ == 3 ? 12u : occ == 2 ? 4u : wide;
+    static const uint32_t wide_knob = [] { const char* e = getenv("RSMP_FFT_WAVE_WIDE"); return e ? static_cast<uint32_t>(atoi(e)) : 0u; }();
+    out->waves = occ == 3 ? 12u : occ == 2 ? 4u : (wide_knob >= 1 && wide_knob <= wide ? wide_knob : wide);
     out->resident = occ == 2 ? 8u : out->waves;
     out->lds = (tables + out->waves * buf) * sizeof(cf);
     return out->fn != nullptr;

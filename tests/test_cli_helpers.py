@@ -74,7 +74,9 @@ def test_pcm_conversion_matches_the_reference_form(bits, channels):
         g = ra.ResamplerFir.new(2, ra.SampleRate.Hz44100, ra.SampleRate.Hz48000, ra.Latency.Sample64, ra.Attenuation.Db90)
         r = o.OracleFir(2, 44100, 48000, 128, 90)
         d_y = torch.zeros(g.bulk_output_bound(want.size, 512), device=dev)
+        torch.cuda.synchronize()   # (the launch runs on the handle's own stream: order it after the fills, wait for it)
         c, p = g.resample_bulk_device(d_out, d_y, 512)
+        torch.cuda.synchronize()
         yr, _ = r.resample_all(want, 512)
         assert c == want.size and p == yr.size
         assert float(np.sqrt(np.mean((d_y[:p].cpu().numpy().astype(np.float64) - yr) ** 2))) <= 1e-6

@@ -248,9 +248,11 @@ def test_block_sharded_stream_equals_the_single_launch(in_hz, out_hz, blocks, wo
     x = synth.sweep(blocks * n_in // 2, 2, float(in_hz))
     d_x = torch.from_numpy(x).to(dev)
     d_whole = torch.zeros(blocks * n_out, device=dev)
+    torch.cuda.synchronize()   # (launches run on the handles' own streams: order them after the fills)
     g.resample_bulk_device(d_x, d_whole, blocks)
     for first, end in sharding.fft_block_shards(blocks, world):
         d_work = torch.zeros((end - first + 1) * n_out, device=dev)
+        torch.cuda.synchronize()
         d_out = sharding.run_fft_block_shard(mk(), first, end, d_x, d_work)
         torch.cuda.synchronize()
         assert d_out.numel() == (end - first) * n_out
@@ -259,24 +261,45 @@ def test_block_sharded_stream_equals_the_single_launch(in_hz, out_hz, blocks, wo
 
 @pytest.mark.gpu
 def test_every_rate_pair_of_the_reference_constructs_and_matches():
-    """All 90 ordered pairs of the reference's SampleRate (src/lib.rs:167-188), one channel, three blocks each
-    through the bulk entry: blocks from 64 to 12288 frames, every kernel flavour (wave, workgroup, one-buffer)."""
+    """All 90 ordered pairs of the reference's SampleRate (src/lib.rs:167-188) through the bulk entry: one channel x
+    three blocks (the any-channel-count builds, no halo) and two channels x 23 blocks (the two-channel builds; more
+    than one run of blocks, so the halo recompute runs): blocks from 64 to 12288 frames, every kernel flavour
+    (wave per transform, workgroup, one-buffer).  The two-channel expectation is the reference run per channel
+    (channels = 1): with two channels its output scratch regions collide for 59 of the 90 pairs (`consistent`,
+    SURVEY 7.3 item 6); where they do not, the two-channel reference is checked as well."""
     torch = pytest.importorskip("torch")
     dev = torch.device("cuda:0")
     worst = 0.0
+    n_two_channel_reference = 0
     for a, b in itertools.permutations(RATES, 2):
-        g = ra.ResamplerFft.new(1, sr(a), sr(b))
-        r = o.OracleFft(1, a, b)
-        n_in, n_out = g.chunk_size_input(), g.chunk_size_output()
-        assert (n_in, n_out, g.delay()) == (r.chunk_size_input(), r.chunk_size_output(), r.delay()), (a, b)
-        blocks = 3
-        x = synth.fast_noise(blocks * n_in, seed=a % 977 + b % 13)
-        d_out = torch.zeros(blocks * n_out, device=dev)
-        g.resample_bulk_device(torch.from_numpy(x).to(dev), d_out, blocks)
-        ref = np.zeros((blocks, n_out), np.float32)
-        for k in range(blocks):
-            assert r.resample(x[k * n_in:(k + 1) * n_in], ref[k]) == 0
-        e = rms(d_out.cpu().numpy(), ref.reshape(-1))
-        assert e <= RMS_TOL, (a, b, e)
-        worst = max(worst, e)
-    assert worst > 0.0
+        for ch, blocks in ((1, 3), (2, 23)):
+            g = ra.ResamplerFft.new(ch, sr(a), sr(b))
+            per_channel = [o.OracleFft(1, a, b) for _ in range(ch)]
+            n_in, n_out = g.chunk_size_input(), g.chunk_size_output()
+            assert (n_in, n_out, g.delay()) == (ch * per_channel[0].chunk_size_input(), ch * per_channel[0].chunk_size_output(),
+                                                per_channel[0].delay()), (a, b)
+            x = synth.fast_noise(blocks * n_in, seed=a % 977 + b % 13 + ch)
+            d_out = torch.zeros(blocks * n_out, device=dev)
+            d_in = torch.from_numpy(x).to(dev)
+            torch.cuda.synchronize()   # (the launch runs on the handle's own stream: order it after the fills)
+            g.resample_bulk_device(d_in, d_out, blocks)
+            torch.cuda.synchronize()
+            ref = np.zeros((blocks, n_out // ch, ch), np.float32)
+            row = np.zeros(n_out // ch, np.float32)
+            for k in range(blocks):
+                xk = x[k * n_in:(k + 1) * n_in].reshape(-1, ch)
+                for c in range(ch):
+                    assert per_channel[c].resample(np.ascontiguousarray(xk[:, c]), row) == 0
+                    ref[k, :, c] = row
+            y = d_out.cpu().numpy()
+            e = rms(y, ref.reshape(-1))
+            assert e <= RMS_TOL, (a, b, ch, e)
+            worst = max(worst, e)
+            if ch > 1 and consistent(ch, a, b):
+                r = o.OracleFft(ch, a, b)
+                whole = np.zeros((blocks, n_out), np.float32)
+                for k in range(blocks):
+                    assert r.resample(x[k * n_in:(k + 1) * n_in], whole[k]) == 0
+                assert np.array_equal(whole.reshape(-1), ref.reshape(-1)), (a, b)
+                n_two_channel_reference += 1
+    assert worst > 0.0 and n_two_channel_reference == 31

@@ -463,6 +463,7 @@ def test_time_sharded_stream_equals_the_single_launch(ch, in_hz, out_hz, lat, at
     d_x = torch.from_numpy(x).to(dev)
     whole_h = mk()
     d_whole = torch.zeros(whole_h.bulk_output_bound(x.size, chunk * ch), device=dev)
+    torch.cuda.synchronize()   # (launches run on the handles' own streams: order them after the fills)
     consumed, produced = whole_h.resample_bulk_device(d_x, d_whole, chunk * ch)
     assert consumed == x.size
     shards = sharding.fir_time_shards(in_hz, out_hz, getattr(ra.Latency, lat), frames, chunk, world)
@@ -471,6 +472,7 @@ def test_time_sharded_stream_equals_the_single_launch(ch, in_hz, out_hz, lat, at
     for s in shards:
         h = mk()
         d_out = torch.zeros(max(1, s.out_frames) * ch + 64, device=dev)
+        torch.cuda.synchronize()
         c, p = sharding.run_fir_time_shard(h, s, d_x, d_out, ch, chunk)
         assert (c, p) == (s.in_frames * ch, s.out_frames * ch), s.rank
         torch.cuda.synchronize()
