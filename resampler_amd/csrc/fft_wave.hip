@@ -459,8 +459,14 @@ __global__ __launch_bounds__(wave_group_threads(OCC), OCC == 1 ? 2 : OCC) void f
     constexpr int FI = FWD::N, FO = INV::N;
     constexpr int LDSC = FWD::kBuf > INV::kBuf ? FWD::kBuf : INV::kBuf;   // (+ the padding of a fused first pass or of a stage)
     constexpr int SF = FWD::kStages, SI = INV::kStages;
-    constexpr int RL = INV::kR[SI - 1], ML = FO / RL, ITERL = (ML + 63) / 64, HL = RL / 2;
-    static_assert(RL % 2 == 0, "the last inverse stage splits its outputs into output half and carry half");
+    // The last inverse stage keeps its outputs in registers where its radix is even: outputs q < RL / 2 of a butterfly
+    // are the block's frames, the others the overlap carried to the next block.  An odd last radix (the 44.1 kHz
+    // family as the output side) runs the stage through LDS like the others and splits in a pass of its own.
+    constexpr int RL = INV::kR[SI - 1], ML = FO / RL, ITERL = (ML + 63) / 64;
+    constexpr bool kOddLast = RL % 2 != 0;
+    constexpr int HL = kOddLast ? 1 : RL / 2;               // carried values per lane and trip
+    constexpr int CM = kOddLast ? FO / 2 : ML;              // carry (it, q) <-> complex index lane + 64 it + q CM
+    constexpr int CIT = (CM + 63) / 64;
     static_assert(FI % 2 == 0 && FO % 2 == 0, "frame pairs");
     const int lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -516,15 +522,15 @@ __global__ __launch_bounds__(wave_group_threads(OCC), OCC == 1 ? 2 : OCC) void f
     // overlap carried into the run: the stream state, or the predecessor block recomputed (not emitted).
     // Held as the unconjugated transform outputs (the conjugation of radix_fft.rs:656-669 is a modifier of
     // the overlap-add below).
-    cf carry[ITERL][HL];
+    cf carry[CIT][HL];
 #pragma unroll
-    for (int it = 0; it < ITERL; ++it) {
+    for (int it = 0; it < CIT; ++it) {
         const int i = lane + 64 * it;
 #pragma unroll
         for (int q = 0; q < HL; ++q) {
             carry[it][q] = cf_make(0.f, 0.f);
-            if (first == 0 && i < ML) {
-                const int c = i + q * ML;   // complex index = reals 2c, 2c + 1 of the channel's overlap row
+            if (first == 0 && i < CM) {
+                const int c = i + q * CM;   // complex index = reals 2c, 2c + 1 of the channel's overlap row
                 const GFloat* ov = as_global(d.overlap);
                 carry[it][q] = cf_make(ov[ch * FO + 2 * c], -ov[ch * FO + 2 * c + 1]);
             }
@@ -566,7 +572,7 @@ __global__ __launch_bounds__(wave_group_threads(OCC), OCC == 1 ? 2 : OCC) void f
             if constexpr (INV::kFused) wave_fused_first<FO, INV::kR[0], INV::kR[1], INV::kFusedPad>(buf, tw_i + INV::tab(1), lane, from_lds);
             else wave_first<FO, INV::kR[0]>(buf, lane, from_lds);
         }
-        static_for<(INV::kFused ? 2 : 1), SI - 1>([&](auto s_c) {
+        static_for<(INV::kFused ? 2 : 1), (kOddLast ? SI : SI - 1)>([&](auto s_c) {
             constexpr int s = decltype(s_c)::value;
             wave_stage<FO, INV::kR[s], INV::stride(s), FO / INV::kR[s] + INV::in_pad(s), INV::out_pad(s)>(buf, tw_i + INV::tab(s), lane);
         });
@@ -574,6 +580,21 @@ __global__ __launch_bounds__(wave_group_threads(OCC), OCC == 1 ? 2 : OCC) void f
         // output conjugation (radix_fft.rs:656-669) makes reals 2c, 2c + 1 of the channel out of Z[c]; the
         // first FO reals are overlap-added and stored, the second FO become the next overlap (:416-423).
         GFloat* xout = as_global(d.out) + static_cast<size_t>(b) * FO * C;
+        if constexpr (kOddLast) {
+#pragma unroll
+            for (int it = 0; it < CIT; ++it) {
+                const int c = lane + 64 * it;
+                if ((it + 1) * 64 <= CM || c < CM) {
+                    const cf z = lds_ld(buf + c), z2 = lds_ld(buf + c + CM);
+                    if (emit) {
+                        const cf v = cf_conj_add_conj(z, carry[it][0]);
+                        xout[static_cast<size_t>(2 * c) * C + ch] = v.x;
+                        xout[static_cast<size_t>(2 * c + 1) * C + ch] = v.y;
+                    }
+                    carry[it][0] = z2;
+                }
+            }
+        } else {
         // reads of butterfly it + 1 are issued before butterfly it runs (all of them at once do not fit the
         // 168 registers of three waves per SIMD next to the carry)
         cf tl[2][RL], rawl[2][kFetch<RL>];
@@ -608,16 +629,17 @@ __global__ __launch_bounds__(wave_group_threads(OCC), OCC == 1 ? 2 : OCC) void f
                 }
             }
         }
+        }
         lds_order();
     }
     if (last == d.n_blocks) {
 #pragma unroll
-        for (int it = 0; it < ITERL; ++it) {
+        for (int it = 0; it < CIT; ++it) {
             const int i = lane + 64 * it;
-            if (i < ML) {
+            if (i < CM) {
 #pragma unroll
                 for (int q = 0; q < HL; ++q) {
-                    const int c = i + q * ML;
+                    const int c = i + q * CM;
                     GFloat* ov = as_global(d.overlap_next);
                     ov[ch * FO + 2 * c] = carry[it][q].x;
                     ov[ch * FO + 2 * c + 1] = -carry[it][q].y;
@@ -713,7 +735,8 @@ hipError_t launch_fft_ola_wave(const FftPlanDev& plan, const FftStreamDesc* d_de
                        wave_choices<W588, W1280, W2560>(plan, C, occ_env, &wc) || wave_choices<W882, W640, W1280>(plan, C, occ_env, &wc) ||
                        wave_choices<W1764, W640, W1280>(plan, C, occ_env, &wc) || wave_choices<W2352, W1280, W2560>(plan, C, occ_env, &wc) ||
                        wave_choice<W1176, W2560>(plan, C, occ_env, &wc) || wave_choice<W1280, W2352>(plan, C, occ_env, &wc) ||
-                       wave_choice<W2560, W2352>(plan, C, occ_env, &wc);
+                       wave_choices<W2560, W2352, W1176, W588>(plan, C, occ_env, &wc) || wave_choices<W640, W882, W1764>(plan, C, occ_env, &wc) ||
+                       wave_choices<W1280, W588, W882, W1764>(plan, C, occ_env, &wc);
     if (!found) return hipErrorNotSupported;
     const uint32_t kWavesPerGroup = wc.waves;
     const size_t lds = wc.lds;
