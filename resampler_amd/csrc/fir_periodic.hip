@@ -225,6 +225,75 @@ __device__ __forceinline__ void tile_taps_c2(v2f (&acc)[8], v2f& accw, const flo
     }
 }
 
+// ---- one channel per lane (CG == 1): packed FMAs over class pairs ------------------------------------
+// acc[p] = (class 2p, class 2p + 1) += (c[2p], c[2p + 1]) * x for the four class pairs of two consecutive taps:
+// src0 is the SGPR pair of the two coefficients, src1 a VGPR pair holding the two taps' samples, of which
+// op_sel broadcasts the low (first tap) or the high one (second tap) to both halves.  Half the vector
+// instructions of one v_fma_f32 per class and tap; every class still accumulates its taps in order.
+__device__ __forceinline__ void pk_fma8_c1(v2f (&acc)[4], v2f c0, v2f c1, v2f c2, v2f c3, v2f d0, v2f d1, v2f d2, v2f d3, v2f x) {
+    asm("v_pk_fma_f32 %0, %4, %12, %0 op_sel_hi:[1,0,1]\n\t"
+        "v_pk_fma_f32 %1, %5, %12, %1 op_sel_hi:[1,0,1]\n\t"
+        "v_pk_fma_f32 %2, %6, %12, %2 op_sel_hi:[1,0,1]\n\t"
+        "v_pk_fma_f32 %3, %7, %12, %3 op_sel_hi:[1,0,1]\n\t"
+        "v_pk_fma_f32 %0, %8, %12, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+        "v_pk_fma_f32 %1, %9, %12, %1 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+        "v_pk_fma_f32 %2, %10, %12, %2 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+        "v_pk_fma_f32 %3, %11, %12, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]"
+        : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3])
+        : "s"(c0), "s"(c1), "s"(c2), "s"(c3), "s"(d0), "s"(d1), "s"(d2), "s"(d3), "v"(x));
+}
+
+template <bool WRAP, int NT>
+__device__ __forceinline__ void taps_c1(v2f (&acc)[4], float& accw, const float (&x)[NT], const_v2f_ptr gc, const_f32_ptr gwc) {
+    static_assert(NT % 2 == 0, "taps go in pairs");
+    v2f c[4 * NT];
+#pragma unroll
+    for (int i = 0; i < 4 * NT; ++i) c[i] = gc[i];
+#pragma unroll
+    for (int u = 0; u < NT; u += 2) {
+        pk_fma8_c1(acc, c[4 * u], c[4 * u + 1], c[4 * u + 2], c[4 * u + 3], c[4 * u + 4], c[4 * u + 5], c[4 * u + 6], c[4 * u + 7],
+                   v2f{x[u], x[u + 1]});
+        if constexpr (WRAP) {
+            accw = fmaf(gwc[u], x[u], accw);
+            accw = fmaf(gwc[u + 1], x[u + 1], accw);
+        }
+    }
+}
+
+// rowA / rowB: the lane's channel in its own period row (from the tile's window start) and in the next row;
+// `cs` dwords between frames
+template <bool WRAP, int NT>
+__device__ __forceinline__ void tile_taps_c1(v2f (&acc)[4], float& accw, const float* rowA, const float* rowB, uint32_t cs,
+                                             uint32_t n1, uint32_t row_len, const_f32_ptr g, const_f32_ptr gw) {
+    const uint32_t n_chunks = row_len / NT;
+    const uint32_t chunks_a = n1 / NT;          // chunks entirely inside the lane's own row
+    const_v2f_ptr gc = (const_v2f_ptr)g;
+    uint32_t c = 0;
+    for (; c < chunks_a; ++c) {
+        float x[NT];
+#pragma unroll
+        for (int u = 0; u < NT; ++u) x[u] = rowA[(NT * c + u) * cs];
+        taps_c1<WRAP, NT>(acc, accw, x, gc + 4 * NT * c, gw + NT * c);
+    }
+    if (c < n_chunks && (n1 % NT)) {            // the chunk that straddles the two rows
+        float x[NT];
+#pragma unroll
+        for (int u = 0; u < NT; ++u) {
+            const uint32_t m = NT * c + u;
+            x[u] = m < n1 ? rowA[m * cs] : rowB[(m - n1) * cs];
+        }
+        taps_c1<WRAP, NT>(acc, accw, x, gc + 4 * NT * c, gw + NT * c);
+        ++c;
+    }
+    for (; c < n_chunks; ++c) {
+        const float* pb = rowB + (NT * c - n1) * cs;
+        float x[NT];
+#pragma unroll
+        for (int u = 0; u < NT; ++u) x[u] = pb[u * cs];
+        taps_c1<WRAP, NT>(acc, accw, x, gc + 4 * NT * c, gw + NT * c);
+    }
+}
+
 // Up to 768 threads = 12 waves (3 per SIMD); two workgroups per CU -> 6 waves per SIMD -> at
 // most 80 VGPRs.
 // C2 = true: exactly two channels, both handled by one lane (CG == 2) -- the headline config.
@@ -396,6 +465,20 @@ __device__ __forceinline__ void process_tile(const GeoArgs& geo, const ItemCtx& 
         for (int i = 0; i < 8; ++i) { av[i][0] = acc[i].x; av[i][1] = acc[i].y; }
         aw[0] = accw.x;
         aw[1] = accw.y;
+    } else if constexpr (CG == 1) {
+        v2f acc[4];
+        float accw = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = v2f{0.f, 0.f};
+        if (!(geo.debug & 2)) {
+            if (has_wrap)
+                tile_taps_c1<true, NT>(acc, accw, lane_row + ob * C, lane_row + geo.row_stride, C, n1, geo.row_len, g, gw);
+            else
+                tile_taps_c1<false, NT>(acc, accw, lane_row + ob * C, lane_row + geo.row_stride, C, n1, geo.row_len, g, gw);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { av[2 * i][0] = acc[i].x; av[2 * i + 1][0] = acc[i].y; }
+        aw[0] = accw;
     } else {
         Acc<CG> acc;
 #pragma unroll

@@ -115,6 +115,11 @@ def test_error_codes_match_reference():
     (2, 96000, 48000, ra.Attenuation.Db90),
     (8, 96000, 44100, ra.Attenuation.Db120),
     (4, 22050, 48000, ra.Attenuation.Db60),
+    # more than two channels at 147/160 (vector kernel: the matrix-core kernels are two-channel kernels)
+    (4, 44100, 48000, ra.Attenuation.Db90),
+    (6, 48000, 44100, ra.Attenuation.Db90),
+    (8, 44100, 48000, ra.Attenuation.Db120),
+    (3, 44100, 48000, ra.Attenuation.Db90),
 ])
 def test_bulk_matches_reference_driver_loop(kernel, ch, in_hz, out_hz, att):
     g, r = make_pair(ch, in_hz, out_hz, att=att, kernel=kernel)
@@ -132,6 +137,8 @@ def test_bulk_matches_reference_driver_loop(kernel, ch, in_hz, out_hz, att):
     yg2, _ = g.resample_bulk(x2[ch * 3000:], chunk)
     yr2, _ = r.resample_all(x2[ch * 3000:], chunk)
     assert yg2.size == yr2.size and rms(yg2, yr2) <= RMS_TOL
+    if kernel == ra.FirKernel.Periodic and ch == 2 and {in_hz, out_hz} == {44100, 48000} and os.environ.get("RSMP_FIR_MFMA", "3") == "3":
+        assert g.kernel_variant() == SPLIT_VARIANT
     if kernel == ra.FirKernel.PeriodicVector:
         assert g.kernel_variant() in (1, 2)   # never the matrix-core kernel
     if kernel == ra.FirKernel.PeriodicF32:
