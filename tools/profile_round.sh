@@ -4,7 +4,7 @@
 # is what gets copied to profiles/<tag>/):
 #   1. bench.py as the driver runs it (headline line incl. cpu_baseline and `secondary`)     -> bench_n1.json
 #      bench.py --path fft / --config c4 / --config c5                                        -> bench_fft.json, bench_c4.json, bench_c5.json
-#      per-call latency of config 5, other channel counts                                     -> bench_c5_calls.json, channels_bench.txt, fft_channels_bench.txt
+#      per-call latency of config 5, other channel counts, all 90 FFT rate pairs              -> bench_c5_calls.json, channels_bench.txt, fft_channels_bench.txt, fft_pairs_bench.txt
 #   2. rocprofv3 --kernel-trace --stats of the three commands                                 -> *_kernel_stats.csv
 #   3. separate --pmc passes FETCH_SIZE, WRITE_SIZE per workload (guide's gfx950 correction)  -> traffic_*.json, traffic_latest.json
 #   4. separate --pmc passes: SQ / MFMA / LDS counters per workload                           -> pmc_*.txt
@@ -24,6 +24,7 @@ python3 "$R/bench.py" --config c5 --steps 10 --warmup 2 > "$SUM/bench_c5.json" 2
 python3 "$R/tools/configs_bench.py" > "$SUM/bench_c5_calls.json" 2> "$OUT/bench_c5_calls.err"
 python3 "$R/tools/channels_bench.py" > "$SUM/channels_bench.txt" 2> "$OUT/channels_bench.err"
 python3 "$R/tools/fft_channels_bench.py" > "$SUM/fft_channels_bench.txt" 2> "$OUT/fft_channels_bench.err"
+python3 "$R/tools/fft_pairs_bench.py" --all > "$SUM/fft_pairs_bench.txt" 2> "$OUT/fft_pairs_bench.err"
 RSMP_LS_TRACE="$SUM/ls_trace_raw.txt" python3 "$R/tools/ls_trace.py" > "$SUM/ls_trace.txt" 2> "$OUT/ls_trace.err"; rm -f "$SUM/ls_trace_raw.txt"
 RSMP_FIR_WTRACE="$OUT/wtrace.txt" python3 "$R/bench.py" --no-cpu --no-secondary --steps 3 --warmup 1 --spinup-seconds 0 > /dev/null 2>&1
 python3 "$R/tools/wphase_report.py" "$OUT/wtrace.txt" 111.5 > "$SUM/wphase_split.txt" 2>/dev/null
