@@ -69,6 +69,15 @@ __device__ __forceinline__ cf lds_ld(const cf* p) {
     typedef const volatile __attribute__((address_space(3))) cf* LdsPtr;
     return *(LdsPtr)(p);
 }
+// Likewise one ds_write_b64 per value: the ds_write2_b64 the compiler forms of two costs 13 LDS cycles against 6 + 6.
+__device__ __forceinline__ void lds_st(cf* p, cf v) {
+#ifdef RSMP_FFT_WAVE_MERGED_STORES
+    *p = v;
+#else
+    typedef volatile __attribute__((address_space(3))) cf* LdsPtr;
+    *(LdsPtr)(p) = v;
+#endif
+}
 
 // A transform of N complex points in `Rs...` Stockham stages (2 .. 4 of them), as the reference's planner orders
 // them (src/fft/optimizer.rs).  Where the first two radices multiply to at most 21 values per unit (and a third
@@ -205,7 +214,7 @@ __device__ __forceinline__ void wave_stage(cf* buf, const cf* __restrict__ tw, i
             pdft<R>(t[it], o);
             cf* d = buf + R * i - (R - 1) * k + (OPAD ? OPAD * (i / STRIDE) : 0);
 #pragma unroll
-            for (int q = 0; q < R; ++q) d[q * STRIDE] = o[q];
+            for (int q = 0; q < R; ++q) lds_st(d + q * STRIDE, o[q]);
         }
     }
     lds_order();
@@ -280,7 +289,7 @@ __device__ __forceinline__ void wave_fused_first(cf* dst, const cf* __restrict__
                     u[qp] = k == 0 ? s[it][qp][k] : cf_mul(w1[k][qp], s[it][qp][k]);
                 pdft<RB>(u, o);
 #pragma unroll
-                for (int qq = 0; qq < RB; ++qq) dst[RA * RB * j + (PADJ ? j / (PADJ ? PADJ : 1) : 0) + k + RA * qq] = o[qq];
+                for (int qq = 0; qq < RB; ++qq) lds_st(dst + RA * RB * j + (PADJ ? j / (PADJ ? PADJ : 1) : 0) + k + RA * qq, o[qq]);
             }
         }
     }
@@ -313,7 +322,7 @@ __device__ __forceinline__ void wave_first(cf* dst, int lane, Load load) {
             cf o[R];
             pdft_tail<R, NZ>(t[it], o);
 #pragma unroll
-            for (int q = 0; q < R; ++q) dst[R * i + q] = o[q];
+            for (int q = 0; q < R; ++q) lds_st(dst + R * i + q, o[q]);
         }
     }
     lds_order();
