@@ -83,10 +83,21 @@ __device__ __forceinline__ void lds_st(cf* p, cf v) {
 // them (src/fft/optimizer.rs).  Where the first two radices multiply to at most 21 values per unit (and a third
 // stage exists) they run as one register pass (wave_fused_first); every later stage but the inverse's last is a
 // wave_stage; the twiddle tables of all stages sit in LDS.
-// With 21 columns a half wave of 32 lanes spans two blocks of a radix-7 stage's outputs, and 147 values = 294
-// dwords put the second block's first columns on the first block's last banks; two values more after every
-// block (298 = 42 mod 64) and every half wave of the stage stores conflict-free.
-constexpr int stage_out_pad(int r, int stride) { return r == 7 && stride == 21 ? 2 : 0; }
+// LDS stores go 16 lanes at a time over 32 banks (MI355X_MICROARCH.md, LDS table; tools/fft_bank_model.py counts the
+// array cycles of every pass of a plan pair).  A stage's lane i stores its value q at R (i - k) + k + q stride
+// (k = i mod stride): lanes 16 apart in i are in different blocks of `stride` columns unless stride >= 16, and a
+// block is (R - 1) stride values further than the lane index says -- two values per 16 lanes of shift keep the
+// 16 lanes of a store on distinct banks iff (R - 1) stride + pad is a multiple of 16 values.  (Radix 7, stride 21:
+// 147-value blocks, 2 values of padding; radix 8, stride 20: 4.)
+constexpr int stage_out_pad(int r, int stride) { return (16 - ((r - 1) * stride) % 16) % 16; }
+constexpr int gcd_c(int a, int b) { return b == 0 ? a : gcd_c(b, a % b); }
+// Twiddles a stage keeps per column in LDS: all R - 1 of the row, or -- radix 7 and 8 -- only w, w^2 and w^4 (the
+// stage multiplies the others out, see twiddle_expand; the tables of the 1176 <-> 1280 pair shrink from 39 to 29 KB).
+#if !defined(RSMP_FFT_WAVE_EXACT) && !defined(RSMP_FFT_WAVE_ALL_TWIDDLES)
+constexpr int fetch_count(int r) { return (r == 7 || r == 8) ? 3 : r - 1; }
+#else
+constexpr int fetch_count(int r) { return r - 1; }
+#endif
 template <int N_, int... Rs>
 struct WavePlan {
     static constexpr int N = N_;
@@ -99,34 +110,47 @@ struct WavePlan {
     // Stage twiddles, unique per column: stage s (s >= 1) holds stride(s) rows of R_s - 1.  In LDS the rows of a
     // wave_stage are (R - 1) | 1 values apart: lane k reads row k, and an even row length puts lanes 16 apart
     // (radix 7: six values = 12 dwords) on the same banks.  (The fused pass reads its rows by constant index.)
-    static constexpr int row(int r) { return (r - 1) | 1; }
+    static constexpr int row(int r) { return fetch_count(r) | 1; }
     static constexpr int pitch(int s) { return kFused && s == 1 ? kR[1] - 1 : row(kR[s]); }
     static constexpr int tab(int s) { int off = 0; for (int i = 1; i < s; ++i) off += stride(i) * pitch(i); return off; }   // LDS offset of stage s
     static constexpr int src(int s) { int off = 0; for (int i = 1; i < s; ++i) off += stride(i) * (kR[i] - 1); return off; }   // offset in the plan's array
     static constexpr int kTw = tab(kStages);
     static constexpr int kRc = N_ / 2 - 1;   // real <-> complex twiddles
-    // Padding between passes (LDS banks): after every fused_period() outputs of the fused pass one value, where
-    // its units are an even number of values apart and the next stage's input distance is that period; after
-    // the blocks of a radix-7 stage of stride 21 two values (stage_out_pad).  in_pad(s): what stage s's input
-    // distance N / R_s grows by.
-    static constexpr int fused_period() { return 8 * kR[0] * kR[1]; }
-    static constexpr bool kFusedPad = kFused && (kR[0] * kR[1]) % 2 == 0 && N_ / kR[2 < kStages ? 2 : 0] == fused_period();
+    // Padding between passes (LDS banks).  The first pass (fused or not) writes kUnit values per lane side by side:
+    // an even kUnit puts lanes 32 / gcd(2 kUnit, 32) apart on the same banks, so one value of padding follows every
+    // kPadJ units (20 values per unit: every 4) where the next stage's input distance is a multiple of that period.
+    // After the blocks of a later stage: stage_out_pad, where the stage that follows reads block by block.
+    // in_pad(s): what stage s's input distance N / R_s grows by; in_period(s): elements between two padding values
+    // inside that distance (0 = none).
+    static constexpr int kUnit = kFused ? kR[0] * kR[1] : kR[0];
+    static constexpr int kNext = kFused ? 2 : 1;   // the stage that reads the first pass's output
+    // (Plans above 2048 points run at the 256-register cap of their wide workgroups: the padded addressing spilled
+    // there -- 2352 -> 2560 points 0.80 -> 1.00 ms -- so they keep the plain layout, but for the radix-7 blocks.)
+    static constexpr bool kPadded = N_ <= 2048;
+    static constexpr int first_padj() {
+        if (!kPadded || kUnit % 2 != 0 || kNext >= kStages) return 0;
+        const int p = 32 / gcd_c(2 * kUnit, 32);
+        return (N_ / kR[kNext < kStages ? kNext : 0]) % (p * kUnit) == 0 ? p : 0;
+    }
+    static constexpr int kPadJ = first_padj();
     static constexpr int out_pad(int s) {
         if (s < 1 || s + 1 >= kStages || (kFused && s == 1)) return 0;
-        const int p = stage_out_pad(kR[s], stride(s));
+        if (stride(s) >= N_ / kR[s]) return 0;   // one block
+        const int p = kPadded || (kR[s] == 7 && stride(s) == 21) ? stage_out_pad(kR[s], stride(s)) : 0;
         return p != 0 && N_ / kR[s + 1] == stride(s + 1) ? p : 0;
     }
     static constexpr int in_pad(int s) {
-        if (kFused && s == 2) return kFusedPad ? 1 : 0;
+        if (s == kNext) return kPadJ ? (N_ / kR[s]) / (kPadJ * kUnit) : 0;
         return s >= 2 ? out_pad(s - 1) : 0;
     }
-    static constexpr int buf_values() {   // what the wave's buffer needs: the points, bin N (real <-> complex passes), the widest padded layout
-        int pad = kFusedPad ? N_ / fused_period() : 0;
+    static constexpr int in_period(int s) { return s == kNext && kPadJ && N_ / kR[s] > kPadJ * kUnit ? kPadJ * kUnit : 0; }
+    static constexpr int buf_values() {   // what the wave's buffer needs: the points + bin N and its neighbour (real <-> complex passes), or the widest padded layout
+        int pad = kPadJ ? N_ / (kPadJ * kUnit) : 0;
         for (int s = 1; s + 1 < kStages; ++s) {
             const int p = out_pad(s) * (N_ / stride(s + 1));
             if (p > pad) pad = p;
         }
-        return N_ + 2 + pad;
+        return N_ + (pad > 2 ? pad : 2);
     }
     static constexpr int kBuf = buf_values();
     static bool matches(uint32_t n, uint32_t n_stages, const uint32_t* radix) {
@@ -145,17 +169,13 @@ struct WavePlan {
 // the others out (one or two roundings more on those twiddles; -DRSMP_FFT_WAVE_EXACT fetches all of them).
 // A row is FETCHED (twiddle_fetch: kFetch<R> LDS reads, issued with the stage's data reads) and EXPANDED
 // when its butterfly runs.
-#if !defined(RSMP_FFT_WAVE_EXACT) && !defined(RSMP_FFT_WAVE_ALL_TWIDDLES)
-template <int R> constexpr int kFetch = (R == 7 || R == 8) ? 3 : R - 1;
-#else
-template <int R> constexpr int kFetch = R - 1;
-#endif
+template <int R> constexpr int kFetch = fetch_count(R);
 template <int R>
 __device__ __forceinline__ void twiddle_fetch(const cf* __restrict__ w, cf (&raw)[kFetch<R>]) {
     if constexpr (kFetch<R> != R - 1) {
-        raw[0] = lds_ld(w);
+        raw[0] = lds_ld(w);       // (the LDS row holds w, w^2, w^4)
         raw[1] = lds_ld(w + 1);
-        raw[2] = lds_ld(w + 3);
+        raw[2] = lds_ld(w + 2);
     } else {
 #pragma unroll
         for (int q = 0; q < R - 1; ++q) raw[q] = lds_ld(w + q);
@@ -182,21 +202,54 @@ __device__ __forceinline__ void twiddle_expand(const cf (&raw)[kFetch<R>], cf (&
 // columns a half wave of 32 lanes spans two blocks, and 147 values = 294 dwords put the second block's first
 // columns on the first block's last banks; two values more (298 = 42 mod 64) and every half wave of the
 // stage stores conflict-free.  The next stage then reads its inputs N / R' + OPAD apart (stage_out_pad).
-template <int N, int R, int STRIDE, int QS = N / R, int OPAD = 0>
+// IPP: the producer (the first pass) left one value of padding after every IPP of the stage's inputs (0 = none).
+template <int N, int R, int STRIDE, int QS = N / R, int OPAD = 0, int IPP = 0>
 __device__ __forceinline__ void wave_stage(cf* buf, const cf* __restrict__ tw, int lane) {
     constexpr int M = N / R;
     constexpr int ITER = (M + 63) / 64;
-    constexpr int ROW = (R - 1) | 1;
+    constexpr int ROW = fetch_count(R) | 1;
     // Every LDS read of the stage -- data and twiddle rows, in the order of their use -- is issued before the
     // first butterfly: the wave then waits for a read once per stage, not once per butterfly (LDS operations
     // of a wave complete in order, so butterfly 0 runs while the later reads are still in flight).
+    if constexpr (STRIDE == M && QS == M && OPAD == 0 && IPP == 0 && ITER >= 4) {
+        // A plan's last stage writes every value where it read it (stride = M: the butterfly's own points), so
+        // butterflies need not wait for each other's reads: of a long stage (4 or 5 trips: 64-80 values and their
+        // twiddles in registers at once, which the plans of 2048 points and more paid with spills) only the next
+        // trip's reads are in flight while one runs.
+        cf t2[2][R], raw2[2][kFetch<R>];
+        auto fetch = [&](int it) {
+            const int i = lane + 64 * it;
+            if ((it + 1) * 64 <= M || i < M) {
+#pragma unroll
+                for (int q = 0; q < R; ++q) t2[it & 1][q] = lds_ld(buf + i + q * M);
+                twiddle_fetch<R>(tw + i * ROW, raw2[it & 1]);
+            }
+        };
+        fetch(0);
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            const int i = lane + 64 * it;
+            if (it + 1 < ITER) fetch(it + 1);
+            if ((it + 1) * 64 <= M || i < M) {
+                cf twr[R], o[R];
+                twiddle_expand<R>(raw2[it & 1], twr);
+#pragma unroll
+                for (int q = 1; q < R; ++q) t2[it & 1][q] = cf_mul(twr[q], t2[it & 1][q]);
+                pdft<R>(t2[it & 1], o);
+#pragma unroll
+                for (int q = 0; q < R; ++q) lds_st(buf + i + q * M, o[q]);
+            }
+        }
+        lds_order();
+        return;
+    }
     cf t[ITER][R], raw[ITER][kFetch<R>];
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
         const int i = lane + 64 * it;
         if ((it + 1) * 64 <= M || i < M) {
 #pragma unroll
-            for (int q = 0; q < R; ++q) t[it][q] = lds_ld(buf + i + q * QS);
+            for (int q = 0; q < R; ++q) t[it][q] = lds_ld(buf + i + (IPP ? i / (IPP ? IPP : 1) : 0) + q * QS);
             twiddle_fetch<R>(tw + (i % STRIDE) * ROW, raw[it]);
         }
     }
@@ -241,11 +294,10 @@ __device__ __forceinline__ void static_for(F&& f) {
 // NVALID: points at index >= NVALID of the stage-0 input are zero and are neither fetched nor computed with
 // (the zero padding of the forward transform: resampler_fft.rs:387-388).  Butterfly q' takes the points
 // j + M2 (q' + RB q): the last NZ of its RA inputs are padding for every j (pdft_tail).
-// PAD: one value of padding after every 8 units (WavePlan::kFusedPad).
-template <int N, int RA, int RB, bool PAD, int NVALID = N, class Load>
+// PADJ: one value of padding after every PADJ units (WavePlan::kPadJ; 0 = none).
+template <int N, int RA, int RB, int PADJ, int NVALID = N, class Load>
 __device__ __forceinline__ void wave_fused_first(cf* dst, const cf* __restrict__ tw1, int lane, Load load) {
     constexpr int M2 = N / (RA * RB);
-    constexpr int PADJ = PAD ? 8 : 0;   // units per padding value
     constexpr int ITER = (M2 + 63) / 64;
     cf s[ITER][RB][RA];
 #pragma unroll
@@ -299,7 +351,7 @@ __device__ __forceinline__ void wave_fused_first(cf* dst, const cf* __restrict__
 // Stage 0 alone (stride 1, no twiddles) for the plans that do not fuse it with stage 1: butterfly i takes the
 // points i + q N / R through `load` (LDS, or samples straight from HBM; points at index >= NVALID are zero) and
 // writes R i + q.
-template <int N, int R, int NVALID = N, class Load>
+template <int N, int R, int PADJ, int NVALID = N, class Load>
 __device__ __forceinline__ void wave_first(cf* dst, int lane, Load load) {
     constexpr int M = N / R;
     constexpr int ITER = (M + 63) / 64;
@@ -322,7 +374,7 @@ __device__ __forceinline__ void wave_first(cf* dst, int lane, Load load) {
             cf o[R];
             pdft_tail<R, NZ>(t[it], o);
 #pragma unroll
-            for (int q = 0; q < R; ++q) lds_st(dst + R * i + q, o[q]);
+            for (int q = 0; q < R; ++q) lds_st(dst + R * i + (PADJ ? i / (PADJ ? PADJ : 1) : 0) + q, o[q]);
         }
     }
     lds_order();
@@ -458,8 +510,13 @@ __device__ __forceinline__ void wave_filter_preprocess(cf* y, const cf* __restri
 // 1 = one workgroup of as many waves (<= 8) as the CU's LDS holds buffers for (the long plans; the launch
 // decides).  (16 waves per CU for the short plans measured within 2 % of 12: the LDS is the bound, not latency.)
 constexpr int wave_group_threads(int occ) { return occ == 3 ? 768 : occ == 2 ? 256 : 512; }
+// Both transforms above 2048 points (88.2 <-> 96 kHz): four or five trips per stage in registers next to the
+// carry do not fit 256 registers -- these pairs run one wave per SIMD with the full register file instead of two
+// that spill (88.2 -> 96 kHz: 0.94 -> 0.76 ms).
+template <class FWD, class INV> constexpr bool kOneWavePerSimd = FWD::N > 2048 && INV::N > 2048;
 template <class FWD, class INV, bool C2, int OCC>
-__global__ __launch_bounds__(wave_group_threads(OCC), OCC == 1 ? 2 : OCC) void fft_ola_wave_kernel(FftPlanDev plan,
+__global__ __launch_bounds__((OCC == 1 && kOneWavePerSimd<FWD, INV> ? 256 : wave_group_threads(OCC)),
+                             (OCC == 1 ? (kOneWavePerSimd<FWD, INV> ? 1 : 2) : OCC)) void fft_ola_wave_kernel(FftPlanDev plan,
                                                                               const FftStreamDesc* __restrict__ descs,
                                                                               uint32_t run, uint32_t runs_per_stream,
                                                                               uint32_t total_waves) {
@@ -476,6 +533,7 @@ __global__ __launch_bounds__(wave_group_threads(OCC), OCC == 1 ? 2 : OCC) void f
     constexpr int HL = kOddLast ? 1 : RL / 2;               // carried values per lane and trip
     constexpr int CM = kOddLast ? FO / 2 : ML;              // carry (it, q) <-> complex index lane + 64 it + q CM
     constexpr int CIT = (CM + 63) / 64;
+    constexpr int kLastIpp = INV::in_period(SI - 1);   // (a two- or three-stage inverse: its last stage reads the first pass's output)
     static_assert(FI % 2 == 0 && FO % 2 == 0, "frame pairs");
     const int lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -491,15 +549,20 @@ __global__ __launch_bounds__(wave_group_threads(OCC), OCC == 1 ? 2 : OCC) void f
         auto copy = [&](cf* dst, const cf* __restrict__ src, int n) {
             for (int i = threadIdx.x; i < n; i += kWavesPerGroup * 64) dst[i] = src[i];
         };
-        // stage twiddles: rows re-spaced to the pitch the stage reads them with (WavePlan::pitch)
-        auto rows = [&](cf* dst, const cf* __restrict__ src, int n_rows, int len, int pitch) {
-            for (int i = threadIdx.x; i < n_rows * len; i += kWavesPerGroup * 64) dst[(i / len) * pitch + i % len] = src[i];
+        // stage twiddles: rows re-spaced to the pitch the stage reads them with (WavePlan::pitch); of a row of
+        // `len` values the first `keep` are taken, or (keep == 3 < len) w, w^2 and w^4
+        auto rows = [&](cf* dst, const cf* __restrict__ src, int n_rows, int len, int keep, int pitch) {
+            for (int i = threadIdx.x; i < n_rows * keep; i += kWavesPerGroup * 64) {
+                const int r = i / keep, j = i - r * keep;
+                dst[r * pitch + j] = src[r * len + (keep < len && j == 2 ? 3 : j)];
+            }
         };
         auto stage_tables = [&](cf* dst, const cf* __restrict__ src, auto P) {
             typedef decltype(P) PL;
             static_for<1, PL::kStages>([&](auto s_c) {
                 constexpr int s = decltype(s_c)::value;
-                rows(dst + PL::tab(s), src + PL::src(s), PL::stride(s), PL::kR[s] - 1, PL::pitch(s));
+                constexpr int len = PL::kR[s] - 1;
+                rows(dst + PL::tab(s), src + PL::src(s), PL::stride(s), len, PL::kFused && s == 1 ? len : fetch_count(PL::kR[s]), PL::pitch(s));
             });
         };
         stage_tables(tab + kTabF, reinterpret_cast<const cf*>(plan.tw_f), FWD{});
@@ -565,12 +628,12 @@ __global__ __launch_bounds__(wave_group_threads(OCC), OCC == 1 ? 2 : OCC) void f
                 }
                 return v;
             };
-            if constexpr (FWD::kFused) wave_fused_first<FI, FWD::kR[0], FWD::kR[1], FWD::kFusedPad, FI / 2>(buf, tw_f + FWD::tab(1), lane, sample);
-            else wave_first<FI, FWD::kR[0], FI / 2>(buf, lane, sample);
+            if constexpr (FWD::kFused) wave_fused_first<FI, FWD::kR[0], FWD::kR[1], FWD::kPadJ, FI / 2>(buf, tw_f + FWD::tab(1), lane, sample);
+            else wave_first<FI, FWD::kR[0], FWD::kPadJ, FI / 2>(buf, lane, sample);
         }
         static_for<(FWD::kFused ? 2 : 1), SF>([&](auto s_c) {
             constexpr int s = decltype(s_c)::value;
-            wave_stage<FI, FWD::kR[s], FWD::stride(s), FI / FWD::kR[s] + FWD::in_pad(s), FWD::out_pad(s)>(buf, tw_f + FWD::tab(s), lane);
+            wave_stage<FI, FWD::kR[s], FWD::stride(s), FI / FWD::kR[s] + FWD::in_pad(s), FWD::out_pad(s), FWD::in_period(s)>(buf, tw_f + FWD::tab(s), lane);
         });
         wave_postprocess<FI>(buf, rc_f, lane);
         wave_filter_preprocess<FO, (FI < FO ? FI + 1 : FO), FI>(buf, filter, rc_i, lane);
@@ -578,12 +641,12 @@ __global__ __launch_bounds__(wave_group_threads(OCC), OCC == 1 ? 2 : OCC) void f
         // ---- inverse transform, in place; its last stage below
         {
             auto from_lds = [&](int j) -> cf { return lds_ld(buf + j); };
-            if constexpr (INV::kFused) wave_fused_first<FO, INV::kR[0], INV::kR[1], INV::kFusedPad>(buf, tw_i + INV::tab(1), lane, from_lds);
-            else wave_first<FO, INV::kR[0]>(buf, lane, from_lds);
+            if constexpr (INV::kFused) wave_fused_first<FO, INV::kR[0], INV::kR[1], INV::kPadJ>(buf, tw_i + INV::tab(1), lane, from_lds);
+            else wave_first<FO, INV::kR[0], INV::kPadJ>(buf, lane, from_lds);
         }
         static_for<(INV::kFused ? 2 : 1), (kOddLast ? SI : SI - 1)>([&](auto s_c) {
             constexpr int s = decltype(s_c)::value;
-            wave_stage<FO, INV::kR[s], INV::stride(s), FO / INV::kR[s] + INV::in_pad(s), INV::out_pad(s)>(buf, tw_i + INV::tab(s), lane);
+            wave_stage<FO, INV::kR[s], INV::stride(s), FO / INV::kR[s] + INV::in_pad(s), INV::out_pad(s), INV::in_period(s)>(buf, tw_i + INV::tab(s), lane);
         });
         // ---- last inverse stage: outputs stay in registers.  Butterfly i (k = i) yields Z[i + q*ML]; the
         // output conjugation (radix_fft.rs:656-669) makes reals 2c, 2c + 1 of the channel out of Z[c]; the
@@ -611,7 +674,7 @@ __global__ __launch_bounds__(wave_group_threads(OCC), OCC == 1 ? 2 : OCC) void f
             const int i = lane + 64 * it;
             if ((it + 1) * 64 <= ML || i < ML) {
 #pragma unroll
-                for (int q = 0; q < RL; ++q) tl[it & 1][q] = lds_ld(buf + i + q * (ML + INV::in_pad(SI - 1)));
+                for (int q = 0; q < RL; ++q) tl[it & 1][q] = lds_ld(buf + i + (kLastIpp ? i / (kLastIpp ? kLastIpp : 1) : 0) + q * (ML + INV::in_pad(SI - 1)));
                 twiddle_fetch<RL>(tw_i + INV::tab(SI - 1) + i * INV::row(RL), rawl[it & 1]);
             }
         };
@@ -697,7 +760,8 @@ bool wave_choice(const FftPlanDev& plan, uint32_t channels, int occ_env, WaveCho
     constexpr size_t buf = FWD::kBuf > INV::kBuf ? FWD::kBuf : INV::kBuf;
     constexpr size_t kCu = 160 * 1024 / sizeof(cf);
     constexpr bool fit12 = tables + 12 * buf <= kCu, fit4 = 2 * (tables + 4 * buf) <= kCu;
-    constexpr uint32_t wide = (kCu - tables) / buf < 8 ? static_cast<uint32_t>((kCu - tables) / buf) : 8u;
+    constexpr uint32_t wide_fit = (kCu - tables) / buf < 8 ? static_cast<uint32_t>((kCu - tables) / buf) : 8u;
+    constexpr uint32_t wide = kOneWavePerSimd<FWD, INV> && wide_fit > 4 ? 4u : wide_fit;
     static_assert(fit4 || wide >= 4, "a plan this long belongs to the workgroup kernels");
     static const bool no_c2 = getenv("RSMP_FFT_WAVE_NOC2") != nullptr;   // A/B: the any-channel-count build for two channels
     int occ = channels == 2 && !no_c2 ? (fit12 ? 3 : fit4 ? 2 : 1) : (fit4 ? 2 : 1);
