@@ -77,6 +77,7 @@ constexpr uint32_t kStagers = 5;                          // (row block, period 
 struct SplitArgs {
     uint32_t a, b, taps, n_tiles, rows, slots, lds_bytes, blocks_per_stream, total_items, debug;
     uint32_t n_streams, fuse_tail;   // fuse_tail: also copy every stream's still-buffered tail into hist_next
+    uint32_t cstride, pairs;         // WIDE kernels: channels of a frame and channel pairs = cstride / 2 (an item = one pair of a block)
     unsigned long long* wtrace;   // RSMP_FIR_WTRACE: kWtraceSlots timestamped events per wave
     NfArgs nf;                    // non-finite sums are marked here (fir_nonfinite.h)
 };
@@ -203,17 +204,31 @@ struct Item {
 
 // Walks a workgroup's items in order without per-item divisions or 64-bit multiplications: the item
 // values of a stream advance by constants from one block to the next.
+// WIDE (streams of 4, 8, 12, 16 channels): an item is one channel PAIR of a block, the pairs of a block are
+// consecutive items -- the workgroup that staged a block's first pair finds the lines of the others in its L2,
+// and their 8-byte stores into the same lines meet there.
 struct Cursor {
     uint32_t item, stream, block;   // the next item to look at
+    uint32_t pair, cur_pair;        // WIDE: its channel pair; the pair of the item `next` returned
     bool fresh;                     // `c` and the values below belong to (stream, block)
     StreamCtx c;
     uint64_t q0, q_limit;           // valid iff q0 < q_limit
     int32_t n_block0, k_block0;
     int64_t f0;                     // frame index of (period q0, row 0) in [hist|in]
+    template <bool WIDE>
     __device__ __forceinline__ void init(const SplitArgs& g, uint32_t first) {
         item = first;
-        stream = first / g.blocks_per_stream;
-        block = first - stream * g.blocks_per_stream;
+        pair = cur_pair = 0;
+        if constexpr (WIDE) {
+            const uint32_t per_stream = g.blocks_per_stream * g.pairs;
+            stream = first / per_stream;
+            const uint32_t rem = first - stream * per_stream;
+            block = rem / g.pairs;
+            pair = rem - block * g.pairs;
+        } else {
+            stream = first / g.blocks_per_stream;
+            block = first - stream * g.blocks_per_stream;
+        }
         fresh = false;
         c = StreamCtx{};
         q0 = q_limit = 0;
@@ -222,6 +237,7 @@ struct Cursor {
     }
     // Finds the next valid item before `end`; returns false when there is none.  On success the values
     // (c, q0, n_block0, k_block0, f0) describe it and `found` is its index.
+    template <bool WIDE>
     __device__ __forceinline__ bool next(const SplitArgs& g, const FirStreamDesc* descs, uint32_t end, uint32_t& found) {
         while (item < end) {
             if (!fresh) {
@@ -232,7 +248,7 @@ struct Cursor {
                 k_block0 = static_cast<int32_t>(static_cast<int64_t>(q0) - static_cast<int64_t>(c.wrap_k0));
                 f0 = static_cast<int64_t>(q0 * g.a) - static_cast<int64_t>(c.abs_consumed);
                 fresh = true;
-            } else {
+            } else if (!WIDE || pair == 0) {   // (WIDE: the first pair of the stream's next block)
                 q0 += 16;
                 n_block0 += static_cast<int32_t>(16u * g.b);
                 k_block0 += 16;
@@ -241,12 +257,16 @@ struct Cursor {
             found = item;
             const bool valid = q0 < q_limit;
             ++item;
-            if (++block == g.blocks_per_stream) {
+            bool block_done = true;
+            if constexpr (WIDE) {
+                cur_pair = pair;
+                if (++pair == g.pairs) pair = 0;
+                else block_done = false;
+            }
+            if (block_done && ++block == g.blocks_per_stream) {
                 block = 0;
                 ++stream;
                 fresh = false;
-            } else if (!valid) {
-                // past the stream's last period: skip the rest of its blocks
             }
             if (valid) return true;
         }
@@ -289,6 +309,9 @@ __device__ __forceinline__ const void* uniform_ptr(const void* p) {   // into sc
 __device__ __forceinline__ void gload4(v4f& dst, uint32_t byte_off, const void* base) {
     asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(byte_off), "s"(base) : "memory");
 }
+__device__ __forceinline__ void gload2(v2f& dst, uint32_t byte_off, const void* base) {
+    asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(dst) : "v"(byte_off), "s"(base) : "memory");
+}
 __device__ __forceinline__ void gload1(uint32_t& dst, uint32_t byte_off, const void* base) {
     asm volatile("global_load_dword %0, %1, %2" : "=v"(dst) : "v"(byte_off), "s"(base) : "memory");
 }
@@ -307,6 +330,7 @@ __device__ __forceinline__ float row_sum16(float v) {
 // A producer's view of a work item (wave-uniform).
 struct PItem {
     uint32_t item;        // index in the launch; item_end = none
+    uint32_t pair;        // WIDE: the item's channel pair
     Item it;
     int64_t f0;           // frame index of (period q0, row 0) in [hist|in]
     bool interior;        // the image and its wrap windows lie inside `in`, below 2^28 frames
@@ -324,10 +348,18 @@ __device__ __forceinline__ uint32_t consumer_index(uint32_t w) { return w < 6 ? 
 
 // DIAG: the diagnostic instantiation (RSMP_FIR_DEBUG switches for timing experiments, RSMP_FIR_WTRACE phase
 // clocks); in the shipping instantiation `dbg` is the constant 0 and every such test folds away.
-template <int NK, int PLANES, bool DIAG>
+// WIDE: streams of 4, 8, 12 or 16 channels, as channel pairs (see Cursor): a frame is g.cstride floats, the pair's
+// two channels 8 bytes inside it.  The stagers load 16 bytes = two pairs of one frame (load_task_wide: issued for
+// the even pair, kept in registers for the odd one), the wrap passes load 8 bytes per frame, the consumers store
+// 8 bytes per frame; everything between the loads and the stores is the two-channel kernel.  The wrap-only
+// producer and the stagers are separate instantiations of the staging loop (ROLE), so that neither pays for the
+// other's registers (two wrap passes against one + the 40 registers of a stager's loads).
+template <int NK, int PLANES, bool DIAG, bool WIDE>
 __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __restrict__ descs,
                                                          const SplitArgs g) {
     constexpr uint32_t kRowBytes = row_bytes(PLANES);
+    const uint32_t fs = WIDE ? g.cstride : 2u;   // floats per frame
+    const uint32_t fsb = fs * 4u;                // bytes per frame
     const uint32_t dbg = DIAG ? g.debug : 0u;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     uint32_t* ctrl = reinterpret_cast<uint32_t*>(lds);
@@ -354,7 +386,7 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
             uint32_t* dst = reinterpret_cast<uint32_t*>(&d);
 #pragma unroll
             for (size_t i = 0; i < sizeof(FirStreamDesc) / 4; ++i) dst[i] = src[i];
-            const uint32_t total = d.tail_frames * 2u, first = d.tail_start * 2u, hist_values = d.hist_frames * 2u;
+            const uint32_t total = d.tail_frames * fs, first = d.tail_start * fs, hist_values = d.hist_frames * fs;
             for (uint32_t i = lane; i < total; i += 64) {
                 const uint32_t sv = first + i;
                 d.hist_next[i] = sv < hist_values ? d.hist[sv] : d.in[sv - hist_values];
@@ -386,17 +418,19 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
         uint32_t ln = lane;
 
         Cursor cu;
-        cu.init(g, item_begin);
+        cu.template init<WIDE>(g, item_begin);
         auto find_next = [&]() -> PItem {   // the next valid item; its stream context is cu.c
             PItem r;
             r.item = item_end;
+            r.pair = 0;
             r.it = Item{};
             r.f0 = 0;
             r.interior = false;
             r.off0 = 0;
             uint32_t found;
-            if (cu.next(g, descs, item_end, found)) {
+            if (cu.template next<WIDE>(g, descs, item_end, found)) {
                 r.item = found;
+                r.pair = cu.cur_pair;
                 r.it.q0 = cu.q0;
                 r.it.n_block0 = cu.n_block0;
                 r.it.k_block0 = cu.k_block0;
@@ -404,16 +438,18 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
                 r.f0 = cu.f0;
                 const int64_t hf = cu.c.hist_frames;
                 r.interior = r.f0 > hf && r.f0 + static_cast<int64_t>(17u * g.a + 2u) <= hf + static_cast<int64_t>(cu.c.in_frames) &&
-                             cu.c.in_frames < (1u << 27);
+                             (WIDE ? static_cast<uint64_t>(cu.c.in_frames) * fsb < (1ull << 32) - 65536u : cu.c.in_frames < (1u << 27));   // (32-bit byte offsets)
                 r.off0 = static_cast<uint32_t>(r.f0 - hf);
             }
             return r;
         };
-        auto fetch_edge = [&](const StreamCtx& c, int64_t f) -> v2f {
+        auto fetch_edge = [&](const StreamCtx& c, uint32_t pair, int64_t f) -> v2f {
             const int64_t hf = c.hist_frames, total = hf + static_cast<int64_t>(c.in_frames);
             const bool ok = f >= 0 && f < total;
             const int64_t fc = f < 0 ? 0 : (f >= total ? total - 1 : f);
-            v2f v = fc < hf ? ((gconst_f2_ptr)c.hist)[fc] : ((gconst_f2_ptr)c.in)[fc - hf];
+            v2f v;
+            if constexpr (WIDE) v = fc < hf ? *(gconst_f2_ptr)(c.hist + fc * fs + 2 * pair) : *(gconst_f2_ptr)(c.in + (fc - hf) * fs + 2 * pair);
+            else v = fc < hf ? ((gconst_f2_ptr)c.hist)[fc] : ((gconst_f2_ptr)c.in)[fc - hf];
             if (!ok) v = v2f{0.f, 0.f};
             return v;
         };
@@ -429,7 +465,10 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
         PItem ecur = nxt;
         StreamCtx ectx = cu.c;
 
-        {
+        // ROLE 0: the two-channel kernel's producers; WIDE: 1 = the wrap-only producer, 2 = a stager
+        auto staging = [&](auto role_c) {
+            constexpr int ROLE = decltype(role_c)::value;
+            constexpr int kMaxPass = ROLE == 2 ? 1 : 2;   // wrap passes (of four periods) a wave may take
             // ---- staging (all producers) + one pass of the wrap variant (producers 0-3) ---------------
             uint32_t t = P * 64 + lane;   // (one division for the whole launch)
             const bool real_task = P * 64 < n_lane_tasks;
@@ -444,8 +483,21 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
 #pragma unroll
                 for (int i = 0; i < 5; ++i) gload4(v[i], off + i * step, base);
             };
+            // WIDE: a 16-byte load is FOUR channels of one frame -- two channel pairs, i.e. two consecutive items of the
+            // block: the loads are issued for the even pair (`base` = its first channel) and stay in the registers
+            // for the odd one.  Per item that is five loads as in the two-channel kernel, and every line is used whole.
+            auto load_task_wide = [&](v4f (&v)[5][2], const PItem& pi, const void* base) {
+                const uint32_t off = (pi.off0 + 4 * tQ * g.a + 2 * tK) * fsb;
+                const uint32_t step = g.a * fsb;
+#pragma unroll
+                for (int i = 0; i < 5; ++i) {
+                    gload4(v[i][0], off + i * step, base);
+                    gload4(v[i][1], off + i * step + fsb, base);
+                }
+            };
             // v[i] = (ch0, ch1) of frame 2K and (ch0, ch1) of frame 2K+1 in period 4Q+i
-            auto store_task = [&](char* img, const v4f (&v)[5]) {
+            // at(i, fr, c) = channel c of frame 2K + fr in period 4Q + i
+            auto store_task = [&](char* img, auto&& at) {
                 typedef uint32_t u2 __attribute__((ext_vector_type(2)));
                 const uint32_t k0 = 2 * tK;   // rows k0 and k0 + 1 share a swizzle (k0 is even)
                 char* prim = img + k0 * kRowBytes + ((tQ ^ ((k0 >> 2) & 3)) << 3);
@@ -465,7 +517,7 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
                         if constexpr (PLANES == 3) {
                             uint32_t pl[3][5];
 #pragma unroll
-                            for (int i = 0; i < 5; ++i) split3(v[i][2 * fr + c], pl[0][i], pl[1][i], pl[2][i]);
+                            for (int i = 0; i < 5; ++i) split3(at(i, fr, c), pl[0][i], pl[1][i], pl[2][i]);
 #pragma unroll
                             for (int p = 0; p < 3; ++p) {
                                 *reinterpret_cast<u2*>(pr + (3 * c + p) * 32) =
@@ -477,7 +529,7 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
                             // two fp16 planes: h1 = RN16(s), h2 = RN16(s - h1) with s = 2^12 x (s - h1 is exact)
                             float s[5];
 #pragma unroll
-                            for (int i = 0; i < 5; ++i) s[i] = v[i][2 * fr + c] * kXScale;
+                            for (int i = 0; i < 5; ++i) s[i] = at(i, fr, c) * kXScale;
                             const uint32_t a01 = cvt_pk_f16(s[0], s[1]), a23 = cvt_pk_f16(s[2], s[3]), a4 = cvt_pk_f16(s[4], s[4]);
                             const uint32_t b01 = cvt_pk_f16(s[0] - f16_lo(a01), s[1] - f16_hi(a01));
                             const uint32_t b23 = cvt_pk_f16(s[2] - f16_lo(a23), s[3] - f16_hi(a23));
@@ -504,13 +556,26 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
             float wcoef[kWrapTaps];
             const float* cur_coeffs = nullptr;
             v4f wx[2][kWrapTaps / 2];
-            uint32_t wword[2] = {0, 0}, wsel[2] = {32, 32};   // the bitmap word with this lane's period's take bit, the bit (32 = none)
+            v2f wxw[kMaxPass][kWrapTaps];   // WIDE: one frame (the pair's two channels) per load
+            uint32_t wword[kMaxPass], wsel[kMaxPass];   // the bitmap word with this lane's period's take bit, the bit (32 = none)
+#pragma unroll
+            for (int ps = 0; ps < kMaxPass; ++ps) {
+                wword[ps] = 0;
+                wsel[ps] = 32;
+            }
             auto load_wrap = [&](int ps, const PItem& pi, const StreamCtx& c) {
                 const uint32_t wper = 4 * (pass0 + ps) + (ln >> 4);
-                const void* base = uniform_ptr(c.in);
-                const uint32_t off = (pi.off0 + wper * g.a - 1 + wpart * kWrapTaps) * 8u;
+                if constexpr (ROLE != 0) {
+                    const void* base = uniform_ptr(c.in + 2 * pi.pair);
+                    const uint32_t off = (pi.off0 + wper * g.a - 1 + wpart * kWrapTaps) * fsb;
 #pragma unroll
-                for (int i = 0; i < kWrapTaps / 2; ++i) gload4(wx[ps][i], off + i * 16u, base);
+                    for (int i = 0; i < kWrapTaps; ++i) gload2(wxw[ps][i], off + i * fsb, base);
+                } else {
+                    const void* base = uniform_ptr(c.in);
+                    const uint32_t off = (pi.off0 + wper * g.a - 1 + wpart * kWrapTaps) * 8u;
+#pragma unroll
+                    for (int i = 0; i < kWrapTaps / 2; ++i) gload4(wx[ps][i], off + i * 16u, base);
+                }
                 const int32_t nw = pi.it.n_block0 + static_cast<int32_t>(wper * g.b);
                 const bool in_launch = nw >= 0 && nw < static_cast<int32_t>(c.n_out);
                 const uint32_t K = in_launch ? static_cast<uint32_t>(pi.it.k_block0) + wper : 0u;   // (word 0 always exists)
@@ -532,10 +597,14 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
                 if (wpart == 0) *reinterpret_cast<v4f*>(wv + wper * 4) = v4f{acc.x, acc.y, __uint_as_float(take), 0.f};
             };
             v4f x[5];
+            v4f xq[5][2];         // ROLE 2: (period, frame) x four channels
+            uint32_t cpair = 0;   // WIDE: the current item's channel pair
             for (;;) {
                 const bool more = nxt.item != item_end;
                 if (!have && !more) break;
-                const bool pre = more && nxt.interior && !(dbg & 8192);   // the next item's loads can be issued ahead
+                bool pre = more && nxt.interior && !(dbg & 8192);   // the next item's loads can be issued ahead
+                // (a WIDE stager's odd pair lives on its even neighbour's loads, the item before it in this loop)
+                if constexpr (ROLE == 2) pre = pre && ((nxt.pair & 1u) == 0 || (have && loaded));
                 asm volatile("" : "+v"(ln), "+v"(tQ), "+v"(tK));
                 char* img = lds + kImageBase + slot * image_bytes;
                 if (have) {
@@ -545,47 +614,63 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
                 }
                 asm volatile("s_waitcnt vmcnt(0)" : : : "memory");   // the current item's loads (or dummies)
                 if (have) wt.event(6);
+                if constexpr (ROLE == 2) {
 #pragma unroll
-                for (int i = 0; i < 5; ++i) asm volatile("" : "+v"(x[i]));
+                    for (int i = 0; i < 5; ++i) asm volatile("" : "+v"(xq[i][0]), "+v"(xq[i][1]));
+                } else if constexpr (ROLE == 0) {
 #pragma unroll
-                for (int ps = 0; ps < 2; ++ps) {
+                    for (int i = 0; i < 5; ++i) asm volatile("" : "+v"(x[i]));
+                }
 #pragma unroll
-                    for (int i = 0; i < kWrapTaps / 2; ++i) asm volatile("" : "+v"(wx[ps][i]));
+                for (int ps = 0; ps < kMaxPass; ++ps) {
+                    if constexpr (ROLE != 0) {
+#pragma unroll
+                        for (int i = 0; i < kWrapTaps; ++i) asm volatile("" : "+v"(wxw[ps][i]));
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < kWrapTaps / 2; ++i) asm volatile("" : "+v"(wx[ps][i]));
+                    }
                     asm volatile("" : "+v"(wword[ps]));
                 }
                 if (have && real_task && !(dbg & 1)) {
                     if (loaded) {
-                        store_task(img, x);
+                        if constexpr (ROLE == 2) store_task(img, [&](int i, int fr, int c) { return (cpair & 1u) ? xq[i][fr][2 + c] : xq[i][fr][c]; });
+                        else store_task(img, [&](int i, int fr, int c) { return x[i][2 * fr + c]; });
                     } else {
                         // stream edges: frames outside [hist|in] read as zero; plain loads
                         v4f e[5];
 #pragma unroll
                         for (int i = 0; i < 5; ++i) {
                             const int64_t f = ecur.f0 + static_cast<int64_t>((4 * tQ + i) * g.a + 2 * tK);
-                            const v2f lo = fetch_edge(ectx, f), hi = fetch_edge(ectx, f + 1);
+                            const v2f lo = fetch_edge(ectx, ecur.pair, f), hi = fetch_edge(ectx, ecur.pair, f + 1);
                             e[i] = v4f{lo.x, lo.y, hi.x, hi.y};
                         }
-                        store_task(img, e);
+                        store_task(img, [&](int i, int fr, int c) { return e[i][2 * fr + c]; });
                     }
                 }
                 if (have && wrapper) {
                     wt.event(13);
 #pragma unroll
-                    for (int ps = 0; ps < 2; ++ps) {
+                    for (int ps = 0; ps < kMaxPass; ++ps) {
                         if (static_cast<uint32_t>(ps) >= n_pass) continue;
                         const uint32_t wper = 4 * (pass0 + ps) + (ln >> 4);
                         v2f w[kWrapTaps];
                         if (loaded) {
 #pragma unroll
                             for (int i = 0; i < kWrapTaps / 2; ++i) {
-                                w[2 * i] = v2f{wx[ps][i].x, wx[ps][i].y};
-                                w[2 * i + 1] = v2f{wx[ps][i].z, wx[ps][i].w};
+                                if constexpr (ROLE != 0) {
+                                    w[2 * i] = wxw[ps][2 * i];
+                                    w[2 * i + 1] = wxw[ps][2 * i + 1];
+                                } else {
+                                    w[2 * i] = v2f{wx[ps][i].x, wx[ps][i].y};
+                                    w[2 * i + 1] = v2f{wx[ps][i].z, wx[ps][i].w};
+                                }
                             }
                             wrap_out(w, wper, wsel[ps] < 32 ? (wword[ps] >> wsel[ps]) & 1u : 0u);
                         } else {
                             const int64_t fw = ecur.f0 + static_cast<int64_t>(wper * g.a) - 1 + wpart * kWrapTaps;
 #pragma unroll
-                            for (int i = 0; i < kWrapTaps; ++i) w[i] = fetch_edge(ectx, fw + i);
+                            for (int i = 0; i < kWrapTaps; ++i) w[i] = fetch_edge(ectx, ecur.pair, fw + i);
                             const int32_t nw = ecur.it.n_block0 + static_cast<int32_t>(wper * g.b);
                             const bool in_launch = nw >= 0 && nw < static_cast<int32_t>(ectx.n_out);
                             const uint32_t K = in_launch ? static_cast<uint32_t>(ecur.it.k_block0) + wper : 0u;
@@ -608,9 +693,13 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
                     for (int i = 0; i < kWrapTaps; ++i) asm volatile("" : "+v"(wcoef[i]));
                 }
                 if (pre) {
-                    if (real_task) load_task(x, true, nxt, uniform_ptr(cu.c.in));
+                    if constexpr (ROLE == 2) {
+                        if (real_task && (nxt.pair & 1u) == 0) load_task_wide(xq, nxt, uniform_ptr(cu.c.in + 2 * nxt.pair));
+                    } else if constexpr (ROLE == 0) {
+                        if (real_task) load_task(x, true, nxt, uniform_ptr(cu.c.in));
+                    }
 #pragma unroll
-                    for (int ps = 0; ps < 2; ++ps)
+                    for (int ps = 0; ps < kMaxPass; ++ps)
                         if (static_cast<uint32_t>(ps) < n_pass) load_wrap(ps, nxt, cu.c);
                 }
                 if (have) {
@@ -628,10 +717,19 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
                     ecur = nxt;
                     ectx = cu.c;
                 }
-                if (more) nxt = find_next();
+                if (more) {
+                    cpair = nxt.pair;
+                    nxt = find_next();
+                }
                 if (have) wt.event(5);
             }
             #undef wpart
+        };
+        if constexpr (WIDE) {
+            if (P == 5) staging(std::integral_constant<int, 1>{});
+            else staging(std::integral_constant<int, 2>{});
+        } else {
+            staging(std::integral_constant<int, 0>{});
         }
         asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
         wt.flush();
@@ -657,18 +755,30 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
     v4f pend_lo = v4f{0.f, 0.f, 0.f, 0.f}, pend_hi = v4f{0.f, 0.f, 0.f, 0.f};
     g_f32_ptr pend_o = nullptr;
     bool pend = false;
+    typedef v2f __attribute__((address_space(1)))* g_f2_ptr;
+    // a lane's four frames x two channels: 32 contiguous bytes, or (WIDE) 8 bytes in each of four frames
+    auto store_frames = [&](g_f32_ptr o, const v4f& lo, const v4f& hi) {
+        if constexpr (WIDE) {
+            *((g_f2_ptr)o) = v2f{lo.x, lo.y};
+            *((g_f2_ptr)(o + fs)) = v2f{lo.z, lo.w};
+            *((g_f2_ptr)(o + 2 * fs)) = v2f{hi.x, hi.y};
+            *((g_f2_ptr)(o + 3 * fs)) = v2f{hi.z, hi.w};
+        } else {
+            typedef v4f __attribute__((address_space(1), aligned(8)))* g_f4a8_ptr;
+            ((g_f4a8_ptr)o)[0] = lo;
+            ((g_f4a8_ptr)o)[1] = hi;
+        }
+    };
     auto flush_pending = [&]() {
         if (pend) {   // wave-uniform
-            typedef v4f __attribute__((address_space(1), aligned(8)))* g_f4a8_ptr;
-            ((g_f4a8_ptr)pend_o)[0] = pend_lo;
-            ((g_f4a8_ptr)pend_o)[1] = pend_hi;
+            store_frames(pend_o, pend_lo, pend_hi);
             pend = false;
         }
     };
     Cursor cu;
-    cu.init(g, item_begin);
+    cu.template init<WIDE>(g, item_begin);
     uint32_t item;
-    while (cu.next(g, descs, item_end, item)) {
+    while (cu.template next<WIDE>(g, descs, item_end, item)) {
         const StreamCtx& d = cu.c;
         Item it;
         it.q0 = cu.q0;
@@ -693,7 +803,7 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
             if (f < 0) f = 0;
             if (f >= static_cast<int64_t>(d.in_frames)) f = static_cast<int64_t>(d.in_frames) - 1;
             typedef __attribute__((address_space(3))) void* lds_void_ptr;
-            __builtin_amdgcn_global_load_lds((gconst_f32_ptr)d.in + f * 2,
+            __builtin_amdgcn_global_load_lds((gconst_f32_ptr)d.in + f * fs,
                                              (lds_void_ptr)(lds + kCtrlBytes + kWrapBytes + T * 256), 4, 0, 0);
         }
         wt.event(1);
@@ -739,7 +849,8 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
                 acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[s][0], x1, acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[s][0], y1, acc1, 0, 0, 0);
             }
-            if (s == 0 && !(dbg & 131072)) {
+            // (WIDE: an even pair's sums wait for the odd pair of their block -- the next item -- and leave as 16-byte stores)
+            if (s == 0 && !(dbg & 131072) && (!WIDE || (cu.cur_pair & 1u) == 0)) {
                 __builtin_amdgcn_sched_barrier(0);
                 flush_pending();
                 __builtin_amdgcn_sched_barrier(0);
@@ -749,7 +860,7 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
             acc0 *= kOutScale;
             acc1 *= kOutScale;
         }
-        flush_pending();   // (no MFMA loop ran, or the experiment switch above)
+        if (!WIDE || (cu.cur_pair & 1u) == 0) flush_pending();   // (no MFMA loop ran, or the experiment switch above)
         // class 0 may take the wrap variant the producers left with the image (tile 0, D row 0)
         if (T == 0) {
             const v4f w = *reinterpret_cast<const v4f*>(lds + kCtrlBytes + slot * 256 + pl * 16);
@@ -767,29 +878,40 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
         // a non-finite sum (inf / NaN sample, or one too large for the 16-bit planes): the chunk is redone
         // in the reference's form by the repair launch
         nf_mark(g.nf, nf_is_bad(acc0.x + acc1.x), d.sidx, n0, 4, n_limit);
-        g_f32_ptr o = (g_f32_ptr)d.out + static_cast<int64_t>(n0) * 2;
+        g_f32_ptr o = (g_f32_ptr)d.out + static_cast<int64_t>(n0) * fs + (WIDE ? 2 * cu.cur_pair : 0u);
         const v4f lo = v4f{acc0.x, acc1.x, acc0.y, acc1.y};
         const v4f hi = v4f{acc0.z, acc1.z, acc0.w, acc1.w};
         if (!(dbg & 16)) {
             const bool full = j0 + 4 <= g.b && n0 >= 0 && n0 + 4 <= n_limit;
-            if (__builtin_expect(__all(full), 1)) {   // the whole wave inside the launch: stored inside the next item's stream
+            bool combined = false;
+            if constexpr (WIDE) {
+                // the odd pair of a block whose even pair is pending: four channels of a frame side by side, 16-byte stores
+                if ((cu.cur_pair & 1u) && pend && pend_o + 2 == o && __all(full)) {
+                    typedef v4f __attribute__((address_space(1), aligned(8)))* g_f4a8_ptr;
+                    *((g_f4a8_ptr)pend_o) = v4f{pend_lo.x, pend_lo.y, lo.x, lo.y};
+                    *((g_f4a8_ptr)(pend_o + fs)) = v4f{pend_lo.z, pend_lo.w, lo.z, lo.w};
+                    *((g_f4a8_ptr)(pend_o + 2 * fs)) = v4f{pend_hi.x, pend_hi.y, hi.x, hi.y};
+                    *((g_f4a8_ptr)(pend_o + 3 * fs)) = v4f{pend_hi.z, pend_hi.w, hi.z, hi.w};
+                    pend = false;
+                    combined = true;
+                } else {
+                    flush_pending();   // (an even pair left without its partner: the workgroup's range ended between them)
+                }
+            }
+            if (combined) {
+            } else if (__builtin_expect(__all(full), 1)) {   // the whole wave inside the launch: stored inside the next item's stream
                 pend_lo = lo;
                 pend_hi = hi;
                 pend_o = o;
                 pend = true;
             } else if (full) {
-                typedef v4f __attribute__((address_space(1), aligned(8)))* g_f4a8_ptr;
-                ((g_f4a8_ptr)o)[0] = lo;
-                ((g_f4a8_ptr)o)[1] = hi;
+                store_frames(o, lo, hi);
             } else {
                 const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int32_t n = n0 + r;
-                    if (j0 + r < g.b && n >= 0 && n < n_limit) {
-                        typedef v2f __attribute__((address_space(1)))* g_f2_ptr;
-                        *((g_f2_ptr)(o + 2 * r)) = v2f{v[2 * r], v[2 * r + 1]};
-                    }
+                    if (j0 + r < g.b && n >= 0 && n < n_limit) *((g_f2_ptr)(o + fs * r)) = v2f{v[2 * r], v[2 * r + 1]};
                 }
             }
         }
@@ -826,7 +948,10 @@ PeriodicGeometry split_geometry(uint64_t num, uint64_t den, uint32_t taps, uint3
     PeriodicGeometry g;
     const uint32_t planes = split_planes_knob();
     const uint32_t kRowBytes = row_bytes(static_cast<int>(planes));
-    if (channels != 2 || num == 0 || num > 4096 || den < 16 || den > 16 * kConsumers) return g;
+    // two channels, or (RSMP_FIR_SPLIT_WIDE=0 turns it off) 4, 8, 12 or 16 taken as channel pairs, two pairs per 16-byte load
+    static const bool wide_ok = [] { const char* e = getenv("RSMP_FIR_SPLIT_WIDE"); return !e || atoi(e) != 0; }();
+    if (channels != 2 && (channels % 4 != 0 || channels > 16 || !wide_ok)) return g;
+    if (num == 0 || num > 4096 || den < 16 || den > 16 * kConsumers) return g;
     const uint32_t a = static_cast<uint32_t>(num), b = static_cast<uint32_t>(den);
     const uint32_t n_tiles = (b + 15) / 16;
     uint32_t shift = 0, ob_max = 0;
@@ -858,7 +983,7 @@ PeriodicGeometry split_geometry(uint64_t num, uint64_t den, uint32_t taps, uint3
     g.n_tiles = n_tiles;
     g.n_units = n_tiles;
     g.cg = 2;
-    g.lp = 1;
+    g.lp = channels / 2;       // channel pairs of a frame (an item of the launch = one pair of a block)
     g.pw = 16;
     g.row_stride = rows;       // rows of an image (frames of a period + window reach)
     g.waves = kWaves;
@@ -932,17 +1057,21 @@ hipError_t launch_fir_split(const FirStreamDesc* d_descs, uint32_t n_streams, co
         const char* e = getenv("RSMP_FIR_DEBUG");
         return e ? static_cast<uint32_t>(atoi(e)) : 0u;
     }();
-    SplitArgs args{geo.a, geo.b, geo.taps, geo.n_tiles, geo.row_stride, geo.images, geo.lds_bytes, max_blocks, max_blocks * n_streams, debug, n_streams, fuse_tail ? 1u : 0u, nullptr, nf};
+    const uint32_t pairs = geo.lp;
+    const bool wide = pairs > 1;
+    SplitArgs args{geo.a, geo.b, geo.taps, geo.n_tiles, geo.row_stride, geo.images, geo.lds_bytes, max_blocks, max_blocks * n_streams * pairs,
+                   debug, n_streams, fuse_tail ? 1u : 0u, 2 * pairs, pairs, nullptr, nf};
     static const char* wtrace_path = getenv("RSMP_FIR_WTRACE");
     const bool diag = debug != 0 || wtrace_path != nullptr;
-#define RSMP_SPLIT_FNS(P, D)                                                                              \
-    {reinterpret_cast<const void*>(fir_split_kernel<1, P, D>), reinterpret_cast<const void*>(fir_split_kernel<2, P, D>), \
-     reinterpret_cast<const void*>(fir_split_kernel<3, P, D>), reinterpret_cast<const void*>(fir_split_kernel<4, P, D>), \
-     reinterpret_cast<const void*>(fir_split_kernel<5, P, D>)}
-    static const void* const fns_all[2][2][5] = {{RSMP_SPLIT_FNS(2, false), RSMP_SPLIT_FNS(2, true)},
-                                                 {RSMP_SPLIT_FNS(3, false), RSMP_SPLIT_FNS(3, true)}};
+#define RSMP_SPLIT_FNS(P, D, W)                                                                              \
+    {reinterpret_cast<const void*>(fir_split_kernel<1, P, D, W>), reinterpret_cast<const void*>(fir_split_kernel<2, P, D, W>), \
+     reinterpret_cast<const void*>(fir_split_kernel<3, P, D, W>), reinterpret_cast<const void*>(fir_split_kernel<4, P, D, W>), \
+     reinterpret_cast<const void*>(fir_split_kernel<5, P, D, W>)}
+    static const void* const fns_all[2][2][5] = {{RSMP_SPLIT_FNS(2, false, false), RSMP_SPLIT_FNS(2, true, false)},
+                                                 {RSMP_SPLIT_FNS(3, false, false), RSMP_SPLIT_FNS(3, true, false)}};
+    static const void* const fns_wide[2][5] = {RSMP_SPLIT_FNS(2, false, true), RSMP_SPLIT_FNS(3, false, true)};   // (no diagnostic build)
 #undef RSMP_SPLIT_FNS
-    const void* const* fns = fns_all[geo.planes == 3 ? 1 : 0][diag ? 1 : 0];
+    const void* const* fns = wide ? fns_wide[geo.planes == 3 ? 1 : 0] : fns_all[geo.planes == 3 ? 1 : 0][diag ? 1 : 0];
     const uint32_t nk = geo.row_len / 32;
     if (nk < 1 || nk > 5) return hipErrorInvalidValue;
     int device = 0;
@@ -952,7 +1081,7 @@ hipError_t launch_fir_split(const FirStreamDesc* d_descs, uint32_t n_streams, co
     static std::map<std::pair<int, uint32_t>, bool> granted;
     {
         std::lock_guard<std::mutex> lock(mu);
-        bool& have = granted[{device, (nk * 8 + geo.planes) * 2 + (diag ? 1u : 0u)}];
+        bool& have = granted[{device, ((nk * 8 + geo.planes) * 2 + (diag && !wide ? 1u : 0u)) * 2 + (wide ? 1u : 0u)}];
         if (!have) {
             e = hipFuncSetAttribute(fns[nk - 1], hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit);
             if (e != hipSuccess) return e;

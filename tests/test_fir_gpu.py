@@ -115,11 +115,14 @@ def test_error_codes_match_reference():
     (2, 96000, 48000, ra.Attenuation.Db90),
     (8, 96000, 44100, ra.Attenuation.Db120),
     (4, 22050, 48000, ra.Attenuation.Db60),
-    # more than two channels at 147/160 (vector kernel: the matrix-core kernels are two-channel kernels)
+    # more than two channels at 147/160: 4, 8, 12, 16 channels run the split matrix kernel as channel pairs, the
+    # others the vector kernel
     (4, 44100, 48000, ra.Attenuation.Db90),
     (6, 48000, 44100, ra.Attenuation.Db90),
     (8, 44100, 48000, ra.Attenuation.Db120),
     (3, 44100, 48000, ra.Attenuation.Db90),
+    (12, 48000, 44100, ra.Attenuation.Db90),
+    (16, 44100, 48000, ra.Attenuation.Db90),
 ])
 def test_bulk_matches_reference_driver_loop(kernel, ch, in_hz, out_hz, att):
     g, r = make_pair(ch, in_hz, out_hz, att=att, kernel=kernel)
@@ -137,7 +140,8 @@ def test_bulk_matches_reference_driver_loop(kernel, ch, in_hz, out_hz, att):
     yg2, _ = g.resample_bulk(x2[ch * 3000:], chunk)
     yr2, _ = r.resample_all(x2[ch * 3000:], chunk)
     assert yg2.size == yr2.size and rms(yg2, yr2) <= RMS_TOL
-    if kernel == ra.FirKernel.Periodic and ch == 2 and {in_hz, out_hz} == {44100, 48000} and os.environ.get("RSMP_FIR_MFMA", "3") == "3":
+    if (kernel == ra.FirKernel.Periodic and ch in (2, 4, 8, 12, 16) and {in_hz, out_hz} == {44100, 48000}
+            and os.environ.get("RSMP_FIR_MFMA", "3") == "3" and os.environ.get("RSMP_FIR_SPLIT_WIDE", "1") != "0"):
         assert g.kernel_variant() == SPLIT_VARIANT
     if kernel == ra.FirKernel.PeriodicVector:
         assert g.kernel_variant() in (1, 2)   # never the matrix-core kernel
@@ -145,6 +149,37 @@ def test_bulk_matches_reference_driver_loop(kernel, ch, in_hz, out_hz, att):
         assert g.kernel_variant() in (1, 2, 3)   # never the split-bf16 kernel
     if kernel == ra.FirKernel.Generic:
         assert g.kernel_variant() == 0
+
+
+@pytest.mark.parametrize("ch,in_hz,out_hz", [(4, 44100, 48000), (8, 48000, 44100)])
+def test_split_kernel_channel_pairs_long_stream(ch, in_hz, out_hz):
+    """4 / 8 channels at 147/160 on the split matrix kernel (an item = one channel pair of a block): a stream long
+    enough that a workgroup gets both pairs of a block (16-byte loads shared by two items, the even pair's sums
+    stored together with the odd pair's) as well as blocks cut between two workgroups; non-finite and out-of-range
+    samples in single channels go through the repair launch."""
+    g, _ = make_pair(ch, in_hz, out_hz, kernel=ra.FirKernel.Periodic)
+    r = o.OracleFir(ch, in_hz, out_hz, 128, 90, o.CONVOLVE_AVX_FMA if o.have_avx_fma() else o.CONVOLVE_SCALAR)
+    n = 700_000
+    x = synth.fast_noise(ch * n, seed=31 + ch)
+    x[ch * 1000 + 2] = np.inf
+    x[ch * 300_000 + 1] = np.nan
+    x[ch * 500_000 + 3] = 1000.0        # beyond the two-plane fp16 split
+    chunk = 512 * ch
+    yg, consumed = g.resample_bulk(x, chunk)
+    yr, _ = r.resample_all(x, chunk)
+    assert consumed == x.size and yg.size == yr.size
+    if os.environ.get("RSMP_FIR_MFMA", "3") == "3" and os.environ.get("RSMP_FIR_SPLIT_WIDE", "1") != "0":
+        assert g.kernel_variant() == SPLIT_VARIANT
+    fin_r, fin_g = np.isfinite(yr), np.isfinite(yg)
+    assert np.array_equal(fin_g, fin_r), np.flatnonzero(fin_g != fin_r)[:10]
+    assert (~fin_r).any()
+    ok = fin_r
+    assert rms(yg[ok], yr[ok]) <= RMS_TOL * max(1.0, float(np.sqrt(np.mean(yr[ok].astype(np.float64) ** 2))))
+    # every channel carries its own signal: per channel as well
+    for c in range(ch):
+        a, b = yg[c::ch], yr[c::ch]
+        m = np.isfinite(b)
+        assert rms(a[m], b[m]) <= RMS_TOL * max(1.0, float(np.sqrt(np.mean(b[m].astype(np.float64) ** 2)))), c
 
 
 @pytest.mark.parametrize("taps_lat", [ra.Latency.Sample8, ra.Latency.Sample16, ra.Latency.Sample32])
