@@ -204,7 +204,7 @@ struct Item {
 
 // Walks a workgroup's items in order without per-item divisions or 64-bit multiplications: the item
 // values of a stream advance by constants from one block to the next.
-// WIDE (streams of 4, 8, 12, 16 channels): an item is one channel PAIR of a block, the pairs of a block are
+// WIDE (streams of 4, 6, 8 .. 16 channels): an item is one channel PAIR of a block, the pairs of a block are
 // consecutive items -- the workgroup that staged a block's first pair finds the lines of the others in its L2,
 // and their 8-byte stores into the same lines meet there.
 struct Cursor {
@@ -348,7 +348,7 @@ __device__ __forceinline__ uint32_t consumer_index(uint32_t w) { return w < 6 ? 
 
 // DIAG: the diagnostic instantiation (RSMP_FIR_DEBUG switches for timing experiments, RSMP_FIR_WTRACE phase
 // clocks); in the shipping instantiation `dbg` is the constant 0 and every such test folds away.
-// WIDE: streams of 4, 8, 12 or 16 channels, as channel pairs (see Cursor): a frame is g.cstride floats, the pair's
+// WIDE: streams of 4, 6, 8 .. 16 channels, as channel pairs (see Cursor): a frame is g.cstride floats, the pair's
 // two channels 8 bytes inside it.  The stagers load 16 bytes = two pairs of one frame (load_task_wide: issued for
 // the even pair, kept in registers for the odd one), the wrap passes load 8 bytes per frame, the consumers store
 // 8 bytes per frame; everything between the loads and the stores is the two-channel kernel.  The wrap-only
@@ -437,7 +437,7 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
                 r.it.valid = true;
                 r.f0 = cu.f0;
                 const int64_t hf = cu.c.hist_frames;
-                r.interior = r.f0 > hf && r.f0 + static_cast<int64_t>(17u * g.a + 2u) <= hf + static_cast<int64_t>(cu.c.in_frames) &&
+                r.interior = r.f0 > hf && r.f0 + static_cast<int64_t>(17u * g.a + (WIDE ? 3u : 2u)) <= hf + static_cast<int64_t>(cu.c.in_frames) &&
                              (WIDE ? static_cast<uint64_t>(cu.c.in_frames) * fsb < (1ull << 32) - 65536u : cu.c.in_frames < (1u << 27));   // (32-bit byte offsets)
                 r.off0 = static_cast<uint32_t>(r.f0 - hf);
             }
@@ -948,9 +948,10 @@ PeriodicGeometry split_geometry(uint64_t num, uint64_t den, uint32_t taps, uint3
     PeriodicGeometry g;
     const uint32_t planes = split_planes_knob();
     const uint32_t kRowBytes = row_bytes(static_cast<int>(planes));
-    // two channels, or (RSMP_FIR_SPLIT_WIDE=0 turns it off) 4, 8, 12 or 16 taken as channel pairs, two pairs per 16-byte load
+    // two channels, or (RSMP_FIR_SPLIT_WIDE=0 turns it off) an even number up to 16 taken as channel pairs, two pairs per
+    // 16-byte load (6, 10, 14 channels: the last pair alone -- its load reaches 8 bytes into the next frame)
     static const bool wide_ok = [] { const char* e = getenv("RSMP_FIR_SPLIT_WIDE"); return !e || atoi(e) != 0; }();
-    if (channels != 2 && (channels % 4 != 0 || channels > 16 || !wide_ok)) return g;
+    if (channels != 2 && (channels % 2 != 0 || channels > 16 || !wide_ok)) return g;
     if (num == 0 || num > 4096 || den < 16 || den > 16 * kConsumers) return g;
     const uint32_t a = static_cast<uint32_t>(num), b = static_cast<uint32_t>(den);
     const uint32_t n_tiles = (b + 15) / 16;
