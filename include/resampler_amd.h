@@ -48,11 +48,12 @@ enum { RSMP_LATENCY_SAMPLE8 = 0, RSMP_LATENCY_SAMPLE16, RSMP_LATENCY_SAMPLE32, R
 enum { RSMP_ATTENUATION_DB60 = 0, RSMP_ATTENUATION_DB90, RSMP_ATTENUATION_DB120 };
 
 /* FIR kernel selection (rsmp_fir_set_kernel).  AUTO picks PERIODIC when the rate pair reduces to
- * a small rational and the launch is long enough, GENERIC otherwise.  PERIODIC runs 2-channel
- * streams on the matrix cores where the geometry allows: the split kernel (every f32 operand as the sum
+ * a small rational and the launch is long enough, GENERIC otherwise.  PERIODIC runs streams
+ * on the matrix cores where the geometry allows: the split kernel (every f32 operand as the sum
  * of two fp16 values of the scaled operand, three fp16 MFMA products accumulated in f32; RSMP_FIR_SPLIT_PLANES=3
  * selects three bf16 planes / six products, exact in every bit) for rate pairs with
- * 16..160 classes such as 44.1 <-> 48 kHz, the exact-f32 MFMA kernel otherwise.  PERIODIC_F32 keeps
+ * 16..160 classes such as 44.1 <-> 48 kHz and 2, 4, 6 .. 16 channels (channel pairs), the exact-f32 MFMA
+ * kernel for other 2-channel geometries, the vector kernel otherwise.  PERIODIC_F32 keeps
  * every product in f32 (exact-f32 MFMA or vector kernels, never the split one); PERIODIC_VECTOR forces
  * the packed-FMA vector kernel for every channel count.  All produce the same results within the
  * 1e-6 RMS gate (measured against the CPU path: about 1.2e-7 RMS each).
