@@ -123,6 +123,7 @@ def test_error_codes_match_reference():
     (3, 44100, 48000, ra.Attenuation.Db90),
     (12, 48000, 44100, ra.Attenuation.Db90),
     (16, 44100, 48000, ra.Attenuation.Db90),
+    (1, 48000, 44100, ra.Attenuation.Db90),     # BASELINE config 1's stream (vector kernel)
 ])
 def test_bulk_matches_reference_driver_loop(kernel, ch, in_hz, out_hz, att):
     g, r = make_pair(ch, in_hz, out_hz, att=att, kernel=kernel)
@@ -161,9 +162,9 @@ def test_split_kernel_channel_pairs_long_stream(ch, in_hz, out_hz):
     r = o.OracleFir(ch, in_hz, out_hz, 128, 90, o.CONVOLVE_AVX_FMA if o.have_avx_fma() else o.CONVOLVE_SCALAR)
     n = 700_000
     x = synth.fast_noise(ch * n, seed=31 + ch)
-    x[ch * 1000 + 2] = np.inf
-    x[ch * 300_000 + 1] = np.nan
-    x[ch * 500_000 + 3] = 1000.0        # beyond the two-plane fp16 split
+    x[ch * 1000 + min(2, ch - 1)] = np.inf
+    x[ch * 300_000 + min(1, ch - 1)] = np.nan
+    x[ch * 500_000 + min(3, ch - 1)] = 1000.0        # beyond the two-plane fp16 split
     chunk = 512 * ch
     yg, consumed = g.resample_bulk(x, chunk)
     yr, _ = r.resample_all(x, chunk)
