@@ -300,10 +300,18 @@ __device__ __forceinline__ uint32_t pack_hi16(uint32_t hi, uint32_t lo) {
 // compiler's own wait insertion falls back to vmcnt(0) in this loop -- every store waited for the
 // loads just issued, i.e. the full HBM latency seven times per item.)  vmcnt is in order: waiting
 // until at most N operations are outstanding completes everything older than the N youngest.
+template <bool GUARD = false>
 __device__ __forceinline__ const void* uniform_ptr(const void* p) {   // into scalar registers, whatever the compiler thought
     const uint64_t v = reinterpret_cast<uint64_t>(p);
-    const uint32_t lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v));
-    const uint32_t hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v >> 32));
+    uint32_t lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v));
+    uint32_t hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(v >> 32));
+    // The loads that take these scalar registers as base address are inline asm, which the compiler's hazard
+    // recogniser does not look into; where a vector instruction wrote them (v_readfirstlane here, or v_readlane
+    // restoring a spilled SGPR -- the many-channel build spills a hundred) the ISA wants five wait states before a
+    // vector-memory instruction reads them.  Spent here, tied to the two registers so that nothing moves across.
+    // (A one-channel build of this kernel read a stale base -- address 0 + offset -- without them.)
+    // (GUARD: the many-channel build; the two-channel one keeps its pointers in scalar registers throughout)
+    if constexpr (GUARD) asm volatile("s_nop 4" : "+s"(lo), "+s"(hi));
     return reinterpret_cast<const void*>(static_cast<uint64_t>(hi) << 32 | lo);
 }
 __device__ __forceinline__ void gload4(v4f& dst, uint32_t byte_off, const void* base) {
@@ -566,12 +574,12 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
             auto load_wrap = [&](int ps, const PItem& pi, const StreamCtx& c) {
                 const uint32_t wper = 4 * (pass0 + ps) + (ln >> 4);
                 if constexpr (ROLE != 0) {
-                    const void* base = uniform_ptr(c.in + 2 * pi.pair);
+                    const void* base = uniform_ptr<WIDE>(c.in + 2 * pi.pair);
                     const uint32_t off = (pi.off0 + wper * g.a - 1 + wpart * kWrapTaps) * fsb;
 #pragma unroll
                     for (int i = 0; i < kWrapTaps; ++i) gload2(wxw[ps][i], off + i * fsb, base);
                 } else {
-                    const void* base = uniform_ptr(c.in);
+                    const void* base = uniform_ptr<WIDE>(c.in);
                     const uint32_t off = (pi.off0 + wper * g.a - 1 + wpart * kWrapTaps) * 8u;
 #pragma unroll
                     for (int i = 0; i < kWrapTaps / 2; ++i) gload4(wx[ps][i], off + i * 16u, base);
@@ -579,7 +587,7 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
                 const int32_t nw = pi.it.n_block0 + static_cast<int32_t>(wper * g.b);
                 const bool in_launch = nw >= 0 && nw < static_cast<int32_t>(c.n_out);
                 const uint32_t K = in_launch ? static_cast<uint32_t>(pi.it.k_block0) + wper : 0u;   // (word 0 always exists)
-                gload1(wword[ps], (K >> 5) * 4u, uniform_ptr(c.wrap_bits));
+                gload1(wword[ps], (K >> 5) * 4u, uniform_ptr<WIDE>(c.wrap_bits));
                 wsel[ps] = in_launch ? K & 31u : 32u;
             };
             auto wrap_out = [&](const v2f (&w)[kWrapTaps], uint32_t wper, uint32_t take) {
@@ -694,9 +702,9 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
                 }
                 if (pre) {
                     if constexpr (ROLE == 2) {
-                        if (real_task && (nxt.pair & 1u) == 0) load_task_wide(xq, nxt, uniform_ptr(cu.c.in + 2 * nxt.pair));
+                        if (real_task && (nxt.pair & 1u) == 0) load_task_wide(xq, nxt, uniform_ptr<WIDE>(cu.c.in + 2 * nxt.pair));
                     } else if constexpr (ROLE == 0) {
-                        if (real_task) load_task(x, true, nxt, uniform_ptr(cu.c.in));
+                        if (real_task) load_task(x, true, nxt, uniform_ptr<WIDE>(cu.c.in));
                     }
 #pragma unroll
                     for (int ps = 0; ps < kMaxPass; ++ps)
