@@ -362,12 +362,15 @@ __device__ __forceinline__ uint32_t consumer_index(uint32_t w) { return w < 6 ? 
 // 8 bytes per frame; everything between the loads and the stores is the two-channel kernel.  The wrap-only
 // producer and the stagers are separate instantiations of the staging loop (ROLE), so that neither pays for the
 // other's registers (two wrap passes against one + the 40 registers of a stager's loads).
-template <int NK, int PLANES, bool DIAG, bool WIDE>
+template <int NK, int PLANES, bool DIAG, int WIDE>   // WIDE: 0 two channels, 1 channel pairs, 2 one channel
 __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __restrict__ descs,
                                                          const SplitArgs g) {
     constexpr uint32_t kRowBytes = row_bytes(PLANES);
     const uint32_t fs = WIDE ? g.cstride : 2u;   // floats per frame
     const uint32_t fsb = fs * 4u;                // bytes per frame
+    // One channel: a pair whose second channel is a phantom -- the loads take the following frame's sample for it, its
+    // sums are computed and dropped (half the matrix work of a pair is waste: still faster than the vector kernel).
+    constexpr bool mono = WIDE == 2;
     const uint32_t dbg = DIAG ? g.debug : 0u;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     uint32_t* ctrl = reinterpret_cast<uint32_t*>(lds);
@@ -426,7 +429,7 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
         uint32_t ln = lane;
 
         Cursor cu;
-        cu.template init<WIDE>(g, item_begin);
+        cu.template init<(WIDE != 0)>(g, item_begin);
         auto find_next = [&]() -> PItem {   // the next valid item; its stream context is cu.c
             PItem r;
             r.item = item_end;
@@ -436,7 +439,7 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
             r.interior = false;
             r.off0 = 0;
             uint32_t found;
-            if (cu.template next<WIDE>(g, descs, item_end, found)) {
+            if (cu.template next<(WIDE != 0)>(g, descs, item_end, found)) {
                 r.item = found;
                 r.pair = cu.cur_pair;
                 r.it.q0 = cu.q0;
@@ -445,7 +448,7 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
                 r.it.valid = true;
                 r.f0 = cu.f0;
                 const int64_t hf = cu.c.hist_frames;
-                r.interior = r.f0 > hf && r.f0 + static_cast<int64_t>(17u * g.a + (WIDE ? 3u : 2u)) <= hf + static_cast<int64_t>(cu.c.in_frames) &&
+                r.interior = r.f0 > hf && r.f0 + static_cast<int64_t>(17u * g.a + (WIDE ? 6u : 2u)) <= hf + static_cast<int64_t>(cu.c.in_frames) &&
                              (WIDE ? static_cast<uint64_t>(cu.c.in_frames) * fsb < (1ull << 32) - 65536u : cu.c.in_frames < (1u << 27));   // (32-bit byte offsets)
                 r.off0 = static_cast<uint32_t>(r.f0 - hf);
             }
@@ -456,7 +459,10 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
             const bool ok = f >= 0 && f < total;
             const int64_t fc = f < 0 ? 0 : (f >= total ? total - 1 : f);
             v2f v;
-            if constexpr (WIDE) v = fc < hf ? *(gconst_f2_ptr)(c.hist + fc * fs + 2 * pair) : *(gconst_f2_ptr)(c.in + (fc - hf) * fs + 2 * pair);
+            if constexpr (WIDE) {
+                if (mono) v = v2f{fc < hf ? ((gconst_f32_ptr)c.hist)[fc] : ((gconst_f32_ptr)c.in)[fc - hf], 0.f};
+                else v = fc < hf ? *(gconst_f2_ptr)(c.hist + fc * fs + 2 * pair) : *(gconst_f2_ptr)(c.in + (fc - hf) * fs + 2 * pair);
+            }
             else v = fc < hf ? ((gconst_f2_ptr)c.hist)[fc] : ((gconst_f2_ptr)c.in)[fc - hf];
             if (!ok) v = v2f{0.f, 0.f};
             return v;
@@ -494,6 +500,14 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
             // WIDE: a 16-byte load is FOUR channels of one frame -- two channel pairs, i.e. two consecutive items of the
             // block: the loads are issued for the even pair (`base` = its first channel) and stay in the registers
             // for the odd one.  Per item that is five loads as in the two-channel kernel, and every line is used whole.
+            // one channel: the two frames of a period are neighbours -- one 8-byte load; the phantom channel of frame 2K
+            // is frame 2K + 1, that of frame 2K + 1 is zero
+            auto load_task_mono = [&](v2f (&v)[5], const PItem& pi, const void* base) {
+                const uint32_t off = (pi.off0 + 4 * tQ * g.a + 2 * tK) * 4u;
+                const uint32_t step = g.a * 4u;
+#pragma unroll
+                for (int i = 0; i < 5; ++i) gload2(v[i], off + i * step, base);
+            };
             auto load_task_wide = [&](v4f (&v)[5][2], const PItem& pi, const void* base) {
                 const uint32_t off = (pi.off0 + 4 * tQ * g.a + 2 * tK) * fsb;
                 const uint32_t step = g.a * fsb;
@@ -574,12 +588,12 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
             auto load_wrap = [&](int ps, const PItem& pi, const StreamCtx& c) {
                 const uint32_t wper = 4 * (pass0 + ps) + (ln >> 4);
                 if constexpr (ROLE != 0) {
-                    const void* base = uniform_ptr<WIDE>(c.in + 2 * pi.pair);
+                    const void* base = uniform_ptr<(WIDE != 0)>(c.in + 2 * pi.pair);
                     const uint32_t off = (pi.off0 + wper * g.a - 1 + wpart * kWrapTaps) * fsb;
 #pragma unroll
                     for (int i = 0; i < kWrapTaps; ++i) gload2(wxw[ps][i], off + i * fsb, base);
                 } else {
-                    const void* base = uniform_ptr<WIDE>(c.in);
+                    const void* base = uniform_ptr<(WIDE != 0)>(c.in);
                     const uint32_t off = (pi.off0 + wper * g.a - 1 + wpart * kWrapTaps) * 8u;
 #pragma unroll
                     for (int i = 0; i < kWrapTaps / 2; ++i) gload4(wx[ps][i], off + i * 16u, base);
@@ -587,7 +601,7 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
                 const int32_t nw = pi.it.n_block0 + static_cast<int32_t>(wper * g.b);
                 const bool in_launch = nw >= 0 && nw < static_cast<int32_t>(c.n_out);
                 const uint32_t K = in_launch ? static_cast<uint32_t>(pi.it.k_block0) + wper : 0u;   // (word 0 always exists)
-                gload1(wword[ps], (K >> 5) * 4u, uniform_ptr<WIDE>(c.wrap_bits));
+                gload1(wword[ps], (K >> 5) * 4u, uniform_ptr<(WIDE != 0)>(c.wrap_bits));
                 wsel[ps] = in_launch ? K & 31u : 32u;
             };
             auto wrap_out = [&](const v2f (&w)[kWrapTaps], uint32_t wper, uint32_t take) {
@@ -606,6 +620,7 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
             };
             v4f x[5];
             v4f xq[5][2];         // ROLE 2: (period, frame) x four channels
+            v2f xm[5];            // ROLE 2, one channel: frames 2K, 2K + 1 of a period
             uint32_t cpair = 0;   // WIDE: the current item's channel pair
             for (;;) {
                 const bool more = nxt.item != item_end;
@@ -624,7 +639,10 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
                 if (have) wt.event(6);
                 if constexpr (ROLE == 2) {
 #pragma unroll
-                    for (int i = 0; i < 5; ++i) asm volatile("" : "+v"(xq[i][0]), "+v"(xq[i][1]));
+                    for (int i = 0; i < 5; ++i) {
+                        if constexpr (mono) asm volatile("" : "+v"(xm[i]));
+                        else asm volatile("" : "+v"(xq[i][0]), "+v"(xq[i][1]));
+                    }
                 } else if constexpr (ROLE == 0) {
 #pragma unroll
                     for (int i = 0; i < 5; ++i) asm volatile("" : "+v"(x[i]));
@@ -642,7 +660,10 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
                 }
                 if (have && real_task && !(dbg & 1)) {
                     if (loaded) {
-                        if constexpr (ROLE == 2) store_task(img, [&](int i, int fr, int c) { return (cpair & 1u) ? xq[i][fr][2 + c] : xq[i][fr][c]; });
+                        if constexpr (ROLE == 2) {
+                            if constexpr (mono) store_task(img, [&](int i, int fr, int c) { return c == 0 ? xm[i][fr] : (fr == 0 ? xm[i][1] : 0.f); });
+                            else store_task(img, [&](int i, int fr, int c) { return (cpair & 1u) ? xq[i][fr][2 + c] : xq[i][fr][c]; });
+                        }
                         else store_task(img, [&](int i, int fr, int c) { return x[i][2 * fr + c]; });
                     } else {
                         // stream edges: frames outside [hist|in] read as zero; plain loads
@@ -702,9 +723,11 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
                 }
                 if (pre) {
                     if constexpr (ROLE == 2) {
-                        if (real_task && (nxt.pair & 1u) == 0) load_task_wide(xq, nxt, uniform_ptr<WIDE>(cu.c.in + 2 * nxt.pair));
+                        if constexpr (mono) {
+                            if (real_task) load_task_mono(xm, nxt, uniform_ptr<(WIDE != 0)>(cu.c.in));
+                        } else if (real_task && (nxt.pair & 1u) == 0) load_task_wide(xq, nxt, uniform_ptr<(WIDE != 0)>(cu.c.in + 2 * nxt.pair));
                     } else if constexpr (ROLE == 0) {
-                        if (real_task) load_task(x, true, nxt, uniform_ptr<WIDE>(cu.c.in));
+                        if (real_task) load_task(x, true, nxt, uniform_ptr<(WIDE != 0)>(cu.c.in));
                     }
 #pragma unroll
                     for (int ps = 0; ps < kMaxPass; ++ps)
@@ -767,10 +790,15 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
     // a lane's four frames x two channels: 32 contiguous bytes, or (WIDE) 8 bytes in each of four frames
     auto store_frames = [&](g_f32_ptr o, const v4f& lo, const v4f& hi) {
         if constexpr (WIDE) {
-            *((g_f2_ptr)o) = v2f{lo.x, lo.y};
-            *((g_f2_ptr)(o + fs)) = v2f{lo.z, lo.w};
-            *((g_f2_ptr)(o + 2 * fs)) = v2f{hi.x, hi.y};
-            *((g_f2_ptr)(o + 3 * fs)) = v2f{hi.z, hi.w};
+            if (mono) {   // four frames of the one channel
+                typedef v4f __attribute__((address_space(1), aligned(4)))* g_f4a4_ptr;
+                *((g_f4a4_ptr)o) = v4f{lo.x, lo.z, hi.x, hi.z};
+            } else {
+                *((g_f2_ptr)o) = v2f{lo.x, lo.y};
+                *((g_f2_ptr)(o + fs)) = v2f{lo.z, lo.w};
+                *((g_f2_ptr)(o + 2 * fs)) = v2f{hi.x, hi.y};
+                *((g_f2_ptr)(o + 3 * fs)) = v2f{hi.z, hi.w};
+            }
         } else {
             typedef v4f __attribute__((address_space(1), aligned(8)))* g_f4a8_ptr;
             ((g_f4a8_ptr)o)[0] = lo;
@@ -784,9 +812,9 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
         }
     };
     Cursor cu;
-    cu.template init<WIDE>(g, item_begin);
+    cu.template init<(WIDE != 0)>(g, item_begin);
     uint32_t item;
-    while (cu.template next<WIDE>(g, descs, item_end, item)) {
+    while (cu.template next<(WIDE != 0)>(g, descs, item_end, item)) {
         const StreamCtx& d = cu.c;
         Item it;
         it.q0 = cu.q0;
@@ -885,7 +913,7 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
         const int32_t n_limit = static_cast<int32_t>(d.n_out);
         // a non-finite sum (inf / NaN sample, or one too large for the 16-bit planes): the chunk is redone
         // in the reference's form by the repair launch
-        nf_mark(g.nf, nf_is_bad(acc0.x + acc1.x), d.sidx, n0, 4, n_limit);
+        nf_mark(g.nf, nf_is_bad(mono ? acc0.x : acc0.x + acc1.x), d.sidx, n0, 4, n_limit);
         g_f32_ptr o = (g_f32_ptr)d.out + static_cast<int64_t>(n0) * fs + (WIDE ? 2 * cu.cur_pair : 0u);
         const v4f lo = v4f{acc0.x, acc1.x, acc0.y, acc1.y};
         const v4f hi = v4f{acc0.z, acc1.z, acc0.w, acc1.w};
@@ -919,7 +947,10 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int32_t n = n0 + r;
-                    if (j0 + r < g.b && n >= 0 && n < n_limit) *((g_f2_ptr)(o + fs * r)) = v2f{v[2 * r], v[2 * r + 1]};
+                    if (j0 + r < g.b && n >= 0 && n < n_limit) {
+                        if (mono) o[r] = v[2 * r];
+                        else *((g_f2_ptr)(o + fs * r)) = v2f{v[2 * r], v[2 * r + 1]};
+                    }
                 }
             }
         }
@@ -959,7 +990,7 @@ PeriodicGeometry split_geometry(uint64_t num, uint64_t den, uint32_t taps, uint3
     // two channels, or (RSMP_FIR_SPLIT_WIDE=0 turns it off) an even number up to 16 taken as channel pairs, two pairs per
     // 16-byte load (6, 10, 14 channels: the last pair alone -- its load reaches 8 bytes into the next frame)
     static const bool wide_ok = [] { const char* e = getenv("RSMP_FIR_SPLIT_WIDE"); return !e || atoi(e) != 0; }();
-    if (channels != 2 && (channels % 2 != 0 || channels > 16 || !wide_ok)) return g;
+    if (channels != 2 && ((channels % 2 != 0 && channels != 1) || channels > 16 || !wide_ok)) return g;
     if (num == 0 || num > 4096 || den < 16 || den > 16 * kConsumers) return g;
     const uint32_t a = static_cast<uint32_t>(num), b = static_cast<uint32_t>(den);
     const uint32_t n_tiles = (b + 15) / 16;
@@ -991,8 +1022,8 @@ PeriodicGeometry split_geometry(uint64_t num, uint64_t den, uint32_t taps, uint3
     g.row_len = kpad;
     g.n_tiles = n_tiles;
     g.n_units = n_tiles;
-    g.cg = 2;
-    g.lp = channels / 2;       // channel pairs of a frame (an item of the launch = one pair of a block)
+    g.cg = channels == 1 ? 1 : 2;   // (1: one channel, taken as a pair with a phantom second channel)
+    g.lp = (channels + 1) / 2;      // channel pairs of a frame (an item of the launch = one pair of a block)
     g.pw = 16;
     g.row_stride = rows;       // rows of an image (frames of a period + window reach)
     g.waves = kWaves;
@@ -1067,20 +1098,24 @@ hipError_t launch_fir_split(const FirStreamDesc* d_descs, uint32_t n_streams, co
         return e ? static_cast<uint32_t>(atoi(e)) : 0u;
     }();
     const uint32_t pairs = geo.lp;
-    const bool wide = pairs > 1;
+    const bool wide = pairs > 1 || geo.cg == 1;
     SplitArgs args{geo.a, geo.b, geo.taps, geo.n_tiles, geo.row_stride, geo.images, geo.lds_bytes, max_blocks, max_blocks * n_streams * pairs,
-                   debug, n_streams, fuse_tail ? 1u : 0u, 2 * pairs, pairs, nullptr, nf};
+                   debug, n_streams, fuse_tail ? 1u : 0u, geo.cg == 1 ? 1u : 2 * pairs, pairs, nullptr, nf};
     static const char* wtrace_path = getenv("RSMP_FIR_WTRACE");
     const bool diag = debug != 0 || wtrace_path != nullptr;
 #define RSMP_SPLIT_FNS(P, D, W)                                                                              \
     {reinterpret_cast<const void*>(fir_split_kernel<1, P, D, W>), reinterpret_cast<const void*>(fir_split_kernel<2, P, D, W>), \
      reinterpret_cast<const void*>(fir_split_kernel<3, P, D, W>), reinterpret_cast<const void*>(fir_split_kernel<4, P, D, W>), \
      reinterpret_cast<const void*>(fir_split_kernel<5, P, D, W>)}
-    static const void* const fns_all[2][2][5] = {{RSMP_SPLIT_FNS(2, false, false), RSMP_SPLIT_FNS(2, true, false)},
-                                                 {RSMP_SPLIT_FNS(3, false, false), RSMP_SPLIT_FNS(3, true, false)}};
-    static const void* const fns_wide[2][5] = {RSMP_SPLIT_FNS(2, false, true), RSMP_SPLIT_FNS(3, false, true)};   // (no diagnostic build)
+    static const void* const fns_all[2][2][5] = {{RSMP_SPLIT_FNS(2, false, 0), RSMP_SPLIT_FNS(2, true, 0)},
+                                                 {RSMP_SPLIT_FNS(3, false, 0), RSMP_SPLIT_FNS(3, true, 0)}};
+    static const void* const fns_wide[2][5] = {RSMP_SPLIT_FNS(2, false, 1), RSMP_SPLIT_FNS(3, false, 1)};   // (no diagnostic build)
+    static const void* const fns_mono[2][5] = {RSMP_SPLIT_FNS(2, false, 2), RSMP_SPLIT_FNS(3, false, 2)};
 #undef RSMP_SPLIT_FNS
-    const void* const* fns = wide ? fns_wide[geo.planes == 3 ? 1 : 0] : fns_all[geo.planes == 3 ? 1 : 0][diag ? 1 : 0];
+    const bool one_channel = geo.cg == 1;
+    const void* const* fns = one_channel ? fns_mono[geo.planes == 3 ? 1 : 0]
+                             : wide      ? fns_wide[geo.planes == 3 ? 1 : 0]
+                                         : fns_all[geo.planes == 3 ? 1 : 0][diag ? 1 : 0];
     const uint32_t nk = geo.row_len / 32;
     if (nk < 1 || nk > 5) return hipErrorInvalidValue;
     int device = 0;
@@ -1090,7 +1125,7 @@ hipError_t launch_fir_split(const FirStreamDesc* d_descs, uint32_t n_streams, co
     static std::map<std::pair<int, uint32_t>, bool> granted;
     {
         std::lock_guard<std::mutex> lock(mu);
-        bool& have = granted[{device, ((nk * 8 + geo.planes) * 2 + (diag && !wide ? 1u : 0u)) * 2 + (wide ? 1u : 0u)}];
+        bool& have = granted[{device, ((nk * 8 + geo.planes) * 2 + (diag && !wide ? 1u : 0u)) * 4 + (one_channel ? 2u : wide ? 1u : 0u)}];
         if (!have) {
             e = hipFuncSetAttribute(fns[nk - 1], hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit);
             if (e != hipSuccess) return e;
