@@ -362,7 +362,7 @@ __device__ __forceinline__ uint32_t consumer_index(uint32_t w) { return w < 6 ? 
 // 8 bytes per frame; everything between the loads and the stores is the two-channel kernel.  The wrap-only
 // producer and the stagers are separate instantiations of the staging loop (ROLE), so that neither pays for the
 // other's registers (two wrap passes against one + the 40 registers of a stager's loads).
-template <int NK, int PLANES, bool DIAG, int WIDE>   // WIDE: 0 two channels, 1 channel pairs, 2 one channel
+template <int NK, int PLANES, bool DIAG, int WIDE>   // WIDE: 0 two channels, 1 channel pairs, 2 one channel, 3 pairs + a last channel alone
 __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __restrict__ descs,
                                                          const SplitArgs g) {
     constexpr uint32_t kRowBytes = row_bytes(PLANES);
@@ -371,6 +371,11 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
     // One channel: a pair whose second channel is a phantom -- the loads take the following frame's sample for it, its
     // sums are computed and dropped (half the matrix work of a pair is waste: still faster than the vector kernel).
     constexpr bool mono = WIDE == 2;
+    // WIDE == 3, an odd channel count: the last pair is the last channel + a phantom (the next frame's first channel is
+    // what the loads deliver for it; its sums are dropped); pointers into such frames are only 4-byte aligned.
+    constexpr bool kOdd = WIDE == 3;
+    auto phantom = [&](uint32_t pair) { return kOdd && pair + 1 == g.pairs; };
+    typedef v2f __attribute__((address_space(1), aligned(4)))* g_f2u_ptr;
     const uint32_t dbg = DIAG ? g.debug : 0u;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     uint32_t* ctrl = reinterpret_cast<uint32_t*>(lds);
@@ -461,7 +466,11 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
             v2f v;
             if constexpr (WIDE) {
                 if (mono) v = v2f{fc < hf ? ((gconst_f32_ptr)c.hist)[fc] : ((gconst_f32_ptr)c.in)[fc - hf], 0.f};
-                else v = fc < hf ? *(gconst_f2_ptr)(c.hist + fc * fs + 2 * pair) : *(gconst_f2_ptr)(c.in + (fc - hf) * fs + 2 * pair);
+                else if (phantom(pair)) v = v2f{fc < hf ? ((gconst_f32_ptr)c.hist)[fc * fs + 2 * pair] : ((gconst_f32_ptr)c.in)[(fc - hf) * fs + 2 * pair], 0.f};
+                else if constexpr (kOdd) {
+                    typedef const v2f __attribute__((address_space(1), aligned(4)))* gconst_f2u_ptr;
+                    v = fc < hf ? *(gconst_f2u_ptr)(c.hist + fc * fs + 2 * pair) : *(gconst_f2u_ptr)(c.in + (fc - hf) * fs + 2 * pair);
+                } else v = fc < hf ? *(gconst_f2_ptr)(c.hist + fc * fs + 2 * pair) : *(gconst_f2_ptr)(c.in + (fc - hf) * fs + 2 * pair);
             }
             else v = fc < hf ? ((gconst_f2_ptr)c.hist)[fc] : ((gconst_f2_ptr)c.in)[fc - hf];
             if (!ok) v = v2f{0.f, 0.f};
@@ -785,12 +794,23 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
     // a divergent store path inside the stream would issue MFMAs under a partial EXEC mask.
     v4f pend_lo = v4f{0.f, 0.f, 0.f, 0.f}, pend_hi = v4f{0.f, 0.f, 0.f, 0.f};
     g_f32_ptr pend_o = nullptr;
+    bool pend_ph = false;   // WIDE == 3: the pending sums are the last channel's
     bool pend = false;
     typedef v2f __attribute__((address_space(1)))* g_f2_ptr;
     // a lane's four frames x two channels: 32 contiguous bytes, or (WIDE) 8 bytes in each of four frames
-    auto store_frames = [&](g_f32_ptr o, const v4f& lo, const v4f& hi) {
+    auto store_frames = [&](g_f32_ptr o, const v4f& lo, const v4f& hi, bool ph) {
         if constexpr (WIDE) {
-            if (mono) {   // four frames of the one channel
+            if (kOdd && ph) {   // the last channel alone: one value per frame
+                o[0] = lo.x;
+                o[fs] = lo.z;
+                o[2 * fs] = hi.x;
+                o[3 * fs] = hi.z;
+            } else if constexpr (kOdd) {
+                *((g_f2u_ptr)o) = v2f{lo.x, lo.y};
+                *((g_f2u_ptr)(o + fs)) = v2f{lo.z, lo.w};
+                *((g_f2u_ptr)(o + 2 * fs)) = v2f{hi.x, hi.y};
+                *((g_f2u_ptr)(o + 3 * fs)) = v2f{hi.z, hi.w};
+            } else if (mono) {   // four frames of the one channel
                 typedef v4f __attribute__((address_space(1), aligned(4)))* g_f4a4_ptr;
                 *((g_f4a4_ptr)o) = v4f{lo.x, lo.z, hi.x, hi.z};
             } else {
@@ -807,7 +827,7 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
     };
     auto flush_pending = [&]() {
         if (pend) {   // wave-uniform
-            store_frames(pend_o, pend_lo, pend_hi);
+            store_frames(pend_o, pend_lo, pend_hi, pend_ph);
             pend = false;
         }
     };
@@ -913,7 +933,7 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
         const int32_t n_limit = static_cast<int32_t>(d.n_out);
         // a non-finite sum (inf / NaN sample, or one too large for the 16-bit planes): the chunk is redone
         // in the reference's form by the repair launch
-        nf_mark(g.nf, nf_is_bad(mono ? acc0.x : acc0.x + acc1.x), d.sidx, n0, 4, n_limit);
+        nf_mark(g.nf, nf_is_bad(mono || phantom(cu.cur_pair) ? acc0.x : acc0.x + acc1.x), d.sidx, n0, 4, n_limit);
         g_f32_ptr o = (g_f32_ptr)d.out + static_cast<int64_t>(n0) * fs + (WIDE ? 2 * cu.cur_pair : 0u);
         const v4f lo = v4f{acc0.x, acc1.x, acc0.y, acc1.y};
         const v4f hi = v4f{acc0.z, acc1.z, acc0.w, acc1.w};
@@ -922,8 +942,10 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
             bool combined = false;
             if constexpr (WIDE) {
                 // the odd pair of a block whose even pair is pending: four channels of a frame side by side, 16-byte stores
-                if ((cu.cur_pair & 1u) && pend && pend_o + 2 == o && __all(full)) {
-                    typedef v4f __attribute__((address_space(1), aligned(8)))* g_f4a8_ptr;
+                if ((cu.cur_pair & 1u) && pend && pend_o + 2 == o && __all(full) && !phantom(cu.cur_pair)) {
+                    typedef v4f __attribute__((address_space(1), aligned(4)))* g_f4a4_ptr;
+                    typedef v4f __attribute__((address_space(1), aligned(8)))* g_f4a8e_ptr;
+                    typedef typename std::conditional<kOdd, g_f4a4_ptr, g_f4a8e_ptr>::type g_f4a8_ptr;
                     *((g_f4a8_ptr)pend_o) = v4f{pend_lo.x, pend_lo.y, lo.x, lo.y};
                     *((g_f4a8_ptr)(pend_o + fs)) = v4f{pend_lo.z, pend_lo.w, lo.z, lo.w};
                     *((g_f4a8_ptr)(pend_o + 2 * fs)) = v4f{pend_hi.x, pend_hi.y, hi.x, hi.y};
@@ -939,9 +961,10 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
                 pend_lo = lo;
                 pend_hi = hi;
                 pend_o = o;
+                pend_ph = phantom(cu.cur_pair);
                 pend = true;
             } else if (full) {
-                store_frames(o, lo, hi);
+                store_frames(o, lo, hi, phantom(cu.cur_pair));
             } else {
                 const float v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
 #pragma unroll
@@ -949,6 +972,8 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
                     const int32_t n = n0 + r;
                     if (j0 + r < g.b && n >= 0 && n < n_limit) {
                         if (mono) o[r] = v[2 * r];
+                        else if (phantom(cu.cur_pair)) o[fs * r] = v[2 * r];
+                        else if constexpr (kOdd) *((g_f2u_ptr)(o + fs * r)) = v2f{v[2 * r], v[2 * r + 1]};
                         else *((g_f2_ptr)(o + fs * r)) = v2f{v[2 * r], v[2 * r + 1]};
                     }
                 }
@@ -990,7 +1015,7 @@ PeriodicGeometry split_geometry(uint64_t num, uint64_t den, uint32_t taps, uint3
     // two channels, or (RSMP_FIR_SPLIT_WIDE=0 turns it off) an even number up to 16 taken as channel pairs, two pairs per
     // 16-byte load (6, 10, 14 channels: the last pair alone -- its load reaches 8 bytes into the next frame)
     static const bool wide_ok = [] { const char* e = getenv("RSMP_FIR_SPLIT_WIDE"); return !e || atoi(e) != 0; }();
-    if (channels != 2 && ((channels % 2 != 0 && channels != 1) || channels > 16 || !wide_ok)) return g;
+    if (channels != 2 && (channels > 16 || !wide_ok)) return g;
     if (num == 0 || num > 4096 || den < 16 || den > 16 * kConsumers) return g;
     const uint32_t a = static_cast<uint32_t>(num), b = static_cast<uint32_t>(den);
     const uint32_t n_tiles = (b + 15) / 16;
@@ -1022,7 +1047,7 @@ PeriodicGeometry split_geometry(uint64_t num, uint64_t den, uint32_t taps, uint3
     g.row_len = kpad;
     g.n_tiles = n_tiles;
     g.n_units = n_tiles;
-    g.cg = channels == 1 ? 1 : 2;   // (1: one channel, taken as a pair with a phantom second channel)
+    g.cg = channels == 1 ? 1 : (channels % 2 ? 3 : 2);   // (1: one channel, a pair with a phantom second channel; 3: odd count, the last pair likewise)
     g.lp = (channels + 1) / 2;      // channel pairs of a frame (an item of the launch = one pair of a block)
     g.pw = 16;
     g.row_stride = rows;       // rows of an image (frames of a period + window reach)
@@ -1100,7 +1125,7 @@ hipError_t launch_fir_split(const FirStreamDesc* d_descs, uint32_t n_streams, co
     const uint32_t pairs = geo.lp;
     const bool wide = pairs > 1 || geo.cg == 1;
     SplitArgs args{geo.a, geo.b, geo.taps, geo.n_tiles, geo.row_stride, geo.images, geo.lds_bytes, max_blocks, max_blocks * n_streams * pairs,
-                   debug, n_streams, fuse_tail ? 1u : 0u, geo.cg == 1 ? 1u : 2 * pairs, pairs, nullptr, nf};
+                   debug, n_streams, fuse_tail ? 1u : 0u, geo.cg == 1 ? 1u : (geo.cg == 3 ? 2 * pairs - 1 : 2 * pairs), pairs, nullptr, nf};
     static const char* wtrace_path = getenv("RSMP_FIR_WTRACE");
     const bool diag = debug != 0 || wtrace_path != nullptr;
 #define RSMP_SPLIT_FNS(P, D, W)                                                                              \
@@ -1111,9 +1136,12 @@ hipError_t launch_fir_split(const FirStreamDesc* d_descs, uint32_t n_streams, co
                                                  {RSMP_SPLIT_FNS(3, false, 0), RSMP_SPLIT_FNS(3, true, 0)}};
     static const void* const fns_wide[2][5] = {RSMP_SPLIT_FNS(2, false, 1), RSMP_SPLIT_FNS(3, false, 1)};   // (no diagnostic build)
     static const void* const fns_mono[2][5] = {RSMP_SPLIT_FNS(2, false, 2), RSMP_SPLIT_FNS(3, false, 2)};
+    static const void* const fns_odd[2][5] = {RSMP_SPLIT_FNS(2, false, 3), RSMP_SPLIT_FNS(3, false, 3)};
 #undef RSMP_SPLIT_FNS
     const bool one_channel = geo.cg == 1;
+    const bool odd_count = geo.cg == 3;
     const void* const* fns = one_channel ? fns_mono[geo.planes == 3 ? 1 : 0]
+                             : odd_count ? fns_odd[geo.planes == 3 ? 1 : 0]
                              : wide      ? fns_wide[geo.planes == 3 ? 1 : 0]
                                          : fns_all[geo.planes == 3 ? 1 : 0][diag ? 1 : 0];
     const uint32_t nk = geo.row_len / 32;
@@ -1125,7 +1153,7 @@ hipError_t launch_fir_split(const FirStreamDesc* d_descs, uint32_t n_streams, co
     static std::map<std::pair<int, uint32_t>, bool> granted;
     {
         std::lock_guard<std::mutex> lock(mu);
-        bool& have = granted[{device, ((nk * 8 + geo.planes) * 2 + (diag && !wide ? 1u : 0u)) * 4 + (one_channel ? 2u : wide ? 1u : 0u)}];
+        bool& have = granted[{device, ((nk * 8 + geo.planes) * 2 + (diag && !wide ? 1u : 0u)) * 4 + (one_channel ? 2u : odd_count ? 3u : wide ? 1u : 0u)}];
         if (!have) {
             e = hipFuncSetAttribute(fns[nk - 1], hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit);
             if (e != hipSuccess) return e;

@@ -141,7 +141,7 @@ def test_bulk_matches_reference_driver_loop(kernel, ch, in_hz, out_hz, att):
     yg2, _ = g.resample_bulk(x2[ch * 3000:], chunk)
     yr2, _ = r.resample_all(x2[ch * 3000:], chunk)
     assert yg2.size == yr2.size and rms(yg2, yr2) <= RMS_TOL
-    if (kernel == ra.FirKernel.Periodic and ch in (1, 2, 4, 6, 8, 12, 16) and {in_hz, out_hz} == {44100, 48000}
+    if (kernel == ra.FirKernel.Periodic and ch in (1, 2, 3, 4, 6, 8, 12, 16) and {in_hz, out_hz} == {44100, 48000}
             and os.environ.get("RSMP_FIR_MFMA", "3") == "3" and os.environ.get("RSMP_FIR_SPLIT_WIDE", "1") != "0"):
         assert g.kernel_variant() == SPLIT_VARIANT
     if kernel == ra.FirKernel.PeriodicVector:
@@ -152,7 +152,8 @@ def test_bulk_matches_reference_driver_loop(kernel, ch, in_hz, out_hz, att):
         assert g.kernel_variant() == 0
 
 
-@pytest.mark.parametrize("ch,in_hz,out_hz", [(4, 44100, 48000), (8, 48000, 44100), (6, 44100, 48000), (1, 48000, 44100)])
+@pytest.mark.parametrize("ch,in_hz,out_hz", [(4, 44100, 48000), (8, 48000, 44100), (6, 44100, 48000), (1, 48000, 44100), (3, 44100, 48000),
+                                             (5, 48000, 44100)])
 def test_split_kernel_channel_pairs_long_stream(ch, in_hz, out_hz):
     """4 / 8 channels at 147/160 on the split matrix kernel (an item = one channel pair of a block): a stream long
     enough that a workgroup gets both pairs of a block (16-byte loads shared by two items, the even pair's sums
