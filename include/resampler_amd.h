@@ -52,7 +52,7 @@ enum { RSMP_ATTENUATION_DB60 = 0, RSMP_ATTENUATION_DB90, RSMP_ATTENUATION_DB120 
  * on the matrix cores where the geometry allows: the split kernel (every f32 operand as the sum
  * of two fp16 values of the scaled operand, three fp16 MFMA products accumulated in f32; RSMP_FIR_SPLIT_PLANES=3
  * selects three bf16 planes / six products, exact in every bit) for rate pairs with
- * 16..160 classes such as 44.1 <-> 48 kHz and 1, 2, 4, 6 .. 16 channels (channel pairs), the exact-f32 MFMA
+ * 16..160 classes such as 44.1 <-> 48 kHz and 1 .. 16 channels (channel pairs), the exact-f32 MFMA
  * kernel for other 2-channel geometries, the vector kernel otherwise.  PERIODIC_F32 keeps
  * every product in f32 (exact-f32 MFMA or vector kernels, never the split one); PERIODIC_VECTOR forces
  * the packed-FMA vector kernel for every channel count.  All produce the same results within the
