@@ -314,6 +314,41 @@ def fir_kernel_point(ctx: Ctx, ra, args, kernel, steps: int):
             "Msamples_in_per_s_kernel": round(S * CHANNELS * N / (k_ms * 1e-3) / 1e6, 1)}
 
 
+def fir_channels_point(ctx: Ctx, ra, args, channels: int, steps: int):
+    """Kernel time / roofline fraction of the default FIR kernel for another channel count: the headline's rate pair
+    and taps, 128 / channels streams x `--frames` frames per launch (the split matrix kernel on channel pairs)."""
+    from resampler_amd import synth
+    torch = ctx.torch
+    S, N = max(1, 128 // channels), args.frames
+    handles = [ra.ResamplerFir.new(channels, ra.SampleRate.Hz44100, ra.SampleRate.Hz48000, ra.Latency.Sample64,
+                                   ra.Attenuation.Db90, device=ctx.local_rank) for _ in range(S)]
+    x = torch.from_numpy(synth.fast_noise(N * channels, seed=7)).to(ctx.dev)
+    chunk = 512 * channels
+    cap = handles[0].bulk_output_bound(channels * N, chunk)
+    d_out = [torch.empty(cap, device=ctx.dev, dtype=torch.float32) for _ in range(S)]
+    batch = ra.FirBatch(handles)
+    batch.bind([x for _ in range(S)], d_out)
+
+    def step():
+        batch.reset()
+        return batch.resample_bulk_device(chunk, ctx.stream)
+    consumed, produced = step()
+    out_values = int(sum(produced))
+    spinup(ctx, step, 0.3)
+    handles[0].set_profiling(True)
+    for _ in range(steps):
+        step()
+    k_ms, _ = handles[0].mean_kernel_ms()
+    handles[0].set_profiling(False)
+    alg = 4.0 * (S * channels * N + out_values) + 4.0 * 1024 * 128
+    ach = alg / (k_ms * 1e-3) / 1e9
+    point = {"kernel": KERNEL_NAMES.get(handles[0].kernel_variant(), "?"), "streams": S, "kernel_ms": round(k_ms, 4),
+             "achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4),
+             "Msamples_in_per_s_kernel": round(S * channels * N / (k_ms * 1e-3) / 1e6, 1)}
+    del batch, handles
+    return point
+
+
 def bench_fft(ctx: Ctx, args, steps: int, warmup: int, with_cpu: bool):
     """ResamplerFft 2 ch 44.1k -> 48k (BASELINE config 3): a batch of `--streams` streams x 892 blocks
     of 1176 frames per step, one launch of the overlap-add FFT kernel."""
@@ -557,6 +592,8 @@ def secondary_lines(ctx: Ctx, args):
                   "roofline": fft["roofline"], "cpu_baseline": fft.get("cpu_baseline")}
     sec["fir_exact_f32"] = fir_kernel_point(ctx, ra, args, ra.FirKernel.PeriodicF32, 16)
     sec["fir_vector_no_mfma"] = fir_kernel_point(ctx, ra, args, ra.FirKernel.PeriodicVector, 16)
+    # other channel counts on the default kernel (same rate pair and taps)
+    sec["fir_channels"] = {str(c): fir_channels_point(ctx, ra, args, c, 8) for c in (1, 4, 8)}
     # the same launch with every stream in a different state: nothing shares a plan
     t0 = time.perf_counter()
     handles, batch = make_fir_batch(ctx, ra, args.streams, args.frames, args.chunk, ra.FirKernel.Auto,
