@@ -513,7 +513,7 @@ constexpr int wave_group_threads(int occ) { return occ == 3 ? 768 : occ == 2 ? 2
 // Both transforms above 2048 points (88.2 <-> 96 kHz): four or five trips per stage in registers next to the
 // carry do not fit 256 registers -- these pairs run one wave per SIMD with the full register file instead of two
 // that spill (88.2 -> 96 kHz: 0.94 -> 0.76 ms).
-template <class FWD, class INV> constexpr bool kOneWavePerSimd = FWD::N > 2048 && INV::N > 2048;
+template <class FWD, class INV> constexpr bool kOneWavePerSimd = (FWD::N > 2048 && INV::N > 2048) || FWD::N > 2560 || INV::N > 2560;
 template <class FWD, class INV, bool C2, int OCC>
 __global__ __launch_bounds__((OCC == 1 && kOneWavePerSimd<FWD, INV> ? 256 : wave_group_threads(OCC)),
                              (OCC == 1 ? (kOneWavePerSimd<FWD, INV> ? 1 : 2) : OCC)) void fft_ola_wave_kernel(FftPlanDev plan,
@@ -731,6 +731,9 @@ typedef WavePlan<64, 8, 8> W64;
 typedef WavePlan<768, 3, 4, 8, 8> W768;
 typedef WavePlan<1536, 3, 8, 8, 8> W1536;
 typedef WavePlan<2048, 4, 8, 8, 8> W2048;
+typedef WavePlan<3072, 2, 3, 8, 8, 8> W3072;   // (x6: six trips per stage -- one wave per SIMD with the whole register file)
+typedef WavePlan<4096, 8, 8, 8, 8> W4096;      // (x8: three waves per CU are all the LDS holds)
+typedef WavePlan<3528, 3, 3, 7, 7, 8> W3528;   // 88.2 kHz against the 16 / 32 kHz families
 typedef WavePlan<588, 3, 4, 7, 7> W588;     // 22.05 kHz against the 48 kHz family (input side: the inverse's last radix must be even)
 typedef WavePlan<882, 2, 3, 3, 7, 7> W882;
 typedef WavePlan<1764, 3, 3, 4, 7, 7> W1764;
@@ -762,7 +765,12 @@ bool wave_choice(const FftPlanDev& plan, uint32_t channels, int occ_env, WaveCho
     constexpr bool fit12 = tables + 12 * buf <= kCu, fit4 = 2 * (tables + 4 * buf) <= kCu;
     constexpr uint32_t wide_fit = (kCu - tables) / buf < 8 ? static_cast<uint32_t>((kCu - tables) / buf) : 8u;
     constexpr uint32_t wide = kOneWavePerSimd<FWD, INV> && wide_fit > 4 ? 4u : wide_fit;
-    static_assert(fit4 || wide >= 4, "a plan this long belongs to the workgroup kernels");
+    // (fewer than three waves per CU -- the longest plans in the exact build, whose twiddle rows are whole -- belong to
+    // the workgroup kernels)
+    if constexpr (!fit4 && wide < 3) {
+        (void)channels; (void)occ_env; (void)out;
+        return false;
+    } else {
     static const bool no_c2 = getenv("RSMP_FFT_WAVE_NOC2") != nullptr;   // A/B: the any-channel-count build for two channels
     int occ = channels == 2 && !no_c2 ? (fit12 ? 3 : fit4 ? 2 : 1) : (fit4 ? 2 : 1);
     if (channels == 2 && ((occ_env == 3 && fit12) || (occ_env == 2 && fit4))) occ = occ_env;
@@ -781,6 +789,7 @@ bool wave_choice(const FftPlanDev& plan, uint32_t channels, int occ_env, WaveCho
     out->resident = occ == 2 ? 8u : out->waves;
     out->lds = (tables + out->waves * buf) * sizeof(cf);
     return out->fn != nullptr;
+    }
 }
 template <class FWD, class... INVS>
 bool wave_choices(const FftPlanDev& plan, uint32_t channels, int occ_env, WaveChoice* out) {
@@ -802,14 +811,14 @@ hipError_t launch_fft_ola_wave(const FftPlanDev& plan, const FftStreamDesc* d_de
     static const int occ_env = [] { const char* e = getenv("RSMP_FFT_WAVE_OCC"); return e ? atoi(e) : 0; }();
     WaveChoice wc;
     const bool found = wave_choices<W1176, W1280>(plan, C, occ_env, &wc) || wave_choices<W1280, W1176>(plan, C, occ_env, &wc) ||
-                       wave_choices<W512, W64, W128, W256, W768, W1024, W1536, W2048>(plan, C, occ_env, &wc) ||
+                       wave_choices<W512, W64, W128, W256, W768, W1024, W1536, W2048, W3072, W4096>(plan, C, occ_env, &wc) ||
                        wave_choices<W768, W64, W128, W256, W512>(plan, C, occ_env, &wc) ||
                        wave_choices<W1536, W64, W128>(plan, C, occ_env, &wc) ||
                        wave_choices<W588, W1280, W2560>(plan, C, occ_env, &wc) || wave_choices<W882, W640, W1280>(plan, C, occ_env, &wc) ||
                        wave_choices<W1764, W640, W1280>(plan, C, occ_env, &wc) || wave_choices<W2352, W1280, W2560>(plan, C, occ_env, &wc) ||
                        wave_choice<W1176, W2560>(plan, C, occ_env, &wc) || wave_choice<W1280, W2352>(plan, C, occ_env, &wc) ||
-                       wave_choices<W2560, W2352, W1176, W588>(plan, C, occ_env, &wc) || wave_choices<W640, W882, W1764>(plan, C, occ_env, &wc) ||
-                       wave_choices<W1280, W588, W882, W1764>(plan, C, occ_env, &wc);
+                       wave_choices<W2560, W2352, W1176, W588>(plan, C, occ_env, &wc) || wave_choices<W640, W882, W1764, W3528>(plan, C, occ_env, &wc) || wave_choices<W3528, W640, W1280>(plan, C, occ_env, &wc) ||
+                       wave_choices<W1280, W588, W882, W1764, W3528>(plan, C, occ_env, &wc);
     if (!found) return hipErrorNotSupported;
     const uint32_t kWavesPerGroup = wc.waves;
     const size_t lds = wc.lds;
