@@ -734,6 +734,8 @@ typedef WavePlan<2048, 4, 8, 8, 8> W2048;
 typedef WavePlan<3072, 2, 3, 8, 8, 8> W3072;   // (x6: six trips per stage -- one wave per SIMD with the whole register file)
 typedef WavePlan<4096, 8, 8, 8, 8> W4096;      // (x8: three waves per CU are all the LDS holds)
 typedef WavePlan<3528, 3, 3, 7, 7, 8> W3528;   // 88.2 kHz against the 16 / 32 kHz families
+typedef WavePlan<4704, 3, 4, 7, 7, 8> W4704;   // 176.4 kHz (two waves per CU)
+typedef WavePlan<5120, 2, 5, 8, 8, 8> W5120;   // 192 kHz
 typedef WavePlan<588, 3, 4, 7, 7> W588;     // 22.05 kHz against the 48 kHz family (input side: the inverse's last radix must be even)
 typedef WavePlan<882, 2, 3, 3, 7, 7> W882;
 typedef WavePlan<1764, 3, 3, 4, 7, 7> W1764;
@@ -765,9 +767,9 @@ bool wave_choice(const FftPlanDev& plan, uint32_t channels, int occ_env, WaveCho
     constexpr bool fit12 = tables + 12 * buf <= kCu, fit4 = 2 * (tables + 4 * buf) <= kCu;
     constexpr uint32_t wide_fit = (kCu - tables) / buf < 8 ? static_cast<uint32_t>((kCu - tables) / buf) : 8u;
     constexpr uint32_t wide = kOneWavePerSimd<FWD, INV> && wide_fit > 4 ? 4u : wide_fit;
-    // (fewer than three waves per CU -- the longest plans in the exact build, whose twiddle rows are whole -- belong to
+    // (fewer than two waves per CU -- the longest plans in the exact build, whose twiddle rows are whole -- belong to
     // the workgroup kernels)
-    if constexpr (!fit4 && wide < 3) {
+    if constexpr (!fit4 && wide < 2) {
         (void)channels; (void)occ_env; (void)out;
         return false;
     } else {
@@ -818,7 +820,10 @@ hipError_t launch_fft_ola_wave(const FftPlanDev& plan, const FftStreamDesc* d_de
                        wave_choices<W1764, W640, W1280>(plan, C, occ_env, &wc) || wave_choices<W2352, W1280, W2560>(plan, C, occ_env, &wc) ||
                        wave_choice<W1176, W2560>(plan, C, occ_env, &wc) || wave_choice<W1280, W2352>(plan, C, occ_env, &wc) ||
                        wave_choices<W2560, W2352, W1176, W588>(plan, C, occ_env, &wc) || wave_choices<W640, W882, W1764, W3528>(plan, C, occ_env, &wc) || wave_choices<W3528, W640, W1280>(plan, C, occ_env, &wc) ||
-                       wave_choices<W1280, W588, W882, W1764, W3528>(plan, C, occ_env, &wc);
+                       wave_choices<W1280, W588, W882, W1764, W3528, W4704>(plan, C, occ_env, &wc) ||
+                       wave_choices<W4704, W1280, W2560>(plan, C, occ_env, &wc) || wave_choices<W5120, W1176, W2352>(plan, C, occ_env, &wc) ||
+                       wave_choice<W2560, W4704>(plan, C, occ_env, &wc) || wave_choice<W1176, W5120>(plan, C, occ_env, &wc) ||
+                       wave_choice<W2352, W5120>(plan, C, occ_env, &wc) || wave_choice<W588, W5120>(plan, C, occ_env, &wc);
     if (!found) return hipErrorNotSupported;
     const uint32_t kWavesPerGroup = wc.waves;
     const size_t lds = wc.lds;
