@@ -523,6 +523,7 @@ __global__ __launch_bounds__((OCC == 1 && kOneWavePerSimd<FWD, INV> ? 256 : wave
     extern __shared__ __attribute__((aligned(16))) cf lds2[];
     const int kWavesPerGroup = OCC == 1 ? static_cast<int>(blockDim.x >> 6) : wave_group_threads(OCC) / 64;
     constexpr int FI = FWD::N, FO = INV::N;
+    constexpr int kFilterLen = FI < FO ? FI + 1 : FO;   // bins the filter multiplies (new_length): the rest of its spectrum stays in HBM
     constexpr int LDSC = FWD::kBuf > INV::kBuf ? FWD::kBuf : INV::kBuf;   // (+ the padding of a fused first pass or of a stage)
     constexpr int SF = FWD::kStages, SI = INV::kStages;
     // The last inverse stage keeps its outputs in registers where its radix is even: outputs q < RL / 2 of a butterfly
@@ -538,12 +539,12 @@ __global__ __launch_bounds__((OCC == 1 && kOneWavePerSimd<FWD, INV> ? 256 : wave
     const int lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t gw = blockIdx.x * kWavesPerGroup + wave;
-    // Every table of the plan (stage twiddles, real <-> complex twiddles, filter spectrum: 39 KB) is copied
+    // Every table of the plan (stage twiddles, real <-> complex twiddles, the filter bins in use: 29 KB) is copied
     // to LDS once per workgroup: the per-butterfly twiddle fetches were the kernel's main wait (48 % of the
     // wave time at s_waitcnt, vector-memory instructions in flight 4x the LDS ones).  The only barrier of
     // the kernel follows; after it the waves never meet again.
     constexpr int kTabF = 0, kTabI = kTabF + FWD::kTw, kTabRcF = kTabI + INV::kTw, kTabRcI = kTabRcF + FWD::kRc,
-                  kTabFilter = kTabRcI + INV::kRc, kTabEnd = kTabFilter + FI + 1;
+                  kTabFilter = kTabRcI + INV::kRc, kTabEnd = kTabFilter + kFilterLen;
     cf* tab = lds2;
     {
         auto copy = [&](cf* dst, const cf* __restrict__ src, int n) {
@@ -569,7 +570,7 @@ __global__ __launch_bounds__((OCC == 1 && kOneWavePerSimd<FWD, INV> ? 256 : wave
         stage_tables(tab + kTabI, reinterpret_cast<const cf*>(plan.tw_i), INV{});
         copy(tab + kTabRcF, reinterpret_cast<const cf*>(plan.rc_f), FWD::kRc);
         copy(tab + kTabRcI, reinterpret_cast<const cf*>(plan.rc_i), INV::kRc);
-        copy(tab + kTabFilter, reinterpret_cast<const cf*>(plan.filter), FI + 1);
+        copy(tab + kTabFilter, reinterpret_cast<const cf*>(plan.filter), kFilterLen);
     }
     __syncthreads();
     if (gw >= total_waves) return;
@@ -636,7 +637,7 @@ __global__ __launch_bounds__((OCC == 1 && kOneWavePerSimd<FWD, INV> ? 256 : wave
             wave_stage<FI, FWD::kR[s], FWD::stride(s), FI / FWD::kR[s] + FWD::in_pad(s), FWD::out_pad(s), FWD::in_period(s)>(buf, tw_f + FWD::tab(s), lane);
         });
         wave_postprocess<FI>(buf, rc_f, lane);
-        wave_filter_preprocess<FO, (FI < FO ? FI + 1 : FO), FI>(buf, filter, rc_i, lane);
+        wave_filter_preprocess<FO, kFilterLen, kFilterLen - 1>(buf, filter, rc_i, lane);
 
         // ---- inverse transform, in place; its last stage below
         {
@@ -761,7 +762,7 @@ template <class FWD, class INV>
 bool wave_choice(const FftPlanDev& plan, uint32_t channels, int occ_env, WaveChoice* out) {
     if (!FWD::matches(plan.fft_in, plan.n_stages_f, plan.radix_f) || !INV::matches(plan.fft_out, plan.n_stages_i, plan.radix_i))
         return false;
-    constexpr size_t tables = static_cast<size_t>(FWD::kTw + INV::kTw + FWD::kRc + INV::kRc + FWD::N + 1);
+    constexpr size_t tables = static_cast<size_t>(FWD::kTw + INV::kTw + FWD::kRc + INV::kRc + (FWD::N < INV::N ? FWD::N + 1 : INV::N));   // (+ the filter bins in use)
     constexpr size_t buf = FWD::kBuf > INV::kBuf ? FWD::kBuf : INV::kBuf;
     constexpr size_t kCu = 160 * 1024 / sizeof(cf);
     constexpr bool fit12 = tables + 12 * buf <= kCu, fit4 = 2 * (tables + 4 * buf) <= kCu;
