@@ -88,17 +88,30 @@ class Ctx:
         if self.world != max(1, args.gpus) and self.rank == 0:
             print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={self.world}; using WORLD_SIZE", file=sys.stderr)
         self.dist = None
-        if self.world > 1:
+        if self.world > 1 or getattr(args, "feed", "resident") == "rccl":
+            # (--feed rccl on one GPU: a world of one rank, so that RCCL's init, group launch and the ordering of
+            # its work against the resampling kernels run on whatever hardware there is)
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{self.local_rank}"))
+            if self.world == 1 and "MASTER_PORT" not in os.environ:
+                with socket.socket() as so:
+                    so.bind(("127.0.0.1", 0))
+                    os.environ["MASTER_PORT"] = str(so.getsockname()[1])
+            dist.init_process_group(backend="nccl", rank=self.rank, world_size=self.world,
+                                    device_id=torch.device(f"cuda:{self.local_rank}"))
             self.dist = dist
         import resampler_amd as ra
         if not torch.cuda.is_available() or ra.device_count() <= self.local_rank:
             raise SystemExit("bench.py needs a HIP device per rank (no CPU fallback)")
         torch.cuda.set_device(self.local_rank)
         self.dev = torch.device(f"cuda:{self.local_rank}")
-        self.stream = torch.cuda.current_stream().cuda_stream
+        # Everything this rank enqueues -- torch fills and copies, RCCL work (its handles block the CURRENT torch
+        # stream) and the library's launches -- goes to ONE non-default stream, so a step's stages are ordered by
+        # the stream itself.  (torch's default stream has handle 0, which the C ABI reads as "the handle's own
+        # non-blocking stream": launches there would be ordered against nothing torch does.)
+        self.torch_stream = torch.cuda.Stream(device=self.dev)
+        torch.cuda.set_stream(self.torch_stream)
+        self.stream = ra.torch_stream(self.torch_stream)
 
     def barrier(self):
         self.torch.cuda.synchronize()
@@ -323,11 +336,13 @@ def fir_channels_point(ctx: Ctx, ra, args, channels: int, steps: int):
     handles = [ra.ResamplerFir.new(channels, ra.SampleRate.Hz44100, ra.SampleRate.Hz48000, ra.Latency.Sample64,
                                    ra.Attenuation.Db90, device=ctx.local_rank) for _ in range(S)]
     x = torch.from_numpy(synth.fast_noise(N * channels, seed=7)).to(ctx.dev)
+    gains = torch.linspace(0.5, 1.0, S, device=ctx.dev)
+    d_in = [(x * gains[i]).contiguous() for i in range(S)]   # a buffer of its own per stream: every byte comes from HBM
     chunk = 512 * channels
     cap = handles[0].bulk_output_bound(channels * N, chunk)
     d_out = [torch.empty(cap, device=ctx.dev, dtype=torch.float32) for _ in range(S)]
     batch = ra.FirBatch(handles)
-    batch.bind([x for _ in range(S)], d_out)
+    batch.bind(d_in, d_out)
 
     def step():
         batch.reset()
@@ -425,7 +440,8 @@ def bench_c4(ctx: Ctx, args, steps: int, warmup: int):
         # a step's chunks arrive from GPU 0 and its outputs return there: the streams are bound straight
         # to their slices of the exchange buffers
         parts = sharding.partition([s.work() for s in specs], ctx.world)
-        feed = sharding.StepFeed(ctx.dist, ctx.rank, ctx.world, parts, [frames * CHANNELS] * n, caps_all, ctx.dev)
+        feed = sharding.StepFeed(ctx.dist, ctx.rank, ctx.world, parts, [frames * CHANNELS] * n, caps_all, ctx.dev,
+                                 loopback=(ctx.world == 1))
         stage_in = stage_out = None
         if ctx.rank == 0:
             stage_in = [torch.from_numpy(synth.fast_noise(n * frames * CHANNELS, seed=10 + j)).to(ctx.dev) for j in range(ring)]
@@ -483,8 +499,9 @@ def bench_c4(ctx: Ctx, args, steps: int, warmup: int):
                                f"(6 ordered), {frames}-frame lock-step steps on carried state, one launch per "
                                f"step and GPU, streams partitioned by predicted work",
                    "streams_this_rank": len(mine), "workgroups_this_rank": ls.workgroups() if ls else 0,
-                   "feed": "rccl send/recv scatter-v + gather-v through GPU 0, inside the timed step" if feed
-                           else "resident per GPU (no data-path collective)",
+                   "feed": ("rccl send/recv scatter-v + gather-v through GPU 0, inside the timed step"
+                            + (" (world of one rank: GPU 0 sends to and receives from itself)" if ctx.world == 1 else ""))
+                           if feed else "resident per GPU (no data-path collective)",
                    "host_enqueue_ms_per_step": round(host_dt / steps * 1e3, 5)},
         "roofline": {"bound": "hbm", "kernel": "fir_lockstep_kernel (%s, row = stream)" %
                                ("fp16x2 MFMA" if ls and ls.split_workgroups() else "exact-f32 MFMA"),

@@ -7,8 +7,11 @@
  * values across all channels exactly as in the reference (src/resampler_fir.rs:617-620).
  *
  * Pointers named `in`/`out` are HOST pointers; pointers named `d_in`/`d_out` are DEVICE (HBM)
- * pointers on the handle's device.  `stream` is a hipStream_t passed as void* (NULL = the
- * handle's own stream).  Device entry points are asynchronous on `stream`; the returned counts
+ * pointers on the handle's device.  `stream` is a hipStream_t passed as void*.  NULL = the handle's
+ * (or batch's) OWN stream, created hipStreamNonBlocking: work enqueued there is NOT ordered against
+ * the legacy default stream -- a caller whose buffers are produced / consumed on the default stream
+ * passes RSMP_STREAM_LEGACY (== hipStreamLegacy) instead, or a stream of its own and orders that.
+ * Device entry points are asynchronous on `stream`; the returned counts
  * are exact and available immediately (they come from the host-side mirror of the reference
  * state machine, not from the GPU).
  *
@@ -25,6 +28,9 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+
+/* The legacy default stream as a `stream` argument (the value of hipStreamLegacy); NULL does not mean it. */
+#define RSMP_STREAM_LEGACY ((void*)1)
 
 /* ---- status codes: 1 and 2 are ResampleError (src/error.rs:3-8) ------------------------------- */
 enum {
@@ -110,8 +116,10 @@ int rsmp_fir_last_kernel_ms(rsmp_fir* r, float* ms);
 int rsmp_fir_mean_kernel_ms(rsmp_fir* r, float* ms, size_t* launches);
 /* Which kernel the handle's last launch used (diagnostic, for benchmark reports): 0 generic
  * (any ratio), 1 periodic vector kernel, 2 periodic vector kernel with double-buffered
- * workgroups, 3 periodic exact-f32 matrix-core kernel, 4 periodic split-bf16 matrix-core kernel;
- * negative: invalid handle. */
+ * workgroups, 3 periodic exact-f32 matrix-core kernel, 4 periodic split matrix-core kernel with
+ * three bf16 planes per operand (RSMP_FIR_SPLIT_PLANES=3), 5 periodic split matrix-core kernel with
+ * two fp16 planes per operand (the default for rate pairs it has a geometry for); negative: invalid
+ * handle. */
 int rsmp_fir_kernel_variant(const rsmp_fir* r);
 
 /* ResamplerFir::resample (resampler_fir.rs:509-621): one call, host buffers, synchronous. */

@@ -64,7 +64,9 @@ size_t orc_interp_hermite(size_t channels, uint32_t in_hz, uint32_t out_hz, cons
  * pcm: little-endian samples of `bits` (16, 24 packed, 32); n_samples over all channels; out holds
  * n_samples values (stereo in) or 2 * n_samples (mono in).  Returns values written. */
 size_t orc_pcm_to_stereo_f32(const uint8_t* pcm, int bits, int channels, size_t n_samples, float* out) {
-    const float max_value = (float)((int64_t)1 << (bits - 1));
+    /* `(1 << (spec.bits_per_sample - 1)) as f32` (main.rs:131): an i32 literal, so bits == 32 gives
+     * 1i32 << 31 = i32::MIN = -2^31 and 32-bit samples come out with inverted polarity. */
+    const float max_value = bits == 32 ? -2147483648.0f : (float)((int32_t)1 << (bits - 1));
     size_t w = 0;
     for (size_t i = 0; i < n_samples; ++i) {
         int32_t s;

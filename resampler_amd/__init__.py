@@ -218,6 +218,18 @@ def device_count() -> int:
     return lib().rsmp_device_count()
 
 
+STREAM_LEGACY = 1   # RSMP_STREAM_LEGACY: the legacy default stream as a `stream` argument (None / 0 = the handle's own stream)
+
+
+def torch_stream(stream=None) -> int:
+    """The `stream` argument that makes a device entry point run on a torch stream (default: torch's current
+    one).  torch reports its default stream as handle 0, which at the C ABI means "the handle's own non-blocking
+    stream" -- work there is not ordered against torch's; this maps it to RSMP_STREAM_LEGACY."""
+    import torch
+    s = torch.cuda.current_stream() if stream is None else stream
+    return int(s.cuda_stream) or STREAM_LEGACY
+
+
 def _check(rc: int) -> None:
     if rc == RSMP_OK:
         return

@@ -68,7 +68,9 @@ __global__ __launch_bounds__(kThreads) void pcm_kernel(const uint8_t* __restrict
     } else {
         s = reinterpret_cast<const int32_t*>(pcm)[i];
     }
-    const float max_value = static_cast<float>(1ll << (BITS - 1));            // main.rs:131
+    // main.rs:131 `(1 << (bits_per_sample - 1)) as f32`: the literal is an i32, so 32-bit files divide by
+    // 1i32 << 31 = i32::MIN = -2^31 -- the reference decodes them with inverted polarity, and so does this.
+    const float max_value = BITS == 32 ? -2147483648.0f : static_cast<float>(1 << (BITS - 1));
     const float v = static_cast<float>(s) / max_value;
     if (mono) {                                                               // main.rs:141-146
         reinterpret_cast<float2*>(out)[i] = make_float2(v, v);

@@ -11,6 +11,7 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <unordered_set>
 #include <vector>
 
 #include "common.h"
@@ -131,6 +132,8 @@ struct rsmp_fft {
     float* d_overlap = nullptr;   // 2 x [channels][fft_out] (ping-pong per launch), zero at construction (:81)
     int cur = 0;
     hipStream_t stream = nullptr;
+    hipStream_t last_stream = nullptr;   // the stream of the handle's previous launch (launches of one handle are ordered)
+    bool last_stream_valid = false;
     hipEvent_t desc_copied = nullptr;
     bool desc_pending = false;
     PinnedBuffer h_desc;
@@ -154,6 +157,19 @@ struct FftJob {
 int launch_fft_jobs(rsmp_fft* leader, const std::vector<FftJob>& jobs, hipStream_t stream) {
     const size_t n = jobs.size();
     const size_t bytes = n * sizeof(FftStreamDesc);
+    // A handle's launches are ordered (&mut self in the reference): launch k + 1 reads the overlap rows launch k
+    // writes, so a caller that changes streams between two calls waits here for the first -- as the FIR path does.
+    // A handle listed twice in one batch would read one old state through both descriptors: refused.
+    std::unordered_set<const rsmp_fft*> seen;
+    for (size_t i = 0; i < n; ++i)
+        if (!seen.insert(jobs[i].r).second)
+            return rsmp::fail(RSMP_ERR_INVALID_ARGUMENT, "ResamplerFft batch: handle %zu is listed twice", i);
+    for (size_t i = 0; i < n; ++i) {
+        rsmp_fft* h = jobs[i].r;
+        if (h->last_stream_valid && h->last_stream != stream) RSMP_HIP_CHECK(hipStreamSynchronize(h->last_stream));
+        h->last_stream = stream;
+        h->last_stream_valid = true;
+    }
     if (leader->desc_pending) {
         RSMP_HIP_CHECK(hipEventSynchronize(leader->desc_copied));
         leader->desc_pending = false;

@@ -26,11 +26,13 @@ struct NfArgs {
     uint32_t chunks;    // chunks per stream
 };
 
-// `bad`: the sum this lane tested among its outputs n_first .. n_first + n_count - 1 (launch-relative output
-// frames of stream `stream`, of which [0, n_limit) exist) is not finite.  A lane tests ONE frame of its 4 or
-// 8 (both channels): a non-finite sample spoils a run of >= taps consecutive outputs, so every spoilt run
-// contains tested frames -- except possibly its first and last few, which is why the marked range is
-// widened by the lane's frame count on both sides.
+// `bad`: the sum over EVERY value this lane is about to store for its outputs n_first .. n_first + n_count - 1
+// (launch-relative output frames of stream `stream`, of which [0, n_limit) exist) is not finite.  Every frame
+// is tested: a non-finite sample spoils only about taps * out_hz / in_hz consecutive outputs, which with few
+// taps and heavy down-sampling is fewer than a lane's frames (Sample8 at 192 -> 44.1 kHz: ~4), so a sampled
+// test could step over a spoilt run.  (inf - inf and sums that overflow are also `bad`: the repair launch
+// then recomputes a chunk that did not need it, which changes nothing.)  The marked range is still widened
+// by the lane's frame count on both sides: the pre-mixed rows' zero padding (0 * inf) reaches that far.
 __device__ __forceinline__ void nf_mark(const NfArgs& nf, bool bad, uint32_t stream, int32_t n_first, int32_t n_count,
                                         int32_t n_limit) {
     if (__builtin_expect(__any(bad), 0)) {
@@ -50,5 +52,10 @@ __device__ __forceinline__ void nf_mark(const NfArgs& nf, bool bad, uint32_t str
 }
 
 __device__ __forceinline__ bool nf_is_bad(float sum) { return !(fabsf(sum) <= FLT_MAX); }
+// the eight sums (four frames x two channels) of a matrix-core lane, as one value to test
+template <typename V4>
+__device__ __forceinline__ float nf_sum8(const V4& a, const V4& b) {
+    return ((a.x + a.y) + (a.z + a.w)) + ((b.x + b.y) + (b.z + b.w));
+}
 
 }  // namespace rsmp

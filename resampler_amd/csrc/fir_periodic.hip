@@ -532,9 +532,11 @@ __device__ __forceinline__ void process_tile(const GeoArgs& geo, const ItemCtx& 
 
     // ---- non-finite sums: the chunk is redone in the reference's form by the repair launch ---------
     {
-        float chk = av[0][0];   // one frame of the lane's eight, every channel of the lane
+        float chk = 0.f;   // every frame and channel the lane stores (inf - inf = NaN: still not finite)
 #pragma unroll
-        for (int k = 1; k < CG; ++k) chk += av[0][k];
+        for (int i = 0; i < (int)kClassTile; ++i)
+#pragma unroll
+            for (int k = 0; k < CG; ++k) chk += av[i][k];
         nf_mark(geo.nf, cx.lane_on && nf_is_bad(chk), cx.stream, n_lane0, static_cast<int32_t>(kClassTile), n_limit);
     }
     // ---- store -------------------------------------------------------------------------------
@@ -770,7 +772,7 @@ __device__ __forceinline__ void mfma_store_unit(const GeoArgs& geo, const ItemCt
 #pragma unroll
     for (int g = 0; g < G; ++g) {
         const v4f s0 = acc[g][0], s1 = acc[g][1];
-        nf_mark(geo.nf, p_on[g] && nf_is_bad(s0.x + s1.x), cx.stream,
+        nf_mark(geo.nf, p_on[g] && nf_is_bad(nf_sum8(s0, s1)), cx.stream,
                 cx.n_block0 + static_cast<int32_t>(p_idx[g] * geo.b + j0), 4, cx.n_limit);
     }
 #pragma unroll
@@ -1056,7 +1058,7 @@ __device__ __forceinline__ void mfma_store_pending_group(const GeoArgs& geo, con
     const MfmaUnit<G>& u = pend.unit;
     if (pend.valid) {
         const v4f s0 = pend.acc[g][0], s1 = pend.acc[g][1];
-        nf_mark(geo.nf, u.mode[g] != 0 && nf_is_bad(s0.x + s1.x), u.stream, u.n0[g], 4, u.n_limit);
+        nf_mark(geo.nf, u.mode[g] != 0 && nf_is_bad(nf_sum8(s0, s1)), u.stream, u.n0[g], 4, u.n_limit);
     }
     if (__builtin_expect(pend.valid && u.fast && !u.wrap && !(geo.debug & 16), 1)) {
         const v4f a0 = pend.acc[g][0], a1 = pend.acc[g][1];

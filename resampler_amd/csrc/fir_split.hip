@@ -933,7 +933,7 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
         const int32_t n_limit = static_cast<int32_t>(d.n_out);
         // a non-finite sum (inf / NaN sample, or one too large for the 16-bit planes): the chunk is redone
         // in the reference's form by the repair launch
-        nf_mark(g.nf, nf_is_bad(mono || phantom(cu.cur_pair) ? acc0.x : acc0.x + acc1.x), d.sidx, n0, 4, n_limit);
+        nf_mark(g.nf, nf_is_bad(mono || phantom(cu.cur_pair) ? (acc0.x + acc0.y) + (acc0.z + acc0.w) : nf_sum8(acc0, acc1)), d.sidx, n0, 4, n_limit);
         g_f32_ptr o = (g_f32_ptr)d.out + static_cast<int64_t>(n0) * fs + (WIDE ? 2 * cu.cur_pair : 0u);
         const v4f lo = v4f{acc0.x, acc1.x, acc0.y, acc1.y};
         const v4f hi = v4f{acc0.z, acc1.z, acc0.w, acc1.w};

@@ -83,9 +83,14 @@ class StepFeed:
     in_sizes[i] / out_sizes[i]: f32 values of stream i's input chunk / output room per step; `parts`:
     the contiguous stream range of every rank (sharding.partition)."""
 
-    def __init__(self, dist, rank: int, world: int, parts, in_sizes, out_sizes, device, root: int = 0):
+    def __init__(self, dist, rank: int, world: int, parts, in_sizes, out_sizes, device, root: int = 0,
+                 loopback: bool = False):
+        """loopback: the root's own piece also travels through the process group (a send to itself and the
+        matching receive in the same group) instead of a device copy -- lets a single-GPU box execute the
+        RCCL send / recv path (bench.py --config c4 --feed rccl --gpus 1)."""
         import torch
         self.dist, self.rank, self.world, self.root = dist, rank, world, root
+        self.loopback = bool(loopback and dist is not None)
         self.parts = list(parts)
         self.in_off = [0]
         self.out_off = [0]
@@ -121,10 +126,12 @@ class StepFeed:
         if self.rank == self.root:
             for r in range(self.world):
                 piece = self._slice(stage_in, self.in_off, r)
-                if r == self.root:
+                if r == self.root and not self.loopback:
                     self.local_in.copy_(piece)
                 elif piece.numel():
                     ops.append(d.P2POp(d.isend, piece, r))
+                    if r == self.root:
+                        ops.append(d.P2POp(d.irecv, self.local_in, self.root))
         elif self.local_in.numel():
             ops.append(d.P2POp(d.irecv, self.local_in, self.root))
         self._exchange(ops)
@@ -137,10 +144,12 @@ class StepFeed:
         if self.rank == self.root:
             for r in range(self.world):
                 piece = self._slice(stage_out, self.out_off, r)
-                if r == self.root:
+                if r == self.root and not self.loopback:
                     piece.copy_(self.local_out)
                 elif piece.numel():
                     ops.append(d.P2POp(d.irecv, piece, r))
+                    if r == self.root:
+                        ops.append(d.P2POp(d.isend, self.local_out, self.root))
         elif self.local_out.numel():
             ops.append(d.P2POp(d.isend, self.local_out, self.root))
         self._exchange(ops)

@@ -26,6 +26,13 @@ def test_oracle_interpolators_known_points():
     pcm = np.array([0, 16384, -32768, 32767], "<i2").tobytes()
     assert np.array_equal(o.pcm_to_stereo_f32(pcm, 16, 1),
                           np.repeat(np.array([0, 0.5, -1.0, 32767 / 32768], np.float32), 2))
+    # 32-bit PCM: the reference's divisor `(1 << 31) as f32` is an i32 shift = -2^31 (main.rs:131): polarity
+    # inverted.  By hand: 2^30 -> -0.5, i32::MIN -> +1.0, -2^29 -> +0.25
+    pcm = np.array([0, 1 << 30, -(1 << 31), -(1 << 29)], "<i4").tobytes()
+    assert np.array_equal(o.pcm_to_stereo_f32(pcm, 32, 2), np.array([0.0, -0.5, 1.0, 0.25], np.float32))
+    # 24-bit: +2^23
+    pcm = bytes([0x00, 0x00, 0x40, 0x00, 0x00, 0x80])   # 0x400000 = 2^22, 0x800000 = -2^23
+    assert np.array_equal(o.pcm_to_stereo_f32(pcm, 24, 2), np.array([0.5, -1.0], np.float32))
 
 
 @pytest.mark.gpu
@@ -50,7 +57,7 @@ def test_interpolators_match_the_reference_form(mode, ch, rin, rout):
 @pytest.mark.parametrize("bits", [16, 24, 32])
 @pytest.mark.parametrize("channels", [1, 2])
 def test_pcm_conversion_matches_the_reference_form(bits, channels):
-    import torch
+    torch = pytest.importorskip("torch")
     rng = np.random.default_rng(bits * 10 + channels)
     n = 100003 if channels == 1 else 100002
     lo, hi = -(1 << (bits - 1)), (1 << (bits - 1)) - 1
@@ -64,6 +71,13 @@ def test_pcm_conversion_matches_the_reference_form(bits, channels):
         b = s.astype("<i4").view(np.uint8).reshape(-1, 4)[:, :3]
         pcm = np.ascontiguousarray(b).tobytes()
     want = o.pcm_to_stereo_f32(pcm, bits, channels)
+    # known answers by hand (main.rs:131: 16- and 24-bit divide by +2^(bits-1); the 32-bit divisor is the i32
+    # `1 << 31` = -2^31): full-scale negative, full-scale positive, zero, -1
+    k = 2 if channels == 1 else 1
+    sign = -1.0 if bits == 32 else 1.0
+    assert want[0] == sign * -1.0 and want[2 * k] == 0.0
+    assert want[k] == np.float32(sign * np.float32(hi) / np.float32(2.0 ** (bits - 1)))
+    assert want[3 * k] == np.float32(sign * -1.0 / 2.0 ** (bits - 1))
     dev = torch.device("cuda:0")
     d_pcm = torch.frombuffer(bytearray(pcm), dtype=torch.uint8).to(dev)
     d_out = torch.zeros(want.size, device=dev)

@@ -104,6 +104,35 @@ def test_error_codes_and_oversized_buffers():
 
 
 @pytest.mark.gpu
+def test_one_handle_across_streams_and_twice_in_a_batch():
+    """A handle's calls are ordered whatever stream each is enqueued on (`&mut self`, resampler_fft.rs:182):
+    call k + 1 reads the overlap rows call k writes.  A handle listed twice in one batch is refused."""
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda:0")
+    g = ra.ResamplerFft.new(2, ra.SampleRate.Hz44100, ra.SampleRate.Hz48000)
+    r = o.OracleFft(2, 44100, 48000)
+    n_in, n_out = g.chunk_size_input(), g.chunk_size_output()
+    blocks, calls = 40, 6
+    x = synth.fast_noise(calls * blocks * n_in, seed=21)
+    d_x = torch.from_numpy(x).to(dev)
+    d_y = torch.zeros(calls * blocks * n_out, device=dev)
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(device=dev) for _ in range(3)]
+    for k in range(calls):   # no host sync between the calls; the stream changes every time
+        g.resample_bulk_device(d_x[k * blocks * n_in:(k + 1) * blocks * n_in],
+                               d_y[k * blocks * n_out:(k + 1) * blocks * n_out], blocks, streams[k % 3].cuda_stream)
+    torch.cuda.synchronize()
+    want = np.zeros(calls * blocks * n_out, np.float32)
+    for b in range(calls * blocks):
+        assert r.resample(x[b * n_in:(b + 1) * n_in], want[b * n_out:(b + 1) * n_out]) == 0
+    assert rms(d_y.cpu().numpy(), want) <= RMS_TOL
+    batch = ra.FftBatch([g, g])
+    batch.bind([d_x, d_x], [d_y, d_y], [1, 1])
+    with pytest.raises(ra.ResampleError):
+        batch.resample_bulk_device()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("ch,in_hz,out_hz,blocks", [(2, 44100, 48000, 37), (1, 48000, 44100, 50),
                                                     (2, 48000, 96000, 20)])
 def test_bulk_equals_consecutive_calls(ch, in_hz, out_hz, blocks):
@@ -138,7 +167,7 @@ def test_c3_full_size_and_batch_device_api():
     d_out = [torch.zeros(blocks * n_out, device=dev) for _ in range(n_streams)]
     batch = ra.FftBatch(gs)
     batch.bind(d_in, d_out, [blocks] * n_streams)
-    batch.resample_bulk_device(torch.cuda.current_stream().cuda_stream)
+    batch.resample_bulk_device(ra.torch_stream())
     torch.cuda.synchronize()
     for i in range(n_streams):
         r = o.OracleFft(2, 44100, 48000)
@@ -219,7 +248,7 @@ for in_hz, out_hz, a, b in ((44100, 48000, ra.SampleRate.Hz44100, ra.SampleRate.
     d_in, d_out = [torch.from_numpy(x).to(dev)], [torch.zeros(blocks * n_out, device=dev)]
     batch = ra.FftBatch([g])
     batch.bind(d_in, d_out, [blocks])
-    batch.resample_bulk_device(torch.cuda.current_stream().cuda_stream)
+    batch.resample_bulk_device(ra.torch_stream())
     torch.cuda.synchronize()
     r = o.OracleFft(2, in_hz, out_hz)
     ref = np.zeros((blocks, n_out), np.float32)

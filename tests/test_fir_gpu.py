@@ -225,7 +225,7 @@ def test_device_resident_api_and_batch():
         d_in = [torch.from_numpy(x).to(dev) for x in xs]
         d_out = [torch.zeros(g.bulk_output_bound(x.size, 512), device=dev) for g, x in zip(gs, xs)]
         batch.bind(d_in, d_out)
-        consumed, produced = batch.resample_bulk_device(512, torch.cuda.current_stream().cuda_stream)
+        consumed, produced = batch.resample_bulk_device(512, ra.torch_stream())
         torch.cuda.synchronize()
         for i in range(n_streams):
             yr, calls = rs[i].resample_all(xs[i], 512)
@@ -236,7 +236,7 @@ def test_device_resident_api_and_batch():
     x = synth.fast_noise(2 * 2000, seed=9)
     d_x = torch.from_numpy(x).to(dev)
     d_y = torch.zeros(g.buffer_size_output(), device=dev)
-    c, p = g.resample_device(d_x, d_y, torch.cuda.current_stream().cuda_stream)
+    c, p = g.resample_device(d_x, d_y, ra.torch_stream())
     torch.cuda.synchronize()
     orr = np.zeros(r.buffer_size_output(), np.float32)
     rc, cr, pr = r.resample(x, orr)
@@ -264,7 +264,7 @@ def test_matrix_core_kernel_ragged_batch_and_edges(kernel):
         d_in = [torch.from_numpy(x).to(dev) for x in xs]
         d_out = [torch.zeros(g.bulk_output_bound(x.size, 512), device=dev) for g, x in zip(gs, xs)]
         batch.bind(d_in, d_out)
-        consumed, produced = batch.resample_bulk_device(512, torch.cuda.current_stream().cuda_stream)
+        consumed, produced = batch.resample_bulk_device(512, ra.torch_stream())
         torch.cuda.synchronize()
         for i in range(len(frames)):
             yr, _ = rs[i].resample_all(xs[i], 512)
@@ -303,7 +303,7 @@ def test_batch_with_two_rate_pairs_and_mixed_kernels():
         d_in = [torch.from_numpy(x).to(dev) for x in xs]
         d_out = [torch.zeros(g.bulk_output_bound(x.size, 512), device=dev) for g, x in zip(gs, xs)]
         batch.bind(d_in, d_out)
-        consumed, produced = batch.resample_bulk_device(512, torch.cuda.current_stream().cuda_stream)
+        consumed, produced = batch.resample_bulk_device(512, ra.torch_stream())
         torch.cuda.synchronize()
         for i in range(len(spec)):
             chunk = 512 - 512 % spec[i][0]
@@ -327,7 +327,7 @@ def test_repeated_launches_are_bit_identical():
     d_out = [torch.zeros(gs[0].bulk_output_bound(2 * frames, 512), device=dev) for _ in range(n_streams)]
     batch = ra.FirBatch(gs)
     batch.bind(d_in, d_out)
-    stream = torch.cuda.current_stream().cuda_stream
+    stream = ra.torch_stream()
     first = None
     for launch in range(40):
         for o_ in d_out:
@@ -485,6 +485,29 @@ def test_non_finite_and_huge_input_match_the_reference(kernel):
     assert big.any() and np.all(np.abs(yg[big] - yr[big]) <= 1e-5 * np.abs(yr[big]))
     small = fin_r & ~big
     assert rms(yg[small], yr[small]) <= RMS_TOL
+
+
+@pytest.mark.parametrize("in_hz,out_hz", [(96000, 44100), (192000, 44100), (384000, 16000)])
+@pytest.mark.parametrize("kernel", [ra.FirKernel.Periodic, ra.FirKernel.PeriodicVector])
+def test_non_finite_input_with_few_taps_and_heavy_downsampling(kernel, in_hz, out_hz):
+    """Sample8 (16 taps) while down-sampling: one inf / NaN sample spoils only ~16 * out / in consecutive outputs
+    (7, 4 and fewer than 1 here) -- fewer than the frames a lane of the periodic kernels stores, so the store
+    paths test EVERY frame they write (fir_nonfinite.h), not one per lane.  Same finite / inf / NaN pattern as
+    the reference (src/fir/avx.rs:25-58), finite outputs inside the gate."""
+    g, _ = make_pair(2, in_hz, out_hz, lat=ra.Latency.Sample8, kernel=kernel)
+    r = o.OracleFir(2, in_hz, out_hz, 16, 90, o.CONVOLVE_AVX_FMA if o.have_avx_fma() else o.CONVOLVE_SCALAR)
+    n = 200_000
+    x = synth.fast_noise(2 * n, seed=78)
+    rng = np.random.default_rng(5)
+    for k, f in enumerate(rng.choice(np.arange(100, n - 100), size=48, replace=False)):
+        x[2 * f + (k & 1)] = (np.inf, -np.inf, np.nan)[k % 3]
+    yg, consumed = g.resample_bulk(x, 512)
+    yr, _ = r.resample_all(x, 512)
+    assert consumed == x.size and yg.size == yr.size
+    fin_r, fin_g = np.isfinite(yr), np.isfinite(yg)
+    assert (~fin_r).any()
+    assert np.array_equal(fin_g, fin_r), np.flatnonzero(fin_g != fin_r)[:10]
+    assert rms(yg[fin_r], yr[fin_r]) <= RMS_TOL
 
 
 @pytest.mark.gpu

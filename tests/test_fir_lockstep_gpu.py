@@ -2,6 +2,8 @@
 exactly one reference resample() call (src/resampler_fir.rs:509-621) -- identical (consumed, produced),
 output within 1e-6 RMS of the CPU oracle -- with the streams' state resident in HBM and the control flow
 run inside the kernel."""
+import os
+
 import numpy as np
 import pytest
 
@@ -362,34 +364,92 @@ def test_rejects_small_output_and_busy_streams():
         ra.FirLockstep([h, h], 512)
 
 
-def test_sharded_step_feed_on_device():
-    # The per-rank device path of the multi-GPU form (bench.py --config c4 --feed rccl) at world size 1:
-    # a step's chunks arrive through sharding.StepFeed's exchange buffers, the streams are bound straight
-    # to their slices of them, the outputs leave through the gather side.  (World 2 moves the same
-    # buffers over gloo in tests/test_sharding_gloo.py.)
+def _feed_steps(feed, ls, specs, caps, refs, dev, stream_arg, steps=5, frames=512):
     import torch
-    dev = torch.device("cuda:0")
-    n, frames, steps = 30, 512, 5
-    specs = sharding.mixed_rate_batch(n, 2, frames)
-    parts = sharding.partition([s.work() for s in specs], 1)
-    caps = [sharding.buffer_size_output(s) for s in specs]
-    hs = [ra.ResamplerFir.new_from_hz(2, s.in_hz, s.out_hz, ra.Latency.Sample64, ra.Attenuation.Db90) for s in specs]
-    assert caps == [h.buffer_size_output() for h in hs]
-    refs = [o.OracleFir(2, s.in_hz, s.out_hz, 128, 90) for s in specs]
-    feed = sharding.StepFeed(None, 0, 1, parts, [frames * 2] * n, caps, dev)
-    ls = ra.FirLockstep(hs, frames)
-    ls.bind_caps([feed.local_in_view(i) for i in range(n)], [feed.local_out_view(i) for i in range(n)], caps)
+    n = len(specs)
     stage_out = torch.zeros(sum(caps), device=dev)
     rng = np.random.default_rng(77)
     for k in range(steps):
         x = (rng.random(n * frames * 2, dtype=np.float32) * 2 - 1).astype(np.float32)
-        feed.scatter(torch.from_numpy(x).to(dev))
-        ls.step(frames, 0, stream=torch.cuda.current_stream().cuda_stream)
+        d_x = torch.from_numpy(x).to(dev, non_blocking=True)
+        # scatter -> step -> gather: nothing but the stream orders them (no host sync in between)
+        feed.scatter(d_x)
+        ls.step(frames, 0, stream=stream_arg)
         feed.gather(stage_out)
         cons, prod = ls.counts()
+        torch.cuda.current_stream().synchronize()
         got = stage_out.cpu().numpy()
         for i in range(n):
             out = np.zeros(caps[i], np.float32)
             rc, c, p = refs[i].resample(x[i * frames * 2:(i + 1) * frames * 2], out)
             assert rc == 0 and (int(cons[i]), int(prod[i])) == (c, p)
             assert rms(got[feed.out_off[i]:feed.out_off[i] + p], out[:p]) <= RMS_TOL
+
+
+def _feed_fixture(n=30, frames=512):
+    specs = sharding.mixed_rate_batch(n, 2, frames)
+    parts = sharding.partition([s.work() for s in specs], 1)
+    caps = [sharding.buffer_size_output(s) for s in specs]
+    hs = [ra.ResamplerFir.new_from_hz(2, s.in_hz, s.out_hz, ra.Latency.Sample64, ra.Attenuation.Db90) for s in specs]
+    assert caps == [h.buffer_size_output() for h in hs]
+    refs = [o.OracleFir(2, s.in_hz, s.out_hz, 128, 90) for s in specs]
+    return specs, parts, caps, hs, refs
+
+
+@pytest.mark.parametrize("side_stream", [False, True])
+def test_sharded_step_feed_on_device(side_stream):
+    # The per-rank device path of the multi-GPU form (bench.py --config c4 --feed rccl) at world size 1:
+    # a step's chunks arrive through sharding.StepFeed's exchange buffers, the streams are bound straight
+    # to their slices of them, the outputs leave through the gather side.  (World 2 moves the same
+    # buffers over gloo in tests/test_sharding_gloo.py.)  The step runs on torch's CURRENT stream -- the
+    # default one (passed as RSMP_STREAM_LEGACY: a NULL stream argument would mean the batch's own
+    # non-blocking stream, ordered against neither the scatter nor the gather) or a side stream.
+    import torch
+    dev = torch.device("cuda:0")
+    n, frames = 30, 512
+    specs, parts, caps, hs, refs = _feed_fixture(n, frames)
+    feed = sharding.StepFeed(None, 0, 1, parts, [frames * 2] * n, caps, dev)
+    ls = ra.FirLockstep(hs, frames)
+    ls.bind_caps([feed.local_in_view(i) for i in range(n)], [feed.local_out_view(i) for i in range(n)], caps)
+    torch.cuda.synchronize()
+    if side_stream:
+        st = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(st):
+            assert ra.torch_stream() == st.cuda_stream != 0
+            _feed_steps(feed, ls, specs, caps, refs, dev, ra.torch_stream())
+    else:
+        assert ra.torch_stream() == ra.STREAM_LEGACY
+        _feed_steps(feed, ls, specs, caps, refs, dev, ra.torch_stream())
+    ls.close()
+
+
+def test_sharded_step_feed_through_rccl_at_world_one():
+    # The same step with the exchange really going through RCCL (backend "nccl"): a world of one rank whose
+    # GPU sends its shard to itself and receives it in the same group (StepFeed loopback), on a side stream.
+    # What this executes on hardware: RCCL init, the grouped ncclSend / ncclRecv launch of batch_isend_irecv and
+    # the stream ordering scatter -> fir_lockstep_kernel -> gather.  (More than one GPU: the driver's scaling run.)
+    import socket
+    import torch
+    import torch.distributed as dist
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    dev = torch.device("cuda:0")
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group(backend="nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=dev)
+    try:
+        n, frames = 30, 512
+        specs, parts, caps, hs, refs = _feed_fixture(n, frames)
+        st = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(st):
+            feed = sharding.StepFeed(dist, 0, 1, parts, [frames * 2] * n, caps, dev, loopback=True)
+            ls = ra.FirLockstep(hs, frames)
+            ls.bind_caps([feed.local_in_view(i) for i in range(n)], [feed.local_out_view(i) for i in range(n)], caps)
+            torch.cuda.synchronize()
+            _feed_steps(feed, ls, specs, caps, refs, dev, ra.torch_stream(), steps=4)
+            ls.close()
+    finally:
+        dist.destroy_process_group()

@@ -20,11 +20,11 @@ def main():
         streams = max(1, 128 // ch)
         hs = [ra.ResamplerFir.new_from_hz(ch, in_hz, out_hz, ra.Latency.Sample64, ra.Attenuation.Db90) for _ in range(streams)]
         x = torch.from_numpy(synth.fast_noise(frames * ch, seed=2)).to(dev)
-        d_in = [x for _ in hs]
+        d_in = [(x * (0.5 + 0.5 * i / len(hs))).contiguous() for i in range(len(hs))]   # a buffer per stream: all bytes from HBM
         d_out = [torch.empty(hs[0].bulk_output_bound(frames * ch, 512 * ch), device=dev) for _ in hs]
         batch = ra.FirBatch(hs)
         batch.bind(d_in, d_out)
-        s = torch.cuda.current_stream().cuda_stream
+        s = ra.torch_stream()
 
         def step():
             batch.reset()

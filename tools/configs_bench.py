@@ -40,7 +40,7 @@ def c5(chunks: int):
     lat = np.array(lat[20:]) * 1e6
     d_x = torch.from_numpy(x).to(dev)
     d_y = torch.empty(h.buffer_size_output(), device=dev)
-    stream = torch.cuda.current_stream().cuda_stream
+    stream = ra.torch_stream()
     lat_d = []
     for i in range(chunks + 20):
         t0 = time.perf_counter()

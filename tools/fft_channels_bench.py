@@ -18,11 +18,11 @@ def main():
         hs = [ra.ResamplerFft.new(ch, ra.SampleRate.Hz44100, ra.SampleRate.Hz48000) for _ in range(streams)]
         n_in, n_out = hs[0].chunk_size_input(), hs[0].chunk_size_output()
         x = torch.from_numpy(synth.fast_noise(blocks * n_in, seed=3)).to(dev)
-        d_in = [x for _ in hs]
+        d_in = [(x * (0.5 + 0.5 * i / len(hs))).contiguous() for i in range(len(hs))]   # a buffer per stream: all bytes from HBM
         d_out = [torch.empty(blocks * n_out, device=dev) for _ in hs]
         batch = ra.FftBatch(hs)
         batch.bind(d_in, d_out, [blocks] * streams)
-        s = torch.cuda.current_stream().cuda_stream
+        s = ra.torch_stream()
         for _ in range(5):
             batch.resample_bulk_device(s)
         torch.cuda.synchronize()

@@ -30,7 +30,7 @@ def main():
         d_in, d_out = [torch.from_numpy(x).to(dev)], [torch.zeros(blocks * n_out, device=dev)]
         batch = ra.FftBatch([g])
         batch.bind(d_in, d_out, [blocks])
-        batch.resample_bulk_device(torch.cuda.current_stream().cuda_stream)
+        batch.resample_bulk_device(ra.torch_stream())
         torch.cuda.synchronize()
         y = d_out[0].cpu().numpy()
         r = o.OracleFft(2, in_hz, out_hz)

@@ -29,11 +29,11 @@ def main():
         n_in, n_out = hs[0].chunk_size_input(), hs[0].chunk_size_output()
         blocks = max(4, (1 << 21) // n_in)          # ~2^20 frames per stream
         x = torch.from_numpy(synth.fast_noise(blocks * n_in, seed=3)).to(dev)
-        d_in = [x for _ in hs]
+        d_in = [(x * (0.5 + 0.5 * i / len(hs))).contiguous() for i in range(len(hs))]   # a buffer per stream: all bytes from HBM
         d_out = [torch.empty(blocks * n_out, device=dev) for _ in hs]
         batch = ra.FftBatch(hs)
         batch.bind(d_in, d_out, [blocks] * streams)
-        s = torch.cuda.current_stream().cuda_stream
+        s = ra.torch_stream()
         for _ in range(3):
             batch.resample_bulk_device(s)
         torch.cuda.synchronize()

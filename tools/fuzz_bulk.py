@@ -64,7 +64,7 @@ def fir_round(rng, dev):
     d_out = [torch.zeros(h.bulk_output_bound(x.size, chunk), device=dev) for h, x in zip(hs, xs)]
     batch = ra.FirBatch(hs)
     batch.bind(d_in, d_out)
-    cons, prod = batch.resample_bulk_device(chunk, torch.cuda.current_stream().cuda_stream)
+    cons, prod = batch.resample_bulk_device(chunk, ra.torch_stream())
     torch.cuda.synchronize()
     worst = 0.0
     for i in range(n):
@@ -101,7 +101,7 @@ def fft_round(rng, dev):
     d_out = [torch.zeros(blocks * n_out, device=dev) for _ in range(n)]
     batch = ra.FftBatch(hs)
     batch.bind(d_in, d_out, [blocks] * n)
-    batch.resample_bulk_device(torch.cuda.current_stream().cuda_stream)
+    batch.resample_bulk_device(ra.torch_stream())
     torch.cuda.synchronize()
     worst = 0.0
     for i in range(n):

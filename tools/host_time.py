@@ -11,7 +11,7 @@ d_in = [base.clone() for _ in range(S)]
 cap = hs[0].bulk_output_bound(2 * N, 512)
 d_out = [torch.empty(cap, device=dev) for _ in range(S)]
 b = ra.FirBatch(hs); b.bind(d_in, d_out)
-st = torch.cuda.current_stream().cuda_stream
+st = ra.torch_stream()
 for _ in range(50):
     b.reset(); b.resample_bulk_device(512, st)
 torch.cuda.synchronize()

@@ -18,7 +18,7 @@ d_in = [torch.from_numpy(x).to(dev) for x in xs]
 d_out = [torch.zeros(gs[0].bulk_output_bound(2 * frames, 512), device=dev) for _ in range(n_streams)]
 batch = ra.FirBatch(gs)
 batch.bind(d_in, d_out)
-stream = torch.cuda.current_stream().cuda_stream
+stream = ra.torch_stream()
 first = None
 t0 = time.time()
 for launch in range(launches):
