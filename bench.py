@@ -196,70 +196,112 @@ def _fir_cpu_worker(x, seconds, chunk, out, idx, specs=(CHANNELS, IN_HZ, OUT_HZ,
     from oracle import pyoracle as orc
     kind = orc.CONVOLVE_AVX_FMA if orc.have_avx_fma() else orc.CONVOLVE_SCALAR
     r = orc.OracleFir(specs[0], specs[1], specs[2], specs[3], specs[4], kind)
-    r.resample_all(x[: 2 * 65536], chunk)          # warm caches / page in
+    y = np.empty(int(x.size / r.ratio) + 4 * r.buffer_size_output(), np.float32)
+    r.resample_all_into(x[: 2 * 65536], chunk, y)  # warm caches / page in
+    y[:] = 0
     t0 = time.perf_counter()
     values = 0
     while True:
         r.reset()
-        r.resample_all(x, chunk)                   # (ctypes releases the GIL for the call)
+        r.resample_all_into(x, chunk, y)           # the CLI's driver loop in C (ctypes releases the GIL for the call)
         values += x.size
         if time.perf_counter() - t0 >= seconds:
             break
     out[idx] = (values, time.perf_counter() - t0)
 
 
+def _fft_cpu_worker(x, seconds, out, idx):
+    from oracle import pyoracle as orc
+    r = orc.OracleFft(CHANNELS, IN_HZ, OUT_HZ)
+    y = np.zeros((x.size // r.chunk_size_input() + 1) * r.chunk_size_output(), np.float32)
+    r.resample_all_into(x[: 8 * r.chunk_size_input()], y)
+    t0 = time.perf_counter()
+    values = 0
+    while True:
+        r.resample_all_into(x, y)                  # the CLI's driver loop in C (one ctypes call per pass)
+        values += x.size
+        if time.perf_counter() - t0 >= seconds:
+            break
+    out[idx] = (values, time.perf_counter() - t0)
+
+
+def _all_cores(worker, args, seconds, cores):
+    n = min(cores, 256)
+    res = [None] * n
+    ths = [threading.Thread(target=worker, args=args + (seconds, res, i)) for i in range(n)]
+    t0 = time.perf_counter()
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    wall = time.perf_counter() - t0
+    return round(sum(r[0] for r in res) / wall / 1e6, 1), n, wall
+
+
+# BASELINE.md section 1, converted to this metric (input values/s, one core of a Ryzen 9 9950X3D, v0.3.3 criterion
+# benches over four rate pairs; the changelog does not say which end belongs to 44.1 -> 48 kHz)
+PUBLISHED_REF = {"fir": {"Msamples_in_per_s": [120, 130], "source": "CHANGELOG.md:77 (503-540 MiB/s out)", "cpu": "Ryzen 9 9950X3D, 1 thread"},
+                 "fft": {"Msamples_in_per_s": [190, 290], "source": "CHANGELOG.md:76 (780-1192 MiB/s out)", "cpu": "Ryzen 9 9950X3D, 1 thread"}}
+
+
 def cpu_baseline_fir(frames: int, seconds: float, all_cores_seconds: float):
-    """Oracle (port of the reference AVX+FMA path, fir/avx.rs + resampler_fir.rs): the same 2 ch
-    44.1k->48k 128-tap sweep in 512-value calls, repeated for ~`seconds` on ONE core; then one
-    stream per core on all host cores (the reference is single-threaded per instance)."""
+    """Oracle (port of the reference AVX+FMA path, fir/avx.rs + resampler_fir.rs), built as BASELINE.md section 2
+    prescribes (oracle/liboracle_native.so: -O3 -mavx2 -mfma; bit-identical to the portable build,
+    tests/test_oracle_native.py): the same 2 ch 44.1k->48k 128-tap sweep in 512-value calls, repeated for ~`seconds`
+    on ONE core; then one stream per core on all host cores (the reference is single-threaded per instance)."""
     from oracle import pyoracle as orc
     from resampler_amd import synth
     model, cores = cpu_info()
-    x = synth.sweep(frames, CHANNELS, float(IN_HZ))
-    res = [None]
-    _fir_cpu_worker(x, seconds, 512, res, 0)
-    one = res[0][0] / res[0][1] / 1e6
-    line = {
-        "value": round(one, 3), "unit": "Msamples/s", "cores": 1, "kind": "port", "model": model,
-        "host_cores": cores,
-        "sample": f"{res[0][0] // x.size} passes of one {frames}-frame 2ch sweep, 512-value calls, "
-                  f"{'AVX+FMA' if orc.have_avx_fma() else 'scalar'} convolve, {res[0][1]:.1f} s",
-    }
-    if all_cores_seconds > 0 and cores > 1:
-        n = min(cores, 256)
-        xs = x[: 2 * (1 << 18)]                    # a quarter of the sweep per thread: bounded sample
-        res = [None] * n
-        ths = [threading.Thread(target=_fir_cpu_worker, args=(xs, all_cores_seconds, 512, res, i)) for i in range(n)]
-        t0 = time.perf_counter()
-        for t in ths:
-            t.start()
-        for t in ths:
-            t.join()
-        wall = time.perf_counter() - t0
-        line["all_cores"] = {"value": round(sum(r[0] for r in res) / wall / 1e6, 1), "unit": "Msamples/s",
-                             "cores": n, "sample": f"one stream per core, 2^18-frame sweeps, {wall:.1f} s"}
+    native = orc.use_native(True)
+    try:
+        x = synth.sweep(frames, CHANNELS, float(IN_HZ))
+        res = [None]
+        _fir_cpu_worker(x, seconds, 512, res, 0)
+        one = res[0][0] / res[0][1] / 1e6
+        line = {
+            "value": round(one, 3), "unit": "Msamples/s", "cores": 1, "kind": "port", "model": model,
+            "host_cores": cores, "build_flags": orc.build_flags(), "published_ref": PUBLISHED_REF["fir"],
+            "sample": f"{res[0][0] // x.size} passes of one {frames}-frame 2ch sweep, 512-value calls, "
+                      f"{'AVX+FMA' if orc.have_avx_fma() else 'scalar'} convolve, {res[0][1]:.1f} s",
+        }
+        if all_cores_seconds > 0 and cores > 1:
+            xs = x[: 2 * (1 << 18)]                    # a quarter of the sweep per thread: bounded sample
+            v, n, wall = _all_cores(lambda x_, c_, s_, r_, i_: _fir_cpu_worker(x_, s_, c_, r_, i_), (xs, 512), all_cores_seconds, cores)
+            line["all_cores"] = {"value": v, "unit": "Msamples/s", "cores": n,
+                                 "sample": f"one stream per core, 2^18-frame sweeps, {wall:.1f} s"}
+    finally:
+        orc.use_native(False)
+    if not native:
+        line["note"] = "this CPU lacks AVX2+FMA: portable build timed"
     return line
 
 
-def cpu_baseline_fft(seconds: float):
-    """OracleFft (port of resampler_fft.rs:182-240 + src/fft, scalar butterflies) on one core."""
+def cpu_baseline_fft(seconds: float, all_cores_seconds: float = 0.0):
+    """OracleFft (port of resampler_fft.rs:182-240 + src/fft with the reference's SCALAR butterflies,
+    butterflies/*/mod.rs -- its AVX butterflies are not restated; precomputed twiddles as RadixFFT::new), native
+    build, the CLI's driver loop over 256 blocks on one core, then one stream per core."""
     from oracle import pyoracle as orc
     from resampler_amd import synth
     model, cores = cpu_info()
-    r = orc.OracleFft(CHANNELS, IN_HZ, OUT_HZ)
-    n_in, n_out = r.chunk_size_input(), r.chunk_size_output()
-    blocks = 256
-    x = synth.sweep(blocks * n_in // CHANNELS, CHANNELS, float(IN_HZ))
-    out = np.zeros(n_out, np.float32)
-    t0 = time.perf_counter()
-    values = 0
-    while time.perf_counter() - t0 < seconds:
-        for b in range(blocks):
-            r.resample(x[b * n_in:(b + 1) * n_in], out)
-        values += blocks * n_in
-    dt = time.perf_counter() - t0
-    return {"value": round(values / dt / 1e6, 3), "unit": "Msamples/s", "cores": 1, "kind": "port",
-            "model": model, "sample": f"{values // n_in} blocks of 1176 frames, scalar butterflies, {dt:.1f} s"}
+    orc.use_native(True)
+    try:
+        n_in = orc.OracleFft(CHANNELS, IN_HZ, OUT_HZ).chunk_size_input()
+        blocks = 256
+        x = synth.sweep(blocks * n_in // CHANNELS, CHANNELS, float(IN_HZ))
+        res = [None]
+        _fft_cpu_worker(x, seconds, res, 0)
+        values, dt = res[0]
+        line = {"value": round(values / dt / 1e6, 3), "unit": "Msamples/s", "cores": 1, "kind": "port",
+                "model": model, "host_cores": cores, "build_flags": orc.build_flags(), "published_ref": PUBLISHED_REF["fft"],
+                "sample": f"{values // n_in} blocks of 1176 frames, scalar butterflies (the reference's AVX butterflies "
+                          f"are not restated: expect the Rust crate ~2-3x above this), {dt:.1f} s"}
+        if all_cores_seconds > 0 and cores > 1:
+            v, n, wall = _all_cores(lambda x_, s_, r_, i_: _fft_cpu_worker(x_, s_, r_, i_), (x,), all_cores_seconds, cores)
+            line["all_cores"] = {"value": v, "unit": "Msamples/s", "cores": n,
+                                 "sample": f"one stream per core, 256-block passes, {wall:.1f} s"}
+    finally:
+        orc.use_native(False)
+    return line
 
 
 # ------------------------------------------------------------------------------------------------
@@ -410,7 +452,7 @@ def bench_fft(ctx: Ctx, args, steps: int, warmup: int, with_cpu: bool):
                      "kernel_ms": round(k_ms, 4), "algorithmic_bytes": int(alg_bytes)},
     }
     if with_cpu:
-        line["cpu_baseline"] = cpu_baseline_fft(min(args.cpu_seconds, 6.0))
+        line["cpu_baseline"] = cpu_baseline_fft(min(args.cpu_seconds, 6.0), min(args.cpu_all_cores_seconds, 4.0))
     return line
 
 
@@ -757,6 +799,12 @@ def main() -> int:
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         return spawn_ranks(args)       # nothing below has run: this process never touches the GPU
 
+    # RCCL prints a version banner to the C-level stdout (flushed at exit when stdout is a pipe or a file): everything
+    # any library writes to fd 1 goes to stderr, the JSON line alone to the real stdout.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     ctx = Ctx(args)
     if args.path == "fft":
         line = bench_fft(ctx, args, args.steps, args.warmup, with_cpu=(not args.no_cpu and ctx.world == 1))
@@ -772,7 +820,7 @@ def main() -> int:
             if not args.no_secondary:
                 line["secondary"] = secondary_lines(ctx, args)
     if ctx.rank == 0:
-        print(json.dumps(line), flush=True)
+        os.write(real_stdout, (json.dumps(line) + "\n").encode())
     ctx.close()
     return 0
 

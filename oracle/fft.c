@@ -153,6 +153,8 @@ struct orc_rfft {
     c32* rc_twiddles;     /* expansion (forward) or reduction (inverse) twiddles, k = 1.. */
     size_t n_rc;
     c32* scratch;         /* 3 * n */
+    c32* stage_tw[24];    /* per stage (stride > 1): [k][q - 1] = twiddle_f32(k * q, stride * r), k < stride, q = 1 .. r - 1
+                           * -- computed once here as RadixFFT::new does (radix_fft.rs:273-362), in f64 -> f32 */
 };
 
 /* radix_fft.rs:251-258 */
@@ -205,6 +207,17 @@ orc_rfft* orc_rfft_new(const int* factors, size_t n_factors, int inverse) {
                                         : c_new(t.re * 0.5f, t.im * 0.5f); /* :377-386 */
     }
     f->scratch = (c32*)calloc(3 * n, sizeof(c32));
+    size_t stride = 1;
+    for (size_t s = 0; s < f->n_factors; s++) {
+        const size_t r = (size_t)f->factors[s];
+        if (stride > 1) {
+            c32* tw = (c32*)malloc(sizeof(c32) * stride * (r - 1));
+            for (size_t k = 0; k < stride; k++)
+                for (size_t q = 1; q < r; q++) tw[k * (r - 1) + (q - 1)] = twiddle_f32(k * q, stride * r);
+            f->stage_tw[s] = tw;
+        }
+        stride *= r;
+    }
     return f;
 }
 
@@ -212,6 +225,7 @@ void orc_rfft_free(orc_rfft* f) {
     if (!f) return;
     free(f->rc_twiddles);
     free(f->scratch);
+    for (size_t s = 0; s < 24; s++) free(f->stage_tw[s]);
     free(f);
 }
 size_t orc_rfft_len(const orc_rfft* f) { return f->n; }
@@ -221,16 +235,15 @@ size_t orc_rfft_stage_factors(const orc_rfft* f, int* out) {
 }
 
 /* One out-of-place Stockham stage of radix r (scalar butterfly specs, butterflyN/mod.rs). */
-static void stage(const c32* src, c32* dst, size_t n, int r, size_t stride) {
+static inline __attribute__((always_inline)) void stage_body(const c32* src, c32* dst, size_t n, const int r, size_t stride, const c32* tw) {
     const size_t m = n / (size_t)r;
-    const size_t stage_size = stride * (size_t)r;
-    for (size_t i = 0; i < m; i++) {
-        const size_t k = i % stride;
+    size_t k = 0;   /* i % stride */
+    for (size_t i = 0; i < m; i++, k = (k + 1 == stride) ? 0 : k + 1) {
         c32 z[8], t[8];
         for (int q = 0; q < r; q++) z[q] = src[i + (size_t)q * m];
         t[0] = z[0];
         for (int q = 1; q < r; q++)
-            t[q] = (stride == 1) ? z[q] : c_mul(twiddle_f32(k * (size_t)q, stage_size), z[q]);
+            t[q] = (stride == 1) ? z[q] : c_mul(tw[k * (size_t)(r - 1) + (size_t)(q - 1)], z[q]);
         const size_t j = (size_t)r * i - (size_t)(r - 1) * k;
         c32* o = dst + j;
         switch (r) {
@@ -321,19 +334,32 @@ static void stage(const c32* src, c32* dst, size_t n, int r, size_t stride) {
     }
 }
 
+/* One instance per radix (the reference has one function per radix too, butterflies/mod.rs): with `r` a constant the
+ * compiler unrolls the loads and drops the switch; the arithmetic and its order are unchanged. */
+static void stage(const c32* src, c32* dst, size_t n, int r, size_t stride, const c32* tw) {
+    switch (r) {
+        case 2: stage_body(src, dst, n, 2, stride, tw); break;
+        case 3: stage_body(src, dst, n, 3, stride, tw); break;
+        case 4: stage_body(src, dst, n, 4, stride, tw); break;
+        case 5: stage_body(src, dst, n, 5, stride, tw); break;
+        case 7: stage_body(src, dst, n, 7, stride, tw); break;
+        case 8: stage_body(src, dst, n, 8, stride, tw); break;
+    }
+}
+
 /* stockham_autosort.rs:169-247 (ping-pong; returns 1 when the result is in `scratch`), with the
  * single-factor special case of radix_fft.rs:476-497 (result copied back to data). */
 static int stockham(const orc_rfft* f, c32* data, c32* scratch) {
     if (f->n_factors == 0) return 0;
     if (f->n_factors == 1) {
-        stage(data, scratch, f->n2, f->factors[0], 1);
+        stage(data, scratch, f->n2, f->factors[0], 1, NULL);
         memcpy(data, scratch, sizeof(c32) * f->n2);
         return 0;
     }
     c32 *in = data, *out = scratch;
     size_t stride = 1;
     for (size_t s = 0; s < f->n_factors; s++) {
-        stage(in, out, f->n2, f->factors[s], stride);
+        stage(in, out, f->n2, f->factors[s], stride, f->stage_tw[s]);
         c32* tmp = in; in = out; out = tmp;
         stride *= (size_t)f->factors[s];
     }
@@ -525,4 +551,23 @@ int orc_fft_resample(orc_fft_resampler* r, const float* in, size_t in_len, float
             out[f * ch + c] = r->output_scratch[c * out_ch_len + f];
         }
     return 0;
+}
+
+/* resample/src/main.rs:256-313 (resample_batch): complete chunks straight from the input, a last partial chunk
+ * zero padded, the output trimmed to ceil(in_len * chunk_out / chunk_in).  Returns values written (0 on error or
+ * when out_cap is too small). */
+size_t orc_fft_resample_all(orc_fft_resampler* r, const float* in, size_t in_len, float* out, size_t out_cap) {
+    const size_t ci = orc_fft_chunk_size_input(r), co = orc_fft_chunk_size_output(r);
+    const size_t complete = in_len / ci, rem = in_len % ci, total = complete + (rem ? 1 : 0);
+    if (out_cap < total * co) return 0;
+    for (size_t k = 0; k < complete; k++)
+        if (orc_fft_resample(r, in + k * ci, ci, out + k * co, co) != 0) return 0;
+    if (rem) {
+        float* padded = (float*)calloc(ci, sizeof(float));
+        memcpy(padded, in + complete * ci, sizeof(float) * rem);
+        const int rc = orc_fft_resample(r, padded, ci, out + complete * co, co);
+        free(padded);
+        if (rc != 0) return 0;
+    }
+    return (size_t)ceil((double)in_len * (double)co / (double)ci);
 }

@@ -105,6 +105,8 @@ size_t orc_fft_delay(const orc_fft_resampler* r);                         /* :15
 int orc_fft_resample(orc_fft_resampler* r, const float* in, size_t in_len, float* out,
                      size_t out_len);                                     /* :182-240 */
 const orc_c32* orc_fft_filter_spectrum(const orc_fft_resampler* r, size_t* len);
+/* The CLI driver loop resample_batch (resample/src/main.rs:256-313); returns values written, 0 on error. */
+size_t orc_fft_resample_all(orc_fft_resampler* r, const float* in, size_t in_len, float* out, size_t out_cap);
 
 /* ---- resample/src (CLI helpers around the path) --------------------------------------------- */
 /* interpolation_resampler.rs:41-126; return output frames (0 when out_cap is too small). */

@@ -13,6 +13,12 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "liboracle.so")
+# The same sources built as BASELINE.md section 2 prescribes for the timed CPU baseline (-O3 -mavx2 -mfma, still
+# -ffp-contract=off: floor / trunc / conversions inline, loops vectorised, no operation fused or reordered).
+# tests/test_oracle_native.py checks that it returns the portable build's values bit for bit.
+_NATIVE_PATH = os.path.join(_HERE, "liboracle_native.so")
+NATIVE_BUILD_FLAGS = "gcc -O3 -mavx2 -mfma -ffp-contract=off -fno-fast-math"
+PORTABLE_BUILD_FLAGS = "gcc -O2 -ffp-contract=off -fno-fast-math (AVX+FMA only inside convolve_interp_avx_fma)"
 
 WINDOW_PERIODIC = 0
 WINDOW_SYMMETRIC = 1
@@ -28,16 +34,49 @@ def build(force: bool = False) -> str:
     return _LIB_PATH
 
 
-_lib = None
+_libs = {}
+_native = False
+
+
+def cpu_has_avx2_fma() -> bool:
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("flags"):
+                    fl = ln.split()
+                    return "avx2" in fl and "fma" in fl
+    except OSError:
+        pass
+    return False
+
+
+def use_native(flag: bool) -> bool:
+    """Objects created from now on come from liboracle_native.so (False: back to liboracle.so).  Returns whether
+    the native build is in use (it needs AVX2 + FMA on this CPU).  An object keeps the library that made it."""
+    global _native
+    _native = bool(flag) and cpu_has_avx2_fma() and (os.path.exists(_NATIVE_PATH) or _try_build())
+    return _native
+
+
+def _try_build() -> bool:
+    try:
+        build()
+    except Exception:
+        return False
+    return os.path.exists(_NATIVE_PATH)
+
+
+def build_flags() -> str:
+    return NATIVE_BUILD_FLAGS if _native else PORTABLE_BUILD_FLAGS
 
 
 def lib() -> C.CDLL:
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(_LIB_PATH):
+    path = _NATIVE_PATH if _native else _LIB_PATH
+    if path in _libs:
+        return _libs[path]
+    if not os.path.exists(path):
         build()
-    L = C.CDLL(_LIB_PATH)
+    L = C.CDLL(path)
     f32p = C.POINTER(C.c_float)
     szp = C.POINTER(C.c_size_t)
     L.orc_bessel_i0.restype = C.c_double
@@ -99,13 +138,15 @@ def lib() -> C.CDLL:
         L.orc_fft_resample.argtypes = [C.c_void_p, f32p, C.c_size_t, f32p, C.c_size_t]
         L.orc_fft_filter_spectrum.restype = f32p
         L.orc_fft_filter_spectrum.argtypes = [C.c_void_p, szp]
+    L.orc_fft_resample_all.restype = C.c_size_t
+    L.orc_fft_resample_all.argtypes = [C.c_void_p, f32p, C.c_size_t, f32p, C.c_size_t]
     for name in ("orc_interp_linear", "orc_interp_hermite"):
         fn = getattr(L, name)
         fn.restype = C.c_size_t
         fn.argtypes = [C.c_size_t, C.c_uint32, C.c_uint32, f32p, C.c_size_t, f32p, C.c_size_t]
     L.orc_pcm_to_stereo_f32.restype = C.c_size_t
     L.orc_pcm_to_stereo_f32.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_size_t, f32p]
-    _lib = L
+    _libs[path] = L
     return L
 
 
@@ -160,7 +201,8 @@ class OracleFir:
     """Mirror of ResamplerFir (resampler_fir.rs:179-643) on the oracle."""
 
     def __init__(self, channels, in_hz, out_hz, taps=128, attenuation_db=120, kind=CONVOLVE_SCALAR):
-        self._h = lib().orc_fir_new(channels, in_hz, out_hz, taps, attenuation_db, kind)
+        self._L = lib()
+        self._h = self._L.orc_fir_new(channels, in_hz, out_hz, taps, attenuation_db, kind)
         if not self._h:
             raise ValueError("invalid ResamplerFir arguments")
         self.channels = channels
@@ -168,42 +210,42 @@ class OracleFir:
 
     def __del__(self):
         if getattr(self, "_h", None):
-            lib().orc_fir_free(self._h)
+            self._L.orc_fir_free(self._h)
             self._h = None
 
     def buffer_size_output(self) -> int:
-        return lib().orc_fir_buffer_size_output(self._h)
+        return self._L.orc_fir_buffer_size_output(self._h)
 
     def delay(self) -> int:
-        return lib().orc_fir_delay(self._h)
+        return self._L.orc_fir_delay(self._h)
 
     def reset(self) -> None:
-        lib().orc_fir_reset(self._h)
+        self._L.orc_fir_reset(self._h)
 
     @property
     def ratio(self) -> float:
-        return lib().orc_fir_ratio(self._h)
+        return self._L.orc_fir_ratio(self._h)
 
     def coeffs(self) -> np.ndarray:
-        p = lib().orc_fir_coeffs(self._h)
+        p = self._L.orc_fir_coeffs(self._h)
         return np.ctypeslib.as_array(p, shape=(1024, self.taps)).copy()
 
     def state(self):
         rp, av, pos = C.c_size_t(), C.c_size_t(), C.c_double()
-        lib().orc_fir_state(self._h, C.byref(rp), C.byref(av), C.byref(pos))
+        self._L.orc_fir_state(self._h, C.byref(rp), C.byref(av), C.byref(pos))
         return rp.value, av.value, pos.value
 
     def seek(self, state, history: np.ndarray) -> None:
         """Test support: (read_position, available_frames, position) + the input preceding the point."""
         h = np.ascontiguousarray(history, np.float32)
-        if lib().orc_fir_seek(self._h, state[0], state[1], state[2], _f32p(h), h.size) != 0:
+        if self._L.orc_fir_seek(self._h, state[0], state[1], state[2], _f32p(h), h.size) != 0:
             raise ValueError("orc_fir_seek: history shorter than the buffered frames")
 
     def resample(self, inp: np.ndarray, out: np.ndarray):
         """Returns (status, consumed, produced); status 0/1/2 as error.rs:3-8."""
         inp = np.ascontiguousarray(inp, np.float32)
         c, p = C.c_size_t(), C.c_size_t()
-        rc = lib().orc_fir_resample(self._h, _f32p(inp), inp.size, _f32p(out), out.size,
+        rc = self._L.orc_fir_resample(self._h, _f32p(inp), inp.size, _f32p(out), out.size,
                                     C.byref(c), C.byref(p))
         return rc, c.value, p.value
 
@@ -217,11 +259,18 @@ class OracleFir:
             max_calls = inp.size // max(1, min(chunk_len, 64)) + 16
         calls = np.zeros(2 * max_calls, np.uintp)
         nc = C.c_size_t()
-        n = lib().orc_fir_resample_all(self._h, _f32p(inp), inp.size, chunk_len, _f32p(out), cap,
+        n = self._L.orc_fir_resample_all(self._h, _f32p(inp), inp.size, chunk_len, _f32p(out), cap,
                                        calls.ctypes.data_as(C.POINTER(C.c_size_t)), max_calls,
                                        C.byref(nc))
         k = min(nc.value, max_calls)
         return out[:n].copy(), calls[:2 * k].reshape(k, 2).astype(np.int64)
+
+
+    def resample_all_into(self, inp: np.ndarray, chunk_len: int, out: np.ndarray) -> int:
+        """The same driver loop into a caller-owned buffer (no allocation: timing loops on many threads)."""
+        nc = C.c_size_t()
+        return self._L.orc_fir_resample_all(self._h, _f32p(inp), inp.size, chunk_len, _f32p(out), out.size,
+                                            None, 0, C.byref(nc))
 
 
 # ---- fft -----------------------------------------------------------------------------------
@@ -248,34 +297,35 @@ class OracleRfft:
 
     def __init__(self, factors, inverse=False):
         arr = (C.c_int * len(factors))(*factors)
-        self._h = lib().orc_rfft_new(arr, len(factors), 1 if inverse else 0)
+        self._L = lib()
+        self._h = self._L.orc_rfft_new(arr, len(factors), 1 if inverse else 0)
         if not self._h:
             raise ValueError("bad factors")
-        self.n = lib().orc_rfft_len(self._h)
+        self.n = self._L.orc_rfft_len(self._h)
         self.inverse = inverse
 
     def __del__(self):
         if getattr(self, "_h", None):
-            lib().orc_rfft_free(self._h)
+            self._L.orc_rfft_free(self._h)
             self._h = None
 
     def stage_factors(self):
         arr = (C.c_int * 32)()
-        n = lib().orc_rfft_stage_factors(self._h, arr)
+        n = self._L.orc_rfft_stage_factors(self._h, arr)
         return list(arr[:n])
 
     def forward(self, x: np.ndarray) -> np.ndarray:
         x = np.ascontiguousarray(x, np.float32)
         assert x.size == self.n and not self.inverse
         out = np.empty(2 * (self.n // 2 + 1), np.float32)
-        lib().orc_rfft_forward(self._h, _f32p(x), _f32p(out))
+        self._L.orc_rfft_forward(self._h, _f32p(x), _f32p(out))
         return out.view(np.complex64)
 
     def inverse_transform(self, X: np.ndarray) -> np.ndarray:
         X = np.ascontiguousarray(X, np.complex64)
         assert X.size == self.n // 2 + 1 and self.inverse
         out = np.empty(self.n, np.float32)
-        lib().orc_rfft_inverse(self._h, _f32p(X.view(np.float32)), _f32p(out))
+        self._L.orc_rfft_inverse(self._h, _f32p(X.view(np.float32)), _f32p(out))
         return out
 
 
@@ -283,33 +333,47 @@ class OracleFft:
     """Mirror of ResamplerFft (resampler_fft.rs:43-240) on the oracle."""
 
     def __init__(self, channels, in_hz, out_hz):
-        self._h = lib().orc_fft_new(channels, in_hz, out_hz)
+        self._L = lib()
+        self._h = self._L.orc_fft_new(channels, in_hz, out_hz)
         if not self._h:
             raise ValueError("invalid ResamplerFft arguments")
         self.channels = channels
 
     def __del__(self):
         if getattr(self, "_h", None):
-            lib().orc_fft_free(self._h)
+            self._L.orc_fft_free(self._h)
             self._h = None
 
     def chunk_size_input(self):
-        return lib().orc_fft_chunk_size_input(self._h)
+        return self._L.orc_fft_chunk_size_input(self._h)
 
     def chunk_size_output(self):
-        return lib().orc_fft_chunk_size_output(self._h)
+        return self._L.orc_fft_chunk_size_output(self._h)
 
     def delay(self):
-        return lib().orc_fft_delay(self._h)
+        return self._L.orc_fft_delay(self._h)
 
     def filter_spectrum(self) -> np.ndarray:
         n = C.c_size_t()
-        p = lib().orc_fft_filter_spectrum(self._h, C.byref(n))
+        p = self._L.orc_fft_filter_spectrum(self._h, C.byref(n))
         return np.ctypeslib.as_array(p, shape=(2 * n.value,)).copy().view(np.complex64)
 
     def resample(self, inp: np.ndarray, out: np.ndarray) -> int:
         inp = np.ascontiguousarray(inp, np.float32)
-        return lib().orc_fft_resample(self._h, _f32p(inp), inp.size, _f32p(out), out.size)
+        return self._L.orc_fft_resample(self._h, _f32p(inp), inp.size, _f32p(out), out.size)
+
+    def resample_all(self, inp: np.ndarray) -> np.ndarray:
+        """resample_batch (resample/src/main.rs:256-313): whole buffer, last chunk zero padded, output trimmed."""
+        inp = np.ascontiguousarray(inp, np.float32)
+        ci, co = self.chunk_size_input(), self.chunk_size_output()
+        out = np.zeros(((inp.size + ci - 1) // ci) * co, np.float32)
+        n = self._L.orc_fft_resample_all(self._h, _f32p(inp), inp.size, _f32p(out), out.size)
+        if n == 0 and inp.size:
+            raise ValueError("orc_fft_resample_all failed")
+        return out[:n]
+
+    def resample_all_into(self, inp: np.ndarray, out: np.ndarray) -> int:
+        return self._L.orc_fft_resample_all(self._h, _f32p(inp), inp.size, _f32p(out), out.size)
 
 
 # ---- resample/src: interpolators and WAV sample conversion ----------------------------------------

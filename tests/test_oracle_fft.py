@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 
 from oracle import pyoracle as o
+from resampler_amd import synth
 
 # (factors for RadixFFT::new) as used by the reference's multi-stage tests plus the production plans
 FACTOR_LISTS = [
@@ -155,3 +156,19 @@ def test_resampler_sizes_and_errors():
     q = o.OracleFft(2, 32000, 16000)
     assert q.resample(np.zeros(q.chunk_size_input(), np.float32),
                       np.zeros(q.chunk_size_output(), np.float32)) in (0, 3)
+
+
+def test_driver_loop_pads_the_tail_and_trims_like_the_cli():
+    # resample_batch (resample/src/main.rs:256-313): complete chunks, the last partial chunk zero padded, output
+    # trimmed to ceil(len * chunk_out / chunk_in)
+    r = o.OracleFft(2, 44100, 48000)
+    ci, co = r.chunk_size_input(), r.chunk_size_output()
+    x = synth.fast_noise(3 * ci + 1000, seed=9)
+    y = r.resample_all(x)
+    assert y.size == int(np.ceil(x.size * co / ci))
+    r2 = o.OracleFft(2, 44100, 48000)
+    want = np.zeros(4 * co, np.float32)
+    xp = np.concatenate([x, np.zeros(4 * ci - x.size, np.float32)])
+    for k in range(4):
+        assert r2.resample(xp[k * ci:(k + 1) * ci], want[k * co:(k + 1) * co]) == 0
+    assert np.array_equal(y, want[:y.size])
