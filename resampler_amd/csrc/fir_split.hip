@@ -63,9 +63,14 @@ __host__ __device__ constexpr uint32_t row_bytes(int planes) { return planes == 
 // samples down to 2^-26 and taps down to 2^-27 keep their full relative precision (fp16 normals start at
 // 2^-14); samples of magnitude >= 16 overflow to infinity there -- the launch's non-finite check then has
 // the item recomputed in the reference's f32 form.
-constexpr float kXScale = 4096.0f;        // 2^12
+constexpr float kXScale = 4096.0f;        // 2^12 (the sample scale of an item without samples; see `peak`)
+#ifndef RSMP_EXP
+#define RSMP_EXP 0   // A/B builds (make exp): timing experiments, never shipped
+#endif
+constexpr uint32_t kPeakHeadroom = 4;     // a predicted scale leaves 2^4 above the pair's latest peak
+constexpr uint32_t kPeakQuiet = 10;       // an item whose peak lies more than 2^-10 below what its scale allows (2^-6 below the prediction) is redone
+constexpr uint32_t kPeakExactMax = 134;   // an exact scale is not taken from samples of 2^8 and above (they overflow the planes: redone)
 constexpr float kCScale = 8192.0f;        // 2^13
-constexpr float kOutScale = 1.0f / (4096.0f * 8192.0f);
 constexpr uint32_t kTouchAhead = 3;                    // items between a touch and the producers' loads of the same frames
 constexpr uint32_t kLdsLimit = 160 * 1024;
 #ifndef RSMP_POLL_SLEEP
@@ -310,7 +315,7 @@ __device__ __forceinline__ const void* uniform_ptr(const void* p) {   // into sc
     // restoring a spilled SGPR -- the many-channel build spills a hundred) the ISA wants five wait states before a
     // vector-memory instruction reads them.  Spent here, tied to the two registers so that nothing moves across.
     // (A one-channel build of this kernel read a stale base -- address 0 + offset -- without them.)
-    // (GUARD: the many-channel build; the two-channel one keeps its pointers in scalar registers throughout)
+    // (every build takes the guard: with the peak bookkeeping the two-channel build spills scalar registers too)
     if constexpr (GUARD) asm volatile("s_nop 4" : "+s"(lo), "+s"(hi));
     return reinterpret_cast<const void*>(static_cast<uint64_t>(hi) << 32 | lo);
 }
@@ -381,6 +386,24 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
     uint32_t* ctrl = reinterpret_cast<uint32_t*>(lds);
     uint32_t* staged = ctrl;        // [slot]: producers that finished staging, cumulative
     uint32_t* done = ctrl + 4;      // [slot]: consumers that finished reading, cumulative
+    // Two-plane split: the image of an item is block floating point -- its samples are scaled by a power of two that
+    // puts the item's peak near the top of the fp16 range before they are cut into planes, so quiet passages, loud ones
+    // and signals far outside [-1, 1] all keep 22 significant bits per sample down to 2^-13 of the item's peak (and
+    // 2^-38 of the peak in absolute terms below that); the consumers undo the scale.  The scale must be the same for
+    // every stager of an item and known before the first conversion:
+    //   * normally it is PREDICTED: every stager adds its share of the item's true peak to `peak[slot]` (one atomic
+    //     max, no waiting); when the consumers have the complete image they copy the final value to `fin[slot]`, and
+    //     the stagers of the item that reuses the slot -- `slots` items later, all of them after the same wait -- read
+    //     it into a running table of the stream's latest peak per channel pair.  The scale of an item allows 2^4 above
+    //     the latest peak of its pair.  A louder item overflows a plane (non-finite sums), a much quieter one is seen by
+    //     the consumers (final peak against the scale used): both mark their outputs for the repair launch
+    //     (fir_nonfinite.h), which evaluates them in the reference's f32 form;
+    //   * an item without history (the first items of a stream in this workgroup) takes the exact peak: the stagers
+    //     meet at a counter (`premax`) after adding their shares.
+    uint32_t* premax = ctrl + 8;    // stagers that have added their share of an item's peak and wait for the others, cumulative
+    uint32_t* peak = ctrl + 12;     // [slot]: (use + 1) << 8 | biased exponent of the peak so far (monotonic: never reset)
+    uint32_t* used = ctrl + 16;     // [slot]: biased exponent the item's scale was derived from (stager 0)
+    uint32_t* fin = ctrl + 20;      // [slot][2]: (stream << 4 | pair) + 1 and final peak exponent of the slot's last item (consumer 0)
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     for (uint32_t i = threadIdx.x; i < (g.lds_bytes + (DIAG && g.wtrace ? 16 * kWtraceSlots * 8 : 0)) / 4; i += blockDim.x)
@@ -428,6 +451,7 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
         const uint32_t P = producer_index(wave);
         const uint32_t half_a = (g.a + 1) / 2;
         const uint32_t n_lane_tasks = 4 * half_a;   // <= 64 * kStagers (split_geometry)
+        const uint32_t n_real = (n_lane_tasks + 63) / 64;   // stagers that have lane tasks (the others only signal)
         // (the lane id behind an optimisation barrier per item: otherwise loop-invariant addressing is
         // hoisted out of the item loop, spilled, and each reload from scratch waits for ALL the
         // prefetches in flight -- scratch loads share the in-order vmcnt)
@@ -495,6 +519,11 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
             // ---- staging (all producers) + one pass of the wrap variant (producers 0-3) ---------------
             uint32_t t = P * 64 + lane;   // (one division for the whole launch)
             const bool real_task = P * 64 < n_lane_tasks;
+            float xs = kXScale;   // two planes: the current item's sample scale (block floating point, see `peak`)
+            uint64_t hist_e = 0;                  // latest final peak exponent per channel pair (8 bits each; 0 = none) ...
+            uint32_t hist_stream = 0xFFFFFFFFu;   // ... of this stream
+            uint32_t n_met = 0;                   // meetings at `premax` so far
+            uint32_t cstream = cu.c.sidx;         // the current item's stream
             if (t >= n_lane_tasks) t = n_lane_tasks - 1;   // surplus lanes repeat the last lane task
             uint32_t tQ = t / half_a;
             uint32_t tK = t - tQ * half_a;
@@ -560,7 +589,7 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
                             // two fp16 planes: h1 = RN16(s), h2 = RN16(s - h1) with s = 2^12 x (s - h1 is exact)
                             float s[5];
 #pragma unroll
-                            for (int i = 0; i < 5; ++i) s[i] = at(i, fr, c) * kXScale;
+                            for (int i = 0; i < 5; ++i) s[i] = at(i, fr, c) * xs;
                             const uint32_t a01 = cvt_pk_f16(s[0], s[1]), a23 = cvt_pk_f16(s[2], s[3]), a4 = cvt_pk_f16(s[4], s[4]);
                             const uint32_t b01 = cvt_pk_f16(s[0] - f16_lo(a01), s[1] - f16_hi(a01));
                             const uint32_t b23 = cvt_pk_f16(s[2] - f16_lo(a23), s[3] - f16_hi(a23));
@@ -597,12 +626,12 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
             auto load_wrap = [&](int ps, const PItem& pi, const StreamCtx& c) {
                 const uint32_t wper = 4 * (pass0 + ps) + (ln >> 4);
                 if constexpr (ROLE != 0) {
-                    const void* base = uniform_ptr<(WIDE != 0)>(c.in + 2 * pi.pair);
+                    const void* base = uniform_ptr<true>(c.in + 2 * pi.pair);
                     const uint32_t off = (pi.off0 + wper * g.a - 1 + wpart * kWrapTaps) * fsb;
 #pragma unroll
                     for (int i = 0; i < kWrapTaps; ++i) gload2(wxw[ps][i], off + i * fsb, base);
                 } else {
-                    const void* base = uniform_ptr<(WIDE != 0)>(c.in);
+                    const void* base = uniform_ptr<true>(c.in);
                     const uint32_t off = (pi.off0 + wper * g.a - 1 + wpart * kWrapTaps) * 8u;
 #pragma unroll
                     for (int i = 0; i < kWrapTaps / 2; ++i) gload4(wx[ps][i], off + i * 16u, base);
@@ -610,7 +639,7 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
                 const int32_t nw = pi.it.n_block0 + static_cast<int32_t>(wper * g.b);
                 const bool in_launch = nw >= 0 && nw < static_cast<int32_t>(c.n_out);
                 const uint32_t K = in_launch ? static_cast<uint32_t>(pi.it.k_block0) + wper : 0u;   // (word 0 always exists)
-                gload1(wword[ps], (K >> 5) * 4u, uniform_ptr<(WIDE != 0)>(c.wrap_bits));
+                gload1(wword[ps], (K >> 5) * 4u, uniform_ptr<true>(c.wrap_bits));
                 wsel[ps] = in_launch ? K & 31u : 32u;
             };
             auto wrap_out = [&](const v2f (&w)[kWrapTaps], uint32_t wper, uint32_t take) {
@@ -639,9 +668,14 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
                 if constexpr (ROLE == 2) pre = pre && ((nxt.pair & 1u) == 0 || (have && loaded));
                 asm volatile("" : "+v"(ln), "+v"(tQ), "+v"(tK));
                 char* img = lds + kImageBase + slot * image_bytes;
+                uint32_t f_id_v = 0, f_e_v = 0;   // what the slot's previous item turned out to peak at (see `fin`)
                 if (have) {
                     wt.event(11);
                     while (lds_load_acquire(done + slot) < n_active * use) __builtin_amdgcn_s_sleep(RSMP_POLL_SLEEP);
+                    if constexpr (PLANES == 2) {   // (requested here, used behind the wait for the loads)
+                        f_id_v = __hip_atomic_load(fin + 2 * slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        f_e_v = __hip_atomic_load(fin + 2 * slot + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
                     wt.event(12);
                 }
                 asm volatile("s_waitcnt vmcnt(0)" : : : "memory");   // the current item's loads (or dummies)
@@ -668,23 +702,83 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
                     asm volatile("" : "+v"(wword[ps]));
                 }
                 if (have && real_task && !(dbg & 1)) {
-                    if (loaded) {
-                        if constexpr (ROLE == 2) {
-                            if constexpr (mono) store_task(img, [&](int i, int fr, int c) { return c == 0 ? xm[i][fr] : (fr == 0 ? xm[i][1] : 0.f); });
-                            else store_task(img, [&](int i, int fr, int c) { return (cpair & 1u) ? xq[i][fr][2 + c] : xq[i][fr][c]; });
-                        }
-                        else store_task(img, [&](int i, int fr, int c) { return x[i][2 * fr + c]; });
-                    } else {
-                        // stream edges: frames outside [hist|in] read as zero; plain loads
-                        v4f e[5];
+                    if (!loaded) {
+                        // stream edges: frames outside [hist|in] read as zero; plain loads into the same registers
 #pragma unroll
                         for (int i = 0; i < 5; ++i) {
                             const int64_t f = ecur.f0 + static_cast<int64_t>((4 * tQ + i) * g.a + 2 * tK);
                             const v2f lo = fetch_edge(ectx, ecur.pair, f), hi = fetch_edge(ectx, ecur.pair, f + 1);
-                            e[i] = v4f{lo.x, lo.y, hi.x, hi.y};
+                            if constexpr (ROLE == 2) {
+                                if constexpr (mono) xm[i] = v2f{lo.x, hi.x};
+                                else {
+                                    xq[i][0] = v4f{lo.x, lo.y, lo.x, lo.y};
+                                    xq[i][1] = v4f{hi.x, hi.y, hi.x, hi.y};
+                                }
+                            } else {
+                                x[i] = v4f{lo.x, lo.y, hi.x, hi.y};
+                            }
                         }
-                        store_task(img, [&](int i, int fr, int c) { return e[i][2 * fr + c]; });
                     }
+                    // at(i, fr, c) = channel c of frame 2K + fr in period 4Q + i
+                    auto at = [&](int i, int fr, int c) -> float {
+                        if constexpr (ROLE == 2) {
+                            if constexpr (mono) return c == 0 ? xm[i][fr] : (fr == 0 ? xm[i][1] : 0.f);
+                            else return (cpair & 1u) ? xq[i][fr][2 + c] : xq[i][fr][c];
+                        } else {
+                            return x[i][2 * fr + c];
+                        }
+                    };
+                    if constexpr (PLANES == 2) {
+                        // what the slot's previous item (`slots` items back) turned out to peak at: into the running table
+                        const uint32_t f_id = __builtin_amdgcn_readfirstlane(f_id_v), f_e = __builtin_amdgcn_readfirstlane(f_e_v);
+                        if (f_id != 0) {
+                            const uint32_t f_stream = (f_id - 1) >> 4, f_pair = (f_id - 1) & 15u;
+                            if (f_stream != hist_stream) {
+                                hist_stream = f_stream;
+                                hist_e = 0;
+                            }
+                            hist_e = (hist_e & ~(0xFFull << (8 * f_pair))) | (static_cast<uint64_t>(f_e) << (8 * f_pair));
+                        }
+                        // the item's peak: this lane's samples, the wave, then (one atomic) every stager's
+                        float m = 0.f;
+#pragma unroll
+                        for (int i = 0; i < 5; ++i)
+#pragma unroll
+                            for (int fr = 0; fr < 2; ++fr)
+#pragma unroll
+                                for (int c = 0; c < (mono ? 1 : 2); ++c) m = __builtin_fmaxf(m, __builtin_fabsf(at(i, fr, c)));
+                        uint32_t mb = __float_as_uint(m);   // (non-negative floats order like their bit patterns; a NaN is left to the sums)
+                        mb = max(mb, static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(mb), 0x128, 0xf, 0xf, false)));
+                        mb = max(mb, static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(mb), 0x124, 0xf, 0xf, false)));
+                        mb = max(mb, static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(mb), 0x122, 0xf, 0xf, false)));
+                        mb = max(mb, static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(mb), 0x121, 0xf, 0xf, false)));
+                        const uint32_t wm = max(max(static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(mb), 0)),
+                                                    static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(mb), 16))),
+                                                max(static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(mb), 32)),
+                                                    static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(mb), 48))));
+                        if (lane == 0)
+                            (void)__hip_atomic_fetch_max(peak + slot, ((use + 1) << 8) | (wm >> 23), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        const uint32_t e_hist = hist_stream == cstream ? static_cast<uint32_t>(hist_e >> (8 * cpair)) & 255u : 0u;
+                        uint32_t E;
+                        if (e_hist != 0) {   // predicted: 2^4 above the pair's latest peak
+                            E = e_hist + kPeakHeadroom;
+                            E = E > 254u ? 254u : E;
+                        } else {             // no history: the exact peak, once every stager has added its share
+                            // (one monotonic counter for all slots: nobody gets past meeting k before every stager has
+                            // arrived at it, so arrivals at meeting k + 1 cannot be taken for arrivals at k)
+                            lds_signal(premax);
+                            ++n_met;
+                            while (lds_load_acquire(premax) < n_real * n_met) __builtin_amdgcn_s_sleep(RSMP_POLL_SLEEP);
+                            E = __hip_atomic_load(peak + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) & 255u;
+                            E = E > kPeakExactMax ? kPeakExactMax : E;   // (a lone outlier must overflow, not push the rest of the item below the planes)
+                        }
+                        E = __builtin_amdgcn_readfirstlane(E < 31u ? 31u : E);   // (below 2^-96: treated as that)
+                        // a peak in [2^(E-127), 2^(E-126)) times 2^(141-E) lies in [2^14, 2^15), inside fp16
+                        xs = __uint_as_float((268u - E) << 23);
+                        if (P == 0 && lane == 0) used[slot] = E;
+                        wt.event(9);
+                    }
+                    store_task(img, at);
                 }
                 if (have && wrapper) {
                     wt.event(13);
@@ -733,10 +827,10 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
                 if (pre) {
                     if constexpr (ROLE == 2) {
                         if constexpr (mono) {
-                            if (real_task) load_task_mono(xm, nxt, uniform_ptr<(WIDE != 0)>(cu.c.in));
-                        } else if (real_task && (nxt.pair & 1u) == 0) load_task_wide(xq, nxt, uniform_ptr<(WIDE != 0)>(cu.c.in + 2 * nxt.pair));
+                            if (real_task) load_task_mono(xm, nxt, uniform_ptr<true>(cu.c.in));
+                        } else if (real_task && (nxt.pair & 1u) == 0) load_task_wide(xq, nxt, uniform_ptr<true>(cu.c.in + 2 * nxt.pair));
                     } else if constexpr (ROLE == 0) {
-                        if (real_task) load_task(x, true, nxt, uniform_ptr<(WIDE != 0)>(cu.c.in));
+                        if (real_task) load_task(x, true, nxt, uniform_ptr<true>(cu.c.in));
                     }
 #pragma unroll
                     for (int ps = 0; ps < kMaxPass; ++ps)
@@ -759,6 +853,7 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
                 }
                 if (more) {
                     cpair = nxt.pair;
+                    cstream = cu.c.sidx;
                     nxt = find_next();
                 }
                 if (have) wt.event(5);
@@ -912,9 +1007,18 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        bool item_bad = false;   // (wave-uniform) the item's scale was off: its outputs are redone by the repair launch
         if constexpr (PLANES == 2) {
-            acc0 *= kOutScale;
-            acc1 *= kOutScale;
+            const uint32_t e_used = __builtin_amdgcn_readfirstlane(__hip_atomic_load(used + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+            const uint32_t e_act = __builtin_amdgcn_readfirstlane(__hip_atomic_load(peak + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) & 255u;
+            item_bad = e_act != 0 && e_act + kPeakQuiet < e_used;
+            if (T == 0 && lane == 0) {   // for the stagers of the item that takes this slot next (read behind their wait for `done`)
+                fin[2 * slot] = ((d.sidx << 4) | (WIDE ? cu.cur_pair : 0u)) + 1u;
+                fin[2 * slot + 1] = e_act;
+            }
+            const float os = __uint_as_float((e_used - 27u) << 23);   // 2^(E-141): the item's scale undone; 2^-13: the taps'
+            acc0 *= os;
+            acc1 *= os;
         }
         if (!WIDE || (cu.cur_pair & 1u) == 0) flush_pending();   // (no MFMA loop ran, or the experiment switch above)
         // class 0 may take the wrap variant the producers left with the image (tile 0, D row 0)
@@ -933,7 +1037,7 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
         const int32_t n_limit = static_cast<int32_t>(d.n_out);
         // a non-finite sum (inf / NaN sample, or one too large for the 16-bit planes): the chunk is redone
         // in the reference's form by the repair launch
-        nf_mark(g.nf, nf_is_bad(mono || phantom(cu.cur_pair) ? (acc0.x + acc0.y) + (acc0.z + acc0.w) : nf_sum8(acc0, acc1)), d.sidx, n0, 4, n_limit);
+        nf_mark(g.nf, item_bad || nf_is_bad(mono || phantom(cu.cur_pair) ? (acc0.x + acc0.y) + (acc0.z + acc0.w) : nf_sum8(acc0, acc1)), d.sidx, n0, 4, n_limit);
         g_f32_ptr o = (g_f32_ptr)d.out + static_cast<int64_t>(n0) * fs + (WIDE ? 2 * cu.cur_pair : 0u);
         const v4f lo = v4f{acc0.x, acc1.x, acc0.y, acc1.y};
         const v4f hi = v4f{acc0.z, acc1.z, acc0.w, acc1.w};

@@ -60,7 +60,7 @@ def fir_config(name, ch, in_hz, out_hz, att_db, x, chunk, kind=o.CONVOLVE_SCALAR
 
 
 def main():
-    fx = {"generator": "tests/golden/make_fixtures.py", "oracle": "oracle/*.c (scalar convolve; AVX+FMA differs in rounding only)"}
+    fx = {"generator": "tests/golden/make_fixtures.py", "oracle": "oracle/*.c (c1 .. c5: scalar convolve; *_avx_fma and c4_256: convolve_interp_avx_fma)"}
     # C1: 1 ch 48000 -> 44100, Sample64 / Db90, 512-sample calls, 2^20-frame sweep
     fx["c1"] = fir_config("c1", 1, 48000, 44100, 90, synth.sweep(1 << 20, 1, 48000.0), 512)
     # C2: 2 ch 44100 -> 48000, 128 taps, 2^20-frame sweep, the CLI's 512-value calls
@@ -102,6 +102,29 @@ def main():
                 "sha256_of_stream_sha256s": all_hash.hexdigest()}
     # C5: 8 ch 96000 -> 44100, 128 taps, Db120, 512-frame chunks (64 of them)
     fx["c5"] = fir_config("c5", 8, 96000, 44100, 120, synth.hash_noise(64 * 512 * 8, seed=5), 512 * 8)
+    # C2 / C5 again through convolve_interp_avx_fma (src/fir/avx.rs:5-61) -- the CPU SIMD path north_star names; its
+    # lane structure and FMAs are exact operations, so every CPU with AVX + FMA returns these bits
+    assert o.have_avx_fma(), "fixtures are generated on a CPU with AVX + FMA"
+    fx["c2_avx_fma"] = fir_config("c2_avx_fma", 2, 44100, 48000, 90, synth.sweep(1 << 20, 2, 44100.0), 512, o.CONVOLVE_AVX_FMA)
+    fx["c5_avx_fma"] = fir_config("c5_avx_fma", 8, 96000, 44100, 120, synth.hash_noise(64 * 512 * 8, seed=5), 512 * 8,
+                                  o.CONVOLVE_AVX_FMA)
+    # C4 at its full length (256 steps) for two streams of every rate pair, AVX + FMA path
+    long_detail = []
+    for i in list(range(12)):
+        s = specs[i]
+        r = o.OracleFir(2, s.in_hz, s.out_hz, 128, 90, o.CONVOLVE_AVX_FMA)
+        x = synth.hash_noise(256 * 512 * 2, seed=i)
+        out = np.zeros(r.buffer_size_output(), np.float32)
+        ys, counts = [], []
+        for k in range(256):
+            rc, c, p = r.resample(x[k * 1024:(k + 1) * 1024], out)
+            assert rc == 0
+            counts.append([c, p])
+            ys.append(out[:p].copy())
+        y = np.concatenate(ys)
+        long_detail.append({"index": i, "in_hz": s.in_hz, "out_hz": s.out_hz, "counts_rle": rle(np.array(counts)),
+                            "sha256": sha(y), "head": pack(y[:256]), "tail": pack(y[-256:]), "final_state": list(r.state())})
+    fx["c4_256"] = {"name": "c4_256", "steps": 256, "frames_per_step": 512, "detail": long_detail}
     path = os.path.join(ROOT, "tests", "golden", "config_fixtures.json")
     with open(path, "w") as fh:
         json.dump(fx, fh)

@@ -23,11 +23,16 @@ def rms(a, b):
     return float(np.sqrt(np.mean((a.astype(np.float64) - b.astype(np.float64)) ** 2)))
 
 
+ORACLE_KIND = o.CONVOLVE_AVX_FMA if o.have_avx_fma() else o.CONVOLVE_SCALAR   # north_star: "matches the reference CPU SIMD path"
+
+
 def make_pair(ch, in_hz, out_hz, lat=ra.Latency.Sample64, att=ra.Attenuation.Db90, kernel=None):
+    """The HIP resampler and the oracle on convolve_interp_avx_fma (src/fir/avx.rs:5-61), the path north_star names
+    (scalar spec, src/fir/mod.rs:47-62, on a CPU without AVX + FMA)."""
     g = ra.ResamplerFir.new_from_hz(ch, in_hz, out_hz, lat, att)
     if kernel is not None:
         g.set_kernel(kernel)
-    r = o.OracleFir(ch, in_hz, out_hz, lat.taps(), ATT_DB[att])
+    r = o.OracleFir(ch, in_hz, out_hz, lat.taps(), ATT_DB[att], ORACLE_KIND)
     return g, r
 
 
@@ -194,7 +199,8 @@ def test_bulk_periodic_other_tap_counts(taps_lat):
 
 
 def test_c2_full_size_bulk_parity_and_max_abs():
-    # BASELINE config 2: 2 ch interleaved 44100 -> 48000, 128 taps, 2^20-frame sine sweep.
+    # BASELINE config 2: 2 ch interleaved 44100 -> 48000, 128 taps, 2^20-frame sine sweep, against the oracle's
+    # convolve_interp_avx_fma (the CPU SIMD path north_star names; make_pair).
     g, r = make_pair(2, 44100, 48000)
     x = synth.sweep(1 << 20, 2, 44100.0)
     yg, consumed, calls_g = g.resample_bulk(x, 512, want_calls=True)
@@ -206,6 +212,45 @@ def test_c2_full_size_bulk_parity_and_max_abs():
     assert float(np.max(np.abs(yg.astype(np.float64) - yr))) < 2e-5
     if os.environ.get("RSMP_FIR_MFMA", "3") == "3":
         assert g.kernel_variant() == SPLIT_VARIANT   # the full-size config runs on the split matrix kernel (the bench's kernel)
+
+
+def rel_rms(a, b):
+    return rms(a, b) / max(float(np.sqrt(np.mean(b.astype(np.float64) ** 2))), 1e-300)
+
+
+@pytest.mark.parametrize("ch,in_hz,out_hz", [(2, 44100, 48000), (2, 48000, 44100), (4, 44100, 48000), (8, 48000, 44100),
+                                             (1, 48000, 44100), (3, 44100, 48000), (8, 96000, 44100), (2, 44100, 96000),
+                                             (2, 48000, 96000), (2, 96000, 48000)])
+@pytest.mark.parametrize("level", ["2^-10", "2^-17", "2^-24", "1e-30", "3e4", "mix"])
+def test_quiet_and_loud_signals_keep_their_relative_precision(ch, in_hz, out_hz, level):
+    """The gate is 1e-6 RMS on full-scale audio; a drop-in for an f32 resampler must hold it RELATIVE to the signal at
+    any level: the C2 sweep scaled by 2^-10, 2^-17, 2^-24 (one f32 ulp of full scale), 1e-30, 3e4 (far outside
+    [-1, 1]), and a full-scale sweep carrying a -100 dBFS one ("mix": after subtracting the loud part's own output the
+    quiet part must still be there to 1e-3 of ITS level).  The split matrix kernels cut every item's samples into two
+    fp16 planes as block floating point (fir_split.hip, `peak`), so all of these keep f32-class precision."""
+    g, r = make_pair(ch, in_hz, out_hz, kernel=ra.FirKernel.Periodic)
+    n = 70000
+    x = synth.sweep(n, ch, float(in_hz))
+    if level == "mix":
+        q = synth.fast_noise(n * ch, seed=11) * np.float32(1e-5)
+        xm = (x + q).astype(np.float32)
+        yg, _ = g.resample_bulk(xm, 512 - 512 % ch)
+        yr, _ = r.resample_all(xm, 512 - 512 % ch)
+        assert yg.size == yr.size and rel_rms(yg, yr) <= RMS_TOL
+        # the quiet component alone: the oracle's response to (x + q) minus its response to x
+        r2 = o.OracleFir(ch, in_hz, out_hz, 128, 90, ORACLE_KIND)
+        y0, _ = r2.resample_all(x, 512 - 512 % ch)
+        quiet_ref = yr.astype(np.float64) - y0
+        quiet_got = yg.astype(np.float64) - y0
+        # (what is left is the f32 rounding of the loud part, ~1e-7 of ITS level)
+        assert rms(quiet_got, quiet_ref) <= max(2e-2 * float(np.sqrt(np.mean(quiet_ref ** 2))), 3e-7 * float(np.sqrt(np.mean(yr.astype(np.float64) ** 2))))
+        return
+    scale = {"2^-10": 2.0 ** -10, "2^-17": 2.0 ** -17, "2^-24": 2.0 ** -24, "1e-30": 1e-30, "3e4": 3e4}[level]
+    xs = (x * np.float32(scale)).astype(np.float32)
+    yg, consumed = g.resample_bulk(xs, 512 - 512 % ch)
+    yr, _ = r.resample_all(xs, 512 - 512 % ch)
+    assert consumed == xs.size and yg.size == yr.size
+    assert rel_rms(yg, yr) <= RMS_TOL, (level, rel_rms(yg, yr))
 
 
 def test_device_resident_api_and_batch():

@@ -47,15 +47,17 @@ def expand(rle):
 def fir_input(name):
     if name == "c1":
         return synth.sweep(1 << 20, 1, 48000.0)
-    if name == "c2":
+    if name.startswith("c2"):
         return synth.sweep(1 << 20, 2, 44100.0)
     return synth.hash_noise(64 * 512 * 8, seed=5)
 
 
 def check_oracle(fx):
-    for name in ("c1", "c2", "c5"):
+    names = ("c1", "c2", "c5") + (("c2_avx_fma", "c5_avx_fma") if o.have_avx_fma() else ())
+    for name in names:
         c = fx[name]
-        r = o.OracleFir(c["channels"], c["in_hz"], c["out_hz"], c["taps"], c["attenuation_db"])
+        kind = o.CONVOLVE_AVX_FMA if name.endswith("avx_fma") else o.CONVOLVE_SCALAR
+        r = o.OracleFir(c["channels"], c["in_hz"], c["out_hz"], c["taps"], c["attenuation_db"], kind)
         assert sha(r.coeffs()) == c["table_sha256"], name       # the polyphase table, bit for bit
         y, calls = r.resample_all(fir_input(name), c["chunk_values"])
         assert y.size == c["out_values"] and np.array_equal(calls, expand(c["calls_rle"])), name
@@ -92,6 +94,20 @@ def check_oracle(fx):
         if i in detail:
             assert counts == detail[i]["counts"] and digest == detail[i]["sha256"], i
     assert all_hash.hexdigest() == c4["sha256_of_stream_sha256s"]
+    if o.have_avx_fma():   # config 4 at its full length (256 steps), two streams of every rate pair, AVX + FMA path
+        c4l = fx["c4_256"]
+        for d in c4l["detail"]:
+            r = o.OracleFir(2, d["in_hz"], d["out_hz"], 128, 90, o.CONVOLVE_AVX_FMA)
+            x = synth.hash_noise(c4l["steps"] * 1024, seed=d["index"])
+            out = np.zeros(r.buffer_size_output(), np.float32)
+            ys, counts = [], []
+            for k in range(c4l["steps"]):
+                rc, c, p = r.resample(x[k * 1024:(k + 1) * 1024], out)
+                assert rc == 0
+                counts.append([c, p])
+                ys.append(out[:p].copy())
+            assert np.array_equal(np.array(counts), expand(d["counts_rle"])), d["index"]
+            assert sha(np.concatenate(ys)) == d["sha256"] and list(r.state()) == d["final_state"], d["index"]
 
 
 def test_oracle_reproduces_the_golden_configs(fx):
@@ -115,7 +131,7 @@ def test_oracle_reproduces_the_golden_configs_on_the_gpu_box(fx):
 def test_hip_path_against_the_golden_configs(fx):
     att = {90: ra.Attenuation.Db90, 120: ra.Attenuation.Db120}
     # C1 / C2 / C5 through the bulk driver (the reference loop with the config's call size)
-    for name in ("c1", "c2", "c5"):
+    for name in ("c1", "c2", "c5", "c2_avx_fma", "c5_avx_fma"):   # (*_avx_fma: the CPU SIMD path north_star names)
         c = fx[name]
         g = ra.ResamplerFir.new_from_hz(c["channels"], c["in_hz"], c["out_hz"], ra.Latency.Sample64, att[c["attenuation_db"]])
         assert g.buffer_size_output() == c["buffer_size_output"]
@@ -171,3 +187,61 @@ def test_hip_path_against_the_golden_configs(fx):
         y = d_out[i][:total].cpu().numpy()
         head, tail = unpack(d["head"]), unpack(d["tail"])
         assert rms(y[:head.size], head) <= RMS_TOL and rms(y[-tail.size:], tail) <= RMS_TOL, i
+    ls.close()
+
+
+@pytest.mark.gpu
+def test_config4_at_its_full_length(fx):
+    """BASELINE config 4 as stated: 1024 mixed-rate streams x 256 lock-step steps of 512 frames.  Every stream's
+    (consumed, produced) of every step against the host mirror of the reference state machine (exact, no samples);
+    samples, counts and the final state of two streams per rate pair against the frozen AVX+FMA oracle run
+    (fixture c4_256), and of 18 more streams spread over the batch against the oracle run here."""
+    import torch
+    dev = torch.device("cuda:0")
+    c4l = fx["c4_256"]
+    n, steps, frames = 1024, c4l["steps"], c4l["frames_per_step"]
+    specs = sharding.mixed_rate_batch(n, 2, frames)
+    hs = [ra.ResamplerFir.new_from_hz(2, s.in_hz, s.out_hz, ra.Latency.Sample64, ra.Attenuation.Db90) for s in specs]
+    checked = sorted(set(d["index"] for d in c4l["detail"]) | set(range(100, 1024, 53)))
+    caps = [h.buffer_size_output() for h in hs]
+    # every stream reads its own input and appends its outputs (at most ceil(512 * out / in) + 1 frames per step)
+    d_in = [torch.from_numpy(synth.hash_noise(steps * frames * 2, seed=i)).to(dev) for i in range(n)]
+    room = [steps * 2 * (frames * s.out_hz // s.in_hz + 2) + caps[i] for i, s in enumerate(specs)]
+    d_out = [torch.zeros(room[i], device=dev) for i in range(n)]
+    plans = [ra.FirPlan(s.in_hz, s.out_hz, ra.Latency.Sample64) for s in specs[:6]]   # one per rate pair
+    want_counts = []
+    for i, pl in enumerate(plans):
+        per = []
+        for k in range(steps):
+            acc, prod = pl.call(frames, caps[i] // 2)
+            per.append((acc * 2, prod * 2))
+        want_counts.append(per)
+    ls = ra.FirLockstep(hs, frames)
+    ls.bind_caps(d_in, d_out, caps)
+    got = {i: [] for i in checked}
+    for k in range(steps):
+        ls.step(frames, k * frames, append=True)
+        cons, prod = ls.counts()
+        for i in range(n):
+            assert (int(cons[i]), int(prod[i])) == want_counts[i % 6][k], (i, k)
+        for i in checked:
+            got[i].append([int(cons[i]), int(prod[i])])
+    detail = {d["index"]: d for d in c4l["detail"]}
+    for i in checked:
+        total = sum(p for _, p in got[i])
+        y = d_out[i][:total].cpu().numpy()
+        if i in detail:
+            d = detail[i]
+            assert np.array_equal(np.array(got[i]), expand(d["counts_rle"])), i
+            head, tail = unpack(d["head"]), unpack(d["tail"])
+            assert rms(y[:head.size], head) <= RMS_TOL and rms(y[-tail.size:], tail) <= RMS_TOL, i
+        r = o.OracleFir(2, specs[i].in_hz, specs[i].out_hz, 128, 90, o.CONVOLVE_AVX_FMA if o.have_avx_fma() else o.CONVOLVE_SCALAR)
+        x = synth.hash_noise(steps * frames * 2, seed=i)
+        out = np.zeros(caps[i], np.float32)
+        ys = []
+        for k in range(steps):
+            rc, c, p = r.resample(x[k * 1024:(k + 1) * 1024], out)
+            assert rc == 0 and [c, p] == got[i][k], (i, k)
+            ys.append(out[:p].copy())
+        assert rms(y, np.concatenate(ys)) <= RMS_TOL, i
+    ls.close()
