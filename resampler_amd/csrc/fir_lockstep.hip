@@ -54,8 +54,8 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef const v4u __attribute__((address_space(1)))* gconst_u4_ptr;
 typedef const v2f __attribute__((address_space(1)))* gconst_f2_ptr;
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
-constexpr float kLsXScale = 4096.0f;                               // samples: 2^12 (taps: 2^13, in the table)
-constexpr float kLsOutScale = 1.0f / (4096.0f * 8192.0f);
+// samples: block floating point per column (`colpeak`), as fir_split.hip per item; taps: 2^13, in the table
+constexpr uint32_t kLsPeakExactMax = 134;                          // a column's scale is not taken from samples of 2^8 and above (they overflow: reference form)
 constexpr uint32_t kLsPlanner = kLsWaves - 1;                      // the wave that plans the next step
 constexpr uint32_t kLsStagers = kLsWaves - 2;                      // waves 1 .. kLsStagers stage the frames
 constexpr uint32_t kLsSyncBytes = 32;                              // n_cols, unit counter, image counter, early flag, ready counter
@@ -88,7 +88,8 @@ struct PlanLds {             // one stream's step, in LDS
 };
 static_assert(sizeof(PlanLds) == 64, "PlanLds layout");
 
-static_assert(sizeof(FirMirrorState) <= 96, "state stash slots are 96 bytes");
+static_assert(sizeof(FirMirrorState) == 88, "the stash holds 16 states of 88 bytes in 16 x 96 bytes: the last 128 bytes are the column peaks");
+constexpr uint32_t kLsPeakOff = kLsMaxSlots * 64 + kLsSyncBytes + kLsMaxSlots * 88;   // colpeak[16], peak counter (17 of the 32 spare words)
 
 struct ColLds {              // one column of the matrix product: super period q of a stream
     int32_t frame0;          // span-relative frame of absolute input frame q * a
@@ -206,7 +207,7 @@ __device__ __forceinline__ float ls_f16_hi(uint32_t w) { return static_cast<floa
 template <uint32_t NK, uint32_t ROWB>   // 32-tap steps of the tile window and the row pitch: compile-time, so that step s + 1's
                                         // reads are in flight under step s's MFMAs and every offset is an immediate
 __device__ __forceinline__ void unit_mfma_split_nk(const v4f (&a_reg)[kLsMaxBlk], char* lds, uint32_t image_off,
-                                                   uint32_t base_row, uint32_t lane, v4f& acc0, v4f& acc1) {
+                                                   uint32_t base_row, uint32_t lane, float os, v4f& acc0, v4f& acc1) {
     const uint32_t grp = lane >> 4, q = (lane >> 2) & 3, pc = lane & 3;
     const uint32_t row0 = base_row + 4 * grp + q;
     const uint32_t base = image_off + row0 * ROWB + ((pc ^ ((row0 >> 2) & 3)) << 3);
@@ -227,26 +228,31 @@ __device__ __forceinline__ void unit_mfma_split_nk(const v4f (&a_reg)[kLsMaxBlk]
         acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(c1, x1, acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(c1, y1, acc1, 0, 0, 0);
     }
-    acc0 *= kLsOutScale;
-    acc1 *= kLsOutScale;
+    acc0 *= os;   // the lane's column's scale and the taps' 2^13, undone
+    acc1 *= os;
 }
 template <uint32_t ROWB>
 __device__ __forceinline__ void unit_mfma_split_rb(const v4f (&a_reg)[kLsMaxBlk], uint32_t nk, char* lds, uint32_t image_off,
-                                                   uint32_t base_row, uint32_t lane, v4f& acc0, v4f& acc1) {
+                                                   uint32_t base_row, uint32_t lane, float os, v4f& acc0, v4f& acc1) {
     switch (nk) {   // (workgroup-uniform)
-        case 1: unit_mfma_split_nk<1, ROWB>(a_reg, lds, image_off, base_row, lane, acc0, acc1); break;
-        case 2: unit_mfma_split_nk<2, ROWB>(a_reg, lds, image_off, base_row, lane, acc0, acc1); break;
-        case 3: unit_mfma_split_nk<3, ROWB>(a_reg, lds, image_off, base_row, lane, acc0, acc1); break;
-        case 4: unit_mfma_split_nk<4, ROWB>(a_reg, lds, image_off, base_row, lane, acc0, acc1); break;
-        case 5: unit_mfma_split_nk<5, ROWB>(a_reg, lds, image_off, base_row, lane, acc0, acc1); break;
-        default: unit_mfma_split_nk<kLsMaxK32, ROWB>(a_reg, lds, image_off, base_row, lane, acc0, acc1); break;
+        case 1: unit_mfma_split_nk<1, ROWB>(a_reg, lds, image_off, base_row, lane, os, acc0, acc1); break;
+        case 2: unit_mfma_split_nk<2, ROWB>(a_reg, lds, image_off, base_row, lane, os, acc0, acc1); break;
+        case 3: unit_mfma_split_nk<3, ROWB>(a_reg, lds, image_off, base_row, lane, os, acc0, acc1); break;
+        case 4: unit_mfma_split_nk<4, ROWB>(a_reg, lds, image_off, base_row, lane, os, acc0, acc1); break;
+        case 5: unit_mfma_split_nk<5, ROWB>(a_reg, lds, image_off, base_row, lane, os, acc0, acc1); break;
+        default: unit_mfma_split_nk<kLsMaxK32, ROWB>(a_reg, lds, image_off, base_row, lane, os, acc0, acc1); break;
     }
 }
 __device__ __forceinline__ void unit_mfma_split(const v4f (&a_reg)[kLsMaxBlk], uint32_t nk, uint32_t row_bytes, char* lds,
-                                                uint32_t image_off, uint32_t base_row, uint32_t lane, v4f& acc0, v4f& acc1) {
-    if (row_bytes == kLsImageRowBytes) unit_mfma_split_rb<kLsImageRowBytes>(a_reg, nk, lds, image_off, base_row, lane, acc0, acc1);
-    else unit_mfma_split_rb<kLsImageRowBytesPacked>(a_reg, nk, lds, image_off, base_row, lane, acc0, acc1);
+                                                uint32_t image_off, uint32_t base_row, uint32_t lane, float os, v4f& acc0, v4f& acc1) {
+    if (row_bytes == kLsImageRowBytes) unit_mfma_split_rb<kLsImageRowBytes>(a_reg, nk, lds, image_off, base_row, lane, os, acc0, acc1);
+    else unit_mfma_split_rb<kLsImageRowBytesPacked>(a_reg, nk, lds, image_off, base_row, lane, os, acc0, acc1);
 }
+// the scale of a column whose largest sample has biased exponent e (clamped: see colpeak): 2^(141 - e) puts that
+// sample into [2^14, 2^15), inside fp16; and the factor that takes the column's sums back (2^13: the taps)
+__device__ __forceinline__ uint32_t ls_peak_clamp(uint32_t e) { return e < 31u ? 31u : (e > kLsPeakExactMax ? kLsPeakExactMax : e); }
+__device__ __forceinline__ float ls_col_scale(uint32_t e) { return __uint_as_float((268u - ls_peak_clamp(e)) << 23); }
+__device__ __forceinline__ float ls_col_unscale(uint32_t e) { return __uint_as_float((ls_peak_clamp(e) - 27u) << 23); }
 
 // Frame f (relative to the first buffered frame) of a stream's [buffered | new] frames, channel c: from the
 // LDS span (zeroed guards around it), or -- split variant, which keeps no f32 copy in LDS -- from HBM.
@@ -311,8 +317,64 @@ __global__ __launch_bounds__(kLsWaves * 64, kLsWaves / 2) void fir_lockstep_kern
     // src: lane c < 16 holds column c's ColSrc (8 words).
     const uint32_t image_off = lay.spans;
     const bool aligned8 = args.in_aligned8 != 0;
+    // Block floating point per stream: before they cut frames into planes the staging waves scan every stream's
+    // [buffered | new] span once (coalesced 8-byte loads, the image's loads then hit L2), agree on its largest magnitude
+    // (an atomic max per column in LDS and a count the six of them wait for) and scale the stream's columns by the power
+    // of two that puts that peak just below the top of the fp16 range -- a quiet stream next to a loud one, or one far
+    // outside [-1, 1], keeps 22 significant bits per sample.
+    uint32_t* colpeak = reinterpret_cast<uint32_t*>(lds + kLsPeakOff);   // [16]: bits of the largest |sample| of the column's stream; [16]: the count
     auto write_image = [&](const uint32_t (&src)[8]) {
-        for (uint32_t r = threadIdx.x - 64; r < g.rows; r += kLsStagers * 64) {
+        const uint32_t t0 = threadIdx.x - 64;
+        {
+            uint32_t colpk = 0;   // lane c < 16: this wave's share of column c's stream's peak
+            uint32_t prev_lo = 0, prev_hi = 0, pv = 0;
+#pragma unroll 1
+            for (uint32_t c = 0; c < 16; ++c) {
+                auto word = [&](int k) -> uint32_t { return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(src[k]), static_cast<int>(c))); };
+                const uint32_t h_lo = word(0), h_hi = word(1);
+                const uint32_t span_fr = word(6);
+                if (c == 0 || h_lo != prev_lo || h_hi != prev_hi) {   // (the columns of a stream are neighbours: one scan per stream)
+                    prev_lo = h_lo;
+                    prev_hi = h_hi;
+                    gconst_f32_ptr hist = (gconst_f32_ptr) reinterpret_cast<const float*>((static_cast<uint64_t>(h_hi) << 32) | h_lo);
+                    gconst_f32_ptr in = (gconst_f32_ptr) reinterpret_cast<const float*>((static_cast<uint64_t>(word(3)) << 32) | word(2));
+                    const uint32_t hist_fr = word(5);
+                    float m = 0.f;
+                    for (uint32_t f = t0; f < span_fr; f += kLsStagers * 64) {
+                        gconst_f32_ptr p = f < hist_fr ? hist + 2 * f : in + 2 * (f - hist_fr);
+                        float a, b;
+                        if (aligned8) {
+                            const v2f v = *(gconst_f2_ptr)p;
+                            a = v.x;
+                            b = v.y;
+                        } else {
+                            a = p[0];
+                            b = p[1];
+                        }
+                        m = __builtin_fmaxf(m, __builtin_fmaxf(__builtin_fabsf(a), __builtin_fabsf(b)));   // (a NaN is left to the sums)
+                    }
+                    uint32_t mb = __float_as_uint(m);   // (non-negative floats order like their bit patterns)
+                    mb = max(mb, static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(mb), 0x128, 0xf, 0xf, false)));
+                    mb = max(mb, static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(mb), 0x124, 0xf, 0xf, false)));
+                    mb = max(mb, static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(mb), 0x122, 0xf, 0xf, false)));
+                    mb = max(mb, static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(mb), 0x121, 0xf, 0xf, false)));
+                    pv = max(max(static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(mb), 0)),
+                                 static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(mb), 16))),
+                             max(static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(mb), 32)),
+                                 static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(mb), 48))));
+                }
+                colpk = lane == c ? pv : colpk;
+            }
+            if (lane < 16 && colpk != 0)
+                (void)__hip_atomic_fetch_max(colpeak + lane, colpk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        // the six staging waves meet: every share of every stream's peak is in
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) (void)__hip_atomic_fetch_add(colpeak + 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        while (__hip_atomic_load(colpeak + 16, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < kLsStagers) __builtin_amdgcn_s_sleep(1);
+        uint32_t xsv = __float_as_uint(ls_col_scale(__hip_atomic_load(colpeak + (lane & 15u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> 23));
+        asm volatile("" : "+v"(xsv));   // lane c < 16: column c's scale (defined under the full EXEC mask: read by lane index below)
+        for (uint32_t r = t0; r < g.rows; r += kLsStagers * 64) {
             // every column's frame of this row is requested before the first is converted: one memory
             // latency per row block, not one per column
             float x0[16], x1[16];
@@ -350,7 +412,8 @@ __global__ __launch_bounds__(kLsWaves * 64, kLsWaves / 2) void fir_lockstep_kern
             const uint32_t sw = (r >> 2) & 3;
 #pragma unroll
             for (uint32_t c = 0; c < 16; ++c) {
-                const float s0 = x0[c] * kLsXScale, s1 = x1[c] * kLsXScale;
+                const float xs = __uint_as_float(static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(xsv), c)));
+                const float s0 = x0[c] * xs, s1 = x1[c] * xs;
                 const uint32_t hi = ls_cvt_pk_f16(s0, s1);
                 const uint32_t lo = ls_cvt_pk_f16(s0 - ls_f16_lo(hi), s1 - ls_f16_hi(hi));
                 char* e = row + ((((c >> 2) ^ sw) << 3) + (c & 3) * 2);
@@ -368,6 +431,7 @@ __global__ __launch_bounds__(kLsWaves * 64, kLsWaves / 2) void fir_lockstep_kern
     // The sync words start at zero (unit counter, image counter, early flag, ready counter): the only
     // workgroup barrier before the final one -- every wave is here at once.
     if (threadIdx.x < kLsSyncBytes / 4) n_cols_p[threadIdx.x] = 0;
+    if (threadIdx.x >= 64 && threadIdx.x < 64 + 17) reinterpret_cast<uint32_t*>(lds + kLsPeakOff)[threadIdx.x - 64] = 0;   // column peaks, their count
     __syncthreads();
 
     // The NEXT step's plan (the reference's control flow for step k + 1, ~20 k cycles of serial f64 arithmetic
@@ -737,7 +801,8 @@ __global__ __launch_bounds__(kLsWaves * 64, kLsWaves / 2) void fir_lockstep_kern
                 const bool two = c0 + 1 < C;
                 v4f acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
                 if (split) {
-                    unit_mfma_split(a_reg, g.row_len / 32, g.row_bytes, lds, image_off, tile_base, lane, acc0, acc1);
+                    unit_mfma_split(a_reg, g.row_len / 32, g.row_bytes, lds, image_off, tile_base, lane,
+                                    ls_col_unscale(colpeak[lane & 15u] >> 23), acc0, acc1);
                 } else if (two && pair_ok) {
                     unit_mfma<2>(a_reg, nblk, xb + c0, C, acc0, acc1);
                 } else {

@@ -24,7 +24,7 @@ def rms(a, b):
 
 
 def run_lockstep(specs, steps, frames, seed=0, lat=ra.Latency.Sample64, att=ra.Attenuation.Db90,
-                 prefeed=None, in_frames_per_stream=None, x_override=None, append=True, exact=None):
+                 prefeed=None, in_frames_per_stream=None, x_override=None, append=True, exact=None, relative=False):
     """Runs `steps` lock-step steps of `frames` frames over the streams in `specs` on the GPU and the same
     calls through one OracleFir per stream.  Returns the worst RMS error over the streams; asserts equal
     counts at every step.  prefeed[i]: frames pushed through stream i with ordinary resample() calls
@@ -37,7 +37,8 @@ def run_lockstep(specs, steps, frames, seed=0, lat=ra.Latency.Sample64, att=ra.A
         for i, h in enumerate(hs):
             if exact(i):
                 h.set_kernel(ra.FirKernel.PeriodicF32)
-    refs = [o.OracleFir(s.channels, s.in_hz, s.out_hz, lat.taps(), ATT_DB[att]) for s in specs]
+    kind = o.CONVOLVE_AVX_FMA if o.have_avx_fma() else o.CONVOLVE_SCALAR   # the CPU SIMD path north_star names
+    refs = [o.OracleFir(s.channels, s.in_hz, s.out_hz, lat.taps(), ATT_DB[att], kind) for s in specs]
     rng = np.random.default_rng(seed)
     if prefeed is not None:
         for i, (h, r) in enumerate(zip(hs, refs)):
@@ -86,12 +87,34 @@ def run_lockstep(specs, steps, frames, seed=0, lat=ra.Latency.Sample64, att=ra.A
         want = np.concatenate(ref_out[i]) if ref_out[i] else np.zeros(0, np.float32)
         got = d_out[i][:want.size].cpu().numpy() if append else np.concatenate(gpu_step_out[i])
         e = rms(got, want)
+        if relative:   # relative to the stream's own level
+            e /= max(float(np.sqrt(np.mean(want.astype(np.float64) ** 2))), 1e-300)
         if e > RMS_TOL:
             bad = np.flatnonzero(~(np.abs(got.astype(np.float64) - want) <= 1e-4))
             print(f"lockstep: stream {i} {specs[i]} rms {e:.3e} bad {bad.size}: {bad[:8]} got {got[bad[:4]]} "
                   f"want {want[bad[:4]]}")
         worst = max(worst, e)
     return worst, ls, hs, refs
+
+
+def test_streams_of_very_different_levels_keep_their_relative_precision():
+    """Streams of one batch (and of one workgroup: up to five share an image) at full scale, 2^-10, 2^-17, 2^-24, 1e-30
+    and 3e4, one of them dropping from full scale to 2^-20 halfway: every stream within 1e-6 RMS RELATIVE to its own
+    level.  The split image is block floating point per column (fir_lockstep.hip, `colpeak`)."""
+    specs = sharding.mixed_rate_batch(42, 2, 512)
+    levels = [1.0, 2.0 ** -10, 2.0 ** -17, 2.0 ** -24, 1e-30, 3e4, 1.0]
+    steps, frames = 6, 512
+    rng = np.random.default_rng(123)
+    xs = []
+    for i, sp in enumerate(specs):
+        x = (rng.random(steps * frames * 2, dtype=np.float32) * 2 - 1).astype(np.float32) * np.float32(levels[(i // 6) % 7])
+        if (i // 6) % 7 == 6:
+            x[steps * frames:] *= np.float32(2.0 ** -20)
+        xs.append(x.astype(np.float32))
+    worst, ls, hs, refs = run_lockstep(specs, steps=steps, frames=frames, x_override=xs, relative=True)
+    assert worst <= RMS_TOL, worst
+    # (3e4 overflows nothing: the scale follows the column's peak; only samples of 2^8 and above go to the reference form)
+    ls.close()
 
 
 def test_c4_shape_1024_streams_six_pairs_16_steps():
