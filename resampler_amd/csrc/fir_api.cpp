@@ -445,7 +445,11 @@ int launch_jobs(rsmp_fir* leader, std::vector<Job>& jobs, hipStream_t stream) {
             ds.class_meta = r->periodic.table.d_meta;
             if (geo.inline_wraps) {
                 ds.wrap_bits = reinterpret_cast<const uint32_t*>(d + pp.wrap_off);
-                ds.wrap_k0 = r->mirror.abs_out() / geo.den;
+                // (the split kernel counts periods of b outputs; b = den unless its super period spans several true
+                // periods -- exact ratios only, whose streams have no wrapped outputs: an all-zero bitmap, any indexing)
+                ds.wrap_k0 = r->mirror.abs_out() / (geo.mfma == 3 ? geo.b : geo.den);
+                if (geo.mfma == 3 && geo.b != geo.den && !pl.wraps.empty())
+                    return rsmp::fail(RSMP_ERR_INVALID_ARGUMENT, "split kernel: a stream of an exact ratio has wrapped outputs");
                 if (!pp.written) {
                     const size_t words = rsmp::periodic_wrap_words(r->mirror.abs_out(), ds.n_out, geo.den);
                     rsmp::periodic_fill_wrap_bits(pl.wraps, r->mirror.abs_out(), geo.den,

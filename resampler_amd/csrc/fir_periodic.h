@@ -50,6 +50,8 @@ struct PeriodicGeometry {
     uint32_t mfma = 0;           // > 0: matrix-core kernel (16-class tiles); period groups of 16 per work unit;
                                  // 3: split kernel (fir_split.hip)
     uint32_t planes = 0;         // split kernel: 16-bit planes per f32 operand (3: bf16, exact; 2: fp16)
+    uint32_t groups = 0;         // split kernel: tile groups of ten class tiles (1 or 2)
+    uint32_t rounds = 0;         // split kernel: rounds of lane tasks per stager and item (1: periods <= 160 frames; 2: <= 320)
     uint32_t n_units = 0;        // work units per item: n_tiles (vector kernels) or tiles x unit splits (mfma)
     uint32_t lds_bytes = 0;
     bool inline_wraps = false;   // den >= 8: wrap variant computed inside the kernel

@@ -69,7 +69,7 @@ constexpr float kXScale = 4096.0f;        // 2^12 (the sample scale of an item w
 #endif
 constexpr uint32_t kPeakHeadroom = 4;     // a predicted scale leaves 2^4 above the pair's latest peak
 constexpr uint32_t kPeakQuiet = 10;       // an item whose peak lies more than 2^-10 below what its scale allows (2^-6 below the prediction) is redone
-constexpr uint32_t kPeakExactMax = 134;   // an exact scale is not taken from samples of 2^8 and above (they overflow the planes: redone)
+constexpr uint32_t kPeakMax = 138;        // no scale is derived from a peak of 2^11 and above (samples of 2^13 and above overflow the planes: redone)
 constexpr float kCScale = 8192.0f;        // 2^13
 constexpr uint32_t kTouchAhead = 3;                    // items between a touch and the producers' loads of the same frames
 constexpr uint32_t kLdsLimit = 160 * 1024;
@@ -83,6 +83,7 @@ struct SplitArgs {
     uint32_t a, b, taps, n_tiles, rows, slots, lds_bytes, blocks_per_stream, total_items, debug;
     uint32_t n_streams, fuse_tail;   // fuse_tail: also copy every stream's still-buffered tail into hist_next
     uint32_t cstride, pairs;         // WIDE kernels: channels of a frame and channel pairs = cstride / 2 (an item = one pair of a block)
+    uint32_t groups, per_group;      // more than ten class tiles (b > 160): tile groups of ten; items per group (the launch's items = groups x that)
     unsigned long long* wtrace;   // RSMP_FIR_WTRACE: kWtraceSlots timestamped events per wave
     NfArgs nf;                    // non-finite sums are marked here (fir_nonfinite.h)
 };
@@ -212,8 +213,14 @@ struct Item {
 // WIDE (streams of 4, 6, 8 .. 16 channels): an item is one channel PAIR of a block, the pairs of a block are
 // consecutive items -- the workgroup that staged a block's first pair finds the lines of the others in its L2,
 // and their 8-byte stores into the same lines meet there.
+// More than ten class tiles (up to 320 classes: 44.1 -> 96 kHz, 48 -> 96 kHz): the launch's items come in tile GROUPS
+// of ten tiles, group-major -- the workgroups of the first half of the grid take every block with tiles 0 .. 9, those
+// of the second half the same blocks with tiles 10 .. 19 at about the same time (workgroup w and w + grid / 2 share an
+// XCD under round-robin placement, so the second read of a block's frames is an L2 hit).  A consumer keeps its
+// coefficient tile in registers across the items of a group.
 struct Cursor {
     uint32_t item, stream, block;   // the next item to look at
+    uint32_t group, cur_group;      // its tile group; the group of the item `next` returned
     uint32_t pair, cur_pair;        // WIDE: its channel pair; the pair of the item `next` returned
     bool fresh;                     // `c` and the values below belong to (stream, block)
     StreamCtx c;
@@ -224,15 +231,17 @@ struct Cursor {
     __device__ __forceinline__ void init(const SplitArgs& g, uint32_t first) {
         item = first;
         pair = cur_pair = 0;
+        group = cur_group = first / g.per_group;
+        const uint32_t in_group = first - group * g.per_group;
         if constexpr (WIDE) {
             const uint32_t per_stream = g.blocks_per_stream * g.pairs;
-            stream = first / per_stream;
-            const uint32_t rem = first - stream * per_stream;
+            stream = in_group / per_stream;
+            const uint32_t rem = in_group - stream * per_stream;
             block = rem / g.pairs;
             pair = rem - block * g.pairs;
         } else {
-            stream = first / g.blocks_per_stream;
-            block = first - stream * g.blocks_per_stream;
+            stream = in_group / g.blocks_per_stream;
+            block = in_group - stream * g.blocks_per_stream;
         }
         fresh = false;
         c = StreamCtx{};
@@ -260,6 +269,7 @@ struct Cursor {
                 f0 += 16u * g.a;
             }
             found = item;
+            cur_group = group;
             const bool valid = q0 < q_limit;
             ++item;
             bool block_done = true;
@@ -270,8 +280,11 @@ struct Cursor {
             }
             if (block_done && ++block == g.blocks_per_stream) {
                 block = 0;
-                ++stream;
                 fresh = false;
+                if (++stream == g.n_streams) {   // the next tile group starts over
+                    stream = 0;
+                    ++group;
+                }
             }
             if (valid) return true;
         }
@@ -367,9 +380,12 @@ __device__ __forceinline__ uint32_t consumer_index(uint32_t w) { return w < 6 ? 
 // 8 bytes per frame; everything between the loads and the stores is the two-channel kernel.  The wrap-only
 // producer and the stagers are separate instantiations of the staging loop (ROLE), so that neither pays for the
 // other's registers (two wrap passes against one + the 40 registers of a stager's loads).
-template <int NK, int PLANES, bool DIAG, int WIDE>   // WIDE: 0 two channels, 1 channel pairs, 2 one channel, 3 pairs + a last channel alone
+// ROUNDS: lane tasks per stager lane and item -- 2 for periods of 161 .. 320 frames (96 -> 44.1 kHz, 96 -> 48 kHz): both
+// rounds' loads are in flight together, one item ahead, like the single round's.
+template <int NK, int PLANES, bool DIAG, int WIDE, int ROUNDS = 1>   // WIDE: 0 two channels, 1 channel pairs, 2 one channel, 3 pairs + a last channel alone
 __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __restrict__ descs,
                                                          const SplitArgs g) {
+    static_assert(ROUNDS == 1 || ((WIDE == 0 || WIDE == 1) && PLANES == 2 && !DIAG), "two rounds: two channels or channel pairs, fp16 planes");
     constexpr uint32_t kRowBytes = row_bytes(PLANES);
     const uint32_t fs = WIDE ? g.cstride : 2u;   // floats per frame
     const uint32_t fsb = fs * 4u;                // bytes per frame
@@ -412,7 +428,7 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
 
     const uint32_t R = g.rows;
     const uint32_t image_bytes = R * kRowBytes;
-    const uint32_t n_active = g.n_tiles < kConsumers ? g.n_tiles : kConsumers;
+    const uint32_t n_active = g.n_tiles < kConsumers ? g.n_tiles : kConsumers;   // consumers that take part (with tile groups: all ten)
     const uint32_t item_begin = static_cast<uint32_t>(static_cast<uint64_t>(blockIdx.x) * g.total_items / gridDim.x);
     const uint32_t item_end = static_cast<uint32_t>(static_cast<uint64_t>(blockIdx.x + 1) * g.total_items / gridDim.x);
     // The frames that stay buffered after the launch move to hist_next (what fir_tail_copy_kernel does in
@@ -450,8 +466,8 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
         // across items.  A global load costs a wave ~100 cycles to issue here, whatever its width: few, wide.
         const uint32_t P = producer_index(wave);
         const uint32_t half_a = (g.a + 1) / 2;
-        const uint32_t n_lane_tasks = 4 * half_a;   // <= 64 * kStagers (split_geometry)
-        const uint32_t n_real = (n_lane_tasks + 63) / 64;   // stagers that have lane tasks (the others only signal)
+        const uint32_t n_lane_tasks = 4 * half_a;   // <= 64 * kStagers * ROUNDS (split_geometry)
+        const uint32_t n_real = (n_lane_tasks + 63) / 64 < kStagers ? (n_lane_tasks + 63) / 64 : kStagers;   // stagers that have lane tasks (the others only signal)
         // (the lane id behind an optimisation barrier per item: otherwise loop-invariant addressing is
         // hoisted out of the item loop, spilled, and each reload from scratch waits for ALL the
         // prefetches in flight -- scratch loads share the in-order vmcnt)
@@ -512,25 +528,34 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
         PItem ecur = nxt;
         StreamCtx ectx = cu.c;
 
-        // ROLE 0: the two-channel kernel's producers; WIDE: 1 = the wrap-only producer, 2 = a stager
+        // ROLE 0: the two-channel kernel's producers; WIDE: 1 = the wrap-only producer, 2 = a stager; two rounds
+        // (two channels): 1 = the wrap-only producer, 3 = a stager (x[2][5] next to two wrap passes spilled)
         auto staging = [&](auto role_c) {
             constexpr int ROLE = decltype(role_c)::value;
-            constexpr int kMaxPass = ROLE == 2 ? 1 : 2;   // wrap passes (of four periods) a wave may take
+            constexpr int kMaxPass = ROLE >= 2 ? 1 : 2;   // wrap passes (of four periods) a wave may take at a time
             // ---- staging (all producers) + one pass of the wrap variant (producers 0-3) ---------------
-            uint32_t t = P * 64 + lane;   // (one division for the whole launch)
-            const bool real_task = P * 64 < n_lane_tasks;
+            uint32_t tQ[ROUNDS], tK[ROUNDS];   // (one division per round for the whole launch)
+            bool real_rd[ROUNDS];
+#pragma unroll
+            for (int rd = 0; rd < ROUNDS; ++rd) {
+                uint32_t t = rd * (64 * kStagers) + P * 64 + lane;
+                real_rd[rd] = ROLE != 1 && P < kStagers && rd * (64 * kStagers) + P * 64 < n_lane_tasks;   // (the wrap-only producer stages nothing)
+                if (t >= n_lane_tasks) t = n_lane_tasks - 1;   // surplus lanes repeat the last lane task
+                tQ[rd] = t / half_a;
+                tK[rd] = t - tQ[rd] * half_a;
+            }
+            const bool real_task = real_rd[0];
             float xs = kXScale;   // two planes: the current item's sample scale (block floating point, see `peak`)
             uint64_t hist_e = 0;                  // latest final peak exponent per channel pair (8 bits each; 0 = none) ...
             uint32_t hist_stream = 0xFFFFFFFFu;   // ... of this stream
             uint32_t n_met = 0;                   // meetings at `premax` so far
             uint32_t cstream = cu.c.sidx;         // the current item's stream
-            if (t >= n_lane_tasks) t = n_lane_tasks - 1;   // surplus lanes repeat the last lane task
-            uint32_t tQ = t / half_a;
-            uint32_t tK = t - tQ * half_a;
+            uint32_t cur_off0 = 0;                // ... where its frames start in `in` (two rounds: the second is loaded late)
+            const float* cur_in = nullptr;
             // real = false: dummy loads of the first bytes of the descriptor array (always mapped), so that
             // every pass through the loop issues the same loads
-            auto load_task = [&](v4f (&v)[5], bool real, const PItem& pi, const void* base) {
-                const uint32_t off = real ? (pi.off0 + 4 * tQ * g.a + 2 * tK) * 8u : 0u;
+            auto load_task = [&](v4f (&v)[5], bool real, const PItem& pi, const void* base, int rd) {
+                const uint32_t off = real ? (pi.off0 + 4 * tQ[rd] * g.a + 2 * tK[rd]) * 8u : 0u;
                 const uint32_t step = real ? g.a * 8u : 0u;
 #pragma unroll
                 for (int i = 0; i < 5; ++i) gload4(v[i], off + i * step, base);
@@ -540,14 +565,25 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
             // for the odd one.  Per item that is five loads as in the two-channel kernel, and every line is used whole.
             // one channel: the two frames of a period are neighbours -- one 8-byte load; the phantom channel of frame 2K
             // is frame 2K + 1, that of frame 2K + 1 is zero
+            // two rounds, channel pairs: the pair's two channels of a frame are one 8-byte load (sixteen-byte loads shared by
+            // two items, as the one-round stagers have them, would hold both rounds' registers across two items)
+            auto load_task_pair = [&](v2f (&lo)[5], v2f (&hi)[5], const PItem& pi, const void* base, int rd) {
+                const uint32_t off = (pi.off0 + 4 * tQ[rd] * g.a + 2 * tK[rd]) * fsb;
+                const uint32_t step = g.a * fsb;
+#pragma unroll
+                for (int i = 0; i < 5; ++i) {
+                    gload2(lo[i], off + i * step, base);
+                    gload2(hi[i], off + i * step + fsb, base);
+                }
+            };
             auto load_task_mono = [&](v2f (&v)[5], const PItem& pi, const void* base) {
-                const uint32_t off = (pi.off0 + 4 * tQ * g.a + 2 * tK) * 4u;
+                const uint32_t off = (pi.off0 + 4 * tQ[0] * g.a + 2 * tK[0]) * 4u;
                 const uint32_t step = g.a * 4u;
 #pragma unroll
                 for (int i = 0; i < 5; ++i) gload2(v[i], off + i * step, base);
             };
             auto load_task_wide = [&](v4f (&v)[5][2], const PItem& pi, const void* base) {
-                const uint32_t off = (pi.off0 + 4 * tQ * g.a + 2 * tK) * fsb;
+                const uint32_t off = (pi.off0 + 4 * tQ[0] * g.a + 2 * tK[0]) * fsb;
                 const uint32_t step = g.a * fsb;
 #pragma unroll
                 for (int i = 0; i < 5; ++i) {
@@ -557,16 +593,17 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
             };
             // v[i] = (ch0, ch1) of frame 2K and (ch0, ch1) of frame 2K+1 in period 4Q+i
             // at(i, fr, c) = channel c of frame 2K + fr in period 4Q + i
-            auto store_task = [&](char* img, auto&& at) {
+            auto store_task = [&](char* img, auto&& at, int rd) {
                 typedef uint32_t u2 __attribute__((ext_vector_type(2)));
-                const uint32_t k0 = 2 * tK;   // rows k0 and k0 + 1 share a swizzle (k0 is even)
-                char* prim = img + k0 * kRowBytes + ((tQ ^ ((k0 >> 2) & 3)) << 3);
+                const uint32_t tQ_ = tQ[rd];
+                const uint32_t k0 = 2 * tK[rd];   // rows k0 and k0 + 1 share a swizzle (k0 is even)
+                char* prim = img + k0 * kRowBytes + ((tQ_ ^ ((k0 >> 2) & 3)) << 3);
                 // rows past the image: their copies go to the touch landing zone instead -- an unconditional
                 // store is cheaper than a predicated one
                 char* land = lds + kCtrlBytes + kWrapBytes;
                 const uint32_t kd0 = k0 + g.a, kd1 = k0 + 1 + g.a;
-                char* dup0 = kd0 < R ? img + kd0 * kRowBytes + ((tQ ^ ((kd0 >> 2) & 3)) << 3) : land;
-                char* dup1 = kd1 < R ? img + kd1 * kRowBytes + ((tQ ^ ((kd1 >> 2) & 3)) << 3) : land;
+                char* dup0 = kd0 < R ? img + kd0 * kRowBytes + ((tQ_ ^ ((kd0 >> 2) & 3)) << 3) : land;
+                char* dup1 = kd1 < R ? img + kd1 * kRowBytes + ((tQ_ ^ ((kd1 >> 2) & 3)) << 3) : land;
                 char* prim1 = k0 + 1 < R ? prim + kRowBytes : land;
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {          // channel
@@ -657,6 +694,8 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
                 if (wpart == 0) *reinterpret_cast<v4f*>(wv + wper * 4) = v4f{acc.x, acc.y, __uint_as_float(take), 0.f};
             };
             v4f x[5];
+            v2f xl[5], xh[5];     // ROLE 3, channel pairs: frames 2K and 2K + 1 of a period (the pair's two channels)
+            constexpr bool kPairLoads = ROLE == 3 && WIDE == 1;
             v4f xq[5][2];         // ROLE 2: (period, frame) x four channels
             v2f xm[5];            // ROLE 2, one channel: frames 2K, 2K + 1 of a period
             uint32_t cpair = 0;   // WIDE: the current item's channel pair
@@ -666,7 +705,9 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
                 bool pre = more && nxt.interior && !(dbg & 8192);   // the next item's loads can be issued ahead
                 // (a WIDE stager's odd pair lives on its even neighbour's loads, the item before it in this loop)
                 if constexpr (ROLE == 2) pre = pre && ((nxt.pair & 1u) == 0 || (have && loaded));
-                asm volatile("" : "+v"(ln), "+v"(tQ), "+v"(tK));
+                asm volatile("" : "+v"(ln));
+#pragma unroll
+                for (int rd = 0; rd < ROUNDS; ++rd) asm volatile("" : "+v"(tQ[rd]), "+v"(tK[rd]));
                 char* img = lds + kImageBase + slot * image_bytes;
                 uint32_t f_id_v = 0, f_e_v = 0;   // what the slot's previous item turned out to peak at (see `fin`)
                 if (have) {
@@ -686,7 +727,10 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
                         if constexpr (mono) asm volatile("" : "+v"(xm[i]));
                         else asm volatile("" : "+v"(xq[i][0]), "+v"(xq[i][1]));
                     }
-                } else if constexpr (ROLE == 0) {
+                } else if constexpr (kPairLoads) {
+#pragma unroll
+                    for (int i = 0; i < 5; ++i) asm volatile("" : "+v"(xl[i]), "+v"(xh[i]));
+                } else if constexpr (ROLE == 0 || ROLE == 3) {
 #pragma unroll
                     for (int i = 0; i < 5; ++i) asm volatile("" : "+v"(x[i]));
                 }
@@ -701,12 +745,12 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
                     }
                     asm volatile("" : "+v"(wword[ps]));
                 }
-                if (have && real_task && !(dbg & 1)) {
-                    if (!loaded) {
-                        // stream edges: frames outside [hist|in] read as zero; plain loads into the same registers
+                if constexpr (ROLE != 1) if (have && real_task && !(dbg & 1)) {
+                    // stream edges: frames outside [hist|in] read as zero; plain loads into the registers of the asm loads
+                    auto fetch_edge_round = [&](int rd) {
 #pragma unroll
                         for (int i = 0; i < 5; ++i) {
-                            const int64_t f = ecur.f0 + static_cast<int64_t>((4 * tQ + i) * g.a + 2 * tK);
+                            const int64_t f = ecur.f0 + static_cast<int64_t>((4 * tQ[rd] + i) * g.a + 2 * tK[rd]);
                             const v2f lo = fetch_edge(ectx, ecur.pair, f), hi = fetch_edge(ectx, ecur.pair, f + 1);
                             if constexpr (ROLE == 2) {
                                 if constexpr (mono) xm[i] = v2f{lo.x, hi.x};
@@ -714,32 +758,28 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
                                     xq[i][0] = v4f{lo.x, lo.y, lo.x, lo.y};
                                     xq[i][1] = v4f{hi.x, hi.y, hi.x, hi.y};
                                 }
+                            } else if constexpr (kPairLoads) {
+                                xl[i] = lo;
+                                xh[i] = hi;
                             } else {
                                 x[i] = v4f{lo.x, lo.y, hi.x, hi.y};
                             }
                         }
-                    }
-                    // at(i, fr, c) = channel c of frame 2K + fr in period 4Q + i
+                    };
+                    if (!loaded) fetch_edge_round(0);
+                    // at(i, fr, c) = channel c of frame 2K + fr in period 4Q + i of the lane task in the registers
                     auto at = [&](int i, int fr, int c) -> float {
                         if constexpr (ROLE == 2) {
                             if constexpr (mono) return c == 0 ? xm[i][fr] : (fr == 0 ? xm[i][1] : 0.f);
                             else return (cpair & 1u) ? xq[i][fr][2 + c] : xq[i][fr][c];
+                        } else if constexpr (kPairLoads) {
+                            return fr ? xh[i][c] : xl[i][c];
                         } else {
                             return x[i][2 * fr + c];
                         }
                     };
-                    if constexpr (PLANES == 2) {
-                        // what the slot's previous item (`slots` items back) turned out to peak at: into the running table
-                        const uint32_t f_id = __builtin_amdgcn_readfirstlane(f_id_v), f_e = __builtin_amdgcn_readfirstlane(f_e_v);
-                        if (f_id != 0) {
-                            const uint32_t f_stream = (f_id - 1) >> 4, f_pair = (f_id - 1) & 15u;
-                            if (f_stream != hist_stream) {
-                                hist_stream = f_stream;
-                                hist_e = 0;
-                            }
-                            hist_e = (hist_e & ~(0xFFull << (8 * f_pair))) | (static_cast<uint64_t>(f_e) << (8 * f_pair));
-                        }
-                        // the item's peak: this lane's samples, the wave, then (one atomic) every stager's
+                    // the peak of the samples in the registers: this lane's, the wave's, then (one atomic) into the item's
+                    auto add_peak = [&]() {
                         float m = 0.f;
 #pragma unroll
                         for (int i = 0; i < 5; ++i)
@@ -758,36 +798,80 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
                                                     static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(mb), 48))));
                         if (lane == 0)
                             (void)__hip_atomic_fetch_max(peak + slot, ((use + 1) << 8) | (wm >> 23), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        const uint32_t e_hist = hist_stream == cstream ? static_cast<uint32_t>(hist_e >> (8 * cpair)) & 255u : 0u;
+                    };
+                    uint32_t e_hist = 0;
+                    if constexpr (PLANES == 2) {
+                        // what the slot's previous item (`slots` items back) turned out to peak at: into the running table
+                        const uint32_t f_id = __builtin_amdgcn_readfirstlane(f_id_v), f_e = __builtin_amdgcn_readfirstlane(f_e_v);
+                        if (f_id != 0) {
+                            const uint32_t f_stream = (f_id - 1) >> 4, f_pair = (f_id - 1) & 15u;
+                            if (f_stream != hist_stream) {
+                                hist_stream = f_stream;
+                                hist_e = 0;
+                            }
+                            hist_e = (hist_e & ~(0xFFull << (8 * f_pair))) | (static_cast<uint64_t>(f_e) << (8 * f_pair));
+                        }
+                        e_hist = hist_stream == cstream ? static_cast<uint32_t>(hist_e >> (8 * cpair)) & 255u : 0u;
+                        add_peak();
+                    }
+                    // the item's scale: predicted from the pair's latest peak, or (no history) from the peak of what the stagers
+                    // hold once every one of them has added its share -- the whole item, or (two rounds) its first round:
+                    // ten of its sixteen periods, taken with the same headroom as a prediction
+                    auto set_scale = [&]() {
                         uint32_t E;
-                        if (e_hist != 0) {   // predicted: 2^4 above the pair's latest peak
+                        if (e_hist != 0) {   // 2^4 above the pair's latest peak
                             E = e_hist + kPeakHeadroom;
-                            E = E > 254u ? 254u : E;
-                        } else {             // no history: the exact peak, once every stager has added its share
+                        } else {
                             // (one monotonic counter for all slots: nobody gets past meeting k before every stager has
                             // arrived at it, so arrivals at meeting k + 1 cannot be taken for arrivals at k)
                             lds_signal(premax);
                             ++n_met;
                             while (lds_load_acquire(premax) < n_real * n_met) __builtin_amdgcn_s_sleep(RSMP_POLL_SLEEP);
                             E = __hip_atomic_load(peak + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) & 255u;
-                            E = E > kPeakExactMax ? kPeakExactMax : E;   // (a lone outlier must overflow, not push the rest of the item below the planes)
+                            if (ROUNDS == 2 && E != 0) E += kPeakHeadroom;
                         }
+                        // (never scaled for peaks of 2^11 and above: such samples must overflow the planes and have the item
+                        // redone, not push the audio next to them below the planes' range)
+                        E = E > kPeakMax ? kPeakMax : E;
                         E = __builtin_amdgcn_readfirstlane(E < 31u ? 31u : E);   // (below 2^-96: treated as that)
                         // a peak in [2^(E-127), 2^(E-126)) times 2^(141-E) lies in [2^14, 2^15), inside fp16
                         xs = __uint_as_float((268u - E) << 23);
                         if (P == 0 && lane == 0) used[slot] = E;
-                        wt.event(9);
+                    };
+                    if constexpr (PLANES == 2) set_scale();
+                    wt.event(9);
+                    store_task(img, at, 0);
+                    if constexpr (ROUNDS == 2) {
+                        // Two rounds of lane tasks through ONE set of registers (two sets next to the consumers' coefficient
+                        // tile spill): round 0 arrived with the item; round 1 is loaded while the consumers still read the
+                        // image before, converted and written behind round 0.
+                        if (real_rd[1]) {
+                            if (loaded) {
+                                PItem pc;   // (of an interior item only where its frames start is needed)
+                                pc.off0 = cur_off0;
+                                if constexpr (kPairLoads) load_task_pair(xl, xh, pc, uniform_ptr<true>(cur_in), 1);
+                                else load_task(x, true, pc, uniform_ptr<true>(cur_in), 1);
+                                asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+#pragma unroll
+                                for (int i = 0; i < 5; ++i) {
+                                    if constexpr (kPairLoads) asm volatile("" : "+v"(xl[i]), "+v"(xh[i]));
+                                    else asm volatile("" : "+v"(x[i]));
+                                }
+                            } else {
+                                fetch_edge_round(1);
+                            }
+                            add_peak();
+                            store_task(img, at, 1);
+                        }
                     }
-                    store_task(img, at);
                 }
-                if (have && wrapper) {
-                    wt.event(13);
+                auto wrap_passes = [&](bool from_regs) {
 #pragma unroll
                     for (int ps = 0; ps < kMaxPass; ++ps) {
                         if (static_cast<uint32_t>(ps) >= n_pass) continue;
                         const uint32_t wper = 4 * (pass0 + ps) + (ln >> 4);
                         v2f w[kWrapTaps];
-                        if (loaded) {
+                        if (from_regs) {
 #pragma unroll
                             for (int i = 0; i < kWrapTaps / 2; ++i) {
                                 if constexpr (ROLE != 0) {
@@ -810,6 +894,10 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
                             wrap_out(w, wper, in_launch ? (word >> (K & 31)) & 1u : 0u);
                         }
                     }
+                };
+                if (have && wrapper) {
+                    wt.event(13);
+                    wrap_passes(loaded);
                 }
                 if (more && wrapper && cu.c.coeffs != cur_coeffs) {   // the next item's taps of row 1023 (rare: compiler-visible loads)
                     cur_coeffs = cu.c.coeffs;
@@ -829,8 +917,10 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
                         if constexpr (mono) {
                             if (real_task) load_task_mono(xm, nxt, uniform_ptr<true>(cu.c.in));
                         } else if (real_task && (nxt.pair & 1u) == 0) load_task_wide(xq, nxt, uniform_ptr<true>(cu.c.in + 2 * nxt.pair));
-                    } else if constexpr (ROLE == 0) {
-                        if (real_task) load_task(x, true, nxt, uniform_ptr<true>(cu.c.in));
+                    } else if constexpr (kPairLoads) {
+                        if (real_task) load_task_pair(xl, xh, nxt, uniform_ptr<true>(cu.c.in + 2 * nxt.pair), 0);
+                    } else if constexpr (ROLE == 0 || ROLE == 3) {
+                        if (real_task) load_task(x, true, nxt, uniform_ptr<true>(cu.c.in), 0);   // (two rounds: round 0)
                     }
 #pragma unroll
                     for (int ps = 0; ps < kMaxPass; ++ps)
@@ -854,15 +944,20 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
                 if (more) {
                     cpair = nxt.pair;
                     cstream = cu.c.sidx;
+                    cur_off0 = nxt.off0;
+                    cur_in = cu.c.in + (WIDE == 1 ? 2 * nxt.pair : 0u);
                     nxt = find_next();
                 }
                 if (have) wt.event(5);
             }
             #undef wpart
         };
-        if constexpr (WIDE) {
+        if constexpr (WIDE != 0 && ROUNDS == 1) {
             if (P == 5) staging(std::integral_constant<int, 1>{});
             else staging(std::integral_constant<int, 2>{});
+        } else if constexpr (ROUNDS == 2) {
+            if (P == 5) staging(std::integral_constant<int, 1>{});
+            else staging(std::integral_constant<int, 3>{});
         } else {
             staging(std::integral_constant<int, 0>{});
         }
@@ -873,13 +968,20 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
 
     // ---- consumer ----------------------------------------------------------------------------------
     const uint32_t T = consumer_index(wave);
-    if (T >= g.n_tiles) return;
+    if (T >= n_active) return;
     const uint32_t grp = lane >> 4, q = (lane >> 2) & 3, pc = lane & 3;
-    const uint32_t ob = (T * 16u * g.a) / g.b;        // first frame of the tile's window
-    const uint32_t row0 = ob + 4 * grp + q;
-    const uint32_t lane_off = row0 * kRowBytes + ((pc ^ ((row0 >> 2) & 3)) << 3);
-    const uint32_t j0 = T * 16u + 4 * grp;             // the lane's four classes (D rows)
     const uint32_t pl = lane & 15;                     // the lane's period (D column)
+    // the wave's class tile: T in the item's tile group (ten tiles per group; the last group may have fewer -- a consumer
+    // without a tile there still waits for the image and counts itself done)
+    uint32_t Tt = T, lane_off = 0, j0 = 0;
+    uint32_t cur_group = 0xFFFFFFFFu;
+    auto set_tile = [&](uint32_t group) {
+        Tt = group * kConsumers + T;
+        const uint32_t ob = (Tt * 16u * g.a) / g.b;        // first frame of the tile's window
+        const uint32_t row0 = ob + 4 * grp + q;
+        lane_off = row0 * kRowBytes + ((pc ^ ((row0 >> 2) & 3)) << 3);
+        j0 = Tt * 16u + 4 * grp;                           // the lane's four classes (D rows)
+    };
 
     typedef typename std::conditional<PLANES == 3, bf16x8, f16x8>::type frag_t;
     frag_t A[NK][PLANES];
@@ -936,9 +1038,12 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
         it.n_block0 = cu.n_block0;
         it.k_block0 = cu.k_block0;
         it.valid = true;
-        if (d.class_coef != cur_table) {   // streams of one launch may differ in drift
+        if (d.class_coef != cur_table || cu.cur_group != cur_group) {   // streams of one launch may differ in drift
             cur_table = d.class_coef;
-            gconst_u4_ptr tp = (gconst_u4_ptr)(cur_table) + static_cast<size_t>(T) * (NK * PLANES * 64) + lane;
+            cur_group = cu.cur_group;
+            set_tile(cur_group);
+            const uint32_t Tl = Tt < g.n_tiles ? Tt : 0u;   // (a consumer without a tile in this group loads any tile)
+            gconst_u4_ptr tp = (gconst_u4_ptr)(cur_table) + static_cast<size_t>(Tl) * (NK * PLANES * 64) + lane;
 #pragma unroll
             for (int s = 0; s < NK; ++s)
 #pragma unroll
@@ -961,6 +1066,15 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
         if (!(dbg & 16384))
             while (lds_load_acquire(staged + slot) < kProducers * (use + 1)) __builtin_amdgcn_s_sleep(RSMP_POLL_SLEEP);
         wt.event(2);
+        if (Tt >= g.n_tiles) {   // (wave-uniform) no tile for this wave in the item's group: done with the image
+            flush_pending();
+            lds_signal_local(done + slot);
+            if (++slot == g.slots) {
+                slot = 0;
+                ++use;
+            }
+            continue;
+        }
 
         v4f acc0 = v4f{0.f, 0.f, 0.f, 0.f}, acc1 = v4f{0.f, 0.f, 0.f, 0.f};
         auto frag = [&](uint32_t plane_ch, int s) -> frag_t {
@@ -1022,7 +1136,7 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
         }
         if (!WIDE || (cu.cur_pair & 1u) == 0) flush_pending();   // (no MFMA loop ran, or the experiment switch above)
         // class 0 may take the wrap variant the producers left with the image (tile 0, D row 0)
-        if (T == 0) {
+        if (Tt == 0) {
             const v4f w = *reinterpret_cast<const v4f*>(lds + kCtrlBytes + slot * 256 + pl * 16);
             if (grp == 0 && __float_as_uint(w.z) != 0u && !(dbg & 2048)) {
                 acc0.x = w.x;
@@ -1099,9 +1213,12 @@ inline uint32_t split_class_offset(uint32_t a, uint32_t b, uint32_t j) {
 
 }  // namespace
 
-// Geometry of the split-bf16 kernel for num/den, or !ok: two channels, one true period per class
-// pattern (b = den: 16..160 classes = at most one tile per consumer wave), window of <= 160 taps,
-// two images within the LDS.
+// Geometry of the split kernel for num/den, or !ok.  A super period of a = r num input frames and b = r den outputs:
+// r = 1 for 16 .. 320 classes; a ratio with a power-of-two denominator below 16 (48 <-> 96 kHz: exact in f64, so no
+// output ever takes the row-1023 variant and every class of the super period is an ordinary one) takes the largest r
+// with a, b <= 320.  Up to ten class tiles per tile group (one tile per consumer wave), up to two groups; periods of up
+// to 160 frames in one round of lane tasks, up to 320 in two (two-channel streams); window of <= 160 taps (192 with
+// two rounds); two to four images within the LDS.
 // RSMP_FIR_SPLIT_PLANES = 3 selects the three-plane bf16 split (every f32 operand exactly), default 2: two
 // fp16 planes per operand, three matrix products instead of six.
 static uint32_t split_planes_knob() {
@@ -1119,10 +1236,24 @@ PeriodicGeometry split_geometry(uint64_t num, uint64_t den, uint32_t taps, uint3
     // two channels, or (RSMP_FIR_SPLIT_WIDE=0 turns it off) an even number up to 16 taken as channel pairs, two pairs per
     // 16-byte load (6, 10, 14 channels: the last pair alone -- its load reaches 8 bytes into the next frame)
     static const bool wide_ok = [] { const char* e = getenv("RSMP_FIR_SPLIT_WIDE"); return !e || atoi(e) != 0; }();
+    static const bool long_ok = [] { const char* e = getenv("RSMP_FIR_SPLIT_LONG"); return !e || atoi(e) != 0; }();   // 0: round 2's geometries only
     if (channels != 2 && (channels > 16 || !wide_ok)) return g;
-    if (num == 0 || num > 4096 || den < 16 || den > 16 * kConsumers) return g;
-    const uint32_t a = static_cast<uint32_t>(num), b = static_cast<uint32_t>(den);
+    constexpr uint32_t kMaxAB = 320;
+    if (num == 0 || den == 0 || num > kMaxAB || den > kMaxAB) return g;
+    uint32_t r = 1;
+    if (den < 16) {
+        if ((den & (den - 1)) != 0) return g;   // (the wrap variant exists for class 0 only: exact ratios need none)
+        r = static_cast<uint32_t>(std::min(kMaxAB / num, kMaxAB / den));
+        r -= r % (16 / static_cast<uint32_t>(den));   // whole tiles
+        if (r == 0) return g;
+    }
+    const uint32_t a = static_cast<uint32_t>(num) * r, b = static_cast<uint32_t>(den) * r;
+    if (b < 16) return g;
     const uint32_t n_tiles = (b + 15) / 16;
+    const uint32_t groups = (n_tiles + kConsumers - 1) / kConsumers;
+    const uint32_t rounds = 4 * ((a + 1) / 2) > 64 * kStagers ? 2u : 1u;
+    if (!long_ok && (groups > 1 || rounds > 1 || r > 1)) return g;
+    if (groups > 2 || (rounds == 2 && (channels % 2 != 0 || planes != 2))) return g;   // (two rounds: channel pairs, fp16 planes)
     uint32_t shift = 0, ob_max = 0;
     for (uint32_t t = 0; t < n_tiles; ++t) {
         const uint32_t ob = split_class_offset(a, b, 16 * t);
@@ -1133,12 +1264,12 @@ PeriodicGeometry split_geometry(uint64_t num, uint64_t den, uint32_t taps, uint3
         }
     }
     const uint32_t kpad = (taps + shift + 31) / 32 * 32;
-    if (kpad / 32 < 1 || kpad / 32 > 5 || taps > 16 * kWrapTaps) return g;
+    if (kpad / 32 < 1 || kpad / 32 > (rounds == 2 ? 6u : 5u) || taps > 16 * kWrapTaps) return g;
     // Rows a plane really needs: the last tile's window ends at ob_max + taps + shift.  The MFMA steps read
     // on to ob_max + kpad with zero coefficients -- into the rows that follow in LDS (the next plane, the next
     // image, the pad after the last image: always finite values, the whole LDS is zeroed at the start).
     const uint32_t rows = ob_max + taps + shift;
-    if (4 * ((a + 1) / 2) > 64 * kStagers || rows < a || rows > 2 * a) return g;   // (rows beyond a repeat the next period)
+    if (4 * ((a + 1) / 2) > 64 * kStagers * rounds || rows < a || rows > 2 * a) return g;   // (rows beyond a repeat the next period)
     const uint32_t pad = (kpad - (taps + shift)) * kRowBytes;
     uint32_t slots = (kLdsLimit - kImageBase - pad) / (rows * kRowBytes);   // ring of images: slack between producers and consumers
     if (slots > 4) slots = 4;
@@ -1146,7 +1277,7 @@ PeriodicGeometry split_geometry(uint64_t num, uint64_t den, uint32_t taps, uint3
     const uint32_t lds = kImageBase + slots * rows * kRowBytes + pad;
     g.a = a;
     g.b = b;
-    g.den = b;
+    g.den = static_cast<uint32_t>(den);   // the true period of the phase pattern (b = r den)
     g.taps = taps;
     g.row_len = kpad;
     g.n_tiles = n_tiles;
@@ -1160,6 +1291,8 @@ PeriodicGeometry split_geometry(uint64_t num, uint64_t den, uint32_t taps, uint3
     g.images = slots;
     g.mfma = 3;
     g.planes = planes;
+    g.groups = groups;
+    g.rounds = rounds;
     g.lds_bytes = lds;
     g.inline_wraps = true;
     g.ok = true;
@@ -1228,8 +1361,10 @@ hipError_t launch_fir_split(const FirStreamDesc* d_descs, uint32_t n_streams, co
     }();
     const uint32_t pairs = geo.lp;
     const bool wide = pairs > 1 || geo.cg == 1;
-    SplitArgs args{geo.a, geo.b, geo.taps, geo.n_tiles, geo.row_stride, geo.images, geo.lds_bytes, max_blocks, max_blocks * n_streams * pairs,
-                   debug, n_streams, fuse_tail ? 1u : 0u, geo.cg == 1 ? 1u : (geo.cg == 3 ? 2 * pairs - 1 : 2 * pairs), pairs, nullptr, nf};
+    const uint32_t groups = geo.groups ? geo.groups : 1u, per_group = max_blocks * n_streams * pairs;
+    SplitArgs args{geo.a, geo.b, geo.taps, geo.n_tiles, geo.row_stride, geo.images, geo.lds_bytes, max_blocks, per_group * groups,
+                   debug, n_streams, fuse_tail ? 1u : 0u, geo.cg == 1 ? 1u : (geo.cg == 3 ? 2 * pairs - 1 : 2 * pairs), pairs,
+                   groups, per_group, nullptr, nf};
     static const char* wtrace_path = getenv("RSMP_FIR_WTRACE");
     const bool diag = debug != 0 || wtrace_path != nullptr;
 #define RSMP_SPLIT_FNS(P, D, W)                                                                              \
@@ -1244,12 +1379,21 @@ hipError_t launch_fir_split(const FirStreamDesc* d_descs, uint32_t n_streams, co
 #undef RSMP_SPLIT_FNS
     const bool one_channel = geo.cg == 1;
     const bool odd_count = geo.cg == 3;
-    const void* const* fns = one_channel ? fns_mono[geo.planes == 3 ? 1 : 0]
+    // two rounds of lane tasks (periods of 161 .. 320 frames): two-channel fp16 kernel, windows of 5 or 6 steps
+    static const void* const fns_long[2][6] = {{nullptr, nullptr, nullptr, nullptr,
+                                                reinterpret_cast<const void*>(fir_split_kernel<5, 2, false, 0, 2>),
+                                                reinterpret_cast<const void*>(fir_split_kernel<6, 2, false, 0, 2>)},
+                                               {nullptr, nullptr, nullptr, nullptr,
+                                                reinterpret_cast<const void*>(fir_split_kernel<5, 2, false, 1, 2>),
+                                                reinterpret_cast<const void*>(fir_split_kernel<6, 2, false, 1, 2>)}};
+    const bool two_rounds = geo.rounds == 2;
+    const void* const* fns = two_rounds  ? fns_long[wide ? 1 : 0]
+                             : one_channel ? fns_mono[geo.planes == 3 ? 1 : 0]
                              : odd_count ? fns_odd[geo.planes == 3 ? 1 : 0]
                              : wide      ? fns_wide[geo.planes == 3 ? 1 : 0]
                                          : fns_all[geo.planes == 3 ? 1 : 0][diag ? 1 : 0];
     const uint32_t nk = geo.row_len / 32;
-    if (nk < 1 || nk > 5) return hipErrorInvalidValue;
+    if (nk < 1 || nk > (two_rounds ? 6u : 5u) || fns[nk - 1] == nullptr) return hipErrorInvalidValue;
     int device = 0;
     hipError_t e = hipGetDevice(&device);
     if (e != hipSuccess) return e;
@@ -1257,7 +1401,7 @@ hipError_t launch_fir_split(const FirStreamDesc* d_descs, uint32_t n_streams, co
     static std::map<std::pair<int, uint32_t>, bool> granted;
     {
         std::lock_guard<std::mutex> lock(mu);
-        bool& have = granted[{device, ((nk * 8 + geo.planes) * 2 + (diag && !wide ? 1u : 0u)) * 4 + (one_channel ? 2u : odd_count ? 3u : wide ? 1u : 0u)}];
+        bool& have = granted[{device, (((nk * 8 + geo.planes) * 2 + (diag && !wide ? 1u : 0u)) * 4 + (one_channel ? 2u : odd_count ? 3u : wide ? 1u : 0u)) * 2 + (two_rounds ? 1u : 0u)}];
         if (!have) {
             e = hipFuncSetAttribute(fns[nk - 1], hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit);
             if (e != hipSuccess) return e;
@@ -1267,8 +1411,8 @@ hipError_t launch_fir_split(const FirStreamDesc* d_descs, uint32_t n_streams, co
     const dim3 grid(args.total_items < cus ? args.total_items : cus);
     static const bool verbose = getenv("RSMP_FIR_VERBOSE") != nullptr;
     if (verbose)
-        fprintf(stderr, "[rsmp] split launch: a=%u b=%u window=%u tiles=%u rows=%u lds=%u items=%u grid=%u\n",
-                geo.a, geo.b, geo.row_len, geo.n_tiles, geo.row_stride, geo.lds_bytes, args.total_items, grid.x);
+        fprintf(stderr, "[rsmp] split launch: a=%u b=%u window=%u tiles=%u groups=%u rounds=%u rows=%u slots=%u lds=%u items=%u grid=%u\n",
+                geo.a, geo.b, geo.row_len, geo.n_tiles, groups, geo.rounds, geo.row_stride, geo.images, geo.lds_bytes, args.total_items, grid.x);
     static unsigned long long* d_wtrace = nullptr;
     const size_t wtrace_words = static_cast<size_t>(grid.x) * 16 * kWtraceSlots;
     if (wtrace_path) {

@@ -119,6 +119,10 @@ def test_error_codes_match_reference():
     (2, 48000, 96000, ra.Attenuation.Db90),
     (2, 96000, 48000, ra.Attenuation.Db90),
     (8, 96000, 44100, ra.Attenuation.Db120),
+    (2, 44100, 96000, ra.Attenuation.Db90),
+    (4, 44100, 96000, ra.Attenuation.Db90),
+    (2, 88200, 44100, ra.Attenuation.Db90),
+    (2, 192000, 48000, ra.Attenuation.Db90),
     (4, 22050, 48000, ra.Attenuation.Db60),
     # more than two channels at 147/160: even counts up to 16 run the split matrix kernel as channel pairs, the
     # others the vector kernel
@@ -148,6 +152,11 @@ def test_bulk_matches_reference_driver_loop(kernel, ch, in_hz, out_hz, att):
     assert yg2.size == yr2.size and rms(yg2, yr2) <= RMS_TOL
     if (kernel == ra.FirKernel.Periodic and ch in (1, 2, 3, 4, 6, 8, 12, 16) and {in_hz, out_hz} == {44100, 48000}
             and os.environ.get("RSMP_FIR_MFMA", "3") == "3" and os.environ.get("RSMP_FIR_SPLIT_WIDE", "1") != "0"):
+        assert g.kernel_variant() == SPLIT_VARIANT
+    # the other rate pairs of config 4 and config 5's: tile groups (up to 320 classes), two rounds of lane tasks (periods of
+    # up to 320 frames), super periods of exact ratios (48 <-> 96 kHz)
+    if (kernel == ra.FirKernel.Periodic and (ch, in_hz, out_hz) in ((2, 96000, 44100), (1, 44100, 96000), (2, 48000, 96000), (2, 96000, 48000))
+            and os.environ.get("RSMP_FIR_MFMA", "3") == "3" and os.environ.get("RSMP_FIR_SPLIT_LONG", "1") != "0" and SPLIT_VARIANT == 5):
         assert g.kernel_variant() == SPLIT_VARIANT
     if kernel == ra.FirKernel.PeriodicVector:
         assert g.kernel_variant() in (1, 2)   # never the matrix-core kernel
@@ -326,7 +335,8 @@ def test_matrix_core_kernel_ragged_batch_and_edges(kernel):
     yg, _ = g.resample_bulk(x, 512)
     yr, _ = r.resample_all(x, 512)
     assert yg.size == yr.size and rms(yg, yr) <= RMS_TOL
-    assert g.kernel_variant() == (3 if mfma_on else 1)
+    long_split = split and os.environ.get("RSMP_FIR_SPLIT_LONG", "1") != "0" and SPLIT_VARIANT == 5   # (two tile groups on the split kernel)
+    assert g.kernel_variant() == ((SPLIT_VARIANT if long_split else 3) if mfma_on else 1)
 
 
 def test_batch_with_two_rate_pairs_and_mixed_kernels():

@@ -15,7 +15,8 @@ from resampler_amd import synth
 def main():
     dev = torch.device("cuda:0")
     frames = 1 << 20
-    for ch, in_hz, out_hz in ((1, 48000, 44100), (3, 44100, 48000), (4, 96000, 44100), (4, 44100, 48000), (6, 44100, 48000),
+    for ch, in_hz, out_hz in ((2, 44100, 96000), (2, 96000, 44100), (2, 48000, 96000), (2, 96000, 48000), (2, 48000, 44100),
+                              (1, 48000, 44100), (3, 44100, 48000), (4, 96000, 44100), (4, 44100, 48000), (6, 44100, 48000),
                               (6, 96000, 44100), (8, 96000, 44100), (8, 44100, 48000), (8, 48000, 96000)):
         streams = max(1, 128 // ch)
         hs = [ra.ResamplerFir.new_from_hz(ch, in_hz, out_hz, ra.Latency.Sample64, ra.Attenuation.Db90) for _ in range(streams)]
