@@ -545,7 +545,6 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
                 tK[rd] = t - tQ[rd] * half_a;
             }
             const bool real_task = real_rd[0];
-            float xs = kXScale;   // two planes: the current item's sample scale (block floating point, see `peak`)
             uint64_t hist_e = 0;                  // latest final peak exponent per channel pair (8 bits each; 0 = none) ...
             uint32_t hist_stream = 0xFFFFFFFFu;   // ... of this stream
             uint32_t n_met = 0;                   // meetings at `premax` so far
@@ -565,15 +564,16 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
             // for the odd one.  Per item that is five loads as in the two-channel kernel, and every line is used whole.
             // one channel: the two frames of a period are neighbours -- one 8-byte load; the phantom channel of frame 2K
             // is frame 2K + 1, that of frame 2K + 1 is zero
-            // two rounds, channel pairs: the pair's two channels of a frame are one 8-byte load (sixteen-byte loads shared by
-            // two items, as the one-round stagers have them, would hold both rounds' registers across two items)
-            auto load_task_pair = [&](v2f (&lo)[5], v2f (&hi)[5], const PItem& pi, const void* base, int rd) {
+            // two rounds, channel pairs: a 16-byte load is four channels of a frame -- the even pair of a block and its odd
+            // partner; a stager converts both items from the same registers (even pair into this slot's image, odd pair
+            // into the next slot's), round after round
+            auto load_task_quad = [&](v4f (&v)[5][2], const PItem& pi, const void* base, int rd) {
                 const uint32_t off = (pi.off0 + 4 * tQ[rd] * g.a + 2 * tK[rd]) * fsb;
                 const uint32_t step = g.a * fsb;
 #pragma unroll
                 for (int i = 0; i < 5; ++i) {
-                    gload2(lo[i], off + i * step, base);
-                    gload2(hi[i], off + i * step + fsb, base);
+                    gload4(v[i][0], off + i * step, base);
+                    gload4(v[i][1], off + i * step + fsb, base);
                 }
             };
             auto load_task_mono = [&](v2f (&v)[5], const PItem& pi, const void* base) {
@@ -593,7 +593,7 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
             };
             // v[i] = (ch0, ch1) of frame 2K and (ch0, ch1) of frame 2K+1 in period 4Q+i
             // at(i, fr, c) = channel c of frame 2K + fr in period 4Q + i
-            auto store_task = [&](char* img, auto&& at, int rd) {
+            auto store_task = [&](char* img, auto&& at, int rd, float xsc) {
                 typedef uint32_t u2 __attribute__((ext_vector_type(2)));
                 const uint32_t tQ_ = tQ[rd];
                 const uint32_t k0 = 2 * tK[rd];   // rows k0 and k0 + 1 share a swizzle (k0 is even)
@@ -626,7 +626,7 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
                             // two fp16 planes: h1 = RN16(s), h2 = RN16(s - h1) with s = 2^12 x (s - h1 is exact)
                             float s[5];
 #pragma unroll
-                            for (int i = 0; i < 5; ++i) s[i] = at(i, fr, c) * xs;
+                            for (int i = 0; i < 5; ++i) s[i] = at(i, fr, c) * xsc;
                             const uint32_t a01 = cvt_pk_f16(s[0], s[1]), a23 = cvt_pk_f16(s[2], s[3]), a4 = cvt_pk_f16(s[4], s[4]);
                             const uint32_t b01 = cvt_pk_f16(s[0] - f16_lo(a01), s[1] - f16_hi(a01));
                             const uint32_t b23 = cvt_pk_f16(s[2] - f16_lo(a23), s[3] - f16_hi(a23));
@@ -694,8 +694,9 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
                 if (wpart == 0) *reinterpret_cast<v4f*>(wv + wper * 4) = v4f{acc.x, acc.y, __uint_as_float(take), 0.f};
             };
             v4f x[5];
-            v2f xl[5], xh[5];     // ROLE 3, channel pairs: frames 2K and 2K + 1 of a period (the pair's two channels)
-            constexpr bool kPairLoads = ROLE == 3 && WIDE == 1;
+            constexpr bool kShare = ROLE == 3 && WIDE == 1;   // two rounds, channel pairs: an even item stages its odd partner too
+            bool odd_done = false;     // kShare: the current (odd) item was staged with the item before it
+            uint32_t cur_item = 0;     // the current item's index in the launch
             v4f xq[5][2];         // ROLE 2: (period, frame) x four channels
             v2f xm[5];            // ROLE 2, one channel: frames 2K, 2K + 1 of a period
             uint32_t cpair = 0;   // WIDE: the current item's channel pair
@@ -705,6 +706,7 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
                 bool pre = more && nxt.interior && !(dbg & 8192);   // the next item's loads can be issued ahead
                 // (a WIDE stager's odd pair lives on its even neighbour's loads, the item before it in this loop)
                 if constexpr (ROLE == 2) pre = pre && ((nxt.pair & 1u) == 0 || (have && loaded));
+                if constexpr (kShare) pre = pre && (nxt.pair & 1u) == 0;   // (an odd item is staged by its even neighbour, or from plain loads)
                 asm volatile("" : "+v"(ln));
 #pragma unroll
                 for (int rd = 0; rd < ROUNDS; ++rd) asm volatile("" : "+v"(tQ[rd]), "+v"(tK[rd]));
@@ -721,15 +723,12 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
                 }
                 asm volatile("s_waitcnt vmcnt(0)" : : : "memory");   // the current item's loads (or dummies)
                 if (have) wt.event(6);
-                if constexpr (ROLE == 2) {
+                if constexpr (ROLE == 2 || kShare) {
 #pragma unroll
                     for (int i = 0; i < 5; ++i) {
                         if constexpr (mono) asm volatile("" : "+v"(xm[i]));
                         else asm volatile("" : "+v"(xq[i][0]), "+v"(xq[i][1]));
                     }
-                } else if constexpr (kPairLoads) {
-#pragma unroll
-                    for (int i = 0; i < 5; ++i) asm volatile("" : "+v"(xl[i]), "+v"(xh[i]));
                 } else if constexpr (ROLE == 0 || ROLE == 3) {
 #pragma unroll
                     for (int i = 0; i < 5; ++i) asm volatile("" : "+v"(x[i]));
@@ -745,48 +744,49 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
                     }
                     asm volatile("" : "+v"(wword[ps]));
                 }
-                if constexpr (ROLE != 1) if (have && real_task && !(dbg & 1)) {
+                const bool staged_already = kShare && odd_done;   // (an odd item its even neighbour has staged)
+                if constexpr (kShare) odd_done = false;
+                if constexpr (ROLE != 1) if (have && real_task && !(dbg & 1) && !staged_already) {
                     // stream edges: frames outside [hist|in] read as zero; plain loads into the registers of the asm loads
                     auto fetch_edge_round = [&](int rd) {
 #pragma unroll
                         for (int i = 0; i < 5; ++i) {
                             const int64_t f = ecur.f0 + static_cast<int64_t>((4 * tQ[rd] + i) * g.a + 2 * tK[rd]);
                             const v2f lo = fetch_edge(ectx, ecur.pair, f), hi = fetch_edge(ectx, ecur.pair, f + 1);
-                            if constexpr (ROLE == 2) {
+                            if constexpr (ROLE == 2 || kShare) {
                                 if constexpr (mono) xm[i] = v2f{lo.x, hi.x};
                                 else {
                                     xq[i][0] = v4f{lo.x, lo.y, lo.x, lo.y};
                                     xq[i][1] = v4f{hi.x, hi.y, hi.x, hi.y};
                                 }
-                            } else if constexpr (kPairLoads) {
-                                xl[i] = lo;
-                                xh[i] = hi;
                             } else {
                                 x[i] = v4f{lo.x, lo.y, hi.x, hi.y};
                             }
                         }
                     };
                     if (!loaded) fetch_edge_round(0);
-                    // at(i, fr, c) = channel c of frame 2K + fr in period 4Q + i of the lane task in the registers
+                    // at(i, fr, c) = channel c of frame 2K + fr in period 4Q + i of the lane task in the registers; partner:
+                    // the same of the block's odd pair (kShare: the upper half of the sixteen bytes)
                     auto at = [&](int i, int fr, int c) -> float {
                         if constexpr (ROLE == 2) {
                             if constexpr (mono) return c == 0 ? xm[i][fr] : (fr == 0 ? xm[i][1] : 0.f);
                             else return (cpair & 1u) ? xq[i][fr][2 + c] : xq[i][fr][c];
-                        } else if constexpr (kPairLoads) {
-                            return fr ? xh[i][c] : xl[i][c];
+                        } else if constexpr (kShare) {
+                            return xq[i][fr][c];
                         } else {
                             return x[i][2 * fr + c];
                         }
                     };
+                    auto at_partner = [&](int i, int fr, int c) -> float { return xq[i][fr][2 + c]; };
                     // the peak of the samples in the registers: this lane's, the wave's, then (one atomic) into the item's
-                    auto add_peak = [&]() {
+                    auto add_peak = [&](auto&& src, uint32_t sl, uint32_t us) {
                         float m = 0.f;
 #pragma unroll
                         for (int i = 0; i < 5; ++i)
 #pragma unroll
                             for (int fr = 0; fr < 2; ++fr)
 #pragma unroll
-                                for (int c = 0; c < (mono ? 1 : 2); ++c) m = __builtin_fmaxf(m, __builtin_fabsf(at(i, fr, c)));
+                                for (int c = 0; c < (mono ? 1 : 2); ++c) m = __builtin_fmaxf(m, __builtin_fabsf(src(i, fr, c)));
                         uint32_t mb = __float_as_uint(m);   // (non-negative floats order like their bit patterns; a NaN is left to the sums)
                         mb = max(mb, static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(mb), 0x128, 0xf, 0xf, false)));
                         mb = max(mb, static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(mb), 0x124, 0xf, 0xf, false)));
@@ -797,12 +797,10 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
                                                 max(static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(mb), 32)),
                                                     static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(mb), 48))));
                         if (lane == 0)
-                            (void)__hip_atomic_fetch_max(peak + slot, ((use + 1) << 8) | (wm >> 23), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            (void)__hip_atomic_fetch_max(peak + sl, ((us + 1) << 8) | (wm >> 23), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     };
-                    uint32_t e_hist = 0;
-                    if constexpr (PLANES == 2) {
-                        // what the slot's previous item (`slots` items back) turned out to peak at: into the running table
-                        const uint32_t f_id = __builtin_amdgcn_readfirstlane(f_id_v), f_e = __builtin_amdgcn_readfirstlane(f_e_v);
+                    // what a slot's previous item (`slots` items back) turned out to peak at: into the running table
+                    auto note_fin = [&](uint32_t f_id, uint32_t f_e) {
                         if (f_id != 0) {
                             const uint32_t f_stream = (f_id - 1) >> 4, f_pair = (f_id - 1) & 15u;
                             if (f_stream != hist_stream) {
@@ -811,13 +809,12 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
                             }
                             hist_e = (hist_e & ~(0xFFull << (8 * f_pair))) | (static_cast<uint64_t>(f_e) << (8 * f_pair));
                         }
-                        e_hist = hist_stream == cstream ? static_cast<uint32_t>(hist_e >> (8 * cpair)) & 255u : 0u;
-                        add_peak();
-                    }
-                    // the item's scale: predicted from the pair's latest peak, or (no history) from the peak of what the stagers
+                    };
+                    auto hist_of = [&](uint32_t pr) -> uint32_t { return hist_stream == cstream ? static_cast<uint32_t>(hist_e >> (8 * pr)) & 255u : 0u; };
+                    // an item's scale: predicted from its pair's latest peak, or (no history) from the peak of what the stagers
                     // hold once every one of them has added its share -- the whole item, or (two rounds) its first round:
                     // ten of its sixteen periods, taken with the same headroom as a prediction
-                    auto set_scale = [&]() {
+                    auto scale_for = [&](uint32_t e_hist, uint32_t sl) -> float {
                         uint32_t E;
                         if (e_hist != 0) {   // 2^4 above the pair's latest peak
                             E = e_hist + kPeakHeadroom;
@@ -827,43 +824,72 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
                             lds_signal(premax);
                             ++n_met;
                             while (lds_load_acquire(premax) < n_real * n_met) __builtin_amdgcn_s_sleep(RSMP_POLL_SLEEP);
-                            E = __hip_atomic_load(peak + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) & 255u;
+                            E = __hip_atomic_load(peak + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) & 255u;
                             if (ROUNDS == 2 && E != 0) E += kPeakHeadroom;
                         }
                         // (never scaled for peaks of 2^11 and above: such samples must overflow the planes and have the item
                         // redone, not push the audio next to them below the planes' range)
                         E = E > kPeakMax ? kPeakMax : E;
                         E = __builtin_amdgcn_readfirstlane(E < 31u ? 31u : E);   // (below 2^-96: treated as that)
+                        if (P == 0 && lane == 0) used[sl] = E;
                         // a peak in [2^(E-127), 2^(E-126)) times 2^(141-E) lies in [2^14, 2^15), inside fp16
-                        xs = __uint_as_float((268u - E) << 23);
-                        if (P == 0 && lane == 0) used[slot] = E;
+                        return __uint_as_float((268u - E) << 23);
                     };
-                    if constexpr (PLANES == 2) set_scale();
+                    float xs = kXScale, xs2 = kXScale;   // the item's sample scale (block floating point); its partner's
+                    if constexpr (PLANES == 2) {
+                        note_fin(__builtin_amdgcn_readfirstlane(f_id_v), __builtin_amdgcn_readfirstlane(f_e_v));
+                        add_peak(at, slot, use);
+                        xs = scale_for(hist_of(cpair), slot);
+                    }
                     wt.event(9);
-                    store_task(img, at, 0);
+                    store_task(img, at, 0, xs);
+                    // kShare: the block's odd pair from the same registers, into the next slot's image
+                    bool share = false;
+                    uint32_t slot2 = 0, use2 = 0;
+                    char* img2 = img;
+                    if constexpr (kShare) {
+                        share = loaded && more && (cpair & 1u) == 0 && nxt.item == cur_item + 1 && nxt.pair == cpair + 1;
+                        if (share) {
+                            slot2 = slot + 1 == g.slots ? 0u : slot + 1;
+                            use2 = slot + 1 == g.slots ? use + 1 : use;
+                            img2 = lds + kImageBase + slot2 * image_bytes;
+                            while (lds_load_acquire(done + slot2) < n_active * use2) __builtin_amdgcn_s_sleep(RSMP_POLL_SLEEP);
+                            note_fin(__builtin_amdgcn_readfirstlane(__hip_atomic_load(fin + 2 * slot2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)),
+                                     __builtin_amdgcn_readfirstlane(__hip_atomic_load(fin + 2 * slot2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)));
+                            add_peak(at_partner, slot2, use2);
+                            xs2 = scale_for(hist_of(cpair + 1), slot2);
+                            store_task(img2, at_partner, 0, xs2);
+                        }
+                    }
                     if constexpr (ROUNDS == 2) {
                         // Two rounds of lane tasks through ONE set of registers (two sets next to the consumers' coefficient
-                        // tile spill): round 0 arrived with the item; round 1 is loaded while the consumers still read the
-                        // image before, converted and written behind round 0.
+                        // tile spill): round 0 arrived with the item; round 1 is loaded here, converted and written behind it.
                         if (real_rd[1]) {
                             if (loaded) {
                                 PItem pc;   // (of an interior item only where its frames start is needed)
                                 pc.off0 = cur_off0;
-                                if constexpr (kPairLoads) load_task_pair(xl, xh, pc, uniform_ptr<true>(cur_in), 1);
+                                if constexpr (kShare) load_task_quad(xq, pc, uniform_ptr<true>(cur_in), 1);
                                 else load_task(x, true, pc, uniform_ptr<true>(cur_in), 1);
                                 asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
 #pragma unroll
                                 for (int i = 0; i < 5; ++i) {
-                                    if constexpr (kPairLoads) asm volatile("" : "+v"(xl[i]), "+v"(xh[i]));
+                                    if constexpr (kShare) asm volatile("" : "+v"(xq[i][0]), "+v"(xq[i][1]));
                                     else asm volatile("" : "+v"(x[i]));
                                 }
                             } else {
                                 fetch_edge_round(1);
                             }
-                            add_peak();
-                            store_task(img, at, 1);
+                            if constexpr (PLANES == 2) add_peak(at, slot, use);
+                            store_task(img, at, 1, xs);
+                            if constexpr (kShare) {
+                                if (share) {
+                                    add_peak(at_partner, slot2, use2);
+                                    store_task(img2, at_partner, 1, xs2);
+                                }
+                            }
                         }
                     }
+                    if constexpr (kShare) odd_done = share;
                 }
                 auto wrap_passes = [&](bool from_regs) {
 #pragma unroll
@@ -917,8 +943,8 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
                         if constexpr (mono) {
                             if (real_task) load_task_mono(xm, nxt, uniform_ptr<true>(cu.c.in));
                         } else if (real_task && (nxt.pair & 1u) == 0) load_task_wide(xq, nxt, uniform_ptr<true>(cu.c.in + 2 * nxt.pair));
-                    } else if constexpr (kPairLoads) {
-                        if (real_task) load_task_pair(xl, xh, nxt, uniform_ptr<true>(cu.c.in + 2 * nxt.pair), 0);
+                    } else if constexpr (kShare) {
+                        if (real_task) load_task_quad(xq, nxt, uniform_ptr<true>(cu.c.in + 2 * nxt.pair), 0);   // (an even pair: `pre`)
                     } else if constexpr (ROLE == 0 || ROLE == 3) {
                         if (real_task) load_task(x, true, nxt, uniform_ptr<true>(cu.c.in), 0);   // (two rounds: round 0)
                     }
@@ -943,6 +969,7 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
                 }
                 if (more) {
                     cpair = nxt.pair;
+                    cur_item = nxt.item;
                     cstream = cu.c.sidx;
                     cur_off0 = nxt.off0;
                     cur_in = cu.c.in + (WIDE == 1 ? 2 * nxt.pair : 0u);
@@ -1265,6 +1292,7 @@ PeriodicGeometry split_geometry(uint64_t num, uint64_t den, uint32_t taps, uint3
     }
     const uint32_t kpad = (taps + shift + 31) / 32 * 32;
     if (kpad / 32 < 1 || kpad / 32 > (rounds == 2 ? 6u : 5u) || taps > 16 * kWrapTaps) return g;
+    if (rounds == 2 && kpad / 32 < 5) return g;   // (the two-round kernels exist for windows of 160 and 192 taps: 128-tap filters)
     // Rows a plane really needs: the last tile's window ends at ob_max + taps + shift.  The MFMA steps read
     // on to ob_max + kpad with zero coefficients -- into the rows that follow in LDS (the next plane, the next
     // image, the pad after the last image: always finite values, the whole LDS is zeroed at the start).

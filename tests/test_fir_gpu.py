@@ -155,7 +155,7 @@ def test_bulk_matches_reference_driver_loop(kernel, ch, in_hz, out_hz, att):
         assert g.kernel_variant() == SPLIT_VARIANT
     # the other rate pairs of config 4 and config 5's: tile groups (up to 320 classes), two rounds of lane tasks (periods of
     # up to 320 frames), super periods of exact ratios (48 <-> 96 kHz)
-    if (kernel == ra.FirKernel.Periodic and (ch, in_hz, out_hz) in ((2, 96000, 44100), (1, 44100, 96000), (2, 48000, 96000), (2, 96000, 48000))
+    if (kernel == ra.FirKernel.Periodic and (ch, in_hz, out_hz) in ((2, 96000, 44100), (8, 96000, 44100), (2, 44100, 96000), (4, 44100, 96000), (2, 48000, 96000), (2, 96000, 48000), (2, 88200, 44100), (2, 192000, 48000))
             and os.environ.get("RSMP_FIR_MFMA", "3") == "3" and os.environ.get("RSMP_FIR_SPLIT_LONG", "1") != "0" and SPLIT_VARIANT == 5):
         assert g.kernel_variant() == SPLIT_VARIANT
     if kernel == ra.FirKernel.PeriodicVector:
