@@ -385,7 +385,7 @@ __device__ __forceinline__ uint32_t consumer_index(uint32_t w) { return w < 6 ? 
 template <int NK, int PLANES, bool DIAG, int WIDE, int ROUNDS = 1>   // WIDE: 0 two channels, 1 channel pairs, 2 one channel, 3 pairs + a last channel alone
 __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __restrict__ descs,
                                                          const SplitArgs g) {
-    static_assert(ROUNDS == 1 || ((WIDE == 0 || WIDE == 1) && PLANES == 2 && !DIAG), "two rounds: two channels or channel pairs, fp16 planes");
+    static_assert(ROUNDS == 1 || ((WIDE == 0 || WIDE == 1) && PLANES == 2), "two rounds: two channels or channel pairs, fp16 planes");
     constexpr uint32_t kRowBytes = row_bytes(PLANES);
     const uint32_t fs = WIDE ? g.cstride : 2u;   // floats per frame
     const uint32_t fsb = fs * 4u;                // bytes per frame
@@ -576,6 +576,12 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
                     gload4(v[i][1], off + i * step + fsb, base);
                 }
             };
+            auto load_task_quad_half = [&](v4f (&v)[5][2], const PItem& pi, const void* base, int rd, int fr) {
+                const uint32_t off = (pi.off0 + 4 * tQ[rd] * g.a + 2 * tK[rd]) * fsb + fr * fsb;
+                const uint32_t step = g.a * fsb;
+#pragma unroll
+                for (int i = 0; i < 5; ++i) gload4(v[i][fr], off + i * step, base);
+            };
             auto load_task_mono = [&](v2f (&v)[5], const PItem& pi, const void* base) {
                 const uint32_t off = (pi.off0 + 4 * tQ[0] * g.a + 2 * tK[0]) * 4u;
                 const uint32_t step = g.a * 4u;
@@ -593,7 +599,7 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
             };
             // v[i] = (ch0, ch1) of frame 2K and (ch0, ch1) of frame 2K+1 in period 4Q+i
             // at(i, fr, c) = channel c of frame 2K + fr in period 4Q + i
-            auto store_task = [&](char* img, auto&& at, int rd, float xsc) {
+            auto store_task = [&](char* img, auto&& at, int rd, float xsc, int fr_lo = 0, int fr_hi = 2) {
                 typedef uint32_t u2 __attribute__((ext_vector_type(2)));
                 const uint32_t tQ_ = tQ[rd];
                 const uint32_t k0 = 2 * tK[rd];   // rows k0 and k0 + 1 share a swizzle (k0 is even)
@@ -609,6 +615,7 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
                 for (int c = 0; c < 2; ++c) {          // channel
 #pragma unroll
                     for (int fr = 0; fr < 2; ++fr) {   // frame 2K + fr
+                        if (fr < fr_lo || fr >= fr_hi) continue;   // (a compile-time range at every call site)
                         char* pr = fr ? prim1 : prim;
                         char* du = fr ? dup1 : dup0;
                         if constexpr (PLANES == 3) {
@@ -694,6 +701,7 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
                 if (wpart == 0) *reinterpret_cast<v4f*>(wv + wper * 4) = v4f{acc.x, acc.y, __uint_as_float(take), 0.f};
             };
             v4f x[5];
+            v4f x2[5];            // two rounds, two channels: round 1's loads
             constexpr bool kShare = ROLE == 3 && WIDE == 1;   // two rounds, channel pairs: an even item stages its odd partner too
             bool odd_done = false;     // kShare: the current (odd) item was staged with the item before it
             uint32_t cur_item = 0;     // the current item's index in the launch
@@ -778,15 +786,20 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
                         }
                     };
                     auto at_partner = [&](int i, int fr, int c) -> float { return xq[i][fr][2 + c]; };
-                    // the peak of the samples in the registers: this lane's, the wave's, then (one atomic) into the item's
-                    auto add_peak = [&](auto&& src, uint32_t sl, uint32_t us) {
-                        float m = 0.f;
+                    // the peak of the samples in the registers: this lane's (lane_max), then the wave's and (one atomic) into
+                    // the item's (publish) -- once per item and pair where the scale is predicted, once more after the first
+                    // round where the scale is taken from it
+                    auto lane_max = [&](auto&& src, float m, int fr_lo = 0, int fr_hi = 2) -> float {
 #pragma unroll
                         for (int i = 0; i < 5; ++i)
 #pragma unroll
                             for (int fr = 0; fr < 2; ++fr)
 #pragma unroll
-                                for (int c = 0; c < (mono ? 1 : 2); ++c) m = __builtin_fmaxf(m, __builtin_fabsf(src(i, fr, c)));
+                                for (int c = 0; c < (mono ? 1 : 2); ++c)
+                                    if (fr >= fr_lo && fr < fr_hi) m = __builtin_fmaxf(m, __builtin_fabsf(src(i, fr, c)));
+                        return m;
+                    };
+                    auto publish = [&](float m, uint32_t sl, uint32_t us) {
                         uint32_t mb = __float_as_uint(m);   // (non-negative floats order like their bit patterns; a NaN is left to the sums)
                         mb = max(mb, static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(mb), 0x128, 0xf, 0xf, false)));
                         mb = max(mb, static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(mb), 0x124, 0xf, 0xf, false)));
@@ -836,13 +849,16 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
                         return __uint_as_float((268u - E) << 23);
                     };
                     float xs = kXScale, xs2 = kXScale;   // the item's sample scale (block floating point); its partner's
+                    float m_own = 0.f, m_partner = 0.f;   // running peaks of this lane's samples (own pair, partner pair)
+                    constexpr bool kLatePeak = ROUNDS == 2;   // (one round: the item's whole peak is known here)
                     if constexpr (PLANES == 2) {
                         note_fin(__builtin_amdgcn_readfirstlane(f_id_v), __builtin_amdgcn_readfirstlane(f_e_v));
-                        add_peak(at, slot, use);
-                        xs = scale_for(hist_of(cpair), slot);
+                        m_own = lane_max(at, 0.f);
+                        const uint32_t eh = hist_of(cpair);
+                        if (!kLatePeak || eh == 0 || !real_rd[ROUNDS - 1]) publish(m_own, slot, use);
+                        xs = scale_for(eh, slot);
                     }
                     wt.event(9);
-                    store_task(img, at, 0, xs);
                     // kShare: the block's odd pair from the same registers, into the next slot's image
                     bool share = false;
                     uint32_t slot2 = 0, use2 = 0;
@@ -856,38 +872,78 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
                             while (lds_load_acquire(done + slot2) < n_active * use2) __builtin_amdgcn_s_sleep(RSMP_POLL_SLEEP);
                             note_fin(__builtin_amdgcn_readfirstlane(__hip_atomic_load(fin + 2 * slot2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)),
                                      __builtin_amdgcn_readfirstlane(__hip_atomic_load(fin + 2 * slot2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)));
-                            add_peak(at_partner, slot2, use2);
-                            xs2 = scale_for(hist_of(cpair + 1), slot2);
-                            store_task(img2, at_partner, 0, xs2);
+                            m_partner = lane_max(at_partner, 0.f);
+                            const uint32_t eh2 = hist_of(cpair + 1);
+                            if (eh2 == 0 || !real_rd[ROUNDS - 1]) publish(m_partner, slot2, use2);
+                            xs2 = scale_for(eh2, slot2);
                         }
                     }
-                    if constexpr (ROUNDS == 2) {
-                        // Two rounds of lane tasks through ONE set of registers (two sets next to the consumers' coefficient
-                        // tile spill): round 0 arrived with the item; round 1 is loaded here, converted and written behind it.
+                    PItem pc;   // (of an interior item only where its frames start is needed)
+                    pc.off0 = cur_off0;
+                    if constexpr (kShare) {
+                        // Two rounds through ONE set of registers, pipelined by frame: when the frames 2K of round 0 are
+                        // written their registers take round 1's frames 2K, which fly while the frames 2K + 1 are written.
+                        const bool ahead = loaded && real_rd[1];
+                        store_task(img, at, 0, xs, 0, 1);
+                        if (share) store_task(img2, at_partner, 0, xs2, 0, 1);
+                        if (ahead) load_task_quad_half(xq, pc, uniform_ptr<true>(cur_in), 1, 0);
+                        store_task(img, at, 0, xs, 1, 2);
+                        if (share) store_task(img2, at_partner, 0, xs2, 1, 2);
                         if (real_rd[1]) {
-                            if (loaded) {
-                                PItem pc;   // (of an interior item only where its frames start is needed)
-                                pc.off0 = cur_off0;
-                                if constexpr (kShare) load_task_quad(xq, pc, uniform_ptr<true>(cur_in), 1);
-                                else load_task(x, true, pc, uniform_ptr<true>(cur_in), 1);
+                            wt.event(10);
+                            if (ahead) {
+                                load_task_quad_half(xq, pc, uniform_ptr<true>(cur_in), 1, 1);
+                                asm volatile("s_waitcnt vmcnt(5)" : : : "memory");   // the frames 2K (the five loads issued last may fly on)
+#pragma unroll
+                                for (int i = 0; i < 5; ++i) asm volatile("" : "+v"(xq[i][0]));
+                            } else {
+                                fetch_edge_round(1);
+                            }
+                            wt.event(3);
+                            m_own = lane_max(at, m_own, 0, 1);
+                            store_task(img, at, 1, xs, 0, 1);
+                            if (share) {
+                                m_partner = lane_max(at_partner, m_partner, 0, 1);
+                                store_task(img2, at_partner, 1, xs2, 0, 1);
+                            }
+                            if (ahead) {
+                                asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+#pragma unroll
+                                for (int i = 0; i < 5; ++i) asm volatile("" : "+v"(xq[i][1]));
+                            }
+                            m_own = lane_max(at, m_own, 1, 2);
+                            publish(m_own, slot, use);
+                            store_task(img, at, 1, xs, 1, 2);
+                            if (share) {
+                                m_partner = lane_max(at_partner, m_partner, 1, 2);
+                                publish(m_partner, slot2, use2);
+                                store_task(img2, at_partner, 1, xs2, 1, 2);
+                            }
+                        }
+                    } else if constexpr (ROUNDS == 2) {
+                        // Two rounds (two channels): round 1's loads fly while round 0's planes are written (a second set
+                        // of registers: twenty more next to a 99-register kernel)
+                        const bool ahead = loaded && real_rd[1];
+                        if (ahead) load_task(x2, true, pc, uniform_ptr<true>(cur_in), 1);
+                        store_task(img, at, 0, xs);
+                        if (real_rd[1]) {
+                            wt.event(10);
+                            if (ahead) {
                                 asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
 #pragma unroll
                                 for (int i = 0; i < 5; ++i) {
-                                    if constexpr (kShare) asm volatile("" : "+v"(xq[i][0]), "+v"(xq[i][1]));
-                                    else asm volatile("" : "+v"(x[i]));
+                                    asm volatile("" : "+v"(x2[i]));
+                                    x[i] = x2[i];
                                 }
                             } else {
                                 fetch_edge_round(1);
                             }
-                            if constexpr (PLANES == 2) add_peak(at, slot, use);
+                            wt.event(3);
+                            if constexpr (PLANES == 2) publish(lane_max(at, m_own), slot, use);
                             store_task(img, at, 1, xs);
-                            if constexpr (kShare) {
-                                if (share) {
-                                    add_peak(at_partner, slot2, use2);
-                                    store_task(img2, at_partner, 1, xs2);
-                                }
-                            }
                         }
+                    } else {
+                        store_task(img, at, 0, xs);
                     }
                     if constexpr (kShare) odd_done = share;
                 }
@@ -1408,14 +1464,20 @@ hipError_t launch_fir_split(const FirStreamDesc* d_descs, uint32_t n_streams, co
     const bool one_channel = geo.cg == 1;
     const bool odd_count = geo.cg == 3;
     // two rounds of lane tasks (periods of 161 .. 320 frames): two-channel fp16 kernel, windows of 5 or 6 steps
-    static const void* const fns_long[2][6] = {{nullptr, nullptr, nullptr, nullptr,
+    static const void* const fns_long[4][6] = {{nullptr, nullptr, nullptr, nullptr,
                                                 reinterpret_cast<const void*>(fir_split_kernel<5, 2, false, 0, 2>),
                                                 reinterpret_cast<const void*>(fir_split_kernel<6, 2, false, 0, 2>)},
                                                {nullptr, nullptr, nullptr, nullptr,
                                                 reinterpret_cast<const void*>(fir_split_kernel<5, 2, false, 1, 2>),
-                                                reinterpret_cast<const void*>(fir_split_kernel<6, 2, false, 1, 2>)}};
+                                                reinterpret_cast<const void*>(fir_split_kernel<6, 2, false, 1, 2>)},
+                                               // (diagnostic builds of the 192-tap window: config 5's geometry)
+                                               {nullptr, nullptr, nullptr, nullptr, nullptr,
+                                                reinterpret_cast<const void*>(fir_split_kernel<6, 2, true, 0, 2>)},
+                                               {nullptr, nullptr, nullptr, nullptr, nullptr,
+                                                reinterpret_cast<const void*>(fir_split_kernel<6, 2, true, 1, 2>)}};
     const bool two_rounds = geo.rounds == 2;
-    const void* const* fns = two_rounds  ? fns_long[wide ? 1 : 0]
+    const bool diag_long = two_rounds && diag && geo.row_len / 32 == 6;
+    const void* const* fns = two_rounds  ? fns_long[(wide ? 1 : 0) + (diag_long ? 2 : 0)]
                              : one_channel ? fns_mono[geo.planes == 3 ? 1 : 0]
                              : odd_count ? fns_odd[geo.planes == 3 ? 1 : 0]
                              : wide      ? fns_wide[geo.planes == 3 ? 1 : 0]
@@ -1429,7 +1491,7 @@ hipError_t launch_fir_split(const FirStreamDesc* d_descs, uint32_t n_streams, co
     static std::map<std::pair<int, uint32_t>, bool> granted;
     {
         std::lock_guard<std::mutex> lock(mu);
-        bool& have = granted[{device, (((nk * 8 + geo.planes) * 2 + (diag && !wide ? 1u : 0u)) * 4 + (one_channel ? 2u : odd_count ? 3u : wide ? 1u : 0u)) * 2 + (two_rounds ? 1u : 0u)}];
+        bool& have = granted[{device, (((nk * 8 + geo.planes) * 2 + ((diag && !wide) || diag_long ? 1u : 0u)) * 4 + (one_channel ? 2u : odd_count ? 3u : wide ? 1u : 0u)) * 2 + (two_rounds ? 1u : 0u)}];
         if (!have) {
             e = hipFuncSetAttribute(fns[nk - 1], hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit);
             if (e != hipSuccess) return e;

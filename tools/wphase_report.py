@@ -3,7 +3,7 @@
 cycles per item spent in each phase, per wave of the workgroup (averaged over workgroups)."""
 import sys
 import numpy as np
-NAMES = {1: "wait staged", 2: "MFMA", 7: "signal+stores", 8: "next item", 11: "wait free", 12: "wait loads", 6: "peak + scale", 9: "split+write", 13: "wait wrap loads", 3: "wrap sums+next loads", 4: "signal", 14: "find next", 5: "loop top"}
+NAMES = {1: "wait staged", 2: "MFMA", 7: "signal+stores", 8: "next item", 11: "wait free", 12: "wait loads", 6: "peak + scale", 9: "split+write", 13: "wait wrap loads", 3: "round-1 write", 10: "round-1 loads", 4: "signal", 14: "find next", 5: "loop top"}
 rows = [list(map(int, l.split())) for l in open(sys.argv[1])]
 items = float(sys.argv[2]) if len(sys.argv) > 2 else 111.5
 a = np.array(rows, dtype=np.float64)
