@@ -763,7 +763,9 @@ def bench_c5(ctx: Ctx, args, steps: int, warmup: int):
                    "chunk_latency_us": lat, "algorithmic_GBps": round(alg * steps / dt / 1e9, 1),
                    "shard_planning_s": round(plan_s, 3), "host_enqueue_ms_per_step": round(host_dt / steps * 1e3, 4)},
         "roofline": {"bound": "hbm", "kernel": variant, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS * ctx.world,
-                     "unit": "GB/s", "frac": round(ach / (HBM_PEAK_GBS * ctx.world), 4), "traffic": None,
+                     "unit": "GB/s", "frac": round(ach / (HBM_PEAK_GBS * ctx.world), 4),
+                     "traffic": traffic_from_profiles("c5", variant) if frames == 57_600_000 and ctx.world == 1 else None,
+                     "kernel_variant": h.kernel_variant(),
                      "kernel_ms": round(k_ms, 4), "algorithmic_bytes": int(alg)},
     }
 

@@ -18,6 +18,9 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
 #include <vector>
 
 #include "common.h"
@@ -302,6 +305,82 @@ int plan_job(Job& j) {
     const int rc = plan_job_uncached(j, false);
     if (rc == RSMP_OK) plan_cache().insert(key, j.plan);
     return rc;
+}
+
+// Process-wide workers for planning batches of streams in distinct states (rsmp_fir_batch_resample_bulk_device): the
+// items of a run are claimed from an atomic counter by the pool's threads and by the caller; one run at a time.
+class PlanPool {
+public:
+    ~PlanPool() {
+        {
+            std::lock_guard<std::mutex> lock(mu_);
+            stop_ = true;
+        }
+        cv_work_.notify_all();
+        for (std::thread& t : threads_) t.join();
+    }
+    template <class F>
+    void run(size_t total, F&& fn) {
+        std::lock_guard<std::mutex> one_run(run_mu_);
+        ensure_threads(total);
+        std::function<void(size_t)> f = fn;
+        {
+            std::lock_guard<std::mutex> lock(mu_);
+            fn_ = &f;
+            total_ = total;
+            next_.store(0, std::memory_order_relaxed);
+            pending_ = total;
+            ++generation_;
+        }
+        cv_work_.notify_all();
+        drain();
+        std::unique_lock<std::mutex> lock(mu_);
+        cv_done_.wait(lock, [&] { return pending_ == 0 && active_ == 0; });
+        fn_ = nullptr;
+    }
+
+private:
+    void ensure_threads(size_t total) {
+        unsigned hw = std::thread::hardware_concurrency();
+        const size_t want = std::min<size_t>(total - 1, std::min<size_t>(hw > 1 ? hw - 1 : 0, 63));
+        while (threads_.size() < want) threads_.emplace_back([this] { loop(); });
+    }
+    void drain() {
+        for (;;) {
+            const size_t m = next_.fetch_add(1, std::memory_order_relaxed);
+            if (m >= total_) break;
+            (*fn_)(m);
+            std::lock_guard<std::mutex> lock(mu_);
+            if (--pending_ == 0) cv_done_.notify_all();
+        }
+    }
+    void loop() {
+        uint64_t seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lock(mu_);
+                cv_work_.wait(lock, [&] { return stop_ || generation_ != seen; });
+                if (stop_) return;
+                seen = generation_;
+                ++active_;
+            }
+            drain();
+            std::lock_guard<std::mutex> lock(mu_);
+            if (--active_ == 0 && pending_ == 0) cv_done_.notify_all();
+        }
+    }
+    std::mutex mu_, run_mu_;
+    std::condition_variable cv_work_, cv_done_;
+    std::vector<std::thread> threads_;
+    const std::function<void(size_t)>* fn_ = nullptr;
+    size_t total_ = 0, pending_ = 0, active_ = 0;
+    std::atomic<size_t> next_{0};
+    uint64_t generation_ = 0;
+    bool stop_ = false;
+};
+PlanPool& plan_pool() {
+    static PlanPool* pool = new PlanPool();   // (leaked on purpose: joining workers from a static destructor at exit races the runtime's teardown)
+    return *pool;
 }
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -877,28 +956,22 @@ extern "C" int rsmp_fir_batch_resample_bulk_device(rsmp_fir* const* rs, size_t n
         rep.push_back(m);
     }
     // Distinct keys are planned in parallel: replaying a long stream's control flow is ~0.5 ms of serial
-    // f64 arithmetic on one core, and a batch of streams in different states has one replay per stream.
+    // f64 arithmetic on one core, and a batch of streams in different states has one replay per stream.  The
+    // workers are a process-wide pool (creating a thread costs as much as a tenth of a replay).
     {
         const size_t todo = memo.size();
-        unsigned hw = std::thread::hardware_concurrency();
-        const size_t n_threads = std::min<size_t>(todo, std::min<size_t>(hw ? hw : 1, 32));
         std::vector<int> rcs(todo, RSMP_OK);
         std::vector<std::string> msgs(todo);
-        auto work = [&](size_t t) {
-            for (size_t m = t; m < todo; m += n_threads) {
-                Job& j = jobs[memo_job[m]];
-                rcs[m] = plan_job(j);
-                if (rcs[m] != RSMP_OK) msgs[m] = rsmp::last_error_slot();   // (the slot is thread local)
-                memo[m].second = j.plan;
-            }
+        auto work = [&](size_t m) {
+            Job& j = jobs[memo_job[m]];
+            rcs[m] = plan_job(j);
+            if (rcs[m] != RSMP_OK) msgs[m] = rsmp::last_error_slot();   // (the slot is thread local)
+            memo[m].second = j.plan;
         };
-        if (n_threads <= 1) {
-            work(0);
+        if (todo <= 1) {
+            if (todo == 1) work(0);
         } else {
-            std::vector<std::thread> pool;
-            for (size_t t = 1; t < n_threads; ++t) pool.emplace_back(work, t);
-            work(0);
-            for (std::thread& th : pool) th.join();
+            plan_pool().run(todo, work);
         }
         for (size_t m = 0; m < todo; ++m)
             if (rcs[m] != RSMP_OK) {

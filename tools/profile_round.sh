@@ -21,6 +21,8 @@ python3 "$R/bench.py" --steps 20 --warmup 3 > "$SUM/bench_n1.json" 2> "$OUT/benc
 python3 "$R/bench.py" --path fft --steps 20 --warmup 3 > "$SUM/bench_fft.json" 2> "$OUT/bench_fft.err"
 python3 "$R/bench.py" --config c4 --steps 256 --warmup 16 > "$SUM/bench_c4.json" 2> "$OUT/bench_c4.err"
 python3 "$R/bench.py" --config c5 --steps 10 --warmup 2 > "$SUM/bench_c5.json" 2> "$OUT/bench_c5.err"
+# the RCCL exchange on what hardware there is: a world of one rank sending to / receiving from itself
+timeout -k 5 300 python3 "$R/bench.py" --config c4 --feed rccl --gpus 1 --steps 256 --warmup 16 > "$SUM/bench_c4_rccl_world1.json" 2> "$OUT/bench_c4_rccl.err"
 python3 "$R/tools/configs_bench.py" > "$SUM/bench_c5_calls.json" 2> "$OUT/bench_c5_calls.err"
 python3 "$R/tools/channels_bench.py" > "$SUM/channels_bench.txt" 2> "$OUT/channels_bench.err"
 python3 "$R/tools/fft_channels_bench.py" > "$SUM/fft_channels_bench.txt" 2> "$OUT/fft_channels_bench.err"
@@ -28,6 +30,7 @@ python3 "$R/tools/fft_pairs_bench.py" --all > "$SUM/fft_pairs_bench.txt" 2> "$OU
 RSMP_LS_TRACE="$SUM/ls_trace_raw.txt" python3 "$R/tools/ls_trace.py" > "$SUM/ls_trace.txt" 2> "$OUT/ls_trace.err"; rm -f "$SUM/ls_trace_raw.txt"
 RSMP_FIR_WTRACE="$OUT/wtrace.txt" python3 "$R/bench.py" --no-cpu --no-secondary --steps 3 --warmup 1 --spinup-seconds 0 > /dev/null 2>&1
 python3 "$R/tools/wphase_report.py" "$OUT/wtrace.txt" 111.5 > "$SUM/wphase_split.txt" 2>/dev/null
+(cd "$R" && tools/c5_trace.sh > /dev/null 2>&1; cp gpurun_out/c5trace/wphase_*.txt "$SUM/" 2>/dev/null)
 
 declare -A CMD
 CMD[fir]="--steps 20 --warmup 3 --no-cpu --no-secondary"
@@ -35,7 +38,7 @@ CMD[fft]="--path fft --steps 20 --warmup 3 --no-cpu"
 CMD[c4]="--config c4 --steps 256 --warmup 16"
 CMD[c5]="--config c5 --steps 10 --warmup 2"
 for w in fir fft c4 c5; do
-    rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_$w" -- python3 "$R/bench.py" ${CMD[$w]} \
+    timeout -k 5 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_$w" -- python3 "$R/bench.py" ${CMD[$w]} \
         > "$SUM/bench_${w}_under_rocprofv3.json" 2> "$OUT/kt_$w.err"
     cp "$(find "$OUT/kt_$w" -name '*kernel_stats.csv' | head -1)" "$SUM/${w}_kernel_stats.csv" 2>/dev/null
 done
@@ -44,9 +47,10 @@ declare -A PCMD
 PCMD[fir]="--steps 3 --warmup 1 --no-cpu --no-secondary"
 PCMD[fft]="--path fft --steps 3 --warmup 1 --no-cpu"
 PCMD[c4]="--config c4 --steps 32 --warmup 4 --spinup-seconds 0"
-for w in fir fft c4; do
+PCMD[c5]="--config c5 --steps 2 --warmup 1 --spinup-seconds 0"
+for w in fir fft c4 c5; do
     for c in FETCH_SIZE WRITE_SIZE; do
-        rocprofv3 --pmc $c --output-format csv -d "$OUT/pmc_${w}_$c" -- python3 "$R/bench.py" ${PCMD[$w]} \
+        timeout -k 5 600 rocprofv3 --pmc $c --output-format csv -d "$OUT/pmc_${w}_$c" -- python3 "$R/bench.py" ${PCMD[$w]} \
             > /dev/null 2> "$OUT/pmc_${w}_$c.err"
     done
     for grp in "SQ_INSTS_VALU_MFMA_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES" \
@@ -56,7 +60,8 @@ for w in fir fft c4; do
                "SQ_INST_LEVEL_VMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU" \
                "GRBM_GUI_ACTIVE"; do
         n=$(echo $grp | tr ' ' '_' | cut -c1-40)
-        rocprofv3 --pmc $grp --output-format csv -d "$OUT/pmc_${w}_$n" -- python3 "$R/bench.py" ${PCMD[$w]} \
+        [ "$w" = c5 ] && continue   # (config 5: traffic counters only)
+        timeout -k 5 600 rocprofv3 --pmc $grp --output-format csv -d "$OUT/pmc_${w}_$n" -- python3 "$R/bench.py" ${PCMD[$w]} \
             > /dev/null 2> "$OUT/pmc_${w}_$n.err"
     done
 done

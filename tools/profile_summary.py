@@ -11,8 +11,8 @@ import os
 import sys
 
 raw, out = sys.argv[1], sys.argv[2]
-KERNELS = {"fir": ("fir_split", "fir_periodic"), "fft": ("fft_ola",), "c4": ("fir_lockstep",)}
-BENCH = {"fir": "bench_n1.json", "fft": "bench_fft.json", "c4": "bench_c4.json"}
+KERNELS = {"fir": ("fir_split", "fir_periodic"), "fft": ("fft_ola",), "c4": ("fir_lockstep",), "c5": ("fir_split", "fir_periodic")}
+BENCH = {"fir": "bench_n1.json", "fft": "bench_fft.json", "c4": "bench_c4.json", "c5": "bench_c5.json"}
 latest = {}
 for w, names in KERNELS.items():
     tot = collections.defaultdict(list)
