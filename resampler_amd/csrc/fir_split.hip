@@ -83,7 +83,8 @@ struct SplitArgs {
     uint32_t a, b, taps, n_tiles, rows, slots, lds_bytes, blocks_per_stream, total_items, debug;
     uint32_t n_streams, fuse_tail;   // fuse_tail: also copy every stream's still-buffered tail into hist_next
     uint32_t cstride, pairs;         // WIDE kernels: channels of a frame and channel pairs = cstride / 2 (an item = one pair of a block)
-    uint32_t groups, per_group;      // more than ten class tiles (b > 160): tile groups of ten; items per group (the launch's items = groups x that)
+    uint32_t groups, per_group;      // more than ten class tiles (b > 160): tile groups of ten; items per slice (the launch's items = groups x quads x that)
+    uint32_t quads, qpairs;          // channel counts of 8, 12, 16: the launch's items are quad-major (see Cursor); pairs per slice (2, or all)
     unsigned long long* wtrace;   // RSMP_FIR_WTRACE: kWtraceSlots timestamped events per wave
     NfArgs nf;                    // non-finite sums are marked here (fir_nonfinite.h)
 };
@@ -218,6 +219,10 @@ struct Item {
 // of the second half the same blocks with tiles 10 .. 19 at about the same time (workgroup w and w + grid / 2 share an
 // XCD under round-robin placement, so the second read of a block's frames is an L2 hit).  A consumer keeps its
 // coefficient tile in registers across the items of a group.
+// Frames of 8, 12 or 16 channels are cut the same way into QUADS (two channel pairs = the sixteen bytes a stager load
+// covers): a quad of a block is two consecutive items, the quads of a block belong to different slices of the launch --
+// different workgroups at about the same time -- instead of following each other on one workgroup a whole block of
+// staging apart, by when the lines they share have left the L2 (config 5: 2.7x the algorithmic HBM traffic).
 struct Cursor {
     uint32_t item, stream, block;   // the next item to look at
     uint32_t group, cur_group;      // its tile group; the group of the item `next` returned
@@ -231,14 +236,15 @@ struct Cursor {
     __device__ __forceinline__ void init(const SplitArgs& g, uint32_t first) {
         item = first;
         pair = cur_pair = 0;
-        group = cur_group = first / g.per_group;
+        group = first / g.per_group;   // slice: tile group x quad
+        cur_group = group / g.quads;
         const uint32_t in_group = first - group * g.per_group;
         if constexpr (WIDE) {
-            const uint32_t per_stream = g.blocks_per_stream * g.pairs;
+            const uint32_t per_stream = g.blocks_per_stream * g.qpairs;
             stream = in_group / per_stream;
             const uint32_t rem = in_group - stream * per_stream;
-            block = rem / g.pairs;
-            pair = rem - block * g.pairs;
+            block = rem / g.qpairs;
+            pair = (group % g.quads) * g.qpairs + (rem - block * g.qpairs);
         } else {
             stream = in_group / g.blocks_per_stream;
             block = in_group - stream * g.blocks_per_stream;
@@ -262,28 +268,30 @@ struct Cursor {
                 k_block0 = static_cast<int32_t>(static_cast<int64_t>(q0) - static_cast<int64_t>(c.wrap_k0));
                 f0 = static_cast<int64_t>(q0 * g.a) - static_cast<int64_t>(c.abs_consumed);
                 fresh = true;
-            } else if (!WIDE || pair == 0) {   // (WIDE: the first pair of the stream's next block)
+            } else if (!WIDE || pair == (group % g.quads) * g.qpairs) {   // (WIDE: the slice's first pair of the stream's next block)
                 q0 += 16;
                 n_block0 += static_cast<int32_t>(16u * g.b);
                 k_block0 += 16;
                 f0 += 16u * g.a;
             }
             found = item;
-            cur_group = group;
+            cur_group = group / g.quads;
             const bool valid = q0 < q_limit;
             ++item;
             bool block_done = true;
             if constexpr (WIDE) {
                 cur_pair = pair;
-                if (++pair == g.pairs) pair = 0;
+                const uint32_t pair_lo = (group % g.quads) * g.qpairs;
+                if (++pair == pair_lo + g.qpairs) pair = pair_lo;
                 else block_done = false;
             }
             if (block_done && ++block == g.blocks_per_stream) {
                 block = 0;
                 fresh = false;
-                if (++stream == g.n_streams) {   // the next tile group starts over
+                if (++stream == g.n_streams) {   // the next slice (tile group, quad) starts over
                     stream = 0;
                     ++group;
+                    if constexpr (WIDE) pair = (group % g.quads) * g.qpairs;
                 }
             }
             if (valid) return true;
@@ -1445,10 +1453,13 @@ hipError_t launch_fir_split(const FirStreamDesc* d_descs, uint32_t n_streams, co
     }();
     const uint32_t pairs = geo.lp;
     const bool wide = pairs > 1 || geo.cg == 1;
-    const uint32_t groups = geo.groups ? geo.groups : 1u, per_group = max_blocks * n_streams * pairs;
-    SplitArgs args{geo.a, geo.b, geo.taps, geo.n_tiles, geo.row_stride, geo.images, geo.lds_bytes, max_blocks, per_group * groups,
+    static const bool quad_major = [] { const char* e = getenv("RSMP_FIR_SPLIT_QUADS"); return !e || atoi(e) != 0; }();
+    const uint32_t quads = quad_major && geo.cg == 2 && pairs >= 4 && pairs % 2 == 0 ? pairs / 2 : 1u;   // 8, 12, 16 channels
+    const uint32_t qpairs = pairs / quads;
+    const uint32_t groups = geo.groups ? geo.groups : 1u, per_group = max_blocks * n_streams * qpairs;
+    SplitArgs args{geo.a, geo.b, geo.taps, geo.n_tiles, geo.row_stride, geo.images, geo.lds_bytes, max_blocks, per_group * groups * quads,
                    debug, n_streams, fuse_tail ? 1u : 0u, geo.cg == 1 ? 1u : (geo.cg == 3 ? 2 * pairs - 1 : 2 * pairs), pairs,
-                   groups, per_group, nullptr, nf};
+                   groups, per_group, quads, qpairs, nullptr, nf};
     static const char* wtrace_path = getenv("RSMP_FIR_WTRACE");
     const bool diag = debug != 0 || wtrace_path != nullptr;
 #define RSMP_SPLIT_FNS(P, D, W)                                                                              \
