@@ -85,6 +85,7 @@ struct LockstepArgs {
     // leaves the result in the stream's plan record; step k + 1 then starts from the record instead of
     // ~20 k cycles of serial f64 arithmetic.  A record is used only if its epoch, step and frame count
     // match; otherwise the step plans in line as before.
+    uint32_t* peaks;                      // [n_streams][4]: epoch, step it is a prediction for, bits of the stream's latest peak, -
     char* recs;                           // [2][n_streams] records of rec_stride bytes (parity = step & 1)
     uint32_t rec_stride, n_streams;
     uint32_t epoch, step;

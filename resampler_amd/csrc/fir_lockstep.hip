@@ -55,7 +55,7 @@ typedef const v4u __attribute__((address_space(1)))* gconst_u4_ptr;
 typedef const v2f __attribute__((address_space(1)))* gconst_f2_ptr;
 typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
 // samples: block floating point per column (`colpeak`), as fir_split.hip per item; taps: 2^13, in the table
-constexpr uint32_t kLsPeakExactMax = 134;                          // a column's scale is not taken from samples of 2^8 and above (they overflow: reference form)
+constexpr uint32_t kLsPeakMax = 138;                               // no scale is derived from a peak of 2^11 and above (samples of 2^13 and above overflow: reference form)
 constexpr uint32_t kLsPlanner = kLsWaves - 1;                      // the wave that plans the next step
 constexpr uint32_t kLsStagers = kLsWaves - 2;                      // waves 1 .. kLsStagers stage the frames
 constexpr uint32_t kLsSyncBytes = 32;                              // n_cols, unit counter, image counter, early flag, ready counter
@@ -250,9 +250,8 @@ __device__ __forceinline__ void unit_mfma_split(const v4f (&a_reg)[kLsMaxBlk], u
 }
 // the scale of a column whose largest sample has biased exponent e (clamped: see colpeak): 2^(141 - e) puts that
 // sample into [2^14, 2^15), inside fp16; and the factor that takes the column's sums back (2^13: the taps)
-__device__ __forceinline__ uint32_t ls_peak_clamp(uint32_t e) { return e < 31u ? 31u : (e > kLsPeakExactMax ? kLsPeakExactMax : e); }
-__device__ __forceinline__ float ls_col_scale(uint32_t e) { return __uint_as_float((268u - ls_peak_clamp(e)) << 23); }
-__device__ __forceinline__ float ls_col_unscale(uint32_t e) { return __uint_as_float((ls_peak_clamp(e) - 27u) << 23); }
+__device__ __forceinline__ uint32_t ls_peak_clamp(uint32_t e) { return e < 31u ? 31u : (e > kLsPeakMax ? kLsPeakMax : e); }
+__device__ __forceinline__ float ls_col_unscale(uint32_t e) { return __uint_as_float((e - 27u) << 23); }   // (e: clamped)
 
 // Frame f (relative to the first buffered frame) of a stream's [buffered | new] frames, channel c: from the
 // LDS span (zeroed guards around it), or -- split variant, which keeps no f32 copy in LDS -- from HBM.
@@ -317,15 +316,32 @@ __global__ __launch_bounds__(kLsWaves * 64, kLsWaves / 2) void fir_lockstep_kern
     // src: lane c < 16 holds column c's ColSrc (8 words).
     const uint32_t image_off = lay.spans;
     const bool aligned8 = args.in_aligned8 != 0;
-    // Block floating point per stream: before they cut frames into planes the staging waves scan every stream's
-    // [buffered | new] span once (coalesced 8-byte loads, the image's loads then hit L2), agree on its largest magnitude
-    // (an atomic max per column in LDS and a count the six of them wait for) and scale the stream's columns by the power
-    // of two that puts that peak just below the top of the fp16 range -- a quiet stream next to a loud one, or one far
-    // outside [-1, 1], keeps 22 significant bits per sample.
-    uint32_t* colpeak = reinterpret_cast<uint32_t*>(lds + kLsPeakOff);   // [16]: bits of the largest |sample| of the column's stream; [16]: the count
-    auto write_image = [&](const uint32_t (&src)[8]) {
+    // Block floating point per stream: a stream's columns are cut into planes scaled by a power of two that puts the
+    // stream's level near the top of the fp16 range -- a quiet stream next to a loud one, or one far outside [-1, 1], keeps
+    // 22 significant bits per sample.  The level is the largest magnitude in the stream's [buffered | new] span, which the
+    // staging waves find with one scan (coalesced 8-byte loads, an atomic max per column in LDS):
+    //   * normally the scale is PREDICTED from the peak the previous step's scan left in `peaks` (2^4 of headroom) and the
+    //     image is written at once; the scan follows (its loads hit L2 then) and leaves this step's peak for the next
+    //     step.  A stream that got louder than the headroom overflows a plane (non-finite sums), one that fell more than
+    //     2^-6 below the prediction is seen by the units (peak against scale): both are redone in the reference's f32 form
+    //     inside this launch (kFlagNonFinite), as inf / NaN samples are;
+    //   * a step without a prediction for every stream of the workgroup (the first step) scans first: the staging waves
+    //     meet at a count and take the exact peaks.
+    uint32_t* colpeak = reinterpret_cast<uint32_t*>(lds + kLsPeakOff);   // [16]: bits of the largest |sample| of the column's stream; [16]: a count; [17..20]: the exponents the columns were scaled for
+    uint8_t* colscale = reinterpret_cast<uint8_t*>(colpeak + 17);
+    auto write_image = [&](uint32_t (&src)[8]) {
         const uint32_t t0 = threadIdx.x - 64;
-        {
+        // the previous step's peak of column c's stream (lane c < 16; src[7] = stream index + 1, 0 = no stream)
+        uint32_t pred_e = 0;
+        bool pred_ok = true;
+        if (lane < 16 && src[7] != 0) {
+            const uint32_t* rec = args.peaks + 4 * static_cast<size_t>(src[7] - 1);
+            pred_ok = rec[0] == args.epoch && rec[1] == args.step;
+            pred_e = rec[2] >> 23;
+        }
+        const bool predicted = __builtin_amdgcn_readfirstlane(__all(pred_ok) ? 1 : 0) != 0;
+        // one scan per stream (the columns of a stream are neighbours); this wave's share of every column's peak by one atomic each
+        auto scan = [&]() {
             uint32_t colpk = 0;   // lane c < 16: this wave's share of column c's stream's peak
             uint32_t prev_lo = 0, prev_hi = 0, pv = 0;
 #pragma unroll 1
@@ -333,7 +349,7 @@ __global__ __launch_bounds__(kLsWaves * 64, kLsWaves / 2) void fir_lockstep_kern
                 auto word = [&](int k) -> uint32_t { return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(src[k]), static_cast<int>(c))); };
                 const uint32_t h_lo = word(0), h_hi = word(1);
                 const uint32_t span_fr = word(6);
-                if (c == 0 || h_lo != prev_lo || h_hi != prev_hi) {   // (the columns of a stream are neighbours: one scan per stream)
+                if (c == 0 || h_lo != prev_lo || h_hi != prev_hi) {
                     prev_lo = h_lo;
                     prev_hi = h_hi;
                     gconst_f32_ptr hist = (gconst_f32_ptr) reinterpret_cast<const float*>((static_cast<uint64_t>(h_hi) << 32) | h_lo);
@@ -367,12 +383,34 @@ __global__ __launch_bounds__(kLsWaves * 64, kLsWaves / 2) void fir_lockstep_kern
             }
             if (lane < 16 && colpk != 0)
                 (void)__hip_atomic_fetch_max(colpeak + lane, colpk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        };
+        // this step's peaks to the next step's predictions: by the staging wave that counts in last (every share is in then)
+        auto count_in_and_publish = [&]() -> bool {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            uint32_t old = 0;
+            if (lane == 0) old = __hip_atomic_fetch_add(colpeak + 16, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const bool last = __builtin_amdgcn_readfirstlane(old) == kLsStagers - 1;
+            if (last && lane < 16 && src[7] != 0) {
+                uint32_t* rec = args.peaks + 4 * static_cast<size_t>(src[7] - 1);
+                const uint32_t bits = __hip_atomic_load(colpeak + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                rec[0] = args.epoch;
+                rec[1] = args.step + 1u;
+                rec[2] = bits;
+            }
+            return last;
+        };
+        uint32_t e_used;   // lane c < 16: the exponent column c is scaled for
+        if (predicted) {
+            e_used = pred_e == 0 ? 127u : pred_e + 4u;   // (a silent stream: as full-scale audio; a first sample overflows, is redone)
+        } else {
+            scan();
+            (void)count_in_and_publish();
+            while (__hip_atomic_load(colpeak + 16, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < kLsStagers) __builtin_amdgcn_s_sleep(1);
+            e_used = __hip_atomic_load(colpeak + (lane & 15u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> 23;
         }
-        // the six staging waves meet: every share of every stream's peak is in
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if (lane == 0) (void)__hip_atomic_fetch_add(colpeak + 16, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        while (__hip_atomic_load(colpeak + 16, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < kLsStagers) __builtin_amdgcn_s_sleep(1);
-        uint32_t xsv = __float_as_uint(ls_col_scale(__hip_atomic_load(colpeak + (lane & 15u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> 23));
+        e_used = ls_peak_clamp(e_used);
+        if (wave == 1 && lane < 16) colscale[lane] = static_cast<uint8_t>(e_used);
+        uint32_t xsv = (268u - e_used) << 23;
         asm volatile("" : "+v"(xsv));   // lane c < 16: column c's scale (defined under the full EXEC mask: read by lane index below)
         for (uint32_t r = t0; r < g.rows; r += kLsStagers * 64) {
             // every column's frame of this row is requested before the first is converted: one memory
@@ -423,6 +461,10 @@ __global__ __launch_bounds__(kLsWaves * 64, kLsWaves / 2) void fir_lockstep_kern
                 *reinterpret_cast<uint16_t*>(e + 96) = static_cast<uint16_t>(lo >> 16);  // channel 1, low plane
             }
         }
+        if (predicted) {   // the step's own peaks: for the units' check and the next step's predictions
+            scan();
+            (void)count_in_and_publish();
+        }
     };
 
     // ---- A: plan (wave 0) | stage (waves 1..) ---------------------------------------------------
@@ -431,7 +473,7 @@ __global__ __launch_bounds__(kLsWaves * 64, kLsWaves / 2) void fir_lockstep_kern
     // The sync words start at zero (unit counter, image counter, early flag, ready counter): the only
     // workgroup barrier before the final one -- every wave is here at once.
     if (threadIdx.x < kLsSyncBytes / 4) n_cols_p[threadIdx.x] = 0;
-    if (threadIdx.x >= 64 && threadIdx.x < 64 + 17) reinterpret_cast<uint32_t*>(lds + kLsPeakOff)[threadIdx.x - 64] = 0;   // column peaks, their count
+    if (threadIdx.x >= 64 && threadIdx.x < 64 + 21) reinterpret_cast<uint32_t*>(lds + kLsPeakOff)[threadIdx.x - 64] = 0;   // column peaks, their count, the scales
     __syncthreads();
 
     // The NEXT step's plan (the reference's control flow for step k + 1, ~20 k cycles of serial f64 arithmetic
@@ -525,6 +567,7 @@ __global__ __launch_bounds__(kLsWaves * 64, kLsWaves / 2) void fir_lockstep_kern
                     src[0] = w0; src[1] = w1; src[2] = w2; src[3] = w3;
                     src[4] = w4 + (lane - acc) * g.a;
                     src[5] = w5; src[6] = w6;
+                    src[7] = g.first + s + 1u;   // the column's stream (+ 1: 0 = a column without one)
                 }
                 acc += take;
             }
@@ -640,7 +683,7 @@ __global__ __launch_bounds__(kLsWaves * 64, kLsWaves / 2) void fir_lockstep_kern
                 cols[before + i] = cl;
                 if (split)
                     colsrc[before + i] = ColSrc{ptrs[lane].hist, ptrs[lane].in, cl.frame0, pl.hist_frames,
-                                                pl.hist_frames + pl.accepted, 0u};
+                                                pl.hist_frames + pl.accepted, g.first + lane + 1u};   // (pad: the stream's index + 1)
             }
         }
         if (lane == 0) {
@@ -802,7 +845,7 @@ __global__ __launch_bounds__(kLsWaves * 64, kLsWaves / 2) void fir_lockstep_kern
                 v4f acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
                 if (split) {
                     unit_mfma_split(a_reg, g.row_len / 32, g.row_bytes, lds, image_off, tile_base, lane,
-                                    ls_col_unscale(colpeak[lane & 15u] >> 23), acc0, acc1);
+                                    ls_col_unscale(colscale[lane & 15u]), acc0, acc1);
                 } else if (two && pair_ok) {
                     unit_mfma<2>(a_reg, nblk, xb + c0, C, acc0, acc1);
                 } else {
@@ -816,7 +859,14 @@ __global__ __launch_bounds__(kLsWaves * 64, kLsWaves / 2) void fir_lockstep_kern
                 }
                 // a non-finite sum anywhere in the tile: the stream's step is redone in reference form
                 const float chk = (acc0.x + acc0.y) + (acc0.z + acc0.w) + (acc1.x + acc1.y) + (acc1.z + acc1.w);
-                if (on && !(fabsf(chk) <= FLT_MAX))
+                // ... and so is one whose level fell more than 2^-10 below what its planes were scaled for (2^-6 below the
+                // prediction): the planes no longer hold its samples to 22 bits
+                bool redo = !(fabsf(chk) <= FLT_MAX);
+                if (split) {
+                    const uint32_t e_act = colpeak[lane & 15u] >> 23, e_sc = colscale[lane & 15u];
+                    redo = redo || (e_act != 0 && e_act + 10u < e_sc);
+                }
+                if (on && redo)
                     (void)__hip_atomic_fetch_or(&plan[cl.slot].flags, kFlagNonFinite, __ATOMIC_RELAXED,
                                                 __HIP_MEMORY_SCOPE_WORKGROUP);
                 const float v0[4] = {acc0.x, acc0.y, acc0.z, acc0.w};

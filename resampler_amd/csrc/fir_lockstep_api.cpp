@@ -32,7 +32,7 @@ struct rsmp_fir_lockstep {
     std::vector<LockstepStream> streams;   // internal order
     std::vector<uint32_t> channels;        // internal order
     bool in_aligned8 = false;
-    DeviceBuffer d_groups, d_streams, d_states, d_cursor, d_counts, d_status, d_order, d_recs;
+    DeviceBuffer d_groups, d_streams, d_states, d_cursor, d_counts, d_status, d_order, d_recs, d_peaks;
     uint32_t rec_stride = 0, epoch = 1, step = 0;   // plan-ahead records (fir_lockstep.h)
     uint32_t max_lds = 0;
     bool bound = false;
@@ -181,6 +181,7 @@ extern "C" rsmp_fir_lockstep* rsmp_fir_lockstep_new(rsmp_fir* const* rs, size_t 
         ls->d_status.reserve(n * sizeof(uint32_t)) != hipSuccess ||
         ls->d_order.reserve(n * sizeof(uint32_t)) != hipSuccess ||
         ls->d_recs.reserve(2 * n * static_cast<size_t>(ls->rec_stride)) != hipSuccess ||
+        ls->d_peaks.reserve(n * 16) != hipSuccess ||
         hipStreamCreateWithFlags(&ls->own_stream, hipStreamNonBlocking) != hipSuccess) {
         rsmp::fail(RSMP_ERR_HIP, "lock-step batch: cannot allocate device state");
         return nullptr;
@@ -194,6 +195,7 @@ extern "C" rsmp_fir_lockstep* rsmp_fir_lockstep_new(rsmp_fir* const* rs, size_t 
                   hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(ls->d_order.get(), ls->order.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemset(ls->d_recs.get(), 0, 2 * n * static_cast<size_t>(ls->rec_stride)) != hipSuccess ||
+        hipMemset(ls->d_peaks.get(), 0, n * 16) != hipSuccess ||
         hipMemset(ls->d_cursor.get(), 0, n * sizeof(uint64_t)) != hipSuccess ||
         hipMemset(ls->d_counts.get(), 0, 2 * n * sizeof(uint64_t)) != hipSuccess ||
         hipMemset(ls->d_status.get(), 0, n * sizeof(uint32_t)) != hipSuccess ||
@@ -290,6 +292,7 @@ extern "C" int rsmp_fir_lockstep_step(rsmp_fir_lockstep* ls, size_t in_frames, s
     a.in_aligned8 = ls->in_aligned8 ? 1u : 0u;
     a.trace = nullptr;
     a.recs = ls->d_recs.as<char>();
+    a.peaks = ls->d_peaks.as<uint32_t>();
     a.rec_stride = ls->rec_stride;
     a.n_streams = static_cast<uint32_t>(ls->rs.size());
     a.epoch = ls->epoch;
