@@ -85,6 +85,8 @@ struct SplitArgs {
     uint32_t cstride, pairs;         // WIDE kernels: channels of a frame and channel pairs = cstride / 2 (an item = one pair of a block)
     uint32_t groups, per_group;      // more than ten class tiles (b > 160): tile groups of ten; items per slice (the launch's items = groups x quads x that)
     uint32_t quads, qpairs;          // channel counts of 8, 12, 16: the launch's items are quad-major (see Cursor); pairs per slice (2, or all)
+    uint32_t wide;                   // frames of other than two channels (the WIDE instantiations)
+    const uint32_t* items;           // the launch's item table (split_items_kernel): kItemWords words per item
     unsigned long long* wtrace;   // RSMP_FIR_WTRACE: kWtraceSlots timestamped events per wave
     NfArgs nf;                    // non-finite sums are marked here (fir_nonfinite.h)
 };
@@ -223,82 +225,93 @@ struct Item {
 // covers): a quad of a block is two consecutive items, the quads of a block belong to different slices of the launch --
 // different workgroups at about the same time -- instead of following each other on one workgroup a whole block of
 // staging apart, by when the lines they share have left the L2 (config 5: 2.7x the algorithmic HBM traffic).
+// The items of a launch are tabulated once, by a small launch in front of the kernel (split_items_kernel: one thread per
+// item): every one of a workgroup's sixteen waves walks the same items, and deriving an item from its index -- stream,
+// block, pair, tile group, period, output and frame offsets, whether its frames lie inside the input -- was several
+// hundred cycles of scalar 64-bit arithmetic per wave and item (round 2's phase clocks: "find next" / "next item").
+constexpr uint32_t kItemWords = 8;   // stream | flags << 24, pair | group << 8, n_block0, k_block0, f0 (2), off0, -
+constexpr uint32_t kItemValid = 1, kItemInterior = 2;
 struct Cursor {
-    uint32_t item, stream, block;   // the next item to look at
-    uint32_t group, cur_group;      // its tile group; the group of the item `next` returned
-    uint32_t pair, cur_pair;        // WIDE: its channel pair; the pair of the item `next` returned
-    bool fresh;                     // `c` and the values below belong to (stream, block)
+    uint32_t item;                  // the next item to look at
+    uint32_t cur_pair, cur_group;   // channel pair and tile group of the item `next` returned
+    uint32_t cur_stream;            // the stream `c` describes (0xFFFFFFFF: none yet)
     StreamCtx c;
-    uint64_t q0, q_limit;           // valid iff q0 < q_limit
-    int32_t n_block0, k_block0;
-    int64_t f0;                     // frame index of (period q0, row 0) in [hist|in]
+    int32_t n_block0, k_block0;     // launch-relative output index / wrap-bitmap index of (first period, class 0)
+    int64_t f0;                     // frame index of (first period, row 0) in [hist|in]
+    uint32_t off0;                  // interior items: f0 - hist_frames
+    bool interior;                  // the image and its wrap windows lie inside `in` (32-bit byte offsets)
     template <bool WIDE>
-    __device__ __forceinline__ void init(const SplitArgs& g, uint32_t first) {
+    __device__ __forceinline__ void init(const SplitArgs&, uint32_t first) {
         item = first;
-        pair = cur_pair = 0;
-        group = first / g.per_group;   // slice: tile group x quad
-        cur_group = group / g.quads;
-        const uint32_t in_group = first - group * g.per_group;
-        if constexpr (WIDE) {
-            const uint32_t per_stream = g.blocks_per_stream * g.qpairs;
-            stream = in_group / per_stream;
-            const uint32_t rem = in_group - stream * per_stream;
-            block = rem / g.qpairs;
-            pair = (group % g.quads) * g.qpairs + (rem - block * g.qpairs);
-        } else {
-            stream = in_group / g.blocks_per_stream;
-            block = in_group - stream * g.blocks_per_stream;
-        }
-        fresh = false;
+        cur_pair = cur_group = 0;
+        cur_stream = 0xFFFFFFFFu;
         c = StreamCtx{};
-        q0 = q_limit = 0;
         n_block0 = k_block0 = 0;
         f0 = 0;
+        off0 = 0;
+        interior = false;
     }
-    // Finds the next valid item before `end`; returns false when there is none.  On success the values
-    // (c, q0, n_block0, k_block0, f0) describe it and `found` is its index.
+    // Finds the next valid item before `end`; returns false when there is none.  On success the fields describe it and
+    // `found` is its index.
     template <bool WIDE>
     __device__ __forceinline__ bool next(const SplitArgs& g, const FirStreamDesc* descs, uint32_t end, uint32_t& found) {
+        typedef const uint32_t __attribute__((address_space(4)))* const_u32_ptr;
         while (item < end) {
-            if (!fresh) {
-                c = load_stream(descs, stream, g.b);
-                q0 = c.q_first + static_cast<uint64_t>(block) * 16u;
-                q_limit = c.n_out != 0 ? (c.abs_out + c.n_out + g.b - 1) / g.b : 0;
-                n_block0 = static_cast<int32_t>(static_cast<int64_t>(q0 * g.b) - static_cast<int64_t>(c.abs_out));
-                k_block0 = static_cast<int32_t>(static_cast<int64_t>(q0) - static_cast<int64_t>(c.wrap_k0));
-                f0 = static_cast<int64_t>(q0 * g.a) - static_cast<int64_t>(c.abs_consumed);
-                fresh = true;
-            } else if (!WIDE || pair == (group % g.quads) * g.qpairs) {   // (WIDE: the slice's first pair of the stream's next block)
-                q0 += 16;
-                n_block0 += static_cast<int32_t>(16u * g.b);
-                k_block0 += 16;
-                f0 += 16u * g.a;
-            }
+            const_u32_ptr rec = (const_u32_ptr)(g.items + static_cast<size_t>(item) * kItemWords);
+            uint32_t w[kItemWords];
+#pragma unroll
+            for (uint32_t k = 0; k < kItemWords; ++k) w[k] = rec[k];
             found = item;
-            cur_group = group / g.quads;
-            const bool valid = q0 < q_limit;
             ++item;
-            bool block_done = true;
-            if constexpr (WIDE) {
-                cur_pair = pair;
-                const uint32_t pair_lo = (group % g.quads) * g.qpairs;
-                if (++pair == pair_lo + g.qpairs) pair = pair_lo;
-                else block_done = false;
+            if (!((w[0] >> 24) & kItemValid)) continue;
+            const uint32_t stream = w[0] & 0xFFFFFFu;
+            if (stream != cur_stream) {
+                c = load_stream(descs, stream, g.b);
+                cur_stream = stream;
             }
-            if (block_done && ++block == g.blocks_per_stream) {
-                block = 0;
-                fresh = false;
-                if (++stream == g.n_streams) {   // the next slice (tile group, quad) starts over
-                    stream = 0;
-                    ++group;
-                    if constexpr (WIDE) pair = (group % g.quads) * g.qpairs;
-                }
-            }
-            if (valid) return true;
+            interior = ((w[0] >> 24) & kItemInterior) != 0;
+            cur_pair = w[1] & 255u;
+            cur_group = w[1] >> 8;
+            n_block0 = static_cast<int32_t>(w[2]);
+            k_block0 = static_cast<int32_t>(w[3]);
+            f0 = static_cast<int64_t>((static_cast<uint64_t>(w[5]) << 32) | w[4]);
+            off0 = w[6];
+            return true;
         }
         return false;
     }
 };
+
+// One thread per item of the launch: the item's record (kItemWords words, see Cursor).  Item order: slices (tile group x
+// quad), inside a slice streams, blocks of 16 periods, the slice's channel pairs.
+__global__ __launch_bounds__(256) void split_items_kernel(const FirStreamDesc* __restrict__ descs, const SplitArgs g,
+                                                          uint32_t* __restrict__ items) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= g.total_items) return;
+    const uint32_t slice = i / g.per_group, in_slice = i - slice * g.per_group;
+    const uint32_t group = slice / g.quads, quad = slice - group * g.quads;
+    const uint32_t per_stream = g.blocks_per_stream * g.qpairs;
+    const uint32_t stream = in_slice / per_stream, rem = in_slice - stream * per_stream;
+    const uint32_t block = rem / g.qpairs, pair = quad * g.qpairs + (rem - block * g.qpairs);
+    const FirStreamDesc& d = descs[stream];
+    const uint64_t q0 = d.abs_out / g.b + static_cast<uint64_t>(block) * 16u;
+    const uint64_t q_limit = d.n_out != 0 ? (d.abs_out + d.n_out + g.b - 1) / g.b : 0;
+    const bool valid = q0 < q_limit;
+    const int64_t f0 = static_cast<int64_t>(q0 * g.a) - static_cast<int64_t>(d.abs_consumed);
+    const int64_t hf = d.hist_frames;
+    const uint32_t fsb = g.cstride * 4u;
+    const bool interior = f0 > hf && f0 + static_cast<int64_t>(17u * g.a + (g.wide ? 6u : 2u)) <= hf + static_cast<int64_t>(d.in_frames) &&
+                          (g.wide ? static_cast<uint64_t>(d.in_frames) * fsb < (1ull << 32) - 65536u : d.in_frames < (1u << 27));   // (32-bit byte offsets)
+    uint32_t* w = items + static_cast<size_t>(i) * kItemWords;
+    w[0] = stream | ((valid ? kItemValid : 0u) | (interior ? kItemInterior : 0u)) << 24;
+    w[1] = pair | group << 8;
+    w[2] = static_cast<uint32_t>(static_cast<int32_t>(static_cast<int64_t>(q0 * g.b) - static_cast<int64_t>(d.abs_out)));
+    w[3] = static_cast<uint32_t>(static_cast<int32_t>(static_cast<int64_t>(q0) - static_cast<int64_t>(d.wrap_k0)));
+    w[4] = static_cast<uint32_t>(static_cast<uint64_t>(f0));
+    w[5] = static_cast<uint32_t>(static_cast<uint64_t>(f0) >> 32);
+    w[6] = static_cast<uint32_t>(f0 - hf);
+    w[7] = 0;
+}
 
 // f32 -> three bf16 planes by truncation: x == p1 + p2 + p3 exactly (24 significant bits = 8 + 8 + 8;
 // both subtractions are exact).  Returned as f32 bit patterns whose low halves are don't-care.
@@ -495,15 +508,13 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
             if (cu.template next<(WIDE != 0)>(g, descs, item_end, found)) {
                 r.item = found;
                 r.pair = cu.cur_pair;
-                r.it.q0 = cu.q0;
+                r.it.q0 = 0;
                 r.it.n_block0 = cu.n_block0;
                 r.it.k_block0 = cu.k_block0;
                 r.it.valid = true;
                 r.f0 = cu.f0;
-                const int64_t hf = cu.c.hist_frames;
-                r.interior = r.f0 > hf && r.f0 + static_cast<int64_t>(17u * g.a + (WIDE ? 6u : 2u)) <= hf + static_cast<int64_t>(cu.c.in_frames) &&
-                             (WIDE ? static_cast<uint64_t>(cu.c.in_frames) * fsb < (1ull << 32) - 65536u : cu.c.in_frames < (1u << 27));   // (32-bit byte offsets)
-                r.off0 = static_cast<uint32_t>(r.f0 - hf);
+                r.interior = cu.interior;   // (the image and its wrap windows lie inside `in`: split_items_kernel)
+                r.off0 = cu.off0;
             }
             return r;
         };
@@ -1125,7 +1136,7 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
     while (cu.template next<(WIDE != 0)>(g, descs, item_end, item)) {
         const StreamCtx& d = cu.c;
         Item it;
-        it.q0 = cu.q0;
+        it.q0 = 0;
         it.n_block0 = cu.n_block0;
         it.k_block0 = cu.k_block0;
         it.valid = true;
@@ -1459,7 +1470,7 @@ hipError_t launch_fir_split(const FirStreamDesc* d_descs, uint32_t n_streams, co
     const uint32_t groups = geo.groups ? geo.groups : 1u, per_group = max_blocks * n_streams * qpairs;
     SplitArgs args{geo.a, geo.b, geo.taps, geo.n_tiles, geo.row_stride, geo.images, geo.lds_bytes, max_blocks, per_group * groups * quads,
                    debug, n_streams, fuse_tail ? 1u : 0u, geo.cg == 1 ? 1u : (geo.cg == 3 ? 2 * pairs - 1 : 2 * pairs), pairs,
-                   groups, per_group, quads, qpairs, nullptr, nf};
+                   groups, per_group, quads, qpairs, wide ? 1u : 0u, nullptr, nullptr, nf};
     static const char* wtrace_path = getenv("RSMP_FIR_WTRACE");
     const bool diag = debug != 0 || wtrace_path != nullptr;
 #define RSMP_SPLIT_FNS(P, D, W)                                                                              \
@@ -1521,6 +1532,32 @@ hipError_t launch_fir_split(const FirStreamDesc* d_descs, uint32_t n_streams, co
         if (hipMalloc(&d_wtrace, wtrace_words * 8) != hipSuccess) return hipErrorOutOfMemory;
         (void)hipMemsetAsync(d_wtrace, 0, wtrace_words * 8, stream);
         args.wtrace = d_wtrace;
+    }
+    // the item table: a launch of its own in front (one thread per item), in a workspace kept per stream
+    {
+        static std::mutex ws_mu;
+        static std::map<std::pair<int, hipStream_t>, std::pair<uint32_t*, size_t>> ws;
+        const size_t need = static_cast<size_t>(args.total_items) * kItemWords * sizeof(uint32_t);
+        uint32_t* d_items = nullptr;
+        {
+            std::lock_guard<std::mutex> lock(ws_mu);
+            auto& slot = ws[{device, stream}];
+            if (slot.second < need) {
+                if (slot.first) {   // (a launch on this stream may still read the old table)
+                    if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
+                    (void)hipFree(slot.first);
+                    slot.first = nullptr;
+                    slot.second = 0;
+                }
+                const size_t cap = need + need / 2 + 4096;
+                if ((e = hipMalloc(&slot.first, cap)) != hipSuccess) return e;
+                slot.second = cap;
+            }
+            d_items = slot.first;
+        }
+        args.items = d_items;
+        split_items_kernel<<<dim3((args.total_items + 255) / 256), dim3(256), 0, stream>>>(d_descs, args, d_items);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
     }
     void* kargs[2] = {&d_descs, &args};
     e = hipLaunchKernel(fns[nk - 1], grid, dim3(kWaves * 64), kargs,
