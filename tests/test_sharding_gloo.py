@@ -144,13 +144,16 @@ def _feed_worker(rank, world, port, steps, n_streams, frames, q):
     dist.destroy_process_group()
 
 
-def test_world2_gloo_scatter_compute_gather_moves_real_samples():
+@pytest.mark.parametrize("world,n_streams", [(2, 14), (4, 3)])   # (4 ranks, 3 streams: one rank owns nothing and takes part in no exchange)
+def test_world2_gloo_scatter_compute_gather_moves_real_samples(world, n_streams):
     import hashlib
 
     import torch.multiprocessing as mp
     from oracle import pyoracle as o
 
-    world, steps, n_streams, frames = 2, 4, 14, 256
+    steps, frames = 4, 256
+    parts = sharding.partition([s.work() for s in sharding.mixed_rate_batch(n_streams, 2, frames)], world)
+    assert (world, n_streams) != (4, 3) or any(a == b for a, b in parts)   # the empty shard this case is about
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
