@@ -572,9 +572,21 @@ __global__ __launch_bounds__((OCC == 1 && kOneWavePerSimd<FWD, INV> ? 256 : wave
         copy(tab + kTabRcI, reinterpret_cast<const cf*>(plan.rc_i), INV::kRc);
         copy(tab + kTabFilter, reinterpret_cast<const cf*>(plan.filter), kFilterLen);
     }
+    // Two-channel streams: the two waves of a stream's channels (neighbours, wave ^ 1) exchange half of their final
+    // values through LDS so that each stores whole 16-byte pieces of the interleaved output -- frames 2c, 2c + 1 of BOTH
+    // channels -- instead of two 4-byte stores per value at a stride of 16 bytes that only sometimes merged with the
+    // other wave's in L2 (HBM writes 1.2x the output).  Per wave two words: blocks whose outgoing values are in its
+    // buffer (`ready`), blocks whose outgoing values the neighbour has taken (`taken`).  (The long plans have no
+    // registers to spare for the values in flight and keep the 4-byte stores.)
+    constexpr bool kXch = C2 && !kOddLast && HL % 2 == 0 && FI <= 2048 && FO <= 2048;
+    uint32_t* xflags = reinterpret_cast<uint32_t*>(lds2 + kTabEnd + kWavesPerGroup * LDSC);
+    if (kXch && threadIdx.x < 2u * kWavesPerGroup) xflags[threadIdx.x] = 0;
     __syncthreads();
     if (gw >= total_waves) return;
+    const bool xch = kXch && kWavesPerGroup % 2 == 0;   // (an odd number of waves per workgroup would part a pair)
+    uint32_t xseq = 0;                                   // blocks exchanged so far
     cf* buf = lds2 + kTabEnd + wave * LDSC;
+    cf* pbuf = lds2 + kTabEnd + (wave ^ 1u) * LDSC;      // the neighbour's buffer
     const cf* tw_f = tab + kTabF;
     const cf* tw_i = tab + kTabI;
     const cf* rc_f = tab + kTabRcF;
@@ -613,6 +625,10 @@ __global__ __launch_bounds__((OCC == 1 && kOneWavePerSimd<FWD, INV> ? 256 : wave
 
     for (int64_t b = b_begin; b < static_cast<int64_t>(last); ++b) {
         const bool emit = b >= static_cast<int64_t>(first);
+        if constexpr (kXch) {   // the neighbour must have taken the previous block's outgoing values out of this buffer
+            if (xch && xseq > 0)
+                while (__hip_atomic_load(xflags + 2 * wave + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < xseq) __builtin_amdgcn_s_sleep(1);
+        }
         // ---- forward transform: the first pass takes its inputs straight from HBM: complex j of the block's
         // channel = frames 2j, 2j + 1 (j < FI / 2), zero beyond (resampler_fft.rs:387-388)
         {
@@ -671,6 +687,9 @@ __global__ __launch_bounds__((OCC == 1 && kOneWavePerSimd<FWD, INV> ? 256 : wave
         // reads of butterfly it + 1 are issued before butterfly it runs (all of them at once do not fit the
         // 168 registers of three waves per SIMD next to the carry)
         cf tl[2][RL], rawl[2][kFetch<RL>];
+        cf vkeep[ITERL][HL / 2 > 0 ? HL / 2 : 1];   // kXch: the values this wave stores itself (q of its channel's parity)
+        // where a lane's outgoing value j of trip it goes: the slots its own inputs q = j of that trip came from
+        auto xaddr = [&](int i, int j) -> int { return i + (kLastIpp ? i / (kLastIpp ? kLastIpp : 1) : 0) + j * (ML + INV::in_pad(SI - 1)); };
         auto fetch = [&](int it) {
             const int i = lane + 64 * it;
             if ((it + 1) * 64 <= ML || i < ML) {
@@ -695,11 +714,49 @@ __global__ __launch_bounds__((OCC == 1 && kOneWavePerSimd<FWD, INV> ? 256 : wave
                     const int c = i + q * ML;
                     if (emit) {
                         const cf v = cf_conj_add_conj(o[q], carry[it][q]);
-                        xout[static_cast<size_t>(2 * c) * C + ch] = v.x;
-                        xout[static_cast<size_t>(2 * c + 1) * C + ch] = v.y;
+                        if (kXch && xch) {
+                            if (static_cast<uint32_t>(q & 1) == ch) vkeep[it][q >> 1] = v;
+                            else lds_st(buf + xaddr(i, q >> 1), v);
+                        } else {
+                            xout[static_cast<size_t>(2 * c) * C + ch] = v.x;
+                            xout[static_cast<size_t>(2 * c + 1) * C + ch] = v.y;
+                        }
                     }
                     carry[it][q] = o[q + HL];
                 }
+            }
+        }
+        if constexpr (kXch) {
+            if (xch && emit) {
+                lds_order();
+                if (lane == 0) __hip_atomic_store(xflags + 2 * wave, xseq + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // (a wave's LDS operations complete in order)
+                while (__hip_atomic_load(xflags + 2 * (wave ^ 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < xseq + 1) __builtin_amdgcn_s_sleep(1);
+                lds_order();
+                cf got[ITERL][HL / 2 > 0 ? HL / 2 : 1];
+#pragma unroll
+                for (int it = 0; it < ITERL; ++it) {
+                    const int i = lane + 64 * it;
+                    if ((it + 1) * 64 <= ML || i < ML) {
+#pragma unroll
+                        for (int j = 0; j < HL / 2; ++j) got[it][j] = lds_ld(pbuf + xaddr(i, j));
+                    }
+                }
+#pragma unroll
+                for (int it = 0; it < ITERL; ++it) {
+                    const int i = lane + 64 * it;
+                    if ((it + 1) * 64 <= ML || i < ML) {
+#pragma unroll
+                        for (int j = 0; j < HL / 2; ++j) {
+                            const int c = i + (2 * j + static_cast<int>(ch)) * ML;   // frames 2c, 2c + 1, both channels: 16 bytes
+                            const cf v0 = ch == 0 ? vkeep[it][j] : got[it][j], v1 = ch == 0 ? got[it][j] : vkeep[it][j];
+                            ((GFloat4*)xout)[c] = f4{v0.x, v1.x, v0.y, v1.y};
+                        }
+                    }
+                }
+                lds_order();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the neighbour's values are in registers
+                if (lane == 0) __hip_atomic_store(xflags + 2 * (wave ^ 1u) + 1, xseq + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                ++xseq;
             }
         }
         }
@@ -765,8 +822,9 @@ bool wave_choice(const FftPlanDev& plan, uint32_t channels, int occ_env, WaveCho
     constexpr size_t tables = static_cast<size_t>(FWD::kTw + INV::kTw + FWD::kRc + INV::kRc + (FWD::N < INV::N ? FWD::N + 1 : INV::N));   // (+ the filter bins in use)
     constexpr size_t buf = FWD::kBuf > INV::kBuf ? FWD::kBuf : INV::kBuf;
     constexpr size_t kCu = 160 * 1024 / sizeof(cf);
-    constexpr bool fit12 = tables + 12 * buf <= kCu, fit4 = 2 * (tables + 4 * buf) <= kCu;
-    constexpr uint32_t wide_fit = (kCu - tables) / buf < 8 ? static_cast<uint32_t>((kCu - tables) / buf) : 8u;
+    constexpr size_t kFlags = 16;   // cf-sized words of exchange flags behind the buffers (two 32-bit words per wave, up to 16 waves)
+    constexpr bool fit12 = tables + 12 * buf + kFlags <= kCu, fit4 = 2 * (tables + 4 * buf + kFlags) <= kCu;
+    constexpr uint32_t wide_fit = (kCu - tables - kFlags) / buf < 8 ? static_cast<uint32_t>((kCu - tables - kFlags) / buf) : 8u;
     constexpr uint32_t wide = kOneWavePerSimd<FWD, INV> && wide_fit > 4 ? 4u : wide_fit;
     // (fewer than two waves per CU -- the longest plans in the exact build, whose twiddle rows are whole -- belong to
     // the workgroup kernels)
@@ -790,7 +848,7 @@ bool wave_choice(const FftPlanDev& plan, uint32_t channels, int occ_env, WaveCho
     static const uint32_t wide_knob = [] { const char* e = getenv("RSMP_FFT_WAVE_WIDE"); return e ? static_cast<uint32_t>(atoi(e)) : 0u; }();
     out->waves = occ == 3 ? 12u : occ == 2 ? 4u : (wide_knob >= 1 && wide_knob <= wide ? wide_knob : wide);
     out->resident = occ == 2 ? 8u : out->waves;
-    out->lds = (tables + out->waves * buf) * sizeof(cf);
+    out->lds = (tables + out->waves * buf + kFlags) * sizeof(cf);
     return out->fn != nullptr;
     }
 }
