@@ -329,6 +329,24 @@ __device__ __forceinline__ uint32_t cvt_pk_f16(float a, float b) {
 }
 __device__ __forceinline__ float f16_lo(uint32_t w) { return static_cast<float>(__builtin_bit_cast(f16x2, w)[0]); }
 __device__ __forceinline__ float f16_hi(uint32_t w) { return static_cast<float>(__builtin_bit_cast(f16x2, w)[1]); }
+// s - (float)half of w in ONE instruction (v_fma_mix_f32: the fp16 operand is widened inside the FMA; the result is exact
+// either way).  The stagers are bound by what one wave can issue: the compiler's v_cvt_f32_f16 + v_sub_f32 per sample, and
+// its v_pk_mul_f32 / v_pk_add_f32 pairs with a v_mov per operand to line the registers up, were a quarter of the split.
+__device__ __forceinline__ float resid_lo(float s, uint32_t w) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(w), "v"(s));
+    return r;
+}
+__device__ __forceinline__ float resid_hi(float s, uint32_t w) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(w), "v"(s));
+    return r;
+}
+__device__ __forceinline__ float mul_plain(float a, float b) {   // (one v_mul_f32: not paired into v_pk_mul_f32)
+    float r;
+    asm("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 // (high half of hi) : (high half of lo)
 __device__ __forceinline__ uint32_t pack_hi16(uint32_t hi, uint32_t lo) {
     return __builtin_amdgcn_perm(hi, lo, 0x07060302u);
@@ -652,11 +670,11 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
                             // two fp16 planes: h1 = RN16(s), h2 = RN16(s - h1) with s = 2^12 x (s - h1 is exact)
                             float s[5];
 #pragma unroll
-                            for (int i = 0; i < 5; ++i) s[i] = at(i, fr, c) * xsc;
+                            for (int i = 0; i < 5; ++i) s[i] = mul_plain(at(i, fr, c), xsc);
                             const uint32_t a01 = cvt_pk_f16(s[0], s[1]), a23 = cvt_pk_f16(s[2], s[3]), a4 = cvt_pk_f16(s[4], s[4]);
-                            const uint32_t b01 = cvt_pk_f16(s[0] - f16_lo(a01), s[1] - f16_hi(a01));
-                            const uint32_t b23 = cvt_pk_f16(s[2] - f16_lo(a23), s[3] - f16_hi(a23));
-                            const uint32_t b4 = cvt_pk_f16(s[4] - f16_lo(a4), 0.f);
+                            const uint32_t b01 = cvt_pk_f16(resid_lo(s[0], a01), resid_hi(s[1], a01));
+                            const uint32_t b23 = cvt_pk_f16(resid_lo(s[2], a23), resid_hi(s[3], a23));
+                            const uint32_t b4 = cvt_pk_f16(resid_lo(s[4], a4), 0.f);
                             // periods (4Q, 4Q+1), (4Q+2, 4Q+3) to row k; (4Q+1, 4Q+2), (4Q+3, 4Q+4) to row k + a
                             *reinterpret_cast<u2*>(pr + (2 * c) * 32) = u2{a01, a23};
                             *reinterpret_cast<u2*>(pr + (2 * c + 1) * 32) = u2{b01, b23};
