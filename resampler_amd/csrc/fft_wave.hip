@@ -57,6 +57,8 @@ __device__ __forceinline__ void lds_order() { asm volatile("" ::: "memory"); }
 typedef __attribute__((address_space(1))) float GFloat;
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(1))) f4 GFloat4;
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(1))) f2 GFloat2;
 __device__ __forceinline__ const GFloat* as_global(const float* p) { return (const GFloat*)p; }
 __device__ __forceinline__ GFloat* as_global(float* p) { return (GFloat*)p; }
 
@@ -514,13 +516,16 @@ constexpr int wave_group_threads(int occ) { return occ == 3 ? 768 : occ == 2 ? 2
 // carry do not fit 256 registers -- these pairs run one wave per SIMD with the full register file instead of two
 // that spill (88.2 -> 96 kHz: 0.94 -> 0.76 ms).
 template <class FWD, class INV> constexpr bool kOneWavePerSimd = (FWD::N > 2048 && INV::N > 2048) || FWD::N > 2560 || INV::N > 2560;
-template <class FWD, class INV, bool C2, int OCC>
+// CHM: 0 = any number of channels (a wave per channel, 4-byte accesses at the frame's stride), 1 = two channels (16-byte
+// accesses), 2 = an even number of channels taken as channel pairs (8-byte accesses at the frame's stride)
+template <class FWD, class INV, int CHM, int OCC>
 __global__ __launch_bounds__((OCC == 1 && kOneWavePerSimd<FWD, INV> ? 256 : wave_group_threads(OCC)),
                              (OCC == 1 ? (kOneWavePerSimd<FWD, INV> ? 1 : 2) : OCC)) void fft_ola_wave_kernel(FftPlanDev plan,
                                                                               const FftStreamDesc* __restrict__ descs,
                                                                               uint32_t run, uint32_t runs_per_stream,
-                                                                              uint32_t total_waves) {
+                                                                              uint32_t total_waves, uint32_t pairs) {
     extern __shared__ __attribute__((aligned(16))) cf lds2[];
+    constexpr bool C2 = CHM != 0;
     const int kWavesPerGroup = OCC == 1 ? static_cast<int>(blockDim.x >> 6) : wave_group_threads(OCC) / 64;
     constexpr int FI = FWD::N, FO = INV::N;
     constexpr int kFilterLen = FI < FO ? FI + 1 : FO;   // bins the filter multiplies (new_length): the rest of its spectrum stays in HBM
@@ -593,13 +598,21 @@ __global__ __launch_bounds__((OCC == 1 && kOneWavePerSimd<FWD, INV> ? 256 : wave
     const cf* rc_i = tab + kTabRcI;
     const cf* filter = tab + kTabFilter;
 
-    // wave -> (stream, run of blocks, channel); the channels of a run are neighbouring waves
-    const uint32_t stream_idx = gw / (runs_per_stream * (C2 ? 2u : descs[0].channels));
+    // wave -> (stream, run of blocks, channel); the channels of a run are neighbouring waves.
+    // C2: a stream of `pairs` channel PAIRS is taken as that many two-channel streams whose frames lie 2 * pairs values
+    // apart (pairs = 1: stereo) -- `ch` is the wave's channel inside its pair, `chan` in the frame.
+    const uint32_t vstream = C2 ? gw / (runs_per_stream * 2u) : gw / (runs_per_stream * descs[0].channels);
+    const uint32_t stream_idx = CHM == 2 ? vstream / pairs : vstream;
+    const uint32_t pair = CHM == 2 ? vstream - stream_idx * pairs : 0u;
     const FftStreamDesc d = descs[stream_idx];
-    const uint32_t C = C2 ? 2u : d.channels;
-    const uint32_t in_stream = gw - stream_idx * runs_per_stream * C;
-    const uint32_t run_idx = in_stream / C;
-    const uint32_t ch = in_stream - run_idx * C;
+    const uint32_t C = CHM == 1 ? 2u : CHM == 2 ? 2u * pairs : d.channels;
+    const uint32_t CW = C2 ? 2u : C;   // channels that share a run's neighbouring waves
+    const uint32_t in_stream = gw - vstream * runs_per_stream * CW;
+    const uint32_t run_idx = in_stream / CW;
+    const uint32_t ch = in_stream - run_idx * CW;
+    const uint32_t chan = C2 ? 2u * pair + ch : ch;
+    constexpr bool stereo = CHM == 1;   // (frames of exactly the two channels: 16-byte loads and stores)
+    const uint32_t pair2 = 2u * pair;
     const uint32_t first = run_idx * run;
     if (first >= d.n_blocks) return;
     const uint32_t last = first + run < d.n_blocks ? first + run : d.n_blocks;  // exclusive
@@ -617,7 +630,7 @@ __global__ __launch_bounds__((OCC == 1 && kOneWavePerSimd<FWD, INV> ? 256 : wave
             if (first == 0 && i < CM) {
                 const int c = i + q * CM;   // complex index = reals 2c, 2c + 1 of the channel's overlap row
                 const GFloat* ov = as_global(d.overlap);
-                carry[it][q] = cf_make(ov[ch * FO + 2 * c], -ov[ch * FO + 2 * c + 1]);
+                carry[it][q] = cf_make(ov[chan * FO + 2 * c], -ov[chan * FO + 2 * c + 1]);
             }
         }
     }
@@ -637,8 +650,15 @@ __global__ __launch_bounds__((OCC == 1 && kOneWavePerSimd<FWD, INV> ? 256 : wave
                 cf v = cf_make(0.f, 0.f);
                 if (j < FI / 2) {
                     if constexpr (C2) {
-                        const f4 f = ((const GFloat4*)xin)[j];
-                        v = ch == 0 ? cf_make(f.x, f.z) : cf_make(f.y, f.w);
+                        if constexpr (stereo) {
+                            const f4 f = ((const GFloat4*)xin)[j];
+                            v = ch == 0 ? cf_make(f.x, f.z) : cf_make(f.y, f.w);
+                        } else {   // the pair's eight bytes in each of the two frames (32-bit offsets from a uniform base)
+                            const uint32_t fo = 2u * static_cast<uint32_t>(j) * C + pair2;
+                            const f2 a = *(const GFloat2*)(xin + fo);
+                            const f2 bb = *(const GFloat2*)(xin + fo + C);
+                            v = ch == 0 ? cf_make(a.x, bb.x) : cf_make(a.y, bb.y);
+                        }
                     } else {
                         v = cf_make(xin[static_cast<size_t>(2 * j) * C + ch], xin[static_cast<size_t>(2 * j + 1) * C + ch]);
                     }
@@ -677,8 +697,8 @@ __global__ __launch_bounds__((OCC == 1 && kOneWavePerSimd<FWD, INV> ? 256 : wave
                     const cf z = lds_ld(buf + c), z2 = lds_ld(buf + c + CM);
                     if (emit) {
                         const cf v = cf_conj_add_conj(z, carry[it][0]);
-                        xout[static_cast<size_t>(2 * c) * C + ch] = v.x;
-                        xout[static_cast<size_t>(2 * c + 1) * C + ch] = v.y;
+                        xout[static_cast<size_t>(2 * c) * C + chan] = v.x;
+                        xout[static_cast<size_t>(2 * c + 1) * C + chan] = v.y;
                     }
                     carry[it][0] = z2;
                 }
@@ -718,8 +738,8 @@ __global__ __launch_bounds__((OCC == 1 && kOneWavePerSimd<FWD, INV> ? 256 : wave
                             if (static_cast<uint32_t>(q & 1) == ch) vkeep[it][q >> 1] = v;
                             else lds_st(buf + xaddr(i, q >> 1), v);
                         } else {
-                            xout[static_cast<size_t>(2 * c) * C + ch] = v.x;
-                            xout[static_cast<size_t>(2 * c + 1) * C + ch] = v.y;
+                            xout[static_cast<size_t>(2 * c) * C + chan] = v.x;
+                            xout[static_cast<size_t>(2 * c + 1) * C + chan] = v.y;
                         }
                     }
                     carry[it][q] = o[q + HL];
@@ -749,7 +769,13 @@ __global__ __launch_bounds__((OCC == 1 && kOneWavePerSimd<FWD, INV> ? 256 : wave
                         for (int j = 0; j < HL / 2; ++j) {
                             const int c = i + (2 * j + static_cast<int>(ch)) * ML;   // frames 2c, 2c + 1, both channels: 16 bytes
                             const cf v0 = ch == 0 ? vkeep[it][j] : got[it][j], v1 = ch == 0 ? got[it][j] : vkeep[it][j];
-                            ((GFloat4*)xout)[c] = f4{v0.x, v1.x, v0.y, v1.y};
+                            if constexpr (stereo) {
+                                ((GFloat4*)xout)[c] = f4{v0.x, v1.x, v0.y, v1.y};
+                            } else {   // the pair's eight bytes in each of the two frames
+                                const uint32_t fo = 2u * static_cast<uint32_t>(c) * C + pair2;
+                                *(GFloat2*)(xout + fo) = f2{v0.x, v1.x};
+                                *(GFloat2*)(xout + fo + C) = f2{v0.y, v1.y};
+                            }
                         }
                     }
                 }
@@ -771,8 +797,8 @@ __global__ __launch_bounds__((OCC == 1 && kOneWavePerSimd<FWD, INV> ? 256 : wave
                 for (int q = 0; q < HL; ++q) {
                     const int c = i + q * CM;
                     GFloat* ov = as_global(d.overlap_next);
-                    ov[ch * FO + 2 * c] = carry[it][q].x;
-                    ov[ch * FO + 2 * c + 1] = -carry[it][q].y;
+                    ov[chan * FO + 2 * c] = carry[it][q].x;
+                    ov[chan * FO + 2 * c + 1] = -carry[it][q].y;
                 }
             }
         }
@@ -801,7 +827,7 @@ typedef WavePlan<2352, 2, 3, 7, 7, 8> W2352; // 88.2 kHz
 typedef WavePlan<2560, 5, 8, 8, 8> W2560;    // 96 kHz
 typedef WavePlan<640, 2, 5, 8, 8> W640;        // 16 kHz against the 44.1 kHz family
 
-typedef void (*WaveKernel)(FftPlanDev, const FftStreamDesc*, uint32_t, uint32_t, uint32_t);
+typedef void (*WaveKernel)(FftPlanDev, const FftStreamDesc*, uint32_t, uint32_t, uint32_t, uint32_t);
 struct WaveChoice {
     WaveKernel fn = nullptr;
     size_t lds = 0;          // bytes of a workgroup
@@ -812,7 +838,8 @@ struct WaveChoice {
 
 // The instantiation for (FWD, INV) if the plan is that pair.  Waves per CU, by what the CU's LDS holds (one copy
 // of the tables per workgroup + a buffer per wave) and what the registers allow: two-channel streams run 12
-// (<= 168 registers) or 2 x 4 waves; the any-channel-count build needs ~250 registers (strided
+// (<= 168 registers) or 2 x 4 waves; streams of 4, 6, 8 .. channels run as channel pairs on the same code with 8-byte
+// accesses (2 x 4 waves); the any-channel-count build (odd counts) needs ~250 registers (strided
 // sample addressing; it spilled 290 bytes per lane under the 168 cap and ran 25-30 % slower,
 // tools/fft_channels_bench.py) and runs 2 x 4.  Plans too long for that run one workgroup of up to 8 waves.
 template <class FWD, class INV>
@@ -833,17 +860,25 @@ bool wave_choice(const FftPlanDev& plan, uint32_t channels, int occ_env, WaveCho
         return false;
     } else {
     static const bool no_c2 = getenv("RSMP_FFT_WAVE_NOC2") != nullptr;   // A/B: the any-channel-count build for two channels
-    int occ = channels == 2 && !no_c2 ? (fit12 ? 3 : fit4 ? 2 : 1) : (fit4 ? 2 : 1);
-    if (channels == 2 && ((occ_env == 3 && fit12) || (occ_env == 2 && fit4))) occ = occ_env;
+    // (an even number of channels: channel pairs on the two-channel build)
+    const bool paired = channels % 2 == 0 && !no_c2;
+    // (the pairs build addresses its frames at a run-time stride: under the 168-register cap of twelve waves per CU it
+    // spills 25 registers and runs 13 % slower than 2 x 4 waves with all of them -- 8 channels 0.84 against 0.73 ms)
+    int occ = paired ? (fit12 && channels == 2 ? 3 : fit4 ? 2 : 1) : (fit4 ? 2 : 1);
+    if (paired && ((occ_env == 3 && fit12) || (occ_env == 2 && fit4))) occ = occ_env;
     out->occ = occ;
     out->fn = nullptr;
-    if (channels == 2 && !no_c2) {
-        if constexpr (fit12) if (occ == 3) out->fn = fft_ola_wave_kernel<FWD, INV, true, 3>;
-        if constexpr (fit4) if (occ == 2) out->fn = fft_ola_wave_kernel<FWD, INV, true, 2>;
-        if constexpr (!fit4) if (occ == 1) out->fn = fft_ola_wave_kernel<FWD, INV, true, 1>;
+    if (paired && channels == 2) {
+        if constexpr (fit12) if (occ == 3) out->fn = fft_ola_wave_kernel<FWD, INV, 1, 3>;
+        if constexpr (fit4) if (occ == 2) out->fn = fft_ola_wave_kernel<FWD, INV, 1, 2>;
+        if constexpr (!fit4) if (occ == 1) out->fn = fft_ola_wave_kernel<FWD, INV, 1, 1>;
+    } else if (paired) {
+        if constexpr (fit12) if (occ == 3) out->fn = fft_ola_wave_kernel<FWD, INV, 2, 3>;
+        if constexpr (fit4) if (occ == 2) out->fn = fft_ola_wave_kernel<FWD, INV, 2, 2>;
+        if constexpr (!fit4) if (occ == 1) out->fn = fft_ola_wave_kernel<FWD, INV, 2, 1>;
     } else {
-        if constexpr (fit4) out->fn = fft_ola_wave_kernel<FWD, INV, false, 2>;
-        else out->fn = fft_ola_wave_kernel<FWD, INV, false, 1>;
+        if constexpr (fit4) out->fn = fft_ola_wave_kernel<FWD, INV, 0, 2>;
+        else out->fn = fft_ola_wave_kernel<FWD, INV, 0, 1>;
     }
     static const uint32_t wide_knob = [] { const char* e = getenv("RSMP_FFT_WAVE_WIDE"); return e ? static_cast<uint32_t>(atoi(e)) : 0u; }();
     out->waves = occ == 3 ? 12u : occ == 2 ? 4u : (wide_knob >= 1 && wide_knob <= wide ? wide_knob : wide);
@@ -915,7 +950,7 @@ hipError_t launch_fft_ola_wave(const FftPlanDev& plan, const FftStreamDesc* d_de
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(fn, grid, dim3(kWavesPerGroup * 64), lds, stream, plan, d_descs, run, runs_per_stream,
-                       total_waves);
+                       total_waves, C / 2);   // (channel pairs: read by the two-channel build only)
     return hipGetLastError();
 }
 
