@@ -1394,6 +1394,8 @@ PeriodicGeometry split_geometry(uint64_t num, uint64_t den, uint32_t taps, uint3
     const uint32_t pad = (kpad - (taps + shift)) * kRowBytes;
     uint32_t slots = (kLdsLimit - kImageBase - pad) / (rows * kRowBytes);   // ring of images: slack between producers and consumers
     if (slots > 4) slots = 4;
+    static const uint32_t slots_knob = [] { const char* e = getenv("RSMP_FIR_SPLIT_SLOTS"); return e ? static_cast<uint32_t>(atoi(e)) : 0u; }();   // A/B: fewer images
+    if (slots_knob >= 2 && slots_knob < slots) slots = slots_knob;
     if (slots < 2) return g;
     const uint32_t lds = kImageBase + slots * rows * kRowBytes + pad;
     g.a = a;
