@@ -153,6 +153,28 @@ def timed(ctx: Ctx, step, steps: int, warmup: int):
     return ctx.max_over_ranks(dt), host_dt
 
 
+def device_copy_gbs(ctx: Ctx, nbytes: int) -> float:
+    """What a plain device-to-device copy of `nbytes` (read) + `nbytes` (written) reaches on this GPU, in GB/s of
+    read + written bytes: the PRACTICAL ceiling of a kernel that streams as much in as out, next to the 8 TB/s
+    the roofline is priced against ('also report a measured device-copy GB/s as the practical
+    peak').  torch's copy kernel on the bench's stream, torch events, 20 copies after 5."""
+    torch = ctx.torch
+    n = max(1 << 20, int(nbytes) // 4)
+    src = torch.empty(n, device=ctx.dev, dtype=torch.float32).normal_()
+    dst = torch.empty_like(src)
+    for _ in range(5):
+        dst.copy_(src)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        dst.copy_(src)
+    e1.record()
+    e1.synchronize()
+    ms = e0.elapsed_time(e1) / 20
+    del src, dst
+    return 2.0 * 4.0 * n / (ms * 1e-3) / 1e9
+
+
 def spinup(ctx: Ctx, step, seconds: float) -> None:
     """Untimed steps of the same workload until `seconds` have passed, before the contract's warmup
     steps.  Measured on the pool's MI355X: the first ~100 launches after idle run ~18 % slower than
@@ -451,6 +473,9 @@ def bench_fft(ctx: Ctx, args, steps: int, warmup: int, with_cpu: bool):
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic_from_profiles("fft"),
                      "kernel_ms": round(k_ms, 4), "algorithmic_bytes": int(alg_bytes)},
     }
+    copy_gbs = device_copy_gbs(ctx, alg_bytes / 2)
+    line["roofline"]["device_copy"] = round(copy_gbs, 1)
+    line["roofline"]["frac_of_device_copy"] = round(achieved / copy_gbs, 4)
     if with_cpu:
         line["cpu_baseline"] = cpu_baseline_fft(min(args.cpu_seconds, 6.0), min(args.cpu_all_cores_seconds, 4.0))
     return line
@@ -594,6 +619,7 @@ def bench_fir(ctx: Ctx, args):
     values_out_per_step = int(produced.sum())
     alg_bytes = 4.0 * (values_in_per_step + values_out_per_step) + 4.0 * 1024 * 128
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+    copy_gbs = device_copy_gbs(ctx, alg_bytes / 2)
     variant = handles[0].kernel_variant()
     line = {
         "metric": "Msamples/s (in) 44.1k->48k FIR 128-tap",
@@ -633,6 +659,9 @@ def bench_fir(ctx: Ctx, args):
             "kernel_ms": round(k_ms, 4),
             "kernel_launches_timed": int(k_launches),
             "algorithmic_bytes": int(alg_bytes),
+            # a plain device copy of the same volume on this GPU (read + written GB/s) and the kernel against it
+            "device_copy": round(copy_gbs, 1),
+            "frac_of_device_copy": round(achieved / copy_gbs, 4),
             # useful f32 FMAs (128 taps per output value), T/s
             "fma_per_s": round(values_out_per_step * 128 / (k_ms * 1e-3) / 1e12, 2),
         },
