@@ -221,6 +221,42 @@ def test_whole_file_driver_matches_reference_loop():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("ch,in_hz,out_hz,blocks", [
+    (4, 44100, 48000, 29), (8, 48000, 44100, 23), (6, 44100, 48000, 19),   # the 1176 <-> 1280 plans
+    (4, 48000, 96000, 17), (8, 96000, 48000, 17),                           # 512-frame families
+    (4, 22050, 48000, 13), (4, 88200, 96000, 9), (6, 44100, 192000, 7),     # long plans (one workgroup of a few waves)
+    (16, 44100, 48000, 9),
+])
+def test_even_channel_counts_run_as_channel_pairs(ch, in_hz, out_hz, blocks):
+    """Streams of 4, 6, 8 .. channels: channel pairs on the two-channel wave kernel (8-byte accesses at the frame's
+    stride, the pair's waves exchange their final values through LDS).  Expectation: the reference run per channel;
+    two bulk calls, so the second starts from a carried overlap and both contain more than one run of blocks."""
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda:0")
+    g = ra.ResamplerFft.new(ch, sr(in_hz), sr(out_hz))
+    per_channel = [o.OracleFft(1, in_hz, out_hz) for _ in range(ch)]
+    n_in, n_out = g.chunk_size_input(), g.chunk_size_output()
+    x = synth.fast_noise(blocks * n_in, seed=ch + blocks)
+    ref = np.zeros((blocks, n_out // ch, ch), np.float32)
+    row = np.zeros(n_out // ch, np.float32)
+    for k in range(blocks):
+        xk = x[k * n_in:(k + 1) * n_in].reshape(-1, ch)
+        for c in range(ch):
+            assert per_channel[c].resample(np.ascontiguousarray(xk[:, c]), row) == 0
+            ref[k, :, c] = row
+    first = blocks // 3
+    d_in = torch.from_numpy(x).to(dev)
+    d_out = torch.zeros(blocks * n_out, device=dev)
+    torch.cuda.synchronize()
+    g.resample_bulk_device(d_in[:first * n_in], d_out[:first * n_out], first)
+    g.resample_bulk_device(d_in[first * n_in:], d_out[first * n_out:], blocks - first)
+    torch.cuda.synchronize()
+    y = d_out.cpu().numpy()
+    assert rms(y, ref.reshape(-1)) <= RMS_TOL, rms(y, ref.reshape(-1))
+    assert float(np.max(np.abs(y - ref.reshape(-1)))) < 2e-5
+
+
+@pytest.mark.gpu
 def test_exact_build_is_bit_identical_to_the_reference_arithmetic():
     """libresampler_amd_fftexact.so = the same library with the wave kernel compiled without fused
     multiply-adds and with every twiddle fetched (make -C resampler_amd/csrc): its output equals the CPU
@@ -256,6 +292,22 @@ for in_hz, out_hz, a, b in ((44100, 48000, ra.SampleRate.Hz44100, ra.SampleRate.
         assert r.resample(x[k * n_in:(k + 1) * n_in], ref[k]) == 0
     y = d_out[0].cpu().numpy()
     assert np.array_equal(y, ref.reshape(-1)), (in_hz, float(np.abs(y - ref.reshape(-1)).max()))
+# four channels (two channel pairs on the same code): the reference run per channel
+g = ra.ResamplerFft.new(4, ra.SampleRate.Hz44100, ra.SampleRate.Hz48000)
+n_in, n_out = g.chunk_size_input(), g.chunk_size_output()
+x = synth.sweep(blocks * n_in // 4, 4, 44100.0)
+d_in, d_out = torch.from_numpy(x).to(dev), torch.zeros(blocks * n_out, device=dev)
+torch.cuda.synchronize()
+g.resample_bulk_device(d_in, d_out, blocks)
+torch.cuda.synchronize()
+ref = np.zeros((blocks, n_out // 4, 4), np.float32)
+row = np.zeros(n_out // 4, np.float32)
+for c in range(4):
+    r = o.OracleFft(1, 44100, 48000)
+    for k in range(blocks):
+        assert r.resample(np.ascontiguousarray(x[k * n_in:(k + 1) * n_in].reshape(-1, 4)[:, c]), row) == 0
+        ref[k, :, c] = row
+assert np.array_equal(d_out.cpu().numpy(), ref.reshape(-1)), "4 channels"
 print("bit-identical")
 """
     env = dict(os.environ, RSMP_AMD_LIB=exact, PYTHONPATH=root)
