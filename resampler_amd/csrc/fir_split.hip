@@ -741,6 +741,7 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
             v4f x2[5];            // two rounds, two channels: round 1's loads
             constexpr bool kShare = ROLE == 3 && WIDE == 1;   // two rounds, channel pairs: an even item stages its odd partner too
             bool odd_done = false;     // kShare: the current (odd) item was staged with the item before it
+            bool wloaded = false;      // the current item's wrap windows are in the registers (as `loaded` for its image)
             uint32_t cur_item = 0;     // the current item's index in the launch
             v4f xq[5][2];         // ROLE 2: (period, frame) x four channels
             v2f xm[5];            // ROLE 2, one channel: frames 2K, 2K + 1 of a period
@@ -789,6 +790,37 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
                     }
                     asm volatile("" : "+v"(wword[ps]));
                 }
+                auto wrap_passes = [&](bool from_regs) {
+#pragma unroll
+                    for (int ps = 0; ps < kMaxPass; ++ps) {
+                        if (static_cast<uint32_t>(ps) >= n_pass) continue;
+                        const uint32_t wper = 4 * (pass0 + ps) + (ln >> 4);
+                        v2f w[kWrapTaps];
+                        if (from_regs) {
+#pragma unroll
+                            for (int i = 0; i < kWrapTaps / 2; ++i) {
+                                if constexpr (ROLE != 0) {
+                                    w[2 * i] = wxw[ps][2 * i];
+                                    w[2 * i + 1] = wxw[ps][2 * i + 1];
+                                } else {
+                                    w[2 * i] = v2f{wx[ps][i].x, wx[ps][i].y};
+                                    w[2 * i + 1] = v2f{wx[ps][i].z, wx[ps][i].w};
+                                }
+                            }
+                            wrap_out(w, wper, wsel[ps] < 32 ? (wword[ps] >> wsel[ps]) & 1u : 0u);
+                        } else {
+                            const int64_t fw = ecur.f0 + static_cast<int64_t>(wper * g.a) - 1 + wpart * kWrapTaps;
+#pragma unroll
+                            for (int i = 0; i < kWrapTaps; ++i) w[i] = fetch_edge(ectx, ecur.pair, fw + i);
+                            const int32_t nw = ecur.it.n_block0 + static_cast<int32_t>(wper * g.b);
+                            const bool in_launch = nw >= 0 && nw < static_cast<int32_t>(ectx.n_out);
+                            const uint32_t K = in_launch ? static_cast<uint32_t>(ecur.it.k_block0) + wper : 0u;
+                            const uint32_t word = ((gconst_u32_ptr)ectx.wrap_bits)[K >> 5];
+                            wrap_out(w, wper, in_launch ? (word >> (K & 31)) & 1u : 0u);
+                        }
+                    }
+                };
+                bool signalled = false;   // kShare: the item's `staged` count was given early (below)
                 const bool staged_already = kShare && odd_done;   // (an odd item its even neighbour has staged)
                 if constexpr (kShare) odd_done = false;
                 if constexpr (ROLE != 1) if (have && real_task && !(dbg & 1) && !staged_already) {
@@ -906,15 +938,19 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
                             slot2 = slot + 1 == g.slots ? 0u : slot + 1;
                             use2 = slot + 1 == g.slots ? use + 1 : use;
                             img2 = lds + kImageBase + slot2 * image_bytes;
-                            while (lds_load_acquire(done + slot2) < n_active * use2) __builtin_amdgcn_s_sleep(RSMP_POLL_SLEEP);
-                            note_fin(__builtin_amdgcn_readfirstlane(__hip_atomic_load(fin + 2 * slot2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)),
-                                     __builtin_amdgcn_readfirstlane(__hip_atomic_load(fin + 2 * slot2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)));
-                            m_partner = lane_max(at_partner, 0.f);
-                            const uint32_t eh2 = hist_of(cpair + 1);
-                            if (eh2 == 0 || !real_rd[ROUNDS - 1]) publish(m_partner, slot2, use2);
-                            xs2 = scale_for(eh2, slot2);
                         }
                     }
+                    // The partner's image slot is the one the consumers free LAST (they take the quad's items in order), so
+                    // it is waited for as late as the shared registers allow: behind the item's own first plane set.
+                    auto partner_slot = [&]() {
+                        while (lds_load_acquire(done + slot2) < n_active * use2) __builtin_amdgcn_s_sleep(RSMP_POLL_SLEEP);
+                        note_fin(__builtin_amdgcn_readfirstlane(__hip_atomic_load(fin + 2 * slot2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)),
+                                 __builtin_amdgcn_readfirstlane(__hip_atomic_load(fin + 2 * slot2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)));
+                        m_partner = lane_max(at_partner, 0.f);
+                        const uint32_t eh2 = hist_of(cpair + 1);
+                        if (eh2 == 0 || !real_rd[ROUNDS - 1]) publish(m_partner, slot2, use2);
+                        xs2 = scale_for(eh2, slot2);
+                    };
                     PItem pc;   // (of an interior item only where its frames start is needed)
                     pc.off0 = cur_off0;
                     if constexpr (kShare) {
@@ -922,7 +958,10 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
                         // written their registers take round 1's frames 2K, which fly while the frames 2K + 1 are written.
                         const bool ahead = loaded && real_rd[1];
                         store_task(img, at, 0, xs, 0, 1);
-                        if (share) store_task(img2, at_partner, 0, xs2, 0, 1);
+                        if (share) {
+                            partner_slot();
+                            store_task(img2, at_partner, 0, xs2, 0, 1);
+                        }
                         if (ahead) load_task_quad_half(xq, pc, uniform_ptr<true>(cur_in), 1, 0);
                         store_task(img, at, 0, xs, 1, 2);
                         if (share) store_task(img2, at_partner, 0, xs2, 1, 2);
@@ -952,6 +991,11 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
                             publish(m_own, slot, use);
                             store_task(img, at, 1, xs, 1, 2);
                             if (share) {
+                                // the item itself is complete here: its count is given before the partner's last plane set,
+                                // so the consumers start on it that much earlier (no load of this wave is in flight)
+                                if (wrapper) wrap_passes(wloaded);
+                                lds_signal(staged + slot);
+                                signalled = true;
                                 m_partner = lane_max(at_partner, m_partner, 1, 2);
                                 publish(m_partner, slot2, use2);
                                 store_task(img2, at_partner, 1, xs2, 1, 2);
@@ -984,39 +1028,9 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
                     }
                     if constexpr (kShare) odd_done = share;
                 }
-                auto wrap_passes = [&](bool from_regs) {
-#pragma unroll
-                    for (int ps = 0; ps < kMaxPass; ++ps) {
-                        if (static_cast<uint32_t>(ps) >= n_pass) continue;
-                        const uint32_t wper = 4 * (pass0 + ps) + (ln >> 4);
-                        v2f w[kWrapTaps];
-                        if (from_regs) {
-#pragma unroll
-                            for (int i = 0; i < kWrapTaps / 2; ++i) {
-                                if constexpr (ROLE != 0) {
-                                    w[2 * i] = wxw[ps][2 * i];
-                                    w[2 * i + 1] = wxw[ps][2 * i + 1];
-                                } else {
-                                    w[2 * i] = v2f{wx[ps][i].x, wx[ps][i].y};
-                                    w[2 * i + 1] = v2f{wx[ps][i].z, wx[ps][i].w};
-                                }
-                            }
-                            wrap_out(w, wper, wsel[ps] < 32 ? (wword[ps] >> wsel[ps]) & 1u : 0u);
-                        } else {
-                            const int64_t fw = ecur.f0 + static_cast<int64_t>(wper * g.a) - 1 + wpart * kWrapTaps;
-#pragma unroll
-                            for (int i = 0; i < kWrapTaps; ++i) w[i] = fetch_edge(ectx, ecur.pair, fw + i);
-                            const int32_t nw = ecur.it.n_block0 + static_cast<int32_t>(wper * g.b);
-                            const bool in_launch = nw >= 0 && nw < static_cast<int32_t>(ectx.n_out);
-                            const uint32_t K = in_launch ? static_cast<uint32_t>(ecur.it.k_block0) + wper : 0u;
-                            const uint32_t word = ((gconst_u32_ptr)ectx.wrap_bits)[K >> 5];
-                            wrap_out(w, wper, in_launch ? (word >> (K & 31)) & 1u : 0u);
-                        }
-                    }
-                };
-                if (have && wrapper) {
+                if (have && wrapper && !signalled) {
                     wt.event(13);
-                    wrap_passes(loaded);
+                    wrap_passes(wloaded);
                 }
                 if (more && wrapper && cu.c.coeffs != cur_coeffs) {   // the next item's taps of row 1023 (rare: compiler-visible loads)
                     cur_coeffs = cu.c.coeffs;
@@ -1041,13 +1055,17 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
                     } else if constexpr (ROLE == 0 || ROLE == 3) {
                         if (real_task) load_task(x, true, nxt, uniform_ptr<true>(cu.c.in), 0);   // (two rounds: round 0)
                     }
+                }
+                // (kShare: an odd item's image comes with its even neighbour's, its wrap windows are prefetched like any item's)
+                const bool wpre = pre || (kShare && more && nxt.interior && !(dbg & 8192));
+                if (wpre) {
 #pragma unroll
                     for (int ps = 0; ps < kMaxPass; ++ps)
                         if (static_cast<uint32_t>(ps) < n_pass) load_wrap(ps, nxt, cu.c);
                 }
                 if (have) {
                     wt.event(4);
-                    lds_signal(staged + slot);
+                    if (!signalled) lds_signal(staged + slot);
                     wt.event(14);
                     if (++slot == g.slots) {
                         slot = 0;
@@ -1056,6 +1074,7 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
                 }
                 have = more;
                 loaded = pre;
+                wloaded = wpre;
                 if (more && !pre) {   // an edge item comes next: keep its description
                     ecur = nxt;
                     ectx = cu.c;
