@@ -38,3 +38,8 @@ print("wave 1 per unit: units p50 %.1f | setup %.0f | tile wait %.0f | mfma %.0f
 # by geometry: group rows by their 'end'
 order = np.argsort(rows[:, 7])
 print("slowest workgroups:", rows[order[-5:], 0].astype(int), rows[order[-5:], 7])
+# end time by workgroup index (the batch's internal order groups the streams by geometry: buckets of 20 workgroups)
+end = rows[:, 7]
+print("end by workgroup bucket (p50 / max, k cycles):", " ".join(f"{b * 20}:{np.percentile(end[b * 20:(b + 1) * 20], 50) / 1e3:.0f}/{end[b * 20:(b + 1) * 20].max() / 1e3:.0f}" for b in range((len(end) + 19) // 20)))
+stage = rows[:, 3]
+print("barrier1 by bucket (p50):", " ".join(f"{b * 20}:{np.percentile(stage[b * 20:(b + 1) * 20], 50) / 1e3:.0f}" for b in range((len(end) + 19) // 20)))
