@@ -680,6 +680,18 @@ def secondary_lines(ctx: Ctx, args):
                   "roofline": fft["roofline"], "cpu_baseline": fft.get("cpu_baseline")}
     sec["fir_exact_f32"] = fir_kernel_point(ctx, ra, args, ra.FirKernel.PeriodicF32, 16)
     sec["fir_vector_no_mfma"] = fir_kernel_point(ctx, ra, args, ra.FirKernel.PeriodicVector, 16)
+    # the split kernel with every f32 operand cut EXACTLY into three bf16 planes (six products per term): a knob the
+    # library reads once per process, so a child runs the same headline launch with it
+    try:
+        child = subprocess.run([sys.executable, os.path.abspath(__file__), "--no-cpu", "--no-secondary", "--steps", "16",
+                                "--warmup", "3", "--spinup-seconds", "1", "--streams", str(args.streams),
+                                "--frames", str(args.frames)],
+                               env=dict(os.environ, RSMP_FIR_SPLIT_PLANES="3", WORLD_SIZE="1", RANK="0", LOCAL_RANK=str(ctx.local_rank)),
+                               capture_output=True, text=True, timeout=300)
+        r3 = json.loads(child.stdout.strip().splitlines()[-1])["roofline"]
+        sec["fir_split_bf16x3"] = {k: r3[k] for k in ("kernel", "kernel_ms", "achieved", "frac")}
+    except Exception as e:   # (the headline does not depend on it)
+        sec["fir_split_bf16x3"] = {"error": repr(e)[:200]}
     # other channel counts on the default kernel (same rate pair and taps)
     sec["fir_channels"] = {str(c): fir_channels_point(ctx, ra, args, c, 8) for c in (1, 4, 8)}
     # the same launch with every stream in a different state: nothing shares a plan
