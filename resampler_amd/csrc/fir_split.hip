@@ -737,8 +737,13 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
                 float* wv = reinterpret_cast<float*>(lds + kCtrlBytes + slot * 256);
                 if (wpart == 0) *reinterpret_cast<v4f*>(wv + wper * 4) = v4f{acc.x, acc.y, __uint_as_float(take), 0.f};
             };
+            // x / x2 are written by the asm loads ONLY (and read once, behind the wait for them): a register that is in
+            // flight across the loop's back edge must have no other definition, or the allocator may give the loop-carried
+            // value a second home and copy it there at the latch -- before it has landed (it did: the three-plane build
+            // copied x at the latch once the edge path wrote x too, and converted garbage).  The item's samples live in xc.
             v4f x[5];
             v4f x2[5];            // two rounds, two channels: round 1's loads
+            v4f xc[5];            // the current item's (round's) lane task: x, x2 or the edge frames
             constexpr bool kShare = ROLE == 3 && WIDE == 1;   // two rounds, channel pairs: an even item stages its odd partner too
             bool odd_done = false;     // kShare: the current (odd) item was staged with the item before it
             bool wloaded = false;      // the current item's wrap windows are in the registers (as `loaded` for its image)
@@ -837,11 +842,15 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
                                     xq[i][1] = v4f{hi.x, hi.y, hi.x, hi.y};
                                 }
                             } else {
-                                x[i] = v4f{lo.x, lo.y, hi.x, hi.y};
+                                xc[i] = v4f{lo.x, lo.y, hi.x, hi.y};
                             }
                         }
                     };
                     if (!loaded) fetch_edge_round(0);
+                    else if constexpr ((ROLE == 0 || ROLE == 3) && !kShare) {
+#pragma unroll
+                        for (int i = 0; i < 5; ++i) xc[i] = x[i];
+                    }
                     // at(i, fr, c) = channel c of frame 2K + fr in period 4Q + i of the lane task in the registers; partner:
                     // the same of the block's odd pair (kShare: the upper half of the sixteen bytes)
                     auto at = [&](int i, int fr, int c) -> float {
@@ -851,7 +860,7 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
                         } else if constexpr (kShare) {
                             return xq[i][fr][c];
                         } else {
-                            return x[i][2 * fr + c];
+                            return xc[i][2 * fr + c];
                         }
                     };
                     auto at_partner = [&](int i, int fr, int c) -> float { return xq[i][fr][2 + c]; };
@@ -1014,7 +1023,7 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
 #pragma unroll
                                 for (int i = 0; i < 5; ++i) {
                                     asm volatile("" : "+v"(x2[i]));
-                                    x[i] = x2[i];
+                                    xc[i] = x2[i];
                                 }
                             } else {
                                 fetch_edge_round(1);
@@ -1370,7 +1379,8 @@ static uint32_t split_planes_knob() {
 
 PeriodicGeometry split_geometry(uint64_t num, uint64_t den, uint32_t taps, uint32_t channels) {
     PeriodicGeometry g;
-    const uint32_t planes = split_planes_knob();
+    // (three planes: the two-channel kernel only -- the channel-pair, one-channel and odd-count builds keep two)
+    const uint32_t planes = channels == 2 ? split_planes_knob() : 2u;
     const uint32_t kRowBytes = row_bytes(static_cast<int>(planes));
     // two channels, or (RSMP_FIR_SPLIT_WIDE=0 turns it off) an even number up to 16 taken as channel pairs, two pairs per
     // 16-byte load (6, 10, 14 channels: the last pair alone -- its load reaches 8 bytes into the next frame)
@@ -1518,9 +1528,9 @@ hipError_t launch_fir_split(const FirStreamDesc* d_descs, uint32_t n_streams, co
      reinterpret_cast<const void*>(fir_split_kernel<5, P, D, W>)}
     static const void* const fns_all[2][2][5] = {{RSMP_SPLIT_FNS(2, false, 0), RSMP_SPLIT_FNS(2, true, 0)},
                                                  {RSMP_SPLIT_FNS(3, false, 0), RSMP_SPLIT_FNS(3, true, 0)}};
-    static const void* const fns_wide[2][5] = {RSMP_SPLIT_FNS(2, false, 1), RSMP_SPLIT_FNS(3, false, 1)};   // (no diagnostic build)
-    static const void* const fns_mono[2][5] = {RSMP_SPLIT_FNS(2, false, 2), RSMP_SPLIT_FNS(3, false, 2)};
-    static const void* const fns_odd[2][5] = {RSMP_SPLIT_FNS(2, false, 3), RSMP_SPLIT_FNS(3, false, 3)};
+    static const void* const fns_wide[1][5] = {RSMP_SPLIT_FNS(2, false, 1)};   // (no diagnostic build; two planes only)
+    static const void* const fns_mono[1][5] = {RSMP_SPLIT_FNS(2, false, 2)};
+    static const void* const fns_odd[1][5] = {RSMP_SPLIT_FNS(2, false, 3)};
 #undef RSMP_SPLIT_FNS
     const bool one_channel = geo.cg == 1;
     const bool odd_count = geo.cg == 3;
@@ -1539,9 +1549,9 @@ hipError_t launch_fir_split(const FirStreamDesc* d_descs, uint32_t n_streams, co
     const bool two_rounds = geo.rounds == 2;
     const bool diag_long = two_rounds && diag && geo.row_len / 32 == 6;
     const void* const* fns = two_rounds  ? fns_long[(wide ? 1 : 0) + (diag_long ? 2 : 0)]
-                             : one_channel ? fns_mono[geo.planes == 3 ? 1 : 0]
-                             : odd_count ? fns_odd[geo.planes == 3 ? 1 : 0]
-                             : wide      ? fns_wide[geo.planes == 3 ? 1 : 0]
+                             : one_channel ? fns_mono[0]
+                             : odd_count ? fns_odd[0]
+                             : wide      ? fns_wide[0]
                                          : fns_all[geo.planes == 3 ? 1 : 0][diag ? 1 : 0];
     const uint32_t nk = geo.row_len / 32;
     if (nk < 1 || nk > (two_rounds ? 6u : 5u) || fns[nk - 1] == nullptr) return hipErrorInvalidValue;

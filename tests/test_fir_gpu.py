@@ -615,3 +615,39 @@ def test_time_sharded_stream_equals_the_single_launch(ch, in_hz, out_hz, lat, at
     s = shards[-1]
     with pytest.raises(ra.ResampleError):
         mk().seek(s.plan, d_x[:max(0, s.history_frames - 1) * ch])
+
+
+@pytest.mark.gpu
+def test_three_plane_split_kernel_in_a_child_process():
+    """RSMP_FIR_SPLIT_PLANES=3 (read once per process): every f32 operand cut exactly into three bf16 planes, six
+    products per term -- the knob bench.py's `secondary.fir_split_bf16x3` measures; two-channel streams (the other
+    channel counts keep the two-plane builds).  Same gate as the default kernel (1e-6 RMS relative to the signal,
+    identical counts) on the bulk entry, interior and edge items, at full scale and at 2^-20."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import numpy as np
+import resampler_amd as ra
+from oracle import pyoracle as o
+from resampler_amd import synth
+kind = o.CONVOLVE_AVX_FMA if o.have_avx_fma() else o.CONVOLVE_SCALAR
+for ch, a, b, n, level in ((2, 44100, 48000, 300000, 1.0), (2, 48000, 44100, 200000, 2.0 ** -20), (8, 44100, 48000, 120000, 1.0),
+                           (1, 48000, 44100, 150000, 1.0), (3, 44100, 48000, 100000, 30.0)):
+    g = ra.ResamplerFir.new_from_hz(ch, a, b, ra.Latency.Sample64, ra.Attenuation.Db90)
+    g.set_kernel(ra.FirKernel.Periodic)
+    r = o.OracleFir(ch, a, b, 128, 90, kind)
+    x = (synth.sweep(n, ch, float(a)) * np.float32(level)).astype(np.float32)
+    chunk = 512 - 512 % ch
+    yg, consumed, calls_g = g.resample_bulk(x, chunk, want_calls=True)
+    yr, calls_r = r.resample_all(x, chunk)
+    assert g.kernel_variant() == (4 if ch == 2 else 5), (ch, a, b, g.kernel_variant())
+    assert yg.size == yr.size and np.array_equal(calls_g, calls_r), (ch, a, b)
+    e = float(np.sqrt(np.mean((yg.astype(np.float64) - yr) ** 2))) / float(np.sqrt(np.mean(yr.astype(np.float64) ** 2)))
+    assert e <= 1e-6, (ch, a, b, e)
+print("three planes ok")
+"""
+    env = dict(os.environ, RSMP_FIR_SPLIT_PLANES="3", PYTHONPATH=root)
+    out = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "three planes ok" in out.stdout, out.stdout + out.stderr
