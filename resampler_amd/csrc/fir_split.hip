@@ -991,11 +991,11 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
                                 m_partner = lane_max(at_partner, m_partner, 0, 1);
                                 store_task(img2, at_partner, 1, xs2, 0, 1);
                             }
-                            if (ahead) {
-                                asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
+                            // (unconditional: free when nothing is in flight, and tools/asm_inflight_lint.py follows no
+                            // correlated branches)
+                            asm volatile("s_waitcnt vmcnt(0)" : : : "memory");
 #pragma unroll
-                                for (int i = 0; i < 5; ++i) asm volatile("" : "+v"(xq[i][1]));
-                            }
+                            for (int i = 0; i < 5; ++i) asm volatile("" : "+v"(xq[i][1]));
                             m_own = lane_max(at, m_own, 1, 2);
                             publish(m_own, slot, use);
                             store_task(img, at, 1, xs, 1, 2);
