@@ -1003,10 +1003,16 @@ __global__ __launch_bounds__(kLsWaves * 64, kLsWaves / 2) void fir_lockstep_kern
 
     // ---- D: reference form for the streams that need it -------------------------------------------
     if constexpr (TRACE) tr[5] = __builtin_amdgcn_s_memtime();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // phase B/C stores are acknowledged before D overwrites
-    __syncthreads();
+    __syncthreads();   // (every wave's units are done: the flags they may have set are final)
     if constexpr (TRACE) tr[6] = __builtin_amdgcn_s_memtime();
-    {
+    bool any_reference = false;   // (workgroup-uniform) some stream is redone in the reference's form: rare
+    for (uint32_t s = 0; s < g.count; ++s)
+        any_reference = any_reference || ((plan[s].flags & (kFlagReference | kFlagNonFinite)) && plan[s].n_out != 0);
+    if (any_reference) {
+        // phase B/C stores are acknowledged before D overwrites them -- a wait (an HBM store's round trip) and a second
+        // barrier that only the workgroups with such a stream pay
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
         const uint32_t grp = threadIdx.x >> 3, ngrp = kLsWaves * 8, gl = threadIdx.x & 7;
         for (uint32_t s = 0; s < g.count; ++s) {
             const PlanLds& pl = plan[s];
