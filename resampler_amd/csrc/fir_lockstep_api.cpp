@@ -173,6 +173,19 @@ extern "C" rsmp_fir_lockstep* rsmp_fir_lockstep_new(rsmp_fir* const* rs, size_t 
         }
         k = e;
     }
+    // Workgroup order = dispatch order: with more workgroups than CUs (two fit a CU) number k + CUs becomes the second
+    // tenant of the CU that took number k.  The slow geometries first and the quick ones last pairs each slow workgroup
+    // with a quick one (or leaves it alone) instead of with its own kind -- a step ends with its slowest workgroup, and
+    // two slow tenants slow each other (`tools/ls_trace.py`: the 20-tile and the 505-row images end at 46-52 k cycles, the
+    // one-stream 48 -> 96 kHz ones at 27 k).  Cost: matrix units + rows to stage, a packed image's bank conflicts on top.
+    {
+        auto cost = [](const LockstepGroup& g) {
+            const double units = static_cast<double>(g.n_tiles) * ((g.max_cols + 15) / 16);
+            return units + g.count * (g.split ? g.rows : g.region_frames) / 64.0 + (g.split && g.row_bytes == rsmp::kLsImageRowBytesPacked ? 10.0 : 0.0);
+        };
+        std::stable_sort(ls->groups.begin(), ls->groups.end(),
+                         [&](const LockstepGroup& x, const LockstepGroup& y) { return cost(x) > cost(y); });
+    }
     if (ls->d_groups.reserve(ls->groups.size() * sizeof(LockstepGroup)) != hipSuccess ||
         ls->d_streams.reserve(n * sizeof(LockstepStream)) != hipSuccess ||
         ls->d_states.reserve(n * sizeof(FirMirrorState)) != hipSuccess ||
