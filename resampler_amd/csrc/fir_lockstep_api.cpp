@@ -175,7 +175,7 @@ extern "C" rsmp_fir_lockstep* rsmp_fir_lockstep_new(rsmp_fir* const* rs, size_t 
     }
     // Workgroup order = dispatch order: with more workgroups than CUs (two fit a CU) number k + CUs becomes the second
     // tenant of the CU that took number k.  The slow geometries first and the quick ones last pairs each slow workgroup
-    // with a quick one (or leaves it alone) instead of with its own kind -- a step ends with its slowest workgroup, and
+    // with a quick one (or leaves it alone, see below) instead of with its own kind -- a step ends with its slowest workgroup, and
     // two slow tenants slow each other (`tools/ls_trace.py`: the 20-tile and the 505-row images end at 46-52 k cycles, the
     // one-stream 48 -> 96 kHz ones at 27 k).  Cost: matrix units + rows to stage, a packed image's bank conflicts on top.
     {
@@ -185,6 +185,19 @@ extern "C" rsmp_fir_lockstep* rsmp_fir_lockstep_new(rsmp_fir* const* rs, size_t 
         };
         std::stable_sort(ls->groups.begin(), ls->groups.end(),
                          [&](const LockstepGroup& x, const LockstepGroup& y) { return cost(x) > cost(y); });
+        // ... and the slowest of all ALONE: with n workgroups on c CUs the indices n - c .. c - 1 get no second tenant, so the
+        // order is [next slowest: first tenants][slowest: alone][quickest: second tenants] (0.0184 -> 0.0181 ms per step)
+        int cus = 256;
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ls->device);
+        const size_t n = ls->groups.size(), c = static_cast<size_t>(cus);
+        if (n > c && n < 2 * c) {
+            const size_t second = n - c, alone = c - second;
+            std::vector<LockstepGroup> o;
+            o.insert(o.end(), ls->groups.begin() + alone, ls->groups.begin() + alone + second);
+            o.insert(o.end(), ls->groups.begin(), ls->groups.begin() + alone);
+            o.insert(o.end(), ls->groups.begin() + alone + second, ls->groups.end());
+            ls->groups.swap(o);
+        }
     }
     if (ls->d_groups.reserve(ls->groups.size() * sizeof(LockstepGroup)) != hipSuccess ||
         ls->d_streams.reserve(n * sizeof(LockstepStream)) != hipSuccess ||
