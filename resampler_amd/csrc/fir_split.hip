@@ -704,24 +704,57 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
                 wword[ps] = 0;
                 wsel[ps] = 32;
             }
-            auto load_wrap = [&](int ps, const PItem& pi, const StreamCtx& c) {
+            // The wrap variant's windows are fetched only for the periods whose output TAKES it (the bitmap says so: about
+            // four periods in ten of the bench's stream, none of an exact ratio's).  A window load is 8 lines per period and
+            // instruction where an image load is 8 lines per 64 lanes: fetched for every period the windows were 2.5x the
+            // image's address work.  The bitmap words of the NEXT item are requested at the loop's top (load_wrap_bits) and
+            // have landed when its windows are requested at the pass's end (load_wrap), lanes without a take switched off.
+            // Two-round kernels only: where one round of lane tasks fills the item's time (the 147/160 pair, the tile-group
+            // pairs) a vector load in flight across the conversion costs more than the windows' address work saves
+            // (measured in one lease: 8 ch 96 -> 44.1 kHz 0.95 -> 0.75 ms, 8 ch 48 -> 96 kHz 0.91 -> 0.69, 4 ch 96 -> 44.1
+            // 0.29 -> 0.25; the headline 0.286 -> 0.338, 2 ch 44.1 -> 96 kHz 0.64 -> 0.71).
+            constexpr bool kWrapByTake = ROUNDS == 2;
+            uint32_t wnext[kMaxPass], wnsel[kMaxPass];
+#pragma unroll
+            for (int ps = 0; ps < kMaxPass; ++ps) {
+                wnext[ps] = 0;
+                wnsel[ps] = 32;
+            }
+            auto load_wrap_bits = [&](int ps, const PItem& pi, const StreamCtx& c) {
                 const uint32_t wper = 4 * (pass0 + ps) + (ln >> 4);
-                if constexpr (ROLE != 0) {
-                    const void* base = uniform_ptr<true>(c.in + 2 * pi.pair);
-                    const uint32_t off = (pi.off0 + wper * g.a - 1 + wpart * kWrapTaps) * fsb;
-#pragma unroll
-                    for (int i = 0; i < kWrapTaps; ++i) gload2(wxw[ps][i], off + i * fsb, base);
-                } else {
-                    const void* base = uniform_ptr<true>(c.in);
-                    const uint32_t off = (pi.off0 + wper * g.a - 1 + wpart * kWrapTaps) * 8u;
-#pragma unroll
-                    for (int i = 0; i < kWrapTaps / 2; ++i) gload4(wx[ps][i], off + i * 16u, base);
-                }
                 const int32_t nw = pi.it.n_block0 + static_cast<int32_t>(wper * g.b);
                 const bool in_launch = nw >= 0 && nw < static_cast<int32_t>(c.n_out);
                 const uint32_t K = in_launch ? static_cast<uint32_t>(pi.it.k_block0) + wper : 0u;   // (word 0 always exists)
-                gload1(wword[ps], (K >> 5) * 4u, uniform_ptr<true>(c.wrap_bits));
-                wsel[ps] = in_launch ? K & 31u : 32u;
+                gload1(wnext[ps], (K >> 5) * 4u, uniform_ptr<true>(c.wrap_bits));
+                wnsel[ps] = in_launch ? K & 31u : 32u;
+            };
+            auto load_wrap = [&](int ps, const PItem& pi, const StreamCtx& c) {
+                const uint32_t wper = 4 * (pass0 + ps) + (ln >> 4);
+                bool fetch = true;
+                if constexpr (kWrapByTake) {
+                    wword[ps] = wnext[ps];
+                    wsel[ps] = wnsel[ps];
+                    fetch = wsel[ps] < 32 && ((wword[ps] >> wsel[ps]) & 1u);   // (lanes of the periods that take it)
+                } else {   // every window, and the bitmap word with them
+                    const int32_t nw = pi.it.n_block0 + static_cast<int32_t>(wper * g.b);
+                    const bool in_launch = nw >= 0 && nw < static_cast<int32_t>(c.n_out);
+                    const uint32_t K = in_launch ? static_cast<uint32_t>(pi.it.k_block0) + wper : 0u;   // (word 0 always exists)
+                    gload1(wword[ps], (K >> 5) * 4u, uniform_ptr<true>(c.wrap_bits));
+                    wsel[ps] = in_launch ? K & 31u : 32u;
+                }
+                if (fetch) {
+                    if constexpr (ROLE != 0) {
+                        const void* base = uniform_ptr<true>(c.in + 2 * pi.pair);
+                        const uint32_t off = (pi.off0 + wper * g.a - 1 + wpart * kWrapTaps) * fsb;
+#pragma unroll
+                        for (int i = 0; i < kWrapTaps; ++i) gload2(wxw[ps][i], off + i * fsb, base);
+                    } else {
+                        const void* base = uniform_ptr<true>(c.in);
+                        const uint32_t off = (pi.off0 + wper * g.a - 1 + wpart * kWrapTaps) * 8u;
+#pragma unroll
+                        for (int i = 0; i < kWrapTaps / 2; ++i) gload4(wx[ps][i], off + i * 16u, base);
+                    }
+                }
             };
             auto wrap_out = [&](const v2f (&w)[kWrapTaps], uint32_t wper, uint32_t take) {
                 v2f acc = v2f{0.f, 0.f};
@@ -773,6 +806,15 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
                     wt.event(12);
                 }
                 asm volatile("s_waitcnt vmcnt(0)" : : : "memory");   // the current item's loads (or dummies)
+                // (kShare: an odd item's image comes with its even neighbour's, its wrap windows are prefetched like any item's)
+                const bool wpre = pre || (kShare && more && nxt.interior && !(dbg & 8192));
+                if constexpr (kWrapByTake) {
+                    if (wpre) {
+#pragma unroll
+                        for (int ps = 0; ps < kMaxPass; ++ps)
+                            if (static_cast<uint32_t>(ps) < n_pass) load_wrap_bits(ps, nxt, cu.c);
+                    }
+                }
                 if (have) wt.event(6);
                 if constexpr (ROLE == 2 || kShare) {
 #pragma unroll
@@ -1054,6 +1096,16 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
 #pragma unroll
                     for (int i = 0; i < kWrapTaps; ++i) asm volatile("" : "+v"(wcoef[i]));
                 }
+                if constexpr (kWrapByTake) {
+                    if (wpre && wrapper) {
+                        asm volatile("s_waitcnt vmcnt(0)" : : : "memory");   // the bitmap words requested at the top (nothing else is in flight)
+#pragma unroll
+                        for (int ps = 0; ps < kMaxPass; ++ps) asm volatile("" : "+v"(wnext[ps]));
+#pragma unroll
+                        for (int ps = 0; ps < kMaxPass; ++ps)
+                            if (static_cast<uint32_t>(ps) < n_pass) load_wrap(ps, nxt, cu.c);
+                    }
+                }
                 if (pre) {
                     if constexpr (ROLE == 2) {
                         if constexpr (mono) {
@@ -1065,12 +1117,12 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
                         if (real_task) load_task(x, true, nxt, uniform_ptr<true>(cu.c.in), 0);   // (two rounds: round 0)
                     }
                 }
-                // (kShare: an odd item's image comes with its even neighbour's, its wrap windows are prefetched like any item's)
-                const bool wpre = pre || (kShare && more && nxt.interior && !(dbg & 8192));
-                if (wpre) {
+                if constexpr (!kWrapByTake) {
+                    if (wpre) {
 #pragma unroll
-                    for (int ps = 0; ps < kMaxPass; ++ps)
-                        if (static_cast<uint32_t>(ps) < n_pass) load_wrap(ps, nxt, cu.c);
+                        for (int ps = 0; ps < kMaxPass; ++ps)
+                            if (static_cast<uint32_t>(ps) < n_pass) load_wrap(ps, nxt, cu.c);
+                    }
                 }
                 if (have) {
                     wt.event(4);

@@ -48,7 +48,24 @@ def transfer(state, ins, report=None):
         srcs = set().union(*[regs(o) for o in ops]) if ops else set()
         dst = set()
     else:
-        srcs = set().union(*[regs(o) for o in ops[1:]]) if len(ops) > 1 else set()
+        src_ops = ops[1:]
+        if op.startswith("v_pk_") and op.endswith("_f32"):
+            # a packed-f32 source is a register pair of which op_sel / op_sel_hi say which halves are read: [0, 0] = the low
+            # register twice (a scalar broadcast), [1, 1] = the high one twice
+            sel = re.search(r"op_sel:\[([01,]+)\]", rest)
+            hi = re.search(r"op_sel_hi:\[([01,]+)\]", rest)
+            sel = [int(v) for v in sel.group(1).split(",")] if sel else [0, 0, 0]
+            hi = [int(v) for v in hi.group(1).split(",")] if hi else [1, 1, 1]
+            src_ops = [re.sub(r"\s*op_sel.*$", "", o) for o in src_ops]
+            picked = []
+            for k, o in enumerate(src_ops[:3]):
+                m = re.match(r"^-?\|?v\[(\d+):(\d+)\]\|?$", o.strip())
+                if m and k < len(sel) and k < len(hi) and sel[k] == hi[k]:
+                    picked.append("v%d" % (int(m.group(1)) + sel[k]))
+                else:
+                    picked.append(o)
+            src_ops = picked
+        srcs = set().union(*[regs(o) for o in src_ops]) if src_ops else set()
         dst = regs(ops[0]) if ops else set()
     bad = sorted(r for r in srcs if r in st)
     if bad and report is not None:
