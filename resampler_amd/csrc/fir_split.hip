@@ -86,6 +86,7 @@ struct SplitArgs {
     uint32_t groups, per_group;      // more than ten class tiles (b > 160): tile groups of ten; items per slice (the launch's items = groups x quads x that)
     uint32_t quads, qpairs;          // channel counts of 8, 12, 16: the launch's items are quad-major (see Cursor); pairs per slice (2, or all)
     uint32_t wide;                   // frames of other than two channels (the WIDE instantiations)
+    uint32_t nowrap;                 // an exact ratio (super period: no output ever takes the wrap variant) on a WIDE build: its windows are not fetched
     const uint32_t* items;           // the launch's item table (split_items_kernel): kItemWords words per item
     unsigned long long* wtrace;   // RSMP_FIR_WTRACE: kWtraceSlots timestamped events per wave
     NfArgs nf;                    // non-finite sums are marked here (fir_nonfinite.h)
@@ -735,6 +736,9 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
                     wword[ps] = wnext[ps];
                     wsel[ps] = wnsel[ps];
                     fetch = wsel[ps] < 32 && ((wword[ps] >> wsel[ps]) & 1u);   // (lanes of the periods that take it)
+                } else if (g.nowrap) {   // (launch-uniform) an exact ratio: nothing to fetch, nothing taken
+                    fetch = false;
+                    wsel[ps] = 32u;
                 } else {   // every window, and the bitmap word with them
                     const int32_t nw = pi.it.n_block0 + static_cast<int32_t>(wper * g.b);
                     const bool in_launch = nw >= 0 && nw < static_cast<int32_t>(c.n_out);
@@ -758,7 +762,7 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
             };
             auto wrap_out = [&](const v2f (&w)[kWrapTaps], uint32_t wper, uint32_t take) {
                 v2f acc = v2f{0.f, 0.f};
-                if (!(dbg & 1024)) {
+                if (!(dbg & 1024) && !g.nowrap) {
 #pragma unroll
                     for (int i = 0; i < kWrapTaps; ++i) {
                         acc.x = fmaf(wcoef[i], w[i].x, acc.x);
@@ -1571,7 +1575,10 @@ hipError_t launch_fir_split(const FirStreamDesc* d_descs, uint32_t n_streams, co
     const uint32_t groups = geo.groups ? geo.groups : 1u, per_group = max_blocks * n_streams * qpairs;
     SplitArgs args{geo.a, geo.b, geo.taps, geo.n_tiles, geo.row_stride, geo.images, geo.lds_bytes, max_blocks, per_group * groups * quads,
                    debug, n_streams, fuse_tail ? 1u : 0u, geo.cg == 1 ? 1u : (geo.cg == 3 ? 2 * pairs - 1 : 2 * pairs), pairs,
-                   groups, per_group, quads, qpairs, wide ? 1u : 0u, nullptr, nullptr, nf};
+                   groups, per_group, quads, qpairs, wide ? 1u : 0u,
+                   // (b = r den with r > 1: a super period of an exact ratio.  WIDE builds only: the two-channel tile-group
+                   // kernel got SLOWER without the fetches -- 2 ch 48 -> 96 kHz 0.59 -> 0.66 ms)
+                   wide && geo.b != geo.den ? 1u : 0u, nullptr, nullptr, nf};
     static const char* wtrace_path = getenv("RSMP_FIR_WTRACE");
     const bool diag = debug != 0 || wtrace_path != nullptr;
 #define RSMP_SPLIT_FNS(P, D, W)                                                                              \
