@@ -712,7 +712,7 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
             // have landed when its windows are requested at the pass's end (load_wrap), lanes without a take switched off.
             // Two-round kernels only: where one round of lane tasks fills the item's time (the 147/160 pair, the tile-group
             // pairs) a vector load in flight across the conversion costs more than the windows' address work saves
-            // (measured in one lease: 8 ch 96 -> 44.1 kHz 0.95 -> 0.75 ms, 8 ch 48 -> 96 kHz 0.91 -> 0.69, 4 ch 96 -> 44.1
+            // (measured in one lease: 8 ch 96 -> 44.1 kHz 0.95 -> 0.75 ms, 4 ch 96 -> 44.1
             // 0.29 -> 0.25; the headline 0.286 -> 0.338, 2 ch 44.1 -> 96 kHz 0.64 -> 0.71).
             constexpr bool kWrapByTake = ROUNDS == 2;
             uint32_t wnext[kMaxPass], wnsel[kMaxPass];
