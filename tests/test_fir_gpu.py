@@ -123,6 +123,8 @@ def test_error_codes_match_reference():
     (4, 44100, 96000, ra.Attenuation.Db90),
     (2, 88200, 44100, ra.Attenuation.Db90),
     (2, 192000, 48000, ra.Attenuation.Db90),
+    (8, 48000, 96000, ra.Attenuation.Db90),    # channel pairs of an exact ratio: no wrap windows fetched
+    (6, 96000, 48000, ra.Attenuation.Db90),    # ... two rounds, windows by take (none)
     (4, 22050, 48000, ra.Attenuation.Db60),
     # more than two channels at 147/160: even counts up to 16 run the split matrix kernel as channel pairs, the
     # others the vector kernel
@@ -155,7 +157,7 @@ def test_bulk_matches_reference_driver_loop(kernel, ch, in_hz, out_hz, att):
         assert g.kernel_variant() == SPLIT_VARIANT
     # the other rate pairs of config 4 and config 5's: tile groups (up to 320 classes), two rounds of lane tasks (periods of
     # up to 320 frames), super periods of exact ratios (48 <-> 96 kHz)
-    if (kernel == ra.FirKernel.Periodic and (ch, in_hz, out_hz) in ((2, 96000, 44100), (8, 96000, 44100), (2, 44100, 96000), (4, 44100, 96000), (2, 48000, 96000), (2, 96000, 48000), (2, 88200, 44100), (2, 192000, 48000))
+    if (kernel == ra.FirKernel.Periodic and (ch, in_hz, out_hz) in ((2, 96000, 44100), (8, 96000, 44100), (2, 44100, 96000), (4, 44100, 96000), (2, 48000, 96000), (2, 96000, 48000), (2, 88200, 44100), (2, 192000, 48000), (8, 48000, 96000), (6, 96000, 48000))
             and os.environ.get("RSMP_FIR_MFMA", "3") == "3" and os.environ.get("RSMP_FIR_SPLIT_LONG", "1") != "0" and SPLIT_VARIANT == 5):
         assert g.kernel_variant() == SPLIT_VARIANT
     if kernel == ra.FirKernel.PeriodicVector:
