@@ -502,7 +502,10 @@ def bench_c4(ctx: Ctx, args, steps: int, warmup: int):
     assert all(c == h.buffer_size_output() for c, h in zip(caps, hs))
     ls = ra.FirLockstep(hs, frames) if hs else None
     feed = None
-    ring = 8                                        # chunks of input resident per stream, cycled
+    kk = max(1, args.c4_k)                          # calls per launch (rsmp_fir_lockstep_run)
+    if kk > 1 and args.feed == "rccl":
+        raise SystemExit("--c4-k > 1 runs on resident input (--feed resident)")
+    ring = max(8, kk)                               # chunks of input resident per stream, cycled
     if args.feed == "rccl":
         # a step's chunks arrive from GPU 0 and its outputs return there: the streams are bound straight
         # to their slices of the exchange buffers
@@ -520,7 +523,9 @@ def bench_c4(ctx: Ctx, args, steps: int, warmup: int):
         x = torch.from_numpy(synth.fast_noise(ring * frames * CHANNELS, seed=1 + ctx.rank)).to(ctx.dev)
         gains = torch.linspace(0.5, 1.0, max(1, len(mine)), device=ctx.dev)
         d_in = [(x * gains[i]).contiguous() for i in range(len(mine))]
-        d_out = [torch.empty(c, device=ctx.dev, dtype=torch.float32) for c in caps]
+        # (a run of kk calls appends their outputs: at most ceil(512 * out / in) + 1 frames per call)
+        d_out = [torch.empty(c + (kk - 1) * CHANNELS * (frames * s.out_hz // s.in_hz + 2), device=ctx.dev, dtype=torch.float32)
+                 for c, s in zip(caps, mine)]
         ring_frames = frames
     if ls:
         ls.bind_caps(d_in, d_out, caps)
@@ -529,24 +534,33 @@ def bench_c4(ctx: Ctx, args, steps: int, warmup: int):
     def step():
         if feed:
             feed.scatter(stage_in[k[0] % ring] if ctx.rank == 0 else None)
-        if ls:
+        if ls and kk > 1:    # kk calls per stream in one go, from the front of the resident input
+            ls.run(kk, frames, 0, append=False, stream=ctx.stream)
+        elif ls:
             ls.step(frames, (k[0] % ring) * ring_frames, append=False, stream=ctx.stream)
         if feed:
             feed.gather(stage_out)
         k[0] += 1
     step()
     spinup(ctx, step, args.spinup_seconds)
-    dt, host_dt = timed(ctx, step, steps, warmup)
+    launches, warm_launches = max(1, steps // kk), max(1, warmup // kk) if warmup else 0
+    steps = launches * kk
+    dt, host_dt = timed(ctx, step, launches, warm_launches)
     k_ms = 0.0
     out_values = 0
     if ls:
         ls.set_profiling(True)
-        for _ in range(32):
+        for _ in range(max(2, 32 // kk)):
             step()
         k_ms, _ = ls.mean_kernel_ms()
+        k_ms /= kk                         # per 512-frame step
         ls.set_profiling(False)
-        _, prod = ls.counts()
-        out_values = int(prod.sum())
+        if kk > 1:
+            _, prod = ls.run_counts()
+            out_values = int(prod.sum()) // kk
+        else:
+            _, prod = ls.counts()
+            out_values = int(prod.sum())
     k_ms = ctx.max_over_ranks(k_ms)
     out_values_all = ctx.sum_over_ranks(float(out_values))
     values_in = n * CHANNELS * frames
@@ -563,15 +577,18 @@ def bench_c4(ctx: Ctx, args, steps: int, warmup: int):
                   % (ls.workgroups() - ls.split_workgroups(), ls.workgroups()) if ls and ls.split_workgroups()
                   else "f32 (exact-f32 MFMA)"), "data": "synthetic",
         "config": {"workload": f"{n} ResamplerFir streams 2ch 128-tap (Sample64/Db90), pairs 44.1/48/96 kHz "
-                               f"(6 ordered), {frames}-frame lock-step steps on carried state, one launch per "
-                               f"step and GPU, streams partitioned by predicted work",
-                   "streams_this_rank": len(mine), "workgroups_this_rank": ls.workgroups() if ls else 0,
+                               f"(6 ordered), {frames}-frame lock-step steps on carried state, "
+                               + ("one launch per step and GPU" if kk == 1 else
+                                  f"{kk} steps per launch (rsmp_fir_lockstep_run: planned on the device, one bulk launch per rate pair)")
+                               + ", streams partitioned by predicted work",
+                   "steps_per_launch": kk, "streams_this_rank": len(mine), "workgroups_this_rank": ls.workgroups() if ls else 0,
                    "feed": ("rccl send/recv scatter-v + gather-v through GPU 0, inside the timed step"
                             + (" (world of one rank: GPU 0 sends to and receives from itself)" if ctx.world == 1 else ""))
                            if feed else "resident per GPU (no data-path collective)",
                    "host_enqueue_ms_per_step": round(host_dt / steps * 1e3, 5)},
-        "roofline": {"bound": "hbm", "kernel": "fir_lockstep_kernel (%s, row = stream)" %
-                               ("fp16x2 MFMA" if ls and ls.split_workgroups() else "exact-f32 MFMA"),
+        "roofline": {"bound": "hbm", "kernel": ("fir_lockstep_kernel (%s, row = stream)" %
+                               ("fp16x2 MFMA" if ls and ls.split_workgroups() else "exact-f32 MFMA")) if kk == 1 else
+                               "fir_lockstep_plan_kernel + fir_split_kernel per rate pair (whole run, per 512-frame step)",
                      "achieved": round(ach, 1), "peak": HBM_PEAK_GBS * ctx.world, "unit": "GB/s",
                      "frac": round(ach / (HBM_PEAK_GBS * ctx.world), 4), "traffic": traffic_from_profiles("c4"),
                      "kernel_ms": round(k_ms, 5), "algorithmic_bytes": int(alg)},
@@ -823,6 +840,7 @@ def main() -> int:
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--streams", type=int, default=64, help="streams per GPU (c2 / fft)")
     ap.add_argument("--c4-streams", type=int, default=1024, help="streams of the whole config-4 batch")
+    ap.add_argument("--c4-k", type=int, default=1, help="config 4: lock-step calls per launch (rsmp_fir_lockstep_run); 1 = one call per launch")
     ap.add_argument("--frames", type=int, default=1 << 20, help="input frames per stream per step")
     ap.add_argument("--c5-frames", type=int, default=57_600_000, help="input frames of the config-5 stream (10 min at 96 kHz)")
     ap.add_argument("--chunk", type=int, default=512, help="reference call size in f32 values")

@@ -186,9 +186,24 @@ int rsmp_fir_lockstep_bind(rsmp_fir_lockstep* ls, const float* const* d_in, floa
 int rsmp_fir_lockstep_step(rsmp_fir_lockstep* ls, size_t in_frames, size_t in_offset_frames,
                            const uint32_t* d_in_frames, int append, void* stream);
 int rsmp_fir_lockstep_counts(rsmp_fir_lockstep* ls, size_t* consumed, size_t* produced);
+/* k_steps consecutive steps in one go: per stream the reference's driver loop (resample/src/main.rs:226-254) over the
+ * k_steps * in_frames frames at d_in[i] + in_offset_frames, one resample() call (src/resampler_fir.rs:509-621) per
+ * in_frames frames -- the same calls, counts, samples and end state as k_steps calls of rsmp_fir_lockstep_step with
+ * `append` at offsets in_offset_frames + s * in_frames.  The calls are planned on the device (one lane per stream
+ * replays the reference's control flow for the k_steps calls) and computed by the bulk kernels, one launch per rate
+ * pair for the whole run, instead of k_steps launches of the one-call kernel.  The outputs of the calls follow each
+ * other in d_out[i]: behind what was appended before (append != 0), or from the front of the buffer (append == 0: the
+ * append position starts again there); the caller sizes d_out[i] for the run.  rsmp_fir_lockstep_counts returns the
+ * last call's counts, rsmp_fir_lockstep_run_counts all of them: consumed[s * n + i], produced[s * n + i] for call s
+ * of stream i (up to max_steps calls).  Batches with a rate pair no bulk kernel serves (irrational ratios) and runs
+ * of one call are executed as a loop of steps. */
+int rsmp_fir_lockstep_run(rsmp_fir_lockstep* ls, size_t k_steps, size_t in_frames, size_t in_offset_frames,
+                          int append, void* stream);
+int rsmp_fir_lockstep_run_counts(rsmp_fir_lockstep* ls, size_t* consumed, size_t* produced, size_t max_steps);
 /* Sticky per-stream flags: 1 = more position runs in one step than the kernel keeps (outputs of that step
  * undefined; never observed), 2 = a step saw non-finite samples and was evaluated in the reference's
- * two-row form, 4 = the f64 position drifted out of the class tables' tolerance (reference form from then on). */
+ * two-row form, 4 = the f64 position drifted out of the class tables' tolerance (reference form from then on),
+ * 8 = a call of a run accepted fewer frames than it was offered (cannot happen below 3960 frames per step). */
 int rsmp_fir_lockstep_status(rsmp_fir_lockstep* ls, uint32_t* status);
 int rsmp_fir_lockstep_sync(rsmp_fir_lockstep* ls);
 /* Measurement hooks, as rsmp_fir_set_profiling / rsmp_fir_mean_kernel_ms: HIP events on the launch stream

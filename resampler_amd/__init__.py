@@ -136,6 +136,8 @@ _SIGNATURES = [
     ("rsmp_fir_lockstep_bind", C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _szp]),
     ("rsmp_fir_lockstep_step", C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p]),
     ("rsmp_fir_lockstep_counts", C.c_int, [C.c_void_p, _szp, _szp]),
+    ("rsmp_fir_lockstep_run", C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p]),
+    ("rsmp_fir_lockstep_run_counts", C.c_int, [C.c_void_p, _szp, _szp, C.c_size_t]),
     ("rsmp_fir_lockstep_status", C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
     ("rsmp_fir_lockstep_split_workgroups", C.c_size_t, [C.c_void_p]),
     ("rsmp_fir_lockstep_sync", C.c_int, [C.c_void_p]),
@@ -511,6 +513,22 @@ class FirLockstep:
             ptr = C.c_void_p(d_in_frames.data_ptr())
         _check(lib().rsmp_fir_lockstep_step(self._h, in_frames, in_offset_frames, ptr, 1 if append else 0,
                                             C.c_void_p(stream or 0)))
+
+    def run(self, k_steps: int, in_frames: int, in_offset_frames: int = 0, append: bool = True,
+            stream: Optional[int] = None) -> None:
+        """k_steps consecutive steps in one go (rsmp_fir_lockstep_run): planned on the device, computed by the bulk
+        kernels; the calls' outputs follow each other in the output buffers."""
+        _check(lib().rsmp_fir_lockstep_run(self._h, k_steps, in_frames, in_offset_frames, 1 if append else 0,
+                                           C.c_void_p(stream or 0)))
+        self._last_run = k_steps
+
+    def run_counts(self):
+        """(consumed, produced) of every call of the last run: two int64 arrays [k_steps][streams], in f32 values."""
+        k, n = self._last_run, len(self.resamplers)
+        cons, prod = (C.c_size_t * (k * n))(), (C.c_size_t * (k * n))()
+        _check(lib().rsmp_fir_lockstep_run_counts(self._h, cons, prod, k))
+        return (np.ctypeslib.as_array(cons).astype(np.int64).reshape(k, n),
+                np.ctypeslib.as_array(prod).astype(np.int64).reshape(k, n))
 
     def counts(self):
         """(consumed, produced) of the last step per stream, in f32 values (waits for the step)."""

@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "fir_mirror_core.h"
+#include "fir_kernels.h"
 #include "fir_periodic.h"
 
 namespace rsmp {
@@ -89,6 +90,7 @@ struct LockstepArgs {
     char* recs;                           // [2][n_streams] records of rec_stride bytes (parity = step & 1)
     uint32_t rec_stride, n_streams;
     uint32_t epoch, step;
+    uint32_t hist_parity;                 // 0: this step reads `hist` and leaves its tail in `hist_alt`; 1: the other way round
 };
 
 struct LsPlanHeader {          // head of a plan record; followed by kLsSegCap runs (24 B each), then the wrap list
@@ -106,6 +108,7 @@ inline uint32_t lockstep_rec_stride(uint32_t wrap_cap) { return (kLsRecWraps + 4
 constexpr uint32_t kLsStatusRunOverflow = 1;   // more than kLsSegCap position runs in one step
 constexpr uint32_t kLsStatusNonFinite = 2;     // a step saw non-finite samples (reference-form path taken)
 constexpr uint32_t kLsStatusAperiodic = 4;     // the f64 drift left the class tables' tolerance
+constexpr uint32_t kLsStatusPartialAccept = 8; // rsmp_fir_lockstep_run: a call accepted fewer frames than it was offered
 
 // Geometry of one (rate pair, taps, channels, step size) combination.
 struct LockstepGeometry {
@@ -130,5 +133,32 @@ constexpr uint32_t kLsLdsPerWorkgroup = 80 * 1024 - 512;   // two workgroups per
 
 hipError_t launch_fir_lockstep(const LockstepArgs& args, uint32_t n_groups, uint32_t max_lds_bytes,
                                hipStream_t stream);
+
+// ---- rsmp_fir_lockstep_run: k calls per stream, planned on the device, computed by the bulk kernels ------------
+struct LsRunStream {           // per stream (internal order), constant for the batch
+    uint32_t wrap_unit;        // the bitmap of wrapped outputs starts at output (abs_out / wrap_unit) * wrap_unit: the bulk
+                               // geometry's b (= den unless a super period of an exact ratio, whose outputs never wrap)
+    uint32_t den, channels;
+    uint32_t caller;           // the stream's index in the caller's order
+};
+struct LsRunArgs {
+    const LockstepStream* streams;
+    const LsRunStream* rs;
+    const uint32_t* waves;     // [n_waves][2]: first stream and stream count of a planner wave (one rate pair per wave)
+    const FirMirrorState* states_in;
+    FirMirrorState* states_out;
+    const uint64_t* cursor_in;
+    uint64_t* cursor_out;
+    FirStreamDesc* descs;      // [n]: the run's descriptors (the constant fields are the host's)
+    uint32_t* wrap_bits;       // [n][wrap_words]
+    uint32_t* counts;          // [k][n][2] in the caller's order: (consumed, produced) per call in f32 values
+    uint64_t* last_counts;     // [n][2], internal order: the last call's (rsmp_fir_lockstep_counts)
+    uint32_t* status;
+    uint64_t in_offset;        // frames added to every stream's `in`
+    uint32_t n_streams, k, in_frames, wrap_words, append, hist_parity;
+};
+hipError_t launch_fir_lockstep_plan(const LsRunArgs& args, uint32_t n_waves, hipStream_t stream);
+hipError_t launch_fir_lockstep_gather_counts(const uint64_t* last_counts, const LsRunStream* rs, uint32_t* counts, uint32_t n,
+                                             hipStream_t stream);
 
 }  // namespace rsmp

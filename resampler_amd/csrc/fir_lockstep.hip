@@ -536,7 +536,7 @@ __global__ __launch_bounds__(kLsWaves * 64, kLsWaves / 2) void fir_lockstep_kern
             const uint32_t h_hist = hd->hist_frames, h_acc = hd->accepted, h_flags = hd->flags;
             const uint64_t h_abs_out = hd->abs_out, h_abs_consumed = hd->abs_consumed;
             const LockstepStream& ls = args.streams[gs];
-            f_hist = reinterpret_cast<uint64_t>((args.step & 1u) ? ls.hist_alt : ls.hist);
+            f_hist = reinterpret_cast<uint64_t>((args.hist_parity != 0) ? ls.hist_alt : ls.hist);
             f_in = reinterpret_cast<uint64_t>(ls.in + args.in_offset * C);
             valid = h_epoch == args.epoch && h_step == args.step && h_in == args.in_frames;
             if (valid && h_n_out != 0 && !(h_flags & kFlagReference)) {
@@ -641,8 +641,8 @@ __global__ __launch_bounds__(kLsWaves * 64, kLsWaves / 2) void fir_lockstep_kern
             pl.out = ls.out + cursor;
             plan[lane] = pl;
             stash[lane] = st;
-            ptrs[lane] = SlotPtrs{(args.step & 1u) ? ls.hist_alt : ls.hist, ls.in + args.in_offset * C,
-                                  (args.step & 1u) ? ls.hist : ls.hist_alt, 0};
+            ptrs[lane] = SlotPtrs{(args.hist_parity != 0) ? ls.hist_alt : ls.hist, ls.in + args.in_offset * C,
+                                  (args.hist_parity != 0) ? ls.hist : ls.hist_alt, 0};
             args.counts[2 * gs] = static_cast<uint64_t>(pl.accepted) * C;
             args.counts[2 * gs + 1] = static_cast<uint64_t>(pl.n_out) * C;
         }
@@ -715,7 +715,7 @@ __global__ __launch_bounds__(kLsWaves * 64, kLsWaves / 2) void fir_lockstep_kern
             if (acc > kMirrorInputCapacity - avail) acc = kMirrorInputCapacity - avail;
             my_hist_dw = static_cast<uint32_t>(avail) * C;
             my_span_dw = my_hist_dw + static_cast<uint32_t>(acc) * C;
-            my_hist = reinterpret_cast<unsigned long long>((args.step & 1u) ? args.streams[gs].hist_alt : args.streams[gs].hist);
+            my_hist = reinterpret_cast<unsigned long long>((args.hist_parity != 0) ? args.streams[gs].hist_alt : args.streams[gs].hist);
             my_in = reinterpret_cast<unsigned long long>(args.streams[gs].in + args.in_offset * C);
         }
         const uint32_t guard_dw = g.guard_frames * C;

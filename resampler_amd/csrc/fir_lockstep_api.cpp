@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -40,6 +41,17 @@ struct rsmp_fir_lockstep {
     hipStream_t own_stream = nullptr;
     std::vector<uint64_t> h_counts;
     std::vector<FirMirrorState> h_states;
+    uint32_t hist_parity = 0;   // 0: the next step / run reads `hist` of LockstepStream and leaves its tail in `hist_alt`
+    // rsmp_fir_lockstep_run (k calls per stream and launch): the bulk kernels' geometry per rate pair, the run's
+    // descriptors and what the device-side planner leaves for them (fir_lockstep_run.hip)
+    struct RunGroup { rsmp::PeriodicGeometry geo; size_t first = 0, count = 0; uint32_t max_out_step = 0; };
+    int run_state = 0;          // 0: not looked at yet, 1: every rate pair has a bulk kernel, -1: runs are loops of steps
+    std::vector<RunGroup> run_groups;
+    std::vector<uint32_t> run_waves;
+    DeviceBuffer d_run_descs, d_run_rs, d_run_waves, d_run_bits, d_run_counts, d_run_nf, d_run_work;
+    uint32_t run_wrap_words = 0, run_k = 0, run_nf_tag = 0;
+    size_t run_counts_k = 0;    // calls of the most recent run whose counts are in d_run_counts (0: it was a loop of steps)
+    std::vector<uint32_t> h_run_counts;
     // optional timing of the step launches (rsmp_fir_lockstep_set_profiling): ring of event pairs
     static constexpr int kProfRing = 64;
     bool profiling = false;
@@ -56,7 +68,7 @@ void refresh_history_index(rsmp_fir_lockstep* ls) {
     if (!ls->bound) return;
     for (size_t k = 0; k < ls->rs.size(); ++k) {
         rsmp_fir* r = ls->rs[ls->order[k]];
-        const float* live = (ls->step & 1u) ? ls->streams[k].hist_alt : ls->streams[k].hist;
+        const float* live = ls->hist_parity ? ls->streams[k].hist_alt : ls->streams[k].hist;
         r->cur = live == r->d_hist[0] ? 0 : 1;
     }
 }
@@ -274,8 +286,8 @@ extern "C" int rsmp_fir_lockstep_bind(rsmp_fir_lockstep* ls, const float* const*
         if (reinterpret_cast<uintptr_t>(d_in[i]) % 8 != 0) aligned8 = false;
         s.in = d_in[i];
         s.out = d_out[i];
-        s.hist = r->d_hist[(ls->step & 1u) ? r->cur ^ 1 : r->cur];       // the next step reads the handle's current buffer
-        s.hist_alt = r->d_hist[(ls->step & 1u) ? r->cur : r->cur ^ 1];
+        s.hist = r->d_hist[ls->hist_parity ? r->cur ^ 1 : r->cur];       // the next step reads the handle's current buffer
+        s.hist_alt = r->d_hist[ls->hist_parity ? r->cur : r->cur ^ 1];
         s.coeffs = r->d_coeffs;
         s.out_cap_frames = out_caps[i] / r->channels;
     }
@@ -323,6 +335,9 @@ extern "C" int rsmp_fir_lockstep_step(rsmp_fir_lockstep* ls, size_t in_frames, s
     a.n_streams = static_cast<uint32_t>(ls->rs.size());
     a.epoch = ls->epoch;
     a.step = ls->step++;
+    a.hist_parity = ls->hist_parity;
+    ls->hist_parity ^= 1u;
+    ls->run_counts_k = 0;
     if (ls->profiling)
         RSMP_HIP_CHECK(hipEventRecord(ls->prof_start[ls->prof_count % rsmp_fir_lockstep::kProfRing], s));
     RSMP_HIP_CHECK(rsmp::launch_fir_lockstep(a, static_cast<uint32_t>(ls->groups.size()), ls->max_lds, s));
@@ -415,5 +430,226 @@ extern "C" int rsmp_fir_lockstep_mean_kernel_ms(rsmp_fir_lockstep* ls, float* ms
     }
     *ms = static_cast<float>(sum / static_cast<double>(n));
     if (launches) *launches = n;
+    return RSMP_OK;
+}
+
+// ---- rsmp_fir_lockstep_run: k consecutive calls per stream in one go -----------------------------------------
+namespace {
+
+// The bulk kernels' side of a batch: one geometry + class table per rate pair, the constant half of every
+// stream's descriptor, the planner's waves.  Done once, at the first run.
+int prepare_run(rsmp_fir_lockstep* ls) {
+    if (ls->run_state != 0) return RSMP_OK;
+    const size_t n = ls->rs.size();
+    std::vector<rsmp::FirStreamDesc> descs(n);
+    std::vector<rsmp::LsRunStream> rstreams(n);
+    std::memset(descs.data(), 0, n * sizeof(rsmp::FirStreamDesc));
+    ls->run_groups.clear();
+    ls->run_waves.clear();
+    auto same = [&](const rsmp_fir* x, const rsmp_fir* y) {
+        return x->table.get() == y->table.get() && x->in_hz == y->in_hz && x->out_hz == y->out_hz &&
+               x->channels == y->channels && x->taps == y->taps && x->kernel_mode == y->kernel_mode;
+    };
+    size_t k = 0;
+    while (k < n) {
+        const rsmp_fir* r0 = ls->rs[ls->order[k]];
+        size_t e = k;
+        while (e < n && same(ls->rs[ls->order[e]], r0)) ++e;
+        const int mode = r0->kernel_mode;
+        rsmp::PeriodicGeometry geo;
+        if (mode != RSMP_FIR_KERNEL_GENERIC && r0->mirror.periodic_ok())
+            geo = rsmp::periodic_geometry(r0->mirror.num(), r0->mirror.den(), static_cast<uint32_t>(r0->taps),
+                                          static_cast<uint32_t>(r0->channels), mode != RSMP_FIR_KERNEL_PERIODIC_VECTOR,
+                                          mode != RSMP_FIR_KERNEL_PERIODIC_F32);
+        const uint64_t den = r0->mirror.den();
+        // (a geometry without the wrap variant in the kernel wants a list of wrapped outputs, which the device
+        // planner does not keep -- unless the ratio is exact in f64 and no output ever wraps)
+        if (!geo.ok || (!geo.inline_wraps && (den & (den - 1)) != 0)) {
+            // runs are loops of steps; their per-call counts are gathered with the streams' caller indices
+            for (size_t i = 0; i < n; ++i) rstreams[i].caller = ls->order[i];
+            if (ls->d_run_rs.reserve(n * sizeof(rsmp::LsRunStream)) != hipSuccess)
+                return rsmp::fail(RSMP_ERR_HIP, "lock-step run: cannot allocate device state");
+            RSMP_HIP_CHECK(hipMemcpy(ls->d_run_rs.get(), rstreams.data(), n * sizeof(rsmp::LsRunStream), hipMemcpyHostToDevice));
+            ls->run_state = -1;
+            return RSMP_OK;
+        }
+        rsmp::ClassTable ct;
+        if (rsmp::class_table_for(ls->device, *r0->table, geo, 0.0, &ct) != RSMP_OK) return RSMP_ERR_HIP;
+        rsmp_fir_lockstep::RunGroup g;
+        g.geo = geo;
+        g.first = k;
+        g.count = e - k;
+        g.max_out_step = static_cast<uint32_t>(std::ceil(static_cast<double>(ls->step_frames + 8) / r0->mirror.ratio())) + 2;
+        ls->run_groups.push_back(g);
+        for (size_t i = k; i < e; ++i) {
+            const rsmp_fir* r = ls->rs[ls->order[i]];
+            rsmp::FirStreamDesc& d = descs[i];
+            d.coeffs = r->d_coeffs;
+            d.class_coef = ct.d_coef;
+            d.class_wrap_coef = ct.d_wrap_coef;
+            d.class_meta = ct.d_meta;
+            d.channels = static_cast<uint32_t>(r->channels);
+            d.taps = static_cast<uint32_t>(r->taps);
+            d.num = static_cast<uint32_t>(r->mirror.num());
+            d.den = static_cast<uint32_t>(den);
+            d.drift = 0.0;
+            rstreams[i].wrap_unit = geo.mfma == 3 ? geo.b : geo.den;
+            rstreams[i].den = static_cast<uint32_t>(den);
+            rstreams[i].channels = static_cast<uint32_t>(r->channels);
+            rstreams[i].caller = ls->order[i];
+        }
+        for (size_t first = k; first < e; first += 64) {   // a planner wave: up to 64 streams of one rate pair
+            ls->run_waves.push_back(static_cast<uint32_t>(first));
+            ls->run_waves.push_back(static_cast<uint32_t>(std::min<size_t>(64, e - first)));
+        }
+        k = e;
+    }
+    if (ls->d_run_descs.reserve(n * sizeof(rsmp::FirStreamDesc)) != hipSuccess ||
+        ls->d_run_rs.reserve(n * sizeof(rsmp::LsRunStream)) != hipSuccess ||
+        ls->d_run_waves.reserve(ls->run_waves.size() * sizeof(uint32_t)) != hipSuccess ||
+        ls->d_run_work.reserve(sizeof(unsigned long long)) != hipSuccess)
+        return rsmp::fail(RSMP_ERR_HIP, "lock-step run: cannot allocate device state");
+    RSMP_HIP_CHECK(hipMemcpy(ls->d_run_descs.get(), descs.data(), n * sizeof(rsmp::FirStreamDesc), hipMemcpyHostToDevice));
+    RSMP_HIP_CHECK(hipMemcpy(ls->d_run_rs.get(), rstreams.data(), n * sizeof(rsmp::LsRunStream), hipMemcpyHostToDevice));
+    RSMP_HIP_CHECK(hipMemcpy(ls->d_run_waves.get(), ls->run_waves.data(), ls->run_waves.size() * sizeof(uint32_t),
+                             hipMemcpyHostToDevice));
+    RSMP_HIP_CHECK(hipMemset(ls->d_run_work.get(), 0, sizeof(unsigned long long)));
+    ls->run_state = 1;
+    return RSMP_OK;
+}
+
+}  // namespace
+
+extern "C" int rsmp_fir_lockstep_run(rsmp_fir_lockstep* ls, size_t k_steps, size_t in_frames, size_t in_offset_frames,
+                                     int append, void* stream) {
+    if (!ls || !ls->bound)
+        return rsmp::fail(RSMP_ERR_INVALID_ARGUMENT, "rsmp_fir_lockstep_run: bind buffers first");
+    if (k_steps == 0) return RSMP_OK;
+    if (in_frames > ls->step_frames)
+        return rsmp::fail(RSMP_ERR_INVALID_INPUT_BUFFER_SIZE,
+                          "lock-step batch: %zu frames offered, created for %u per step", in_frames, ls->step_frames);
+    DeviceGuard guard(ls->device);
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : ls->own_stream;
+    if (int rc = prepare_run(ls)) return rc;
+    // A run is defined as k steps.  The bulk kernels read a stream's accepted frames as ONE span of its input, which
+    // they are as long as every call accepts all it is offered (resampler_fir.rs:524-528: always, unless the step is
+    // nearly as long as the reference's 4096-frame input buffer).
+    size_t max_taps = 0;
+    for (const rsmp_fir* r : ls->rs) max_taps = std::max(max_taps, r->taps);
+    const bool whole_accept = in_frames + max_taps + 8 <= rsmp::kMirrorInputCapacity;
+    // The outputs of a run's calls follow each other in `out`: behind what earlier steps / runs appended, or -- without
+    // `append` -- from the front of the buffer (the append position starts again there).
+    if (!append) RSMP_HIP_CHECK(hipMemsetAsync(ls->d_cursor.get(), 0, ls->rs.size() * sizeof(uint64_t), s));
+    const size_t n = ls->rs.size();
+    if (k_steps > (1u << 20)) return rsmp::fail(RSMP_ERR_INVALID_ARGUMENT, "rsmp_fir_lockstep_run: at most 2^20 calls per run");
+    const uint32_t k = static_cast<uint32_t>(k_steps);
+    if (k > ls->run_k) {
+        RSMP_HIP_CHECK(hipStreamSynchronize(s));
+        if (ls->d_run_counts.reserve(2 * n * static_cast<size_t>(k) * sizeof(uint32_t)) != hipSuccess)
+            return rsmp::fail(RSMP_ERR_HIP, "lock-step run: cannot allocate the counts of %u calls", k);
+        ls->run_k = k;
+    }
+    if (ls->run_state < 0 || k == 1 || !whole_accept || k * static_cast<uint64_t>(ls->step_frames) > (1u << 27)) {
+        for (uint32_t i = 0; i < k; ++i) {
+            if (int rc = rsmp_fir_lockstep_step(ls, in_frames, in_offset_frames + static_cast<size_t>(i) * in_frames, nullptr, 1, stream))
+                return rc;
+            RSMP_HIP_CHECK(rsmp::launch_fir_lockstep_gather_counts(ls->d_counts.as<uint64_t>(), ls->d_run_rs.as<rsmp::LsRunStream>(),
+                                                                   ls->d_run_counts.as<uint32_t>() + 2 * n * static_cast<size_t>(i),
+                                                                   static_cast<uint32_t>(n), s));
+        }
+        ls->run_counts_k = k;
+        return RSMP_OK;
+    }
+    if (ls->last_stream && ls->last_stream != s) RSMP_HIP_CHECK(hipStreamSynchronize(ls->last_stream));
+    // workspaces that grow with k: the per-call counts, the bitmaps of wrapped outputs, the non-finite marks
+    uint32_t wrap_words = 1, nf_words = 0;
+    for (const auto& g : ls->run_groups) {
+        const uint64_t n_out_max = static_cast<uint64_t>(k) * g.max_out_step;
+        wrap_words = std::max<uint32_t>(wrap_words, static_cast<uint32_t>(n_out_max / g.geo.den / 32 + 2));
+        nf_words += 1 + static_cast<uint32_t>((g.count * ((n_out_max >> rsmp::kNfChunkShift) + 1) + 31) / 32);
+    }
+    if (wrap_words > ls->run_wrap_words) {
+        RSMP_HIP_CHECK(hipStreamSynchronize(s));
+        if (ls->d_run_bits.reserve(n * static_cast<size_t>(wrap_words) * sizeof(uint32_t)) != hipSuccess)
+            return rsmp::fail(RSMP_ERR_HIP, "lock-step run: cannot allocate the plan of %u calls", k);
+        ls->run_wrap_words = wrap_words;
+    }
+    if (nf_words * sizeof(uint32_t) > ls->d_run_nf.capacity()) {
+        RSMP_HIP_CHECK(hipStreamSynchronize(s));
+        RSMP_HIP_CHECK(ls->d_run_nf.reserve(nf_words * sizeof(uint32_t)));
+        RSMP_HIP_CHECK(hipMemsetAsync(ls->d_run_nf.get(), 0, ls->d_run_nf.capacity(), s));
+    }
+    rsmp::LsRunArgs a;
+    a.streams = ls->d_streams.as<LockstepStream>();
+    a.rs = ls->d_run_rs.as<rsmp::LsRunStream>();
+    a.waves = ls->d_run_waves.as<uint32_t>();
+    a.states_in = ls->d_states.as<FirMirrorState>();
+    a.states_out = ls->d_states.as<FirMirrorState>();
+    a.cursor_in = ls->d_cursor.as<uint64_t>();
+    a.cursor_out = ls->d_cursor.as<uint64_t>();
+    a.descs = ls->d_run_descs.as<rsmp::FirStreamDesc>();
+    a.wrap_bits = ls->d_run_bits.as<uint32_t>();
+    a.counts = ls->d_run_counts.as<uint32_t>();
+    a.last_counts = ls->d_counts.as<uint64_t>();
+    a.status = ls->d_status.as<uint32_t>();
+    a.in_offset = in_offset_frames;
+    a.n_streams = static_cast<uint32_t>(n);
+    a.k = k;
+    a.in_frames = static_cast<uint32_t>(in_frames);
+    a.wrap_words = ls->run_wrap_words;
+    a.append = 1u;
+    a.hist_parity = ls->hist_parity;
+    if (ls->profiling)
+        RSMP_HIP_CHECK(hipEventRecord(ls->prof_start[ls->prof_count % rsmp_fir_lockstep::kProfRing], s));
+    RSMP_HIP_CHECK(rsmp::launch_fir_lockstep_plan(a, static_cast<uint32_t>(ls->run_waves.size() / 2), s));
+    const rsmp::FirStreamDesc* d_descs = ls->d_run_descs.as<rsmp::FirStreamDesc>();
+    struct Repair { size_t first; uint32_t count; rsmp::NfArgs nf; };
+    std::vector<Repair> repairs;
+    uint32_t nf_off = 0, max_tail_values = 0;
+    for (const auto& g : ls->run_groups) {
+        const uint64_t n_out_max = static_cast<uint64_t>(k) * g.max_out_step;
+        const uint32_t max_blocks = static_cast<uint32_t>((n_out_max / g.geo.b + 1) / g.geo.pw + 1);
+        Repair rp;
+        rp.first = g.first;
+        rp.count = static_cast<uint32_t>(g.count);
+        rp.nf.chunks = static_cast<uint32_t>(n_out_max >> rsmp::kNfChunkShift) + 1;
+        rp.nf.words = ls->d_run_nf.as<uint32_t>() + nf_off;
+        if (++ls->run_nf_tag == 0) ls->run_nf_tag = 1;
+        rp.nf.tag = ls->run_nf_tag;
+        nf_off += 1 + static_cast<uint32_t>((g.count * static_cast<uint64_t>(rp.nf.chunks) + 31) / 32);
+        repairs.push_back(rp);
+        RSMP_HIP_CHECK(rsmp::launch_fir_periodic(d_descs + g.first, rp.count, g.geo, max_blocks,
+                                                 ls->d_run_work.as<unsigned long long>(), rp.nf, s, false));
+        const rsmp_fir* r0 = ls->rs[ls->order[g.first]];
+        max_tail_values = std::max<uint32_t>(max_tail_values, static_cast<uint32_t>((r0->taps + 8) * r0->channels));
+    }
+    for (const Repair& rp : repairs)
+        RSMP_HIP_CHECK(rsmp::launch_fir_repair(d_descs + rp.first, rp.count, rp.nf, s));
+    RSMP_HIP_CHECK(rsmp::launch_fir_tail_copy(d_descs, static_cast<uint32_t>(n), max_tail_values, s));
+    if (ls->profiling) {
+        RSMP_HIP_CHECK(hipEventRecord(ls->prof_stop[ls->prof_count % rsmp_fir_lockstep::kProfRing], s));
+        ++ls->prof_count;
+    }
+    ls->hist_parity ^= 1u;
+    ls->step += k;
+    ++ls->epoch;   // plans the one-call kernel made ahead belong to the states before the run
+    ls->run_counts_k = k;
+    ls->last_stream = s;
+    return RSMP_OK;
+}
+
+extern "C" int rsmp_fir_lockstep_run_counts(rsmp_fir_lockstep* ls, size_t* consumed, size_t* produced, size_t max_steps) {
+    if (!ls) return rsmp::fail(RSMP_ERR_INVALID_ARGUMENT, "rsmp_fir_lockstep_run_counts: null batch");
+    if (ls->run_counts_k == 0)
+        return rsmp::fail(RSMP_ERR_INVALID_ARGUMENT, "rsmp_fir_lockstep_run_counts: the last launch was not a run of several calls");
+    DeviceGuard guard(ls->device);
+    const size_t n = ls->rs.size(), k = std::min(ls->run_counts_k, max_steps);
+    if (ls->last_stream) RSMP_HIP_CHECK(hipStreamSynchronize(ls->last_stream));
+    ls->h_run_counts.resize(2 * n * k);
+    RSMP_HIP_CHECK(hipMemcpy(ls->h_run_counts.data(), ls->d_run_counts.get(), 2 * n * k * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n * k; ++i) {
+        if (consumed) consumed[i] = ls->h_run_counts[2 * i];
+        if (produced) produced[i] = ls->h_run_counts[2 * i + 1];
+    }
     return RSMP_OK;
 }
