@@ -200,10 +200,15 @@ int rsmp_fir_lockstep_counts(rsmp_fir_lockstep* ls, size_t* consumed, size_t* pr
 int rsmp_fir_lockstep_run(rsmp_fir_lockstep* ls, size_t k_steps, size_t in_frames, size_t in_offset_frames,
                           int append, void* stream);
 int rsmp_fir_lockstep_run_counts(rsmp_fir_lockstep* ls, size_t* consumed, size_t* produced, size_t max_steps);
+/* Diagnostic: calls of the last run (all streams) that the device planner's fast path declined and the plain state
+ * machine did (fir_mirror_fast.h); 0 for a run executed as a loop of steps. */
+int rsmp_fir_lockstep_run_slow_calls(rsmp_fir_lockstep* ls, size_t* slow_calls);
 /* Sticky per-stream flags: 1 = more position runs in one step than the kernel keeps (outputs of that step
  * undefined; never observed), 2 = a step saw non-finite samples and was evaluated in the reference's
  * two-row form, 4 = the f64 position drifted out of the class tables' tolerance (reference form from then on),
- * 8 = a call of a run accepted fewer frames than it was offered (cannot happen below 3960 frames per step). */
+ * 8 = a call of a run accepted fewer frames than it was offered (cannot happen below 3960 frames per step),
+ * 16 = rsmp_fir_lockstep_run's planner found, replaying a call, a premise of its closed form violated (a drift of the f64
+ * position beyond 1 / out_hz; never observed: the run's counts are then not the reference's). */
 int rsmp_fir_lockstep_status(rsmp_fir_lockstep* ls, uint32_t* status);
 int rsmp_fir_lockstep_sync(rsmp_fir_lockstep* ls);
 /* Measurement hooks, as rsmp_fir_set_profiling / rsmp_fir_mean_kernel_ms: HIP events on the launch stream
@@ -248,6 +253,14 @@ rsmp_fir_plan* rsmp_fir_plan_clone(const rsmp_fir_plan* p);
  * (0 = no limit).  Totals in frames.  What rsmp_fir_resample_bulk would do to a stream in this state. */
 int rsmp_fir_plan_bulk(rsmp_fir_plan* p, size_t in_frames, size_t chunk_frames, size_t max_calls,
                        size_t* frames_accepted, size_t* frames_produced, size_t* n_calls);
+/* Diagnostic: the device planner's arithmetic for runs of equal calls (rsmp_fir_lockstep_run; fir_mirror_fast.h:
+ * structure predicted in exact integer arithmetic, the f64 chain verified against it) run on the host next to the
+ * plain state machine for `calls` calls of in_frames frames, predicted in runs of run_len calls; compares counts,
+ * every bit of the state and the outputs at integer positions call by call.  *mismatches must come back 0;
+ * *slow_calls = calls the fast path declined (done by the plain state machine), *lean_calls = calls that were also done
+ * by the unchecked chain the device takes where the prediction has no tie.  The plan advances by the calls. */
+int rsmp_fir_plan_selftest_fast(rsmp_fir_plan* p, size_t in_frames, size_t calls, size_t run_len,
+                                size_t* mismatches, size_t* slow_calls, size_t* lean_calls);
 /* Starts a resampler in the middle of a stream: the handle takes the plan's state (same rate pair and
  * latency) and, as its buffered frames, the last available_frames * channels values of `history` -- the
  * input that precedes the point (host or device memory).  A stream cut at call boundaries found with

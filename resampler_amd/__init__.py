@@ -138,6 +138,7 @@ _SIGNATURES = [
     ("rsmp_fir_lockstep_counts", C.c_int, [C.c_void_p, _szp, _szp]),
     ("rsmp_fir_lockstep_run", C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p]),
     ("rsmp_fir_lockstep_run_counts", C.c_int, [C.c_void_p, _szp, _szp, C.c_size_t]),
+    ("rsmp_fir_lockstep_run_slow_calls", C.c_int, [C.c_void_p, _szp]),
     ("rsmp_fir_lockstep_status", C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
     ("rsmp_fir_lockstep_split_workgroups", C.c_size_t, [C.c_void_p]),
     ("rsmp_fir_lockstep_sync", C.c_int, [C.c_void_p]),
@@ -154,6 +155,7 @@ _SIGNATURES = [
      [C.c_void_p, C.c_size_t, C.c_size_t, _szp, _szp, C.POINTER(_Segment), C.c_size_t, _szp]),
     ("rsmp_fir_plan_clone", C.c_void_p, [C.c_void_p]),
     ("rsmp_fir_plan_bulk", C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, _szp, _szp, _szp]),
+    ("rsmp_fir_plan_selftest_fast", C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, _szp, _szp, _szp]),
     ("rsmp_fir_seek", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
     ("rsmp_interp_output_len", C.c_size_t, [C.c_size_t, C.c_uint32, C.c_uint32, C.c_size_t]),
     ("rsmp_interp_resample", C.c_int,
@@ -529,6 +531,12 @@ class FirLockstep:
         _check(lib().rsmp_fir_lockstep_run_counts(self._h, cons, prod, k))
         return (np.ctypeslib.as_array(cons).astype(np.int64).reshape(k, n),
                 np.ctypeslib.as_array(prod).astype(np.int64).reshape(k, n))
+
+    def run_slow_calls(self) -> int:
+        """Calls of the last run that the device planner's fast path declined (diagnostic)."""
+        v = C.c_size_t()
+        _check(lib().rsmp_fir_lockstep_run_slow_calls(self._h, C.byref(v)))
+        return v.value
 
     def counts(self):
         """(consumed, produced) of the last step per stream, in f32 values (waits for the step)."""

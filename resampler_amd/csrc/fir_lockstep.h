@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "fir_mirror_core.h"
+#include "fir_mirror_fast.h"
 #include "fir_kernels.h"
 #include "fir_periodic.h"
 
@@ -109,6 +110,7 @@ constexpr uint32_t kLsStatusRunOverflow = 1;   // more than kLsSegCap position r
 constexpr uint32_t kLsStatusNonFinite = 2;     // a step saw non-finite samples (reference-form path taken)
 constexpr uint32_t kLsStatusAperiodic = 4;     // the f64 drift left the class tables' tolerance
 constexpr uint32_t kLsStatusPartialAccept = 8; // rsmp_fir_lockstep_run: a call accepted fewer frames than it was offered
+constexpr uint32_t kLsStatusPlannerCheck = 16; // rsmp_fir_lockstep_run: the replay of a call found a premise of the planner's closed form violated (never observed)
 
 // Geometry of one (rate pair, taps, channels, step size) combination.
 struct LockstepGeometry {
@@ -144,9 +146,13 @@ struct LsRunStream {           // per stream (internal order), constant for the 
 struct LsRunArgs {
     const LockstepStream* streams;
     const LsRunStream* rs;
-    const uint32_t* waves;     // [n_waves][2]: first stream and stream count of a planner wave (one rate pair per wave)
     const FirMirrorState* states_in;
     FirMirrorState* states_out;
+    FirMirrorState* states_before;   // [n]: copy of the states the run started from
+    MirrorPred* preds;         // [n][k]: the predicted structure of every call (fir_mirror_fast.h)
+    void* call_recs;           // [n][k] x 24 bytes: what the chain leaves per call for the replay
+    double* drift_cells;       // [n][ceil(k / 64)]: the replay's drift per chunk of calls
+    uint32_t* drift_last;      // [n]: 1 + the latest chunk that left one (zero between runs)
     const uint64_t* cursor_in;
     uint64_t* cursor_out;
     FirStreamDesc* descs;      // [n]: the run's descriptors (the constant fields are the host's)
@@ -157,7 +163,7 @@ struct LsRunArgs {
     uint64_t in_offset;        // frames added to every stream's `in`
     uint32_t n_streams, k, in_frames, wrap_words, append, hist_parity;
 };
-hipError_t launch_fir_lockstep_plan(const LsRunArgs& args, uint32_t n_waves, hipStream_t stream);
+hipError_t launch_fir_lockstep_plan(const LsRunArgs& args, hipStream_t stream);
 hipError_t launch_fir_lockstep_gather_counts(const uint64_t* last_counts, const LsRunStream* rs, uint32_t* counts, uint32_t n,
                                              hipStream_t stream);
 

@@ -47,9 +47,9 @@ struct rsmp_fir_lockstep {
     struct RunGroup { rsmp::PeriodicGeometry geo; size_t first = 0, count = 0; uint32_t max_out_step = 0; };
     int run_state = 0;          // 0: not looked at yet, 1: every rate pair has a bulk kernel, -1: runs are loops of steps
     std::vector<RunGroup> run_groups;
-    std::vector<uint32_t> run_waves;
-    DeviceBuffer d_run_descs, d_run_rs, d_run_waves, d_run_bits, d_run_counts, d_run_nf, d_run_work;
+    DeviceBuffer d_run_descs, d_run_rs, d_run_bits, d_run_counts, d_run_nf, d_run_work, d_run_preds, d_run_recs, d_run_states0, d_run_drift, d_run_drift_last;
     uint32_t run_wrap_words = 0, run_k = 0, run_nf_tag = 0;
+    bool run_planned = false;   // the most recent run went through the device planner
     size_t run_counts_k = 0;    // calls of the most recent run whose counts are in d_run_counts (0: it was a loop of steps)
     std::vector<uint32_t> h_run_counts;
     // optional timing of the step launches (rsmp_fir_lockstep_set_profiling): ring of event pairs
@@ -445,7 +445,6 @@ int prepare_run(rsmp_fir_lockstep* ls) {
     std::vector<rsmp::LsRunStream> rstreams(n);
     std::memset(descs.data(), 0, n * sizeof(rsmp::FirStreamDesc));
     ls->run_groups.clear();
-    ls->run_waves.clear();
     auto same = [&](const rsmp_fir* x, const rsmp_fir* y) {
         return x->table.get() == y->table.get() && x->in_hz == y->in_hz && x->out_hz == y->out_hz &&
                x->channels == y->channels && x->taps == y->taps && x->kernel_mode == y->kernel_mode;
@@ -498,22 +497,18 @@ int prepare_run(rsmp_fir_lockstep* ls) {
             rstreams[i].channels = static_cast<uint32_t>(r->channels);
             rstreams[i].caller = ls->order[i];
         }
-        for (size_t first = k; first < e; first += 64) {   // a planner wave: up to 64 streams of one rate pair
-            ls->run_waves.push_back(static_cast<uint32_t>(first));
-            ls->run_waves.push_back(static_cast<uint32_t>(std::min<size_t>(64, e - first)));
-        }
         k = e;
     }
     if (ls->d_run_descs.reserve(n * sizeof(rsmp::FirStreamDesc)) != hipSuccess ||
         ls->d_run_rs.reserve(n * sizeof(rsmp::LsRunStream)) != hipSuccess ||
-        ls->d_run_waves.reserve(ls->run_waves.size() * sizeof(uint32_t)) != hipSuccess ||
-        ls->d_run_work.reserve(sizeof(unsigned long long)) != hipSuccess)
+        ls->d_run_states0.reserve(n * sizeof(FirMirrorState)) != hipSuccess ||
+        ls->d_run_drift_last.reserve(n * sizeof(uint32_t)) != hipSuccess ||
+        ls->d_run_work.reserve(64 * sizeof(unsigned long long)) != hipSuccess)
         return rsmp::fail(RSMP_ERR_HIP, "lock-step run: cannot allocate device state");
     RSMP_HIP_CHECK(hipMemcpy(ls->d_run_descs.get(), descs.data(), n * sizeof(rsmp::FirStreamDesc), hipMemcpyHostToDevice));
     RSMP_HIP_CHECK(hipMemcpy(ls->d_run_rs.get(), rstreams.data(), n * sizeof(rsmp::LsRunStream), hipMemcpyHostToDevice));
-    RSMP_HIP_CHECK(hipMemcpy(ls->d_run_waves.get(), ls->run_waves.data(), ls->run_waves.size() * sizeof(uint32_t),
-                             hipMemcpyHostToDevice));
-    RSMP_HIP_CHECK(hipMemset(ls->d_run_work.get(), 0, sizeof(unsigned long long)));
+    RSMP_HIP_CHECK(hipMemset(ls->d_run_work.get(), 0, 64 * sizeof(unsigned long long)));
+    RSMP_HIP_CHECK(hipMemset(ls->d_run_drift_last.get(), 0, n * sizeof(uint32_t)));
     ls->run_state = 1;
     return RSMP_OK;
 }
@@ -545,8 +540,11 @@ extern "C" int rsmp_fir_lockstep_run(rsmp_fir_lockstep* ls, size_t k_steps, size
     const uint32_t k = static_cast<uint32_t>(k_steps);
     if (k > ls->run_k) {
         RSMP_HIP_CHECK(hipStreamSynchronize(s));
-        if (ls->d_run_counts.reserve(2 * n * static_cast<size_t>(k) * sizeof(uint32_t)) != hipSuccess)
-            return rsmp::fail(RSMP_ERR_HIP, "lock-step run: cannot allocate the counts of %u calls", k);
+        if (ls->d_run_counts.reserve(2 * n * static_cast<size_t>(k) * sizeof(uint32_t)) != hipSuccess ||
+            ls->d_run_preds.reserve(n * static_cast<size_t>(k) * sizeof(rsmp::MirrorPred)) != hipSuccess ||
+            ls->d_run_recs.reserve(n * static_cast<size_t>(k) * 24) != hipSuccess ||
+            ls->d_run_drift.reserve(n * static_cast<size_t>((k + 63) / 64) * sizeof(double)) != hipSuccess)
+            return rsmp::fail(RSMP_ERR_HIP, "lock-step run: cannot allocate the plan of %u calls", k);
         ls->run_k = k;
     }
     if (ls->run_state < 0 || k == 1 || !whole_accept || k * static_cast<uint64_t>(ls->step_frames) > (1u << 27)) {
@@ -558,6 +556,7 @@ extern "C" int rsmp_fir_lockstep_run(rsmp_fir_lockstep* ls, size_t k_steps, size
                                                                    static_cast<uint32_t>(n), s));
         }
         ls->run_counts_k = k;
+        ls->run_planned = false;
         return RSMP_OK;
     }
     if (ls->last_stream && ls->last_stream != s) RSMP_HIP_CHECK(hipStreamSynchronize(ls->last_stream));
@@ -582,9 +581,13 @@ extern "C" int rsmp_fir_lockstep_run(rsmp_fir_lockstep* ls, size_t k_steps, size
     rsmp::LsRunArgs a;
     a.streams = ls->d_streams.as<LockstepStream>();
     a.rs = ls->d_run_rs.as<rsmp::LsRunStream>();
-    a.waves = ls->d_run_waves.as<uint32_t>();
     a.states_in = ls->d_states.as<FirMirrorState>();
     a.states_out = ls->d_states.as<FirMirrorState>();
+    a.states_before = ls->d_run_states0.as<FirMirrorState>();
+    a.preds = ls->d_run_preds.as<rsmp::MirrorPred>();
+    a.call_recs = ls->d_run_recs.get();
+    a.drift_cells = ls->d_run_drift.as<double>();
+    a.drift_last = ls->d_run_drift_last.as<uint32_t>();
     a.cursor_in = ls->d_cursor.as<uint64_t>();
     a.cursor_out = ls->d_cursor.as<uint64_t>();
     a.descs = ls->d_run_descs.as<rsmp::FirStreamDesc>();
@@ -601,30 +604,29 @@ extern "C" int rsmp_fir_lockstep_run(rsmp_fir_lockstep* ls, size_t k_steps, size
     a.hist_parity = ls->hist_parity;
     if (ls->profiling)
         RSMP_HIP_CHECK(hipEventRecord(ls->prof_start[ls->prof_count % rsmp_fir_lockstep::kProfRing], s));
-    RSMP_HIP_CHECK(rsmp::launch_fir_lockstep_plan(a, static_cast<uint32_t>(ls->run_waves.size() / 2), s));
+    RSMP_HIP_CHECK(rsmp::launch_fir_lockstep_plan(a, s));
     const rsmp::FirStreamDesc* d_descs = ls->d_run_descs.as<rsmp::FirStreamDesc>();
-    struct Repair { size_t first; uint32_t count; rsmp::NfArgs nf; };
-    std::vector<Repair> repairs;
+    // One launch of the bulk kernel per rate pair, one after the other on the caller's stream.  (Measured and dropped: the
+    // rate pairs' launches side by side on streams of their own, each with its share of the compute units -- a run of 16
+    // calls is then bound by the host's ~40 stream / event / launch calls, 0.38 ms against 0.25 ms.)
+    const size_t n_groups = ls->run_groups.size();
     uint32_t nf_off = 0, max_tail_values = 0;
-    for (const auto& g : ls->run_groups) {
+    for (size_t gi = 0; gi < n_groups; ++gi) {
+        const auto& g = ls->run_groups[gi];
         const uint64_t n_out_max = static_cast<uint64_t>(k) * g.max_out_step;
         const uint32_t max_blocks = static_cast<uint32_t>((n_out_max / g.geo.b + 1) / g.geo.pw + 1);
-        Repair rp;
-        rp.first = g.first;
-        rp.count = static_cast<uint32_t>(g.count);
-        rp.nf.chunks = static_cast<uint32_t>(n_out_max >> rsmp::kNfChunkShift) + 1;
-        rp.nf.words = ls->d_run_nf.as<uint32_t>() + nf_off;
+        rsmp::NfArgs nf;
+        nf.chunks = static_cast<uint32_t>(n_out_max >> rsmp::kNfChunkShift) + 1;
+        nf.words = ls->d_run_nf.as<uint32_t>() + nf_off;
         if (++ls->run_nf_tag == 0) ls->run_nf_tag = 1;
-        rp.nf.tag = ls->run_nf_tag;
-        nf_off += 1 + static_cast<uint32_t>((g.count * static_cast<uint64_t>(rp.nf.chunks) + 31) / 32);
-        repairs.push_back(rp);
-        RSMP_HIP_CHECK(rsmp::launch_fir_periodic(d_descs + g.first, rp.count, g.geo, max_blocks,
-                                                 ls->d_run_work.as<unsigned long long>(), rp.nf, s, false));
+        nf.tag = ls->run_nf_tag;
+        nf_off += 1 + static_cast<uint32_t>((g.count * static_cast<uint64_t>(nf.chunks) + 31) / 32);
+        RSMP_HIP_CHECK(rsmp::launch_fir_periodic(d_descs + g.first, static_cast<uint32_t>(g.count), g.geo, max_blocks,
+                                                 ls->d_run_work.as<unsigned long long>() + gi, nf, s, false));
+        RSMP_HIP_CHECK(rsmp::launch_fir_repair(d_descs + g.first, static_cast<uint32_t>(g.count), nf, s));
         const rsmp_fir* r0 = ls->rs[ls->order[g.first]];
         max_tail_values = std::max<uint32_t>(max_tail_values, static_cast<uint32_t>((r0->taps + 8) * r0->channels));
     }
-    for (const Repair& rp : repairs)
-        RSMP_HIP_CHECK(rsmp::launch_fir_repair(d_descs + rp.first, rp.count, rp.nf, s));
     RSMP_HIP_CHECK(rsmp::launch_fir_tail_copy(d_descs, static_cast<uint32_t>(n), max_tail_values, s));
     if (ls->profiling) {
         RSMP_HIP_CHECK(hipEventRecord(ls->prof_stop[ls->prof_count % rsmp_fir_lockstep::kProfRing], s));
@@ -634,6 +636,7 @@ extern "C" int rsmp_fir_lockstep_run(rsmp_fir_lockstep* ls, size_t k_steps, size
     ls->step += k;
     ++ls->epoch;   // plans the one-call kernel made ahead belong to the states before the run
     ls->run_counts_k = k;
+    ls->run_planned = true;
     ls->last_stream = s;
     return RSMP_OK;
 }
@@ -651,5 +654,18 @@ extern "C" int rsmp_fir_lockstep_run_counts(rsmp_fir_lockstep* ls, size_t* consu
         if (consumed) consumed[i] = ls->h_run_counts[2 * i];
         if (produced) produced[i] = ls->h_run_counts[2 * i + 1];
     }
+    return RSMP_OK;
+}
+
+extern "C" int rsmp_fir_lockstep_run_slow_calls(rsmp_fir_lockstep* ls, size_t* slow_calls) {
+    if (!ls || !slow_calls) return rsmp::fail(RSMP_ERR_INVALID_ARGUMENT, "rsmp_fir_lockstep_run_slow_calls: null argument");
+    *slow_calls = 0;
+    if (ls->run_counts_k <= 1 || ls->run_state <= 0 || !ls->run_planned) return RSMP_OK;   // (a loop of steps)
+    DeviceGuard guard(ls->device);
+    if (ls->last_stream) RSMP_HIP_CHECK(hipStreamSynchronize(ls->last_stream));
+    struct Rec { double pos, drift; uint32_t flags, pad; };
+    std::vector<Rec> h(ls->rs.size() * ls->run_counts_k);
+    RSMP_HIP_CHECK(hipMemcpy(h.data(), ls->d_run_recs.get(), h.size() * sizeof(Rec), hipMemcpyDeviceToHost));
+    for (const Rec& r : h) *slow_calls += r.flags & 1u;
     return RSMP_OK;
 }

@@ -16,6 +16,7 @@
 #include "fir_lockstep.h"
 
 #include "common.h"
+#include "fir_mirror_fast.h"
 
 namespace rsmp {
 
@@ -25,48 +26,114 @@ struct RunSink {             // mirror_call sink: the wrapped outputs go straigh
     uint32_t* bits;
     uint32_t rel;            // (absolute index of the call's first output) - wrap_k0 * den
     uint32_t den, n_bits;
-    bool periodic, overflow;
+    bool periodic, overflow, atomic;
     __host__ __device__ bool want_wraps() const { return periodic; }
     __host__ __device__ void run(uint64_t, uint64_t, double, double) {}
-    __host__ __device__ void wrap(uint64_t index) {
+    __device__ void wrap(uint64_t index) {
         const uint32_t K = (rel + static_cast<uint32_t>(index)) / den;
-        if (K < n_bits) bits[K >> 5] |= 1u << (K & 31);
-        else overflow = true;
+        if (K >= n_bits) overflow = true;
+        else if (atomic) (void)atomicOr(bits + (K >> 5), 1u << (K & 31));   // (the calls of a stream are replayed in parallel)
+        else bits[K >> 5] |= 1u << (K & 31);
     }
 };
 
-__global__ __launch_bounds__(64) void fir_lockstep_plan_kernel(LsRunArgs a) {
-    const uint32_t first = a.waves[2 * blockIdx.x], count = a.waves[2 * blockIdx.x + 1];
-    if (threadIdx.x >= count) return;
-    const uint32_t gs = first + threadIdx.x;
+constexpr uint32_t kCallSlow = 1, kCallAhead = 2, kCallHasInt = 4, kCallLean = 8;
+struct CallRec {             // what the chain leaves per call for the replay of its outputs at integer positions
+    double pos;              // the f64 position the call started from
+    double drift;            // slow calls: the stream's drift after the call
+    uint32_t flags, pad;
+};
+static_assert(sizeof(CallRec) == 24, "CallRec layout");
+
+// K1 -- the structure of every call of the run, in exact integer arithmetic: one thread per (stream, call).
+__global__ __launch_bounds__(256) void fir_lockstep_predict_kernel(LsRunArgs a) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= a.n_streams * a.k) return;
+    const uint32_t gs = t / a.k, c = t - gs * a.k;
+    const MirrorRunBase base = mirror_run_base(a.states_in[gs], a.in_frames, a.k);
+    if (base.usable) a.preds[t] = mirror_predict(base, c);
+    if (c == 0) a.states_before[gs] = a.states_in[gs];   // (the chain overwrites the states; the replay starts from these)
+    for (uint32_t w = c; w < a.wrap_words; w += a.k) a.wrap_bits[static_cast<size_t>(gs) * a.wrap_words + w] = 0;
+}
+
+// K2 -- the serial chain: one wave per stream walks the stream's k calls (mirror_call_fast: two
+// dependent f64 operations per binade; mirror_call where a check fails); the whole wave moves the predictions into LDS
+// and the per-call counts and call records out of it, 64 calls at a time, so that the chain itself never waits for HBM.
+// The run's descriptor and the state after the run follow at the end.
+static_assert(sizeof(MirrorPred) == 56, "MirrorPred is staged as seven 64-bit words");
+__global__ __launch_bounds__(64) void fir_lockstep_chain_kernel(LsRunArgs a) {
+    __shared__ uint64_t s_pred[64 * 7];
+    __shared__ uint64_t s_rec[64 * 3];
+    __shared__ uint32_t s_cnt[64 * 2];
+    const uint32_t gs = blockIdx.x, lane = threadIdx.x;
     const LockstepStream ls = a.streams[gs];
     const LsRunStream rs = a.rs[gs];
     FirMirrorState st = a.states_in[gs];
-    FirStreamDesc* d = a.descs + gs;
     uint32_t* bits = a.wrap_bits + static_cast<size_t>(gs) * a.wrap_words;
-    for (uint32_t w = 0; w < a.wrap_words; ++w) bits[w] = 0;
+    const MirrorRunBase base = mirror_run_base(st, a.in_frames, a.k);
+    const MirrorBinades bn = mirror_binades(st.ratio, base.e0);
+    const bool chain_ready = base.usable && mirror_chain_ready(bn);
 
     const uint32_t C = rs.channels;
     const uint64_t abs_out0 = st.abs_out, abs_consumed0 = st.abs_consumed;
     const uint64_t k0 = abs_out0 / rs.wrap_unit;
     const uint32_t hist_frames = static_cast<uint32_t>(st.available);
-    RunSink sink{bits, static_cast<uint32_t>(abs_out0 - k0 * rs.wrap_unit), rs.den, a.wrap_words * 32u,
-                 rs.wrap_unit == rs.den, false};   // (a super period of an exact ratio: no output ever wraps)
+    const bool wraps_exist = rs.wrap_unit == rs.den;   // (a super period of an exact ratio: no output ever wraps)
+    RunSink sink{bits, static_cast<uint32_t>(abs_out0 - k0 * rs.wrap_unit), rs.den, a.wrap_words * 32u, wraps_exist, false, false};
     uint32_t n_out = 0, accepted = 0, consumed = 0, flags = 0;
-    uint32_t* counts = a.counts + 2 * static_cast<size_t>(rs.caller);
-    for (uint32_t s = 0; s < a.k; ++s) {
-        sink.periodic = rs.wrap_unit == rs.den && st.periodic_ok != 0;
-        const FirCallCounts c = mirror_call(st, a.in_frames, ls.out_cap_frames, sink);
-        if (c.accepted != a.in_frames) flags |= kLsStatusPartialAccept;
-        counts[0] = static_cast<uint32_t>(c.accepted) * C;
-        counts[1] = static_cast<uint32_t>(c.produced) * C;
-        counts += 2 * static_cast<size_t>(a.n_streams);
-        n_out += static_cast<uint32_t>(c.produced);
-        accepted += static_cast<uint32_t>(c.accepted);
-        consumed += static_cast<uint32_t>(c.consumed);
-        sink.rel += static_cast<uint32_t>(c.produced);
+    uint32_t last_c0 = 0, last_c1 = 0;
+    const uint64_t* preds = reinterpret_cast<const uint64_t*>(a.preds + static_cast<size_t>(gs) * a.k);
+    uint64_t* recs = reinterpret_cast<uint64_t*>(a.call_recs) + static_cast<size_t>(gs) * a.k * 3;
+    for (uint32_t c0 = 0; c0 < a.k; c0 += 64) {
+        const uint32_t nc = a.k - c0 < 64u ? a.k - c0 : 64u;
+        for (uint32_t i = lane; i < 7 * nc; i += 64) s_pred[i] = preds[static_cast<size_t>(c0) * 7 + i];
+        __syncthreads();
+        {   // every lane runs the chain on the same values: the control flow stays uniform (scalar branches, no masking)
+#pragma unroll 1
+            for (uint32_t s = 0; s < nc; ++s) {
+                const MirrorPred pr = *reinterpret_cast<const MirrorPred*>(s_pred + 7 * s);
+                CallRec rec;
+                rec.pos = st.position;
+                rec.drift = 0.0;
+                rec.flags = st.abs_out != pr.m0 ? kCallAhead : 0u;
+                rec.pad = 0;
+                FirCallCounts c;
+                // nothing for the f64 drift to decide in this call (the rule): the chain alone, checked by the replay
+                const bool lean = chain_ready && pr.ties == 0 && st.abs_out == pr.m0 && st.abs_consumed == pr.c0 &&
+                                  st.read_position + st.available + a.in_frames <= kMirrorBufferSize &&
+                                  st.available + a.in_frames <= kMirrorInputCapacity && pr.n_total + 1 < ls.out_cap_frames;
+                if (lean) {
+                    mirror_call_chain(st, a.in_frames, pr, bn, c);
+                    rec.flags |= kCallLean;
+                } else if (!base.usable || !mirror_call_fast(st, a.in_frames, ls.out_cap_frames, pr, bn, c, [](uint32_t, uint32_t, double, double) {})) {
+                    const uint32_t ni = st.next_int;
+                    sink.periodic = wraps_exist && st.periodic_ok != 0;
+                    c = mirror_call(st, a.in_frames, ls.out_cap_frames, sink);
+                    rec.flags = kCallSlow | (ni < c.produced ? kCallHasInt : 0u);
+                    rec.drift = st.drift;
+                }
+                *reinterpret_cast<CallRec*>(s_rec + 3 * s) = rec;
+                if (c.accepted != a.in_frames) flags |= kLsStatusPartialAccept;
+                last_c0 = static_cast<uint32_t>(c.accepted) * C;
+                last_c1 = static_cast<uint32_t>(c.produced) * C;
+                s_cnt[2 * s] = last_c0;
+                s_cnt[2 * s + 1] = last_c1;
+                n_out += static_cast<uint32_t>(c.produced);
+                accepted += static_cast<uint32_t>(c.accepted);
+                consumed += static_cast<uint32_t>(c.consumed);
+                sink.rel += static_cast<uint32_t>(c.produced);
+            }
+        }
+        __syncthreads();
+        for (uint32_t i = lane; i < 3 * nc; i += 64) recs[static_cast<size_t>(c0) * 3 + i] = s_rec[i];
+        if (lane < nc) {
+            uint32_t* counts = a.counts + 2 * (static_cast<size_t>(c0 + lane) * a.n_streams + rs.caller);
+            counts[0] = s_cnt[2 * lane];
+            counts[1] = s_cnt[2 * lane + 1];
+        }
+        __syncthreads();
     }
-    if (st.periodic_ok == 0) flags |= kLsStatusAperiodic;
+    if (lane != 0) return;
     if (sink.overflow) flags |= kLsStatusRunOverflow;
 
     uint64_t cursor = 0;
@@ -74,6 +141,7 @@ __global__ __launch_bounds__(64) void fir_lockstep_plan_kernel(LsRunArgs a) {
         cursor = a.cursor_in[gs];
         a.cursor_out[gs] = cursor + static_cast<uint64_t>(n_out) * C;
     }
+    FirStreamDesc* d = a.descs + gs;
     d->in = ls.in + a.in_offset * C;
     d->hist = a.hist_parity ? ls.hist_alt : ls.hist;
     d->hist_next = a.hist_parity ? ls.hist : ls.hist_alt;
@@ -89,10 +157,84 @@ __global__ __launch_bounds__(64) void fir_lockstep_plan_kernel(LsRunArgs a) {
     d->wrap_k0 = k0;
     a.states_out[gs] = st;
     // the last call's counts, where rsmp_fir_lockstep_counts looks for them
-    counts -= 2 * static_cast<size_t>(a.n_streams);
-    a.last_counts[2 * gs] = counts[0];
-    a.last_counts[2 * gs + 1] = counts[1];
+    a.last_counts[2 * gs] = last_c0;
+    a.last_counts[2 * gs + 1] = last_c1;
     if (flags) a.status[gs] |= flags;
+}
+
+// K3 -- the outputs at integer positions (the row-1023 variant's bitmap, the stream's drift): one wave per stream, a
+// lane per call replays its call's chain from the recorded start position (mirror_replay_wraps).  The drift the
+// stream ends with is that of the last call that had such an output.
+__global__ __launch_bounds__(64) void fir_lockstep_wraps_kernel(LsRunArgs a) {
+    const uint32_t n_chunks = (a.k + 63) / 64;
+    const uint32_t gs = blockIdx.x / n_chunks, chunk = blockIdx.x - gs * n_chunks, lane = threadIdx.x;
+    const LsRunStream rs = a.rs[gs];
+    const FirMirrorState st0 = a.states_before[gs];   // the state before the run
+    const MirrorRunBase base = mirror_run_base(st0, a.in_frames, a.k);
+    const MirrorBinades bn = mirror_binades(st0.ratio, base.e0);
+    const bool wraps_exist = rs.wrap_unit == rs.den && st0.periodic_ok != 0;
+    uint32_t* bits = a.wrap_bits + static_cast<size_t>(gs) * a.wrap_words;
+    const uint64_t k0 = st0.abs_out / rs.wrap_unit;
+    const MirrorPred* preds = a.preds + static_cast<size_t>(gs) * a.k;
+    const CallRec* recs = reinterpret_cast<const CallRec*>(a.call_recs) + static_cast<size_t>(gs) * a.k;
+    bool aperiodic = false, overflow = false, unchecked = false;
+    const uint32_t c = chunk * 64 + lane;
+    bool has_int = false;
+    double my_drift = 0.0;
+    if (c < a.k) {
+        const CallRec rec = recs[c];
+        if (rec.flags & kCallSlow) {
+            has_int = (rec.flags & kCallHasInt) != 0;
+            my_drift = rec.drift;
+        } else if (wraps_exist || (rec.flags & kCallLean)) {
+            const MirrorPred pr = preds[c];
+            FirMirrorState st = st0;   // the call's start state, as far as the replay looks at it
+            st.read_position = 0;
+            st.abs_out = pr.m0 + ((rec.flags & kCallAhead) ? 1u : 0u);
+            st.abs_consumed = pr.c0;
+            st.available = st0.abs_consumed + st0.available + static_cast<uint64_t>(c) * a.in_frames - pr.c0;
+            st.position = rec.pos;
+            RunSink sink{bits, static_cast<uint32_t>(st.abs_out - k0 * rs.wrap_unit), rs.den, a.wrap_words * 32u, wraps_exist, false, true};
+            bool checked = true;
+            has_int = mirror_replay_wraps(st, a.in_frames, pr, bn, sink, &checked) && wraps_exist;
+            unchecked = !checked;   // (the chain took this call without checks: they were made here)
+            my_drift = st.drift;
+            aperiodic = st.periodic_ok == 0;
+            overflow = sink.overflow;
+        }
+    }
+    // the stream ends with the drift of its LAST call that had an output at an integer position: chunks publish theirs
+    // in order of the call index (a 64-bit maximum of call index : slot; the drift itself sits in the slot's cell)
+    const unsigned long long m = __ballot(has_int);
+    aperiodic = __any(aperiodic);
+    overflow = __any(overflow);
+    unchecked = __any(unchecked);
+    if (m) {
+        const int last = 63 - __builtin_clzll(m);
+        const double d = __shfl(my_drift, last, 64);
+        if (lane == 0) {
+            a.drift_cells[static_cast<size_t>(gs) * n_chunks + chunk] = d;
+            __threadfence();
+            (void)atomicMax(a.drift_last + gs, chunk + 1u);
+        }
+    }
+    if (lane == 0) {
+        const uint32_t flags = (overflow ? kLsStatusRunOverflow : 0u) | (unchecked ? kLsStatusPlannerCheck : 0u) |
+                               (aperiodic ? kLsStatusAperiodic : 0u);
+        if (flags) (void)atomicOr(a.status + gs, flags);
+        if (aperiodic) a.states_out[gs].periodic_ok = 0;
+    }
+}
+
+// ... and the last word: the drift of the latest chunk that had one (one thread per stream).
+__global__ __launch_bounds__(256) void fir_lockstep_drift_kernel(LsRunArgs a) {
+    const uint32_t gs = blockIdx.x * 256u + threadIdx.x;
+    if (gs >= a.n_streams) return;
+    const uint32_t n_chunks = (a.k + 63) / 64;
+    const uint32_t last = a.drift_last[gs];
+    if (last) a.states_out[gs].drift = a.drift_cells[static_cast<size_t>(gs) * n_chunks + last - 1];
+    a.drift_last[gs] = 0;
+    if (a.states_out[gs].periodic_ok == 0) (void)atomicOr(a.status + gs, kLsStatusAperiodic);
 }
 
 // a loop of steps as a run: the step's counts (internal order, 64-bit) to row s of the run's [k][n] table
@@ -113,9 +255,13 @@ hipError_t launch_fir_lockstep_gather_counts(const uint64_t* last_counts, const 
     return hipGetLastError();
 }
 
-hipError_t launch_fir_lockstep_plan(const LsRunArgs& args, uint32_t n_waves, hipStream_t stream) {
-    if (n_waves == 0) return hipSuccess;
-    hipLaunchKernelGGL(fir_lockstep_plan_kernel, dim3(n_waves), dim3(64), 0, stream, args);
+hipError_t launch_fir_lockstep_plan(const LsRunArgs& args, hipStream_t stream) {
+    if (args.n_streams == 0 || args.k == 0) return hipSuccess;
+    const uint32_t threads = args.n_streams * args.k;
+    hipLaunchKernelGGL(fir_lockstep_predict_kernel, dim3((threads + 255) / 256), dim3(256), 0, stream, args);
+    hipLaunchKernelGGL(fir_lockstep_chain_kernel, dim3(args.n_streams), dim3(64), 0, stream, args);
+    hipLaunchKernelGGL(fir_lockstep_wraps_kernel, dim3(args.n_streams * ((args.k + 63) / 64)), dim3(64), 0, stream, args);
+    hipLaunchKernelGGL(fir_lockstep_drift_kernel, dim3((args.n_streams + 255) / 256), dim3(256), 0, stream, args);
     return hipGetLastError();
 }
 

@@ -70,6 +70,43 @@ __host__ __device__ inline double mirror_from_bits(uint64_t u) {
     return x.d;
 }
 
+// The outputs of one position run (p_k = pos + k*inc, k < run; `count` = call-relative index of its first output)
+// whose exact position n_abs*num/den is an integer (k = next_int, next_int + den, ...): the rounded f64 position is
+// that integer + d_k with |d_k| tiny, and d_k moves LINEARLY with k inside a run (every p_k is exact), so its sign
+// changes at most once: evaluate the two ends, search the change if there is one.  Reports the wrapped ones (d < 0:
+// floor() picks the previous frame) to the sink, leaves the last deviation in st.drift and returns the new next_int
+// (outputs from the END of the run to the next integer position).  Requires next_int < run.
+template <class Idx, class Sink>
+__host__ __device__ inline Idx mirror_run_wraps(FirMirrorState& st, Idx next_int, Idx count, Idx run, double pos, double inc,
+                                                Idx den, double den_d, Sink& sink) {
+    const Idx n_int = (run - 1 - next_int) / den + 1;
+    const double next_d = static_cast<double>(next_int);
+    auto dev = [&](Idx i) -> double {   // signed distance of the i-th such position from its integer
+        const double p = fma(fma(static_cast<double>(i), den_d, next_d), inc, pos);
+        const double fr = p - floor(p);
+        return fr > 0.5 ? fr - 1.0 : fr;
+    };
+    const double d_first = dev(0), d_last = n_int > 1 ? dev(n_int - 1) : d_first;
+    st.drift = d_last;
+    if ((d_first < 0.0 ? -d_first : d_first) > 1e-5 || (d_last < 0.0 ? -d_last : d_last) > 1e-5)
+        st.periodic_ok = 0;
+    // wrapped = below the integer (d < 0): floor() picks the previous frame
+    Idx w_begin = 0, w_end = 0;   // [w_begin, w_end) of the n_int positions
+    if (d_first < 0.0 && d_last < 0.0) {
+        w_end = n_int;
+    } else if (d_first < 0.0 || d_last < 0.0) {
+        Idx lo = 0, hi = n_int - 1;   // the sign at lo differs from the sign at hi
+        while (hi - lo > 1) {
+            const Idx mid = lo + (hi - lo) / 2;
+            if ((dev(mid) < 0.0) == (d_first < 0.0)) lo = mid; else hi = mid;
+        }
+        if (d_first < 0.0) { w_begin = 0; w_end = hi; } else { w_begin = hi; w_end = n_int; }
+    }
+    for (Idx i = w_begin; i < w_end; ++i)
+        sink.wrap(static_cast<uint64_t>(count) + next_int + static_cast<uint64_t>(i) * den);
+    return static_cast<Idx>(static_cast<uint64_t>(next_int) + static_cast<uint64_t>(n_int) * den - run);
+}
+
 // One reference resample() call in frames.  `Sink` receives the exact position runs
 //   sink.run(out_index_of_first_frame, count, p0, inc)          (p_k = p0 + k*inc, inc == 0: one frame)
 // and, when sink.want_wraps() and the stream is still periodic, the call-relative indices of outputs
@@ -125,36 +162,7 @@ __host__ __device__ inline uint64_t mirror_output_loop(FirMirrorState& st, Idx o
         }
         sink.run(count, run, pos, inc);
         if (rational && next_int < run) {
-            // Outputs of the run whose exact position n_abs*num/den is an integer (k = next_int,
-            // next_int + den, ...): the rounded f64 position is that integer + d_k with |d_k| tiny,
-            // and d_k moves LINEARLY with k inside a run (every p_k is exact), so its sign changes at
-            // most once: evaluate the two ends, search the change if there is one.
-            const Idx n_int = (run - 1 - next_int) / den + 1;
-            const double next_d = static_cast<double>(next_int);
-            auto dev = [&](Idx i) -> double {   // signed distance of the i-th such position from its integer
-                const double p = fma(fma(static_cast<double>(i), den_d, next_d), inc, pos);
-                const double fr = p - floor(p);
-                return fr > 0.5 ? fr - 1.0 : fr;
-            };
-            const double d_first = dev(0), d_last = n_int > 1 ? dev(n_int - 1) : d_first;
-            st.drift = d_last;
-            if ((d_first < 0.0 ? -d_first : d_first) > 1e-5 || (d_last < 0.0 ? -d_last : d_last) > 1e-5)
-                st.periodic_ok = 0;
-            // wrapped = below the integer (d < 0): floor() picks the previous frame
-            Idx w_begin = 0, w_end = 0;   // [w_begin, w_end) of the n_int positions
-            if (d_first < 0.0 && d_last < 0.0) {
-                w_end = n_int;
-            } else if (d_first < 0.0 || d_last < 0.0) {
-                Idx lo = 0, hi = n_int - 1;   // the sign at lo differs from the sign at hi
-                while (hi - lo > 1) {
-                    const Idx mid = lo + (hi - lo) / 2;
-                    if ((dev(mid) < 0.0) == (d_first < 0.0)) lo = mid; else hi = mid;
-                }
-                if (d_first < 0.0) { w_begin = 0; w_end = hi; } else { w_begin = hi; w_end = n_int; }
-            }
-            for (Idx i = w_begin; i < w_end; ++i)
-                sink.wrap(static_cast<uint64_t>(count) + next_int + static_cast<uint64_t>(i) * st.den);
-            next_int = static_cast<Idx>(static_cast<uint64_t>(next_int) + static_cast<uint64_t>(n_int) * st.den - run);
+            next_int = mirror_run_wraps<Idx>(st, next_int, count, run, pos, inc, den, den_d, sink);
         } else if (rational) {
             next_int -= run;
         }

@@ -3,11 +3,14 @@
 // sum are provably exact.
 #include "fir_plan.h"
 
+#include <algorithm>
 #include <cmath>
+#include <cstring>
 #include <numeric>
 
 #include "common.h"
 #include "filter_design.h"
+#include "fir_mirror_fast.h"
 
 #pragma STDC FP_CONTRACT OFF
 
@@ -134,3 +137,74 @@ extern "C" int rsmp_fir_plan_bulk(rsmp_fir_plan* p, size_t in_frames, size_t chu
     return RSMP_OK;
 }
 
+
+// Self-test of the run planner's fast path (fir_mirror_fast.h) against mirror_call, on the host: `calls` calls of
+// `in_frames` frames from the plan's current state, predicted in runs of `run_len` calls.  Every call is done both ways
+// (mirror_call_fast falling back to mirror_call where a check fails, exactly as the device planner does) and compared:
+// counts, every bit of the state, the outputs taking the row-1023 variant, the drift.  The plan ends in the state after
+// the calls.  mismatches: calls that differed (must be 0); slow_calls: calls the fast path declined.
+extern "C" int rsmp_fir_plan_selftest_fast(rsmp_fir_plan* p, size_t in_frames, size_t calls, size_t run_len,
+                                           size_t* mismatches, size_t* slow_calls, size_t* lean_calls) {
+    if (!p || run_len == 0 || in_frames == 0 || in_frames > rsmp::kMirrorInputCapacity)
+        return rsmp::fail(RSMP_ERR_INVALID_ARGUMENT, "rsmp_fir_plan_selftest_fast: invalid argument");
+    struct WrapSink {
+        std::vector<uint64_t>* w;
+        bool want_wraps() const { return true; }
+        void run(uint64_t, uint64_t, double, double) {}
+        void wrap(uint64_t index) { w->push_back(index); }
+    };
+    rsmp::FirMirrorState ref = p->mirror.state(), fast = ref;
+    const uint64_t cap = p->mirror.buffer_size_output_frames();
+    size_t bad = 0, slow = 0, n_lean = 0;
+    std::vector<uint64_t> w_ref, w_fast;
+    for (size_t done = 0; done < calls; done += run_len) {
+        const uint32_t len = static_cast<uint32_t>(std::min(run_len, calls - done));
+        const rsmp::MirrorRunBase base = rsmp::mirror_run_base(fast, static_cast<uint32_t>(in_frames), len);
+        const rsmp::MirrorBinades bn = rsmp::mirror_binades(fast.ratio, base.e0);
+        const bool chain_ready = rsmp::mirror_chain_ready(bn);
+        for (uint32_t c = 0; c < len; ++c) {
+            w_ref.clear();
+            w_fast.clear();
+            WrapSink s_ref{&w_ref}, s_fast{&w_fast};
+            const rsmp::FirCallCounts c_ref = rsmp::mirror_call(ref, in_frames, cap, s_ref);
+            rsmp::FirCallCounts c_fast{};
+            const rsmp::FirMirrorState before = fast;
+            bool took_fast = false;
+            if (base.usable) {
+                const rsmp::MirrorPred pr = rsmp::mirror_predict(base, c);
+                took_fast = rsmp::mirror_call_fast(fast, static_cast<uint32_t>(in_frames), cap, pr, bn, c_fast,
+                                                   [](uint32_t, uint32_t, double, double) {});
+                // the unchecked chain, where the device planner takes it: must land on the same state
+                if (took_fast && pr.ties == 0 && chain_ready && before.abs_out == pr.m0) {
+                    rsmp::FirMirrorState lean = before;
+                    rsmp::FirCallCounts c_lean{};
+                    rsmp::mirror_call_chain(lean, static_cast<uint32_t>(in_frames), pr, bn, c_lean);
+                    ++n_lean;
+                    if (std::memcmp(&lean, &fast, sizeof lean) != 0 || c_lean.produced != c_fast.produced ||
+                        c_lean.consumed != c_fast.consumed)
+                        ++bad;
+                }
+                if (took_fast) {   // the outputs at integer positions: by replay from the call's start state
+                    rsmp::FirMirrorState start = before;
+                    start.read_position = 0;
+                    if (rsmp::mirror_replay_wraps(start, static_cast<uint32_t>(in_frames), pr, bn, s_fast)) {
+                        fast.drift = start.drift;
+                        if (start.periodic_ok == 0) fast.periodic_ok = 0;
+                    }
+                }
+            }
+            if (!took_fast) {
+                ++slow;
+                c_fast = rsmp::mirror_call(fast, in_frames, cap, s_fast);
+            }
+            const bool same = c_ref.accepted == c_fast.accepted && c_ref.produced == c_fast.produced &&
+                              c_ref.consumed == c_fast.consumed && std::memcmp(&ref, &fast, sizeof ref) == 0 && w_ref == w_fast;
+            if (!same) ++bad;
+        }
+    }
+    p->mirror.set_state(ref);
+    if (mismatches) *mismatches = bad;
+    if (slow_calls) *slow_calls = slow;
+    if (lean_calls) *lean_calls = n_lean;
+    return RSMP_OK;
+}

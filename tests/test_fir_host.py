@@ -149,3 +149,27 @@ def test_plan_segments_reproduce_the_f64_recurrence_exactly(in_hz, out_hz):
     a, p, segs = plan2.call(4096, 10 ** 6, want_segments=True)
     if p > 200 and ratio < 64:
         assert len(segs) < 60, len(segs)
+
+
+def test_run_planner_fast_path_equals_the_plain_state_machine():
+    """The device planner of rsmp_fir_lockstep_run (fir_mirror_fast.h: call structure predicted in exact integer arithmetic,
+    the f64 chain checked against it, outputs at integer positions by replay) against mirror_call on the host, call by
+    call: counts, every bit of the state, the outputs taking the row-1023 variant -- all ordered pairs of twelve rates x
+    five (latency, call size, run length) shapes, ~1 M calls, from a non-fresh state."""
+    import itertools
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools"))
+    from selftest_fast_planner import RATES, SHAPES, selftest
+    total = slow_total = 0
+    for i, o_ in itertools.permutations(RATES, 2):
+        for lat, frames, calls, runlen in SHAPES:
+            bad, slow, lean = selftest(i, o_, lat, frames, calls, runlen, prefeed=(i // 100) % 300)
+            assert bad == 0, (i, o_, lat, frames, bad)
+            total += calls
+            slow_total += slow
+    # the fast path must be the rule (what it declines: calls of > 65535 outputs inside one binade)
+    assert slow_total * 100 < total, (slow_total, total)
+    # BASELINE config 4's pairs at its call size: never declined
+    for i, o_ in [(44100, 48000), (48000, 44100), (44100, 96000), (96000, 44100), (48000, 96000), (96000, 48000)]:
+        bad, slow, lean = selftest(i, o_, 3, 512, 20000, 256)
+        assert (bad, slow) == (0, 0) and lean > 15000, (i, o_, bad, slow, lean)   # (and mostly by the unchecked chain)
