@@ -503,8 +503,8 @@ def bench_c4(ctx: Ctx, args, steps: int, warmup: int):
     ls = ra.FirLockstep(hs, frames) if hs else None
     feed = None
     kk = max(1, args.c4_k)                          # calls per launch (rsmp_fir_lockstep_run)
-    if kk > 1 and args.feed == "rccl":
-        raise SystemExit("--c4-k > 1 runs on resident input (--feed resident)")
+    if args.feed == "rccl":
+        kk = 1                                      # (the exchange moves one step's chunks per group)
     ring = max(8, kk)                               # chunks of input resident per stream, cycled
     if args.feed == "rccl":
         # a step's chunks arrive from GPU 0 and its outputs return there: the streams are bound straight
@@ -724,7 +724,7 @@ def secondary_lines(ctx: Ctx, args):
                 f"replays its own control flow on the host, then one launch)",
         "step_ms_cold": round(cold, 2), "setup_s": round(t1 - t0, 2)}
     del batch, handles
-    c4 = bench_c4(ctx, args, steps=256, warmup=8)
+    c4 = bench_c4(ctx, args, steps=256 * 8, warmup=256)   # (eight launches of the configuration's 256 steps)
     sec["config4"] = {k: c4[k] for k in ("metric", "value", "unit", "ms_per_step", "scaling", "dtype", "config", "roofline")}
     c5 = bench_c5(ctx, args, steps=10, warmup=2)
     sec["config5"] = {k: c5[k] for k in ("metric", "value", "unit", "ms_per_step", "scaling", "dtype", "config", "roofline")}
@@ -840,7 +840,7 @@ def main() -> int:
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--streams", type=int, default=64, help="streams per GPU (c2 / fft)")
     ap.add_argument("--c4-streams", type=int, default=1024, help="streams of the whole config-4 batch")
-    ap.add_argument("--c4-k", type=int, default=1, help="config 4: lock-step calls per launch (rsmp_fir_lockstep_run); 1 = one call per launch")
+    ap.add_argument("--c4-k", type=int, default=256, help="config 4: lock-step calls per launch (rsmp_fir_lockstep_run; 256 = the configuration's 256 steps in one go); 1 = one call per launch (rsmp_fir_lockstep_step)")
     ap.add_argument("--frames", type=int, default=1 << 20, help="input frames per stream per step")
     ap.add_argument("--c5-frames", type=int, default=57_600_000, help="input frames of the config-5 stream (10 min at 96 kHz)")
     ap.add_argument("--chunk", type=int, default=512, help="reference call size in f32 values")

@@ -191,8 +191,11 @@ def test_hip_path_against_the_golden_configs(fx):
 
 
 @pytest.mark.gpu
-def test_config4_at_its_full_length(fx):
-    """BASELINE config 4 as stated: 1024 mixed-rate streams x 256 lock-step steps of 512 frames.  Every stream's
+@pytest.mark.parametrize("k", [1, 16, 256])
+def test_config4_at_its_full_length(fx, k):
+    """BASELINE config 4 as stated: 1024 mixed-rate streams x 256 lock-step steps of 512 frames, k steps per launch (k = 1:
+    rsmp_fir_lockstep_step; k = 16, 256: rsmp_fir_lockstep_run -- planned on the device, one bulk launch per rate pair;
+    k = 256 is the whole configuration in one go).  Every stream's
     (consumed, produced) of every step against the host mirror of the reference state machine (exact, no samples);
     samples, counts and the final state of two streams per rate pair against the frozen AVX+FMA oracle run
     (fixture c4_256), and of 18 more streams spread over the batch against the oracle run here."""
@@ -212,20 +215,27 @@ def test_config4_at_its_full_length(fx):
     want_counts = []
     for i, pl in enumerate(plans):
         per = []
-        for k in range(steps):
+        for _ in range(steps):
             acc, prod = pl.call(frames, caps[i] // 2)
             per.append((acc * 2, prod * 2))
         want_counts.append(per)
     ls = ra.FirLockstep(hs, frames)
     ls.bind_caps(d_in, d_out, caps)
     got = {i: [] for i in checked}
-    for k in range(steps):
-        ls.step(frames, k * frames, append=True)
-        cons, prod = ls.counts()
-        for i in range(n):
-            assert (int(cons[i]), int(prod[i])) == want_counts[i % 6][k], (i, k)
+    want = np.array([[want_counts[i % 6][s] for i in range(n)] for s in range(steps)])   # [step][stream][2]
+    for s0 in range(0, steps, k):
+        if k == 1:
+            ls.step(frames, s0 * frames, append=True)
+            cons, prod = ls.counts()
+            cons, prod = cons[None, :], prod[None, :]
+        else:
+            ls.run(k, frames, s0 * frames, append=True)
+            cons, prod = ls.run_counts()
+            assert ls.run_slow_calls() == 0   # (these six rate pairs never leave the planner's fast path)
+        assert np.array_equal(cons, want[s0:s0 + k, :, 0]) and np.array_equal(prod, want[s0:s0 + k, :, 1]), s0
         for i in checked:
-            got[i].append([int(cons[i]), int(prod[i])])
+            got[i].extend([[int(cons[s][i]), int(prod[s][i])] for s in range(cons.shape[0])])
+    assert not ls.status().any()
     detail = {d["index"]: d for d in c4l["detail"]}
     for i in checked:
         total = sum(p for _, p in got[i])
@@ -239,9 +249,18 @@ def test_config4_at_its_full_length(fx):
         x = synth.hash_noise(steps * frames * 2, seed=i)
         out = np.zeros(caps[i], np.float32)
         ys = []
-        for k in range(steps):
-            rc, c, p = r.resample(x[k * 1024:(k + 1) * 1024], out)
-            assert rc == 0 and [c, p] == got[i][k], (i, k)
+        for s in range(steps):
+            rc, c, p = r.resample(x[s * 1024:(s + 1) * 1024], out)
+            assert rc == 0 and [c, p] == got[i][s], (i, s)
             ys.append(out[:p].copy())
         assert rms(y, np.concatenate(ys)) <= RMS_TOL, i
+    # the states written back equal the oracle's, bit for bit
+    ls.sync()
+    for i in checked:
+        r = o.OracleFir(2, specs[i].in_hz, specs[i].out_hz, 128, 90)
+        out = np.zeros(caps[i], np.float32)
+        x = synth.hash_noise(steps * frames * 2, seed=i)
+        for s in range(steps):
+            r.resample(x[s * 1024:(s + 1) * 1024], out)
+        assert hs[i].state() == r.state(), i
     ls.close()
