@@ -157,17 +157,19 @@ def device_copy_gbs(ctx: Ctx, nbytes: int) -> float:
     """What a plain device-to-device copy of `nbytes` (read) + `nbytes` (written) reaches on this GPU, in GB/s of
     read + written bytes: the PRACTICAL ceiling of a kernel that streams as much in as out, next to the 8 TB/s
     the roofline is priced against ('also report a measured device-copy GB/s as the practical
-    peak').  torch's copy kernel on the bench's stream, torch events, 20 copies after 5."""
+    peak').  The library's own 16-bytes-per-lane copy kernel (rsmp_device_stream_copy; round 3 timed torch's
+    Tensor.copy_, which stops at 4.8-5.4 TB/s) on the bench's stream, torch events, 20 copies after 5."""
+    import resampler_amd as ra
     torch = ctx.torch
-    n = max(1 << 20, int(nbytes) // 4)
+    n = max(1 << 20, int(nbytes) // 4) // 4 * 4
     src = torch.empty(n, device=ctx.dev, dtype=torch.float32).normal_()
     dst = torch.empty_like(src)
     for _ in range(5):
-        dst.copy_(src)
+        ra.device_stream_copy(src, dst, ctx.stream)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(20):
-        dst.copy_(src)
+        ra.device_stream_copy(src, dst, ctx.stream)
     e1.record()
     e1.synchronize()
     ms = e0.elapsed_time(e1) / 20

@@ -283,6 +283,10 @@ int rsmp_interp_resample_device(int mode, size_t channels, uint32_t in_hz, uint3
  * (2 channels in) or 2 * n_samples (1 channel in).  Device pointers, asynchronous on `stream`. */
 int rsmp_pcm_to_stereo_f32_device(const void* d_pcm, int bits, int channels, size_t n_samples, float* d_out,
                                   void* stream);
+/* Measurement aid (no counterpart in the reference): a plain streaming copy of n_values floats, 16 bytes per lane --
+ * the rate a kernel that reads as much as it writes can reach on this GPU; bench.py reports it next to every
+ * roofline fraction.  16-byte aligned device pointers, n_values a multiple of 4, asynchronous on `stream`. */
+int rsmp_device_stream_copy(const float* d_src, float* d_dst, size_t n_values, void* stream);
 
 /* ============================ ResamplerFft (src/resampler_fft.rs) =============================== */
 typedef struct rsmp_fft rsmp_fft;

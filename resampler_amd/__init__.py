@@ -163,6 +163,7 @@ _SIGNATURES = [
     ("rsmp_interp_resample_device", C.c_int,
      [C.c_int, C.c_size_t, C.c_uint32, C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, _szp, C.c_void_p]),
     ("rsmp_pcm_to_stereo_f32_device", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p]),
+    ("rsmp_device_stream_copy", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     ("rsmp_fft_new", C.c_void_p, [C.c_size_t, C.c_int, C.c_int, C.c_int]),
     ("rsmp_fft_free", None, [C.c_void_p]),
     ("rsmp_fft_chunk_size_input", C.c_size_t, [C.c_void_p]),
@@ -783,3 +784,10 @@ class FirPlan:
             return a.value, p.value, [(s.out_start, s.count, s.in_base, s.p0, s.inc)
                                       for s in segs[:ns.value]]
         return a.value, p.value
+
+
+def device_stream_copy(d_src, d_dst, stream: Optional[int] = None) -> None:
+    """rsmp_device_stream_copy: a plain 16-bytes-per-lane copy between two device tensors (measurement aid)."""
+    assert d_src.is_cuda and d_dst.is_cuda and d_src.numel() == d_dst.numel()
+    _check(lib().rsmp_device_stream_copy(C.c_void_p(d_src.data_ptr()), C.c_void_p(d_dst.data_ptr()), d_src.numel(),
+                                         C.c_void_p(stream or 0)))

@@ -614,9 +614,19 @@ int launch_jobs(rsmp_fir* leader, std::vector<Job>& jobs, hipStream_t stream) {
         rp.nf.words = leader->d_nf.as<uint32_t>() + reinterpret_cast<size_t>(rp.nf.words) / sizeof(uint32_t);
         if (++leader->nf_tag == 0) leader->nf_tag = 1;
         rp.nf.tag = leader->nf_tag;
+        // what the split kernel's item table is a function of (fir_split.hip, split_items_kernel): FNV-1a over it
+        uint64_t key = 1469598103934665603ull;
+        auto mix = [&](uint64_t v) { for (int b = 0; b < 8; ++b) { key ^= (v >> (8 * b)) & 0xFFu; key *= 1099511628211ull; } };
+        mix(g.geo.a); mix(g.geo.b); mix(g.geo.lp); mix(g.geo.groups); mix(max_blocks); mix(g.members.size());
+        for (size_t i : g.members) {
+            const Job& j = jobs[i];
+            mix(j.r->mirror.abs_out()); mix(j.r->mirror.abs_consumed()); mix(j.plan->produced_frames);
+            mix(j.plan->hist_frames); mix(j.plan->accepted_frames); mix(j.r->channels);
+        }
+        if (key == 0) key = 1;
         RSMP_HIP_CHECK(rsmp::launch_fir_periodic(d_descs + first,
                                                  static_cast<uint32_t>(g.members.size()), g.geo,
-                                                 max_blocks, leader->d_work_counter, rp.nf, stream, tail_fused));
+                                                 max_blocks, leader->d_work_counter, rp.nf, stream, tail_fused, key));
         first += g.members.size();
     }
     if (leader->profiling) {

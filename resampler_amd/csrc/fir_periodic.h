@@ -121,10 +121,12 @@ void periodic_fill_wrap_bits(const std::vector<uint32_t>& wraps, uint64_t abs_ou
 // `d_work_counter` is a zero-initialised 64-bit device word owned by the caller; the kernel leaves it
 // at zero again (launches sharing it must be ordered, which launch_jobs enforces per handle).
 // `nf`: where non-finite sums are marked (fir_nonfinite.h); the caller follows up with launch_fir_repair.
+// items_key: a hash of everything the split kernel's item table depends on (the streams' counters in launch order; 0 =
+// none): a launch with the key of the table already in the stream's workspace does not rebuild it.
 hipError_t launch_fir_periodic(const FirStreamDesc* d_descs, uint32_t n_streams,
                                const PeriodicGeometry& geo, uint32_t max_blocks,
                                unsigned long long* d_work_counter, const NfArgs& nf, hipStream_t stream,
-                               bool fuse_tail = false);
+                               bool fuse_tail = false, uint64_t items_key = 0);
 // Recomputes the outputs listed in each stream's `wraps` with row 1023 / previous frame
 // (only for geometries without inline wraps).
 hipError_t launch_fir_wrap_fixup(const FirStreamDesc* d_descs, uint32_t n_streams,
@@ -140,7 +142,8 @@ void split_store_class(std::vector<float>& coef, const PeriodicGeometry& g, uint
                        uint32_t shift, const std::vector<float>& mixed);
 // fuse_tail: the kernel also copies every stream's still-buffered tail into hist_next (no tail-copy launch)
 hipError_t launch_fir_split(const FirStreamDesc* d_descs, uint32_t n_streams, const PeriodicGeometry& geo,
-                            uint32_t max_blocks, uint32_t cus, bool fuse_tail, const NfArgs& nf, hipStream_t stream);
+                            uint32_t max_blocks, uint32_t cus, bool fuse_tail, const NfArgs& nf, hipStream_t stream,
+                            uint64_t items_key = 0);
 
 // Host build of the class table (exposed for tests).
 struct HostClassTable {

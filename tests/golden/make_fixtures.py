@@ -59,6 +59,38 @@ def fir_config(name, ch, in_hz, out_hz, att_db, x, chunk, kind=o.CONVOLVE_SCALAR
             "buffer_size_output": r.buffer_size_output(), "final_state": list(r.state())}
 
 
+C5_FULL_FRAMES = 57_600_000   # BASELINE config 5 as stated: ten minutes of 8-channel audio at 96 kHz
+
+
+def c5_full_input() -> np.ndarray:
+    """The ten-minute stream of config 5: hash_noise(seed 55), generated in pieces (the generator's 64-bit temporaries of
+    460.8 M values at once would be ~11 GB)."""
+    n = C5_FULL_FRAMES * 8
+    x = np.empty(n, np.float32)
+    step = 1 << 24
+    for a in range(0, n, step):
+        b = min(n, a + step)
+        with np.errstate(over="ignore"):
+            z = (np.arange(a, b, dtype=np.uint64) + np.uint64(55) * np.uint64(0x9E3779B97F4A7C15) + np.uint64(0x9E3779B97F4A7C15))
+            z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+            z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+            z = z ^ (z >> np.uint64(31))
+        x[a:b] = ((z >> np.uint64(40)).astype(np.float64) / float(1 << 23) - 1.0).astype(np.float32)
+    return x
+
+
+def c5_full():
+    """Config 5 at its stated length through convolve_interp_avx_fma, 512-frame calls: hashes only (0.85 GB of output)."""
+    r = o.OracleFir(8, 96000, 44100, 128, 120, o.CONVOLVE_AVX_FMA)
+    x = c5_full_input()
+    assert np.array_equal(x[:4096], synth.hash_noise(4096, seed=55))
+    y, calls = r.resample_all(x, 512 * 8)
+    return {"name": "c5_full", "channels": 8, "in_hz": 96000, "out_hz": 44100, "taps": 128, "attenuation_db": 120,
+            "chunk_values": 512 * 8, "in_values": int(x.size), "out_values": int(y.size), "n_calls": int(calls.shape[0]),
+            "calls_sha256": hashlib.sha256(np.ascontiguousarray(calls, "<i8").tobytes()).hexdigest(),
+            "sha256": sha(y), "final_state": list(r.state())}
+
+
 def main():
     fx = {"generator": "tests/golden/make_fixtures.py", "oracle": "oracle/*.c (c1 .. c5: scalar convolve; *_avx_fma and c4_256: convolve_interp_avx_fma)"}
     # C1: 1 ch 48000 -> 44100, Sample64 / Db90, 512-sample calls, 2^20-frame sweep
@@ -126,10 +158,20 @@ def main():
                             "sha256": sha(y), "head": pack(y[:256]), "tail": pack(y[-256:]), "final_state": list(r.state())})
     fx["c4_256"] = {"name": "c4_256", "steps": 256, "frames_per_step": 512, "detail": long_detail}
     path = os.path.join(ROOT, "tests", "golden", "config_fixtures.json")
+    fx["c5_full"] = c5_full()
     with open(path, "w") as fh:
         json.dump(fx, fh)
     print("wrote", path, os.path.getsize(path), "bytes")
 
 
 if __name__ == "__main__":
-    main()
+    if "--c5-full-only" in sys.argv:   # adds / refreshes that one entry of the committed file (the rest takes minutes)
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "config_fixtures.json")
+        with open(path) as fh:
+            fx = json.load(fh)
+        fx["c5_full"] = c5_full()
+        with open(path, "w") as fh:
+            json.dump(fx, fh)
+        print("c5_full:", fx["c5_full"])
+    else:
+        main()

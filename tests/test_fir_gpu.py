@@ -653,3 +653,88 @@ print("three planes ok")
     env = dict(os.environ, RSMP_FIR_SPLIT_PLANES="3", PYTHONPATH=root)
     out = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "three planes ok" in out.stdout, out.stdout + out.stderr
+
+
+PAIR_FLOOR = 2.0 ** -36   # what a sample keeps at least, relative to the largest sample of its channel pair's work item
+
+
+def _per_channel_errors(yg, yr, ch):
+    yg, yr = yg.reshape(-1, ch).astype(np.float64), yr.reshape(-1, ch).astype(np.float64)
+    return [(float(np.sqrt(np.mean((yg[:, c] - yr[:, c]) ** 2))), float(np.sqrt(np.mean(yr[:, c] ** 2)))) for c in range(ch)]
+
+
+@pytest.mark.parametrize("ch,in_hz,out_hz", [(2, 44100, 48000), (4, 44100, 48000), (8, 48000, 44100), (8, 96000, 44100),
+                                             (2, 96000, 44100), (2, 44100, 96000)])
+@pytest.mark.parametrize("quiet_exp", [12, 20, 30])
+def test_channels_of_a_pair_at_very_different_levels(ch, in_hz, out_hz, quiet_exp):
+    """The split kernels' block-floating-point scale belongs to a work item of a channel PAIR (16 periods of two channels):
+    the odd channels here carry the sweep at 2^-12, 2^-20, 2^-30 of the even ones.  Asserted PER CHANNEL: 1e-6 RMS
+    relative to the channel's own level, or -- where the quiet channel sits more than ~2^-13 below its partner -- the
+    documented floor of 2^-36 of the pair's peak ("Numerical range"; measured 2^-41 .. 2^-37), which is
+    ten thousand times below north_star's absolute gate.  The loud channels keep 1e-6 of their level throughout."""
+    g, r = make_pair(ch, in_hz, out_hz, kernel=ra.FirKernel.Periodic)
+    n = 70000
+    x = synth.sweep(n, ch, float(in_hz)).reshape(n, ch).copy()
+    x[:, 1::2] *= np.float32(2.0 ** -quiet_exp)
+    x = x.reshape(-1)
+    yg, _ = g.resample_bulk(x, 512 - 512 % ch)
+    yr, _ = r.resample_all(x, 512 - 512 % ch)
+    assert yg.size == yr.size
+    peak = float(np.max(np.abs(x)))
+    for c, (err, level) in enumerate(_per_channel_errors(yg, yr, ch)):
+        assert err <= max(RMS_TOL * level, PAIR_FLOOR * peak), (c, err, level)
+        if c % 2 == 0 or quiet_exp <= 12:
+            assert err <= RMS_TOL * level, (c, err, level)
+
+
+def test_a_burst_followed_by_near_silence_inside_one_work_item():
+    """Full-scale samples for 40 frames, 2^-20 noise around them: the outputs behind the burst that still belong to its
+    16-period work item (53 ms at 44.1 kHz) are scaled for the burst.  They keep 1e-6 of THEIR level here; the documented
+    floor is 2^-36 of the burst."""
+    g, r = make_pair(2, 44100, 48000, kernel=ra.FirKernel.Periodic)
+    n = 70000
+    x = (synth.fast_noise(n * 2, seed=3) * np.float32(2.0 ** -20)).reshape(n, 2)
+    x[1000:1040] = synth.fast_noise(80, seed=4).reshape(40, 2)
+    x = x.reshape(-1).astype(np.float32)
+    yg, _ = g.resample_bulk(x, 512)
+    yr, _ = r.resample_all(x, 512)
+    assert rel_rms(yg, yr) <= RMS_TOL
+    seg = slice(2 * 1400, 2 * 3400)   # behind the burst, inside its work item
+    err = rms(yg[seg], yr[seg])
+    level = float(np.sqrt(np.mean(yr[seg].astype(np.float64) ** 2)))
+    assert err <= max(RMS_TOL * level, PAIR_FLOOR), (err, level)
+
+
+def test_lockstep_channels_at_very_different_levels():
+    """The same through the lock-step batch (one scale per STREAM and step there) and through runs of several steps (the
+    bulk kernels): per channel 1e-6 of its level or the 2^-36 floor of the stream's peak."""
+    torch = pytest.importorskip("torch")
+    from resampler_amd import sharding
+    dev = torch.device("cuda:0")
+    specs = sharding.mixed_rate_batch(12, 2, 512)
+    steps = 12
+    for mode in ("step", "run"):
+        hs = [ra.ResamplerFir.new_from_hz(2, s.in_hz, s.out_hz, ra.Latency.Sample64, ra.Attenuation.Db90) for s in specs]
+        refs = [o.OracleFir(2, s.in_hz, s.out_hz, 128, 90, ORACLE_KIND) for s in specs]
+        xs = []
+        for i, s in enumerate(specs):
+            x = synth.sweep(steps * 512, 2, float(s.in_hz)).reshape(-1, 2).copy()
+            x[:, 1] *= np.float32(2.0 ** -(12, 20, 30)[(i // 6) % 3 if i >= 6 else 1])
+            xs.append(x.reshape(-1))
+        caps = [h.buffer_size_output() for h in hs]
+        d_in = [torch.from_numpy(x).to(dev) for x in xs]
+        d_out = [torch.zeros(steps * c, device=dev) for c in caps]
+        ls = ra.FirLockstep(hs, 512)
+        ls.bind_caps(d_in, d_out, caps)
+        if mode == "run":
+            ls.run(steps, 512, 0, append=True)
+        else:
+            for k in range(steps):
+                ls.step(512, k * 512, append=True)
+        ls.sync()
+        for i, r in enumerate(refs):
+            yr, _ = r.resample_all(xs[i], 1024)
+            yg = d_out[i][:yr.size].cpu().numpy()
+            for c, (err, level) in enumerate(_per_channel_errors(yg, yr, 2)):
+                assert err <= max(RMS_TOL * level, PAIR_FLOOR), (mode, i, c, err, level)
+        ls.close()

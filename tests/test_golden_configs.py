@@ -264,3 +264,41 @@ def test_config4_at_its_full_length(fx, k):
             r.resample(x[s * 1024:(s + 1) * 1024], out)
         assert hs[i].state() == r.state(), i
     ls.close()
+
+
+@pytest.mark.gpu
+def test_config5_at_its_full_length(fx):
+    """BASELINE config 5 as stated: ONE 8-channel 96 -> 44.1 kHz stream of ten minutes (57.6 M frames, 128 taps, Db120,
+    512-frame calls), sample by sample: the oracle's convolve_interp_avx_fma run must reproduce the frozen hashes (fixture
+    c5_full: output, per-call counts, final state), the HIP path's bulk launch must return the same counts for all
+    112 500 calls, the same final state, and every output value within 1e-6 RMS over the whole stream and over each
+    tenth of it (the channel-pair kernel rebuilds its class table as the f64 position drifts: the end of the stream is
+    where that would show)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from make_fixtures import c5_full_input
+    if not o.have_avx_fma():
+        pytest.skip("the frozen run is the AVX + FMA path")
+    c5 = fx["c5_full"]
+    x = c5_full_input()
+    assert x.size == c5["in_values"]
+    ref = o.OracleFir(8, 96000, 44100, 128, 120, o.CONVOLVE_AVX_FMA)
+    want, calls = ref.resample_all(x, c5["chunk_values"])
+    assert want.size == c5["out_values"] and calls.shape[0] == c5["n_calls"]
+    assert hashlib.sha256(np.ascontiguousarray(calls, "<i8").tobytes()).hexdigest() == c5["calls_sha256"]
+    assert sha(want) == c5["sha256"]
+    assert list(ref.state()) == c5["final_state"]
+    gpu = ra.ResamplerFir.new_from_hz(8, 96000, 44100, ra.Latency.Sample64, ra.Attenuation.Db120)
+    got, consumed, g_calls = gpu.resample_bulk(x, c5["chunk_values"], want_calls=True)
+    assert consumed == x.size and got.size == want.size
+    assert np.array_equal(g_calls, calls)
+    assert list(gpu.state()) == c5["final_state"]
+    tenth = want.size // 10
+    total = 0.0
+    for part in range(10):
+        a, b = part * tenth, (want.size if part == 9 else (part + 1) * tenth)
+        d = got[a:b].astype(np.float64) - want[a:b]
+        sq = float(np.dot(d, d))
+        assert np.sqrt(sq / (b - a)) <= RMS_TOL, (part, np.sqrt(sq / (b - a)))
+        total += sq
+    assert np.sqrt(total / want.size) <= RMS_TOL
