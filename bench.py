@@ -161,6 +161,8 @@ def device_copy_gbs(ctx: Ctx, nbytes: int) -> float:
     Tensor.copy_, which stops at 4.8-5.4 TB/s) on the bench's stream, torch events, 20 copies after 5."""
     import resampler_amd as ra
     torch = ctx.torch
+    if not hasattr(ra.lib(), "rsmp_device_stream_copy"):   # (an A/B library of an older commit)
+        return 0.0
     n = max(1 << 20, int(nbytes) // 4) // 4 * 4
     src = torch.empty(n, device=ctx.dev, dtype=torch.float32).normal_()
     dst = torch.empty_like(src)
@@ -680,7 +682,7 @@ def bench_fir(ctx: Ctx, args):
             "algorithmic_bytes": int(alg_bytes),
             # a plain device copy of the same volume on this GPU (read + written GB/s) and the kernel against it
             "device_copy": round(copy_gbs, 1),
-            "frac_of_device_copy": round(achieved / copy_gbs, 4),
+            "frac_of_device_copy": round(achieved / copy_gbs, 4) if copy_gbs else None,
             # useful f32 FMAs (128 taps per output value), T/s
             "fma_per_s": round(values_out_per_step * 128 / (k_ms * 1e-3) / 1e12, 2),
         },

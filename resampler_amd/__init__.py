@@ -208,7 +208,11 @@ def lib() -> C.CDLL:
         pass
     L = C.CDLL(LIB_PATH)
     for name, restype, argtypes in _SIGNATURES:
-        fn = getattr(L, name)
+        fn = getattr(L, name, None)
+        if fn is None and os.environ.get("RSMP_AMD_LIB"):
+            continue   # (an A/B library built from an older commit: tools/ab_headline.sh)
+        if fn is None:
+            raise ImportError(f"{LIB_PATH} does not export {name}: rebuild it")
         fn.restype = restype
         fn.argtypes = argtypes
     _lib = L
