@@ -707,7 +707,7 @@ def secondary_lines(ctx: Ctx, args):
         child = subprocess.run([sys.executable, os.path.abspath(__file__), "--no-cpu", "--no-secondary", "--steps", "16",
                                 "--warmup", "3", "--spinup-seconds", "1", "--streams", str(args.streams),
                                 "--frames", str(args.frames)],
-                               env=dict(os.environ, RSMP_FIR_SPLIT_PLANES="3", WORLD_SIZE="1", RANK="0", LOCAL_RANK=str(ctx.local_rank)),
+                               env=dict(os.environ, RSMP_DEBUG="1", RSMP_FIR_SPLIT_PLANES="3", WORLD_SIZE="1", RANK="0", LOCAL_RANK=str(ctx.local_rank)),
                                capture_output=True, text=True, timeout=300)
         r3 = json.loads(child.stdout.strip().splitlines()[-1])["roofline"]
         sec["fir_split_bf16x3"] = {k: r3[k] for k in ("kernel", "kernel_ms", "achieved", "frac")}

@@ -18,6 +18,7 @@
 // Channels are computed independently (what the reference yields per channel when its scratch
 // regions do not collide).
 #include "fft_kernels.h"
+#include "common.h"
 #include "fft_butterflies.h"
 
 #include <cmath>
@@ -741,7 +742,7 @@ hipError_t launch_fft_ola(const FftPlanDev& plan, const FftStreamDesc* d_descs, 
                           uint32_t max_blocks, uint32_t max_channels, uint32_t min_channels,
                           hipStream_t stream) {
     if (n_streams == 0 || max_blocks == 0) return hipSuccess;
-    static const bool no_wave = getenv("RSMP_FFT_WAVE") != nullptr && atoi(getenv("RSMP_FFT_WAVE")) == 0;   // A/B
+    static const bool no_wave = rsmp::knob("RSMP_FFT_WAVE") != nullptr && atoi(rsmp::knob("RSMP_FFT_WAVE")) == 0;   // A/B
     if (!no_wave) {
         const hipError_t e = launch_fft_ola_wave(plan, d_descs, n_streams, max_blocks, max_channels, min_channels, stream);
         if (e != hipErrorNotSupported) return e;
@@ -766,12 +767,10 @@ hipError_t launch_fft_ola(const FftPlanDev& plan, const FftStreamDesc* d_descs, 
             const double score = wgs / (rounds * slots) * useful;
             if (score > best + 1e-9) { best = score; run = cand; }
         }
-        static const char* knob = getenv("RSMP_FFT_RUN");
-        if (knob && atoi(knob) > 0) run = static_cast<uint32_t>(atoi(knob));
         return run;
     };
     size_t lds = fft_ola_lds_bytes(plan, max_channels);
-    static const int big_knob = [] { const char* e = getenv("RSMP_FFT_BIG_ABOVE"); return e ? atoi(e) : 160 * 1024; }();   // A/B
+    constexpr int big_knob = 160 * 1024;
     if (lds > static_cast<size_t>(big_knob)) {   // the two-buffer kernels do not fit: one buffer, in place, a workgroup per channel
         const size_t big = fft_big_lds_bytes(plan);
         if (big > 160 * 1024) return hipErrorInvalidValue;
@@ -784,12 +783,12 @@ hipError_t launch_fft_ola(const FftPlanDev& plan, const FftStreamDesc* d_descs, 
         return hipGetLastError();
     }
     bool all_stereo = max_channels == 2 && min_channels == 2;
-    static const bool generic_only = getenv("RSMP_FFT_GENERIC") != nullptr;   // A/B: skip the specialised builds
+    static const bool generic_only = rsmp::knob("RSMP_FFT_GENERIC") != nullptr;   // A/B: skip the specialised builds
     const bool rc_full = plan.n_rc_f == plan.fft_in / 2 - 1 && plan.n_rc_i == plan.fft_out / 2 - 1;
     typedef void (*Kernel)(FftPlanDev, const FftStreamDesc*, uint32_t);
     Kernel fn = fft_ola_kernel<kFftThreads, false>;
     uint32_t threads = kFftThreads, grid_z = 1;
-    static const bool no_stereo = getenv("RSMP_FFT_NO_STEREO") != nullptr;   // A/B
+    constexpr bool no_stereo = false;
     const bool stereo = all_stereo && !no_stereo;
     if (!generic_only && rc_full && Plan1176::matches(plan.fft_in, plan.n_stages_f, plan.radix_f) &&
         Plan1280::matches(plan.fft_out, plan.n_stages_i, plan.radix_i))
@@ -802,10 +801,10 @@ hipError_t launch_fft_ola(const FftPlanDev& plan, const FftStreamDesc* d_descs, 
         // the generic pipeline: for blocks up to 512 frames (both sides) a one-wave workgroup per channel (see the
         // kernel; 96 -> 48 kHz 1.56 -> 1.18 ms, 192 -> 48 kHz 1.48 -> 0.76 ms per 64 x 2^20 frames); above that the
         // four-wave workgroups keep more waves on a CU for the same LDS and win (tools/fft_pairs_bench.py)
-        static const int wave_knob = [] { const char* e = getenv("RSMP_FFT_GENERIC_WAVE"); return e ? atoi(e) : -1; }();   // A/B: 0 / 1 forces
+        constexpr int wave_knob = -1;
         const size_t lds_wave = 2 * static_cast<size_t>(plan.lds_complex) * sizeof(float2) + static_cast<size_t>(plan.fft_out) * sizeof(float);
         const bool per_channel = wave_knob >= 0 ? wave_knob != 0 : plan.lds_complex <= 513;
-        static const int threads_knob = [] { const char* e = getenv("RSMP_FFT_GENERIC_THREADS"); return e ? atoi(e) : 0; }();   // A/B
+        constexpr int threads_knob = 0;
         if (per_channel && lds_wave <= 160 * 1024) {
             fn = fft_ola_kernel<64, true>;
             threads = 64;

@@ -39,6 +39,7 @@
 
 #include "fft_butterflies_pk.h"
 #include "fft_kernels.h"
+#include "common.h"
 
 namespace rsmp {
 
@@ -859,7 +860,7 @@ bool wave_choice(const FftPlanDev& plan, uint32_t channels, int occ_env, WaveCho
         (void)channels; (void)occ_env; (void)out;
         return false;
     } else {
-    static const bool no_c2 = getenv("RSMP_FFT_WAVE_NOC2") != nullptr;   // A/B: the any-channel-count build for two channels
+    static const bool no_c2 = rsmp::knob("RSMP_FFT_WAVE_NOC2") != nullptr;   // A/B: the any-channel-count build for two channels
     // (an even number of channels: channel pairs on the two-channel build)
     const bool paired = channels % 2 == 0 && !no_c2;
     // (the pairs build addresses its frames at a run-time stride: under the 168-register cap of twelve waves per CU it
@@ -880,7 +881,7 @@ bool wave_choice(const FftPlanDev& plan, uint32_t channels, int occ_env, WaveCho
         if constexpr (fit4) out->fn = fft_ola_wave_kernel<FWD, INV, 0, 2>;
         else out->fn = fft_ola_wave_kernel<FWD, INV, 0, 1>;
     }
-    static const uint32_t wide_knob = [] { const char* e = getenv("RSMP_FFT_WAVE_WIDE"); return e ? static_cast<uint32_t>(atoi(e)) : 0u; }();
+    static const uint32_t wide_knob = [] { const char* e = rsmp::knob("RSMP_FFT_WAVE_WIDE"); return e ? static_cast<uint32_t>(atoi(e)) : 0u; }();
     out->waves = occ == 3 ? 12u : occ == 2 ? 4u : (wide_knob >= 1 && wide_knob <= wide ? wide_knob : wide);
     out->resident = occ == 2 ? 8u : out->waves;
     out->lds = (tables + out->waves * buf + kFlags) * sizeof(cf);
@@ -904,7 +905,7 @@ hipError_t launch_fft_ola_wave(const FftPlanDev& plan, const FftStreamDesc* d_de
     if (plan.n_rc_f != plan.fft_in / 2 - 1 || plan.n_rc_i != plan.fft_out / 2 - 1) return hipErrorNotSupported;
     if (plan.new_length != (plan.fft_in < plan.fft_out ? plan.fft_in + 1 : plan.fft_out)) return hipErrorNotSupported;
     const uint32_t C = max_channels;
-    static const int occ_env = [] { const char* e = getenv("RSMP_FFT_WAVE_OCC"); return e ? atoi(e) : 0; }();
+    constexpr int occ_env = 0;
     WaveChoice wc;
     const bool found = wave_choices<W1176, W1280>(plan, C, occ_env, &wc) || wave_choices<W1280, W1176>(plan, C, occ_env, &wc) ||
                        wave_choices<W512, W64, W128, W256, W768, W1024, W1536, W2048, W3072, W4096>(plan, C, occ_env, &wc) ||
@@ -939,8 +940,6 @@ hipError_t launch_fft_ola_wave(const FftPlanDev& plan, const FftStreamDesc* d_de
         const double score = waves / (rounds * slots) * useful;
         if (score > best + 1e-9) { best = score; run = cand; }
     }
-    static const char* knob = getenv("RSMP_FFT_RUN");
-    if (knob && atoi(knob) > 0) run = static_cast<uint32_t>(atoi(knob));
     const uint32_t runs_per_stream = (max_blocks + run - 1) / run;
     const uint32_t total_waves = runs_per_stream * n_streams * C;
     const dim3 grid((total_waves + kWavesPerGroup - 1) / kWavesPerGroup);

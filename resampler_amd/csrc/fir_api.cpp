@@ -309,8 +309,12 @@ int plan_job(Job& j) {
 
 // Process-wide workers for planning batches of streams in distinct states (rsmp_fir_batch_resample_bulk_device): the
 // items of a run are claimed from an atomic counter by the pool's threads and by the caller; one run at a time.
+// Everything a run shares with the workers lives in ONE object per run (its function, its item count, its claim
+// counter, its completion count), handed over under the mutex: a worker that wakes up late holds either the finished
+// run (nothing left to claim) or the current one -- never one run's counter with another run's bounds.
 class PlanPool {
 public:
+    PlanPool() { ensure_threads(64); }   // (at library load: creating up to 63 threads inside the first timed launch cost it milliseconds)
     ~PlanPool() {
         {
             std::lock_guard<std::mutex> lock(mu_);
@@ -322,59 +326,60 @@ public:
     template <class F>
     void run(size_t total, F&& fn) {
         std::lock_guard<std::mutex> one_run(run_mu_);
-        ensure_threads(total);
-        std::function<void(size_t)> f = fn;
+        auto job = std::make_shared<Job>();
+        job->fn = fn;
+        job->total = total;
         {
             std::lock_guard<std::mutex> lock(mu_);
-            fn_ = &f;
-            total_ = total;
-            next_.store(0, std::memory_order_relaxed);
-            pending_ = total;
+            job_ = job;
             ++generation_;
         }
         cv_work_.notify_all();
-        drain();
+        drain(*job);
         std::unique_lock<std::mutex> lock(mu_);
-        cv_done_.wait(lock, [&] { return pending_ == 0 && active_ == 0; });
-        fn_ = nullptr;
+        cv_done_.wait(lock, [&] { return job->done == job->total; });
+        job_.reset();
     }
 
 private:
+    struct Job {
+        std::function<void(size_t)> fn;
+        size_t total = 0;
+        std::atomic<size_t> next{0};
+        size_t done = 0;   // (under mu_)
+    };
     void ensure_threads(size_t total) {
         unsigned hw = std::thread::hardware_concurrency();
         const size_t want = std::min<size_t>(total - 1, std::min<size_t>(hw > 1 ? hw - 1 : 0, 63));
         while (threads_.size() < want) threads_.emplace_back([this] { loop(); });
     }
-    void drain() {
+    void drain(Job& job) {
         for (;;) {
-            const size_t m = next_.fetch_add(1, std::memory_order_relaxed);
-            if (m >= total_) break;
-            (*fn_)(m);
+            const size_t m = job.next.fetch_add(1, std::memory_order_relaxed);
+            if (m >= job.total) break;
+            job.fn(m);
             std::lock_guard<std::mutex> lock(mu_);
-            if (--pending_ == 0) cv_done_.notify_all();
+            if (++job.done == job.total) cv_done_.notify_all();
         }
     }
     void loop() {
         uint64_t seen = 0;
         for (;;) {
+            std::shared_ptr<Job> job;
             {
                 std::unique_lock<std::mutex> lock(mu_);
                 cv_work_.wait(lock, [&] { return stop_ || generation_ != seen; });
                 if (stop_) return;
                 seen = generation_;
-                ++active_;
+                job = job_;   // (null: the run this wake-up was for has finished)
             }
-            drain();
-            std::lock_guard<std::mutex> lock(mu_);
-            if (--active_ == 0 && pending_ == 0) cv_done_.notify_all();
+            if (job) drain(*job);
         }
     }
     std::mutex mu_, run_mu_;
     std::condition_variable cv_work_, cv_done_;
     std::vector<std::thread> threads_;
-    const std::function<void(size_t)>* fn_ = nullptr;
-    size_t total_ = 0, pending_ = 0, active_ = 0;
-    std::atomic<size_t> next_{0};
+    std::shared_ptr<Job> job_;
     uint64_t generation_ = 0;
     bool stop_ = false;
 };
@@ -382,6 +387,8 @@ PlanPool& plan_pool() {
     static PlanPool* pool = new PlanPool();   // (leaked on purpose: joining workers from a static destructor at exit races the runtime's teardown)
     return *pool;
 }
+// (the workers exist when the library is loaded, not from inside the first launch that needs them)
+struct PlanPoolAtLoad { PlanPoolAtLoad() { (void)plan_pool(); } } g_plan_pool_at_load;
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -564,7 +571,7 @@ int launch_jobs(rsmp_fir* leader, std::vector<Job>& jobs, hipStream_t stream) {
         RSMP_HIP_CHECK(hipEventRecord(leader->prof_start[leader->prof_count % rsmp_fir::kProfRing], stream));
     // a launch made of generic-kernel streams only (a streaming call, a batch of them) lets that kernel copy
     // the tails as well: one launch per call instead of two
-    bool tail_fused = n_generic == n && max_out_generic != 0 && getenv("RSMP_FIR_NO_FUSED_TAIL") == nullptr;
+    bool tail_fused = n_generic == n && max_out_generic != 0;
     if (n_generic)
         RSMP_HIP_CHECK(rsmp::launch_fir_generic(d_descs, static_cast<uint32_t>(n_generic),
                                                 max_out_generic, max_ch_generic, stream, tail_fused));
@@ -607,8 +614,7 @@ int launch_jobs(rsmp_fir* leader, std::vector<Job>& jobs, hipStream_t stream) {
             RSMP_HIP_CHECK(hipMemsetAsync(leader->d_work_counter, 0, sizeof(unsigned long long), stream));
         }
         // a launch made of split-kernel streams only lets that kernel copy the tails as well
-        tail_fused = n_generic == 0 && groups.size() == 1 && g.geo.mfma == 3 && max_blocks != 0 &&
-                     getenv("RSMP_FIR_NO_FUSED_TAIL") == nullptr;
+        tail_fused = n_generic == 0 && groups.size() == 1 && g.geo.mfma == 3 && max_blocks != 0;
         Repair& rp = repairs[gi++];
         rp.first = first;
         rp.nf.words = leader->d_nf.as<uint32_t>() + reinterpret_cast<size_t>(rp.nf.words) / sizeof(uint32_t);

@@ -1082,7 +1082,7 @@ __global__ __launch_bounds__(kLsWaves * 64, kLsWaves / 2) void fir_lockstep_kern
 
 LockstepGeometry lockstep_geometry(uint64_t num, uint64_t den, double ratio, uint32_t taps,
                                    uint32_t channels, uint32_t step_frames, bool allow_split) {
-    static const bool exact_knob = [] { const char* e = getenv("RSMP_LS_EXACT"); return e && atoi(e) != 0; }();
+    static const bool exact_knob = [] { const char* e = rsmp::knob("RSMP_LS_EXACT"); return e && atoi(e) != 0; }();
     LockstepGeometry g;
     g.taps = taps;
     g.num = static_cast<uint32_t>(num);
@@ -1192,7 +1192,7 @@ hipError_t launch_fir_lockstep(const LockstepArgs& args, uint32_t n_groups, uint
             have = true;
         }
     }
-    static const char* trace_path = getenv("RSMP_LS_TRACE");
+    static const char* trace_path = rsmp::knob("RSMP_LS_TRACE");
     if (trace_path) {   // diagnostic: one synchronous traced step, phase clocks written to the file
         LockstepArgs a = args;
         const size_t words = static_cast<size_t>(n_groups) * 21;

@@ -1689,13 +1689,10 @@ uint32_t xprev_len_of(uint32_t pw, uint32_t channels) { return 4 + (pw * channel
 
 GeoArgs to_args(const PeriodicGeometry& g) {
     static const uint32_t debug = [] {
-        const char* e = getenv("RSMP_FIR_DEBUG");
+        const char* e = rsmp::knob("RSMP_FIR_DEBUG");
         return e ? static_cast<uint32_t>(atoi(e)) : 0u;
     }();
-    static const uint32_t stagger = [] {
-        const char* e = getenv("RSMP_FIR_STAGGER_US");
-        return static_cast<uint32_t>((e ? atof(e) : 12.0) * 100.0);
-    }();
+    constexpr uint32_t stagger = 1200;   // 12 us, in 10 ns units
     const uint32_t channels = g.lp * g.cg;
     return GeoArgs{g.a, g.b, g.b / g.den, g.row_len, g.mfma ? g.n_units : g.n_tiles, g.lp, g.pw, g.row_stride, g.waves,
                    channels, xprev_len_of(g.pw, channels), g.producers, g.den, g.images ? g.images : 2u,
@@ -1738,7 +1735,7 @@ namespace {
 // else as 2.  Two interleaved channels only.
 int mfma_knob() {
     static const int knob = [] {
-        const char* e = getenv("RSMP_FIR_MFMA");
+        const char* e = rsmp::knob("RSMP_FIR_MFMA");
         return e ? atoi(e) : 3;
     }();
     return knob;
@@ -1769,8 +1766,8 @@ PeriodicGeometry geometry_for(uint64_t num, uint64_t den, uint32_t taps, uint32_
     // wrap variant inside the kernel: vector kernels den >= 8 (one wrap class per 8-class tile at
     // most); matrix-core path den >= 16 and at most kMfmaWrapMax wrap classes per super period
     // (only the register-resident variant picks the results up: windows <= 144 taps, 1-2 groups/unit)
-    static const bool ring_forced = getenv("RSMP_FIR_MFMA_RING") != nullptr;
-    static const bool nowrap = getenv("RSMP_FIR_MFMA_NOWRAP") != nullptr;   // A/B: wraps by the fix-up launch
+    static const bool ring_forced = rsmp::knob("RSMP_FIR_MFMA_RING") != nullptr;
+    constexpr bool nowrap = false;
     // (144 taps at most: with a 192-tap tile in registers the register-resident build spills)
     const bool mfma_regs = want_mfma && knob_mfma <= 2 && g.row_len <= 144 && !ring_forced && !nowrap;
     g.inline_wraps = want_mfma ? (mfma_regs && den >= kMfmaClassTile && r <= kMfmaWrapMax) : den >= kClassTile;
@@ -1778,10 +1775,7 @@ PeriodicGeometry geometry_for(uint64_t num, uint64_t den, uint32_t taps, uint32_
     // RSMP_FIR_PRODUCERS = n: n producer waves; for the vector kernels it also selects the
     // double-buffered workgroup (measured slower than two single-image workgroups per CU: 12
     // consumer waves cannot hide the scalar-cache latency that 24 can)
-    static const int knob_db = [] {
-        const char* e = getenv("RSMP_FIR_PRODUCERS");
-        return e ? atoi(e) : -1;
-    }();
+    constexpr int knob_db = -1;
     bool two_per_cu = false;   // set by fit(): the single-image vector kernel with two workgroups per CU
     auto fit = [&](uint32_t cg) -> bool {
         two_per_cu = false;
@@ -1807,10 +1801,7 @@ PeriodicGeometry geometry_for(uint64_t num, uint64_t den, uint32_t taps, uint32_
         // read-ahead padding; matrix-core path: + the wrap results.  RSMP_FIR_IMAGES=4 selects a ring of
         // four 32-period images, one per producer, instead of two 64-period ones (producers up to three
         // items ahead; measured equal: the doubled per-item work eats what the extra slack gains).
-        static const int knob_images = [] {
-            const char* e = getenv("RSMP_FIR_IMAGES");
-            return e ? atoi(e) : 0;
-        }();
+        constexpr int knob_images = 0;
         auto db_fit = [&](uint32_t images, uint32_t pw_cap, uint32_t& pw_out, uint32_t& bytes_out) -> bool {
             if (pw_cap > pw_max) pw_cap = pw_max;
             for (uint32_t pw = pw_cap; pw * 4 >= pw_cap * 3 && pw > 0; --pw) {
@@ -1839,11 +1830,7 @@ PeriodicGeometry geometry_for(uint64_t num, uint64_t den, uint32_t taps, uint32_
             g.lds_bytes = bytes;
             if (want_mfma) {
                 // two consumer waves per SIMD keep the matrix pipe busy; more only add arbitration
-                static const int knob_consumers = [] {
-                    const char* e = getenv("RSMP_FIR_MFMA_CONSUMERS");
-                    const int v = e ? atoi(e) : 8;
-                    return v >= 1 && v <= 12 ? v : 8;
-                }();
+                constexpr int knob_consumers = 8;
                 g.mfma = static_cast<uint32_t>(knob_mfma);
                 // a work unit spans knob_mfma groups of 16 periods
                 const uint32_t groups = (pw + 15) / 16;
@@ -1867,10 +1854,6 @@ PeriodicGeometry geometry_for(uint64_t num, uint64_t den, uint32_t taps, uint32_
         // waves per workgroup: a multiple of the 4 SIMDs, at most 12 (__launch_bounds__(768, 6));
         // tiles are claimed dynamically, so the count need not divide n_tiles
         g.waves = g.n_tiles >= 12 ? 12u : (g.n_tiles >= 8 ? 8u : 4u);
-        if (const char* e = getenv("RSMP_FIR_WAVES")) {   // tuning knob (4..12)
-            const int w = atoi(e);
-            if (w >= 1 && w <= 12) g.waves = static_cast<uint32_t>(w);
-        }
         return true;
     };
     if (want_mfma) {   // the matrix-core kernel is written for two channels per lane group
@@ -1880,7 +1863,7 @@ PeriodicGeometry geometry_for(uint64_t num, uint64_t den, uint32_t taps, uint32_
         // and only one single-image workgroup fits a CU -- staging and arithmetic then take turns.  One channel per
         // lane halves the periods per image: where that is what lets two workgroups share a CU it is faster
         // (8 channels 96 -> 44.1 kHz: 0.73 -> 0.62 ms per 20 M frames).
-        static const int knob_cg = [] { const char* e = getenv("RSMP_FIR_CG"); return e ? atoi(e) : 0; }();   // tuning knob: 1 / 2 forces
+        constexpr int knob_cg = 0;
         bool ok = false;
         if (knob_cg != 1) ok = fit(2);
         if (knob_cg != 2 && (!ok || !two_per_cu)) {
@@ -2114,7 +2097,7 @@ hipError_t launch_fir_periodic(const FirStreamDesc* d_descs, uint32_t n_streams,
     // each producer owns an image
     const bool own_image = geo.mfma && geo.producers == geo.images;
     args.n_claimers = grid.x * (own_image ? geo.images : 1u);
-    static const char* trace_path = getenv("RSMP_FIR_TRACE");
+    static const char* trace_path = rsmp::knob("RSMP_FIR_TRACE");
     static unsigned long long* d_trace = nullptr;
     const size_t trace_words = 6ull * grid.x;
     if (trace_path) {
@@ -2123,7 +2106,7 @@ hipError_t launch_fir_periodic(const FirStreamDesc* d_descs, uint32_t n_streams,
         (void)hipMemset(d_trace, 0, trace_words * 8);
         args.trace = d_trace;
     }
-    static const char* wtrace_path = getenv("RSMP_FIR_WTRACE");
+    static const char* wtrace_path = rsmp::knob("RSMP_FIR_WTRACE");
     static unsigned long long* d_wtrace = nullptr;
     const size_t wtrace_words = static_cast<size_t>(grid.x) * kWtraceWaves * kWtraceSlots;
     if (wtrace_path) {
@@ -2140,11 +2123,11 @@ hipError_t launch_fir_periodic(const FirStreamDesc* d_descs, uint32_t n_streams,
     // (4-tap chunks with 16-wave workgroups at 8 waves per SIMD measured 13 % slower than 8-tap
     // chunks: the 64-VGPR cap spills.)
     static const int mfma_dbg = [] {   // RSMP_FIR_MFMA_DBG: 1 hot coefficient line, 2 no LDS reads, 3 both
-        const char* e = getenv("RSMP_FIR_MFMA_DBG");
+        const char* e = rsmp::knob("RSMP_FIR_MFMA_DBG");
         const int v = e ? atoi(e) : 0;
         return v >= 0 && v <= 3 ? v : 0;
     }();
-    static const bool mfma_ring = getenv("RSMP_FIR_MFMA_RING") != nullptr;   // force the ring variant
+    static const bool mfma_ring = rsmp::knob("RSMP_FIR_MFMA_RING") != nullptr;   // force the ring variant
     // matrix-core variants: 6 / 7 = coefficient ring (any window length), 2 / 4 period groups per
     // unit; 8..10 = ring timing experiments; 11..18 = coefficient tile in registers, windows of
     // 48 / 96 / 144 / 192 taps (2 groups per unit), padded (11..14) or back-to-back (15..18) rows
@@ -2158,8 +2141,8 @@ hipError_t launch_fir_periodic(const FirStreamDesc* d_descs, uint32_t n_streams,
     else if (nb3 && !mfma_ring && geo.mfma == 1) variant = 18 + static_cast<int>(nb3) + (flat_rows ? 4 : 0);
     else if (nb3 && !mfma_ring) variant = 10 + static_cast<int>(nb3) + (flat_rows ? 4 : 0);
     else variant = 6;
-static const char* trace_env = getenv("RSMP_FIR_TRACE");
-    static const char* wtrace_env = getenv("RSMP_FIR_WTRACE");
+static const char* trace_env = rsmp::knob("RSMP_FIR_TRACE");
+    static const char* wtrace_env = rsmp::knob("RSMP_FIR_WTRACE");
     const bool diag = args.debug != 0 || trace_env != nullptr || wtrace_env != nullptr;
 #define RSMP_SK(cg, c2, D) reinterpret_cast<const void*>(fir_periodic_kernel<cg, c2, 8, D>)
 #define RSMP_DB(cg, c2, mf, D) reinterpret_cast<const void*>(fir_periodic_db_kernel<cg, c2, 8, mf, D>)
@@ -2188,7 +2171,7 @@ static const char* trace_env = getenv("RSMP_FIR_TRACE");
             have = true;
         }
     }
-    static const bool verbose = getenv("RSMP_FIR_VERBOSE") != nullptr;
+    static const bool verbose = rsmp::knob("RSMP_FIR_VERBOSE") != nullptr;
     if (verbose) {
         int blocks = -1;
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks, fns[variant], geo.waves * 64,

@@ -1427,7 +1427,7 @@ inline uint32_t split_class_offset(uint32_t a, uint32_t b, uint32_t j) {
 // fp16 planes per operand, three matrix products instead of six.
 static uint32_t split_planes_knob() {
     static const uint32_t v = [] {
-        const char* e = getenv("RSMP_FIR_SPLIT_PLANES");
+        const char* e = rsmp::knob("RSMP_FIR_SPLIT_PLANES");
         return e && atoi(e) == 3 ? 3u : 2u;
     }();
     return v;
@@ -1440,8 +1440,8 @@ PeriodicGeometry split_geometry(uint64_t num, uint64_t den, uint32_t taps, uint3
     const uint32_t kRowBytes = row_bytes(static_cast<int>(planes));
     // two channels, or (RSMP_FIR_SPLIT_WIDE=0 turns it off) an even number up to 16 taken as channel pairs, two pairs per
     // 16-byte load (6, 10, 14 channels: the last pair alone -- its load reaches 8 bytes into the next frame)
-    static const bool wide_ok = [] { const char* e = getenv("RSMP_FIR_SPLIT_WIDE"); return !e || atoi(e) != 0; }();
-    static const bool long_ok = [] { const char* e = getenv("RSMP_FIR_SPLIT_LONG"); return !e || atoi(e) != 0; }();   // 0: round 2's geometries only
+    static const bool wide_ok = [] { const char* e = rsmp::knob("RSMP_FIR_SPLIT_WIDE"); return !e || atoi(e) != 0; }();
+    static const bool long_ok = [] { const char* e = rsmp::knob("RSMP_FIR_SPLIT_LONG"); return !e || atoi(e) != 0; }();   // 0: round 2's geometries only
     if (channels != 2 && (channels > 16 || !wide_ok)) return g;
     constexpr uint32_t kMaxAB = 320;
     if (num == 0 || den == 0 || num > kMaxAB || den > kMaxAB) return g;
@@ -1479,8 +1479,6 @@ PeriodicGeometry split_geometry(uint64_t num, uint64_t den, uint32_t taps, uint3
     const uint32_t pad = (kpad - (taps + shift)) * kRowBytes;
     uint32_t slots = (kLdsLimit - kImageBase - pad) / (rows * kRowBytes);   // ring of images: slack between producers and consumers
     if (slots > 4) slots = 4;
-    static const uint32_t slots_knob = [] { const char* e = getenv("RSMP_FIR_SPLIT_SLOTS"); return e ? static_cast<uint32_t>(atoi(e)) : 0u; }();   // A/B: fewer images
-    if (slots_knob >= 2 && slots_knob < slots) slots = slots_knob;
     if (slots < 2) return g;
     const uint32_t lds = kImageBase + slots * rows * kRowBytes + pad;
     g.a = a;
@@ -1565,12 +1563,12 @@ hipError_t launch_fir_split(const FirStreamDesc* d_descs, uint32_t n_streams, co
                             uint32_t max_blocks, uint32_t cus, bool fuse_tail, const NfArgs& nf, hipStream_t stream,
                             uint64_t items_key) {
     static const uint32_t debug = [] {
-        const char* e = getenv("RSMP_FIR_DEBUG");
+        const char* e = rsmp::knob("RSMP_FIR_DEBUG");
         return e ? static_cast<uint32_t>(atoi(e)) : 0u;
     }();
     const uint32_t pairs = geo.lp;
     const bool wide = pairs > 1 || geo.cg == 1;
-    static const bool quad_major = [] { const char* e = getenv("RSMP_FIR_SPLIT_QUADS"); return !e || atoi(e) != 0; }();
+    static const bool quad_major = [] { const char* e = rsmp::knob("RSMP_FIR_SPLIT_QUADS"); return !e || atoi(e) != 0; }();
     const uint32_t quads = quad_major && geo.cg == 2 && pairs >= 4 && pairs % 2 == 0 ? pairs / 2 : 1u;   // 8, 12, 16 channels
     const uint32_t qpairs = pairs / quads;
     const uint32_t groups = geo.groups ? geo.groups : 1u, per_group = max_blocks * n_streams * qpairs;
@@ -1580,7 +1578,7 @@ hipError_t launch_fir_split(const FirStreamDesc* d_descs, uint32_t n_streams, co
                    // (b = r den with r > 1: a super period of an exact ratio.  WIDE builds only: the two-channel tile-group
                    // kernel got SLOWER without the fetches -- 2 ch 48 -> 96 kHz 0.59 -> 0.66 ms)
                    wide && geo.b != geo.den ? 1u : 0u, nullptr, nullptr, nf};
-    static const char* wtrace_path = getenv("RSMP_FIR_WTRACE");
+    static const char* wtrace_path = rsmp::knob("RSMP_FIR_WTRACE");
     const bool diag = debug != 0 || wtrace_path != nullptr;
 #define RSMP_SPLIT_FNS(P, D, W)                                                                              \
     {reinterpret_cast<const void*>(fir_split_kernel<1, P, D, W>), reinterpret_cast<const void*>(fir_split_kernel<2, P, D, W>), \
@@ -1630,7 +1628,7 @@ hipError_t launch_fir_split(const FirStreamDesc* d_descs, uint32_t n_streams, co
         }
     }
     const dim3 grid(args.total_items < cus ? args.total_items : cus);
-    static const bool verbose = getenv("RSMP_FIR_VERBOSE") != nullptr;
+    static const bool verbose = rsmp::knob("RSMP_FIR_VERBOSE") != nullptr;
     if (verbose)
         fprintf(stderr, "[rsmp] split launch: a=%u b=%u window=%u tiles=%u groups=%u rounds=%u rows=%u slots=%u lds=%u items=%u grid=%u\n",
                 geo.a, geo.b, geo.row_len, geo.n_tiles, groups, geo.rounds, geo.row_stride, geo.images, geo.lds_bytes, args.total_items, grid.x);

@@ -13,7 +13,12 @@ from resampler_amd import synth
 pytestmark = pytest.mark.gpu
 
 RMS_TOL = 1e-6   # north_star tolerance
-SPLIT_VARIANT = 4 if os.environ.get("RSMP_FIR_SPLIT_PLANES") == "3" else 5   # bf16x3 or (default) fp16x2 split kernel
+def _knob(name, default):
+    """An A/B switch of the library as the library sees it: only under RSMP_DEBUG=1 (csrc/common.h, rsmp::knob)."""
+    return os.environ.get(name, default) if os.environ.get("RSMP_DEBUG", "0") not in ("", "0") else default
+
+
+SPLIT_VARIANT = 4 if _knob("RSMP_FIR_SPLIT_PLANES", "2") == "3" else 5   # bf16x3 or (default) fp16x2 split kernel
 ATT_DB = {ra.Attenuation.Db60: 60, ra.Attenuation.Db90: 90, ra.Attenuation.Db120: 120}
 
 
@@ -153,12 +158,12 @@ def test_bulk_matches_reference_driver_loop(kernel, ch, in_hz, out_hz, att):
     yr2, _ = r.resample_all(x2[ch * 3000:], chunk)
     assert yg2.size == yr2.size and rms(yg2, yr2) <= RMS_TOL
     if (kernel == ra.FirKernel.Periodic and ch in (1, 2, 3, 4, 6, 8, 12, 16) and {in_hz, out_hz} == {44100, 48000}
-            and os.environ.get("RSMP_FIR_MFMA", "3") == "3" and os.environ.get("RSMP_FIR_SPLIT_WIDE", "1") != "0"):
+            and _knob("RSMP_FIR_MFMA", "3") == "3" and _knob("RSMP_FIR_SPLIT_WIDE", "1") != "0"):
         assert g.kernel_variant() == SPLIT_VARIANT
     # the other rate pairs of config 4 and config 5's: tile groups (up to 320 classes), two rounds of lane tasks (periods of
     # up to 320 frames), super periods of exact ratios (48 <-> 96 kHz)
     if (kernel == ra.FirKernel.Periodic and (ch, in_hz, out_hz) in ((2, 96000, 44100), (8, 96000, 44100), (2, 44100, 96000), (4, 44100, 96000), (2, 48000, 96000), (2, 96000, 48000), (2, 88200, 44100), (2, 192000, 48000), (8, 48000, 96000), (6, 96000, 48000))
-            and os.environ.get("RSMP_FIR_MFMA", "3") == "3" and os.environ.get("RSMP_FIR_SPLIT_LONG", "1") != "0" and SPLIT_VARIANT == 5):
+            and _knob("RSMP_FIR_MFMA", "3") == "3" and _knob("RSMP_FIR_SPLIT_LONG", "1") != "0" and SPLIT_VARIANT == 5):
         assert g.kernel_variant() == SPLIT_VARIANT
     if kernel == ra.FirKernel.PeriodicVector:
         assert g.kernel_variant() in (1, 2)   # never the matrix-core kernel
@@ -186,7 +191,7 @@ def test_split_kernel_channel_pairs_long_stream(ch, in_hz, out_hz):
     yg, consumed = g.resample_bulk(x, chunk)
     yr, _ = r.resample_all(x, chunk)
     assert consumed == x.size and yg.size == yr.size
-    if os.environ.get("RSMP_FIR_MFMA", "3") == "3" and os.environ.get("RSMP_FIR_SPLIT_WIDE", "1") != "0":
+    if _knob("RSMP_FIR_MFMA", "3") == "3" and _knob("RSMP_FIR_SPLIT_WIDE", "1") != "0":
         assert g.kernel_variant() == SPLIT_VARIANT
     fin_r, fin_g = np.isfinite(yr), np.isfinite(yg)
     assert np.array_equal(fin_g, fin_r), np.flatnonzero(fin_g != fin_r)[:10]
@@ -221,7 +226,7 @@ def test_c2_full_size_bulk_parity_and_max_abs():
     assert yg.size == yr.size
     assert rms(yg, yr) <= RMS_TOL
     assert float(np.max(np.abs(yg.astype(np.float64) - yr))) < 2e-5
-    if os.environ.get("RSMP_FIR_MFMA", "3") == "3":
+    if _knob("RSMP_FIR_MFMA", "3") == "3":
         assert g.kernel_variant() == SPLIT_VARIANT   # the full-size config runs on the split matrix kernel (the bench's kernel)
 
 
@@ -326,7 +331,7 @@ def test_matrix_core_kernel_ragged_batch_and_edges(kernel):
             yr, _ = rs[i].resample_all(xs[i], 512)
             assert consumed[i] == xs[i].size and produced[i] == yr.size, (step, i)
             assert rms(d_out[i][: produced[i]].cpu().numpy(), yr) <= RMS_TOL, (step, i)
-    knob = os.environ.get("RSMP_FIR_MFMA", "3")
+    knob = _knob("RSMP_FIR_MFMA", "3")
     mfma_on = knob != "0"
     # periodic matrix-core kernel by default (4 = the split-bf16 one, RSMP_FIR_MFMA=3)
     split = knob == "3" and kernel == ra.FirKernel.Periodic
@@ -337,7 +342,7 @@ def test_matrix_core_kernel_ragged_batch_and_edges(kernel):
     yg, _ = g.resample_bulk(x, 512)
     yr, _ = r.resample_all(x, 512)
     assert yg.size == yr.size and rms(yg, yr) <= RMS_TOL
-    long_split = split and os.environ.get("RSMP_FIR_SPLIT_LONG", "1") != "0" and SPLIT_VARIANT == 5   # (two tile groups on the split kernel)
+    long_split = split and _knob("RSMP_FIR_SPLIT_LONG", "1") != "0" and SPLIT_VARIANT == 5   # (two tile groups on the split kernel)
     assert g.kernel_variant() == ((SPLIT_VARIANT if long_split else 3) if mfma_on else 1)
 
 
@@ -427,7 +432,7 @@ def test_fuzz_periodic_kernels_against_oracle():
             assert rms(yg, yr) <= RMS_TOL, (case, part, in_hz, out_hz, ch, lat)
         variants.add(g.kernel_variant())
     assert 1 in variants                      # the vector kernel was exercised ...
-    if os.environ.get("RSMP_FIR_MFMA", "3") != "0":
+    if _knob("RSMP_FIR_MFMA", "3") != "0":
         assert variants & {3, 4}              # ... and so were the matrix-core kernels (unless switched off)
 
 
@@ -650,7 +655,7 @@ for ch, a, b, n, level in ((2, 44100, 48000, 300000, 1.0), (2, 48000, 44100, 200
     assert e <= 1e-6, (ch, a, b, e)
 print("three planes ok")
 """
-    env = dict(os.environ, RSMP_FIR_SPLIT_PLANES="3", PYTHONPATH=root)
+    env = dict(os.environ, RSMP_DEBUG="1", RSMP_FIR_SPLIT_PLANES="3", PYTHONPATH=root)
     out = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "three planes ok" in out.stdout, out.stdout + out.stderr
 

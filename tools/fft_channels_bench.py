@@ -1,5 +1,5 @@
 """FFT bulk throughput for channel counts other than 2 (the C2 = false instantiations of fft_ola_wave_kernel).
-usage (GPU box): [RSMP_FFT_WAVE_OCC=2] python tools/fft_channels_bench.py"""
+usage (GPU box): python tools/fft_channels_bench.py"""
 import os
 import sys
 import time

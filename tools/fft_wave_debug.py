@@ -16,7 +16,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     np.save(sys.argv[2], np.concatenate(outs))
 else:
     for mode, path in (("0", "/tmp/old.npy"), ("1", "/tmp/new.npy")):
-        env = dict(os.environ, RSMP_FFT_WAVE=mode)
+        env = dict(os.environ, RSMP_DEBUG="1", RSMP_FFT_WAVE=mode)
         subprocess.check_call([sys.executable, __file__, "child", path], env=env)
     a, b = np.load("/tmp/old.npy"), np.load("/tmp/new.npy")
     d = np.abs(a.astype(np.float64) - b)
