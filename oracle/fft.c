@@ -347,6 +347,12 @@ static void stage(const c32* src, c32* dst, size_t n, int r, size_t stride, cons
     }
 }
 
+/* One stage on caller-owned arrays: what the reference's own butterfly tests call (butterfly8/mod.rs:616-697,
+ * butterflies/mod.rs:129-290).  tw: (radix - 1) twiddles per column, unused when stride == 1. */
+void orc_butterfly_stage(const orc_c32* src, orc_c32* dst, size_t n, int radix, size_t stride, const orc_c32* tw) {
+    stage((const c32*)src, (c32*)dst, n, radix, stride, (const c32*)tw);
+}
+
 /* stockham_autosort.rs:169-247 (ping-pong; returns 1 when the result is in `scratch`), with the
  * single-factor special case of radix_fft.rs:476-497 (result copied back to data). */
 static int stockham(const orc_rfft* f, c32* data, c32* scratch) {

@@ -95,6 +95,8 @@ size_t orc_rfft_stage_factors(const orc_rfft* f, int* out);  /* the n/2-point st
 void orc_rfft_forward(orc_rfft* f, const float* in, orc_c32* out);
 /* inverse: n/2+1 complex -> n reals, unnormalised (radix_fft.rs:565-589). */
 void orc_rfft_inverse(orc_rfft* f, const orc_c32* in, float* out);
+/* one out-of-place Stockham stage of the scalar butterfly specs (butterfly{2,3,4,5,7,8}/mod.rs) on n complex values */
+void orc_butterfly_stage(const orc_c32* src, orc_c32* dst, size_t n, int radix, size_t stride, const orc_c32* tw);
 
 typedef struct orc_fft_resampler orc_fft_resampler;
 orc_fft_resampler* orc_fft_new(size_t channels, uint32_t in_hz, uint32_t out_hz); /* resampler_fft.rs:75-119 */

@@ -134,6 +134,7 @@ struct rsmp_fft {
     hipStream_t stream = nullptr;
     hipStream_t last_stream = nullptr;   // the stream of the handle's previous launch (launches of one handle are ordered)
     bool last_stream_valid = false;
+    hipEvent_t last_launch = nullptr;    // recorded behind the handle's most recent launch, on that launch's stream
     hipEvent_t desc_copied = nullptr;
     bool desc_pending = false;
     PinnedBuffer h_desc;
@@ -166,7 +167,10 @@ int launch_fft_jobs(rsmp_fft* leader, const std::vector<FftJob>& jobs, hipStream
             return rsmp::fail(RSMP_ERR_INVALID_ARGUMENT, "ResamplerFft batch: handle %zu is listed twice", i);
     for (size_t i = 0; i < n; ++i) {
         rsmp_fft* h = jobs[i].r;
-        if (h->last_stream_valid && h->last_stream != stream) RSMP_HIP_CHECK(hipStreamSynchronize(h->last_stream));
+        // (an event, not the previous stream's handle: the caller may have destroyed that stream by now, and a wait on an
+        // event neither blocks the host nor breaks a stream capture)
+        if (h->last_stream_valid && h->last_stream != stream && h->last_launch)
+            RSMP_HIP_CHECK(hipStreamWaitEvent(stream, h->last_launch, 0));
         h->last_stream = stream;
         h->last_stream_valid = true;
     }
@@ -204,8 +208,10 @@ int launch_fft_jobs(rsmp_fft* leader, const std::vector<FftJob>& jobs, hipStream
         RSMP_HIP_CHECK(hipEventRecord(leader->prof_stop, stream));
         leader->prof_valid = true;
     }
-    for (const FftJob& j : jobs)
+    for (const FftJob& j : jobs) {
         if (j.n_blocks != 0) j.r->cur ^= 1;   // (a stream without blocks in this launch keeps its state where it is)
+        if (j.r->last_launch) RSMP_HIP_CHECK(hipEventRecord(j.r->last_launch, stream));
+    }
     return RSMP_OK;
 }
 
@@ -248,7 +254,8 @@ extern "C" rsmp_fft* rsmp_fft_new(size_t channels, int input_rate, int output_ra
     if (hipMalloc(&r->d_overlap, ov_bytes) != hipSuccess || hipMemset(r->d_overlap, 0, ov_bytes) != hipSuccess ||
         hipStreamSynchronize(nullptr) != hipSuccess ||   // (the handle's stream is non-blocking: no implicit order)
         hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&r->desc_copied, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&r->desc_copied, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&r->last_launch, hipEventDisableTiming) != hipSuccess) {
         rsmp::fail(RSMP_ERR_HIP, "ResamplerFft: cannot allocate stream state");
         if (r->d_overlap) (void)hipFree(r->d_overlap);
         return nullptr;
@@ -262,6 +269,7 @@ extern "C" void rsmp_fft_free(rsmp_fft* r) {
     (void)hipDeviceSynchronize();
     if (r->d_overlap) (void)hipFree(r->d_overlap);
     if (r->desc_copied) (void)hipEventDestroy(r->desc_copied);
+    if (r->last_launch) (void)hipEventDestroy(r->last_launch);
     if (r->prof_start) (void)hipEventDestroy(r->prof_start);
     if (r->prof_stop) (void)hipEventDestroy(r->prof_stop);
     if (r->stream) (void)hipStreamDestroy(r->stream);

@@ -113,7 +113,8 @@ def test_streams_of_very_different_levels_keep_their_relative_precision():
         xs.append(x.astype(np.float32))
     worst, ls, hs, refs = run_lockstep(specs, steps=steps, frames=frames, x_override=xs, relative=True)
     assert worst <= RMS_TOL, worst
-    # (3e4 overflows nothing: the scale follows the column's peak; only samples of 2^8 and above go to the reference form)
+    # (3e4 overflows nothing: the scale follows the stream's peak; no scale is derived from a peak of 2^11 and above --
+    # kLsPeakMax -- so samples of 2^13 and above overflow the planes and go to the reference form)
     ls.close()
 
 

@@ -172,3 +172,30 @@ def test_driver_loop_pads_the_tail_and_trims_like_the_cli():
     for k in range(4):
         assert r2.resample(xp[k * ci:(k + 1) * ci], want[k * co:(k + 1) * co]) == 0
     assert np.array_equal(y, want[:y.size])
+
+
+def test_radix8_butterfly_against_the_references_fixed_vectors():   # butterfly8/mod.rs:616-697
+    """The four fixed inputs of the reference's test_radix8_vs_naive_dft through the oracle's radix-8 stage (stride 1,
+    identity twiddles), against the naive f32 DFT the reference compares with (:593-611), at its tolerance of 1e-5."""
+    import ctypes as C
+    import json
+    import os
+    ka = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_known_answers.json")))["radix8_vs_naive_dft"]
+    L = o.lib()
+    L.orc_butterfly_stage.restype = None
+    L.orc_butterfly_stage.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_size_t, C.c_void_p]
+    assert len(ka["inputs"]) == 4
+    for case in ka["inputs"]:
+        x = np.array(case, np.float32)            # [8][re, im]
+        dst = np.zeros_like(x)
+        tw = np.tile(np.array([[1.0, 0.0]], np.float32), (7, 1))
+        L.orc_butterfly_stage(x.ctypes.data, dst.ctypes.data, 8, 8, 1, tw.ctypes.data)
+        z = x[:, 0].astype(np.complex64) + 1j * x[:, 1].astype(np.complex64)
+        want = np.zeros(8, np.complex64)
+        for k in range(8):                         # the reference's naive DFT in f32
+            acc = np.complex64(0)
+            for i in range(8):
+                ang = np.float32(-2.0) * np.float32(np.pi) * np.float32(k * i) / np.float32(8)
+                acc = np.complex64(acc + np.complex64(complex(np.cos(ang, dtype=np.float32), np.sin(ang, dtype=np.float32))) * z[i])
+            want[k] = acc
+        assert np.max(np.abs(dst[:, 0] - want.real)) < ka["tolerance"] and np.max(np.abs(dst[:, 1] - want.imag)) < ka["tolerance"]

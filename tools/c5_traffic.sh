@@ -1,8 +1,10 @@
 #!/bin/bash
 # tools/c5_traffic.sh -- HBM traffic of config 5's bulk launch: separate FETCH_SIZE / WRITE_SIZE passes (the guide's gfx950
 # correction: FETCH_SIZE x 2) against the algorithmic bytes.  Run from the repository root on the GPU box.
+set -eu
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; O=$R/gpurun_out/c5traffic
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/c5traffic; rm -rf $O; mkdir -p $O
+rm -rf "$O"; mkdir -p "$O"
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout -k 5 300 rocprofv3 --pmc $c --output-format csv -d $O/$c -- python3 $R/bench.py --config c5 --steps 2 --warmup 1 --spinup-seconds 0 > $O/$c.json 2> $O/$c.err
 done
