@@ -60,6 +60,8 @@ pub enum Attenuation { Db60 = 0, Db90, #[default] Db120 }
 type rsmp_fir = c_void;
 #[allow(non_camel_case_types)]
 type rsmp_fft = c_void;
+#[allow(non_camel_case_types)]
+type rsmp_fir_lockstep = c_void;
 
 extern "C" {
     fn rsmp_fir_new(channels: usize, input_rate: c_int, output_rate: c_int, latency: c_int,
@@ -85,6 +87,19 @@ extern "C" {
     fn rsmp_fir_taps(r: *const rsmp_fir) -> usize;
     fn rsmp_fir_phases(r: *const rsmp_fir) -> usize;
     fn rsmp_fft_channels(r: *const rsmp_fft) -> usize;
+    // additions to the reference API: a fixed set of streams stepped together on device-resident state
+    fn rsmp_fir_lockstep_new(rs: *const *mut rsmp_fir, n: usize, max_step_frames: usize) -> *mut rsmp_fir_lockstep;
+    fn rsmp_fir_lockstep_free(ls: *mut rsmp_fir_lockstep);
+    fn rsmp_fir_lockstep_bind(ls: *mut rsmp_fir_lockstep, d_in: *const *const f32, d_out: *const *mut f32,
+                              out_caps: *const usize) -> c_int;
+    fn rsmp_fir_lockstep_step(ls: *mut rsmp_fir_lockstep, in_frames: usize, in_offset_frames: usize,
+                              d_in_frames: *const u32, append: c_int, stream: *mut c_void) -> c_int;
+    fn rsmp_fir_lockstep_run(ls: *mut rsmp_fir_lockstep, k_steps: usize, in_frames: usize, in_offset_frames: usize,
+                             append: c_int, stream: *mut c_void) -> c_int;
+    fn rsmp_fir_lockstep_counts(ls: *mut rsmp_fir_lockstep, consumed: *mut usize, produced: *mut usize) -> c_int;
+    fn rsmp_fir_lockstep_run_counts(ls: *mut rsmp_fir_lockstep, consumed: *mut usize, produced: *mut usize,
+                                    max_steps: usize) -> c_int;
+    fn rsmp_fir_lockstep_sync(ls: *mut rsmp_fir_lockstep) -> c_int;
 }
 
 fn device() -> c_int {
@@ -203,4 +218,56 @@ impl core::fmt::Debug for ResamplerFft {
 
 impl Drop for ResamplerFft {
     fn drop(&mut self) { unsafe { rsmp_fft_free(self.handle) } }
+}
+
+/// NOT part of the reference API: a fixed set of `ResamplerFir` streams fed one chunk each per step from buffers in
+/// GPU memory (include/resampler_amd.h, rsmp_fir_lockstep_*).  `step` is one `resample()` call per stream
+/// (src/resampler_fir.rs:509-621), `run` is k of them per stream in one go -- the loop of resample/src/main.rs:226-254
+/// over a resident buffer -- planned and computed on the device.  Pointers are device pointers (hipMalloc).
+pub struct LockstepBatch { handle: *mut rsmp_fir_lockstep, streams: Vec<ResamplerFir>, last_run: usize }
+unsafe impl Send for LockstepBatch {}
+
+impl LockstepBatch {
+    pub fn new(streams: Vec<ResamplerFir>, max_step_frames: usize) -> Self {
+        let handles: Vec<*mut rsmp_fir> = streams.iter().map(|s| s.handle).collect();
+        let handle = unsafe { rsmp_fir_lockstep_new(handles.as_ptr(), handles.len(), max_step_frames) };
+        assert!(!handle.is_null(), "{}", last_error());
+        Self { handle, streams, last_run: 0 }
+    }
+    /// `out_caps[i]` >= `buffer_size_output()` of stream i: the room of ONE call; the buffers hold a whole run.
+    pub unsafe fn bind(&mut self, d_in: &[*const f32], d_out: &[*mut f32], out_caps: &[usize]) -> Result<(), ResampleError> {
+        assert!(d_in.len() == self.streams.len() && d_out.len() == d_in.len() && out_caps.len() == d_in.len());
+        status(rsmp_fir_lockstep_bind(self.handle, d_in.as_ptr(), d_out.as_ptr(), out_caps.as_ptr()))
+    }
+    pub fn step(&mut self, in_frames: usize, in_offset_frames: usize, append: bool) -> Result<(), ResampleError> {
+        self.last_run = 1;
+        status(unsafe { rsmp_fir_lockstep_step(self.handle, in_frames, in_offset_frames, std::ptr::null(), append as c_int, std::ptr::null_mut()) })
+    }
+    pub fn run(&mut self, k_steps: usize, in_frames: usize, in_offset_frames: usize, append: bool) -> Result<(), ResampleError> {
+        self.last_run = k_steps;
+        status(unsafe { rsmp_fir_lockstep_run(self.handle, k_steps, in_frames, in_offset_frames, append as c_int, std::ptr::null_mut()) })
+    }
+    /// (consumed, produced) of the last call of every stream, in f32 values; waits for the launch.
+    pub fn counts(&mut self) -> Vec<(usize, usize)> {
+        let n = self.streams.len();
+        let (mut c, mut p) = (vec![0usize; n], vec![0usize; n]);
+        status(unsafe { rsmp_fir_lockstep_counts(self.handle, c.as_mut_ptr(), p.as_mut_ptr()) }).expect("counts");
+        c.into_iter().zip(p).collect()
+    }
+    /// ... of every call of the last run: `[call][stream]`.
+    pub fn run_counts(&mut self) -> Vec<Vec<(usize, usize)>> {
+        let (n, k) = (self.streams.len(), self.last_run);
+        let (mut c, mut p) = (vec![0usize; n * k], vec![0usize; n * k]);
+        status(unsafe { rsmp_fir_lockstep_run_counts(self.handle, c.as_mut_ptr(), p.as_mut_ptr(), k) }).expect("run_counts");
+        (0..k).map(|s| (0..n).map(|i| (c[s * n + i], p[s * n + i])).collect()).collect()
+    }
+    /// Writes the device state back into the streams and hands them back.
+    pub fn into_streams(mut self) -> Vec<ResamplerFir> {
+        unsafe { rsmp_fir_lockstep_sync(self.handle); }
+        std::mem::take(&mut self.streams)
+    }
+}
+
+impl Drop for LockstepBatch {
+    fn drop(&mut self) { unsafe { rsmp_fir_lockstep_free(self.handle) } }
 }

@@ -19,7 +19,9 @@ cd /tmp && export TMPDIR=/tmp
 
 python3 "$R/bench.py" --steps 20 --warmup 3 > "$SUM/bench_n1.json" 2> "$OUT/bench_n1.err"
 python3 "$R/bench.py" --path fft --steps 20 --warmup 3 > "$SUM/bench_fft.json" 2> "$OUT/bench_fft.err"
-python3 "$R/bench.py" --config c4 --steps 256 --warmup 16 > "$SUM/bench_c4.json" 2> "$OUT/bench_c4.err"
+python3 "$R/bench.py" --config c4 --steps 2048 --warmup 256 > "$SUM/bench_c4.json" 2> "$OUT/bench_c4.err"
+python3 "$R/bench.py" --config c4 --c4-k 1 --steps 256 --warmup 16 > "$SUM/bench_c4_k1.json" 2> "$OUT/bench_c4_k1.err"
+(cd "$R" && tools/c4_shard_sweep.sh > "$SUM/c4_shard_sweep.txt" 2> "$OUT/c4_shard_sweep.err")
 python3 "$R/bench.py" --config c5 --steps 10 --warmup 2 > "$SUM/bench_c5.json" 2> "$OUT/bench_c5.err"
 # the RCCL exchange on what hardware there is: a world of one rank sending to / receiving from itself
 timeout -k 5 300 python3 "$R/bench.py" --config c4 --feed rccl --gpus 1 --steps 256 --warmup 16 > "$SUM/bench_c4_rccl_world1.json" 2> "$OUT/bench_c4_rccl.err"
@@ -35,7 +37,7 @@ python3 "$R/tools/wphase_report.py" "$OUT/wtrace.txt" 111.5 > "$SUM/wphase_split
 declare -A CMD
 CMD[fir]="--steps 20 --warmup 3 --no-cpu --no-secondary"
 CMD[fft]="--path fft --steps 20 --warmup 3 --no-cpu"
-CMD[c4]="--config c4 --steps 256 --warmup 16"
+CMD[c4]="--config c4 --steps 2048 --warmup 256"
 CMD[c5]="--config c5 --steps 10 --warmup 2"
 for w in fir fft c4 c5; do
     timeout -k 5 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_$w" -- python3 "$R/bench.py" ${CMD[$w]} \
@@ -46,7 +48,7 @@ done
 declare -A PCMD
 PCMD[fir]="--steps 3 --warmup 1 --no-cpu --no-secondary"
 PCMD[fft]="--path fft --steps 3 --warmup 1 --no-cpu"
-PCMD[c4]="--config c4 --steps 32 --warmup 4 --spinup-seconds 0"
+PCMD[c4]="--config c4 --steps 512 --warmup 256 --spinup-seconds 0"
 PCMD[c5]="--config c5 --steps 2 --warmup 1 --spinup-seconds 0"
 for w in fir fft c4 c5; do
     for c in FETCH_SIZE WRITE_SIZE; do

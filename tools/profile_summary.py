@@ -27,6 +27,23 @@ for w, names in KERNELS.items():
         bench = None
     roof = bench["roofline"] if bench else {}
     alg = roof.get("algorithmic_bytes")
+    kk = (bench or {}).get("config", {}).get("steps_per_launch", 1) if w == "c4" else 1
+    if w == "c4" and kk > 1:
+        # a run of kk lock-step calls is several launches (planner kernels, one bulk kernel per rate pair, repair, tail
+        # copy): the traffic of ALL of them per run, against the algorithmic bytes of the run's kk steps
+        run_names = ("fir_lockstep", "fir_split", "split_items", "fir_repair", "fir_tail_copy", "fir_periodic")
+        sums, runs = collections.defaultdict(float), collections.defaultdict(int)
+        for f in glob.glob(f"{raw}/pmc_{w}_*/**/*counter_collection.csv", recursive=True):
+            for r in csv.DictReader(open(f)):
+                if any(n in r["Kernel_Name"] for n in run_names):
+                    sums[r["Counter_Name"]] += float(r["Counter_Value"])
+                    if "fir_lockstep_chain" in r["Kernel_Name"]:
+                        runs[r["Counter_Name"]] += 1
+        for c in ("FETCH_SIZE", "WRITE_SIZE"):
+            if runs[c]:
+                mean[c] = sums[c] / runs[c]
+                tot[c] = [0.0] * runs[c]
+        alg = alg * kk if alg else alg
     if "FETCH_SIZE" in mean and "WRITE_SIZE" in mean:
         fetch = mean["FETCH_SIZE"] * 1024 * 2      # gfx950: FETCH_SIZE tallies 128-B requests at 64 B
         write = mean["WRITE_SIZE"] * 1024
