@@ -236,9 +236,9 @@ def _fir_cpu_worker(x, seconds, chunk, out, idx, specs=(CHANNELS, IN_HZ, OUT_HZ,
     out[idx] = (values, time.perf_counter() - t0)
 
 
-def _fft_cpu_worker(x, seconds, out, idx):
+def _fft_cpu_worker(x, seconds, out, idx, simd=True):
     from oracle import pyoracle as orc
-    r = orc.OracleFft(CHANNELS, IN_HZ, OUT_HZ)
+    r = orc.OracleFft(CHANNELS, IN_HZ, OUT_HZ, simd=simd)
     y = np.zeros((x.size // r.chunk_size_input() + 1) * r.chunk_size_output(), np.float32)
     r.resample_all_into(x[: 8 * r.chunk_size_input()], y)
     t0 = time.perf_counter()
@@ -303,9 +303,10 @@ def cpu_baseline_fir(frames: int, seconds: float, all_cores_seconds: float):
 
 
 def cpu_baseline_fft(seconds: float, all_cores_seconds: float = 0.0):
-    """OracleFft (port of resampler_fft.rs:182-240 + src/fft with the reference's SCALAR butterflies,
-    butterflies/*/mod.rs -- its AVX butterflies are not restated; precomputed twiddles as RadixFFT::new), native
-    build, the CLI's driver loop over 256 blocks on one core, then one stream per core."""
+    """OracleFft (port of resampler_fft.rs:182-240 + src/fft) through the reference's AVX + FMA code path -- its
+    butterflies 3 / 4 / 5 / 7 / 8 and real <-> complex passes restated intrinsic for intrinsic (oracle/fft_avx.c; packed
+    twiddles as RadixFFT::new) --, native build, the CLI's driver loop over 256 blocks on one core, then one stream per
+    core; the scalar-butterfly figure of rounds 1-3 rides along as `scalar_value`."""
     from oracle import pyoracle as orc
     from resampler_amd import synth
     model, cores = cpu_info()
@@ -314,13 +315,16 @@ def cpu_baseline_fft(seconds: float, all_cores_seconds: float = 0.0):
         n_in = orc.OracleFft(CHANNELS, IN_HZ, OUT_HZ).chunk_size_input()
         blocks = 256
         x = synth.sweep(blocks * n_in // CHANNELS, CHANNELS, float(IN_HZ))
-        res = [None]
-        _fft_cpu_worker(x, seconds, res, 0)
+        res = [None, None]
+        simd = orc.have_avx_fma()
+        _fft_cpu_worker(x, seconds, res, 0, simd)
+        _fft_cpu_worker(x, min(seconds, 2.0), res, 1, False)
         values, dt = res[0]
-        line = {"value": round(values / dt / 1e6, 3), "unit": "Msamples/s", "cores": 1, "kind": "port",
+        line = {"value": round(values / dt / 1e6, 3), "unit": "Msamples/s", "cores": 1, "kind": "port-avx" if simd else "port",
                 "model": model, "host_cores": cores, "build_flags": orc.build_flags(), "published_ref": PUBLISHED_REF["fft"],
-                "sample": f"{values // n_in} blocks of 1176 frames, scalar butterflies (the reference's AVX butterflies "
-                          f"are not restated: expect the Rust crate ~2-3x above this), {dt:.1f} s"}
+                "scalar_value": round(res[1][0] / res[1][1] / 1e6, 3),
+                "sample": f"{values // n_in} blocks of 1176 frames, " + ("the reference's AVX + FMA butterflies and real <-> complex "
+                          "passes (oracle/fft_avx.c)" if simd else "scalar butterflies (no AVX + FMA on this CPU)") + f", {dt:.1f} s"}
         if all_cores_seconds > 0 and cores > 1:
             v, n, wall = _all_cores(lambda x_, s_, r_, i_: _fft_cpu_worker(x_, s_, r_, i_), (x,), all_cores_seconds, cores)
             line["all_cores"] = {"value": v, "unit": "Msamples/s", "cores": n,

@@ -155,7 +155,16 @@ struct orc_rfft {
     c32* scratch;         /* 3 * n */
     c32* stage_tw[24];    /* per stage (stride > 1): [k][q - 1] = twiddle_f32(k * q, stride * r), k < stride, q = 1 .. r - 1
                            * -- computed once here as RadixFFT::new does (radix_fft.rs:273-362), in f64 -> f32 */
+    int simd;             /* 1: the reference's AVX + FMA butterflies and real <-> complex passes (fft_avx.c) */
+    c32* packed_tw[24];   /* simd: the same twiddles packed per SIMD width, [group of 4 butterflies][q - 1][4] (:273-362) */
 };
+/* fft_avx.c */
+size_t orc_avx_stage3(const c32* src, c32* dst, size_t n, size_t stride, const c32* tw);
+size_t orc_avx_stage4(const c32* src, c32* dst, size_t n, size_t stride, const c32* tw);
+size_t orc_avx_stage5(const c32* src, c32* dst, size_t n, size_t stride, const c32* tw);
+size_t orc_avx_stage7(const c32* src, c32* dst, size_t n, size_t stride, const c32* tw);
+size_t orc_avx_stage8(const c32* src, c32* dst, size_t n, size_t stride, const c32* tw);
+size_t orc_avx_real_complex(c32* lm, c32* right, size_t rm_len, const c32* twiddles, size_t iters, int forward);
 
 /* radix_fft.rs:251-258 */
 static c32 twiddle_f32(size_t index, size_t fft_len) {
@@ -182,7 +191,9 @@ static size_t compute_factors(const int* in, size_t n, int* out) {
     return (size_t)-1;
 }
 
-orc_rfft* orc_rfft_new(const int* factors, size_t n_factors, int inverse) {
+orc_rfft* orc_rfft_new(const int* factors, size_t n_factors, int inverse) { return orc_rfft_new_simd(factors, n_factors, inverse, 0); }
+
+orc_rfft* orc_rfft_new_simd(const int* factors, size_t n_factors, int inverse, int simd) {
     if (n_factors == 0 || n_factors > 24) return NULL;
     size_t n = 1;
     for (size_t i = 0; i < n_factors; i++) {
@@ -195,6 +206,7 @@ orc_rfft* orc_rfft_new(const int* factors, size_t n_factors, int inverse) {
     f->n = n;
     f->n2 = n / 2;
     f->inverse = inverse;
+    f->simd = simd && orc_have_avx_fma();
     size_t nf = compute_factors(factors, n_factors, f->factors);
     if (nf == (size_t)-1) { free(f); return NULL; }
     f->n_factors = orc_optimize_factors(f->factors, nf);      /* radix_fft.rs:117-118 */
@@ -215,6 +227,14 @@ orc_rfft* orc_rfft_new(const int* factors, size_t n_factors, int inverse) {
             for (size_t k = 0; k < stride; k++)
                 for (size_t q = 1; q < r; q++) tw[k * (r - 1) + (q - 1)] = twiddle_f32(k * q, stride * r);
             f->stage_tw[s] = tw;
+            if (f->simd && r != 2) {
+                const size_t m = f->n2 / r, simd_iters = (m >> 2) << 2;
+                c32* pk = (c32*)malloc(sizeof(c32) * (simd_iters ? simd_iters : 1) * (r - 1));
+                for (size_t i = 0; i < simd_iters; i++)
+                    for (size_t q = 1; q < r; q++)
+                        pk[(i / 4) * 4 * (r - 1) + 4 * (q - 1) + (i % 4)] = tw[(i % stride) * (r - 1) + (q - 1)];
+                f->packed_tw[s] = pk;
+            }
         }
         stride *= r;
     }
@@ -225,7 +245,7 @@ void orc_rfft_free(orc_rfft* f) {
     if (!f) return;
     free(f->rc_twiddles);
     free(f->scratch);
-    for (size_t s = 0; s < 24; s++) free(f->stage_tw[s]);
+    for (size_t s = 0; s < 24; s++) { free(f->stage_tw[s]); free(f->packed_tw[s]); }
     free(f);
 }
 size_t orc_rfft_len(const orc_rfft* f) { return f->n; }
@@ -235,10 +255,10 @@ size_t orc_rfft_stage_factors(const orc_rfft* f, int* out) {
 }
 
 /* One out-of-place Stockham stage of radix r (scalar butterfly specs, butterflyN/mod.rs). */
-static inline __attribute__((always_inline)) void stage_body(const c32* src, c32* dst, size_t n, const int r, size_t stride, const c32* tw) {
+static inline __attribute__((always_inline)) void stage_body(const c32* src, c32* dst, size_t n, const int r, size_t stride, const c32* tw, size_t i0) {
     const size_t m = n / (size_t)r;
-    size_t k = 0;   /* i % stride */
-    for (size_t i = 0; i < m; i++, k = (k + 1 == stride) ? 0 : k + 1) {
+    size_t k = i0 % stride;   /* i % stride */
+    for (size_t i = i0; i < m; i++, k = (k + 1 == stride) ? 0 : k + 1) {
         c32 z[8], t[8];
         for (int q = 0; q < r; q++) z[q] = src[i + (size_t)q * m];
         t[0] = z[0];
@@ -336,15 +356,35 @@ static inline __attribute__((always_inline)) void stage_body(const c32* src, c32
 
 /* One instance per radix (the reference has one function per radix too, butterflies/mod.rs): with `r` a constant the
  * compiler unrolls the loads and drops the switch; the arithmetic and its order are unchanged. */
-static void stage(const c32* src, c32* dst, size_t n, int r, size_t stride, const c32* tw) {
+/* i0: the butterflies [0, i0) have been done already (by the AVX path, whose leftovers are the scalar spec's) */
+static void stage_from(const c32* src, c32* dst, size_t n, int r, size_t stride, const c32* tw, size_t i0) {
     switch (r) {
-        case 2: stage_body(src, dst, n, 2, stride, tw); break;
-        case 3: stage_body(src, dst, n, 3, stride, tw); break;
-        case 4: stage_body(src, dst, n, 4, stride, tw); break;
-        case 5: stage_body(src, dst, n, 5, stride, tw); break;
-        case 7: stage_body(src, dst, n, 7, stride, tw); break;
-        case 8: stage_body(src, dst, n, 8, stride, tw); break;
+        case 2: stage_body(src, dst, n, 2, stride, tw, i0); break;
+        case 3: stage_body(src, dst, n, 3, stride, tw, i0); break;
+        case 4: stage_body(src, dst, n, 4, stride, tw, i0); break;
+        case 5: stage_body(src, dst, n, 5, stride, tw, i0); break;
+        case 7: stage_body(src, dst, n, 7, stride, tw, i0); break;
+        case 8: stage_body(src, dst, n, 8, stride, tw, i0); break;
     }
+}
+static void stage(const c32* src, c32* dst, size_t n, int r, size_t stride, const c32* tw) { stage_from(src, dst, n, r, stride, tw, 0); }
+/* a stage of the plan: the AVX + FMA butterflies where the plan asks for them (radix 2 has no stage of its own in the
+ * plans of the resampler: scalar) */
+static void plan_stage(const orc_rfft* f, size_t s, const c32* src, c32* dst, size_t stride) {
+    const int r = f->factors[s];
+    size_t done = 0;
+    if (f->simd && (stride == 1 || f->packed_tw[s])) {
+        const c32* pk = f->packed_tw[s];
+        switch (r) {
+            case 3: done = orc_avx_stage3(src, dst, f->n2, stride, pk); break;
+            case 4: done = orc_avx_stage4(src, dst, f->n2, stride, pk); break;
+            case 5: done = orc_avx_stage5(src, dst, f->n2, stride, pk); break;
+            case 7: done = orc_avx_stage7(src, dst, f->n2, stride, pk); break;
+            case 8: done = orc_avx_stage8(src, dst, f->n2, stride, pk); break;
+            default: break;
+        }
+    }
+    stage_from(src, dst, f->n2, r, stride, f->stage_tw[s], done);
 }
 
 /* One stage on caller-owned arrays: what the reference's own butterfly tests call (butterfly8/mod.rs:616-697,
@@ -358,14 +398,14 @@ void orc_butterfly_stage(const orc_c32* src, orc_c32* dst, size_t n, int radix, 
 static int stockham(const orc_rfft* f, c32* data, c32* scratch) {
     if (f->n_factors == 0) return 0;
     if (f->n_factors == 1) {
-        stage(data, scratch, f->n2, f->factors[0], 1, NULL);
+        plan_stage(f, 0, data, scratch, 1);
         memcpy(data, scratch, sizeof(c32) * f->n2);
         return 0;
     }
     c32 *in = data, *out = scratch;
     size_t stride = 1;
     for (size_t s = 0; s < f->n_factors; s++) {
-        stage(in, out, f->n2, f->factors[s], stride, f->stage_tw[s]);
+        plan_stage(f, s, in, out, stride);
         c32* tmp = in; in = out; out = tmp;
         stride *= (size_t)f->factors[s];
     }
@@ -391,7 +431,7 @@ void orc_rfft_forward(orc_rfft* f, const float* in, orc_c32* out) {
     size_t lm_len = split - 1, rm_len = right_len - 1;
     size_t iters = lm_len < rm_len ? lm_len : rm_len;
     if (f->n_rc < iters) iters = f->n_rc;
-    for (size_t i = 0; i < iters; i++) {
+    for (size_t i = f->simd ? orc_avx_real_complex(lm, right, rm_len, f->rc_twiddles, iters, 1) : 0; i < iters; i++) {
         c32 o = lm[i];
         size_t rev = rm_len - 1 - i;
         c32 orv = right[rev];
@@ -425,7 +465,7 @@ void orc_rfft_inverse(orc_rfft* f, const orc_c32* in, float* out) {
         size_t lm_len = split - 1, rm_len = right_len - 1;
         size_t iters = lm_len < rm_len ? lm_len : rm_len;
         if (f->n_rc < iters) iters = f->n_rc;
-        for (size_t i = 0; i < iters; i++) {
+        for (size_t i = f->simd ? orc_avx_real_complex(lm, right, rm_len, f->rc_twiddles, iters, 0) : 0; i < iters; i++) {
             c32 a = lm[i];
             size_t rev = rm_len - 1 - i;
             c32 b = right[rev];
@@ -464,7 +504,10 @@ struct orc_fft_resampler {
     c32 *input_spectrum, *output_spectrum;
 };
 
-orc_fft_resampler* orc_fft_new(size_t channels, uint32_t in_hz, uint32_t out_hz) {
+orc_fft_resampler* orc_fft_new(size_t channels, uint32_t in_hz, uint32_t out_hz) { return orc_fft_new_simd(channels, in_hz, out_hz, 0); }
+
+/* simd != 0: the transforms (and so the filter spectrum) through the reference's AVX + FMA code path (fft_avx.c) */
+orc_fft_resampler* orc_fft_new_simd(size_t channels, uint32_t in_hz, uint32_t out_hz, int simd) {
     size_t fft_in, fft_out, ni, no;
     int fin[32], fout[32];
     if (channels == 0 || orc_fft_plan(in_hz, out_hz, &fft_in, &fft_out, fin, &ni, fout, &no, 1)) return NULL;
@@ -474,8 +517,8 @@ orc_fft_resampler* orc_fft_new(size_t channels, uint32_t in_hz, uint32_t out_hz)
     r->fft_out = fft_out;
     fin[ni++] = 2;                                           /* resampler_fft.rs:345-348 */
     fout[no++] = 2;
-    r->fft = orc_rfft_new(fin, ni, 0);
-    r->ifft = orc_rfft_new(fout, no, 1);
+    r->fft = orc_rfft_new_simd(fin, ni, 0, simd);
+    r->ifft = orc_rfft_new_simd(fout, no, 1, simd);
     /* resampler_fft.rs:353-359 */
     double cutoff = fft_in > fft_out
         ? orc_calculate_cutoff_kaiser(fft_out, 10.0) * ((double)fft_out / (double)fft_in)

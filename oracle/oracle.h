@@ -88,6 +88,8 @@ size_t orc_optimize_factors(int* factors, size_t n);
 typedef struct orc_rfft orc_rfft;
 /* RadixFFT::new (radix_fft.rs:105-183): factors multiply to the REAL length n (even). */
 orc_rfft* orc_rfft_new(const int* factors, size_t n_factors, int inverse);
+/* simd != 0: the reference's AVX + FMA butterflies and real <-> complex passes (fft_avx.c; scalar on a CPU without them) */
+orc_rfft* orc_rfft_new_simd(const int* factors, size_t n_factors, int inverse, int simd);
 void orc_rfft_free(orc_rfft* f);
 size_t orc_rfft_len(const orc_rfft* f);
 size_t orc_rfft_stage_factors(const orc_rfft* f, int* out);  /* the n/2-point stage list */
@@ -100,6 +102,7 @@ void orc_butterfly_stage(const orc_c32* src, orc_c32* dst, size_t n, int radix, 
 
 typedef struct orc_fft_resampler orc_fft_resampler;
 orc_fft_resampler* orc_fft_new(size_t channels, uint32_t in_hz, uint32_t out_hz); /* resampler_fft.rs:75-119 */
+orc_fft_resampler* orc_fft_new_simd(size_t channels, uint32_t in_hz, uint32_t out_hz, int simd);
 void orc_fft_free(orc_fft_resampler* r);
 size_t orc_fft_chunk_size_input(const orc_fft_resampler* r);              /* :135-138 */
 size_t orc_fft_chunk_size_output(const orc_fft_resampler* r);             /* :142-145 */

@@ -295,10 +295,12 @@ def optimize_factors(factors):
 class OracleRfft:
     """RadixFFT<Forward|Inverse> (radix_fft.rs:105-713) on the oracle."""
 
-    def __init__(self, factors, inverse=False):
+    def __init__(self, factors, inverse=False, simd=False):
         arr = (C.c_int * len(factors))(*factors)
         self._L = lib()
-        self._h = self._L.orc_rfft_new(arr, len(factors), 1 if inverse else 0)
+        self._L.orc_rfft_new_simd.restype = C.c_void_p
+        self._L.orc_rfft_new_simd.argtypes = [C.POINTER(C.c_int), C.c_size_t, C.c_int, C.c_int]
+        self._h = self._L.orc_rfft_new_simd(arr, len(factors), 1 if inverse else 0, 1 if simd else 0)
         if not self._h:
             raise ValueError("bad factors")
         self.n = self._L.orc_rfft_len(self._h)
@@ -332,9 +334,13 @@ class OracleRfft:
 class OracleFft:
     """Mirror of ResamplerFft (resampler_fft.rs:43-240) on the oracle."""
 
-    def __init__(self, channels, in_hz, out_hz):
+    def __init__(self, channels, in_hz, out_hz, simd=False):
+        """simd: the reference's AVX + FMA butterflies and real <-> complex passes (oracle/fft_avx.c) instead of the scalar
+        specs (use_native(True) selects the -O3 -mavx2 -mfma build of the same sources: the timed CPU baseline)."""
         self._L = lib()
-        self._h = self._L.orc_fft_new(channels, in_hz, out_hz)
+        self._L.orc_fft_new_simd.restype = C.c_void_p
+        self._L.orc_fft_new_simd.argtypes = [C.c_size_t, C.c_uint32, C.c_uint32, C.c_int]
+        self._h = self._L.orc_fft_new_simd(channels, in_hz, out_hz, 1 if simd else 0)
         if not self._h:
             raise ValueError("invalid ResamplerFft arguments")
         self.channels = channels

@@ -199,3 +199,34 @@ def test_radix8_butterfly_against_the_references_fixed_vectors():   # butterfly8
                 acc = np.complex64(acc + np.complex64(complex(np.cos(ang, dtype=np.float32), np.sin(ang, dtype=np.float32))) * z[i])
             want[k] = acc
         assert np.max(np.abs(dst[:, 0] - want.real)) < ka["tolerance"] and np.max(np.abs(dst[:, 1] - want.imag)) < ka["tolerance"]
+
+
+@pytest.mark.parametrize("in_hz,out_hz", [(44100, 48000), (48000, 44100), (22050, 48000), (96000, 44100), (48000, 96000), (16000, 44100)])
+def test_avx_fma_fft_path_agrees_with_the_scalar_specs(in_hz, out_hz):
+    """oracle/fft_avx.c (the reference's AVX + FMA butterflies 3 / 4 / 5 / 7 / 8 and real <-> complex passes, restated)
+    against the scalar specs of oracle/fft.c: the reference holds its own two paths to 1e-6 (butterflies/mod.rs:129-290,
+    real_complex/mod.rs:284-395) -- here whole transforms and the whole resampler, on full-scale noise."""
+    if not o.have_avx_fma():
+        pytest.skip("needs AVX + FMA")
+    fi, fo, fin, fout = o.fft_plan(in_hz, out_hz)
+    rng = np.random.default_rng(5)
+    for factors, inverse in ((fin, False), (fout, True)):
+        a, b = o.OracleRfft(factors + [2], inverse), o.OracleRfft(factors + [2], inverse, simd=True)
+        if not inverse:
+            x = (rng.random(a.n, dtype=np.float32) * 2 - 1).astype(np.float32)
+            ya, yb = a.forward(x).view(np.float32), b.forward(x).view(np.float32)
+        else:
+            z = ((rng.random((a.n // 2 + 1, 2), dtype=np.float32) * 2 - 1)).astype(np.float32)
+            z[0, 1] = z[-1, 1] = 0
+            zc = z.reshape(-1).view(np.complex64)
+            ya, yb = a.inverse_transform(zc), b.inverse_transform(zc)
+        scale = float(np.sqrt(np.mean(np.asarray(ya, np.float64) ** 2)))
+        err = float(np.sqrt(np.mean((np.asarray(ya, np.float64) - np.asarray(yb, np.float64)) ** 2)))
+        assert err <= 1e-6 * scale, (factors, inverse, err, scale)
+    ra_, rb_ = o.OracleFft(1, in_hz, out_hz), o.OracleFft(1, in_hz, out_hz, simd=True)   # (one channel: the reference's two-channel scratch collides for some pairs)
+    n_in, n_out = ra_.chunk_size_input(), ra_.chunk_size_output()
+    oa, ob = np.zeros(n_out, np.float32), np.zeros(n_out, np.float32)
+    for blk in range(6):
+        x = (rng.random(n_in, dtype=np.float32) * 2 - 1).astype(np.float32)
+        assert ra_.resample(x, oa) == 0 and rb_.resample(x, ob) == 0
+        assert float(np.sqrt(np.mean((oa.astype(np.float64) - ob) ** 2))) <= 1e-6
