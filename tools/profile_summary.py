@@ -56,8 +56,11 @@ for w, names in KERNELS.items():
                "algorithmic_bytes_per_launch": alg,
                "ratio_traffic_to_algorithmic": (fetch + write) / alg if alg else None}
         json.dump(ent, open(os.path.join(out, f"traffic_{w}.json"), "w"), indent=1)
-        latest[w] = {"hbm_bytes_per_launch": int(fetch + write), "kernel": roof.get("kernel"),
+        latest[w] = {"hbm_bytes_per_launch": int((fetch + write) / kk), "kernel": roof.get("kernel"),
                      "source": f"profiles/<tag>/traffic_{w}.json"}
+        if kk > 1:   # (bench.py's config-4 line is per 512-frame step: the run's traffic / its steps)
+            latest[w]["steps_per_launch"] = kk
+            latest[w]["hbm_bytes_per_run"] = int(fetch + write)
     with open(os.path.join(out, f"pmc_{w}.txt"), "w") as f:
         f.write("%s, per-dispatch means (rocprofv3 --pmc, separate passes)\n" % (roof.get("kernel") or w))
         for k in sorted(mean):
