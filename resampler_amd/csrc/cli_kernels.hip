@@ -155,24 +155,17 @@ extern "C" int rsmp_pcm_to_stereo_f32_device(const void* d_pcm, int bits, int ch
 }
 
 // ---- measurement aid: the chip's streaming rate --------------------------------------------------------------
-// A plain copy, 16 bytes per lane and instruction, four loads in flight per lane, a grid of eight workgroups per
-// compute unit walking the buffer: what a kernel that reads as much as it writes can reach at all (the guide measures
-// ~6.3 TB/s of read + written bytes on MI355X this way).  bench.py prices every roofline fraction against the 8 TB/s
-// spec AND reports this figure beside it (`roofline.device_copy`).
+// A plain copy, 16 bytes per lane and instruction, four workgroups per compute unit walking the buffer side by side (the
+// whole grid touches one contiguous stretch per iteration): what a kernel that reads as much as it writes can reach at
+// all.  tools/copy_probe.hip swept the shape on the pool's MI355X (0.56 GB buffers): this one 5.83 TB/s of read +
+// written bytes; eight workgroups per CU 4.9, four loads in flight per lane 4.2-4.4, non-temporal accesses 4.3-5.6 --
+// the guide's figure is 6.29 TB/s.  bench.py prices every roofline fraction against the 8 TB/s spec AND reports this
+// figure beside it (`roofline.device_copy`).
 namespace {
 typedef float v4f_copy __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void stream_copy_kernel(const v4f_copy* __restrict__ src, v4f_copy* __restrict__ dst, uint64_t n16) {
     const uint64_t stride = static_cast<uint64_t>(gridDim.x) * 256u;
-    uint64_t i = static_cast<uint64_t>(blockIdx.x) * 256u + threadIdx.x;
-    for (; i + 3 * stride < n16; i += 4 * stride) {
-        const v4f_copy a = __builtin_nontemporal_load(src + i), b = __builtin_nontemporal_load(src + i + stride);
-        const v4f_copy c = __builtin_nontemporal_load(src + i + 2 * stride), d = __builtin_nontemporal_load(src + i + 3 * stride);
-        __builtin_nontemporal_store(a, dst + i);
-        __builtin_nontemporal_store(b, dst + i + stride);
-        __builtin_nontemporal_store(c, dst + i + 2 * stride);
-        __builtin_nontemporal_store(d, dst + i + 3 * stride);
-    }
-    for (; i < n16; i += stride) __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
+    for (uint64_t i = static_cast<uint64_t>(blockIdx.x) * 256u + threadIdx.x; i < n16; i += stride) dst[i] = src[i];
 }
 }  // namespace
 
@@ -185,7 +178,7 @@ extern "C" int rsmp_device_stream_copy(const float* d_src, float* d_dst, size_t 
     int device = 0;
     (void)hipGetDevice(&device);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
-    hipLaunchKernelGGL(stream_copy_kernel, dim3(static_cast<uint32_t>(cus) * 8u), dim3(256), 0, static_cast<hipStream_t>(stream),
+    hipLaunchKernelGGL(stream_copy_kernel, dim3(static_cast<uint32_t>(cus) * 4u), dim3(256), 0, static_cast<hipStream_t>(stream),
                        reinterpret_cast<const v4f_copy*>(d_src), reinterpret_cast<v4f_copy*>(d_dst), static_cast<uint64_t>(n_values / 4));
     RSMP_HIP_CHECK(hipGetLastError());
     return RSMP_OK;

@@ -124,6 +124,11 @@ int get_plan(int device, uint32_t in_hz, uint32_t out_hz, std::shared_ptr<Device
 
 }  // namespace
 
+struct LaunchEvent {
+    hipEvent_t ev = nullptr;
+    ~LaunchEvent() { if (ev) (void)hipEventDestroy(ev); }
+};
+
 struct rsmp_fft {
     int device = 0;
     size_t channels = 0;
@@ -134,7 +139,9 @@ struct rsmp_fft {
     hipStream_t stream = nullptr;
     hipStream_t last_stream = nullptr;   // the stream of the handle's previous launch (launches of one handle are ordered)
     bool last_stream_valid = false;
-    hipEvent_t last_launch = nullptr;    // recorded behind the handle's most recent launch, on that launch's stream
+    // recorded behind the handle's most recent launch, on that launch's stream: the LEADER's event of that launch, shared
+    // by the batch's handles (one record per launch, not one per stream; it outlives the leader through the reference)
+    std::shared_ptr<LaunchEvent> last_launch, launch_ev;
     hipEvent_t desc_copied = nullptr;
     bool desc_pending = false;
     PinnedBuffer h_desc;
@@ -170,7 +177,7 @@ int launch_fft_jobs(rsmp_fft* leader, const std::vector<FftJob>& jobs, hipStream
         // (an event, not the previous stream's handle: the caller may have destroyed that stream by now, and a wait on an
         // event neither blocks the host nor breaks a stream capture)
         if (h->last_stream_valid && h->last_stream != stream && h->last_launch)
-            RSMP_HIP_CHECK(hipStreamWaitEvent(stream, h->last_launch, 0));
+            RSMP_HIP_CHECK(hipStreamWaitEvent(stream, h->last_launch->ev, 0));
         h->last_stream = stream;
         h->last_stream_valid = true;
     }
@@ -208,9 +215,14 @@ int launch_fft_jobs(rsmp_fft* leader, const std::vector<FftJob>& jobs, hipStream
         RSMP_HIP_CHECK(hipEventRecord(leader->prof_stop, stream));
         leader->prof_valid = true;
     }
+    if (!leader->launch_ev) {
+        leader->launch_ev = std::make_shared<LaunchEvent>();
+        RSMP_HIP_CHECK(hipEventCreateWithFlags(&leader->launch_ev->ev, hipEventDisableTiming));
+    }
+    RSMP_HIP_CHECK(hipEventRecord(leader->launch_ev->ev, stream));
     for (const FftJob& j : jobs) {
         if (j.n_blocks != 0) j.r->cur ^= 1;   // (a stream without blocks in this launch keeps its state where it is)
-        if (j.r->last_launch) RSMP_HIP_CHECK(hipEventRecord(j.r->last_launch, stream));
+        j.r->last_launch = leader->launch_ev;
     }
     return RSMP_OK;
 }
@@ -254,8 +266,7 @@ extern "C" rsmp_fft* rsmp_fft_new(size_t channels, int input_rate, int output_ra
     if (hipMalloc(&r->d_overlap, ov_bytes) != hipSuccess || hipMemset(r->d_overlap, 0, ov_bytes) != hipSuccess ||
         hipStreamSynchronize(nullptr) != hipSuccess ||   // (the handle's stream is non-blocking: no implicit order)
         hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&r->desc_copied, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&r->last_launch, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&r->desc_copied, hipEventDisableTiming) != hipSuccess) {
         rsmp::fail(RSMP_ERR_HIP, "ResamplerFft: cannot allocate stream state");
         if (r->d_overlap) (void)hipFree(r->d_overlap);
         return nullptr;
@@ -269,7 +280,6 @@ extern "C" void rsmp_fft_free(rsmp_fft* r) {
     (void)hipDeviceSynchronize();
     if (r->d_overlap) (void)hipFree(r->d_overlap);
     if (r->desc_copied) (void)hipEventDestroy(r->desc_copied);
-    if (r->last_launch) (void)hipEventDestroy(r->last_launch);
     if (r->prof_start) (void)hipEventDestroy(r->prof_start);
     if (r->prof_stop) (void)hipEventDestroy(r->prof_stop);
     if (r->stream) (void)hipStreamDestroy(r->stream);
