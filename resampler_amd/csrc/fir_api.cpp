@@ -82,7 +82,10 @@ void fir_destroy(rsmp_fir* r) {
     for (hipEvent_t e : r->plan_copied) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : r->prof_start) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : r->prof_stop) if (e) (void)hipEventDestroy(e);
-    if (r->stream) (void)hipStreamDestroy(r->stream);
+    if (r->stream) {
+        rsmp::split_release_stream(r->device, r->stream);
+        (void)hipStreamDestroy(r->stream);
+    }
     delete r;
 }
 

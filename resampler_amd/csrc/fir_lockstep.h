@@ -151,8 +151,6 @@ struct LsRunArgs {
     FirMirrorState* states_before;   // [n]: copy of the states the run started from
     MirrorPred* preds;         // [n][k]: the predicted structure of every call (fir_mirror_fast.h)
     void* call_recs;           // [n][k] x 24 bytes: what the chain leaves per call for the replay
-    double* drift_cells;       // [n][ceil(k / 64)]: the replay's drift per chunk of calls
-    uint32_t* drift_last;      // [n]: 1 + the latest chunk that left one (zero between runs)
     const uint64_t* cursor_in;
     uint64_t* cursor_out;
     FirStreamDesc* descs;      // [n]: the run's descriptors (the constant fields are the host's)

@@ -47,7 +47,7 @@ struct rsmp_fir_lockstep {
     struct RunGroup { rsmp::PeriodicGeometry geo; size_t first = 0, count = 0; uint32_t max_out_step = 0; };
     int run_state = 0;          // 0: not looked at yet, 1: every rate pair has a bulk kernel, -1: runs are loops of steps
     std::vector<RunGroup> run_groups;
-    DeviceBuffer d_run_descs, d_run_rs, d_run_bits, d_run_counts, d_run_nf, d_run_work, d_run_preds, d_run_recs, d_run_states0, d_run_drift, d_run_drift_last;
+    DeviceBuffer d_run_descs, d_run_rs, d_run_bits, d_run_counts, d_run_nf, d_run_work, d_run_preds, d_run_recs, d_run_states0;
     uint32_t run_wrap_words = 0, run_k = 0, run_nf_tag = 0;
     bool run_planned = false;   // the most recent run went through the device planner
     size_t run_counts_k = 0;    // calls of the most recent run whose counts are in d_run_counts (0: it was a loop of steps)
@@ -248,7 +248,10 @@ extern "C" void rsmp_fir_lockstep_free(rsmp_fir_lockstep* ls) {
     if (!ls) return;
     DeviceGuard guard(ls->device);
     (void)rsmp_fir_lockstep_sync(ls);
-    if (ls->own_stream) (void)hipStreamDestroy(ls->own_stream);
+    if (ls->own_stream) {
+        rsmp::split_release_stream(ls->device, ls->own_stream);
+        (void)hipStreamDestroy(ls->own_stream);
+    }
     for (hipEvent_t e : ls->prof_start) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : ls->prof_stop) if (e) (void)hipEventDestroy(e);
     delete ls;
@@ -502,13 +505,11 @@ int prepare_run(rsmp_fir_lockstep* ls) {
     if (ls->d_run_descs.reserve(n * sizeof(rsmp::FirStreamDesc)) != hipSuccess ||
         ls->d_run_rs.reserve(n * sizeof(rsmp::LsRunStream)) != hipSuccess ||
         ls->d_run_states0.reserve(n * sizeof(FirMirrorState)) != hipSuccess ||
-        ls->d_run_drift_last.reserve(n * sizeof(uint32_t)) != hipSuccess ||
         ls->d_run_work.reserve(64 * sizeof(unsigned long long)) != hipSuccess)
         return rsmp::fail(RSMP_ERR_HIP, "lock-step run: cannot allocate device state");
     RSMP_HIP_CHECK(hipMemcpy(ls->d_run_descs.get(), descs.data(), n * sizeof(rsmp::FirStreamDesc), hipMemcpyHostToDevice));
     RSMP_HIP_CHECK(hipMemcpy(ls->d_run_rs.get(), rstreams.data(), n * sizeof(rsmp::LsRunStream), hipMemcpyHostToDevice));
     RSMP_HIP_CHECK(hipMemset(ls->d_run_work.get(), 0, 64 * sizeof(unsigned long long)));
-    RSMP_HIP_CHECK(hipMemset(ls->d_run_drift_last.get(), 0, n * sizeof(uint32_t)));
     ls->run_state = 1;
     return RSMP_OK;
 }
@@ -534,7 +535,10 @@ extern "C" int rsmp_fir_lockstep_run(rsmp_fir_lockstep* ls, size_t k_steps, size
     const bool whole_accept = in_frames + max_taps + 8 <= rsmp::kMirrorInputCapacity;
     // The outputs of a run's calls follow each other in `out`: behind what earlier steps / runs appended, or -- without
     // `append` -- from the front of the buffer (the append position starts again there).
-    if (!append) RSMP_HIP_CHECK(hipMemsetAsync(ls->d_cursor.get(), 0, ls->rs.size() * sizeof(uint64_t), s));
+    const bool loop_of_steps = ls->run_state < 0 || k_steps == 1 || !whole_accept ||
+                               k_steps * static_cast<uint64_t>(ls->step_frames) > (1u << 27);
+    if (!append && loop_of_steps)   // (the device planner starts a run at the front itself: no launch for it)
+        RSMP_HIP_CHECK(hipMemsetAsync(ls->d_cursor.get(), 0, ls->rs.size() * sizeof(uint64_t), s));
     const size_t n = ls->rs.size();
     if (k_steps > (1u << 20)) return rsmp::fail(RSMP_ERR_INVALID_ARGUMENT, "rsmp_fir_lockstep_run: at most 2^20 calls per run");
     const uint32_t k = static_cast<uint32_t>(k_steps);
@@ -542,12 +546,11 @@ extern "C" int rsmp_fir_lockstep_run(rsmp_fir_lockstep* ls, size_t k_steps, size
         RSMP_HIP_CHECK(hipStreamSynchronize(s));
         if (ls->d_run_counts.reserve(2 * n * static_cast<size_t>(k) * sizeof(uint32_t)) != hipSuccess ||
             ls->d_run_preds.reserve(n * static_cast<size_t>(k) * sizeof(rsmp::MirrorPred)) != hipSuccess ||
-            ls->d_run_recs.reserve(n * static_cast<size_t>(k) * 24) != hipSuccess ||
-            ls->d_run_drift.reserve(n * static_cast<size_t>((k + 63) / 64) * sizeof(double)) != hipSuccess)
+            ls->d_run_recs.reserve(n * static_cast<size_t>(k) * 24) != hipSuccess)
             return rsmp::fail(RSMP_ERR_HIP, "lock-step run: cannot allocate the plan of %u calls", k);
         ls->run_k = k;
     }
-    if (ls->run_state < 0 || k == 1 || !whole_accept || k * static_cast<uint64_t>(ls->step_frames) > (1u << 27)) {
+    if (loop_of_steps) {
         for (uint32_t i = 0; i < k; ++i) {
             if (int rc = rsmp_fir_lockstep_step(ls, in_frames, in_offset_frames + static_cast<size_t>(i) * in_frames, nullptr, 1, stream))
                 return rc;
@@ -586,8 +589,6 @@ extern "C" int rsmp_fir_lockstep_run(rsmp_fir_lockstep* ls, size_t k_steps, size
     a.states_before = ls->d_run_states0.as<FirMirrorState>();
     a.preds = ls->d_run_preds.as<rsmp::MirrorPred>();
     a.call_recs = ls->d_run_recs.get();
-    a.drift_cells = ls->d_run_drift.as<double>();
-    a.drift_last = ls->d_run_drift_last.as<uint32_t>();
     a.cursor_in = ls->d_cursor.as<uint64_t>();
     a.cursor_out = ls->d_cursor.as<uint64_t>();
     a.descs = ls->d_run_descs.as<rsmp::FirStreamDesc>();
@@ -600,7 +601,7 @@ extern "C" int rsmp_fir_lockstep_run(rsmp_fir_lockstep* ls, size_t k_steps, size
     a.k = k;
     a.in_frames = static_cast<uint32_t>(in_frames);
     a.wrap_words = ls->run_wrap_words;
-    a.append = 1u;
+    a.append = append ? 1u : 0u;   // (0: the planner starts the run at the front of `out`)
     a.hist_parity = ls->hist_parity;
     if (ls->profiling)
         RSMP_HIP_CHECK(hipEventRecord(ls->prof_start[ls->prof_count % rsmp_fir_lockstep::kProfRing], s));

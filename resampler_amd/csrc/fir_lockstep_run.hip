@@ -136,11 +136,9 @@ __global__ __launch_bounds__(64) void fir_lockstep_chain_kernel(LsRunArgs a) {
     if (lane != 0) return;
     if (sink.overflow) flags |= kLsStatusRunOverflow;
 
-    uint64_t cursor = 0;
-    if (a.append) {
-        cursor = a.cursor_in[gs];
-        a.cursor_out[gs] = cursor + static_cast<uint64_t>(n_out) * C;
-    }
+    // the calls' outputs follow each other: behind what was appended before, or (no `append`) from the front of `out`
+    const uint64_t cursor = a.append ? a.cursor_in[gs] : 0;
+    a.cursor_out[gs] = cursor + static_cast<uint64_t>(n_out) * C;
     FirStreamDesc* d = a.descs + gs;
     d->in = ls.in + a.in_offset * C;
     d->hist = a.hist_parity ? ls.hist_alt : ls.hist;
@@ -166,8 +164,7 @@ __global__ __launch_bounds__(64) void fir_lockstep_chain_kernel(LsRunArgs a) {
 // lane per call replays its call's chain from the recorded start position (mirror_replay_wraps).  The drift the
 // stream ends with is that of the last call that had such an output.
 __global__ __launch_bounds__(64) void fir_lockstep_wraps_kernel(LsRunArgs a) {
-    const uint32_t n_chunks = (a.k + 63) / 64;
-    const uint32_t gs = blockIdx.x / n_chunks, chunk = blockIdx.x - gs * n_chunks, lane = threadIdx.x;
+    const uint32_t gs = blockIdx.x, lane = threadIdx.x;
     const LsRunStream rs = a.rs[gs];
     const FirMirrorState st0 = a.states_before[gs];   // the state before the run
     const MirrorRunBase base = mirror_run_base(st0, a.in_frames, a.k);
@@ -177,64 +174,54 @@ __global__ __launch_bounds__(64) void fir_lockstep_wraps_kernel(LsRunArgs a) {
     const uint64_t k0 = st0.abs_out / rs.wrap_unit;
     const MirrorPred* preds = a.preds + static_cast<size_t>(gs) * a.k;
     const CallRec* recs = reinterpret_cast<const CallRec*>(a.call_recs) + static_cast<size_t>(gs) * a.k;
-    bool aperiodic = false, overflow = false, unchecked = false;
-    const uint32_t c = chunk * 64 + lane;
-    bool has_int = false;
-    double my_drift = 0.0;
-    if (c < a.k) {
-        const CallRec rec = recs[c];
-        if (rec.flags & kCallSlow) {
-            has_int = (rec.flags & kCallHasInt) != 0;
-            my_drift = rec.drift;
-        } else if (wraps_exist || (rec.flags & kCallLean)) {
-            const MirrorPred pr = preds[c];
-            FirMirrorState st = st0;   // the call's start state, as far as the replay looks at it
-            st.read_position = 0;
-            st.abs_out = pr.m0 + ((rec.flags & kCallAhead) ? 1u : 0u);
-            st.abs_consumed = pr.c0;
-            st.available = st0.abs_consumed + st0.available + static_cast<uint64_t>(c) * a.in_frames - pr.c0;
-            st.position = rec.pos;
-            RunSink sink{bits, static_cast<uint32_t>(st.abs_out - k0 * rs.wrap_unit), rs.den, a.wrap_words * 32u, wraps_exist, false, true};
-            bool checked = true;
-            has_int = mirror_replay_wraps(st, a.in_frames, pr, bn, sink, &checked) && wraps_exist;
-            unchecked = !checked;   // (the chain took this call without checks: they were made here)
-            my_drift = st.drift;
-            aperiodic = st.periodic_ok == 0;
-            overflow = sink.overflow;
+    double drift = st0.drift;
+    bool have = false, aperiodic = false, overflow = false, unchecked = false;
+    // (the chunks of a stream one after the other on one wave: a wave per chunk -- four times the waves at 256 calls --
+    // was measured slower, 59 against 33 us per run of config 4)
+    for (uint32_t c0 = 0; c0 < a.k; c0 += 64) {
+        const uint32_t c = c0 + lane;
+        bool has_int = false;
+        double my_drift = 0.0;
+        if (c < a.k) {
+            const CallRec rec = recs[c];
+            if (rec.flags & kCallSlow) {
+                has_int = (rec.flags & kCallHasInt) != 0;
+                my_drift = rec.drift;
+            } else if (wraps_exist || (rec.flags & kCallLean)) {
+                const MirrorPred pr = preds[c];
+                FirMirrorState st = st0;   // the call's start state, as far as the replay looks at it
+                st.read_position = 0;
+                st.abs_out = pr.m0 + ((rec.flags & kCallAhead) ? 1u : 0u);
+                st.abs_consumed = pr.c0;
+                st.available = st0.abs_consumed + st0.available + static_cast<uint64_t>(c) * a.in_frames - pr.c0;
+                st.position = rec.pos;
+                RunSink sink{bits, static_cast<uint32_t>(st.abs_out - k0 * rs.wrap_unit), rs.den, a.wrap_words * 32u, wraps_exist, false, true};
+                bool checked = true;
+                has_int = mirror_replay_wraps(st, a.in_frames, pr, bn, sink, &checked) && wraps_exist;
+                unchecked = unchecked || !checked;   // (the chain took this call without checks: they were made here)
+                my_drift = st.drift;
+                aperiodic = aperiodic || st.periodic_ok == 0;
+                overflow = overflow || sink.overflow;
+            }
+        }
+        // the stream ends with the drift of its LAST call that had an output at an integer position
+        const unsigned long long m = __ballot(has_int);
+        if (m) {
+            const int last = 63 - __builtin_clzll(m);
+            drift = __shfl(my_drift, last, 64);
+            have = true;
         }
     }
-    // the stream ends with the drift of its LAST call that had an output at an integer position: chunks publish theirs
-    // in order of the call index (a 64-bit maximum of call index : slot; the drift itself sits in the slot's cell)
-    const unsigned long long m = __ballot(has_int);
     aperiodic = __any(aperiodic);
     overflow = __any(overflow);
     unchecked = __any(unchecked);
-    if (m) {
-        const int last = 63 - __builtin_clzll(m);
-        const double d = __shfl(my_drift, last, 64);
-        if (lane == 0) {
-            a.drift_cells[static_cast<size_t>(gs) * n_chunks + chunk] = d;
-            __threadfence();
-            (void)atomicMax(a.drift_last + gs, chunk + 1u);
-        }
-    }
     if (lane == 0) {
-        const uint32_t flags = (overflow ? kLsStatusRunOverflow : 0u) | (unchecked ? kLsStatusPlannerCheck : 0u) |
-                               (aperiodic ? kLsStatusAperiodic : 0u);
-        if (flags) (void)atomicOr(a.status + gs, flags);
+        if (have) a.states_out[gs].drift = drift;
         if (aperiodic) a.states_out[gs].periodic_ok = 0;
+        uint32_t flags = (overflow ? kLsStatusRunOverflow : 0u) | (unchecked ? kLsStatusPlannerCheck : 0u);
+        if (a.states_out[gs].periodic_ok == 0 || aperiodic) flags |= kLsStatusAperiodic;
+        if (flags) a.status[gs] |= flags;
     }
-}
-
-// ... and the last word: the drift of the latest chunk that had one (one thread per stream).
-__global__ __launch_bounds__(256) void fir_lockstep_drift_kernel(LsRunArgs a) {
-    const uint32_t gs = blockIdx.x * 256u + threadIdx.x;
-    if (gs >= a.n_streams) return;
-    const uint32_t n_chunks = (a.k + 63) / 64;
-    const uint32_t last = a.drift_last[gs];
-    if (last) a.states_out[gs].drift = a.drift_cells[static_cast<size_t>(gs) * n_chunks + last - 1];
-    a.drift_last[gs] = 0;
-    if (a.states_out[gs].periodic_ok == 0) (void)atomicOr(a.status + gs, kLsStatusAperiodic);
 }
 
 // a loop of steps as a run: the step's counts (internal order, 64-bit) to row s of the run's [k][n] table
@@ -260,8 +247,7 @@ hipError_t launch_fir_lockstep_plan(const LsRunArgs& args, hipStream_t stream) {
     const uint32_t threads = args.n_streams * args.k;
     hipLaunchKernelGGL(fir_lockstep_predict_kernel, dim3((threads + 255) / 256), dim3(256), 0, stream, args);
     hipLaunchKernelGGL(fir_lockstep_chain_kernel, dim3(args.n_streams), dim3(64), 0, stream, args);
-    hipLaunchKernelGGL(fir_lockstep_wraps_kernel, dim3(args.n_streams * ((args.k + 63) / 64)), dim3(64), 0, stream, args);
-    hipLaunchKernelGGL(fir_lockstep_drift_kernel, dim3((args.n_streams + 255) / 256), dim3(256), 0, stream, args);
+    hipLaunchKernelGGL(fir_lockstep_wraps_kernel, dim3(args.n_streams), dim3(64), 0, stream, args);
     return hipGetLastError();
 }
 

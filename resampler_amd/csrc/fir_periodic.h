@@ -145,6 +145,9 @@ hipError_t launch_fir_split(const FirStreamDesc* d_descs, uint32_t n_streams, co
                             uint32_t max_blocks, uint32_t cus, bool fuse_tail, const NfArgs& nf, hipStream_t stream,
                             uint64_t items_key = 0);
 
+// Gives back the split kernel's item-table workspace of a stream that is about to be destroyed.
+void split_release_stream(int device, hipStream_t stream);
+
 // Host build of the class table (exposed for tests).
 struct HostClassTable {
     std::vector<float> coef;       // [tile][row_len][8]; mfma: [tile][row_len / 16][64 lanes][4 steps]

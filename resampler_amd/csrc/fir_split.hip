@@ -1559,6 +1559,26 @@ size_t split_table_floats(const PeriodicGeometry& g) {
     return static_cast<size_t>(g.n_tiles) * (g.row_len / 32) * g.planes * 64 * 4;
 }
 
+// The item tables' workspaces, one per (device, stream) that has launched the split kernel.
+namespace {
+struct ItemsSlot { uint32_t* ptr = nullptr; size_t cap = 0; uint64_t key = 0; uint32_t items = 0; };
+std::mutex& items_ws_mu() { static std::mutex* m = new std::mutex; return *m; }
+std::map<std::pair<int, hipStream_t>, ItemsSlot>& items_ws() {
+    static auto* w = new std::map<std::pair<int, hipStream_t>, ItemsSlot>;   // (leaked on purpose: process lifetime)
+    return *w;
+}
+}  // namespace
+
+// A handle or batch that destroys a stream of its own gives the stream's workspace back first (the work on the stream is
+// complete by then): without this every create / destroy cycle left a device allocation and a dead key behind.
+void split_release_stream(int device, hipStream_t stream) {
+    std::lock_guard<std::mutex> lock(items_ws_mu());
+    auto it = items_ws().find({device, stream});
+    if (it == items_ws().end()) return;
+    if (it->second.ptr) (void)hipFree(it->second.ptr);
+    items_ws().erase(it);
+}
+
 hipError_t launch_fir_split(const FirStreamDesc* d_descs, uint32_t n_streams, const PeriodicGeometry& geo,
                             uint32_t max_blocks, uint32_t cus, bool fuse_tail, const NfArgs& nf, hipStream_t stream,
                             uint64_t items_key) {
@@ -1642,12 +1662,12 @@ hipError_t launch_fir_split(const FirStreamDesc* d_descs, uint32_t n_streams, co
     }
     // the item table: a launch of its own in front (one thread per item), in a workspace kept per stream
     {
-        static std::mutex ws_mu;
         // The table is a pure function of the streams' counters and the geometry: a launch whose key (the caller's hash of
         // exactly those, 0 = none) equals the key of the table the workspace holds finds it there -- a service resampling
         // batch after batch of equally long files, the bench's step -- and skips the table launch (5 us in front of the kernel).
-        struct Slot { uint32_t* ptr = nullptr; size_t cap = 0; uint64_t key = 0; uint32_t items = 0; };
-        static std::map<std::pair<int, hipStream_t>, Slot> ws;
+        std::mutex& ws_mu = items_ws_mu();
+        auto& ws = items_ws();
+        typedef ItemsSlot Slot;
         const size_t need = static_cast<size_t>(args.total_items) * kItemWords * sizeof(uint32_t);
         uint32_t* d_items = nullptr;
         bool have_table = false;
