@@ -89,9 +89,23 @@ __global__ __launch_bounds__(64) void fir_lockstep_chain_kernel(LsRunArgs a) {
         for (uint32_t i = lane; i < 7 * nc; i += 64) s_pred[i] = preds[static_cast<size_t>(c0) * 7 + i];
         __syncthreads();
         {   // every lane runs the chain on the same values: the control flow stays uniform (scalar branches, no masking)
+            // the prediction of call s + 1 is requested from LDS while call s runs and taken into scalar registers at the
+            // top of the next trip: the chain never waits for an LDS read either
+            uint32_t nx[14];
+            auto request = [&](uint32_t s, uint32_t (&v)[14]) {
+                const uint32_t* p = reinterpret_cast<const uint32_t*>(s_pred + 7 * s);
+#pragma unroll
+                for (int i = 0; i < 14; ++i) v[i] = p[i];
+            };
+            request(0, nx);
 #pragma unroll 1
             for (uint32_t s = 0; s < nc; ++s) {
-                const MirrorPred pr = *reinterpret_cast<const MirrorPred*>(s_pred + 7 * s);
+                uint32_t cur[14];
+#pragma unroll
+                for (int i = 0; i < 14; ++i) cur[i] = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(nx[i])));
+                if (s + 1 < nc) request(s + 1, nx);
+                MirrorPred pr;
+                __builtin_memcpy(&pr, cur, sizeof pr);
                 CallRec rec;
                 rec.pos = st.position;
                 rec.drift = 0.0;
