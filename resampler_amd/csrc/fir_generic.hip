@@ -13,6 +13,7 @@
 // 256 consecutive output frames.  Samples come straight from [hist|in] in HBM/L2 (each lane
 // reads 16-byte-contiguous frames); this kernel is the correctness backbone and the latency
 // path -- the throughput path for rational rate pairs is fir_periodic.hip.
+#include <algorithm>
 #include "fir_kernels.h"
 
 namespace rsmp {
@@ -141,8 +142,7 @@ __global__ __launch_bounds__(kBlock) void fir_tail_copy_kernel(const FirStreamDe
 // stream's class table was built for -- the same phase rows and frac the periodic kernel pre-mixed -- and
 // outputs at an integer position take the previous frame and row 1023 where the wrap bitmap says so
 // (resampler_fir.rs:544, :562-565).
-__global__ __launch_bounds__(kBlock) void fir_repair_kernel(const FirStreamDesc* __restrict__ descs,
-                                                            uint32_t n_streams, NfArgs nf) {
+__device__ __forceinline__ void fir_repair_body(const FirStreamDesc* __restrict__ descs, uint32_t n_streams, const NfArgs& nf) {
     if (__hip_atomic_load(nf.words, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != nf.tag) return;
     const int g = threadIdx.x & (kLanesPerFrame - 1);
     const uint32_t slot = threadIdx.x / kLanesPerFrame;
@@ -211,6 +211,18 @@ __global__ __launch_bounds__(kBlock) void fir_repair_kernel(const FirStreamDesc*
         if (threadIdx.x == 0) (void)atomicAnd(nf.words + 1 + (idx >> 5), ~(1u << (idx & 31)));   // the bitmap is zero again for the next launch
     }
 }
+__global__ __launch_bounds__(kBlock) void fir_repair_kernel(const FirStreamDesc* __restrict__ descs,
+                                                            uint32_t n_streams, NfArgs nf) {
+    fir_repair_body(descs, n_streams, nf);
+}
+struct RepairMulti {
+    const FirStreamDesc* descs[kMaxRepairJobs];
+    uint32_t n_streams[kMaxRepairJobs];
+    NfArgs nf[kMaxRepairJobs];
+};
+__global__ __launch_bounds__(kBlock) void fir_repair_multi_kernel(const RepairMulti m) {   // grid = (blocks, jobs)
+    fir_repair_body(m.descs[blockIdx.y], m.n_streams[blockIdx.y], m.nf[blockIdx.y]);
+}
 
 }  // namespace
 
@@ -219,6 +231,25 @@ hipError_t launch_fir_repair(const FirStreamDesc* d_descs, uint32_t n_streams, c
     const uint32_t total = n_streams * nf.chunks;
     hipLaunchKernelGGL(fir_repair_kernel, dim3(total < 512 ? total : 512), dim3(kBlock), 0, stream, d_descs, n_streams, nf);
     return hipGetLastError();
+}
+
+hipError_t launch_fir_repair_multi(const RepairJob* jobs, size_t n_jobs, hipStream_t stream) {
+    for (size_t j = 0; j < n_jobs;) {
+        RepairMulti m{};
+        uint32_t n = 0, max_total = 0;
+        for (; j < n_jobs && n < kMaxRepairJobs; ++j) {
+            if (jobs[j].n_streams == 0 || !jobs[j].nf.words || jobs[j].nf.chunks == 0) continue;
+            m.descs[n] = jobs[j].d_descs;
+            m.n_streams[n] = jobs[j].n_streams;
+            m.nf[n] = jobs[j].nf;
+            max_total = std::max(max_total, jobs[j].n_streams * jobs[j].nf.chunks);
+            ++n;
+        }
+        if (n == 0) continue;
+        hipLaunchKernelGGL(fir_repair_multi_kernel, dim3(max_total < 512 ? max_total : 512, n), dim3(kBlock), 0, stream, m);
+        if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 hipError_t launch_fir_generic(const FirStreamDesc* d_descs, uint32_t n_streams, uint32_t max_out,

@@ -53,6 +53,14 @@ hipError_t launch_fir_generic(const FirStreamDesc* d_descs, uint32_t n_streams, 
 // Re-evaluates, in the reference's two-row form, the output chunks a periodic launch marked as non-finite
 // (fir_nonfinite.h); exits at once when the launch marked nothing.
 hipError_t launch_fir_repair(const FirStreamDesc* d_descs, uint32_t n_streams, const NfArgs& nf, hipStream_t stream);
+// The same for up to eight groups of streams (each with its own marks) in one launch.
+struct RepairJob {
+    const FirStreamDesc* d_descs;
+    uint32_t n_streams;
+    NfArgs nf;
+};
+constexpr uint32_t kMaxRepairJobs = 8;
+hipError_t launch_fir_repair_multi(const RepairJob* jobs, size_t n_jobs, hipStream_t stream);
 // Copies the still-buffered tail of [hist|in] into hist_next; grid = (blocks, streams).
 hipError_t launch_fir_tail_copy(const FirStreamDesc* d_descs, uint32_t n_streams,
                                 uint32_t max_tail_values, hipStream_t stream);

@@ -157,11 +157,25 @@ struct LsRunArgs {
     uint32_t* wrap_bits;       // [n][wrap_words]
     uint32_t* counts;          // [k][n][2] in the caller's order: (consumed, produced) per call in f32 values
     uint64_t* last_counts;     // [n][2], internal order: the last call's (rsmp_fir_lockstep_counts)
-    uint32_t* status;
+    uint32_t* status;          // per-stream flags: ORed into
+    uint32_t* zero_status;     // non-null: `status` is a scratch copy of a run planned AHEAD -- cleared here first (the commit ORs it in)
     uint64_t in_offset;        // frames added to every stream's `in`
     uint32_t n_streams, k, in_frames, wrap_words, append, hist_parity;
 };
 hipError_t launch_fir_lockstep_plan(const LsRunArgs& args, hipStream_t stream);
+// One wave that sleeps until `ticks` of the 100 MHz clock have passed (0: returns at once): what the batch tries out with
+// whether two streams run side by side (pick_plan_stream).
+hipError_t launch_fir_lockstep_idle(uint32_t ticks, hipStream_t stream);
+// A run planned ahead (on a stream of its own, while the previous run computes) left its results in scratch copies:
+// states, append positions, the last call's counts, status flags -> the batch's own, when the run is really asked for.
+struct LsCommitArgs {
+    FirMirrorState* states; const FirMirrorState* sp_states;
+    uint64_t* cursor; const uint64_t* sp_cursor;
+    uint64_t* last_counts; const uint64_t* sp_last_counts;
+    uint32_t* status; const uint32_t* sp_status;
+    uint32_t n_streams;
+};
+hipError_t launch_fir_lockstep_commit(const LsCommitArgs& args, hipStream_t stream);
 hipError_t launch_fir_lockstep_gather_counts(const uint64_t* last_counts, const LsRunStream* rs, uint32_t* counts, uint32_t n,
                                              hipStream_t stream);
 

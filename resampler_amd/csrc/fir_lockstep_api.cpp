@@ -6,7 +6,9 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -47,10 +49,28 @@ struct rsmp_fir_lockstep {
     struct RunGroup { rsmp::PeriodicGeometry geo; size_t first = 0, count = 0; uint32_t max_out_step = 0; };
     int run_state = 0;          // 0: not looked at yet, 1: every rate pair has a bulk kernel, -1: runs are loops of steps
     std::vector<RunGroup> run_groups;
-    DeviceBuffer d_run_descs, d_run_rs, d_run_bits, d_run_counts, d_run_nf, d_run_work, d_run_preds, d_run_recs, d_run_states0;
+    // The run's descriptors, bitmaps, per-call counts and call records exist twice ("slots", used alternately): the NEXT run
+    // is planned ahead on a stream of its own while the current one computes (plan_ahead below) and must not overwrite
+    // what the current run's kernels and the caller (run_counts) still read.
+    struct RunSlot { DeviceBuffer descs, bits, counts, recs; hipEvent_t compute_done = nullptr; bool used = false; };
+    RunSlot slot[2];
+    int next_slot = 0, last_slot = 0;
+    DeviceBuffer d_run_rs, d_run_nf, d_run_work, d_run_preds, d_run_states0;
+    // planned ahead: states / append positions / last counts / status flags of the run AFTER the current one, in scratch
+    // copies until the run is really asked for (then committed by one small kernel), or dropped
+    DeviceBuffer sp_states, sp_cursor, sp_last, sp_status;
+    hipStream_t plan_stream = nullptr;   // the candidate picked for the caller's stream of the last run (pick_plan_stream)
+    hipStream_t plan_candidates[2] = {nullptr, nullptr};
+    std::map<hipStream_t, int> plan_pick;   // caller's stream -> candidate that runs beside it (-1: none does)
+    hipEvent_t ev_ready = nullptr, plan_done = nullptr;
+    struct RunKey { uint32_t k = 0, in_frames = 0, append = 0, parity = 0; uint64_t in_offset = 0, seq = 0; int slot = 0; bool valid = false; };
+    RunKey ahead;               // what the plan stream was asked to plan
+    bool ahead_inflight = false;   // ... and has not been waited for since
+    RunKey prev;                // the previous run (the pattern the next one is guessed from)
+    uint64_t run_seq = 0;
     uint32_t run_wrap_words = 0, run_k = 0, run_nf_tag = 0;
     bool run_planned = false;   // the most recent run went through the device planner
-    size_t run_counts_k = 0;    // calls of the most recent run whose counts are in d_run_counts (0: it was a loop of steps)
+    size_t run_counts_k = 0;    // calls of the most recent run whose counts are in slot[last_slot].counts
     std::vector<uint32_t> h_run_counts;
     // optional timing of the step launches (rsmp_fir_lockstep_set_profiling): ring of event pairs
     static constexpr int kProfRing = 64;
@@ -60,6 +80,8 @@ struct rsmp_fir_lockstep {
 };
 
 namespace {
+
+int drop_plan_ahead(rsmp_fir_lockstep* ls, hipStream_t s);   // (rsmp_fir_lockstep_run, below)
 
 // A stream's buffered frames alternate between its two history buffers (fir_lockstep.h, LockstepStream):
 // the next step (index ls->step) reads `hist` when its index is even.  After any number of steps the handle's
@@ -248,6 +270,17 @@ extern "C" void rsmp_fir_lockstep_free(rsmp_fir_lockstep* ls) {
     if (!ls) return;
     DeviceGuard guard(ls->device);
     (void)rsmp_fir_lockstep_sync(ls);
+    for (hipStream_t& q : ls->plan_candidates) {
+        if (!q) continue;
+        (void)hipStreamSynchronize(q);
+        (void)hipStreamDestroy(q);
+        q = nullptr;
+    }
+    if (ls->plan_stream) {
+        ls->plan_stream = nullptr;
+    }
+    for (hipEvent_t e : {ls->ev_ready, ls->plan_done, ls->slot[0].compute_done, ls->slot[1].compute_done})
+        if (e) (void)hipEventDestroy(e);
     if (ls->own_stream) {
         rsmp::split_release_stream(ls->device, ls->own_stream);
         (void)hipStreamDestroy(ls->own_stream);
@@ -272,6 +305,8 @@ extern "C" int rsmp_fir_lockstep_bind(rsmp_fir_lockstep* ls, const float* const*
     DeviceGuard guard(ls->device);
     const size_t n = ls->rs.size();
     if (ls->last_stream) RSMP_HIP_CHECK(hipStreamSynchronize(ls->last_stream));
+    if (int rc = drop_plan_ahead(ls, nullptr)) return rc;
+    ls->prev.valid = false;
     refresh_history_index(ls);
     bool aligned8 = true;
     for (size_t k = 0; k < n; ++k) {
@@ -318,6 +353,8 @@ extern "C" int rsmp_fir_lockstep_step(rsmp_fir_lockstep* ls, size_t in_frames, s
         // steps of one batch are ordered: a change of stream waits for the previous step
         RSMP_HIP_CHECK(hipStreamSynchronize(ls->last_stream));
     }
+    if (int rc = drop_plan_ahead(ls, s)) return rc;   // (a run planned ahead read the states this step is about to change)
+    ls->prev.valid = false;
     rsmp::LockstepArgs a;
     a.groups = ls->d_groups.as<LockstepGroup>();
     a.streams = ls->d_streams.as<LockstepStream>();
@@ -397,6 +434,8 @@ extern "C" int rsmp_fir_lockstep_reset(rsmp_fir_lockstep* ls) {
     DeviceGuard guard(ls->device);
     const size_t n = ls->rs.size();
     if (ls->last_stream) RSMP_HIP_CHECK(hipStreamSynchronize(ls->last_stream));
+    if (int rc = drop_plan_ahead(ls, nullptr)) return rc;
+    ls->prev.valid = false;
     for (rsmp_fir* r : ls->rs) r->mirror.reset();   // resampler_fir.rs:638-642
     RSMP_HIP_CHECK(hipMemset(ls->d_cursor.get(), 0, n * sizeof(uint64_t)));
     RSMP_HIP_CHECK(hipMemset(ls->d_status.get(), 0, n * sizeof(uint32_t)));
@@ -438,6 +477,46 @@ extern "C" int rsmp_fir_lockstep_mean_kernel_ms(rsmp_fir_lockstep* ls, float* ms
 
 // ---- rsmp_fir_lockstep_run: k consecutive calls per stream in one go -----------------------------------------
 namespace {
+
+// The plan stream of a caller's stream: one that runs BESIDE it.  HIP deals a handful of hardware queues to its streams in
+// turn, and two streams on one queue run their kernels one after the other (the bench's torch stream and the batch's plan
+// stream met on one: planned ahead, nothing overlapped).  Nothing tells which queue a stream has, so it is tried out, once per
+// caller's stream: a kernel that idles 300 us goes to the caller's stream, an empty one to a candidate; if the candidate is
+// through before that one can be, the two run side by side.  Two candidates created one after the other sit
+// on different queues, so at most one of them shares the caller's.  (A stream of higher priority has a queue of its own for
+// certain -- and starves the short kernels between the bulk launches: a run of 16 calls took 2.7x as long.)
+int pick_plan_stream(rsmp_fir_lockstep* ls, hipStream_t s) {
+    auto it = ls->plan_pick.find(s);
+    if (it == ls->plan_pick.end()) {
+        int pick = -1;
+        for (int c = 0; c < 2 && pick < 0; ++c) {
+            const auto t0 = std::chrono::steady_clock::now();
+            RSMP_HIP_CHECK(rsmp::launch_fir_lockstep_idle(30000u, s));   // (100 MHz ticks: 300 us)
+            RSMP_HIP_CHECK(rsmp::launch_fir_lockstep_idle(0u, ls->plan_candidates[c]));
+            RSMP_HIP_CHECK(hipStreamSynchronize(ls->plan_candidates[c]));
+            // behind the idling kernel on one queue the candidate cannot be through before that one is
+            if (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() < 200.0) pick = c;
+        }
+        static const bool verbose = rsmp::knob("RSMP_FIR_VERBOSE") != nullptr;
+        if (verbose) fprintf(stderr, "[rsmp] lock-step run: plan stream candidate %d runs beside stream %p\n", pick, static_cast<void*>(s));
+        it = ls->plan_pick.emplace(s, pick).first;
+    }
+    ls->plan_stream = it->second >= 0 ? ls->plan_candidates[it->second] : nullptr;
+    return RSMP_OK;
+}
+
+// Whatever the plan stream was asked to plan ahead is dropped: the caller did something else than repeat its run.  Its
+// kernels only WRITE scratch copies and the other slot, but they READ the batch's states, append positions and bound
+// pointers: before those change, the plan stream must have finished (`s`: that stream waits; null: the host does).
+int drop_plan_ahead(rsmp_fir_lockstep* ls, hipStream_t s) {
+    if (ls->ahead_inflight && ls->plan_done) {
+        if (s) RSMP_HIP_CHECK(hipStreamWaitEvent(s, ls->plan_done, 0));
+        else RSMP_HIP_CHECK(hipEventSynchronize(ls->plan_done));
+    }
+    ls->ahead_inflight = false;
+    ls->ahead.valid = false;
+    return RSMP_OK;
+}
 
 // The bulk kernels' side of a batch: one geometry + class table per rate pair, the constant half of every
 // stream's descriptor, the planner's waves.  Done once, at the first run.
@@ -502,12 +581,24 @@ int prepare_run(rsmp_fir_lockstep* ls) {
         }
         k = e;
     }
-    if (ls->d_run_descs.reserve(n * sizeof(rsmp::FirStreamDesc)) != hipSuccess ||
+    if (ls->slot[0].descs.reserve(n * sizeof(rsmp::FirStreamDesc)) != hipSuccess ||
+        ls->slot[1].descs.reserve(n * sizeof(rsmp::FirStreamDesc)) != hipSuccess ||
+        ls->sp_states.reserve(n * sizeof(FirMirrorState)) != hipSuccess ||
+        ls->sp_cursor.reserve(n * sizeof(uint64_t)) != hipSuccess ||
+        ls->sp_last.reserve(2 * n * sizeof(uint64_t)) != hipSuccess ||
+        ls->sp_status.reserve(n * sizeof(uint32_t)) != hipSuccess ||
+        hipStreamCreateWithFlags(&ls->plan_candidates[0], hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&ls->plan_candidates[1], hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&ls->ev_ready, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ls->plan_done, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ls->slot[0].compute_done, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ls->slot[1].compute_done, hipEventDisableTiming) != hipSuccess ||
         ls->d_run_rs.reserve(n * sizeof(rsmp::LsRunStream)) != hipSuccess ||
         ls->d_run_states0.reserve(n * sizeof(FirMirrorState)) != hipSuccess ||
         ls->d_run_work.reserve(64 * sizeof(unsigned long long)) != hipSuccess)
         return rsmp::fail(RSMP_ERR_HIP, "lock-step run: cannot allocate device state");
-    RSMP_HIP_CHECK(hipMemcpy(ls->d_run_descs.get(), descs.data(), n * sizeof(rsmp::FirStreamDesc), hipMemcpyHostToDevice));
+    for (auto& sl : ls->slot)
+        RSMP_HIP_CHECK(hipMemcpy(sl.descs.get(), descs.data(), n * sizeof(rsmp::FirStreamDesc), hipMemcpyHostToDevice));
     RSMP_HIP_CHECK(hipMemcpy(ls->d_run_rs.get(), rstreams.data(), n * sizeof(rsmp::LsRunStream), hipMemcpyHostToDevice));
     RSMP_HIP_CHECK(hipMemset(ls->d_run_work.get(), 0, 64 * sizeof(unsigned long long)));
     ls->run_state = 1;
@@ -537,81 +628,157 @@ extern "C" int rsmp_fir_lockstep_run(rsmp_fir_lockstep* ls, size_t k_steps, size
     // `append` -- from the front of the buffer (the append position starts again there).
     const bool loop_of_steps = ls->run_state < 0 || k_steps == 1 || !whole_accept ||
                                k_steps * static_cast<uint64_t>(ls->step_frames) > (1u << 27);
-    if (!append && loop_of_steps)   // (the device planner starts a run at the front itself: no launch for it)
-        RSMP_HIP_CHECK(hipMemsetAsync(ls->d_cursor.get(), 0, ls->rs.size() * sizeof(uint64_t), s));
     const size_t n = ls->rs.size();
     if (k_steps > (1u << 20)) return rsmp::fail(RSMP_ERR_INVALID_ARGUMENT, "rsmp_fir_lockstep_run: at most 2^20 calls per run");
     const uint32_t k = static_cast<uint32_t>(k_steps);
-    if (k > ls->run_k) {
-        RSMP_HIP_CHECK(hipStreamSynchronize(s));
-        if (ls->d_run_counts.reserve(2 * n * static_cast<size_t>(k) * sizeof(uint32_t)) != hipSuccess ||
-            ls->d_run_preds.reserve(n * static_cast<size_t>(k) * sizeof(rsmp::MirrorPred)) != hipSuccess ||
-            ls->d_run_recs.reserve(n * static_cast<size_t>(k) * 24) != hipSuccess)
-            return rsmp::fail(RSMP_ERR_HIP, "lock-step run: cannot allocate the plan of %u calls", k);
-        ls->run_k = k;
-    }
-    if (loop_of_steps) {
-        for (uint32_t i = 0; i < k; ++i) {
-            if (int rc = rsmp_fir_lockstep_step(ls, in_frames, in_offset_frames + static_cast<size_t>(i) * in_frames, nullptr, 1, stream))
-                return rc;
-            RSMP_HIP_CHECK(rsmp::launch_fir_lockstep_gather_counts(ls->d_counts.as<uint64_t>(), ls->d_run_rs.as<rsmp::LsRunStream>(),
-                                                                   ls->d_run_counts.as<uint32_t>() + 2 * n * static_cast<size_t>(i),
-                                                                   static_cast<uint32_t>(n), s));
-        }
-        ls->run_counts_k = k;
-        ls->run_planned = false;
-        return RSMP_OK;
-    }
-    if (ls->last_stream && ls->last_stream != s) RSMP_HIP_CHECK(hipStreamSynchronize(ls->last_stream));
-    // workspaces that grow with k: the per-call counts, the bitmaps of wrapped outputs, the non-finite marks
+    // workspaces that grow with k: the per-call counts and records, the predictions, the bitmaps of wrapped outputs, the
+    // non-finite marks.  (A reallocation waits for both streams: kernels planned ahead may still use the old buffers.)
     uint32_t wrap_words = 1, nf_words = 0;
     for (const auto& g : ls->run_groups) {
         const uint64_t n_out_max = static_cast<uint64_t>(k) * g.max_out_step;
         wrap_words = std::max<uint32_t>(wrap_words, static_cast<uint32_t>(n_out_max / g.geo.den / 32 + 2));
         nf_words += 1 + static_cast<uint32_t>((g.count * ((n_out_max >> rsmp::kNfChunkShift) + 1) + 31) / 32);
     }
-    if (wrap_words > ls->run_wrap_words) {
+    if (k > ls->run_k || (!loop_of_steps && wrap_words > ls->run_wrap_words)) {
         RSMP_HIP_CHECK(hipStreamSynchronize(s));
-        if (ls->d_run_bits.reserve(n * static_cast<size_t>(wrap_words) * sizeof(uint32_t)) != hipSuccess)
+        if (int rc = drop_plan_ahead(ls, nullptr)) return rc;
+        const uint32_t kk = std::max(k, ls->run_k), ww = std::max(wrap_words, ls->run_wrap_words);
+        for (auto& sl : ls->slot)
+            if (sl.counts.reserve(2 * n * static_cast<size_t>(kk) * sizeof(uint32_t)) != hipSuccess ||
+                sl.recs.reserve(n * static_cast<size_t>(kk) * 24) != hipSuccess ||
+                sl.bits.reserve(n * static_cast<size_t>(ww) * sizeof(uint32_t)) != hipSuccess)
+                return rsmp::fail(RSMP_ERR_HIP, "lock-step run: cannot allocate the plan of %u calls", k);
+        if (ls->d_run_preds.reserve(n * static_cast<size_t>(kk) * sizeof(rsmp::MirrorPred)) != hipSuccess)
             return rsmp::fail(RSMP_ERR_HIP, "lock-step run: cannot allocate the plan of %u calls", k);
-        ls->run_wrap_words = wrap_words;
+        ls->run_k = kk;
+        ls->run_wrap_words = ww;
     }
+    if (loop_of_steps) {
+        if (int rc = drop_plan_ahead(ls, s)) return rc;
+        ls->prev.valid = false;
+        if (!append)   // (the device planner starts a run at the front itself: no launch for it)
+            RSMP_HIP_CHECK(hipMemsetAsync(ls->d_cursor.get(), 0, n * sizeof(uint64_t), s));
+        const int sl = ls->next_slot;
+        for (uint32_t i = 0; i < k; ++i) {
+            if (int rc = rsmp_fir_lockstep_step(ls, in_frames, in_offset_frames + static_cast<size_t>(i) * in_frames, nullptr, 1, stream))
+                return rc;
+            RSMP_HIP_CHECK(rsmp::launch_fir_lockstep_gather_counts(ls->d_counts.as<uint64_t>(), ls->d_run_rs.as<rsmp::LsRunStream>(),
+                                                                   ls->slot[sl].counts.as<uint32_t>() + 2 * n * static_cast<size_t>(i),
+                                                                   static_cast<uint32_t>(n), s));
+        }
+        ls->last_slot = sl;
+        ls->run_counts_k = k;
+        ls->run_planned = false;
+        return RSMP_OK;
+    }
+    if (ls->last_stream && ls->last_stream != s) RSMP_HIP_CHECK(hipStreamSynchronize(ls->last_stream));
     if (nf_words * sizeof(uint32_t) > ls->d_run_nf.capacity()) {
         RSMP_HIP_CHECK(hipStreamSynchronize(s));
         RSMP_HIP_CHECK(ls->d_run_nf.reserve(nf_words * sizeof(uint32_t)));
         RSMP_HIP_CHECK(hipMemsetAsync(ls->d_run_nf.get(), 0, ls->d_run_nf.capacity(), s));
     }
-    rsmp::LsRunArgs a;
-    a.streams = ls->d_streams.as<LockstepStream>();
-    a.rs = ls->d_run_rs.as<rsmp::LsRunStream>();
-    a.states_in = ls->d_states.as<FirMirrorState>();
-    a.states_out = ls->d_states.as<FirMirrorState>();
-    a.states_before = ls->d_run_states0.as<FirMirrorState>();
-    a.preds = ls->d_run_preds.as<rsmp::MirrorPred>();
-    a.call_recs = ls->d_run_recs.get();
-    a.cursor_in = ls->d_cursor.as<uint64_t>();
-    a.cursor_out = ls->d_cursor.as<uint64_t>();
-    a.descs = ls->d_run_descs.as<rsmp::FirStreamDesc>();
-    a.wrap_bits = ls->d_run_bits.as<uint32_t>();
-    a.counts = ls->d_run_counts.as<uint32_t>();
-    a.last_counts = ls->d_counts.as<uint64_t>();
-    a.status = ls->d_status.as<uint32_t>();
-    a.in_offset = in_offset_frames;
-    a.n_streams = static_cast<uint32_t>(n);
-    a.k = k;
-    a.in_frames = static_cast<uint32_t>(in_frames);
-    a.wrap_words = ls->run_wrap_words;
-    a.append = append ? 1u : 0u;   // (0: the planner starts the run at the front of `out`)
-    a.hist_parity = ls->hist_parity;
+    // ---- the plan: taken from the plan stream if this very run was planned ahead there, made here otherwise --------
+    const int sl = ls->next_slot;
+    rsmp_fir_lockstep::RunKey key;
+    key.k = k;
+    key.in_frames = static_cast<uint32_t>(in_frames);
+    key.append = append ? 1u : 0u;
+    key.parity = ls->hist_parity;
+    key.in_offset = in_offset_frames;
+    key.seq = ls->run_seq;
+    key.slot = sl;
+    key.valid = true;
+    auto same_key = [](const rsmp_fir_lockstep::RunKey& x, const rsmp_fir_lockstep::RunKey& y) {
+        return x.valid && y.valid && x.k == y.k && x.in_frames == y.in_frames && x.append == y.append && x.parity == y.parity &&
+               x.in_offset == y.in_offset && x.seq == y.seq && x.slot == y.slot;
+    };
+    auto plan_args = [&](const rsmp_fir_lockstep::RunKey& kk, bool scratch) {
+        rsmp::LsRunArgs a;
+        rsmp_fir_lockstep::RunSlot& t = ls->slot[kk.slot];
+        a.streams = ls->d_streams.as<LockstepStream>();
+        a.rs = ls->d_run_rs.as<rsmp::LsRunStream>();
+        a.states_in = ls->d_states.as<FirMirrorState>();
+        a.states_out = scratch ? ls->sp_states.as<FirMirrorState>() : ls->d_states.as<FirMirrorState>();
+        a.states_before = ls->d_run_states0.as<FirMirrorState>();
+        a.preds = ls->d_run_preds.as<rsmp::MirrorPred>();
+        a.call_recs = t.recs.get();
+        a.cursor_in = ls->d_cursor.as<uint64_t>();
+        a.cursor_out = scratch ? ls->sp_cursor.as<uint64_t>() : ls->d_cursor.as<uint64_t>();
+        a.descs = t.descs.as<rsmp::FirStreamDesc>();
+        a.wrap_bits = t.bits.as<uint32_t>();
+        a.counts = t.counts.as<uint32_t>();
+        a.last_counts = scratch ? ls->sp_last.as<uint64_t>() : ls->d_counts.as<uint64_t>();
+        a.status = scratch ? ls->sp_status.as<uint32_t>() : ls->d_status.as<uint32_t>();
+        a.zero_status = scratch ? ls->sp_status.as<uint32_t>() : nullptr;
+        a.in_offset = kk.in_offset;
+        a.n_streams = static_cast<uint32_t>(n);
+        a.k = kk.k;
+        a.in_frames = kk.in_frames;
+        a.wrap_words = ls->run_wrap_words;
+        a.append = kk.append;
+        a.hist_parity = kk.parity;
+        return a;
+    };
     if (ls->profiling)
         RSMP_HIP_CHECK(hipEventRecord(ls->prof_start[ls->prof_count % rsmp_fir_lockstep::kProfRing], s));
-    RSMP_HIP_CHECK(rsmp::launch_fir_lockstep_plan(a, s));
-    const rsmp::FirStreamDesc* d_descs = ls->d_run_descs.as<rsmp::FirStreamDesc>();
-    // One launch of the bulk kernel per rate pair, one after the other on the caller's stream.  (Measured and dropped: the
-    // rate pairs' launches side by side on streams of their own, each with its share of the compute units -- a run of 16
-    // calls is then bound by the host's ~40 stream / event / launch calls, 0.38 ms against 0.25 ms.)
+    if (same_key(ls->ahead, key)) {
+        // planned while the previous run computed: wait for it (an event, no host block) and take its results over
+        RSMP_HIP_CHECK(hipStreamWaitEvent(s, ls->plan_done, 0));
+        ls->ahead_inflight = false;
+        rsmp::LsCommitArgs c;
+        c.states = ls->d_states.as<FirMirrorState>();
+        c.sp_states = ls->sp_states.as<FirMirrorState>();
+        c.cursor = ls->d_cursor.as<uint64_t>();
+        c.sp_cursor = ls->sp_cursor.as<uint64_t>();
+        c.last_counts = ls->d_counts.as<uint64_t>();
+        c.sp_last_counts = ls->sp_last.as<uint64_t>();
+        c.status = ls->d_status.as<uint32_t>();
+        c.sp_status = ls->sp_status.as<uint32_t>();
+        c.n_streams = static_cast<uint32_t>(n);
+        RSMP_HIP_CHECK(rsmp::launch_fir_lockstep_commit(c, s));
+    } else {
+        if (int rc = drop_plan_ahead(ls, s)) return rc;   // (whatever the plan stream still does: finished before this stream goes on)
+        RSMP_HIP_CHECK(rsmp::launch_fir_lockstep_plan(plan_args(key, false), s));
+    }
+    ls->ahead.valid = false;
+    // Is the NEXT run worth planning ahead?  When this run repeats the previous one's shape (the loop of a caller that
+    // feeds run after run): then the run after this one is guessed to repeat it again, its input offset moving on as it
+    // did between the last two.  Its planner goes to the plan stream below and runs beside this run's bulk kernels (its
+    // kernels use no LDS: the split kernel's ring of images fills a CU's).  What that buys depends on the batch: a small one
+    // (128 streams: the bulk kernels leave most of a run's time to the chain's latency) runs 1.5x faster, config 4's 1024
+    // streams the same -- the stagers of the split kernel and the chain compete for the same issue slots, and each is slowed
+    // by what the other takes.  RSMP_LS_AHEAD=0 (debug): every run plans on the caller's stream.
+    static const bool ahead_on = [] { const char* e = rsmp::knob("RSMP_LS_AHEAD"); return !e || atoi(e) != 0; }();
+    bool repeat = ahead_on && ls->prev.valid && ls->prev.k == key.k && ls->prev.in_frames == key.in_frames && ls->prev.append == key.append;
+    if (repeat) {
+        if (int rc = pick_plan_stream(ls, s)) return rc;
+        repeat = ls->plan_stream != nullptr;
+    }
+    RSMP_HIP_CHECK(hipEventRecord(ls->ev_ready, s));   // the states after this run are in place
+    if (repeat) {   // (before this run's bulk kernels are launched: the planner starts as soon as the states are there)
+        rsmp_fir_lockstep::RunKey nx = key;
+        nx.in_offset = key.in_offset + (key.in_offset - ls->prev.in_offset);
+        nx.parity = ls->hist_parity ^ 1u;
+        nx.seq = ls->run_seq + 1;
+        nx.slot = sl ^ 1;
+        hipStream_t q = ls->plan_stream;
+        RSMP_HIP_CHECK(hipStreamWaitEvent(q, ls->ev_ready, 0));
+        if (ls->slot[nx.slot].used) RSMP_HIP_CHECK(hipStreamWaitEvent(q, ls->slot[nx.slot].compute_done, 0));   // its buffers are free
+        RSMP_HIP_CHECK(rsmp::launch_fir_lockstep_plan(plan_args(nx, true), q));
+        RSMP_HIP_CHECK(hipEventRecord(ls->plan_done, q));
+        ls->ahead = nx;
+        ls->ahead_inflight = true;
+    }
+    const rsmp::FirStreamDesc* d_descs = ls->slot[sl].descs.as<rsmp::FirStreamDesc>();
+    // The bulk kernels over the run's descriptors.  The rate pairs the split kernel takes go into launches shared by as
+    // many of them as have the same kernel build (launch_fir_split_multi), with one item-table launch in front and one
+    // repair launch behind for all of them: six rate pairs one after the other were 18 launches, most of a run of 16 calls.
+    // (Measured and dropped before that: the rate pairs' launches side by side on streams of their own, each with its share
+    // of the compute units -- a run of 16 calls was then bound by the host's ~40 stream / event / launch calls.)
     const size_t n_groups = ls->run_groups.size();
     uint32_t nf_off = 0, max_tail_values = 0;
+    std::vector<rsmp::SplitJob> split_jobs;
+    std::vector<rsmp::RepairJob> repair_jobs;
     for (size_t gi = 0; gi < n_groups; ++gi) {
         const auto& g = ls->run_groups[gi];
         const uint64_t n_out_max = static_cast<uint64_t>(k) * g.max_out_step;
@@ -622,13 +789,21 @@ extern "C" int rsmp_fir_lockstep_run(rsmp_fir_lockstep* ls, size_t k_steps, size
         if (++ls->run_nf_tag == 0) ls->run_nf_tag = 1;
         nf.tag = ls->run_nf_tag;
         nf_off += 1 + static_cast<uint32_t>((g.count * static_cast<uint64_t>(nf.chunks) + 31) / 32);
-        RSMP_HIP_CHECK(rsmp::launch_fir_periodic(d_descs + g.first, static_cast<uint32_t>(g.count), g.geo, max_blocks,
-                                                 ls->d_run_work.as<unsigned long long>() + gi, nf, s, false));
-        RSMP_HIP_CHECK(rsmp::launch_fir_repair(d_descs + g.first, static_cast<uint32_t>(g.count), nf, s));
+        if (g.geo.mfma == 3) {
+            split_jobs.push_back(rsmp::SplitJob{d_descs + g.first, static_cast<uint32_t>(g.count), &g.geo, max_blocks, nf});
+        } else {
+            RSMP_HIP_CHECK(rsmp::launch_fir_periodic(d_descs + g.first, static_cast<uint32_t>(g.count), g.geo, max_blocks,
+                                                     ls->d_run_work.as<unsigned long long>() + gi, nf, s));
+        }
+        repair_jobs.push_back(rsmp::RepairJob{d_descs + g.first, static_cast<uint32_t>(g.count), nf});
         const rsmp_fir* r0 = ls->rs[ls->order[g.first]];
         max_tail_values = std::max<uint32_t>(max_tail_values, static_cast<uint32_t>((r0->taps + 8) * r0->channels));
     }
+    if (!split_jobs.empty()) RSMP_HIP_CHECK(rsmp::launch_fir_split_multi(split_jobs.data(), split_jobs.size(), s));
+    RSMP_HIP_CHECK(rsmp::launch_fir_repair_multi(repair_jobs.data(), repair_jobs.size(), s));
     RSMP_HIP_CHECK(rsmp::launch_fir_tail_copy(d_descs, static_cast<uint32_t>(n), max_tail_values, s));
+    RSMP_HIP_CHECK(hipEventRecord(ls->slot[sl].compute_done, s));
+    ls->slot[sl].used = true;
     if (ls->profiling) {
         RSMP_HIP_CHECK(hipEventRecord(ls->prof_stop[ls->prof_count % rsmp_fir_lockstep::kProfRing], s));
         ++ls->prof_count;
@@ -636,9 +811,13 @@ extern "C" int rsmp_fir_lockstep_run(rsmp_fir_lockstep* ls, size_t k_steps, size
     ls->hist_parity ^= 1u;
     ls->step += k;
     ++ls->epoch;   // plans the one-call kernel made ahead belong to the states before the run
+    ++ls->run_seq;
     ls->run_counts_k = k;
     ls->run_planned = true;
     ls->last_stream = s;
+    ls->last_slot = sl;
+    ls->next_slot = sl ^ 1;
+    ls->prev = key;
     return RSMP_OK;
 }
 
@@ -650,7 +829,7 @@ extern "C" int rsmp_fir_lockstep_run_counts(rsmp_fir_lockstep* ls, size_t* consu
     const size_t n = ls->rs.size(), k = std::min(ls->run_counts_k, max_steps);
     if (ls->last_stream) RSMP_HIP_CHECK(hipStreamSynchronize(ls->last_stream));
     ls->h_run_counts.resize(2 * n * k);
-    RSMP_HIP_CHECK(hipMemcpy(ls->h_run_counts.data(), ls->d_run_counts.get(), 2 * n * k * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    RSMP_HIP_CHECK(hipMemcpy(ls->h_run_counts.data(), ls->slot[ls->last_slot].counts.get(), 2 * n * k * sizeof(uint32_t), hipMemcpyDeviceToHost));
     for (size_t i = 0; i < n * k; ++i) {
         if (consumed) consumed[i] = ls->h_run_counts[2 * i];
         if (produced) produced[i] = ls->h_run_counts[2 * i + 1];
@@ -666,7 +845,7 @@ extern "C" int rsmp_fir_lockstep_run_slow_calls(rsmp_fir_lockstep* ls, size_t* s
     if (ls->last_stream) RSMP_HIP_CHECK(hipStreamSynchronize(ls->last_stream));
     struct Rec { double pos, drift; uint32_t flags, pad; };
     std::vector<Rec> h(ls->rs.size() * ls->run_counts_k);
-    RSMP_HIP_CHECK(hipMemcpy(h.data(), ls->d_run_recs.get(), h.size() * sizeof(Rec), hipMemcpyDeviceToHost));
+    RSMP_HIP_CHECK(hipMemcpy(h.data(), ls->slot[ls->last_slot].recs.get(), h.size() * sizeof(Rec), hipMemcpyDeviceToHost));
     for (const Rec& r : h) *slow_calls += r.flags & 1u;
     return RSMP_OK;
 }

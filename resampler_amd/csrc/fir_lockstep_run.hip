@@ -52,19 +52,22 @@ __global__ __launch_bounds__(256) void fir_lockstep_predict_kernel(LsRunArgs a) 
     const uint32_t gs = t / a.k, c = t - gs * a.k;
     const MirrorRunBase base = mirror_run_base(a.states_in[gs], a.in_frames, a.k);
     if (base.usable) a.preds[t] = mirror_predict(base, c);
-    if (c == 0) a.states_before[gs] = a.states_in[gs];   // (the chain overwrites the states; the replay starts from these)
+    if (c == 0) {
+        a.states_before[gs] = a.states_in[gs];   // (the chain overwrites the states; the replay starts from these)
+        if (a.zero_status) a.zero_status[gs] = 0;
+    }
     for (uint32_t w = c; w < a.wrap_words; w += a.k) a.wrap_bits[static_cast<size_t>(gs) * a.wrap_words + w] = 0;
 }
 
-// K2 -- the serial chain: one wave per stream walks the stream's k calls (mirror_call_fast: two
-// dependent f64 operations per binade; mirror_call where a check fails); the whole wave moves the predictions into LDS
-// and the per-call counts and call records out of it, 64 calls at a time, so that the chain itself never waits for HBM.
-// The run's descriptor and the state after the run follow at the end.
-static_assert(sizeof(MirrorPred) == 56, "MirrorPred is staged as seven 64-bit words");
+// K2 -- the serial chain: one wave per stream walks the stream's k calls (mirror_call_chain: two dependent f64
+// operations per binade; mirror_call_fast / mirror_call where the rule or a check asks for them).  Every lane runs the
+// chain on the same values, so the control flow stays uniform (scalar branches, no masking).  The predictions and the
+// per-call results are staged through the wave's own registers, 64 calls at a time: lane j loads the prediction of call
+// j (the next 64 while these 64 run), the chain takes call s's words with v_readlane, and lane s keeps call s's record
+// and counts until the 64 are written back.  No LDS: the bulk kernels of the run before, which fill a CU's LDS with
+// their ring of images, share their CUs with this kernel when the run is planned ahead (fir_lockstep_api.cpp).
+static_assert(sizeof(MirrorPred) == 56, "MirrorPred is staged as fourteen 32-bit words");
 __global__ __launch_bounds__(64) void fir_lockstep_chain_kernel(LsRunArgs a) {
-    __shared__ uint64_t s_pred[64 * 7];
-    __shared__ uint64_t s_rec[64 * 3];
-    __shared__ uint32_t s_cnt[64 * 2];
     const uint32_t gs = blockIdx.x, lane = threadIdx.x;
     const LockstepStream ls = a.streams[gs];
     const LsRunStream rs = a.rs[gs];
@@ -83,69 +86,69 @@ __global__ __launch_bounds__(64) void fir_lockstep_chain_kernel(LsRunArgs a) {
     uint32_t n_out = 0, accepted = 0, consumed = 0, flags = 0;
     uint32_t last_c0 = 0, last_c1 = 0;
     const uint64_t* preds = reinterpret_cast<const uint64_t*>(a.preds + static_cast<size_t>(gs) * a.k);
-    uint64_t* recs = reinterpret_cast<uint64_t*>(a.call_recs) + static_cast<size_t>(gs) * a.k * 3;
+    CallRec* recs = reinterpret_cast<CallRec*>(a.call_recs) + static_cast<size_t>(gs) * a.k;
+    uint64_t mine[7], ahead[7];
+    auto fetch = [&](uint32_t c0, uint64_t (&v)[7]) {
+        const uint32_t c = c0 + lane < a.k ? c0 + lane : a.k - 1;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) v[i] = __builtin_nontemporal_load(preds + static_cast<size_t>(c) * 7 + i);
+    };
+    fetch(0, ahead);
     for (uint32_t c0 = 0; c0 < a.k; c0 += 64) {
         const uint32_t nc = a.k - c0 < 64u ? a.k - c0 : 64u;
-        for (uint32_t i = lane; i < 7 * nc; i += 64) s_pred[i] = preds[static_cast<size_t>(c0) * 7 + i];
-        __syncthreads();
-        {   // every lane runs the chain on the same values: the control flow stays uniform (scalar branches, no masking)
-            // the prediction of call s + 1 is requested from LDS while call s runs and taken into scalar registers at the
-            // top of the next trip: the chain never waits for an LDS read either
-            uint32_t nx[14];
-            auto request = [&](uint32_t s, uint32_t (&v)[14]) {
-                const uint32_t* p = reinterpret_cast<const uint32_t*>(s_pred + 7 * s);
 #pragma unroll
-                for (int i = 0; i < 14; ++i) v[i] = p[i];
-            };
-            request(0, nx);
+        for (int i = 0; i < 7; ++i) mine[i] = ahead[i];
+        if (c0 + 64 < a.k) fetch(c0 + 64, ahead);
+        double my_pos = 0.0, my_drift = 0.0;
+        uint32_t my_flags = 0, my_c0 = 0, my_c1 = 0;
 #pragma unroll 1
-            for (uint32_t s = 0; s < nc; ++s) {
-                uint32_t cur[14];
+        for (uint32_t s = 0; s < nc; ++s) {
+            uint32_t cur[14];
 #pragma unroll
-                for (int i = 0; i < 14; ++i) cur[i] = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(nx[i])));
-                if (s + 1 < nc) request(s + 1, nx);
-                MirrorPred pr;
-                __builtin_memcpy(&pr, cur, sizeof pr);
-                CallRec rec;
-                rec.pos = st.position;
-                rec.drift = 0.0;
-                rec.flags = st.abs_out != pr.m0 ? kCallAhead : 0u;
-                rec.pad = 0;
-                FirCallCounts c;
-                // nothing for the f64 drift to decide in this call (the rule): the chain alone, checked by the replay
-                const bool lean = chain_ready && pr.ties == 0 && st.abs_out == pr.m0 && st.abs_consumed == pr.c0 &&
-                                  st.read_position + st.available + a.in_frames <= kMirrorBufferSize &&
-                                  st.available + a.in_frames <= kMirrorInputCapacity && pr.n_total + 1 < ls.out_cap_frames;
-                if (lean) {
-                    mirror_call_chain(st, a.in_frames, pr, bn, c);
-                    rec.flags |= kCallLean;
-                } else if (!base.usable || !mirror_call_fast(st, a.in_frames, ls.out_cap_frames, pr, bn, c, [](uint32_t, uint32_t, double, double) {})) {
-                    const uint32_t ni = st.next_int;
-                    sink.periodic = wraps_exist && st.periodic_ok != 0;
-                    c = mirror_call(st, a.in_frames, ls.out_cap_frames, sink);
-                    rec.flags = kCallSlow | (ni < c.produced ? kCallHasInt : 0u);
-                    rec.drift = st.drift;
-                }
-                *reinterpret_cast<CallRec*>(s_rec + 3 * s) = rec;
-                if (c.accepted != a.in_frames) flags |= kLsStatusPartialAccept;
-                last_c0 = static_cast<uint32_t>(c.accepted) * C;
-                last_c1 = static_cast<uint32_t>(c.produced) * C;
-                s_cnt[2 * s] = last_c0;
-                s_cnt[2 * s + 1] = last_c1;
-                n_out += static_cast<uint32_t>(c.produced);
-                accepted += static_cast<uint32_t>(c.accepted);
-                consumed += static_cast<uint32_t>(c.consumed);
-                sink.rel += static_cast<uint32_t>(c.produced);
+            for (int i = 0; i < 7; ++i) {
+                cur[2 * i] = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(static_cast<uint32_t>(mine[i])), static_cast<int>(s)));
+                cur[2 * i + 1] = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(static_cast<uint32_t>(mine[i] >> 32)), static_cast<int>(s)));
             }
+            MirrorPred pr;
+            __builtin_memcpy(&pr, cur, sizeof pr);
+            const double pos0 = st.position;
+            double drift = 0.0;
+            uint32_t cf = st.abs_out != pr.m0 ? kCallAhead : 0u;
+            FirCallCounts c;
+            // nothing for the f64 drift to decide in this call (the rule): the chain alone, checked by the replay
+            const bool lean = chain_ready && pr.ties == 0 && st.abs_out == pr.m0 && st.abs_consumed == pr.c0 &&
+                              st.read_position + st.available + a.in_frames <= kMirrorBufferSize &&
+                              st.available + a.in_frames <= kMirrorInputCapacity && pr.n_total + 1 < ls.out_cap_frames;
+            if (lean) {
+                mirror_call_chain(st, a.in_frames, pr, bn, c);
+                cf |= kCallLean;
+            } else if (!base.usable || !mirror_call_fast(st, a.in_frames, ls.out_cap_frames, pr, bn, c, [](uint32_t, uint32_t, double, double) {})) {
+                const uint32_t ni = st.next_int;
+                sink.periodic = wraps_exist && st.periodic_ok != 0;
+                c = mirror_call(st, a.in_frames, ls.out_cap_frames, sink);
+                cf = kCallSlow | (ni < c.produced ? kCallHasInt : 0u);
+                drift = st.drift;
+            }
+            if (c.accepted != a.in_frames) flags |= kLsStatusPartialAccept;
+            last_c0 = static_cast<uint32_t>(c.accepted) * C;
+            last_c1 = static_cast<uint32_t>(c.produced) * C;
+            const bool me = lane == s;   // lane s keeps call s's record and counts
+            my_pos = me ? pos0 : my_pos;
+            my_drift = me ? drift : my_drift;
+            my_flags = me ? cf : my_flags;
+            my_c0 = me ? last_c0 : my_c0;
+            my_c1 = me ? last_c1 : my_c1;
+            n_out += static_cast<uint32_t>(c.produced);
+            accepted += static_cast<uint32_t>(c.accepted);
+            consumed += static_cast<uint32_t>(c.consumed);
+            sink.rel += static_cast<uint32_t>(c.produced);
         }
-        __syncthreads();
-        for (uint32_t i = lane; i < 3 * nc; i += 64) recs[static_cast<size_t>(c0) * 3 + i] = s_rec[i];
         if (lane < nc) {
+            recs[c0 + lane] = CallRec{my_pos, my_drift, my_flags, 0u};
             uint32_t* counts = a.counts + 2 * (static_cast<size_t>(c0 + lane) * a.n_streams + rs.caller);
-            counts[0] = s_cnt[2 * lane];
-            counts[1] = s_cnt[2 * lane + 1];
+            counts[0] = my_c0;
+            counts[1] = my_c1;
         }
-        __syncthreads();
     }
     if (lane != 0) return;
     if (sink.overflow) flags |= kLsStatusRunOverflow;
@@ -248,7 +251,33 @@ __global__ __launch_bounds__(256) void fir_lockstep_gather_counts_kernel(const u
     counts[2 * i + 1] = static_cast<uint32_t>(last_counts[2 * gs + 1]);
 }
 
+__global__ __launch_bounds__(256) void fir_lockstep_commit_kernel(LsCommitArgs a) {
+    const uint32_t gs = blockIdx.x * 256u + threadIdx.x;
+    if (gs >= a.n_streams) return;
+    a.states[gs] = a.sp_states[gs];
+    a.cursor[gs] = a.sp_cursor[gs];
+    a.last_counts[2 * gs] = a.sp_last_counts[2 * gs];
+    a.last_counts[2 * gs + 1] = a.sp_last_counts[2 * gs + 1];
+    const uint32_t f = a.sp_status[gs];
+    if (f) a.status[gs] |= f;
+}
+
+__global__ __launch_bounds__(64) void fir_lockstep_idle_kernel(uint32_t ticks) {
+    const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+}
+
 }  // namespace
+
+hipError_t launch_fir_lockstep_idle(uint32_t ticks, hipStream_t stream) {
+    hipLaunchKernelGGL(fir_lockstep_idle_kernel, dim3(1), dim3(64), 0, stream, ticks);
+    return hipGetLastError();
+}
+
+hipError_t launch_fir_lockstep_commit(const LsCommitArgs& args, hipStream_t stream) {
+    hipLaunchKernelGGL(fir_lockstep_commit_kernel, dim3((args.n_streams + 255) / 256), dim3(256), 0, stream, args);
+    return hipGetLastError();
+}
 
 hipError_t launch_fir_lockstep_gather_counts(const uint64_t* last_counts, const LsRunStream* rs, uint32_t* counts, uint32_t n,
                                              hipStream_t stream) {

@@ -145,6 +145,19 @@ hipError_t launch_fir_split(const FirStreamDesc* d_descs, uint32_t n_streams, co
                             uint32_t max_blocks, uint32_t cus, bool fuse_tail, const NfArgs& nf, hipStream_t stream,
                             uint64_t items_key = 0);
 
+// Several rate pairs in as few launches as their geometries allow (one item-table launch for all of them, then one
+// launch of the kernel per window length among them): `jobs[j]` = the streams d_descs[0 .. n_streams) of geometry
+// `geo`, as for launch_fir_split.  Jobs whose geometry the multi-job build does not cover (other than two channels)
+// get a launch of their own.  The caller follows up with launch_fir_repair_multi over the same jobs' `nf`.
+struct SplitJob {
+    const FirStreamDesc* d_descs;
+    uint32_t n_streams;
+    const PeriodicGeometry* geo;
+    uint32_t max_blocks;
+    NfArgs nf;
+};
+hipError_t launch_fir_split_multi(const SplitJob* jobs, size_t n_jobs, hipStream_t stream);
+
 // Gives back the split kernel's item-table workspace of a stream that is about to be destroyed.
 void split_release_stream(int device, hipStream_t stream);
 

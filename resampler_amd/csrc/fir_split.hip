@@ -37,11 +37,13 @@
 //     on the previous frame, :562-564) is computed by producers in f32 from global memory.
 #include "fir_periodic.h"
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
 #include <type_traits>
+#include <vector>
 #include <mutex>
 
 #include "common.h"
@@ -285,9 +287,8 @@ struct Cursor {
 
 // One thread per item of the launch: the item's record (kItemWords words, see Cursor).  Item order: slices (tile group x
 // quad), inside a slice streams, blocks of 16 periods, the slice's channel pairs.
-__global__ __launch_bounds__(256) void split_items_kernel(const FirStreamDesc* __restrict__ descs, const SplitArgs g,
-                                                          uint32_t* __restrict__ items) {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+__device__ __forceinline__ void split_item_record(const FirStreamDesc* __restrict__ descs, const SplitArgs& g,
+                                                  uint32_t* __restrict__ items, const uint32_t i) {
     if (i >= g.total_items) return;
     const uint32_t slice = i / g.per_group, in_slice = i - slice * g.per_group;
     const uint32_t group = slice / g.quads, quad = slice - group * g.quads;
@@ -312,6 +313,39 @@ __global__ __launch_bounds__(256) void split_items_kernel(const FirStreamDesc* _
     w[5] = static_cast<uint32_t>(static_cast<uint64_t>(f0) >> 32);
     w[6] = static_cast<uint32_t>(f0 - hf);
     w[7] = 0;
+}
+__global__ __launch_bounds__(256) void split_items_kernel(const FirStreamDesc* __restrict__ descs, const SplitArgs g,
+                                                          uint32_t* __restrict__ items) {
+    split_item_record(descs, g, items, blockIdx.x * 256u + threadIdx.x);
+}
+
+// Several jobs (rate pairs: a geometry and the streams that have it) in ONE launch: the launch's workgroups are dealt to
+// the jobs in proportion to their work; a workgroup finds its job from its index and is then exactly the workgroup
+// `wg` of `n_wgs` of a launch of that job alone.  (A run of config 4 is six rate pairs: six launches of this kernel, of
+// the item kernel in front and of the repair kernel behind cost a run of 16 calls more than the work itself.)
+constexpr uint32_t kMaxSplitJobs = 8;
+struct SplitMulti {
+    SplitArgs g[kMaxSplitJobs];
+    const FirStreamDesc* descs[kMaxSplitJobs];
+    uint32_t wg_end[kMaxSplitJobs];      // workgroups of jobs 0 .. j (fir_split_multi_kernel)
+    uint32_t ib_end[kMaxSplitJobs];      // blocks of 256 items of jobs 0 .. j (split_items_multi_kernel)
+    uint32_t n_jobs;
+};
+__device__ __forceinline__ uint32_t split_job_of(const uint32_t (&end)[kMaxSplitJobs], uint32_t n_jobs, uint32_t block, uint32_t& begin) {
+    uint32_t j = 0;
+    begin = 0;
+#pragma unroll
+    for (uint32_t i = 0; i + 1 < kMaxSplitJobs; ++i) {
+        const bool past = i + 1 < n_jobs && block >= end[i];
+        j += past ? 1u : 0u;
+        begin = past ? end[i] : begin;
+    }
+    return j;
+}
+__global__ __launch_bounds__(256) void split_items_multi_kernel(const SplitMulti m) {
+    uint32_t begin;
+    const uint32_t j = split_job_of(m.ib_end, m.n_jobs, blockIdx.x, begin);
+    split_item_record(m.descs[j], m.g[j], const_cast<uint32_t*>(m.g[j].items), (blockIdx.x - begin) * 256u + threadIdx.x);
 }
 
 // f32 -> three bf16 planes by truncation: x == p1 + p2 + p3 exactly (24 significant bits = 8 + 8 + 8;
@@ -423,8 +457,8 @@ __device__ __forceinline__ uint32_t consumer_index(uint32_t w) { return w < 6 ? 
 // ROUNDS: lane tasks per stager lane and item -- 2 for periods of 161 .. 320 frames (96 -> 44.1 kHz, 96 -> 48 kHz): both
 // rounds' loads are in flight together, one item ahead, like the single round's.
 template <int NK, int PLANES, bool DIAG, int WIDE, int ROUNDS = 1>   // WIDE: 0 two channels, 1 channel pairs, 2 one channel, 3 pairs + a last channel alone
-__global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __restrict__ descs,
-                                                         const SplitArgs g) {
+__device__ __forceinline__ void fir_split_body(const FirStreamDesc* __restrict__ descs, const SplitArgs& g,
+                                               const uint32_t wg, const uint32_t n_wgs) {   // workgroup `wg` of the `n_wgs` that share g's items
     static_assert(ROUNDS == 1 || ((WIDE == 0 || WIDE == 1) && PLANES == 2), "two rounds: two channels or channel pairs, fp16 planes");
     constexpr uint32_t kRowBytes = row_bytes(PLANES);
     const uint32_t fs = WIDE ? g.cstride : 2u;   // floats per frame
@@ -460,6 +494,9 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
     uint32_t* peak = ctrl + 12;     // [slot]: (use + 1) << 8 | biased exponent of the peak so far (monotonic: never reset)
     uint32_t* used = ctrl + 16;     // [slot]: biased exponent the item's scale was derived from (stager 0)
     uint32_t* fin = ctrl + 20;      // [slot][2]: (stream << 4 | pair) + 1 and final peak exponent of the slot's last item (consumer 0)
+#if RSMP_EXP == 7
+    __builtin_amdgcn_s_setprio(3);
+#endif
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     for (uint32_t i = threadIdx.x; i < (g.lds_bytes + (DIAG && g.wtrace ? 16 * kWtraceSlots * 8 : 0)) / 4; i += blockDim.x)
@@ -469,13 +506,13 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
     const uint32_t R = g.rows;
     const uint32_t image_bytes = R * kRowBytes;
     const uint32_t n_active = g.n_tiles < kConsumers ? g.n_tiles : kConsumers;   // consumers that take part (with tile groups: all ten)
-    const uint32_t item_begin = static_cast<uint32_t>(static_cast<uint64_t>(blockIdx.x) * g.total_items / gridDim.x);
-    const uint32_t item_end = static_cast<uint32_t>(static_cast<uint64_t>(blockIdx.x + 1) * g.total_items / gridDim.x);
+    const uint32_t item_begin = static_cast<uint32_t>(static_cast<uint64_t>(wg) * g.total_items / n_wgs);
+    const uint32_t item_end = static_cast<uint32_t>(static_cast<uint64_t>(wg + 1) * g.total_items / n_wgs);
     // The frames that stay buffered after the launch move to hist_next (what fir_tail_copy_kernel does in
     // launches that mix kernels): nobody in this launch reads hist_next, the wave with most slack does it.
     if (g.fuse_tail && wave == 0) {
         typedef const uint32_t __attribute__((address_space(4)))* const_u32_ptr;
-        for (uint32_t sidx = blockIdx.x; sidx < g.n_streams; sidx += gridDim.x) {
+        for (uint32_t sidx = wg; sidx < g.n_streams; sidx += n_wgs) {
             FirStreamDesc d;
             const_u32_ptr src = (const_u32_ptr)(descs + sidx);
             uint32_t* dst = reinterpret_cast<uint32_t*>(&d);
@@ -1411,6 +1448,18 @@ __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __
     wt.flush();
 }
 
+template <int NK, int PLANES, bool DIAG, int WIDE, int ROUNDS = 1>
+__global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __restrict__ descs, const SplitArgs g) {
+    fir_split_body<NK, PLANES, DIAG, WIDE, ROUNDS>(descs, g, blockIdx.x, gridDim.x);
+}
+template <int NK, int PLANES, int WIDE, int ROUNDS>
+__global__ __launch_bounds__(1024) void fir_split_multi_kernel(const SplitMulti m) {
+    uint32_t begin;
+    const uint32_t j = __builtin_amdgcn_readfirstlane(split_job_of(m.wg_end, m.n_jobs, blockIdx.x, begin));
+    begin = __builtin_amdgcn_readfirstlane(begin);
+    fir_split_body<NK, PLANES, false, WIDE, ROUNDS>(m.descs[j], m.g[j], blockIdx.x - begin, m.wg_end[j] - begin);
+}
+
 inline uint32_t split_class_offset(uint32_t a, uint32_t b, uint32_t j) {
     return static_cast<uint32_t>((static_cast<uint64_t>(j) * a) / b);
 }
@@ -1579,25 +1628,72 @@ void split_release_stream(int device, hipStream_t stream) {
     items_ws().erase(it);
 }
 
-hipError_t launch_fir_split(const FirStreamDesc* d_descs, uint32_t n_streams, const PeriodicGeometry& geo,
-                            uint32_t max_blocks, uint32_t cus, bool fuse_tail, const NfArgs& nf, hipStream_t stream,
-                            uint64_t items_key) {
+namespace {
+uint32_t split_debug_knob() {
     static const uint32_t debug = [] {
         const char* e = rsmp::knob("RSMP_FIR_DEBUG");
         return e ? static_cast<uint32_t>(atoi(e)) : 0u;
     }();
+    return debug;
+}
+// The kernel's arguments for the streams of one geometry (everything but the item table's address).
+SplitArgs make_split_args(const PeriodicGeometry& geo, uint32_t n_streams, uint32_t max_blocks, bool fuse_tail, const NfArgs& nf) {
     const uint32_t pairs = geo.lp;
     const bool wide = pairs > 1 || geo.cg == 1;
     static const bool quad_major = [] { const char* e = rsmp::knob("RSMP_FIR_SPLIT_QUADS"); return !e || atoi(e) != 0; }();
     const uint32_t quads = quad_major && geo.cg == 2 && pairs >= 4 && pairs % 2 == 0 ? pairs / 2 : 1u;   // 8, 12, 16 channels
     const uint32_t qpairs = pairs / quads;
     const uint32_t groups = geo.groups ? geo.groups : 1u, per_group = max_blocks * n_streams * qpairs;
-    SplitArgs args{geo.a, geo.b, geo.taps, geo.n_tiles, geo.row_stride, geo.images, geo.lds_bytes, max_blocks, per_group * groups * quads,
-                   debug, n_streams, fuse_tail ? 1u : 0u, geo.cg == 1 ? 1u : (geo.cg == 3 ? 2 * pairs - 1 : 2 * pairs), pairs,
-                   groups, per_group, quads, qpairs, wide ? 1u : 0u,
-                   // (b = r den with r > 1: a super period of an exact ratio.  WIDE builds only: the two-channel tile-group
-                   // kernel got SLOWER without the fetches -- 2 ch 48 -> 96 kHz 0.59 -> 0.66 ms)
-                   wide && geo.b != geo.den ? 1u : 0u, nullptr, nullptr, nf};
+    return SplitArgs{geo.a, geo.b, geo.taps, geo.n_tiles, geo.row_stride, geo.images, geo.lds_bytes, max_blocks, per_group * groups * quads,
+                     split_debug_knob(), n_streams, fuse_tail ? 1u : 0u, geo.cg == 1 ? 1u : (geo.cg == 3 ? 2 * pairs - 1 : 2 * pairs), pairs,
+                     groups, per_group, quads, qpairs, wide ? 1u : 0u,
+                     // (b = r den with r > 1: a super period of an exact ratio.  WIDE builds only: the two-channel tile-group
+                     // kernel got SLOWER without the fetches -- 2 ch 48 -> 96 kHz 0.59 -> 0.66 ms)
+                     wide && geo.b != geo.den ? 1u : 0u, nullptr, nullptr, nf};
+}
+// The item-table workspace of (device, stream), at least `need` bytes.  `key` / `items`: see launch_fir_split; *have_table =
+// the workspace already holds the table with that key.
+hipError_t items_workspace(int device, hipStream_t stream, size_t need, uint64_t key, uint32_t items, uint32_t** d_items, bool* have_table) {
+    std::lock_guard<std::mutex> lock(items_ws_mu());
+    ItemsSlot& slot = items_ws()[{device, stream}];
+    if (slot.cap < need) {
+        if (slot.ptr) {   // (a launch on this stream may still read the old table)
+            if (hipError_t e = hipStreamSynchronize(stream); e != hipSuccess) return e;
+            (void)hipFree(slot.ptr);
+            slot = ItemsSlot{};
+        }
+        const size_t cap = need + need / 2 + 4096;
+        if (hipError_t e = hipMalloc(&slot.ptr, cap); e != hipSuccess) return e;
+        slot.cap = cap;
+    }
+    *d_items = slot.ptr;
+    *have_table = key != 0 && slot.key == key && slot.items == items;
+    slot.key = key;
+    slot.items = items;
+    return hipSuccess;
+}
+uint32_t device_cus(int device) {
+    static std::mutex mu;
+    static std::map<int, uint32_t> count;
+    std::lock_guard<std::mutex> lock(mu);
+    uint32_t& c = count[device];
+    if (c == 0) {
+        int v = 0;
+        (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device);
+        c = static_cast<uint32_t>(v > 0 ? v : 256);
+    }
+    return c;
+}
+}  // namespace
+
+hipError_t launch_fir_split(const FirStreamDesc* d_descs, uint32_t n_streams, const PeriodicGeometry& geo,
+                            uint32_t max_blocks, uint32_t cus, bool fuse_tail, const NfArgs& nf, hipStream_t stream,
+                            uint64_t items_key) {
+    const uint32_t debug = split_debug_knob();
+    const uint32_t pairs = geo.lp;
+    const bool wide = pairs > 1 || geo.cg == 1;
+    SplitArgs args = make_split_args(geo, n_streams, max_blocks, fuse_tail, nf);
+    const uint32_t groups = args.groups;
     static const char* wtrace_path = rsmp::knob("RSMP_FIR_WTRACE");
     const bool diag = debug != 0 || wtrace_path != nullptr;
 #define RSMP_SPLIT_FNS(P, D, W)                                                                              \
@@ -1619,13 +1715,14 @@ hipError_t launch_fir_split(const FirStreamDesc* d_descs, uint32_t n_streams, co
                                                {nullptr, nullptr, nullptr, nullptr,
                                                 reinterpret_cast<const void*>(fir_split_kernel<5, 2, false, 1, 2>),
                                                 reinterpret_cast<const void*>(fir_split_kernel<6, 2, false, 1, 2>)},
-                                               // (diagnostic builds of the 192-tap window: config 5's geometry)
-                                               {nullptr, nullptr, nullptr, nullptr, nullptr,
+                                               // (diagnostic builds: config 5's geometry, the 192-tap window; config 4's two-channel streams)
+                                               {nullptr, nullptr, nullptr, nullptr,
+                                                reinterpret_cast<const void*>(fir_split_kernel<5, 2, true, 0, 2>),
                                                 reinterpret_cast<const void*>(fir_split_kernel<6, 2, true, 0, 2>)},
                                                {nullptr, nullptr, nullptr, nullptr, nullptr,
                                                 reinterpret_cast<const void*>(fir_split_kernel<6, 2, true, 1, 2>)}};
     const bool two_rounds = geo.rounds == 2;
-    const bool diag_long = two_rounds && diag && geo.row_len / 32 == 6;
+    const bool diag_long = two_rounds && diag && (geo.row_len / 32 == 6 || (geo.row_len / 32 == 5 && !wide));
     const void* const* fns = two_rounds  ? fns_long[(wide ? 1 : 0) + (diag_long ? 2 : 0)]
                              : one_channel ? fns_mono[0]
                              : odd_count ? fns_odd[0]
@@ -1665,30 +1762,10 @@ hipError_t launch_fir_split(const FirStreamDesc* d_descs, uint32_t n_streams, co
         // The table is a pure function of the streams' counters and the geometry: a launch whose key (the caller's hash of
         // exactly those, 0 = none) equals the key of the table the workspace holds finds it there -- a service resampling
         // batch after batch of equally long files, the bench's step -- and skips the table launch (5 us in front of the kernel).
-        std::mutex& ws_mu = items_ws_mu();
-        auto& ws = items_ws();
-        typedef ItemsSlot Slot;
         const size_t need = static_cast<size_t>(args.total_items) * kItemWords * sizeof(uint32_t);
         uint32_t* d_items = nullptr;
         bool have_table = false;
-        {
-            std::lock_guard<std::mutex> lock(ws_mu);
-            Slot& slot = ws[{device, stream}];
-            if (slot.cap < need) {
-                if (slot.ptr) {   // (a launch on this stream may still read the old table)
-                    if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
-                    (void)hipFree(slot.ptr);
-                    slot = Slot{};
-                }
-                const size_t cap = need + need / 2 + 4096;
-                if ((e = hipMalloc(&slot.ptr, cap)) != hipSuccess) return e;
-                slot.cap = cap;
-            }
-            d_items = slot.ptr;
-            have_table = items_key != 0 && slot.key == items_key && slot.items == args.total_items;
-            slot.key = items_key;
-            slot.items = args.total_items;
-        }
+        if ((e = items_workspace(device, stream, need, items_key, args.total_items, &d_items, &have_table)) != hipSuccess) return e;
         args.items = d_items;
         if (!have_table) {
             split_items_kernel<<<dim3((args.total_items + 255) / 256), dim3(256), 0, stream>>>(d_descs, args, d_items);
@@ -1710,6 +1787,145 @@ hipError_t launch_fir_split(const FirStreamDesc* d_descs, uint32_t n_streams, co
                 fprintf(f, "\n");
             }
             fclose(f);
+        }
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_fir_split_multi(const SplitJob* jobs, size_t n_jobs, hipStream_t stream) {
+    int device = 0;
+    hipError_t e = hipGetDevice(&device);
+    if (e != hipSuccess) return e;
+    const uint32_t cus = device_cus(device);
+    static const bool diag = split_debug_knob() != 0 || rsmp::knob("RSMP_FIR_WTRACE") != nullptr;
+    static const bool multi_on = [] { const char* v = rsmp::knob("RSMP_FIR_SPLIT_MULTI"); return !v || atoi(v) != 0; }();
+    // the multi-job builds: two channels, two fp16 planes; windows of 1 .. 5 steps in one round, 5 or 6 in two
+    static const void* const fns_multi[2][6] = {
+        {reinterpret_cast<const void*>(fir_split_multi_kernel<1, 2, 0, 1>), reinterpret_cast<const void*>(fir_split_multi_kernel<2, 2, 0, 1>),
+         reinterpret_cast<const void*>(fir_split_multi_kernel<3, 2, 0, 1>), reinterpret_cast<const void*>(fir_split_multi_kernel<4, 2, 0, 1>),
+         reinterpret_cast<const void*>(fir_split_multi_kernel<5, 2, 0, 1>), nullptr},
+        {nullptr, nullptr, nullptr, nullptr,
+         reinterpret_cast<const void*>(fir_split_multi_kernel<5, 2, 0, 2>), reinterpret_cast<const void*>(fir_split_multi_kernel<6, 2, 0, 2>)}};
+    auto multi_fn = [&](const PeriodicGeometry& g) -> const void* {
+        if (diag || !multi_on || g.mfma != 3 || g.cg != 2 || g.lp != 1 || g.planes != 2) return nullptr;
+        const uint32_t nk = g.row_len / 32;
+        if (nk < 1 || nk > 6 || (g.rounds != 1 && g.rounds != 2)) return nullptr;
+        return fns_multi[g.rounds - 1][nk - 1];
+    };
+    // jobs the multi-job builds do not cover: a launch each, as before
+    std::vector<size_t> covered;
+    for (size_t j = 0; j < n_jobs; ++j) {
+        const SplitJob& job = jobs[j];
+        if (job.n_streams == 0 || job.max_blocks == 0) continue;
+        if (multi_fn(*job.geo)) covered.push_back(j);
+        else if ((e = launch_fir_split(job.d_descs, job.n_streams, *job.geo, job.max_blocks, cus, false, job.nf, stream, 0)) != hipSuccess) return e;
+    }
+    for (size_t c0 = 0; c0 < covered.size(); c0 += kMaxSplitJobs) {
+        const uint32_t n = static_cast<uint32_t>(std::min<size_t>(kMaxSplitJobs, covered.size() - c0));
+        SplitArgs args[kMaxSplitJobs];
+        const void* fn[kMaxSplitJobs];
+        size_t total_items = 0;
+        for (uint32_t i = 0; i < n; ++i) {
+            const SplitJob& job = jobs[covered[c0 + i]];
+            args[i] = make_split_args(*job.geo, job.n_streams, job.max_blocks, false, job.nf);
+            fn[i] = multi_fn(*job.geo);
+            total_items += args[i].total_items;
+        }
+        // one item table after the other in the stream's workspace, built by one launch
+        uint32_t* d_items = nullptr;
+        bool have_table = false;
+        if ((e = items_workspace(device, stream, total_items * kItemWords * sizeof(uint32_t), 0, 0, &d_items, &have_table)) != hipSuccess) return e;
+        {
+            SplitMulti m{};
+            size_t off = 0;
+            uint32_t blocks = 0;
+            for (uint32_t i = 0; i < n; ++i) {
+                args[i].items = d_items + off * kItemWords;
+                off += args[i].total_items;
+                m.g[i] = args[i];
+                m.descs[i] = jobs[covered[c0 + i]].d_descs;
+                blocks += (args[i].total_items + 255) / 256;
+                m.ib_end[i] = blocks;
+            }
+            m.n_jobs = n;
+            hipLaunchKernelGGL(split_items_multi_kernel, dim3(blocks), dim3(256), 0, stream, m);
+            if ((e = hipGetLastError()) != hipSuccess) return e;
+        }
+        // one launch per kernel build among the jobs; its workgroups dealt in proportion to the jobs' staging work
+        // (items x frames of a period: the stagers bound this kernel)
+        bool done[kMaxSplitJobs] = {};
+        for (uint32_t i0 = 0; i0 < n; ++i0) {
+            if (done[i0]) continue;
+            SplitMulti m{};
+            uint32_t idx[kMaxSplitJobs], nb = 0, lds = 0;
+            double weight[kMaxSplitJobs], weight_sum = 0.0;
+            uint64_t items_sum = 0;
+            for (uint32_t i = i0; i < n; ++i) {
+                if (done[i] || fn[i] != fn[i0]) continue;
+                done[i] = true;
+                idx[nb] = i;
+                weight[nb] = static_cast<double>(args[i].total_items) * args[i].a;
+                weight_sum += weight[nb];
+                items_sum += args[i].total_items;
+                lds = std::max(lds, args[i].lds_bytes);
+                ++nb;
+            }
+            const uint32_t wgs = static_cast<uint32_t>(std::min<uint64_t>(cus, items_sum));
+            if (wgs < nb) {   // (fewer items than jobs cannot be: every job has at least one)
+                return hipErrorInvalidValue;
+            }
+            // at least one workgroup per job, no more than it has items; the rest by weight (largest remainder)
+            uint32_t share[kMaxSplitJobs], given = 0;
+            double frac[kMaxSplitJobs];
+            for (uint32_t b = 0; b < nb; ++b) {
+                const double ideal = weight[b] / weight_sum * wgs;
+                uint32_t w = static_cast<uint32_t>(ideal);
+                w = std::max<uint32_t>(1u, std::min<uint32_t>(w, args[idx[b]].total_items));
+                share[b] = w;
+                frac[b] = ideal - w;
+                given += w;
+            }
+            while (given > wgs) {   // (the minimum of one pushed the sum over: take from the largest)
+                uint32_t big = 0;
+                for (uint32_t b = 1; b < nb; ++b) if (share[b] > share[big]) big = b;
+                --share[big];
+                frac[big] += 1.0;
+                --given;
+            }
+            while (given < wgs) {
+                int best = -1;
+                for (uint32_t b = 0; b < nb; ++b)
+                    if (share[b] < args[idx[b]].total_items && (best < 0 || frac[b] > frac[best])) best = static_cast<int>(b);
+                if (best < 0) break;
+                ++share[best];
+                frac[best] -= 1.0;
+                ++given;
+            }
+            uint32_t end = 0;
+            for (uint32_t b = 0; b < nb; ++b) {
+                m.g[b] = args[idx[b]];
+                m.descs[b] = jobs[covered[c0 + idx[b]]].d_descs;
+                end += share[b];
+                m.wg_end[b] = end;
+            }
+            m.n_jobs = nb;
+            static std::mutex mu;
+            static std::map<std::pair<int, const void*>, bool> granted;
+            {
+                std::lock_guard<std::mutex> lock(mu);
+                bool& have = granted[{device, fn[i0]}];
+                if (!have) {
+                    if ((e = hipFuncSetAttribute(fn[i0], hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit)) != hipSuccess) return e;
+                    have = true;
+                }
+            }
+            static const bool verbose = rsmp::knob("RSMP_FIR_VERBOSE") != nullptr;
+            if (verbose)
+                for (uint32_t b = 0; b < nb; ++b)
+                    fprintf(stderr, "[rsmp] split multi launch: job %u of %u: a=%u b=%u rounds=%u items=%u workgroups=%u\n", b, nb, m.g[b].a, m.g[b].b,
+                            jobs[covered[c0 + idx[b]]].geo->rounds, m.g[b].total_items, share[b]);
+            void* kargs[1] = {&m};
+            if ((e = hipLaunchKernel(fn[i0], dim3(end), dim3(kWaves * 64), kargs, lds, stream)) != hipSuccess) return e;
         }
     }
     return hipGetLastError();

@@ -240,3 +240,49 @@ def test_without_append_a_run_starts_at_the_front_of_the_output():
             want = np.concatenate(ys)
             assert rms(d_out[i][:want.size].cpu().numpy(), want) <= RMS_TOL
     ls.close()
+
+
+def test_runs_in_a_row_are_planned_ahead_and_still_exact():
+    """From the third run of one shape on, the next run is planned on a stream of its own while the current one computes
+    (guessed to repeat the shape, its input offset moving on as before) and taken over when it is really asked for:
+    same counts, samples and states; a guess that does not come true (a step in between, another k, a reset) is dropped."""
+    specs = sharding.mixed_rate_batch(30, 2, 512)
+    sched = [("run", 5)] * 6 + [("step",)] + [("run", 5)] * 4 + [("run", 3)] * 4 + [("reset",)] + [("run", 6)] * 5 + [("step",), ("step",)]
+    worst, ls, hs, refs = drive(specs, sched, 512, seed=21)
+    assert worst <= RMS_TOL, worst
+    assert not ls.status().any()
+    ls.close()
+
+
+def test_the_same_span_run_again_and_again_without_append():
+    """The bench's pattern: every run reads the SAME resident span (offset 0) on carried state and starts at the front of
+    the output -- the run planned ahead guesses an unchanged offset from the second repetition on."""
+    import torch
+    dev = torch.device("cuda:0")
+    specs = sharding.mixed_rate_batch(18, 2, 512)
+    k = 8
+    hs = [ra.ResamplerFir.new_from_hz(2, s.in_hz, s.out_hz, ra.Latency.Sample64, ra.Attenuation.Db90) for s in specs]
+    kind = o.CONVOLVE_AVX_FMA if o.have_avx_fma() else o.CONVOLVE_SCALAR
+    refs = [o.OracleFir(2, s.in_hz, s.out_hz, 128, 90, kind) for s in specs]
+    xs = [synth.hash_noise(k * 512 * 2, seed=40 + i) for i in range(len(specs))]
+    caps = [h.buffer_size_output() for h in hs]
+    d_in = [torch.from_numpy(x).to(dev) for x in xs]
+    d_out = [torch.zeros(k * c, device=dev) for c in caps]
+    ls = ra.FirLockstep(hs, 512)
+    ls.bind_caps(d_in, d_out, caps)
+    for rep in range(7):
+        ls.run(k, 512, 0, append=False)
+        cons, prod = ls.run_counts()
+        for i, r in enumerate(refs):
+            out = np.zeros(caps[i], np.float32)
+            ys = []
+            for s in range(k):
+                rc, c, p = r.resample(xs[i][s * 1024:(s + 1) * 1024], out)
+                assert rc == 0 and (c, p) == (int(cons[s][i]), int(prod[s][i])), (rep, i, s)
+                ys.append(out[:p].copy())
+            want = np.concatenate(ys)
+            assert rms(d_out[i][:want.size].cpu().numpy(), want) <= RMS_TOL, (rep, i)
+    ls.sync()
+    for h, r in zip(hs, refs):
+        assert h.state() == r.state()
+    ls.close()

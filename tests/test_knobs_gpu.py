@@ -62,6 +62,18 @@ def test_lockstep_exact_f32_switch_in_a_child_process():
     assert p.returncode == 0, p.stdout[-3000:]
 
 
+@pytest.mark.parametrize("knob", ["RSMP_FIR_SPLIT_MULTI", "RSMP_LS_AHEAD"])
+def test_lockstep_run_switches_in_a_child_process(knob):
+    """The run of several calls with one launch per rate pair (no multi-job launch) / planned on the caller's stream only."""
+    env = dict(os.environ, RSMP_DEBUG="1", PYTHONPATH=ROOT)
+    env[knob] = "0"
+    p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_fir_lockstep_run_gpu.py"), "-q", "-m", "gpu",
+                        "-k", "planned_ahead or k_calls_equals or interleave or append or different_states", "-p", "no:cacheprovider"],
+                       env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-3000:]
+    assert " passed" in p.stdout, p.stdout[-1000:]
+
+
 def test_without_rsmp_debug_no_switch_is_read():
     """RSMP_FIR_SPLIT_PLANES=3 alone (no RSMP_DEBUG) must leave the default kernel in place: variant 5, not 4."""
     env = dict(os.environ, RSMP_FIR_SPLIT_PLANES="3", PYTHONPATH=ROOT)

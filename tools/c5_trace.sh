@@ -2,9 +2,9 @@
 # tools/c5_trace.sh -- per-wave phase clocks of the two-round split kernel on config 5's stream (8 ch) and on its
 # two-channel sibling (diagnostic instantiation, RSMP_FIR_WTRACE), one short bulk launch each.
 O=gpurun_out/c5trace; mkdir -p $O
-RSMP_FIR_WTRACE=$PWD/$O/w8.txt timeout -k 5 100 python bench.py --config c5 --c5-frames 5760000 --steps 2 --warmup 1 --spinup-seconds 0 > /dev/null 2>$O/err8.txt
+RSMP_DEBUG=1 RSMP_FIR_WTRACE=$PWD/$O/w8.txt timeout -k 5 100 python bench.py --config c5 --c5-frames 5760000 --steps 2 --warmup 1 --spinup-seconds 0 > /dev/null 2>$O/err8.txt
 python tools/wphase_report.py $O/w8.txt 17.6 > $O/wphase_c5_8ch.txt; cat $O/wphase_c5_8ch.txt
-RSMP_FIR_WTRACE=$PWD/$O/w2.txt timeout -k 5 100 python - <<'PY' 2>$O/err2.txt
+RSMP_DEBUG=1 RSMP_FIR_WTRACE=$PWD/$O/w2.txt timeout -k 5 100 python - <<'PY' 2>$O/err2.txt
 import torch, resampler_amd as ra
 from resampler_amd import synth
 dev = torch.device("cuda:0")

@@ -4,7 +4,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:?run through gpurun}
 for d in 0 16; do
-  export RSMP_FIR_DEBUG=$d
+  export RSMP_DEBUG=1 RSMP_FIR_DEBUG=$d
   rm -rf "$R/gpurun_out/clk_kt_$d" "$R/gpurun_out/clk_pmc_$d"
   rocprofv3 --kernel-trace --output-format csv -d "$R/gpurun_out/clk_kt_$d" -- python3 "$R/bench.py" --steps 5 --warmup 2 --no-cpu --no-secondary > /dev/null 2>&1
   rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d "$R/gpurun_out/clk_pmc_$d" -- python3 "$R/bench.py" --steps 5 --warmup 2 --no-cpu --no-secondary > /dev/null 2>&1

@@ -6,9 +6,11 @@ import os, sys, json
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("RSMP_DEBUG", "1")   # (the library reads its diagnostic switches only then)
 path = os.environ.get("RSMP_LS_TRACE") or os.path.join(ROOT, "gpurun_out", "ls_trace.txt")
 if os.path.exists(path):
     os.remove(path)
+os.environ["RSMP_LS_TRACE"] = path
 import torch
 import resampler_amd as ra
 from resampler_amd import sharding, synth

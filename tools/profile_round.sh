@@ -29,8 +29,8 @@ python3 "$R/tools/configs_bench.py" > "$SUM/bench_c5_calls.json" 2> "$OUT/bench_
 python3 "$R/tools/channels_bench.py" > "$SUM/channels_bench.txt" 2> "$OUT/channels_bench.err"
 python3 "$R/tools/fft_channels_bench.py" > "$SUM/fft_channels_bench.txt" 2> "$OUT/fft_channels_bench.err"
 python3 "$R/tools/fft_pairs_bench.py" --all > "$SUM/fft_pairs_bench.txt" 2> "$OUT/fft_pairs_bench.err"
-RSMP_LS_TRACE="$SUM/ls_trace_raw.txt" python3 "$R/tools/ls_trace.py" > "$SUM/ls_trace.txt" 2> "$OUT/ls_trace.err"; rm -f "$SUM/ls_trace_raw.txt"
-RSMP_FIR_WTRACE="$OUT/wtrace.txt" python3 "$R/bench.py" --no-cpu --no-secondary --steps 3 --warmup 1 --spinup-seconds 0 > /dev/null 2>&1
+RSMP_DEBUG=1 RSMP_LS_TRACE="$SUM/ls_trace_raw.txt" python3 "$R/tools/ls_trace.py" > "$SUM/ls_trace.txt" 2> "$OUT/ls_trace.err"; rm -f "$SUM/ls_trace_raw.txt"
+RSMP_DEBUG=1 RSMP_FIR_WTRACE="$OUT/wtrace.txt" python3 "$R/bench.py" --no-cpu --no-secondary --steps 3 --warmup 1 --spinup-seconds 0 > /dev/null 2>&1
 python3 "$R/tools/wphase_report.py" "$OUT/wtrace.txt" 111.5 > "$SUM/wphase_split.txt" 2>/dev/null
 (cd "$R" && tools/c5_trace.sh > /dev/null 2>&1; cp gpurun_out/c5trace/wphase_*.txt "$SUM/" 2>/dev/null)
 
