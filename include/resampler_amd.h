@@ -203,6 +203,11 @@ int rsmp_fir_lockstep_run_counts(rsmp_fir_lockstep* ls, size_t* consumed, size_t
 /* Diagnostic: calls of the last run (all streams) that the device planner's fast path declined and the plain state
  * machine did (fir_mirror_fast.h); 0 for a run executed as a loop of steps. */
 int rsmp_fir_lockstep_run_slow_calls(rsmp_fir_lockstep* ls, size_t* slow_calls);
+/* Diagnostic: how often a class of the batch's streams was given new class tables because the streams' f64 position drift
+ * (src/resampler_fir.rs:589: ~1e-14 of a frame per output, for as long as a stream runs) had moved away from the drift
+ * its tables were mixed for.  The batch watches the drifts itself (an asynchronous read-back every 2^19 frames per
+ * stream); nothing for the caller to do. */
+int rsmp_fir_lockstep_table_rebinds(const rsmp_fir_lockstep* ls, size_t* rebinds);
 /* Sticky per-stream flags: 1 = more position runs in one step than the kernel keeps (outputs of that step
  * undefined; never observed), 2 = a step saw non-finite samples and was evaluated in the reference's
  * two-row form, 4 = the f64 position drifted out of the class tables' tolerance (reference form from then on),

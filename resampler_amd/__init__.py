@@ -139,6 +139,7 @@ _SIGNATURES = [
     ("rsmp_fir_lockstep_run", C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p]),
     ("rsmp_fir_lockstep_run_counts", C.c_int, [C.c_void_p, _szp, _szp, C.c_size_t]),
     ("rsmp_fir_lockstep_run_slow_calls", C.c_int, [C.c_void_p, _szp]),
+    ("rsmp_fir_lockstep_table_rebinds", C.c_int, [C.c_void_p, _szp]),
     ("rsmp_fir_lockstep_status", C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
     ("rsmp_fir_lockstep_split_workgroups", C.c_size_t, [C.c_void_p]),
     ("rsmp_fir_lockstep_sync", C.c_int, [C.c_void_p]),
@@ -536,6 +537,12 @@ class FirLockstep:
         _check(lib().rsmp_fir_lockstep_run_counts(self._h, cons, prod, k))
         return (np.ctypeslib.as_array(cons).astype(np.int64).reshape(k, n),
                 np.ctypeslib.as_array(prod).astype(np.int64).reshape(k, n))
+
+    def table_rebinds(self) -> int:
+        """Times a class of the batch's streams got new class tables because the f64 position drift had moved on (diagnostic)."""
+        v = C.c_size_t()
+        _check(lib().rsmp_fir_lockstep_table_rebinds(self._h, C.byref(v)))
+        return v.value
 
     def run_slow_calls(self) -> int:
         """Calls of the last run that the device planner's fast path declined (diagnostic)."""

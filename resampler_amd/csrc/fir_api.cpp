@@ -12,6 +12,8 @@
 // kernel writes the next hist.  There is no CPU fallback anywhere in this file.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
+#include <cstdio>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -155,6 +157,7 @@ struct Plan {
     FirMirror planned;                      // mirror state after the launch
     std::vector<rsmp_fir_segment> segs;     // generic kernel: exact position runs
     std::vector<uint32_t> wraps;            // periodic kernel: row-1023 fix-ups
+    std::vector<uint32_t> wrap_bits;        // ... as the bitmap the kernels with inline wraps read (built with the plan, by its worker)
     std::vector<size_t> calls;              // (consumed, produced) per reference call, in values
     size_t accepted_frames = 0;
     size_t produced_frames = 0;
@@ -290,6 +293,9 @@ int plan_job_uncached(Job& j, bool with_segments) {
             !rsmp::periodic_worthwhile(pl.planned, pl.produced_frames, r->kernel_mode))
             return plan_job_uncached(j, true);  // replay once more, keeping the position runs
         pl.periodic = true;
+        // (one 64-bit division per wrapped output: on the planning worker, not on the thread that builds the launch)
+        pl.wrap_bits.resize(rsmp::periodic_wrap_words(r->mirror.abs_out(), static_cast<uint32_t>(pl.produced_frames), r->mirror.den()));
+        rsmp::periodic_fill_wrap_bits(pl.wraps, r->mirror.abs_out(), r->mirror.den(), pl.wrap_bits.data(), pl.wrap_bits.size());
     }
     j.plan = plan;
     return RSMP_OK;
@@ -541,8 +547,11 @@ int launch_jobs(rsmp_fir* leader, std::vector<Job>& jobs, hipStream_t stream) {
                     return rsmp::fail(RSMP_ERR_INVALID_ARGUMENT, "split kernel: a stream of an exact ratio has wrapped outputs");
                 if (!pp.written) {
                     const size_t words = rsmp::periodic_wrap_words(r->mirror.abs_out(), ds.n_out, geo.den);
-                    rsmp::periodic_fill_wrap_bits(pl.wraps, r->mirror.abs_out(), geo.den,
-                                                  reinterpret_cast<uint32_t*>(h + pp.wrap_off), words);
+                    if (pl.wrap_bits.size() == words && geo.den == r->mirror.den())
+                        std::memcpy(h + pp.wrap_off, pl.wrap_bits.data(), words * sizeof(uint32_t));
+                    else
+                        rsmp::periodic_fill_wrap_bits(pl.wraps, r->mirror.abs_out(), geo.den,
+                                                      reinterpret_cast<uint32_t*>(h + pp.wrap_off), words);
                 }
             } else {
                 ds.wraps = reinterpret_cast<const uint32_t*>(d + pp.wrap_off);
@@ -956,6 +965,8 @@ extern "C" int rsmp_fir_batch_resample_bulk_device(rsmp_fir* const* rs, size_t n
     }
     DeviceGuard guard(rs[0]->device);
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : rs[0]->stream;
+    static const bool verbose_t = rsmp::knob("RSMP_FIR_VERBOSE") != nullptr;
+    const auto t_begin = std::chrono::steady_clock::now();
     std::vector<Job> jobs;
     jobs.reserve(n);
     // Streams in the same state that are fed the same amount share one replay of the reference
@@ -1005,8 +1016,15 @@ extern "C" int rsmp_fir_batch_resample_bulk_device(rsmp_fir* const* rs, size_t n
             return rsmp::fail(RSMP_ERR_CAPACITY, "bulk output needs %zu values, room for %zu",
                               j.plan->produced_frames * rs[i]->channels, out_caps[i]);
     }
+    const auto t_planned = std::chrono::steady_clock::now();
     const int rc = launch_jobs(rs[0], jobs, s);
     if (rc != RSMP_OK) return rc;
+    if (verbose_t) {
+        const auto t_end = std::chrono::steady_clock::now();
+        fprintf(stderr, "[rsmp] bulk batch of %zu streams (%zu distinct plans): planning %.3f ms, building and enqueueing the launch %.3f ms\n", n,
+                memo.size(), std::chrono::duration<double, std::milli>(t_planned - t_begin).count(),
+                std::chrono::duration<double, std::milli>(t_end - t_planned).count());
+    }
     for (size_t i = 0; i < n; ++i) {
         if (consumed) consumed[i] = jobs[i].consumed();
         if (produced) produced[i] = jobs[i].produced();

@@ -142,6 +142,12 @@ struct LsRunStream {           // per stream (internal order), constant for the 
                                // geometry's b (= den unless a super period of an exact ratio, whose outputs never wrap)
     uint32_t den, channels;
     uint32_t caller;           // the stream's index in the caller's order
+    // the class tables of the bulk kernels and the drift they were built for: replaced as the stream's f64 drift moves on
+    // (fir_lockstep_api.cpp, DriftClass); the planner copies them into every run's descriptor
+    const float* class_coef;
+    const float* class_wrap_coef;
+    const TileMeta* class_meta;
+    double drift;
 };
 struct LsRunArgs {
     const LockstepStream* streams;
@@ -163,6 +169,9 @@ struct LsRunArgs {
     uint32_t n_streams, k, in_frames, wrap_words, append, hist_parity;
 };
 hipError_t launch_fir_lockstep_plan(const LsRunArgs& args, hipStream_t stream);
+// out[c] = states[reps[c]].drift: the drifts the batch's classes are watched by (one thread per class).
+hipError_t launch_fir_lockstep_gather_drift(const FirMirrorState* states, const uint32_t* reps, double* out, uint32_t n,
+                                            hipStream_t stream);
 // One wave that sleeps until `ticks` of the 100 MHz clock have passed (0: returns at once): what the batch tries out with
 // whether two streams run side by side (pick_plan_stream).
 hipError_t launch_fir_lockstep_idle(uint32_t ticks, hipStream_t stream);

@@ -72,6 +72,30 @@ struct rsmp_fir_lockstep {
     bool run_planned = false;   // the most recent run went through the device planner
     size_t run_counts_k = 0;    // calls of the most recent run whose counts are in slot[last_slot].counts
     std::vector<uint32_t> h_run_counts;
+    // The class tables follow the streams' f64 drift.  The reference's position (src/resampler_fir.rs:589) moves away from
+    // the exact rational one by ~1e-14 of a frame per output for as long as a stream runs (every add rounds on the grid of
+    // its binade): 1e-6 of a frame after half an hour of audio -- 2e-6 of a full-scale sample with coefficient rows mixed
+    // for another drift.  Streams of one key whose drifts lie together form a class; the class's tables are built for the
+    // drift of its first stream, which is read back from the device now and then (asynchronously: a tiny kernel, a copy
+    // into pinned memory, an event looked at when the next step or run is enqueued); when it has moved by more than
+    // kLsDriftTolerance, the tables are replaced (class_table_for: cached per device, built on the host otherwise).
+    struct DriftClass {
+        uint32_t rep = 0;                 // internal index of the stream that stands for the class
+        size_t first = 0, count = 0;      // its streams, internal order
+        double table_drift = 0.0;         // what the bound tables were built for
+        const rsmp_fir* r0 = nullptr;
+        bool has_step = false, has_run = false;
+        rsmp::PeriodicGeometry step_geo, run_geo;
+        rsmp::ClassTable step_table, run_table;
+    };
+    std::vector<DriftClass> classes;
+    std::vector<rsmp::LsRunStream> h_run_rs;
+    DeviceBuffer d_drift_reps;
+    rsmp::PinnedBuffer h_drift, h_stage;            // the drifts read back; staging of the group / stream tables when they change
+    hipEvent_t drift_ev = nullptr, stage_ev = nullptr;
+    bool drift_inflight = false, stage_inflight = false, groups_dirty = false, rs_dirty = false;
+    uint64_t frames_since_drift = 0;
+    size_t table_rebinds = 0;                 // times a class got new tables (diagnostic)
     // optional timing of the step launches (rsmp_fir_lockstep_set_profiling): ring of event pairs
     static constexpr int kProfRing = 64;
     bool profiling = false;
@@ -82,6 +106,119 @@ struct rsmp_fir_lockstep {
 namespace {
 
 int drop_plan_ahead(rsmp_fir_lockstep* ls, hipStream_t s);   // (rsmp_fir_lockstep_run, below)
+
+constexpr double kLsDriftQuantum = 1e-8;      // tables are built for drifts on this grid (frames)
+constexpr double kLsDriftClass = 2e-8;        // streams of one key whose drifts round to the same multiple share a class
+// A class's tables are replaced when its drift is further from theirs than this: 2e-7 of a full-scale sample at worst,
+// a fifth of the 1e-6 the path is allowed.  (Tighter costs: a replacement is a table built on the host per class, ~0.5 ms;
+// config 4 on one GPU runs 0.13 M frames of every stream per millisecond, and at 4e-8 its six classes were rebuilt every
+// 35 ms -- 10 % of the bench's step.  A real-time stream crosses 1.2e-7 every five minutes.)
+constexpr double kLsDriftTolerance = 1.2e-7;
+constexpr uint64_t kLsDriftCheckFrames = 1u << 19;   // input frames per stream between two looks at the drifts (~5e-9 of drift)
+
+double quantized_drift(double d) { return std::round(d / kLsDriftQuantum) * kLsDriftQuantum; }
+
+// New tables for class `c`, built for drift `d`: the host copies of the group and stream tables are changed and marked;
+// flush_tables moves them to the device in front of the next launch.
+int rebind_class(rsmp_fir_lockstep* ls, size_t c, double d) {
+    rsmp_fir_lockstep::DriftClass& cl = ls->classes[c];
+    const double t = quantized_drift(d);
+    if (cl.has_step) {
+        rsmp::ClassTable ct;
+        if (int rc = rsmp::class_table_for(ls->device, *cl.r0->table, cl.step_geo, t, &ct)) return rc;
+        cl.step_table = ct;
+        for (LockstepGroup& g : ls->groups)
+            if (g.periodic && g.pad0 == c) {
+                g.class_coef = ct.d_coef;
+                g.class_meta = ct.d_meta;
+            }
+        ls->groups_dirty = true;
+    }
+    if (cl.has_run && ls->run_state == 1) {
+        rsmp::ClassTable ct;
+        if (int rc = rsmp::class_table_for(ls->device, *cl.r0->table, cl.run_geo, t, &ct)) return rc;
+        cl.run_table = ct;
+        for (size_t i = cl.first; i < cl.first + cl.count; ++i) {
+            ls->h_run_rs[i].class_coef = ct.d_coef;
+            ls->h_run_rs[i].class_wrap_coef = ct.d_wrap_coef;
+            ls->h_run_rs[i].class_meta = ct.d_meta;
+            ls->h_run_rs[i].drift = t;
+        }
+        ls->rs_dirty = true;
+    }
+    cl.table_drift = t;
+    ++ls->table_rebinds;
+    return RSMP_OK;
+}
+
+// The drifts that have come back from the device since the last look: classes that have moved get new tables.
+int poll_drift(rsmp_fir_lockstep* ls) {
+    if (!ls->drift_inflight || hipEventQuery(ls->drift_ev) != hipSuccess) {
+        (void)hipGetLastError();   // (hipErrorNotReady is not an error here)
+        return RSMP_OK;
+    }
+    ls->drift_inflight = false;
+    const double* d = ls->h_drift.as<double>();
+    for (size_t c = 0; c < ls->classes.size(); ++c)
+        if (std::fabs(d[c] - ls->classes[c].table_drift) > kLsDriftTolerance)
+            if (int rc = rebind_class(ls, c, d[c])) return rc;
+    return RSMP_OK;
+}
+
+// Changed group / stream tables go to the device, in stream order in front of what is enqueued next.  (Called where no
+// planner of the batch is running: the plan stream has been waited for.)
+int flush_tables(rsmp_fir_lockstep* ls, hipStream_t s) {
+    if (!ls->groups_dirty && !ls->rs_dirty) return RSMP_OK;
+    const size_t gb = ls->groups.size() * sizeof(LockstepGroup), rb = ls->h_run_rs.size() * sizeof(rsmp::LsRunStream);
+    if (ls->stage_inflight) {   // (the staging memory of the previous change: long since read)
+        RSMP_HIP_CHECK(hipEventSynchronize(ls->stage_ev));
+        ls->stage_inflight = false;
+    }
+    RSMP_HIP_CHECK(ls->h_stage.reserve(gb + rb));
+    char* h = ls->h_stage.as<char>();
+    if (ls->groups_dirty) {
+        std::memcpy(h, ls->groups.data(), gb);
+        RSMP_HIP_CHECK(hipMemcpyAsync(ls->d_groups.get(), h, gb, hipMemcpyHostToDevice, s));
+    }
+    if (ls->rs_dirty) {
+        std::memcpy(h + gb, ls->h_run_rs.data(), rb);
+        RSMP_HIP_CHECK(hipMemcpyAsync(ls->d_run_rs.get(), h + gb, rb, hipMemcpyHostToDevice, s));
+    }
+    RSMP_HIP_CHECK(hipEventRecord(ls->stage_ev, s));
+    ls->stage_inflight = true;
+    ls->groups_dirty = ls->rs_dirty = false;
+    return RSMP_OK;
+}
+
+// After a step or run of `frames` input frames per stream: now and then the classes' drifts start their way to the host.
+int request_drift(rsmp_fir_lockstep* ls, hipStream_t s, uint64_t frames) {
+    ls->frames_since_drift += frames;
+    if (ls->drift_inflight || ls->frames_since_drift < kLsDriftCheckFrames || ls->classes.empty()) return RSMP_OK;
+    const uint32_t nc = static_cast<uint32_t>(ls->classes.size());
+    // (the kernel stores straight into the mapped, coherent host buffer: a copy-engine operation in the stream costs the
+    // stream ~0.1 ms of cross-queue synchronisation, 6-9 % of config 4's step when done every fourth run)
+    RSMP_HIP_CHECK(rsmp::launch_fir_lockstep_gather_drift(ls->d_states.as<FirMirrorState>(), ls->d_drift_reps.as<uint32_t>(),
+                                                          ls->h_drift.as<double>(), nc, s));
+    RSMP_HIP_CHECK(hipEventRecord(ls->drift_ev, s));
+    ls->drift_inflight = true;
+    ls->frames_since_drift = 0;
+    return RSMP_OK;
+}
+
+// The host knows the states (creation, reset): every class gets the tables of its first stream's drift at once.
+int rebind_from_host_states(rsmp_fir_lockstep* ls) {
+    if (ls->drift_inflight) {   // (what is on its way belongs to the old states)
+        RSMP_HIP_CHECK(hipEventSynchronize(ls->drift_ev));
+        ls->drift_inflight = false;
+    }
+    ls->frames_since_drift = 0;
+    for (size_t c = 0; c < ls->classes.size(); ++c) {
+        const double d = ls->rs[ls->order[ls->classes[c].rep]]->mirror.drift();
+        if (std::fabs(d - ls->classes[c].table_drift) > kLsDriftQuantum)
+            if (int rc = rebind_class(ls, c, d)) return rc;
+    }
+    return RSMP_OK;
+}
 
 // A stream's buffered frames alternate between its two history buffers (fir_lockstep.h, LockstepStream):
 // the next step (index ls->step) reads `hist` when its index is even.  After any number of steps the handle's
@@ -132,10 +269,12 @@ extern "C" rsmp_fir_lockstep* rsmp_fir_lockstep_new(rsmp_fir* const* rs, size_t 
     // Streams that share a polyphase table, a rate pair and a channel count share a class table and
     // a geometry: they become neighbours, then workgroups of `slots` streams.
     // (a stream set to RSMP_FIR_KERNEL_PERIODIC_F32 keeps every product in f32: its own groups)
-    typedef std::tuple<const void*, uint32_t, uint32_t, size_t, size_t, bool> Key;
+    // (... and whose f64 drifts lie together: DriftClass)
+    typedef std::tuple<const void*, uint32_t, uint32_t, size_t, size_t, bool, long long> Key;
     auto exact_of = [](const rsmp_fir* r) { return r->kernel_mode != RSMP_FIR_KERNEL_AUTO; };
     auto key_of = [&](const rsmp_fir* r) {
-        return Key(static_cast<const void*>(r->table.get()), r->in_hz, r->out_hz, r->channels, r->taps, exact_of(r));
+        return Key(static_cast<const void*>(r->table.get()), r->in_hz, r->out_hz, r->channels, r->taps, exact_of(r),
+                   std::llround(r->mirror.drift() / kLsDriftClass));
     };
     ls->order.resize(n);
     for (size_t i = 0; i < n; ++i) ls->order[i] = static_cast<uint32_t>(i);
@@ -159,10 +298,21 @@ extern "C" rsmp_fir_lockstep* rsmp_fir_lockstep_new(rsmp_fir* const* rs, size_t 
             return nullptr;
         }
         rsmp::ClassTable ct;
+        rsmp_fir_lockstep::DriftClass cl;
+        cl.rep = static_cast<uint32_t>(k);
+        cl.first = k;
+        cl.count = e - k;
+        cl.r0 = r0;
+        cl.table_drift = quantized_drift(r0->mirror.drift());
+        cl.has_step = geo.periodic;
         if (geo.periodic) {
-            if (rsmp::class_table_for(ls->device, *r0->table, rsmp::lockstep_class_geometry(geo), 0.0, &ct) != RSMP_OK)
+            cl.step_geo = rsmp::lockstep_class_geometry(geo);
+            if (rsmp::class_table_for(ls->device, *r0->table, cl.step_geo, cl.table_drift, &ct) != RSMP_OK)
                 return nullptr;
+            cl.step_table = ct;
         }
+        const uint32_t class_index = static_cast<uint32_t>(ls->classes.size());
+        ls->classes.push_back(cl);
         for (size_t first = k; first < e; first += geo.slots) {
             LockstepGroup g;
             std::memset(&g, 0, sizeof g);
@@ -191,6 +341,7 @@ extern "C" rsmp_fir_lockstep* rsmp_fir_lockstep_new(rsmp_fir* const* rs, size_t 
             g.split = geo.split ? 1u : 0u;
             g.rows = geo.rows;
             g.row_bytes = geo.row_bytes;
+            g.pad0 = class_index;   // (host side only: which DriftClass the group's tables belong to)
             ls->groups.push_back(g);
             if (geo.lds_bytes > ls->max_lds) ls->max_lds = geo.lds_bytes;
             if (rsmp::lockstep_rec_stride(geo.wrap_cap) > ls->rec_stride) ls->rec_stride = rsmp::lockstep_rec_stride(geo.wrap_cap);
@@ -242,6 +393,10 @@ extern "C" rsmp_fir_lockstep* rsmp_fir_lockstep_new(rsmp_fir* const* rs, size_t 
         ls->d_order.reserve(n * sizeof(uint32_t)) != hipSuccess ||
         ls->d_recs.reserve(2 * n * static_cast<size_t>(ls->rec_stride)) != hipSuccess ||
         ls->d_peaks.reserve(n * 16) != hipSuccess ||
+        ls->d_drift_reps.reserve(ls->classes.size() * sizeof(uint32_t)) != hipSuccess ||
+        ls->h_drift.reserve(ls->classes.size() * sizeof(double)) != hipSuccess ||
+        hipEventCreateWithFlags(&ls->drift_ev, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ls->stage_ev, hipEventDisableTiming) != hipSuccess ||
         hipStreamCreateWithFlags(&ls->own_stream, hipStreamNonBlocking) != hipSuccess) {
         rsmp::fail(RSMP_ERR_HIP, "lock-step batch: cannot allocate device state");
         return nullptr;
@@ -254,6 +409,11 @@ extern "C" rsmp_fir_lockstep* rsmp_fir_lockstep_new(rsmp_fir* const* rs, size_t 
     if (hipMemcpy(ls->d_groups.get(), ls->groups.data(), ls->groups.size() * sizeof(LockstepGroup),
                   hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(ls->d_order.get(), ls->order.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess ||
+        [&] {
+            std::vector<uint32_t> reps;
+            for (const auto& cl : ls->classes) reps.push_back(cl.rep);
+            return hipMemcpy(ls->d_drift_reps.get(), reps.data(), reps.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+        }() != hipSuccess ||
         hipMemset(ls->d_recs.get(), 0, 2 * n * static_cast<size_t>(ls->rec_stride)) != hipSuccess ||
         hipMemset(ls->d_peaks.get(), 0, n * 16) != hipSuccess ||
         hipMemset(ls->d_cursor.get(), 0, n * sizeof(uint64_t)) != hipSuccess ||
@@ -270,6 +430,8 @@ extern "C" void rsmp_fir_lockstep_free(rsmp_fir_lockstep* ls) {
     if (!ls) return;
     DeviceGuard guard(ls->device);
     (void)rsmp_fir_lockstep_sync(ls);
+    if (ls->drift_ev) (void)hipEventDestroy(ls->drift_ev);
+    if (ls->stage_ev) (void)hipEventDestroy(ls->stage_ev);
     for (hipStream_t& q : ls->plan_candidates) {
         if (!q) continue;
         (void)hipStreamSynchronize(q);
@@ -355,6 +517,8 @@ extern "C" int rsmp_fir_lockstep_step(rsmp_fir_lockstep* ls, size_t in_frames, s
     }
     if (int rc = drop_plan_ahead(ls, s)) return rc;   // (a run planned ahead read the states this step is about to change)
     ls->prev.valid = false;
+    if (int rc = poll_drift(ls)) return rc;
+    if (int rc = flush_tables(ls, s)) return rc;
     rsmp::LockstepArgs a;
     a.groups = ls->d_groups.as<LockstepGroup>();
     a.streams = ls->d_streams.as<LockstepStream>();
@@ -386,7 +550,7 @@ extern "C" int rsmp_fir_lockstep_step(rsmp_fir_lockstep* ls, size_t in_frames, s
         ++ls->prof_count;
     }
     ls->last_stream = s;
-    return RSMP_OK;
+    return request_drift(ls, s, in_frames);
 }
 
 extern "C" int rsmp_fir_lockstep_counts(rsmp_fir_lockstep* ls, size_t* consumed, size_t* produced) {
@@ -440,7 +604,11 @@ extern "C" int rsmp_fir_lockstep_reset(rsmp_fir_lockstep* ls) {
     RSMP_HIP_CHECK(hipMemset(ls->d_cursor.get(), 0, n * sizeof(uint64_t)));
     RSMP_HIP_CHECK(hipMemset(ls->d_status.get(), 0, n * sizeof(uint32_t)));
     ++ls->epoch;   // plans made ahead belong to the old states
-    return upload_states(ls);
+    if (int rc = upload_states(ls)) return rc;
+    if (int rc = rebind_from_host_states(ls)) return rc;   // (fresh streams: drift 0)
+    if (int rc = flush_tables(ls, ls->own_stream)) return rc;
+    RSMP_HIP_CHECK(hipStreamSynchronize(ls->own_stream));
+    return RSMP_OK;
 }
 
 extern "C" int rsmp_fir_lockstep_set_profiling(rsmp_fir_lockstep* ls, int enable) {
@@ -527,15 +695,10 @@ int prepare_run(rsmp_fir_lockstep* ls) {
     std::vector<rsmp::LsRunStream> rstreams(n);
     std::memset(descs.data(), 0, n * sizeof(rsmp::FirStreamDesc));
     ls->run_groups.clear();
-    auto same = [&](const rsmp_fir* x, const rsmp_fir* y) {
-        return x->table.get() == y->table.get() && x->in_hz == y->in_hz && x->out_hz == y->out_hz &&
-               x->channels == y->channels && x->taps == y->taps && x->kernel_mode == y->kernel_mode;
-    };
-    size_t k = 0;
-    while (k < n) {
-        const rsmp_fir* r0 = ls->rs[ls->order[k]];
-        size_t e = k;
-        while (e < n && same(ls->rs[ls->order[e]], r0)) ++e;
+    for (size_t c = 0; c < ls->classes.size(); ++c) {   // one group of streams per drift class (key + drift: rsmp_fir_lockstep_new)
+        rsmp_fir_lockstep::DriftClass& cl = ls->classes[c];
+        const size_t k = cl.first, e = cl.first + cl.count;
+        const rsmp_fir* r0 = cl.r0;
         const int mode = r0->kernel_mode;
         rsmp::PeriodicGeometry geo;
         if (mode != RSMP_FIR_KERNEL_GENERIC && r0->mirror.periodic_ok())
@@ -547,6 +710,7 @@ int prepare_run(rsmp_fir_lockstep* ls) {
         // planner does not keep -- unless the ratio is exact in f64 and no output ever wraps)
         if (!geo.ok || (!geo.inline_wraps && (den & (den - 1)) != 0)) {
             // runs are loops of steps; their per-call counts are gathered with the streams' caller indices
+            for (auto& x : ls->classes) x.has_run = false;
             for (size_t i = 0; i < n; ++i) rstreams[i].caller = ls->order[i];
             if (ls->d_run_rs.reserve(n * sizeof(rsmp::LsRunStream)) != hipSuccess)
                 return rsmp::fail(RSMP_ERR_HIP, "lock-step run: cannot allocate device state");
@@ -555,7 +719,10 @@ int prepare_run(rsmp_fir_lockstep* ls) {
             return RSMP_OK;
         }
         rsmp::ClassTable ct;
-        if (rsmp::class_table_for(ls->device, *r0->table, geo, 0.0, &ct) != RSMP_OK) return RSMP_ERR_HIP;
+        if (rsmp::class_table_for(ls->device, *r0->table, geo, cl.table_drift, &ct) != RSMP_OK) return RSMP_ERR_HIP;
+        cl.has_run = true;
+        cl.run_geo = geo;
+        cl.run_table = ct;
         rsmp_fir_lockstep::RunGroup g;
         g.geo = geo;
         g.first = k;
@@ -573,14 +740,18 @@ int prepare_run(rsmp_fir_lockstep* ls) {
             d.taps = static_cast<uint32_t>(r->taps);
             d.num = static_cast<uint32_t>(r->mirror.num());
             d.den = static_cast<uint32_t>(den);
-            d.drift = 0.0;
+            d.drift = cl.table_drift;
             rstreams[i].wrap_unit = geo.mfma == 3 ? geo.b : geo.den;
             rstreams[i].den = static_cast<uint32_t>(den);
             rstreams[i].channels = static_cast<uint32_t>(r->channels);
             rstreams[i].caller = ls->order[i];
+            rstreams[i].class_coef = ct.d_coef;          // (the planner writes these into the run's descriptor: they follow the drift)
+            rstreams[i].class_wrap_coef = ct.d_wrap_coef;
+            rstreams[i].class_meta = ct.d_meta;
+            rstreams[i].drift = cl.table_drift;
         }
-        k = e;
     }
+    ls->h_run_rs = rstreams;
     if (ls->slot[0].descs.reserve(n * sizeof(rsmp::FirStreamDesc)) != hipSuccess ||
         ls->slot[1].descs.reserve(n * sizeof(rsmp::FirStreamDesc)) != hipSuccess ||
         ls->sp_states.reserve(n * sizeof(FirMirrorState)) != hipSuccess ||
@@ -721,10 +892,12 @@ extern "C" int rsmp_fir_lockstep_run(rsmp_fir_lockstep* ls, size_t k_steps, size
     };
     if (ls->profiling)
         RSMP_HIP_CHECK(hipEventRecord(ls->prof_start[ls->prof_count % rsmp_fir_lockstep::kProfRing], s));
+    if (int rc = poll_drift(ls)) return rc;
     if (same_key(ls->ahead, key)) {
         // planned while the previous run computed: wait for it (an event, no host block) and take its results over
         RSMP_HIP_CHECK(hipStreamWaitEvent(s, ls->plan_done, 0));
         ls->ahead_inflight = false;
+        if (int rc = flush_tables(ls, s)) return rc;   // (new tables: from the next plan on; this run was planned with the old ones)
         rsmp::LsCommitArgs c;
         c.states = ls->d_states.as<FirMirrorState>();
         c.sp_states = ls->sp_states.as<FirMirrorState>();
@@ -738,6 +911,7 @@ extern "C" int rsmp_fir_lockstep_run(rsmp_fir_lockstep* ls, size_t k_steps, size
         RSMP_HIP_CHECK(rsmp::launch_fir_lockstep_commit(c, s));
     } else {
         if (int rc = drop_plan_ahead(ls, s)) return rc;   // (whatever the plan stream still does: finished before this stream goes on)
+        if (int rc = flush_tables(ls, s)) return rc;
         RSMP_HIP_CHECK(rsmp::launch_fir_lockstep_plan(plan_args(key, false), s));
     }
     ls->ahead.valid = false;
@@ -818,7 +992,7 @@ extern "C" int rsmp_fir_lockstep_run(rsmp_fir_lockstep* ls, size_t k_steps, size
     ls->last_slot = sl;
     ls->next_slot = sl ^ 1;
     ls->prev = key;
-    return RSMP_OK;
+    return request_drift(ls, s, static_cast<uint64_t>(k) * in_frames);
 }
 
 extern "C" int rsmp_fir_lockstep_run_counts(rsmp_fir_lockstep* ls, size_t* consumed, size_t* produced, size_t max_steps) {
@@ -834,6 +1008,12 @@ extern "C" int rsmp_fir_lockstep_run_counts(rsmp_fir_lockstep* ls, size_t* consu
         if (consumed) consumed[i] = ls->h_run_counts[2 * i];
         if (produced) produced[i] = ls->h_run_counts[2 * i + 1];
     }
+    return RSMP_OK;
+}
+
+extern "C" int rsmp_fir_lockstep_table_rebinds(const rsmp_fir_lockstep* ls, size_t* rebinds) {
+    if (!ls || !rebinds) return rsmp::fail(RSMP_ERR_INVALID_ARGUMENT, "rsmp_fir_lockstep_table_rebinds: null argument");
+    *rebinds = ls->table_rebinds;
     return RSMP_OK;
 }
 

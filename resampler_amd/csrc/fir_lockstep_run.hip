@@ -233,6 +233,13 @@ __global__ __launch_bounds__(64) void fir_lockstep_wraps_kernel(LsRunArgs a) {
     overflow = __any(overflow);
     unchecked = __any(unchecked);
     if (lane == 0) {
+        // the class tables of the run's descriptor follow the stream's drift (LsRunStream; written here and not by the
+        // chain kernel: four more values alive across its loop were 28 more spilled registers, 10 % of its time)
+        FirStreamDesc* d = a.descs + gs;
+        d->class_coef = rs.class_coef;
+        d->class_wrap_coef = rs.class_wrap_coef;
+        d->class_meta = rs.class_meta;
+        d->drift = rs.drift;
         if (have) a.states_out[gs].drift = drift;
         if (aperiodic) a.states_out[gs].periodic_ok = 0;
         uint32_t flags = (overflow ? kLsStatusRunOverflow : 0u) | (unchecked ? kLsStatusPlannerCheck : 0u);
@@ -262,12 +269,24 @@ __global__ __launch_bounds__(256) void fir_lockstep_commit_kernel(LsCommitArgs a
     if (f) a.status[gs] |= f;
 }
 
+__global__ __launch_bounds__(64) void fir_lockstep_gather_drift_kernel(const FirMirrorState* states, const uint32_t* reps, double* out, uint32_t n) {
+    const uint32_t c = blockIdx.x * 64u + threadIdx.x;
+    if (c < n) out[c] = states[reps[c]].drift;
+}
+
 __global__ __launch_bounds__(64) void fir_lockstep_idle_kernel(uint32_t ticks) {
     const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
     while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
 }
 
 }  // namespace
+
+hipError_t launch_fir_lockstep_gather_drift(const FirMirrorState* states, const uint32_t* reps, double* out, uint32_t n,
+                                            hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(fir_lockstep_gather_drift_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, states, reps, out, n);
+    return hipGetLastError();
+}
 
 hipError_t launch_fir_lockstep_idle(uint32_t ticks, hipStream_t stream) {
     hipLaunchKernelGGL(fir_lockstep_idle_kernel, dim3(1), dim3(64), 0, stream, ticks);

@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <memory>
 #include <vector>
 
 #include "fir_kernels.h"
@@ -82,10 +83,14 @@ static_assert(sizeof(TileMeta) == 32, "TileMeta is read with one s_load_dwordx8"
 
 // Device image of one class table: [tile][row_len][8] coefficients, [tile][row_len] wrap-variant
 // coefficients, [tile] TileMeta.
+// `hold` keeps the device allocation alive: the cache is bounded (a stream's drift moves on for as long as it runs, and
+// every drift step is a new table), and a table that has left it is freed once nobody holds it any more AND the device
+// has been waited for (kernels already enqueued may still read it): class_table_for.
 struct ClassTable {
     const float* d_coef = nullptr;
     const float* d_wrap_coef = nullptr;
     const TileMeta* d_meta = nullptr;
+    std::shared_ptr<void> hold;
 };
 
 // Per-handle periodic state: the class table currently bound to the stream.

@@ -1714,11 +1714,40 @@ struct ClassTableKey {
 };
 struct ClassTableCache {
     std::mutex mu;
-    std::map<ClassTableKey, ClassTable> tables;
+    struct Entry { ClassTable ct; uint64_t used; };
+    std::map<ClassTableKey, Entry> tables;
+    uint64_t tick = 0;
+    static constexpr size_t kMaxTables = 96;    // (a geometry's table is 0.1-0.4 MB)
 };
 ClassTableCache& class_cache() {
     static ClassTableCache* c = new ClassTableCache;
     return *c;
+}
+// Device allocations of tables nobody holds any more.  Kernels enqueued earlier may still read them, so they are freed in
+// batches, behind a hipDeviceSynchronize (class_table_for, on its slow path: a table is being built anyway).
+struct ClassTableGraveyard {
+    std::mutex mu;
+    std::vector<std::pair<int, void*>> dead;   // (device, allocation)
+    static constexpr size_t kPurgeAt = 32;
+};
+ClassTableGraveyard& class_graveyard() {
+    static ClassTableGraveyard* g = new ClassTableGraveyard;
+    return *g;
+}
+void purge_class_graveyard(int device) {
+    ClassTableGraveyard& gy = class_graveyard();
+    std::vector<std::pair<int, void*>> mine;
+    {
+        std::lock_guard<std::mutex> lock(gy.mu);
+        if (gy.dead.size() < ClassTableGraveyard::kPurgeAt) return;
+        for (auto it = gy.dead.begin(); it != gy.dead.end();) {
+            if (it->first == device) { mine.push_back(*it); it = gy.dead.erase(it); }
+            else ++it;
+        }
+    }
+    if (mine.empty()) return;
+    (void)hipDeviceSynchronize();   // (the current device is `device`: the callers' DeviceGuard)
+    for (auto& d : mine) (void)hipFree(d.second);
 }
 
 constexpr double kDriftQuantum = 2e-9;  // positions this close share a class table
@@ -2018,6 +2047,13 @@ int class_table_for(int device, const std::vector<float>& table, const PeriodicG
                             g.mfma == 3 ? 8u + g.planes : (g.mfma ? 1u : 0u), bits};
     auto it = cache.tables.find(key);
     if (it == cache.tables.end()) {
+        purge_class_graveyard(device);
+        if (cache.tables.size() >= ClassTableCache::kMaxTables) {   // the least recently used one leaves (its holders keep it alive)
+            auto lru = cache.tables.begin();
+            for (auto e = cache.tables.begin(); e != cache.tables.end(); ++e)
+                if (e->second.used < lru->second.used) lru = e;
+            cache.tables.erase(lru);
+        }
         const HostClassTable host = build_class_table(table, g, drift);
         const size_t coef_bytes = host.coef.size() * sizeof(float);
         const size_t wrap_bytes = host.wrap_coef.size() * sizeof(float);
@@ -2033,9 +2069,15 @@ int class_table_for(int device, const std::vector<float>& table, const PeriodicG
         ct.d_coef = reinterpret_cast<const float*>(dptr);
         ct.d_wrap_coef = reinterpret_cast<const float*>(dptr + coef_bytes);
         ct.d_meta = reinterpret_cast<const TileMeta*>(dptr + coef_bytes + wrap_bytes);
-        it = cache.tables.emplace(key, ct).first;
+        ct.hold = std::shared_ptr<void>(dptr, [device](void* p) {
+            ClassTableGraveyard& gy = class_graveyard();
+            std::lock_guard<std::mutex> lock(gy.mu);
+            gy.dead.emplace_back(device, p);
+        });
+        it = cache.tables.emplace(key, ClassTableCache::Entry{ct, 0}).first;
     }
-    *out = it->second;
+    it->second.used = ++cache.tick;
+    *out = it->second.ct;
     return RSMP_OK;
 }
 

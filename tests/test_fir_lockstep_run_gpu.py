@@ -286,3 +286,101 @@ def test_the_same_span_run_again_and_again_without_append():
     for h, r in zip(hs, refs):
         assert h.state() == r.state()
     ls.close()
+
+
+def test_an_old_stream_keeps_parity_through_runs():
+    """The reference's f64 position drifts away from the exact rational one by ~1e-14 of a frame per output
+    (src/resampler_fir.rs:589: every add rounds on the grid of its binade); after half an hour of audio that is 1e-6 of a
+    frame -- 2e-6 of a full-scale sample with coefficient rows mixed for the position without the drift.  A stream that old
+    (aged through the bulk path, which follows the drift) must come through runs and steps like a young one."""
+    import torch
+    dev = torch.device("cuda:0")
+    g = ra.ResamplerFir.new_from_hz(2, 44100, 48000, ra.Latency.Sample64, ra.Attenuation.Db90)
+    kind = o.CONVOLVE_AVX_FMA if o.have_avx_fma() else o.CONVOLVE_SCALAR
+    r = o.OracleFir(2, 44100, 48000, 128, 90, kind)
+    x = synth.fast_noise(2 * (4 << 20), seed=21)
+    for _ in range(32):   # 134 M frames: 51 minutes at 44.1 kHz
+        _, consumed = g.resample_bulk(x, 1024)
+        r.resample_all(x, 1024)
+        assert consumed == x.size
+    assert g.state() == r.state()
+    frames, k = 512, 48
+    xs = synth.fast_noise(2 * frames * (2 * k + 1), seed=22)
+    d_in = [torch.from_numpy(xs).to(dev)]
+    cap = g.buffer_size_output()
+    d_out = [torch.zeros((2 * k + 1) * cap, device=dev)]
+    ls = ra.FirLockstep([g], frames)
+    ls.bind_caps(d_in, d_out, [cap])
+    want = []
+    orr = np.zeros(r.buffer_size_output(), np.float32)
+
+    def oracle(calls, first, cons, prod):
+        for s in range(calls):
+            rc, cr, pr = r.resample(xs[(first + s) * frames * 2:(first + s + 1) * frames * 2], orr)
+            assert rc == 0 and (int(cons[s][0]), int(prod[s][0])) == (cr, pr)
+            want.append(orr[:pr].copy())
+    assert ls.table_rebinds() == 0   # (created on the old stream: its tables are mixed for its drift from the start)
+    ls.run(k, frames, 0, append=True)
+    oracle(k, 0, *ls.run_counts())
+    ls.step(frames, k * frames, append=True)
+    c, p = ls.counts()
+    oracle(1, k, c[None, :], p[None, :])
+    ls.run(k, frames, (k + 1) * frames, append=True)
+    oracle(k, k + 1, *ls.run_counts())
+    w = np.concatenate(want)
+    got = d_out[0][:w.size].cpu().numpy()
+    assert rms(got, w) <= RMS_TOL, rms(got, w)
+    ls.sync()
+    assert g.state() == r.state()
+
+
+def test_class_tables_follow_the_drift_while_a_batch_runs():
+    """Two streams run 17 M frames in lock-step (runs of 256 calls, a few steps in between): the drift moves by more than
+    the tolerance of a set of class tables, the batch replaces them on the way (table_rebinds), counts, samples and states
+    keep matching the oracle; a reset takes the streams -- and the tables -- back to drift 0."""
+    import torch
+    dev = torch.device("cuda:0")
+    specs = [(44100, 48000), (48000, 44100)]
+    hs = [ra.ResamplerFir.new_from_hz(2, i, o_, ra.Latency.Sample64, ra.Attenuation.Db90) for i, o_ in specs]
+    kind = o.CONVOLVE_AVX_FMA if o.have_avx_fma() else o.CONVOLVE_SCALAR
+    refs = [o.OracleFir(2, i, o_, 128, 90, kind) for i, o_ in specs]
+    frames, k, runs = 512, 256, 128
+    x = synth.fast_noise(2 * frames * (k + 1), seed=31)     # the same span of input again and again
+    d_in = [torch.from_numpy(x).to(dev) for _ in hs]
+    caps = [h.buffer_size_output() for h in hs]
+    d_out = [torch.zeros((k + 1) * c, device=dev) for c in caps]
+    ls = ra.FirLockstep(hs, frames)
+    ls.bind_caps(d_in, d_out, caps)
+    orr = [np.zeros(r.buffer_size_output(), np.float32) for r in refs]
+
+    def one_pass(check):
+        ls.run(k, frames, 0, append=False)
+        cons, prod = ls.run_counts()
+        ls.step(frames, k * frames, append=True)
+        c1, p1 = ls.counts()
+        worst = 0.0
+        for i, r in enumerate(refs):
+            want = []
+            for s in range(k + 1):
+                rc, cr, pr = r.resample(x[s * frames * 2:(s + 1) * frames * 2], orr[i])
+                cg, pg = (cons[s][i], prod[s][i]) if s < k else (c1[i], p1[i])
+                assert rc == 0 and (int(cg), int(pg)) == (cr, pr), (s, i)
+                if check:
+                    want.append(orr[i][:pr].copy())
+            if check:
+                w = np.concatenate(want)
+                worst = max(worst, rms(d_out[i][:w.size].cpu().numpy(), w))
+        return worst
+    for p in range(runs):
+        worst = one_pass(check=(p % 16 == 15))
+        assert worst <= RMS_TOL, (p, worst)
+    assert ls.table_rebinds() >= 2   # (both rate pairs have moved by more than 1.2e-7 of a frame)
+    ls.sync()
+    for h, r in zip(hs, refs):
+        assert h.state() == r.state()
+    before = ls.table_rebinds()
+    ls.reset()
+    for r in refs:
+        r.reset()
+    assert ls.table_rebinds() > before   # back to the tables of drift 0
+    assert one_pass(check=True) <= RMS_TOL
