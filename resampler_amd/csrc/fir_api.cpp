@@ -433,6 +433,7 @@ int launch_jobs(rsmp_fir* leader, std::vector<Job>& jobs, hipStream_t stream) {
         Job& j = jobs[i];
         if (!j.plan->periodic) continue;
         const int rc = rsmp::periodic_bind(j.r->periodic, j.r->device, *j.r->table, j.r->kernel_mode, j.plan->planned,
+                                           0.5 * (j.r->mirror.drift() + j.plan->planned.drift()),
                                            static_cast<uint32_t>(j.r->channels), stream);
         if (rc != RSMP_OK) return rc;
         bool found = false;
@@ -684,9 +685,50 @@ void report_calls(const Plan& pl, size_t* calls, size_t max_calls, size_t* n_cal
         }
 }
 
+int run_single_piece(rsmp_fir* r, const float* d_in, size_t in_len, float* d_out, size_t out_cap,
+                     size_t chunk_len, size_t* consumed, size_t* produced, size_t* calls,
+                     size_t max_calls, size_t* n_calls, hipStream_t stream);
+
+// A launch's coefficient rows are mixed for ONE drift, the stream's f64 drift moves by ~1e-14 of a frame per output: a
+// bulk call of more than kMaxLaunchOutputs outputs is cut into launches of at most that many (at call boundaries: the
+// reference's loop, resample/src/main.rs:226-254, does not know the difference), each with the table of its own middle --
+// 2e-7 of a frame from either end, 3e-7 of a full-scale sample.  (Config 5's 26.5 M outputs stay one launch.)
+constexpr uint64_t kMaxLaunchOutputs = 46000000ull;
+
 int run_single(rsmp_fir* r, const float* d_in, size_t in_len, float* d_out, size_t out_cap,
                size_t chunk_len, size_t* consumed, size_t* produced, size_t* calls,
                size_t max_calls, size_t* n_calls, hipStream_t stream) {
+    const size_t ch = r->channels;
+    if (chunk_len == 0 || chunk_len % ch != 0 || in_len % ch != 0)
+        return run_single_piece(r, d_in, in_len, d_out, out_cap, chunk_len, consumed, produced, calls, max_calls, n_calls, stream);
+    const size_t chunk_frames = chunk_len / ch;
+    size_t piece_chunks = static_cast<size_t>(static_cast<double>(kMaxLaunchOutputs) * r->mirror.ratio() / static_cast<double>(chunk_frames));
+    if (piece_chunks == 0) piece_chunks = 1;
+    const size_t piece_len = piece_chunks * chunk_len;
+    if (in_len <= piece_len)
+        return run_single_piece(r, d_in, in_len, d_out, out_cap, chunk_len, consumed, produced, calls, max_calls, n_calls, stream);
+    size_t off = 0, made = 0, n_total = 0;
+    while (off < in_len) {
+        const size_t take = std::min(piece_len, in_len - off);
+        size_t c = 0, p = 0, nc = 0;
+        const size_t room = n_total < max_calls ? max_calls - n_total : 0;
+        if (int rc = run_single_piece(r, d_in + off, take, d_out + made, out_cap - made, chunk_len, &c, &p,
+                                      calls && room ? calls + 2 * n_total : nullptr, room, &nc, stream))
+            return rc;
+        off += c;
+        made += p;
+        n_total += nc;
+        if (c != take) break;   // (cannot happen in a bulk call: every call accepts what it is offered)
+    }
+    if (consumed) *consumed = off;
+    if (produced) *produced = made;
+    if (n_calls) *n_calls = n_total;
+    return RSMP_OK;
+}
+
+int run_single_piece(rsmp_fir* r, const float* d_in, size_t in_len, float* d_out, size_t out_cap,
+                     size_t chunk_len, size_t* consumed, size_t* produced, size_t* calls,
+                     size_t max_calls, size_t* n_calls, hipStream_t stream) {
     std::vector<Job> jobs;
     jobs.push_back(Job{r, d_in, in_len, d_out, out_cap, chunk_len, nullptr});
     int rc = plan_job(jobs[0]);

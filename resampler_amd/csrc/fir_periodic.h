@@ -109,8 +109,10 @@ bool periodic_worthwhile(const FirMirror& planned, size_t produced_frames, int k
 // Makes sure `st` holds the geometry and the device class table matching the stream's rate pair
 // and its current f64 drift (host build + one upload, cached per device and shared by every
 // stream with the same polyphase table, rate pair and drift).
+// `drift`: what the launch's coefficient rows are mixed for -- the middle between the stream's drift before the launch and
+// behind it (the drift moves by ~1e-14 of a frame per output: a launch is half as far from its table that way).
 int periodic_bind(PeriodicState& st, int device, const std::vector<float>& table, int kernel_mode,
-                  const FirMirror& planned, uint32_t channels, hipStream_t stream);
+                  const FirMirror& planned, double drift, uint32_t channels, hipStream_t stream);
 
 // Device class table for a geometry and drift (built on the host once, cached per device).
 int class_table_for(int device, const std::vector<float>& table, const PeriodicGeometry& g, double drift,

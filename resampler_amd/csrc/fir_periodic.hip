@@ -2082,7 +2082,7 @@ int class_table_for(int device, const std::vector<float>& table, const PeriodicG
 }
 
 int periodic_bind(PeriodicState& st, int device, const std::vector<float>& table, int kernel_mode,
-                  const FirMirror& planned, uint32_t channels, hipStream_t stream) {
+                  const FirMirror& planned, double launch_drift, uint32_t channels, hipStream_t stream) {
     (void)stream;
     const bool allow_matrix = kernel_mode != RSMP_FIR_KERNEL_PERIODIC_VECTOR;
     if (!st.geo_valid || st.geo_mode != kernel_mode) {   // (rsmp_fir_set_kernel may switch between them)
@@ -2093,7 +2093,7 @@ int periodic_bind(PeriodicState& st, int device, const std::vector<float>& table
         st.table_valid = false;
     }
     if (!st.geo.ok) return fail(RSMP_ERR_INVALID_ARGUMENT, "periodic kernel: unsupported geometry");
-    const double drift = std::round(planned.drift() / kDriftQuantum) * kDriftQuantum;
+    const double drift = std::round(launch_drift / kDriftQuantum) * kDriftQuantum;
     if (st.table_valid && drift == st.table_drift) return RSMP_OK;
     ClassTable ct;
     const int rc = class_table_for(device, table, st.geo, drift, &ct);

@@ -743,3 +743,25 @@ def test_lockstep_channels_at_very_different_levels():
             for c, (err, level) in enumerate(_per_channel_errors(yg, yr, 2)):
                 assert err <= max(RMS_TOL * level, PAIR_FLOOR), (mode, i, c, err, level)
         ls.close()
+
+
+def test_a_bulk_call_longer_than_one_launch():
+    """50 M frames in one bulk call (19 minutes at 44.1 kHz): more outputs than one launch takes (its coefficient rows
+    are mixed for one drift; the library cuts the call at call boundaries, fir_api.cpp run_single) -- the calls, the samples
+    (over the whole stream and over its first and last twentieth, where a table mixed for the wrong end would show) and
+    the final state are the reference's."""
+    if not o.have_avx_fma():
+        pytest.skip("needs the oracle's AVX + FMA path (time)")
+    n = 50_000_000
+    x = synth.fast_noise(2 * n, seed=41)
+    g = ra.ResamplerFir.new_from_hz(2, 44100, 48000, ra.Latency.Sample64, ra.Attenuation.Db90)
+    r = o.OracleFir(2, 44100, 48000, 128, 90, o.CONVOLVE_AVX_FMA)
+    yg, consumed, calls_g = g.resample_bulk(x, 1024, want_calls=True)
+    yr, calls_r = r.resample_all(x, 1024)
+    assert consumed == x.size and np.array_equal(calls_g, calls_r)
+    assert yg.size == yr.size
+    part = yr.size // 20
+    for a, b in ((0, part), (yr.size - part, yr.size), (0, yr.size)):
+        d = yg[a:b].astype(np.float64) - yr[a:b]
+        assert np.sqrt(np.dot(d, d) / (b - a)) <= RMS_TOL, (a, b)
+    assert g.state() == r.state()
