@@ -613,6 +613,7 @@ int launch_jobs(rsmp_fir* leader, std::vector<Job>& jobs, hipStream_t stream) {
         RSMP_HIP_CHECK(hipMemsetAsync(leader->d_nf.get(), 0, leader->d_nf.capacity(), stream));
     }
     size_t gi = 0;
+    std::vector<rsmp::SplitJob> split_jobs;
     for (const Group& g : groups) {
         uint32_t max_blocks = 0;
         for (size_t i : g.members) {
@@ -643,17 +644,30 @@ int launch_jobs(rsmp_fir* leader, std::vector<Job>& jobs, hipStream_t stream) {
             mix(j.plan->hist_frames); mix(j.plan->accepted_frames); mix(j.r->channels);
         }
         if (key == 0) key = 1;
-        RSMP_HIP_CHECK(rsmp::launch_fir_periodic(d_descs + first,
-                                                 static_cast<uint32_t>(g.members.size()), g.geo,
-                                                 max_blocks, leader->d_work_counter, rp.nf, stream, tail_fused, key));
+        if (groups.size() > 1 && g.geo.mfma == 3) {
+            // several rate pairs in one batch: those of the split kernel share launches (launch_fir_split_multi: one item
+            // table launch, one kernel launch per kernel build among them), as in rsmp_fir_lockstep_run
+            split_jobs.push_back(rsmp::SplitJob{d_descs + first, static_cast<uint32_t>(g.members.size()), &g.geo, max_blocks, rp.nf});
+        } else {
+            RSMP_HIP_CHECK(rsmp::launch_fir_periodic(d_descs + first,
+                                                     static_cast<uint32_t>(g.members.size()), g.geo,
+                                                     max_blocks, leader->d_work_counter, rp.nf, stream, tail_fused, key));
+        }
         first += g.members.size();
     }
+    if (!split_jobs.empty()) RSMP_HIP_CHECK(rsmp::launch_fir_split_multi(split_jobs.data(), split_jobs.size(), stream));
     if (leader->profiling) {
         RSMP_HIP_CHECK(hipEventRecord(leader->prof_stop[leader->prof_count % rsmp_fir::kProfRing], stream));
         ++leader->prof_count;
     }
-    for (const Repair& rp : repairs)
-        RSMP_HIP_CHECK(rsmp::launch_fir_repair(d_descs + rp.first, rp.count, rp.nf, stream));
+    if (repairs.size() > 1) {
+        std::vector<rsmp::RepairJob> rj;
+        for (const Repair& rp : repairs) rj.push_back(rsmp::RepairJob{d_descs + rp.first, rp.count, rp.nf});
+        RSMP_HIP_CHECK(rsmp::launch_fir_repair_multi(rj.data(), rj.size(), stream));
+    } else {
+        for (const Repair& rp : repairs)
+            RSMP_HIP_CHECK(rsmp::launch_fir_repair(d_descs + rp.first, rp.count, rp.nf, stream));
+    }
     if (n > n_generic && max_wraps > 0)
         RSMP_HIP_CHECK(rsmp::launch_fir_wrap_fixup(d_descs + n_generic,
                                                    static_cast<uint32_t>(n - n_generic), max_wraps,
@@ -990,6 +1004,10 @@ extern "C" int rsmp_fir_resample_bulk(rsmp_fir* r, const float* in, size_t in_le
     return RSMP_OK;
 }
 
+static int batch_bulk_piece(rsmp_fir* const* rs, size_t n, const float* const* d_in, const size_t* in_lens,
+                            size_t chunk_len, float* const* d_out, const size_t* out_caps, size_t* consumed,
+                            size_t* produced, void* stream);
+
 extern "C" int rsmp_fir_batch_resample_bulk_device(rsmp_fir* const* rs, size_t n,
                                                    const float* const* d_in, const size_t* in_lens,
                                                    size_t chunk_len, float* const* d_out,
@@ -998,6 +1016,63 @@ extern "C" int rsmp_fir_batch_resample_bulk_device(rsmp_fir* const* rs, size_t n
     if (n == 0) return RSMP_OK;
     if (!rs || !d_in || !in_lens || !d_out || !out_caps || chunk_len == 0)
         return rsmp::fail(RSMP_ERR_INVALID_ARGUMENT, "rsmp_fir_batch_resample_bulk_device: null/zero argument");
+    // A launch's coefficient rows are mixed for one drift (run_single): a stream offered more than kMaxLaunchOutputs outputs'
+    // worth of input takes part in several launches, cut at call boundaries; the others are through after the first.
+    std::vector<size_t> piece(n, 0);
+    bool cut = false;
+    for (size_t i = 0; i < n; ++i) {
+        if (!rs[i]) return rsmp::fail(RSMP_ERR_INVALID_ARGUMENT, "rsmp_fir_batch_resample_bulk_device: null stream");
+        const size_t ch = rs[i]->channels;
+        piece[i] = in_lens[i];
+        if (chunk_len % ch != 0 || in_lens[i] % ch != 0) continue;
+        size_t chunks = static_cast<size_t>(static_cast<double>(kMaxLaunchOutputs) * rs[i]->mirror.ratio() / static_cast<double>(chunk_len / ch));
+        if (chunks == 0) chunks = 1;
+        if (in_lens[i] > chunks * chunk_len) {
+            piece[i] = chunks * chunk_len;
+            cut = true;
+        }
+    }
+    if (!cut) return batch_bulk_piece(rs, n, d_in, in_lens, chunk_len, d_out, out_caps, consumed, produced, stream);
+    std::vector<size_t> off(n, 0), made(n, 0);
+    std::vector<char> stopped(n, 0);
+    for (;;) {
+        std::vector<rsmp_fir*> sub_rs;
+        std::vector<const float*> sub_in;
+        std::vector<float*> sub_out;
+        std::vector<size_t> sub_len, sub_cap, idx;
+        for (size_t i = 0; i < n; ++i) {
+            if (stopped[i] || off[i] >= in_lens[i]) continue;   // (through; a stream offered nothing takes part in no launch)
+            idx.push_back(i);
+            sub_rs.push_back(rs[i]);
+            sub_in.push_back(d_in[i] + off[i]);
+            sub_len.push_back(std::min(piece[i], in_lens[i] - off[i]));
+            sub_out.push_back(d_out[i] + made[i]);
+            sub_cap.push_back(out_caps[i] - made[i]);
+        }
+        if (idx.empty()) break;
+        std::vector<size_t> c(idx.size(), 0), p(idx.size(), 0);
+        if (int rc = batch_bulk_piece(sub_rs.data(), idx.size(), sub_in.data(), sub_len.data(), chunk_len, sub_out.data(),
+                                      sub_cap.data(), c.data(), p.data(), stream))
+            return rc;
+        bool progress = false;
+        for (size_t k = 0; k < idx.size(); ++k) {
+            off[idx[k]] += c[k];
+            made[idx[k]] += p[k];
+            if (c[k] != sub_len[k]) stopped[idx[k]] = 1;   // (cannot happen in a bulk call; the rest is not offered again)
+            progress = progress || c[k] != 0;
+        }
+        if (!progress) break;
+    }
+    for (size_t i = 0; i < n; ++i) {
+        if (consumed) consumed[i] = off[i];
+        if (produced) produced[i] = made[i];
+    }
+    return RSMP_OK;
+}
+
+static int batch_bulk_piece(rsmp_fir* const* rs, size_t n, const float* const* d_in, const size_t* in_lens,
+                            size_t chunk_len, float* const* d_out, const size_t* out_caps, size_t* consumed,
+                            size_t* produced, void* stream) {
     for (size_t i = 0; i < n; ++i) {
         if (!rs[i] || rs[i]->device != rs[0]->device)
             return rsmp::fail(RSMP_ERR_INVALID_ARGUMENT, "batch streams must share one device");

@@ -765,3 +765,32 @@ def test_a_bulk_call_longer_than_one_launch():
         d = yg[a:b].astype(np.float64) - yr[a:b]
         assert np.sqrt(np.dot(d, d) / (b - a)) <= RMS_TOL, (a, b)
     assert g.state() == r.state()
+
+
+def test_a_batch_with_one_stream_longer_than_one_launch_and_mixed_rate_pairs():
+    """A bulk batch of three streams: 44.1 -> 48 kHz with 50 M frames (cut into two launches, the others take part in the
+    first only), 48 -> 44.1 kHz and 96 -> 44.1 kHz with 2^20 (three rate pairs: the split kernel's jobs share launches).
+    Counts, samples and states per stream are the reference's."""
+    import torch
+    if not o.have_avx_fma():
+        pytest.skip("needs the oracle's AVX + FMA path (time)")
+    dev = torch.device("cuda:0")
+    specs = [(44100, 48000, 50_000_000), (48000, 44100, 1 << 20), (96000, 44100, 1 << 20)]
+    hs = [ra.ResamplerFir.new_from_hz(2, i, o_, ra.Latency.Sample64, ra.Attenuation.Db90) for i, o_, _ in specs]
+    refs = [o.OracleFir(2, i, o_, 128, 90, o.CONVOLVE_AVX_FMA) for i, o_, _ in specs]
+    xs = [synth.fast_noise(2 * n, seed=50 + k) for k, (_, _, n) in enumerate(specs)]
+    d_in = [torch.from_numpy(x).to(dev) for x in xs]
+    d_out = [torch.empty(h.bulk_output_bound(x.size, 1024), device=dev) for h, x in zip(hs, xs)]
+    b = ra.FirBatch(hs)
+    b.bind(d_in, d_out)
+    consumed, produced = b.resample_bulk_device(1024, ra.torch_stream())
+    torch.cuda.synchronize()
+    for k, (h, r, x) in enumerate(zip(hs, refs, xs)):
+        want, _ = r.resample_all(x, 1024)
+        assert consumed[k] == x.size and produced[k] == want.size, k
+        got = d_out[k][:want.size].cpu().numpy()
+        part = max(1, want.size // 20)
+        for a, e in ((0, part), (want.size - part, want.size), (0, want.size)):
+            d = got[a:e].astype(np.float64) - want[a:e]
+            assert np.sqrt(np.dot(d, d) / (e - a)) <= RMS_TOL, (k, a, e)
+        assert h.state() == r.state(), k
