@@ -100,6 +100,7 @@ extern "C" {
     fn rsmp_fir_lockstep_run_counts(ls: *mut rsmp_fir_lockstep, consumed: *mut usize, produced: *mut usize,
                                     max_steps: usize) -> c_int;
     fn rsmp_fir_lockstep_sync(ls: *mut rsmp_fir_lockstep) -> c_int;
+    fn rsmp_fir_lockstep_table_rebinds(ls: *const rsmp_fir_lockstep, rebinds: *mut usize) -> c_int;
 }
 
 fn device() -> c_int {
@@ -260,6 +261,13 @@ impl LockstepBatch {
         let (mut c, mut p) = (vec![0usize; n * k], vec![0usize; n * k]);
         status(unsafe { rsmp_fir_lockstep_run_counts(self.handle, c.as_mut_ptr(), p.as_mut_ptr(), k) }).expect("run_counts");
         (0..k).map(|s| (0..n).map(|i| (c[s * n + i], p[s * n + i])).collect()).collect()
+    }
+    /// Times the batch replaced a class of streams' coefficient tables because their f64 position drift had moved on
+    /// (diagnostic; the batch watches the drift itself).
+    pub fn table_rebinds(&self) -> usize {
+        let mut v = 0usize;
+        status(unsafe { rsmp_fir_lockstep_table_rebinds(self.handle, &mut v) }).expect("table_rebinds");
+        v
     }
     /// Writes the device state back into the streams and hands them back.
     pub fn into_streams(mut self) -> Vec<ResamplerFir> {

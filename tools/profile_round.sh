@@ -5,6 +5,7 @@
 #   1. bench.py as the driver runs it (headline line incl. cpu_baseline and `secondary`)     -> bench_n1.json
 #      bench.py --path fft / --config c4 / --config c5                                        -> bench_fft.json, bench_c4.json, bench_c5.json
 #      per-call latency of config 5, other channel counts, all 90 FFT rate pairs              -> bench_c5_calls.json, channels_bench.txt, fft_channels_bench.txt, fft_pairs_bench.txt
+#      config 4's run: timelines (tools/kt_timeline.py), phase clocks, 16 steps per launch        -> c4_run_timeline_*.txt, wphase_c4_run_*.txt, bench_c4_k16.json
 #   2. rocprofv3 --kernel-trace --stats of the three commands                                 -> *_kernel_stats.csv
 #   3. separate --pmc passes FETCH_SIZE, WRITE_SIZE per workload (guide's gfx950 correction)  -> traffic_*.json, traffic_latest.json
 #   4. separate --pmc passes: SQ / MFMA / LDS counters per workload                           -> pmc_*.txt
@@ -21,6 +22,8 @@ python3 "$R/bench.py" --steps 20 --warmup 3 > "$SUM/bench_n1.json" 2> "$OUT/benc
 python3 "$R/bench.py" --path fft --steps 20 --warmup 3 > "$SUM/bench_fft.json" 2> "$OUT/bench_fft.err"
 python3 "$R/bench.py" --config c4 --steps 2048 --warmup 256 > "$SUM/bench_c4.json" 2> "$OUT/bench_c4.err"
 python3 "$R/bench.py" --config c4 --c4-k 1 --steps 256 --warmup 16 > "$SUM/bench_c4_k1.json" 2> "$OUT/bench_c4_k1.err"
+python3 "$R/bench.py" --config c4 --c4-k 16 --steps 2048 --warmup 256 > "$SUM/bench_c4_k16.json" 2> "$OUT/bench_c4_k16.err"
+python3 "$R/tools/distinct_probe.py" 64 > "$SUM/distinct_states_probe.txt" 2> "$OUT/distinct_probe.err"
 (cd "$R" && tools/c4_shard_sweep.sh > "$SUM/c4_shard_sweep.txt" 2> "$OUT/c4_shard_sweep.err")
 python3 "$R/bench.py" --config c5 --steps 10 --warmup 2 > "$SUM/bench_c5.json" 2> "$OUT/bench_c5.err"
 # the RCCL exchange on what hardware there is: a world of one rank sending to / receiving from itself
@@ -33,6 +36,18 @@ RSMP_DEBUG=1 RSMP_LS_TRACE="$SUM/ls_trace_raw.txt" python3 "$R/tools/ls_trace.py
 RSMP_DEBUG=1 RSMP_FIR_WTRACE="$OUT/wtrace.txt" python3 "$R/bench.py" --no-cpu --no-secondary --steps 3 --warmup 1 --spinup-seconds 0 > /dev/null 2>&1
 python3 "$R/tools/wphase_report.py" "$OUT/wtrace.txt" 111.5 > "$SUM/wphase_split.txt" 2>/dev/null
 (cd "$R" && tools/c5_trace.sh > /dev/null 2>&1; cp gpurun_out/c5trace/wphase_*.txt "$SUM/" 2>/dev/null)
+# config 4's run: queue / start / duration of the last kernels of a run of 256 and of 16 calls (planned ahead: q of the plan
+# stream next to the caller's), the same without plan-ahead, and the phase clocks of the two-round kernel inside a run
+for k in 256 16; do
+    timeout -k 5 300 rocprofv3 --kernel-trace --output-format csv -d "$OUT/kt_run$k" -- python3 "$R/tools/run_probe.py" 1024 $k > /dev/null 2> "$OUT/kt_run$k.err"
+    python3 "$R/tools/kt_timeline.py" "$(find "$OUT/kt_run$k" -name '*kernel_trace.csv' | head -1)" 30 > "$SUM/c4_run_timeline_k$k.txt" 2>/dev/null
+done
+RSMP_DEBUG=1 RSMP_LS_AHEAD=0 timeout -k 5 300 rocprofv3 --kernel-trace --output-format csv -d "$OUT/kt_run_noahead" -- python3 "$R/tools/run_probe.py" 1024 256 > /dev/null 2> "$OUT/kt_run_noahead.err"
+python3 "$R/tools/kt_timeline.py" "$(find "$OUT/kt_run_noahead" -name '*kernel_trace.csv' | head -1)" 24 > "$SUM/c4_run_timeline_k256_no_plan_ahead.txt" 2>/dev/null
+for k in 256 16; do
+    RSMP_DEBUG=1 RSMP_LS_AHEAD=0 RSMP_FIR_WTRACE="$OUT/w_c4.raw" python3 "$R/tools/run_probe.py" 1024 $k > /dev/null 2>&1
+    python3 "$R/tools/wphase_report.py" "$OUT/w_c4.raw" $([ $k = 256 ] && echo 36 || echo 2.25) > "$SUM/wphase_c4_run_k$k.txt" 2>/dev/null
+done
 
 declare -A CMD
 CMD[fir]="--steps 20 --warmup 3 --no-cpu --no-secondary"
