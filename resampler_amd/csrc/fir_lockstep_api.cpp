@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <future>
 #include <map>
 #include <memory>
 #include <tuple>
@@ -87,6 +88,12 @@ struct rsmp_fir_lockstep {
         bool has_step = false, has_run = false;
         rsmp::PeriodicGeometry step_geo, run_geo;
         rsmp::ClassTable step_table, run_table;
+        // the NEXT tables' host images, built on a thread of their own when the drift has covered most of the way to
+        // the tolerance (0.35-0.7 ms of host arithmetic each: at config 4's 2900x real time six classes cross every
+        // ~100 ms, and built when needed they held the enqueueing thread -- and the GPU behind it -- for 3-6 ms)
+        bool next_pending = false;
+        double next_drift = 0.0;
+        std::future<rsmp::HostClassTable> next_step, next_run;
     };
     std::vector<DriftClass> classes;
     std::vector<rsmp::LsRunStream> h_run_rs;
@@ -122,10 +129,22 @@ double quantized_drift(double d) { return std::round(d / kLsDriftQuantum) * kLsD
 // flush_tables moves them to the device in front of the next launch.
 int rebind_class(rsmp_fir_lockstep* ls, size_t c, double d) {
     rsmp_fir_lockstep::DriftClass& cl = ls->classes[c];
-    const double t = quantized_drift(d);
+    double t = quantized_drift(d);
+    // the tables prepared ahead, if they are for (about) this drift: only their upload is left
+    rsmp::HostClassTable pre_step, pre_run;
+    bool have_pre = false;
+    if (cl.next_pending) {
+        if (cl.next_step.valid()) pre_step = cl.next_step.get();
+        if (cl.next_run.valid()) pre_run = cl.next_run.get();
+        cl.next_pending = false;
+        if (std::fabs(d - cl.next_drift) <= 0.5 * kLsDriftTolerance) {
+            have_pre = true;
+            t = cl.next_drift;
+        }
+    }
     if (cl.has_step) {
         rsmp::ClassTable ct;
-        if (int rc = rsmp::class_table_for(ls->device, *cl.r0->table, cl.step_geo, t, &ct)) return rc;
+        if (int rc = rsmp::class_table_for(ls->device, *cl.r0->table, cl.step_geo, t, &ct, have_pre && !pre_step.coef.empty() ? &pre_step : nullptr)) return rc;
         cl.step_table = ct;
         for (LockstepGroup& g : ls->groups)
             if (g.periodic && g.pad0 == c) {
@@ -136,7 +155,7 @@ int rebind_class(rsmp_fir_lockstep* ls, size_t c, double d) {
     }
     if (cl.has_run && ls->run_state == 1) {
         rsmp::ClassTable ct;
-        if (int rc = rsmp::class_table_for(ls->device, *cl.r0->table, cl.run_geo, t, &ct)) return rc;
+        if (int rc = rsmp::class_table_for(ls->device, *cl.r0->table, cl.run_geo, t, &ct, have_pre && !pre_run.coef.empty() ? &pre_run : nullptr)) return rc;
         cl.run_table = ct;
         for (size_t i = cl.first; i < cl.first + cl.count; ++i) {
             ls->h_run_rs[i].class_coef = ct.d_coef;
@@ -159,9 +178,27 @@ int poll_drift(rsmp_fir_lockstep* ls) {
     }
     ls->drift_inflight = false;
     const double* d = ls->h_drift.as<double>();
-    for (size_t c = 0; c < ls->classes.size(); ++c)
-        if (std::fabs(d[c] - ls->classes[c].table_drift) > kLsDriftTolerance)
+    for (size_t c = 0; c < ls->classes.size(); ++c) {
+        rsmp_fir_lockstep::DriftClass& cl = ls->classes[c];
+        const double off = d[c] - cl.table_drift;
+        if (std::fabs(off) > kLsDriftTolerance) {
             if (int rc = rebind_class(ls, c, d[c])) return rc;
+        } else if (std::fabs(off) > 0.6 * kLsDriftTolerance && !cl.next_pending) {
+            // most of the way: the tables the class will want at the crossing are built now, beside everything else
+            cl.next_drift = quantized_drift(cl.table_drift + (off > 0.0 ? kLsDriftTolerance : -kLsDriftTolerance));
+            const double nd = cl.next_drift;
+            const auto tab = cl.r0->table;   // (shared: outlives the task)
+            if (cl.has_step) {
+                const rsmp::PeriodicGeometry g = cl.step_geo;
+                cl.next_step = std::async(std::launch::async, [tab, g, nd] { return rsmp::build_class_table(*tab, g, nd); });
+            }
+            if (cl.has_run && ls->run_state == 1) {
+                const rsmp::PeriodicGeometry g = cl.run_geo;
+                cl.next_run = std::async(std::launch::async, [tab, g, nd] { return rsmp::build_class_table(*tab, g, nd); });
+            }
+            cl.next_pending = true;
+        }
+    }
     return RSMP_OK;
 }
 
@@ -312,7 +349,7 @@ extern "C" rsmp_fir_lockstep* rsmp_fir_lockstep_new(rsmp_fir* const* rs, size_t 
             cl.step_table = ct;
         }
         const uint32_t class_index = static_cast<uint32_t>(ls->classes.size());
-        ls->classes.push_back(cl);
+        ls->classes.push_back(std::move(cl));
         for (size_t first = k; first < e; first += geo.slots) {
             LockstepGroup g;
             std::memset(&g, 0, sizeof g);

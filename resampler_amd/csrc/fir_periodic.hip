@@ -19,7 +19,9 @@
 // (<= a few hundred KB) stays in L2 / scalar cache.
 #include "fir_periodic.h"
 
+#include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -2038,7 +2040,7 @@ HostClassTable build_class_table(const std::vector<float>& coeffs, const Periodi
 }
 
 int class_table_for(int device, const std::vector<float>& table, const PeriodicGeometry& g, double drift,
-                    ClassTable* out) {
+                    ClassTable* out, const HostClassTable* prebuilt) {
     ClassTableCache& cache = class_cache();
     std::lock_guard<std::mutex> lock(cache.mu);
     uint64_t bits;
@@ -2054,7 +2056,11 @@ int class_table_for(int device, const std::vector<float>& table, const PeriodicG
                 if (e->second.used < lru->second.used) lru = e;
             cache.tables.erase(lru);
         }
-        const HostClassTable host = build_class_table(table, g, drift);
+        const auto tb0 = std::chrono::steady_clock::now();
+        HostClassTable built;
+        if (!prebuilt) built = build_class_table(table, g, drift);   // (0.35-0.7 ms of host arithmetic; `prebuilt`: somebody did it ahead)
+        const HostClassTable& host = prebuilt ? *prebuilt : built;
+        const auto tb1 = std::chrono::steady_clock::now();
         const size_t coef_bytes = host.coef.size() * sizeof(float);
         const size_t wrap_bytes = host.wrap_coef.size() * sizeof(float);
         const size_t meta_bytes = host.meta.size() * sizeof(TileMeta);
@@ -2075,6 +2081,11 @@ int class_table_for(int device, const std::vector<float>& table, const PeriodicG
             gy.dead.emplace_back(device, p);
         });
         it = cache.tables.emplace(key, ClassTableCache::Entry{ct, 0}).first;
+        static const bool verbose = rsmp::knob("RSMP_FIR_VERBOSE") != nullptr;
+        if (verbose)
+            fprintf(stderr, "[rsmp] class table a=%u b=%u drift %.3g: built in %.3f ms on the host, %zu KB allocated and uploaded in %.3f ms\n", g.a, g.b, drift,
+                    std::chrono::duration<double, std::milli>(tb1 - tb0).count(), (coef_bytes + wrap_bytes + meta_bytes) >> 10,
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tb1).count());
     }
     it->second.used = ++cache.tick;
     *out = it->second.ct;

@@ -1653,6 +1653,9 @@ SplitArgs make_split_args(const PeriodicGeometry& geo, uint32_t n_streams, uint3
 }
 // The item-table workspace of (device, stream), at least `need` bytes.  `key` / `items`: see launch_fir_split; *have_table =
 // the workspace already holds the table with that key.
+// Held from taking a stream's item table to the launch that reads it: two host threads that enqueue on one stream would
+// otherwise interleave table launch and kernel launch and read each other's table (enqueueing takes microseconds).
+std::mutex& items_launch_mu() { static std::mutex* m = new std::mutex; return *m; }
 hipError_t items_workspace(int device, hipStream_t stream, size_t need, uint64_t key, uint32_t items, uint32_t** d_items, bool* have_table) {
     std::lock_guard<std::mutex> lock(items_ws_mu());
     ItemsSlot& slot = items_ws()[{device, stream}];
@@ -1757,6 +1760,7 @@ hipError_t launch_fir_split(const FirStreamDesc* d_descs, uint32_t n_streams, co
         (void)hipMemsetAsync(d_wtrace, 0, wtrace_words * 8, stream);
         args.wtrace = d_wtrace;
     }
+    std::unique_lock<std::mutex> launch_lock(items_launch_mu(), std::defer_lock);
     // the item table: a launch of its own in front (one thread per item), in a workspace kept per stream
     {
         // The table is a pure function of the streams' counters and the geometry: a launch whose key (the caller's hash of
@@ -1765,6 +1769,7 @@ hipError_t launch_fir_split(const FirStreamDesc* d_descs, uint32_t n_streams, co
         const size_t need = static_cast<size_t>(args.total_items) * kItemWords * sizeof(uint32_t);
         uint32_t* d_items = nullptr;
         bool have_table = false;
+        launch_lock.lock();
         if ((e = items_workspace(device, stream, need, items_key, args.total_items, &d_items, &have_table)) != hipSuccess) return e;
         args.items = d_items;
         if (!have_table) {
@@ -1834,6 +1839,7 @@ hipError_t launch_fir_split_multi(const SplitJob* jobs, size_t n_jobs, hipStream
         // one item table after the other in the stream's workspace, built by one launch
         uint32_t* d_items = nullptr;
         bool have_table = false;
+        std::lock_guard<std::mutex> launch_lock(items_launch_mu());   // (to the end of this batch of jobs: table launch + kernel launches)
         if ((e = items_workspace(device, stream, total_items * kItemWords * sizeof(uint32_t), 0, 0, &d_items, &have_table)) != hipSuccess) return e;
         {
             SplitMulti m{};
