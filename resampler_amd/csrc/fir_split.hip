@@ -494,9 +494,6 @@ __device__ __forceinline__ void fir_split_body(const FirStreamDesc* __restrict__
     uint32_t* peak = ctrl + 12;     // [slot]: (use + 1) << 8 | biased exponent of the peak so far (monotonic: never reset)
     uint32_t* used = ctrl + 16;     // [slot]: biased exponent the item's scale was derived from (stager 0)
     uint32_t* fin = ctrl + 20;      // [slot][2]: (stream << 4 | pair) + 1 and final peak exponent of the slot's last item (consumer 0)
-#if RSMP_EXP == 7
-    __builtin_amdgcn_s_setprio(3);
-#endif
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     for (uint32_t i = threadIdx.x; i < (g.lds_bytes + (DIAG && g.wtrace ? 16 * kWtraceSlots * 8 : 0)) / 4; i += blockDim.x)
