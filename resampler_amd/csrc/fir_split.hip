@@ -494,6 +494,7 @@ __device__ __forceinline__ void fir_split_body(const FirStreamDesc* __restrict__
     uint32_t* peak = ctrl + 12;     // [slot]: (use + 1) << 8 | biased exponent of the peak so far (monotonic: never reset)
     uint32_t* used = ctrl + 16;     // [slot]: biased exponent the item's scale was derived from (stager 0)
     uint32_t* fin = ctrl + 20;      // [slot][2]: (stream << 4 | pair) + 1 and final peak exponent of the slot's last item (consumer 0)
+    uint32_t* pubd = ctrl + 32;     // [slot]: stagers that have added their share of a PREDICTED item's peak (behind its `staged` count), cumulative
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     for (uint32_t i = threadIdx.x; i < (g.lds_bytes + (DIAG && g.wtrace ? 16 * kWtraceSlots * 8 : 0)) / 4; i += blockDim.x)
@@ -906,6 +907,26 @@ __device__ __forceinline__ void fir_split_body(const FirStreamDesc* __restrict__
                     }
                 };
                 bool signalled = false;   // kShare: the item's `staged` count was given early (below)
+                // One round, two channels: the share of a PREDICTED item's peak is added behind the item's `staged` count --
+                // nobody needs it before the consumers are through with the item (they wait for `pubd`), and the wave
+                // reduction + LDS atomic were ~300 cycles in front of every count.
+                constexpr bool kDeferPeak = ROLE == 0 && ROUNDS == 1 && PLANES == 2;
+                bool peak_deferred = false;
+                float peak_m = 0.f;
+                // the peak of the samples a lane holds (lane_max below), then the wave's, into the item's `peak` word (one atomic)
+                auto publish = [&](float m, uint32_t sl, uint32_t us) {
+                    uint32_t mb = __float_as_uint(m);   // (non-negative floats order like their bit patterns; a NaN is left to the sums)
+                    mb = max(mb, static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(mb), 0x128, 0xf, 0xf, false)));
+                    mb = max(mb, static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(mb), 0x124, 0xf, 0xf, false)));
+                    mb = max(mb, static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(mb), 0x122, 0xf, 0xf, false)));
+                    mb = max(mb, static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(mb), 0x121, 0xf, 0xf, false)));
+                    const uint32_t wm = max(max(static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(mb), 0)),
+                                                static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(mb), 16))),
+                                            max(static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(mb), 32)),
+                                                static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(mb), 48))));
+                    if (lane == 0)
+                        (void)__hip_atomic_fetch_max(peak + sl, ((us + 1) << 8) | (wm >> 23), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                };
                 const bool staged_already = kShare && odd_done;   // (an odd item its even neighbour has staged)
                 if constexpr (kShare) odd_done = false;
                 if constexpr (ROLE != 1) if (have && real_task && !(dbg & 1) && !staged_already) {
@@ -957,19 +978,6 @@ __device__ __forceinline__ void fir_split_body(const FirStreamDesc* __restrict__
                                     if (fr >= fr_lo && fr < fr_hi) m = __builtin_fmaxf(m, __builtin_fabsf(src(i, fr, c)));
                         return m;
                     };
-                    auto publish = [&](float m, uint32_t sl, uint32_t us) {
-                        uint32_t mb = __float_as_uint(m);   // (non-negative floats order like their bit patterns; a NaN is left to the sums)
-                        mb = max(mb, static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(mb), 0x128, 0xf, 0xf, false)));
-                        mb = max(mb, static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(mb), 0x124, 0xf, 0xf, false)));
-                        mb = max(mb, static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(mb), 0x122, 0xf, 0xf, false)));
-                        mb = max(mb, static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(mb), 0x121, 0xf, 0xf, false)));
-                        const uint32_t wm = max(max(static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(mb), 0)),
-                                                    static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(mb), 16))),
-                                                max(static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(mb), 32)),
-                                                    static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(mb), 48))));
-                        if (lane == 0)
-                            (void)__hip_atomic_fetch_max(peak + sl, ((us + 1) << 8) | (wm >> 23), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    };
                     // what a slot's previous item (`slots` items back) turned out to peak at: into the running table
                     auto note_fin = [&](uint32_t f_id, uint32_t f_e) {
                         if (f_id != 0) {
@@ -1011,9 +1019,15 @@ __device__ __forceinline__ void fir_split_body(const FirStreamDesc* __restrict__
                     constexpr bool kLatePeak = ROUNDS == 2;   // (one round: the item's whole peak is known here)
                     if constexpr (PLANES == 2) {
                         note_fin(__builtin_amdgcn_readfirstlane(f_id_v), __builtin_amdgcn_readfirstlane(f_e_v));
-                        m_own = lane_max(at, 0.f);
+                        m_own = lane_max(at, 0.f);   // (here: keeping the samples alive behind the count as well cost 11 %)
                         const uint32_t eh = hist_of(cpair);
-                        if (!kLatePeak || eh == 0 || !real_rd[ROUNDS - 1]) publish(m_own, slot, use);
+                        if (kDeferPeak && eh != 0) {
+                            peak_deferred = true;
+                            peak_m = m_own;
+                        } else if (!kLatePeak || eh == 0 || !real_rd[ROUNDS - 1]) {
+                            publish(m_own, slot, use);
+                            if constexpr (kDeferPeak) lds_signal(pubd + slot);
+                        }
                         xs = scale_for(eh, slot);
                     }
                     wt.event(9);
@@ -1165,6 +1179,12 @@ __device__ __forceinline__ void fir_split_body(const FirStreamDesc* __restrict__
                 if (have) {
                     wt.event(4);
                     if (!signalled) lds_signal(staged + slot);
+                    if constexpr (kDeferPeak) {
+                        if (peak_deferred) {
+                            publish(peak_m, slot, use);
+                            lds_signal(pubd + slot);
+                        }
+                    }
                     wt.event(14);
                     if (++slot == g.slots) {
                         slot = 0;
@@ -1361,6 +1381,11 @@ __device__ __forceinline__ void fir_split_body(const FirStreamDesc* __restrict__
         }
         bool item_bad = false;   // (wave-uniform) the item's scale was off: its outputs are redone by the repair launch
         if constexpr (PLANES == 2) {
+            if constexpr (WIDE == 0 && ROUNDS == 1) {   // the stagers' shares of the peak: all in (added behind `staged`; long since)
+                const uint32_t half_a_c = (g.a + 1) / 2, tasks_c = 4 * half_a_c;
+                const uint32_t n_real_c = (tasks_c + 63) / 64 < kStagers ? (tasks_c + 63) / 64 : kStagers;
+                while (lds_load_acquire(pubd + slot) < n_real_c * (use + 1)) __builtin_amdgcn_s_sleep(RSMP_POLL_SLEEP);
+            }
             const uint32_t e_used = __builtin_amdgcn_readfirstlane(__hip_atomic_load(used + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
             const uint32_t e_act = __builtin_amdgcn_readfirstlane(__hip_atomic_load(peak + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) & 255u;
             item_bad = e_act != 0 && e_act + kPeakQuiet < e_used;
