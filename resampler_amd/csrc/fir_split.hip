@@ -910,8 +910,8 @@ __device__ __forceinline__ void fir_split_body(const FirStreamDesc* __restrict__
                 // One round, two channels: the share of a PREDICTED item's peak is added behind the item's `staged` count --
                 // nobody needs it before the consumers are through with the item (they wait for `pubd`), and the wave
                 // reduction + LDS atomic were ~300 cycles in front of every count.
-                constexpr bool kDeferPeak = (ROLE == 0 || ROLE == 3) && WIDE == 0 && PLANES == 2;   // (two channels, one or two rounds)
-                bool peak_deferred = false, staged_here = false;
+                constexpr bool kDeferPeak = ROLE == 0 && ROUNDS == 1 && PLANES == 2;
+                bool peak_deferred = false;
                 float peak_m = 0.f;
                 // the peak of the samples a lane holds (lane_max below), then the wave's, into the item's `peak` word (one atomic)
                 auto publish = [&](float m, uint32_t sl, uint32_t us) {
@@ -1021,12 +1021,12 @@ __device__ __forceinline__ void fir_split_body(const FirStreamDesc* __restrict__
                         note_fin(__builtin_amdgcn_readfirstlane(f_id_v), __builtin_amdgcn_readfirstlane(f_e_v));
                         m_own = lane_max(at, 0.f);   // (here: keeping the samples alive behind the count as well cost 11 %)
                         const uint32_t eh = hist_of(cpair);
-                        staged_here = true;
                         if (kDeferPeak && eh != 0) {
-                            peak_deferred = true;   // (two rounds: round 1's samples join below)
+                            peak_deferred = true;
                             peak_m = m_own;
                         } else if (!kLatePeak || eh == 0 || !real_rd[ROUNDS - 1]) {
                             publish(m_own, slot, use);
+                            if constexpr (kDeferPeak) lds_signal(pubd + slot);
                         }
                         xs = scale_for(eh, slot);
                     }
@@ -1123,11 +1123,7 @@ __device__ __forceinline__ void fir_split_body(const FirStreamDesc* __restrict__
                                 fetch_edge_round(1);
                             }
                             wt.event(3);
-                            if constexpr (PLANES == 2) {
-                                const float mm = lane_max(at, m_own);
-                                if (kDeferPeak && peak_deferred) peak_m = mm;
-                                else publish(mm, slot, use);
-                            }
+                            if constexpr (PLANES == 2) publish(lane_max(at, m_own), slot, use);
                             store_task(img, at, 1, xs);
                         }
                     } else {
@@ -1184,8 +1180,8 @@ __device__ __forceinline__ void fir_split_body(const FirStreamDesc* __restrict__
                     wt.event(4);
                     if (!signalled) lds_signal(staged + slot);
                     if constexpr (kDeferPeak) {
-                        if (staged_here) {   // one count per stager and item, behind every share it has added
-                            if (peak_deferred) publish(peak_m, slot, use);
+                        if (peak_deferred) {
+                            publish(peak_m, slot, use);
                             lds_signal(pubd + slot);
                         }
                     }
@@ -1385,7 +1381,7 @@ __device__ __forceinline__ void fir_split_body(const FirStreamDesc* __restrict__
         }
         bool item_bad = false;   // (wave-uniform) the item's scale was off: its outputs are redone by the repair launch
         if constexpr (PLANES == 2) {
-            if constexpr (WIDE == 0) if (!(dbg & 1)) {   // the stagers' shares of the peak: all in (added behind `staged`; long since)
+            if constexpr (WIDE == 0 && ROUNDS == 1) {   // the stagers' shares of the peak: all in (added behind `staged`; long since)
                 const uint32_t half_a_c = (g.a + 1) / 2, tasks_c = 4 * half_a_c;
                 const uint32_t n_real_c = (tasks_c + 63) / 64 < kStagers ? (tasks_c + 63) / 64 : kStagers;
                 while (lds_load_acquire(pubd + slot) < n_real_c * (use + 1)) __builtin_amdgcn_s_sleep(RSMP_POLL_SLEEP);
