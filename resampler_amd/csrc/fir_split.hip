@@ -1381,7 +1381,7 @@ __device__ __forceinline__ void fir_split_body(const FirStreamDesc* __restrict__
         }
         bool item_bad = false;   // (wave-uniform) the item's scale was off: its outputs are redone by the repair launch
         if constexpr (PLANES == 2) {
-            if constexpr (WIDE == 0 && ROUNDS == 1) {   // the stagers' shares of the peak: all in (added behind `staged`; long since)
+            if constexpr (WIDE == 0 && ROUNDS == 1) if (!(dbg & 1)) {   // the stagers' shares of the peak: all in (added behind `staged`; long since).  (dbg & 1: the timing experiment without staging adds none)
                 const uint32_t half_a_c = (g.a + 1) / 2, tasks_c = 4 * half_a_c;
                 const uint32_t n_real_c = (tasks_c + 63) / 64 < kStagers ? (tasks_c + 63) / 64 : kStagers;
                 while (lds_load_acquire(pubd + slot) < n_real_c * (use + 1)) __builtin_amdgcn_s_sleep(RSMP_POLL_SLEEP);
