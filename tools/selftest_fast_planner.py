@@ -3,9 +3,11 @@ machine on the host (rsmp_fir_plan_selftest_fast): all ordered pairs of twelve r
 run length) shapes; prints the calls compared, the mismatches (must be 0) and the share of calls the fast path declined."""
 import ctypes as C
 import itertools
+import os
 import sys
 import time
 
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import resampler_amd as ra
 
 
