@@ -3,8 +3,9 @@
 // calls of a whole run become ONE launch of the bulk kernels per rate pair instead of k launches of the
 // one-call-per-stream kernel.
 //
-// One lane per stream replays the reference's control flow for the k calls (fir_mirror_core.h: the f64 position
-// recurrence in closed form) and leaves, in HBM,
+// Three kernels plan the k calls of every stream (fir_mirror_fast.h): K1 the structure of every call in exact integer
+// arithmetic (one thread per stream and call), K2 the serial f64 position chain (one wave per stream), K3 the outputs at
+// integer positions by a replay of every call in parallel.  They leave, in HBM,
 //   * the per-call (consumed, produced) counts of every stream: [k][n] pairs;
 //   * the run's stream descriptor (FirStreamDesc, fir_kernels.h) exactly as the host planner of the bulk entry
 //     points (fir_api.cpp, launch_jobs) would have built it: outputs / frames accepted / frames retired by the
