@@ -553,16 +553,21 @@ def bench_c4(ctx: Ctx, args, steps: int, warmup: int):
     spinup(ctx, step, args.spinup_seconds)
     launches, warm_launches = max(1, steps // kk), max(1, warmup // kk) if warmup else 0
     steps = launches * kk
+    st0 = ls.stats() if ls else {}
     dt, host_dt = timed(ctx, step, launches, warm_launches)
-    k_ms = 0.0
+    st1 = ls.stats() if ls else {}
+    k_ms = k_med = k_max = 0.0
     out_values = 0
     if ls:
+        # device time of every launch of a second pass (HIP events on the launch stream, no host sync between the
+        # launches): mean -> roofline, median and max beside it (one slow launch moves a mean of few)
+        n_prof = min(256, max(launches, 2, 32 // kk))
         ls.set_profiling(True)
-        for _ in range(max(2, 32 // kk)):
+        for _ in range(n_prof):
             step()
-        k_ms, _ = ls.mean_kernel_ms()
-        k_ms /= kk                         # per 512-frame step
+        per_launch = ls.kernel_ms(n_prof) / kk     # per 512-frame step
         ls.set_profiling(False)
+        k_ms, k_med, k_max = float(per_launch.mean()), float(np.median(per_launch)), float(per_launch.max())
         if kk > 1:
             _, prod = ls.run_counts()
             out_values = int(prod.sum()) // kk
@@ -576,7 +581,8 @@ def bench_c4(ctx: Ctx, args, steps: int, warmup: int):
     alg = 4.0 * (values_in + out_values_all)
     ach = alg / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
     return {
-        "metric": "Msamples/s (in) config 4: 1024 mixed-rate FIR streams, 512-frame lock-step steps",
+        "metric": "Msamples/s (in) config 4: 1024 mixed-rate FIR streams, 512-frame lock-step steps"
+                  + (f", {kk} steps per launch" if kk > 1 else ", one step per launch"),
         "value": round(values_in * steps / dt / 1e6, 1), "unit": "Msamples/s", "n_gpus": ctx.world,
         "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 5),
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
@@ -593,13 +599,23 @@ def bench_c4(ctx: Ctx, args, steps: int, warmup: int):
                    "feed": ("rccl send/recv scatter-v + gather-v through GPU 0, inside the timed step"
                             + (" (world of one rank: GPU 0 sends to and receives from itself)" if ctx.world == 1 else ""))
                            if feed else "resident per GPU (no data-path collective)",
-                   "host_enqueue_ms_per_step": round(host_dt / steps * 1e3, 5)},
+                   "host_enqueue_ms_per_step": round(host_dt / steps * 1e3, 5),
+                   "launches_timed": launches, "timed_region_ms": round(dt * 1e3, 2),
+                   # what the batch did inside the timed region (rsmp_fir_lockstep_stats): class tables replaced because the
+                   # streams' f64 drift had moved on, runs whose plan was made ahead on the plan stream
+                   "table_rebinds_timed": st1.get("table_rebinds", 0) - st0.get("table_rebinds", 0),
+                   "plan_ahead_hits_timed": st1.get("plan_ahead_hits", 0) - st0.get("plan_ahead_hits", 0),
+                   "table_waits_total": st1.get("table_waits", 0), "late_table_polls_total": st1.get("late_table_polls", 0)},
         "roofline": {"bound": "hbm", "kernel": ("fir_lockstep_kernel (%s, row = stream)" %
                                ("fp16x2 MFMA" if ls and ls.split_workgroups() else "exact-f32 MFMA")) if kk == 1 else
                                "fir_lockstep_plan_kernel + fir_split_kernel per rate pair (whole run, per 512-frame step)",
                      "achieved": round(ach, 1), "peak": HBM_PEAK_GBS * ctx.world, "unit": "GB/s",
                      "frac": round(ach / (HBM_PEAK_GBS * ctx.world), 4), "traffic": traffic_from_profiles("c4"),
-                     "kernel_ms": round(k_ms, 5), "algorithmic_bytes": int(alg)},
+                     "kernel_ms": round(k_ms, 5), "kernel_ms_median": round(k_med, 5), "kernel_ms_max": round(k_max, 5),
+                     "kernel_ms_covers": ("the step kernel" if kk == 1 else
+                                          "the caller's stream from the run's first launch to its last, per 512-frame step "
+                                          "(the planner of a run planned ahead ran on the plan stream beside the run before)"),
+                     "algorithmic_bytes": int(alg)},
     }
 
 
@@ -745,7 +761,7 @@ def secondary_lines(ctx: Ctx, args):
         "step_ms_cold": round(cold, 2), "step_ms_replanned_median": round(sorted(again)[len(again) // 2], 2),
         "kernel_ms_replanned": round(k_again, 3), "setup_s": round(t1 - t0, 2)}
     del batch, handles
-    c4 = bench_c4(ctx, args, steps=256 * 8, warmup=256)   # (eight launches of the configuration's 256 steps)
+    c4 = bench_c4(ctx, args, steps=256 * 64, warmup=256 * 2)   # (64 launches of the configuration's 256 steps: ~60 ms)
     sec["config4"] = {k: c4[k] for k in ("metric", "value", "unit", "ms_per_step", "scaling", "dtype", "config", "roofline")}
     c5 = bench_c5(ctx, args, steps=10, warmup=2)
     sec["config5"] = {k: c5[k] for k in ("metric", "value", "unit", "ms_per_step", "scaling", "dtype", "config", "roofline")}
@@ -834,7 +850,8 @@ def bench_c5(ctx: Ctx, args, steps: int, warmup: int):
         "metric": "Msamples/s (in) config 5: one 8-channel 96k->44.1k FIR stream, time-sharded",
         "value": round(values_in * steps / dt / 1e6, 1), "unit": "Msamples/s", "n_gpus": ctx.world,
         "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 4),
-        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": FIR_DTYPE.get(h.kernel_variant(), "f32"),
+        "data": "synthetic",
         "config": {"workload": f"ResamplerFir 8ch 96000->44100 128-tap (Sample64/Db120), {frames} input frames in "
                                f"{chunk}-frame calls, cut into {ctx.world} run(s) of calls at the host mirror's exact "
                                f"state, each run one seek + one bulk launch on its GPU",

@@ -101,6 +101,8 @@ extern "C" {
                                     max_steps: usize) -> c_int;
     fn rsmp_fir_lockstep_sync(ls: *mut rsmp_fir_lockstep) -> c_int;
     fn rsmp_fir_lockstep_table_rebinds(ls: *const rsmp_fir_lockstep, rebinds: *mut usize) -> c_int;
+    fn rsmp_fir_lockstep_stats(ls: *const rsmp_fir_lockstep, out: *mut u64, n: usize) -> c_int;
+    fn rsmp_fir_lockstep_set_drift_policy(ls: *mut rsmp_fir_lockstep, tolerance_frames: f64, check_frames: usize) -> c_int;
 }
 
 fn device() -> c_int {
@@ -241,7 +243,7 @@ impl LockstepBatch {
         status(rsmp_fir_lockstep_bind(self.handle, d_in.as_ptr(), d_out.as_ptr(), out_caps.as_ptr()))
     }
     pub fn step(&mut self, in_frames: usize, in_offset_frames: usize, append: bool) -> Result<(), ResampleError> {
-        self.last_run = 1;
+        self.last_run = 0;   // (a step is not a run: run_counts() has nothing to report, counts() has the step's)
         status(unsafe { rsmp_fir_lockstep_step(self.handle, in_frames, in_offset_frames, std::ptr::null(), append as c_int, std::ptr::null_mut()) })
     }
     pub fn run(&mut self, k_steps: usize, in_frames: usize, in_offset_frames: usize, append: bool) -> Result<(), ResampleError> {
@@ -258,6 +260,7 @@ impl LockstepBatch {
     /// ... of every call of the last run: `[call][stream]`.
     pub fn run_counts(&mut self) -> Vec<Vec<(usize, usize)>> {
         let (n, k) = (self.streams.len(), self.last_run);
+        if k == 0 { return Vec::new(); }   // no run yet, or a step since (the C side answers that with an error)
         let (mut c, mut p) = (vec![0usize; n * k], vec![0usize; n * k]);
         status(unsafe { rsmp_fir_lockstep_run_counts(self.handle, c.as_mut_ptr(), p.as_mut_ptr(), k) }).expect("run_counts");
         (0..k).map(|s| (0..n).map(|i| (c[s * n + i], p[s * n + i])).collect()).collect()
@@ -268,6 +271,18 @@ impl LockstepBatch {
         let mut v = 0usize;
         status(unsafe { rsmp_fir_lockstep_table_rebinds(self.handle, &mut v) }).expect("table_rebinds");
         v
+    }
+    /// Diagnostic counters (include/resampler_amd.h, rsmp_fir_lockstep_stats): table rebinds, runs taken over from the
+    /// plan stream, runs planned ahead and dropped, late table polls, waits for the table worker, plan-stream probes,
+    /// whether the last run's stream has a plan stream, drift classes.
+    pub fn stats(&self) -> [u64; 8] {
+        let mut v = [0u64; 8];
+        status(unsafe { rsmp_fir_lockstep_stats(self.handle, v.as_mut_ptr(), v.len()) }).expect("stats");
+        v
+    }
+    /// How closely the coefficient tables follow the streams' f64 drift (default 1.2e-7 of a frame, looked at every 2^19 frames).
+    pub fn set_drift_policy(&mut self, tolerance_frames: f64, check_frames: usize) -> Result<(), ResampleError> {
+        status(unsafe { rsmp_fir_lockstep_set_drift_policy(self.handle, tolerance_frames, check_frames) })
     }
     /// Writes the device state back into the streams and hands them back.
     pub fn into_streams(mut self) -> Vec<ResamplerFir> {

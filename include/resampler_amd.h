@@ -208,6 +208,19 @@ int rsmp_fir_lockstep_run_slow_calls(rsmp_fir_lockstep* ls, size_t* slow_calls);
  * its tables were mixed for.  The batch watches the drifts itself (an asynchronous read-back every 2^19 frames per
  * stream); nothing for the caller to do. */
 int rsmp_fir_lockstep_table_rebinds(const rsmp_fir_lockstep* ls, size_t* rebinds);
+/* Diagnostic counters of a batch, out[0 .. n): [0] table rebinds (as above), [1] runs taken over from the plan stream
+ * (planned while the run before them computed), [2] runs planned ahead and dropped (the caller did something else),
+ * [3] looks at the drifts that found a class past its tolerance with its next tables still on their way (the old ones
+ * serve until the next look; a replacement is prepared by a worker thread, never inside a launch call), [4] times a
+ * launch call WAITED for that worker (a class three tolerances past its tables: never observed), [5] probes of which
+ * plan stream runs beside a caller's stream, [6] 1 if the last run's stream has a plan stream, [7] drift classes. */
+#define RSMP_LS_STAT_COUNT 8
+int rsmp_fir_lockstep_stats(const rsmp_fir_lockstep* ls, uint64_t* out, size_t n);
+/* How closely the class tables follow the streams' drift: a class gets new tables when its drift is more than
+ * `tolerance_frames` (default 1.2e-7: at worst 2e-7 of a full-scale sample, a fifth of the 1e-6 bound; 2e-8 .. 1e-6) from
+ * what its tables were mixed for; the drifts are read back every `check_frames` input frames per stream (default 2^19).
+ * Tighter = closer to the reference's phase rows, more replacements (each is prepared off the launch path). */
+int rsmp_fir_lockstep_set_drift_policy(rsmp_fir_lockstep* ls, double tolerance_frames, size_t check_frames);
 /* Sticky per-stream flags: 1 = more position runs in one step than the kernel keeps (outputs of that step
  * undefined; never observed), 2 = a step saw non-finite samples and was evaluated in the reference's
  * two-row form, 4 = the f64 position drifted out of the class tables' tolerance (reference form from then on),
@@ -220,6 +233,8 @@ int rsmp_fir_lockstep_sync(rsmp_fir_lockstep* ls);
  * around every step while enabled; the mean covers the (up to 64) most recent steps. */
 int rsmp_fir_lockstep_set_profiling(rsmp_fir_lockstep* ls, int enable);
 int rsmp_fir_lockstep_mean_kernel_ms(rsmp_fir_lockstep* ls, float* ms, size_t* launches);
+/* ... and each of the last min(cap, 256) profiled launches' device time, oldest first (median / max of a bench) */
+int rsmp_fir_lockstep_kernel_ms(rsmp_fir_lockstep* ls, float* ms, size_t cap, size_t* launches);
 int rsmp_fir_lockstep_reset(rsmp_fir_lockstep* ls);   /* reset() of every stream (resampler_fir.rs:638-642) */
 
 /* ---- host-only: filter design and the (consumed, produced) state machine ----------------------- */

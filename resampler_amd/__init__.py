@@ -146,6 +146,9 @@ _SIGNATURES = [
     ("rsmp_fir_lockstep_reset", C.c_int, [C.c_void_p]),
     ("rsmp_fir_lockstep_set_profiling", C.c_int, [C.c_void_p, C.c_int]),
     ("rsmp_fir_lockstep_mean_kernel_ms", C.c_int, [C.c_void_p, C.POINTER(C.c_float), _szp]),
+    ("rsmp_fir_lockstep_kernel_ms", C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_size_t, _szp]),
+    ("rsmp_fir_lockstep_stats", C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_size_t]),
+    ("rsmp_fir_lockstep_set_drift_policy", C.c_int, [C.c_void_p, C.c_double, C.c_size_t]),
     ("rsmp_design_fir_coeffs", C.c_int, [C.c_uint32, C.c_uint32, C.c_int, C.c_int, _f32p, C.c_size_t]),
     ("rsmp_design_cutoff_kaiser", C.c_double, [C.c_size_t, C.c_double]),
     ("rsmp_fir_plan_new", C.c_void_p, [C.c_uint32, C.c_uint32, C.c_int]),
@@ -477,6 +480,7 @@ class FirLockstep:
         self._out_caps = (C.c_size_t * n)()
         self._consumed = (C.c_size_t * n)()
         self._produced = (C.c_size_t * n)()
+        self._last_run = 0
 
     def close(self) -> None:
         if getattr(self, "_h", None):
@@ -521,6 +525,7 @@ class FirLockstep:
             ptr = C.c_void_p(d_in_frames.data_ptr())
         _check(lib().rsmp_fir_lockstep_step(self._h, in_frames, in_offset_frames, ptr, 1 if append else 0,
                                             C.c_void_p(stream or 0)))
+        self._last_run = 0
 
     def run(self, k_steps: int, in_frames: int, in_offset_frames: int = 0, append: bool = True,
             stream: Optional[int] = None) -> None:
@@ -533,6 +538,8 @@ class FirLockstep:
     def run_counts(self):
         """(consumed, produced) of every call of the last run: two int64 arrays [k_steps][streams], in f32 values."""
         k, n = self._last_run, len(self.resamplers)
+        if k == 0:   # (no run yet, or a step since: nothing to report -- the C side says the same with an error)
+            return np.zeros((0, n), np.int64), np.zeros((0, n), np.int64)
         cons, prod = (C.c_size_t * (k * n))(), (C.c_size_t * (k * n))()
         _check(lib().rsmp_fir_lockstep_run_counts(self._h, cons, prod, k))
         return (np.ctypeslib.as_array(cons).astype(np.int64).reshape(k, n),
@@ -543,6 +550,25 @@ class FirLockstep:
         v = C.c_size_t()
         _check(lib().rsmp_fir_lockstep_table_rebinds(self._h, C.byref(v)))
         return v.value
+
+    STAT_NAMES = ("table_rebinds", "plan_ahead_hits", "plan_ahead_misses", "late_table_polls", "table_waits",
+                  "plan_stream_probes", "has_plan_stream", "drift_classes")
+
+    def stats(self) -> dict:
+        """Diagnostic counters of the batch (rsmp_fir_lockstep_stats)."""
+        v = (C.c_uint64 * len(self.STAT_NAMES))()
+        _check(lib().rsmp_fir_lockstep_stats(self._h, v, len(self.STAT_NAMES)))
+        return {k: int(x) for k, x in zip(self.STAT_NAMES, v)}
+
+    def set_drift_policy(self, tolerance_frames: float, check_frames: int) -> None:
+        """How closely the class tables follow the streams' f64 drift (rsmp_fir_lockstep_set_drift_policy)."""
+        _check(lib().rsmp_fir_lockstep_set_drift_policy(self._h, tolerance_frames, check_frames))
+
+    def kernel_ms(self, max_launches: int = 256) -> np.ndarray:
+        """Device time of each of the last profiled launches (steps or runs), oldest first, in ms."""
+        ms, n = (C.c_float * max_launches)(), C.c_size_t()
+        _check(lib().rsmp_fir_lockstep_kernel_ms(self._h, ms, max_launches, C.byref(n)))
+        return np.ctypeslib.as_array(ms)[:n.value].astype(np.float64).copy()
 
     def run_slow_calls(self) -> int:
         """Calls of the last run that the device planner's fast path declined (diagnostic)."""

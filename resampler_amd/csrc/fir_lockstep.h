@@ -172,9 +172,30 @@ hipError_t launch_fir_lockstep_plan(const LsRunArgs& args, hipStream_t stream);
 // out[c] = states[reps[c]].drift: the drifts the batch's classes are watched by (one thread per class).
 hipError_t launch_fir_lockstep_gather_drift(const FirMirrorState* states, const uint32_t* reps, double* out, uint32_t n,
                                             hipStream_t stream);
-// One wave that sleeps until `ticks` of the 100 MHz clock have passed (0: returns at once): what the batch tries out with
-// whether two streams run side by side (pick_plan_stream).
-hipError_t launch_fir_lockstep_idle(uint32_t ticks, hipStream_t stream);
+// Do two streams run side by side?  (HIP deals a handful of hardware queues to its streams in turn; two streams on one
+// queue run their kernels strictly one after the other.)  `wait` goes to the one stream: a single wave that polls *flag
+// until it reads `token` or `timeout_ticks` of the 100 MHz clock have passed, and stores 1 / 0 to *result (mapped host
+// memory).  `set` goes to the other stream and stores `token` to *flag.  On one queue `set` cannot start before `wait`
+// has given up: the result is decided by the DEVICE, whatever the host's threads are doing meanwhile (round 4 timed the
+// pair with the host's clock against a 200 us threshold, which a busy host fails both ways).
+hipError_t launch_fir_lockstep_probe_wait(uint32_t* flag, uint32_t token, uint32_t timeout_ticks, uint32_t* result, hipStream_t stream);
+hipError_t launch_fir_lockstep_probe_set(uint32_t* flag, uint32_t token, hipStream_t stream);
+// New class tables for up to kLsMaxPatches drift classes, written into the device copies of the group table (step
+// kernel: the groups whose `pad0` names the class) and the run planner's stream table (streams [first, first + count))
+// by ONE small kernel in stream order -- no copy-engine operation, no staging buffer to wait for.
+constexpr uint32_t kLsMaxPatches = 8;
+struct LsTablePatch {
+    uint32_t cls, first, count, flags;     // flags: 1 = step table, 2 = run table
+    const float* step_coef; const TileMeta* step_meta;
+    const float* run_coef; const float* run_wrap_coef; const TileMeta* run_meta;
+    double drift;
+};
+struct LsPatchArgs {
+    LockstepGroup* groups; LsRunStream* rs;   // (rs: null before the batch's first run)
+    uint32_t n_groups, n_streams, n_patches, pad;
+    LsTablePatch p[kLsMaxPatches];
+};
+hipError_t launch_fir_lockstep_patch_tables(const LsPatchArgs& args, hipStream_t stream);
 // A run planned ahead (on a stream of its own, while the previous run computes) left its results in scratch copies:
 // states, append positions, the last call's counts, status flags -> the batch's own, when the run is really asked for.
 struct LsCommitArgs {

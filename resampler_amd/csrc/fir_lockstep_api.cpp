@@ -10,7 +10,6 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
-#include <future>
 #include <map>
 #include <memory>
 #include <tuple>
@@ -20,6 +19,7 @@
 #include "device_util.h"
 #include "fir_handle.h"
 #include "fir_lockstep.h"
+#include "fir_table_refresher.h"
 
 using rsmp::DeviceBuffer;
 using rsmp::DeviceGuard;
@@ -62,7 +62,15 @@ struct rsmp_fir_lockstep {
     DeviceBuffer sp_states, sp_cursor, sp_last, sp_status;
     hipStream_t plan_stream = nullptr;   // the candidate picked for the caller's stream of the last run (pick_plan_stream)
     hipStream_t plan_candidates[2] = {nullptr, nullptr};
-    std::map<hipStream_t, int> plan_pick;   // caller's stream -> candidate that runs beside it (-1: none does)
+    // caller's stream -> the candidate that runs beside it, found out by a probe that the DEVICE decides and the host
+    // never waits for (launch_fir_lockstep_probe_wait): until it is known, runs on that stream are not planned ahead
+    struct PlanPick { int pick = -1; bool decided = false, probing = false; int cand = 0, tries = 0; };
+    std::map<hipStream_t, PlanPick> plan_pick;
+    DeviceBuffer d_probe;                // the probes' flag word
+    rsmp::PinnedBuffer h_probe;          // ... and their result
+    hipEvent_t probe_ev = nullptr;
+    hipStream_t probe_owner = nullptr;   // the caller's stream whose probe is in flight (one at a time)
+    uint32_t probe_token = 0;
     hipEvent_t ev_ready = nullptr, plan_done = nullptr;
     struct RunKey { uint32_t k = 0, in_frames = 0, append = 0, parity = 0; uint64_t in_offset = 0, seq = 0; int slot = 0; bool valid = false; };
     RunKey ahead;               // what the plan stream was asked to plan
@@ -88,14 +96,27 @@ struct rsmp_fir_lockstep {
         bool has_step = false, has_run = false;
         rsmp::PeriodicGeometry step_geo, run_geo;
         rsmp::ClassTable step_table, run_table;
-        // the NEXT tables' host images, built on a thread of their own when the drift has covered most of the way to
-        // the tolerance (0.35-0.7 ms of host arithmetic each: at config 4's 2900x real time six classes cross every
-        // ~100 ms, and built when needed they held the enqueueing thread -- and the GPU behind it -- for 3-6 ms)
-        bool next_pending = false;
+        // Tables of the process-wide cache this class has bound (creation, reset: the host knows the states and may
+        // wait) stay held until nothing enqueued or planned ahead can read them (bind / reset, behind their waits) --
+        // the cache is bounded, and a table it has evicted lives by its holders alone.
+        std::vector<std::shared_ptr<void>> holds;
+        // The NEXT tables: owned double-buffered device images that the batch's worker thread fills when the drift has
+        // covered most of the way to the tolerance (TableRefresher: host arithmetic, allocation, upload and the wait
+        // for it all happen there); the crossing swaps pointers.
+        rsmp::TableRefresher::Table* step_next = nullptr;
+        rsmp::TableRefresher::Table* run_next = nullptr;
+        bool next_pending = false;        // a request is out (or its result is waiting to be taken)
         double next_drift = 0.0;
-        std::future<rsmp::HostClassTable> next_step, next_run;
+        double seen_drift = 0.0;          // the class's drift as last read back
+        bool late = false;                // past the tolerance, the next tables not there yet
     };
     std::vector<DriftClass> classes;
+    std::unique_ptr<rsmp::TableRefresher> refresher;
+    double drift_tolerance = 0.0;         // (set at creation: kLsDriftTolerance; rsmp_fir_lockstep_set_drift_policy)
+    uint64_t drift_check_frames = 0;
+    size_t n_late = 0;                    // classes currently `late`
+    // diagnostics (rsmp_fir_lockstep_stats)
+    uint64_t stat_ahead_hits = 0, stat_ahead_misses = 0, stat_late_polls = 0, stat_table_waits = 0, stat_probes = 0;
     std::vector<rsmp::LsRunStream> h_run_rs;
     DeviceBuffer d_drift_reps;
     rsmp::PinnedBuffer h_drift, h_stage;            // the drifts read back; staging of the group / stream tables when they change
@@ -104,7 +125,7 @@ struct rsmp_fir_lockstep {
     uint64_t frames_since_drift = 0;
     size_t table_rebinds = 0;                 // times a class got new tables (diagnostic)
     // optional timing of the step launches (rsmp_fir_lockstep_set_profiling): ring of event pairs
-    static constexpr int kProfRing = 64;
+    static constexpr int kProfRing = 256;
     bool profiling = false;
     hipEvent_t prof_start[kProfRing] = {}, prof_stop[kProfRing] = {};
     size_t prof_count = 0;
@@ -125,85 +146,154 @@ constexpr uint64_t kLsDriftCheckFrames = 1u << 19;   // input frames per stream 
 
 double quantized_drift(double d) { return std::round(d / kLsDriftQuantum) * kLsDriftQuantum; }
 
-// New tables for class `c`, built for drift `d`: the host copies of the group and stream tables are changed and marked;
-// flush_tables moves them to the device in front of the next launch.
-int rebind_class(rsmp_fir_lockstep* ls, size_t c, double d) {
+// Class `c` takes `step` / `run` as its tables (either may be null: not replaced), built for drift `t`: the host copies
+// of the group and stream tables are changed; the caller moves them to the device (flush_tables, or a patch kernel).
+void bind_class_tables(rsmp_fir_lockstep* ls, size_t c, const rsmp::ClassTable* step, const rsmp::ClassTable* run, double t) {
     rsmp_fir_lockstep::DriftClass& cl = ls->classes[c];
-    double t = quantized_drift(d);
-    // the tables prepared ahead, if they are for (about) this drift: only their upload is left
-    rsmp::HostClassTable pre_step, pre_run;
-    bool have_pre = false;
-    if (cl.next_pending) {
-        if (cl.next_step.valid()) pre_step = cl.next_step.get();
-        if (cl.next_run.valid()) pre_run = cl.next_run.get();
-        cl.next_pending = false;
-        if (std::fabs(d - cl.next_drift) <= 0.5 * kLsDriftTolerance) {
-            have_pre = true;
-            t = cl.next_drift;
-        }
-    }
-    if (cl.has_step) {
-        rsmp::ClassTable ct;
-        if (int rc = rsmp::class_table_for(ls->device, *cl.r0->table, cl.step_geo, t, &ct, have_pre && !pre_step.coef.empty() ? &pre_step : nullptr)) return rc;
-        cl.step_table = ct;
+    if (step) {
+        if (cl.step_table.hold) cl.holds.push_back(cl.step_table.hold);   // (a run planned ahead may still name it)
+        cl.step_table = *step;
         for (LockstepGroup& g : ls->groups)
             if (g.periodic && g.pad0 == c) {
-                g.class_coef = ct.d_coef;
-                g.class_meta = ct.d_meta;
+                g.class_coef = step->d_coef;
+                g.class_meta = step->d_meta;
             }
-        ls->groups_dirty = true;
     }
-    if (cl.has_run && ls->run_state == 1) {
-        rsmp::ClassTable ct;
-        if (int rc = rsmp::class_table_for(ls->device, *cl.r0->table, cl.run_geo, t, &ct, have_pre && !pre_run.coef.empty() ? &pre_run : nullptr)) return rc;
-        cl.run_table = ct;
+    if (run) {
+        if (cl.run_table.hold) cl.holds.push_back(cl.run_table.hold);
+        cl.run_table = *run;
         for (size_t i = cl.first; i < cl.first + cl.count; ++i) {
-            ls->h_run_rs[i].class_coef = ct.d_coef;
-            ls->h_run_rs[i].class_wrap_coef = ct.d_wrap_coef;
-            ls->h_run_rs[i].class_meta = ct.d_meta;
+            ls->h_run_rs[i].class_coef = run->d_coef;
+            ls->h_run_rs[i].class_wrap_coef = run->d_wrap_coef;
+            ls->h_run_rs[i].class_meta = run->d_meta;
             ls->h_run_rs[i].drift = t;
         }
-        ls->rs_dirty = true;
     }
     cl.table_drift = t;
     ++ls->table_rebinds;
+}
+
+// New tables for class `c` from the process-wide cache, built for drift `d` -- where the HOST knows the states and may
+// wait (creation, reset): class_table_for builds on this thread, allocates and copies synchronously.
+int rebind_class_blocking(rsmp_fir_lockstep* ls, size_t c, double d) {
+    rsmp_fir_lockstep::DriftClass& cl = ls->classes[c];
+    const double t = quantized_drift(d);
+    rsmp::ClassTable st, rt;
+    const bool want_run = cl.has_run && ls->run_state == 1;
+    if (cl.has_step)
+        if (int rc = rsmp::class_table_for(ls->device, *cl.r0->table, cl.step_geo, t, &st)) return rc;
+    if (want_run)
+        if (int rc = rsmp::class_table_for(ls->device, *cl.r0->table, cl.run_geo, t, &rt)) return rc;
+    bind_class_tables(ls, c, cl.has_step ? &st : nullptr, want_run ? &rt : nullptr, t);
+    if (cl.has_step) ls->groups_dirty = true;
+    if (want_run) ls->rs_dirty = true;
+    if (cl.late) { cl.late = false; --ls->n_late; }
     return RSMP_OK;
 }
 
-// The drifts that have come back from the device since the last look: classes that have moved get new tables.
-int poll_drift(rsmp_fir_lockstep* ls) {
-    if (!ls->drift_inflight || hipEventQuery(ls->drift_ev) != hipSuccess) {
-        (void)hipGetLastError();   // (hipErrorNotReady is not an error here)
-        return RSMP_OK;
-    }
-    ls->drift_inflight = false;
-    const double* d = ls->h_drift.as<double>();
-    for (size_t c = 0; c < ls->classes.size(); ++c) {
-        rsmp_fir_lockstep::DriftClass& cl = ls->classes[c];
-        const double off = d[c] - cl.table_drift;
-        if (std::fabs(off) > kLsDriftTolerance) {
-            if (int rc = rebind_class(ls, c, d[c])) return rc;
-        } else if (std::fabs(off) > 0.6 * kLsDriftTolerance && !cl.next_pending) {
-            // most of the way: the tables the class will want at the crossing are built now, beside everything else
-            cl.next_drift = quantized_drift(cl.table_drift + (off > 0.0 ? kLsDriftTolerance : -kLsDriftTolerance));
-            const double nd = cl.next_drift;
-            const auto tab = cl.r0->table;   // (shared: outlives the task)
-            if (cl.has_step) {
-                const rsmp::PeriodicGeometry g = cl.step_geo;
-                cl.next_step = std::async(std::launch::async, [tab, g, nd] { return rsmp::build_class_table(*tab, g, nd); });
-            }
-            if (cl.has_run && ls->run_state == 1) {
-                const rsmp::PeriodicGeometry g = cl.run_geo;
-                cl.next_run = std::async(std::launch::async, [tab, g, nd] { return rsmp::build_class_table(*tab, g, nd); });
-            }
-            cl.next_pending = true;
+// The launch path's side of a replacement.  Where the drifts that have come back from the device say so, a class's next
+// tables are ASKED FOR (most of the way to the tolerance: one event record), and a class past the tolerance TAKES the
+// tables the worker has left for it (pointer swaps + one patch kernel for all classes of this look).  Nothing here
+// builds, allocates, copies or waits -- unless a class has run three tolerances past its tables without new ones
+// (a worker starved for ~30 polls; counted in stat_table_waits, never observed).
+int poll_drift(rsmp_fir_lockstep* ls, hipStream_t s) {
+    bool fresh = false;
+    if (ls->drift_inflight) {
+        if (hipEventQuery(ls->drift_ev) == hipSuccess) {
+            ls->drift_inflight = false;
+            fresh = true;
+            const double* d = ls->h_drift.as<double>();
+            for (size_t c = 0; c < ls->classes.size(); ++c) ls->classes[c].seen_drift = d[c];
+        } else {
+            (void)hipGetLastError();   // (hipErrorNotReady is not an error here)
         }
     }
-    return RSMP_OK;
+    if (!fresh && ls->n_late == 0) return RSMP_OK;
+    using TR = rsmp::TableRefresher;
+    const double tol = ls->drift_tolerance;
+    rsmp::LsPatchArgs pa;
+    pa.groups = ls->d_groups.as<LockstepGroup>();
+    pa.rs = ls->run_state == 1 ? ls->d_run_rs.as<rsmp::LsRunStream>() : nullptr;
+    pa.n_groups = static_cast<uint32_t>(ls->groups.size());
+    pa.n_streams = static_cast<uint32_t>(ls->rs.size());
+    pa.n_patches = 0;
+    pa.pad = 0;
+    auto flush_patches = [&]() -> int {
+        if (pa.n_patches) RSMP_HIP_CHECK(rsmp::launch_fir_lockstep_patch_tables(pa, s));
+        pa.n_patches = 0;
+        return RSMP_OK;
+    };
+    for (size_t c = 0; c < ls->classes.size(); ++c) {
+        rsmp_fir_lockstep::DriftClass& cl = ls->classes[c];
+        if (!fresh && !cl.late) continue;
+        const double off = cl.seen_drift - cl.table_drift;
+        const bool want_step = cl.has_step, want_run = cl.has_run && ls->run_state == 1;
+        if (!want_step && !want_run) continue;
+        auto state_of = [](TR::Table* t) { return t ? t->state.load(std::memory_order_acquire) : static_cast<int>(TR::kReady); };
+        auto ask = [&](double nd) -> int {
+            cl.next_drift = nd;
+            if (want_step) if (int rc = ls->refresher->request(cl.step_next, nd, s)) return rc;
+            if (want_run) if (int rc = ls->refresher->request(cl.run_next, nd, s)) return rc;
+            cl.next_pending = true;
+            return RSMP_OK;
+        };
+        if (std::fabs(off) > tol) {
+            if (!cl.late) { cl.late = true; ++ls->n_late; }
+            int st = want_step ? state_of(cl.step_next) : TR::kReady, rt = want_run ? state_of(cl.run_next) : TR::kReady;
+            if (cl.next_pending && (st == TR::kRequested || rt == TR::kRequested) && std::fabs(off) > 3.0 * tol) {
+                if (want_step) ls->refresher->wait(cl.step_next);
+                if (want_run) ls->refresher->wait(cl.run_next);
+                ++ls->stat_table_waits;
+                st = want_step ? state_of(cl.step_next) : TR::kReady;
+                rt = want_run ? state_of(cl.run_next) : TR::kReady;
+            }
+            if (cl.next_pending && (st == TR::kRequested || rt == TR::kRequested)) {
+                ++ls->stat_late_polls;   // on their way: the old tables serve a little longer (a fifth of the bound per tolerance)
+                continue;
+            }
+            if (cl.next_pending && (st == TR::kFailed || rt == TR::kFailed))
+                return rsmp::fail(RSMP_ERR_HIP, "lock-step batch: the replacement class tables could not be made");
+            if (cl.next_pending && std::fabs(cl.seen_drift - cl.next_drift) <= 0.5 * tol) {
+                rsmp::ClassTable stt, rtt;
+                if (want_step) stt = ls->refresher->take(cl.step_next);
+                if (want_run) rtt = ls->refresher->take(cl.run_next);
+                cl.next_pending = false;
+                bind_class_tables(ls, c, want_step ? &stt : nullptr, want_run ? &rtt : nullptr, cl.next_drift);
+                cl.late = false;
+                --ls->n_late;
+                rsmp::LsTablePatch& q = pa.p[pa.n_patches++];
+                q.cls = static_cast<uint32_t>(c);
+                q.first = static_cast<uint32_t>(cl.first);
+                q.count = static_cast<uint32_t>(cl.count);
+                q.flags = (want_step ? 1u : 0u) | (want_run ? 2u : 0u);
+                q.step_coef = stt.d_coef;
+                q.step_meta = stt.d_meta;
+                q.run_coef = rtt.d_coef;
+                q.run_wrap_coef = rtt.d_wrap_coef;
+                q.run_meta = rtt.d_meta;
+                q.drift = cl.next_drift;
+                if (pa.n_patches == rsmp::kLsMaxPatches) if (int rc = flush_patches()) return rc;
+                continue;
+            }
+            // nothing asked for yet, or what was prepared is for another drift (a jump): ask now
+            if (cl.next_pending) {   // (both results are in: drop them, the images are free again)
+                if (want_step) ls->refresher->discard(cl.step_next);
+                if (want_run) ls->refresher->discard(cl.run_next);
+                cl.next_pending = false;
+            }
+            ++ls->stat_late_polls;
+            if (int rc = ask(quantized_drift(cl.seen_drift))) return rc;
+        } else if (std::fabs(off) > 0.6 * tol && !cl.next_pending) {
+            // most of the way: the tables the class will want at the crossing are made now, beside everything else
+            if (int rc = ask(quantized_drift(cl.table_drift + (off > 0.0 ? tol : -tol)))) return rc;
+        }
+    }
+    return flush_patches();
 }
 
-// Changed group / stream tables go to the device, in stream order in front of what is enqueued next.  (Called where no
-// planner of the batch is running: the plan stream has been waited for.)
+// Changed group / stream tables go to the device as a whole, in stream order in front of what is enqueued next: the
+// blocking paths' way (reset, the first run).  (Called where no planner of the batch is running: the plan stream has
+// been waited for.)
 int flush_tables(rsmp_fir_lockstep* ls, hipStream_t s) {
     if (!ls->groups_dirty && !ls->rs_dirty) return RSMP_OK;
     const size_t gb = ls->groups.size() * sizeof(LockstepGroup), rb = ls->h_run_rs.size() * sizeof(rsmp::LsRunStream);
@@ -217,7 +307,7 @@ int flush_tables(rsmp_fir_lockstep* ls, hipStream_t s) {
         std::memcpy(h, ls->groups.data(), gb);
         RSMP_HIP_CHECK(hipMemcpyAsync(ls->d_groups.get(), h, gb, hipMemcpyHostToDevice, s));
     }
-    if (ls->rs_dirty) {
+    if (ls->rs_dirty && ls->run_state == 1) {
         std::memcpy(h + gb, ls->h_run_rs.data(), rb);
         RSMP_HIP_CHECK(hipMemcpyAsync(ls->d_run_rs.get(), h + gb, rb, hipMemcpyHostToDevice, s));
     }
@@ -230,7 +320,7 @@ int flush_tables(rsmp_fir_lockstep* ls, hipStream_t s) {
 // After a step or run of `frames` input frames per stream: now and then the classes' drifts start their way to the host.
 int request_drift(rsmp_fir_lockstep* ls, hipStream_t s, uint64_t frames) {
     ls->frames_since_drift += frames;
-    if (ls->drift_inflight || ls->frames_since_drift < kLsDriftCheckFrames || ls->classes.empty()) return RSMP_OK;
+    if (ls->drift_inflight || ls->frames_since_drift < ls->drift_check_frames || ls->classes.empty()) return RSMP_OK;
     const uint32_t nc = static_cast<uint32_t>(ls->classes.size());
     // (the kernel stores straight into the mapped, coherent host buffer: a copy-engine operation in the stream costs the
     // stream ~0.1 ms of cross-queue synchronisation, 6-9 % of config 4's step when done every fourth run)
@@ -242,7 +332,8 @@ int request_drift(rsmp_fir_lockstep* ls, hipStream_t s, uint64_t frames) {
     return RSMP_OK;
 }
 
-// The host knows the states (creation, reset): every class gets the tables of its first stream's drift at once.
+// The host knows the states (creation, reset): every class gets the tables of its first stream's drift at once.  What
+// the worker was asked for belongs to the old states: waited for and dropped.
 int rebind_from_host_states(rsmp_fir_lockstep* ls) {
     if (ls->drift_inflight) {   // (what is on its way belongs to the old states)
         RSMP_HIP_CHECK(hipEventSynchronize(ls->drift_ev));
@@ -250,9 +341,19 @@ int rebind_from_host_states(rsmp_fir_lockstep* ls) {
     }
     ls->frames_since_drift = 0;
     for (size_t c = 0; c < ls->classes.size(); ++c) {
-        const double d = ls->rs[ls->order[ls->classes[c].rep]]->mirror.drift();
-        if (std::fabs(d - ls->classes[c].table_drift) > kLsDriftQuantum)
-            if (int rc = rebind_class(ls, c, d)) return rc;
+        rsmp_fir_lockstep::DriftClass& cl = ls->classes[c];
+        if (cl.next_pending) {
+            for (rsmp::TableRefresher::Table* t : {cl.step_next, cl.run_next})
+                if (t && t->state.load(std::memory_order_acquire) != rsmp::TableRefresher::kIdle) {
+                    ls->refresher->wait(t);
+                    ls->refresher->discard(t);   // (nobody bound the image: it is the next to be filled again)
+                }
+            cl.next_pending = false;
+        }
+        const double d = ls->rs[ls->order[cl.rep]]->mirror.drift();
+        cl.seen_drift = d;
+        if (std::fabs(d - cl.table_drift) > kLsDriftQuantum || cl.late)
+            if (int rc = rebind_class_blocking(ls, c, d)) return rc;
     }
     return RSMP_OK;
 }
@@ -303,6 +404,9 @@ extern "C" rsmp_fir_lockstep* rsmp_fir_lockstep_new(rsmp_fir* const* rs, size_t 
     ls->device = rs[0]->device;
     ls->step_frames = static_cast<uint32_t>(step_frames);
     ls->rs.assign(rs, rs + n);
+    ls->drift_tolerance = kLsDriftTolerance;
+    ls->drift_check_frames = kLsDriftCheckFrames;
+    ls->refresher.reset(new rsmp::TableRefresher(ls->device));   // (its thread exists from here on: none is created in a launch path)
     // Streams that share a polyphase table, a rate pair and a channel count share a class table and
     // a geometry: they become neighbours, then workgroups of `slots` streams.
     // (a stream set to RSMP_FIR_KERNEL_PERIODIC_F32 keeps every product in f32: its own groups)
@@ -347,7 +451,13 @@ extern "C" rsmp_fir_lockstep* rsmp_fir_lockstep_new(rsmp_fir* const* rs, size_t 
             if (rsmp::class_table_for(ls->device, *r0->table, cl.step_geo, cl.table_drift, &ct) != RSMP_OK)
                 return nullptr;
             cl.step_table = ct;
+            cl.step_next = ls->refresher->add_table(cl.step_geo, r0->table);
+            if (!cl.step_next) {
+                rsmp::fail(RSMP_ERR_HIP, "lock-step batch: cannot create an event");
+                return nullptr;
+            }
         }
+        cl.seen_drift = cl.table_drift;
         const uint32_t class_index = static_cast<uint32_t>(ls->classes.size());
         ls->classes.push_back(std::move(cl));
         for (size_t first = k; first < e; first += geo.slots) {
@@ -434,6 +544,10 @@ extern "C" rsmp_fir_lockstep* rsmp_fir_lockstep_new(rsmp_fir* const* rs, size_t 
         ls->h_drift.reserve(ls->classes.size() * sizeof(double)) != hipSuccess ||
         hipEventCreateWithFlags(&ls->drift_ev, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ls->stage_ev, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ls->probe_ev, hipEventDisableTiming) != hipSuccess ||
+        ls->d_probe.reserve(sizeof(uint32_t)) != hipSuccess ||
+        ls->h_probe.reserve(sizeof(uint32_t)) != hipSuccess ||
+        hipMemset(ls->d_probe.get(), 0, sizeof(uint32_t)) != hipSuccess ||
         hipStreamCreateWithFlags(&ls->own_stream, hipStreamNonBlocking) != hipSuccess) {
         rsmp::fail(RSMP_ERR_HIP, "lock-step batch: cannot allocate device state");
         return nullptr;
@@ -469,6 +583,10 @@ extern "C" void rsmp_fir_lockstep_free(rsmp_fir_lockstep* ls) {
     (void)rsmp_fir_lockstep_sync(ls);
     if (ls->drift_ev) (void)hipEventDestroy(ls->drift_ev);
     if (ls->stage_ev) (void)hipEventDestroy(ls->stage_ev);
+    if (ls->probe_ev) {
+        (void)hipEventSynchronize(ls->probe_ev);   // (a probe's kernels name d_probe / h_probe)
+        (void)hipEventDestroy(ls->probe_ev);
+    }
     for (hipStream_t& q : ls->plan_candidates) {
         if (!q) continue;
         (void)hipStreamSynchronize(q);
@@ -486,6 +604,7 @@ extern "C" void rsmp_fir_lockstep_free(rsmp_fir_lockstep* ls) {
     }
     for (hipEvent_t e : ls->prof_start) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : ls->prof_stop) if (e) (void)hipEventDestroy(e);
+    ls->refresher.reset();   // (joins its thread, frees the images: every kernel that read them has been waited for above)
     delete ls;
 }
 
@@ -506,6 +625,7 @@ extern "C" int rsmp_fir_lockstep_bind(rsmp_fir_lockstep* ls, const float* const*
     if (ls->last_stream) RSMP_HIP_CHECK(hipStreamSynchronize(ls->last_stream));
     if (int rc = drop_plan_ahead(ls, nullptr)) return rc;
     ls->prev.valid = false;
+    for (auto& cl : ls->classes) cl.holds.clear();   // (nothing enqueued or planned ahead names a replaced cache table any more)
     refresh_history_index(ls);
     bool aligned8 = true;
     for (size_t k = 0; k < n; ++k) {
@@ -554,7 +674,7 @@ extern "C" int rsmp_fir_lockstep_step(rsmp_fir_lockstep* ls, size_t in_frames, s
     }
     if (int rc = drop_plan_ahead(ls, s)) return rc;   // (a run planned ahead read the states this step is about to change)
     ls->prev.valid = false;
-    if (int rc = poll_drift(ls)) return rc;
+    if (int rc = poll_drift(ls, s)) return rc;
     if (int rc = flush_tables(ls, s)) return rc;
     rsmp::LockstepArgs a;
     a.groups = ls->d_groups.as<LockstepGroup>();
@@ -637,6 +757,7 @@ extern "C" int rsmp_fir_lockstep_reset(rsmp_fir_lockstep* ls) {
     if (ls->last_stream) RSMP_HIP_CHECK(hipStreamSynchronize(ls->last_stream));
     if (int rc = drop_plan_ahead(ls, nullptr)) return rc;
     ls->prev.valid = false;
+    for (auto& cl : ls->classes) cl.holds.clear();
     for (rsmp_fir* r : ls->rs) r->mirror.reset();   // resampler_fir.rs:638-642
     RSMP_HIP_CHECK(hipMemset(ls->d_cursor.get(), 0, n * sizeof(uint64_t)));
     RSMP_HIP_CHECK(hipMemset(ls->d_status.get(), 0, n * sizeof(uint32_t)));
@@ -680,33 +801,72 @@ extern "C" int rsmp_fir_lockstep_mean_kernel_ms(rsmp_fir_lockstep* ls, float* ms
     return RSMP_OK;
 }
 
+extern "C" int rsmp_fir_lockstep_kernel_ms(rsmp_fir_lockstep* ls, float* ms, size_t cap, size_t* launches) {
+    if (!ls || !ms || !launches) return rsmp::fail(RSMP_ERR_INVALID_ARGUMENT, "rsmp_fir_lockstep_kernel_ms: null argument");
+    DeviceGuard guard(ls->device);
+    const size_t ring = rsmp_fir_lockstep::kProfRing;
+    const size_t n = std::min(cap, std::min(ls->prof_count, ring));
+    *launches = n;
+    if (n == 0) return RSMP_OK;
+    RSMP_HIP_CHECK(hipEventSynchronize(ls->prof_stop[(ls->prof_count - 1) % ring]));
+    for (size_t k = 0; k < n; ++k) {   // oldest first
+        const size_t i = (ls->prof_count - n + k) % ring;
+        RSMP_HIP_CHECK(hipEventElapsedTime(&ms[k], ls->prof_start[i], ls->prof_stop[i]));
+    }
+    return RSMP_OK;
+}
+
 // ---- rsmp_fir_lockstep_run: k consecutive calls per stream in one go -----------------------------------------
 namespace {
 
 // The plan stream of a caller's stream: one that runs BESIDE it.  HIP deals a handful of hardware queues to its streams in
 // turn, and two streams on one queue run their kernels one after the other (the bench's torch stream and the batch's plan
 // stream met on one: planned ahead, nothing overlapped).  Nothing tells which queue a stream has, so it is tried out, once per
-// caller's stream: a kernel that idles 300 us goes to the caller's stream, an empty one to a candidate; if the candidate is
-// through before that one can be, the two run side by side.  Two candidates created one after the other sit
-// on different queues, so at most one of them shares the caller's.  (A stream of higher priority has a queue of its own for
-// certain -- and starves the short kernels between the bulk launches: a run of 16 calls took 2.7x as long.)
+// caller's stream, by a probe the DEVICE decides (launch_fir_lockstep_probe_wait: a wave on the caller's stream waits up to
+// 1 ms for a word that a kernel on the candidate stores; behind it on one queue that kernel cannot start in time) and whose
+// result the host looks at when its event has passed -- no host clock, no host wait: round 4's version timed the pair with
+// the host's clock against 200 us around a hipStreamSynchronize, which a busy host fails for both candidates, and the batch
+// then silently ran without plan-ahead.  Two candidates created one after the other sit on different queues, so at most one of
+// them shares the caller's; a candidate that fails is tried once more after the other one (a host descheduled for a
+// millisecond between the two launches reads like a shared queue).  Until a stream's answer is in, its runs plan on the
+// stream itself.  (A stream of higher priority has a queue of its own for certain -- and starves the short kernels between
+// the bulk launches: a run of 16 calls took 2.7x as long.)
 int pick_plan_stream(rsmp_fir_lockstep* ls, hipStream_t s) {
-    auto it = ls->plan_pick.find(s);
-    if (it == ls->plan_pick.end()) {
-        int pick = -1;
-        for (int c = 0; c < 2 && pick < 0; ++c) {
-            const auto t0 = std::chrono::steady_clock::now();
-            RSMP_HIP_CHECK(rsmp::launch_fir_lockstep_idle(30000u, s));   // (100 MHz ticks: 300 us)
-            RSMP_HIP_CHECK(rsmp::launch_fir_lockstep_idle(0u, ls->plan_candidates[c]));
-            RSMP_HIP_CHECK(hipStreamSynchronize(ls->plan_candidates[c]));
-            // behind the idling kernel on one queue the candidate cannot be through before that one is
-            if (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() < 200.0) pick = c;
+    rsmp_fir_lockstep::PlanPick& pp = ls->plan_pick[s];
+    static const bool verbose = rsmp::knob("RSMP_FIR_VERBOSE") != nullptr;
+    if (!pp.decided) {
+        if (pp.probing && ls->probe_owner == s) {
+            if (hipEventQuery(ls->probe_ev) == hipSuccess) {
+                pp.probing = false;
+                ls->probe_owner = nullptr;
+                if (*ls->h_probe.as<volatile uint32_t>() == 1u) {
+                    pp.pick = pp.cand;
+                    pp.decided = true;
+                } else if (++pp.tries >= 4) {
+                    pp.pick = -1;
+                    pp.decided = true;
+                } else {
+                    pp.cand ^= 1;
+                }
+                if (verbose && pp.decided)
+                    fprintf(stderr, "[rsmp] lock-step run: plan stream candidate %d runs beside stream %p (%d probes)\n", pp.pick,
+                            static_cast<void*>(s), pp.tries + 1);
+            } else {
+                (void)hipGetLastError();
+            }
         }
-        static const bool verbose = rsmp::knob("RSMP_FIR_VERBOSE") != nullptr;
-        if (verbose) fprintf(stderr, "[rsmp] lock-step run: plan stream candidate %d runs beside stream %p\n", pick, static_cast<void*>(s));
-        it = ls->plan_pick.emplace(s, pick).first;
+        if (!pp.decided && !pp.probing && ls->probe_owner == nullptr) {
+            const uint32_t token = ++ls->probe_token ? ls->probe_token : ++ls->probe_token;
+            *ls->h_probe.as<volatile uint32_t>() = 0u;
+            RSMP_HIP_CHECK(rsmp::launch_fir_lockstep_probe_wait(ls->d_probe.as<uint32_t>(), token, 100000u, ls->h_probe.as<uint32_t>(), s));
+            RSMP_HIP_CHECK(rsmp::launch_fir_lockstep_probe_set(ls->d_probe.as<uint32_t>(), token, ls->plan_candidates[pp.cand]));
+            RSMP_HIP_CHECK(hipEventRecord(ls->probe_ev, s));
+            pp.probing = true;
+            ls->probe_owner = s;
+            ++ls->stat_probes;
+        }
     }
-    ls->plan_stream = it->second >= 0 ? ls->plan_candidates[it->second] : nullptr;
+    ls->plan_stream = pp.decided && pp.pick >= 0 ? ls->plan_candidates[pp.pick] : nullptr;
     return RSMP_OK;
 }
 
@@ -760,6 +920,8 @@ int prepare_run(rsmp_fir_lockstep* ls) {
         cl.has_run = true;
         cl.run_geo = geo;
         cl.run_table = ct;
+        if (!cl.run_next) cl.run_next = ls->refresher->add_table(geo, r0->table);
+        if (!cl.run_next) return rsmp::fail(RSMP_ERR_HIP, "lock-step run: cannot create an event");
         rsmp_fir_lockstep::RunGroup g;
         g.geo = geo;
         g.first = k;
@@ -803,12 +965,13 @@ int prepare_run(rsmp_fir_lockstep* ls) {
         hipEventCreateWithFlags(&ls->slot[1].compute_done, hipEventDisableTiming) != hipSuccess ||
         ls->d_run_rs.reserve(n * sizeof(rsmp::LsRunStream)) != hipSuccess ||
         ls->d_run_states0.reserve(n * sizeof(FirMirrorState)) != hipSuccess ||
-        ls->d_run_work.reserve(64 * sizeof(unsigned long long)) != hipSuccess)
+        ls->d_run_work.reserve(std::max<size_t>(64, ls->run_groups.size()) * sizeof(unsigned long long)) != hipSuccess)
         return rsmp::fail(RSMP_ERR_HIP, "lock-step run: cannot allocate device state");
     for (auto& sl : ls->slot)
         RSMP_HIP_CHECK(hipMemcpy(sl.descs.get(), descs.data(), n * sizeof(rsmp::FirStreamDesc), hipMemcpyHostToDevice));
     RSMP_HIP_CHECK(hipMemcpy(ls->d_run_rs.get(), rstreams.data(), n * sizeof(rsmp::LsRunStream), hipMemcpyHostToDevice));
-    RSMP_HIP_CHECK(hipMemset(ls->d_run_work.get(), 0, 64 * sizeof(unsigned long long)));
+    // (one work counter per run group: a batch of many drift classes on a non-split geometry has more than 64)
+    RSMP_HIP_CHECK(hipMemset(ls->d_run_work.get(), 0, std::max<size_t>(64, ls->run_groups.size()) * sizeof(unsigned long long)));
     ls->run_state = 1;
     return RSMP_OK;
 }
@@ -834,8 +997,12 @@ extern "C" int rsmp_fir_lockstep_run(rsmp_fir_lockstep* ls, size_t k_steps, size
     const bool whole_accept = in_frames + max_taps + 8 <= rsmp::kMirrorInputCapacity;
     // The outputs of a run's calls follow each other in `out`: behind what earlier steps / runs appended, or -- without
     // `append` -- from the front of the buffer (the append position starts again there).
+    // (the planner's counters of a run -- outputs, frames, bitmap bits -- are 32-bit: a run whose inputs or whose outputs of
+    // any rate pair could pass 2^27 / 2^31 is a loop of steps; 8 -> 384 kHz makes 48 outputs per frame)
+    uint64_t max_out_run = 0;
+    for (const auto& g : ls->run_groups) max_out_run = std::max<uint64_t>(max_out_run, k_steps * static_cast<uint64_t>(g.max_out_step));
     const bool loop_of_steps = ls->run_state < 0 || k_steps == 1 || !whole_accept ||
-                               k_steps * static_cast<uint64_t>(ls->step_frames) > (1u << 27);
+                               k_steps * static_cast<uint64_t>(ls->step_frames) > (1u << 27) || max_out_run >= (1ull << 31);
     const size_t n = ls->rs.size();
     if (k_steps > (1u << 20)) return rsmp::fail(RSMP_ERR_INVALID_ARGUMENT, "rsmp_fir_lockstep_run: at most 2^20 calls per run");
     const uint32_t k = static_cast<uint32_t>(k_steps);
@@ -862,6 +1029,7 @@ extern "C" int rsmp_fir_lockstep_run(rsmp_fir_lockstep* ls, size_t k_steps, size
         ls->run_wrap_words = ww;
     }
     if (loop_of_steps) {
+        if (ls->last_stream && ls->last_stream != s) RSMP_HIP_CHECK(hipStreamSynchronize(ls->last_stream));   // (in front of the memset below)
         if (int rc = drop_plan_ahead(ls, s)) return rc;
         ls->prev.valid = false;
         if (!append)   // (the device planner starts a run at the front itself: no launch for it)
@@ -929,12 +1097,16 @@ extern "C" int rsmp_fir_lockstep_run(rsmp_fir_lockstep* ls, size_t k_steps, size
     };
     if (ls->profiling)
         RSMP_HIP_CHECK(hipEventRecord(ls->prof_start[ls->prof_count % rsmp_fir_lockstep::kProfRing], s));
-    if (int rc = poll_drift(ls)) return rc;
     if (same_key(ls->ahead, key)) {
         // planned while the previous run computed: wait for it (an event, no host block) and take its results over
         RSMP_HIP_CHECK(hipStreamWaitEvent(s, ls->plan_done, 0));
         ls->ahead_inflight = false;
-        if (int rc = flush_tables(ls, s)) return rc;   // (new tables: from the next plan on; this run was planned with the old ones)
+        ++ls->stat_ahead_hits;
+        // (new tables: from the next plan on; this run was planned with the old ones, whose images nobody overwrites
+        // before this run's kernels are through -- TableRefresher's guard event.  Behind the wait: the planner read
+        // the stream table this may patch.)
+        if (int rc = poll_drift(ls, s)) return rc;
+        if (int rc = flush_tables(ls, s)) return rc;
         rsmp::LsCommitArgs c;
         c.states = ls->d_states.as<FirMirrorState>();
         c.sp_states = ls->sp_states.as<FirMirrorState>();
@@ -947,7 +1119,9 @@ extern "C" int rsmp_fir_lockstep_run(rsmp_fir_lockstep* ls, size_t k_steps, size
         c.n_streams = static_cast<uint32_t>(n);
         RSMP_HIP_CHECK(rsmp::launch_fir_lockstep_commit(c, s));
     } else {
+        if (ls->ahead.valid) ++ls->stat_ahead_misses;
         if (int rc = drop_plan_ahead(ls, s)) return rc;   // (whatever the plan stream still does: finished before this stream goes on)
+        if (int rc = poll_drift(ls, s)) return rc;
         if (int rc = flush_tables(ls, s)) return rc;
         RSMP_HIP_CHECK(rsmp::launch_fir_lockstep_plan(plan_args(key, false), s));
     }
@@ -1064,5 +1238,21 @@ extern "C" int rsmp_fir_lockstep_run_slow_calls(rsmp_fir_lockstep* ls, size_t* s
     std::vector<Rec> h(ls->rs.size() * ls->run_counts_k);
     RSMP_HIP_CHECK(hipMemcpy(h.data(), ls->slot[ls->last_slot].recs.get(), h.size() * sizeof(Rec), hipMemcpyDeviceToHost));
     for (const Rec& r : h) *slow_calls += r.flags & 1u;
+    return RSMP_OK;
+}
+
+extern "C" int rsmp_fir_lockstep_stats(const rsmp_fir_lockstep* ls, uint64_t* out, size_t n) {
+    if (!ls || !out) return rsmp::fail(RSMP_ERR_INVALID_ARGUMENT, "rsmp_fir_lockstep_stats: null argument");
+    const uint64_t v[RSMP_LS_STAT_COUNT] = {ls->table_rebinds, ls->stat_ahead_hits, ls->stat_ahead_misses, ls->stat_late_polls,
+                                            ls->stat_table_waits, ls->stat_probes, ls->plan_stream ? 1u : 0u, ls->classes.size()};
+    for (size_t i = 0; i < n && i < RSMP_LS_STAT_COUNT; ++i) out[i] = v[i];
+    return RSMP_OK;
+}
+
+extern "C" int rsmp_fir_lockstep_set_drift_policy(rsmp_fir_lockstep* ls, double tolerance_frames, size_t check_frames) {
+    if (!ls || !(tolerance_frames >= 2.0 * kLsDriftQuantum) || tolerance_frames > 1e-6 || check_frames == 0)
+        return rsmp::fail(RSMP_ERR_INVALID_ARGUMENT, "rsmp_fir_lockstep_set_drift_policy: tolerance in [2e-8, 1e-6] frames, check_frames > 0");
+    ls->drift_tolerance = tolerance_frames;
+    ls->drift_check_frames = check_frames;
     return RSMP_OK;
 }

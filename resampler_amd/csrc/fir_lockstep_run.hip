@@ -275,9 +275,40 @@ __global__ __launch_bounds__(64) void fir_lockstep_gather_drift_kernel(const Fir
     if (c < n) out[c] = states[reps[c]].drift;
 }
 
-__global__ __launch_bounds__(64) void fir_lockstep_idle_kernel(uint32_t ticks) {
+// (fir_lockstep.h: launch_fir_lockstep_probe_wait / _set)
+__global__ __launch_bounds__(64) void fir_lockstep_probe_wait_kernel(uint32_t* flag, uint32_t token, uint32_t timeout_ticks, uint32_t* result) {
     const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
-    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+    uint32_t seen = 0;
+    for (;;) {
+        seen = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == token ? 1u : 0u;
+        if (seen || __builtin_amdgcn_s_memrealtime() - t0 >= timeout_ticks) break;
+        __builtin_amdgcn_s_sleep(32);
+    }
+    if (threadIdx.x == 0) __hip_atomic_store(result, seen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__global__ __launch_bounds__(64) void fir_lockstep_probe_set_kernel(uint32_t* flag, uint32_t token) {
+    if (threadIdx.x == 0) __hip_atomic_store(flag, token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ __launch_bounds__(256) void fir_lockstep_patch_tables_kernel(LsPatchArgs a) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t < a.n_groups) {
+        const uint32_t cls = a.groups[t].pad0;
+        for (uint32_t i = 0; i < a.n_patches; ++i)
+            if ((a.p[i].flags & 1u) && a.p[i].cls == cls && a.groups[t].periodic) {
+                a.groups[t].class_coef = a.p[i].step_coef;
+                a.groups[t].class_meta = a.p[i].step_meta;
+            }
+    } else if (a.rs && t - a.n_groups < a.n_streams) {
+        const uint32_t gs = t - a.n_groups;
+        for (uint32_t i = 0; i < a.n_patches; ++i)
+            if ((a.p[i].flags & 2u) && gs - a.p[i].first < a.p[i].count) {
+                a.rs[gs].class_coef = a.p[i].run_coef;
+                a.rs[gs].class_wrap_coef = a.p[i].run_wrap_coef;
+                a.rs[gs].class_meta = a.p[i].run_meta;
+                a.rs[gs].drift = a.p[i].drift;
+            }
+    }
 }
 
 }  // namespace
@@ -289,8 +320,20 @@ hipError_t launch_fir_lockstep_gather_drift(const FirMirrorState* states, const 
     return hipGetLastError();
 }
 
-hipError_t launch_fir_lockstep_idle(uint32_t ticks, hipStream_t stream) {
-    hipLaunchKernelGGL(fir_lockstep_idle_kernel, dim3(1), dim3(64), 0, stream, ticks);
+hipError_t launch_fir_lockstep_probe_wait(uint32_t* flag, uint32_t token, uint32_t timeout_ticks, uint32_t* result, hipStream_t stream) {
+    hipLaunchKernelGGL(fir_lockstep_probe_wait_kernel, dim3(1), dim3(64), 0, stream, flag, token, timeout_ticks, result);
+    return hipGetLastError();
+}
+
+hipError_t launch_fir_lockstep_probe_set(uint32_t* flag, uint32_t token, hipStream_t stream) {
+    hipLaunchKernelGGL(fir_lockstep_probe_set_kernel, dim3(1), dim3(64), 0, stream, flag, token);
+    return hipGetLastError();
+}
+
+hipError_t launch_fir_lockstep_patch_tables(const LsPatchArgs& args, hipStream_t stream) {
+    if (args.n_patches == 0) return hipSuccess;
+    const uint32_t threads = args.n_groups + (args.rs ? args.n_streams : 0u);
+    hipLaunchKernelGGL(fir_lockstep_patch_tables_kernel, dim3((threads + 255) / 256), dim3(256), 0, stream, args);
     return hipGetLastError();
 }
 

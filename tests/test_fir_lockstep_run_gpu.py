@@ -384,3 +384,57 @@ def test_class_tables_follow_the_drift_while_a_batch_runs():
         r.reset()
     assert ls.table_rebinds() > before   # back to the tables of drift 0
     assert one_pass(check=True) <= RMS_TOL
+
+
+def test_table_replacements_stay_off_the_launch_path():
+    """a class of streams that crosses its drift tolerance gets new class tables WITHOUT the
+    launch call building, allocating, copying or waiting (fir_table_refresher.h: a worker thread fills the other of
+    two owned device images, the crossing swaps pointers with one patch kernel).  Six rate pairs run 96 runs of 256
+    calls with the tolerance at its minimum (2e-8 of a frame, looked at after every run), so every class is replaced
+    several times: every run call -- also those that swap tables -- returns in well under a tenth of a millisecond
+    of host time, nobody ever waits for the worker, the calls' counts and the samples keep matching the oracle."""
+    import time
+    import torch
+    dev = torch.device("cuda:0")
+    pairs = [(44100, 48000), (48000, 44100), (44100, 96000), (96000, 44100), (48000, 96000), (96000, 48000)]
+    hs = [ra.ResamplerFir.new_from_hz(2, i, o_, ra.Latency.Sample64, ra.Attenuation.Db90) for i, o_ in pairs]
+    kind = o.CONVOLVE_AVX_FMA if o.have_avx_fma() else o.CONVOLVE_SCALAR
+    refs = [o.OracleFir(2, i, o_, 128, 90, kind) for i, o_ in pairs]
+    frames, k, runs = 512, 256, 96
+    x = synth.fast_noise(2 * frames * k, seed=77)          # the same span of input again and again
+    d_in = [torch.from_numpy(x).to(dev) for _ in hs]
+    caps = [h.buffer_size_output() for h in hs]
+    d_out = [torch.zeros(k * c, device=dev) for c in caps]
+    ls = ra.FirLockstep(hs, frames)
+    ls.bind_caps(d_in, d_out, caps)
+    ls.set_drift_policy(2e-8, 1)
+    stream = torch.cuda.Stream()
+    host_us, swapped = [], []
+    worst = 0.0
+    with torch.cuda.stream(stream):
+        for p in range(runs):
+            before = ls.stats()["table_rebinds"]
+            t0 = time.perf_counter()
+            ls.run(k, frames, 0, append=False, stream=stream.cuda_stream)
+            host_us.append((time.perf_counter() - t0) * 1e6)
+            swapped.append(ls.stats()["table_rebinds"] > before)
+            stream.synchronize()
+            check = p % 12 == 11 or swapped[-1]
+            cons, prod = ls.run_counts() if check else (None, None)
+            for i, r in enumerate(refs):
+                y, calls = r.resample_all(x, 2 * frames, max_calls=k + 4)
+                if check:
+                    assert calls.shape[0] == k and (calls[:, 0] == cons[:, i]).all() and (calls[:, 1] == prod[:, i]).all(), (p, i)
+                    worst = max(worst, rms(d_out[i][:y.size].cpu().numpy(), y))
+    st = ls.stats()
+    assert worst <= RMS_TOL, worst
+    assert st["table_rebinds"] >= 12 and sum(swapped) >= 6, st      # (every class replaced, most of them more than once)
+    assert st["table_waits"] == 0, st
+    assert st["plan_ahead_hits"] >= runs - 12, st                   # (the plan stream was found by the device-side probe)
+    warm = np.array(host_us[8:])
+    swap_calls = np.array([h for h, s in zip(host_us[8:], swapped[8:]) if s])
+    assert np.median(warm) < 100.0, (np.median(warm), warm.max())
+    assert swap_calls.size and np.median(swap_calls) < 100.0 and swap_calls.max() < 300.0, swap_calls
+    ls.sync()
+    for h, r in zip(hs, refs):
+        assert h.state() == r.state()
