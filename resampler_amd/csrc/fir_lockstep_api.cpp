@@ -115,6 +115,7 @@ struct rsmp_fir_lockstep {
     double drift_tolerance = 0.0;         // (set at creation: kLsDriftTolerance; rsmp_fir_lockstep_set_drift_policy)
     uint64_t drift_check_frames = 0;
     size_t n_late = 0;                    // classes currently `late`
+    std::vector<rsmp::TableRefresher::Table*> guards_due;   // images unbound by this call's replacements (record_guards)
     // diagnostics (rsmp_fir_lockstep_stats)
     uint64_t stat_ahead_hits = 0, stat_ahead_misses = 0, stat_late_polls = 0, stat_table_waits = 0, stat_probes = 0;
     std::vector<rsmp::LsRunStream> h_run_rs;
@@ -232,8 +233,8 @@ int poll_drift(rsmp_fir_lockstep* ls, hipStream_t s) {
         auto state_of = [](TR::Table* t) { return t ? t->state.load(std::memory_order_acquire) : static_cast<int>(TR::kReady); };
         auto ask = [&](double nd) -> int {
             cl.next_drift = nd;
-            if (want_step) if (int rc = ls->refresher->request(cl.step_next, nd, s)) return rc;
-            if (want_run) if (int rc = ls->refresher->request(cl.run_next, nd, s)) return rc;
+            if (want_step) if (int rc = ls->refresher->request(cl.step_next, nd)) return rc;
+            if (want_run) if (int rc = ls->refresher->request(cl.run_next, nd)) return rc;
             cl.next_pending = true;
             return RSMP_OK;
         };
@@ -248,6 +249,8 @@ int poll_drift(rsmp_fir_lockstep* ls, hipStream_t s) {
                 rt = want_run ? state_of(cl.run_next) : TR::kReady;
             }
             if (cl.next_pending && (st == TR::kRequested || rt == TR::kRequested)) {
+                static const bool verbose = rsmp::knob("RSMP_FIR_VERBOSE") != nullptr;
+                if (verbose) fprintf(stderr, "[rsmp] class %zu: drift %.3g past its tables' %.3g, the next ones (%.3g) on their way\n", c, cl.seen_drift, cl.table_drift, cl.next_drift);
                 ++ls->stat_late_polls;   // on their way: the old tables serve a little longer (a fifth of the bound per tolerance)
                 continue;
             }
@@ -255,9 +258,11 @@ int poll_drift(rsmp_fir_lockstep* ls, hipStream_t s) {
                 return rsmp::fail(RSMP_ERR_HIP, "lock-step batch: the replacement class tables could not be made");
             if (cl.next_pending && std::fabs(cl.seen_drift - cl.next_drift) <= 0.5 * tol) {
                 rsmp::ClassTable stt, rtt;
-                if (want_step) stt = ls->refresher->take(cl.step_next);
-                if (want_run) rtt = ls->refresher->take(cl.run_next);
+                if (want_step) { stt = ls->refresher->take(cl.step_next); ls->guards_due.push_back(cl.step_next); }
+                if (want_run) { rtt = ls->refresher->take(cl.run_next); ls->guards_due.push_back(cl.run_next); }
                 cl.next_pending = false;
+                static const bool verbose = rsmp::knob("RSMP_FIR_VERBOSE") != nullptr;
+                if (verbose) fprintf(stderr, "[rsmp] class %zu: drift %.3g, tables %.3g -> %.3g\n", c, cl.seen_drift, cl.table_drift, cl.next_drift);
                 bind_class_tables(ls, c, want_step ? &stt : nullptr, want_run ? &rtt : nullptr, cl.next_drift);
                 cl.late = false;
                 --ls->n_late;
@@ -282,6 +287,8 @@ int poll_drift(rsmp_fir_lockstep* ls, hipStream_t s) {
                 cl.next_pending = false;
             }
             ++ls->stat_late_polls;
+            static const bool verbose = rsmp::knob("RSMP_FIR_VERBOSE") != nullptr;
+            if (verbose) fprintf(stderr, "[rsmp] class %zu: drift %.3g past its tables' %.3g with nothing asked for\n", c, cl.seen_drift, cl.table_drift);
             if (int rc = ask(quantized_drift(cl.seen_drift))) return rc;
         } else if (std::fabs(off) > 0.6 * tol && !cl.next_pending) {
             // most of the way: the tables the class will want at the crossing are made now, beside everything else
@@ -318,7 +325,11 @@ int flush_tables(rsmp_fir_lockstep* ls, hipStream_t s) {
 }
 
 // After a step or run of `frames` input frames per stream: now and then the classes' drifts start their way to the host.
+// Images this call's replacements have unbound may be overwritten behind everything enqueued so far.
 int request_drift(rsmp_fir_lockstep* ls, hipStream_t s, uint64_t frames) {
+    for (rsmp::TableRefresher::Table* t : ls->guards_due)
+        if (int rc = ls->refresher->record_guard(t, s)) return rc;
+    ls->guards_due.clear();
     ls->frames_since_drift += frames;
     if (ls->drift_inflight || ls->frames_since_drift < ls->drift_check_frames || ls->classes.empty()) return RSMP_OK;
     const uint32_t nc = static_cast<uint32_t>(ls->classes.size());

@@ -60,14 +60,33 @@ __global__ __launch_bounds__(256) void fir_lockstep_predict_kernel(LsRunArgs a) 
     for (uint32_t w = c; w < a.wrap_words; w += a.k) a.wrap_bits[static_cast<size_t>(gs) * a.wrap_words + w] = 0;
 }
 
-// K2 -- the serial chain: one wave per stream walks the stream's k calls (mirror_call_chain: two dependent f64
-// operations per binade; mirror_call_fast / mirror_call where the rule or a check asks for them).  Every lane runs the
-// chain on the same values, so the control flow stays uniform (scalar branches, no masking).  The predictions and the
-// per-call results are staged through the wave's own registers, 64 calls at a time: lane j loads the prediction of call
-// j (the next 64 while these 64 run), the chain takes call s's words with v_readlane, and lane s keeps call s's record
-// and counts until the 64 are written back.  No LDS: the bulk kernels of the run before, which fill a CU's LDS with
-// their ring of images, share their CUs with this kernel when the run is planned ahead (fir_lockstep_api.cpp).
+// K2 -- the serial chain: one wave per stream walks the stream's k calls.  Every lane runs the chain on the same
+// values, so the control flow stays uniform (scalar branches, no masking).  Predictions and per-call results are staged
+// through the wave's own registers, 64 calls at a time: lane j loads the prediction of call j (the next 64 while these
+// 64 run) and keeps call j's record and counts until the 64 are written back.  No LDS: the bulk kernels of the run
+// before, which fill a CU's LDS with their ring of images, share their CUs with this kernel when the run is planned
+// ahead (fir_lockstep_api.cpp).
+//
+// Round 5: what is SERIAL per call is the f64 position alone (~25 dependent operations); round 4's loop issued 220
+// instructions around it -- fourteen v_readlane to rebuild a MirrorPred, the counters in 64-bit vector arithmetic,
+// the checks of the lean rule call by call -- on a wave that is alone on its SIMD: 0.91 us per call whatever the batch,
+// the Amdahl term of a shard.  Now
+//   * the lanes decide IN PARALLEL, 64 calls at a time, which calls may take the unchecked chain (nothing for the f64
+//     drift to decide, room in the output, the whole offer accepted: from the prediction and the exact closed form of
+//     the buffered frames) and whether a call's prediction continues its predecessor's (m0 = m0' + n', the frames
+//     retired in between): two ballots;
+//   * a call on that track takes mirror_chain_lean: nine v_readlane (the binade counts as packed words), the counters in
+//     scalar registers, `on track` kept by one scalar compare of the frames it retired with the prediction's;
+//   * anything else (6 % of config 4's calls) takes round 4's path unchanged: mirror_call_fast with every premise
+//     checked, mirror_call where that declines.
 static_assert(sizeof(MirrorPred) == 56, "MirrorPred is staged as fourteen 32-bit words");
+__device__ inline uint32_t rl(uint32_t v, uint32_t lane) {
+    return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(v), static_cast<int>(lane)));
+}
+__device__ inline uint32_t rfl(uint32_t v) { return static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(v))); }
+__device__ inline uint64_t rfl64(uint64_t v) {
+    return static_cast<uint64_t>(rfl(static_cast<uint32_t>(v))) | (static_cast<uint64_t>(rfl(static_cast<uint32_t>(v >> 32))) << 32);
+}
 __global__ __launch_bounds__(64) void fir_lockstep_chain_kernel(LsRunArgs a) {
     const uint32_t gs = blockIdx.x, lane = threadIdx.x;
     const LockstepStream ls = a.streams[gs];
@@ -88,53 +107,121 @@ __global__ __launch_bounds__(64) void fir_lockstep_chain_kernel(LsRunArgs a) {
     uint32_t last_c0 = 0, last_c1 = 0;
     const uint64_t* preds = reinterpret_cast<const uint64_t*>(a.preds + static_cast<size_t>(gs) * a.k);
     CallRec* recs = reinterpret_cast<CallRec*>(a.call_recs) + static_cast<size_t>(gs) * a.k;
-    uint64_t mine[7], ahead[7];
-    auto fetch = [&](uint32_t c0, uint64_t (&v)[7]) {
+    // the state while the stream runs on the unchecked chain: the f64 position in a vector register, the counters in
+    // scalar ones; `st` holds the state only while st_valid (at the start, after a call off that track)
+    const double ratio = st.ratio;
+    double pos = st.position;
+    ChainScalars sc{rfl64(st.abs_out), rfl64(st.abs_consumed), rfl(static_cast<uint32_t>(st.read_position)),
+                    rfl(static_cast<uint32_t>(st.available))};
+    bool st_valid = true, on_track = true;
+    uint32_t lean_ni_after = 0;   // next_int behind the latest lean call (scalar; read from the prediction when `st` is filled)
+    const uint64_t frames0 = rfl64(base.abs_consumed0 + base.avail0);   // frames accepted before the run
+    const uint32_t out_cap = rfl(static_cast<uint32_t>(ls.out_cap_frames < 0xFFFFFFFFull ? ls.out_cap_frames : 0xFFFFFFFFull));
+    uint64_t mine[7], ahead[7], succ[2], succ_ahead[2];
+    auto fetch = [&](uint32_t c0, uint64_t (&v)[7], uint64_t (&sv)[2]) {
         const uint32_t c = c0 + lane < a.k ? c0 + lane : a.k - 1;
+        const uint32_t cn = c + 1 < a.k ? c + 1 : a.k - 1;
 #pragma unroll
         for (int i = 0; i < 7; ++i) v[i] = __builtin_nontemporal_load(preds + static_cast<size_t>(c) * 7 + i);
+        sv[0] = __builtin_nontemporal_load(preds + static_cast<size_t>(cn) * 7);       // the next call's m0, c0
+        sv[1] = __builtin_nontemporal_load(preds + static_cast<size_t>(cn) * 7 + 1);
     };
-    fetch(0, ahead);
+    fetch(0, ahead, succ_ahead);
     for (uint32_t c0 = 0; c0 < a.k; c0 += 64) {
         const uint32_t nc = a.k - c0 < 64u ? a.k - c0 : 64u;
 #pragma unroll
         for (int i = 0; i < 7; ++i) mine[i] = ahead[i];
-        if (c0 + 64 < a.k) fetch(c0 + 64, ahead);
+        succ[0] = succ_ahead[0];
+        succ[1] = succ_ahead[1];
+        if (c0 + 64 < a.k) fetch(c0 + 64, ahead, succ_ahead);
+        // ---- the lanes' part: which of these 64 calls may take the unchecked chain, and which continue their predecessor
+        const uint32_t my_call = c0 + lane;
+        const uint32_t my_n_total = static_cast<uint32_t>(mine[2]);
+        const uint32_t my_ties = static_cast<uint32_t>(mine[2] >> 48);
+        // frames buffered when call j starts, IF the stream is on the prediction's track there: accepted - retired
+        const uint64_t my_avail = frames0 + static_cast<uint64_t>(my_call) * a.in_frames - mine[1];
+        const bool my_struct_ok = lane < nc && my_ties == 0 && my_n_total + 1 < out_cap && my_avail + a.in_frames <= kMirrorInputCapacity;
+        const bool my_last = my_call + 1 >= a.k;
+        const bool my_succ_ok = my_last || succ[0] == mine[0] + my_n_total;
+        const uint32_t my_cpred = static_cast<uint32_t>(succ[1] - mine[1]);   // frames the prediction has the call retire
+        const uint64_t lean_mask = __ballot(my_struct_ok && chain_ready);
+        const uint64_t succ_mask = __ballot(my_succ_ok);
+        uint64_t nonlean_mask = 0;
         double my_pos = 0.0, my_drift = 0.0;
         uint32_t my_flags = 0, my_c0 = 0, my_c1 = 0;
 #pragma unroll 1
         for (uint32_t s = 0; s < nc; ++s) {
+            const double pos0 = st_valid ? st.position : pos;
+            my_pos = lane == s ? pos0 : my_pos;   // lane s keeps call s's start position
+            if (!on_track) {   // (behind a call off the track: is the state where this call's prediction starts?)
+                const uint64_t m0 = static_cast<uint64_t>(rl(static_cast<uint32_t>(mine[0]), s)) | (static_cast<uint64_t>(rl(static_cast<uint32_t>(mine[0] >> 32), s)) << 32);
+                const uint64_t cc0 = static_cast<uint64_t>(rl(static_cast<uint32_t>(mine[1]), s)) | (static_cast<uint64_t>(rl(static_cast<uint32_t>(mine[1] >> 32), s)) << 32);
+                // (... with as many frames buffered as the lanes' closed form has it)
+                on_track = rfl64(st.abs_out) == m0 && rfl64(st.abs_consumed) == cc0 &&
+                           rfl(static_cast<uint32_t>(st.available)) == rl(static_cast<uint32_t>(my_avail), s) &&
+                           rfl(static_cast<uint32_t>(st.read_position)) + rfl(static_cast<uint32_t>(st.available)) + a.in_frames <= kMirrorBufferSize;
+            }
+            if (on_track && ((lean_mask >> s) & 1ull)) {
+                if (st_valid) {   // (the counters leave `st`)
+                    pos = st.position;
+                    sc = ChainScalars{rfl64(st.abs_out), rfl64(st.abs_consumed), rfl(static_cast<uint32_t>(st.read_position)),
+                                      rfl(static_cast<uint32_t>(st.available))};
+                    st_valid = false;
+                }
+                const uint32_t n_total = rl(static_cast<uint32_t>(mine[2]), s);
+                const uint32_t n_low = rl(static_cast<uint32_t>(mine[2] >> 32), s) & 0xFFFFu;
+                const uint32_t q[6] = {rl(static_cast<uint32_t>(mine[4]), s), rl(static_cast<uint32_t>(mine[4] >> 32), s),
+                                       rl(static_cast<uint32_t>(mine[5]), s), rl(static_cast<uint32_t>(mine[5] >> 32), s),
+                                       rl(static_cast<uint32_t>(mine[6]), s), rl(static_cast<uint32_t>(mine[6] >> 32), s)};
+                const uint32_t cpred = rl(my_cpred, s);
+                const uint32_t cons = mirror_chain_lean(pos, sc, a.in_frames, ratio, bn, n_total, n_low, q);
+                on_track = cons == cpred && ((succ_mask >> s) & 1ull);
+                last_c0 = a.in_frames * C;
+                last_c1 = n_total * C;
+                n_out += n_total;
+                accepted += a.in_frames;
+                consumed += cons;
+                sink.rel += n_total;
+                continue;
+            }
+            // ---- off the track: round 4's path (every premise checked, or the plain state machine)
             uint32_t cur[14];
 #pragma unroll
             for (int i = 0; i < 7; ++i) {
-                cur[2 * i] = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(static_cast<uint32_t>(mine[i])), static_cast<int>(s)));
-                cur[2 * i + 1] = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(static_cast<uint32_t>(mine[i] >> 32)), static_cast<int>(s)));
+                cur[2 * i] = rl(static_cast<uint32_t>(mine[i]), s);
+                cur[2 * i + 1] = rl(static_cast<uint32_t>(mine[i] >> 32), s);
             }
             MirrorPred pr;
             __builtin_memcpy(&pr, cur, sizeof pr);
-            const double pos0 = st.position;
+            if (!st_valid) {   // the counters go back into `st` (next_int: a call on the track starts where its prediction says)
+                st.position = pos;
+                st.abs_out = sc.abs_out;
+                st.abs_consumed = sc.abs_consumed;
+                st.read_position = sc.read_position;
+                st.available = sc.available;
+                st.next_int = pr.ni_before;   // (on the track: = the previous call's ni_after)
+                if (!on_track) {   // (the previous lean call left the track: its own end decides)
+                    const uint64_t ph = sc.abs_out % st.den;
+                    st.next_int = static_cast<uint32_t>(ph ? st.den - ph : 0);
+                }
+                st_valid = true;
+            }
             double drift = 0.0;
             uint32_t cf = st.abs_out != pr.m0 ? kCallAhead : 0u;
             FirCallCounts c;
-            // nothing for the f64 drift to decide in this call (the rule): the chain alone, checked by the replay
-            const bool lean = chain_ready && pr.ties == 0 && st.abs_out == pr.m0 && st.abs_consumed == pr.c0 &&
-                              st.read_position + st.available + a.in_frames <= kMirrorBufferSize &&
-                              st.available + a.in_frames <= kMirrorInputCapacity && pr.n_total + 1 < ls.out_cap_frames;
-            if (lean) {
-                mirror_call_chain(st, a.in_frames, pr, bn, c);
-                cf |= kCallLean;
-            } else if (!base.usable || !mirror_call_fast(st, a.in_frames, ls.out_cap_frames, pr, bn, c, [](uint32_t, uint32_t, double, double) {})) {
+            if (!base.usable || !mirror_call_fast(st, a.in_frames, ls.out_cap_frames, pr, bn, c, [](uint32_t, uint32_t, double, double) {})) {
                 const uint32_t ni = st.next_int;
                 sink.periodic = wraps_exist && st.periodic_ok != 0;
                 c = mirror_call(st, a.in_frames, ls.out_cap_frames, sink);
                 cf = kCallSlow | (ni < c.produced ? kCallHasInt : 0u);
                 drift = st.drift;
             }
+            on_track = false;   // (looked at again at the top of the next call)
+            nonlean_mask |= 1ull << s;
             if (c.accepted != a.in_frames) flags |= kLsStatusPartialAccept;
             last_c0 = static_cast<uint32_t>(c.accepted) * C;
             last_c1 = static_cast<uint32_t>(c.produced) * C;
             const bool me = lane == s;   // lane s keeps call s's record and counts
-            my_pos = me ? pos0 : my_pos;
             my_drift = me ? drift : my_drift;
             my_flags = me ? cf : my_flags;
             my_c0 = me ? last_c0 : my_c0;
@@ -144,12 +231,22 @@ __global__ __launch_bounds__(64) void fir_lockstep_chain_kernel(LsRunArgs a) {
             consumed += static_cast<uint32_t>(c.consumed);
             sink.rel += static_cast<uint32_t>(c.produced);
         }
+        if (!st_valid) lean_ni_after = rl(static_cast<uint32_t>(mine[3] >> 32), nc - 1);   // (the latest call's ni_after, should the run end here)
         if (lane < nc) {
-            recs[c0 + lane] = CallRec{my_pos, my_drift, my_flags, 0u};
+            const bool was_lean = ((nonlean_mask >> lane) & 1ull) == 0;
+            recs[c0 + lane] = CallRec{my_pos, was_lean ? 0.0 : my_drift, was_lean ? kCallLean : my_flags, 0u};
             uint32_t* counts = a.counts + 2 * (static_cast<size_t>(c0 + lane) * a.n_streams + rs.caller);
-            counts[0] = my_c0;
-            counts[1] = my_c1;
+            counts[0] = was_lean ? a.in_frames * C : my_c0;
+            counts[1] = was_lean ? my_n_total * C : my_c1;
         }
+    }
+    if (!st_valid) {   // the run ended on the chain: the state goes back into `st`
+        st.position = pos;
+        st.abs_out = sc.abs_out;
+        st.abs_consumed = sc.abs_consumed;
+        st.read_position = sc.read_position;
+        st.available = sc.available;
+        st.next_int = lean_ni_after;
     }
     if (lane != 0) return;
     if (sink.overflow) flags |= kLsStatusRunOverflow;

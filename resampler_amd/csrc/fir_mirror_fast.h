@@ -273,6 +273,49 @@ __host__ __device__ inline void mirror_call_chain(FirMirrorState& st, uint32_t i
     out = FirCallCounts{in_frames, pr.n_total, consumed};
 }
 
+// The same call with the integer half of the stream's state held apart (on the device: in SCALAR registers, updated by
+// the scalar unit in the shadow of the f64 chain's latency) and the prediction taken as the packed words the planner's
+// lanes hold: q[0 .. 5] = MirrorPred::n[12] as 16-bit halves.  The chain kernel's round-4 form spent 220 instructions a
+// call on a lone wave (fourteen v_readlane to rebuild a MirrorPred, 64-bit vector arithmetic for the counters, five
+// lane selects for the record: 0.91 us); this is ~25 dependent f64 operations and as many scalar ones.  Bit for bit
+// mirror_call_chain: the same rounded adds in the same order; min(floor(pos), avail) taken in f64 (exact: both are
+// integers below 2^53).  Returns the frames the call retires.
+struct ChainScalars {
+    uint64_t abs_out, abs_consumed;
+    uint32_t read_position, available;
+};
+__host__ __device__ inline uint32_t mirror_chain_lean(double& pos_io, ChainScalars& sc, uint32_t in_frames, double ratio,
+                                                      const MirrorBinades& bn, uint32_t n_total, uint32_t n_low,
+                                                      const uint32_t (&q)[6]) {
+    double pos = pos_io;
+    for (uint32_t k = 0; k < n_low; ++k) pos += ratio;
+#pragma unroll
+    for (uint32_t i = 0; i < kPredBinades; ++i) {
+        const uint32_t n = (q[i >> 1] >> (16u * (i & 1u))) & 0xFFFFu;
+        if (n >= 3) {
+            pos = fma(static_cast<double>(n - 1), bn.inc[i], pos) + ratio;
+        } else {
+            for (uint32_t k = 0; k < n; ++k) pos += ratio;
+        }
+    }
+    const uint32_t avail = sc.available + in_frames;
+    const double fl = floor(pos), avd = static_cast<double>(avail);
+    const double cd = fl > avd ? avd : fl;        // (double)min(floor(pos), avail), :596-597
+    pos_io = pos - cd;                            // :602
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t consumed = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(static_cast<uint32_t>(cd))));
+#else
+    const uint32_t consumed = static_cast<uint32_t>(cd);
+#endif
+    uint32_t rp = sc.read_position + consumed;
+    if (rp > kMirrorInputCapacity) rp = 0;        // :605-615
+    sc.read_position = rp;
+    sc.available = avail - consumed;
+    sc.abs_out += n_total;
+    sc.abs_consumed += consumed;
+    return consumed;
+}
+
 // The outputs at integer positions of one call done by mirror_call_fast, found by replaying it from its start state
 // (`st`: the state the call started from; only position, available and the counters matter).  Sink::wrap as for
 // mirror_call; st.drift / st.periodic_ok are updated as mirror_call updates them.  Returns whether the call had an

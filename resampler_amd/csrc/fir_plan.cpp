@@ -183,6 +183,18 @@ extern "C" int rsmp_fir_plan_selftest_fast(rsmp_fir_plan* p, size_t in_frames, s
                     if (std::memcmp(&lean, &fast, sizeof lean) != 0 || c_lean.produced != c_fast.produced ||
                         c_lean.consumed != c_fast.consumed)
                         ++bad;
+                    // ... and the chain kernel's form of it (the counters apart, the prediction as packed words)
+                    rsmp::ChainScalars sc{before.abs_out, before.abs_consumed, static_cast<uint32_t>(before.read_position),
+                                          static_cast<uint32_t>(before.available)};
+                    uint32_t q[6];
+                    std::memcpy(q, pr.n, sizeof q);
+                    double pos = before.position;
+                    const uint32_t cons = rsmp::mirror_chain_lean(pos, sc, static_cast<uint32_t>(in_frames), before.ratio, bn,
+                                                                  pr.n_total, pr.n_low, q);
+                    if (cons != c_fast.consumed || std::memcmp(&pos, &fast.position, sizeof pos) != 0 || sc.abs_out != fast.abs_out ||
+                        sc.abs_consumed != fast.abs_consumed || sc.read_position != fast.read_position ||
+                        sc.available != fast.available || pr.ni_after != fast.next_int)
+                        ++bad;
                 }
                 if (took_fast) {   // the outputs at integer positions: by replay from the call's start state
                     rsmp::FirMirrorState start = before;

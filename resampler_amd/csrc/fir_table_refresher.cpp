@@ -1,6 +1,7 @@
 // fir_table_refresher.cpp -- the worker thread that builds and uploads replacement class tables (fir_table_refresher.h).
 #include "fir_table_refresher.h"
 
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 
@@ -36,9 +37,13 @@ TableRefresher::Table* TableRefresher::add_table(const PeriodicGeometry& geo, st
     return tables_.back().get();
 }
 
-int TableRefresher::request(Table* t, double drift, hipStream_t s) {
-    t->want_drift = drift;
+int TableRefresher::record_guard(Table* t, hipStream_t s) {
     RSMP_HIP_CHECK(hipEventRecord(t->guard, s));
+    return RSMP_OK;
+}
+
+int TableRefresher::request(Table* t, double drift) {
+    t->want_drift = drift;
     t->state.store(kRequested, std::memory_order_release);
     {
         std::lock_guard<std::mutex> lock(mu_);   // (held by the worker only while it takes an entry off the queue)
@@ -83,7 +88,7 @@ int TableRefresher::refresh(Table* t) {
     std::memcpy(h + cb, host.wrap_coef.data(), wb);
     std::memcpy(h + cb + wb, host.meta.data(), mb);
     char* d = t->d_buf[t->next_buf];
-    // the image was bound two replacements ago: what the requester had enqueued by then may still read it
+    // the image was bound until the last replacement: what had been enqueued by then may still read it (record_guard)
     RSMP_HIP_CHECK(hipStreamWaitEvent(copy_stream_, t->guard, 0));
     RSMP_HIP_CHECK(hipMemcpyAsync(d, h, total, hipMemcpyHostToDevice, copy_stream_));
     RSMP_HIP_CHECK(hipStreamSynchronize(copy_stream_));
@@ -114,11 +119,13 @@ void TableRefresher::loop() {
             else
                 device_ready = true;
         }
+        const auto t0 = std::chrono::steady_clock::now();
         if (rc == RSMP_OK) rc = refresh(t);
         static const bool verbose = rsmp::knob("RSMP_FIR_VERBOSE") != nullptr;
         if (verbose)
-            fprintf(stderr, "[rsmp] table refresher: a=%u b=%u drift %.3g -> image %d (%s)\n", t->geo.a, t->geo.b, t->want_drift,
-                    t->next_buf, rc == RSMP_OK ? "ready" : "failed");
+            fprintf(stderr, "[rsmp] table refresher: a=%u b=%u drift %.3g -> image %d (%s) in %.3f ms\n", t->geo.a, t->geo.b, t->want_drift,
+                    t->next_buf, rc == RSMP_OK ? "ready" : "failed",
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
         {
             std::lock_guard<std::mutex> lock(mu_);
             t->state.store(rc == RSMP_OK ? kReady : kFailed, std::memory_order_release);

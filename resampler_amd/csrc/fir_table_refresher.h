@@ -9,8 +9,8 @@
 //
 // Now every refreshable table owns TWO device images, used alternately, and a worker thread per batch does everything
 // slow: the host arithmetic (build_class_table, 0.35-0.7 ms), the first refresh's allocations, the upload on a copy
-// stream of its own (behind an event the requester recorded: what may still read the image's old contents), the wait
-// for it.  The launch path asks (one event record), and later finds an atomic flag set and swaps pointers.  Nothing in
+// stream of its own (behind an event recorded when the image was last unbound: what may still read its old contents),
+// the wait for it.  The launch path asks, and later finds an atomic flag set and swaps pointers (+ one event record).  Nothing in
 // it allocates, copies synchronously, takes a lock another thread holds for long, or waits.
 #pragma once
 
@@ -38,7 +38,7 @@ public:
         size_t coef_bytes = 0, wrap_bytes = 0, meta_bytes = 0;
         int next_buf = 0;                                   // the image the next refresh fills; the other one may be bound
         double want_drift = 0.0;                            // request: written before `state` goes to kRequested
-        hipEvent_t guard = nullptr;                         // request: the work that may still read d_buf[next_buf]
+        hipEvent_t guard = nullptr;                         // the work that may still read d_buf[next_buf] (record_guard)
         ClassTable ready;                                   // result: pointers into d_buf[next_buf] (no `hold`: owned here)
         double ready_drift = 0.0;
         std::atomic<int> state{kIdle};
@@ -52,11 +52,15 @@ public:
 
     // Not on the launch path (batch creation / first run): registers a table; no device work.
     Table* add_table(const PeriodicGeometry& geo, std::shared_ptr<const std::vector<float>> coeffs);
-    // Launch path: have `t` rebuilt for `drift`.  `s`: the stream whose work enqueued so far may still read the image
-    // that will be overwritten (one hipEventRecord).  `t` must be kIdle (or kFailed / kReady with a result nobody wants).
-    int request(Table* t, double drift, hipStream_t s);
-    // Launch path: a kReady result is taken over -- `t` is idle again and its other image is the next to be filled.
+    // Launch path: have `t` rebuilt for `drift`; returns at once.  `t` must be kIdle.
+    int request(Table* t, double drift);
+    // Launch path: a kReady result is taken over -- `t` is idle again and its other image, the one bound until now, is the
+    // next to be filled.  The caller then enqueues whatever was planned with the old image and calls record_guard: the
+    // next refresh overwrites the old image behind that point of stream `s` (recorded at the REPLACEMENT, not at the
+    // next request: the host runs many launches ahead of the device, and an event recorded at request time was reached
+    // 20 ms later -- by when the tables it held back were due).
     ClassTable take(Table* t);
+    int record_guard(Table* t, hipStream_t s);
     // A result nobody wants (the states changed meanwhile): `t` is idle again, the same image is the next to be filled.
     void discard(Table* t) { t->state.store(kIdle, std::memory_order_release); }
     // Blocks until `t` has left kRequested (only where a batch has run 3x past a tolerance without its tables: never
