@@ -87,6 +87,28 @@ __device__ inline uint32_t rfl(uint32_t v) { return static_cast<uint32_t>(__buil
 __device__ inline uint64_t rfl64(uint64_t v) {
     return static_cast<uint64_t>(rfl(static_cast<uint32_t>(v))) | (static_cast<uint64_t>(rfl(static_cast<uint32_t>(v >> 32))) << 32);
 }
+__device__ inline double rl_f64(double v, uint32_t lane) {
+    const uint64_t b = mirror_bits(v);
+    return mirror_from_bits(static_cast<uint64_t>(rl(static_cast<uint32_t>(b), lane)) | (static_cast<uint64_t>(rl(static_cast<uint32_t>(b >> 32), lane)) << 32));
+}
+// Call s of the chunk, whose ChainPlan lane s holds, on the chain of its shape (mirror_chain_step<L, TIES>): the
+// multipliers of the binades in use come over by v_readlane.
+template <bool TIES, uint32_t L = 0>
+__device__ inline uint32_t chain_step_of_shape(uint32_t shape, uint32_t s, const ChainPlan& cp, double& pos, ChainScalars& sc, uint32_t in_frames,
+                                               double ratio, const MirrorBinades& bn, uint32_t n_total, uint32_t ctl, uint32_t n_last) {
+    if constexpr (L < kPredBinades) {
+        if (shape == L) {
+            double m[kPredBinades];
+#pragma unroll
+            for (uint32_t i = 0; i < kPredBinades; ++i) m[i] = i <= L ? rl_f64(cp.m[i], s) : 0.0;
+            return mirror_chain_step<L, TIES>(pos, sc, in_frames, ratio, bn, n_total, ctl, n_last, m);
+        }
+        return chain_step_of_shape<TIES, L + 1>(shape, s, cp, pos, sc, in_frames, ratio, bn, n_total, ctl, n_last);
+    } else {
+        return 0;
+    }
+}
+
 __global__ __launch_bounds__(64) void fir_lockstep_chain_kernel(LsRunArgs a) {
     const uint32_t gs = blockIdx.x, lane = threadIdx.x;
     const LockstepStream ls = a.streams[gs];
@@ -103,8 +125,9 @@ __global__ __launch_bounds__(64) void fir_lockstep_chain_kernel(LsRunArgs a) {
     const uint32_t hist_frames = static_cast<uint32_t>(st.available);
     const bool wraps_exist = rs.wrap_unit == rs.den;   // (a super period of an exact ratio: no output ever wraps)
     RunSink sink{bits, static_cast<uint32_t>(abs_out0 - k0 * rs.wrap_unit), rs.den, a.wrap_words * 32u, wraps_exist, false, false};
-    uint32_t n_out = 0, accepted = 0, consumed = 0, flags = 0;
-    uint32_t last_c0 = 0, last_c1 = 0;
+    uint32_t flags = 0;
+    uint32_t last_c0 = 0, last_c1 = 0, lean_last_n = 0;   // the latest call's counts (a lean call's: in_frames, lean_last_n)
+    bool last_lean = false;
     const uint64_t* preds = reinterpret_cast<const uint64_t*>(a.preds + static_cast<size_t>(gs) * a.k);
     CallRec* recs = reinterpret_cast<CallRec*>(a.call_recs) + static_cast<size_t>(gs) * a.k;
     // the state while the stream runs on the unchecked chain: the f64 position in a vector register, the counters in
@@ -137,10 +160,12 @@ __global__ __launch_bounds__(64) void fir_lockstep_chain_kernel(LsRunArgs a) {
         // ---- the lanes' part: which of these 64 calls may take the unchecked chain, and which continue their predecessor
         const uint32_t my_call = c0 + lane;
         const uint32_t my_n_total = static_cast<uint32_t>(mine[2]);
-        const uint32_t my_ties = static_cast<uint32_t>(mine[2] >> 48);
+        MirrorPred my_pr;
+        __builtin_memcpy(&my_pr, mine, sizeof my_pr);
+        const ChainPlan my_cp = mirror_chain_plan(my_pr);   // (what the chain needs of this lane's call: multipliers, shape)
         // frames buffered when call j starts, IF the stream is on the prediction's track there: accepted - retired
         const uint64_t my_avail = frames0 + static_cast<uint64_t>(my_call) * a.in_frames - mine[1];
-        const bool my_struct_ok = lane < nc && my_ties == 0 && my_n_total + 1 < out_cap && my_avail + a.in_frames <= kMirrorInputCapacity;
+        const bool my_struct_ok = lane < nc && (my_cp.ctl & kChainLean) && my_n_total + 1 < out_cap && my_avail + a.in_frames <= kMirrorInputCapacity;
         const bool my_last = my_call + 1 >= a.k;
         const bool my_succ_ok = my_last || succ[0] == mine[0] + my_n_total;
         const uint32_t my_cpred = static_cast<uint32_t>(succ[1] - mine[1]);   // frames the prediction has the call retire
@@ -168,20 +193,15 @@ __global__ __launch_bounds__(64) void fir_lockstep_chain_kernel(LsRunArgs a) {
                                       rfl(static_cast<uint32_t>(st.available))};
                     st_valid = false;
                 }
-                const uint32_t n_total = rl(static_cast<uint32_t>(mine[2]), s);
-                const uint32_t n_low = rl(static_cast<uint32_t>(mine[2] >> 32), s) & 0xFFFFu;
-                const uint32_t q[6] = {rl(static_cast<uint32_t>(mine[4]), s), rl(static_cast<uint32_t>(mine[4] >> 32), s),
-                                       rl(static_cast<uint32_t>(mine[5]), s), rl(static_cast<uint32_t>(mine[5] >> 32), s),
-                                       rl(static_cast<uint32_t>(mine[6]), s), rl(static_cast<uint32_t>(mine[6] >> 32), s)};
+                const uint32_t n_total = rl(my_n_total, s);
+                const uint32_t ctl = rl(my_cp.ctl, s), n_last = rl(my_cp.n_last, s);
                 const uint32_t cpred = rl(my_cpred, s);
-                const uint32_t cons = mirror_chain_lean(pos, sc, a.in_frames, ratio, bn, n_total, n_low, q);
+                const uint32_t shape = (ctl >> 8) & 0xFu;
+                const uint32_t cons = (ctl & 0xFFF000u) ? chain_step_of_shape<true>(shape, s, my_cp, pos, sc, a.in_frames, ratio, bn, n_total, ctl, n_last)
+                                                        : chain_step_of_shape<false>(shape, s, my_cp, pos, sc, a.in_frames, ratio, bn, n_total, ctl, n_last);
                 on_track = cons == cpred && ((succ_mask >> s) & 1ull);
-                last_c0 = a.in_frames * C;
-                last_c1 = n_total * C;
-                n_out += n_total;
-                accepted += a.in_frames;
-                consumed += cons;
-                sink.rel += n_total;
+                lean_last_n = n_total;     // (the run's totals follow from the counters at its end, see below)
+                last_lean = true;
                 continue;
             }
             // ---- off the track: round 4's path (every premise checked, or the plain state machine)
@@ -211,6 +231,7 @@ __global__ __launch_bounds__(64) void fir_lockstep_chain_kernel(LsRunArgs a) {
             FirCallCounts c;
             if (!base.usable || !mirror_call_fast(st, a.in_frames, ls.out_cap_frames, pr, bn, c, [](uint32_t, uint32_t, double, double) {})) {
                 const uint32_t ni = st.next_int;
+                sink.rel = static_cast<uint32_t>(st.abs_out - k0 * rs.wrap_unit);   // (the call's first output, relative to the bitmap's start)
                 sink.periodic = wraps_exist && st.periodic_ok != 0;
                 c = mirror_call(st, a.in_frames, ls.out_cap_frames, sink);
                 cf = kCallSlow | (ni < c.produced ? kCallHasInt : 0u);
@@ -226,10 +247,7 @@ __global__ __launch_bounds__(64) void fir_lockstep_chain_kernel(LsRunArgs a) {
             my_flags = me ? cf : my_flags;
             my_c0 = me ? last_c0 : my_c0;
             my_c1 = me ? last_c1 : my_c1;
-            n_out += static_cast<uint32_t>(c.produced);
-            accepted += static_cast<uint32_t>(c.accepted);
-            consumed += static_cast<uint32_t>(c.consumed);
-            sink.rel += static_cast<uint32_t>(c.produced);
+            last_lean = false;
         }
         if (!st_valid) lean_ni_after = rl(static_cast<uint32_t>(mine[3] >> 32), nc - 1);   // (the latest call's ni_after, should the run end here)
         if (lane < nc) {
@@ -250,6 +268,15 @@ __global__ __launch_bounds__(64) void fir_lockstep_chain_kernel(LsRunArgs a) {
     }
     if (lane != 0) return;
     if (sink.overflow) flags |= kLsStatusRunOverflow;
+    // the run's totals, from the counters it ends with: outputs, frames retired, frames accepted (= retired + what the
+    // buffered frames grew by)
+    const uint32_t n_out = static_cast<uint32_t>(st.abs_out - abs_out0);
+    const uint32_t consumed = static_cast<uint32_t>(st.abs_consumed - abs_consumed0);
+    const uint32_t accepted = static_cast<uint32_t>(st.abs_consumed + st.available - abs_consumed0 - hist_frames);
+    if (last_lean) {
+        last_c0 = a.in_frames * C;
+        last_c1 = lean_last_n * C;
+    }
 
     // the calls' outputs follow each other: behind what was appended before, or (no `append`) from the front of `out`
     const uint64_t cursor = a.append ? a.cursor_in[gs] : 0;

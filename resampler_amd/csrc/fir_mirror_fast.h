@@ -273,27 +273,79 @@ __host__ __device__ inline void mirror_call_chain(FirMirrorState& st, uint32_t i
     out = FirCallCounts{in_frames, pr.n_total, consumed};
 }
 
-// The same call with the integer half of the stream's state held apart (on the device: in SCALAR registers, updated by
-// the scalar unit in the shadow of the f64 chain's latency) and the prediction taken as the packed words the planner's
-// lanes hold: q[0 .. 5] = MirrorPred::n[12] as 16-bit halves.  The chain kernel's round-4 form spent 220 instructions a
-// call on a lone wave (fourteen v_readlane to rebuild a MirrorPred, 64-bit vector arithmetic for the counters, five
-// lane selects for the record: 0.91 us); this is ~25 dependent f64 operations and as many scalar ones.  Bit for bit
-// mirror_call_chain: the same rounded adds in the same order; min(floor(pos), avail) taken in f64 (exact: both are
-// integers below 2^53).  Returns the frames the call retires.
+// ---- the chain kernel's form of a call (round 5) ---------------------------------------------------------------------------
+// A lone wave issues an instruction every ~4 ns whatever it is, so a call costs what it ISSUES: round 4's loop rebuilt a
+// MirrorPred from fourteen v_readlane, kept the counters in 64-bit vector arithmetic and branched per binade -- 220
+// instructions, 0.91 us, the Amdahl term of a shard.  Here the lanes prepare, for 64 calls at a time
+// and in parallel, what the serial chain needs per call (ChainPlan: the closed form's multipliers as f64, the shape of
+// the call as two control words), the integer half of the state lives apart (on the device: in SCALAR registers, updated
+// by the scalar unit in the shadow of the f64 latency), and the chain itself is unrolled for the call's shape: the
+// binades below the top one are full (>= 4 outputs each: two instructions), the top one is cut by the call's limit.
+// Calls with an output EXACTLY at a binade's edge (5 % of config 4's: an integer position that is a power of two, where
+// the f64 drift decides which binade's grid the add before it rounds on) take the same chain with that one comparison per
+// marked binade (TIES); the rest of mirror_call_fast's checks are made by the replay of the call, as for every call of
+// the unchecked chain.  Bit for bit mirror_call_chain / mirror_call_fast: the same rounded operations in the same order;
+// min(floor(pos), avail) is taken in f64 (exact: both are integers below 2^53).
 struct ChainScalars {
     uint64_t abs_out, abs_consumed;
     uint32_t read_position, available;
 };
-__host__ __device__ inline uint32_t mirror_chain_lean(double& pos_io, ChainScalars& sc, uint32_t in_frames, double ratio,
-                                                      const MirrorBinades& bn, uint32_t n_total, uint32_t n_low,
-                                                      const uint32_t (&q)[6]) {
-    double pos = pos_io;
-    for (uint32_t k = 0; k < n_low; ++k) pos += ratio;
+constexpr uint32_t kChainLean = 1u << 31;
+struct ChainPlan {
+    double m[kPredBinades];   // binade i: n_i - 1 as f64 where n_i >= 3 (the closed form's multiplier), else 0
+    uint32_t ctl;             // bits 0-7 n_low, 8-11 L (the top non-empty binade), 12-23 the prediction's tie bits, 31 kChainLean
+    uint32_t n_last;          // outputs in binade L
+};
+// What a call's prediction says about the chain's shape.  kChainLean: the chain below applies -- no output at the call's
+// limit, no clamped count, the binades below the top one full, n_low small.
+__host__ __device__ inline ChainPlan mirror_chain_plan(const MirrorPred& pr) {
+    ChainPlan p;
+    uint32_t top = 0;
+    bool any = false, full = true;
 #pragma unroll
     for (uint32_t i = 0; i < kPredBinades; ++i) {
-        const uint32_t n = (q[i >> 1] >> (16u * (i & 1u))) & 0xFFFFu;
-        if (n >= 3) {
-            pos = fma(static_cast<double>(n - 1), bn.inc[i], pos) + ratio;
+        const uint32_t n = pr.n[i];
+        p.m[i] = n >= 3 ? static_cast<double>(n - 1) : 0.0;
+        if (n != 0) { top = i; any = true; }
+    }
+#pragma unroll
+    for (uint32_t i = 0; i < kPredBinades; ++i)
+        if (i < top && pr.n[i] < 4) full = false;   // (a binade below the top one: >= 4, so that a tie's single add leaves >= 3)
+    const bool lean = any && full && pr.n_low < 256 && (pr.ties & (kPredLimitTie | kPredIrregular)) == 0;
+    p.ctl = pr.n_low | (top << 8) | ((pr.ties & 0xFFFu) << 12) | (lean ? kChainLean : 0u);
+    p.n_last = pr.n[top];
+    return p;
+}
+// One call of shape L (ctl bits 8-11): the f64 chain on `pos`, then what the call retires (:596-615).  `m[i]`, i <= L, and
+// the two control words are the call's ChainPlan (on the device: v_readlane of the lane that holds it).  Returns the frames
+// the call retires.
+template <uint32_t L, bool TIES>
+__host__ __device__ inline uint32_t mirror_chain_step(double& pos_io, ChainScalars& sc, uint32_t in_frames, double ratio,
+                                                      const MirrorBinades& bn, uint32_t n_total, uint32_t ctl, uint32_t n_last,
+                                                      const double (&m)[kPredBinades]) {
+    double pos = pos_io;
+    for (uint32_t k = ctl & 0xFFu; k != 0; --k) pos += ratio;
+    double half = bn.half0;
+#pragma unroll
+    for (uint32_t i = 0; i < L; ++i, half += half) {   // full binades
+        if (TIES && ((ctl >> (12 + i)) & 1u) && pos < half) {
+            // the binade's first output, exactly at `half` in exact arithmetic, is a hair below it in f64: still the lower
+            // binade's -- one plain add (mirror_call_fast: `pre`)
+            pos += ratio;
+            pos = fma(m[i] - 1.0, bn.inc[i], pos) + ratio;
+        } else {
+            pos = fma(m[i], bn.inc[i], pos) + ratio;
+        }
+    }
+    {   // the top binade, cut by the call's limit: any count >= 1
+        uint32_t n = n_last;
+        if (TIES && ((ctl >> (12 + L)) & 1u) && pos < half) {
+            pos += ratio;
+            n -= 1;
+            if (n >= 3) pos = fma(static_cast<double>(n - 1), bn.inc[L], pos) + ratio;
+            else for (uint32_t k = 0; k < n; ++k) pos += ratio;
+        } else if (n >= 3) {
+            pos = fma(m[L], bn.inc[L], pos) + ratio;
         } else {
             for (uint32_t k = 0; k < n; ++k) pos += ratio;
         }
@@ -314,6 +366,17 @@ __host__ __device__ inline uint32_t mirror_chain_lean(double& pos_io, ChainScala
     sc.abs_out += n_total;
     sc.abs_consumed += consumed;
     return consumed;
+}
+// (host: the shape as a run-time value)
+template <bool TIES, uint32_t L = 0>
+__host__ inline uint32_t mirror_chain_step_any(uint32_t shape, double& pos, ChainScalars& sc, uint32_t in_frames, double ratio,
+                                               const MirrorBinades& bn, uint32_t n_total, const ChainPlan& p) {
+    if constexpr (L < kPredBinades) {
+        if (shape == L) return mirror_chain_step<L, TIES>(pos, sc, in_frames, ratio, bn, n_total, p.ctl, p.n_last, p.m);
+        return mirror_chain_step_any<TIES, L + 1>(shape, pos, sc, in_frames, ratio, bn, n_total, p);
+    } else {
+        return 0;
+    }
 }
 
 // The outputs at integer positions of one call done by mirror_call_fast, found by replaying it from its start state

@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <numeric>
 
@@ -155,7 +156,7 @@ extern "C" int rsmp_fir_plan_selftest_fast(rsmp_fir_plan* p, size_t in_frames, s
     };
     rsmp::FirMirrorState ref = p->mirror.state(), fast = ref;
     const uint64_t cap = p->mirror.buffer_size_output_frames();
-    size_t bad = 0, slow = 0, n_lean = 0;
+    size_t bad = 0, slow = 0, n_lean = 0, off_track = 0;
     std::vector<uint64_t> w_ref, w_fast;
     for (size_t done = 0; done < calls; done += run_len) {
         const uint32_t len = static_cast<uint32_t>(std::min(run_len, calls - done));
@@ -179,20 +180,29 @@ extern "C" int rsmp_fir_plan_selftest_fast(rsmp_fir_plan* p, size_t in_frames, s
                     rsmp::FirMirrorState lean = before;
                     rsmp::FirCallCounts c_lean{};
                     rsmp::mirror_call_chain(lean, static_cast<uint32_t>(in_frames), pr, bn, c_lean);
-                    ++n_lean;
                     if (std::memcmp(&lean, &fast, sizeof lean) != 0 || c_lean.produced != c_fast.produced ||
                         c_lean.consumed != c_fast.consumed)
                         ++bad;
-                    // ... and the chain kernel's form of it (the counters apart, the prediction as packed words)
+                }
+                // ... and the chain kernel's form of it (the counters apart, the call's shape unrolled; calls with an output
+                // exactly at a binade's edge included), where the kernel takes it: on the prediction's track
+                const rsmp::ChainPlan cp = rsmp::mirror_chain_plan(pr);
+                if (took_fast && (cp.ctl & rsmp::kChainLean) && chain_ready && before.abs_out == pr.m0 && before.abs_consumed == pr.c0 &&
+                    pr.n_total + 1 < cap) {
                     rsmp::ChainScalars sc{before.abs_out, before.abs_consumed, static_cast<uint32_t>(before.read_position),
                                           static_cast<uint32_t>(before.available)};
-                    uint32_t q[6];
-                    std::memcpy(q, pr.n, sizeof q);
                     double pos = before.position;
-                    const uint32_t cons = rsmp::mirror_chain_lean(pos, sc, static_cast<uint32_t>(in_frames), before.ratio, bn,
-                                                                  pr.n_total, pr.n_low, q);
-                    if (cons != c_fast.consumed || std::memcmp(&pos, &fast.position, sizeof pos) != 0 || sc.abs_out != fast.abs_out ||
-                        sc.abs_consumed != fast.abs_consumed || sc.read_position != fast.read_position ||
+                    const uint32_t shape = (cp.ctl >> 8) & 0xFu;
+                    const bool ties = ((cp.ctl >> 12) & 0xFFFu) != 0;
+                    const uint32_t cons = ties ? rsmp::mirror_chain_step_any<true>(shape, pos, sc, static_cast<uint32_t>(in_frames), before.ratio, bn, pr.n_total, cp)
+                                               : rsmp::mirror_chain_step_any<false>(shape, pos, sc, static_cast<uint32_t>(in_frames), before.ratio, bn, pr.n_total, cp);
+                    ++n_lean;
+                    if (c + 1 < len) {   // (diagnostic: does the next call's prediction start where this call ends?)
+                        const rsmp::MirrorPred nx = rsmp::mirror_predict(base, c + 1);
+                        if (nx.c0 - pr.c0 != cons || nx.m0 != pr.m0 + pr.n_total) ++off_track;
+                    }
+                    if (cons != c_fast.consumed || c_fast.produced != pr.n_total || std::memcmp(&pos, &fast.position, sizeof pos) != 0 ||
+                        sc.abs_out != fast.abs_out || sc.abs_consumed != fast.abs_consumed || sc.read_position != fast.read_position ||
                         sc.available != fast.available || pr.ni_after != fast.next_int)
                         ++bad;
                 }
@@ -218,5 +228,6 @@ extern "C" int rsmp_fir_plan_selftest_fast(rsmp_fir_plan* p, size_t in_frames, s
     if (mismatches) *mismatches = bad;
     if (slow_calls) *slow_calls = slow;
     if (lean_calls) *lean_calls = n_lean;
+    if (rsmp::knob("RSMP_SELFTEST_VERBOSE")) fprintf(stderr, "[rsmp] selftest: %zu calls, %zu lean, %zu of them leave the prediction's track, %zu slow\n", calls, n_lean, off_track, slow);
     return RSMP_OK;
 }
