@@ -28,15 +28,13 @@ struct RunSink {             // mirror_call sink: the wrapped outputs go straigh
     uint32_t rel;            // (absolute index of the call's first output) - wrap_k0 * den
     uint32_t den, n_bits;
     bool periodic, overflow, atomic;
-    bool whole_wave = false;   // every lane of the wave reports the same output (the chain kernel: uniform control flow): lane 0 sets the bit
     __host__ __device__ bool want_wraps() const { return periodic; }
     __host__ __device__ void run(uint64_t, uint64_t, double, double) {}
     __device__ void wrap(uint64_t index) {
         const uint32_t K = (rel + static_cast<uint32_t>(index)) / den;
         if (K >= n_bits) overflow = true;
-        else if (atomic) {   // (the calls of a stream are replayed in parallel; the chain kernel's words were zeroed by other lanes)
-            if (!whole_wave || (threadIdx.x & 63u) == 0) (void)atomicOr(bits + (K >> 5), 1u << (K & 31));
-        } else bits[K >> 5] |= 1u << (K & 31);
+        else if (atomic) (void)atomicOr(bits + (K >> 5), 1u << (K & 31));   // (the calls of a stream are replayed in parallel)
+        else bits[K >> 5] |= 1u << (K & 31);
     }
 };
 
@@ -47,6 +45,20 @@ struct CallRec {             // what the chain leaves per call for the replay of
     uint32_t flags, pad;
 };
 static_assert(sizeof(CallRec) == 24, "CallRec layout");
+
+// K1 -- the structure of every call of the run, in exact integer arithmetic: one thread per (stream, call).
+__global__ __launch_bounds__(256) void fir_lockstep_predict_kernel(LsRunArgs a) {
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= a.n_streams * a.k) return;
+    const uint32_t gs = t / a.k, c = t - gs * a.k;
+    const MirrorRunBase base = mirror_run_base(a.states_in[gs], a.in_frames, a.k);
+    if (base.usable) a.preds[t] = mirror_predict(base, c);
+    if (c == 0) {
+        a.states_before[gs] = a.states_in[gs];   // (the chain overwrites the states; the replay starts from these)
+        if (a.zero_status) a.zero_status[gs] = 0;
+    }
+    for (uint32_t w = c; w < a.wrap_words; w += a.k) a.wrap_bits[static_cast<size_t>(gs) * a.wrap_words + w] = 0;
+}
 
 // K2 -- the serial chain: one wave per stream walks the stream's k calls.  Every lane runs the chain on the same
 // values, so the control flow stays uniform (scalar branches, no masking).  Predictions and per-call results are staged
@@ -112,7 +124,7 @@ __global__ __launch_bounds__(64) void fir_lockstep_chain_kernel(LsRunArgs a) {
     const uint64_t k0 = abs_out0 / rs.wrap_unit;
     const uint32_t hist_frames = static_cast<uint32_t>(st.available);
     const bool wraps_exist = rs.wrap_unit == rs.den;   // (a super period of an exact ratio: no output ever wraps)
-    RunSink sink{bits, static_cast<uint32_t>(abs_out0 - k0 * rs.wrap_unit), rs.den, a.wrap_words * 32u, wraps_exist, false, true, true};
+    RunSink sink{bits, static_cast<uint32_t>(abs_out0 - k0 * rs.wrap_unit), rs.den, a.wrap_words * 32u, wraps_exist, false, false};
     uint32_t flags = 0;
     uint32_t last_c0 = 0, last_c1 = 0, lean_last_n = 0;   // the latest call's counts (a lean call's: in_frames, lean_last_n)
     bool last_lean = false;
@@ -128,35 +140,23 @@ __global__ __launch_bounds__(64) void fir_lockstep_chain_kernel(LsRunArgs a) {
     uint32_t lean_ni_after = 0;   // next_int behind the latest lean call (scalar; read from the prediction when `st` is filled)
     const uint64_t frames0 = rfl64(base.abs_consumed0 + base.avail0);   // frames accepted before the run
     const uint32_t out_cap = rfl(static_cast<uint32_t>(ls.out_cap_frames < 0xFFFFFFFFull ? ls.out_cap_frames : 0xFFFFFFFFull));
-    // (what round 4's predict kernel did besides predicting)
-    if (lane == 0) {
-        a.states_before[gs] = st;   // the replay of the calls (K3) starts from the state before the run
-        if (a.zero_status) a.zero_status[gs] = 0;
-    }
-    for (uint32_t w = lane; w < a.wrap_words; w += 64) bits[w] = 0;
-    __threadfence();   // (the zeroes are in place before any atomic OR into the words: the slow path's here, the replay's in K3)
-    uint64_t mine[7], succ[2];
+    uint64_t mine[7], ahead[7], succ[2], succ_ahead[2];
+    auto fetch = [&](uint32_t c0, uint64_t (&v)[7], uint64_t (&sv)[2]) {
+        const uint32_t c = c0 + lane < a.k ? c0 + lane : a.k - 1;
+        const uint32_t cn = c + 1 < a.k ? c + 1 : a.k - 1;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) v[i] = __builtin_nontemporal_load(preds + static_cast<size_t>(c) * 7 + i);
+        sv[0] = __builtin_nontemporal_load(preds + static_cast<size_t>(cn) * 7);       // the next call's m0, c0
+        sv[1] = __builtin_nontemporal_load(preds + static_cast<size_t>(cn) * 7 + 1);
+    };
+    fetch(0, ahead, succ_ahead);
     for (uint32_t c0 = 0; c0 < a.k; c0 += 64) {
         const uint32_t nc = a.k - c0 < 64u ? a.k - c0 : 64u;
-        // ---- K1, here: the STRUCTURE of the chunk's 64 calls in exact integer arithmetic, a call per lane
-        // (mirror_predict), left in memory for the replay.  As a kernel of its own (one thread per stream and call,
-        // round 4) it took 10 us alone and 72 us beside the bulk kernels of the run before -- eighteen 64-bit divisions
-        // of code that the split kernel's sixteen differently-programmed waves keep evicting from the instruction
-        // cache -- in front of a chain that takes 100: in a shard of 128 streams the planner IS the run's period.
-        {
-            const uint32_t c = c0 + lane < a.k ? c0 + lane : a.k - 1;
-            MirrorPred pr;
-            __builtin_memset(&pr, 0, sizeof pr);
-            if (base.usable) pr = mirror_predict(base, c);
-            __builtin_memcpy(mine, &pr, sizeof pr);
-            if (lane < nc) {
-                uint64_t* dst = const_cast<uint64_t*>(preds) + static_cast<size_t>(c) * 7;
 #pragma unroll
-                for (int i = 0; i < 7; ++i) dst[i] = mine[i];
-            }
-            succ[0] = __shfl_down(static_cast<unsigned long long>(mine[0]), 1, 64);   // the next call's m0, c0 (lane 63: see my_succ_ok)
-            succ[1] = __shfl_down(static_cast<unsigned long long>(mine[1]), 1, 64);
-        }
+        for (int i = 0; i < 7; ++i) mine[i] = ahead[i];
+        succ[0] = succ_ahead[0];
+        succ[1] = succ_ahead[1];
+        if (c0 + 64 < a.k) fetch(c0 + 64, ahead, succ_ahead);
         // ---- the lanes' part: which of these 64 calls may take the unchecked chain, and which continue their predecessor
         const uint32_t my_call = c0 + lane;
         const uint32_t my_n_total = static_cast<uint32_t>(mine[2]);
@@ -167,8 +167,7 @@ __global__ __launch_bounds__(64) void fir_lockstep_chain_kernel(LsRunArgs a) {
         const uint64_t my_avail = frames0 + static_cast<uint64_t>(my_call) * a.in_frames - mine[1];
         const bool my_struct_ok = lane < nc && (my_cp.ctl & kChainLean) && my_n_total + 1 < out_cap && my_avail + a.in_frames <= kMirrorInputCapacity;
         const bool my_last = my_call + 1 >= a.k;
-        // (the chunk's last call has its successor in the next chunk: the track is looked at again there)
-        const bool my_succ_ok = my_last || (lane != 63 && succ[0] == mine[0] + my_n_total);
+        const bool my_succ_ok = my_last || succ[0] == mine[0] + my_n_total;
         const uint32_t my_cpred = static_cast<uint32_t>(succ[1] - mine[1]);   // frames the prediction has the call retire
         const uint64_t lean_mask = __ballot(my_struct_ok && chain_ready);
         const uint64_t succ_mask = __ballot(my_succ_ok);
@@ -183,10 +182,9 @@ __global__ __launch_bounds__(64) void fir_lockstep_chain_kernel(LsRunArgs a) {
                 const uint64_t m0 = static_cast<uint64_t>(rl(static_cast<uint32_t>(mine[0]), s)) | (static_cast<uint64_t>(rl(static_cast<uint32_t>(mine[0] >> 32), s)) << 32);
                 const uint64_t cc0 = static_cast<uint64_t>(rl(static_cast<uint32_t>(mine[1]), s)) | (static_cast<uint64_t>(rl(static_cast<uint32_t>(mine[1] >> 32), s)) << 32);
                 // (... with as many frames buffered as the lanes' closed form has it)
-                const ChainScalars now = st_valid ? ChainScalars{rfl64(st.abs_out), rfl64(st.abs_consumed), rfl(static_cast<uint32_t>(st.read_position)),
-                                                                   rfl(static_cast<uint32_t>(st.available))} : sc;
-                on_track = now.abs_out == m0 && now.abs_consumed == cc0 && now.available == rl(static_cast<uint32_t>(my_avail), s) &&
-                           now.read_position + now.available + a.in_frames <= kMirrorBufferSize;
+                on_track = rfl64(st.abs_out) == m0 && rfl64(st.abs_consumed) == cc0 &&
+                           rfl(static_cast<uint32_t>(st.available)) == rl(static_cast<uint32_t>(my_avail), s) &&
+                           rfl(static_cast<uint32_t>(st.read_position)) + rfl(static_cast<uint32_t>(st.available)) + a.in_frames <= kMirrorBufferSize;
             }
             if (on_track && ((lean_mask >> s) & 1ull)) {
                 if (st_valid) {   // (the counters leave `st`)
@@ -476,6 +474,8 @@ hipError_t launch_fir_lockstep_gather_counts(const uint64_t* last_counts, const 
 
 hipError_t launch_fir_lockstep_plan(const LsRunArgs& args, hipStream_t stream) {
     if (args.n_streams == 0 || args.k == 0) return hipSuccess;
+    const uint32_t threads = args.n_streams * args.k;
+    hipLaunchKernelGGL(fir_lockstep_predict_kernel, dim3((threads + 255) / 256), dim3(256), 0, stream, args);
     hipLaunchKernelGGL(fir_lockstep_chain_kernel, dim3(args.n_streams), dim3(64), 0, stream, args);
     hipLaunchKernelGGL(fir_lockstep_wraps_kernel, dim3(args.n_streams), dim3(64), 0, stream, args);
     return hipGetLastError();
