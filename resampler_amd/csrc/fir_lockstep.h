@@ -168,7 +168,8 @@ struct LsRunArgs {
     uint64_t in_offset;        // frames added to every stream's `in`
     uint32_t n_streams, k, in_frames, wrap_words, append, hist_parity;
 };
-hipError_t launch_fir_lockstep_plan(const LsRunArgs& args, hipStream_t stream);
+// parts: 1 = K1 (the predictions), 2 = K2 + K3 (chain, replay); 3 = all three in `stream`
+hipError_t launch_fir_lockstep_plan(const LsRunArgs& args, hipStream_t stream, int parts = 3);
 // out[c] = states[reps[c]].drift: the drifts the batch's classes are watched by (one thread per class).
 hipError_t launch_fir_lockstep_gather_drift(const FirMirrorState* states, const uint32_t* reps, double* out, uint32_t n,
                                             hipStream_t stream);

@@ -1150,7 +1150,6 @@ extern "C" int rsmp_fir_lockstep_run(rsmp_fir_lockstep* ls, size_t k_steps, size
         if (int rc = pick_plan_stream(ls, s)) return rc;
         repeat = ls->plan_stream != nullptr;
     }
-    RSMP_HIP_CHECK(hipEventRecord(ls->ev_ready, s));   // the states after this run are in place
     if (repeat) {   // (before this run's bulk kernels are launched: the planner starts as soon as the states are there)
         rsmp_fir_lockstep::RunKey nx = key;
         nx.in_offset = key.in_offset + (key.in_offset - ls->prev.in_offset);
@@ -1158,9 +1157,16 @@ extern "C" int rsmp_fir_lockstep_run(rsmp_fir_lockstep* ls, size_t k_steps, size
         nx.seq = ls->run_seq + 1;
         nx.slot = sl ^ 1;
         hipStream_t q = ls->plan_stream;
+        // K1 of the next run -- eighteen 64-bit divisions per call, a kernel of CODE -- goes in front of this run's bulk
+        // kernels on the caller's own stream: alone it takes 10-18 us, beside the split kernel (whose sixteen differently
+        // programmed waves fill the instruction cache two CUs share) 72 us for a shard of 128 streams and 0.5 ms for the
+        // whole batch, in front of a chain that takes 100-200.  It writes the next run's predictions and bitmaps only; the
+        // chain and the replay follow on the plan stream, beside the bulk kernels.
+        if (ls->slot[nx.slot].used) RSMP_HIP_CHECK(hipStreamWaitEvent(s, ls->slot[nx.slot].compute_done, 0));   // (long past: two runs ago)
+        RSMP_HIP_CHECK(rsmp::launch_fir_lockstep_plan(plan_args(nx, true), s, 1));
+        RSMP_HIP_CHECK(hipEventRecord(ls->ev_ready, s));   // the states after this run are in place, the next run's predictions made
         RSMP_HIP_CHECK(hipStreamWaitEvent(q, ls->ev_ready, 0));
-        if (ls->slot[nx.slot].used) RSMP_HIP_CHECK(hipStreamWaitEvent(q, ls->slot[nx.slot].compute_done, 0));   // its buffers are free
-        RSMP_HIP_CHECK(rsmp::launch_fir_lockstep_plan(plan_args(nx, true), q));
+        RSMP_HIP_CHECK(rsmp::launch_fir_lockstep_plan(plan_args(nx, true), q, 2));
         RSMP_HIP_CHECK(hipEventRecord(ls->plan_done, q));
         ls->ahead = nx;
         ls->ahead_inflight = true;

@@ -472,12 +472,14 @@ hipError_t launch_fir_lockstep_gather_counts(const uint64_t* last_counts, const 
     return hipGetLastError();
 }
 
-hipError_t launch_fir_lockstep_plan(const LsRunArgs& args, hipStream_t stream) {
+hipError_t launch_fir_lockstep_plan(const LsRunArgs& args, hipStream_t stream, int parts) {
     if (args.n_streams == 0 || args.k == 0) return hipSuccess;
     const uint32_t threads = args.n_streams * args.k;
-    hipLaunchKernelGGL(fir_lockstep_predict_kernel, dim3((threads + 255) / 256), dim3(256), 0, stream, args);
-    hipLaunchKernelGGL(fir_lockstep_chain_kernel, dim3(args.n_streams), dim3(64), 0, stream, args);
-    hipLaunchKernelGGL(fir_lockstep_wraps_kernel, dim3(args.n_streams), dim3(64), 0, stream, args);
+    if (parts & 1) hipLaunchKernelGGL(fir_lockstep_predict_kernel, dim3((threads + 255) / 256), dim3(256), 0, stream, args);
+    if (parts & 2) {
+        hipLaunchKernelGGL(fir_lockstep_chain_kernel, dim3(args.n_streams), dim3(64), 0, stream, args);
+        hipLaunchKernelGGL(fir_lockstep_wraps_kernel, dim3(args.n_streams), dim3(64), 0, stream, args);
+    }
     return hipGetLastError();
 }
 

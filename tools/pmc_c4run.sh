@@ -11,12 +11,13 @@ for grp in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES" "SQ_WAVE_CYCLES S
   timeout -k 5 300 rocprofv3 --pmc $grp --output-format csv -d "$O/$n" -- python3 "$R/bench.py" --config c4 --c4-k $K --steps $((2*K)) --warmup 0 --spinup-seconds 0 > /dev/null 2> "$O/$n.err"
 done
 python3 - "$O" <<'PY'
-import csv, glob, sys, collections
+import csv, glob, sys, collections, re
 acc = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
 for f in glob.glob(sys.argv[1] + "/*/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].split("(")[0][-40:]
-        if "lockstep" not in k: continue
+        m = re.search(r"fir_lockstep_\w+", r["Kernel_Name"])
+        if not m: continue
+        k = m.group(0)
         acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
         cnt[(k, r["Counter_Name"])] += 1
 for k in acc:
