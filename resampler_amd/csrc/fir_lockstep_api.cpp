@@ -1162,11 +1162,16 @@ extern "C" int rsmp_fir_lockstep_run(rsmp_fir_lockstep* ls, size_t k_steps, size
         // programmed waves fill the instruction cache two CUs share) 72 us for a shard of 128 streams and 0.5 ms for the
         // whole batch, in front of a chain that takes 100-200.  It writes the next run's predictions and bitmaps only; the
         // chain and the replay follow on the plan stream, beside the bulk kernels.
-        if (ls->slot[nx.slot].used) RSMP_HIP_CHECK(hipStreamWaitEvent(s, ls->slot[nx.slot].compute_done, 0));   // (long past: two runs ago)
-        RSMP_HIP_CHECK(rsmp::launch_fir_lockstep_plan(plan_args(nx, true), s, 1));
-        RSMP_HIP_CHECK(hipEventRecord(ls->ev_ready, s));   // the states after this run are in place, the next run's predictions made
+        // (A small batch -- a shard of 128 streams -- is bound by the planner's own chain, not by the bulk kernels: there the
+        // chain should not start beside the big single-round launch, where it runs 1.5x slower, and K1 on the plan stream
+        // delays it by just about that launch: 0.96 against 1.21 us per step; from 256 streams up K1 in front wins, 1024
+        // streams 3.56 -> 3.38 us per step.  profiles/r05/c4_shard_sweep*.txt.)
+        const bool k1_in_front = n >= 256;
+        if (ls->slot[nx.slot].used) RSMP_HIP_CHECK(hipStreamWaitEvent(k1_in_front ? s : q, ls->slot[nx.slot].compute_done, 0));   // its buffers are free (long since)
+        if (k1_in_front) RSMP_HIP_CHECK(rsmp::launch_fir_lockstep_plan(plan_args(nx, true), s, 1));
+        RSMP_HIP_CHECK(hipEventRecord(ls->ev_ready, s));   // the states after this run are in place (and the next run's predictions made)
         RSMP_HIP_CHECK(hipStreamWaitEvent(q, ls->ev_ready, 0));
-        RSMP_HIP_CHECK(rsmp::launch_fir_lockstep_plan(plan_args(nx, true), q, 2));
+        RSMP_HIP_CHECK(rsmp::launch_fir_lockstep_plan(plan_args(nx, true), q, k1_in_front ? 2 : 3));
         RSMP_HIP_CHECK(hipEventRecord(ls->plan_done, q));
         ls->ahead = nx;
         ls->ahead_inflight = true;
