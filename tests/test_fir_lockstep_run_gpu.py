@@ -434,7 +434,9 @@ def test_table_replacements_stay_off_the_launch_path():
     warm = np.array(host_us[8:])
     swap_calls = np.array([h for h, s in zip(host_us[8:], swapped[8:]) if s])
     assert np.median(warm) < 100.0, (np.median(warm), warm.max())
-    assert swap_calls.size and np.median(swap_calls) < 100.0 and swap_calls.max() < 300.0, swap_calls
+    # (the slowest single call: scheduling noise of a shared host reaches a few hundred us; the launch path this replaces
+    # held the thread for 3-6 ms per crossing)
+    assert swap_calls.size and np.median(swap_calls) < 100.0 and swap_calls.max() < 1000.0, swap_calls
     ls.sync()
     for h, r in zip(hs, refs):
         assert h.state() == r.state()
