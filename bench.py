@@ -350,6 +350,11 @@ def traffic_from_profiles(name: str, kernel_name=None):
         return None
     if kernel_name is not None and ent.get("kernel") not in (None, kernel_name):
         return None   # the counters were collected for another kernel
+    # ... or for other SOURCES of it: the profile names the kernel sources it was taken with, and a kernel changed since
+    # reports no traffic rather than the old one (tools/profile_round.sh renews it)
+    from resampler_amd import provenance
+    if ent.get("kernel_sources_sha") != provenance.kernel_sources_sha(name):
+        return None
     return ent.get("hbm_bytes_per_launch")
 
 
@@ -460,7 +465,7 @@ def bench_fft(ctx: Ctx, args, steps: int, warmup: int, with_cpu: bool):
     dt, _ = timed(ctx, step, steps, max(1, warmup))
     hs[0].set_profiling(True)
     k = []
-    for _ in range(8):
+    for _ in range(32):
         step()
         k.append(hs[0].last_kernel_ms())
     hs[0].set_profiling(False)
@@ -479,7 +484,9 @@ def bench_fft(ctx: Ctx, args, steps: int, warmup: int, with_cpu: bool):
         "roofline": {"bound": "hbm", "kernel": "fft_ola_wave_kernel (wave per transform, 1176/1280 plan)",
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic_from_profiles("fft"),
-                     "kernel_ms": round(k_ms, 4), "algorithmic_bytes": int(alg_bytes)},
+                     "kernel_ms": round(k_ms, 4), "kernel_ms_median": round(float(np.median(k)), 4),
+                     "kernel_ms_max": round(float(np.max(k)), 4), "kernel_launches_timed": len(k),
+                     "algorithmic_bytes": int(alg_bytes)},
     }
     copy_gbs = device_copy_gbs(ctx, alg_bytes / 2)
     line["roofline"]["device_copy"] = round(copy_gbs, 1)
@@ -715,12 +722,13 @@ def secondary_lines(ctx: Ctx, args):
     """N = 1 only: the other figures the headline line is read against."""
     import resampler_amd as ra
     sec = {}
-    fft = bench_fft(ctx, args, steps=min(args.steps, 20), warmup=2, with_cpu=not args.no_cpu)
+    fft = bench_fft(ctx, args, steps=120, warmup=2, with_cpu=not args.no_cpu)   # (120 launches: ~60 ms)
     sec["fft"] = {"metric": fft["metric"], "value": fft["value"], "unit": fft["unit"],
                   "ms_per_step": fft["ms_per_step"], "workload": fft["config"]["workload"],
                   "roofline": fft["roofline"], "cpu_baseline": fft.get("cpu_baseline")}
-    sec["fir_exact_f32"] = fir_kernel_point(ctx, ra, args, ra.FirKernel.PeriodicF32, 16)
-    sec["fir_vector_no_mfma"] = fir_kernel_point(ctx, ra, args, ra.FirKernel.PeriodicVector, 16)
+    # (64 profiled launches each: 25-30 ms of kernel time behind half a second of spin-up)
+    sec["fir_exact_f32"] = fir_kernel_point(ctx, ra, args, ra.FirKernel.PeriodicF32, 64)
+    sec["fir_vector_no_mfma"] = fir_kernel_point(ctx, ra, args, ra.FirKernel.PeriodicVector, 64)
     # the split kernel with every f32 operand cut EXACTLY into three bf16 planes (six products per term): a knob the
     # library reads once per process, so a child runs the same headline launch with it
     try:
@@ -734,7 +742,7 @@ def secondary_lines(ctx: Ctx, args):
     except Exception as e:   # (the headline does not depend on it)
         sec["fir_split_bf16x3"] = {"error": repr(e)[:200]}
     # other channel counts on the default kernel (same rate pair and taps)
-    sec["fir_channels"] = {str(c): fir_channels_point(ctx, ra, args, c, 8) for c in (1, 4, 8)}
+    sec["fir_channels"] = {str(c): fir_channels_point(ctx, ra, args, c, 64) for c in (1, 4, 8)}
     # the same launch with every stream in a different state: nothing shares a plan
     t0 = time.perf_counter()
     handles, batch = make_fir_batch(ctx, ra, args.streams, args.frames, args.chunk, ra.FirKernel.Auto,
@@ -763,7 +771,7 @@ def secondary_lines(ctx: Ctx, args):
     del batch, handles
     c4 = bench_c4(ctx, args, steps=256 * 64, warmup=256 * 2)   # (64 launches of the configuration's 256 steps: ~60 ms)
     sec["config4"] = {k: c4[k] for k in ("metric", "value", "unit", "ms_per_step", "scaling", "dtype", "config", "roofline")}
-    c5 = bench_c5(ctx, args, steps=10, warmup=2)
+    c5 = bench_c5(ctx, args, steps=72, warmup=2)   # (72 launches: ~53 ms)
     sec["config5"] = {k: c5[k] for k in ("metric", "value", "unit", "ms_per_step", "scaling", "dtype", "config", "roofline")}
     return sec
 
@@ -818,11 +826,12 @@ def bench_c5(ctx: Ctx, args, steps: int, warmup: int):
     spinup(ctx, step, args.spinup_seconds)
     dt, host_dt = timed(ctx, step, steps, warmup)
     h.set_profiling(True)
-    for _ in range(8):
+    k_list = []
+    for _ in range(32):
         step()
-    k_ms, _ = h.mean_kernel_ms()
+        k_list.append(h.last_kernel_ms())
     h.set_profiling(False)
-    k_ms = ctx.max_over_ranks(k_ms)
+    k_ms = ctx.max_over_ranks(float(np.mean(k_list)))
     # the same stream call by call (what a live 8-channel feed does): latency of one 512-frame resample() on
     # HBM-resident buffers, call + wait, rank 0 only
     lat = None
@@ -862,7 +871,9 @@ def bench_c5(ctx: Ctx, args, steps: int, warmup: int):
                      "unit": "GB/s", "frac": round(ach / (HBM_PEAK_GBS * ctx.world), 4),
                      "traffic": traffic_from_profiles("c5", variant) if frames == 57_600_000 and ctx.world == 1 else None,
                      "kernel_variant": h.kernel_variant(),
-                     "kernel_ms": round(k_ms, 4), "algorithmic_bytes": int(alg)},
+                     "kernel_ms": round(k_ms, 4), "kernel_ms_median": round(float(np.median(k_list)), 4),
+                     "kernel_ms_max": round(float(np.max(k_list)), 4), "kernel_launches_timed": len(k_list),
+                     "algorithmic_bytes": int(alg)},
     }
 
 
@@ -918,6 +929,12 @@ def main() -> int:
                 line["cpu_baseline"] = cpu_baseline_fir(args.frames, args.cpu_seconds, args.cpu_all_cores_seconds)
             if not args.no_secondary:
                 line["secondary"] = secondary_lines(ctx, args)
+                # both arithmetic classes side by side in the headline's own roofline: `frac` is the shipping kernel (f32
+                # operands cut into two fp16 planes, f32 accumulation on the matrix cores); the reference's arithmetic
+                # class -- every product an f32 FMA -- reaches frac_exact_f32 (matrix cores) / frac_vector_no_mfma
+                # (north_star's "no MFMA" form) on the same workload in the same run
+                line["roofline"]["frac_exact_f32"] = line["secondary"]["fir_exact_f32"]["frac"]
+                line["roofline"]["frac_vector_no_mfma"] = line["secondary"]["fir_vector_no_mfma"]["frac"]
     if ctx.rank == 0:
         os.write(real_stdout, (json.dumps(line) + "\n").encode())
     ctx.close()

@@ -10,6 +10,9 @@ import json
 import os
 import sys
 
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from resampler_amd import provenance
+
 raw, out = sys.argv[1], sys.argv[2]
 KERNELS = {"fir": ("fir_split", "fir_periodic"), "fft": ("fft_ola",), "c4": ("fir_lockstep",), "c5": ("fir_split", "fir_periodic")}
 BENCH = {"fir": "bench_n1.json", "fft": "bench_fft.json", "c4": "bench_c4.json", "c5": "bench_c5.json"}
@@ -57,7 +60,9 @@ for w, names in KERNELS.items():
                "ratio_traffic_to_algorithmic": (fetch + write) / alg if alg else None}
         json.dump(ent, open(os.path.join(out, f"traffic_{w}.json"), "w"), indent=1)
         latest[w] = {"hbm_bytes_per_launch": int((fetch + write) / kk), "kernel": roof.get("kernel"),
-                     "source": f"profiles/<tag>/traffic_{w}.json"}
+                     "source": f"profiles/<tag>/traffic_{w}.json",
+                     # the kernel sources the counters belong to: bench.py reports the traffic only while it runs these
+                     "kernel_sources_sha": provenance.kernel_sources_sha(w)}
         if kk > 1:   # (bench.py's config-4 line is per 512-frame step: the run's traffic / its steps)
             latest[w]["steps_per_launch"] = kk
             latest[w]["hbm_bytes_per_run"] = int(fetch + write)
