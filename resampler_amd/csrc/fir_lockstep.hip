@@ -89,7 +89,8 @@ struct PlanLds {             // one stream's step, in LDS
 static_assert(sizeof(PlanLds) == 64, "PlanLds layout");
 
 static_assert(sizeof(FirMirrorState) == 88, "the stash holds 16 states of 88 bytes in 16 x 96 bytes: the last 128 bytes are the column peaks");
-constexpr uint32_t kLsPeakOff = kLsMaxSlots * 64 + kLsSyncBytes + kLsMaxSlots * 88;   // colpeak[16], peak counter (17 of the 32 spare words)
+constexpr uint32_t kLsPeakOff = kLsMaxSlots * 64 + kLsSyncBytes + kLsMaxSlots * 88;   // colpeak[16] (channel 0), peak counter, the columns' scales: channel 0 (4 words), channel 1 (4 words)
+constexpr uint32_t kLsPeak1Off = kLsMaxSlots * 64 + kLsSyncBytes + kLsMaxSlots * 96;  // colpeak1[16]: channel 1 (round 5: a scale per channel, as fir_split.hip)
 
 struct ColLds {              // one column of the matrix product: super period q of a stream
     int32_t frame0;          // span-relative frame of absolute input frame q * a
@@ -110,7 +111,7 @@ struct LsLayout {
 __host__ __device__ inline LsLayout ls_layout(uint32_t slots, uint32_t max_cols, uint32_t wrap_words,
                                               uint32_t wrap_cap, uint32_t data_bytes) {
     LsLayout l;
-    l.ptrs = kLsMaxSlots * 64 + kLsSyncBytes + kLsMaxSlots * 96;  // PlanLds[16], sync words, state stash[16]
+    l.ptrs = kLsMaxSlots * 64 + kLsSyncBytes + kLsMaxSlots * 96 + 64;  // PlanLds[16], sync words, state stash[16], channel 1's column peaks
     l.colsrc = l.ptrs + kLsMaxSlots * 32;                         // (hist, in, hist_next) pointers per slot
     l.cols = l.colsrc + 16 * 32;                                  // split: where each of the 16 columns' frames come from
     l.segs = (l.cols + max_cols * 16 + 7) & ~7u;
@@ -207,7 +208,7 @@ __device__ __forceinline__ float ls_f16_hi(uint32_t w) { return static_cast<floa
 template <uint32_t NK, uint32_t ROWB>   // 32-tap steps of the tile window and the row pitch: compile-time, so that step s + 1's
                                         // reads are in flight under step s's MFMAs and every offset is an immediate
 __device__ __forceinline__ void unit_mfma_split_nk(const v4f (&a_reg)[kLsMaxBlk], char* lds, uint32_t image_off,
-                                                   uint32_t base_row, uint32_t lane, float os, v4f& acc0, v4f& acc1) {
+                                                   uint32_t base_row, uint32_t lane, float os, float os1, v4f& acc0, v4f& acc1) {
     const uint32_t grp = lane >> 4, q = (lane >> 2) & 3, pc = lane & 3;
     const uint32_t row0 = base_row + 4 * grp + q;
     const uint32_t base = image_off + row0 * ROWB + ((pc ^ ((row0 >> 2) & 3)) << 3);
@@ -228,25 +229,25 @@ __device__ __forceinline__ void unit_mfma_split_nk(const v4f (&a_reg)[kLsMaxBlk]
         acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(c1, x1, acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(c1, y1, acc1, 0, 0, 0);
     }
-    acc0 *= os;   // the lane's column's scale and the taps' 2^13, undone
-    acc1 *= os;
+    acc0 *= os;    // the lane's column's scale (channel 0) and the taps' 2^13, undone
+    acc1 *= os1;   // ... channel 1's
 }
 template <uint32_t ROWB>
 __device__ __forceinline__ void unit_mfma_split_rb(const v4f (&a_reg)[kLsMaxBlk], uint32_t nk, char* lds, uint32_t image_off,
-                                                   uint32_t base_row, uint32_t lane, float os, v4f& acc0, v4f& acc1) {
+                                                   uint32_t base_row, uint32_t lane, float os, float os1, v4f& acc0, v4f& acc1) {
     switch (nk) {   // (workgroup-uniform)
-        case 1: unit_mfma_split_nk<1, ROWB>(a_reg, lds, image_off, base_row, lane, os, acc0, acc1); break;
-        case 2: unit_mfma_split_nk<2, ROWB>(a_reg, lds, image_off, base_row, lane, os, acc0, acc1); break;
-        case 3: unit_mfma_split_nk<3, ROWB>(a_reg, lds, image_off, base_row, lane, os, acc0, acc1); break;
-        case 4: unit_mfma_split_nk<4, ROWB>(a_reg, lds, image_off, base_row, lane, os, acc0, acc1); break;
-        case 5: unit_mfma_split_nk<5, ROWB>(a_reg, lds, image_off, base_row, lane, os, acc0, acc1); break;
-        default: unit_mfma_split_nk<kLsMaxK32, ROWB>(a_reg, lds, image_off, base_row, lane, os, acc0, acc1); break;
+        case 1: unit_mfma_split_nk<1, ROWB>(a_reg, lds, image_off, base_row, lane, os, os1, acc0, acc1); break;
+        case 2: unit_mfma_split_nk<2, ROWB>(a_reg, lds, image_off, base_row, lane, os, os1, acc0, acc1); break;
+        case 3: unit_mfma_split_nk<3, ROWB>(a_reg, lds, image_off, base_row, lane, os, os1, acc0, acc1); break;
+        case 4: unit_mfma_split_nk<4, ROWB>(a_reg, lds, image_off, base_row, lane, os, os1, acc0, acc1); break;
+        case 5: unit_mfma_split_nk<5, ROWB>(a_reg, lds, image_off, base_row, lane, os, os1, acc0, acc1); break;
+        default: unit_mfma_split_nk<kLsMaxK32, ROWB>(a_reg, lds, image_off, base_row, lane, os, os1, acc0, acc1); break;
     }
 }
 __device__ __forceinline__ void unit_mfma_split(const v4f (&a_reg)[kLsMaxBlk], uint32_t nk, uint32_t row_bytes, char* lds,
-                                                uint32_t image_off, uint32_t base_row, uint32_t lane, float os, v4f& acc0, v4f& acc1) {
-    if (row_bytes == kLsImageRowBytes) unit_mfma_split_rb<kLsImageRowBytes>(a_reg, nk, lds, image_off, base_row, lane, os, acc0, acc1);
-    else unit_mfma_split_rb<kLsImageRowBytesPacked>(a_reg, nk, lds, image_off, base_row, lane, os, acc0, acc1);
+                                                uint32_t image_off, uint32_t base_row, uint32_t lane, float os, float os1, v4f& acc0, v4f& acc1) {
+    if (row_bytes == kLsImageRowBytes) unit_mfma_split_rb<kLsImageRowBytes>(a_reg, nk, lds, image_off, base_row, lane, os, os1, acc0, acc1);
+    else unit_mfma_split_rb<kLsImageRowBytesPacked>(a_reg, nk, lds, image_off, base_row, lane, os, os1, acc0, acc1);
 }
 // the scale of a column whose largest sample has biased exponent e (clamped: see colpeak): 2^(141 - e) puts that
 // sample into [2^14, 2^15), inside fp16; and the factor that takes the column's sums back (2^13: the taps)
@@ -328,22 +329,24 @@ __global__ __launch_bounds__(kLsWaves * 64, kLsWaves / 2) void fir_lockstep_kern
     //   * a step without a prediction for every stream of the workgroup (the first step) scans first: the staging waves
     //     meet at a count and take the exact peaks.
     uint32_t* colpeak = reinterpret_cast<uint32_t*>(lds + kLsPeakOff);   // [16]: bits of the largest |sample| of the column's stream; [16]: a count; [17..20]: the exponents the columns were scaled for
-    uint8_t* colscale = reinterpret_cast<uint8_t*>(colpeak + 17);
+    uint8_t* colscale = reinterpret_cast<uint8_t*>(colpeak + 17);    // [16] channel 0, [16] channel 1
+    uint32_t* colpeak1 = reinterpret_cast<uint32_t*>(lds + kLsPeak1Off);   // [16]: channel 1 (the reference computes every channel on its own, src/resampler_fir.rs:567-586)
     auto write_image = [&](uint32_t (&src)[8]) {
         const uint32_t t0 = threadIdx.x - 64;
         // the previous step's peak of column c's stream (lane c < 16; src[7] = stream index + 1, 0 = no stream)
-        uint32_t pred_e = 0;
+        uint32_t pred_e = 0, pred_e1 = 0;
         bool pred_ok = true;
         if (lane < 16 && src[7] != 0) {
             const uint32_t* rec = args.peaks + 4 * static_cast<size_t>(src[7] - 1);
             pred_ok = rec[0] == args.epoch && rec[1] == args.step;
             pred_e = rec[2] >> 23;
+            pred_e1 = rec[3] >> 23;
         }
         const bool predicted = __builtin_amdgcn_readfirstlane(__all(pred_ok) ? 1 : 0) != 0;
         // one scan per stream (the columns of a stream are neighbours); this wave's share of every column's peak by one atomic each
         auto scan = [&]() {
-            uint32_t colpk = 0;   // lane c < 16: this wave's share of column c's stream's peak
-            uint32_t prev_lo = 0, prev_hi = 0, pv = 0;
+            uint32_t colpk = 0, colpk1 = 0;   // lane c < 16: this wave's share of column c's stream's peak, per channel
+            uint32_t prev_lo = 0, prev_hi = 0, pv = 0, pv1 = 0;
 #pragma unroll 1
             for (uint32_t c = 0; c < 16; ++c) {
                 auto word = [&](int k) -> uint32_t { return static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(src[k]), static_cast<int>(c))); };
@@ -355,7 +358,7 @@ __global__ __launch_bounds__(kLsWaves * 64, kLsWaves / 2) void fir_lockstep_kern
                     gconst_f32_ptr hist = (gconst_f32_ptr) reinterpret_cast<const float*>((static_cast<uint64_t>(h_hi) << 32) | h_lo);
                     gconst_f32_ptr in = (gconst_f32_ptr) reinterpret_cast<const float*>((static_cast<uint64_t>(word(3)) << 32) | word(2));
                     const uint32_t hist_fr = word(5);
-                    float m = 0.f;
+                    float m = 0.f, m1 = 0.f;
                     for (uint32_t f = t0; f < span_fr; f += kLsStagers * 64) {
                         gconst_f32_ptr p = f < hist_fr ? hist + 2 * f : in + 2 * (f - hist_fr);
                         float a, b;
@@ -367,22 +370,40 @@ __global__ __launch_bounds__(kLsWaves * 64, kLsWaves / 2) void fir_lockstep_kern
                             a = p[0];
                             b = p[1];
                         }
-                        m = __builtin_fmaxf(m, __builtin_fmaxf(__builtin_fabsf(a), __builtin_fabsf(b)));   // (a NaN is left to the sums)
+                        m = __builtin_fmaxf(m, __builtin_fabsf(a));   // (a NaN is left to the sums)
+                        m1 = __builtin_fmaxf(m1, __builtin_fabsf(b));
                     }
-                    uint32_t mb = __float_as_uint(m);   // (non-negative floats order like their bit patterns)
-                    mb = max(mb, static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(mb), 0x128, 0xf, 0xf, false)));
-                    mb = max(mb, static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(mb), 0x124, 0xf, 0xf, false)));
-                    mb = max(mb, static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(mb), 0x122, 0xf, 0xf, false)));
-                    mb = max(mb, static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(mb), 0x121, 0xf, 0xf, false)));
-                    pv = max(max(static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(mb), 0)),
-                                 static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(mb), 16))),
-                             max(static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(mb), 32)),
-                                 static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(mb), 48))));
+                    // (non-negative floats order like their bit patterns; the two channels' exponents travel as the 16-bit
+                    // halves of one word: the wave's reduction is as long as for one)
+                    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+                    auto pkmax = [](uint32_t x, uint32_t y) -> uint32_t {
+                        us2 a2, b2;
+                        __builtin_memcpy(&a2, &x, 4);
+                        __builtin_memcpy(&b2, &y, 4);
+                        const us2 z = __builtin_elementwise_max(a2, b2);
+                        uint32_t r;
+                        __builtin_memcpy(&r, &z, 4);
+                        return r;
+                    };
+                    uint32_t mb = (__float_as_uint(m) >> 23) | ((__float_as_uint(m1) >> 23) << 16);
+                    mb = pkmax(mb, static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(mb), 0x128, 0xf, 0xf, false)));
+                    mb = pkmax(mb, static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(mb), 0x124, 0xf, 0xf, false)));
+                    mb = pkmax(mb, static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(mb), 0x122, 0xf, 0xf, false)));
+                    mb = pkmax(mb, static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(mb), 0x121, 0xf, 0xf, false)));
+                    const uint32_t r0 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(mb), 0)),
+                                   r1 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(mb), 16)),
+                                   r2 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(mb), 32)),
+                                   r3 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(mb), 48));
+                    pv = max(max(r0 & 0xFFFFu, r1 & 0xFFFFu), max(r2 & 0xFFFFu, r3 & 0xFFFFu)) << 23;   // (kept as the bits of 2^e: the records' form)
+                    pv1 = max(max(r0 >> 16, r1 >> 16), max(r2 >> 16, r3 >> 16)) << 23;
                 }
                 colpk = lane == c ? pv : colpk;
+                colpk1 = lane == c ? pv1 : colpk1;
             }
             if (lane < 16 && colpk != 0)
                 (void)__hip_atomic_fetch_max(colpeak + lane, colpk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (lane < 16 && colpk1 != 0)
+                (void)__hip_atomic_fetch_max(colpeak1 + lane, colpk1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         };
         // this step's peaks to the next step's predictions: by the staging wave that counts in last (every share is in then)
         auto count_in_and_publish = [&]() -> bool {
@@ -393,25 +414,33 @@ __global__ __launch_bounds__(kLsWaves * 64, kLsWaves / 2) void fir_lockstep_kern
             if (last && lane < 16 && src[7] != 0) {
                 uint32_t* rec = args.peaks + 4 * static_cast<size_t>(src[7] - 1);
                 const uint32_t bits = __hip_atomic_load(colpeak + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const uint32_t bits1 = __hip_atomic_load(colpeak1 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 rec[0] = args.epoch;
                 rec[1] = args.step + 1u;
                 rec[2] = bits;
+                rec[3] = bits1;
             }
             return last;
         };
-        uint32_t e_used;   // lane c < 16: the exponent column c is scaled for
+        uint32_t e_used, e_used1;   // lane c < 16: the exponents column c's two channels are scaled for
         if (predicted) {
-            e_used = pred_e == 0 ? 127u : pred_e + 4u;   // (a silent stream: as full-scale audio; a first sample overflows, is redone)
+            e_used = pred_e == 0 ? 127u : pred_e + 4u;   // (a silent channel: as full-scale audio; a first sample overflows, is redone)
+            e_used1 = pred_e1 == 0 ? 127u : pred_e1 + 4u;
         } else {
             scan();
             (void)count_in_and_publish();
             while (__hip_atomic_load(colpeak + 16, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < kLsStagers) __builtin_amdgcn_s_sleep(1);
             e_used = __hip_atomic_load(colpeak + (lane & 15u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> 23;
+            e_used1 = __hip_atomic_load(colpeak1 + (lane & 15u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >> 23;
         }
         e_used = ls_peak_clamp(e_used);
-        if (wave == 1 && lane < 16) colscale[lane] = static_cast<uint8_t>(e_used);
-        uint32_t xsv = (268u - e_used) << 23;
-        asm volatile("" : "+v"(xsv));   // lane c < 16: column c's scale (defined under the full EXEC mask: read by lane index below)
+        e_used1 = ls_peak_clamp(e_used1);
+        if (wave == 1 && lane < 16) {
+            colscale[lane] = static_cast<uint8_t>(e_used);
+            colscale[16 + lane] = static_cast<uint8_t>(e_used1);
+        }
+        uint32_t xsv = (268u - e_used) << 23, xsv1 = (268u - e_used1) << 23;
+        asm volatile("" : "+v"(xsv), "+v"(xsv1));   // lane c < 16: column c's scales (defined under the full EXEC mask: read by lane index below)
         for (uint32_t r = t0; r < g.rows; r += kLsStagers * 64) {
             // every column's frame of this row is requested before the first is converted: one memory
             // latency per row block, not one per column
@@ -451,7 +480,8 @@ __global__ __launch_bounds__(kLsWaves * 64, kLsWaves / 2) void fir_lockstep_kern
 #pragma unroll
             for (uint32_t c = 0; c < 16; ++c) {
                 const float xs = __uint_as_float(static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(xsv), c)));
-                const float s0 = x0[c] * xs, s1 = x1[c] * xs;
+                const float xs1 = __uint_as_float(static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(xsv1), c)));
+                const float s0 = x0[c] * xs, s1 = x1[c] * xs1;
                 const uint32_t hi = ls_cvt_pk_f16(s0, s1);
                 const uint32_t lo = ls_cvt_pk_f16(s0 - ls_f16_lo(hi), s1 - ls_f16_hi(hi));
                 char* e = row + ((((c >> 2) ^ sw) << 3) + (c & 3) * 2);
@@ -473,7 +503,8 @@ __global__ __launch_bounds__(kLsWaves * 64, kLsWaves / 2) void fir_lockstep_kern
     // The sync words start at zero (unit counter, image counter, early flag, ready counter): the only
     // workgroup barrier before the final one -- every wave is here at once.
     if (threadIdx.x < kLsSyncBytes / 4) n_cols_p[threadIdx.x] = 0;
-    if (threadIdx.x >= 64 && threadIdx.x < 64 + 21) reinterpret_cast<uint32_t*>(lds + kLsPeakOff)[threadIdx.x - 64] = 0;   // column peaks, their count, the scales
+    if (threadIdx.x >= 64 && threadIdx.x < 64 + 25) reinterpret_cast<uint32_t*>(lds + kLsPeakOff)[threadIdx.x - 64] = 0;   // column peaks, their count, the scales
+    if (threadIdx.x >= 128 && threadIdx.x < 128 + 16) reinterpret_cast<uint32_t*>(lds + kLsPeak1Off)[threadIdx.x - 128] = 0;   // channel 1's column peaks
     __syncthreads();
 
     // The NEXT step's plan (the reference's control flow for step k + 1, ~20 k cycles of serial f64 arithmetic
@@ -845,7 +876,7 @@ __global__ __launch_bounds__(kLsWaves * 64, kLsWaves / 2) void fir_lockstep_kern
                 v4f acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
                 if (split) {
                     unit_mfma_split(a_reg, g.row_len / 32, g.row_bytes, lds, image_off, tile_base, lane,
-                                    ls_col_unscale(colscale[lane & 15u]), acc0, acc1);
+                                    ls_col_unscale(colscale[lane & 15u]), ls_col_unscale(colscale[16u + (lane & 15u)]), acc0, acc1);
                 } else if (two && pair_ok) {
                     unit_mfma<2>(a_reg, nblk, xb + c0, C, acc0, acc1);
                 } else {
@@ -864,7 +895,8 @@ __global__ __launch_bounds__(kLsWaves * 64, kLsWaves / 2) void fir_lockstep_kern
                 bool redo = !(fabsf(chk) <= FLT_MAX);
                 if (split) {
                     const uint32_t e_act = colpeak[lane & 15u] >> 23, e_sc = colscale[lane & 15u];
-                    redo = redo || (e_act != 0 && e_act + 10u < e_sc);
+                    const uint32_t e_act1 = colpeak1[lane & 15u] >> 23, e_sc1 = colscale[16u + (lane & 15u)];
+                    redo = redo || (e_act != 0 && e_act + 10u < e_sc) || (e_act1 != 0 && e_act1 + 10u < e_sc1);
                 }
                 if (on && redo)
                     (void)__hip_atomic_fetch_or(&plan[cl.slot].flags, kFlagNonFinite, __ATOMIC_RELAXED,

@@ -495,6 +495,13 @@ __device__ __forceinline__ void fir_split_body(const FirStreamDesc* __restrict__
     uint32_t* used = ctrl + 16;     // [slot]: biased exponent the item's scale was derived from (stager 0)
     uint32_t* fin = ctrl + 20;      // [slot][2]: (stream << 4 | pair) + 1 and final peak exponent of the slot's last item (consumer 0)
     uint32_t* pubd = ctrl + 32;     // [slot]: stagers that have added their share of a PREDICTED item's peak (behind its `staged` count), cumulative
+    // Round 5: the two channels of a pair have a scale EACH (`peak`, `used`, `fin` are channel 0's, these channel 1's): the
+    // reference computes every channel on its own (src/resampler_fir.rs:567-586), and with one exponent per pair a channel
+    // 2^-20 below its partner kept 8e-7 .. 9e-6 of its own level instead of the 1e-6 the path is held to (VERDICT r04
+    // missing #3).  The planes of a channel only ever meet that channel's accumulator, so nothing else changes.
+    uint32_t* peak1 = ctrl + 36;    // [slot]
+    uint32_t* used1 = ctrl + 40;    // [slot]
+    uint32_t* fin1 = ctrl + 44;     // [slot]: final peak exponent of channel 1 of the slot's last item
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     for (uint32_t i = threadIdx.x; i < (g.lds_bytes + (DIAG && g.wtrace ? 16 * kWtraceSlots * 8 : 0)) / 4; i += blockDim.x)
@@ -618,7 +625,7 @@ __device__ __forceinline__ void fir_split_body(const FirStreamDesc* __restrict__
                 tK[rd] = t - tQ[rd] * half_a;
             }
             const bool real_task = real_rd[0];
-            uint64_t hist_e = 0;                  // latest final peak exponent per channel pair (8 bits each; 0 = none) ...
+            uint64_t hist_e = 0, hist_e1 = 0;     // latest final peak exponent per channel pair and channel (8 bits each; 0 = none) ...
             uint32_t hist_stream = 0xFFFFFFFFu;   // ... of this stream
             uint32_t n_met = 0;                   // meetings at `premax` so far
             uint32_t cstream = cu.c.sidx;         // the current item's stream
@@ -672,7 +679,7 @@ __device__ __forceinline__ void fir_split_body(const FirStreamDesc* __restrict__
             };
             // v[i] = (ch0, ch1) of frame 2K and (ch0, ch1) of frame 2K+1 in period 4Q+i
             // at(i, fr, c) = channel c of frame 2K + fr in period 4Q + i
-            auto store_task = [&](char* img, auto&& at, int rd, float xsc, int fr_lo = 0, int fr_hi = 2) {
+            auto store_task = [&](char* img, auto&& at, int rd, v2f xsc, int fr_lo = 0, int fr_hi = 2) {
                 typedef uint32_t u2 __attribute__((ext_vector_type(2)));
                 const uint32_t tQ_ = tQ[rd];
                 const uint32_t k0 = 2 * tK[rd];   // rows k0 and k0 + 1 share a swizzle (k0 is even)
@@ -706,7 +713,7 @@ __device__ __forceinline__ void fir_split_body(const FirStreamDesc* __restrict__
                             // two fp16 planes: h1 = RN16(s), h2 = RN16(s - h1) with s = 2^12 x (s - h1 is exact)
                             float s[5];
 #pragma unroll
-                            for (int i = 0; i < 5; ++i) s[i] = mul_plain(at(i, fr, c), xsc);
+                            for (int i = 0; i < 5; ++i) s[i] = mul_plain(at(i, fr, c), c ? xsc.y : xsc.x);
                             const uint32_t a01 = cvt_pk_f16(s[0], s[1]), a23 = cvt_pk_f16(s[2], s[3]), a4 = cvt_pk_f16(s[4], s[4]);
                             const uint32_t b01 = cvt_pk_f16(resid_lo(s[0], a01), resid_hi(s[1], a01));
                             const uint32_t b23 = cvt_pk_f16(resid_lo(s[2], a23), resid_hi(s[3], a23));
@@ -834,13 +841,14 @@ __device__ __forceinline__ void fir_split_body(const FirStreamDesc* __restrict__
 #pragma unroll
                 for (int rd = 0; rd < ROUNDS; ++rd) asm volatile("" : "+v"(tQ[rd]), "+v"(tK[rd]));
                 char* img = lds + kImageBase + slot * image_bytes;
-                uint32_t f_id_v = 0, f_e_v = 0;   // what the slot's previous item turned out to peak at (see `fin`)
+                uint32_t f_id_v = 0, f_e_v = 0, f_e1_v = 0;   // what the slot's previous item turned out to peak at (see `fin`)
                 if (have) {
                     wt.event(11);
                     while (lds_load_acquire(done + slot) < n_active * use) __builtin_amdgcn_s_sleep(RSMP_POLL_SLEEP);
                     if constexpr (PLANES == 2) {   // (requested here, used behind the wait for the loads)
                         f_id_v = __hip_atomic_load(fin + 2 * slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         f_e_v = __hip_atomic_load(fin + 2 * slot + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        f_e1_v = __hip_atomic_load(fin1 + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
                     wt.event(12);
                 }
@@ -912,20 +920,37 @@ __device__ __forceinline__ void fir_split_body(const FirStreamDesc* __restrict__
                 // reduction + LDS atomic were ~300 cycles in front of every count.
                 constexpr bool kDeferPeak = ROLE == 0 && ROUNDS == 1 && PLANES == 2;
                 bool peak_deferred = false;
-                float peak_m = 0.f;
+                v2f peak_m = v2f{0.f, 0.f};
                 // the peak of the samples a lane holds (lane_max below), then the wave's, into the item's `peak` word (one atomic)
-                auto publish = [&](float m, uint32_t sl, uint32_t us) {
-                    uint32_t mb = __float_as_uint(m);   // (non-negative floats order like their bit patterns; a NaN is left to the sums)
-                    mb = max(mb, static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(mb), 0x128, 0xf, 0xf, false)));
-                    mb = max(mb, static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(mb), 0x124, 0xf, 0xf, false)));
-                    mb = max(mb, static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(mb), 0x122, 0xf, 0xf, false)));
-                    mb = max(mb, static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(mb), 0x121, 0xf, 0xf, false)));
-                    const uint32_t wm = max(max(static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(mb), 0)),
-                                                static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(mb), 16))),
-                                            max(static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(mb), 32)),
-                                                static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(mb), 48))));
-                    if (lane == 0)
-                        (void)__hip_atomic_fetch_max(peak + sl, ((us + 1) << 8) | (wm >> 23), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                // (m = the lane's peak per channel; the exponents travel as two 16-bit fields of one word, so the wave's
+                // reduction is as long as it was for one: v_pk_max_u16)
+                auto publish = [&](v2f m, uint32_t sl, uint32_t us) {
+                    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+                    // (non-negative floats order like their bit patterns; a NaN is left to the sums)
+                    uint32_t mb = (__float_as_uint(m.x) >> 23) | ((__float_as_uint(m.y) >> 23) << 16);
+                    auto pkmax = [](uint32_t a, uint32_t b) -> uint32_t {
+                        us2 x, y;
+                        __builtin_memcpy(&x, &a, 4);
+                        __builtin_memcpy(&y, &b, 4);
+                        const us2 z = __builtin_elementwise_max(x, y);
+                        uint32_t r;
+                        __builtin_memcpy(&r, &z, 4);
+                        return r;
+                    };
+                    mb = pkmax(mb, static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(mb), 0x128, 0xf, 0xf, false)));
+                    mb = pkmax(mb, static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(mb), 0x124, 0xf, 0xf, false)));
+                    mb = pkmax(mb, static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(mb), 0x122, 0xf, 0xf, false)));
+                    mb = pkmax(mb, static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(mb), 0x121, 0xf, 0xf, false)));
+                    const uint32_t r0 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(mb), 0)),
+                                   r1 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(mb), 16)),
+                                   r2 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(mb), 32)),
+                                   r3 = static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(mb), 48));
+                    const uint32_t w0 = max(max(r0 & 0xFFFFu, r1 & 0xFFFFu), max(r2 & 0xFFFFu, r3 & 0xFFFFu));
+                    const uint32_t w1 = max(max(r0 >> 16, r1 >> 16), max(r2 >> 16, r3 >> 16));
+                    if (lane == 0) {
+                        (void)__hip_atomic_fetch_max(peak + sl, ((us + 1) << 8) | w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        (void)__hip_atomic_fetch_max(peak1 + sl, ((us + 1) << 8) | w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
                 };
                 const bool staged_already = kShare && odd_done;   // (an odd item its even neighbour has staged)
                 if constexpr (kShare) odd_done = false;
@@ -968,35 +993,44 @@ __device__ __forceinline__ void fir_split_body(const FirStreamDesc* __restrict__
                     // the peak of the samples in the registers: this lane's (lane_max), then the wave's and (one atomic) into
                     // the item's (publish) -- once per item and pair where the scale is predicted, once more after the first
                     // round where the scale is taken from it
-                    auto lane_max = [&](auto&& src, float m, int fr_lo = 0, int fr_hi = 2) -> float {
+                    auto lane_max = [&](auto&& src, v2f m, int fr_lo = 0, int fr_hi = 2) -> v2f {
 #pragma unroll
                         for (int i = 0; i < 5; ++i)
 #pragma unroll
                             for (int fr = 0; fr < 2; ++fr)
 #pragma unroll
                                 for (int c = 0; c < (mono ? 1 : 2); ++c)
-                                    if (fr >= fr_lo && fr < fr_hi) m = __builtin_fmaxf(m, __builtin_fabsf(src(i, fr, c)));
+                                    if (fr >= fr_lo && fr < fr_hi) {
+                                        if (c) m.y = __builtin_fmaxf(m.y, __builtin_fabsf(src(i, fr, c)));
+                                        else m.x = __builtin_fmaxf(m.x, __builtin_fabsf(src(i, fr, c)));
+                                    }
+                        if constexpr (mono) m.y = m.x;   // (the phantom channel is the same channel's odd frames)
                         return m;
                     };
                     // what a slot's previous item (`slots` items back) turned out to peak at: into the running table
-                    auto note_fin = [&](uint32_t f_id, uint32_t f_e) {
+                    auto note_fin = [&](uint32_t f_id, uint32_t f_e, uint32_t f_e1) {
                         if (f_id != 0) {
                             const uint32_t f_stream = (f_id - 1) >> 4, f_pair = (f_id - 1) & 15u;
                             if (f_stream != hist_stream) {
                                 hist_stream = f_stream;
-                                hist_e = 0;
+                                hist_e = hist_e1 = 0;
                             }
                             hist_e = (hist_e & ~(0xFFull << (8 * f_pair))) | (static_cast<uint64_t>(f_e) << (8 * f_pair));
+                            hist_e1 = (hist_e1 & ~(0xFFull << (8 * f_pair))) | (static_cast<uint64_t>(f_e1) << (8 * f_pair));
                         }
                     };
-                    auto hist_of = [&](uint32_t pr) -> uint32_t { return hist_stream == cstream ? static_cast<uint32_t>(hist_e >> (8 * pr)) & 255u : 0u; };
+                    // (channel 0's exponent in bits 0-7, channel 1's in bits 8-15; 0 = none)
+                    auto hist_of = [&](uint32_t pr) -> uint32_t {
+                        return hist_stream == cstream ? (static_cast<uint32_t>(hist_e >> (8 * pr)) & 255u) | ((static_cast<uint32_t>(hist_e1 >> (8 * pr)) & 255u) << 8) : 0u;
+                    };
                     // an item's scale: predicted from its pair's latest peak, or (no history) from the peak of what the stagers
                     // hold once every one of them has added its share -- the whole item, or (two rounds) its first round:
                     // ten of its sixteen periods, taken with the same headroom as a prediction
-                    auto scale_for = [&](uint32_t e_hist, uint32_t sl) -> float {
-                        uint32_t E;
-                        if (e_hist != 0) {   // 2^4 above the pair's latest peak
-                            E = e_hist + kPeakHeadroom;
+                    auto scale_for = [&](uint32_t e_hist, uint32_t sl) -> v2f {
+                        uint32_t E = e_hist & 255u, E1 = e_hist >> 8;
+                        if (E != 0 && E1 != 0) {   // 2^4 above the latest peak of the pair's channel
+                            E += kPeakHeadroom;
+                            E1 += kPeakHeadroom;
                         } else {
                             // (one monotonic counter for all slots: nobody gets past meeting k before every stager has
                             // arrived at it, so arrivals at meeting k + 1 cannot be taken for arrivals at k)
@@ -1004,23 +1038,31 @@ __device__ __forceinline__ void fir_split_body(const FirStreamDesc* __restrict__
                             ++n_met;
                             while (lds_load_acquire(premax) < n_real * n_met) __builtin_amdgcn_s_sleep(RSMP_POLL_SLEEP);
                             E = __hip_atomic_load(peak + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) & 255u;
+                            E1 = __hip_atomic_load(peak1 + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) & 255u;
                             if (ROUNDS == 2 && E != 0) E += kPeakHeadroom;
+                            if (ROUNDS == 2 && E1 != 0) E1 += kPeakHeadroom;
                         }
                         // (never scaled for peaks of 2^11 and above: such samples must overflow the planes and have the item
                         // redone, not push the audio next to them below the planes' range)
                         E = E > kPeakMax ? kPeakMax : E;
+                        E1 = E1 > kPeakMax ? kPeakMax : E1;
                         E = __builtin_amdgcn_readfirstlane(E < 31u ? 31u : E);   // (below 2^-96: treated as that)
-                        if (P == 0 && lane == 0) used[sl] = E;
+                        E1 = __builtin_amdgcn_readfirstlane(E1 < 31u ? 31u : E1);
+                        if (P == 0 && lane == 0) {
+                            used[sl] = E;
+                            used1[sl] = E1;
+                        }
                         // a peak in [2^(E-127), 2^(E-126)) times 2^(141-E) lies in [2^14, 2^15), inside fp16
-                        return __uint_as_float((268u - E) << 23);
+                        return v2f{__uint_as_float((268u - E) << 23), __uint_as_float((268u - E1) << 23)};
                     };
-                    float xs = kXScale, xs2 = kXScale;   // the item's sample scale (block floating point); its partner's
-                    float m_own = 0.f, m_partner = 0.f;   // running peaks of this lane's samples (own pair, partner pair)
+                    v2f xs = v2f{kXScale, kXScale}, xs2 = v2f{kXScale, kXScale};   // the item's sample scales (block floating point, one per channel); its partner's
+                    v2f m_own = v2f{0.f, 0.f}, m_partner = v2f{0.f, 0.f};   // running peaks of this lane's samples (own pair, partner pair), per channel
                     constexpr bool kLatePeak = ROUNDS == 2;   // (one round: the item's whole peak is known here)
                     if constexpr (PLANES == 2) {
-                        note_fin(__builtin_amdgcn_readfirstlane(f_id_v), __builtin_amdgcn_readfirstlane(f_e_v));
-                        m_own = lane_max(at, 0.f);   // (here: keeping the samples alive behind the count as well cost 11 %)
-                        const uint32_t eh = hist_of(cpair);
+                        note_fin(__builtin_amdgcn_readfirstlane(f_id_v), __builtin_amdgcn_readfirstlane(f_e_v), __builtin_amdgcn_readfirstlane(f_e1_v));
+                        m_own = lane_max(at, v2f{0.f, 0.f});   // (here: keeping the samples alive behind the count as well cost 11 %)
+                        const uint32_t eh_raw = hist_of(cpair);
+                        const uint32_t eh = (eh_raw & 255u) != 0 && (eh_raw >> 8) != 0 ? eh_raw : 0u;   // (both channels have a history, or neither)
                         if (kDeferPeak && eh != 0) {
                             peak_deferred = true;
                             peak_m = m_own;
@@ -1048,9 +1090,11 @@ __device__ __forceinline__ void fir_split_body(const FirStreamDesc* __restrict__
                     auto partner_slot = [&]() {
                         while (lds_load_acquire(done + slot2) < n_active * use2) __builtin_amdgcn_s_sleep(RSMP_POLL_SLEEP);
                         note_fin(__builtin_amdgcn_readfirstlane(__hip_atomic_load(fin + 2 * slot2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)),
-                                 __builtin_amdgcn_readfirstlane(__hip_atomic_load(fin + 2 * slot2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)));
-                        m_partner = lane_max(at_partner, 0.f);
-                        const uint32_t eh2 = hist_of(cpair + 1);
+                                 __builtin_amdgcn_readfirstlane(__hip_atomic_load(fin + 2 * slot2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)),
+                                 __builtin_amdgcn_readfirstlane(__hip_atomic_load(fin1 + slot2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)));
+                        m_partner = lane_max(at_partner, v2f{0.f, 0.f});
+                        const uint32_t eh2_raw = hist_of(cpair + 1);
+                        const uint32_t eh2 = (eh2_raw & 255u) != 0 && (eh2_raw >> 8) != 0 ? eh2_raw : 0u;
                         if (eh2 == 0 || !real_rd[ROUNDS - 1]) publish(m_partner, slot2, use2);
                         xs2 = scale_for(eh2, slot2);
                     };
@@ -1387,15 +1431,20 @@ __device__ __forceinline__ void fir_split_body(const FirStreamDesc* __restrict__
                 while (lds_load_acquire(pubd + slot) < n_real_c * (use + 1)) __builtin_amdgcn_s_sleep(RSMP_POLL_SLEEP);
             }
             const uint32_t e_used = __builtin_amdgcn_readfirstlane(__hip_atomic_load(used + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+            const uint32_t e_used1 = __builtin_amdgcn_readfirstlane(__hip_atomic_load(used1 + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
             const uint32_t e_act = __builtin_amdgcn_readfirstlane(__hip_atomic_load(peak + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) & 255u;
-            item_bad = e_act != 0 && e_act + kPeakQuiet < e_used;
+            const uint32_t e_act1 = __builtin_amdgcn_readfirstlane(__hip_atomic_load(peak1 + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) & 255u;
+            // (a channel much quieter than its scale allows: redone.  A channel of zeros has nothing to lose.)
+            item_bad = (e_act != 0 && e_act + kPeakQuiet < e_used) || (e_act1 != 0 && e_act1 + kPeakQuiet < e_used1);
             if (T == 0 && lane == 0) {   // for the stagers of the item that takes this slot next (read behind their wait for `done`)
                 fin[2 * slot] = ((d.sidx << 4) | (WIDE ? cu.cur_pair : 0u)) + 1u;
-                fin[2 * slot + 1] = e_act;
+                // (a channel of zeros counts as a history too -- the smallest scale -- so that a silent channel does not send
+                // every item of its stream to the stagers' meeting)
+                fin[2 * slot + 1] = e_act ? e_act : 1u;
+                fin1[slot] = e_act1 ? e_act1 : 1u;
             }
-            const float os = __uint_as_float((e_used - 27u) << 23);   // 2^(E-141): the item's scale undone; 2^-13: the taps'
-            acc0 *= os;
-            acc1 *= os;
+            acc0 *= __uint_as_float((e_used - 27u) << 23);    // 2^(E-141): channel 0's scale undone; 2^-13: the taps'
+            acc1 *= __uint_as_float((e_used1 - 27u) << 23);   // ... channel 1's
         }
         if (!WIDE || (cu.cur_pair & 1u) == 0) flush_pending();   // (no MFMA loop ran, or the experiment switch above)
         // class 0 may take the wrap variant the producers left with the image (tile 0, D row 0)
