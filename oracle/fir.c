@@ -219,6 +219,39 @@ int orc_fir_resample(orc_fir* r, const float* in, size_t in_len, float* out, siz
     return 0;
 }
 
+/* The control flow of `calls` consecutive resample() calls of `in_frames` frames each WITHOUT their samples: what
+ * resampler_fir.rs:509-621 does to read_position / available_frames / position (the f64 recurrence `position += ratio`,
+ * :589, output by output) when every call's output buffer has room (output_capacity = buffer_size_output()).  The input
+ * ring is left untouched -- orc_fir_seek hands the buffered frames back before the next real call.  For soak tests that
+ * age a stream by hours of audio in seconds (tools/soak_lockstep.py); returns the output frames the calls produce. */
+unsigned long long orc_fir_skip_calls(orc_fir* r, size_t calls, size_t in_frames, unsigned long long* consumed_frames) {
+    unsigned long long produced = 0, consumed = 0;
+    const size_t cap = orc_fir_buffer_size_output(r) / r->channels;
+    for (size_t c = 0; c < calls; c++) {
+        size_t write_position = r->read_position + r->available_frames;
+        size_t remaining_capacity = BUFFER_SIZE > write_position ? BUFFER_SIZE - write_position : 0;
+        size_t frames_to_copy = min_sz(min_sz(in_frames, remaining_capacity), INPUT_CAPACITY - r->available_frames);
+        r->available_frames += frames_to_copy;
+        size_t n = 0;
+        for (;;) {                                                    /* :542-590 */
+            size_t input_offset = (size_t)floor(r->position);
+            if (input_offset + r->taps > r->available_frames) break;
+            if (n >= cap) break;
+            n++;
+            r->position += r->ratio;                                  /* :589 */
+        }
+        size_t consumed_now = min_sz((size_t)floor(r->position), r->available_frames);   /* :596 */
+        r->read_position += consumed_now;
+        r->available_frames -= consumed_now;
+        r->position -= (double)consumed_now;
+        if (r->read_position > INPUT_CAPACITY) r->read_position = 0;  /* :605-615 */
+        produced += n;
+        consumed += frames_to_copy;
+    }
+    if (consumed_frames) *consumed_frames = consumed;
+    return produced;
+}
+
 /* resample/src/main.rs:226-254 with the chunk length as a parameter (CLI: 512 values). */
 size_t orc_fir_resample_all(orc_fir* r, const float* in, size_t in_len, size_t chunk_len,
                             float* out, size_t out_cap, size_t* calls, size_t max_calls,

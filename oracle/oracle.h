@@ -70,6 +70,8 @@ void orc_fir_state(const orc_fir* r, size_t* read_position, size_t* available_fr
 /* The CLI driver loop (resample/src/main.rs:226-254) with a caller-chosen chunk length (in f32
  * values, the CLI uses 512).  Returns number of f32 values written to out (<= out_cap);
  * optional per-call counts are appended to calls[2*i], calls[2*i+1] up to max_calls. */
+/* `calls` resample() calls of in_frames frames each, control flow only (no samples; see fir.c) */
+unsigned long long orc_fir_skip_calls(orc_fir* r, size_t calls, size_t in_frames, unsigned long long* consumed_frames);
 size_t orc_fir_resample_all(orc_fir* r, const float* in, size_t in_len, size_t chunk_len,
                             float* out, size_t out_cap, size_t* calls, size_t max_calls,
                             size_t* n_calls);

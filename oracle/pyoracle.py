@@ -109,6 +109,9 @@ def lib() -> C.CDLL:
     L.orc_fir_state.argtypes = [C.c_void_p, szp, szp, C.POINTER(C.c_double)]
     L.orc_fir_seek.restype = C.c_int
     L.orc_fir_seek.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_double, C.POINTER(C.c_float), C.c_size_t]
+    if hasattr(L, "orc_fir_skip_calls"):
+        L.orc_fir_skip_calls.restype = C.c_ulonglong
+        L.orc_fir_skip_calls.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.POINTER(C.c_ulonglong)]
     L.orc_fir_resample_all.restype = C.c_size_t
     L.orc_fir_resample_all.argtypes = [C.c_void_p, f32p, C.c_size_t, C.c_size_t, f32p, C.c_size_t,
                                        szp, C.c_size_t, szp]
@@ -240,6 +243,14 @@ class OracleFir:
         h = np.ascontiguousarray(history, np.float32)
         if self._L.orc_fir_seek(self._h, state[0], state[1], state[2], _f32p(h), h.size) != 0:
             raise ValueError("orc_fir_seek: history shorter than the buffered frames")
+
+    def skip_calls(self, calls: int, in_frames: int):
+        """`calls` resample() calls of `in_frames` frames each, control flow only (the f64 position recurrence output by
+        output, no samples): returns (frames accepted, frames produced).  The ring's contents are stale afterwards:
+        `seek(self.state(), history)` before the next real call."""
+        c = C.c_ulonglong()
+        p = self._L.orc_fir_skip_calls(self._h, calls, in_frames, C.byref(c))
+        return c.value, p
 
     def resample(self, inp: np.ndarray, out: np.ndarray):
         """Returns (status, consumed, produced); status 0/1/2 as error.rs:3-8."""
