@@ -107,7 +107,8 @@ struct rsmp_fir_lockstep {
         rsmp::TableRefresher::Table* run_next = nullptr;
         bool next_pending = false;        // a request is out (or its result is waiting to be taken)
         double next_drift = 0.0;
-        double seen_drift = 0.0;          // the class's drift as last read back
+        double seen_drift = 0.0;          // the class's drift as last read back ...
+        double rate = 0.0;                // ... and how fast it moves per input frame (from the last two readings)
         bool late = false;                // past the tolerance, the next tables not there yet
     };
     std::vector<DriftClass> classes;
@@ -115,6 +116,15 @@ struct rsmp_fir_lockstep {
     double drift_tolerance = 0.0;         // (set at creation: kLsDriftTolerance; rsmp_fir_lockstep_set_drift_policy)
     uint64_t drift_check_frames = 0;
     size_t n_late = 0;                    // classes currently `late`
+    // A reading tells where the DEVICE was when the gather kernel ran; what the host enqueues now runs later -- by as much
+    // as the host is ahead of the device (a caller that never waits: thousands of launches, tens of millions of frames per
+    // stream: several tolerances of drift).  Decisions are made for the drift a launch enqueued NOW will see: the last
+    // reading + the measured rate x the frames enqueued since that reading was asked for.
+    uint64_t frames_total = 0;            // input frames per stream enqueued through this batch so far
+    uint64_t frames_at_inflight = 0;      // ... when the reading in flight was asked for
+    uint64_t frames_at_seen = 0;          // ... when the latest completed reading was asked for
+    bool have_seen = false;
+    uint64_t frames_at_eval = 0;          // (when the classes were last looked at)
     std::vector<rsmp::TableRefresher::Table*> guards_due;   // images unbound by this call's replacements (record_guards)
     // diagnostics (rsmp_fir_lockstep_stats)
     uint64_t stat_ahead_hits = 0, stat_ahead_misses = 0, stat_late_polls = 0, stat_table_waits = 0, stat_probes = 0;
@@ -204,12 +214,23 @@ int poll_drift(rsmp_fir_lockstep* ls, hipStream_t s) {
             ls->drift_inflight = false;
             fresh = true;
             const double* d = ls->h_drift.as<double>();
-            for (size_t c = 0; c < ls->classes.size(); ++c) ls->classes[c].seen_drift = d[c];
+            const bool rate_ok = ls->have_seen && ls->frames_at_inflight > ls->frames_at_seen;
+            const double span = rate_ok ? static_cast<double>(ls->frames_at_inflight - ls->frames_at_seen) : 1.0;
+            for (size_t c = 0; c < ls->classes.size(); ++c) {
+                rsmp_fir_lockstep::DriftClass& cl = ls->classes[c];
+                if (rate_ok) cl.rate = (d[c] - cl.seen_drift) / span;
+                cl.seen_drift = d[c];
+            }
+            ls->frames_at_seen = ls->frames_at_inflight;
+            ls->have_seen = true;
         } else {
             (void)hipGetLastError();   // (hipErrorNotReady is not an error here)
         }
     }
-    if (!fresh && ls->n_late == 0) return RSMP_OK;
+    // (looked at when a reading has come in, while a class is late, and every 2^17 frames in between: the host's lead grows)
+    if (!fresh && ls->n_late == 0 && ls->frames_total - ls->frames_at_eval < (1u << 17)) return RSMP_OK;
+    ls->frames_at_eval = ls->frames_total;
+    const double lead = ls->have_seen ? static_cast<double>(ls->frames_total - ls->frames_at_seen) : 0.0;
     using TR = rsmp::TableRefresher;
     const double tol = ls->drift_tolerance;
     rsmp::LsPatchArgs pa;
@@ -226,8 +247,8 @@ int poll_drift(rsmp_fir_lockstep* ls, hipStream_t s) {
     };
     for (size_t c = 0; c < ls->classes.size(); ++c) {
         rsmp_fir_lockstep::DriftClass& cl = ls->classes[c];
-        if (!fresh && !cl.late) continue;
-        const double off = cl.seen_drift - cl.table_drift;
+        const double now_drift = cl.seen_drift + cl.rate * lead;   // what a launch enqueued now will see
+        const double off = now_drift - cl.table_drift;
         const bool want_step = cl.has_step, want_run = cl.has_run && ls->run_state == 1;
         if (!want_step && !want_run) continue;
         auto state_of = [](TR::Table* t) { return t ? t->state.load(std::memory_order_acquire) : static_cast<int>(TR::kReady); };
@@ -250,19 +271,19 @@ int poll_drift(rsmp_fir_lockstep* ls, hipStream_t s) {
             }
             if (cl.next_pending && (st == TR::kRequested || rt == TR::kRequested)) {
                 static const bool verbose = rsmp::knob("RSMP_FIR_VERBOSE") != nullptr;
-                if (verbose) fprintf(stderr, "[rsmp] class %zu: drift %.3g past its tables' %.3g, the next ones (%.3g) on their way\n", c, cl.seen_drift, cl.table_drift, cl.next_drift);
+                if (verbose) fprintf(stderr, "[rsmp] class %zu: drift %.3g past its tables' %.3g, the next ones (%.3g) on their way\n", c, now_drift, cl.table_drift, cl.next_drift);
                 ++ls->stat_late_polls;   // on their way: the old tables serve a little longer (a fifth of the bound per tolerance)
                 continue;
             }
             if (cl.next_pending && (st == TR::kFailed || rt == TR::kFailed))
                 return rsmp::fail(RSMP_ERR_HIP, "lock-step batch: the replacement class tables could not be made");
-            if (cl.next_pending && std::fabs(cl.seen_drift - cl.next_drift) <= 0.5 * tol) {
+            if (cl.next_pending && std::fabs(now_drift - cl.next_drift) <= 0.5 * tol) {
                 rsmp::ClassTable stt, rtt;
                 if (want_step) { stt = ls->refresher->take(cl.step_next); ls->guards_due.push_back(cl.step_next); }
                 if (want_run) { rtt = ls->refresher->take(cl.run_next); ls->guards_due.push_back(cl.run_next); }
                 cl.next_pending = false;
                 static const bool verbose = rsmp::knob("RSMP_FIR_VERBOSE") != nullptr;
-                if (verbose) fprintf(stderr, "[rsmp] class %zu: drift %.3g, tables %.3g -> %.3g\n", c, cl.seen_drift, cl.table_drift, cl.next_drift);
+                if (verbose) fprintf(stderr, "[rsmp] class %zu: drift %.3g (read %.3g + lead), tables %.3g -> %.3g\n", c, now_drift, cl.seen_drift, cl.table_drift, cl.next_drift);
                 bind_class_tables(ls, c, want_step ? &stt : nullptr, want_run ? &rtt : nullptr, cl.next_drift);
                 cl.late = false;
                 --ls->n_late;
@@ -288,8 +309,8 @@ int poll_drift(rsmp_fir_lockstep* ls, hipStream_t s) {
             }
             ++ls->stat_late_polls;
             static const bool verbose = rsmp::knob("RSMP_FIR_VERBOSE") != nullptr;
-            if (verbose) fprintf(stderr, "[rsmp] class %zu: drift %.3g past its tables' %.3g with nothing asked for\n", c, cl.seen_drift, cl.table_drift);
-            if (int rc = ask(quantized_drift(cl.seen_drift))) return rc;
+            if (verbose) fprintf(stderr, "[rsmp] class %zu: drift %.3g past its tables' %.3g with nothing asked for\n", c, now_drift, cl.table_drift);
+            if (int rc = ask(quantized_drift(now_drift))) return rc;
         } else if (std::fabs(off) > 0.6 * tol && !cl.next_pending) {
             // most of the way: the tables the class will want at the crossing are made now, beside everything else
             if (int rc = ask(quantized_drift(cl.table_drift + (off > 0.0 ? tol : -tol)))) return rc;
@@ -331,6 +352,7 @@ int request_drift(rsmp_fir_lockstep* ls, hipStream_t s, uint64_t frames) {
         if (int rc = ls->refresher->record_guard(t, s)) return rc;
     ls->guards_due.clear();
     ls->frames_since_drift += frames;
+    ls->frames_total += frames;
     if (ls->drift_inflight || ls->frames_since_drift < ls->drift_check_frames || ls->classes.empty()) return RSMP_OK;
     const uint32_t nc = static_cast<uint32_t>(ls->classes.size());
     // (the kernel stores straight into the mapped, coherent host buffer: a copy-engine operation in the stream costs the
@@ -339,6 +361,7 @@ int request_drift(rsmp_fir_lockstep* ls, hipStream_t s, uint64_t frames) {
                                                           ls->h_drift.as<double>(), nc, s));
     RSMP_HIP_CHECK(hipEventRecord(ls->drift_ev, s));
     ls->drift_inflight = true;
+    ls->frames_at_inflight = ls->frames_total;
     ls->frames_since_drift = 0;
     return RSMP_OK;
 }
@@ -351,6 +374,8 @@ int rebind_from_host_states(rsmp_fir_lockstep* ls) {
         ls->drift_inflight = false;
     }
     ls->frames_since_drift = 0;
+    ls->have_seen = false;
+    ls->frames_at_seen = ls->frames_at_inflight = ls->frames_at_eval = ls->frames_total;
     for (size_t c = 0; c < ls->classes.size(); ++c) {
         rsmp_fir_lockstep::DriftClass& cl = ls->classes[c];
         if (cl.next_pending) {
@@ -363,6 +388,7 @@ int rebind_from_host_states(rsmp_fir_lockstep* ls) {
         }
         const double d = ls->rs[ls->order[cl.rep]]->mirror.drift();
         cl.seen_drift = d;
+        cl.rate = 0.0;
         if (std::fabs(d - cl.table_drift) > kLsDriftQuantum || cl.late)
             if (int rc = rebind_class_blocking(ls, c, d)) return rc;
     }
