@@ -205,8 +205,12 @@ int rebind_class_blocking(rsmp_fir_lockstep* ls, size_t c, double d) {
 // The launch path's side of a replacement.  Where the drifts that have come back from the device say so, a class's next
 // tables are ASKED FOR (most of the way to the tolerance: one event record), and a class past the tolerance TAKES the
 // tables the worker has left for it (pointer swaps + one patch kernel for all classes of this look).  Nothing here
-// builds, allocates, copies or waits -- unless a class has run three tolerances past its tables without new ones
-// (a worker starved for ~30 polls; counted in stat_table_waits, never observed).
+// builds, allocates or copies.  It WAITS for the worker only where a class is three tolerances past its tables without new
+// ones: back-pressure on a caller that enqueues without ever waiting -- the image a replacement overwrites was bound
+// until the replacement before it, and the device must have passed that point (TableRefresher's guard), so the host
+// can be about two table generations ahead of the device and no more (tools/soak_lockstep.py --hours 24 at ~25 k
+// launches per second of host time: 374 waits in 29 k runs, none in the bench's 64 launches or behind a caller that
+// synchronises now and then; counted in stat_table_waits).
 int poll_drift(rsmp_fir_lockstep* ls, hipStream_t s) {
     bool fresh = false;
     if (ls->drift_inflight) {
