@@ -20,7 +20,7 @@ cd /tmp && export TMPDIR=/tmp
 
 python3 "$R/bench.py" --steps 20 --warmup 3 > "$SUM/bench_n1.json" 2> "$OUT/bench_n1.err"
 python3 "$R/bench.py" --path fft --steps 20 --warmup 3 > "$SUM/bench_fft.json" 2> "$OUT/bench_fft.err"
-python3 "$R/bench.py" --config c4 --steps 2048 --warmup 256 > "$SUM/bench_c4.json" 2> "$OUT/bench_c4.err"
+python3 "$R/bench.py" --config c4 --steps 16384 --warmup 512 > "$SUM/bench_c4.json" 2> "$OUT/bench_c4.err"
 python3 "$R/bench.py" --config c4 --c4-k 1 --steps 256 --warmup 16 > "$SUM/bench_c4_k1.json" 2> "$OUT/bench_c4_k1.err"
 python3 "$R/bench.py" --config c4 --c4-k 16 --steps 2048 --warmup 256 > "$SUM/bench_c4_k16.json" 2> "$OUT/bench_c4_k16.err"
 python3 "$R/tools/distinct_probe.py" 64 > "$SUM/distinct_states_probe.txt" 2> "$OUT/distinct_probe.err"
@@ -49,10 +49,13 @@ for k in 256 16; do
     python3 "$R/tools/wphase_report.py" "$OUT/w_c4.raw" $([ $k = 256 ] && echo 36 || echo 2.25) > "$SUM/wphase_c4_run_k$k.txt" 2>/dev/null
 done
 
+(cd "$R" && tools/c4_timelines.sh "$TAG/tl" > /dev/null 2>&1; cp "$OUT/tl/"c4_run_timeline_*_ahead*.txt "$SUM/" 2>/dev/null)
+timeout -k 5 900 python3 "$R/tools/soak_lockstep.py" --hours 24 > "$SUM/soak_lockstep_24h.txt" 2> "$OUT/soak24.err"
+
 declare -A CMD
 CMD[fir]="--steps 20 --warmup 3 --no-cpu --no-secondary"
 CMD[fft]="--path fft --steps 20 --warmup 3 --no-cpu"
-CMD[c4]="--config c4 --steps 2048 --warmup 256"
+CMD[c4]="--config c4 --steps 16384 --warmup 512"
 CMD[c5]="--config c5 --steps 10 --warmup 2"
 for w in fir fft c4 c5; do
     timeout -k 5 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt_$w" -- python3 "$R/bench.py" ${CMD[$w]} \
