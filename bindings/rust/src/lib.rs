@@ -87,6 +87,9 @@ extern "C" {
     fn rsmp_fir_taps(r: *const rsmp_fir) -> usize;
     fn rsmp_fir_phases(r: *const rsmp_fir) -> usize;
     fn rsmp_fft_channels(r: *const rsmp_fft) -> usize;
+    // addition: WAV samples (resample/src/main.rs:128-137) converted inside the FFT kernel's first load
+    fn rsmp_fft_batch_resample_bulk_pcm_device(rs: *const *mut rsmp_fft, n: usize, d_pcm: *const *const std::os::raw::c_void, bits: c_int,
+                                               d_out: *const *mut f32, n_chunks: *const usize, stream: *mut std::os::raw::c_void) -> c_int;
     // additions to the reference API: a fixed set of streams stepped together on device-resident state
     fn rsmp_fir_lockstep_new(rs: *const *mut rsmp_fir, n: usize, max_step_frames: usize) -> *mut rsmp_fir_lockstep;
     fn rsmp_fir_lockstep_free(ls: *mut rsmp_fir_lockstep);
@@ -198,6 +201,13 @@ impl ResamplerFft {
     pub fn chunk_size_input(&self) -> usize { unsafe { rsmp_fft_chunk_size_input(self.handle) } }
     pub fn chunk_size_output(&self) -> usize { unsafe { rsmp_fft_chunk_size_output(self.handle) } }
     pub fn delay(&self) -> usize { unsafe { rsmp_fft_delay(self.handle) } }
+    /// `n_chunks` chunks of a two-channel WAV file's samples as they are in the file -- little-endian PCM of `bits`
+    /// (16 / 24 / 32) per sample in device memory -- resampled into `d_out` (device memory, n_chunks * chunk_size_output()
+    /// values): the conversion of resample/src/main.rs:128-137 happens inside the kernel's first load.
+    pub unsafe fn resample_bulk_pcm_device(&mut self, d_pcm: *const std::os::raw::c_void, bits: u32, d_out: *mut f32, n_chunks: usize) -> Result<(), ResampleError> {
+        let (h, p, o) = ([self.handle], [d_pcm], [d_out]);
+        status(rsmp_fft_batch_resample_bulk_pcm_device(h.as_ptr(), 1, p.as_ptr(), bits as c_int, o.as_ptr(), &n_chunks, std::ptr::null_mut()))
+    }
     pub fn resample(&mut self, input: &[f32], output: &mut [f32]) -> Result<(), ResampleError> {
         status(unsafe {
             rsmp_fft_resample(self.handle, input.as_ptr(), input.len(), output.as_mut_ptr(), output.len())

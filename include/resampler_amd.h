@@ -338,6 +338,14 @@ int rsmp_fft_resample_bulk_device(rsmp_fft* r, const float* d_in, size_t in_len,
 /* n instances with the same rate pair on one device, one launch. */
 int rsmp_fft_batch_resample_bulk_device(rsmp_fft* const* rs, size_t n, const float* const* d_in,
                                         float* const* d_out, const size_t* n_chunks, void* stream);
+/* The same over WAV samples as they sit in the file (resample/src/main.rs:128-137): d_pcm[i] = little-endian PCM of `bits`
+ * (16 / 24 / 32) per sample, two channels a frame, n_chunks[i] * chunk_size_input samples; converted inside the kernel's
+ * first load (`sample as f32 / (1 << (bits - 1)) as f32`, with the reference's 32-bit divisor -2^31) -- bit for bit what
+ * rsmp_pcm_to_stereo_f32_device + rsmp_fft_batch_resample_bulk_device give, one pass over HBM less.  Two-channel streams
+ * of the rate pairs the wave kernel serves (72 of the 90); RSMP_ERR_INVALID_ARGUMENT otherwise.  Alignment of d_pcm[i]:
+ * 8 / 4 / 16 bytes for 16 / 24 / 32 bits. */
+int rsmp_fft_batch_resample_bulk_pcm_device(rsmp_fft* const* rs, size_t n, const void* const* d_pcm, int bits,
+                                            float* const* d_out, const size_t* n_chunks, void* stream);
 
 /* host-only: block sizes and the N/2-point Stockham stage lists for a rate pair
  * (planner.rs:35-245, optimizer.rs:6-64, radix_fft.rs:222-246). */

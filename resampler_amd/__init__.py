@@ -184,6 +184,8 @@ _SIGNATURES = [
      [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p]),
     ("rsmp_fft_batch_resample_bulk_device", C.c_int,
      [C.POINTER(C.c_void_p), C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _szp, C.c_void_p]),
+    ("rsmp_fft_batch_resample_bulk_pcm_device", C.c_int,
+     [C.POINTER(C.c_void_p), C.c_size_t, C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_void_p), _szp, C.c_void_p]),
     ("rsmp_fft_plan_sizes", C.c_int,
      [C.c_uint32, C.c_uint32, _szp, _szp, C.POINTER(C.c_int), _szp, C.POINTER(C.c_int), _szp, C.c_size_t]),
 ]
@@ -714,6 +716,18 @@ class FftBatch:
     def resample_bulk_device(self, stream: Optional[int] = None) -> None:
         _check(lib().rsmp_fft_batch_resample_bulk_device(self._handles, len(self.resamplers), self._in,
                                                          self._out, self._chunks, C.c_void_p(stream or 0)))
+
+    def resample_bulk_pcm_device(self, d_pcms, bits: int, d_outs, n_chunks: Sequence[int], stream: Optional[int] = None) -> None:
+        """The same over WAV samples as they are in the file (rsmp_fft_batch_resample_bulk_pcm_device): d_pcms = uint8
+        tensors of little-endian PCM, `bits` per sample, two channels a frame; converted in the kernel's first load."""
+        n = len(self.resamplers)
+        pin, pout, ch = (C.c_void_p * n)(), (C.c_void_p * n)(), (C.c_size_t * n)()
+        for i, (a, b, k) in enumerate(zip(d_pcms, d_outs, n_chunks)):
+            r = self.resamplers[i]
+            assert a.numel() >= k * r.chunk_size_input() * (bits // 8) and b.numel() >= k * r.chunk_size_output()
+            pin[i], pout[i], ch[i] = a.data_ptr(), _dev_ptr(b), k
+        self._keep_pcm = (list(d_pcms), list(d_outs))
+        _check(lib().rsmp_fft_batch_resample_bulk_pcm_device(self._handles, n, pin, bits, pout, ch, C.c_void_p(stream or 0)))
 
 
 class InterpolationMode(enum.IntEnum):

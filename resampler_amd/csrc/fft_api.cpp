@@ -162,7 +162,7 @@ struct FftJob {
     size_t n_blocks;
 };
 
-int launch_fft_jobs(rsmp_fft* leader, const std::vector<FftJob>& jobs, hipStream_t stream) {
+int launch_fft_jobs(rsmp_fft* leader, const std::vector<FftJob>& jobs, hipStream_t stream, uint32_t pcm_bits = 0) {
     const size_t n = jobs.size();
     const size_t bytes = n * sizeof(FftStreamDesc);
     // A handle's launches are ordered (&mut self in the reference): launch k + 1 reads the overlap rows launch k
@@ -201,6 +201,8 @@ int launch_fft_jobs(rsmp_fft* leader, const std::vector<FftJob>& jobs, hipStream
         h[i].overlap_next = j.r->d_overlap + (j.r->cur ^ 1) * ov;
         h[i].n_blocks = static_cast<uint32_t>(j.n_blocks);
         h[i].channels = static_cast<uint32_t>(j.r->channels);
+        h[i].in_bits = pcm_bits;
+        h[i].pad = 0;
         if (h[i].n_blocks > max_blocks) max_blocks = h[i].n_blocks;
         if (h[i].channels > max_channels) max_channels = h[i].channels;
         if (h[i].channels < min_channels) min_channels = h[i].channels;
@@ -209,8 +211,14 @@ int launch_fft_jobs(rsmp_fft* leader, const std::vector<FftJob>& jobs, hipStream
     RSMP_HIP_CHECK(hipEventRecord(leader->desc_copied, stream));
     leader->desc_pending = true;
     if (leader->profiling) RSMP_HIP_CHECK(hipEventRecord(leader->prof_start, stream));
-    RSMP_HIP_CHECK(rsmp::launch_fft_ola(leader->plan->dev, leader->d_desc.as<FftStreamDesc>(),
-                                        static_cast<uint32_t>(n), max_blocks, max_channels, min_channels, stream));
+    {
+        const hipError_t e = rsmp::launch_fft_ola(leader->plan->dev, leader->d_desc.as<FftStreamDesc>(), static_cast<uint32_t>(n),
+                                                  max_blocks, max_channels, min_channels, stream, pcm_bits);
+        if (e == hipErrorNotSupported && pcm_bits != 0)
+            return rsmp::fail(RSMP_ERR_INVALID_ARGUMENT, "ResamplerFft: PCM input is read in place by the two-channel wave kernel only "
+                                                       "(this rate pair / channel count has none): convert with rsmp_pcm_to_stereo_f32_device first");
+        RSMP_HIP_CHECK(e);
+    }
     if (leader->profiling) {
         RSMP_HIP_CHECK(hipEventRecord(leader->prof_stop, stream));
         leader->prof_valid = true;
@@ -397,4 +405,27 @@ extern "C" int rsmp_fft_batch_resample_bulk_device(rsmp_fft* const* rs, size_t n
     jobs.reserve(n);
     for (size_t i = 0; i < n; ++i) jobs.push_back(FftJob{rs[i], d_in[i], d_out[i], n_chunks[i]});
     return launch_fft_jobs(rs[0], jobs, s);
+}
+
+// The same with the WAV file's samples as they are: little-endian PCM of `bits` (16 / 24 / 32) per sample, two channels a
+// frame, converted inside the kernel's first load as resample/src/main.rs:128-137 converts them (`sample as f32 /
+// (1 << (bits - 1)) as f32`, the 32-bit divisor's sign included) -- rsmp_pcm_to_stereo_f32_device + the f32 entry point
+// give the same samples bit for bit, with one more pass over HBM (PCM read, f32 written, f32 read).
+extern "C" int rsmp_fft_batch_resample_bulk_pcm_device(rsmp_fft* const* rs, size_t n, const void* const* d_pcm, int bits,
+                                                       float* const* d_out, const size_t* n_chunks, void* stream) {
+    if (n == 0) return RSMP_OK;
+    if (!rs || !d_pcm || !d_out || !n_chunks || (bits != 16 && bits != 24 && bits != 32))
+        return rsmp::fail(RSMP_ERR_INVALID_ARGUMENT, "rsmp_fft_batch_resample_bulk_pcm_device: null argument, or bits not 16 / 24 / 32");
+    for (size_t i = 0; i < n; ++i) {
+        if (!rs[i] || rs[i]->device != rs[0]->device || rs[i]->plan != rs[0]->plan || rs[i]->channels != 2)
+            return rsmp::fail(RSMP_ERR_INVALID_ARGUMENT, "PCM batch streams must share one device and one rate pair and have two channels");
+        if (reinterpret_cast<uintptr_t>(d_pcm[i]) % (bits == 32 ? 16 : bits == 16 ? 8 : 4) != 0)
+            return rsmp::fail(RSMP_ERR_INVALID_ARGUMENT, "PCM input must be aligned to 8 (16-bit), 4 (24-bit) or 16 (32-bit) bytes");
+    }
+    DeviceGuard guard(rs[0]->device);
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : rs[0]->stream;
+    std::vector<FftJob> jobs;
+    jobs.reserve(n);
+    for (size_t i = 0; i < n; ++i) jobs.push_back(FftJob{rs[i], static_cast<const float*>(d_pcm[i]), d_out[i], n_chunks[i]});
+    return launch_fft_jobs(rs[0], jobs, s, static_cast<uint32_t>(bits));
 }

@@ -34,15 +34,19 @@ struct FftStreamDesc {
                           // the old state and the one that writes the new one are not ordered)
     uint32_t n_blocks;
     uint32_t channels;
+    uint32_t in_bits;     // 0: `in` is f32; 16 / 24 / 32: `in` is little-endian PCM of that width (two-channel streams on the wave kernel only)
+    uint32_t pad;
 };
 
 // Blocks a workgroup walks in sequence (carrying the overlap on chip); the first block of a run
 // that does not start the launch recomputes its predecessor as halo.
 constexpr uint32_t kFftRun = 16;
 
+// pcm_bits != 0: every stream's `in` is PCM of that width (FftStreamDesc::in_bits); hipErrorNotSupported where no kernel
+// that reads PCM serves the plan / channel count.
 hipError_t launch_fft_ola(const FftPlanDev& plan, const FftStreamDesc* d_descs, uint32_t n_streams,
                           uint32_t max_blocks, uint32_t max_channels, uint32_t min_channels,
-                          hipStream_t stream);
+                          hipStream_t stream, uint32_t pcm_bits = 0);
 // Wave-per-transform build (fft_wave.hip) for the plans it is instantiated for; hipErrorNotSupported
 // otherwise (launch_fft_ola then falls back to the workgroup kernels by itself).
 hipError_t launch_fft_ola_wave(const FftPlanDev& plan, const FftStreamDesc* d_descs, uint32_t n_streams,

@@ -740,12 +740,14 @@ size_t fft_ola_lds_bytes(const FftPlanDev& plan, uint32_t channels) {
 
 hipError_t launch_fft_ola(const FftPlanDev& plan, const FftStreamDesc* d_descs, uint32_t n_streams,
                           uint32_t max_blocks, uint32_t max_channels, uint32_t min_channels,
-                          hipStream_t stream) {
+                          hipStream_t stream, uint32_t pcm_bits) {
     if (n_streams == 0 || max_blocks == 0) return hipSuccess;
     static const bool no_wave = rsmp::knob("RSMP_FFT_WAVE") != nullptr && atoi(rsmp::knob("RSMP_FFT_WAVE")) == 0;   // A/B
+    // (PCM input is read by the two-channel wave kernel only: FftStreamDesc::in_bits)
+    if (pcm_bits != 0 && (no_wave || max_channels != 2 || min_channels != 2)) return hipErrorNotSupported;
     if (!no_wave) {
         const hipError_t e = launch_fft_ola_wave(plan, d_descs, n_streams, max_blocks, max_channels, min_channels, stream);
-        if (e != hipErrorNotSupported) return e;
+        if (e != hipErrorNotSupported || pcm_bits != 0) return e;
     }
     // Blocks per workgroup: every run after a stream's first recomputes its predecessor block (1 / run
     // extra work), and the launch ends with a partly filled round of workgroups unless their number

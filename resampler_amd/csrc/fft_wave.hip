@@ -666,8 +666,64 @@ __global__ __launch_bounds__((OCC == 1 && kOneWavePerSimd<FWD, INV> ? 256 : wave
                 }
                 return v;
             };
-            if constexpr (FWD::kFused) wave_fused_first<FI, FWD::kR[0], FWD::kR[1], FWD::kPadJ, FI / 2>(buf, tw_f + FWD::tab(1), lane, sample);
-            else wave_first<FI, FWD::kR[0], FWD::kPadJ, FI / 2>(buf, lane, sample);
+            auto first_pass = [&](auto&& smp) {
+                if constexpr (FWD::kFused) wave_fused_first<FI, FWD::kR[0], FWD::kR[1], FWD::kPadJ, FI / 2>(buf, tw_f + FWD::tab(1), lane, smp);
+                else wave_first<FI, FWD::kR[0], FWD::kPadJ, FI / 2>(buf, lane, smp);
+            };
+            if constexpr (stereo) {
+                // WAV samples straight from their PCM bytes (resample/src/main.rs:128-137: `sample as f32 / (1 << (bits - 1)) as
+                // f32`; SURVEY 8 f1: "int16/24 -> f32 conversion could be fused into the load kernel"): the conversion pass --
+                // PCM read, f32 written, f32 read again -- is gone, the input side of the launch is 2 (16-bit) or 3 bytes a
+                // sample instead of 4 + 2 + 4.  Little-endian, two channels a frame; complex j = frames 2j, 2j + 1.
+                const uint32_t in_bits = __builtin_amdgcn_readfirstlane(d.in_bits);
+                if (in_bits == 0) {
+                    first_pass(sample);
+                } else {
+                    typedef __attribute__((address_space(1))) uint32_t GU32;
+                    typedef uint32_t u2v __attribute__((ext_vector_type(2)));
+                    typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+                    typedef __attribute__((address_space(1))) u2v GU2;
+                    typedef __attribute__((address_space(1))) u4v GU4;
+                    const GU32* pin = (const GU32*)d.in + (static_cast<size_t>(b) * FI * 2 * (in_bits >> 3)) / 4;   // (FI even: a whole number of words)
+                    auto sext = [](uint32_t v, int bits) -> float { return static_cast<float>(static_cast<int32_t>(v << (32 - bits)) >> (32 - bits)); };
+                    if (in_bits == 16) {
+                        first_pass([&](int j) -> cf {
+                            cf v = cf_make(0.f, 0.f);
+                            if (j < FI / 2) {
+                                const u2v w = ((const GU2*)pin)[j];   // frames 2j, 2j + 1: (ch0 | ch1 << 16) each
+                                const uint32_t sh = ch * 16u;
+                                v = cf_make(sext(w.x >> sh, 16), sext(w.y >> sh, 16)) * (1.0f / 32768.0f);
+                            }
+                            return v;
+                        });
+                    } else if (in_bits == 24) {
+                        first_pass([&](int j) -> cf {
+                            cf v = cf_make(0.f, 0.f);
+                            if (j < FI / 2) {
+                                const GU32* p = pin + 3 * j;   // twelve bytes: frame 2j (ch0, ch1), frame 2j + 1 (ch0, ch1), three bytes each
+                                const uint32_t w0 = p[0], w1 = p[1], w2 = p[2];
+                                const uint32_t a = ch == 0 ? w0 : (w0 >> 24) | (w1 << 8);
+                                const uint32_t c = ch == 0 ? (w1 >> 16) | (w2 << 16) : w2 >> 8;
+                                v = cf_make(sext(a, 24), sext(c, 24)) * (1.0f / 8388608.0f);
+                            }
+                            return v;
+                        });
+                    } else {
+                        first_pass([&](int j) -> cf {
+                            cf v = cf_make(0.f, 0.f);
+                            if (j < FI / 2) {
+                                const u4v w = ((const GU4*)pin)[j];
+                                // (main.rs:131: the divisor `(1 << 31) as f32` is an i32 literal = -2^31: 32-bit files come out with
+                                // inverted polarity in the reference, and so here)
+                                v = cf_make(static_cast<float>(static_cast<int32_t>(ch == 0 ? w.x : w.y)), static_cast<float>(static_cast<int32_t>(ch == 0 ? w.z : w.w))) * (-1.0f / 2147483648.0f);
+                            }
+                            return v;
+                        });
+                    }
+                }
+            } else {
+                first_pass(sample);
+            }
         }
         static_for<(FWD::kFused ? 2 : 1), SF>([&](auto s_c) {
             constexpr int s = decltype(s_c)::value;

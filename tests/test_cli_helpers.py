@@ -94,3 +94,51 @@ def test_pcm_conversion_matches_the_reference_form(bits, channels):
         yr, _ = r.resample_all(want, 512)
         assert c == want.size and p == yr.size
         assert float(np.sqrt(np.mean((d_y[:p].cpu().numpy().astype(np.float64) - yr) ** 2))) <= 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bits", [16, 24, 32])
+@pytest.mark.parametrize("in_rate,out_rate", [(ra.SampleRate.Hz44100, ra.SampleRate.Hz48000), (ra.SampleRate.Hz48000, ra.SampleRate.Hz44100),
+                                              (ra.SampleRate.Hz48000, ra.SampleRate.Hz96000)])
+def test_fft_resamples_pcm_straight_from_its_bytes(bits, in_rate, out_rate):
+    """SURVEY 8 f1 / VERDICT r04 item 10: the WAV sample conversion (resample/src/main.rs:128-137) inside the FFT
+    kernel's first load.  Two streams of stereo PCM through rsmp_fft_batch_resample_bulk_pcm_device against the
+    two-pass route -- rsmp_pcm_to_stereo_f32_device, then the f32 entry point -- which the conversion test above holds
+    to the reference's form: the same output BIT FOR BIT (the same samples reach the same kernel), with the PCM bytes
+    as the only input the launch reads."""
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda:0")
+    blocks = 7
+    hs = [ra.ResamplerFft.new(2, in_rate, out_rate) for _ in range(4)]
+    n_in, n_out = hs[0].chunk_size_input(), hs[0].chunk_size_output()
+    rng = np.random.default_rng(bits)
+    outs = []
+    pcms = []
+    for i in range(2):
+        s = rng.integers(-(1 << (bits - 1)), (1 << (bits - 1)) - 1, blocks * n_in, dtype=np.int64)
+        if bits == 16:
+            raw = s.astype("<i2").tobytes()
+        elif bits == 32:
+            raw = s.astype("<i4").tobytes()
+        else:
+            b = np.zeros((s.size, 3), np.uint8)
+            u = s & 0xFFFFFF
+            b[:, 0], b[:, 1], b[:, 2] = u & 255, (u >> 8) & 255, (u >> 16) & 255
+            raw = b.tobytes()
+        pcms.append(torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev))
+    # two passes: convert, then resample
+    f32 = [torch.empty(blocks * n_in, device=dev) for _ in range(2)]
+    for p, f in zip(pcms, f32):
+        ra.pcm_to_stereo_f32_device(p, bits, 2, f)
+    two_pass = [torch.zeros(blocks * n_out, device=dev) for _ in range(2)]
+    b1 = ra.FftBatch(hs[:2])
+    b1.bind(f32, two_pass, [blocks] * 2)
+    b1.resample_bulk_device()
+    # one pass
+    fused = [torch.zeros(blocks * n_out, device=dev) for _ in range(2)]
+    b2 = ra.FftBatch(hs[2:])
+    b2.resample_bulk_pcm_device(pcms, bits, fused, [blocks] * 2)
+    torch.cuda.synchronize()
+    for a, b in zip(two_pass, fused):
+        assert torch.equal(a, b)
+        assert float(a.abs().max()) > 0.1
