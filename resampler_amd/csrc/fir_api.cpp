@@ -396,8 +396,10 @@ PlanPool& plan_pool() {
     static PlanPool* pool = new PlanPool();   // (leaked on purpose: joining workers from a static destructor at exit races the runtime's teardown)
     return *pool;
 }
-// (the workers exist when the library is loaded, not from inside the first launch that needs them)
-struct PlanPoolAtLoad { PlanPoolAtLoad() { (void)plan_pool(); } } g_plan_pool_at_load;
+// (the workers must not be created inside the first launch that needs them; ADVICE r04: nor from a
+// static initialiser at dlopen, for every user of the library.  They are created by the first ResamplerFir constructor
+// of the process -- rsmp_fir_new_from_hz below -- and idle on a condition variable from then on: at most 63 threads,
+// hardware_concurrency() - 1 if that is less.)
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -767,6 +769,7 @@ extern "C" int rsmp_device_count(void) {
 extern "C" rsmp_fir* rsmp_fir_new_from_hz(size_t channels, uint32_t input_rate_hz,
                                           uint32_t output_rate_hz, int latency, int attenuation,
                                           int device) {
+    (void)plan_pool();   // (the planning workers exist from the process's first ResamplerFir on: see PlanPool)
     return fir_create(channels, input_rate_hz, output_rate_hz, latency, attenuation, device);
 }
 
@@ -778,6 +781,7 @@ extern "C" rsmp_fir* rsmp_fir_new(size_t channels, int input_rate, int output_ra
         rsmp::fail(RSMP_ERR_INVALID_ARGUMENT, "ResamplerFir::new: invalid SampleRate value");
         return nullptr;
     }
+    (void)plan_pool();
     return fir_create(channels, in_hz, out_hz, latency, attenuation, device);
 }
 

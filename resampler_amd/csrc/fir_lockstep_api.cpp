@@ -447,7 +447,7 @@ extern "C" rsmp_fir_lockstep* rsmp_fir_lockstep_new(rsmp_fir* const* rs, size_t 
     ls->rs.assign(rs, rs + n);
     ls->drift_tolerance = kLsDriftTolerance;
     ls->drift_check_frames = kLsDriftCheckFrames;
-    ls->refresher.reset(new rsmp::TableRefresher(ls->device));   // (its thread exists from here on: none is created in a launch path)
+    ls->refresher.reset(new rsmp::TableRefresher(ls->device));   // (its thread starts with the batch's first request)
     // Streams that share a polyphase table, a rate pair and a channel count share a class table and
     // a geometry: they become neighbours, then workgroups of `slots` streams.
     // (a stream set to RSMP_FIR_KERNEL_PERIODIC_F32 keeps every product in f32: its own groups)

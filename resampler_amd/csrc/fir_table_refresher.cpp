@@ -9,9 +9,8 @@
 
 namespace rsmp {
 
-TableRefresher::TableRefresher(int device) : device_(device) {
-    worker_ = std::thread([this] { loop(); });
-}
+TableRefresher::TableRefresher(int device) : device_(device) {}
+
 
 TableRefresher::~TableRefresher() {
     {
@@ -48,6 +47,9 @@ int TableRefresher::request(Table* t, double drift) {
     {
         std::lock_guard<std::mutex> lock(mu_);   // (held by the worker only while it takes an entry off the queue)
         queue_.push_back(t);
+        // (the worker exists from the batch's first request on: a batch whose streams never age that far -- most -- has no
+        // thread; creating it costs the call that asks first ~0.1 ms, once)
+        if (!worker_.joinable()) worker_ = std::thread([this] { loop(); });
     }
     cv_work_.notify_one();
     return RSMP_OK;
