@@ -200,6 +200,15 @@ int rsmp_fir_lockstep_counts(rsmp_fir_lockstep* ls, size_t* consumed, size_t* pr
 int rsmp_fir_lockstep_run(rsmp_fir_lockstep* ls, size_t k_steps, size_t in_frames, size_t in_offset_frames,
                           int append, void* stream);
 int rsmp_fir_lockstep_run_counts(rsmp_fir_lockstep* ls, size_t* consumed, size_t* produced, size_t max_steps);
+/* A whole buffer per stream as the reference's driver loop feeds it (resample/src/main.rs:226-254): total_frames frames
+ * from d_in[i] + in_offset_frames in calls of chunk_frames frames, the last call shorter where total_frames is no
+ * multiple -- floor(total / chunk) calls through rsmp_fir_lockstep_run and the remaining frames as one more call, its
+ * output appended behind theirs.  Asynchronous on `stream`, planned on the device whatever states the streams are in
+ * (no host planning, no host threads): the bulk entry point for batches of streams in DISTINCT states.  Counts:
+ * rsmp_fir_lockstep_run_counts (the equal calls) and rsmp_fir_lockstep_counts (the last call); rsmp_fir_lockstep_sync
+ * brings the streams' states back into their handles.  chunk_frames <= the batch's max_step_frames. */
+int rsmp_fir_lockstep_run_bulk(rsmp_fir_lockstep* ls, size_t total_frames, size_t chunk_frames, size_t in_offset_frames,
+                               int append, void* stream);
 /* Diagnostic: calls of the last run (all streams) that the device planner's fast path declined and the plain state
  * machine did (fir_mirror_fast.h); 0 for a run executed as a loop of steps. */
 int rsmp_fir_lockstep_run_slow_calls(rsmp_fir_lockstep* ls, size_t* slow_calls);

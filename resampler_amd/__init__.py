@@ -138,6 +138,7 @@ _SIGNATURES = [
     ("rsmp_fir_lockstep_counts", C.c_int, [C.c_void_p, _szp, _szp]),
     ("rsmp_fir_lockstep_run", C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p]),
     ("rsmp_fir_lockstep_run_counts", C.c_int, [C.c_void_p, _szp, _szp, C.c_size_t]),
+    ("rsmp_fir_lockstep_run_bulk", C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p]),
     ("rsmp_fir_lockstep_run_slow_calls", C.c_int, [C.c_void_p, _szp]),
     ("rsmp_fir_lockstep_table_rebinds", C.c_int, [C.c_void_p, _szp]),
     ("rsmp_fir_lockstep_status", C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
@@ -536,6 +537,15 @@ class FirLockstep:
         _check(lib().rsmp_fir_lockstep_run(self._h, k_steps, in_frames, in_offset_frames, 1 if append else 0,
                                            C.c_void_p(stream or 0)))
         self._last_run = k_steps
+
+    def run_bulk(self, total_frames: int, chunk_frames: int, in_offset_frames: int = 0, append: bool = False,
+                 stream: Optional[int] = None) -> None:
+        """A whole buffer per stream in calls of `chunk_frames` frames, the last one shorter (the reference's driver
+        loop, resample/src/main.rs:226-254), planned on the device: rsmp_fir_lockstep_run_bulk.  run_counts() has the
+        equal calls' counts, counts() the last call's when total_frames is no multiple of chunk_frames."""
+        _check(lib().rsmp_fir_lockstep_run_bulk(self._h, total_frames, chunk_frames, in_offset_frames, 1 if append else 0,
+                                                C.c_void_p(stream or 0)))
+        self._last_run = total_frames // chunk_frames
 
     def run_counts(self):
         """(consumed, produced) of every call of the last run: two int64 arrays [k_steps][streams], in f32 values."""

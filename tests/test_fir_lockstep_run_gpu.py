@@ -440,3 +440,54 @@ def test_table_replacements_stay_off_the_launch_path():
     ls.sync()
     for h, r in zip(hs, refs):
         assert h.state() == r.state()
+
+
+@pytest.mark.parametrize("total,chunk", [(20000, 256), (16384, 512), (9999, 300)])
+def test_bulk_batch_in_distinct_states_planned_on_the_device(total, chunk):
+    """64 streams of six rate pairs in 64 different states (each has already run a different,
+    ragged amount through its own handle) take a whole buffer each through rsmp_fir_lockstep_run_bulk -- the reference's
+    driver loop (resample/src/main.rs:226-254: calls of `chunk` frames, the last one shorter) planned ON THE DEVICE,
+    nothing replayed on the host: every call's (consumed, produced) of every stream, the samples (1e-6 RMS against the
+    oracle's AVX+FMA path) and the end states (bit for bit)."""
+    import torch
+    dev = torch.device("cuda:0")
+    n = 64
+    specs = sharding.mixed_rate_batch(n, 2, 512)
+    hs = [ra.ResamplerFir.new_from_hz(2, s.in_hz, s.out_hz, ra.Latency.Sample64, ra.Attenuation.Db90) for s in specs]
+    kind = o.CONVOLVE_AVX_FMA if o.have_avx_fma() else o.CONVOLVE_SCALAR
+    refs = [o.OracleFir(2, s.in_hz, s.out_hz, 128, 90, kind) for s in specs]
+    rng = np.random.default_rng(total)
+    for i, (h, r) in enumerate(zip(hs, refs)):   # distinct states: 64 + 37 i frames in ragged calls
+        x = (rng.random(2 * (64 + 37 * i), dtype=np.float32) * 2 - 1).astype(np.float32)
+        og, orr = np.zeros(h.buffer_size_output(), np.float32), np.zeros(r.buffer_size_output(), np.float32)
+        off = 0
+        while off < x.size:
+            cg, pg = h.resample(x[off:off + 2 * 211], og)
+            rc, cr, pr = r.resample(x[off:off + 2 * 211], orr)
+            assert rc == 0 and (cg, pg) == (cr, pr)
+            off += cg
+    assert len({h.state() for h in hs}) > n // 2
+    xs = [(rng.random(2 * total, dtype=np.float32) * 2 - 1).astype(np.float32) for _ in range(n)]
+    d_in = [torch.from_numpy(x).to(dev) for x in xs]
+    caps = [h.buffer_size_output() for h in hs]
+    k = total // chunk
+    d_out = [torch.zeros((k + 2) * c, device=dev) for c in caps]
+    ls = ra.FirLockstep(hs, 512)
+    ls.bind_caps(d_in, d_out, caps)
+    ls.run_bulk(total, chunk)
+    cons, prod = ls.run_counts()
+    tail = total - k * chunk
+    if tail:
+        ct, pt = ls.counts()
+    worst = 0.0
+    for i, r in enumerate(refs):
+        y, calls = r.resample_all(xs[i], 2 * chunk, max_calls=k + 4)
+        assert calls.shape[0] == k + (1 if tail else 0), (i, calls.shape)
+        assert (calls[:k, 0] == cons[:, i]).all() and (calls[:k, 1] == prod[:, i]).all(), i
+        if tail:
+            assert (int(ct[i]), int(pt[i])) == (int(calls[k, 0]), int(calls[k, 1])), i
+        worst = max(worst, rms(d_out[i][:y.size].cpu().numpy(), y))
+    assert worst <= RMS_TOL, worst
+    ls.sync()
+    for h, r in zip(hs, refs):
+        assert h.state() == r.state()
