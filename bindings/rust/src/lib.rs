@@ -104,6 +104,8 @@ extern "C" {
                                     max_steps: usize) -> c_int;
     fn rsmp_fir_lockstep_sync(ls: *mut rsmp_fir_lockstep) -> c_int;
     fn rsmp_fir_lockstep_table_rebinds(ls: *const rsmp_fir_lockstep, rebinds: *mut usize) -> c_int;
+    fn rsmp_fir_lockstep_run_bulk(ls: *mut rsmp_fir_lockstep, total_frames: usize, chunk_frames: usize, in_offset_frames: usize,
+                                  append: c_int, stream: *mut std::os::raw::c_void) -> c_int;
     fn rsmp_fir_lockstep_stats(ls: *const rsmp_fir_lockstep, out: *mut u64, n: usize) -> c_int;
     fn rsmp_fir_lockstep_set_drift_policy(ls: *mut rsmp_fir_lockstep, tolerance_frames: f64, check_frames: usize) -> c_int;
 }
@@ -259,6 +261,12 @@ impl LockstepBatch {
     pub fn run(&mut self, k_steps: usize, in_frames: usize, in_offset_frames: usize, append: bool) -> Result<(), ResampleError> {
         self.last_run = k_steps;
         status(unsafe { rsmp_fir_lockstep_run(self.handle, k_steps, in_frames, in_offset_frames, append as c_int, std::ptr::null_mut()) })
+    }
+    /// A whole buffer per stream in calls of `chunk_frames` frames, the last one shorter (the loop of
+    /// resample/src/main.rs:226-254), planned on the device whatever states the streams are in.
+    pub fn run_bulk(&mut self, total_frames: usize, chunk_frames: usize, in_offset_frames: usize, append: bool) -> Result<(), ResampleError> {
+        self.last_run = total_frames / chunk_frames;
+        status(unsafe { rsmp_fir_lockstep_run_bulk(self.handle, total_frames, chunk_frames, in_offset_frames, append as c_int, std::ptr::null_mut()) })
     }
     /// (consumed, produced) of the last call of every stream, in f32 values; waits for the launch.
     pub fn counts(&mut self) -> Vec<(usize, usize)> {
