@@ -762,7 +762,41 @@ def secondary_lines(ctx: Ctx, args):
         again.append((time.perf_counter() - t2) * 1e3)
     k_again, _ = handles[0].mean_kernel_ms()
     handles[0].set_profiling(False)
+    # ... and the same batch through the DEVICE planner (rsmp_fir_lockstep_run_bulk: the calls' structure, the f64 chain and
+    # the wrapped outputs planned by three small kernels, nothing replayed on the host, no host threads): the first
+    # launch, then launches that continue the streams (each planned anew, the next one planned ahead beside this one's
+    # bulk kernel).  A stream is 4096 calls here and the chain is serial per stream: the planner, not the kernel, is the
+    # launch's length.
+    dp = {}
+    try:
+        frames_call = args.chunk // CHANNELS
+        ls = ra.FirLockstep(handles, frames_call)
+        caps = [h.buffer_size_output() for h in handles]
+        ls.bind_caps(batch._keep[0], batch._keep[1], caps)
+        ctx.torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        ls.run_bulk(args.frames, frames_call, 0, append=False, stream=ctx.stream)
+        ctx.torch.cuda.synchronize()
+        dp_cold = (time.perf_counter() - t3) * 1e3
+        dp_again = []
+        for _ in range(8):
+            t4 = time.perf_counter()
+            ls.run_bulk(args.frames, frames_call, 0, append=False, stream=ctx.stream)
+            ctx.torch.cuda.synchronize()
+            dp_again.append((time.perf_counter() - t4) * 1e3)
+        t5 = time.perf_counter()
+        for _ in range(8):   # ... and without a wait in between: the planner of launch r + 1 beside the kernel of launch r
+            ls.run_bulk(args.frames, frames_call, 0, append=False, stream=ctx.stream)
+        ctx.torch.cuda.synchronize()
+        dp = {"step_ms_cold": round(dp_cold, 2), "step_ms_replanned_median": round(sorted(dp_again)[len(dp_again) // 2], 2),
+              "step_ms_back_to_back": round((time.perf_counter() - t5) * 1e3 / 8, 2), "calls_per_stream": args.frames // frames_call,
+              "what": "rsmp_fir_lockstep_run_bulk on the same 64 streams: planned on the device (no host planning, no host threads)"}
+        ls.sync()
+        ls.close()
+    except Exception as e:
+        dp = {"error": repr(e)[:200]}
     sec["fir_distinct_states"] = {
+        "device_planned": dp,
         "what": f"{args.streams} streams in {args.streams} different states: the first launch (every stream replays its own "
                 f"control flow on the host's planning workers, then one launch), then launches that continue the streams "
                 f"(planned anew every time), wall clock of a launch incl. synchronisation",
