@@ -87,6 +87,10 @@ extern "C" {
     fn rsmp_fir_taps(r: *const rsmp_fir) -> usize;
     fn rsmp_fir_phases(r: *const rsmp_fir) -> usize;
     fn rsmp_fft_channels(r: *const rsmp_fft) -> usize;
+    // addition: WAV samples (resample/src/main.rs:128-137) converted where the FIR kernels read their input
+    fn rsmp_fir_batch_resample_bulk_pcm_device(rs: *const *mut rsmp_fir, n: usize, d_pcm: *const *const std::os::raw::c_void, bits: c_int,
+                                               in_lens: *const usize, chunk_len: usize, d_out: *const *mut f32, out_caps: *const usize,
+                                               consumed: *mut usize, produced: *mut usize, stream: *mut std::os::raw::c_void) -> c_int;
     // addition: WAV samples (resample/src/main.rs:128-137) converted inside the FFT kernel's first load
     fn rsmp_fft_batch_resample_bulk_pcm_device(rs: *const *mut rsmp_fft, n: usize, d_pcm: *const *const std::os::raw::c_void, bits: c_int,
                                                d_out: *const *mut f32, n_chunks: *const usize, stream: *mut std::os::raw::c_void) -> c_int;
@@ -166,6 +170,18 @@ impl ResamplerFir {
                               output.len(), &mut consumed, &mut produced)
         };
         status(rc).map(|_| (consumed, produced))
+    }
+
+    /// Addition to the reference API: the driver loop of resample/src/main.rs:226-254 (calls of `chunk_len` samples) over
+    /// a two-channel WAV file's samples as they are in the file -- `n_samples` little-endian PCM samples of `bits`
+    /// (16 / 24 / 32) in device memory -- into `d_out` (device memory, `out_cap` values); the conversion of
+    /// main.rs:128-137 happens where the kernels read their input.  Returns (consumed, produced) in samples.
+    pub unsafe fn resample_bulk_pcm_device(&mut self, d_pcm: *const std::os::raw::c_void, bits: u32, n_samples: usize, chunk_len: usize,
+                                           d_out: *mut f32, out_cap: usize) -> Result<(usize, usize), ResampleError> {
+        let (h, p, o) = ([self.handle], [d_pcm], [d_out]);
+        let (mut consumed, mut produced) = (0usize, 0usize);
+        status(rsmp_fir_batch_resample_bulk_pcm_device(h.as_ptr(), 1, p.as_ptr(), bits as c_int, &n_samples, chunk_len, o.as_ptr(), &out_cap,
+                                                       &mut consumed, &mut produced, std::ptr::null_mut())).map(|_| (consumed, produced))
     }
 }
 

@@ -151,6 +151,17 @@ int rsmp_fir_batch_resample_bulk_device(rsmp_fir* const* rs, size_t n, const flo
                                         const size_t* in_lens, size_t chunk_len,
                                         float* const* d_out, const size_t* out_caps,
                                         size_t* consumed, size_t* produced, void* stream);
+/* The same over a two-channel WAV file's samples as they are in the file (resample/src/main.rs:128-137): d_pcm[i] =
+ * little-endian PCM of `bits` (16 / 24 / 32) per sample, in_lens[i] SAMPLES (2 per frame), 4-byte aligned.  The samples are
+ * converted where the kernels read their input (`sample as f32 / (1 << (bits - 1)) as f32`, with the reference's 32-bit
+ * divisor -2^31): the output equals rsmp_pcm_to_stereo_f32_device + rsmp_fir_batch_resample_bulk_device's within the
+ * kernels' usual tolerance (the same samples reach the same arithmetic), and the launch reads 2 - 4 bytes a sample
+ * instead of the conversion pass's PCM + 4 written + 4 read.  Long launches need the 128-tap rate pairs of the split
+ * kernel (44.1 <-> 48 kHz, 96 -> 44.1 / 48 kHz ...: RSMP_ERR_INVALID_ARGUMENT otherwise -- convert first); at most one
+ * launch's worth of input per stream (46 M outputs). */
+int rsmp_fir_batch_resample_bulk_pcm_device(rsmp_fir* const* rs, size_t n, const void* const* d_pcm, int bits,
+                                            const size_t* in_lens, size_t chunk_len, float* const* d_out,
+                                            const size_t* out_caps, size_t* consumed, size_t* produced, void* stream);
 
 /* reset() for every stream of a batch. */
 void rsmp_fir_batch_reset(rsmp_fir* const* rs, size_t n);

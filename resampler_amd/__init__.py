@@ -185,6 +185,8 @@ _SIGNATURES = [
      [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p]),
     ("rsmp_fft_batch_resample_bulk_device", C.c_int,
      [C.POINTER(C.c_void_p), C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), _szp, C.c_void_p]),
+    ("rsmp_fir_batch_resample_bulk_pcm_device", C.c_int,
+     [C.POINTER(C.c_void_p), C.c_size_t, C.POINTER(C.c_void_p), C.c_int, _szp, C.c_size_t, C.POINTER(C.c_void_p), _szp, _szp, _szp, C.c_void_p]),
     ("rsmp_fft_batch_resample_bulk_pcm_device", C.c_int,
      [C.POINTER(C.c_void_p), C.c_size_t, C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_void_p), _szp, C.c_void_p]),
     ("rsmp_fft_plan_sizes", C.c_int,
@@ -462,6 +464,21 @@ class FirBatch:
             self._consumed, self._produced, C.c_void_p(stream or 0)))
         # zero-copy views (valid until the next call): converting 2 x n ctypes words to Python
         # ints costs more than the launch for batches of a thousand streams
+        return (np.ctypeslib.as_array(self._consumed), np.ctypeslib.as_array(self._produced))
+
+
+    def resample_bulk_pcm_device(self, d_pcms, bits: int, d_outs, chunk_len: int = 512, stream: Optional[int] = None):
+        """The bulk driver loop over two-channel WAV samples as they are in the file (rsmp_fir_batch_resample_bulk_pcm_device):
+        d_pcms = uint8 tensors of little-endian PCM, `bits` per sample; converted where the kernels read their input."""
+        n = len(self.resamplers)
+        pin, pout = (C.c_void_p * n)(), (C.c_void_p * n)()
+        lens, caps = (C.c_size_t * n)(), (C.c_size_t * n)()
+        for i, (a, b) in enumerate(zip(d_pcms, d_outs)):
+            pin[i], pout[i] = a.data_ptr(), _dev_ptr(b)
+            lens[i], caps[i] = a.numel() // (bits // 8), b.numel()
+        self._keep_pcm = (list(d_pcms), list(d_outs))
+        _check(lib().rsmp_fir_batch_resample_bulk_pcm_device(self._handles, n, pin, bits, lens, chunk_len, pout, caps,
+                                                             self._consumed, self._produced, C.c_void_p(stream or 0)))
         return (np.ctypeslib.as_array(self._consumed), np.ctypeslib.as_array(self._produced))
 
 

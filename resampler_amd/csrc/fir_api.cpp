@@ -405,7 +405,9 @@ size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // Assembles and enqueues the launches for a set of planned jobs on one device / stream.
 // `leader` owns the launch workspace.
-int launch_jobs(rsmp_fir* leader, std::vector<Job>& jobs, hipStream_t stream) {
+// pcm_bits != 0: every job's d_in is a WAV file's PCM of that width, read in place (FirStreamDesc::in_bits): two-channel
+// streams on the generic kernel (short launches) or the split kernel's PCM builds.
+int launch_jobs(rsmp_fir* leader, std::vector<Job>& jobs, hipStream_t stream, uint32_t pcm_bits = 0) {
     // Plans are shared, immutable once built; where a plan's arrays sit in THIS launch's workspace is
     // launch-local (streams of a batch that share a plan share its arrays too).
     struct Placement { size_t seg_off = 0, tile_off = 0, wrap_off = 0; bool written = false; };
@@ -444,6 +446,19 @@ int launch_jobs(rsmp_fir* leader, std::vector<Job>& jobs, hipStream_t stream) {
         if (!found) groups.push_back(Group{j.r->periodic.geo, {i}});
     }
     for (const Group& g : groups) for (size_t i : g.members) order.push_back(i);
+    if (pcm_bits != 0) {
+        for (const Job& j : jobs)
+            if (j.r->channels != 2) return rsmp::fail(RSMP_ERR_INVALID_ARGUMENT, "PCM input: two-channel streams only");
+        for (const Group& g : groups) {
+            const uint32_t nk = g.geo.row_len / 32;
+            const bool ok = g.geo.mfma == 3 && g.geo.planes == 2 && g.geo.lp == 1 && g.geo.cg == 2 &&
+                            ((g.geo.rounds == 1 && nk == 5) || (g.geo.rounds == 2 && (nk == 5 || nk == 6)));
+            if (!ok)
+                return rsmp::fail(RSMP_ERR_INVALID_ARGUMENT,
+                                  "PCM input is read in place by the two-channel split kernel of the 128-tap rate pairs only "
+                                  "(44.1 <-> 48, 96 -> 44.1 / 48 kHz ...): convert with rsmp_pcm_to_stereo_f32_device first");
+        }
+    }
 
     // Workspace layout: [descs] then per distinct plan: [runs][tile index] or [wraps].
     size_t bytes = align_up(n * sizeof(FirStreamDesc), 256);
@@ -518,6 +533,7 @@ int launch_jobs(rsmp_fir* leader, std::vector<Job>& jobs, hipStream_t stream) {
         ds.den = static_cast<uint32_t>(r->mirror.den());
         ds.abs_out = r->mirror.abs_out();
         ds.abs_consumed = r->mirror.abs_consumed();
+        ds.in_bits = pcm_bits;
         if (ds.tail_frames * ch > max_tail_values) max_tail_values = ds.tail_frames * ch;
         if (!pl.periodic) {
             ds.segs = reinterpret_cast<const rsmp_fir_segment*>(d + pp.seg_off);
@@ -646,14 +662,14 @@ int launch_jobs(rsmp_fir* leader, std::vector<Job>& jobs, hipStream_t stream) {
             mix(j.plan->hist_frames); mix(j.plan->accepted_frames); mix(j.r->channels);
         }
         if (key == 0) key = 1;
-        if (groups.size() > 1 && g.geo.mfma == 3) {
+        if (groups.size() > 1 && g.geo.mfma == 3 && pcm_bits == 0) {
             // several rate pairs in one batch: those of the split kernel share launches (launch_fir_split_multi: one item
             // table launch, one kernel launch per kernel build among them), as in rsmp_fir_lockstep_run
             split_jobs.push_back(rsmp::SplitJob{d_descs + first, static_cast<uint32_t>(g.members.size()), &g.geo, max_blocks, rp.nf});
         } else {
             RSMP_HIP_CHECK(rsmp::launch_fir_periodic(d_descs + first,
                                                      static_cast<uint32_t>(g.members.size()), g.geo,
-                                                     max_blocks, leader->d_work_counter, rp.nf, stream, tail_fused, key));
+                                                     max_blocks, leader->d_work_counter, rp.nf, stream, tail_fused, key, pcm_bits));
         }
         first += g.members.size();
     }
@@ -1010,7 +1026,7 @@ extern "C" int rsmp_fir_resample_bulk(rsmp_fir* r, const float* in, size_t in_le
 
 static int batch_bulk_piece(rsmp_fir* const* rs, size_t n, const float* const* d_in, const size_t* in_lens,
                             size_t chunk_len, float* const* d_out, const size_t* out_caps, size_t* consumed,
-                            size_t* produced, void* stream);
+                            size_t* produced, void* stream, uint32_t pcm_bits = 0);
 
 extern "C" int rsmp_fir_batch_resample_bulk_device(rsmp_fir* const* rs, size_t n,
                                                    const float* const* d_in, const size_t* in_lens,
@@ -1076,7 +1092,7 @@ extern "C" int rsmp_fir_batch_resample_bulk_device(rsmp_fir* const* rs, size_t n
 
 static int batch_bulk_piece(rsmp_fir* const* rs, size_t n, const float* const* d_in, const size_t* in_lens,
                             size_t chunk_len, float* const* d_out, const size_t* out_caps, size_t* consumed,
-                            size_t* produced, void* stream) {
+                            size_t* produced, void* stream, uint32_t pcm_bits) {
     for (size_t i = 0; i < n; ++i) {
         if (!rs[i] || rs[i]->device != rs[0]->device)
             return rsmp::fail(RSMP_ERR_INVALID_ARGUMENT, "batch streams must share one device");
@@ -1138,7 +1154,7 @@ static int batch_bulk_piece(rsmp_fir* const* rs, size_t n, const float* const* d
                               j.plan->produced_frames * rs[i]->channels, out_caps[i]);
     }
     const auto t_planned = std::chrono::steady_clock::now();
-    const int rc = launch_jobs(rs[0], jobs, s);
+    const int rc = launch_jobs(rs[0], jobs, s, pcm_bits);
     if (rc != RSMP_OK) return rc;
     if (verbose_t) {
         const auto t_end = std::chrono::steady_clock::now();
@@ -1151,4 +1167,31 @@ static int batch_bulk_piece(rsmp_fir* const* rs, size_t n, const float* const* d
         if (produced) produced[i] = jobs[i].produced();
     }
     return RSMP_OK;
+}
+
+// The bulk driver loop over a WAV file's samples as they are in the file (resample/src/main.rs:128-137 + :226-254):
+// d_pcm[i] = little-endian PCM of `bits` (16 / 24 / 32) per sample, two channels a frame, in_lens[i] SAMPLES; the
+// conversion happens where the kernels read their input -- the split kernel's prefetch loads, its edge and wrap-window
+// paths, the tail copy, the repair pass -- so the launch reads the PCM alone: rsmp_pcm_to_stereo_f32_device + the f32
+// entry point give the same samples with one more pass over HBM (PCM read, f32 written, f32 read).
+extern "C" int rsmp_fir_batch_resample_bulk_pcm_device(rsmp_fir* const* rs, size_t n, const void* const* d_pcm, int bits,
+                                                       const size_t* in_lens, size_t chunk_len, float* const* d_out,
+                                                       const size_t* out_caps, size_t* consumed, size_t* produced, void* stream) {
+    if (n == 0) return RSMP_OK;
+    if (!rs || !d_pcm || !in_lens || !d_out || !out_caps || chunk_len == 0 || (bits != 16 && bits != 24 && bits != 32))
+        return rsmp::fail(RSMP_ERR_INVALID_ARGUMENT, "rsmp_fir_batch_resample_bulk_pcm_device: null / zero argument, or bits not 16 / 24 / 32");
+    std::vector<const float*> in(n);
+    for (size_t i = 0; i < n; ++i) {
+        if (!rs[i] || rs[i]->channels != 2)
+            return rsmp::fail(RSMP_ERR_INVALID_ARGUMENT, "rsmp_fir_batch_resample_bulk_pcm_device: two-channel streams only");
+        if (reinterpret_cast<uintptr_t>(d_pcm[i]) % 4 != 0)
+            return rsmp::fail(RSMP_ERR_INVALID_ARGUMENT, "PCM input must be 4-byte aligned");
+        // (a launch's coefficient rows are mixed for one drift: a stream offered more than one launch's worth of input
+        // goes through the f32 entry point, which cuts it -- 16 minutes of audio)
+        const size_t chunks = static_cast<size_t>(static_cast<double>(kMaxLaunchOutputs) * rs[i]->mirror.ratio() / static_cast<double>(chunk_len / 2 ? chunk_len / 2 : 1));
+        if (chunk_len % 2 == 0 && in_lens[i] % 2 == 0 && in_lens[i] > (chunks ? chunks : 1) * chunk_len)
+            return rsmp::fail(RSMP_ERR_INVALID_ARGUMENT, "rsmp_fir_batch_resample_bulk_pcm_device: more than one launch's worth of input (46 M outputs)");
+        in[i] = static_cast<const float*>(d_pcm[i]);
+    }
+    return batch_bulk_piece(rs, n, in.data(), in_lens, chunk_len, d_out, out_caps, consumed, produced, stream, static_cast<uint32_t>(bits));
 }

@@ -36,7 +36,7 @@ __device__ __forceinline__ float group_sum8(float v) {
 __device__ __forceinline__ float load_sample(const FirStreamDesc& d, int64_t v, uint32_t c) {
     return v < static_cast<int64_t>(d.hist_frames)
                ? d.hist[static_cast<size_t>(v) * d.channels + c]
-               : d.in[static_cast<size_t>(v - d.hist_frames) * d.channels + c];
+               : fir_in_value(d, static_cast<size_t>(v - d.hist_frames) * d.channels + c);
 }
 
 // fuse_tail: the first workgroup of every stream also copies the stream's still-buffered frames into hist_next
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(kBlock) void fir_generic_kernel(const FirStreamDesc
         const size_t hist_values = static_cast<size_t>(d.hist_frames) * d.channels;
         for (size_t i = threadIdx.x; i < total; i += kBlock) {
             const size_t src = first + i;
-            d.hist_next[i] = src < hist_values ? d.hist[src] : d.in[src - hist_values];
+            d.hist_next[i] = src < hist_values ? d.hist[src] : fir_in_value(d, src - hist_values);
         }
     }
     if (tile_first >= d.n_out) return;
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(kBlock) void fir_tail_copy_kernel(const FirStreamDe
     for (size_t i = blockIdx.x * static_cast<size_t>(kBlock) + threadIdx.x; i < total;
          i += static_cast<size_t>(gridDim.x) * kBlock) {
         const size_t src = first + i;
-        d.hist_next[i] = src < hist_values ? d.hist[src] : d.in[src - hist_values];
+        d.hist_next[i] = src < hist_values ? d.hist[src] : fir_in_value(d, src - hist_values);
     }
 }
 

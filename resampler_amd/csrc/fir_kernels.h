@@ -43,7 +43,25 @@ struct FirStreamDesc {
     uint64_t abs_consumed;         // input frames retired since reset, before this launch
     uint64_t wrap_k0;              // wrap_bits bit K <-> absolute output (wrap_k0 + K) * den
     double drift;                  // periodic kernels: the f64 drift the stream's class table was built for
+    // 0: `in` is interleaved f32.  16 / 24 / 32: `in` is a WAV file's little-endian PCM of that width, `channels` samples
+    // a frame, converted where it is read as resample/src/main.rs:128-137 converts it (fir_pcm_value below); `hist`
+    // -- the frames an earlier launch left buffered -- is f32 always.
+    uint32_t in_bits;
+    uint32_t pad_bits;
 };
+
+// One sample of a stream's `in`, index `i` in values (frame * channels + channel).
+// main.rs:131: `sample as f32 / (1 << (bits - 1)) as f32`; the literal is an i32, so 32-bit files divide by -2^31.
+__device__ __forceinline__ float fir_pcm_value(const void* in, uint32_t bits, size_t i) {
+    if (bits == 16) return static_cast<float>(static_cast<const int16_t*>(in)[i]) * (1.0f / 32768.0f);
+    if (bits == 32) return static_cast<float>(static_cast<const int32_t*>(in)[i]) * (-1.0f / 2147483648.0f);
+    const uint8_t* p = static_cast<const uint8_t*>(in) + 3 * i;
+    const uint32_t u = static_cast<uint32_t>(p[0]) | (static_cast<uint32_t>(p[1]) << 8) | (static_cast<uint32_t>(p[2]) << 16);
+    return static_cast<float>(static_cast<int32_t>(u << 8) >> 8) * (1.0f / 8388608.0f);
+}
+__device__ __forceinline__ float fir_in_value(const FirStreamDesc& d, size_t i) {
+    return d.in_bits == 0 ? d.in[i] : fir_pcm_value(d.in, d.in_bits, i);
+}
 
 constexpr uint32_t kFirTile = 32;   // output frames per workgroup tile (generic kernel): one pass of 32 x 8 lanes
 

@@ -133,10 +133,12 @@ void periodic_fill_wrap_bits(const std::vector<uint32_t>& wraps, uint64_t abs_ou
 // `nf`: where non-finite sums are marked (fir_nonfinite.h); the caller follows up with launch_fir_repair.
 // items_key: a hash of everything the split kernel's item table depends on (the streams' counters in launch order; 0 =
 // none): a launch with the key of the table already in the stream's workspace does not rebuild it.
+// pcm_bits != 0: the streams' `in` is PCM of that width (FirStreamDesc::in_bits): the split kernel's two-channel builds
+// read it; hipErrorNotSupported for any other kernel.
 hipError_t launch_fir_periodic(const FirStreamDesc* d_descs, uint32_t n_streams,
                                const PeriodicGeometry& geo, uint32_t max_blocks,
                                unsigned long long* d_work_counter, const NfArgs& nf, hipStream_t stream,
-                               bool fuse_tail = false, uint64_t items_key = 0);
+                               bool fuse_tail = false, uint64_t items_key = 0, uint32_t pcm_bits = 0);
 // Recomputes the outputs listed in each stream's `wraps` with row 1023 / previous frame
 // (only for geometries without inline wraps).
 hipError_t launch_fir_wrap_fixup(const FirStreamDesc* d_descs, uint32_t n_streams,
@@ -153,7 +155,7 @@ void split_store_class(std::vector<float>& coef, const PeriodicGeometry& g, uint
 // fuse_tail: the kernel also copies every stream's still-buffered tail into hist_next (no tail-copy launch)
 hipError_t launch_fir_split(const FirStreamDesc* d_descs, uint32_t n_streams, const PeriodicGeometry& geo,
                             uint32_t max_blocks, uint32_t cus, bool fuse_tail, const NfArgs& nf, hipStream_t stream,
-                            uint64_t items_key = 0);
+                            uint64_t items_key = 0, uint32_t pcm_bits = 0);
 
 // Several rate pairs in as few launches as their geometries allow (one item-table launch for all of them, then one
 // launch of the kernel per window length among them): `jobs[j]` = the streams d_descs[0 .. n_streams) of geometry

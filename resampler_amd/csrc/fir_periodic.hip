@@ -2118,7 +2118,7 @@ int periodic_bind(PeriodicState& st, int device, const std::vector<float>& table
 hipError_t launch_fir_periodic(const FirStreamDesc* d_descs, uint32_t n_streams,
                                const PeriodicGeometry& geo, uint32_t max_blocks,
                                unsigned long long* d_work_counter, const NfArgs& nf, hipStream_t stream,
-                               bool fuse_tail, uint64_t items_key) {
+                               bool fuse_tail, uint64_t items_key, uint32_t pcm_bits) {
     if (n_streams == 0 || max_blocks == 0) return hipSuccess;
     const dim3 block(geo.waves * 64);
     GeoArgs args = to_args(geo);
@@ -2141,7 +2141,8 @@ hipError_t launch_fir_periodic(const FirStreamDesc* d_descs, uint32_t n_streams,
         }
         cus = c;
     }
-    if (geo.mfma == 3) return launch_fir_split(d_descs, n_streams, geo, max_blocks, cus, fuse_tail, nf, stream, items_key);
+    if (geo.mfma == 3) return launch_fir_split(d_descs, n_streams, geo, max_blocks, cus, fuse_tail, nf, stream, items_key, pcm_bits);
+    if (pcm_bits != 0) return hipErrorNotSupported;
     args.nf = nf;
     const uint32_t slots = cus * (geo.lds_bytes > kLdsTwoPerCu ? 1u : 2u);   // workgroups that fit
     const dim3 grid(args.total_items < slots ? args.total_items : slots);

@@ -415,6 +415,31 @@ __device__ __forceinline__ void gload2(v2f& dst, uint32_t byte_off, const void* 
 __device__ __forceinline__ void gload1(uint32_t& dst, uint32_t byte_off, const void* base) {
     asm volatile("global_load_dword %0, %1, %2" : "=v"(dst) : "v"(byte_off), "s"(base) : "memory");
 }
+// PCM input (BITS = 16 / 24 / 32; FirStreamDesc::in_bits): what a prefetch load of two consecutive two-channel FRAMES
+// fetches -- 8 bytes (16-bit), 16 bytes of which the first 12 count (24-bit: at any even byte address) or 16 bytes
+// (32-bit) -- and its conversion to (ch0, ch1, ch0', ch1') as resample/src/main.rs:128-137 converts a sample.
+template <int BITS> struct PcmRaw { typedef v4f type; };
+template <> struct PcmRaw<16> { typedef v2f type; };
+__device__ __forceinline__ void gload_raw(v4f& dst, uint32_t byte_off, const void* base) { gload4(dst, byte_off, base); }
+__device__ __forceinline__ void gload_raw(v2f& dst, uint32_t byte_off, const void* base) { gload2(dst, byte_off, base); }
+template <int BITS, class RAW>
+__device__ __forceinline__ v4f pcm_frames(const RAW& raw) {
+    if constexpr (BITS == 0) {
+        return raw;
+    } else if constexpr (BITS == 16) {
+        const uint32_t w0 = __float_as_uint(raw.x), w1 = __float_as_uint(raw.y);
+        auto lo = [](uint32_t w) { return static_cast<float>(static_cast<int32_t>(w << 16) >> 16); };
+        auto hi = [](uint32_t w) { return static_cast<float>(static_cast<int32_t>(w) >> 16); };
+        return v4f{lo(w0), hi(w0), lo(w1), hi(w1)} * (1.0f / 32768.0f);
+    } else if constexpr (BITS == 24) {
+        const uint32_t w0 = __float_as_uint(raw.x), w1 = __float_as_uint(raw.y), w2 = __float_as_uint(raw.z);
+        auto s24 = [](uint32_t w) { return static_cast<float>(static_cast<int32_t>(w << 8) >> 8); };
+        return v4f{s24(w0), s24((w0 >> 24) | (w1 << 8)), s24((w1 >> 16) | (w2 << 16)), static_cast<float>(static_cast<int32_t>(w2) >> 8)} * (1.0f / 8388608.0f);
+    } else {
+        auto f = [](float w) { return static_cast<float>(static_cast<int32_t>(__float_as_uint(w))); };
+        return v4f{f(raw.x), f(raw.y), f(raw.z), f(raw.w)} * (-1.0f / 2147483648.0f);
+    }
+}
 
 // Sum over the 16 lanes of a DPP row (every lane gets the total).
 __device__ __forceinline__ float row_sum16(float v) {
@@ -456,7 +481,7 @@ __device__ __forceinline__ uint32_t consumer_index(uint32_t w) { return w < 6 ? 
 // other's registers (two wrap passes against one + the 40 registers of a stager's loads).
 // ROUNDS: lane tasks per stager lane and item -- 2 for periods of 161 .. 320 frames (96 -> 44.1 kHz, 96 -> 48 kHz): both
 // rounds' loads are in flight together, one item ahead, like the single round's.
-template <int NK, int PLANES, bool DIAG, int WIDE, int ROUNDS = 1>   // WIDE: 0 two channels, 1 channel pairs, 2 one channel, 3 pairs + a last channel alone
+template <int NK, int PLANES, bool DIAG, int WIDE, int ROUNDS = 1, int BITS = 0>   // WIDE: 0 two channels, 1 channel pairs, 2 one channel, 3 pairs + a last channel alone; BITS: the input's PCM width (0: f32)
 __device__ __forceinline__ void fir_split_body(const FirStreamDesc* __restrict__ descs, const SplitArgs& g,
                                                const uint32_t wg, const uint32_t n_wgs) {   // workgroup `wg` of the `n_wgs` that share g's items
     static_assert(ROUNDS == 1 || ((WIDE == 0 || WIDE == 1) && PLANES == 2), "two rounds: two channels or channel pairs, fp16 planes");
@@ -525,7 +550,7 @@ __device__ __forceinline__ void fir_split_body(const FirStreamDesc* __restrict__
             const uint32_t total = d.tail_frames * fs, first = d.tail_start * fs, hist_values = d.hist_frames * fs;
             for (uint32_t i = lane; i < total; i += 64) {
                 const uint32_t sv = first + i;
-                d.hist_next[i] = sv < hist_values ? d.hist[sv] : d.in[sv - hist_values];
+                d.hist_next[i] = sv < hist_values ? d.hist[sv] : fir_in_value(d, sv - hist_values);
             }
         }
     }
@@ -591,6 +616,7 @@ __device__ __forceinline__ void fir_split_body(const FirStreamDesc* __restrict__
                     v = fc < hf ? *(gconst_f2u_ptr)(c.hist + fc * fs + 2 * pair) : *(gconst_f2u_ptr)(c.in + (fc - hf) * fs + 2 * pair);
                 } else v = fc < hf ? *(gconst_f2_ptr)(c.hist + fc * fs + 2 * pair) : *(gconst_f2_ptr)(c.in + (fc - hf) * fs + 2 * pair);
             }
+            else if constexpr (BITS != 0) v = fc < hf ? ((gconst_f2_ptr)c.hist)[fc] : v2f{fir_pcm_value(c.in, BITS, 2 * static_cast<size_t>(fc - hf)), fir_pcm_value(c.in, BITS, 2 * static_cast<size_t>(fc - hf) + 1)};
             else v = fc < hf ? ((gconst_f2_ptr)c.hist)[fc] : ((gconst_f2_ptr)c.in)[fc - hf];
             if (!ok) v = v2f{0.f, 0.f};
             return v;
@@ -632,11 +658,13 @@ __device__ __forceinline__ void fir_split_body(const FirStreamDesc* __restrict__
             const float* cur_in = nullptr;
             // real = false: dummy loads of the first bytes of the descriptor array (always mapped), so that
             // every pass through the loop issues the same loads
-            auto load_task = [&](v4f (&v)[5], bool real, const PItem& pi, const void* base, int rd) {
-                const uint32_t off = real ? (pi.off0 + 4 * tQ[rd] * g.a + 2 * tK[rd]) * 8u : 0u;
-                const uint32_t step = real ? g.a * 8u : 0u;
+            constexpr uint32_t kInFrameBytes = BITS == 0 ? 8u : 2u * BITS / 8u;   // two channels a frame
+            typedef typename PcmRaw<BITS>::type xraw_t;
+            auto load_task = [&](xraw_t (&v)[5], bool real, const PItem& pi, const void* base, int rd) {
+                const uint32_t off = real ? (pi.off0 + 4 * tQ[rd] * g.a + 2 * tK[rd]) * kInFrameBytes : 0u;
+                const uint32_t step = real ? g.a * kInFrameBytes : 0u;
 #pragma unroll
-                for (int i = 0; i < 5; ++i) gload4(v[i], off + i * step, base);
+                for (int i = 0; i < 5; ++i) gload_raw(v[i], off + i * step, base);
             };
             // WIDE: a 16-byte load is FOUR channels of one frame -- two channel pairs, i.e. two consecutive items of the
             // block: the loads are issued for the even pair (`base` = its first channel) and stay in the registers
@@ -738,7 +766,7 @@ __device__ __forceinline__ void fir_split_body(const FirStreamDesc* __restrict__
             #define wpart (ln & 15)
             float wcoef[kWrapTaps];
             const float* cur_coeffs = nullptr;
-            v4f wx[2][kWrapTaps / 2];
+            xraw_t wx[2][kWrapTaps / 2];
             v2f wxw[kMaxPass][kWrapTaps];   // WIDE: one frame (the pair's two channels) per load
             uint32_t wword[kMaxPass], wsel[kMaxPass];   // the bitmap word with this lane's period's take bit, the bit (32 = none)
 #pragma unroll
@@ -795,9 +823,9 @@ __device__ __forceinline__ void fir_split_body(const FirStreamDesc* __restrict__
                         for (int i = 0; i < kWrapTaps; ++i) gload2(wxw[ps][i], off + i * fsb, base);
                     } else {
                         const void* base = uniform_ptr<true>(c.in);
-                        const uint32_t off = (pi.off0 + wper * g.a - 1 + wpart * kWrapTaps) * 8u;
+                        const uint32_t off = (pi.off0 + wper * g.a - 1 + wpart * kWrapTaps) * kInFrameBytes;
 #pragma unroll
-                        for (int i = 0; i < kWrapTaps / 2; ++i) gload4(wx[ps][i], off + i * 16u, base);
+                        for (int i = 0; i < kWrapTaps / 2; ++i) gload_raw(wx[ps][i], off + i * 2u * kInFrameBytes, base);
                     }
                 }
             };
@@ -819,8 +847,8 @@ __device__ __forceinline__ void fir_split_body(const FirStreamDesc* __restrict__
             // flight across the loop's back edge must have no other definition, or the allocator may give the loop-carried
             // value a second home and copy it there at the latch -- before it has landed (it did: the three-plane build
             // copied x at the latch once the edge path wrote x too, and converted garbage).  The item's samples live in xc.
-            v4f x[5];
-            v4f x2[5];            // two rounds, two channels: round 1's loads
+            xraw_t x[5];
+            xraw_t x2[5];         // two rounds, two channels: round 1's loads
             v4f xc[5];            // the current item's (round's) lane task: x, x2 or the edge frames
             constexpr bool kShare = ROLE == 3 && WIDE == 1;   // two rounds, channel pairs: an even item stages its odd partner too
             bool odd_done = false;     // kShare: the current (odd) item was staged with the item before it
@@ -895,8 +923,9 @@ __device__ __forceinline__ void fir_split_body(const FirStreamDesc* __restrict__
                                     w[2 * i] = wxw[ps][2 * i];
                                     w[2 * i + 1] = wxw[ps][2 * i + 1];
                                 } else {
-                                    w[2 * i] = v2f{wx[ps][i].x, wx[ps][i].y};
-                                    w[2 * i + 1] = v2f{wx[ps][i].z, wx[ps][i].w};
+                                    const v4f wf = pcm_frames<BITS>(wx[ps][i]);
+                                    w[2 * i] = v2f{wf.x, wf.y};
+                                    w[2 * i + 1] = v2f{wf.z, wf.w};
                                 }
                             }
                             wrap_out(w, wper, wsel[ps] < 32 ? (wword[ps] >> wsel[ps]) & 1u : 0u);
@@ -975,7 +1004,7 @@ __device__ __forceinline__ void fir_split_body(const FirStreamDesc* __restrict__
                     if (!loaded) fetch_edge_round(0);
                     else if constexpr ((ROLE == 0 || ROLE == 3) && !kShare) {
 #pragma unroll
-                        for (int i = 0; i < 5; ++i) xc[i] = x[i];
+                        for (int i = 0; i < 5; ++i) xc[i] = pcm_frames<BITS>(x[i]);
                     }
                     // at(i, fr, c) = channel c of frame 2K + fr in period 4Q + i of the lane task in the registers; partner:
                     // the same of the block's odd pair (kShare: the upper half of the sixteen bytes)
@@ -1166,7 +1195,7 @@ __device__ __forceinline__ void fir_split_body(const FirStreamDesc* __restrict__
 #pragma unroll
                                 for (int i = 0; i < 5; ++i) {
                                     asm volatile("" : "+v"(x2[i]));
-                                    xc[i] = x2[i];
+                                    xc[i] = pcm_frames<BITS>(x2[i]);
                                 }
                             } else {
                                 fetch_edge_round(1);
@@ -1524,9 +1553,10 @@ __device__ __forceinline__ void fir_split_body(const FirStreamDesc* __restrict__
     wt.flush();
 }
 
-template <int NK, int PLANES, bool DIAG, int WIDE, int ROUNDS = 1>
+template <int NK, int PLANES, bool DIAG, int WIDE, int ROUNDS = 1, int BITS = 0>
 __global__ __launch_bounds__(1024) void fir_split_kernel(const FirStreamDesc* __restrict__ descs, const SplitArgs g) {
-    fir_split_body<NK, PLANES, DIAG, WIDE, ROUNDS>(descs, g, blockIdx.x, gridDim.x);
+    static_assert(BITS == 0 || (WIDE == 0 && PLANES == 2 && !DIAG), "PCM input: the two-channel fp16 build");
+    fir_split_body<NK, PLANES, DIAG, WIDE, ROUNDS, BITS>(descs, g, blockIdx.x, gridDim.x);
 }
 template <int NK, int PLANES, int WIDE, int ROUNDS>
 __global__ __launch_bounds__(1024) void fir_split_multi_kernel(const SplitMulti m) {
@@ -1767,7 +1797,7 @@ uint32_t device_cus(int device) {
 
 hipError_t launch_fir_split(const FirStreamDesc* d_descs, uint32_t n_streams, const PeriodicGeometry& geo,
                             uint32_t max_blocks, uint32_t cus, bool fuse_tail, const NfArgs& nf, hipStream_t stream,
-                            uint64_t items_key) {
+                            uint64_t items_key, uint32_t pcm_bits) {
     const uint32_t debug = split_debug_knob();
     const uint32_t pairs = geo.lp;
     const bool wide = pairs > 1 || geo.cg == 1;
@@ -1809,6 +1839,21 @@ hipError_t launch_fir_split(const FirStreamDesc* d_descs, uint32_t n_streams, co
                                          : fns_all[geo.planes == 3 ? 1 : 0][diag ? 1 : 0];
     const uint32_t nk = geo.row_len / 32;
     if (nk < 1 || nk > (two_rounds ? 6u : 5u) || fns[nk - 1] == nullptr) return hipErrorInvalidValue;
+    // PCM input (FirStreamDesc::in_bits): the two-channel fp16 builds of the 128-tap windows -- 160 taps in one round
+    // (44.1 <-> 48 kHz) or two, 192 taps in two rounds (96 -> 44.1 kHz) -- exist for the three widths; hipErrorNotSupported
+    // for any other geometry (the caller converts with rsmp_pcm_to_stereo_f32_device first).
+    const void* fn = fns[nk - 1];
+    if (pcm_bits != 0) {
+#define RSMP_PCM_FNS(B)                                                                                                   \
+    {reinterpret_cast<const void*>(fir_split_kernel<5, 2, false, 0, 1, B>), reinterpret_cast<const void*>(fir_split_kernel<5, 2, false, 0, 2, B>), \
+     reinterpret_cast<const void*>(fir_split_kernel<6, 2, false, 0, 2, B>)}
+        static const void* const fns_pcm[3][3] = {RSMP_PCM_FNS(16), RSMP_PCM_FNS(24), RSMP_PCM_FNS(32)};
+#undef RSMP_PCM_FNS
+        const int v = !two_rounds && nk == 5 ? 0 : two_rounds && nk == 5 ? 1 : two_rounds && nk == 6 ? 2 : -1;
+        if (wide || one_channel || odd_count || geo.planes != 2 || diag || v < 0 || (pcm_bits != 16 && pcm_bits != 24 && pcm_bits != 32))
+            return hipErrorNotSupported;
+        fn = fns_pcm[pcm_bits == 16 ? 0 : pcm_bits == 24 ? 1 : 2][v];
+    }
     int device = 0;
     hipError_t e = hipGetDevice(&device);
     if (e != hipSuccess) return e;
@@ -1816,9 +1861,9 @@ hipError_t launch_fir_split(const FirStreamDesc* d_descs, uint32_t n_streams, co
     static std::map<std::pair<int, uint32_t>, bool> granted;
     {
         std::lock_guard<std::mutex> lock(mu);
-        bool& have = granted[{device, (((nk * 8 + geo.planes) * 2 + ((diag && !wide) || diag_long ? 1u : 0u)) * 4 + (one_channel ? 2u : odd_count ? 3u : wide ? 1u : 0u)) * 2 + (two_rounds ? 1u : 0u)}];
+        bool& have = granted[{device, ((((nk * 8 + geo.planes) * 2 + ((diag && !wide) || diag_long ? 1u : 0u)) * 4 + (one_channel ? 2u : odd_count ? 3u : wide ? 1u : 0u)) * 2 + (two_rounds ? 1u : 0u)) * 64 + pcm_bits}];
         if (!have) {
-            e = hipFuncSetAttribute(fns[nk - 1], hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit);
+            e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit);
             if (e != hipSuccess) return e;
             have = true;
         }
@@ -1854,7 +1899,7 @@ hipError_t launch_fir_split(const FirStreamDesc* d_descs, uint32_t n_streams, co
         }
     }
     void* kargs[2] = {&d_descs, &args};
-    e = hipLaunchKernel(fns[nk - 1], grid, dim3(kWaves * 64), kargs,
+    e = hipLaunchKernel(fn, grid, dim3(kWaves * 64), kargs,
                         geo.lds_bytes + (wtrace_path ? 16 * kWtraceSlots * 8 : 0), stream);
     if (e != hipSuccess) return e;
     if (wtrace_path) {   // one line per wave: block wave event...
