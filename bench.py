@@ -441,6 +441,53 @@ def fir_channels_point(ctx: Ctx, ra, args, channels: int, steps: int):
     return point
 
 
+def fir_pcm_point(ctx: Ctx, ra, args, bits: int, steps: int):
+    """The headline launch fed 16-bit WAV samples as they are in the file (rsmp_fir_batch_resample_bulk_pcm_device: the
+    conversion of resample/src/main.rs:128-137 inside the kernels' loads) against the two-pass route: the conversion
+    pass (rsmp_pcm_to_stereo_f32_device per stream) + the f32 launch."""
+    torch = ctx.torch
+    S, N = args.streams, args.frames
+    handles = [ra.ResamplerFir.new(CHANNELS, ra.SampleRate.Hz44100, ra.SampleRate.Hz48000, ra.Latency.Sample64,
+                                   ra.Attenuation.Db90, device=ctx.local_rank) for _ in range(S)]
+    dt = {16: torch.int16, 32: torch.int32}[bits]
+    lim = 1 << (bits - 2)
+    pcm = [torch.randint(-lim, lim, (CHANNELS * N,), device=ctx.dev, dtype=dt).view(torch.uint8) for _ in range(S)]
+    cap = handles[0].bulk_output_bound(CHANNELS * N, args.chunk)
+    d_out = [torch.empty(cap, device=ctx.dev, dtype=torch.float32) for _ in range(S)]
+    f32 = [torch.empty(CHANNELS * N, device=ctx.dev, dtype=torch.float32) for _ in range(S)]
+    batch = ra.FirBatch(handles)
+
+    def step():
+        batch.reset()
+        return batch.resample_bulk_pcm_device(pcm, bits, d_out, args.chunk, ctx.stream)
+    _, produced = step()
+    out_values = int(sum(produced))
+    spinup(ctx, step, 0.3)
+    handles[0].set_profiling(True)
+    for _ in range(steps):
+        step()
+    k_ms, _ = handles[0].mean_kernel_ms()
+    handles[0].set_profiling(False)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(2):
+        e0.record(torch.cuda.current_stream())
+        for p, f in zip(pcm, f32):
+            ra.pcm_to_stereo_f32_device(p, bits, CHANNELS, f, ctx.stream)
+        e1.record(torch.cuda.current_stream())
+        e1.synchronize()
+    conv_ms = e0.elapsed_time(e1)
+    alg = (bits // 8) * S * CHANNELS * N + 4.0 * out_values + 4.0 * 1024 * 128
+    ach = alg / (k_ms * 1e-3) / 1e9
+    point = {"kernel": "fir_split_kernel (fp16x2 MFMA, PCM%d loads)" % bits, "kernel_ms": round(k_ms, 4),
+             "algorithmic_bytes": int(alg), "achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4),
+             "Msamples_in_per_s_kernel": round(S * CHANNELS * N / (k_ms * 1e-3) / 1e6, 1),
+             "two_pass_conversion_ms": round(conv_ms, 4),
+             "what": "the headline launch reading %d-bit PCM in place; two_pass_conversion_ms = what the separate conversion pass "
+                     "of the same %d streams costs in front of the f32 launch" % (bits, S)}
+    del batch, handles
+    return point
+
+
 def bench_fft(ctx: Ctx, args, steps: int, warmup: int, with_cpu: bool):
     """ResamplerFft 2 ch 44.1k -> 48k (BASELINE config 3): a batch of `--streams` streams x 892 blocks
     of 1176 frames per step, one launch of the overlap-add FFT kernel."""
@@ -743,6 +790,10 @@ def secondary_lines(ctx: Ctx, args):
         sec["fir_split_bf16x3"] = {"error": repr(e)[:200]}
     # other channel counts on the default kernel (same rate pair and taps)
     sec["fir_channels"] = {str(c): fir_channels_point(ctx, ra, args, c, 64) for c in (1, 4, 8)}
+    try:
+        sec["fir_pcm16"] = fir_pcm_point(ctx, ra, args, 16, 32)
+    except Exception as e:
+        sec["fir_pcm16"] = {"error": repr(e)[:200]}
     # the same launch with every stream in a different state: nothing shares a plan
     t0 = time.perf_counter()
     handles, batch = make_fir_batch(ctx, ra, args.streams, args.frames, args.chunk, ra.FirKernel.Auto,

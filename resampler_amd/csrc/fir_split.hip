@@ -422,6 +422,20 @@ template <int BITS> struct PcmRaw { typedef v4f type; };
 template <> struct PcmRaw<16> { typedef v2f type; };
 __device__ __forceinline__ void gload_raw(v4f& dst, uint32_t byte_off, const void* base) { gload4(dst, byte_off, base); }
 __device__ __forceinline__ void gload_raw(v2f& dst, uint32_t byte_off, const void* base) { gload2(dst, byte_off, base); }
+// one frame (ch0, ch1) from the eight bytes loaded at its first byte
+template <int BITS>
+__device__ __forceinline__ v2f pcm_frame1(const v2f& raw) {
+    const uint32_t w0 = __float_as_uint(raw.x), w1 = __float_as_uint(raw.y);
+    if constexpr (BITS == 16) {
+        return v2f{static_cast<float>(static_cast<int32_t>(w0 << 16) >> 16), static_cast<float>(static_cast<int32_t>(w0) >> 16)} * (1.0f / 32768.0f);
+    } else if constexpr (BITS == 24) {
+        return v2f{static_cast<float>(static_cast<int32_t>(w0 << 8) >> 8), static_cast<float>(static_cast<int32_t>(((w0 >> 24) | (w1 << 8)) << 8) >> 8)} * (1.0f / 8388608.0f);
+    } else if constexpr (BITS == 32) {
+        return v2f{static_cast<float>(static_cast<int32_t>(w0)), static_cast<float>(static_cast<int32_t>(w1))} * (-1.0f / 2147483648.0f);
+    } else {
+        return raw;
+    }
+}
 template <int BITS, class RAW>
 __device__ __forceinline__ v4f pcm_frames(const RAW& raw) {
     if constexpr (BITS == 0) {
@@ -816,7 +830,14 @@ __device__ __forceinline__ void fir_split_body(const FirStreamDesc* __restrict__
                     wsel[ps] = in_launch ? K & 31u : 32u;
                 }
                 if (fetch) {
-                    if constexpr (ROLE != 0) {
+                    if constexpr (ROLE != 0 && BITS != 0) {
+                        // (two rounds, two channels, PCM: a frame per load -- eight bytes from the frame's first byte, of which
+                        // its 4 / 6 / 8 count; an interior item's windows end a frame before the input does)
+                        const void* base = uniform_ptr<true>(c.in);
+                        const uint32_t off = (pi.off0 + wper * g.a - 1 + wpart * kWrapTaps) * kInFrameBytes;
+#pragma unroll
+                        for (int i = 0; i < kWrapTaps; ++i) gload2(wxw[ps][i], off + i * kInFrameBytes, base);
+                    } else if constexpr (ROLE != 0) {
                         const void* base = uniform_ptr<true>(c.in + 2 * pi.pair);
                         const uint32_t off = (pi.off0 + wper * g.a - 1 + wpart * kWrapTaps) * fsb;
 #pragma unroll
@@ -919,7 +940,10 @@ __device__ __forceinline__ void fir_split_body(const FirStreamDesc* __restrict__
                         if (from_regs) {
 #pragma unroll
                             for (int i = 0; i < kWrapTaps / 2; ++i) {
-                                if constexpr (ROLE != 0) {
+                                if constexpr (ROLE != 0 && BITS != 0) {
+                                    w[2 * i] = pcm_frame1<BITS>(wxw[ps][2 * i]);
+                                    w[2 * i + 1] = pcm_frame1<BITS>(wxw[ps][2 * i + 1]);
+                                } else if constexpr (ROLE != 0) {
                                     w[2 * i] = wxw[ps][2 * i];
                                     w[2 * i + 1] = wxw[ps][2 * i + 1];
                                 } else {
