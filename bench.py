@@ -769,13 +769,24 @@ def secondary_lines(ctx: Ctx, args):
     """N = 1 only: the other figures the headline line is read against."""
     import resampler_amd as ra
     sec = {}
-    fft = bench_fft(ctx, args, steps=120, warmup=2, with_cpu=not args.no_cpu)   # (120 launches: ~60 ms)
-    sec["fft"] = {"metric": fft["metric"], "value": fft["value"], "unit": fft["unit"],
-                  "ms_per_step": fft["ms_per_step"], "workload": fft["config"]["workload"],
-                  "roofline": fft["roofline"], "cpu_baseline": fft.get("cpu_baseline")}
+
+    def guard(name, fn):
+        """One secondary figure; a failure costs that figure, not the line (the headline does not depend on any of them)."""
+        try:
+            sec[name] = fn()
+        except Exception as e:
+            sec[name] = {"error": repr(e)[:300]}
+            ctx.torch.cuda.synchronize()
+
+    def fft_point():
+        fft = bench_fft(ctx, args, steps=120, warmup=2, with_cpu=not args.no_cpu)   # (120 launches: ~60 ms)
+        return {"metric": fft["metric"], "value": fft["value"], "unit": fft["unit"],
+                "ms_per_step": fft["ms_per_step"], "workload": fft["config"]["workload"],
+                "roofline": fft["roofline"], "cpu_baseline": fft.get("cpu_baseline")}
+    guard("fft", fft_point)
     # (64 profiled launches each: 25-30 ms of kernel time behind half a second of spin-up)
-    sec["fir_exact_f32"] = fir_kernel_point(ctx, ra, args, ra.FirKernel.PeriodicF32, 64)
-    sec["fir_vector_no_mfma"] = fir_kernel_point(ctx, ra, args, ra.FirKernel.PeriodicVector, 64)
+    guard("fir_exact_f32", lambda: fir_kernel_point(ctx, ra, args, ra.FirKernel.PeriodicF32, 64))
+    guard("fir_vector_no_mfma", lambda: fir_kernel_point(ctx, ra, args, ra.FirKernel.PeriodicVector, 64))
     # the split kernel with every f32 operand cut EXACTLY into three bf16 planes (six products per term): a knob the
     # library reads once per process, so a child runs the same headline launch with it
     try:
@@ -789,75 +800,73 @@ def secondary_lines(ctx: Ctx, args):
     except Exception as e:   # (the headline does not depend on it)
         sec["fir_split_bf16x3"] = {"error": repr(e)[:200]}
     # other channel counts on the default kernel (same rate pair and taps)
-    sec["fir_channels"] = {str(c): fir_channels_point(ctx, ra, args, c, 64) for c in (1, 4, 8)}
-    try:
-        sec["fir_pcm16"] = fir_pcm_point(ctx, ra, args, 16, 32)
-    except Exception as e:
-        sec["fir_pcm16"] = {"error": repr(e)[:200]}
-    # the same launch with every stream in a different state: nothing shares a plan
-    t0 = time.perf_counter()
-    handles, batch = make_fir_batch(ctx, ra, args.streams, args.frames, args.chunk, ra.FirKernel.Auto,
-                                    distinct_states=True)
-    t1 = time.perf_counter()
-    batch.resample_bulk_device(args.chunk, ctx.stream)
-    ctx.torch.cuda.synchronize()
-    cold = (time.perf_counter() - t1) * 1e3
-    # ... and again and again WITHOUT reset: the streams go on from where they are, every launch plans every stream anew
-    # (no plan-cache hit), which is what a service that keeps feeding the same streams sees
-    again = []
-    handles[0].set_profiling(True)
-    for _ in range(6):
-        t2 = time.perf_counter()
+    guard("fir_channels", lambda: {str(c): fir_channels_point(ctx, ra, args, c, 64) for c in (1, 4, 8)})
+    guard("fir_pcm16", lambda: fir_pcm_point(ctx, ra, args, 16, 32))
+    def distinct_point():
+        # the same launch with every stream in a different state: nothing shares a plan
+        t0 = time.perf_counter()
+        handles, batch = make_fir_batch(ctx, ra, args.streams, args.frames, args.chunk, ra.FirKernel.Auto,
+                                        distinct_states=True)
+        t1 = time.perf_counter()
         batch.resample_bulk_device(args.chunk, ctx.stream)
         ctx.torch.cuda.synchronize()
-        again.append((time.perf_counter() - t2) * 1e3)
-    k_again, _ = handles[0].mean_kernel_ms()
-    handles[0].set_profiling(False)
-    # ... and the same batch through the DEVICE planner (rsmp_fir_lockstep_run_bulk: the calls' structure, the f64 chain and
-    # the wrapped outputs planned by three small kernels, nothing replayed on the host, no host threads): the first
-    # launch, then launches that continue the streams (each planned anew, the next one planned ahead beside this one's
-    # bulk kernel).  A stream is 4096 calls here and the chain is serial per stream: the planner, not the kernel, is the
-    # launch's length.
-    dp = {}
-    try:
-        frames_call = args.chunk // CHANNELS
-        ls = ra.FirLockstep(handles, frames_call)
-        caps = [h.buffer_size_output() for h in handles]
-        ls.bind_caps(batch._keep[0], batch._keep[1], caps)
-        ctx.torch.cuda.synchronize()
-        t3 = time.perf_counter()
-        ls.run_bulk(args.frames, frames_call, 0, append=False, stream=ctx.stream)
-        ctx.torch.cuda.synchronize()
-        dp_cold = (time.perf_counter() - t3) * 1e3
-        dp_again = []
-        for _ in range(8):
-            t4 = time.perf_counter()
+        cold = (time.perf_counter() - t1) * 1e3
+        # ... and again and again WITHOUT reset: the streams go on from where they are, every launch plans every stream anew
+        # (no plan-cache hit), which is what a service that keeps feeding the same streams sees
+        again = []
+        handles[0].set_profiling(True)
+        for _ in range(6):
+            t2 = time.perf_counter()
+            batch.resample_bulk_device(args.chunk, ctx.stream)
+            ctx.torch.cuda.synchronize()
+            again.append((time.perf_counter() - t2) * 1e3)
+        k_again, _ = handles[0].mean_kernel_ms()
+        handles[0].set_profiling(False)
+        # ... and the same batch through the DEVICE planner (rsmp_fir_lockstep_run_bulk: the calls' structure, the f64 chain and
+        # the wrapped outputs planned by three small kernels, nothing replayed on the host, no host threads): the first
+        # launch, then launches that continue the streams (each planned anew, the next one planned ahead beside this one's
+        # bulk kernel).  A stream is 4096 calls here and the chain is serial per stream: the planner, not the kernel, is the
+        # launch's length.
+        dp = {}
+        try:
+            frames_call = args.chunk // CHANNELS
+            ls = ra.FirLockstep(handles, frames_call)
+            caps = [h.buffer_size_output() for h in handles]
+            ls.bind_caps(batch._keep[0], batch._keep[1], caps)
+            ctx.torch.cuda.synchronize()
+            t3 = time.perf_counter()
             ls.run_bulk(args.frames, frames_call, 0, append=False, stream=ctx.stream)
             ctx.torch.cuda.synchronize()
-            dp_again.append((time.perf_counter() - t4) * 1e3)
-        t5 = time.perf_counter()
-        for _ in range(8):   # ... and without a wait in between: the planner of launch r + 1 beside the kernel of launch r
-            ls.run_bulk(args.frames, frames_call, 0, append=False, stream=ctx.stream)
-        ctx.torch.cuda.synchronize()
-        dp = {"step_ms_cold": round(dp_cold, 2), "step_ms_replanned_median": round(sorted(dp_again)[len(dp_again) // 2], 2),
-              "step_ms_back_to_back": round((time.perf_counter() - t5) * 1e3 / 8, 2), "calls_per_stream": args.frames // frames_call,
-              "what": "rsmp_fir_lockstep_run_bulk on the same 64 streams: planned on the device (no host planning, no host threads)"}
-        ls.sync()
-        ls.close()
-    except Exception as e:
-        dp = {"error": repr(e)[:200]}
-    sec["fir_distinct_states"] = {
-        "device_planned": dp,
-        "what": f"{args.streams} streams in {args.streams} different states: the first launch (every stream replays its own "
-                f"control flow on the host's planning workers, then one launch), then launches that continue the streams "
-                f"(planned anew every time), wall clock of a launch incl. synchronisation",
-        "step_ms_cold": round(cold, 2), "step_ms_replanned_median": round(sorted(again)[len(again) // 2], 2),
-        "kernel_ms_replanned": round(k_again, 3), "setup_s": round(t1 - t0, 2)}
-    del batch, handles
-    c4 = bench_c4(ctx, args, steps=256 * 64, warmup=256 * 2)   # (64 launches of the configuration's 256 steps: ~60 ms)
-    sec["config4"] = {k: c4[k] for k in ("metric", "value", "unit", "ms_per_step", "scaling", "dtype", "config", "roofline")}
-    c5 = bench_c5(ctx, args, steps=72, warmup=2)   # (72 launches: ~53 ms)
-    sec["config5"] = {k: c5[k] for k in ("metric", "value", "unit", "ms_per_step", "scaling", "dtype", "config", "roofline")}
+            dp_cold = (time.perf_counter() - t3) * 1e3
+            dp_again = []
+            for _ in range(8):
+                t4 = time.perf_counter()
+                ls.run_bulk(args.frames, frames_call, 0, append=False, stream=ctx.stream)
+                ctx.torch.cuda.synchronize()
+                dp_again.append((time.perf_counter() - t4) * 1e3)
+            t5 = time.perf_counter()
+            for _ in range(8):   # ... and without a wait in between: the planner of launch r + 1 beside the kernel of launch r
+                ls.run_bulk(args.frames, frames_call, 0, append=False, stream=ctx.stream)
+            ctx.torch.cuda.synchronize()
+            dp = {"step_ms_cold": round(dp_cold, 2), "step_ms_replanned_median": round(sorted(dp_again)[len(dp_again) // 2], 2),
+                  "step_ms_back_to_back": round((time.perf_counter() - t5) * 1e3 / 8, 2), "calls_per_stream": args.frames // frames_call,
+                  "what": "rsmp_fir_lockstep_run_bulk on the same 64 streams: planned on the device (no host planning, no host threads)"}
+            ls.sync()
+            ls.close()
+        except Exception as e:
+            dp = {"error": repr(e)[:200]}
+        return {
+            "device_planned": dp,
+            "what": f"{args.streams} streams in {args.streams} different states: the first launch (every stream replays its own "
+                    f"control flow on the host's planning workers, then one launch), then launches that continue the streams "
+                    f"(planned anew every time), wall clock of a launch incl. synchronisation",
+            "step_ms_cold": round(cold, 2), "step_ms_replanned_median": round(sorted(again)[len(again) // 2], 2),
+            "kernel_ms_replanned": round(k_again, 3), "setup_s": round(t1 - t0, 2)}
+    guard("fir_distinct_states", distinct_point)
+    keys = ("metric", "value", "unit", "ms_per_step", "scaling", "dtype", "config", "roofline")
+    # (64 launches of the configuration's 256 steps: ~60 ms; 72 launches of config 5: ~53 ms)
+    guard("config4", lambda: {k: v for k, v in bench_c4(ctx, args, steps=256 * 64, warmup=256 * 2).items() if k in keys})
+    guard("config5", lambda: {k: v for k, v in bench_c5(ctx, args, steps=72, warmup=2).items() if k in keys})
     return sec
 
 
@@ -1018,8 +1027,8 @@ def main() -> int:
                 # operands cut into two fp16 planes, f32 accumulation on the matrix cores); the reference's arithmetic
                 # class -- every product an f32 FMA -- reaches frac_exact_f32 (matrix cores) / frac_vector_no_mfma
                 # (north_star's "no MFMA" form) on the same workload in the same run
-                line["roofline"]["frac_exact_f32"] = line["secondary"]["fir_exact_f32"]["frac"]
-                line["roofline"]["frac_vector_no_mfma"] = line["secondary"]["fir_vector_no_mfma"]["frac"]
+                line["roofline"]["frac_exact_f32"] = line["secondary"]["fir_exact_f32"].get("frac")
+                line["roofline"]["frac_vector_no_mfma"] = line["secondary"]["fir_vector_no_mfma"].get("frac")
     if ctx.rank == 0:
         os.write(real_stdout, (json.dumps(line) + "\n").encode())
     ctx.close()
