@@ -46,13 +46,18 @@ struct CallRec {             // what the chain leaves per call for the replay of
 };
 static_assert(sizeof(CallRec) == 24, "CallRec layout");
 
-// K1 -- the structure of every call of the run, in exact integer arithmetic: one thread per (stream, call).
-__global__ __launch_bounds__(256) void fir_lockstep_predict_kernel(LsRunArgs a) {
-    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
-    if (t >= a.n_streams * a.k) return;
-    const uint32_t gs = t / a.k, c = t - gs * a.k;
+// K1 -- the structure of every call of the run, in exact integer arithmetic: one thread per (stream, call), a workgroup
+// per stream and 256 calls; its first threads make the stream's binade-edge constants (MirrorEdges: thirteen divisions,
+// once per workgroup instead of once per call).
+__global__ __launch_bounds__(256) void fir_lockstep_predict_kernel(LsRunArgs a, uint32_t blocks_per_stream) {
+    __shared__ MirrorEdges edges;
+    const uint32_t gs = blockIdx.x / blocks_per_stream;
+    const uint32_t c = (blockIdx.x - gs * blocks_per_stream) * 256u + threadIdx.x;
     const MirrorRunBase base = mirror_run_base(a.states_in[gs], a.in_frames, a.k);
-    if (base.usable) a.preds[t] = mirror_predict(base, c);
+    if (base.usable && threadIdx.x <= kPredBinades) mirror_edge(base, threadIdx.x, edges.q[threadIdx.x], edges.r[threadIdx.x]);
+    __syncthreads();
+    if (c >= a.k) return;
+    if (base.usable) a.preds[static_cast<size_t>(gs) * a.k + c] = mirror_predict_edges(base, edges, c);
     if (c == 0) {
         a.states_before[gs] = a.states_in[gs];   // (the chain overwrites the states; the replay starts from these)
         if (a.zero_status) a.zero_status[gs] = 0;
@@ -474,8 +479,8 @@ hipError_t launch_fir_lockstep_gather_counts(const uint64_t* last_counts, const 
 
 hipError_t launch_fir_lockstep_plan(const LsRunArgs& args, hipStream_t stream, int parts) {
     if (args.n_streams == 0 || args.k == 0) return hipSuccess;
-    const uint32_t threads = args.n_streams * args.k;
-    if (parts & 1) hipLaunchKernelGGL(fir_lockstep_predict_kernel, dim3((threads + 255) / 256), dim3(256), 0, stream, args);
+    const uint32_t blocks_per_stream = (args.k + 255) / 256;
+    if (parts & 1) hipLaunchKernelGGL(fir_lockstep_predict_kernel, dim3(blocks_per_stream * args.n_streams), dim3(256), 0, stream, args, blocks_per_stream);
     if (parts & 2) {
         hipLaunchKernelGGL(fir_lockstep_chain_kernel, dim3(args.n_streams), dim3(64), 0, stream, args);
         hipLaunchKernelGGL(fir_lockstep_wraps_kernel, dim3(args.n_streams), dim3(64), 0, stream, args);

@@ -157,6 +157,83 @@ __host__ __device__ inline MirrorPred mirror_predict(const MirrorRunBase& b, uin
     return pr;
 }
 
+// The same prediction with the thirteen binade-edge divisions shared by all calls of a stream's run: (c0 + 2^e) den / num
+// = c0 den / num + 2^e den / num, whose second term is a constant of the stream and the run (MirrorEdges: floor and
+// remainder per edge) -- one division of c0 den per call, an add with carry per edge.  Six 64-bit divisions a call instead
+// of eighteen: K1 is a kernel of CODE (a 64-bit division is ~70 instructions), which is what it loses beside the split
+// kernel of the run before (72 us for a 128-stream shard against 10 alone).  Bit for bit mirror_predict
+// (rsmp_fir_plan_selftest_fast compares the two for every call).
+struct MirrorEdges {
+    uint64_t q[kPredBinades + 1];   // floor(2^(e0+i) den / num)
+    uint32_t r[kPredBinades + 1];   // ... and the remainder (< num < 2^21)
+};
+__host__ __device__ inline void mirror_edge(const MirrorRunBase& b, uint32_t i, uint64_t& q, uint32_t& r) {
+    const uint64_t t = (1ull << (b.e0 + i)) * b.den;   // < 2^40 * 2^21
+    q = t / b.num;
+    r = static_cast<uint32_t>(t - q * b.num);
+}
+__host__ __device__ inline MirrorPred mirror_predict_edges(const MirrorRunBase& b, const MirrorEdges& ed, uint32_t c) {
+    MirrorPred pr;
+    const uint64_t a_prev = b.abs_consumed0 + b.avail0 + static_cast<uint64_t>(c) * b.in_frames;
+    const uint64_t a_now = a_prev + b.in_frames;
+    uint64_t m0 = b.abs_out0, c0 = b.abs_consumed0;
+    if (c != 0) {
+        if (a_prev + 1 > b.taps) {
+            const uint64_t m = mirror_outputs_below(a_prev + 1 - b.taps, b.num, b.den);
+            if (m > m0) m0 = m;
+        }
+        c0 = m0 * b.num / b.den;
+        if (c0 > a_prev) c0 = a_prev;
+        if (c0 < b.abs_consumed0) c0 = b.abs_consumed0;
+    }
+    uint64_t m1 = m0;
+    uint16_t ties = 0;
+    if (a_now + 1 > b.taps && a_now - c0 >= b.taps) {
+        const uint64_t t = (a_now + 1 - b.taps) * b.den;
+        const uint64_t qf = t / b.num;
+        const bool exact = t == qf * b.num;
+        const uint64_t m = qf + (exact ? 0u : 1u);
+        if (m > m1) m1 = m;
+        if (exact && m >= m0) ties |= kPredLimitTie;
+    }
+    pr.m0 = m0;
+    pr.c0 = c0;
+    pr.n_total = static_cast<uint32_t>(m1 - m0);
+    const uint64_t r0 = m0 % b.den, r1 = m1 % b.den;
+    pr.ni_before = static_cast<uint32_t>(r0 ? b.den - r0 : 0);
+    pr.ni_after = static_cast<uint32_t>(r1 ? b.den - r1 : 0);
+    // c0 den = qA num + rA, once; edge i: (qA + q_i) num + (rA + r_i)
+    const uint64_t A = c0 * b.den;
+    const uint64_t qA = A / b.num;
+    const uint32_t rA = static_cast<uint32_t>(A - qA * b.num), num32 = static_cast<uint32_t>(b.num);
+    auto below = [&](uint32_t i, bool& tie) -> uint32_t {   // outputs of the call with position < 2^(e0+i)
+        uint32_t rem = rA + ed.r[i];
+        const bool carry = rem >= num32;
+        rem -= carry ? num32 : 0u;
+        uint64_t m = qA + ed.q[i] + (carry ? 1u : 0u) + (rem != 0 ? 1u : 0u);
+        tie = rem == 0 && m >= m0 && m < m1;
+        if (m < m0) m = m0;
+        if (m > m1) m = m1;
+        return static_cast<uint32_t>(m - m0);
+    };
+    bool tie = false;
+    uint32_t prev = below(0, tie);
+    if (tie) ties |= 1u;
+    if (prev > 0xFFFFu) { prev = 0xFFFFu; ties |= kPredIrregular; }
+    pr.n_low = static_cast<uint16_t>(prev);
+    for (uint32_t i = 0; i < kPredBinades; ++i) {
+        const uint32_t v = below(i + 1, tie);
+        if (tie && i + 1 < kPredBinades) ties |= static_cast<uint16_t>(1u << (i + 1));
+        if (v - prev > 0xFFFFu) ties |= kPredIrregular;
+        pr.n[i] = static_cast<uint16_t>(v - prev > 0xFFFFu ? 0xFFFFu : v - prev);
+        prev = v;
+    }
+    if ((b.den & (b.den - 1)) == 0) ties = 0;
+    if (prev != pr.n_total) ties |= kPredIrregular;
+    pr.ties = ties;
+    return pr;
+}
+
 // One call, given its predicted structure.  Returns false -- `st` untouched -- when a check fails; otherwise the call is
 // done exactly as mirror_call does it (same counts, same state bits).  on_run(first, count, p0, inc) receives the
 // position runs (inc == 0: a single output), as Sink::run of mirror_call.

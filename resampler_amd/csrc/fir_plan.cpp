@@ -163,6 +163,8 @@ extern "C" int rsmp_fir_plan_selftest_fast(rsmp_fir_plan* p, size_t in_frames, s
         const rsmp::MirrorRunBase base = rsmp::mirror_run_base(fast, static_cast<uint32_t>(in_frames), len);
         const rsmp::MirrorBinades bn = rsmp::mirror_binades(fast.ratio, base.e0);
         const bool chain_ready = rsmp::mirror_chain_ready(bn);
+        rsmp::MirrorEdges edges;
+        for (uint32_t i = 0; i <= rsmp::kPredBinades; ++i) rsmp::mirror_edge(base, i, edges.q[i], edges.r[i]);
         for (uint32_t c = 0; c < len; ++c) {
             w_ref.clear();
             w_fast.clear();
@@ -173,6 +175,10 @@ extern "C" int rsmp_fir_plan_selftest_fast(rsmp_fir_plan* p, size_t in_frames, s
             bool took_fast = false;
             if (base.usable) {
                 const rsmp::MirrorPred pr = rsmp::mirror_predict(base, c);
+                {   // K1's form of it (the edge divisions shared): the same prediction, field for field
+                    const rsmp::MirrorPred pe = rsmp::mirror_predict_edges(base, edges, c);
+                    if (std::memcmp(&pe, &pr, sizeof pr) != 0) ++bad;
+                }
                 took_fast = rsmp::mirror_call_fast(fast, static_cast<uint32_t>(in_frames), cap, pr, bn, c_fast,
                                                    [](uint32_t, uint32_t, double, double) {});
                 // the unchecked chain, where the device planner takes it: must land on the same state
