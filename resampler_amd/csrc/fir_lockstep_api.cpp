@@ -1236,7 +1236,18 @@ extern "C" int rsmp_fir_lockstep_run(rsmp_fir_lockstep* ls, size_t k_steps, size
         const rsmp_fir* r0 = ls->rs[ls->order[g.first]];
         max_tail_values = std::max<uint32_t>(max_tail_values, static_cast<uint32_t>((r0->taps + 8) * r0->channels));
     }
-    if (!split_jobs.empty()) RSMP_HIP_CHECK(rsmp::launch_fir_split_multi(split_jobs.data(), split_jobs.size(), s));
+    // A workgroup of the split kernel fills its CU (512 vector registers per SIMD lane, 136 KB of LDS): the planner of the
+    // NEXT run, on the plan stream, does not run beside it but behind it, CU by CU as the launch drains -- for a small
+    // batch, whose period is the planner's, that was the bulk launch's length added to every run (K1 "72 us beside the
+    // split kernel, 10 alone").  A batch of fewer than 256 streams planned ahead leaves the planner a wave's worth of CUs
+    // per stream (one chain wave per stream, four SIMDs per CU); its bulk kernels lose an eighth of the chip they do not
+    // need.  RSMP_LS_RESERVE (debug): the number of CUs, 0 = none.
+    uint32_t reserve = 0;
+    if (repeat && n < 256) {
+        static const int knob = [] { const char* e = rsmp::knob("RSMP_LS_RESERVE"); return e ? atoi(e) : -1; }();
+        reserve = knob >= 0 ? static_cast<uint32_t>(knob) : static_cast<uint32_t>(std::min<size_t>(64, (n + 3) / 4 + 8));
+    }
+    if (!split_jobs.empty()) RSMP_HIP_CHECK(rsmp::launch_fir_split_multi(split_jobs.data(), split_jobs.size(), s, reserve));
     RSMP_HIP_CHECK(rsmp::launch_fir_repair_multi(repair_jobs.data(), repair_jobs.size(), s));
     RSMP_HIP_CHECK(rsmp::launch_fir_tail_copy(d_descs, static_cast<uint32_t>(n), max_tail_values, s));
     RSMP_HIP_CHECK(hipEventRecord(ls->slot[sl].compute_done, s));

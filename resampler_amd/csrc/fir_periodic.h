@@ -168,7 +168,7 @@ struct SplitJob {
     uint32_t max_blocks;
     NfArgs nf;
 };
-hipError_t launch_fir_split_multi(const SplitJob* jobs, size_t n_jobs, hipStream_t stream);
+hipError_t launch_fir_split_multi(const SplitJob* jobs, size_t n_jobs, hipStream_t stream, uint32_t reserve_cus = 0);
 
 // Gives back the split kernel's item-table workspace of a stream that is about to be destroyed.
 void split_release_stream(int device, hipStream_t stream);

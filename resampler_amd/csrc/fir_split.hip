@@ -1942,11 +1942,14 @@ hipError_t launch_fir_split(const FirStreamDesc* d_descs, uint32_t n_streams, co
     return hipGetLastError();
 }
 
-hipError_t launch_fir_split_multi(const SplitJob* jobs, size_t n_jobs, hipStream_t stream) {
+hipError_t launch_fir_split_multi(const SplitJob* jobs, size_t n_jobs, hipStream_t stream, uint32_t reserve_cus) {
     int device = 0;
     hipError_t e = hipGetDevice(&device);
     if (e != hipSuccess) return e;
-    const uint32_t cus = device_cus(device);
+    // (reserve_cus: compute units the launches leave to somebody else -- a workgroup of this kernel fills a CU's registers
+    // and LDS, nothing runs BESIDE it on that CU: the run planner of a small lock-step batch, fir_lockstep_api.cpp)
+    const uint32_t cus_all = device_cus(device);
+    const uint32_t cus = reserve_cus < cus_all / 2 ? cus_all - reserve_cus : cus_all;
     static const bool diag = split_debug_knob() != 0 || rsmp::knob("RSMP_FIR_WTRACE") != nullptr;
     static const bool multi_on = [] { const char* v = rsmp::knob("RSMP_FIR_SPLIT_MULTI"); return !v || atoi(v) != 0; }();
     // the multi-job builds: two channels, two fp16 planes; windows of 1 .. 5 steps in one round, 5 or 6 in two
