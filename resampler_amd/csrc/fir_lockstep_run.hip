@@ -114,6 +114,42 @@ __device__ inline uint32_t chain_step_of_shape(uint32_t shape, uint32_t s, const
     }
 }
 
+// A RUN of calls of one shape without ties, all on the prediction's track: the loop the chain spends its time in, with
+// the shape a template parameter of the loop instead of a compare chain per call.  Calls s, s + 1, ... while the masks say
+// so; returns the first call it did not take.  (The counters are in `sc`, the position in `pos`.)
+template <uint32_t L>
+__device__ __forceinline__ uint32_t chain_fast_run(uint32_t s, uint32_t nc, uint64_t fast_mask, uint64_t succ_mask, uint32_t lane, uint32_t my_n_total,
+                                                   const ChainPlan& my_cp, uint32_t my_cpred, double& pos, ChainScalars& sc, bool& on_track, double& my_pos,
+                                                   uint32_t& lean_last_n, uint32_t in_frames, double ratio, const MirrorBinades& bn) {
+#pragma unroll 1
+    do {
+        my_pos = lane == s ? pos : my_pos;   // lane s keeps call s's start position
+        const uint32_t n_total = rl(my_n_total, s), ctl = rl(my_cp.ctl, s), n_last = rl(my_cp.n_last, s), cpred = rl(my_cpred, s);
+        double m[kPredBinades];
+#pragma unroll
+        for (uint32_t i = 0; i < kPredBinades; ++i) m[i] = i <= L ? rl_f64(my_cp.m[i], s) : 0.0;
+        const uint32_t cons = mirror_chain_step<L, false>(pos, sc, in_frames, ratio, bn, n_total, ctl, n_last, m);
+        on_track = cons == cpred && ((succ_mask >> s) & 1ull);
+        lean_last_n = n_total;
+        ++s;
+    } while (s < nc && on_track && ((fast_mask >> s) & 1ull));
+    return s;
+}
+template <uint32_t L = 0>
+__device__ __forceinline__ uint32_t chain_fast_run_of(uint32_t shape, uint32_t s, uint32_t nc, uint64_t fast_mask, uint64_t succ_mask, uint32_t lane,
+                                                      uint32_t my_n_total, const ChainPlan& my_cp, uint32_t my_cpred, double& pos, ChainScalars& sc,
+                                                      bool& on_track, double& my_pos, uint32_t& lean_last_n, uint32_t in_frames, double ratio,
+                                                      const MirrorBinades& bn) {
+    if constexpr (L < kPredBinades) {
+        if (shape == L)
+            return chain_fast_run<L>(s, nc, fast_mask, succ_mask, lane, my_n_total, my_cp, my_cpred, pos, sc, on_track, my_pos, lean_last_n, in_frames, ratio, bn);
+        return chain_fast_run_of<L + 1>(shape, s, nc, fast_mask, succ_mask, lane, my_n_total, my_cp, my_cpred, pos, sc, on_track, my_pos, lean_last_n, in_frames,
+                                        ratio, bn);
+    } else {
+        return s;
+    }
+}
+
 __global__ __launch_bounds__(64) void fir_lockstep_chain_kernel(LsRunArgs a) {
     const uint32_t gs = blockIdx.x, lane = threadIdx.x;
     const LockstepStream ls = a.streams[gs];
@@ -176,11 +212,28 @@ __global__ __launch_bounds__(64) void fir_lockstep_chain_kernel(LsRunArgs a) {
         const uint32_t my_cpred = static_cast<uint32_t>(succ[1] - mine[1]);   // frames the prediction has the call retire
         const uint64_t lean_mask = __ballot(my_struct_ok && chain_ready);
         const uint64_t succ_mask = __ballot(my_succ_ok);
+        // the chunk's common shape (its first such call's): runs of calls of that shape without ties take chain_fast_run
+        const bool my_fast = my_struct_ok && chain_ready && (my_cp.ctl & 0xFFF000u) == 0;
+        const uint64_t any_fast = __ballot(my_fast);
+        const uint32_t shape_d = any_fast ? rl((my_cp.ctl >> 8) & 0xFu, static_cast<uint32_t>(__builtin_ctzll(any_fast))) : 0xFFu;
+        const uint64_t fast_mask = __ballot(my_fast && ((my_cp.ctl >> 8) & 0xFu) == shape_d);
         uint64_t nonlean_mask = 0;
         double my_pos = 0.0, my_drift = 0.0;
         uint32_t my_flags = 0, my_c0 = 0, my_c1 = 0;
 #pragma unroll 1
         for (uint32_t s = 0; s < nc; ++s) {
+            if (on_track && ((fast_mask >> s) & 1ull)) {
+                if (st_valid) {   // (the counters leave `st`)
+                    pos = st.position;
+                    sc = ChainScalars{rfl64(st.abs_out), rfl64(st.abs_consumed), rfl(static_cast<uint32_t>(st.read_position)),
+                                      rfl(static_cast<uint32_t>(st.available))};
+                    st_valid = false;
+                }
+                s = chain_fast_run_of(shape_d, s, nc, fast_mask, succ_mask, lane, my_n_total, my_cp, my_cpred, pos, sc, on_track, my_pos, lean_last_n,
+                                      a.in_frames, ratio, bn);
+                last_lean = true;
+                if (s >= nc) break;
+            }
             const double pos0 = st_valid ? st.position : pos;
             my_pos = lane == s ? pos0 : my_pos;   // lane s keeps call s's start position
             if (!on_track) {   // (behind a call off the track: is the state where this call's prediction starts?)
