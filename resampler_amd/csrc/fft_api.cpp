@@ -6,6 +6,7 @@
 // per instance (scratch pads, spectra) lives in LDS for the duration of a block.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -63,7 +64,8 @@ int get_plan(int device, uint32_t in_hz, uint32_t out_hz, std::shared_ptr<Device
         const FftPlanDev& dv = dp->dev;
         for (const void* q : {static_cast<const void*>(dv.tw_f), static_cast<const void*>(dv.tw_i),
                               static_cast<const void*>(dv.rc_f), static_cast<const void*>(dv.rc_i),
-                              static_cast<const void*>(dv.filter)})
+                              static_cast<const void*>(dv.filter), static_cast<const void*>(dv.chirp_f),
+                              static_cast<const void*>(dv.chirp_i)})
             if (q) (void)hipFree(const_cast<void*>(q));
         delete dp;
     };
@@ -102,6 +104,21 @@ int get_plan(int device, uint32_t in_hz, uint32_t out_hz, std::shared_ptr<Device
     d.n_rc_f = static_cast<uint32_t>(h.forward.rc_twiddles.size());
     d.n_rc_i = static_cast<uint32_t>(h.inverse.rc_twiddles.size());
     d.new_length = static_cast<uint32_t>(h.new_length);
+    // exp(-2 pi i n / 2N) for the two block lengths (f64 -> f32 like every twiddle, radix_fft.rs:251-258): the odd-bin
+    // chain of the two-channel kernel (fft_pair.hip)
+    auto chirp = [](size_t n2) {
+        std::vector<rsmp::Complex32> v(n2);
+        for (size_t n = 0; n < n2; ++n) {
+            const double a = -3.14159265358979323846264338327950288 * static_cast<double>(n) / static_cast<double>(n2);
+            v[n].re = static_cast<float>(std::cos(a));
+            v[n].im = static_cast<float>(std::sin(a));
+        }
+        return v;
+    };
+    if ((rc = upload(chirp(h.fft_in), &ptr)) != RSMP_OK) return rc;
+    d.chirp_f = reinterpret_cast<const float2*>(ptr);
+    if ((rc = upload(chirp(h.fft_out), &ptr)) != RSMP_OK) return rc;
+    d.chirp_i = reinterpret_cast<const float2*>(ptr);
     d.lds_complex = static_cast<uint32_t>((h.fft_in > h.fft_out ? h.fft_in : h.fft_out) + 1);
     if (rsmp::fft_ola_lds_bytes(d, 1) > 160 * 1024 && (rsmp::fft_big_lds_bytes(d) > 160 * 1024 || d.lds_complex > 12288 + 1))
         return rsmp::fail(RSMP_ERR_INVALID_ARGUMENT,

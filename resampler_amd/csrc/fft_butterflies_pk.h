@@ -64,6 +64,9 @@ __device__ __forceinline__ cf cf_mul(cf a, cf b) {
     // one statement: before an asm statement that reads a register the previous instruction wrote, the
     // compiler (which cannot see what kind of instruction it is) spends an s_nop
     cf d;
+#if defined(RSMP_EXP) && (RSMP_EXP & 32)   // (slope experiment: two more packed instructions per complex multiply)
+    { cf e; asm volatile("v_pk_mul_f32 %0, %1, %2\n\tv_pk_mul_f32 %0, %1, %2 op_sel:[1,0]" : "=&v"(e) : "v"(a), "v"(b)); }
+#endif
     asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]\n\t"
         "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
         : "=&v"(d) : "v"(a), "v"(b));

@@ -23,6 +23,8 @@ struct FftPlanDev {
     const float2* filter;                // fft_in + 1 bins
     uint32_t new_length;                 // bins multiplied by the filter, the rest are zero
     uint32_t lds_complex;                // max(fft_in, fft_out) + 1
+    const float2* chirp_f;               // exp(-2 pi i n / (2 fft_in)), n < fft_in   (fft_pair.hip: two channels as one complex signal)
+    const float2* chirp_i;               // exp(-2 pi i n / (2 fft_out)), n < fft_out
 };
 
 // One stream's share of a launch: n_blocks consecutive blocks of all its channels.
@@ -52,6 +54,12 @@ hipError_t launch_fft_ola(const FftPlanDev& plan, const FftStreamDesc* d_descs, 
 hipError_t launch_fft_ola_wave(const FftPlanDev& plan, const FftStreamDesc* d_descs, uint32_t n_streams,
                                uint32_t max_blocks, uint32_t max_channels, uint32_t min_channels,
                                hipStream_t stream);
+// One wave per two-channel stream, the frame (L, R) as the complex sample L + i R (fft_pair.hip); hipErrorNotSupported for
+// the plans it is not instantiated for.
+hipError_t launch_fft_ola_pair(const FftPlanDev& plan, const FftStreamDesc* d_descs, uint32_t n_streams, uint32_t max_blocks,
+                               hipStream_t stream);
+// Whether this library's wave kernels are the operation-for-operation build (libresampler_amd_fftexact.so).
+bool fft_wave_is_exact();
 // filter_spectrum[0 .. fft_in] = forward real FFT of d_filter_time[0 .. 2*fft_in)
 // (resampler_fft.rs:375-376); plan.filter is ignored.
 hipError_t launch_fft_filter_spectrum(const FftPlanDev& plan, const float* d_filter_time,

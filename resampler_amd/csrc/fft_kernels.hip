@@ -745,6 +745,12 @@ hipError_t launch_fft_ola(const FftPlanDev& plan, const FftStreamDesc* d_descs, 
     static const bool no_wave = rsmp::knob("RSMP_FFT_WAVE") != nullptr && atoi(rsmp::knob("RSMP_FFT_WAVE")) == 0;   // A/B
     // (PCM input is read by the two-channel wave kernel only: FftStreamDesc::in_bits)
     if (pcm_bits != 0 && (no_wave || max_channels != 2 || min_channels != 2)) return hipErrorNotSupported;
+    // two-channel f32 streams: a wave per stream, the frame as one complex sample (not in the exact build)
+    static const bool no_pair = rsmp::knob("RSMP_FFT_PAIR") != nullptr && atoi(rsmp::knob("RSMP_FFT_PAIR")) == 0;   // A/B
+    if (!no_wave && !no_pair && pcm_bits == 0 && max_channels == 2 && min_channels == 2 && !fft_wave_is_exact()) {
+        const hipError_t e = launch_fft_ola_pair(plan, d_descs, n_streams, max_blocks, stream);
+        if (e != hipErrorNotSupported) return e;
+    }
     if (!no_wave) {
         const hipError_t e = launch_fft_ola_wave(plan, d_descs, n_streams, max_blocks, max_channels, min_channels, stream);
         if (e != hipErrorNotSupported || pcm_bits != 0) return e;

@@ -1,0 +1,450 @@
+// fft_pair.hip -- ResamplerFft block pipeline for TWO-CHANNEL streams: ONE WAVE per stream, the two channels of a frame
+// taken as ONE complex sample (gfx950).
+//
+// Replaces the same reference code as fft_wave.hip (FftResampler::resample, src/resampler_fft.rs:385-424; RadixFFT
+// forward / inverse, src/fft/radix_fft.rs:476-670; the Stockham stages and butterflies) -- and with it the two
+// real <-> complex passes (radix_fft.rs:500-537, :592-624; real_complex/mod.rs:37-114), which here do not exist.
+//
+// Why: the wave-per-channel kernel's time is the SUM of its vector instructions, its LDS reads and its LDS stores
+// (profiles/r05/fft_slopes.txt: 0.175 / 0.67 / 0.93 us of launch per instruction and block-channel; nothing hides behind
+// anything), and a third of its LDS traffic is not transform at all: the real-FFT post-process, the filter + inverse
+// pre-process pass, the exchange that makes 16-byte stores out of two channels' values.  The resampler is linear with a
+// REAL impulse response (resampler_fft.rs:361-376: the filter's spectrum H is the transform of real taps), so
+//     resample(L + i R) = resample(L) + i resample(R):
+// the interleaved stereo frame (L, R) IS the complex sample z = L + i R.  Per block of FI frames:
+//   Z = DFT_2FI(z, zero padded)          -- as two FI-point transforms, decimation in frequency:
+//       Z[2k'] = DFT_FI(z)[k'],  Z[2k' + 1] = DFT_FI(z w)[k'],  w[n] = exp(-2 pi i n / 2FI)   (the padding makes the
+//       first radix-2 step trivial)
+//   V[k] = H[k] Z[k] (k < NL),  V[2FO - k] = conj(H[k]) Z[2FI - k] (0 < k < NL),  0 elsewhere
+//       (L's and R's spectra are Hermitian, their sum Z is not: both halves are carried; the truncation / zero extension of
+//       resampler_fft.rs:396-408 keeps the parity of a bin, so even bins feed even bins)
+//   v = IDFT_2FO(V)                      -- as two FO-point transforms, decimation in time:
+//       F[n] = A[n] + u[n] B[n],  F[n + FO] = A[n] - u[n] B[n],  A = DFT_FO(conj V even), B = DFT_FO(conj V odd),
+//       u[n] = exp(-2 pi i n / 2FO),  v = conj(F)
+//   frame n of the output = v[n] + overlap[n]; v[FO + n] is the next overlap (resampler_fft.rs:416-423).
+// So a wave runs the EVEN-bin chain start to finish (forward transform, filter, inverse transform: A in registers), then
+// the ODD-bin chain, and the last inverse stage of the second chain combines, overlap-adds and stores whole frames.
+// Per stream and block: 220 LDS stores instead of 322, ~430 reads instead of 514, no exchange between waves, every input
+// frame one 8-byte complex load, every output frame one 8-byte store.  The transforms are the FI / FO-point plans of the
+// wave-per-channel kernel (same stages, same padded layouts: fft_wave_core.h).
+// Arithmetic: the reference's butterflies on other operands -- equal to the CPU path within rounding (tests/test_fft_gpu.py
+// holds it to the gate of 1e-6 RMS; measured ~1.5e-7 like the wave-per-channel kernel), not bit for bit; the exact build
+// (libresampler_amd_fftexact.so) never takes this kernel.
+#include <cmath>
+#include <cstdlib>
+#include <type_traits>
+
+#pragma clang fp contract(fast)
+
+#include "fft_butterflies_pk.h"
+#include "fft_kernels.h"
+#include "common.h"
+
+#ifndef RSMP_EXP
+#define RSMP_EXP 0
+#endif
+#define RSMP_FEAT (RSMP_EXP & 63)   // A/B builds (make exp EXPFILE=fft_pair.hip)
+
+// Diagnostic builds (tools/fft_trace.py, RSMP_EXP >> 6): 1 = every wave's start / end on the constant 100 MHz clock and where it
+// ran; 2 = also the shader-clock cycles a wave spends in each phase of its blocks.
+#if (RSMP_EXP >> 6) != 0
+#define RSMP_FFT_TRACE 1
+__device__ unsigned long long rsmp_fft_trace_buf[4096 * 16];
+extern "C" int rsmp_debug_fft_trace(unsigned long long* out, size_t words) {
+    return static_cast<int>(hipMemcpyFromSymbol(out, HIP_SYMBOL(rsmp_fft_trace_buf), words * 8));
+}
+#endif
+#if (RSMP_EXP >> 6) == 2
+#define RSMP_TR(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); tr_ph[i] += t_ - tr_last; tr_last = t_; } while (0)
+#else
+#define RSMP_TR(i) do { } while (0)
+#endif
+
+namespace rsmp {
+
+namespace {
+
+#include "fft_wave_core.h"
+
+// conj(a) * b = (a.x b.x + a.y b.y, a.x b.y - a.y b.x)
+__device__ __forceinline__ cf cf_mul_cn(cf a, cf b) {
+    cf d;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1]\n\t"
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_hi:[0,1,0]"
+        : "=&v"(d) : "v"(a), "v"(b));
+    return d;
+}
+// conj(a) * conj(b) = conj(a b) = (a.x b.x - a.y b.y, -(a.x b.y + a.y b.x))
+__device__ __forceinline__ cf cf_mul_cc(cf a, cf b) {
+    cf d;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0] neg_hi:[0,1,0]"
+        : "=&v"(d) : "v"(a), "v"(b));
+    return d;
+}
+
+// The last stage of a plan (stride = M: a butterfly's points are its own) with its outputs left in registers: butterfly
+// i = lane + 64 it yields o[it][q] = X[i + q M].  Every read is issued before the first butterfly (what follows overwrites
+// the buffer).  QS / IPP: where the stage's inputs lie (wave_stage).
+template <int N, int R, int QS, int IPP>
+__device__ __forceinline__ void wave_last_regs(const cf* buf, const cf* __restrict__ tw, int lane, cf (&o)[(N / R + 63) / 64][R]) {
+    constexpr int M = N / R;
+    constexpr int ITER = (M + 63) / 64;
+    constexpr int ROW = fetch_count(R) | 1;
+    cf raw[ITER][kFetch<R>];
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+        const int i = lane + 64 * it;
+        if ((it + 1) * 64 <= M || i < M) {
+#pragma unroll
+            for (int q = 0; q < R; ++q) o[it][q] = lds_ld(buf + i + (IPP ? i / (IPP ? IPP : 1) : 0) + q * QS);
+            twiddle_fetch<R>(tw + i * ROW, raw[it]);
+        }
+    }
+    lds_order();
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+        const int i = lane + 64 * it;
+        if ((it + 1) * 64 <= M || i < M) {
+            cf twr[R], t[R];
+            twiddle_expand<R>(raw[it], twr);
+            t[0] = o[it][0];
+#pragma unroll
+            for (int q = 1; q < R; ++q) t[q] = cf_mul(twr[q], o[it][q]);
+            pdft<R>(t, o[it]);
+        }
+    }
+}
+
+// Where the bins of the forward transform go (header): bin k = 2 k' + par of Z is kept as a positive frequency for
+// k <= kPosMax and as a negative one for k >= kNegMin (up-sampling: every bin, and bin FI -- the input's Nyquist bin -- as
+// both; down-sampling: bins of NL - 1 and below either way, resampler_fft.rs:396-408); a kept bin lands at k' (positive) or
+// k' + FO - FI (negative) of the chain's FO-point inverse transform, what lies between reads as zero.
+template <int FI, int FO>
+struct PairBins {
+    static constexpr bool kUp = FI < FO;
+    static constexpr int kNL = kUp ? FI + 1 : FO;
+    static constexpr int kPosMax = kNL - 1;
+    static constexpr int kNegMin = 2 * FI - (kNL - 1);
+    static constexpr int kShift = FO - FI;
+    static constexpr int zero_lo(int par) { return (kPosMax - par) / 2 + 1; }                       // first index nobody writes
+    static constexpr int zero_hi(int par) {                                                           // last one
+        const int kp = (kNegMin - par + 1) / 2;                                                       // smallest k' with 2 k' + par >= kNegMin
+        const int lo_neg = kp + kShift;
+        const int nyq = (kUp && par == 0 && FI % 2 == 0) ? FI / 2 + kShift : lo_neg;                  // (bin FI as a negative frequency)
+        return (nyq < lo_neg ? nyq : lo_neg) - 1;
+    }
+};
+
+template <class FWD, class INV>
+__global__ __launch_bounds__(512, 1) void fft_ola_pair_kernel(FftPlanDev plan, const FftStreamDesc* __restrict__ descs,
+                                                              uint32_t run_long, uint32_t run_short, uint32_t pairs_per_stream,
+                                                              uint32_t total_waves) {
+    extern __shared__ __attribute__((aligned(16))) cf lds2[];
+    constexpr int kWaves = 8;
+    constexpr int FI = FWD::N, FO = INV::N;
+    typedef PairBins<FI, FO> Bins;
+    constexpr int NL = Bins::kNL;
+    constexpr int LDSC = FWD::kBuf > INV::kBuf ? FWD::kBuf : INV::kBuf;
+    constexpr int SF = FWD::kStages, SI = INV::kStages;
+    constexpr int RLF = FWD::kR[SF - 1], MF = FI / RLF, ITF = (MF + 63) / 64;   // last forward stage
+    constexpr int RLI = INV::kR[SI - 1], MI = FO / RLI, ITI = (MI + 63) / 64;   // last inverse stage
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t gw = blockIdx.x * kWaves + wave;
+    (void)gw;
+    // tables, once per workgroup: stage twiddles (rows re-spaced as the stages read them), the filter bins in use, and
+    // the two chirps w (FI values) and u (FO values)
+    constexpr int kTabF = 0, kTabI = kTabF + FWD::kTw, kTabFilter = kTabI + INV::kTw, kTabW = kTabFilter + NL,
+                  kTabU = kTabW + FI, kTabEnd = kTabU + FO;
+    cf* tab = lds2;
+    {
+        auto copy = [&](cf* dst, const cf* __restrict__ src, int n) {
+            for (int i = threadIdx.x; i < n; i += kWaves * 64) dst[i] = src[i];
+        };
+        auto rows = [&](cf* dst, const cf* __restrict__ src, int n_rows, int len, int keep, int pitch) {
+            for (int i = threadIdx.x; i < n_rows * keep; i += kWaves * 64) {
+                const int r = i / keep, j = i - r * keep;
+                dst[r * pitch + j] = src[r * len + (keep < len && j == 2 ? 3 : j)];
+            }
+        };
+        auto stage_tables = [&](cf* dst, const cf* __restrict__ src, auto P) {
+            typedef decltype(P) PL;
+            static_for<1, PL::kStages>([&](auto s_c) {
+                constexpr int s = decltype(s_c)::value;
+                constexpr int len = PL::kR[s] - 1;
+                rows(dst + PL::tab(s), src + PL::src(s), PL::stride(s), len, PL::kFused && s == 1 ? len : fetch_count(PL::kR[s]), PL::pitch(s));
+            });
+        };
+        stage_tables(tab + kTabF, reinterpret_cast<const cf*>(plan.tw_f), FWD{});
+        stage_tables(tab + kTabI, reinterpret_cast<const cf*>(plan.tw_i), INV{});
+        copy(tab + kTabFilter, reinterpret_cast<const cf*>(plan.filter), NL);
+        copy(tab + kTabW, reinterpret_cast<const cf*>(plan.chirp_f), FI);
+        copy(tab + kTabU, reinterpret_cast<const cf*>(plan.chirp_i), FO);
+    }
+    __syncthreads();
+    if ((blockIdx.x * 4u + (wave & 3u)) * 2u >= total_waves) return;   // (a pair beyond the launch's last)
+#ifdef RSMP_FFT_TRACE
+    const unsigned long long tr_t0 = wall_clock64();
+    unsigned long long tr_ph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tr_last = __builtin_readcyclecounter();
+    (void)tr_ph; (void)tr_last;
+#endif
+    cf* buf = lds2 + kTabEnd + wave * LDSC;
+    const cf* tw_f = tab + kTabF;
+    const cf* tw_i = tab + kTabI;
+    const cf* filter = tab + kTabFilter;
+    const cf* chirp_w = tab + kTabW;
+    const cf* chirp_u = tab + kTabU;
+
+    // A SIMD serves its two waves oldest first: the first four waves of a workgroup run nearly unimpeded, the last four in
+    // their gaps, and with equal runs the launch ended with one wave per SIMD for its last quarter (tools/fft_trace.py:
+    // ends at 323 / 429 us; evening the two out by priority gave nothing -- two equals get in each other's way).  So a
+    // stream is cut into PAIRS of runs, a long one for an old wave and a short one for a young wave.
+    const uint32_t kind = wave >> 2;                                  // 0: old wave, long run; 1: young wave, short run
+    const uint32_t pair_idx = blockIdx.x * 4u + (wave & 3u);
+    const uint32_t stream_idx = pair_idx / pairs_per_stream;
+    const uint32_t in_stream = pair_idx - stream_idx * pairs_per_stream;
+    const FftStreamDesc d = descs[stream_idx];
+    const uint32_t first = in_stream * (run_long + run_short) + (kind ? run_long : 0u);
+    const uint32_t run = kind ? run_short : run_long;
+    if (first >= d.n_blocks || run == 0) return;
+    const uint32_t last = first + run < d.n_blocks ? first + run : d.n_blocks;  // exclusive
+
+    // The overlap carried into the run: the stream state ([2][FO] reals, resampler_fft.rs:51), or the predecessor block
+    // recomputed (not emitted).  Held as F[FO + n] = conj(v[FO + n]), n = lane + 64 it + q MI.
+    cf carry[ITI][RLI];
+    {
+        // (every load issued before the first is waited for: a branch per value made them wait for each other, 2 x 24 HBM
+        // round trips in a row for the wave that starts a stream)
+        const GFloat* ov = as_global(d.overlap);
+        const bool have = first == 0;
+        float ca[ITI][RLI], cb[ITI][RLI];
+#pragma unroll
+        for (int it = 0; it < ITI; ++it) {
+            const int i = lane + 64 * it < MI ? lane + 64 * it : MI - 1;
+#pragma unroll
+            for (int q = 0; q < RLI; ++q) {
+                ca[it][q] = have ? ov[i + q * MI] : 0.f;
+                cb[it][q] = have ? ov[FO + i + q * MI] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < ITI; ++it)
+#pragma unroll
+            for (int q = 0; q < RLI; ++q) carry[it][q] = lane + 64 * it < MI ? cf_make(ca[it][q], -cb[it][q]) : cf_make(0.f, 0.f);
+    }
+    const int64_t b_begin = first == 0 ? 0 : static_cast<int64_t>(first) - 1;
+
+    for (int64_t b = b_begin; b < static_cast<int64_t>(last); ++b) {
+        const bool emit = b >= static_cast<int64_t>(first);
+        const GFloat2* xin = (const GFloat2*)(as_global(d.in) + static_cast<size_t>(b) * FI * 2);
+        GFloat2* xout = (GFloat2*)(as_global(d.out) + static_cast<size_t>(b) * FO * 2);
+        cf A[ITI][RLI];   // the even chain's outputs, kept while the odd chain runs
+        static_for<0, 2>([&](auto par_c) {
+            constexpr int par = decltype(par_c)::value;
+            // ---- forward FI-point transform of z (even bins) or z w (odd bins)
+            {
+                auto sample = [&](int j) -> cf {
+                    const f2 v = xin[j];
+                    cf z = cf_make(v.x, v.y);
+                    if constexpr (par == 1) z = cf_mul(lds_ld(chirp_w + j), z);
+                    return z;
+                };
+                if constexpr (FWD::kFused) wave_fused_first<FI, FWD::kR[0], FWD::kR[1], FWD::kPadJ>(buf, tw_f + FWD::tab(1), lane, sample);
+                else wave_first<FI, FWD::kR[0], FWD::kPadJ>(buf, lane, sample);
+            }
+            RSMP_TR(6 * par + 0);
+            static_for<(FWD::kFused ? 2 : 1), SF - 1>([&](auto s_c) {
+                constexpr int s = decltype(s_c)::value;
+                wave_stage<FI, FWD::kR[s], FWD::stride(s), FI / FWD::kR[s] + FWD::in_pad(s), FWD::out_pad(s), FWD::in_period(s)>(buf, tw_f + FWD::tab(s), lane);
+            });
+            RSMP_TR(6 * par + 1);
+            // ---- last forward stage in registers; times the filter; conj(V) of the chain into the buffer, in index order
+            {
+                cf z[ITF][RLF], hv[ITF][RLF];
+                wave_last_regs<FI, RLF, MF + FWD::in_pad(SF - 1), FWD::in_period(SF - 1)>(buf, tw_f + FWD::tab(SF - 1), lane, z);
+#pragma unroll
+                for (int it = 0; it < ITF; ++it) {
+                    const int i = lane + 64 * it;
+                    if ((it + 1) * 64 <= MF || i < MF) {
+#pragma unroll
+                        for (int q = 0; q < RLF; ++q) {
+                            const int k = 2 * (i + q * MF) + par;
+                            const int hi = k <= Bins::kPosMax ? k : 2 * FI - k;
+                            hv[it][q] = lds_ld(filter + (hi < NL ? hi : NL - 1));
+                        }
+                    }
+                }
+                lds_order();
+#pragma unroll
+                for (int it = 0; it < ITF; ++it) {
+                    const int i = lane + 64 * it;
+                    if ((it + 1) * 64 <= MF || i < MF) {
+#pragma unroll
+                        for (int q = 0; q < RLF; ++q) {
+                            const int kp = i + q * MF, k = 2 * kp + par;
+                            // what the bins of this q are, for every lane of the trip (k runs over [klo, khi])
+                            const int klo = 2 * (64 * it + q * MF) + par;
+                            const int khi = 2 * (((it + 1) * 64 <= MF ? 64 * it + 63 : MF - 1) + q * MF) + par;
+                            const bool all_pos = khi <= Bins::kPosMax, no_pos = klo > Bins::kPosMax;
+                            const bool all_neg = klo >= Bins::kNegMin, no_neg = khi < Bins::kNegMin;
+                            // conj(V) = conj(H Z) (positive), = H conj(Z) (negative: V = conj(H) Z)
+                            if (!no_pos) {
+                                const cf u = cf_mul_cc(z[it][q], hv[it][q]);
+                                if (all_pos || k <= Bins::kPosMax) lds_st(buf + kp, u);
+                            }
+                            if (!no_neg) {
+                                // (bin FI of an up-sampling plan is both: its filter value is the one fetched above)
+                                const cf u = cf_mul_cn(z[it][q], hv[it][q]);
+                                if (all_neg || k >= Bins::kNegMin) lds_st(buf + kp + Bins::kShift, u);
+                            }
+                        }
+                    }
+                }
+                lds_order();
+            }
+            RSMP_TR(6 * par + 2);
+            // ---- inverse FO-point transform of the chain's bins (forward butterflies on conjugated input)
+            {
+                constexpr int ZLO = Bins::zero_lo(par), ZHI = Bins::zero_hi(par);
+                auto from_lds = [&](int j) -> cf {
+                    cf v = lds_ld(buf + j);
+                    if (ZLO <= ZHI && j >= ZLO && j <= ZHI) v = cf_make(0.f, 0.f);
+                    return v;
+                };
+                if constexpr (INV::kFused) wave_fused_first<FO, INV::kR[0], INV::kR[1], INV::kPadJ>(buf, tw_i + INV::tab(1), lane, from_lds);
+                else wave_first<FO, INV::kR[0], INV::kPadJ>(buf, lane, from_lds);
+            }
+            RSMP_TR(6 * par + 3);
+            static_for<(INV::kFused ? 2 : 1), SI - 1>([&](auto s_c) {
+                constexpr int s = decltype(s_c)::value;
+                wave_stage<FO, INV::kR[s], INV::stride(s), FO / INV::kR[s] + INV::in_pad(s), INV::out_pad(s), INV::in_period(s)>(buf, tw_i + INV::tab(s), lane);
+            });
+            RSMP_TR(6 * par + 4);
+            if constexpr (par == 0) {
+                wave_last_regs<FO, RLI, MI + INV::in_pad(SI - 1), INV::in_period(SI - 1)>(buf, tw_i + INV::tab(SI - 1), lane, A);
+            } else {
+                cf B[ITI][RLI], uv[ITI][RLI];
+#pragma unroll
+                for (int it = 0; it < ITI; ++it) {
+                    const int i = lane + 64 * it;
+                    if ((it + 1) * 64 <= MI || i < MI) {
+#pragma unroll
+                        for (int q = 0; q < RLI; ++q) uv[it][q] = lds_ld(chirp_u + i + q * MI);
+                    }
+                }
+                wave_last_regs<FO, RLI, MI + INV::in_pad(SI - 1), INV::in_period(SI - 1)>(buf, tw_i + INV::tab(SI - 1), lane, B);
+                // F[n] = A + u B -> frame n = conj(F[n]) + conj(carry[n]); F[n + FO] = A - u B is the next carry
+#pragma unroll
+                for (int it = 0; it < ITI; ++it) {
+                    const int i = lane + 64 * it;
+                    if ((it + 1) * 64 <= MI || i < MI) {
+#pragma unroll
+                        for (int q = 0; q < RLI; ++q) {
+                            const cf t = cf_mul(uv[it][q], B[it][q]);
+                            if (emit) {
+                                const cf v = cf_conj_add_conj(A[it][q] + t, carry[it][q]);
+                                xout[i + q * MI] = f2{v.x, v.y};
+                            }
+                            carry[it][q] = A[it][q] - t;
+                        }
+                    }
+                }
+            }
+            lds_order();
+            RSMP_TR(6 * par + 5);
+        });
+    }
+#ifdef RSMP_FFT_TRACE
+    if (lane == 0 && gw < 4096) {
+        uint32_t hw_id, xcc_id;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
+        unsigned long long* t = rsmp_fft_trace_buf + static_cast<size_t>(gw) * 16;
+        t[0] = tr_t0;
+        t[1] = wall_clock64();
+        t[2] = (static_cast<unsigned long long>(xcc_id) << 32) | hw_id;
+        t[3] = static_cast<unsigned long long>(last - b_begin);
+        for (int i = 0; i < 12; ++i) t[4 + i] = tr_ph[i];
+    }
+#endif
+    if (last == d.n_blocks) {
+#pragma unroll
+        for (int it = 0; it < ITI; ++it) {
+            const int i = lane + 64 * it;
+            if (i < MI) {
+#pragma unroll
+                for (int q = 0; q < RLI; ++q) {
+                    const int n = i + q * MI;
+                    GFloat* ov = as_global(d.overlap_next);
+                    ov[n] = carry[it][q].x;
+                    ov[FO + n] = -carry[it][q].y;
+                }
+            }
+        }
+    }
+}
+
+typedef WavePlan<1176, 3, 7, 7, 8> W1176;   // 44.1 kHz side of the 44.1 <-> 48 kHz family
+typedef WavePlan<1280, 4, 5, 8, 8> W1280;   // 48 kHz side
+
+typedef void (*PairKernel)(FftPlanDev, const FftStreamDesc*, uint32_t, uint32_t, uint32_t, uint32_t);
+
+template <class FWD, class INV>
+bool pair_choice(const FftPlanDev& plan, PairKernel* fn, size_t* lds) {
+    if (!FWD::matches(plan.fft_in, plan.n_stages_f, plan.radix_f) || !INV::matches(plan.fft_out, plan.n_stages_i, plan.radix_i))
+        return false;
+    constexpr size_t buf = FWD::kBuf > INV::kBuf ? FWD::kBuf : INV::kBuf;
+    constexpr size_t tables = static_cast<size_t>(FWD::kTw + INV::kTw + PairBins<FWD::N, INV::N>::kNL + FWD::N + INV::N);
+    static_assert((tables + 8 * buf) * sizeof(cf) <= 160 * 1024, "LDS");
+    *fn = fft_ola_pair_kernel<FWD, INV>;
+    *lds = (tables + 8 * buf) * sizeof(cf);
+    return true;
+}
+
+}  // namespace
+
+// One wave per two-channel stream and run of blocks.  hipErrorNotSupported when the plan is not one of the pairs above
+// (the caller then uses the wave-per-channel kernels).
+hipError_t launch_fft_ola_pair(const FftPlanDev& plan, const FftStreamDesc* d_descs, uint32_t n_streams, uint32_t max_blocks,
+                               hipStream_t stream) {
+    if (plan.chirp_f == nullptr || plan.chirp_i == nullptr) return hipErrorNotSupported;
+    if (plan.new_length != (plan.fft_in < plan.fft_out ? plan.fft_in + 1 : plan.fft_out)) return hipErrorNotSupported;
+    PairKernel fn = nullptr;
+    size_t lds = 0;
+    if (!pair_choice<W1176, W1280>(plan, &fn, &lds) && !pair_choice<W1280, W1176>(plan, &fn, &lds)) return hipErrorNotSupported;
+    // Pairs of runs per stream: every run after a stream's first recomputes its predecessor block (1 / run extra work), and
+    // the launch ends with a partly filled round unless the number of waves is close to a multiple of what the chip holds
+    // (8 per CU).  Of a pair's blocks the old wave takes kLongShare (its share of a SIMD while both waves run).
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const double slots = static_cast<double>(cus) * 8;
+    static const double share_knob = [] { const char* e = rsmp::knob("RSMP_FFT_PAIR_SHARE"); return e ? atof(e) : 0.0; }();   // A/B
+    const double kLongShare = share_knob > 0.0 && share_knob < 1.0 ? share_knob : 0.6;
+    uint32_t both = 32;
+    double best = -1.0;
+    for (uint32_t cand = 12; cand <= 128; ++cand) {   // blocks of a pair
+        const double pairs = static_cast<double>((max_blocks + cand - 1) / cand);
+        const double waves = 2.0 * pairs * n_streams;
+        const double rounds = std::ceil(waves / slots);
+        const double useful = static_cast<double>(max_blocks) / (max_blocks + 2.0 * pairs - 1.0);   // halo blocks
+        const double score = waves / (rounds * slots) * useful;
+        if (score > best + 1e-9) { best = score; both = cand; }
+    }
+    const uint32_t pairs_per_stream = (max_blocks + both - 1) / both;
+    // (the halo block is part of a wave's work: the shares are of both + 2)
+    uint32_t run_long = static_cast<uint32_t>(std::lround(kLongShare * (both + 2.0) - 1.0));
+    if (run_long > both) run_long = both;
+    if (run_long < 1) run_long = 1;
+    const uint32_t run_short = both - run_long;
+    const uint32_t total_waves = pairs_per_stream * n_streams * 2;
+    const dim3 grid((total_waves + 7) / 8);
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(fn, grid, dim3(512), lds, stream, plan, d_descs, run_long, run_short, pairs_per_stream, total_waves);
+    return hipGetLastError();
+}
+
+}  // namespace rsmp

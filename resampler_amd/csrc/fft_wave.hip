@@ -41,347 +41,38 @@
 #include "fft_kernels.h"
 #include "common.h"
 
+#ifndef RSMP_EXP
+#define RSMP_EXP 0   // A/B builds (make exp EXPFILE=fft_wave.hip): timing experiments, never shipped
+#endif
+// RSMP_EXP = features + 64 * trace.  Features (bits): 1 = NO priority feedback between the waves of a SIMD; 4 = NO touch of
+// the next block's samples into L2 (the two things tools/fft_trace.py found, switched off again for an A/B);
+// 8 / 16 = every LDS store / read issued twice, 32 = two more packed instructions per complex multiply (what a store, a read,
+// a vector instruction costs the launch: profiles/r05/fft_slopes.txt).  Trace (tools/fft_trace.py): 1 = every wave's start /
+// end on the constant 100 MHz clock and where it ran; 2 = also the shader-clock cycles a wave spends in each phase of its
+// blocks (the reads of the clock drain the LDS queue at every phase boundary: the phases' shares are what it is for, not the
+// total).
+#define RSMP_FEAT (RSMP_EXP & 63)
+#define RSMP_PRIO (!(RSMP_FEAT & 1))
+#define RSMP_TOUCH (!(RSMP_FEAT & 4))
+#if (RSMP_EXP >> 6) != 0
+#define RSMP_FFT_TRACE 1
+__device__ unsigned long long rsmp_fft_trace_buf[4096 * 16];
+extern "C" int rsmp_debug_fft_trace(unsigned long long* out, size_t words) {
+    return static_cast<int>(hipMemcpyFromSymbol(out, HIP_SYMBOL(rsmp_fft_trace_buf), words * 8));
+}
+#endif
+#if (RSMP_EXP >> 6) == 2
+#define RSMP_TR(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); tr_ph[i] += t_ - tr_last; tr_last = t_; } while (0)
+#else
+#define RSMP_TR(i) do { } while (0)
+#endif
+
 namespace rsmp {
 
 namespace {
 
 
-// Lanes of a wave exchange data through the wave's LDS buffer without any barrier: the hardware executes a
-// wave's LDS operations in issue order.  The COMPILER, however, reasons per thread and may move a thread's
-// store above its own loads of provably different addresses -- which are other lanes' data here (it did,
-// in the radix-4 stage).  This pins the program order of memory operations; it emits no instruction.
-__device__ __forceinline__ void lds_order() { asm volatile("" ::: "memory"); }
-
-// Stream pointers come out of a descriptor in memory, so the compiler knows no address space for them and
-// emits FLAT loads and stores -- which count on the LDS counter too, and so tie every wait for an LDS read to
-// the block's output stores.  Naming the global address space gives global_load / global_store.
-typedef __attribute__((address_space(1))) float GFloat;
-typedef float f4 __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(1))) f4 GFloat4;
-typedef float f2 __attribute__((ext_vector_type(2)));
-typedef __attribute__((address_space(1))) f2 GFloat2;
-__device__ __forceinline__ const GFloat* as_global(const float* p) { return (const GFloat*)p; }
-__device__ __forceinline__ GFloat* as_global(float* p) { return (GFloat*)p; }
-
-// One LDS value by ds_read_b64, which the LDS serves at 256 B/clk.  Left to itself the compiler pairs
-// neighbouring loads into ds_read2_b64 / ds_read2st64_b64, which run at HALF that rate (8 LDS cycles for the
-// 16 bytes per lane against 2 + 2, MI355X_MICROARCH.md LDS table) in a kernel whose bound is the LDS; a
-// volatile access is never merged (and must name the LDS address space: address-space inference skips
-// volatile accesses, which would otherwise become flat loads).
-__device__ __forceinline__ cf lds_ld(const cf* p) {
-    typedef const volatile __attribute__((address_space(3))) cf* LdsPtr;
-    return *(LdsPtr)(p);
-}
-// Likewise one ds_write_b64 per value: the ds_write2_b64 the compiler forms of two costs 13 LDS cycles against 6 + 6.
-__device__ __forceinline__ void lds_st(cf* p, cf v) {
-#ifdef RSMP_FFT_WAVE_MERGED_STORES
-    *p = v;
-#else
-    typedef volatile __attribute__((address_space(3))) cf* LdsPtr;
-    *(LdsPtr)(p) = v;
-#endif
-}
-
-// A transform of N complex points in `Rs...` Stockham stages (2 .. 4 of them), as the reference's planner orders
-// them (src/fft/optimizer.rs).  Where the first two radices multiply to at most 21 values per unit (and a third
-// stage exists) they run as one register pass (wave_fused_first); every later stage but the inverse's last is a
-// wave_stage; the twiddle tables of all stages sit in LDS.
-// LDS stores go 16 lanes at a time over 32 banks (MI355X_MICROARCH.md, LDS table; tools/fft_bank_model.py counts the
-// array cycles of every pass of a plan pair).  A stage's lane i stores its value q at R (i - k) + k + q stride
-// (k = i mod stride): lanes 16 apart in i are in different blocks of `stride` columns unless stride >= 16, and a
-// block is (R - 1) stride values further than the lane index says -- two values per 16 lanes of shift keep the
-// 16 lanes of a store on distinct banks iff (R - 1) stride + pad is a multiple of 16 values.  (Radix 7, stride 21:
-// 147-value blocks, 2 values of padding; radix 8, stride 20: 4.)
-constexpr int stage_out_pad(int r, int stride) { return (16 - ((r - 1) * stride) % 16) % 16; }
-constexpr int gcd_c(int a, int b) { return b == 0 ? a : gcd_c(b, a % b); }
-// Twiddles a stage keeps per column in LDS: all R - 1 of the row, or -- radix 7 and 8 -- only w, w^2 and w^4 (the
-// stage multiplies the others out, see twiddle_expand; the tables of the 1176 <-> 1280 pair shrink from 39 to 29 KB).
-#if !defined(RSMP_FFT_WAVE_EXACT) && !defined(RSMP_FFT_WAVE_ALL_TWIDDLES)
-constexpr int fetch_count(int r) { return (r == 7 || r == 8) ? 3 : r - 1; }
-#else
-constexpr int fetch_count(int r) { return r - 1; }
-#endif
-template <int N_, int... Rs>
-struct WavePlan {
-    static constexpr int N = N_;
-    static constexpr int kStages = sizeof...(Rs);
-    static constexpr int kR[sizeof...(Rs)] = {Rs...};
-    static_assert(kStages >= 2 && kStages <= 5, "stages");
-    static constexpr int stride(int s) { int v = 1; for (int i = 0; i < s; ++i) v *= kR[i]; return v; }
-    static_assert(stride(kStages) == N_, "radices");
-    static constexpr bool kFused = kStages >= 3 && kR[0] * kR[1] <= 21;
-    // Stage twiddles, unique per column: stage s (s >= 1) holds stride(s) rows of R_s - 1.  In LDS the rows of a
-    // wave_stage are (R - 1) | 1 values apart: lane k reads row k, and an even row length puts lanes 16 apart
-    // (radix 7: six values = 12 dwords) on the same banks.  (The fused pass reads its rows by constant index.)
-    static constexpr int row(int r) { return fetch_count(r) | 1; }
-    static constexpr int pitch(int s) { return kFused && s == 1 ? kR[1] - 1 : row(kR[s]); }
-    static constexpr int tab(int s) { int off = 0; for (int i = 1; i < s; ++i) off += stride(i) * pitch(i); return off; }   // LDS offset of stage s
-    static constexpr int src(int s) { int off = 0; for (int i = 1; i < s; ++i) off += stride(i) * (kR[i] - 1); return off; }   // offset in the plan's array
-    static constexpr int kTw = tab(kStages);
-    static constexpr int kRc = N_ / 2 - 1;   // real <-> complex twiddles
-    // Padding between passes (LDS banks).  The first pass (fused or not) writes kUnit values per lane side by side:
-    // an even kUnit puts lanes 32 / gcd(2 kUnit, 32) apart on the same banks, so one value of padding follows every
-    // kPadJ units (20 values per unit: every 4) where the next stage's input distance is a multiple of that period.
-    // After the blocks of a later stage: stage_out_pad, where the stage that follows reads block by block.
-    // in_pad(s): what stage s's input distance N / R_s grows by; in_period(s): elements between two padding values
-    // inside that distance (0 = none).
-    static constexpr int kUnit = kFused ? kR[0] * kR[1] : kR[0];
-    static constexpr int kNext = kFused ? 2 : 1;   // the stage that reads the first pass's output
-    // (Plans above 2048 points run at the 256-register cap of their wide workgroups: the padded addressing spilled
-    // there -- 2352 -> 2560 points 0.80 -> 1.00 ms -- so they keep the plain layout, but for the radix-7 blocks.)
-    static constexpr bool kPadded = N_ <= 2048;
-    static constexpr int first_padj() {
-        if (!kPadded || kUnit % 2 != 0 || kNext >= kStages) return 0;
-        const int p = 32 / gcd_c(2 * kUnit, 32);
-        return (N_ / kR[kNext < kStages ? kNext : 0]) % (p * kUnit) == 0 ? p : 0;
-    }
-    static constexpr int kPadJ = first_padj();
-    static constexpr int out_pad(int s) {
-        if (s < 1 || s + 1 >= kStages || (kFused && s == 1)) return 0;
-        if (stride(s) >= N_ / kR[s]) return 0;   // one block
-        const int p = kPadded || (kR[s] == 7 && stride(s) == 21) ? stage_out_pad(kR[s], stride(s)) : 0;
-        return p != 0 && N_ / kR[s + 1] == stride(s + 1) ? p : 0;
-    }
-    static constexpr int in_pad(int s) {
-        if (s == kNext) return kPadJ ? (N_ / kR[s]) / (kPadJ * kUnit) : 0;
-        return s >= 2 ? out_pad(s - 1) : 0;
-    }
-    static constexpr int in_period(int s) { return s == kNext && kPadJ && N_ / kR[s] > kPadJ * kUnit ? kPadJ * kUnit : 0; }
-    static constexpr int buf_values() {   // what the wave's buffer needs: the points + bin N and its neighbour (real <-> complex passes), or the widest padded layout
-        int pad = kPadJ ? N_ / (kPadJ * kUnit) : 0;
-        for (int s = 1; s + 1 < kStages; ++s) {
-            const int p = out_pad(s) * (N_ / stride(s + 1));
-            if (p > pad) pad = p;
-        }
-        return N_ + (pad > 2 ? pad : 2);
-    }
-    static constexpr int kBuf = buf_values();
-    static bool matches(uint32_t n, uint32_t n_stages, const uint32_t* radix) {
-        if (n != static_cast<uint32_t>(N_) || n_stages != static_cast<uint32_t>(kStages)) return false;
-        for (int s = 0; s < kStages; ++s)
-            if (radix[s] != static_cast<uint32_t>(kR[s])) return false;
-        return true;
-    }
-};
-
-// One Stockham stage in place in the wave's LDS buffer: butterfly i reads buf[i + q*M], twiddles inputs
-// 1..R-1 with w[(i mod STRIDE)*(R-1) + q-1] and writes buf[R*i - (R-1)*k + q*STRIDE]
-// (butterfly4/mod.rs:316-320 etc.).  Every read of the stage is issued before its first write.
-// The R - 1 twiddles of a butterfly are the powers w, w^2 .. w^(R-1) of one value.  The kernel is bound by
-// LDS traffic, of which the twiddle rows were a quarter: radix 7 and 8 fetch w, w^2 and w^4 and multiply
-// the others out (one or two roundings more on those twiddles; -DRSMP_FFT_WAVE_EXACT fetches all of them).
-// A row is FETCHED (twiddle_fetch: kFetch<R> LDS reads, issued with the stage's data reads) and EXPANDED
-// when its butterfly runs.
-template <int R> constexpr int kFetch = fetch_count(R);
-template <int R>
-__device__ __forceinline__ void twiddle_fetch(const cf* __restrict__ w, cf (&raw)[kFetch<R>]) {
-    if constexpr (kFetch<R> != R - 1) {
-        raw[0] = lds_ld(w);       // (the LDS row holds w, w^2, w^4)
-        raw[1] = lds_ld(w + 1);
-        raw[2] = lds_ld(w + 2);
-    } else {
-#pragma unroll
-        for (int q = 0; q < R - 1; ++q) raw[q] = lds_ld(w + q);
-    }
-}
-template <int R>
-__device__ __forceinline__ void twiddle_expand(const cf (&raw)[kFetch<R>], cf (&tw)[R]) {
-    if constexpr (kFetch<R> != R - 1) {
-        tw[1] = raw[0];
-        tw[2] = raw[1];
-        tw[4] = raw[2];
-        tw[3] = cf_mul(tw[1], tw[2]);
-        tw[5] = cf_mul(tw[1], tw[4]);
-        tw[6] = cf_mul(tw[2], tw[4]);
-        if constexpr (R == 8) tw[7] = cf_mul(tw[3], tw[4]);
-    } else {
-#pragma unroll
-        for (int q = 1; q < R; ++q) tw[q] = raw[q - 1];
-    }
-}
-
-// QS: distance of a butterfly's inputs in the buffer (N / R, or more when the producer padded its rows).
-// OPAD: values of padding after every R * STRIDE outputs (one block of the next stage's columns).  With 21
-// columns a half wave of 32 lanes spans two blocks, and 147 values = 294 dwords put the second block's first
-// columns on the first block's last banks; two values more (298 = 42 mod 64) and every half wave of the
-// stage stores conflict-free.  The next stage then reads its inputs N / R' + OPAD apart (stage_out_pad).
-// IPP: the producer (the first pass) left one value of padding after every IPP of the stage's inputs (0 = none).
-template <int N, int R, int STRIDE, int QS = N / R, int OPAD = 0, int IPP = 0>
-__device__ __forceinline__ void wave_stage(cf* buf, const cf* __restrict__ tw, int lane) {
-    constexpr int M = N / R;
-    constexpr int ITER = (M + 63) / 64;
-    constexpr int ROW = fetch_count(R) | 1;
-    // Every LDS read of the stage -- data and twiddle rows, in the order of their use -- is issued before the
-    // first butterfly: the wave then waits for a read once per stage, not once per butterfly (LDS operations
-    // of a wave complete in order, so butterfly 0 runs while the later reads are still in flight).
-    if constexpr (STRIDE == M && QS == M && OPAD == 0 && IPP == 0 && ITER >= 4) {
-        // A plan's last stage writes every value where it read it (stride = M: the butterfly's own points), so
-        // butterflies need not wait for each other's reads: of a long stage (4 or 5 trips: 64-80 values and their
-        // twiddles in registers at once, which the plans of 2048 points and more paid with spills) only the next
-        // trip's reads are in flight while one runs.
-        cf t2[2][R], raw2[2][kFetch<R>];
-        auto fetch = [&](int it) {
-            const int i = lane + 64 * it;
-            if ((it + 1) * 64 <= M || i < M) {
-#pragma unroll
-                for (int q = 0; q < R; ++q) t2[it & 1][q] = lds_ld(buf + i + q * M);
-                twiddle_fetch<R>(tw + i * ROW, raw2[it & 1]);
-            }
-        };
-        fetch(0);
-#pragma unroll
-        for (int it = 0; it < ITER; ++it) {
-            const int i = lane + 64 * it;
-            if (it + 1 < ITER) fetch(it + 1);
-            if ((it + 1) * 64 <= M || i < M) {
-                cf twr[R], o[R];
-                twiddle_expand<R>(raw2[it & 1], twr);
-#pragma unroll
-                for (int q = 1; q < R; ++q) t2[it & 1][q] = cf_mul(twr[q], t2[it & 1][q]);
-                pdft<R>(t2[it & 1], o);
-#pragma unroll
-                for (int q = 0; q < R; ++q) lds_st(buf + i + q * M, o[q]);
-            }
-        }
-        lds_order();
-        return;
-    }
-    cf t[ITER][R], raw[ITER][kFetch<R>];
-#pragma unroll
-    for (int it = 0; it < ITER; ++it) {
-        const int i = lane + 64 * it;
-        if ((it + 1) * 64 <= M || i < M) {
-#pragma unroll
-            for (int q = 0; q < R; ++q) t[it][q] = lds_ld(buf + i + (IPP ? i / (IPP ? IPP : 1) : 0) + q * QS);
-            twiddle_fetch<R>(tw + (i % STRIDE) * ROW, raw[it]);
-        }
-    }
-    lds_order();
-#pragma unroll
-    for (int it = 0; it < ITER; ++it) {
-        const int i = lane + 64 * it;
-        if ((it + 1) * 64 <= M || i < M) {
-            const int k = i % STRIDE;
-            cf twr[R];
-            twiddle_expand<R>(raw[it], twr);
-#pragma unroll
-            for (int q = 1; q < R; ++q) t[it][q] = cf_mul(twr[q], t[it][q]);
-            cf o[R];
-            pdft<R>(t[it], o);
-            cf* d = buf + R * i - (R - 1) * k + (OPAD ? OPAD * (i / STRIDE) : 0);
-#pragma unroll
-            for (int q = 0; q < R; ++q) lds_st(d + q * STRIDE, o[q]);
-        }
-    }
-    lds_order();
-}
-
-// Stages 0 (radix RA, stride 1, no twiddles) and 1 (radix RB, stride RA, twiddles W_(RA*RB)^(k q')) of a
-// transform in ONE register pass.  The three (RA) stage-1 butterflies 3j, 3j+1, 3j+2 consume exactly the
-// outputs of the seven (RB) stage-0 butterflies j + M2*q': unit j therefore takes the RA*RB points
-// j + M2*m (m = q' + RB*q), runs RB radix-RA butterflies, the twiddles and RA radix-RB butterflies in
-// registers, and writes the contiguous outputs RA*RB*j .. RA*RB*j + RA*RB - 1 -- what the two stages
-// would have left in LDS, with one LDS round trip and the stage-1 index arithmetic gone.  Same operations
-// on the same values as the separate stages (the unit twiddles of column k = 0 are skipped).
-// `load(index)` yields point `index` of the stage-0 input (LDS, or samples straight from HBM).
-// A unit's outputs are RA*RB values apart from the next lane's; when that is even (20 values = 40 dwords)
-// the 64 lanes of a store meet on 8 bank pairs, so one value of padding follows every fused_pad<>() values
-// (160: lanes 8 apart move on by a bank pair) and the next stage reads its inputs fused_qs<>() apart.
-template <int I, int E, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (I < E) {
-        f(std::integral_constant<int, I>{});
-        static_for<I + 1, E>(f);
-    }
-}
-// NVALID: points at index >= NVALID of the stage-0 input are zero and are neither fetched nor computed with
-// (the zero padding of the forward transform: resampler_fft.rs:387-388).  Butterfly q' takes the points
-// j + M2 (q' + RB q): the last NZ of its RA inputs are padding for every j (pdft_tail).
-// PADJ: one value of padding after every PADJ units (WavePlan::kPadJ; 0 = none).
-template <int N, int RA, int RB, int PADJ, int NVALID = N, class Load>
-__device__ __forceinline__ void wave_fused_first(cf* dst, const cf* __restrict__ tw1, int lane, Load load) {
-    constexpr int M2 = N / (RA * RB);
-    constexpr int ITER = (M2 + 63) / 64;
-    cf s[ITER][RB][RA];
-#pragma unroll
-    for (int it = 0; it < ITER; ++it) {
-        const int j = lane + 64 * it;
-        if ((it + 1) * 64 <= M2 || j < M2) {
-            static_for<0, RB>([&](auto qp_c) {
-                static_for<0, RA>([&](auto q_c) {
-                    constexpr int m = decltype(qp_c)::value + RB * decltype(q_c)::value;
-                    if constexpr (M2 * m < NVALID) s[it][decltype(qp_c)::value][decltype(q_c)::value] = load(j + M2 * m);
-                });
-            });
-        }
-    }
-    cf w1[RA][RB];   // (the same for every lane: broadcast reads, fetched with the data)
-#pragma unroll
-    for (int k = 1; k < RA; ++k)
-#pragma unroll
-        for (int qp = 1; qp < RB; ++qp) w1[k][qp] = lds_ld(tw1 + k * (RB - 1) + qp - 1);
-    lds_order();
-#pragma unroll
-    for (int it = 0; it < ITER; ++it) {
-        const int j = lane + 64 * it;
-        if ((it + 1) * 64 <= M2 || j < M2) {
-            static_for<0, RB>([&](auto qp_c) {
-                constexpr int qp = decltype(qp_c)::value;
-                // inputs q with M2 (qp + RB q) >= NVALID are zero: count them from the end
-                constexpr int first_zero = M2 * qp >= NVALID ? 0 : (NVALID - M2 * qp + M2 * RB - 1) / (M2 * RB);
-                constexpr int NZ = first_zero >= RA ? 0 : RA - first_zero;
-                cf o[RA];
-                pdft_tail<RA, NZ>(s[it][qp], o);
-#pragma unroll
-                for (int k = 0; k < RA; ++k) s[it][qp][k] = o[k];
-            });
-#pragma unroll
-            for (int k = 0; k < RA; ++k) {
-                cf u[RB], o[RB];
-                u[0] = s[it][0][k];
-#pragma unroll
-                for (int qp = 1; qp < RB; ++qp)
-                    u[qp] = k == 0 ? s[it][qp][k] : cf_mul(w1[k][qp], s[it][qp][k]);
-                pdft<RB>(u, o);
-#pragma unroll
-                for (int qq = 0; qq < RB; ++qq) lds_st(dst + RA * RB * j + (PADJ ? j / (PADJ ? PADJ : 1) : 0) + k + RA * qq, o[qq]);
-            }
-        }
-    }
-    lds_order();
-}
-
-// Stage 0 alone (stride 1, no twiddles) for the plans that do not fuse it with stage 1: butterfly i takes the
-// points i + q N / R through `load` (LDS, or samples straight from HBM; points at index >= NVALID are zero) and
-// writes R i + q.
-template <int N, int R, int PADJ, int NVALID = N, class Load>
-__device__ __forceinline__ void wave_first(cf* dst, int lane, Load load) {
-    constexpr int M = N / R;
-    constexpr int ITER = (M + 63) / 64;
-    constexpr int first_zero = (NVALID + M - 1) / M;            // inputs q >= first_zero are zero for every i
-    constexpr int NZ = first_zero >= R ? 0 : R - first_zero;
-    cf t[ITER][R];
-#pragma unroll
-    for (int it = 0; it < ITER; ++it) {
-        const int i = lane + 64 * it;
-        if ((it + 1) * 64 <= M || i < M) {
-#pragma unroll
-            for (int q = 0; q < R - NZ; ++q) t[it][q] = load(i + q * M);
-        }
-    }
-    lds_order();
-#pragma unroll
-    for (int it = 0; it < ITER; ++it) {
-        const int i = lane + 64 * it;
-        if ((it + 1) * 64 <= M || i < M) {
-            cf o[R];
-            pdft_tail<R, NZ>(t[it], o);
-#pragma unroll
-            for (int q = 0; q < R; ++q) lds_st(dst + R * i + (PADJ ? i / (PADJ ? PADJ : 1) : 0) + q, o[q]);
-        }
-    }
-    lds_order();
-}
+#include "fft_wave_core.h"
 
 // postprocess_fft (radix_fft.rs:500-537 + real_complex/mod.rs:37-74), in place on x[0 .. N2].
 template <int N2>
@@ -587,8 +278,38 @@ __global__ __launch_bounds__((OCC == 1 && kOneWavePerSimd<FWD, INV> ? 256 : wave
     constexpr bool kXch = C2 && !kOddLast && HL % 2 == 0 && FI <= 2048 && FO <= 2048;
     uint32_t* xflags = reinterpret_cast<uint32_t*>(lds2 + kTabEnd + kWavesPerGroup * LDSC);
     if (kXch && threadIdx.x < 2u * kWavesPerGroup) xflags[threadIdx.x] = 0;
+#if RSMP_PRIO
+    // Waves of one SIMD are served oldest first: of the three waves a SIMD holds the oldest ends its run a third earlier
+    // than the youngest (tools/fft_trace.py), and the launch ends with one wave per SIMD.  Each wave publishes its block
+    // count; a wave behind the others of its SIMD raises its priority (s_setprio), the one ahead lowers it.
+    uint32_t* wsimd = xflags + 32;   // SIMD id of each wave of the workgroup
+    uint32_t* wprog = xflags + 48;   // blocks done
+    uint32_t my_simd;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID, 4, 2)" : "=s"(my_simd));
+    if (lane == 0) { wsimd[wave] = my_simd; wprog[wave] = 0; }
+#endif
     __syncthreads();
-    if (gw >= total_waves) return;
+#if RSMP_PRIO
+    uint32_t peer_a = wave, peer_b = wave;
+    for (uint32_t w = 0; w < static_cast<uint32_t>(kWavesPerGroup); ++w) {
+        const uint32_t sd = __builtin_amdgcn_readfirstlane(wsimd[w]);
+        if (w != wave && sd == my_simd) {
+            if (peer_a == wave) peer_a = w; else peer_b = w;
+        }
+    }
+#endif
+    if (gw >= total_waves) {
+#if RSMP_PRIO
+        if (lane == 0) wprog[wave] = 0xffffffffu;
+#endif
+        return;
+    }
+#ifdef RSMP_FFT_TRACE
+    const unsigned long long tr_t0 = wall_clock64();
+    unsigned long long tr_ph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tr_last = __builtin_readcyclecounter();
+    (void)tr_ph; (void)tr_last;
+#endif
     const bool xch = kXch && kWavesPerGroup % 2 == 0;   // (an odd number of waves per workgroup would part a pair)
     uint32_t xseq = 0;                                   // blocks exchanged so far
     cf* buf = lds2 + kTabEnd + wave * LDSC;
@@ -615,7 +336,12 @@ __global__ __launch_bounds__((OCC == 1 && kOneWavePerSimd<FWD, INV> ? 256 : wave
     constexpr bool stereo = CHM == 1;   // (frames of exactly the two channels: 16-byte loads and stores)
     const uint32_t pair2 = 2u * pair;
     const uint32_t first = run_idx * run;
-    if (first >= d.n_blocks) return;
+    if (first >= d.n_blocks) {
+#if RSMP_PRIO
+        if (lane == 0) wprog[wave] = 0xffffffffu;
+#endif
+        return;
+    }
     const uint32_t last = first + run < d.n_blocks ? first + run : d.n_blocks;  // exclusive
 
     // overlap carried into the run: the stream state, or the predecessor block recomputed (not emitted).
@@ -637,12 +363,35 @@ __global__ __launch_bounds__((OCC == 1 && kOneWavePerSimd<FWD, INV> ? 256 : wave
     }
     const int64_t b_begin = first == 0 ? 0 : static_cast<int64_t>(first) - 1;
 
+#if RSMP_TOUCH
+    float pf = 0.f;   // the touch of the next block's lines (a load nobody reads: it is waited for a block later, behind younger stores)
+#endif
     for (int64_t b = b_begin; b < static_cast<int64_t>(last); ++b) {
         const bool emit = b >= static_cast<int64_t>(first);
+#if RSMP_TOUCH
+        asm volatile("" :: "v"(pf));
+#endif
         if constexpr (kXch) {   // the neighbour must have taken the previous block's outgoing values out of this buffer
             if (xch && xseq > 0)
                 while (__hip_atomic_load(xflags + 2 * wave + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < xseq) __builtin_amdgcn_s_sleep(1);
         }
+        RSMP_TR(0);
+#if (RSMP_EXP >> 6) == 2
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the previous block's stores: the first pass's loads wait behind them -- vmcnt counts in order)
+        RSMP_TR(10);
+#endif
+#if RSMP_PRIO
+        {
+            const uint32_t mine = static_cast<uint32_t>(b - b_begin);
+            if (lane == 0) __hip_atomic_store(wprog + wave, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const uint32_t pa = __builtin_amdgcn_readfirstlane(__hip_atomic_load(wprog + peer_a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+            const uint32_t pb = __builtin_amdgcn_readfirstlane(__hip_atomic_load(wprog + peer_b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+            const uint32_t ahead = (peer_a != wave && pa > mine ? 1u : 0u) + (peer_b != wave && pb > mine ? 1u : 0u);   // waves of this SIMD that have done more
+            if (ahead == 0) __builtin_amdgcn_s_setprio(0);
+            else if (ahead == 1) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(2);
+        }
+#endif
         // ---- forward transform: the first pass takes its inputs straight from HBM: complex j of the block's
         // channel = frames 2j, 2j + 1 (j < FI / 2), zero beyond (resampler_fft.rs:387-388)
         {
@@ -725,12 +474,27 @@ __global__ __launch_bounds__((OCC == 1 && kOneWavePerSimd<FWD, INV> ? 256 : wave
                 first_pass(sample);
             }
         }
+#if RSMP_TOUCH
+        if constexpr (stereo) {
+            // The first pass of every block waits for HBM (28 % of a wave's time, tools/fft_trace.py).  The block after this
+            // one is touched into L2 now: the two waves of a stream take every other 128-byte line of its 9.4 KB.
+            if (b + 1 < static_cast<int64_t>(d.n_blocks)) {
+                const GFloat* nx = as_global(d.in) + static_cast<size_t>(b + 1) * FI * C;
+                const uint32_t fl = (2u * static_cast<uint32_t>(lane) + ch) * 32u;
+                if (fl < static_cast<uint32_t>(FI) * 2u) pf = nx[fl];
+            }
+        }
+#endif
+        RSMP_TR(1);
         static_for<(FWD::kFused ? 2 : 1), SF>([&](auto s_c) {
             constexpr int s = decltype(s_c)::value;
             wave_stage<FI, FWD::kR[s], FWD::stride(s), FI / FWD::kR[s] + FWD::in_pad(s), FWD::out_pad(s), FWD::in_period(s)>(buf, tw_f + FWD::tab(s), lane);
+            RSMP_TR(s);   // (2, 3)
         });
         wave_postprocess<FI>(buf, rc_f, lane);
+        RSMP_TR(4);
         wave_filter_preprocess<FO, kFilterLen, kFilterLen - 1>(buf, filter, rc_i, lane);
+        RSMP_TR(5);
 
         // ---- inverse transform, in place; its last stage below
         {
@@ -738,10 +502,12 @@ __global__ __launch_bounds__((OCC == 1 && kOneWavePerSimd<FWD, INV> ? 256 : wave
             if constexpr (INV::kFused) wave_fused_first<FO, INV::kR[0], INV::kR[1], INV::kPadJ>(buf, tw_i + INV::tab(1), lane, from_lds);
             else wave_first<FO, INV::kR[0], INV::kPadJ>(buf, lane, from_lds);
         }
+        RSMP_TR(6);
         static_for<(INV::kFused ? 2 : 1), (kOddLast ? SI : SI - 1)>([&](auto s_c) {
             constexpr int s = decltype(s_c)::value;
             wave_stage<FO, INV::kR[s], INV::stride(s), FO / INV::kR[s] + INV::in_pad(s), INV::out_pad(s), INV::in_period(s)>(buf, tw_i + INV::tab(s), lane);
         });
+        RSMP_TR(7);
         // ---- last inverse stage: outputs stay in registers.  Butterfly i (k = i) yields Z[i + q*ML]; the
         // output conjugation (radix_fft.rs:656-669) makes reals 2c, 2c + 1 of the channel out of Z[c]; the
         // first FO reals are overlap-added and stored, the second FO become the next overlap (:416-423).
@@ -803,6 +569,7 @@ __global__ __launch_bounds__((OCC == 1 && kOneWavePerSimd<FWD, INV> ? 256 : wave
                 }
             }
         }
+        RSMP_TR(8);
         if constexpr (kXch) {
             if (xch && emit) {
                 lds_order();
@@ -844,7 +611,24 @@ __global__ __launch_bounds__((OCC == 1 && kOneWavePerSimd<FWD, INV> ? 256 : wave
         }
         }
         lds_order();
+        RSMP_TR(9);
     }
+#if RSMP_PRIO
+    if (lane == 0) __hip_atomic_store(wprog + wave, 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
+#ifdef RSMP_FFT_TRACE
+    if (lane == 0 && gw < 4096) {
+        uint32_t hw_id, xcc_id;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
+        unsigned long long* t = rsmp_fft_trace_buf + static_cast<size_t>(gw) * 16;
+        t[0] = tr_t0;
+        t[1] = wall_clock64();
+        t[2] = (static_cast<unsigned long long>(xcc_id) << 32) | hw_id;
+        t[3] = static_cast<unsigned long long>(last - b_begin);
+        for (int i = 0; i < 12; ++i) t[4 + i] = tr_ph[i];
+    }
+#endif
     if (last == d.n_blocks) {
 #pragma unroll
         for (int it = 0; it < CIT; ++it) {
@@ -906,7 +690,7 @@ bool wave_choice(const FftPlanDev& plan, uint32_t channels, int occ_env, WaveCho
     constexpr size_t tables = static_cast<size_t>(FWD::kTw + INV::kTw + FWD::kRc + INV::kRc + (FWD::N < INV::N ? FWD::N + 1 : INV::N));   // (+ the filter bins in use)
     constexpr size_t buf = FWD::kBuf > INV::kBuf ? FWD::kBuf : INV::kBuf;
     constexpr size_t kCu = 160 * 1024 / sizeof(cf);
-    constexpr size_t kFlags = 16;   // cf-sized words of exchange flags behind the buffers (two 32-bit words per wave, up to 16 waves)
+    constexpr size_t kFlags = 32;   // cf-sized words behind the buffers: exchange flags (two 32-bit words per wave, up to 16 waves), then the waves' SIMD ids and block counts
     constexpr bool fit12 = tables + 12 * buf + kFlags <= kCu, fit4 = 2 * (tables + 4 * buf + kFlags) <= kCu;
     constexpr uint32_t wide_fit = (kCu - tables - kFlags) / buf < 8 ? static_cast<uint32_t>((kCu - tables - kFlags) / buf) : 8u;
     constexpr uint32_t wide = kOneWavePerSimd<FWD, INV> && wide_fit > 4 ? 4u : wide_fit;
@@ -951,6 +735,14 @@ bool wave_choices(const FftPlanDev& plan, uint32_t channels, int occ_env, WaveCh
 
 }  // namespace
 
+bool fft_wave_is_exact() {
+#ifdef RSMP_FFT_WAVE_EXACT
+    return true;
+#else
+    return false;
+#endif
+}
+
 // Wave-per-transform kernels exist for the 44.1 <-> 48 kHz family (both directions) and for the families whose
 // input block is 512 frames (x2, /2, /4, /8, x3, x1.5 ...).  Returns hipErrorNotSupported when the plan is another
 // one (the caller then uses the workgroup kernels).
@@ -963,7 +755,11 @@ hipError_t launch_fft_ola_wave(const FftPlanDev& plan, const FftStreamDesc* d_de
     const uint32_t C = max_channels;
     constexpr int occ_env = 0;
     WaveChoice wc;
-    const bool found = wave_choices<W1176, W1280>(plan, C, occ_env, &wc) || wave_choices<W1280, W1176>(plan, C, occ_env, &wc) ||
+    const bool found = wave_choices<W1176, W1280>(plan, C, occ_env, &wc) || wave_choices<W1280, W1176>(plan, C, occ_env, &wc)
+#if RSMP_EXP != 0   // (timing experiments instantiate the 44.1 <-> 48 kHz pair alone: 25 s instead of 160 s per build)
+                       ;
+#else
+                       ||
                        wave_choices<W512, W64, W128, W256, W768, W1024, W1536, W2048, W3072, W4096>(plan, C, occ_env, &wc) ||
                        wave_choices<W768, W64, W128, W256, W512>(plan, C, occ_env, &wc) ||
                        wave_choices<W1536, W64, W128>(plan, C, occ_env, &wc) ||
@@ -975,6 +771,7 @@ hipError_t launch_fft_ola_wave(const FftPlanDev& plan, const FftStreamDesc* d_de
                        wave_choices<W4704, W1280, W2560>(plan, C, occ_env, &wc) || wave_choices<W5120, W1176, W2352>(plan, C, occ_env, &wc) ||
                        wave_choice<W2560, W4704>(plan, C, occ_env, &wc) || wave_choice<W1176, W5120>(plan, C, occ_env, &wc) ||
                        wave_choice<W2352, W5120>(plan, C, occ_env, &wc) || wave_choice<W588, W5120>(plan, C, occ_env, &wc);
+#endif
     if (!found) return hipErrorNotSupported;
     const uint32_t kWavesPerGroup = wc.waves;
     const size_t lds = wc.lds;
