@@ -528,7 +528,7 @@ def bench_fft(ctx: Ctx, args, steps: int, warmup: int, with_cpu: bool):
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"ResamplerFft 2ch 44100->48000, {S} streams/GPU x {blocks} blocks of "
                                f"1176 frames per step, one launch per step"},
-        "roofline": {"bound": "hbm", "kernel": "fft_ola_wave_kernel (wave per transform, 1176/1280 plan)",
+        "roofline": {"bound": "hbm", "kernel": "fft_ola_pair_kernel (wave per two-channel stream, 1176/1280 plan)",
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic_from_profiles("fft"),
                      "kernel_ms": round(k_ms, 4), "kernel_ms_median": round(float(np.median(k)), 4),

@@ -83,6 +83,118 @@ __device__ __forceinline__ cf cf_mul_cc(cf a, cf b) {
     return d;
 }
 
+// conj(a) u + conj(c), component by component: (a.x u.x + c.x, -(a.y u.y) - c.y)
+__device__ __forceinline__ cf cf_conj_scale_add_conj(cf a, cf u, cf c) {
+    cf d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 neg_hi:[1,0,1]" : "=v"(d) : "v"(a), "v"(u), "v"(c));
+    return d;
+}
+
+// A value reduced over the wave's 64 lanes (row-wise DPP steps, then the rows' last lanes handed on): the sum, or the
+// largest of non-negative values.  The result is uniform (read out of lane 63).
+template <bool MAX>
+__device__ __forceinline__ float wave_reduce(float v) {
+    auto step = [](float x, auto ctrl_c, auto mask_c) {
+        const int xi = __builtin_bit_cast(int, x);
+        // (rows a step leaves out get 0 / themselves: bound_ctrl off, `old` = the neutral element)
+        const int m = __builtin_amdgcn_update_dpp(MAX ? xi : 0, xi, decltype(ctrl_c)::value, decltype(mask_c)::value, 0xf, false);
+        return MAX ? fmaxf(x, __builtin_bit_cast(float, m)) : x + __builtin_bit_cast(float, m);
+    };
+    v = step(v, std::integral_constant<int, 0xB1>{}, std::integral_constant<int, 0xf>{});    // quad_perm [1,0,3,2]
+    v = step(v, std::integral_constant<int, 0x4E>{}, std::integral_constant<int, 0xf>{});    // quad_perm [2,3,0,1]
+    v = step(v, std::integral_constant<int, 0x141>{}, std::integral_constant<int, 0xf>{});   // row_half_mirror
+    v = step(v, std::integral_constant<int, 0x140>{}, std::integral_constant<int, 0xf>{});   // row_mirror
+    v = step(v, std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xa>{});   // row_bcast:15 into rows 1, 3
+    v = step(v, std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xc>{});   // row_bcast:31 into rows 2, 3
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+// The two channels of a block share every butterfly, so what one channel's rounding leaves behind is relative to the
+// LARGER channel.  Each channel of a block is therefore brought to a level near 1 by a power of two on the way in (exact)
+// and taken back on the way out (exact): a channel 2^-20 below its partner, or silent, comes out as if it had been
+// transformed alone.  `scale` multiplies the samples, `unscale` the outputs; a silent channel's `unscale` is zero (its
+// outputs are exactly the overlap it carries), a non-finite channel's is NaN (bit 0 / 1 of `dead`: its samples are taken
+// as zeros, and what it puts out -- this block and the overlap into the next -- is NaN like the reference's,
+// resampler_fft.rs:385-424 with a NaN anywhere in the block).  The level is the block's ENERGY per channel, summed by the
+// even chain's first pass, which has the whole block in registers (one packed multiply-add per sample); an energy that is
+// not finite -- a NaN, an infinity, or samples beyond 1e17 -- sends the block through the careful path (largest magnitude,
+// NaN / infinity told from large by a sum of products with zero).
+struct PairScale {
+    cf scale, unscale;
+    uint32_t dead;
+    // h = the power of two the channel's level is near: scale = 2^-h, unscale = 2^h (0 for a silent, NaN for a dead channel)
+    static __device__ __forceinline__ void pow2(int h, bool silent, bool is_dead, float* sc, float* un) {
+        h = h < -126 ? -126 : h > 126 ? 126 : h;
+        *sc = __builtin_bit_cast(float, (127 - h) << 23);
+        *un = is_dead ? __builtin_nanf("") : silent ? 0.f : __builtin_bit_cast(float, (127 + h) << 23);
+    }
+    // from the energies of the block's `log2n`-ish many samples (both finite)
+    __device__ __forceinline__ void from_energy(float el, float er, int log2n) {
+        auto h_of = [&](float e) { return (((__builtin_bit_cast(int, e) >> 23) & 0xff) - 127 - log2n) >> 1; };
+        float a, b, c, d2;
+        pow2(h_of(el), el == 0.f, false, &a, &b);
+        pow2(h_of(er), er == 0.f, false, &c, &d2);
+        scale = cf_make(a, c);
+        unscale = cf_make(b, d2);
+    }
+    // from the largest magnitudes (of the channels that are not dead)
+    __device__ __forceinline__ void from_max(float ml, float mr) {
+        auto h_of = [](float m) { return ((__builtin_bit_cast(int, m) >> 23) & 0xff) - 127; };
+        float a, b, c, d2;
+        pow2(h_of(ml), ml == 0.f, (dead & 1u) != 0, &a, &b);
+        pow2(h_of(mr), mr == 0.f, (dead & 2u) != 0, &c, &d2);
+        scale = cf_make(a, c);
+        unscale = cf_make(b, d2);
+    }
+    __device__ __forceinline__ cf kill(cf z) const {   // a dead channel's samples are zeros
+        return cf_make((dead & 1u) ? 0.f : z.x, (dead & 2u) ? 0.f : z.y);
+    }
+};
+struct PairPrep {
+    PairScale* ps;
+    template <int ITER, int K, int M> __device__ __forceinline__ void run(cf (&v)[ITER][K], int lane) const {
+        cf en = cf_make(0.f, 0.f);
+#pragma unroll
+        for (int it = 0; it < ITER; ++it)
+            if ((it + 1) * 64 <= M || lane + 64 * it < M)
+#pragma unroll
+                for (int k = 0; k < K; ++k) en = v[it][k] * v[it][k] + en;
+        const float el = wave_reduce<false>(en.x), er = wave_reduce<false>(en.y);
+        ps->dead = 0;
+        constexpr int kLog2N = 31 - __builtin_clz(static_cast<unsigned>(K * M));
+        if (__builtin_isfinite(el) && __builtin_isfinite(er)) {
+            ps->from_energy(el, er, kLog2N);
+        } else {   // (a wave-uniform branch next to nobody takes)
+            asm volatile("; a channel of this block is not finite, or beyond 1e17");
+            float ml = 0.f, mr = 0.f;
+            cf nf = cf_make(0.f, 0.f), zero = cf_make(0.f, 0.f);   // nf += v * 0: NaN from the first NaN or infinity of a channel on
+            asm volatile("" : "+v"(zero));
+#pragma unroll
+            for (int it = 0; it < ITER; ++it) {
+                if ((it + 1) * 64 <= M || lane + 64 * it < M) {
+#pragma unroll
+                    for (int k = 0; k < K; ++k) {
+                        ml = __builtin_fmaxf(ml, __builtin_fabsf(v[it][k].x));
+                        mr = __builtin_fmaxf(mr, __builtin_fabsf(v[it][k].y));
+                        nf = v[it][k] * zero + nf;
+                    }
+                }
+            }
+            const uint32_t dead = (__builtin_amdgcn_ballot_w64(nf.x != nf.x) != 0 ? 1u : 0u) | (__builtin_amdgcn_ballot_w64(nf.y != nf.y) != 0 ? 2u : 0u);
+            ps->dead = dead;
+#pragma unroll
+            for (int it = 0; it < ITER; ++it)
+#pragma unroll
+                for (int k = 0; k < K; ++k) v[it][k] = ps->kill(v[it][k]);
+            ps->from_max((dead & 1u) ? 0.f : wave_reduce<true>(ml), (dead & 2u) ? 0.f : wave_reduce<true>(mr));
+        }
+#pragma unroll
+        for (int it = 0; it < ITER; ++it)
+#pragma unroll
+            for (int k = 0; k < K; ++k) v[it][k] = v[it][k] * ps->scale;
+    }
+};
+
 // The last stage of a plan (stride = M: a butterfly's points are its own) with its outputs left in registers: butterfly
 // i = lane + 64 it yields o[it][q] = X[i + q M].  Every read is issued before the first butterfly (what follows overwrites
 // the buffer).  QS / IPP: where the stage's inputs lie (wave_stage).
@@ -241,18 +353,24 @@ __global__ __launch_bounds__(512, 1) void fft_ola_pair_kernel(FftPlanDev plan, c
         const GFloat2* xin = (const GFloat2*)(as_global(d.in) + static_cast<size_t>(b) * FI * 2);
         GFloat2* xout = (GFloat2*)(as_global(d.out) + static_cast<size_t>(b) * FO * 2);
         cf A[ITI][RLI];   // the even chain's outputs, kept while the odd chain runs
+        PairScale ps;
+        ps.dead = 0;
         static_for<0, 2>([&](auto par_c) {
             constexpr int par = decltype(par_c)::value;
             // ---- forward FI-point transform of z (even bins) or z w (odd bins)
             {
-                auto sample = [&](int j) -> cf {
-                    const f2 v = xin[j];
-                    cf z = cf_make(v.x, v.y);
-                    if constexpr (par == 1) z = cf_mul(lds_ld(chirp_w + j), z);
-                    return z;
+                auto first_pass = [&](auto&& smp, auto prep) {
+                    if constexpr (FWD::kFused) wave_fused_first<FI, FWD::kR[0], FWD::kR[1], FWD::kPadJ>(buf, tw_f + FWD::tab(1), lane, smp, prep);
+                    else wave_first<FI, FWD::kR[0], FWD::kPadJ>(buf, lane, smp, prep);
                 };
-                if constexpr (FWD::kFused) wave_fused_first<FI, FWD::kR[0], FWD::kR[1], FWD::kPadJ>(buf, tw_f + FWD::tab(1), lane, sample);
-                else wave_first<FI, FWD::kR[0], FWD::kPadJ>(buf, lane, sample);
+                if constexpr (par == 0) {
+                    first_pass([&](int j) -> cf { const f2 v = xin[j]; return cf_make(v.x, v.y); }, PairPrep{&ps});
+                } else if (ps.dead == 0) {
+                    first_pass([&](int j) -> cf { const f2 v = xin[j]; return cf_mul(lds_ld(chirp_w + j), cf_make(v.x, v.y) * ps.scale); }, NoPrep{});
+                } else {   // (a pass of its own for the block with a NaN in it: no select per sample in everybody's path)
+                    asm volatile("; a channel of this block is not finite");
+                    first_pass([&](int j) -> cf { const f2 v = xin[j]; return cf_mul(lds_ld(chirp_w + j), ps.kill(cf_make(v.x, v.y)) * ps.scale); }, NoPrep{});
+                }
             }
             RSMP_TR(6 * par + 0);
             static_for<(FWD::kFused ? 2 : 1), SF - 1>([&](auto s_c) {
@@ -344,10 +462,10 @@ __global__ __launch_bounds__(512, 1) void fft_ola_pair_kernel(FftPlanDev plan, c
                         for (int q = 0; q < RLI; ++q) {
                             const cf t = cf_mul(uv[it][q], B[it][q]);
                             if (emit) {
-                                const cf v = cf_conj_add_conj(A[it][q] + t, carry[it][q]);
+                                const cf v = cf_conj_scale_add_conj(A[it][q] + t, ps.unscale, carry[it][q]);
                                 xout[i + q * MI] = f2{v.x, v.y};
                             }
-                            carry[it][q] = A[it][q] - t;
+                            carry[it][q] = (A[it][q] - t) * ps.unscale;
                         }
                     }
                 }

@@ -262,8 +262,14 @@ __device__ __forceinline__ void static_for(F&& f) {
 // (the zero padding of the forward transform: resampler_fft.rs:387-388).  Butterfly q' takes the points
 // j + M2 (q' + RB q): the last NZ of its RA inputs are padding for every j (pdft_tail).
 // PADJ: one value of padding after every PADJ units (WavePlan::kPadJ; 0 = none).
-template <int N, int RA, int RB, int PADJ, int NVALID = N, class Load>
-__device__ __forceinline__ void wave_fused_first(cf* dst, const cf* __restrict__ tw1, int lane, Load load) {
+// `prep` sees a first pass's inputs between their loads and the first butterfly: run<ITER, K, M>(values, lane) with K values
+// for each of the lane's ITER units (unit lane + 64 it exists while below M); it may change them (fft_pair.hip: the block's
+// two channels are scaled to a common level there).
+struct NoPrep {
+    template <int ITER, int K, int M> __device__ __forceinline__ void run(cf (&)[ITER][K], int) const {}
+};
+template <int N, int RA, int RB, int PADJ, int NVALID = N, class Load, class Prep = NoPrep>
+__device__ __forceinline__ void wave_fused_first(cf* dst, const cf* __restrict__ tw1, int lane, Load load, Prep prep = Prep()) {
     constexpr int M2 = N / (RA * RB);
     constexpr int ITER = (M2 + 63) / 64;
     cf s[ITER][RB][RA];
@@ -278,6 +284,10 @@ __device__ __forceinline__ void wave_fused_first(cf* dst, const cf* __restrict__
                 });
             });
         }
+    }
+    if constexpr (!std::is_same<Prep, NoPrep>::value) {
+        static_assert(NVALID == N, "prep sees every input");
+        prep.template run<ITER, RB * RA, M2>(reinterpret_cast<cf (&)[ITER][RB * RA]>(s), lane);
     }
     cf w1[RA][RB];   // (the same for every lane: broadcast reads, fetched with the data)
 #pragma unroll
@@ -318,8 +328,8 @@ __device__ __forceinline__ void wave_fused_first(cf* dst, const cf* __restrict__
 // Stage 0 alone (stride 1, no twiddles) for the plans that do not fuse it with stage 1: butterfly i takes the
 // points i + q N / R through `load` (LDS, or samples straight from HBM; points at index >= NVALID are zero) and
 // writes R i + q.
-template <int N, int R, int PADJ, int NVALID = N, class Load>
-__device__ __forceinline__ void wave_first(cf* dst, int lane, Load load) {
+template <int N, int R, int PADJ, int NVALID = N, class Load, class Prep = NoPrep>
+__device__ __forceinline__ void wave_first(cf* dst, int lane, Load load, Prep prep = Prep()) {
     constexpr int M = N / R;
     constexpr int ITER = (M + 63) / 64;
     constexpr int first_zero = (NVALID + M - 1) / M;            // inputs q >= first_zero are zero for every i
@@ -332,6 +342,10 @@ __device__ __forceinline__ void wave_first(cf* dst, int lane, Load load) {
 #pragma unroll
             for (int q = 0; q < R - NZ; ++q) t[it][q] = load(i + q * M);
         }
+    }
+    if constexpr (!std::is_same<Prep, NoPrep>::value) {
+        static_assert(NVALID == N, "prep sees every input");
+        prep.template run<ITER, R, M>(t, lane);
     }
     lds_order();
 #pragma unroll

@@ -13,7 +13,7 @@ SOURCES = {
     "fir": _FIR,
     "c5": _FIR,
     "c4": _FIR + ["fir_lockstep.hip", "fir_lockstep_run.hip", "fir_lockstep.h", "fir_mirror_core.h", "fir_mirror_fast.h"],
-    "fft": ["fft_wave.hip", "fft_kernels.hip", "fft_kernels.h", "fft_butterflies.h", "fft_butterflies_pk.h"],
+    "fft": ["fft_pair.hip", "fft_wave.hip", "fft_wave_core.h", "fft_kernels.hip", "fft_kernels.h", "fft_butterflies.h", "fft_butterflies_pk.h"],
 }
 
 

@@ -153,6 +153,73 @@ def test_bulk_equals_consecutive_calls(ch, in_hz, out_hz, blocks):
     assert float(np.max(np.abs(y - ref[3:].reshape(-1)))) < 1e-5
 
 
+def _oracle_blocks(in_hz, out_hz, x, blocks):
+    r = o.OracleFft(2, in_hz, out_hz)
+    n_in, n_out = r.chunk_size_input(), r.chunk_size_output()
+    ref = np.zeros((blocks, n_out), np.float32)
+    for b in range(blocks):
+        assert r.resample(x[b * n_in:(b + 1) * n_in], ref[b]) == 0
+    return ref.reshape(-1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("in_hz,out_hz", [(44100, 48000), (48000, 44100)])
+@pytest.mark.parametrize("quiet_exp", [12, 20, 30])
+def test_channels_of_a_two_channel_stream_at_very_different_levels(in_hz, out_hz, quiet_exp):
+    """The reference transforms every channel on its own (resampler_fft.rs:182-240), so a quiet channel's error is relative to
+    ITS level.  The two-channel kernel (fft_pair.hip) runs both channels through the same butterflies as one complex signal:
+    every channel of every block is brought to a common level first, and each must stay within the gate of its own RMS."""
+    g = ra.ResamplerFft.new(2, sr(in_hz), sr(out_hz))
+    n_in = g.chunk_size_input()
+    blocks = 40
+    x = synth.fast_noise(blocks * n_in, seed=quiet_exp).copy()
+    for quiet in (0, 1):
+        xx = x.copy()
+        xx[quiet::2] *= np.float32(2.0 ** -quiet_exp)
+        # (the quiet channel wanders through the levels: a block that is louder than its neighbours, a silent block)
+        fr = n_in // 2
+        xx[quiet + 2 * 7 * fr:2 * 8 * fr:2] *= np.float32(2.0 ** 9)
+        xx[quiet + 2 * 11 * fr:2 * 12 * fr:2] = 0.0
+        ref = _oracle_blocks(in_hz, out_hz, xx, blocks)
+        y = g.resample_bulk(xx, blocks)
+        g = ra.ResamplerFft.new(2, sr(in_hz), sr(out_hz))
+        for c in (0, 1):
+            level = float(np.sqrt(np.mean(ref[c::2].astype(np.float64) ** 2)))
+            assert rms(y[c::2], ref[c::2]) <= RMS_TOL * level, (quiet, c, rms(y[c::2], ref[c::2]) / level)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("in_hz,out_hz", [(44100, 48000), (48000, 44100)])
+def test_a_silent_channel_stays_silent_and_a_nan_stays_in_its_channel(in_hz, out_hz):
+    g = ra.ResamplerFft.new(2, sr(in_hz), sr(out_hz))
+    n_in, n_out = g.chunk_size_input(), g.chunk_size_output()
+    blocks = 12
+    x = synth.fast_noise(blocks * n_in, seed=5).copy()
+    x[1::2] = 0.0
+    y = g.resample_bulk(x, blocks)
+    assert np.all(y[1::2] == 0.0)                                   # zeros in, zeros out: nothing of channel 0 leaks over
+    ref = _oracle_blocks(in_hz, out_hz, x, blocks)
+    assert rms(y[0::2], ref[0::2]) <= RMS_TOL
+    # one NaN and one infinity in channel 1: that channel's block and the next (its overlap) are NaN like the reference's,
+    # channel 0 does not notice
+    g = ra.ResamplerFft.new(2, sr(in_hz), sr(out_hz))
+    x = synth.fast_noise(blocks * n_in, seed=6).copy()
+    x[1 + 2 * (3 * (n_in // 2) + 17)] = np.nan
+    x[1 + 2 * (8 * (n_in // 2) + 5)] = np.inf
+    with np.errstate(invalid="ignore", over="ignore"):
+        ref = _oracle_blocks(in_hz, out_hz, x, blocks)
+    y = g.resample_bulk(x, blocks)
+    assert rms(y[0::2], ref[0::2]) <= RMS_TOL
+    bad = np.zeros(blocks, bool)
+    bad[[3, 4, 8, 9]] = True
+    for b in range(blocks):
+        yb, rb = y[b * n_out + 1:(b + 1) * n_out:2], ref[b * n_out + 1:(b + 1) * n_out:2]
+        if bad[b]:
+            assert not np.any(np.isfinite(rb)) and not np.any(np.isfinite(yb)), b
+        else:
+            assert np.all(np.isfinite(yb)) and rms(yb, rb) <= RMS_TOL, b
+
+
 @pytest.mark.gpu
 def test_c3_full_size_and_batch_device_api():
     torch = pytest.importorskip("torch")
