@@ -57,7 +57,7 @@ hipError_t launch_fft_ola_wave(const FftPlanDev& plan, const FftStreamDesc* d_de
 // One wave per two-channel stream, the frame (L, R) as the complex sample L + i R (fft_pair.hip); hipErrorNotSupported for
 // the plans it is not instantiated for.
 hipError_t launch_fft_ola_pair(const FftPlanDev& plan, const FftStreamDesc* d_descs, uint32_t n_streams, uint32_t max_blocks,
-                               hipStream_t stream);
+                               hipStream_t stream, uint32_t pcm_bits = 0);
 // Whether this library's wave kernels are the operation-for-operation build (libresampler_amd_fftexact.so).
 bool fft_wave_is_exact();
 // filter_spectrum[0 .. fft_in] = forward real FFT of d_filter_time[0 .. 2*fft_in)

@@ -248,7 +248,10 @@ struct PairBins {
     }
 };
 
-template <class FWD, class INV>
+// BITS: 0 = f32 frames; 16 / 24 / 32 = little-endian WAV PCM frames of that width, converted where they are loaded
+// exactly as resample/src/main.rs:128-137 converts a sample (`sample as f32 / (1 << (bits - 1)) as f32`, the 32-bit divisor
+// an i32 literal = -2^31): bit for bit what rsmp_pcm_to_stereo_f32_device + the f32 launch give.
+template <class FWD, class INV, int BITS>
 __global__ __launch_bounds__(512, 1) void fft_ola_pair_kernel(FftPlanDev plan, const FftStreamDesc* __restrict__ descs,
                                                               uint32_t run_long, uint32_t run_short, uint32_t pairs_per_stream,
                                                               uint32_t total_waves) {
@@ -350,7 +353,32 @@ __global__ __launch_bounds__(512, 1) void fft_ola_pair_kernel(FftPlanDev plan, c
 
     for (int64_t b = b_begin; b < static_cast<int64_t>(last); ++b) {
         const bool emit = b >= static_cast<int64_t>(first);
-        const GFloat2* xin = (const GFloat2*)(as_global(d.in) + static_cast<size_t>(b) * FI * 2);
+        // frame j of the block as the complex sample (channel 0, channel 1)
+        typedef __attribute__((address_space(1))) uint32_t GU32;
+        typedef uint32_t u2v __attribute__((ext_vector_type(2)));
+        typedef __attribute__((address_space(1))) u2v GU2;
+        const __attribute__((address_space(1))) char* xraw = (const __attribute__((address_space(1))) char*)d.in +
+                                                             static_cast<size_t>(b) * FI * (BITS == 0 ? 8 : 2 * (BITS / 8));
+        auto frame = [&](int j) -> cf {
+            if constexpr (BITS == 0) {
+                const f2 v = ((const GFloat2*)xraw)[j];
+                return cf_make(v.x, v.y);
+            } else if constexpr (BITS == 16) {
+                const uint32_t w = ((const GU32*)xraw)[j];
+                return cf_make(static_cast<float>(static_cast<int32_t>(w << 16) >> 16), static_cast<float>(static_cast<int32_t>(w) >> 16)) * (1.0f / 32768.0f);
+            } else if constexpr (BITS == 24) {   // six bytes at an even address: the eight bytes at the word boundary below it
+                typedef u2v __attribute__((address_space(1), aligned(4))) GU2a4;
+                const uint32_t byte = 6u * static_cast<uint32_t>(j);
+                const u2v w = *(const GU2a4*)(xraw + (byte & ~3u));
+                const bool odd = (byte & 2u) != 0;
+                const uint32_t a = odd ? (w.x >> 16) | (w.y << 16) : w.x;
+                const uint32_t c = odd ? w.y >> 8 : (w.x >> 24) | (w.y << 8);
+                return cf_make(static_cast<float>(static_cast<int32_t>(a << 8) >> 8), static_cast<float>(static_cast<int32_t>(c << 8) >> 8)) * (1.0f / 8388608.0f);
+            } else {
+                const u2v w = ((const GU2*)xraw)[j];
+                return cf_make(static_cast<float>(static_cast<int32_t>(w.x)), static_cast<float>(static_cast<int32_t>(w.y))) * (-1.0f / 2147483648.0f);
+            }
+        };
         GFloat2* xout = (GFloat2*)(as_global(d.out) + static_cast<size_t>(b) * FO * 2);
         cf A[ITI][RLI];   // the even chain's outputs, kept while the odd chain runs
         PairScale ps;
@@ -364,12 +392,12 @@ __global__ __launch_bounds__(512, 1) void fft_ola_pair_kernel(FftPlanDev plan, c
                     else wave_first<FI, FWD::kR[0], FWD::kPadJ>(buf, lane, smp, prep);
                 };
                 if constexpr (par == 0) {
-                    first_pass([&](int j) -> cf { const f2 v = xin[j]; return cf_make(v.x, v.y); }, PairPrep{&ps});
+                    first_pass(frame, PairPrep{&ps});
                 } else if (ps.dead == 0) {
-                    first_pass([&](int j) -> cf { const f2 v = xin[j]; return cf_mul(lds_ld(chirp_w + j), cf_make(v.x, v.y) * ps.scale); }, NoPrep{});
+                    first_pass([&](int j) -> cf { return cf_mul(lds_ld(chirp_w + j), frame(j) * ps.scale); }, NoPrep{});
                 } else {   // (a pass of its own for the block with a NaN in it: no select per sample in everybody's path)
                     asm volatile("; a channel of this block is not finite");
-                    first_pass([&](int j) -> cf { const f2 v = xin[j]; return cf_mul(lds_ld(chirp_w + j), ps.kill(cf_make(v.x, v.y)) * ps.scale); }, NoPrep{});
+                    first_pass([&](int j) -> cf { return cf_mul(lds_ld(chirp_w + j), ps.kill(frame(j)) * ps.scale); }, NoPrep{});
                 }
             }
             RSMP_TR(6 * par + 0);
@@ -510,13 +538,14 @@ typedef WavePlan<1280, 4, 5, 8, 8> W1280;   // 48 kHz side
 typedef void (*PairKernel)(FftPlanDev, const FftStreamDesc*, uint32_t, uint32_t, uint32_t, uint32_t);
 
 template <class FWD, class INV>
-bool pair_choice(const FftPlanDev& plan, PairKernel* fn, size_t* lds) {
+bool pair_choice(const FftPlanDev& plan, uint32_t pcm_bits, PairKernel* fn, size_t* lds) {
     if (!FWD::matches(plan.fft_in, plan.n_stages_f, plan.radix_f) || !INV::matches(plan.fft_out, plan.n_stages_i, plan.radix_i))
         return false;
     constexpr size_t buf = FWD::kBuf > INV::kBuf ? FWD::kBuf : INV::kBuf;
     constexpr size_t tables = static_cast<size_t>(FWD::kTw + INV::kTw + PairBins<FWD::N, INV::N>::kNL + FWD::N + INV::N);
     static_assert((tables + 8 * buf) * sizeof(cf) <= 160 * 1024, "LDS");
-    *fn = fft_ola_pair_kernel<FWD, INV>;
+    *fn = pcm_bits == 16 ? fft_ola_pair_kernel<FWD, INV, 16> : pcm_bits == 24 ? fft_ola_pair_kernel<FWD, INV, 24>
+          : pcm_bits == 32 ? fft_ola_pair_kernel<FWD, INV, 32> : fft_ola_pair_kernel<FWD, INV, 0>;
     *lds = (tables + 8 * buf) * sizeof(cf);
     return true;
 }
@@ -526,12 +555,13 @@ bool pair_choice(const FftPlanDev& plan, PairKernel* fn, size_t* lds) {
 // One wave per two-channel stream and run of blocks.  hipErrorNotSupported when the plan is not one of the pairs above
 // (the caller then uses the wave-per-channel kernels).
 hipError_t launch_fft_ola_pair(const FftPlanDev& plan, const FftStreamDesc* d_descs, uint32_t n_streams, uint32_t max_blocks,
-                               hipStream_t stream) {
+                               hipStream_t stream, uint32_t pcm_bits) {
+    if (pcm_bits != 0 && pcm_bits != 16 && pcm_bits != 24 && pcm_bits != 32) return hipErrorNotSupported;
     if (plan.chirp_f == nullptr || plan.chirp_i == nullptr) return hipErrorNotSupported;
     if (plan.new_length != (plan.fft_in < plan.fft_out ? plan.fft_in + 1 : plan.fft_out)) return hipErrorNotSupported;
     PairKernel fn = nullptr;
     size_t lds = 0;
-    if (!pair_choice<W1176, W1280>(plan, &fn, &lds) && !pair_choice<W1280, W1176>(plan, &fn, &lds)) return hipErrorNotSupported;
+    if (!pair_choice<W1176, W1280>(plan, pcm_bits, &fn, &lds) && !pair_choice<W1280, W1176>(plan, pcm_bits, &fn, &lds)) return hipErrorNotSupported;
     // Pairs of runs per stream: every run after a stream's first recomputes its predecessor block (1 / run extra work), and
     // the launch ends with a partly filled round unless the number of waves is close to a multiple of what the chip holds
     // (8 per CU).  Of a pair's blocks the old wave takes kLongShare (its share of a SIMD while both waves run).
