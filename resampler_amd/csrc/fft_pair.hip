@@ -251,12 +251,19 @@ struct PairBins {
 // BITS: 0 = f32 frames; 16 / 24 / 32 = little-endian WAV PCM frames of that width, converted where they are loaded
 // exactly as resample/src/main.rs:128-137 converts a sample (`sample as f32 / (1 << (bits - 1)) as f32`, the 32-bit divisor
 // an i32 literal = -2^31): bit for bit what rsmp_pcm_to_stereo_f32_device + the f32 launch give.
+// Waves per CU: eight (two per SIMD, an old and a young one) where the LDS holds the tables and eight buffers, else four.
+template <class FWD, class INV>
+constexpr int pair_waves() {
+    constexpr size_t buf = FWD::kBuf > INV::kBuf ? FWD::kBuf : INV::kBuf;
+    constexpr size_t tables = static_cast<size_t>(FWD::kTw + INV::kTw + PairBins<FWD::N, INV::N>::kNL + FWD::N + INV::N);
+    return (tables + 8 * buf) * sizeof(cf) <= 160 * 1024 ? 8 : (tables + 4 * buf) * sizeof(cf) <= 160 * 1024 ? 4 : 0;
+}
 template <class FWD, class INV, int BITS>
-__global__ __launch_bounds__(512, 1) void fft_ola_pair_kernel(FftPlanDev plan, const FftStreamDesc* __restrict__ descs,
+__global__ __launch_bounds__((pair_waves<FWD, INV>() ? pair_waves<FWD, INV>() : 4) * 64, 1) void fft_ola_pair_kernel(FftPlanDev plan, const FftStreamDesc* __restrict__ descs,
                                                               uint32_t run_long, uint32_t run_short, uint32_t pairs_per_stream,
                                                               uint32_t total_waves) {
     extern __shared__ __attribute__((aligned(16))) cf lds2[];
-    constexpr int kWaves = 8;
+    constexpr int kWaves = pair_waves<FWD, INV>() ? pair_waves<FWD, INV>() : 4;
     constexpr int FI = FWD::N, FO = INV::N;
     typedef PairBins<FI, FO> Bins;
     constexpr int NL = Bins::kNL;
@@ -298,7 +305,7 @@ __global__ __launch_bounds__(512, 1) void fft_ola_pair_kernel(FftPlanDev plan, c
         copy(tab + kTabU, reinterpret_cast<const cf*>(plan.chirp_i), FO);
     }
     __syncthreads();
-    if ((blockIdx.x * 4u + (wave & 3u)) * 2u >= total_waves) return;   // (a pair beyond the launch's last)
+    if ((blockIdx.x * 4u + (wave & 3u)) * static_cast<uint32_t>(kWaves / 4) >= total_waves) return;   // (a pair beyond the launch's last)
 #ifdef RSMP_FFT_TRACE
     const unsigned long long tr_t0 = wall_clock64();
     unsigned long long tr_ph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -316,6 +323,7 @@ __global__ __launch_bounds__(512, 1) void fft_ola_pair_kernel(FftPlanDev plan, c
     // their gaps, and with equal runs the launch ended with one wave per SIMD for its last quarter (tools/fft_trace.py:
     // ends at 323 / 429 us; evening the two out by priority gave nothing -- two equals get in each other's way).  So a
     // stream is cut into PAIRS of runs, a long one for an old wave and a short one for a young wave.
+    // (four waves per CU: one per SIMD, every run a long one)
     const uint32_t kind = wave >> 2;                                  // 0: old wave, long run; 1: young wave, short run
     const uint32_t pair_idx = blockIdx.x * 4u + (wave & 3u);
     const uint32_t stream_idx = pair_idx / pairs_per_stream;
@@ -534,20 +542,48 @@ __global__ __launch_bounds__(512, 1) void fft_ola_pair_kernel(FftPlanDev plan, c
 
 typedef WavePlan<1176, 3, 7, 7, 8> W1176;   // 44.1 kHz side of the 44.1 <-> 48 kHz family
 typedef WavePlan<1280, 4, 5, 8, 8> W1280;   // 48 kHz side
+// (the other plans of up to 2048 points, as in fft_wave.hip)
+typedef WavePlan<512, 8, 8, 8> W512;
+typedef WavePlan<1024, 2, 8, 8, 8> W1024;
+typedef WavePlan<256, 4, 8, 8> W256;
+typedef WavePlan<128, 2, 8, 8> W128;
+typedef WavePlan<64, 8, 8> W64;
+typedef WavePlan<768, 3, 4, 8, 8> W768;
+typedef WavePlan<1536, 3, 8, 8, 8> W1536;
+typedef WavePlan<588, 3, 4, 7, 7> W588;
+typedef WavePlan<882, 2, 3, 3, 7, 7> W882;
+typedef WavePlan<1764, 3, 3, 4, 7, 7> W1764;
+typedef WavePlan<640, 2, 5, 8, 8> W640;
 
 typedef void (*PairKernel)(FftPlanDev, const FftStreamDesc*, uint32_t, uint32_t, uint32_t, uint32_t);
 
+struct PairChoice {
+    PairKernel fn = nullptr;
+    size_t lds = 0;
+    uint32_t waves = 0;   // per workgroup = per CU
+};
 template <class FWD, class INV>
-bool pair_choice(const FftPlanDev& plan, uint32_t pcm_bits, PairKernel* fn, size_t* lds) {
+bool pair_choice(const FftPlanDev& plan, uint32_t pcm_bits, PairChoice* out) {
     if (!FWD::matches(plan.fft_in, plan.n_stages_f, plan.radix_f) || !INV::matches(plan.fft_out, plan.n_stages_i, plan.radix_i))
         return false;
-    constexpr size_t buf = FWD::kBuf > INV::kBuf ? FWD::kBuf : INV::kBuf;
-    constexpr size_t tables = static_cast<size_t>(FWD::kTw + INV::kTw + PairBins<FWD::N, INV::N>::kNL + FWD::N + INV::N);
-    static_assert((tables + 8 * buf) * sizeof(cf) <= 160 * 1024, "LDS");
-    *fn = pcm_bits == 16 ? fft_ola_pair_kernel<FWD, INV, 16> : pcm_bits == 24 ? fft_ola_pair_kernel<FWD, INV, 24>
-          : pcm_bits == 32 ? fft_ola_pair_kernel<FWD, INV, 32> : fft_ola_pair_kernel<FWD, INV, 0>;
-    *lds = (tables + 8 * buf) * sizeof(cf);
-    return true;
+    constexpr int waves = pair_waves<FWD, INV>();
+    if constexpr (waves == 0) {
+        (void)pcm_bits; (void)out;
+        return false;
+    } else {
+        constexpr size_t buf = FWD::kBuf > INV::kBuf ? FWD::kBuf : INV::kBuf;
+        constexpr size_t tables = static_cast<size_t>(FWD::kTw + INV::kTw + PairBins<FWD::N, INV::N>::kNL + FWD::N + INV::N);
+        out->fn = pcm_bits == 16 ? fft_ola_pair_kernel<FWD, INV, 16> : pcm_bits == 24 ? fft_ola_pair_kernel<FWD, INV, 24>
+                  : pcm_bits == 32 ? fft_ola_pair_kernel<FWD, INV, 32> : fft_ola_pair_kernel<FWD, INV, 0>;
+        out->lds = (tables + waves * buf) * sizeof(cf);
+        out->waves = waves;
+        return true;
+    }
+}
+
+template <class FWD, class... INVS>
+bool pair_choices(const FftPlanDev& plan, uint32_t pcm_bits, PairChoice* out) {
+    return (pair_choice<FWD, INVS>(plan, pcm_bits, out) || ...);
 }
 
 }  // namespace
@@ -559,39 +595,51 @@ hipError_t launch_fft_ola_pair(const FftPlanDev& plan, const FftStreamDesc* d_de
     if (pcm_bits != 0 && pcm_bits != 16 && pcm_bits != 24 && pcm_bits != 32) return hipErrorNotSupported;
     if (plan.chirp_f == nullptr || plan.chirp_i == nullptr) return hipErrorNotSupported;
     if (plan.new_length != (plan.fft_in < plan.fft_out ? plan.fft_in + 1 : plan.fft_out)) return hipErrorNotSupported;
-    PairKernel fn = nullptr;
-    size_t lds = 0;
-    if (!pair_choice<W1176, W1280>(plan, pcm_bits, &fn, &lds) && !pair_choice<W1280, W1176>(plan, pcm_bits, &fn, &lds)) return hipErrorNotSupported;
+    PairChoice pc;
+    const bool found = pair_choice<W1176, W1280>(plan, pcm_bits, &pc) || pair_choice<W1280, W1176>(plan, pcm_bits, &pc)
+#if RSMP_EXP != 0   // (timing experiments instantiate the 44.1 <-> 48 kHz pair alone)
+                       ;
+#else
+                       // (by tools/fft_pairs_bench.py, both kernels in one lease -- profiles/r05/fft_pairs_pair_vs_wave.txt: the
+                       // down-sampling pairs gain 8 - 21 %, 512 -> 1024 frames 4 %; a 1764-point inverse, 512 -> 1536 / 2048,
+                       // 768 -> 256 / 512, 882 -> 1280 and 1764 -> 1280 frames spill or run four waves and stay with fft_wave.hip)
+                       || pair_choices<W512, W64, W128, W256, W768, W1024>(plan, pcm_bits, &pc) || pair_choices<W768, W64, W128>(plan, pcm_bits, &pc) ||
+                       pair_choices<W1536, W64, W128>(plan, pcm_bits, &pc) || pair_choices<W588, W1280>(plan, pcm_bits, &pc) ||
+                       pair_choices<W882, W640>(plan, pcm_bits, &pc) || pair_choices<W1764, W640>(plan, pcm_bits, &pc) ||
+                       pair_choices<W640, W882>(plan, pcm_bits, &pc) || pair_choices<W1280, W588, W882>(plan, pcm_bits, &pc);
+#endif
+    if (!found) return hipErrorNotSupported;
     // Pairs of runs per stream: every run after a stream's first recomputes its predecessor block (1 / run extra work), and
     // the launch ends with a partly filled round unless the number of waves is close to a multiple of what the chip holds
     // (8 per CU).  Of a pair's blocks the old wave takes kLongShare (its share of a SIMD while both waves run).
     int dev = 0, cus = 256;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    const double slots = static_cast<double>(cus) * 8;
+    const uint32_t classes = pc.waves / 4;   // waves per SIMD: 2 (an old and a young one), or 1
+    const double slots = static_cast<double>(cus) * pc.waves;
     static const double share_knob = [] { const char* e = rsmp::knob("RSMP_FFT_PAIR_SHARE"); return e ? atof(e) : 0.0; }();   // A/B
-    const double kLongShare = share_knob > 0.0 && share_knob < 1.0 ? share_knob : 0.6;
+    const double kLongShare = classes == 1 ? 1.0 : share_knob > 0.0 && share_knob < 1.0 ? share_knob : 0.6;
     uint32_t both = 32;
     double best = -1.0;
-    for (uint32_t cand = 12; cand <= 128; ++cand) {   // blocks of a pair
+    for (uint32_t cand = 6 * classes; cand <= 64 * classes; ++cand) {   // blocks of a pair
         const double pairs = static_cast<double>((max_blocks + cand - 1) / cand);
-        const double waves = 2.0 * pairs * n_streams;
+        const double waves = classes * pairs * n_streams;
         const double rounds = std::ceil(waves / slots);
-        const double useful = static_cast<double>(max_blocks) / (max_blocks + 2.0 * pairs - 1.0);   // halo blocks
+        const double useful = static_cast<double>(max_blocks) / (max_blocks + classes * pairs - 1.0);   // halo blocks
         const double score = waves / (rounds * slots) * useful;
         if (score > best + 1e-9) { best = score; both = cand; }
     }
     const uint32_t pairs_per_stream = (max_blocks + both - 1) / both;
     // (the halo block is part of a wave's work: the shares are of both + 2)
-    uint32_t run_long = static_cast<uint32_t>(std::lround(kLongShare * (both + 2.0) - 1.0));
+    uint32_t run_long = classes == 1 ? both : static_cast<uint32_t>(std::lround(kLongShare * (both + 2.0) - 1.0));
     if (run_long > both) run_long = both;
     if (run_long < 1) run_long = 1;
     const uint32_t run_short = both - run_long;
-    const uint32_t total_waves = pairs_per_stream * n_streams * 2;
-    const dim3 grid((total_waves + 7) / 8);
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    const uint32_t total_waves = pairs_per_stream * n_streams * classes;
+    const dim3 grid((total_waves + pc.waves - 1) / pc.waves);
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pc.fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(fn, grid, dim3(512), lds, stream, plan, d_descs, run_long, run_short, pairs_per_stream, total_waves);
+    hipLaunchKernelGGL(pc.fn, grid, dim3(pc.waves * 64), pc.lds, stream, plan, d_descs, run_long, run_short, pairs_per_stream, total_waves);
     return hipGetLastError();
 }
 
