@@ -387,6 +387,17 @@ __global__ __launch_bounds__((pair_waves<FWD, INV>() ? pair_waves<FWD, INV>() : 
                 return cf_make(static_cast<float>(static_cast<int32_t>(w.x)), static_cast<float>(static_cast<int32_t>(w.y))) * (-1.0f / 2147483648.0f);
             }
         };
+        // (the odd chain's read is the samples' last: non-temporal, like the output stores -- HBM traffic 1.19x -> 1.05x
+        // algorithmic with both, profiles/r05/fft_traffic_nt.txt)
+        auto frame_last = [&](int j) -> cf {
+#if !(RSMP_FEAT & 2)
+            if constexpr (BITS == 0) {
+                const f2 v = __builtin_nontemporal_load((const GFloat2*)xraw + j);
+                return cf_make(v.x, v.y);
+            } else
+#endif
+            return frame(j);
+        };
         GFloat2* xout = (GFloat2*)(as_global(d.out) + static_cast<size_t>(b) * FO * 2);
         cf A[ITI][RLI];   // the even chain's outputs, kept while the odd chain runs
         PairScale ps;
@@ -402,10 +413,10 @@ __global__ __launch_bounds__((pair_waves<FWD, INV>() ? pair_waves<FWD, INV>() : 
                 if constexpr (par == 0) {
                     first_pass(frame, PairPrep{&ps});
                 } else if (ps.dead == 0) {
-                    first_pass([&](int j) -> cf { return cf_mul(lds_ld(chirp_w + j), frame(j) * ps.scale); }, NoPrep{});
+                    first_pass([&](int j) -> cf { return cf_mul(lds_ld(chirp_w + j), frame_last(j) * ps.scale); }, NoPrep{});
                 } else {   // (a pass of its own for the block with a NaN in it: no select per sample in everybody's path)
                     asm volatile("; a channel of this block is not finite");
-                    first_pass([&](int j) -> cf { return cf_mul(lds_ld(chirp_w + j), ps.kill(frame(j)) * ps.scale); }, NoPrep{});
+                    first_pass([&](int j) -> cf { return cf_mul(lds_ld(chirp_w + j), ps.kill(frame_last(j)) * ps.scale); }, NoPrep{});
                 }
             }
             RSMP_TR(6 * par + 0);
@@ -499,7 +510,13 @@ __global__ __launch_bounds__((pair_waves<FWD, INV>() ? pair_waves<FWD, INV>() : 
                             const cf t = cf_mul(uv[it][q], B[it][q]);
                             if (emit) {
                                 const cf v = cf_conj_scale_add_conj(A[it][q] + t, ps.unscale, carry[it][q]);
+                                // (non-temporal: the output does not push the block's samples out of L2 before the odd chain reads
+                                // them again -- HBM reads 1.34x -> 1.11x the input, profiles/r05/fft_traffic_nt.txt; the time is the same)
+#if RSMP_FEAT & 1
                                 xout[i + q * MI] = f2{v.x, v.y};
+#else
+                                __builtin_nontemporal_store(f2{v.x, v.y}, xout + i + q * MI);
+#endif
                             }
                             carry[it][q] = (A[it][q] - t) * ps.unscale;
                         }
