@@ -277,6 +277,7 @@ __global__ __launch_bounds__((pair_waves<FWD, INV>() ? pair_waves<FWD, INV>() : 
     (void)gw;
     // tables, once per workgroup: stage twiddles (rows re-spaced as the stages read them), the filter bins in use, and
     // the two chirps w (FI values) and u (FO values)
+    constexpr int kFilterEven = (NL + 1) / 2;   // even bins 0, 2, ..
     constexpr int kTabF = 0, kTabI = kTabF + FWD::kTw, kTabFilter = kTabI + INV::kTw, kTabW = kTabFilter + NL,
                   kTabU = kTabW + FI, kTabEnd = kTabU + FO;
     cf* tab = lds2;
@@ -300,7 +301,10 @@ __global__ __launch_bounds__((pair_waves<FWD, INV>() ? pair_waves<FWD, INV>() : 
         };
         stage_tables(tab + kTabF, reinterpret_cast<const cf*>(plan.tw_f), FWD{});
         stage_tables(tab + kTabI, reinterpret_cast<const cf*>(plan.tw_i), INV{});
-        copy(tab + kTabFilter, reinterpret_cast<const cf*>(plan.filter), NL);
+        // (the filter bins a chain multiplies are every other one: kept by parity -- even bins, then odd bins -- so that a
+        // chain's lanes read neighbouring values, not every second one: two lanes per bank pair otherwise)
+        for (int i = threadIdx.x; i < NL; i += kWaves * 64)
+            tab[kTabFilter + (i & 1) * kFilterEven + (i >> 1)] = reinterpret_cast<const cf*>(plan.filter)[i];
         copy(tab + kTabW, reinterpret_cast<const cf*>(plan.chirp_f), FI);
         copy(tab + kTabU, reinterpret_cast<const cf*>(plan.chirp_i), FO);
     }
@@ -436,8 +440,9 @@ __global__ __launch_bounds__((pair_waves<FWD, INV>() ? pair_waves<FWD, INV>() : 
 #pragma unroll
                         for (int q = 0; q < RLF; ++q) {
                             const int k = 2 * (i + q * MF) + par;
-                            const int hi = k <= Bins::kPosMax ? k : 2 * FI - k;
-                            hv[it][q] = lds_ld(filter + (hi < NL ? hi : NL - 1));
+                            const int hi = k <= Bins::kPosMax ? k : 2 * FI - k;   // (of the chain's parity either way)
+                            const int hc = hi < NL ? hi : NL - 1 - ((NL - 1 - par) & 1);
+                            hv[it][q] = lds_ld(filter + par * kFilterEven + (hc >> 1));
                         }
                     }
                 }
