@@ -22,6 +22,8 @@ FIR = [("RSMP_FIR_SPLIT_LONG", "0", "2 96000 44100 2 48000 96000"),
 FFT = [("RSMP_FFT_WAVE_NOC2", "1", "44100 48000 2 25 44100 48000 4 20"),
        ("RSMP_FFT_WAVE_WIDE", "3", "22050 96000 2 12 88200 96000 2 12"),
        ("RSMP_FFT_WAVE", "0", "44100 48000 2 25"),
+       ("RSMP_FFT_PAIR", "0", "44100 48000 2 25"),        # two-channel streams on the wave-per-channel kernel
+       ("RSMP_FFT_PAIR_SHARE", "0.5", "48000 44100 2 40"),  # equal runs for a SIMD's old and young wave
        ("RSMP_FFT_GENERIC", "1", "44100 48000 2 25")]
 
 
