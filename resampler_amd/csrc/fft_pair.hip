@@ -117,8 +117,9 @@ __device__ __forceinline__ float wave_reduce(float v) {
 // as zeros, and what it puts out -- this block and the overlap into the next -- is NaN like the reference's,
 // resampler_fft.rs:385-424 with a NaN anywhere in the block).  The level is the block's ENERGY per channel, summed by the
 // even chain's first pass, which has the whole block in registers (one packed multiply-add per sample); an energy that is
-// not finite -- a NaN, an infinity, or samples beyond 1e17 -- sends the block through the careful path (largest magnitude,
-// NaN / infinity told from large by a sum of products with zero).
+// not finite -- a NaN, an infinity, or samples beyond 1e17 -- or below 2^-80 -- a silent channel, or samples below 1e-14 --
+// sends the block through the careful path (largest magnitude, NaN / infinity told from large by a sum of products with
+// zero; a channel is silent only if its largest magnitude is zero).
 struct PairScale {
     cf scale, unscale;
     uint32_t dead;
@@ -162,10 +163,12 @@ struct PairPrep {
         const float el = wave_reduce<false>(en.x), er = wave_reduce<false>(en.y);
         ps->dead = 0;
         constexpr int kLog2N = 31 - __builtin_clz(static_cast<unsigned>(K * M));
-        if (__builtin_isfinite(el) && __builtin_isfinite(er)) {
+        // (an energy of zero is a silent channel OR samples below 1e-22, whose squares are lost: told apart by the careful path)
+        constexpr float kTiny = 8.2718061e-25f;   // 2^-80
+        if (__builtin_isfinite(el) && __builtin_isfinite(er) && el >= kTiny && er >= kTiny) {
             ps->from_energy(el, er, kLog2N);
-        } else {   // (a wave-uniform branch next to nobody takes)
-            asm volatile("; a channel of this block is not finite, or beyond 1e17");
+        } else {   // (a wave-uniform branch few blocks take)
+            asm volatile("; a channel of this block is silent or tiny, not finite, or beyond 1e17");
             float ml = 0.f, mr = 0.f;
             cf nf = cf_make(0.f, 0.f), zero = cf_make(0.f, 0.f);   // nf += v * 0: NaN from the first NaN or infinity of a channel on
             asm volatile("" : "+v"(zero));
@@ -379,6 +382,7 @@ __global__ __launch_bounds__((pair_waves<FWD, INV>() ? pair_waves<FWD, INV>() : 
                 const uint32_t w = ((const GU32*)xraw)[j];
                 return cf_make(static_cast<float>(static_cast<int32_t>(w << 16) >> 16), static_cast<float>(static_cast<int32_t>(w) >> 16)) * (1.0f / 32768.0f);
             } else if constexpr (BITS == 24) {   // six bytes at an even address: the eight bytes at the word boundary below it
+                static_assert(BITS != 24 || FI % 2 == 0, "a block's last frame starts at an odd half word: its load ends with the block");
                 typedef u2v __attribute__((address_space(1), aligned(4))) GU2a4;
                 const uint32_t byte = 6u * static_cast<uint32_t>(j);
                 const u2v w = *(const GU2a4*)(xraw + (byte & ~3u));

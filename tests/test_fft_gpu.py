@@ -190,6 +190,27 @@ def test_channels_of_a_two_channel_stream_at_very_different_levels(in_hz, out_hz
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("in_hz,out_hz", [(44100, 48000), (48000, 44100)])
+@pytest.mark.parametrize("level_l,level_r", [(1e-30, 1e-30), (1e-30, 1.0), (3e4, 1e-12), (1e-30, 1e3), (1e15, 1e15)])   # (below ~1e-33 the REFERENCE works in denormals: X H is 1e-5 of the input)
+def test_two_channel_streams_at_the_ends_of_the_f32_range(in_hz, out_hz, level_l, level_r):
+    """f32 arithmetic does not care where a signal sits in its range, and the reference's per-channel transforms inherit
+    that; the two-channel kernel's level estimate (an energy: squares) must not turn a tiny channel into a silent one or a
+    large one into a dead one."""
+    g = ra.ResamplerFft.new(2, sr(in_hz), sr(out_hz))
+    n_in = g.chunk_size_input()
+    blocks = 9
+    x = synth.fast_noise(blocks * n_in, seed=3).copy()
+    x[0::2] *= np.float32(level_l)
+    x[1::2] *= np.float32(level_r)
+    with np.errstate(under="ignore"):
+        ref = _oracle_blocks(in_hz, out_hz, x, blocks)
+        y = g.resample_bulk(x, blocks)
+    for c in (0, 1):
+        level = float(np.sqrt(np.mean(ref[c::2].astype(np.float64) ** 2)))
+        assert level > 0.0 and rms(y[c::2], ref[c::2]) <= RMS_TOL * level, (c, level, rms(y[c::2], ref[c::2]) / level)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("in_hz,out_hz", [(44100, 48000), (48000, 44100)])
 def test_a_silent_channel_stays_silent_and_a_nan_stays_in_its_channel(in_hz, out_hz):
     g = ra.ResamplerFft.new(2, sr(in_hz), sr(out_hz))
     n_in, n_out = g.chunk_size_input(), g.chunk_size_output()
