@@ -24,9 +24,15 @@
 //   frame n of the output = v[n] + overlap[n]; v[FO + n] is the next overlap (resampler_fft.rs:416-423).
 // So a wave runs the EVEN-bin chain start to finish (forward transform, filter, inverse transform: A in registers), then
 // the ODD-bin chain, and the last inverse stage of the second chain combines, overlap-adds and stores whole frames.
-// Per stream and block: 220 LDS stores instead of 322, ~430 reads instead of 514, no exchange between waves, every input
-// frame one 8-byte complex load, every output frame one 8-byte store.  The transforms are the FI / FO-point plans of the
-// wave-per-channel kernel (same stages, same padded layouts: fft_wave_core.h).
+// Per stream and block: 230 LDS stores instead of 322, ~440 reads instead of 514, ~2850 vector instructions instead of ~2860
+// + no exchange between waves, every input frame one 8-byte complex load, every output frame one 8-byte store.  The
+// transforms are the FI / FO-point plans of the wave-per-channel kernel (same stages, same padded layouts:
+// fft_wave_core.h).
+// Around that: every channel of every block is brought to its own level before the two share butterflies (PairScale: a
+// quiet or silent channel beside a loud one, a NaN in one channel); a CU holds eight waves -- two per SIMD, served oldest
+// first -- and a stream's blocks are cut into a LONG run for an old wave and a SHORT one for a young wave (the kernel body's
+// run arithmetic, launch_fft_ola_pair); the output stores and the samples' second read are non-temporal (the block's samples
+// stay in L2 between the chains); WAV PCM is converted where the frames are loaded (BITS).  DESIGN.md 4.4.
 // Arithmetic: the reference's butterflies on other operands -- equal to the CPU path within rounding (tests/test_fft_gpu.py
 // holds it to the gate of 1e-6 RMS; measured ~1.5e-7 like the wave-per-channel kernel), not bit for bit; the exact build
 // (libresampler_amd_fftexact.so) never takes this kernel.

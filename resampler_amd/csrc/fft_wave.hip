@@ -25,6 +25,10 @@
 // reference's and bit-identical to it (tests/test_fft_gpu.py).
 // The two (or C) waves of a block's channels sit in one workgroup, so their half-line stores of the
 // interleaved output meet in the same L2.
+// Round 5 (tools/fft_trace.py, profiles/r05/fft_slopes.txt): a SIMD serves its waves oldest first -- three waves with equal
+// runs ended at 66 / 80 / 97 % of the launch -- so the waves of a SIMD publish their block counts in LDS and the one behind
+// raises its priority; the two waves of a stream touch the next block's lines into L2 a block ahead.  Two-channel streams
+// of the plan pairs it is built for go to fft_pair.hip (a wave per stream, the frame as one complex sample) instead.
 #include <cmath>
 #include <cstdlib>
 #include <type_traits>
