@@ -219,8 +219,25 @@ struct RepairMulti {
     const FirStreamDesc* descs[kMaxRepairJobs];
     uint32_t n_streams[kMaxRepairJobs];
     NfArgs nf[kMaxRepairJobs];
+    // (a lock-step run's last launch: the tails of ALL its streams are copied by one more row of the grid -- a launch and its
+    // gap less per run, fir_lockstep_api.cpp)
+    const FirStreamDesc* tail_descs;
+    uint32_t n_tail, n_jobs;
 };
-__global__ __launch_bounds__(kBlock) void fir_repair_multi_kernel(const RepairMulti m) {   // grid = (blocks, jobs)
+__global__ __launch_bounds__(kBlock) void fir_repair_multi_kernel(const RepairMulti m) {   // grid = (blocks, jobs [+ 1])
+    if (blockIdx.y >= m.n_jobs) {   // the tail row: a workgroup per stream, round the row
+        for (uint32_t s = blockIdx.x; s < m.n_tail; s += gridDim.x) {
+            const FirStreamDesc d = m.tail_descs[s];
+            const size_t total = static_cast<size_t>(d.tail_frames) * d.channels;
+            const size_t first = static_cast<size_t>(d.tail_start) * d.channels;
+            const size_t hist_values = static_cast<size_t>(d.hist_frames) * d.channels;
+            for (size_t i = threadIdx.x; i < total; i += kBlock) {
+                const size_t src = first + i;
+                d.hist_next[i] = src < hist_values ? d.hist[src] : fir_in_value(d, src - hist_values);
+            }
+        }
+        return;
+    }
     fir_repair_body(m.descs[blockIdx.y], m.n_streams[blockIdx.y], m.nf[blockIdx.y]);
 }
 
@@ -233,7 +250,9 @@ hipError_t launch_fir_repair(const FirStreamDesc* d_descs, uint32_t n_streams, c
     return hipGetLastError();
 }
 
-hipError_t launch_fir_repair_multi(const RepairJob* jobs, size_t n_jobs, hipStream_t stream) {
+hipError_t launch_fir_repair_multi(const RepairJob* jobs, size_t n_jobs, hipStream_t stream, const FirStreamDesc* tail_descs,
+                                   uint32_t n_tail, uint32_t max_tail_values) {
+    bool tail_left = tail_descs != nullptr && n_tail != 0 && max_tail_values != 0;
     for (size_t j = 0; j < n_jobs;) {
         RepairMulti m{};
         uint32_t n = 0, max_total = 0;
@@ -246,9 +265,18 @@ hipError_t launch_fir_repair_multi(const RepairJob* jobs, size_t n_jobs, hipStre
             ++n;
         }
         if (n == 0) continue;
-        hipLaunchKernelGGL(fir_repair_multi_kernel, dim3(max_total < 512 ? max_total : 512, n), dim3(kBlock), 0, stream, m);
+        m.n_jobs = n;
+        const bool with_tail = tail_left && j >= n_jobs;   // (the last launch takes the tails along)
+        if (with_tail) {
+            m.tail_descs = tail_descs;
+            m.n_tail = n_tail;
+            tail_left = false;
+            max_total = std::max(max_total, n_tail);
+        }
+        hipLaunchKernelGGL(fir_repair_multi_kernel, dim3(max_total < 512 ? max_total : 512, n + (with_tail ? 1u : 0u)), dim3(kBlock), 0, stream, m);
         if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
     }
+    if (tail_left) return launch_fir_tail_copy(tail_descs, n_tail, max_tail_values, stream);   // (no repair job at all)
     return hipSuccess;
 }
 

@@ -1248,8 +1248,8 @@ extern "C" int rsmp_fir_lockstep_run(rsmp_fir_lockstep* ls, size_t k_steps, size
         reserve = knob >= 0 ? static_cast<uint32_t>(knob) : static_cast<uint32_t>(std::min<size_t>(64, (n + 3) / 4 + 8));
     }
     if (!split_jobs.empty()) RSMP_HIP_CHECK(rsmp::launch_fir_split_multi(split_jobs.data(), split_jobs.size(), s, reserve));
-    RSMP_HIP_CHECK(rsmp::launch_fir_repair_multi(repair_jobs.data(), repair_jobs.size(), s));
-    RSMP_HIP_CHECK(rsmp::launch_fir_tail_copy(d_descs, static_cast<uint32_t>(n), max_tail_values, s));
+    // (the repair launch copies the streams' tails as well: one launch and its gap less per run)
+    RSMP_HIP_CHECK(rsmp::launch_fir_repair_multi(repair_jobs.data(), repair_jobs.size(), s, d_descs, static_cast<uint32_t>(n), max_tail_values));
     RSMP_HIP_CHECK(hipEventRecord(ls->slot[sl].compute_done, s));
     ls->slot[sl].used = true;
     if (ls->profiling) {
