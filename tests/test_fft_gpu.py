@@ -242,6 +242,32 @@ def test_a_silent_channel_stays_silent_and_a_nan_stays_in_its_channel(in_hz, out
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("in_hz,out_hz", [(44100, 48000), (48000, 44100)])
+def test_a_batch_of_two_channel_streams_of_very_different_lengths(in_hz, out_hz):
+    """One launch, streams of 1 .. 150 blocks: the two-channel kernel cuts every stream into pairs of a long and a short run
+    sized for the LONGEST stream, so a short stream is a single (partial) long run, and most waves find nothing to do."""
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda:0")
+    lengths = [1, 7, 40, 3, 150, 2, 61]
+    gs = [ra.ResamplerFft.new(2, sr(in_hz), sr(out_hz)) for _ in lengths]
+    n_in, n_out = gs[0].chunk_size_input(), gs[0].chunk_size_output()
+    xs = [synth.fast_noise(n * n_in, seed=10 + i) for i, n in enumerate(lengths)]
+    d_in = [torch.from_numpy(x).to(dev) for x in xs]
+    d_out = [torch.zeros(n * n_out, device=dev) for n in lengths]
+    batch = ra.FftBatch(gs)
+    for _round in range(2):   # (the second launch starts from the overlap the first left)
+        batch.bind(d_in, d_out, lengths)
+        batch.resample_bulk_device(ra.torch_stream())
+        torch.cuda.synchronize()
+        if _round == 0:
+            first = [d.cpu().numpy().copy() for d in d_out]
+    for i, n in enumerate(lengths):
+        ref = _oracle_blocks(in_hz, out_hz, np.concatenate([xs[i], xs[i]]), 2 * n)
+        assert rms(first[i], ref[:n * n_out]) <= RMS_TOL, i
+        assert rms(d_out[i].cpu().numpy(), ref[n * n_out:]) <= RMS_TOL, i
+
+
+@pytest.mark.gpu
 def test_c3_full_size_and_batch_device_api():
     torch = pytest.importorskip("torch")
     dev = torch.device("cuda:0")
