@@ -265,12 +265,14 @@ template <class FWD, class INV>
 constexpr int pair_waves() {
     constexpr size_t buf = FWD::kBuf > INV::kBuf ? FWD::kBuf : INV::kBuf;
     constexpr size_t tables = static_cast<size_t>(FWD::kTw + INV::kTw + PairBins<FWD::N, INV::N>::kNL + FWD::N + INV::N);
+    // (plans of up to 512 points need ~105 registers: sixteen waves, four per SIMD, hide more of their many short passes)
+    if (FWD::N <= 768 && INV::N <= 512 && (tables + 16 * buf) * sizeof(cf) <= 160 * 1024) return 16;
     return (tables + 8 * buf) * sizeof(cf) <= 160 * 1024 ? 8 : (tables + 4 * buf) * sizeof(cf) <= 160 * 1024 ? 4 : 0;
 }
 template <class FWD, class INV, int BITS>
 __global__ __launch_bounds__((pair_waves<FWD, INV>() ? pair_waves<FWD, INV>() : 4) * 64, 1) void fft_ola_pair_kernel(FftPlanDev plan, const FftStreamDesc* __restrict__ descs,
-                                                              uint32_t run_long, uint32_t run_short, uint32_t pairs_per_stream,
-                                                              uint32_t total_waves) {
+                                                              uint32_t run0, uint32_t run1, uint32_t run2, uint32_t run3,
+                                                              uint32_t pairs_per_stream, uint32_t total_waves) {
     extern __shared__ __attribute__((aligned(16))) cf lds2[];
     constexpr int kWaves = pair_waves<FWD, INV>() ? pair_waves<FWD, INV>() : 4;
     constexpr int FI = FWD::N, FO = INV::N;
@@ -342,8 +344,10 @@ __global__ __launch_bounds__((pair_waves<FWD, INV>() ? pair_waves<FWD, INV>() : 
     const uint32_t stream_idx = pair_idx / pairs_per_stream;
     const uint32_t in_stream = pair_idx - stream_idx * pairs_per_stream;
     const FftStreamDesc d = descs[stream_idx];
-    const uint32_t first = in_stream * (run_long + run_short) + (kind ? run_long : 0u);
-    const uint32_t run = kind ? run_short : run_long;
+    // (sixteen waves per CU: four ages, four run lengths)
+    const uint32_t before = kind == 0 ? 0u : kind == 1 ? run0 : kind == 2 ? run0 + run1 : run0 + run1 + run2;
+    const uint32_t first = in_stream * (run0 + run1 + run2 + run3) + before;
+    const uint32_t run = kind == 0 ? run0 : kind == 1 ? run1 : kind == 2 ? run2 : run3;
     if (first >= d.n_blocks || run == 0) return;
     const uint32_t last = first + run < d.n_blocks ? first + run : d.n_blocks;  // exclusive
 
@@ -587,7 +591,7 @@ typedef WavePlan<882, 2, 3, 3, 7, 7> W882;
 typedef WavePlan<1764, 3, 3, 4, 7, 7> W1764;
 typedef WavePlan<640, 2, 5, 8, 8> W640;
 
-typedef void (*PairKernel)(FftPlanDev, const FftStreamDesc*, uint32_t, uint32_t, uint32_t, uint32_t);
+typedef void (*PairKernel)(FftPlanDev, const FftStreamDesc*, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t);
 
 struct PairChoice {
     PairKernel fn = nullptr;
@@ -635,7 +639,7 @@ hipError_t launch_fft_ola_pair(const FftPlanDev& plan, const FftStreamDesc* d_de
                        // (by tools/fft_pairs_bench.py, both kernels in one lease -- profiles/r05/fft_pairs_pair_vs_wave.txt: the
                        // down-sampling pairs gain 8 - 21 %, 512 -> 1024 frames 4 %; a 1764-point inverse, 512 -> 1536 / 2048,
                        // 768 -> 256 / 512, 882 -> 1280 and 1764 -> 1280 frames spill or run four waves and stay with fft_wave.hip)
-                       || pair_choices<W512, W64, W128, W256, W768, W1024>(plan, pcm_bits, &pc) || pair_choices<W768, W64, W128>(plan, pcm_bits, &pc) ||
+                       || pair_choices<W512, W64, W128, W256, W768, W1024>(plan, pcm_bits, &pc) || pair_choices<W768, W64, W128, W256, W512>(plan, pcm_bits, &pc) ||
                        pair_choices<W1536, W64, W128>(plan, pcm_bits, &pc) || pair_choices<W588, W1280>(plan, pcm_bits, &pc) ||
                        pair_choices<W882, W640>(plan, pcm_bits, &pc) || pair_choices<W1764, W640>(plan, pcm_bits, &pc) ||
                        pair_choices<W640, W882>(plan, pcm_bits, &pc) || pair_choices<W1280, W588, W882>(plan, pcm_bits, &pc);
@@ -647,13 +651,23 @@ hipError_t launch_fft_ola_pair(const FftPlanDev& plan, const FftStreamDesc* d_de
     int dev = 0, cus = 256;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    const uint32_t classes = pc.waves / 4;   // waves per SIMD: 2 (an old and a young one), or 1
+    const uint32_t classes = pc.waves / 4;   // waves per SIMD: ages
     const double slots = static_cast<double>(cus) * pc.waves;
     static const double share_knob = [] { const char* e = rsmp::knob("RSMP_FFT_PAIR_SHARE"); return e ? atof(e) : 0.0; }();   // A/B
-    const double kLongShare = classes == 1 ? 1.0 : share_knob > 0.0 && share_knob < 1.0 ? share_knob : 0.6;
+    // the share of a SIMD each age gets while all of them run (two ages: by a sweep on the 44.1 -> 48 kHz launch; four: the
+    // same falling series, RSMP_FFT_PAIR_SHARE = its ratio)
+    double share[4] = {1.0, 0.0, 0.0, 0.0};
+    if (classes == 2) {
+        share[0] = share_knob > 0.0 && share_knob < 1.0 ? share_knob : 0.6;
+        share[1] = 1.0 - share[0];
+    } else if (classes == 4) {
+        const double r = share_knob > 0.0 && share_knob <= 1.0 ? share_knob : 0.8;
+        const double sum = 1.0 + r + r * r + r * r * r;
+        for (int c = 0; c < 4; ++c) share[c] = std::pow(r, c) / sum;
+    }
     uint32_t both = 32;
     double best = -1.0;
-    for (uint32_t cand = 6 * classes; cand <= 64 * classes; ++cand) {   // blocks of a pair
+    for (uint32_t cand = 6 * classes; cand <= 64 * classes; ++cand) {   // blocks of a group of runs (one per age)
         const double pairs = static_cast<double>((max_blocks + cand - 1) / cand);
         const double waves = classes * pairs * n_streams;
         const double rounds = std::ceil(waves / slots);
@@ -662,16 +676,20 @@ hipError_t launch_fft_ola_pair(const FftPlanDev& plan, const FftStreamDesc* d_de
         if (score > best + 1e-9) { best = score; both = cand; }
     }
     const uint32_t pairs_per_stream = (max_blocks + both - 1) / both;
-    // (the halo block is part of a wave's work: the shares are of both + 2)
-    uint32_t run_long = classes == 1 ? both : static_cast<uint32_t>(std::lround(kLongShare * (both + 2.0) - 1.0));
-    if (run_long > both) run_long = both;
-    if (run_long < 1) run_long = 1;
-    const uint32_t run_short = both - run_long;
+    // (the halo block is part of a wave's work: the shares are of both + classes)
+    uint32_t runs[4] = {0, 0, 0, 0}, given = 0;
+    for (uint32_t c = 0; c + 1 < classes; ++c) {
+        const long v = std::lround(share[c] * (both + static_cast<double>(classes)) - 1.0);
+        runs[c] = static_cast<uint32_t>(v < 1 ? 1 : v);
+        if (given + runs[c] > both) runs[c] = both - given;
+        given += runs[c];
+    }
+    runs[classes - 1] = both - given;
     const uint32_t total_waves = pairs_per_stream * n_streams * classes;
     const dim3 grid((total_waves + pc.waves - 1) / pc.waves);
     const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(pc.fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(pc.fn, grid, dim3(pc.waves * 64), pc.lds, stream, plan, d_descs, run_long, run_short, pairs_per_stream, total_waves);
+    hipLaunchKernelGGL(pc.fn, grid, dim3(pc.waves * 64), pc.lds, stream, plan, d_descs, runs[0], runs[1], runs[2], runs[3], pairs_per_stream, total_waves);
     return hipGetLastError();
 }
 
