@@ -267,6 +267,8 @@ constexpr int pair_waves() {
     constexpr size_t tables = static_cast<size_t>(FWD::kTw + INV::kTw + PairBins<FWD::N, INV::N>::kNL + FWD::N + INV::N);
     // (plans of up to 512 points need ~105 registers: sixteen waves, four per SIMD, hide more of their many short passes)
     if (FWD::N <= 768 && INV::N <= 512 && (tables + 16 * buf) * sizeof(cf) <= 160 * 1024) return 16;
+    // (twelve waves -- 168 registers -- for the plans of up to 1024 points: 26-55 spilled registers, 512 -> 1024 frames 0.72 ->
+    // 0.77 ms, 640 -> 882 0.76 -> 0.87: measured, not kept)
     return (tables + 8 * buf) * sizeof(cf) <= 160 * 1024 ? 8 : (tables + 4 * buf) * sizeof(cf) <= 160 * 1024 ? 4 : 0;
 }
 template <class FWD, class INV, int BITS>
@@ -660,10 +662,11 @@ hipError_t launch_fft_ola_pair(const FftPlanDev& plan, const FftStreamDesc* d_de
     if (classes == 2) {
         share[0] = share_knob > 0.0 && share_knob < 1.0 ? share_knob : 0.6;
         share[1] = 1.0 - share[0];
-    } else if (classes == 4) {
+    } else if (classes >= 3) {
         const double r = share_knob > 0.0 && share_knob <= 1.0 ? share_knob : 0.8;
-        const double sum = 1.0 + r + r * r + r * r * r;
-        for (int c = 0; c < 4; ++c) share[c] = std::pow(r, c) / sum;
+        double sum = 0.0;
+        for (uint32_t c = 0; c < classes; ++c) sum += std::pow(r, static_cast<double>(c));
+        for (uint32_t c = 0; c < classes; ++c) share[c] = std::pow(r, static_cast<double>(c)) / sum;
     }
     uint32_t both = 32;
     double best = -1.0;
