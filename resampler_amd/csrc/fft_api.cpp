@@ -6,6 +6,7 @@
 // per instance (scratch pads, spectra) lives in LDS for the duration of a block.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -163,6 +164,15 @@ struct rsmp_fft {
     bool desc_pending = false;
     PinnedBuffer h_desc;
     DeviceBuffer d_desc;
+    // Small descriptor tables (up to 16 KB: ~340 streams) are not uploaded at all: the kernels read them out of mapped,
+    // coherent host memory -- a copy-engine operation and its wait less in front of every launch (a launch of the bench's 64
+    // streams: ms per step - kernel ms 14 -> 8 us).  A ring of slots, each reusable once the launch that read it has passed
+    // its event.
+    static constexpr int kDescSlots = 4;
+    PinnedBuffer h_desc_ring[kDescSlots];
+    hipEvent_t desc_read[kDescSlots] = {nullptr, nullptr, nullptr, nullptr};
+    bool desc_slot_used[kDescSlots] = {false, false, false, false};
+    int desc_slot = 0;
     DeviceBuffer d_stage_in, d_stage_out;
     rsmp::PinnedBuffer h_stage_in, h_stage_out;   // small calls: mapped host memory instead of copy-engine transfers
     bool profiling = false;
@@ -198,16 +208,35 @@ int launch_fft_jobs(rsmp_fft* leader, const std::vector<FftJob>& jobs, hipStream
         h->last_stream = stream;
         h->last_stream_valid = true;
     }
-    if (leader->desc_pending) {
-        RSMP_HIP_CHECK(hipEventSynchronize(leader->desc_copied));
-        leader->desc_pending = false;
+    // (a launch of a block or two per stream -- a streaming call -- keeps the upload: the table read over the host link at the
+    // kernel's start is on its critical path there, 33.6 against 32.1 us per call)
+    size_t most_blocks = 0;
+    for (size_t i = 0; i < n; ++i) most_blocks = std::max(most_blocks, jobs[i].n_blocks);
+    const bool direct = bytes <= 16 * 1024 && most_blocks >= 4;
+    int slot = 0;
+    FftStreamDesc* h = nullptr;
+    if (direct) {
+        slot = leader->desc_slot;
+        leader->desc_slot = (slot + 1) % rsmp_fft::kDescSlots;
+        if (!leader->desc_read[slot]) RSMP_HIP_CHECK(hipEventCreateWithFlags(&leader->desc_read[slot], hipEventDisableTiming));
+        if (leader->desc_slot_used[slot]) {   // the launch that read this slot (four launches ago) is through
+            RSMP_HIP_CHECK(hipEventSynchronize(leader->desc_read[slot]));
+            leader->desc_slot_used[slot] = false;
+        }
+        RSMP_HIP_CHECK(leader->h_desc_ring[slot].reserve(16 * 1024));
+        h = leader->h_desc_ring[slot].as<FftStreamDesc>();
+    } else {
+        if (leader->desc_pending) {
+            RSMP_HIP_CHECK(hipEventSynchronize(leader->desc_copied));
+            leader->desc_pending = false;
+        }
+        RSMP_HIP_CHECK(leader->h_desc.reserve(bytes));
+        if (bytes > leader->d_desc.capacity()) {
+            RSMP_HIP_CHECK(hipStreamSynchronize(stream));
+            RSMP_HIP_CHECK(leader->d_desc.reserve(bytes));
+        }
+        h = leader->h_desc.as<FftStreamDesc>();
     }
-    RSMP_HIP_CHECK(leader->h_desc.reserve(bytes));
-    if (bytes > leader->d_desc.capacity()) {
-        RSMP_HIP_CHECK(hipStreamSynchronize(stream));
-        RSMP_HIP_CHECK(leader->d_desc.reserve(bytes));
-    }
-    FftStreamDesc* h = leader->h_desc.as<FftStreamDesc>();
     uint32_t max_blocks = 0, max_channels = 0, min_channels = 0xFFFFFFFFu;
     for (size_t i = 0; i < n; ++i) {
         const FftJob& j = jobs[i];
@@ -224,12 +253,16 @@ int launch_fft_jobs(rsmp_fft* leader, const std::vector<FftJob>& jobs, hipStream
         if (h[i].channels > max_channels) max_channels = h[i].channels;
         if (h[i].channels < min_channels) min_channels = h[i].channels;
     }
-    RSMP_HIP_CHECK(hipMemcpyAsync(leader->d_desc.get(), h, bytes, hipMemcpyHostToDevice, stream));
-    RSMP_HIP_CHECK(hipEventRecord(leader->desc_copied, stream));
-    leader->desc_pending = true;
+    const FftStreamDesc* d_descs = h;   // (mapped host memory: the same address on the device)
+    if (!direct) {
+        RSMP_HIP_CHECK(hipMemcpyAsync(leader->d_desc.get(), h, bytes, hipMemcpyHostToDevice, stream));
+        RSMP_HIP_CHECK(hipEventRecord(leader->desc_copied, stream));
+        leader->desc_pending = true;
+        d_descs = leader->d_desc.as<FftStreamDesc>();
+    }
     if (leader->profiling) RSMP_HIP_CHECK(hipEventRecord(leader->prof_start, stream));
     {
-        const hipError_t e = rsmp::launch_fft_ola(leader->plan->dev, leader->d_desc.as<FftStreamDesc>(), static_cast<uint32_t>(n),
+        const hipError_t e = rsmp::launch_fft_ola(leader->plan->dev, d_descs, static_cast<uint32_t>(n),
                                                   max_blocks, max_channels, min_channels, stream, pcm_bits);
         if (e == hipErrorNotSupported && pcm_bits != 0)
             return rsmp::fail(RSMP_ERR_INVALID_ARGUMENT, "ResamplerFft: PCM input is read in place by the two-channel wave kernel only "
@@ -245,6 +278,10 @@ int launch_fft_jobs(rsmp_fft* leader, const std::vector<FftJob>& jobs, hipStream
         RSMP_HIP_CHECK(hipEventCreateWithFlags(&leader->launch_ev->ev, hipEventDisableTiming));
     }
     RSMP_HIP_CHECK(hipEventRecord(leader->launch_ev->ev, stream));
+    if (direct) {   // the slot may be rewritten once this launch's kernels have read it
+        RSMP_HIP_CHECK(hipEventRecord(leader->desc_read[slot], stream));
+        leader->desc_slot_used[slot] = true;
+    }
     for (const FftJob& j : jobs) {
         if (j.n_blocks != 0) j.r->cur ^= 1;   // (a stream without blocks in this launch keeps its state where it is)
         j.r->last_launch = leader->launch_ev;
@@ -305,6 +342,8 @@ extern "C" void rsmp_fft_free(rsmp_fft* r) {
     (void)hipDeviceSynchronize();
     if (r->d_overlap) (void)hipFree(r->d_overlap);
     if (r->desc_copied) (void)hipEventDestroy(r->desc_copied);
+    for (hipEvent_t e : r->desc_read)
+        if (e) (void)hipEventDestroy(e);
     if (r->prof_start) (void)hipEventDestroy(r->prof_start);
     if (r->prof_stop) (void)hipEventDestroy(r->prof_stop);
     if (r->stream) (void)hipStreamDestroy(r->stream);
