@@ -275,14 +275,17 @@ impl LockstepBatch {
         status(unsafe { rsmp_fir_lockstep_step(self.handle, in_frames, in_offset_frames, std::ptr::null(), append as c_int, std::ptr::null_mut()) })
     }
     pub fn run(&mut self, k_steps: usize, in_frames: usize, in_offset_frames: usize, append: bool) -> Result<(), ResampleError> {
+        status(unsafe { rsmp_fir_lockstep_run(self.handle, k_steps, in_frames, in_offset_frames, append as c_int, std::ptr::null_mut()) })?;
         self.last_run = k_steps;
-        status(unsafe { rsmp_fir_lockstep_run(self.handle, k_steps, in_frames, in_offset_frames, append as c_int, std::ptr::null_mut()) })
+        Ok(())
     }
     /// A whole buffer per stream in calls of `chunk_frames` frames, the last one shorter (the loop of
     /// resample/src/main.rs:226-254), planned on the device whatever states the streams are in.
     pub fn run_bulk(&mut self, total_frames: usize, chunk_frames: usize, in_offset_frames: usize, append: bool) -> Result<(), ResampleError> {
+        // (the C side answers chunk_frames == 0 with RSMP_ERR_INVALID_ARGUMENT; last_run moves on success only)
+        status(unsafe { rsmp_fir_lockstep_run_bulk(self.handle, total_frames, chunk_frames, in_offset_frames, append as c_int, std::ptr::null_mut()) })?;
         self.last_run = total_frames / chunk_frames;
-        status(unsafe { rsmp_fir_lockstep_run_bulk(self.handle, total_frames, chunk_frames, in_offset_frames, append as c_int, std::ptr::null_mut()) })
+        Ok(())
     }
     /// (consumed, produced) of the last call of every stream, in f32 values; waits for the launch.
     pub fn counts(&mut self) -> Vec<(usize, usize)> {

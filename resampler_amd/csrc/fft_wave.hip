@@ -482,10 +482,13 @@ __global__ __launch_bounds__((OCC == 1 && kOneWavePerSimd<FWD, INV> ? 256 : wave
         if constexpr (stereo) {
             // The first pass of every block waits for HBM (28 % of a wave's time, tools/fft_trace.py).  The block after this
             // one is touched into L2 now: the two waves of a stream take every other 128-byte line of its 9.4 KB.
+            // A block is FI frames of two samples of 4 bytes (f32) or in_bits / 8 bytes (PCM): the touch stays inside it.
             if (b + 1 < static_cast<int64_t>(d.n_blocks)) {
-                const GFloat* nx = as_global(d.in) + static_cast<size_t>(b + 1) * FI * C;
-                const uint32_t fl = (2u * static_cast<uint32_t>(lane) + ch) * 32u;
-                if (fl < static_cast<uint32_t>(FI) * 2u) pf = nx[fl];
+                const uint32_t bits = __builtin_amdgcn_readfirstlane(d.in_bits);
+                const uint32_t block_bytes = static_cast<uint32_t>(FI) * 2u * (bits ? bits >> 3 : 4u);   // (FI even: a multiple of 4)
+                const GFloat* nx = (const GFloat*)((const __attribute__((address_space(1))) char*)as_global(d.in) + static_cast<size_t>(b + 1) * block_bytes);
+                const uint32_t fl = (2u * static_cast<uint32_t>(lane) + ch) * 32u;   // in 4-byte words: every other 128-byte line
+                if (fl * 4u < block_bytes) pf = nx[fl];
             }
         }
 #endif

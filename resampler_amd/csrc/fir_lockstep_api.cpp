@@ -202,6 +202,16 @@ int rebind_class_blocking(rsmp_fir_lockstep* ls, size_t c, double d) {
     return RSMP_OK;
 }
 
+// Images unbound by a replacement may be overwritten behind everything enqueued on `s` so far.  An image whose guard
+// could not be recorded stays in the list (the next call tries again before it asks for anything).
+int record_due_guards(rsmp_fir_lockstep* ls, hipStream_t s) {
+    while (!ls->guards_due.empty()) {
+        if (int rc = ls->refresher->record_guard(ls->guards_due.back(), s)) return rc;
+        ls->guards_due.pop_back();
+    }
+    return RSMP_OK;
+}
+
 // The launch path's side of a replacement.  Where the drifts that have come back from the device say so, a class's next
 // tables are ASKED FOR (most of the way to the tolerance: one event record), and a class past the tolerance TAKES the
 // tables the worker has left for it (pointer swaps + one patch kernel for all classes of this look).  Nothing here
@@ -212,6 +222,10 @@ int rebind_class_blocking(rsmp_fir_lockstep* ls, size_t c, double d) {
 // launches per second of host time: 374 waits in 29 k runs, none in the bench's 64 launches or behind a caller that
 // synchronises now and then; counted in stat_table_waits).
 int poll_drift(rsmp_fir_lockstep* ls, hipStream_t s) {
+    // Guards a previous call took but did not get to record (it failed between its replacement and request_drift): the
+    // images it unbound must not be refilled before everything enqueued so far has passed -- recorded here, in front of
+    // any request() below, they are later than needed and never stale.
+    if (int rc = record_due_guards(ls, s)) return rc;
     bool fresh = false;
     if (ls->drift_inflight) {
         if (hipEventQuery(ls->drift_ev) == hipSuccess) {
@@ -315,9 +329,12 @@ int poll_drift(rsmp_fir_lockstep* ls, hipStream_t s) {
             static const bool verbose = rsmp::knob("RSMP_FIR_VERBOSE") != nullptr;
             if (verbose) fprintf(stderr, "[rsmp] class %zu: drift %.3g past its tables' %.3g with nothing asked for\n", c, now_drift, cl.table_drift);
             if (int rc = ask(quantized_drift(now_drift))) return rc;
-        } else if (std::fabs(off) > 0.6 * tol && !cl.next_pending) {
-            // most of the way: the tables the class will want at the crossing are made now, beside everything else
-            if (int rc = ask(quantized_drift(cl.table_drift + (off > 0.0 ? tol : -tol)))) return rc;
+        } else {
+            if (cl.late) { cl.late = false; --ls->n_late; }   // (the extrapolation came back inside the tolerance: no more polling on its account)
+            if (std::fabs(off) > 0.6 * tol && !cl.next_pending) {
+                // most of the way: the tables the class will want at the crossing are made now, beside everything else
+                if (int rc = ask(quantized_drift(cl.table_drift + (off > 0.0 ? tol : -tol)))) return rc;
+            }
         }
     }
     return flush_patches();
@@ -352,9 +369,7 @@ int flush_tables(rsmp_fir_lockstep* ls, hipStream_t s) {
 // After a step or run of `frames` input frames per stream: now and then the classes' drifts start their way to the host.
 // Images this call's replacements have unbound may be overwritten behind everything enqueued so far.
 int request_drift(rsmp_fir_lockstep* ls, hipStream_t s, uint64_t frames) {
-    for (rsmp::TableRefresher::Table* t : ls->guards_due)
-        if (int rc = ls->refresher->record_guard(t, s)) return rc;
-    ls->guards_due.clear();
+    if (int rc = record_due_guards(ls, s)) return rc;
     ls->frames_since_drift += frames;
     ls->frames_total += frames;
     if (ls->drift_inflight || ls->frames_since_drift < ls->drift_check_frames || ls->classes.empty()) return RSMP_OK;

@@ -362,8 +362,6 @@ __device__ __forceinline__ uint32_t cvt_pk_f16(float a, float b) {
     const v2f v = v2f{a, b};
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2));
 }
-__device__ __forceinline__ float f16_lo(uint32_t w) { return static_cast<float>(__builtin_bit_cast(f16x2, w)[0]); }
-__device__ __forceinline__ float f16_hi(uint32_t w) { return static_cast<float>(__builtin_bit_cast(f16x2, w)[1]); }
 // s - (float)half of w in ONE instruction (v_fma_mix_f32: the fp16 operand is widened inside the FMA; the result is exact
 // either way).  The stagers are bound by what one wave can issue: the compiler's v_cvt_f32_f16 + v_sub_f32 per sample, and
 // its v_pk_mul_f32 / v_pk_add_f32 pairs with a v_mov per operand to line the registers up, were a quarter of the split.

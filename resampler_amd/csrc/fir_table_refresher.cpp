@@ -72,11 +72,22 @@ int TableRefresher::refresh(Table* t) {
     const size_t cb = host.coef.size() * sizeof(float), wb = host.wrap_coef.size() * sizeof(float),
                  mb = host.meta.size() * sizeof(TileMeta);
     const size_t total = cb + wb + mb;
-    if (!t->d_buf[0]) {   // the table's first refresh: both images (the sizes depend on the geometry alone)
-        for (char*& p : t->d_buf) RSMP_HIP_CHECK(hipMalloc(&p, total));
+    if (!t->d_buf[0] || !t->d_buf[1]) {   // the table's first refresh: both images (the sizes depend on the geometry alone)
+        char* a = nullptr;
+        char* b = nullptr;   // (committed only as a pair: a table is never left with one image)
+        RSMP_HIP_CHECK(hipMalloc(&a, total));
+        if (hipMalloc(&b, total) != hipSuccess) {
+            (void)hipFree(a);
+            return rsmp::fail(RSMP_ERR_HIP, "class table refresher: no device memory for a table's second image");
+        }
+        for (char* p : t->d_buf) if (p) (void)hipFree(p);
+        t->d_buf[0] = a;
+        t->d_buf[1] = b;
         t->coef_bytes = cb;
         t->wrap_bytes = wb;
         t->meta_bytes = mb;
+    } else if (cb != t->coef_bytes || wb != t->wrap_bytes || mb != t->meta_bytes) {
+        return rsmp::fail(RSMP_ERR_HIP, "class table refresher: a table's size changed between refreshes");
     }
     if (total > h_stage_cap_) {
         if (h_stage_) (void)hipHostFree(h_stage_);

@@ -202,3 +202,66 @@ def test_fir_resamples_pcm_straight_from_its_bytes(bits, in_hz, out_hz, frames):
     assert hs[0].state() == hs[1].state() == ref.state()
     if frames >= 100000:
         assert hs[1].kernel_variant() == 5   # (the split kernel took it)
+
+
+class _RawDeviceBytes:
+    """`n` bytes from hipMalloc itself (no torch pool around them: what lies behind the buffer's end is not the
+    caller's), filled from host bytes; quacks like the uint8 tensor the wrappers take (data_ptr / numel)."""
+
+    def __init__(self, raw: bytes):
+        import ctypes as C
+        self._hip = C.CDLL("libamdhip64.so")
+        self._hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+        self._hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        self._hip.hipFree.argtypes = [C.c_void_p]
+        p = C.c_void_p()
+        assert self._hip.hipMalloc(C.byref(p), len(raw)) == 0
+        self._p, self._n = p, len(raw)
+        assert self._hip.hipMemcpy(p, raw, len(raw), 1) == 0   # hipMemcpyHostToDevice
+
+    def data_ptr(self):
+        return self._p.value
+
+    def numel(self):
+        return self._n
+
+    def free(self):
+        if self._p:
+            self._hip.hipFree(self._p)
+            self._p = None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bits", [16, 24])
+@pytest.mark.parametrize("in_rate,out_rate,blocks", [(ra.SampleRate.Hz48000, ra.SampleRate.Hz96000, 1),
+                                                     (ra.SampleRate.Hz48000, ra.SampleRate.Hz96000, 3),
+                                                     (ra.SampleRate.Hz44100, ra.SampleRate.Hz48000, 2)])
+def test_fft_pcm_launch_reads_nothing_behind_an_exactly_sized_buffer(bits, in_rate, out_rate, blocks):
+    """the wave-per-channel kernel's touch of the NEXT block's lines took a block for FI frames of
+    f32 whatever the launch's sample width -- on 16- / 24-bit PCM a load up to twice the buffer's length behind its
+    start.  Launches of fewer than four blocks (and rate pairs fft_pair.hip does not serve) take that kernel: the PCM in
+    an allocation of exactly its size straight from hipMalloc, output equal to the two-pass route's bit for bit."""
+    torch = pytest.importorskip("torch")
+    dev = torch.device("cuda:0")
+    hs = [ra.ResamplerFft.new(2, in_rate, out_rate) for _ in range(2)]
+    n_in, n_out = hs[0].chunk_size_input(), hs[0].chunk_size_output()
+    rng = np.random.default_rng(100 + bits + blocks)
+    s = rng.integers(-(1 << (bits - 1)), (1 << (bits - 1)) - 1, blocks * n_in, dtype=np.int64)
+    raw = _pcm_bytes(s, bits)
+    exact = _RawDeviceBytes(raw)
+    try:
+        pooled = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
+        f32 = torch.empty(blocks * n_in, device=dev)
+        ra.pcm_to_stereo_f32_device(pooled, bits, 2, f32)
+        two_pass = torch.zeros(blocks * n_out, device=dev)
+        b1 = ra.FftBatch(hs[:1])
+        b1.bind([f32], [two_pass], [blocks])
+        b1.resample_bulk_device()
+        fused = torch.zeros(blocks * n_out, device=dev)
+        b2 = ra.FftBatch(hs[1:])
+        b2.resample_bulk_pcm_device([exact], bits, [fused], [blocks])
+        torch.cuda.synchronize()
+        assert torch.equal(two_pass, fused)
+        assert float(fused.abs().max()) > 0.1
+    finally:
+        exact.free()
