@@ -678,6 +678,30 @@ int launch_jobs(rsmp_fir* leader, std::vector<Job>& jobs, hipStream_t stream, ui
         RSMP_HIP_CHECK(hipEventRecord(leader->prof_stop[leader->prof_count % rsmp_fir::kProfRing], stream));
         ++leader->prof_count;
     }
+    // (RSMP_FIR_NO_REPAIR, debug: what the periodic kernels wrote, without the repair pass -- tools/repair_probe.py)
+    static const bool no_repair = rsmp::knob("RSMP_FIR_NO_REPAIR") != nullptr;
+    static const bool count_marks = rsmp::knob("RSMP_FIR_COUNT_MARKS") != nullptr;   // (debug: how many chunks the launch marked, per launch group)
+    if (count_marks) {
+        RSMP_HIP_CHECK(hipStreamSynchronize(stream));
+        for (const Repair& rp : repairs) {
+            const size_t words = 1 + (static_cast<size_t>(rp.count) * rp.nf.chunks + 31) / 32;
+            std::vector<uint32_t> h(words);
+            RSMP_HIP_CHECK(hipMemcpy(h.data(), rp.nf.words, words * sizeof(uint32_t), hipMemcpyDeviceToHost));
+            size_t bits = 0;
+            for (size_t w = 1; w < words; ++w) bits += static_cast<size_t>(__builtin_popcount(h[w]));
+            fprintf(stderr, "[rsmp] launch group of %u streams x %u chunks: tag word %u (this launch's %u), %zu chunks marked\n", rp.count, rp.nf.chunks,
+                    h[0], rp.nf.tag, bits);
+            for (uint32_t st = 0; st < rp.count && st < 3; ++st) {   // (which: the first streams' chunk numbers)
+                fprintf(stderr, "[rsmp]   stream %u:", st);
+                for (uint32_t c = 0; c < rp.nf.chunks; ++c) {
+                    const size_t bit = static_cast<size_t>(st) * rp.nf.chunks + c;
+                    if (h[1 + (bit >> 5)] >> (bit & 31) & 1u) fprintf(stderr, " %u", c);
+                }
+                fprintf(stderr, "\n");
+            }
+        }
+    }
+    if (no_repair) repairs.clear();
     if (repairs.size() > 1) {
         std::vector<rsmp::RepairJob> rj;
         for (const Repair& rp : repairs) rj.push_back(rsmp::RepairJob{d_descs + rp.first, rp.count, rp.nf});

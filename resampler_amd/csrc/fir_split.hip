@@ -1033,6 +1033,14 @@ __device__ __forceinline__ void fir_split_body(const FirStreamDesc* __restrict__
                     auto at = [&](int i, int fr, int c) -> float {
                         if constexpr (ROLE == 2) {
                             if constexpr (mono) return c == 0 ? xm[i][fr] : (fr == 0 ? xm[i][1] : 0.f);
+                            // (an odd count's last pair: the phantom channel is ZEROS, not the next frame's first channel the
+                            // load delivers.  Its sums are dropped either way, but its planes are not alone in the LDS: the last
+                            // tiles of the image in the slot BEFORE read a few rows past their own image -- against zero padding
+                            // coefficients -- and an edge item, whose phantom is zeros (fetch_edge), leaves the pair a history of
+                            // silence from which the next item's real samples were scaled to infinity: 0 x inf = NaN in the
+                            // neighbour's sums, one item per workgroup range and stream redone by the repair pass -- 1.0 ms on
+                            // top of a 0.68 ms launch of three-channel streams, profiles/r06/odd_channels_repair.txt)
+                            else if (kOdd && c == 1 && phantom(cpair)) return 0.f;
                             else return (cpair & 1u) ? xq[i][fr][2 + c] : xq[i][fr][c];
                         } else if constexpr (kShare) {
                             return xq[i][fr][c];
@@ -1040,7 +1048,7 @@ __device__ __forceinline__ void fir_split_body(const FirStreamDesc* __restrict__
                             return xc[i][2 * fr + c];
                         }
                     };
-                    auto at_partner = [&](int i, int fr, int c) -> float { return xq[i][fr][2 + c]; };
+                    auto at_partner = [&](int i, int fr, int c) -> float { return kOdd && c == 1 && phantom(cpair + 1) ? 0.f : xq[i][fr][2 + c]; };
                     // the peak of the samples in the registers: this lane's (lane_max), then the wave's and (one atomic) into
                     // the item's (publish) -- once per item and pair where the scale is predicted, once more after the first
                     // round where the scale is taken from it

@@ -660,6 +660,56 @@ print("three planes ok")
     assert out.returncode == 0 and "three planes ok" in out.stdout, out.stdout + out.stderr
 
 
+@pytest.mark.gpu
+def test_clean_audio_needs_no_repair_pass_in_a_child_process():
+    """The repair pass (fir_nonfinite.h) exists for inf / NaN / out-of-range samples and for items whose predicted scale was
+    off; clean audio must come out of the periodic kernels right BY ITSELF.  Round 5 shipped odd channel counts that did
+    not: the phantom channel of an odd count's last pair was the next frame's first channel, scaled from a history of silence
+    behind an edge item -- infinities in its planes, NaN (0 x inf) in the last class tiles of the image one slot before, one
+    item per workgroup range redone by the repair pass (three channels: 1.0 ms of repairs on a 0.68 ms launch), and no test
+    noticed because the repaired output is right.  RSMP_FIR_NO_REPAIR=1 (debug knob, read once per process) drops the repair
+    launch: noise at a level per stream, several streams per launch (stream edges inside workgroup ranges), every channel
+    count's kind of pair -- against the oracle, every stream."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import numpy as np
+import torch
+import resampler_amd as ra
+from oracle import pyoracle as o
+from resampler_amd import synth
+kind = o.CONVOLVE_AVX_FMA if o.have_avx_fma() else o.CONVOLVE_SCALAR
+dev = torch.device("cuda:0")
+for ch, a, b, streams in ((3, 44100, 48000, 5), (5, 48000, 44100, 3), (1, 48000, 44100, 6), (2, 44100, 48000, 6), (4, 44100, 48000, 4), (7, 44100, 48000, 2)):
+    frames = 60000
+    hs = [ra.ResamplerFir.new_from_hz(ch, a, b, ra.Latency.Sample64, ra.Attenuation.Db90) for _ in range(streams)]
+    x = synth.fast_noise(frames * ch, seed=7 + ch)
+    xs = [(x * np.float32(0.25 + 0.75 * i / streams)).astype(np.float32) for i in range(streams)]
+    d_in = [torch.from_numpy(v).to(dev) for v in xs]
+    d_out = [torch.zeros(hs[0].bulk_output_bound(frames * ch, 512 * ch), device=dev) for _ in hs]
+    batch = ra.FirBatch(hs)
+    batch.bind(d_in, d_out)
+    cons, prod = batch.resample_bulk_device(512 * ch, ra.torch_stream())
+    torch.cuda.synchronize()
+    assert hs[0].kernel_variant() in (4, 5), (ch, hs[0].kernel_variant())
+    for i in range(streams):
+        r = o.OracleFir(ch, a, b, 128, 90, kind)
+        yr, _ = r.resample_all(xs[i], 512 * ch)
+        yg = d_out[i].cpu().numpy()[:int(prod[i])]
+        assert yg.size == yr.size, (ch, i, yg.size, yr.size)
+        g2, r2 = yg.reshape(-1, ch).astype(np.float64), yr.reshape(-1, ch).astype(np.float64)
+        for c in range(ch):
+            e = float(np.sqrt(np.mean(np.nan_to_num(g2[:, c] - r2[:, c], nan=1.0) ** 2))) / float(np.sqrt(np.mean(r2[:, c] ** 2)))
+            assert e <= 1e-6, (ch, a, b, i, c, e)
+print("no repair needed")
+"""
+    env = dict(os.environ, RSMP_DEBUG="1", RSMP_FIR_NO_REPAIR="1", PYTHONPATH=root)
+    out = subprocess.run([sys.executable, "-c", code], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "no repair needed" in out.stdout, out.stdout + out.stderr
+
+
 PAIR_FLOOR = 2.0 ** -36   # what a sample keeps at least, relative to the largest sample of its channel pair's work item
 
 
