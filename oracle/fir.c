@@ -60,6 +60,33 @@ float orc_convolve_interp_avx_fma(const float* input, const float* c1, const flo
     return _mm_cvtss_f32(s2);
 }
 
+int orc_have_avx512f(void) { return __builtin_cpu_supports("avx512f"); }
+
+/* fir/avx512.rs:5-50 -- 16 lanes, two FMA accumulators, per-lane lerp, one horizontal sum.  What the reference's runtime
+ * dispatch takes on a CPU with avx512f and taps >= 16 (resampler_fir.rs:331-345: avx512f is asked for FIRST), i.e. what
+ * its published Zen 5 figures were measured on (CHANGELOG.md:77).  The horizontal sum is `_mm512_reduce_add_ps`: halves,
+ * quarters, [2,3,2,3], lane 1 -- the same tree in GCC's header and in stdarch.  Held to the scalar spec within the
+ * reference's own 1e-5 (fir/mod.rs:137-192); not the leaf the parity oracle uses (north_star names AVX+FMA). */
+__attribute__((target("avx512f")))
+float orc_convolve_interp_avx512(const float* input, const float* c1, const float* c2,
+                                 float frac, size_t taps) {
+    size_t iters = taps / 16;
+    __m512 acc1 = _mm512_setzero_ps();
+    __m512 acc2 = _mm512_setzero_ps();
+    for (size_t i = 0; i < iters; i++) {
+        size_t off = i * 16;
+        __m512 x = _mm512_loadu_ps(input + off);
+        __m512 k1 = _mm512_load_ps(c1 + off);
+        __m512 k2 = _mm512_load_ps(c2 + off);
+        acc1 = _mm512_fmadd_ps(k1, x, acc1);
+        acc2 = _mm512_fmadd_ps(k2, x, acc2);
+    }
+    __m512 fv = _mm512_set1_ps(frac);
+    __m512 omf = _mm512_set1_ps(1.0f - frac);
+    __m512 interp = _mm512_add_ps(_mm512_mul_ps(acc1, omf), _mm512_mul_ps(acc2, fv));
+    return _mm512_reduce_add_ps(interp);
+}
+
 typedef float (*convolve_fn)(const float*, const float*, const float*, float, size_t);
 
 struct orc_fir {
@@ -90,6 +117,7 @@ orc_fir* orc_fir_new(size_t channels, uint32_t in_hz, uint32_t out_hz, size_t ta
     if (in_hz == 0 || out_hz == 0 || channels == 0 || beta < 0.0) return NULL;
     if (!(taps == 16 || taps == 32 || taps == 64 || taps == 128)) return NULL;
     if (convolve_kind == ORC_CONVOLVE_AVX_FMA && !orc_have_avx_fma()) return NULL;
+    if (convolve_kind == ORC_CONVOLVE_AVX512 && !(orc_have_avx512f() && taps >= 16)) return NULL;
 
     orc_fir* r = (orc_fir*)calloc(1, sizeof(orc_fir));
     double in_f = (double)in_hz, out_f = (double)out_hz;
@@ -102,7 +130,8 @@ orc_fir* orc_fir_new(size_t channels, uint32_t in_hz, uint32_t out_hz, size_t ta
     /* :326 cutoff as f32, :407-408 symmetric window, :410-416 row-major flatten */
     orc_make_sincs_for_kaiser(taps, PHASES, (float)cutoff, beta, ORC_WINDOW_SYMMETRIC, r->coeffs);
     r->input_buffers = (float*)calloc(BUFFER_SIZE * channels, sizeof(float));
-    r->convolve = (convolve_kind == ORC_CONVOLVE_AVX_FMA) ? orc_convolve_interp_avx_fma
+    r->convolve = convolve_kind == ORC_CONVOLVE_AVX512    ? orc_convolve_interp_avx512
+                  : convolve_kind == ORC_CONVOLVE_AVX_FMA ? orc_convolve_interp_avx_fma
                                                           : orc_convolve_interp_scalar;
     return r;
 }
@@ -280,4 +309,18 @@ size_t orc_fir_resample_all(orc_fir* r, const float* in, size_t in_len, size_t c
     if (n_calls) *n_calls = nc;
     free(tmp);
     return out_off;
+}
+
+/* The criterion bench's inner loop (benches/benchmark_resampler_fir.rs:50-89): `iterations` calls of resample() on the SAME
+ * `in_len` values (1024 there), the output buffer of buffer_size_output() values; returns the values produced in total.
+ * (One C call for the whole loop: a ctypes call per 8 us resample() would be a tenth of what is timed.) */
+unsigned long long orc_fir_bench_calls(orc_fir* r, const float* in, size_t in_len, float* out, size_t out_len,
+                                       size_t iterations) {
+    unsigned long long total = 0;
+    for (size_t i = 0; i < iterations; i++) {
+        size_t consumed = 0, produced = 0;
+        if (orc_fir_resample(r, in, in_len, out, out_len, &consumed, &produced) != 0) break;
+        total += produced;
+    }
+    return total;
 }

@@ -44,11 +44,14 @@ float orc_convolve_interp_scalar(const float* input, const float* c1, const floa
 float orc_convolve_interp_avx_fma(const float* input, const float* c1, const float* c2,
                                   float frac, size_t taps);               /* fir/avx.rs:5-61  */
 int orc_have_avx_fma(void);
+float orc_convolve_interp_avx512(const float* input, const float* c1, const float* c2,
+                                 float frac, size_t taps);                /* fir/avx512.rs:5-50 (timing + differential test only) */
+int orc_have_avx512f(void);
 
 /* ---- resampler_fir.rs ------------------------------------------------------------------ */
 typedef struct orc_fir orc_fir;
 
-enum { ORC_CONVOLVE_SCALAR = 0, ORC_CONVOLVE_AVX_FMA = 1 };
+enum { ORC_CONVOLVE_SCALAR = 0, ORC_CONVOLVE_AVX_FMA = 1, ORC_CONVOLVE_AVX512 = 2 };
 
 /* taps in {16,32,64,128}; attenuation_db in {60,90,120}; returns NULL on invalid arguments
  * (the reference panics on zero rates, resampler_fir.rs:302-309). */
@@ -72,6 +75,9 @@ void orc_fir_state(const orc_fir* r, size_t* read_position, size_t* available_fr
  * optional per-call counts are appended to calls[2*i], calls[2*i+1] up to max_calls. */
 /* `calls` resample() calls of in_frames frames each, control flow only (no samples; see fir.c) */
 unsigned long long orc_fir_skip_calls(orc_fir* r, size_t calls, size_t in_frames, unsigned long long* consumed_frames);
+/* benches/benchmark_resampler_fir.rs:50-89: `iterations` resample() calls on the same input; values produced in total */
+unsigned long long orc_fir_bench_calls(orc_fir* r, const float* in, size_t in_len, float* out, size_t out_len,
+                                       size_t iterations);
 size_t orc_fir_resample_all(orc_fir* r, const float* in, size_t in_len, size_t chunk_len,
                             float* out, size_t out_cap, size_t* calls, size_t max_calls,
                             size_t* n_calls);

@@ -24,6 +24,7 @@ WINDOW_PERIODIC = 0
 WINDOW_SYMMETRIC = 1
 CONVOLVE_SCALAR = 0
 CONVOLVE_AVX_FMA = 1
+CONVOLVE_AVX512 = 2   # fir/avx512.rs: what the reference's dispatch takes first (timing / differential test; not the parity leaf)
 
 
 def build(force: bool = False) -> str:
@@ -87,11 +88,14 @@ def lib() -> C.CDLL:
     L.orc_calculate_cutoff_kaiser.argtypes = [C.c_size_t, C.c_double]
     L.orc_make_sincs_for_kaiser.restype = None
     L.orc_make_sincs_for_kaiser.argtypes = [C.c_size_t, C.c_size_t, C.c_float, C.c_double, C.c_int, f32p]
-    for name in ("orc_convolve_interp_scalar", "orc_convolve_interp_avx_fma"):
+    for name in ("orc_convolve_interp_scalar", "orc_convolve_interp_avx_fma", "orc_convolve_interp_avx512"):
         fn = getattr(L, name)
         fn.restype = C.c_float
         fn.argtypes = [f32p, f32p, f32p, C.c_float, C.c_size_t]
     L.orc_have_avx_fma.restype = C.c_int
+    L.orc_have_avx512f.restype = C.c_int
+    L.orc_fir_bench_calls.restype = C.c_ulonglong
+    L.orc_fir_bench_calls.argtypes = [C.c_void_p, f32p, C.c_size_t, f32p, C.c_size_t, C.c_size_t]
     L.orc_fir_new.restype = C.c_void_p
     L.orc_fir_new.argtypes = [C.c_size_t, C.c_uint32, C.c_uint32, C.c_size_t, C.c_int, C.c_int]
     L.orc_fir_free.argtypes = [C.c_void_p]
@@ -190,13 +194,18 @@ def convolve_interp(x, c1, c2, frac, kind=CONVOLVE_SCALAR) -> float:
     a2 = buf[o2:o2 + taps]
     a1[:] = c1
     a2[:] = c2
-    fn = lib().orc_convolve_interp_avx_fma if kind == CONVOLVE_AVX_FMA else lib().orc_convolve_interp_scalar
+    fn = (lib().orc_convolve_interp_avx512 if kind == CONVOLVE_AVX512 else
+          lib().orc_convolve_interp_avx_fma if kind == CONVOLVE_AVX_FMA else lib().orc_convolve_interp_scalar)
     return float(fn(_f32p(x), a1.ctypes.data_as(C.POINTER(C.c_float)),
                     a2.ctypes.data_as(C.POINTER(C.c_float)), frac, taps))
 
 
 def have_avx_fma() -> bool:
     return bool(lib().orc_have_avx_fma())
+
+
+def have_avx512f() -> bool:
+    return bool(lib().orc_have_avx512f())
 
 
 # ---- resampler_fir.rs ----------------------------------------------------------------------
@@ -276,6 +285,11 @@ class OracleFir:
         k = min(nc.value, max_calls)
         return out[:n].copy(), calls[:2 * k].reshape(k, 2).astype(np.int64)
 
+
+    def bench_calls(self, inp: np.ndarray, out: np.ndarray, iterations: int) -> int:
+        """The criterion bench's inner loop (benches/benchmark_resampler_fir.rs:50-89): `iterations` resample() calls on the
+        same input; returns the values produced in total."""
+        return int(self._L.orc_fir_bench_calls(self._h, _f32p(inp), inp.size, _f32p(out), out.size, iterations))
 
     def resample_all_into(self, inp: np.ndarray, chunk_len: int, out: np.ndarray) -> int:
         """The same driver loop into a caller-owned buffer (no allocation: timing loops on many threads)."""

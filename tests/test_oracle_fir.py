@@ -61,6 +61,50 @@ def test_convolve_avx_matches_scalar(taps):     # fir/mod.rs:137-192
         assert abs(a - s) < 1e-5
 
 
+@pytest.mark.parametrize("taps", [16, 32, 64, 128])
+def test_convolve_avx512_matches_scalar(taps):  # fir/mod.rs:137-192, for fir/avx512.rs:5-50
+    """The leaf the reference's runtime dispatch takes FIRST where the CPU has avx512f (resampler_fir.rs:331-345) -- what its
+    published Zen 5 figures ran (bench.py cpu_baseline `avx512`).  The reference's own differential recipe and tolerance."""
+    if not o.have_avx512f():
+        pytest.skip("no AVX-512F on this host")
+    i = np.arange(taps, dtype=np.float32)
+    x = np.sin(i * np.float32(0.1)).astype(np.float32)
+    c1 = np.cos(i * np.float32(0.05)).astype(np.float32)
+    c2 = np.cos(i * np.float32(0.05) + np.float32(0.1)).astype(np.float32)
+    for frac in (0.0, 0.25, 0.5, 0.75, 1.0):
+        a = o.convolve_interp(x, c1, c2, frac, o.CONVOLVE_AVX512)
+        s = o.convolve_interp(x, c1, c2, frac, o.CONVOLVE_SCALAR)
+        assert abs(a - s) < 1e-5
+
+
+def test_avx512_stream_equals_the_avx_fma_stream_within_rounding():
+    """A whole stream through the AVX-512 leaf: counts identical to the AVX+FMA run (the control flow does not depend on the
+    leaf), samples within f32 rounding of it (two 16-lane chains instead of two 8-lane ones)."""
+    if not (o.have_avx512f() and o.have_avx_fma()):
+        pytest.skip("no AVX-512F on this host")
+    from resampler_amd import synth
+    x = synth.sweep(40000, 2, 44100.0)
+    ya, ca = o.OracleFir(2, 44100, 48000, 128, 90, o.CONVOLVE_AVX512).resample_all(x, 512)
+    yb, cb = o.OracleFir(2, 44100, 48000, 128, 90, o.CONVOLVE_AVX_FMA).resample_all(x, 512)
+    assert np.array_equal(ca, cb) and ya.size == yb.size
+    assert float(np.sqrt(np.mean((ya.astype(np.float64) - yb) ** 2))) < 2e-7
+
+
+def test_bench_calls_is_the_call_loop():         # benches/benchmark_resampler_fir.rs:50-89
+    from resampler_amd import synth
+    x = synth.lcg_noise(1024)
+    a = o.OracleFir(2, 44100, 48000, 128, 90)
+    b = o.OracleFir(2, 44100, 48000, 128, 90)
+    out = np.zeros(a.buffer_size_output(), np.float32)
+    total = a.bench_calls(x, out, 7)
+    want = 0
+    for _ in range(7):
+        rc, c, p = b.resample(x, out)
+        assert rc == 0
+        want += p
+    assert total == want and a.state() == b.state()
+
+
 def test_convolve_impulse():                    # fir/mod.rs:194-247
     taps = 32
     x = np.zeros(taps, np.float32)
