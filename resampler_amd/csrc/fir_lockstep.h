@@ -169,6 +169,14 @@ struct LsRunArgs {
     uint32_t n_streams, k, in_frames, wrap_words, append, hist_parity;
 };
 // parts: 1 = K1 (the predictions), 2 = K2 + K3 (chain, replay); 3 = all three in `stream`
+// The planner's serial kernels (chain, replay) pack kLsPlanPack streams into a workgroup -- one CU -- for batches of fewer than
+// kLsPlanPackBelow streams: the CUs they take are then few and known (lockstep_plan_cus), whoever reaches the chip first.
+constexpr uint32_t kLsPlanPack = 4, kLsPlanPackBelow = 256;   // (pack 1 / 2 / 4 / 8 at 128 streams: 0.89 / 0.71-0.86 / 0.73 / 0.83-0.95 us per step, profiles/r06/ab_c4_shard.txt: eight waves of this much CODE on one CU starve each other of instructions)
+uint32_t lockstep_plan_pack(size_t n_streams);   // (fir_lockstep_run.hip; RSMP_LS_PACK, debug: 1 / 2 / 4 / 8)
+inline uint32_t lockstep_plan_cus(size_t n_streams) {
+    const uint32_t pack = lockstep_plan_pack(n_streams);
+    return pack > 1 ? static_cast<uint32_t>((n_streams + pack - 1) / pack) : static_cast<uint32_t>((n_streams + 3) / 4);
+}
 hipError_t launch_fir_lockstep_plan(const LsRunArgs& args, hipStream_t stream, int parts = 3);
 // out[c] = states[reps[c]].drift: the drifts the batch's classes are watched by (one thread per class).
 hipError_t launch_fir_lockstep_gather_drift(const FirMirrorState* states, const uint32_t* reps, double* out, uint32_t n,

@@ -71,7 +71,10 @@ struct rsmp_fir_lockstep {
     hipEvent_t probe_ev = nullptr;
     hipStream_t probe_owner = nullptr;   // the caller's stream whose probe is in flight (one at a time)
     uint32_t probe_token = 0;
-    hipEvent_t ev_ready = nullptr, plan_done = nullptr;
+    hipEvent_t ev_ready = nullptr, plan_done = nullptr, ev_commit = nullptr;
+    hipStream_t ahead_q = nullptr;       // the plan stream the run planned ahead was enqueued on
+    uint64_t stat_table_ops = 0;         // patch launches + table uploads enqueued on a caller's stream (poll_drift, flush_tables)
+    uint64_t stat_commits_on_plan_stream = 0;
     struct RunKey { uint32_t k = 0, in_frames = 0, append = 0, parity = 0; uint64_t in_offset = 0, seq = 0; int slot = 0; bool valid = false; };
     RunKey ahead;               // what the plan stream was asked to plan
     bool ahead_inflight = false;   // ... and has not been waited for since
@@ -259,7 +262,10 @@ int poll_drift(rsmp_fir_lockstep* ls, hipStream_t s) {
     pa.n_patches = 0;
     pa.pad = 0;
     auto flush_patches = [&]() -> int {
-        if (pa.n_patches) RSMP_HIP_CHECK(rsmp::launch_fir_lockstep_patch_tables(pa, s));
+        if (pa.n_patches) {
+            RSMP_HIP_CHECK(rsmp::launch_fir_lockstep_patch_tables(pa, s));
+            ++ls->stat_table_ops;
+        }
         pa.n_patches = 0;
         return RSMP_OK;
     };
@@ -345,6 +351,7 @@ int poll_drift(rsmp_fir_lockstep* ls, hipStream_t s) {
 // been waited for.)
 int flush_tables(rsmp_fir_lockstep* ls, hipStream_t s) {
     if (!ls->groups_dirty && !ls->rs_dirty) return RSMP_OK;
+    ++ls->stat_table_ops;
     const size_t gb = ls->groups.size() * sizeof(LockstepGroup), rb = ls->h_run_rs.size() * sizeof(rsmp::LsRunStream);
     if (ls->stage_inflight) {   // (the staging memory of the previous change: long since read)
         RSMP_HIP_CHECK(hipEventSynchronize(ls->stage_ev));
@@ -652,7 +659,7 @@ extern "C" void rsmp_fir_lockstep_free(rsmp_fir_lockstep* ls) {
     if (ls->plan_stream) {
         ls->plan_stream = nullptr;
     }
-    for (hipEvent_t e : {ls->ev_ready, ls->plan_done, ls->slot[0].compute_done, ls->slot[1].compute_done})
+    for (hipEvent_t e : {ls->ev_ready, ls->plan_done, ls->ev_commit, ls->slot[0].compute_done, ls->slot[1].compute_done})
         if (e) (void)hipEventDestroy(e);
     if (ls->own_stream) {
         rsmp::split_release_stream(ls->device, ls->own_stream);
@@ -1017,6 +1024,7 @@ int prepare_run(rsmp_fir_lockstep* ls) {
         hipStreamCreateWithFlags(&ls->plan_candidates[1], hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&ls->ev_ready, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ls->plan_done, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ls->ev_commit, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ls->slot[0].compute_done, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ls->slot[1].compute_done, hipEventDisableTiming) != hipSuccess ||
         ls->d_run_rs.reserve(n * sizeof(rsmp::LsRunStream)) != hipSuccess ||
@@ -1153,6 +1161,7 @@ extern "C" int rsmp_fir_lockstep_run(rsmp_fir_lockstep* ls, size_t k_steps, size
     };
     if (ls->profiling)
         RSMP_HIP_CHECK(hipEventRecord(ls->prof_start[ls->prof_count % rsmp_fir_lockstep::kProfRing], s));
+    bool commit_on_q = false;   // this run's states were committed on the plan stream (below)
     if (same_key(ls->ahead, key)) {
         // planned while the previous run computed: wait for it (an event, no host block) and take its results over
         RSMP_HIP_CHECK(hipStreamWaitEvent(s, ls->plan_done, 0));
@@ -1161,8 +1170,20 @@ extern "C" int rsmp_fir_lockstep_run(rsmp_fir_lockstep* ls, size_t k_steps, size
         // (new tables: from the next plan on; this run was planned with the old ones, whose images nobody overwrites
         // before this run's kernels are through -- TableRefresher's guard event.  Behind the wait: the planner read
         // the stream table this may patch.)
+        const uint64_t table_ops0 = ls->stat_table_ops;
         if (int rc = poll_drift(ls, s)) return rc;
         if (int rc = flush_tables(ls, s)) return rc;
+        // A small batch's period is its PLANNER's (predict + chain + replay, ~150 us for 128 streams x 256 calls, against
+        // ~130 us of bulk kernels), and with the commit on the caller's stream the planner's loop crossed queues twice per
+        // run -- plan stream -> caller's stream (commit) -> plan stream (the next plan): two event hand-overs of ~12 us in a
+        // 185 us period (profiles/r06/c4_run_timeline_128_ahead1.txt).  So the commit goes to the PLAN stream, right behind
+        // the plan it commits, the next plan right behind it, and the caller's stream waits for the commit -- unless this
+        // call put something on the caller's stream that the next plan must see (new class tables: rare).
+        static const bool commit_knob = [] { const char* e = rsmp::knob("RSMP_LS_COMMIT_ON_PLAN"); return !e || atoi(e) != 0; }();
+        commit_on_q = commit_knob && n < 256 && ls->ahead_q != nullptr && ls->stat_table_ops == table_ops0;
+        hipStream_t cs = commit_on_q ? ls->ahead_q : s;
+        if (commit_on_q && ls->drift_inflight)   // (a reading of the states on the caller's stream: in front of what changes them)
+            RSMP_HIP_CHECK(hipStreamWaitEvent(cs, ls->drift_ev, 0));
         rsmp::LsCommitArgs c;
         c.states = ls->d_states.as<FirMirrorState>();
         c.sp_states = ls->sp_states.as<FirMirrorState>();
@@ -1173,7 +1194,12 @@ extern "C" int rsmp_fir_lockstep_run(rsmp_fir_lockstep* ls, size_t k_steps, size
         c.status = ls->d_status.as<uint32_t>();
         c.sp_status = ls->sp_status.as<uint32_t>();
         c.n_streams = static_cast<uint32_t>(n);
-        RSMP_HIP_CHECK(rsmp::launch_fir_lockstep_commit(c, s));
+        RSMP_HIP_CHECK(rsmp::launch_fir_lockstep_commit(c, cs));
+        if (commit_on_q) {
+            RSMP_HIP_CHECK(hipEventRecord(ls->ev_commit, cs));
+            RSMP_HIP_CHECK(hipStreamWaitEvent(s, ls->ev_commit, 0));
+            ++ls->stat_commits_on_plan_stream;
+        }
     } else {
         if (ls->ahead.valid) ++ls->stat_ahead_misses;
         if (int rc = drop_plan_ahead(ls, s)) return rc;   // (whatever the plan stream still does: finished before this stream goes on)
@@ -1214,10 +1240,17 @@ extern "C" int rsmp_fir_lockstep_run(rsmp_fir_lockstep* ls, size_t k_steps, size
         const bool k1_in_front = n >= 256;
         if (ls->slot[nx.slot].used) RSMP_HIP_CHECK(hipStreamWaitEvent(k1_in_front ? s : q, ls->slot[nx.slot].compute_done, 0));   // its buffers are free (long since)
         if (k1_in_front) RSMP_HIP_CHECK(rsmp::launch_fir_lockstep_plan(plan_args(nx, true), s, 1));
-        RSMP_HIP_CHECK(hipEventRecord(ls->ev_ready, s));   // the states after this run are in place (and the next run's predictions made)
-        RSMP_HIP_CHECK(hipStreamWaitEvent(q, ls->ev_ready, 0));
+        if (commit_on_q && !k1_in_front) {
+            // (the states after this run are in place on the plan stream itself: nothing to wait for, unless the probe has
+            // just moved the planner to the other candidate)
+            if (q != ls->ahead_q) RSMP_HIP_CHECK(hipStreamWaitEvent(q, ls->ev_commit, 0));
+        } else {
+            RSMP_HIP_CHECK(hipEventRecord(ls->ev_ready, s));   // the states after this run are in place (and the next run's predictions made)
+            RSMP_HIP_CHECK(hipStreamWaitEvent(q, ls->ev_ready, 0));
+        }
         RSMP_HIP_CHECK(rsmp::launch_fir_lockstep_plan(plan_args(nx, true), q, k1_in_front ? 2 : 3));
         RSMP_HIP_CHECK(hipEventRecord(ls->plan_done, q));
+        ls->ahead_q = q;
         ls->ahead = nx;
         ls->ahead_inflight = true;
     }
@@ -1260,7 +1293,8 @@ extern "C" int rsmp_fir_lockstep_run(rsmp_fir_lockstep* ls, size_t k_steps, size
     uint32_t reserve = 0;
     if (repeat && n < 256) {
         static const int knob = [] { const char* e = rsmp::knob("RSMP_LS_RESERVE"); return e ? atoi(e) : -1; }();
-        reserve = knob >= 0 ? static_cast<uint32_t>(knob) : static_cast<uint32_t>(std::min<size_t>(64, (n + 3) / 4 + 8));
+        // (the planner's packed workgroups take lockstep_plan_cus(n) CUs -- 32 for 128 streams --, + 4 for its one-wave kernels)
+        reserve = knob >= 0 ? static_cast<uint32_t>(knob) : std::min<uint32_t>(64u, rsmp::lockstep_plan_cus(n) + 4u);
     }
     if (!split_jobs.empty()) RSMP_HIP_CHECK(rsmp::launch_fir_split_multi(split_jobs.data(), split_jobs.size(), s, reserve));
     // (the repair launch copies the streams' tails as well: one launch and its gap less per run)

@@ -150,8 +150,14 @@ __device__ __forceinline__ uint32_t chain_fast_run_of(uint32_t shape, uint32_t s
     }
 }
 
-__global__ __launch_bounds__(64) void fir_lockstep_chain_kernel(LsRunArgs a) {
-    const uint32_t gs = blockIdx.x, lane = threadIdx.x;
+// (Waves per workgroup: one, or -- small batches -- kLsPlanPack, a stream each.  A wave of this kernel is a chain of dependent
+// f64 operations: four of them on one CU run as fast as one per CU (eight do not: the kernel is code, and a CU fetches it once for all its waves), and a batch of 128 streams then occupies 32 CUs
+// instead of a wave on each of 128 -- where no workgroup of the split kernel, which needs a CU's whole register file, could
+// start until that wave was through: whether the bulk launch or the planner reached the chip first made a run of the
+// 128-stream shard take 0.72 or 0.91 us per step, profiles/r06/ab_c4_shard.txt.)
+__global__ __launch_bounds__(64 * kLsPlanPack) void fir_lockstep_chain_kernel(LsRunArgs a) {
+    const uint32_t gs = blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (gs >= a.n_streams) return;
     const LockstepStream ls = a.streams[gs];
     const LsRunStream rs = a.rs[gs];
     FirMirrorState st = a.states_in[gs];
@@ -363,8 +369,9 @@ __global__ __launch_bounds__(64) void fir_lockstep_chain_kernel(LsRunArgs a) {
 // K3 -- the outputs at integer positions (the row-1023 variant's bitmap, the stream's drift): one wave per stream, a
 // lane per call replays its call's chain from the recorded start position (mirror_replay_wraps).  The drift the
 // stream ends with is that of the last call that had such an output.
-__global__ __launch_bounds__(64) void fir_lockstep_wraps_kernel(LsRunArgs a) {
-    const uint32_t gs = blockIdx.x, lane = threadIdx.x;
+__global__ __launch_bounds__(64 * kLsPlanPack) void fir_lockstep_wraps_kernel(LsRunArgs a) {
+    const uint32_t gs = blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (gs >= a.n_streams) return;
     const LsRunStream rs = a.rs[gs];
     const FirMirrorState st0 = a.states_before[gs];   // the state before the run
     const MirrorRunBase base = mirror_run_base(st0, a.in_frames, a.k);
@@ -530,13 +537,20 @@ hipError_t launch_fir_lockstep_gather_counts(const uint64_t* last_counts, const 
     return hipGetLastError();
 }
 
+uint32_t lockstep_plan_pack(size_t n_streams) {
+    static const uint32_t knob = [] { const char* e = rsmp::knob("RSMP_LS_PACK"); const int v = e ? atoi(e) : 0; return v == 1 || v == 2 || v == 4 || v == 8 ? static_cast<uint32_t>(v) : 0u; }();
+    if (n_streams >= kLsPlanPackBelow) return 1u;
+    return knob ? knob : kLsPlanPack;
+}
+
 hipError_t launch_fir_lockstep_plan(const LsRunArgs& args, hipStream_t stream, int parts) {
     if (args.n_streams == 0 || args.k == 0) return hipSuccess;
     const uint32_t blocks_per_stream = (args.k + 255) / 256;
     if (parts & 1) hipLaunchKernelGGL(fir_lockstep_predict_kernel, dim3(blocks_per_stream * args.n_streams), dim3(256), 0, stream, args, blocks_per_stream);
     if (parts & 2) {
-        hipLaunchKernelGGL(fir_lockstep_chain_kernel, dim3(args.n_streams), dim3(64), 0, stream, args);
-        hipLaunchKernelGGL(fir_lockstep_wraps_kernel, dim3(args.n_streams), dim3(64), 0, stream, args);
+        const uint32_t pack = lockstep_plan_pack(args.n_streams);
+        hipLaunchKernelGGL(fir_lockstep_chain_kernel, dim3((args.n_streams + pack - 1) / pack), dim3(64 * pack), 0, stream, args);
+        hipLaunchKernelGGL(fir_lockstep_wraps_kernel, dim3((args.n_streams + pack - 1) / pack), dim3(64 * pack), 0, stream, args);
     }
     return hipGetLastError();
 }

@@ -330,6 +330,7 @@ struct SplitMulti {
     uint32_t wg_end[kMaxSplitJobs];      // workgroups of jobs 0 .. j (fir_split_multi_kernel)
     uint32_t ib_end[kMaxSplitJobs];      // blocks of 256 items of jobs 0 .. j (split_items_multi_kernel)
     uint32_t n_jobs;
+    uint32_t build[kMaxSplitJobs];       // fir_split_all_kernel: which body a job's workgroups run (kSplitBuild*)
 };
 __device__ __forceinline__ uint32_t split_job_of(const uint32_t (&end)[kMaxSplitJobs], uint32_t n_jobs, uint32_t block, uint32_t& begin) {
     uint32_t j = 0;
@@ -1596,6 +1597,22 @@ __global__ __launch_bounds__(1024) void fir_split_multi_kernel(const SplitMulti 
     fir_split_body<NK, PLANES, false, WIDE, ROUNDS>(m.descs[j], m.g[j], blockIdx.x - begin, m.wg_end[j] - begin);
 }
 
+// The builds a run of config 4's six rate pairs needs -- one round with a five-step window (44.1 <-> 48 kHz, 44.1 / 48 -> 96 kHz),
+// two rounds with five (96 -> 48 kHz) or six steps (96 -> 44.1 kHz) -- in ONE kernel: a workgroup finds its job as in
+// fir_split_multi_kernel and runs the body of the job's build.  One launch per run instead of three: the two-round builds'
+// jobs are a quarter of the batch, alone they do not fill the chip (a 128-stream shard: 99 + 38 + 34 us one after the
+// other, each with its own ramp-up and tail), side by side they end with the one-round jobs.
+constexpr uint32_t kSplitBuild5x1 = 0, kSplitBuild5x2 = 1, kSplitBuild6x2 = 2;
+__global__ __launch_bounds__(1024) void fir_split_all_kernel(const SplitMulti m) {
+    uint32_t begin;
+    const uint32_t j = __builtin_amdgcn_readfirstlane(split_job_of(m.wg_end, m.n_jobs, blockIdx.x, begin));
+    begin = __builtin_amdgcn_readfirstlane(begin);
+    const uint32_t build = __builtin_amdgcn_readfirstlane(m.build[j]);
+    if (build == kSplitBuild5x1) fir_split_body<5, 2, false, 0, 1>(m.descs[j], m.g[j], blockIdx.x - begin, m.wg_end[j] - begin);
+    else if (build == kSplitBuild5x2) fir_split_body<5, 2, false, 0, 2>(m.descs[j], m.g[j], blockIdx.x - begin, m.wg_end[j] - begin);
+    else fir_split_body<6, 2, false, 0, 2>(m.descs[j], m.g[j], blockIdx.x - begin, m.wg_end[j] - begin);
+}
+
 inline uint32_t split_class_offset(uint32_t a, uint32_t b, uint32_t j) {
     return static_cast<uint32_t>((static_cast<uint64_t>(j) * a) / b);
 }
@@ -1971,6 +1988,17 @@ hipError_t launch_fir_split_multi(const SplitJob* jobs, size_t n_jobs, hipStream
         if (nk < 1 || nk > 6 || (g.rounds != 1 && g.rounds != 2)) return nullptr;
         return fns_multi[g.rounds - 1][nk - 1];
     };
+    // (RSMP_FIR_SPLIT_ALL=0, debug: one launch per kernel build as in round 5)
+    static const bool all_on = [] { const char* v = rsmp::knob("RSMP_FIR_SPLIT_ALL"); return !v || atoi(v) != 0; }();
+    const void* const fn_all = reinterpret_cast<const void*>(fir_split_all_kernel);
+    auto all_build = [&](const PeriodicGeometry& g, uint32_t* build) -> bool {
+        const uint32_t nk = g.row_len / 32;
+        if (g.rounds == 1 && nk == 5) *build = kSplitBuild5x1;
+        else if (g.rounds == 2 && nk == 5) *build = kSplitBuild5x2;
+        else if (g.rounds == 2 && nk == 6) *build = kSplitBuild6x2;
+        else return false;
+        return true;
+    };
     // jobs the multi-job builds do not cover: a launch each, as before
     std::vector<size_t> covered;
     for (size_t j = 0; j < n_jobs; ++j) {
@@ -1983,12 +2011,23 @@ hipError_t launch_fir_split_multi(const SplitJob* jobs, size_t n_jobs, hipStream
         const uint32_t n = static_cast<uint32_t>(std::min<size_t>(kMaxSplitJobs, covered.size() - c0));
         SplitArgs args[kMaxSplitJobs];
         const void* fn[kMaxSplitJobs];
+        uint32_t build[kMaxSplitJobs] = {};
         size_t total_items = 0;
         for (uint32_t i = 0; i < n; ++i) {
             const SplitJob& job = jobs[covered[c0 + i]];
             args[i] = make_split_args(*job.geo, job.n_streams, job.max_blocks, false, job.nf);
             fn[i] = multi_fn(*job.geo);
             total_items += args[i].total_items;
+        }
+        // jobs of more than one build, all of them builds of fir_split_all_kernel: one launch for the lot
+        {
+            bool every = all_on && n > 1, mixed = false;
+            for (uint32_t i = 0; i < n && every; ++i) {
+                every = all_build(*jobs[covered[c0 + i]].geo, &build[i]);
+                mixed = mixed || fn[i] != fn[0];
+            }
+            if (every && mixed)
+                for (uint32_t i = 0; i < n; ++i) fn[i] = fn_all;
         }
         // one item table after the other in the stream's workspace, built by one launch
         uint32_t* d_items = nullptr;
@@ -2086,6 +2125,7 @@ hipError_t launch_fir_split_multi(const SplitJob* jobs, size_t n_jobs, hipStream
             for (uint32_t b = 0; b < nb; ++b) {
                 m.g[b] = args[idx[b]];
                 m.descs[b] = jobs[covered[c0 + idx[b]]].d_descs;
+                m.build[b] = build[idx[b]];
                 end += share[b];
                 m.wg_end[b] = end;
             }
