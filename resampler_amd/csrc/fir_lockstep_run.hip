@@ -14,6 +14,7 @@
 //   * the stream's state after the run.
 // The bulk kernels (fir_split.hip, fir_periodic.hip) then read those descriptors: nothing of a run passes
 // through the host, whatever states the streams are in.
+#include <algorithm>
 #include "fir_lockstep.h"
 
 #include "common.h"
@@ -369,9 +370,17 @@ __global__ __launch_bounds__(64 * kLsPlanPack) void fir_lockstep_chain_kernel(Ls
 // K3 -- the outputs at integer positions (the row-1023 variant's bitmap, the stream's drift): one wave per stream, a
 // lane per call replays its call's chain from the recorded start position (mirror_replay_wraps).  The drift the
 // stream ends with is that of the last call that had such an output.
-__global__ __launch_bounds__(64 * kLsPlanPack) void fir_lockstep_wraps_kernel(LsRunArgs a) {
-    const uint32_t gs = blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
-    if (gs >= a.n_streams) return;
+// (Waves per workgroup = per stream: one walks the run's chunks of 64 calls one after the other -- large batches: "a wave
+// per chunk, four times the waves at 256 calls, was measured slower, 59 against 33 us per run of config 4" --; small batches,
+// whose period is the planner's own latency, give every chunk of a round of kLsWrapWaves chunks a wave of its own and
+// settle the stream's drift -- that of the LAST call with an output at an integer position -- through LDS: 32 -> ~10 us
+// per run at 128 streams x 256 calls.)
+constexpr uint32_t kLsWrapWaves = 4;
+__global__ __launch_bounds__(64 * kLsWrapWaves) void fir_lockstep_wraps_kernel(LsRunArgs a) {
+    __shared__ double s_drift[kLsWrapWaves];
+    __shared__ uint32_t s_chunk[kLsWrapWaves], s_flags[kLsWrapWaves];
+    const uint32_t gs = blockIdx.x, lane = threadIdx.x & 63u;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), n_waves = blockDim.x >> 6;
     const LsRunStream rs = a.rs[gs];
     const FirMirrorState st0 = a.states_before[gs];   // the state before the run
     const MirrorRunBase base = mirror_run_base(st0, a.in_frames, a.k);
@@ -382,10 +391,9 @@ __global__ __launch_bounds__(64 * kLsPlanPack) void fir_lockstep_wraps_kernel(Ls
     const MirrorPred* preds = a.preds + static_cast<size_t>(gs) * a.k;
     const CallRec* recs = reinterpret_cast<const CallRec*>(a.call_recs) + static_cast<size_t>(gs) * a.k;
     double drift = st0.drift;
-    bool have = false, aperiodic = false, overflow = false, unchecked = false;
-    // (the chunks of a stream one after the other on one wave: a wave per chunk -- four times the waves at 256 calls --
-    // was measured slower, 59 against 33 us per run of config 4)
-    for (uint32_t c0 = 0; c0 < a.k; c0 += 64) {
+    uint32_t have_chunk = 0;   // 1 + the index of this wave's last chunk with an output at an integer position
+    bool aperiodic = false, overflow = false, unchecked = false;
+    for (uint32_t c0 = 64u * wave, chunk = wave; c0 < a.k; c0 += 64u * n_waves, chunk += n_waves) {
         const uint32_t c = c0 + lane;
         bool has_int = false;
         double my_drift = 0.0;
@@ -416,13 +424,32 @@ __global__ __launch_bounds__(64 * kLsPlanPack) void fir_lockstep_wraps_kernel(Ls
         if (m) {
             const int last = 63 - __builtin_clzll(m);
             drift = __shfl(my_drift, last, 64);
-            have = true;
+            have_chunk = chunk + 1;
         }
     }
     aperiodic = __any(aperiodic);
     overflow = __any(overflow);
     unchecked = __any(unchecked);
     if (lane == 0) {
+        s_drift[wave] = drift;
+        s_chunk[wave] = have_chunk;
+        s_flags[wave] = (aperiodic ? 1u : 0u) | (overflow ? 2u : 0u) | (unchecked ? 4u : 0u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        bool have = false;
+        uint32_t best = 0, fl = 0;
+        for (uint32_t w = 0; w < n_waves; ++w) {
+            fl |= s_flags[w];
+            if (s_chunk[w] > best) {
+                best = s_chunk[w];
+                drift = s_drift[w];
+                have = true;
+            }
+        }
+        aperiodic = (fl & 1u) != 0;
+        overflow = (fl & 2u) != 0;
+        unchecked = (fl & 4u) != 0;
         // the class tables of the run's descriptor follow the stream's drift (LsRunStream; written here and not by the
         // chain kernel: four more values alive across its loop were 28 more spilled registers, 10 % of its time)
         FirStreamDesc* d = a.descs + gs;
@@ -550,7 +577,10 @@ hipError_t launch_fir_lockstep_plan(const LsRunArgs& args, hipStream_t stream, i
     if (parts & 2) {
         const uint32_t pack = lockstep_plan_pack(args.n_streams);
         hipLaunchKernelGGL(fir_lockstep_chain_kernel, dim3((args.n_streams + pack - 1) / pack), dim3(64 * pack), 0, stream, args);
-        hipLaunchKernelGGL(fir_lockstep_wraps_kernel, dim3((args.n_streams + pack - 1) / pack), dim3(64 * pack), 0, stream, args);
+        // (the replay: a wave per chunk of 64 calls for small batches, one wave per stream otherwise)
+        const uint32_t chunks = (args.k + 63) / 64;
+        const uint32_t wwaves = pack > 1 ? std::min<uint32_t>(kLsWrapWaves, chunks) : 1u;
+        hipLaunchKernelGGL(fir_lockstep_wraps_kernel, dim3(args.n_streams), dim3(64 * wwaves), 0, stream, args);
     }
     return hipGetLastError();
 }
