@@ -2063,21 +2063,10 @@ hipError_t launch_fir_split_multi(const SplitJob* jobs, size_t n_jobs, hipStream
                 if (done[i] || fn[i] != fn[i0]) continue;
                 done[i] = true;
                 idx[nb] = i;
-                // What an item costs its workgroup, by the job's geometry -- measured alone, 64 streams x 2^20 frames on 256
-                // workgroups (profiles/r05/channels_bench.txt): 44.1 -> 48 kHz 2.46 us, 48 -> 44.1 3.00, 44.1 -> 96 2.80 and 48 -> 96
-                // 2.88 (two tile groups: an item per group), 96 -> 44.1 4.39 and 96 -> 48 4.34 (two rounds of lane tasks).  Round 5
-                // dealt the workgroups by items x frames of a period alone, which gives a two-round item (320 frames) 2.1x a
-                // 147-frame one where it takes 1.6-1.8x as long: a run of config 4's six rate pairs ended its two-round jobs 30 %
-                // early and was 11 % longer than an even deal (RSMP_FIR_SPLIT_WEIGHTS=0, debug: the old weights).
-                static const bool cost_weights = [] { const char* v = rsmp::knob("RSMP_FIR_SPLIT_WEIGHTS"); return !v || atoi(v) != 0; }();
-                const PeriodicGeometry& geo_i = *jobs[covered[c0 + i]].geo;
-                double per_frame = 1.0;
-                if (cost_weights) {
-                    if (geo_i.rounds == 2) per_frame = 4.37 / 320.0;
-                    else if (args[i].groups > 1) per_frame = 2.84 / 153.5;
-                    else per_frame = args[i].a < args[i].b ? 2.46 / 147.0 : 3.00 / 160.0;
-                }
-                weight[nb] = static_cast<double>(args[i].total_items) * args[i].a * per_frame;
+                // (items x frames of a period.  Round 6 tried the items' costs measured job by job instead -- 2.46 .. 4.39 us per item,
+                // profiles/r05/channels_bench.txt, by which this deal gives the two-round jobs 30 % too many workgroups: config 4 got
+                // 2 % SLOWER, 3.48 against 3.41 us per step in one lease; inside the shared launch the jobs do not cost what they cost alone)
+                weight[nb] = static_cast<double>(args[i].total_items) * args[i].a;
                 weight_sum += weight[nb];
                 items_sum += args[i].total_items;
                 lds = std::max(lds, args[i].lds_bytes);
