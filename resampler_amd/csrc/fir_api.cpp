@@ -508,7 +508,8 @@ int launch_jobs(rsmp_fir* leader, std::vector<Job>& jobs, hipStream_t stream, ui
     char* d = direct ? leader->h_plan[slot].as<char>() : leader->d_plan[slot].as<char>();
     FirStreamDesc* descs = reinterpret_cast<FirStreamDesc*>(h);
 
-    uint32_t max_out_generic = 0, max_ch_generic = 0, max_tail_values = 0, max_wraps = 0;
+    uint32_t max_out_generic = 0, max_ch_generic = 0, max_tail_values = 0, max_wraps = 0, max_taps_generic = 0, min_ch_generic = 0xFFFFFFFFu, min_taps_generic = 0xFFFFFFFFu;
+    double max_ratio_generic = 0.0;
     for (size_t slot = 0; slot < n; ++slot) {
         Job& j = jobs[order[slot]];
         const Plan& pl = *j.plan;
@@ -551,6 +552,10 @@ int launch_jobs(rsmp_fir* leader, std::vector<Job>& jobs, hipStream_t stream, ui
             }
             if (ds.n_out > max_out_generic) max_out_generic = ds.n_out;
             if (ch > max_ch_generic) max_ch_generic = ch;
+            if (ch < min_ch_generic) min_ch_generic = ch;
+            if (ds.taps > max_taps_generic) max_taps_generic = ds.taps;
+            if (ds.taps < min_taps_generic) min_taps_generic = ds.taps;
+            max_ratio_generic = std::max(max_ratio_generic, static_cast<double>(r->in_hz) / static_cast<double>(r->out_hz));
         } else {
             const rsmp::PeriodicGeometry& geo = r->periodic.geo;
             ds.drift = r->periodic.table_drift;
@@ -603,7 +608,19 @@ int launch_jobs(rsmp_fir* leader, std::vector<Job>& jobs, hipStream_t stream, ui
     // a launch made of generic-kernel streams only (a streaming call, a batch of them) lets that kernel copy
     // the tails as well: one launch per call instead of two
     bool tail_fused = n_generic == n && max_out_generic != 0;
-    if (n_generic)
+    // Long launches of streams without a short period (arbitrary rates, src/resampler_fir.rs:295-301) take the tiled kernel,
+    // whose workgroups sort a tile's outputs by phase row and stage its window in LDS (fir_generic_bulk.hip); streaming calls
+    // keep the one-launch latency path.  (RSMP_FIR_GENERIC_BULK=0, debug: the latency kernel for everything.)
+    static const bool bulk_on = [] { const char* e = rsmp::knob("RSMP_FIR_GENERIC_BULK"); return !e || atoi(e) != 0; }();
+    const bool generic_bulk = bulk_on && n_generic != 0 && max_out_generic >= rsmp::kFirBulkMinOut &&
+                              rsmp::fir_generic_bulk_tile(max_ch_generic, max_taps_generic, max_ratio_generic) != 0;
+    if (generic_bulk) {
+        tail_fused = false;
+        RSMP_HIP_CHECK(rsmp::launch_fir_generic_bulk(d_descs, static_cast<uint32_t>(n_generic), max_out_generic, max_ch_generic,
+                                                     max_taps_generic, max_ratio_generic, stream,
+                                                     min_ch_generic == max_ch_generic ? max_ch_generic : 0u,
+                                                     min_taps_generic == max_taps_generic ? max_taps_generic : 0u));
+    } else if (n_generic)
         RSMP_HIP_CHECK(rsmp::launch_fir_generic(d_descs, static_cast<uint32_t>(n_generic),
                                                 max_out_generic, max_ch_generic, stream, tail_fused));
     size_t first = n_generic;

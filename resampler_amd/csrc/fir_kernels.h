@@ -68,6 +68,15 @@ constexpr uint32_t kFirTile = 32;   // output frames per workgroup tile (generic
 // Generic kernel: any ratio, reference-form two-row interpolation; grid = (max tiles, streams).
 hipError_t launch_fir_generic(const FirStreamDesc* d_descs, uint32_t n_streams, uint32_t max_out,
                               uint32_t max_channels, hipStream_t stream, bool fuse_tail = false);
+// The same arithmetic for LONG launches (fir_generic_bulk.hip): tiles of up to 4096 output frames per workgroup, their outputs sorted
+// by phase row, the tile's input window in LDS.  hipErrorNotSupported where no tile fits the LDS (fir_generic_bulk_tile == 0);
+// does not copy the tails (launch_fir_tail_copy).
+uint32_t fir_generic_bulk_tile(uint32_t max_channels, uint32_t max_taps, double max_ratio);
+// (uniform_channels: 1 / 2 = every stream has that many channels -- the builds for them --, anything else = any counts)
+hipError_t launch_fir_generic_bulk(const FirStreamDesc* d_descs, uint32_t n_streams, uint32_t max_out, uint32_t max_channels,
+                                   uint32_t max_taps, double max_ratio, hipStream_t stream, uint32_t uniform_channels = 0,
+                                   uint32_t uniform_taps = 0);   // (uniform_taps: 128 = every stream has 128 taps)
+constexpr uint32_t kFirBulkMinOut = 8192;   // launches whose longest generic stream produces fewer frames keep fir_generic_kernel
 // Re-evaluates, in the reference's two-row form, the output chunks a periodic launch marked as non-finite
 // (fir_nonfinite.h); exits at once when the launch marked nothing.
 hipError_t launch_fir_repair(const FirStreamDesc* d_descs, uint32_t n_streams, const NfArgs& nf, hipStream_t stream);

@@ -661,6 +661,33 @@ print("three planes ok")
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("ch,in_hz,out_hz,latency,frames", [
+    (2, 44100, 47999, "Sample64", 90000), (1, 44100, 47999, "Sample64", 70000), (3, 48000, 44101, "Sample64", 50000),
+    (2, 96000, 44101, "Sample64", 120000), (8, 44100, 47999, "Sample64", 30000), (2, 44101, 47999, "Sample16", 60000),
+    (2, 47999, 44100, "Sample32", 60000), (5, 44100, 47999, "Sample8", 40000)])
+def test_long_launches_of_ratios_without_a_short_period(ch, in_hz, out_hz, latency, frames):
+    """ResamplerFir::new_from_hz with arbitrary rates (src/resampler_fir.rs:295-301, tested at :841-862): a ratio like 44100 / 47999 has
+    no short period, every output has a phase row of its own.  Long launches of such streams take fir_generic_bulk.hip -- tiles of up to
+    4096 outputs sorted by phase row, the tile's window in LDS --: counts identical to the reference's call loop,
+    samples within 1e-6 RMS of the AVX+FMA oracle relative to the signal; 1 / 2 / odd / many channels, 16 .. 128 taps, both directions.
+    The launch's end state goes on into a second launch (its history buffer is what the first one left)."""
+    lat = getattr(ra.Latency, latency)
+    kind = o.CONVOLVE_AVX_FMA if o.have_avx_fma() else o.CONVOLVE_SCALAR
+    gpu = ra.ResamplerFir.new_from_hz(ch, in_hz, out_hz, lat, ra.Attenuation.Db90)
+    ref = o.OracleFir(ch, in_hz, out_hz, 2 * int(latency[len("Sample"):]), 90, kind)
+    x = synth.sweep(frames, ch, float(in_hz))
+    chunk = 512 - 512 % ch
+    half = (frames // 2) * ch
+    for part in (x[:half], x[half:]):
+        yg, consumed, calls_g = gpu.resample_bulk(part, chunk, want_calls=True)
+        yr, calls_r = ref.resample_all(part, chunk)
+        assert gpu.kernel_variant() == 0, gpu.kernel_variant()   # (no periodic kernel takes these ratios)
+        assert yg.size == yr.size and np.array_equal(calls_g, calls_r)
+        e = float(np.sqrt(np.mean((yg.astype(np.float64) - yr) ** 2))) / float(np.sqrt(np.mean(yr.astype(np.float64) ** 2)))
+        assert e <= 1e-6, (ch, in_hz, out_hz, e)
+
+
+@pytest.mark.gpu
 def test_clean_audio_needs_no_repair_pass_in_a_child_process():
     """The repair pass (fir_nonfinite.h) exists for inf / NaN / out-of-range samples and for items whose predicted scale was
     off; clean audio must come out of the periodic kernels right BY ITSELF.  Round 5 shipped odd channel counts that did
