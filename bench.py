@@ -513,11 +513,57 @@ def fir_channels_point(ctx: Ctx, ra, args, channels: int, steps: int):
         step()
     k_ms, _ = handles[0].mean_kernel_ms()
     handles[0].set_profiling(False)
+    # ... and the wall clock of a step (reset + launch + the repair launch behind it, which the kernel's events do not bracket:
+    # round 5's three-channel launch spent 1.0 ms THERE -- profiles/r06/odd_channels_repair.txt)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(8):
+        step()
+    torch.cuda.synchronize()
+    wall_ms = (time.perf_counter() - t0) / 8 * 1e3
     alg = 4.0 * (S * channels * N + out_values) + 4.0 * 1024 * 128
     ach = alg / (k_ms * 1e-3) / 1e9
     point = {"kernel": KERNEL_NAMES.get(handles[0].kernel_variant(), "?"), "streams": S, "kernel_ms": round(k_ms, 4),
              "achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4),
+             "step_ms_wall": round(wall_ms, 4), "frac_wall": round(alg / (wall_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
              "Msamples_in_per_s_kernel": round(S * channels * N / (k_ms * 1e-3) / 1e6, 1)}
+    del batch, handles
+    return point
+
+
+def fir_nonperiodic_point(ctx: Ctx, ra, args):
+    """A ratio without a short period (ResamplerFir::new_from_hz with arbitrary rates: 2 ch 44100 -> 47999 Hz), the headline's batch
+    shape: fir_generic_bulk.hip (tiles sorted by phase row).  Wall clock of a step."""
+    from resampler_amd import synth
+    torch = ctx.torch
+    S, N = args.streams, args.frames
+    handles = [ra.ResamplerFir.new_from_hz(CHANNELS, 44100, 47999, ra.Latency.Sample64, ra.Attenuation.Db90, device=ctx.local_rank) for _ in range(S)]
+    x = torch.from_numpy(synth.fast_noise(N * CHANNELS, seed=11)).to(ctx.dev)
+    gains = torch.linspace(0.5, 1.0, S, device=ctx.dev)
+    d_in = [(x * gains[i]).contiguous() for i in range(S)]
+    cap = handles[0].bulk_output_bound(CHANNELS * N, args.chunk)
+    d_out = [torch.empty(cap, device=ctx.dev, dtype=torch.float32) for _ in range(S)]
+    batch = ra.FirBatch(handles)
+    batch.bind(d_in, d_out)
+
+    def step():
+        batch.reset()
+        return batch.resample_bulk_device(args.chunk, ctx.stream)
+    consumed, produced = step()
+    out_values = int(sum(produced))
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        step()
+    torch.cuda.synchronize()
+    wall_ms = (time.perf_counter() - t0) / 5 * 1e3
+    alg = 4.0 * (S * CHANNELS * N + out_values) + 4.0 * 1024 * 128
+    point = {"workload": f"2 ch 44100 -> 47999 Hz, {S} streams x {N} frames, 512-value calls", "kernel": "fir_generic_bulk_kernel (reference two-row form, f32)",
+             "kernel_variant": handles[0].kernel_variant(), "step_ms_wall": round(wall_ms, 4),
+             "frac_wall": round(alg / (wall_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+             "Msamples_in_per_s": round(S * CHANNELS * N / (wall_ms * 1e-3) / 1e6, 1)}
     del batch, handles
     return point
 
@@ -881,7 +927,8 @@ def secondary_lines(ctx: Ctx, args):
     except Exception as e:   # (the headline does not depend on it)
         sec["fir_split_bf16x3"] = {"error": repr(e)[:200]}
     # other channel counts on the default kernel (same rate pair and taps)
-    guard("fir_channels", lambda: {str(c): fir_channels_point(ctx, ra, args, c, 64) for c in (1, 4, 8)})
+    guard("fir_channels", lambda: {str(c): fir_channels_point(ctx, ra, args, c, 48) for c in (1, 3, 4, 6, 8)})
+    guard("fir_nonperiodic", lambda: fir_nonperiodic_point(ctx, ra, args))
     guard("fir_pcm16", lambda: fir_pcm_point(ctx, ra, args, 16, 32))
     def distinct_point():
         # the same launch with every stream in a different state: nothing shares a plan
