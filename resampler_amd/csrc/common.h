@@ -6,6 +6,8 @@
 #include <cstdlib>
 #include <string>
 
+#include <hip/hip_runtime.h>
+
 #include "../../include/resampler_amd.h"
 
 namespace rsmp {
@@ -23,6 +25,17 @@ inline const char* knob(const char* name) {
 // Thread-local message returned by rsmp_last_error().
 std::string& last_error_slot();
 int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+
+// hipEventRecord / hipStreamWaitEvent for a stream that may be the caller's RSMP_STREAM_LEGACY.  This image's runtime
+// takes the legacy handle (hipStreamLegacy == (hipStream_t)1) in kernel launches and copies, but an event RECORDED with
+// it keeps the handle as its stream, and a later hipStreamWaitEvent on that event (or with the handle as the waiting
+// stream) dereferences it -- a segfault inside hip::hipStreamWaitEvent_common, found by tools/run_bulk_probe.py under
+// torch's default stream (runs planned ahead are the first path that waits for an event recorded on the caller's
+// stream).  The null stream IS the legacy default stream in this library's build (no per-thread default stream), so
+// events are given that.
+inline hipStream_t event_stream(hipStream_t s) { return s == reinterpret_cast<hipStream_t>(RSMP_STREAM_LEGACY) ? nullptr : s; }
+inline hipError_t event_record(hipEvent_t ev, hipStream_t s) { return hipEventRecord(ev, event_stream(s)); }
+inline hipError_t stream_wait_event(hipStream_t s, hipEvent_t ev) { return hipStreamWaitEvent(event_stream(s), ev, 0); }
 
 }  // namespace rsmp
 

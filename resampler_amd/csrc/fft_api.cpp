@@ -204,7 +204,7 @@ int launch_fft_jobs(rsmp_fft* leader, const std::vector<FftJob>& jobs, hipStream
         // (an event, not the previous stream's handle: the caller may have destroyed that stream by now, and a wait on an
         // event neither blocks the host nor breaks a stream capture)
         if (h->last_stream_valid && h->last_stream != stream && h->last_launch)
-            RSMP_HIP_CHECK(hipStreamWaitEvent(stream, h->last_launch->ev, 0));
+            RSMP_HIP_CHECK(rsmp::stream_wait_event(stream, h->last_launch->ev));
         h->last_stream = stream;
         h->last_stream_valid = true;
     }
@@ -256,11 +256,11 @@ int launch_fft_jobs(rsmp_fft* leader, const std::vector<FftJob>& jobs, hipStream
     const FftStreamDesc* d_descs = h;   // (mapped host memory: the same address on the device)
     if (!direct) {
         RSMP_HIP_CHECK(hipMemcpyAsync(leader->d_desc.get(), h, bytes, hipMemcpyHostToDevice, stream));
-        RSMP_HIP_CHECK(hipEventRecord(leader->desc_copied, stream));
+        RSMP_HIP_CHECK(rsmp::event_record(leader->desc_copied, stream));
         leader->desc_pending = true;
         d_descs = leader->d_desc.as<FftStreamDesc>();
     }
-    if (leader->profiling) RSMP_HIP_CHECK(hipEventRecord(leader->prof_start, stream));
+    if (leader->profiling) RSMP_HIP_CHECK(rsmp::event_record(leader->prof_start, stream));
     {
         const hipError_t e = rsmp::launch_fft_ola(leader->plan->dev, d_descs, static_cast<uint32_t>(n),
                                                   max_blocks, max_channels, min_channels, stream, pcm_bits);
@@ -270,16 +270,16 @@ int launch_fft_jobs(rsmp_fft* leader, const std::vector<FftJob>& jobs, hipStream
         RSMP_HIP_CHECK(e);
     }
     if (leader->profiling) {
-        RSMP_HIP_CHECK(hipEventRecord(leader->prof_stop, stream));
+        RSMP_HIP_CHECK(rsmp::event_record(leader->prof_stop, stream));
         leader->prof_valid = true;
     }
     if (!leader->launch_ev) {
         leader->launch_ev = std::make_shared<LaunchEvent>();
         RSMP_HIP_CHECK(hipEventCreateWithFlags(&leader->launch_ev->ev, hipEventDisableTiming));
     }
-    RSMP_HIP_CHECK(hipEventRecord(leader->launch_ev->ev, stream));
+    RSMP_HIP_CHECK(rsmp::event_record(leader->launch_ev->ev, stream));
     if (direct) {   // the slot may be rewritten once this launch's kernels have read it
-        RSMP_HIP_CHECK(hipEventRecord(leader->desc_read[slot], stream));
+        RSMP_HIP_CHECK(rsmp::event_record(leader->desc_read[slot], stream));
         leader->desc_slot_used[slot] = true;
     }
     for (const FftJob& j : jobs) {

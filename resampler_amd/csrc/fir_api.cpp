@@ -597,14 +597,14 @@ int launch_jobs(rsmp_fir* leader, std::vector<Job>& jobs, hipStream_t stream, ui
         RSMP_HIP_CHECK(leader->h_plan[slot].reserve(bytes));
         std::memcpy(leader->h_plan[slot].get(), h, bytes);
         RSMP_HIP_CHECK(hipMemcpyAsync(d, leader->h_plan[slot].get(), bytes, hipMemcpyHostToDevice, stream));
-        RSMP_HIP_CHECK(hipEventRecord(leader->plan_copied[slot], stream));
+        RSMP_HIP_CHECK(rsmp::event_record(leader->plan_copied[slot], stream));
         leader->plan_pending[slot] = true;
         leader->plan_image[slot].swap(leader->plan_scratch);
     }
 
     const FirStreamDesc* d_descs = reinterpret_cast<const FirStreamDesc*>(d);
     if (leader->profiling)
-        RSMP_HIP_CHECK(hipEventRecord(leader->prof_start[leader->prof_count % rsmp_fir::kProfRing], stream));
+        RSMP_HIP_CHECK(rsmp::event_record(leader->prof_start[leader->prof_count % rsmp_fir::kProfRing], stream));
     // a launch made of generic-kernel streams only (a streaming call, a batch of them) lets that kernel copy
     // the tails as well: one launch per call instead of two
     bool tail_fused = n_generic == n && max_out_generic != 0;
@@ -692,7 +692,7 @@ int launch_jobs(rsmp_fir* leader, std::vector<Job>& jobs, hipStream_t stream, ui
     }
     if (!split_jobs.empty()) RSMP_HIP_CHECK(rsmp::launch_fir_split_multi(split_jobs.data(), split_jobs.size(), stream));
     if (leader->profiling) {
-        RSMP_HIP_CHECK(hipEventRecord(leader->prof_stop[leader->prof_count % rsmp_fir::kProfRing], stream));
+        RSMP_HIP_CHECK(rsmp::event_record(leader->prof_stop[leader->prof_count % rsmp_fir::kProfRing], stream));
         ++leader->prof_count;
     }
     // (RSMP_FIR_NO_REPAIR, debug: what the periodic kernels wrote, without the repair pass -- tools/repair_probe.py)
@@ -735,7 +735,7 @@ int launch_jobs(rsmp_fir* leader, std::vector<Job>& jobs, hipStream_t stream, ui
         RSMP_HIP_CHECK(rsmp::launch_fir_tail_copy(d_descs, static_cast<uint32_t>(n), max_tail_values,
                                                   stream));
     if (direct) {   // the slot may be rewritten once these kernels have read it
-        RSMP_HIP_CHECK(hipEventRecord(leader->plan_copied[slot], stream));
+        RSMP_HIP_CHECK(rsmp::event_record(leader->plan_copied[slot], stream));
         leader->plan_pending[slot] = true;
         leader->plan_image[slot].clear();
     }

@@ -367,7 +367,7 @@ int flush_tables(rsmp_fir_lockstep* ls, hipStream_t s) {
         std::memcpy(h + gb, ls->h_run_rs.data(), rb);
         RSMP_HIP_CHECK(hipMemcpyAsync(ls->d_run_rs.get(), h + gb, rb, hipMemcpyHostToDevice, s));
     }
-    RSMP_HIP_CHECK(hipEventRecord(ls->stage_ev, s));
+    RSMP_HIP_CHECK(rsmp::event_record(ls->stage_ev, s));
     ls->stage_inflight = true;
     ls->groups_dirty = ls->rs_dirty = false;
     return RSMP_OK;
@@ -385,7 +385,7 @@ int request_drift(rsmp_fir_lockstep* ls, hipStream_t s, uint64_t frames) {
     // stream ~0.1 ms of cross-queue synchronisation, 6-9 % of config 4's step when done every fourth run)
     RSMP_HIP_CHECK(rsmp::launch_fir_lockstep_gather_drift(ls->d_states.as<FirMirrorState>(), ls->d_drift_reps.as<uint32_t>(),
                                                           ls->h_drift.as<double>(), nc, s));
-    RSMP_HIP_CHECK(hipEventRecord(ls->drift_ev, s));
+    RSMP_HIP_CHECK(rsmp::event_record(ls->drift_ev, s));
     ls->drift_inflight = true;
     ls->frames_at_inflight = ls->frames_total;
     ls->frames_since_drift = 0;
@@ -763,10 +763,10 @@ extern "C" int rsmp_fir_lockstep_step(rsmp_fir_lockstep* ls, size_t in_frames, s
     ls->hist_parity ^= 1u;
     ls->run_counts_k = 0;
     if (ls->profiling)
-        RSMP_HIP_CHECK(hipEventRecord(ls->prof_start[ls->prof_count % rsmp_fir_lockstep::kProfRing], s));
+        RSMP_HIP_CHECK(rsmp::event_record(ls->prof_start[ls->prof_count % rsmp_fir_lockstep::kProfRing], s));
     RSMP_HIP_CHECK(rsmp::launch_fir_lockstep(a, static_cast<uint32_t>(ls->groups.size()), ls->max_lds, s));
     if (ls->profiling) {
-        RSMP_HIP_CHECK(hipEventRecord(ls->prof_stop[ls->prof_count % rsmp_fir_lockstep::kProfRing], s));
+        RSMP_HIP_CHECK(rsmp::event_record(ls->prof_stop[ls->prof_count % rsmp_fir_lockstep::kProfRing], s));
         ++ls->prof_count;
     }
     ls->last_stream = s;
@@ -923,7 +923,7 @@ int pick_plan_stream(rsmp_fir_lockstep* ls, hipStream_t s) {
             *ls->h_probe.as<volatile uint32_t>() = 0u;
             RSMP_HIP_CHECK(rsmp::launch_fir_lockstep_probe_wait(ls->d_probe.as<uint32_t>(), token, 100000u, ls->h_probe.as<uint32_t>(), s));
             RSMP_HIP_CHECK(rsmp::launch_fir_lockstep_probe_set(ls->d_probe.as<uint32_t>(), token, ls->plan_candidates[pp.cand]));
-            RSMP_HIP_CHECK(hipEventRecord(ls->probe_ev, s));
+            RSMP_HIP_CHECK(rsmp::event_record(ls->probe_ev, s));
             pp.probing = true;
             ls->probe_owner = s;
             ++ls->stat_probes;
@@ -938,7 +938,7 @@ int pick_plan_stream(rsmp_fir_lockstep* ls, hipStream_t s) {
 // pointers: before those change, the plan stream must have finished (`s`: that stream waits; null: the host does).
 int drop_plan_ahead(rsmp_fir_lockstep* ls, hipStream_t s) {
     if (ls->ahead_inflight && ls->plan_done) {
-        if (s) RSMP_HIP_CHECK(hipStreamWaitEvent(s, ls->plan_done, 0));
+        if (s) RSMP_HIP_CHECK(rsmp::stream_wait_event(s, ls->plan_done));
         else RSMP_HIP_CHECK(hipEventSynchronize(ls->plan_done));
     }
     ls->ahead_inflight = false;
@@ -1160,11 +1160,11 @@ extern "C" int rsmp_fir_lockstep_run(rsmp_fir_lockstep* ls, size_t k_steps, size
         return a;
     };
     if (ls->profiling)
-        RSMP_HIP_CHECK(hipEventRecord(ls->prof_start[ls->prof_count % rsmp_fir_lockstep::kProfRing], s));
+        RSMP_HIP_CHECK(rsmp::event_record(ls->prof_start[ls->prof_count % rsmp_fir_lockstep::kProfRing], s));
     bool commit_on_q = false;   // this run's states were committed on the plan stream (below)
     if (same_key(ls->ahead, key)) {
         // planned while the previous run computed: wait for it (an event, no host block) and take its results over
-        RSMP_HIP_CHECK(hipStreamWaitEvent(s, ls->plan_done, 0));
+        RSMP_HIP_CHECK(rsmp::stream_wait_event(s, ls->plan_done));
         ls->ahead_inflight = false;
         ++ls->stat_ahead_hits;
         // (new tables: from the next plan on; this run was planned with the old ones, whose images nobody overwrites
@@ -1183,7 +1183,7 @@ extern "C" int rsmp_fir_lockstep_run(rsmp_fir_lockstep* ls, size_t k_steps, size
         commit_on_q = commit_knob && n < 256 && ls->ahead_q != nullptr && ls->stat_table_ops == table_ops0;
         hipStream_t cs = commit_on_q ? ls->ahead_q : s;
         if (commit_on_q && ls->drift_inflight)   // (a reading of the states on the caller's stream: in front of what changes them)
-            RSMP_HIP_CHECK(hipStreamWaitEvent(cs, ls->drift_ev, 0));
+            RSMP_HIP_CHECK(rsmp::stream_wait_event(cs, ls->drift_ev));
         rsmp::LsCommitArgs c;
         c.states = ls->d_states.as<FirMirrorState>();
         c.sp_states = ls->sp_states.as<FirMirrorState>();
@@ -1196,8 +1196,8 @@ extern "C" int rsmp_fir_lockstep_run(rsmp_fir_lockstep* ls, size_t k_steps, size
         c.n_streams = static_cast<uint32_t>(n);
         RSMP_HIP_CHECK(rsmp::launch_fir_lockstep_commit(c, cs));
         if (commit_on_q) {
-            RSMP_HIP_CHECK(hipEventRecord(ls->ev_commit, cs));
-            RSMP_HIP_CHECK(hipStreamWaitEvent(s, ls->ev_commit, 0));
+            RSMP_HIP_CHECK(rsmp::event_record(ls->ev_commit, cs));
+            RSMP_HIP_CHECK(rsmp::stream_wait_event(s, ls->ev_commit));
             ++ls->stat_commits_on_plan_stream;
         }
     } else {
@@ -1238,18 +1238,18 @@ extern "C" int rsmp_fir_lockstep_run(rsmp_fir_lockstep* ls, size_t k_steps, size
         // delays it by just about that launch: 0.96 against 1.21 us per step; from 256 streams up K1 in front wins, 1024
         // streams 3.56 -> 3.38 us per step.  profiles/r05/c4_shard_sweep*.txt.)
         const bool k1_in_front = n >= 256;
-        if (ls->slot[nx.slot].used) RSMP_HIP_CHECK(hipStreamWaitEvent(k1_in_front ? s : q, ls->slot[nx.slot].compute_done, 0));   // its buffers are free (long since)
+        if (ls->slot[nx.slot].used) RSMP_HIP_CHECK(rsmp::stream_wait_event(k1_in_front ? s : q, ls->slot[nx.slot].compute_done));   // its buffers are free (long since)
         if (k1_in_front) RSMP_HIP_CHECK(rsmp::launch_fir_lockstep_plan(plan_args(nx, true), s, 1));
         if (commit_on_q && !k1_in_front) {
             // (the states after this run are in place on the plan stream itself: nothing to wait for, unless the probe has
             // just moved the planner to the other candidate)
-            if (q != ls->ahead_q) RSMP_HIP_CHECK(hipStreamWaitEvent(q, ls->ev_commit, 0));
+            if (q != ls->ahead_q) RSMP_HIP_CHECK(rsmp::stream_wait_event(q, ls->ev_commit));
         } else {
-            RSMP_HIP_CHECK(hipEventRecord(ls->ev_ready, s));   // the states after this run are in place (and the next run's predictions made)
-            RSMP_HIP_CHECK(hipStreamWaitEvent(q, ls->ev_ready, 0));
+            RSMP_HIP_CHECK(rsmp::event_record(ls->ev_ready, s));   // the states after this run are in place (and the next run's predictions made)
+            RSMP_HIP_CHECK(rsmp::stream_wait_event(q, ls->ev_ready));
         }
         RSMP_HIP_CHECK(rsmp::launch_fir_lockstep_plan(plan_args(nx, true), q, k1_in_front ? 2 : 3));
-        RSMP_HIP_CHECK(hipEventRecord(ls->plan_done, q));
+        RSMP_HIP_CHECK(rsmp::event_record(ls->plan_done, q));
         ls->ahead_q = q;
         ls->ahead = nx;
         ls->ahead_inflight = true;
@@ -1299,10 +1299,10 @@ extern "C" int rsmp_fir_lockstep_run(rsmp_fir_lockstep* ls, size_t k_steps, size
     if (!split_jobs.empty()) RSMP_HIP_CHECK(rsmp::launch_fir_split_multi(split_jobs.data(), split_jobs.size(), s, reserve));
     // (the repair launch copies the streams' tails as well: one launch and its gap less per run)
     RSMP_HIP_CHECK(rsmp::launch_fir_repair_multi(repair_jobs.data(), repair_jobs.size(), s, d_descs, static_cast<uint32_t>(n), max_tail_values));
-    RSMP_HIP_CHECK(hipEventRecord(ls->slot[sl].compute_done, s));
+    RSMP_HIP_CHECK(rsmp::event_record(ls->slot[sl].compute_done, s));
     ls->slot[sl].used = true;
     if (ls->profiling) {
-        RSMP_HIP_CHECK(hipEventRecord(ls->prof_stop[ls->prof_count % rsmp_fir_lockstep::kProfRing], s));
+        RSMP_HIP_CHECK(rsmp::event_record(ls->prof_stop[ls->prof_count % rsmp_fir_lockstep::kProfRing], s));
         ++ls->prof_count;
     }
     ls->hist_parity ^= 1u;

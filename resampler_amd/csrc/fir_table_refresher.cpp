@@ -37,7 +37,7 @@ TableRefresher::Table* TableRefresher::add_table(const PeriodicGeometry& geo, st
 }
 
 int TableRefresher::record_guard(Table* t, hipStream_t s) {
-    RSMP_HIP_CHECK(hipEventRecord(t->guard, s));
+    RSMP_HIP_CHECK(rsmp::event_record(t->guard, s));
     return RSMP_OK;
 }
 
@@ -102,7 +102,7 @@ int TableRefresher::refresh(Table* t) {
     std::memcpy(h + cb + wb, host.meta.data(), mb);
     char* d = t->d_buf[t->next_buf];
     // the image was bound until the last replacement: what had been enqueued by then may still read it (record_guard)
-    RSMP_HIP_CHECK(hipStreamWaitEvent(copy_stream_, t->guard, 0));
+    RSMP_HIP_CHECK(rsmp::stream_wait_event(copy_stream_, t->guard));
     RSMP_HIP_CHECK(hipMemcpyAsync(d, h, total, hipMemcpyHostToDevice, copy_stream_));
     RSMP_HIP_CHECK(hipStreamSynchronize(copy_stream_));
     t->ready.d_coef = reinterpret_cast<const float*>(d);

@@ -288,6 +288,40 @@ def test_the_same_span_run_again_and_again_without_append():
     ls.close()
 
 
+def test_runs_ordered_on_the_legacy_default_stream():
+    """What a torch caller under its default stream passes (ra.torch_stream() == RSMP_STREAM_LEGACY): from the third
+    run on the caller's stream WAITS for the plan stream's event -- this image's hipStreamWaitEvent dereferences the
+    legacy handle (a segfault found by tools/run_bulk_probe.py), so the library hands it the null stream instead
+    (common.h stream_wait_event)."""
+    import torch
+    dev = torch.device("cuda:0")
+    assert ra.torch_stream() == ra.STREAM_LEGACY
+    specs = sharding.mixed_rate_batch(12, 2, 512)
+    k = 6
+    hs = [ra.ResamplerFir.new_from_hz(2, s.in_hz, s.out_hz, ra.Latency.Sample64, ra.Attenuation.Db90) for s in specs]
+    refs = [o.OracleFir(2, s.in_hz, s.out_hz, 128, 90) for s in specs]
+    xs = [synth.hash_noise(k * 512 * 2, seed=70 + i) for i in range(len(specs))]
+    caps = [h.buffer_size_output() for h in hs]
+    d_in = [torch.from_numpy(x).to(dev) for x in xs]
+    d_out = [torch.zeros(k * c, device=dev) for c in caps]
+    ls = ra.FirLockstep(hs, 512)
+    ls.bind_caps(d_in, d_out, caps)
+    for rep in range(5):
+        ls.run(k, 512, 0, append=False, stream=ra.STREAM_LEGACY)
+        got = [t.cpu().numpy() for t in d_out]   # (torch's copy on the default stream: ordered behind the run)
+        cons, prod = ls.run_counts()
+        for i, r in enumerate(refs):
+            out = np.zeros(caps[i], np.float32)
+            ys = []
+            for s in range(k):
+                rc, c, p = r.resample(xs[i][s * 1024:(s + 1) * 1024], out)
+                assert rc == 0 and (c, p) == (int(cons[s][i]), int(prod[s][i])), (rep, i, s)
+                ys.append(out[:p].copy())
+            want = np.concatenate(ys)
+            assert rms(got[i][:want.size], want) <= RMS_TOL, (rep, i)
+    ls.close()
+
+
 def test_an_old_stream_keeps_parity_through_runs():
     """The reference's f64 position drifts away from the exact rational one by ~1e-14 of a frame per output
     (src/resampler_fir.rs:589: every add rounds on the grid of its binade); after half an hour of audio that is 1e-6 of a
