@@ -167,6 +167,7 @@ struct LsRunArgs {
     uint32_t* zero_status;     // non-null: `status` is a scratch copy of a run planned AHEAD -- cleared here first (the commit ORs it in)
     uint64_t in_offset;        // frames added to every stream's `in`
     uint32_t n_streams, k, in_frames, wrap_words, append, hist_parity;
+    uint32_t parallel_chain;   // K2: chunks of lean calls by the parallel chain (set by launch_fir_lockstep_plan; RSMP_LS_PCHAIN=0, debug: never)
 };
 // parts: 1 = K1 (the predictions), 2 = K2 + K3 (chain, replay); 3 = all three in `stream`
 // The planner's serial kernels (chain, replay) pack kLsPlanPack streams into a workgroup -- one CU -- for batches of fewer than

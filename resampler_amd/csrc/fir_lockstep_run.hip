@@ -151,6 +151,58 @@ __device__ __forceinline__ uint32_t chain_fast_run_of(uint32_t shape, uint32_t s
     }
 }
 
+// ---- the chain of a chunk of calls IN PARALLEL (round 6) ------------------------------------------------------------------------
+// What is serial per call is the f64 position -- but a lean call's effect on it is a SHIFT that does not depend on where exactly the
+// call starts: a rounded add moves every f64 of a binade by the same multiple of that binade's grid (MirrorBinades), the call's start
+// p is itself a multiple of the grid of the TOP binade the call before it reached (its last add rounded there, the integer it then
+// retires changes nothing), and every grid below divides that one.  So D = F(p) - p is the same for every p of the call's SHAPE (the
+// prediction's per-binade counts) -- except where this call climbs one binade higher than the one before: the add that enters the
+// higher binade rounds p's lowest bit away, up or down by the ratio's residue there, and D depends on that ONE bit of p.  A call is
+// therefore a map on (residue bit r, position): r -> (D[r], r'), and maps compose associatively.  Per chunk of up to 64 calls, a call
+// per lane: the lane runs its call's chain (mirror_chain_step, the very function of the serial loop) from two representative starts
+// -- the position a plain f64 sum of the prediction puts the call at, rounded to the higher grid, + r grid steps --, a prefix scan
+// composes the maps (six shuffle steps), and from the chunk's true start every call's start follows.  Then every lane runs its call
+// ONCE MORE from that start and the chunk is accepted only if each call reproduces the shift the scan used and retires what the
+// prediction says: p[k + 1] = F_k(p[k]) for every k from the true p[0] IS the serial recurrence, bit for bit.  Anything else -- a
+// call that is not lean, calls whose top binades differ by more than one, a start off the grid (a stream's first chunk), a tie the
+// representative saw from the other side -- leaves the chunk to the serial loop below, unchanged.  ~2 us per chunk against 64 x 0.41.
+struct ChainMap {
+    double d0, d1;        // the shift for start residue 0 / 1
+    uint32_t bits;        // bit 0 / 1: the residue after the call for start residue 0 / 1; bit 2 / 3: that start is valid
+};
+__device__ __forceinline__ ChainMap chain_map_identity() { return ChainMap{0.0, 0.0, 0x2u | 0xCu}; }   // r -> r, both valid
+// `first` then `second`
+__device__ __forceinline__ ChainMap chain_map_compose(const ChainMap& first, const ChainMap& second) {
+    ChainMap m;
+    const uint32_t o0 = first.bits & 1u, o1 = (first.bits >> 1) & 1u;
+    m.d0 = first.d0 + (o0 ? second.d1 : second.d0);
+    m.d1 = first.d1 + (o1 ? second.d1 : second.d0);
+    const uint32_t so0 = (second.bits >> o0) & 1u, so1 = (second.bits >> o1) & 1u;
+    const uint32_t v0 = ((first.bits >> 2) & 1u) & ((second.bits >> (2 + o0)) & 1u), v1 = ((first.bits >> 3) & 1u) & ((second.bits >> (2 + o1)) & 1u);
+    m.bits = so0 | (so1 << 1) | (v0 << 2) | (v1 << 3);
+    return m;
+}
+__device__ __forceinline__ double shfl_up_f64(double v, int d) {
+    const uint64_t b = mirror_bits(v);
+    const uint32_t lo = static_cast<uint32_t>(__shfl_up(static_cast<int>(static_cast<uint32_t>(b)), d, 64));
+    const uint32_t hi = static_cast<uint32_t>(__shfl_up(static_cast<int>(static_cast<uint32_t>(b >> 32)), d, 64));
+    return mirror_from_bits(static_cast<uint64_t>(lo) | (static_cast<uint64_t>(hi) << 32));
+}
+// The lane's own call from `start`: the position after it (already less what it retires) and the frames it retires.
+template <uint32_t L = 0>
+__device__ inline uint32_t chain_eval_lane(uint32_t shape, double& pos, uint32_t avail, uint32_t in_frames, double ratio, const MirrorBinades& bn,
+                                           uint32_t n_total, const ChainPlan& cp) {
+    if constexpr (L < kPredBinades) {
+        if (shape == L) {
+            ChainScalars tmp{0, 0, 0, avail};
+            return mirror_chain_step<L, true, false>(pos, tmp, in_frames, ratio, bn, n_total, cp.ctl, cp.n_last, cp.m);
+        }
+        return chain_eval_lane<L + 1>(shape, pos, avail, in_frames, ratio, bn, n_total, cp);
+    } else {
+        return 0xFFFFFFFFu;
+    }
+}
+
 // (Waves per workgroup: one, or -- small batches -- kLsPlanPack, a stream each.  A wave of this kernel is a chain of dependent
 // f64 operations: four of them on one CU run as fast as one per CU (eight do not: the kernel is code, and a CU fetches it once for all its waves), and a batch of 128 streams then occupies 32 CUs
 // instead of a wave on each of 128 -- where no workgroup of the split kernel, which needs a CU's whole register file, could
@@ -227,8 +279,154 @@ __global__ __launch_bounds__(64 * kLsPlanPack) void fir_lockstep_chain_kernel(Ls
         uint64_t nonlean_mask = 0;
         double my_pos = 0.0, my_drift = 0.0;
         uint32_t my_flags = 0, my_c0 = 0, my_c1 = 0;
+        // ---- a RUN of lean calls [s0, e0) of the chunk in parallel (every call of it lean, each one's prediction continuing its
+        // predecessor's); true: done, the state is behind call e0 - 1
+        auto parallel_run = [&](uint32_t s0, uint32_t e0) -> bool {
+            const uint64_t full_mask = ((e0 >= 64u ? ~0ull : (1ull << e0) - 1ull)) & ~((1ull << s0) - 1ull);
+            const bool in_seg = lane >= s0 && lane < e0;
+            bool chunk_done = false;
+            {
+            const double p_start = st_valid ? st.position : pos;
+            const uint32_t my_shape = (my_cp.ctl >> 8) & 0xFu;
+            // where a plain f64 sum of the prediction puts every call's start (good to ~1e-12: the same SHAPE as the true start
+            // unless the f64 drift is smaller than that -- then the check below fails and the serial loop takes the chunk)
+            double est = in_seg ? static_cast<double>(my_n_total) * ratio - static_cast<double>(my_cpred) : 0.0;
+#pragma unroll
+            for (int sft = 1; sft < 64; sft <<= 1) {
+                const double upv = shfl_up_f64(est, sft);
+                if (lane >= static_cast<uint32_t>(sft)) est += upv;
+            }
+            const double before = shfl_up_f64(est, 1);
+            const double x_start = p_start + (lane <= s0 ? 0.0 : before);
+            // the representative start: on the grid of [4096, 8192) -- a multiple of every grid a call of at most 4096 buffered frames rounds on
+            const double kCoarse = 1099511627776.0;   // 2^40
+            const double rep = floor(x_start * kCoarse + 0.5) * (1.0 / kCoarse);
+            // ... from which the call's LAST add (the one behind its last output) lands in this lane's top binade
+            double pe0 = rep;
+            const uint32_t cons0 = in_seg ? chain_eval_lane(my_shape, pe0, static_cast<uint32_t>(my_avail), a.in_frames, ratio, bn, my_n_total, my_cp) : 0u;
+            const double raw0 = pe0 + static_cast<double>(cons0 == 0xFFFFFFFFu ? 0u : cons0);
+            const uint32_t my_exp = in_seg ? static_cast<uint32_t>((mirror_bits(raw0) >> 52) & 0x7FFu) : 0u;   // biased exponent of the end position
+            const uint32_t exp0 = rl(my_exp, s0);
+            const uint64_t eq = __ballot(in_seg && my_exp == exp0), up = __ballot(in_seg && my_exp == exp0 + 1u),
+                           dn = __ballot(in_seg && my_exp + 1u == exp0);
+            uint32_t e_lo = exp0, e_hi = exp0;
+            bool shapes_ok = exp0 >= 1023u - 2u && exp0 <= 1023u + 12u;
+            if ((eq | up) == full_mask) e_hi = up ? exp0 + 1u : exp0;
+            else if ((eq | dn) == full_mask) e_lo = exp0 - 1u;
+            else shapes_ok = false;
+            const bool two = e_hi != e_lo;
+            // the grids of the lower / higher top binade
+            const double u_lo = mirror_from_bits(static_cast<uint64_t>(e_lo - 52u) << 52);
+            const double inv_lo = mirror_from_bits(static_cast<uint64_t>(2046u + 52u - e_lo) << 52);   // 1 / u_lo
+            const double q_start = p_start * inv_lo;            // exact (a power of two)
+            shapes_ok = shapes_ok && q_start == floor(q_start) && q_start < 9007199254740992.0;   // the start lies on the lower grid
+            if (shapes_ok) {
+                const uint32_t r_start = two ? static_cast<uint32_t>(static_cast<uint64_t>(q_start) & 1ull) : 0u;
+                ChainMap me = chain_map_identity();
+                double d_own[2] = {0.0, 0.0};
+                if (in_seg) {
+                    uint32_t bits = 0;
+#pragma unroll
+                    for (uint32_t r = 0; r < 2; ++r) {
+                        const double s0 = rep + (r ? u_lo : 0.0);
+                        double pe = r == 0 ? pe0 : s0;
+                        uint32_t cons = cons0;
+                        if (r == 1) cons = two ? chain_eval_lane(my_shape, pe, static_cast<uint32_t>(my_avail), a.in_frames, ratio, bn, my_n_total, my_cp) : 0u;
+                        const double d = pe - s0;                 // exact: both on the lower grid
+                        const double q_end = pe * inv_lo;
+                        // (the run's LAST call has no successor to predict what it retires: whatever the chain says)
+                        const bool ok = (r == 0 || two) && (cons == my_cpred || my_last) && cons != 0xFFFFFFFFu && q_end == floor(q_end) && pe >= 0.0;
+                        const uint32_t r_end = two ? static_cast<uint32_t>(static_cast<uint64_t>(q_end < 0.0 ? 0.0 : q_end) & 1ull) : 0u;
+                        d_own[r] = d;
+                        bits |= (r_end << r) | ((ok ? 1u : 0u) << (2 + r));
+                    }
+                    if (!two) {   // (one grid: residue 1 does not exist; the map ignores it)
+                        d_own[1] = d_own[0];
+                        bits = (bits & 0x5u) | ((bits & 1u) << 1) | ((bits & 4u) << 1);
+                    }
+                    me = ChainMap{d_own[0], d_own[1], bits};
+                }
+                ChainMap incl = me;
+#pragma unroll
+                for (int sft = 1; sft < 64; sft <<= 1) {
+                    ChainMap left;
+                    left.d0 = shfl_up_f64(incl.d0, sft);
+                    left.d1 = shfl_up_f64(incl.d1, sft);
+                    left.bits = static_cast<uint32_t>(__shfl_up(static_cast<int>(incl.bits), sft, 64));
+                    if (lane >= static_cast<uint32_t>(sft)) incl = chain_map_compose(left, incl);
+                }
+                // this lane's call starts behind calls 0 .. lane - 1
+                ChainMap excl;
+                excl.d0 = shfl_up_f64(incl.d0, 1);
+                excl.d1 = shfl_up_f64(incl.d1, 1);
+                excl.bits = static_cast<uint32_t>(__shfl_up(static_cast<int>(incl.bits), 1, 64));
+                if (lane <= s0) excl = chain_map_identity();
+                const double p_mine = p_start + (r_start ? excl.d1 : excl.d0);
+                const uint32_t r_mine = (excl.bits >> r_start) & 1u;
+                const bool guess_ok = ((incl.bits >> (2 + r_start)) & 1u) != 0;
+                // the check: the call once more, from the start the scan gives it
+                bool same = true;
+                uint32_t my_cons = 0;
+                if (in_seg) {
+                    double pe = p_mine;
+                    my_cons = chain_eval_lane(my_shape, pe, static_cast<uint32_t>(my_avail), a.in_frames, ratio, bn, my_n_total, my_cp);
+                    same = guess_ok && (my_cons == my_cpred || my_last) && my_cons != 0xFFFFFFFFu && (pe - p_mine) == d_own[r_mine];
+                }
+                if (__all(same)) {
+                    if (st_valid) {   // (the counters leave `st`)
+                        sc = ChainScalars{rfl64(st.abs_out), rfl64(st.abs_consumed), rfl(static_cast<uint32_t>(st.read_position)),
+                                          rfl(static_cast<uint32_t>(st.available))};
+                        st_valid = false;
+                    }
+                    const uint32_t last = e0 - 1;
+                    pos = rl_f64(p_start + (r_start ? incl.d1 : incl.d0), last);
+                    my_pos = in_seg ? p_mine : my_pos;
+                    // the counters behind the chunk, from the last call's prediction; the ring's read position call by call (:605-615)
+                    uint32_t rp = sc.read_position;
+                    for (uint32_t k = s0; k < e0; ++k) {
+                        rp += rl(my_cons, k);
+                        if (rp > kMirrorInputCapacity) rp = 0;
+                    }
+                    const uint32_t n_last_total = rl(my_n_total, last), c_last = rl(my_cons, last);
+                    const uint64_t m0_last = static_cast<uint64_t>(rl(static_cast<uint32_t>(mine[0]), last)) | (static_cast<uint64_t>(rl(static_cast<uint32_t>(mine[0] >> 32), last)) << 32);
+                    const uint64_t c0_last = static_cast<uint64_t>(rl(static_cast<uint32_t>(mine[1]), last)) | (static_cast<uint64_t>(rl(static_cast<uint32_t>(mine[1] >> 32), last)) << 32);
+                    sc.abs_out = m0_last + n_last_total;
+                    sc.abs_consumed = c0_last + c_last;
+                    sc.read_position = rp;
+                    sc.available = rl(static_cast<uint32_t>(my_avail), last) + a.in_frames - c_last;
+                    on_track = ((succ_mask >> last) & 1ull) != 0;
+                    lean_last_n = n_last_total;
+                    last_lean = true;
+                    chunk_done = true;
+                }
+            }
+        }
+            return chunk_done;
+        };
 #pragma unroll 1
         for (uint32_t s = 0; s < nc; ++s) {
+            if (a.parallel_chain) {
+                if (!on_track && st_valid) {   // (behind a call off the track: is the state where this call's prediction starts?  As below.)
+                    const uint64_t m0 = static_cast<uint64_t>(rl(static_cast<uint32_t>(mine[0]), s)) | (static_cast<uint64_t>(rl(static_cast<uint32_t>(mine[0] >> 32), s)) << 32);
+                    const uint64_t cc0 = static_cast<uint64_t>(rl(static_cast<uint32_t>(mine[1]), s)) | (static_cast<uint64_t>(rl(static_cast<uint32_t>(mine[1] >> 32), s)) << 32);
+                    on_track = rfl64(st.abs_out) == m0 && rfl64(st.abs_consumed) == cc0 &&
+                               rfl(static_cast<uint32_t>(st.available)) == rl(static_cast<uint32_t>(my_avail), s) &&
+                               rfl(static_cast<uint32_t>(st.read_position)) + rfl(static_cast<uint32_t>(st.available)) + a.in_frames <= kMirrorBufferSize;
+                }
+                if (on_track && ((lean_mask >> s) & 1ull)) {
+                    // the run of lean calls from s: up to the first call that is not lean, or just behind the first whose successor's
+                    // prediction does not continue it
+                    const uint64_t not_lean = ~lean_mask >> s, not_succ = ~succ_mask >> s;
+                    uint32_t e = s + (not_lean ? static_cast<uint32_t>(__builtin_ctzll(not_lean)) : 64u - s);
+                    const uint32_t e2 = s + (not_succ ? static_cast<uint32_t>(__builtin_ctzll(not_succ)) + 1u : 64u - s);
+                    e = e < e2 ? e : e2;
+                    e = e < nc ? e : nc;
+                    if (e >= s + 8u && parallel_run(s, e)) {
+                        s = e - 1;
+                        continue;
+                    }
+                }
+            }
             if (on_track && ((fast_mask >> s) & 1ull)) {
                 if (st_valid) {   // (the counters leave `st`)
                     pos = st.position;
@@ -565,13 +763,16 @@ hipError_t launch_fir_lockstep_gather_counts(const uint64_t* last_counts, const 
 }
 
 uint32_t lockstep_plan_pack(size_t n_streams) {
-    static const uint32_t knob = [] { const char* e = rsmp::knob("RSMP_LS_PACK"); const int v = e ? atoi(e) : 0; return v == 1 || v == 2 || v == 4 || v == 8 ? static_cast<uint32_t>(v) : 0u; }();
+    static const uint32_t knob = [] { const char* e = rsmp::knob("RSMP_LS_PACK"); const int v = e ? atoi(e) : 0; return v == 1 || v == 2 || v == 4 ? static_cast<uint32_t>(v) : 0u; }();
     if (n_streams >= kLsPlanPackBelow) return 1u;
     return knob ? knob : kLsPlanPack;
 }
 
-hipError_t launch_fir_lockstep_plan(const LsRunArgs& args, hipStream_t stream, int parts) {
-    if (args.n_streams == 0 || args.k == 0) return hipSuccess;
+hipError_t launch_fir_lockstep_plan(const LsRunArgs& args_in, hipStream_t stream, int parts) {
+    if (args_in.n_streams == 0 || args_in.k == 0) return hipSuccess;
+    static const bool pchain = [] { const char* e = rsmp::knob("RSMP_LS_PCHAIN"); return !e || atoi(e) != 0; }();
+    LsRunArgs args = args_in;
+    args.parallel_chain = pchain ? 1u : 0u;
     const uint32_t blocks_per_stream = (args.k + 255) / 256;
     if (parts & 1) hipLaunchKernelGGL(fir_lockstep_predict_kernel, dim3(blocks_per_stream * args.n_streams), dim3(256), 0, stream, args, blocks_per_stream);
     if (parts & 2) {

@@ -396,7 +396,9 @@ __host__ __device__ inline ChainPlan mirror_chain_plan(const MirrorPred& pr) {
 // One call of shape L (ctl bits 8-11): the f64 chain on `pos`, then what the call retires (:596-615).  `m[i]`, i <= L, and
 // the two control words are the call's ChainPlan (on the device: v_readlane of the lane that holds it).  Returns the frames
 // the call retires.
-template <uint32_t L, bool TIES>
+// (UNIFORM: every lane of the wave runs the SAME call -- the retired count is taken through a scalar register; false: a call per lane,
+// the parallel chain of fir_lockstep_run.hip)
+template <uint32_t L, bool TIES, bool UNIFORM = true>
 __host__ __device__ inline uint32_t mirror_chain_step(double& pos_io, ChainScalars& sc, uint32_t in_frames, double ratio,
                                                       const MirrorBinades& bn, uint32_t n_total, uint32_t ctl, uint32_t n_last,
                                                       const double (&m)[kPredBinades]) {
@@ -432,7 +434,8 @@ __host__ __device__ inline uint32_t mirror_chain_step(double& pos_io, ChainScala
     const double cd = fl > avd ? avd : fl;        // (double)min(floor(pos), avail), :596-597
     pos_io = pos - cd;                            // :602
 #if defined(__HIP_DEVICE_COMPILE__)
-    const uint32_t consumed = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(static_cast<uint32_t>(cd))));
+    const uint32_t consumed = UNIFORM ? static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(static_cast<uint32_t>(cd))))
+                                      : static_cast<uint32_t>(cd);
 #else
     const uint32_t consumed = static_cast<uint32_t>(cd);
 #endif

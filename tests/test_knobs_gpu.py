@@ -64,13 +64,26 @@ def test_lockstep_exact_f32_switch_in_a_child_process():
     assert p.returncode == 0, p.stdout[-3000:]
 
 
-@pytest.mark.parametrize("knob", ["RSMP_FIR_SPLIT_MULTI", "RSMP_LS_AHEAD"])
-def test_lockstep_run_switches_in_a_child_process(knob):
-    """The run of several calls with one launch per rate pair (no multi-job launch) / planned on the caller's stream only."""
+@pytest.mark.parametrize("knob,value", [("RSMP_FIR_SPLIT_MULTI", "0"), ("RSMP_LS_AHEAD", "0"), ("RSMP_LS_PCHAIN", "0"), ("RSMP_LS_COMMIT_ON_PLAN", "0"),
+                                        ("RSMP_FIR_SPLIT_ALL", "0"), ("RSMP_LS_PACK", "1")])
+def test_lockstep_run_switches_in_a_child_process(knob, value):
+    """The run of several calls with one launch per rate pair (no multi-job launch) / planned on the caller's stream only / the
+    planner's chain call by call (round 5's) instead of a chunk of calls per wave in parallel / the states committed on the
+    caller's stream / one split launch per kernel build instead of one for all / one planner wave per workgroup."""
     env = dict(os.environ, RSMP_DEBUG="1", PYTHONPATH=ROOT)
-    env[knob] = "0"
+    env[knob] = value
     p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_fir_lockstep_run_gpu.py"), "-q", "-m", "gpu",
-                        "-k", "planned_ahead or k_calls_equals or interleave or append or different_states", "-p", "no:cacheprovider"],
+                        "-k", "planned_ahead or k_calls_equals or interleave or append or different_states or same_span or old_stream", "-p", "no:cacheprovider"],
+                       env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-3000:]
+    assert " passed" in p.stdout, p.stdout[-1000:]
+
+
+def test_long_generic_launches_on_the_latency_kernel_in_a_child_process():
+    """RSMP_FIR_GENERIC_BULK=0: ratios without a short period keep fir_generic_kernel for launches of any length."""
+    env = dict(os.environ, RSMP_DEBUG="1", RSMP_FIR_GENERIC_BULK="0", PYTHONPATH=ROOT)
+    p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_fir_gpu.py"), "-q", "-m", "gpu",
+                        "-k", "without_a_short_period", "-p", "no:cacheprovider"],
                        env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-3000:]
     assert " passed" in p.stdout, p.stdout[-1000:]
