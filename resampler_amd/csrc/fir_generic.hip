@@ -14,6 +14,8 @@
 // reads 16-byte-contiguous frames); this kernel is the correctness backbone and the latency
 // path -- the throughput path for rational rate pairs is fir_periodic.hip.
 #include <algorithm>
+#include <hip/hip_ext.h>
+
 #include "fir_kernels.h"
 
 namespace rsmp {
@@ -251,7 +253,8 @@ hipError_t launch_fir_repair(const FirStreamDesc* d_descs, uint32_t n_streams, c
 }
 
 hipError_t launch_fir_repair_multi(const RepairJob* jobs, size_t n_jobs, hipStream_t stream, const FirStreamDesc* tail_descs,
-                                   uint32_t n_tail, uint32_t max_tail_values) {
+                                   uint32_t n_tail, uint32_t max_tail_values, hipEvent_t done, bool* done_attached) {
+    if (done_attached) *done_attached = false;
     bool tail_left = tail_descs != nullptr && n_tail != 0 && max_tail_values != 0;
     for (size_t j = 0; j < n_jobs;) {
         RepairMulti m{};
@@ -273,7 +276,13 @@ hipError_t launch_fir_repair_multi(const RepairJob* jobs, size_t n_jobs, hipStre
             tail_left = false;
             max_total = std::max(max_total, n_tail);
         }
-        hipLaunchKernelGGL(fir_repair_multi_kernel, dim3(max_total < 512 ? max_total : 512, n + (with_tail ? 1u : 0u)), dim3(kBlock), 0, stream, m);
+        const dim3 grid(max_total < 512 ? max_total : 512, n + (with_tail ? 1u : 0u));
+        if (done && done_attached && j >= n_jobs && !tail_left) {   // (the last launch of the lot: it completes `done` itself)
+            hipExtLaunchKernelGGL(fir_repair_multi_kernel, grid, dim3(kBlock), 0, stream, nullptr, done, 0, m);
+            *done_attached = true;
+        } else {
+            hipLaunchKernelGGL(fir_repair_multi_kernel, grid, dim3(kBlock), 0, stream, m);
+        }
         if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
     }
     if (tail_left) return launch_fir_tail_copy(tail_descs, n_tail, max_tail_values, stream);   // (no repair job at all)

@@ -89,8 +89,10 @@ struct RepairJob {
 constexpr uint32_t kMaxRepairJobs = 8;
 // (tail_descs: the launch also copies the tails of these n_tail streams -- what launch_fir_tail_copy does -- in one more row
 // of its grid)
+// (done / done_attached: an event the LAST of these launches completes itself -- hipExtLaunchKernel's stop event, no packet of its
+// own behind the kernel as hipEventRecord puts there; *done_attached = false: there was no such launch, record it yourself)
 hipError_t launch_fir_repair_multi(const RepairJob* jobs, size_t n_jobs, hipStream_t stream, const FirStreamDesc* tail_descs = nullptr,
-                                   uint32_t n_tail = 0, uint32_t max_tail_values = 0);
+                                   uint32_t n_tail = 0, uint32_t max_tail_values = 0, hipEvent_t done = nullptr, bool* done_attached = nullptr);
 // Copies the still-buffered tail of [hist|in] into hist_next; grid = (blocks, streams).
 hipError_t launch_fir_tail_copy(const FirStreamDesc* d_descs, uint32_t n_streams,
                                 uint32_t max_tail_values, hipStream_t stream);

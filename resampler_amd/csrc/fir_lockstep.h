@@ -169,7 +169,17 @@ struct LsRunArgs {
     uint32_t n_streams, k, in_frames, wrap_words, append, hist_parity;
     uint32_t parallel_chain;   // K2: chunks of lean calls by the parallel chain (set by launch_fir_lockstep_plan; RSMP_LS_PCHAIN=0, debug: never)
 };
+struct LsCommitArgs {
+    FirMirrorState* states; const FirMirrorState* sp_states;
+    uint64_t* cursor; const uint64_t* sp_cursor;
+    uint64_t* last_counts; const uint64_t* sp_last_counts;
+    uint32_t* status; const uint32_t* sp_status;
+    uint32_t n_streams;
+};
 // parts: 1 = K1 (the predictions), 2 = K2 + K3 (chain, replay); 3 = all three in `stream`
+// (commit, with part 1: K1 also does what launch_fir_lockstep_commit does -- the first thread of a stream's calls copies the
+// stream's scratch results into place -- and reads the states it predicts from out of the scratch copies: one launch less in
+// front of a run planned ahead)
 // The planner's serial kernels (chain, replay) pack kLsPlanPack streams into a workgroup -- one CU -- for batches of fewer than
 // kLsPlanPackBelow streams: the CUs they take are then few and known (lockstep_plan_cus), whoever reaches the chip first.
 constexpr uint32_t kLsPlanPack = 4, kLsPlanPackBelow = 256;   // (pack 1 / 2 / 4 / 8 at 128 streams: 0.89 / 0.71-0.86 / 0.73 / 0.83-0.95 us per step, profiles/r06/ab_c4_shard.txt: eight waves of this much CODE on one CU starve each other of instructions)
@@ -178,7 +188,10 @@ inline uint32_t lockstep_plan_cus(size_t n_streams) {
     const uint32_t pack = lockstep_plan_pack(n_streams);
     return pack > 1 ? static_cast<uint32_t>((n_streams + pack - 1) / pack) : static_cast<uint32_t>((n_streams + 3) / 4);
 }
-hipError_t launch_fir_lockstep_plan(const LsRunArgs& args, hipStream_t stream, int parts = 3);
+// (k1_done, with part 1: an event the K1 launch itself completes -- hipExtLaunchKernel's stop event --, no packet of its own
+// behind it as hipEventRecord would put there)
+hipError_t launch_fir_lockstep_plan(const LsRunArgs& args, hipStream_t stream, int parts = 3, const LsCommitArgs* commit = nullptr,
+                                    hipEvent_t k1_done = nullptr);
 // out[c] = states[reps[c]].drift: the drifts the batch's classes are watched by (one thread per class).
 hipError_t launch_fir_lockstep_gather_drift(const FirMirrorState* states, const uint32_t* reps, double* out, uint32_t n,
                                             hipStream_t stream);
@@ -208,13 +221,6 @@ struct LsPatchArgs {
 hipError_t launch_fir_lockstep_patch_tables(const LsPatchArgs& args, hipStream_t stream);
 // A run planned ahead (on a stream of its own, while the previous run computes) left its results in scratch copies:
 // states, append positions, the last call's counts, status flags -> the batch's own, when the run is really asked for.
-struct LsCommitArgs {
-    FirMirrorState* states; const FirMirrorState* sp_states;
-    uint64_t* cursor; const uint64_t* sp_cursor;
-    uint64_t* last_counts; const uint64_t* sp_last_counts;
-    uint32_t* status; const uint32_t* sp_status;
-    uint32_t n_streams;
-};
 hipError_t launch_fir_lockstep_commit(const LsCommitArgs& args, hipStream_t stream);
 hipError_t launch_fir_lockstep_gather_counts(const uint64_t* last_counts, const LsRunStream* rs, uint32_t* counts, uint32_t n,
                                              hipStream_t stream);

@@ -53,7 +53,9 @@ struct rsmp_fir_lockstep {
     // The run's descriptors, bitmaps, per-call counts and call records exist twice ("slots", used alternately): the NEXT run
     // is planned ahead on a stream of its own while the current one computes (plan_ahead below) and must not overwrite
     // what the current run's kernels and the caller (run_counts) still read.
-    struct RunSlot { DeviceBuffer descs, bits, counts, recs; hipEvent_t compute_done = nullptr; bool used = false; };
+    struct RunSlot { DeviceBuffer descs, bits, counts, recs; hipEvent_t compute_done = nullptr; hipStream_t compute_stream = nullptr; bool used = false, compute_recorded = false;
+                     // the split kernel's item tables of the run planned ahead into this slot, built on the plan stream behind its plan
+                     DeviceBuffer items; uint64_t items_seq = 0, items_ops = 0; bool items_valid = false; };
     RunSlot slot[2];
     int next_slot = 0, last_slot = 0;
     DeviceBuffer d_run_rs, d_run_nf, d_run_work, d_run_preds, d_run_states0;
@@ -73,6 +75,8 @@ struct rsmp_fir_lockstep {
     uint32_t probe_token = 0;
     hipEvent_t ev_ready = nullptr, plan_done = nullptr, ev_commit = nullptr;
     hipStream_t ahead_q = nullptr;       // the plan stream the run planned ahead was enqueued on
+    bool ahead_waited = false;           // the caller's stream `ahead_waited_on` already waits for plan_done (rsmp_fir_lockstep_run)
+    hipStream_t ahead_waited_on = nullptr;
     uint64_t stat_table_ops = 0;         // patch launches + table uploads enqueued on a caller's stream (poll_drift, flush_tables)
     uint64_t stat_commits_on_plan_stream = 0;
     struct RunKey { uint32_t k = 0, in_frames = 0, append = 0, parity = 0; uint64_t in_offset = 0, seq = 0; int slot = 0; bool valid = false; };
@@ -942,6 +946,7 @@ int drop_plan_ahead(rsmp_fir_lockstep* ls, hipStream_t s) {
         else RSMP_HIP_CHECK(hipEventSynchronize(ls->plan_done));
     }
     ls->ahead_inflight = false;
+    ls->ahead_waited = false;
     ls->ahead.valid = false;
     return RSMP_OK;
 }
@@ -1162,10 +1167,16 @@ extern "C" int rsmp_fir_lockstep_run(rsmp_fir_lockstep* ls, size_t k_steps, size
     if (ls->profiling)
         RSMP_HIP_CHECK(rsmp::event_record(ls->prof_start[ls->prof_count % rsmp_fir_lockstep::kProfRing], s));
     bool commit_on_q = false;   // this run's states were committed on the plan stream (below)
+    bool plan_taken_over = false;
+    bool commit_pending = false;   // ... are still to be committed on the caller's stream: by K1 of the next run, or a launch of its own
+    rsmp::LsCommitArgs c{};
     if (same_key(ls->ahead, key)) {
         // planned while the previous run computed: wait for it (an event, no host block) and take its results over
-        RSMP_HIP_CHECK(rsmp::stream_wait_event(s, ls->plan_done));
+        // (a big batch's caller stream has waited already, behind the previous run's split launch -- see below)
+        if (!(ls->ahead_waited && ls->ahead_waited_on == s)) RSMP_HIP_CHECK(rsmp::stream_wait_event(s, ls->plan_done));
+        ls->ahead_waited = false;
         ls->ahead_inflight = false;
+        plan_taken_over = true;
         ++ls->stat_ahead_hits;
         // (new tables: from the next plan on; this run was planned with the old ones, whose images nobody overwrites
         // before this run's kernels are through -- TableRefresher's guard event.  Behind the wait: the planner read
@@ -1180,11 +1191,11 @@ extern "C" int rsmp_fir_lockstep_run(rsmp_fir_lockstep* ls, size_t k_steps, size
         // the plan it commits, the next plan right behind it, and the caller's stream waits for the commit -- unless this
         // call put something on the caller's stream that the next plan must see (new class tables: rare).
         static const bool commit_knob = [] { const char* e = rsmp::knob("RSMP_LS_COMMIT_ON_PLAN"); return !e || atoi(e) != 0; }();
-        commit_on_q = commit_knob && n < 256 && ls->ahead_q != nullptr && ls->stat_table_ops == table_ops0;
+        static const bool commit_any_n = [] { const char* e = rsmp::knob("RSMP_LS_COMMIT_ON_PLAN"); return e && atoi(e) == 2; }();
+        commit_on_q = commit_knob && (n < 256 || commit_any_n) && ls->ahead_q != nullptr && ls->stat_table_ops == table_ops0;
         hipStream_t cs = commit_on_q ? ls->ahead_q : s;
         if (commit_on_q && ls->drift_inflight)   // (a reading of the states on the caller's stream: in front of what changes them)
             RSMP_HIP_CHECK(rsmp::stream_wait_event(cs, ls->drift_ev));
-        rsmp::LsCommitArgs c;
         c.states = ls->d_states.as<FirMirrorState>();
         c.sp_states = ls->sp_states.as<FirMirrorState>();
         c.cursor = ls->d_cursor.as<uint64_t>();
@@ -1194,13 +1205,15 @@ extern "C" int rsmp_fir_lockstep_run(rsmp_fir_lockstep* ls, size_t k_steps, size
         c.status = ls->d_status.as<uint32_t>();
         c.sp_status = ls->sp_status.as<uint32_t>();
         c.n_streams = static_cast<uint32_t>(n);
-        RSMP_HIP_CHECK(rsmp::launch_fir_lockstep_commit(c, cs));
+        if (commit_on_q) RSMP_HIP_CHECK(rsmp::launch_fir_lockstep_commit(c, cs));
+        else commit_pending = true;
         if (commit_on_q) {
             RSMP_HIP_CHECK(rsmp::event_record(ls->ev_commit, cs));
             RSMP_HIP_CHECK(rsmp::stream_wait_event(s, ls->ev_commit));
             ++ls->stat_commits_on_plan_stream;
         }
     } else {
+        ls->ahead_waited = false;
         if (ls->ahead.valid) ++ls->stat_ahead_misses;
         if (int rc = drop_plan_ahead(ls, s)) return rc;   // (whatever the plan stream still does: finished before this stream goes on)
         if (int rc = poll_drift(ls, s)) return rc;
@@ -1221,6 +1234,13 @@ extern "C" int rsmp_fir_lockstep_run(rsmp_fir_lockstep* ls, size_t k_steps, size
         if (int rc = pick_plan_stream(ls, s)) return rc;
         repeat = ls->plan_stream != nullptr;
     }
+    // (the commit of a run planned ahead: K1 of the next run does it where that is launched on this stream, in front of the bulk
+    // kernels -- a launch of 5 us less between two split launches, RSMP_LS_FUSE_COMMIT=0, debug: always a launch of its own)
+    static const bool fuse_commit = [] { const char* e = rsmp::knob("RSMP_LS_FUSE_COMMIT"); return !e || atoi(e) != 0; }();
+    if (commit_pending && !(fuse_commit && repeat && n >= 256)) {
+        RSMP_HIP_CHECK(rsmp::launch_fir_lockstep_commit(c, s));
+        commit_pending = false;
+    }
     if (repeat) {   // (before this run's bulk kernels are launched: the planner starts as soon as the states are there)
         rsmp_fir_lockstep::RunKey nx = key;
         nx.in_offset = key.in_offset + (key.in_offset - ls->prev.in_offset);
@@ -1238,17 +1258,63 @@ extern "C" int rsmp_fir_lockstep_run(rsmp_fir_lockstep* ls, size_t k_steps, size
         // delays it by just about that launch: 0.96 against 1.21 us per step; from 256 streams up K1 in front wins, 1024
         // streams 3.56 -> 3.38 us per step.  profiles/r05/c4_shard_sweep*.txt.)
         const bool k1_in_front = n >= 256;
-        if (ls->slot[nx.slot].used) RSMP_HIP_CHECK(rsmp::stream_wait_event(k1_in_front ? s : q, ls->slot[nx.slot].compute_done));   // its buffers are free (long since)
-        if (k1_in_front) RSMP_HIP_CHECK(rsmp::launch_fir_lockstep_plan(plan_args(nx, true), s, 1));
+        // its buffers are free (long since); K1 on the very stream that computed on them is behind that anyway, and a big batch
+        // does not even record the event (below) -- every event operation is a packet of its own that costs the queue 4-6 us
+        // between two kernels (profiles/r06/c4_between_split_launches.txt).  Whoever needs it after all records it now: on the
+        // stream that computed, behind everything enqueued there since.
+        auto& nslot = ls->slot[nx.slot];
+        if (nslot.used && !(k1_in_front && nslot.compute_stream == s)) {
+            if (!nslot.compute_recorded) {
+                RSMP_HIP_CHECK(rsmp::event_record(nslot.compute_done, nslot.compute_stream));
+                nslot.compute_recorded = true;
+            }
+            RSMP_HIP_CHECK(rsmp::stream_wait_event(k1_in_front ? s : q, nslot.compute_done));
+        }
+        // (ev_ready below: completed by the K1 launch itself where that is on a stream of the caller's own -- not the legacy handle,
+        // which an event must not carry, common.h)
+        static const bool stop_ev = [] { const char* e = rsmp::knob("RSMP_LS_STOP_EVENT"); return !e || atoi(e) != 0; }();
+        const bool k1_completes_ready = stop_ev && k1_in_front && s != reinterpret_cast<hipStream_t>(RSMP_STREAM_LEGACY);
+        if (k1_in_front)
+            RSMP_HIP_CHECK(rsmp::launch_fir_lockstep_plan(plan_args(nx, true), s, 1, commit_pending ? &c : nullptr, k1_completes_ready ? ls->ev_ready : nullptr));
         if (commit_on_q && !k1_in_front) {
             // (the states after this run are in place on the plan stream itself: nothing to wait for, unless the probe has
             // just moved the planner to the other candidate)
             if (q != ls->ahead_q) RSMP_HIP_CHECK(rsmp::stream_wait_event(q, ls->ev_commit));
         } else {
-            RSMP_HIP_CHECK(rsmp::event_record(ls->ev_ready, s));   // the states after this run are in place (and the next run's predictions made)
+            if (!k1_completes_ready) RSMP_HIP_CHECK(rsmp::event_record(ls->ev_ready, s));   // the states after this run are in place (and the next run's predictions made)
             RSMP_HIP_CHECK(rsmp::stream_wait_event(q, ls->ev_ready));
         }
         RSMP_HIP_CHECK(rsmp::launch_fir_lockstep_plan(plan_args(nx, true), q, k1_in_front ? 2 : 3));
+        // The split kernel's item tables of that run (one record per item: which frames, which outputs -- from the descriptors the
+        // planner has just written) are built here as well, behind the plan on the plan stream: in front of the run's own kernels
+        // the table launch was 6 us between two split launches.  (RSMP_LS_ITEMS_AHEAD=0, debug: built where they are used.)
+        static const bool items_ahead = [] { const char* e = rsmp::knob("RSMP_LS_ITEMS_AHEAD"); return !e || atoi(e) != 0; }();
+        ls->slot[nx.slot].items_valid = false;
+        if (items_ahead) {
+            std::vector<rsmp::SplitJob> jobs;
+            const rsmp::FirStreamDesc* nd = ls->slot[nx.slot].descs.as<rsmp::FirStreamDesc>();
+            for (const auto& g : ls->run_groups) {
+                if (g.geo.mfma != 3) continue;
+                const uint64_t n_out_max = static_cast<uint64_t>(k) * g.max_out_step;
+                jobs.push_back(rsmp::SplitJob{nd + g.first, static_cast<uint32_t>(g.count), &g.geo,
+                                              static_cast<uint32_t>((n_out_max / g.geo.b + 1) / g.geo.pw + 1), rsmp::NfArgs{}});
+            }
+            const size_t bytes = rsmp::fir_split_multi_item_words(jobs.data(), jobs.size()) * sizeof(uint32_t);
+            auto& ns = ls->slot[nx.slot];
+            bool room = bytes <= ns.items.capacity();
+            if (!room && bytes != 0) {   // (once per shape of run: nothing in flight reads a table that is about to be built for the first time)
+                RSMP_HIP_CHECK(hipStreamSynchronize(q));
+                RSMP_HIP_CHECK(hipStreamSynchronize(s));
+                RSMP_HIP_CHECK(ns.items.reserve(bytes + bytes / 2));
+                room = true;
+            }
+            if (room && bytes != 0) {
+                RSMP_HIP_CHECK(rsmp::launch_fir_split_multi(jobs.data(), jobs.size(), q, 0, ns.items.as<uint32_t>(), q));
+                ns.items_seq = nx.seq;
+                ns.items_ops = ls->stat_table_ops;
+                ns.items_valid = true;
+            }
+        }
         RSMP_HIP_CHECK(rsmp::event_record(ls->plan_done, q));
         ls->ahead_q = q;
         ls->ahead = nx;
@@ -1296,10 +1362,34 @@ extern "C" int rsmp_fir_lockstep_run(rsmp_fir_lockstep* ls, size_t k_steps, size
         // (the planner's packed workgroups take lockstep_plan_cus(n) CUs -- 32 for 128 streams --, + 4 for its one-wave kernels)
         reserve = knob >= 0 ? static_cast<uint32_t>(knob) : std::min<uint32_t>(64u, rsmp::lockstep_plan_cus(n) + 4u);
     }
-    if (!split_jobs.empty()) RSMP_HIP_CHECK(rsmp::launch_fir_split_multi(split_jobs.data(), split_jobs.size(), s, reserve));
+    // (the item tables: built on the plan stream behind this run's plan, if it was planned ahead and no table has changed since)
+    const auto& cslot = ls->slot[sl];
+    const uint32_t* items_prebuilt = plan_taken_over && cslot.items_valid && cslot.items_seq == key.seq && cslot.items_ops == ls->stat_table_ops
+                                         ? cslot.items.as<uint32_t>() : nullptr;
+    if (!split_jobs.empty()) RSMP_HIP_CHECK(rsmp::launch_fir_split_multi(split_jobs.data(), split_jobs.size(), s, reserve, items_prebuilt));
+    // A big batch's planner is through long before its split launch (profiles/r06/c4_run_timeline_1024_ahead1.txt): the wait for
+    // it goes HERE, behind the split launch, where the queue's processor handles the cross-queue dependency while the launch
+    // drains -- in front of the next run's first kernel it was 11 us of idle chip between two split launches.
+    // (RSMP_LS_EARLY_WAIT=0, debug: the wait where the plan is taken over.)
+    static const bool early_wait = [] { const char* e = rsmp::knob("RSMP_LS_EARLY_WAIT"); return !e || atoi(e) != 0; }();
+    if (early_wait && repeat && n >= 256 && ls->ahead_inflight) {
+        RSMP_HIP_CHECK(rsmp::stream_wait_event(s, ls->plan_done));
+        ls->ahead_waited = true;
+        ls->ahead_waited_on = s;
+    }
     // (the repair launch copies the streams' tails as well: one launch and its gap less per run)
-    RSMP_HIP_CHECK(rsmp::launch_fir_repair_multi(repair_jobs.data(), repair_jobs.size(), s, d_descs, static_cast<uint32_t>(n), max_tail_values));
-    RSMP_HIP_CHECK(rsmp::event_record(ls->slot[sl].compute_done, s));
+    // (the slot's "computed" event: a small batch's plan stream waits for it before it plans into the slot again; a big batch's K1 runs
+    // on this very stream and needs none -- RSMP_LS_LAZY_DONE=0, debug: recorded always)
+    static const bool lazy_done = [] { const char* e = rsmp::knob("RSMP_LS_LAZY_DONE"); return !e || atoi(e) != 0; }();
+    static const bool stop_ev2 = [] { const char* e = rsmp::knob("RSMP_LS_STOP_EVENT"); return !e || atoi(e) != 0; }();
+    const bool record_done = !(lazy_done && n >= 256);
+    bool done_attached = false;
+    const bool attach = record_done && stop_ev2 && s != reinterpret_cast<hipStream_t>(RSMP_STREAM_LEGACY);
+    RSMP_HIP_CHECK(rsmp::launch_fir_repair_multi(repair_jobs.data(), repair_jobs.size(), s, d_descs, static_cast<uint32_t>(n), max_tail_values,
+                                                 attach ? ls->slot[sl].compute_done : nullptr, &done_attached));
+    if (record_done && !done_attached) RSMP_HIP_CHECK(rsmp::event_record(ls->slot[sl].compute_done, s));
+    ls->slot[sl].compute_recorded = record_done;
+    ls->slot[sl].compute_stream = s;
     ls->slot[sl].used = true;
     if (ls->profiling) {
         RSMP_HIP_CHECK(rsmp::event_record(ls->prof_stop[ls->prof_count % rsmp_fir_lockstep::kProfRing], s));

@@ -15,6 +15,9 @@
 // The bulk kernels (fir_split.hip, fir_periodic.hip) then read those descriptors: nothing of a run passes
 // through the host, whatever states the streams are in.
 #include <algorithm>
+
+#include <hip/hip_ext.h>
+
 #include "fir_lockstep.h"
 
 #include "common.h"
@@ -50,17 +53,28 @@ static_assert(sizeof(CallRec) == 24, "CallRec layout");
 // K1 -- the structure of every call of the run, in exact integer arithmetic: one thread per (stream, call), a workgroup
 // per stream and 256 calls; its first threads make the stream's binade-edge constants (MirrorEdges: thirteen divisions,
 // once per workgroup instead of once per call).
-__global__ __launch_bounds__(256) void fir_lockstep_predict_kernel(LsRunArgs a, uint32_t blocks_per_stream) {
+__global__ __launch_bounds__(256) void fir_lockstep_predict_kernel(LsRunArgs a, uint32_t blocks_per_stream, LsCommitArgs cm) {
     __shared__ MirrorEdges edges;
     const uint32_t gs = blockIdx.x / blocks_per_stream;
     const uint32_t c = (blockIdx.x - gs * blocks_per_stream) * 256u + threadIdx.x;
-    const MirrorRunBase base = mirror_run_base(a.states_in[gs], a.in_frames, a.k);
+    // (cm.n_streams != 0: the states before this run are still in the scratch copies of the run planned before it; they are read
+    // from there, and the stream's first thread puts them -- and what else that plan left -- in place for the kernels behind)
+    const FirMirrorState* const states_now = cm.n_streams ? cm.sp_states : a.states_in;
+    const MirrorRunBase base = mirror_run_base(states_now[gs], a.in_frames, a.k);
     if (base.usable && threadIdx.x <= kPredBinades) mirror_edge(base, threadIdx.x, edges.q[threadIdx.x], edges.r[threadIdx.x]);
     __syncthreads();
     if (c >= a.k) return;
     if (base.usable) a.preds[static_cast<size_t>(gs) * a.k + c] = mirror_predict_edges(base, edges, c);
     if (c == 0) {
-        a.states_before[gs] = a.states_in[gs];   // (the chain overwrites the states; the replay starts from these)
+        if (cm.n_streams) {
+            cm.states[gs] = cm.sp_states[gs];
+            cm.cursor[gs] = cm.sp_cursor[gs];
+            cm.last_counts[2 * gs] = cm.sp_last_counts[2 * gs];
+            cm.last_counts[2 * gs + 1] = cm.sp_last_counts[2 * gs + 1];
+            const uint32_t f = cm.sp_status[gs];
+            if (f) cm.status[gs] |= f;
+        }
+        a.states_before[gs] = states_now[gs];   // (the chain overwrites the states; the replay starts from these)
         if (a.zero_status) a.zero_status[gs] = 0;
     }
     for (uint32_t w = c; w < a.wrap_words; w += a.k) a.wrap_bits[static_cast<size_t>(gs) * a.wrap_words + w] = 0;
@@ -768,13 +782,21 @@ uint32_t lockstep_plan_pack(size_t n_streams) {
     return knob ? knob : kLsPlanPack;
 }
 
-hipError_t launch_fir_lockstep_plan(const LsRunArgs& args_in, hipStream_t stream, int parts) {
+hipError_t launch_fir_lockstep_plan(const LsRunArgs& args_in, hipStream_t stream, int parts, const LsCommitArgs* commit, hipEvent_t k1_done) {
     if (args_in.n_streams == 0 || args_in.k == 0) return hipSuccess;
     static const bool pchain = [] { const char* e = rsmp::knob("RSMP_LS_PCHAIN"); return !e || atoi(e) != 0; }();
     LsRunArgs args = args_in;
     args.parallel_chain = pchain ? 1u : 0u;
     const uint32_t blocks_per_stream = (args.k + 255) / 256;
-    if (parts & 1) hipLaunchKernelGGL(fir_lockstep_predict_kernel, dim3(blocks_per_stream * args.n_streams), dim3(256), 0, stream, args, blocks_per_stream);
+    if (parts & 1) {
+        LsCommitArgs cm{};
+        if (commit) cm = *commit;
+        if (k1_done)
+            hipExtLaunchKernelGGL(fir_lockstep_predict_kernel, dim3(blocks_per_stream * args.n_streams), dim3(256), 0, stream, nullptr, k1_done, 0, args,
+                                  blocks_per_stream, cm);
+        else
+            hipLaunchKernelGGL(fir_lockstep_predict_kernel, dim3(blocks_per_stream * args.n_streams), dim3(256), 0, stream, args, blocks_per_stream, cm);
+    }
     if (parts & 2) {
         const uint32_t pack = lockstep_plan_pack(args.n_streams);
         hipLaunchKernelGGL(fir_lockstep_chain_kernel, dim3((args.n_streams + pack - 1) / pack), dim3(64 * pack), 0, stream, args);

@@ -168,7 +168,11 @@ struct SplitJob {
     uint32_t max_blocks;
     NfArgs nf;
 };
-hipError_t launch_fir_split_multi(const SplitJob* jobs, size_t n_jobs, hipStream_t stream, uint32_t reserve_cus = 0);
+// (items_prebuilt: the covered jobs' item tables, one behind the other, built before by a call with items_only = the stream to build
+// them on -- which launches nothing else; fir_split_multi_item_words: how many words they take)
+hipError_t launch_fir_split_multi(const SplitJob* jobs, size_t n_jobs, hipStream_t stream, uint32_t reserve_cus = 0,
+                                  const uint32_t* items_prebuilt = nullptr, hipStream_t items_only = nullptr);
+size_t fir_split_multi_item_words(const SplitJob* jobs, size_t n_jobs);
 
 // Gives back the split kernel's item-table workspace of a stream that is about to be destroyed.
 void split_release_stream(int device, hipStream_t stream);

@@ -1965,7 +1965,16 @@ hipError_t launch_fir_split(const FirStreamDesc* d_descs, uint32_t n_streams, co
     return hipGetLastError();
 }
 
-hipError_t launch_fir_split_multi(const SplitJob* jobs, size_t n_jobs, hipStream_t stream, uint32_t reserve_cus) {
+size_t fir_split_multi_item_words(const SplitJob* jobs, size_t n_jobs) {
+    size_t items = 0;   // (every job counted, covered by the multi-job builds or not: an upper bound)
+    for (size_t j = 0; j < n_jobs; ++j)
+        if (jobs[j].n_streams != 0 && jobs[j].max_blocks != 0)
+            items += make_split_args(*jobs[j].geo, jobs[j].n_streams, jobs[j].max_blocks, false, jobs[j].nf).total_items;
+    return items * kItemWords;
+}
+
+hipError_t launch_fir_split_multi(const SplitJob* jobs, size_t n_jobs, hipStream_t stream, uint32_t reserve_cus, const uint32_t* items_prebuilt,
+                                  hipStream_t items_only) {
     int device = 0;
     hipError_t e = hipGetDevice(&device);
     if (e != hipSuccess) return e;
@@ -2000,13 +2009,17 @@ hipError_t launch_fir_split_multi(const SplitJob* jobs, size_t n_jobs, hipStream
         return true;
     };
     // jobs the multi-job builds do not cover: a launch each, as before
+    // (items_only: nothing but the covered jobs' item tables, written to items_prebuilt by launches on that stream -- what a later
+    // call with the same jobs and items_prebuilt then does not launch in front of its kernels)
     std::vector<size_t> covered;
     for (size_t j = 0; j < n_jobs; ++j) {
         const SplitJob& job = jobs[j];
         if (job.n_streams == 0 || job.max_blocks == 0) continue;
         if (multi_fn(*job.geo)) covered.push_back(j);
+        else if (items_only) continue;
         else if ((e = launch_fir_split(job.d_descs, job.n_streams, *job.geo, job.max_blocks, cus, false, job.nf, stream, 0)) != hipSuccess) return e;
     }
+    size_t prebuilt_off = 0;   // items of the batches of jobs before this one
     for (size_t c0 = 0; c0 < covered.size(); c0 += kMaxSplitJobs) {
         const uint32_t n = static_cast<uint32_t>(std::min<size_t>(kMaxSplitJobs, covered.size() - c0));
         SplitArgs args[kMaxSplitJobs];
@@ -2033,7 +2046,9 @@ hipError_t launch_fir_split_multi(const SplitJob* jobs, size_t n_jobs, hipStream
         uint32_t* d_items = nullptr;
         bool have_table = false;
         std::lock_guard<std::mutex> launch_lock(items_launch_mu());   // (to the end of this batch of jobs: table launch + kernel launches)
-        if ((e = items_workspace(device, stream, total_items * kItemWords * sizeof(uint32_t), 0, 0, &d_items, &have_table)) != hipSuccess) return e;
+        if (items_prebuilt) d_items = const_cast<uint32_t*>(items_prebuilt) + prebuilt_off * kItemWords;
+        else if ((e = items_workspace(device, stream, total_items * kItemWords * sizeof(uint32_t), 0, 0, &d_items, &have_table)) != hipSuccess) return e;
+        prebuilt_off += total_items;
         {
             SplitMulti m{};
             size_t off = 0;
@@ -2047,9 +2062,12 @@ hipError_t launch_fir_split_multi(const SplitJob* jobs, size_t n_jobs, hipStream
                 m.ib_end[i] = blocks;
             }
             m.n_jobs = n;
-            hipLaunchKernelGGL(split_items_multi_kernel, dim3(blocks), dim3(256), 0, stream, m);
-            if ((e = hipGetLastError()) != hipSuccess) return e;
+            if (items_only || !items_prebuilt) {
+                hipLaunchKernelGGL(split_items_multi_kernel, dim3(blocks), dim3(256), 0, items_only ? items_only : stream, m);
+                if ((e = hipGetLastError()) != hipSuccess) return e;
+            }
         }
+        if (items_only) continue;
         // one launch per kernel build among the jobs; its workgroups dealt in proportion to the jobs' staging work
         // (items x frames of a period: the stagers bound this kernel)
         bool done[kMaxSplitJobs] = {};

@@ -5,7 +5,7 @@ REPS=${1:-2}
 for rep in $(seq $REPS); do
   for n in 1024 128 64; do
     for k in 1 0; do
-      RSMP_DEBUG=1 RSMP_LS_PCHAIN=$k timeout -k 5 200 python bench.py --config c4 --c4-streams $n --steps 32 --warmup 4 2>/dev/null | python -c "
+      RSMP_DEBUG=1 RSMP_LS_PCHAIN=$k timeout -k 5 200 python bench.py --config c4 --c4-streams $n --steps 16384 --warmup 512 2>/dev/null | python -c "
 import json,sys; d=json.loads(sys.stdin.read()); print('streams %4d parallel_chain=$k  us/step %.3f' % ($n, d['ms_per_step']*1e3))"
     done
   done
