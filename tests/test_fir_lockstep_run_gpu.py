@@ -2,6 +2,8 @@
 driven like resample/src/main.rs:226-254) planned on the device and computed by the bulk kernels in one go -- the same
 calls, (consumed, produced) per call, samples (1e-6 RMS against the CPU oracle's AVX+FMA path) and end state (bit for
 bit) as k lock-step steps."""
+import os
+
 import numpy as np
 import pytest
 
@@ -282,6 +284,66 @@ def test_the_same_span_run_again_and_again_without_append():
                 ys.append(out[:p].copy())
             want = np.concatenate(ys)
             assert rms(d_out[i][:want.size].cpu().numpy(), want) <= RMS_TOL, (rep, i)
+    ls.sync()
+    for h, r in zip(hs, refs):
+        assert h.state() == r.state()
+    ls.close()
+
+
+@pytest.mark.parametrize("own_stream", [True, False])
+def test_a_big_batch_runs_in_a_row(own_stream):
+    """Config 4's path proper: from 256 streams on, K1 of the next run goes in FRONT of a run's bulk kernels on the caller's
+    stream and commits the run planned ahead on its way, the caller's stream waits for the planner behind the split launch,
+    the item tables come from the plan stream, and -- on a stream of the caller's own -- the launches complete the events
+    themselves (fir_lockstep_api.cpp, round 6).  264 streams, runs of 8 calls over the same span again and again, a step in
+    between (the plan made ahead is dropped, its commit still due): counts, samples, states."""
+    import torch
+    dev = torch.device("cuda:0")
+    n, k = 264, 8
+    specs = sharding.mixed_rate_batch(n, 2, 512)
+    hs = [ra.ResamplerFir.new_from_hz(2, s.in_hz, s.out_hz, ra.Latency.Sample64, ra.Attenuation.Db90) for s in specs]
+    kind = o.CONVOLVE_AVX_FMA if o.have_avx_fma() else o.CONVOLVE_SCALAR
+    refs = [o.OracleFir(2, s.in_hz, s.out_hz, 128, 90, kind) for s in specs]
+    xs = [synth.hash_noise(k * 512 * 2, seed=300 + i) for i in range(n)]
+    caps = [h.buffer_size_output() for h in hs]
+    d_in = [torch.from_numpy(x).to(dev) for x in xs]
+    d_out = [torch.zeros(k * c, device=dev) for c in caps]
+    ls = ra.FirLockstep(hs, 512)
+    ls.bind_caps(d_in, d_out, caps)
+    st = torch.cuda.Stream() if own_stream else None
+    handle = st.cuda_stream if own_stream else ra.STREAM_LEGACY
+    out = [np.zeros(c, np.float32) for c in caps]
+
+    def check_run(rep):
+        if st:
+            st.synchronize()
+        cons, prod = ls.run_counts()
+        for i, r in enumerate(refs):
+            ys = []
+            for c in range(k):
+                rc, cc, pp = r.resample(xs[i][c * 1024:(c + 1) * 1024], out[i])
+                assert rc == 0 and (cc, pp) == (int(cons[c][i]), int(prod[c][i])), (rep, i, c)
+                ys.append(out[i][:pp].copy())
+            if i % 7 == rep % 7:   # (the samples of every seventh stream, another seven each time)
+                want = np.concatenate(ys)
+                assert rms(d_out[i][:want.size].cpu().numpy(), want) <= RMS_TOL, (rep, i)
+
+    for rep in range(5):
+        ls.run(k, 512, 0, append=False, stream=handle)
+        check_run(rep)
+    ls.step(512, 0, append=False, stream=handle)   # (a plan was made ahead for a sixth run: dropped)
+    if st:
+        st.synchronize()
+    c1, p1 = ls.counts()
+    for i, r in enumerate(refs):
+        rc, cc, pp = r.resample(xs[i][:1024], out[i])
+        assert rc == 0 and (cc, pp) == (int(c1[i]), int(p1[i])), i
+    for rep in range(5, 9):
+        ls.run(k, 512, 0, append=False, stream=handle)
+        check_run(rep)
+    stats = ls.stats()
+    if os.environ.get("RSMP_LS_AHEAD") != "0":   # (tests/test_knobs_gpu.py runs this without the plan stream as well)
+        assert stats["plan_ahead_hits"] >= 3, stats   # (the first runs of a shape probe for a plan stream and have nothing to repeat)
     ls.sync()
     for h, r in zip(hs, refs):
         assert h.state() == r.state()

@@ -65,15 +65,18 @@ def test_lockstep_exact_f32_switch_in_a_child_process():
 
 
 @pytest.mark.parametrize("knob,value", [("RSMP_FIR_SPLIT_MULTI", "0"), ("RSMP_LS_AHEAD", "0"), ("RSMP_LS_PCHAIN", "0"), ("RSMP_LS_COMMIT_ON_PLAN", "0"),
-                                        ("RSMP_FIR_SPLIT_ALL", "0"), ("RSMP_LS_PACK", "1")])
+                                        ("RSMP_FIR_SPLIT_ALL", "0"), ("RSMP_LS_PACK", "1"), ("RSMP_LS_FUSE_COMMIT", "0"), ("RSMP_LS_EARLY_WAIT", "0"),
+                                        ("RSMP_LS_STOP_EVENT", "0"), ("RSMP_LS_LAZY_DONE", "0"), ("RSMP_LS_ITEMS_AHEAD", "0")])
 def test_lockstep_run_switches_in_a_child_process(knob, value):
     """The run of several calls with one launch per rate pair (no multi-job launch) / planned on the caller's stream only / the
     planner's chain call by call (round 5's) instead of a chunk of calls per wave in parallel / the states committed on the
-    caller's stream / one split launch per kernel build instead of one for all / one planner wave per workgroup."""
+    caller's stream / one split launch per kernel build instead of one for all / one planner wave per workgroup / round 6's
+    changes between two split launches one by one (the commit a launch of its own, the wait for the planner in front of the
+    next run, events recorded by packets, the "computed" event always recorded, the item tables built in front of the kernel)."""
     env = dict(os.environ, RSMP_DEBUG="1", PYTHONPATH=ROOT)
     env[knob] = value
     p = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_fir_lockstep_run_gpu.py"), "-q", "-m", "gpu",
-                        "-k", "planned_ahead or k_calls_equals or interleave or append or different_states or same_span or old_stream", "-p", "no:cacheprovider"],
+                        "-k", "planned_ahead or k_calls_equals or interleave or append or different_states or same_span or old_stream or big_batch", "-p", "no:cacheprovider"],
                        env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-3000:]
     assert " passed" in p.stdout, p.stdout[-1000:]
