@@ -202,16 +202,54 @@ __device__ __forceinline__ double shfl_up_f64(double v, int d) {
     const uint32_t hi = static_cast<uint32_t>(__shfl_up(static_cast<int>(static_cast<uint32_t>(b >> 32)), d, 64));
     return mirror_from_bits(static_cast<uint64_t>(lo) | (static_cast<uint64_t>(hi) << 32));
 }
+// The prefix scans' steps as DPP moves (a ds_bpermute per 32 bits was ~250 cycles a step): the value of the lane 1 / 2 / 4 / 8 to the
+// left within a row of 16, then lane 15 of rows 0 / 2 to rows 1 / 3, then lane 31 to rows 2 and 3 -- lanes without a source get `old`.
+constexpr int kDppShr1 = 0x111, kDppShr2 = 0x112, kDppShr4 = 0x114, kDppShr8 = 0x118, kDppBcast15 = 0x142, kDppBcast31 = 0x143;
+template <int CTRL, int ROWS>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t v, uint32_t old) {
+    return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(static_cast<int>(old), static_cast<int>(v), CTRL, ROWS, 0xF, false));
+}
+template <int CTRL, int ROWS>
+__device__ __forceinline__ double dpp_f64(double v) {   // (`old`: 0.0)
+    const uint64_t b = mirror_bits(v);
+    return mirror_from_bits(static_cast<uint64_t>(dpp_u32<CTRL, ROWS>(static_cast<uint32_t>(b), 0u)) |
+                            (static_cast<uint64_t>(dpp_u32<CTRL, ROWS>(static_cast<uint32_t>(b >> 32), 0u)) << 32));
+}
+template <int CTRL, int ROWS>
+__device__ __forceinline__ ChainMap dpp_map(const ChainMap& v) {   // (`old`: the identity)
+    return ChainMap{dpp_f64<CTRL, ROWS>(v.d0), dpp_f64<CTRL, ROWS>(v.d1), dpp_u32<CTRL, ROWS>(v.bits, 0x2u | 0xCu)};
+}
+// inclusive prefix sums over the wave's 64 lanes (exact where the terms are multiples of one power of two and small)
+__device__ __forceinline__ double wave_prefix_sum(double v) {
+    v += dpp_f64<kDppShr1, 0xF>(v);
+    v += dpp_f64<kDppShr2, 0xF>(v);
+    v += dpp_f64<kDppShr4, 0xF>(v);
+    v += dpp_f64<kDppShr8, 0xF>(v);
+    v += dpp_f64<kDppBcast15, 0xA>(v);
+    v += dpp_f64<kDppBcast31, 0xC>(v);
+    return v;
+}
+// ... and of maps: lane j gets map 0 then 1 then ... then j
+__device__ __forceinline__ ChainMap wave_prefix_maps(ChainMap v) {
+    v = chain_map_compose(dpp_map<kDppShr1, 0xF>(v), v);
+    v = chain_map_compose(dpp_map<kDppShr2, 0xF>(v), v);
+    v = chain_map_compose(dpp_map<kDppShr4, 0xF>(v), v);
+    v = chain_map_compose(dpp_map<kDppShr8, 0xF>(v), v);
+    v = chain_map_compose(dpp_map<kDppBcast15, 0xA>(v), v);
+    v = chain_map_compose(dpp_map<kDppBcast31, 0xC>(v), v);
+    return v;
+}
 // The lane's own call from `start`: the position after it (already less what it retires) and the frames it retires.
-template <uint32_t L = 0>
+// (TIES: some lane's call has an output exactly on a binade's edge in exact arithmetic -- mirror_chain_step looks which side f64 puts it)
+template <bool TIES, uint32_t L = 0>
 __device__ inline uint32_t chain_eval_lane(uint32_t shape, double& pos, uint32_t avail, uint32_t in_frames, double ratio, const MirrorBinades& bn,
                                            uint32_t n_total, const ChainPlan& cp) {
     if constexpr (L < kPredBinades) {
         if (shape == L) {
             ChainScalars tmp{0, 0, 0, avail};
-            return mirror_chain_step<L, true, false>(pos, tmp, in_frames, ratio, bn, n_total, cp.ctl, cp.n_last, cp.m);
+            return mirror_chain_step<L, TIES, false>(pos, tmp, in_frames, ratio, bn, n_total, cp.ctl, cp.n_last, cp.m);
         }
-        return chain_eval_lane<L + 1>(shape, pos, avail, in_frames, ratio, bn, n_total, cp);
+        return chain_eval_lane<TIES, L + 1>(shape, pos, avail, in_frames, ratio, bn, n_total, cp);
     } else {
         return 0xFFFFFFFFu;
     }
@@ -302,22 +340,24 @@ __global__ __launch_bounds__(64 * kLsPlanPack) void fir_lockstep_chain_kernel(Ls
             {
             const double p_start = st_valid ? st.position : pos;
             const uint32_t my_shape = (my_cp.ctl >> 8) & 0xFu;
-            // where a plain f64 sum of the prediction puts every call's start (good to ~1e-12: the same SHAPE as the true start
-            // unless the f64 drift is smaller than that -- then the check below fails and the serial loop takes the chunk)
-            double est = in_seg ? static_cast<double>(my_n_total) * ratio - static_cast<double>(my_cpred) : 0.0;
-#pragma unroll
-            for (int sft = 1; sft < 64; sft <<= 1) {
-                const double upv = shfl_up_f64(est, sft);
-                if (lane >= static_cast<uint32_t>(sft)) est += upv;
-            }
-            const double before = shfl_up_f64(est, 1);
-            const double x_start = p_start + (lane <= s0 ? 0.0 : before);
+            // where the prediction puts every call's start in plain f64 (good to ~1e-12: the same SHAPE as the true start unless the f64
+            // drift is smaller than that -- then the check below fails and the serial loop takes the chunk): the run's start + the outputs
+            // since x the ratio - the frames retired since, from the predictions' absolute counters
+            const uint64_t m0_s0 = static_cast<uint64_t>(rl(static_cast<uint32_t>(mine[0]), s0)) | (static_cast<uint64_t>(rl(static_cast<uint32_t>(mine[0] >> 32), s0)) << 32);
+            const uint64_t c0_s0 = static_cast<uint64_t>(rl(static_cast<uint32_t>(mine[1]), s0)) | (static_cast<uint64_t>(rl(static_cast<uint32_t>(mine[1] >> 32), s0)) << 32);
+            const uint32_t outs_before = in_seg ? static_cast<uint32_t>(mine[0] - m0_s0) : 0u, retired_before = in_seg ? static_cast<uint32_t>(mine[1] - c0_s0) : 0u;
+            const double x_start = p_start + (static_cast<double>(outs_before) * ratio - static_cast<double>(retired_before));
+            const bool any_ties = __any(in_seg && (my_cp.ctl & 0xFFF000u) != 0);
+            auto eval = [&](double& pe) -> uint32_t {
+                return any_ties ? chain_eval_lane<true>(my_shape, pe, static_cast<uint32_t>(my_avail), a.in_frames, ratio, bn, my_n_total, my_cp)
+                                : chain_eval_lane<false>(my_shape, pe, static_cast<uint32_t>(my_avail), a.in_frames, ratio, bn, my_n_total, my_cp);
+            };
             // the representative start: on the grid of [4096, 8192) -- a multiple of every grid a call of at most 4096 buffered frames rounds on
             const double kCoarse = 1099511627776.0;   // 2^40
             const double rep = floor(x_start * kCoarse + 0.5) * (1.0 / kCoarse);
             // ... from which the call's LAST add (the one behind its last output) lands in this lane's top binade
             double pe0 = rep;
-            const uint32_t cons0 = in_seg ? chain_eval_lane(my_shape, pe0, static_cast<uint32_t>(my_avail), a.in_frames, ratio, bn, my_n_total, my_cp) : 0u;
+            const uint32_t cons0 = in_seg ? eval(pe0) : 0u;
             const double raw0 = pe0 + static_cast<double>(cons0 == 0xFFFFFFFFu ? 0u : cons0);
             const uint32_t my_exp = in_seg ? static_cast<uint32_t>((mirror_bits(raw0) >> 52) & 0x7FFu) : 0u;   // biased exponent of the end position
             const uint32_t exp0 = rl(my_exp, s0);
@@ -337,7 +377,7 @@ __global__ __launch_bounds__(64 * kLsPlanPack) void fir_lockstep_chain_kernel(Ls
             if (shapes_ok) {
                 const uint32_t r_start = two ? static_cast<uint32_t>(static_cast<uint64_t>(q_start) & 1ull) : 0u;
                 ChainMap me = chain_map_identity();
-                double d_own[2] = {0.0, 0.0};
+                double d_own0 = 0.0, d_own1 = 0.0;   // (scalars: an array indexed by the residue would live in LDS)
                 if (in_seg) {
                     uint32_t bits = 0;
 #pragma unroll
@@ -345,35 +385,35 @@ __global__ __launch_bounds__(64 * kLsPlanPack) void fir_lockstep_chain_kernel(Ls
                         const double s0 = rep + (r ? u_lo : 0.0);
                         double pe = r == 0 ? pe0 : s0;
                         uint32_t cons = cons0;
-                        if (r == 1) cons = two ? chain_eval_lane(my_shape, pe, static_cast<uint32_t>(my_avail), a.in_frames, ratio, bn, my_n_total, my_cp) : 0u;
+                        if (r == 1) cons = two ? eval(pe) : 0u;
                         const double d = pe - s0;                 // exact: both on the lower grid
                         const double q_end = pe * inv_lo;
                         // (the run's LAST call has no successor to predict what it retires: whatever the chain says)
                         const bool ok = (r == 0 || two) && (cons == my_cpred || my_last) && cons != 0xFFFFFFFFu && q_end == floor(q_end) && pe >= 0.0;
                         const uint32_t r_end = two ? static_cast<uint32_t>(static_cast<uint64_t>(q_end < 0.0 ? 0.0 : q_end) & 1ull) : 0u;
-                        d_own[r] = d;
+                        if (r == 0) d_own0 = d; else d_own1 = d;
                         bits |= (r_end << r) | ((ok ? 1u : 0u) << (2 + r));
                     }
                     if (!two) {   // (one grid: residue 1 does not exist; the map ignores it)
-                        d_own[1] = d_own[0];
+                        d_own1 = d_own0;
                         bits = (bits & 0x5u) | ((bits & 1u) << 1) | ((bits & 4u) << 1);
                     }
-                    me = ChainMap{d_own[0], d_own[1], bits};
+                    me = ChainMap{d_own0, d_own1, bits};
                 }
-                ChainMap incl = me;
-#pragma unroll
-                for (int sft = 1; sft < 64; sft <<= 1) {
-                    ChainMap left;
-                    left.d0 = shfl_up_f64(incl.d0, sft);
-                    left.d1 = shfl_up_f64(incl.d1, sft);
-                    left.bits = static_cast<uint32_t>(__shfl_up(static_cast<int>(incl.bits), sft, 64));
-                    if (lane >= static_cast<uint32_t>(sft)) incl = chain_map_compose(left, incl);
+                // (one grid: every map is r -> 0 with one shift -- a prefix sum of the shifts and a vote on the validity)
+                ChainMap incl;
+                if (two) {
+                    incl = wave_prefix_maps(me);
+                } else {
+                    const double sum = wave_prefix_sum(me.d0);
+                    const bool all_ok = __all(!in_seg || ((me.bits >> 2) & 1u) != 0);
+                    incl = ChainMap{sum, sum, all_ok ? 0xCu : 0u};
                 }
                 // this lane's call starts behind calls 0 .. lane - 1
                 ChainMap excl;
                 excl.d0 = shfl_up_f64(incl.d0, 1);
-                excl.d1 = shfl_up_f64(incl.d1, 1);
-                excl.bits = static_cast<uint32_t>(__shfl_up(static_cast<int>(incl.bits), 1, 64));
+                excl.d1 = two ? shfl_up_f64(incl.d1, 1) : excl.d0;
+                excl.bits = two ? static_cast<uint32_t>(__shfl_up(static_cast<int>(incl.bits), 1, 64)) : incl.bits;
                 if (lane <= s0) excl = chain_map_identity();
                 const double p_mine = p_start + (r_start ? excl.d1 : excl.d0);
                 const uint32_t r_mine = (excl.bits >> r_start) & 1u;
@@ -383,8 +423,8 @@ __global__ __launch_bounds__(64 * kLsPlanPack) void fir_lockstep_chain_kernel(Ls
                 uint32_t my_cons = 0;
                 if (in_seg) {
                     double pe = p_mine;
-                    my_cons = chain_eval_lane(my_shape, pe, static_cast<uint32_t>(my_avail), a.in_frames, ratio, bn, my_n_total, my_cp);
-                    same = guess_ok && (my_cons == my_cpred || my_last) && my_cons != 0xFFFFFFFFu && (pe - p_mine) == d_own[r_mine];
+                    my_cons = eval(pe);
+                    same = guess_ok && (my_cons == my_cpred || my_last) && my_cons != 0xFFFFFFFFu && (pe - p_mine) == (r_mine ? d_own1 : d_own0);
                 }
                 if (__all(same)) {
                     if (st_valid) {   // (the counters leave `st`)
@@ -395,12 +435,23 @@ __global__ __launch_bounds__(64 * kLsPlanPack) void fir_lockstep_chain_kernel(Ls
                     const uint32_t last = e0 - 1;
                     pos = rl_f64(p_start + (r_start ? incl.d1 : incl.d0), last);
                     my_pos = in_seg ? p_mine : my_pos;
-                    // the counters behind the chunk, from the last call's prediction; the ring's read position call by call (:605-615)
-                    uint32_t rp = sc.read_position;
-                    for (uint32_t k = s0; k < e0; ++k) {
-                        rp += rl(my_cons, k);
-                        if (rp > kMirrorInputCapacity) rp = 0;
+                    // the counters behind the chunk, from the last call's prediction; the ring's read position (:605-615: back to 0 when it
+                    // passes the capacity) from the frames retired before every call -- call by call only if some call does send it back
+                    // (the ring's read position goes back to 0 every capacity / call size calls: from one such call to the next by a vote
+                    // on the frames retired since, not call by call)
+                    const uint32_t retired_through = retired_before + my_cons;   // frames the run has retired through this lane's call
+                    uint32_t rp_base = sc.read_position;   // the read position where the count `since` starts ...
+                    uint32_t since = 0;                    // ... the frames retired up to there
+                    uint64_t left = full_mask;
+                    for (;;) {
+                        const uint64_t over = __ballot(in_seg && rp_base + (retired_through - since) > kMirrorInputCapacity) & left;
+                        if (!over) break;
+                        const uint32_t j = static_cast<uint32_t>(__builtin_ctzll(over));   // the first call that sends it back
+                        since = rl(retired_through, j);
+                        rp_base = 0;
+                        left = j >= 63u ? 0ull : left & ~((2ull << j) - 1ull);
                     }
+                    const uint32_t rp = rp_base + (rl(retired_through, last) - since);
                     const uint32_t n_last_total = rl(my_n_total, last), c_last = rl(my_cons, last);
                     const uint64_t m0_last = static_cast<uint64_t>(rl(static_cast<uint32_t>(mine[0]), last)) | (static_cast<uint64_t>(rl(static_cast<uint32_t>(mine[0] >> 32), last)) << 32);
                     const uint64_t c0_last = static_cast<uint64_t>(rl(static_cast<uint32_t>(mine[1]), last)) | (static_cast<uint64_t>(rl(static_cast<uint32_t>(mine[1] >> 32), last)) << 32);
@@ -587,7 +638,7 @@ __global__ __launch_bounds__(64 * kLsPlanPack) void fir_lockstep_chain_kernel(Ls
 // whose period is the planner's own latency, give every chunk of a round of kLsWrapWaves chunks a wave of its own and
 // settle the stream's drift -- that of the LAST call with an output at an integer position -- through LDS: 32 -> ~10 us
 // per run at 128 streams x 256 calls.)
-constexpr uint32_t kLsWrapWaves = 4;
+constexpr uint32_t kLsWrapWaves = 16;   // (at most: a run of 256 calls has four chunks, a bulk launch of 4096 calls sixty-four)
 __global__ __launch_bounds__(64 * kLsWrapWaves) void fir_lockstep_wraps_kernel(LsRunArgs a) {
     __shared__ double s_drift[kLsWrapWaves];
     __shared__ uint32_t s_chunk[kLsWrapWaves], s_flags[kLsWrapWaves];
