@@ -377,20 +377,20 @@ struct ChainPlan {
 // limit, no clamped count, the binades below the top one full, n_low small.
 __host__ __device__ inline ChainPlan mirror_chain_plan(const MirrorPred& pr) {
     ChainPlan p;
-    uint32_t top = 0;
+    uint32_t top = 0, n_top = pr.n[0];
     bool any = false, full = true;
 #pragma unroll
     for (uint32_t i = 0; i < kPredBinades; ++i) {
         const uint32_t n = pr.n[i];
         p.m[i] = n >= 3 ? static_cast<double>(n - 1) : 0.0;
-        if (n != 0) { top = i; any = true; }
-    }
+        if (n != 0) { top = i; any = true; n_top = n; }   // (n_top = pr.n[top] without an index that is not a constant: on the device
+    }                                                      // that index put the whole prediction record into LDS)
 #pragma unroll
     for (uint32_t i = 0; i < kPredBinades; ++i)
         if (i < top && pr.n[i] < 4) full = false;   // (a binade below the top one: >= 4, so that a tie's single add leaves >= 3)
     const bool lean = any && full && pr.n_low < 256 && (pr.ties & (kPredLimitTie | kPredIrregular)) == 0;
     p.ctl = pr.n_low | (top << 8) | ((pr.ties & 0xFFFu) << 12) | (lean ? kChainLean : 0u);
-    p.n_last = pr.n[top];
+    p.n_last = n_top;
     return p;
 }
 // One call of shape L (ctl bits 8-11): the f64 chain on `pos`, then what the call retires (:596-615).  `m[i]`, i <= L, and

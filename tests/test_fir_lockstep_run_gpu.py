@@ -541,6 +541,53 @@ def test_table_replacements_stay_off_the_launch_path():
         assert h.state() == r.state()
 
 
+@pytest.mark.parametrize("calls,chunk,fresh", [(1100, 64, False), (4096, 32, False), (2000, 48, True), (1024, 128, False)])
+def test_long_runs_of_few_streams(calls, chunk, fresh):
+    """Bulk launches of thousands of calls per stream (rsmp_fir_lockstep_run_bulk: 16 .. 64 chunks of 64 calls for the
+    planner's chain, whose parallel path takes a chunk at a time -- a run of lean calls -- and leaves the call in ~160
+    with an output exactly at its limit to the checked path).  Twelve streams of six rate pairs in twelve states (`fresh`:
+    straight from reset), launch after launch on the streams' own state: every call's counts, the samples, the end states."""
+    import torch
+    dev = torch.device("cuda:0")
+    n = 12
+    specs = sharding.mixed_rate_batch(n, 2, 512)
+    hs = [ra.ResamplerFir.new_from_hz(2, s.in_hz, s.out_hz, ra.Latency.Sample64, ra.Attenuation.Db90) for s in specs]
+    kind = o.CONVOLVE_AVX_FMA if o.have_avx_fma() else o.CONVOLVE_SCALAR
+    refs = [o.OracleFir(2, s.in_hz, s.out_hz, 128, 90, kind) for s in specs]
+    rng = np.random.default_rng(calls)
+    if not fresh:
+        for i, (h, r) in enumerate(zip(hs, refs)):   # distinct states
+            x = (rng.random(2 * (300 + 41 * i), dtype=np.float32) * 2 - 1).astype(np.float32)
+            og, orr = np.zeros(h.buffer_size_output(), np.float32), np.zeros(r.buffer_size_output(), np.float32)
+            off = 0
+            while off < x.size:
+                cg, pg = h.resample(x[off:off + 2 * 173], og)
+                rc, cr, pr = r.resample(x[off:off + 2 * 173], orr)
+                assert rc == 0 and (cg, pg) == (cr, pr)
+                off += cg
+    total = calls * chunk
+    caps = [h.buffer_size_output() for h in hs]
+    ls = ra.FirLockstep(hs, 512)
+    for launch in range(3):
+        xs = [(rng.random(2 * total, dtype=np.float32) * 2 - 1).astype(np.float32) for _ in range(n)]
+        d_in = [torch.from_numpy(x).to(dev) for x in xs]
+        d_out = [torch.zeros((calls + 2) * c, device=dev) for c in caps]
+        ls.bind_caps(d_in, d_out, caps)
+        ls.run_bulk(total, chunk)
+        cons, prod = ls.run_counts()
+        worst = 0.0
+        for i, r in enumerate(refs):
+            y, cl = r.resample_all(xs[i], 2 * chunk, max_calls=calls + 4)
+            assert cl.shape[0] == calls, (i, cl.shape)
+            assert (cl[:, 0] == cons[:, i]).all() and (cl[:, 1] == prod[:, i]).all(), (launch, i)
+            worst = max(worst, rms(d_out[i][:y.size].cpu().numpy(), y))
+        assert worst <= RMS_TOL, (launch, worst)
+        ls.sync()
+        for h, r in zip(hs, refs):
+            assert h.state() == r.state(), launch
+    ls.close()
+
+
 @pytest.mark.parametrize("total,chunk", [(20000, 256), (16384, 512), (9999, 300)])
 def test_bulk_batch_in_distinct_states_planned_on_the_device(total, chunk):
     """64 streams of six rate pairs in 64 different states (each has already run a different,
