@@ -179,8 +179,7 @@ __device__ __forceinline__ uint32_t chain_fast_run_of(uint32_t shape, uint32_t s
 // ONCE MORE from that start and the chunk is accepted only if each call reproduces the shift the scan used and retires what the
 // prediction says: p[k + 1] = F_k(p[k]) for every k from the true p[0] IS the serial recurrence, bit for bit.  Anything else -- a
 // call that is not lean, calls whose top binades differ by more than one, a start off the grid (a stream's first chunk), a tie the
-// representative saw from the other side -- leaves those calls to the serial loop below, unchanged.  ~7 us per chunk against 64 x 0.41
-// (DESIGN.md section 4.3b).
+// representative saw from the other side -- leaves the chunk to the serial loop below, unchanged.  ~2 us per chunk against 64 x 0.41.
 struct ChainMap {
     double d0, d1;        // the shift for start residue 0 / 1
     uint32_t bits;        // bit 0 / 1: the residue after the call for start residue 0 / 1; bit 2 / 3: that start is valid
