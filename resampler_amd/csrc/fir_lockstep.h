@@ -184,6 +184,8 @@ struct LsCommitArgs {
 // kLsPlanPackBelow streams: the CUs they take are then few and known (lockstep_plan_cus), whoever reaches the chip first.
 constexpr uint32_t kLsPlanPack = 4, kLsPlanPackBelow = 256;   // (pack 1 / 2 / 4 / 8 at 128 streams: 0.89 / 0.71-0.86 / 0.73 / 0.83-0.95 us per step, profiles/r06/ab_c4_shard.txt: eight waves of this much CODE on one CU starve each other of instructions)
 uint32_t lockstep_plan_pack(size_t n_streams);   // (fir_lockstep_run.hip; RSMP_LS_PACK, debug: 1 / 2 / 4 / 8)
+// CUs the replay (K3) of a run of k calls takes when it has a wave per chunk (batches below kLsPlanPackBelow streams): sixteen waves a CU
+uint32_t lockstep_replay_cus(size_t n_streams, uint32_t k);   // (fir_lockstep_run.hip)
 inline uint32_t lockstep_plan_cus(size_t n_streams) {
     const uint32_t pack = lockstep_plan_pack(n_streams);
     return pack > 1 ? static_cast<uint32_t>((n_streams + pack - 1) / pack) : static_cast<uint32_t>((n_streams + 3) / 4);

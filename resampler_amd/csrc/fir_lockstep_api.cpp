@@ -1359,8 +1359,11 @@ extern "C" int rsmp_fir_lockstep_run(rsmp_fir_lockstep* ls, size_t k_steps, size
     uint32_t reserve = 0;
     if (repeat && n < 256) {
         static const int knob = [] { const char* e = rsmp::knob("RSMP_LS_RESERVE"); return e ? atoi(e) : -1; }();
-        // (the planner's packed workgroups take lockstep_plan_cus(n) CUs -- 32 for 128 streams --, + 4 for its one-wave kernels)
-        reserve = knob >= 0 ? static_cast<uint32_t>(knob) : std::min<uint32_t>(64u, rsmp::lockstep_plan_cus(n) + 4u);
+        // (the planner's packed workgroups take lockstep_plan_cus(n) CUs -- 32 for 128 streams --, + 4 for its one-wave kernels; the
+        // replay behind the chain a wave per chunk: a bulk launch of 64 streams x 4096 calls has 1024 of them, 64 CUs' worth, and with
+        // 20 CUs left to it every fourth launch took 0.78 instead of 0.56 ms -- profiles/r06/bulk_distinct_reserve.txt)
+        reserve = knob >= 0 ? static_cast<uint32_t>(knob)
+                            : std::min<uint32_t>(64u, std::max(rsmp::lockstep_plan_cus(n), rsmp::lockstep_replay_cus(n, k)) + 4u);
     }
     // (the item tables: built on the plan stream behind this run's plan, if it was planned ahead and no table has changed since)
     const auto& cslot = ls->slot[sl];

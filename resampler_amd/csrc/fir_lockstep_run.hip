@@ -833,6 +833,12 @@ uint32_t lockstep_plan_pack(size_t n_streams) {
     return knob ? knob : kLsPlanPack;
 }
 
+uint32_t lockstep_replay_cus(size_t n_streams, uint32_t k) {
+    if (lockstep_plan_pack(n_streams) <= 1) return 0;
+    const uint32_t chunks = (k + 63) / 64, waves = std::min<uint32_t>(kLsWrapWaves, chunks);
+    return static_cast<uint32_t>((n_streams * waves + 15) / 16);
+}
+
 hipError_t launch_fir_lockstep_plan(const LsRunArgs& args_in, hipStream_t stream, int parts, const LsCommitArgs* commit, hipEvent_t k1_done) {
     if (args_in.n_streams == 0 || args_in.k == 0) return hipSuccess;
     static const bool pchain = [] { const char* e = rsmp::knob("RSMP_LS_PCHAIN"); return !e || atoi(e) != 0; }();
