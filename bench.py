@@ -936,6 +936,9 @@ def secondary_lines(ctx: Ctx, args):
         handles, batch = make_fir_batch(ctx, ra, args.streams, args.frames, args.chunk, ra.FirKernel.Auto,
                                         distinct_states=True)
         t1 = time.perf_counter()
+        setup_s = t1 - t0
+        # (1) the C entry as it is, rsmp_fir_batch_resample_bulk_device: every distinct state planned on the host's worker pool
+        batch.device_planner = False
         batch.resample_bulk_device(args.chunk, ctx.stream)
         ctx.torch.cuda.synchronize()
         cold = (time.perf_counter() - t1) * 1e3
@@ -950,6 +953,26 @@ def secondary_lines(ctx: Ctx, args):
             again.append((time.perf_counter() - t2) * 1e3)
         k_again, _ = handles[0].mean_kernel_ms()
         handles[0].set_profiling(False)
+        host_planned = {"step_ms_cold": round(cold, 2), "step_ms_replanned_median": round(sorted(again)[len(again) // 2], 2),
+                        "kernel_ms_replanned": round(k_again, 3),
+                        "what": "rsmp_fir_batch_resample_bulk_device itself (FirBatch.device_planner = False): every distinct state planned "
+                                "on the host's worker pool, counts returned when the launch is enqueued"}
+        # (2) the host entry as a caller of resampler_amd.FirBatch gets it: a batch in this many different states goes through the
+        # device planner behind the same method (a lock-step batch over the same handles, kept from launch to launch, the states
+        # written back into the handles before the call returns -- so the call returns when the launch is through)
+        batch.device_planner = None
+        t1 = time.perf_counter()
+        batch.resample_bulk_device(args.chunk, ctx.stream)
+        ctx.torch.cuda.synchronize()
+        cold = (time.perf_counter() - t1) * 1e3
+        again = []
+        for _ in range(8):
+            t2 = time.perf_counter()
+            batch.resample_bulk_device(args.chunk, ctx.stream)
+            ctx.torch.cuda.synchronize()
+            again.append((time.perf_counter() - t2) * 1e3)
+        routed = getattr(batch, "_ls", None) is not None
+        k_again = host_planned["kernel_ms_replanned"]
         # ... and the same batch through the DEVICE planner (rsmp_fir_lockstep_run_bulk: the calls' structure, the f64 chain and
         # the wrapped outputs planned by three small kernels, nothing replayed on the host, no host threads): the first
         # launch, then launches that continue the streams (each planned anew, the next one planned ahead beside this one's
@@ -985,11 +1008,14 @@ def secondary_lines(ctx: Ctx, args):
             dp = {"error": repr(e)[:200]}
         return {
             "device_planned": dp,
-            "what": f"{args.streams} streams in {args.streams} different states: the first launch (every stream replays its own "
-                    f"control flow on the host's planning workers, then one launch), then launches that continue the streams "
-                    f"(planned anew every time), wall clock of a launch incl. synchronisation",
+            "host_planned_c_entry": host_planned,
+            "routed_through_device_planner": routed,
+            "what": f"{args.streams} streams in {args.streams} different states through FirBatch.resample_bulk_device: the first launch, then "
+                    f"launches that continue the streams (planned anew every time), wall clock of a launch incl. synchronisation.  FirBatch "
+                    f"routes a batch in >= {ra.FirBatch.kDevicePlanStates} different states through rsmp_fir_lockstep_run_bulk over the same handles "
+                    f"(planned on the device; `host_planned_c_entry`: the C entry's own host planner on the same batch)",
             "step_ms_cold": round(cold, 2), "step_ms_replanned_median": round(sorted(again)[len(again) // 2], 2),
-            "kernel_ms_replanned": round(k_again, 3), "setup_s": round(t1 - t0, 2)}
+            "kernel_ms_replanned": round(k_again, 3), "setup_s": round(setup_s, 2)}
     guard("fir_distinct_states", distinct_point)
     keys = ("metric", "value", "unit", "ms_per_step", "scaling", "dtype", "config", "roofline")
     # (64 launches of the configuration's 256 steps: ~60 ms; 72 launches of config 5: ~53 ms)

@@ -107,6 +107,13 @@ extern "C" {
     fn rsmp_fir_lockstep_run_counts(ls: *mut rsmp_fir_lockstep, consumed: *mut usize, produced: *mut usize,
                                     max_steps: usize) -> c_int;
     fn rsmp_fir_lockstep_sync(ls: *mut rsmp_fir_lockstep) -> c_int;
+    fn rsmp_fir_lockstep_sync_totals(ls: *mut rsmp_fir_lockstep, accepted: *mut usize, produced: *mut usize, status_or: *mut u32) -> c_int;
+    #[allow(dead_code)]
+    fn rsmp_fir_lockstep_in_sync(ls: *const rsmp_fir_lockstep, in_sync: *mut c_int) -> c_int;
+    #[allow(dead_code)]
+    fn rsmp_fir_lockstep_discard(ls: *mut rsmp_fir_lockstep);
+    #[allow(dead_code)]
+    fn rsmp_fir_batch_distinct_states(rs: *const *mut rsmp_fir, n: usize, distinct: *mut usize) -> c_int;
     fn rsmp_fir_lockstep_table_rebinds(ls: *const rsmp_fir_lockstep, rebinds: *mut usize) -> c_int;
     fn rsmp_fir_lockstep_run_bulk(ls: *mut rsmp_fir_lockstep, total_frames: usize, chunk_frames: usize, in_offset_frames: usize,
                                   append: c_int, stream: *mut std::os::raw::c_void) -> c_int;
@@ -320,6 +327,14 @@ impl LockstepBatch {
     /// How closely the coefficient tables follow the streams' f64 drift (default 1.2e-7 of a frame, looked at every 2^19 frames).
     pub fn set_drift_policy(&mut self, tolerance_frames: f64, check_frames: usize) -> Result<(), ResampleError> {
         status(unsafe { rsmp_fir_lockstep_set_drift_policy(self.handle, tolerance_frames, check_frames) })
+    }
+    /// Waits for what has been launched, writes the device state back into the streams and returns, per stream, the values accepted and
+    /// produced since the states were last exchanged (what a bulk driver loop over the same input returns) and the OR of the status flags.
+    pub fn sync_totals(&mut self) -> Result<(Vec<usize>, Vec<usize>, u32), ResampleError> {
+        let n = self.streams.len();
+        let (mut a, mut p, mut f) = (vec![0usize; n], vec![0usize; n], 0u32);
+        status(unsafe { rsmp_fir_lockstep_sync_totals(self.handle, a.as_mut_ptr(), p.as_mut_ptr(), &mut f) })?;
+        Ok((a, p, f))
     }
     /// Writes the device state back into the streams and hands them back.
     pub fn into_streams(mut self) -> Vec<ResamplerFir> {

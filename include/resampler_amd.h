@@ -217,7 +217,9 @@ int rsmp_fir_lockstep_run_counts(rsmp_fir_lockstep* ls, size_t* consumed, size_t
  * output appended behind theirs.  Asynchronous on `stream`, planned on the device whatever states the streams are in
  * (no host planning, no host threads): the bulk entry point for batches of streams in DISTINCT states.  Counts:
  * rsmp_fir_lockstep_run_counts (the equal calls) and rsmp_fir_lockstep_counts (the last call); rsmp_fir_lockstep_sync
- * brings the streams' states back into their handles.  chunk_frames <= the batch's max_step_frames. */
+ * brings the streams' states back into their handles.  chunk_frames <= the batch's max_step_frames, and calls every stream
+ * accepts WHOLE: chunk_frames + taps + 8 <= 4096 (INPUT_CAPACITY, resampler_fir.rs:18; the driver loop offers a call's
+ * remainder again, a run's calls read at fixed offsets) -- RSMP_ERR_INVALID_INPUT_BUFFER_SIZE otherwise. */
 int rsmp_fir_lockstep_run_bulk(rsmp_fir_lockstep* ls, size_t total_frames, size_t chunk_frames, size_t in_offset_frames,
                                int append, void* stream);
 /* Diagnostic: calls of the last run (all streams) that the device planner's fast path declined and the plain state
@@ -249,6 +251,19 @@ int rsmp_fir_lockstep_set_drift_policy(rsmp_fir_lockstep* ls, double tolerance_f
  * position beyond 1 / out_hz; never observed: the run's counts are then not the reference's). */
 int rsmp_fir_lockstep_status(rsmp_fir_lockstep* ls, uint32_t* status);
 int rsmp_fir_lockstep_sync(rsmp_fir_lockstep* ls);
+/* rsmp_fir_lockstep_sync + what every stream has done since the batch's states were last exchanged with the handles (creation, reset,
+ * the previous sync): accepted[i] = frames accepted x channels, produced[i] = frames produced x channels -- the (consumed, produced) a
+ * bulk driver loop over the same input would return (resample/src/main.rs:226-254: every call accepts its whole offer) --, *status_or =
+ * the OR of the streams' sticky flags.  rsmp_fir_lockstep_in_sync: *in_sync = 1 if no handle has been touched through another entry
+ * point since (its state and history buffer are what the batch last wrote back): a host that alternates between the batch and other
+ * entries re-creates the batch when this says 0.  rsmp_fir_batch_distinct_states: how many different states n handles are in (what a
+ * host-planned bulk launch has to plan: streams in one state and fed the same amount share a plan). */
+/* rsmp_fir_lockstep_free without the write-back: for a batch whose handles have been used through other entry points since its last
+ * sync (the handles hold the newer state). */
+void rsmp_fir_lockstep_discard(rsmp_fir_lockstep* ls);
+int rsmp_fir_lockstep_sync_totals(rsmp_fir_lockstep* ls, size_t* accepted, size_t* produced, uint32_t* status_or);
+int rsmp_fir_lockstep_in_sync(const rsmp_fir_lockstep* ls, int* in_sync);
+int rsmp_fir_batch_distinct_states(rsmp_fir* const* rs, size_t n, size_t* distinct);
 /* Measurement hooks, as rsmp_fir_set_profiling / rsmp_fir_mean_kernel_ms: HIP events on the launch stream
  * around every step while enabled; the mean covers the (up to 64) most recent steps. */
 int rsmp_fir_lockstep_set_profiling(rsmp_fir_lockstep* ls, int enable);

@@ -644,10 +644,14 @@ extern "C" rsmp_fir_lockstep* rsmp_fir_lockstep_new(rsmp_fir* const* rs, size_t 
     return ls.release();
 }
 
-extern "C" void rsmp_fir_lockstep_free(rsmp_fir_lockstep* ls) {
+static void lockstep_destroy(rsmp_fir_lockstep* ls, bool write_back);
+extern "C" void rsmp_fir_lockstep_free(rsmp_fir_lockstep* ls) { lockstep_destroy(ls, true); }
+extern "C" void rsmp_fir_lockstep_discard(rsmp_fir_lockstep* ls) { lockstep_destroy(ls, false); }
+static void lockstep_destroy(rsmp_fir_lockstep* ls, bool write_back) {
     if (!ls) return;
     DeviceGuard guard(ls->device);
-    (void)rsmp_fir_lockstep_sync(ls);
+    if (write_back) (void)rsmp_fir_lockstep_sync(ls);
+    else if (ls->last_stream) (void)hipStreamSynchronize(ls->last_stream);
     if (ls->drift_ev) (void)hipEventDestroy(ls->drift_ev);
     if (ls->stage_ev) (void)hipEventDestroy(ls->stage_ev);
     if (ls->probe_ev) {
@@ -814,6 +818,61 @@ extern "C" int rsmp_fir_lockstep_sync(rsmp_fir_lockstep* ls) {
                              hipMemcpyDeviceToHost));
     for (size_t k = 0; k < n; ++k) ls->rs[ls->order[k]]->mirror.set_state(ls->h_states[k]);
     refresh_history_index(ls);
+    return RSMP_OK;
+}
+
+extern "C" int rsmp_fir_lockstep_sync_totals(rsmp_fir_lockstep* ls, size_t* accepted, size_t* produced, uint32_t* status_or) {
+    if (!ls) return rsmp::fail(RSMP_ERR_INVALID_ARGUMENT, "rsmp_fir_lockstep_sync_totals: null batch");
+    const size_t n = ls->rs.size();
+    const std::vector<FirMirrorState> before = ls->h_states;   // (internal order: what was last exchanged with the handles)
+    if (before.size() != n) return rsmp::fail(RSMP_ERR_INVALID_ARGUMENT, "rsmp_fir_lockstep_sync_totals: the batch has no states yet");
+    if (int rc = rsmp_fir_lockstep_sync(ls)) return rc;
+    for (size_t k = 0; k < n; ++k) {
+        const uint32_t i = ls->order[k];
+        const size_t ch = ls->rs[i]->channels;
+        const FirMirrorState &a = before[k], &b = ls->h_states[k];
+        if (accepted) accepted[i] = static_cast<size_t>((b.abs_consumed + b.available) - (a.abs_consumed + a.available)) * ch;
+        if (produced) produced[i] = static_cast<size_t>(b.abs_out - a.abs_out) * ch;
+    }
+    if (status_or) {
+        std::vector<uint32_t> st(n);
+        RSMP_HIP_CHECK(hipMemcpy(st.data(), ls->d_status.get(), n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        uint32_t v = 0;
+        for (uint32_t f : st) v |= f;
+        *status_or = v;
+    }
+    return RSMP_OK;
+}
+
+extern "C" int rsmp_fir_lockstep_in_sync(const rsmp_fir_lockstep* ls, int* in_sync) {
+    if (!ls || !in_sync) return rsmp::fail(RSMP_ERR_INVALID_ARGUMENT, "rsmp_fir_lockstep_in_sync: null argument");
+    const size_t n = ls->rs.size();
+    *in_sync = 0;
+    if (ls->h_states.size() != n) return RSMP_OK;
+    for (size_t k = 0; k < n; ++k) {
+        const rsmp_fir* r = ls->rs[ls->order[k]];
+        const FirMirrorState now = r->mirror.state();
+        if (memcmp(&now, &ls->h_states[k], sizeof now) != 0) return RSMP_OK;
+        // (the frames the stream has buffered: in the buffer the batch's next step reads)
+        const float* live = ls->hist_parity ? ls->streams[k].hist_alt : ls->streams[k].hist;
+        if (ls->bound && live != r->d_hist[r->cur]) return RSMP_OK;
+    }
+    *in_sync = 1;
+    return RSMP_OK;
+}
+
+extern "C" int rsmp_fir_batch_distinct_states(rsmp_fir* const* rs, size_t n, size_t* distinct) {
+    if (!rs || !distinct) return rsmp::fail(RSMP_ERR_INVALID_ARGUMENT, "rsmp_fir_batch_distinct_states: null argument");
+    std::vector<FirMirrorState> seen;
+    for (size_t i = 0; i < n; ++i) {
+        if (!rs[i]) return rsmp::fail(RSMP_ERR_INVALID_ARGUMENT, "rsmp_fir_batch_distinct_states: null stream");
+        const FirMirrorState s = rs[i]->mirror.state();
+        bool found = false;
+        for (const FirMirrorState& t : seen)
+            if (memcmp(&s, &t, sizeof s) == 0) { found = true; break; }
+        if (!found) seen.push_back(s);
+    }
+    *distinct = seen.size();
     return RSMP_OK;
 }
 
@@ -1477,6 +1536,15 @@ extern "C" int rsmp_fir_lockstep_run_bulk(rsmp_fir_lockstep* ls, size_t total_fr
     if (chunk_frames > ls->step_frames)
         return rsmp::fail(RSMP_ERR_INVALID_INPUT_BUFFER_SIZE, "lock-step batch: calls of %zu frames, created for %u per step", chunk_frames,
                           ls->step_frames);
+    // The driver loop this stands for offers a call's remainder again when the call accepts less than its offer (resample/src/main.rs:
+    // 226-254); a run's calls read their input at fixed offsets.  So the calls must be ones every stream accepts whole: a stream buffers at
+    // most INPUT_CAPACITY = 4096 frames (resampler_fir.rs:18, :524-528) and keeps up to taps + 1 of them between calls.
+    size_t max_taps = 0;
+    for (const rsmp_fir* r : ls->rs) max_taps = std::max<size_t>(max_taps, r->taps);
+    if (chunk_frames + max_taps + 8 > rsmp::kMirrorInputCapacity)
+        return rsmp::fail(RSMP_ERR_INVALID_INPUT_BUFFER_SIZE,
+                          "rsmp_fir_lockstep_run_bulk: calls of %zu frames are not accepted whole by a stream of %zu taps (at most %zu)", chunk_frames,
+                          max_taps, static_cast<size_t>(rsmp::kMirrorInputCapacity) - max_taps - 8);
     const size_t k = total_frames / chunk_frames, tail = total_frames - k * chunk_frames;
     if (k > 0)
         if (int rc = rsmp_fir_lockstep_run(ls, k, chunk_frames, in_offset_frames, append, stream)) return rc;

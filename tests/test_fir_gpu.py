@@ -885,3 +885,74 @@ def test_a_batch_with_one_stream_longer_than_one_launch_and_mixed_rate_pairs():
             d = got[a:e].astype(np.float64) - want[a:e]
             assert np.sqrt(np.dot(d, d) / (e - a)) <= RMS_TOL, (k, a, e)
         assert h.state() == r.state(), k
+
+
+@pytest.mark.gpu
+def test_a_batch_in_many_states_goes_through_the_device_planner_and_back():
+    """FirBatch.resample_bulk_device routes a batch whose streams are in many different states through the device planner
+    (rsmp_fir_lockstep_run_bulk over the same handles, states written back before the call returns) and everything else
+    through the host planner -- whichever it takes, and however the two and a stream's own entries alternate on the same
+    handles: the reference driver loop's (consumed, produced), its samples, its end states."""
+    import torch
+    dev = torch.device("cuda:0")
+    n, chunk = 20, 256
+    pairs = [(44100, 48000), (48000, 44100), (96000, 44100), (44100, 96000)]
+    hs = [ra.ResamplerFir.new_from_hz(2, *pairs[i % 4], ra.Latency.Sample64, ra.Attenuation.Db90) for i in range(n)]
+    kind = o.CONVOLVE_AVX_FMA if o.have_avx_fma() else o.CONVOLVE_SCALAR
+    refs = [o.OracleFir(2, *pairs[i % 4], 128, 90, kind) for i in range(n)]
+    rng = np.random.default_rng(5)
+
+    def feed_own_entry(i, frames):   # a stream through its own resample(): the handle moves on under any batch
+        x = (rng.random(2 * frames, dtype=np.float32) * 2 - 1).astype(np.float32)
+        og, orr = np.zeros(hs[i].buffer_size_output(), np.float32), np.zeros(refs[i].buffer_size_output(), np.float32)
+        off = 0
+        while off < x.size:
+            cg, pg = hs[i].resample(x[off:off + 2 * 150], og)
+            rc, cr, pr = refs[i].resample(x[off:off + 2 * 150], orr)
+            assert rc == 0 and (cg, pg) == (cr, pr)
+            assert rms(og[:pg], orr[:pr]) <= RMS_TOL
+            off += cg
+
+    for i in range(n):
+        feed_own_entry(i, 200 + 31 * i)   # twenty states
+    batch = ra.FirBatch(hs)
+    frames = 30000
+    routed = []
+    for launch in range(6):
+        if launch == 3:
+            feed_own_entry(7, 333)        # behind the batch's back: its lock-step batch is out of sync and is made anew
+        if launch == 4:
+            batch.device_planner = False  # ... and the host planner on the handles the device planner left
+        if launch == 5:
+            batch.device_planner = None
+        xs = [(rng.random(2 * frames, dtype=np.float32) * 2 - 1).astype(np.float32) for _ in range(n)]
+        d_in = [torch.from_numpy(x).to(dev) for x in xs]
+        d_out = [torch.zeros(h.bulk_output_bound(2 * frames, chunk), device=dev) for h in hs]
+        batch.bind(d_in, d_out)
+        before = getattr(batch, "_ls", None)
+        cons, prod = batch.resample_bulk_device(chunk)
+        torch.cuda.synchronize()
+        routed.append(getattr(batch, "_ls", None) is not None and (launch != 4))
+        for i, r in enumerate(refs):
+            y, calls = r.resample_all(xs[i], chunk)
+            assert int(cons[i]) == xs[i].size and int(prod[i]) == y.size, (launch, i, int(cons[i]), int(prod[i]), y.size)
+            assert rms(d_out[i][:y.size].cpu().numpy(), y) <= RMS_TOL, (launch, i)
+            assert hs[i].state() == r.state(), (launch, i)
+        if launch == 3:
+            assert batch._ls is not before   # (made anew: the old one's states were stale)
+    assert routed[0] and routed[1] and routed[2] and routed[5], routed
+    # all streams in ONE state: the host planner's shared plan, no device planning
+    for h, r in zip(hs, refs):
+        h.reset()
+        r.reset()
+    same = ra.FirBatch(hs[0::4])
+    xs = [(rng.random(2 * frames, dtype=np.float32) * 2 - 1).astype(np.float32)] * len(hs[0::4])
+    d_in = [torch.from_numpy(x).to(dev) for x in xs]
+    d_out = [torch.zeros(h.bulk_output_bound(2 * frames, chunk), device=dev) for h in hs[0::4]]
+    same.bind(d_in, d_out)
+    cons, prod = same.resample_bulk_device(chunk)
+    torch.cuda.synchronize()
+    assert getattr(same, "_ls", None) is None
+    y, _ = refs[0].resample_all(xs[0], chunk)
+    assert int(prod[0]) == y.size and rms(d_out[0][:y.size].cpu().numpy(), y) <= RMS_TOL
+

@@ -588,6 +588,25 @@ def test_long_runs_of_few_streams(calls, chunk, fresh):
     ls.close()
 
 
+def test_bulk_calls_a_stream_cannot_accept_whole_are_refused():
+    """The driver loop offers a call's remainder again when the call accepts less than its offer (resample/src/main.rs:
+    226-254); a run's calls read at fixed offsets -- so rsmp_fir_lockstep_run_bulk takes only calls every stream accepts whole
+    (a stream buffers at most 4096 frames, resampler_fir.rs:18, and keeps up to taps + 1 between calls): anything longer
+    is refused, not resampled with frames dropped (found by tools/fuzz_bulk.py through FirBatch's routing, round 6)."""
+    import torch
+    dev = torch.device("cuda:0")
+    hs = [ra.ResamplerFir.new_from_hz(1, 48000, 48000, ra.Latency.Sample8, ra.Attenuation.Db120) for _ in range(2)]
+    x = torch.zeros(60000, device=dev)
+    caps = [h.buffer_size_output() for h in hs]
+    ls = ra.FirLockstep(hs, 4096)
+    ls.bind_caps([x, x.clone()], [torch.zeros(70000, device=dev) for _ in hs], caps)
+    with pytest.raises(ra.ResampleError):
+        ls.run_bulk(60000, 4090)
+    ls.run_bulk(60000, 2048)   # (what fits goes through)
+    ls.sync()
+    ls.close()
+
+
 @pytest.mark.parametrize("total,chunk", [(20000, 256), (16384, 512), (9999, 300)])
 def test_bulk_batch_in_distinct_states_planned_on_the_device(total, chunk):
     """64 streams of six rate pairs in 64 different states (each has already run a different,
