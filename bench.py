@@ -966,7 +966,7 @@ def secondary_lines(ctx: Ctx, args):
         ctx.torch.cuda.synchronize()
         cold = (time.perf_counter() - t1) * 1e3
         again = []
-        for _ in range(8):
+        for _ in range(12):   # (the first four find the plan stream and have no run to repeat yet: `step_ms_replanned_each`)
             t2 = time.perf_counter()
             batch.resample_bulk_device(args.chunk, ctx.stream)
             ctx.torch.cuda.synchronize()
@@ -1015,6 +1015,7 @@ def secondary_lines(ctx: Ctx, args):
                     f"routes a batch in >= {ra.FirBatch.kDevicePlanStates} different states through rsmp_fir_lockstep_run_bulk over the same handles "
                     f"(planned on the device; `host_planned_c_entry`: the C entry's own host planner on the same batch)",
             "step_ms_cold": round(cold, 2), "step_ms_replanned_median": round(sorted(again)[len(again) // 2], 2),
+            "step_ms_replanned_each": [round(t, 2) for t in again],
             "kernel_ms_replanned": round(k_again, 3), "setup_s": round(setup_s, 2)}
     guard("fir_distinct_states", distinct_point)
     keys = ("metric", "value", "unit", "ms_per_step", "scaling", "dtype", "config", "roofline")
