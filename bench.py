@@ -955,11 +955,11 @@ def secondary_lines(ctx: Ctx, args):
         handles[0].set_profiling(False)
         host_planned = {"step_ms_cold": round(cold, 2), "step_ms_replanned_median": round(sorted(again)[len(again) // 2], 2),
                         "kernel_ms_replanned": round(k_again, 3),
-                        "what": "rsmp_fir_batch_resample_bulk_device itself (FirBatch.device_planner = False): every distinct state planned "
+                        "what": "rsmp_fir_batch_resample_bulk_device_ex with planner = 0 (FirBatch.device_planner = False): every distinct state planned "
                                 "on the host's worker pool, counts returned when the launch is enqueued"}
-        # (2) the host entry as a caller of resampler_amd.FirBatch gets it: a batch in this many different states goes through the
-        # device planner behind the same method (a lock-step batch over the same handles, kept from launch to launch, the states
-        # written back into the handles before the call returns -- so the call returns when the launch is through)
+        # (2) the entry as a caller gets it, rsmp_fir_batch_resample_bulk_device: a batch in this many different states goes through the
+        # device planner behind the same entry (a lock-step batch over the same handles, kept by the library from launch to launch,
+        # the states written back into the handles before the call returns -- so the call returns when the launch is through)
         batch.device_planner = None
         t1 = time.perf_counter()
         batch.resample_bulk_device(args.chunk, ctx.stream)
@@ -971,7 +971,7 @@ def secondary_lines(ctx: Ctx, args):
             batch.resample_bulk_device(args.chunk, ctx.stream)
             ctx.torch.cuda.synchronize()
             again.append((time.perf_counter() - t2) * 1e3)
-        routed = getattr(batch, "_ls", None) is not None
+        routed = bool(batch.planned_on_device)
         k_again = host_planned["kernel_ms_replanned"]
         # ... and the same batch through the DEVICE planner (rsmp_fir_lockstep_run_bulk: the calls' structure, the f64 chain and
         # the wrapped outputs planned by three small kernels, nothing replayed on the host, no host threads): the first
@@ -1010,10 +1010,10 @@ def secondary_lines(ctx: Ctx, args):
             "device_planned": dp,
             "host_planned_c_entry": host_planned,
             "routed_through_device_planner": routed,
-            "what": f"{args.streams} streams in {args.streams} different states through FirBatch.resample_bulk_device: the first launch, then "
-                    f"launches that continue the streams (planned anew every time), wall clock of a launch incl. synchronisation.  FirBatch "
+            "what": f"{args.streams} streams in {args.streams} different states through rsmp_fir_batch_resample_bulk_device: the first launch, then "
+                    f"launches that continue the streams (planned anew every time), wall clock of a launch incl. synchronisation.  The entry "
                     f"routes a batch in >= {ra.FirBatch.kDevicePlanStates} different states through rsmp_fir_lockstep_run_bulk over the same handles "
-                    f"(planned on the device; `host_planned_c_entry`: the C entry's own host planner on the same batch)",
+                    f"(planned on the device; `host_planned_c_entry`: the same entry with its host planner named, planner = 0)",
             "step_ms_cold": round(cold, 2), "step_ms_replanned_median": round(sorted(again)[len(again) // 2], 2),
             "step_ms_replanned_each": [round(t, 2) for t in again],
             "kernel_ms_replanned": round(k_again, 3), "setup_s": round(setup_s, 2)}

@@ -151,6 +151,19 @@ int rsmp_fir_batch_resample_bulk_device(rsmp_fir* const* rs, size_t n, const flo
                                         const size_t* in_lens, size_t chunk_len,
                                         float* const* d_out, const size_t* out_caps,
                                         size_t* consumed, size_t* produced, void* stream);
+/* The same with the PLANNER named.  A launch plans every distinct state among its streams on the host (streams in one state that are
+ * fed the same amount share a plan): ~30 us of a core per state and thousand calls -- 2-3 ms for 64 streams x 4096 calls in 64 states
+ * around a 0.3 ms kernel.  planner = 1 plans on the DEVICE instead (rsmp_fir_lockstep_run_bulk on a lock-step batch over the same
+ * handles, which the library keeps from launch to launch for as long as the handles are touched through nothing else; the states are
+ * written back into the handles before the call returns, so the call returns when the launch is THROUGH, not when it is enqueued);
+ * planner = 0 never; planner = -1 -- what rsmp_fir_batch_resample_bulk_device does -- where the batch has at least 16 different
+ * states.  The device planner takes batches of one channel count and one buffer length, calls of at most 2048 frames, at least eight
+ * of them, and output buffers of rsmp_fir_bulk_output_bound; anything else is planned on the host whatever `planner` says.
+ * *planned_on_device (may be null): which it was.  Same (consumed, produced), samples and end states either way. */
+int rsmp_fir_batch_resample_bulk_device_ex(rsmp_fir* const* rs, size_t n, const float* const* d_in,
+                                           const size_t* in_lens, size_t chunk_len,
+                                           float* const* d_out, const size_t* out_caps,
+                                           size_t* consumed, size_t* produced, void* stream, int planner, int* planned_on_device);
 /* The same over a two-channel WAV file's samples as they are in the file (resample/src/main.rs:128-137): d_pcm[i] =
  * little-endian PCM of `bits` (16 / 24 / 32) per sample, in_lens[i] SAMPLES (2 per frame), 4-byte aligned.  The samples are
  * converted where the kernels read their input (`sample as f32 / (1 << (bits - 1)) as f32`, with the reference's 32-bit

@@ -128,6 +128,9 @@ _SIGNATURES = [
     ("rsmp_fir_batch_resample_bulk_device", C.c_int,
      [C.POINTER(C.c_void_p), C.c_size_t, C.POINTER(C.c_void_p), _szp, C.c_size_t,
       C.POINTER(C.c_void_p), _szp, _szp, _szp, C.c_void_p]),
+    ("rsmp_fir_batch_resample_bulk_device_ex", C.c_int,
+     [C.POINTER(C.c_void_p), C.c_size_t, C.POINTER(C.c_void_p), _szp, C.c_size_t,
+      C.POINTER(C.c_void_p), _szp, _szp, _szp, C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
     ("rsmp_fir_batch_reset", None, [C.POINTER(C.c_void_p), C.c_size_t]),
     ("rsmp_fir_lockstep_new", C.c_void_p, [C.POINTER(C.c_void_p), C.c_size_t, C.c_size_t]),
     ("rsmp_fir_lockstep_free", None, [C.c_void_p]),
@@ -452,7 +455,6 @@ class FirBatch:
     def bind(self, d_ins, d_outs) -> None:
         """Binds one input and one output tensor per stream (kept until the next bind)."""
         self._keep = (list(d_ins), list(d_outs))
-        self._ls_fit = None
         for i, (a, b) in enumerate(zip(d_ins, d_outs)):
             self._in[i] = _dev_ptr(a)
             self._out[i] = _dev_ptr(b)
@@ -462,73 +464,24 @@ class FirBatch:
     def reset(self) -> None:
         lib().rsmp_fir_batch_reset(self._handles, len(self.resamplers))
 
-    # A bulk launch plans every DISTINCT state among its streams on the host (streams in one state share a plan): ~30 us of a
-    # core per state and thousand calls, 2-3 ms for 64 streams in 64 states around a 0.3 ms kernel.  Such a batch goes through
-    # the device planner instead (rsmp_fir_lockstep_run_bulk: nothing replayed on the host), behind this same method: a
-    # lock-step batch over the same handles, kept while the handles are touched through nothing else
-    # (rsmp_fir_lockstep_in_sync), its states written back into the handles before the call returns -- which therefore
-    # returns when the launch is THROUGH, not when it is enqueued.  `device_planner`: None = decide by the batch (at least
-    # kDevicePlanStates different states, equal buffers, calls that fit), False = never, True = whenever it can.
+    # A bulk launch plans every DISTINCT state among its streams on the host (streams in one state share a plan): 2-3 ms for 64
+    # streams in 64 states around a 0.3 ms kernel.  Such a batch goes through the device planner instead, behind the same entry
+    # (rsmp_fir_batch_resample_bulk_device_ex: a lock-step batch over the same handles, kept by the library from launch to launch,
+    # the states written back into the handles before the call returns -- which therefore returns when the launch is THROUGH).
+    # `device_planner`: None = the library decides (at least 16 different states, ...), False = never, True = whenever it can;
+    # `planned_on_device`: which planner the last launch had.
     kDevicePlanStates = 16
     device_planner: Optional[bool] = None
-
-    def _plan_on_device(self, chunk_len: int, stream) -> bool:
-        n = len(self.resamplers)
-        if self.device_planner is False or getattr(self, "_ls_unfit", False) or n < 2:
-            return False
-        ch = self.resamplers[0].channels
-        if any(r.channels != ch for r in self.resamplers) or chunk_len % ch:
-            return False
-        length = self._in_lens[0]
-        frames = chunk_len // ch
-        fit = getattr(self, "_ls_fit", None)   # (what does not change between two binds: checked once per bind and call size)
-        if fit is None or fit[0] != chunk_len:
-            # (calls every stream accepts whole -- a stream buffers at most 4096 frames, resampler_fir.rs:18 --, and at least eight of them)
-            ok = frames <= 2048 and not (length % ch or length // ch < 8 * frames or any(self._in_lens[i] != length for i in range(n)))
-            # (the host entry checks the room exactly, and says so)
-            ok = ok and all(self._out_caps[i] >= r.bulk_output_bound(length, chunk_len) for i, r in enumerate(self.resamplers))
-            key = tuple(self._in[i] for i in range(n)) + tuple(self._out[i] for i in range(n))
-            fit = self._ls_fit = (chunk_len, ok, key)
-        if not fit[1]:
-            return False
-        if self.device_planner is None:
-            d = C.c_size_t()
-            _check(lib().rsmp_fir_batch_distinct_states(self._handles, n, C.byref(d)))
-            if d.value < min(self.kDevicePlanStates, n):
-                return False
-        ls = getattr(self, "_ls", None)
-        if ls is not None:
-            ok = C.c_int()
-            _check(lib().rsmp_fir_lockstep_in_sync(ls._h, C.byref(ok)))
-            if not ok.value or self._ls_frames < frames:
-                ls.close()
-                ls = self._ls = None
-        if ls is None:
-            try:
-                ls = FirLockstep(self.resamplers, frames)
-            except ResampleError:
-                self._ls_unfit = True   # (streams the lock-step batch does not take)
-                return False
-            ls.discard_on_close = True   # (its states are in the handles after every launch; the handles may have moved on since)
-            self._ls, self._ls_frames, self._ls_bound = ls, frames, None
-        key = fit[2]
-        if self._ls_bound != key:
-            ls.bind_caps(self._keep[0], self._keep[1], [r.buffer_size_output() for r in self.resamplers])
-            self._ls_bound = key
-        ls.run_bulk(length // ch, frames, 0, append=False, stream=stream)
-        flags = C.c_uint32()
-        _check(lib().rsmp_fir_lockstep_sync_totals(ls._h, self._consumed, self._produced, C.byref(flags)))
-        if flags.value & (1 | 8 | 16):
-            raise ResampleError(3, "lock-step batch: status flags %d after a bulk launch" % flags.value)
-        return True
+    planned_on_device = False
 
     def resample_bulk_device(self, chunk_len: int = 512, stream: Optional[int] = None):
         n = len(self.resamplers)
-        if self._plan_on_device(chunk_len, stream):
-            return (np.ctypeslib.as_array(self._consumed), np.ctypeslib.as_array(self._produced))
-        _check(lib().rsmp_fir_batch_resample_bulk_device(
+        took = C.c_int()
+        mode = -1 if self.device_planner is None else (1 if self.device_planner else 0)
+        _check(lib().rsmp_fir_batch_resample_bulk_device_ex(
             self._handles, n, self._in, self._in_lens, chunk_len, self._out, self._out_caps,
-            self._consumed, self._produced, C.c_void_p(stream or 0)))
+            self._consumed, self._produced, C.c_void_p(stream or 0), mode, C.byref(took)))
+        self.planned_on_device = bool(took.value)
         # zero-copy views (valid until the next call): converting 2 x n ctypes words to Python
         # ints costs more than the launch for batches of a thousand streams
         return (np.ctypeslib.as_array(self._consumed), np.ctypeslib.as_array(self._produced))

@@ -23,6 +23,7 @@
 #include <atomic>
 #include <condition_variable>
 #include <functional>
+#include <algorithm>
 #include <vector>
 
 #include "common.h"
@@ -73,9 +74,42 @@ int upload_table(int device, const std::shared_ptr<const std::vector<float>>& ho
 
 namespace {
 
+// ---- batches in many different states: planned on the device (see rsmp_fir_batch_resample_bulk_device_ex) ---------------------------
+// The lock-step batch a routed launch runs on is kept per list of handles, from launch to launch: its plan stream, its class tables and
+// the run it plans ahead are what make the second and later launches cheap.  Its states are written back into the handles before a
+// routed call returns, so the handles are always current and the batch can be thrown away at any time WITHOUT a write-back
+// (rsmp_fir_lockstep_discard) -- which is what happens when a handle has been touched through another entry since, when the cache is
+// full, and when one of its handles is destroyed.
+struct RoutedBatch {
+    rsmp_fir_lockstep* ls = nullptr;
+    size_t frames = 0;                     // max_step_frames it was made for
+    std::vector<const void*> bound;        // d_in / d_out it is bound to
+    uint64_t used = 0;
+};
+std::mutex& routed_mu() { static std::mutex* m = new std::mutex; return *m; }
+std::map<std::vector<rsmp_fir*>, RoutedBatch>& routed_cache() { static auto* c = new std::map<std::vector<rsmp_fir*>, RoutedBatch>; return *c; }
+uint64_t routed_clock = 0;
+constexpr size_t kRoutedCacheSize = 8;
+constexpr size_t kRoutedMinStates = 16;    // fewer different states than this (and than streams): the host's shared plans are cheaper
+constexpr size_t kRoutedMaxCallFrames = 2048, kRoutedMinCalls = 8;
+
+void routed_forget(const rsmp_fir* r) {
+    std::lock_guard<std::mutex> lock(routed_mu());
+    auto& cache = routed_cache();
+    for (auto it = cache.begin(); it != cache.end();) {
+        if (std::find(it->first.begin(), it->first.end(), r) != it->first.end()) {
+            rsmp_fir_lockstep_discard(it->second.ls);
+            it = cache.erase(it);
+        } else {
+            ++it;
+        }
+    }
+}
+
 // Releases everything a (possibly half-built) handle owns.
 void fir_destroy(rsmp_fir* r) {
     if (!r) return;
+    routed_forget(r);
     DeviceGuard guard(r->device);
     if (r->stream) (void)hipStreamSynchronize(r->stream);
     (void)hipDeviceSynchronize();
@@ -1069,14 +1103,150 @@ static int batch_bulk_piece(rsmp_fir* const* rs, size_t n, const float* const* d
                             size_t chunk_len, float* const* d_out, const size_t* out_caps, size_t* consumed,
                             size_t* produced, void* stream, uint32_t pcm_bits = 0);
 
+// The launch through the device planner, if the batch is one for it.  *took = 1: done (rc is the call's result).
+static int batch_bulk_routed(rsmp_fir* const* rs, size_t n, const float* const* d_in, const size_t* in_lens, size_t chunk_len,
+                             float* const* d_out, const size_t* out_caps, size_t* consumed, size_t* produced, void* stream, int planner,
+                             int* took) {
+    *took = 0;
+    if (planner == 0 || n < 2) return RSMP_OK;
+    const size_t ch = rs[0]->channels, length = in_lens[0];
+    if (ch == 0 || chunk_len % ch != 0 || length % ch != 0) return RSMP_OK;
+    const size_t frames = chunk_len / ch;
+    // calls every stream accepts whole (rsmp_fir_lockstep_run_bulk), at least a handful of them, the same buffer length for all
+    if (frames > kRoutedMaxCallFrames || length / ch < kRoutedMinCalls * frames) return RSMP_OK;
+    for (size_t i = 0; i < n; ++i) {
+        if (!rs[i] || rs[i]->channels != ch || rs[i]->device != rs[0]->device || in_lens[i] != length) return RSMP_OK;
+        // room for what the launch will produce: the outputs below the limit once `length` more values are accepted, in exact arithmetic
+        // (fir_mirror_fast.h: mirror_predict's m1), + 2 for an output that f64 puts a hair below it.  (rsmp_fir_bulk_output_bound is
+        // no test here: it grows with the frames a stream has buffered, and a buffer sized by it before the stream's first launch
+        // would fail it ever after.)  Anything else: the host path, which checks the room exactly and says so.
+        {
+            const rsmp::FirMirrorState st = rs[i]->mirror.state();
+            const uint64_t a_now = st.abs_consumed + st.available + length / ch;
+            if (st.num == 0 || st.den == 0 || st.den >= (1ull << 21) || st.num >= (1ull << 21) || a_now >= (1ull << 40)) return RSMP_OK;
+            // ceil(x den / num): the outputs m >= 0 with m num / den < x
+            const uint64_t m1 = a_now + 1 > st.taps ? ((a_now + 1 - st.taps) * st.den + st.num - 1) / st.num : 0;
+            const uint64_t made = (m1 > st.abs_out ? m1 - st.abs_out : 0) + 2;
+            if (out_caps[i] / ch < made) return RSMP_OK;
+        }
+        for (size_t k = 0; k < i; ++k)
+            if (rs[k] == rs[i]) return RSMP_OK;
+    }
+    if (planner < 0) {
+        size_t distinct = 0;
+        if (rsmp_fir_batch_distinct_states(rs, n, &distinct) != RSMP_OK || distinct < std::min(kRoutedMinStates, n)) return RSMP_OK;
+    }
+    std::lock_guard<std::mutex> lock(routed_mu());
+    auto& cache = routed_cache();
+    const std::vector<rsmp_fir*> key(rs, rs + n);
+    auto it = cache.find(key);
+    if (it != cache.end() && it->second.ls == nullptr) {   // (a batch the lock-step entry has refused before: the host planner's)
+        it->second.used = ++routed_clock;
+        return RSMP_OK;
+    }
+    if (it != cache.end()) {
+        int in_sync = 0;
+        static const bool trace = rsmp::knob("RSMP_ROUTE_TRACE") != nullptr;
+        const int rc_sync = rsmp_fir_lockstep_in_sync(it->second.ls, &in_sync);
+        if (trace) fprintf(stderr, "[rsmp] routed batch: in_sync rc %d -> %d, frames %zu / %zu\n", rc_sync, in_sync, it->second.frames, frames);
+        if (rc_sync != RSMP_OK || !in_sync || it->second.frames < frames) {
+            rsmp_fir_lockstep_discard(it->second.ls);   // (the handles have moved on: they hold the newer state)
+            cache.erase(it);
+            it = cache.end();
+        }
+    }
+    if (it == cache.end()) {
+        // (a handle of this batch in ANOTHER cached batch: that one's device states go stale with this launch, which its own next use
+        // finds out -- rsmp_fir_lockstep_in_sync --, nothing to do here)
+        if (cache.size() >= kRoutedCacheSize) {
+            auto oldest = cache.begin();
+            for (auto jt = cache.begin(); jt != cache.end(); ++jt)
+                if (jt->second.used < oldest->second.used) oldest = jt;
+            rsmp_fir_lockstep_discard(oldest->second.ls);
+            cache.erase(oldest);
+        }
+        rsmp_fir_lockstep* ls = rsmp_fir_lockstep_new(rs, n, frames);
+        if (!ls) {   // (streams a lock-step batch does not take: the host planner's, without an error of this call's -- and remembered)
+            rsmp::last_error_slot().clear();
+            RoutedBatch none;
+            none.used = ++routed_clock;
+            cache.emplace(key, std::move(none));
+            return RSMP_OK;
+        }
+        RoutedBatch rb;
+        rb.ls = ls;
+        rb.frames = frames;
+        it = cache.emplace(key, std::move(rb)).first;
+    }
+    RoutedBatch& rb = it->second;
+    rb.used = ++routed_clock;
+    auto fail_and_drop = [&](int rc) {   // (whatever state the batch is in now: not one to keep)
+        const std::string msg = rsmp::last_error_slot();
+        rsmp_fir_lockstep_discard(rb.ls);
+        cache.erase(it);
+        rsmp::last_error_slot() = msg;
+        *took = 1;
+        return rc;
+    };
+    std::vector<const void*> bound;
+    bound.reserve(2 * n);
+    for (size_t i = 0; i < n; ++i) bound.push_back(d_in[i]);
+    for (size_t i = 0; i < n; ++i) bound.push_back(d_out[i]);
+    {
+        static const bool trace = rsmp::knob("RSMP_ROUTE_TRACE") != nullptr;
+        if (trace) fprintf(stderr, "[rsmp] routed batch: %s\n", bound != rb.bound ? "bind" : "bound already");
+    }
+    if (bound != rb.bound) {
+        std::vector<size_t> caps(n);
+        for (size_t i = 0; i < n; ++i) caps[i] = rsmp_fir_buffer_size_output(rs[i]);   // per CALL, as the reference sizes a call's buffer
+        if (int rc = rsmp_fir_lockstep_bind(rb.ls, d_in, d_out, caps.data())) return fail_and_drop(rc);
+        rb.bound = bound;
+    }
+    if (int rc = rsmp_fir_lockstep_run_bulk(rb.ls, length / ch, frames, 0, 0, stream)) return fail_and_drop(rc);
+    uint32_t flags = 0;
+    std::vector<size_t> acc(n), made(n);
+    if (int rc = rsmp_fir_lockstep_sync_totals(rb.ls, acc.data(), made.data(), &flags)) return fail_and_drop(rc);
+    if (flags & (1u | 8u | 16u)) {
+        rsmp::fail(RSMP_ERR_INVALID_ARGUMENT, "bulk batch planned on the device: status flags %u", flags);
+        return fail_and_drop(RSMP_ERR_INVALID_ARGUMENT);
+    }
+    for (size_t i = 0; i < n; ++i) {
+        if (consumed) consumed[i] = acc[i];
+        if (produced) produced[i] = made[i];
+    }
+    *took = 1;
+    return RSMP_OK;
+}
+
 extern "C" int rsmp_fir_batch_resample_bulk_device(rsmp_fir* const* rs, size_t n,
                                                    const float* const* d_in, const size_t* in_lens,
                                                    size_t chunk_len, float* const* d_out,
                                                    const size_t* out_caps, size_t* consumed,
                                                    size_t* produced, void* stream) {
+    return rsmp_fir_batch_resample_bulk_device_ex(rs, n, d_in, in_lens, chunk_len, d_out, out_caps, consumed, produced, stream, -1, nullptr);
+}
+
+extern "C" int rsmp_fir_batch_resample_bulk_device_ex(rsmp_fir* const* rs, size_t n,
+                                                      const float* const* d_in, const size_t* in_lens,
+                                                      size_t chunk_len, float* const* d_out,
+                                                      const size_t* out_caps, size_t* consumed,
+                                                      size_t* produced, void* stream, int planner, int* planned_on_device) {
+    if (planned_on_device) *planned_on_device = 0;
     if (n == 0) return RSMP_OK;
     if (!rs || !d_in || !in_lens || !d_out || !out_caps || chunk_len == 0)
         return rsmp::fail(RSMP_ERR_INVALID_ARGUMENT, "rsmp_fir_batch_resample_bulk_device: null/zero argument");
+    {
+        bool any_null = false;
+        for (size_t i = 0; i < n; ++i) any_null = any_null || !rs[i];
+        int took = 0;
+        if (!any_null) {
+            const int rc = batch_bulk_routed(rs, n, d_in, in_lens, chunk_len, d_out, out_caps, consumed, produced, stream, planner, &took);
+            if (took) {
+                if (planned_on_device) *planned_on_device = 1;
+                return rc;
+            }
+        }
+    }
     // A launch's coefficient rows are mixed for one drift (run_single): a stream offered more than kMaxLaunchOutputs outputs'
     // worth of input takes part in several launches, cut at call boundaries; the others are through after the first.
     std::vector<size_t> piece(n, 0);
