@@ -260,6 +260,9 @@ __device__ inline uint32_t chain_eval_lane(uint32_t shape, double& pos, uint32_t
 // instead of a wave on each of 128 -- where no workgroup of the split kernel, which needs a CU's whole register file, could
 // start until that wave was through: whether the bulk launch or the planner reached the chip first made a run of the
 // 128-stream shard take 0.72 or 0.91 us per step, profiles/r06/ab_c4_shard.txt.)
+// (PCHAIN: the build with the parallel chain and without round 5's run of equal-shape calls -- chain_fast_run, twelve instantiations --
+// and the other way round for RSMP_LS_PCHAIN=0: a wave of this kernel is bound by instruction fetch, and neither build needs both)
+template <bool PCHAIN>
 __global__ __launch_bounds__(64 * kLsPlanPack) void fir_lockstep_chain_kernel(LsRunArgs a) {
     const uint32_t gs = blockIdx.x * (blockDim.x >> 6) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
     if (gs >= a.n_streams) return;
@@ -470,7 +473,7 @@ __global__ __launch_bounds__(64 * kLsPlanPack) void fir_lockstep_chain_kernel(Ls
         };
 #pragma unroll 1
         for (uint32_t s = 0; s < nc; ++s) {
-            if (a.parallel_chain) {
+            if constexpr (PCHAIN) {
                 if (!on_track && st_valid) {   // (behind a call off the track: is the state where this call's prediction starts?  As below.)
                     const uint64_t m0 = static_cast<uint64_t>(rl(static_cast<uint32_t>(mine[0]), s)) | (static_cast<uint64_t>(rl(static_cast<uint32_t>(mine[0] >> 32), s)) << 32);
                     const uint64_t cc0 = static_cast<uint64_t>(rl(static_cast<uint32_t>(mine[1]), s)) | (static_cast<uint64_t>(rl(static_cast<uint32_t>(mine[1] >> 32), s)) << 32);
@@ -492,6 +495,7 @@ __global__ __launch_bounds__(64 * kLsPlanPack) void fir_lockstep_chain_kernel(Ls
                     }
                 }
             }
+            if constexpr (!PCHAIN) {
             if (on_track && ((fast_mask >> s) & 1ull)) {
                 if (st_valid) {   // (the counters leave `st`)
                     pos = st.position;
@@ -503,6 +507,7 @@ __global__ __launch_bounds__(64 * kLsPlanPack) void fir_lockstep_chain_kernel(Ls
                                       a.in_frames, ratio, bn);
                 last_lean = true;
                 if (s >= nc) break;
+            }
             }
             const double pos0 = st_valid ? st.position : pos;
             my_pos = lane == s ? pos0 : my_pos;   // lane s keeps call s's start position
@@ -856,7 +861,8 @@ hipError_t launch_fir_lockstep_plan(const LsRunArgs& args_in, hipStream_t stream
     }
     if (parts & 2) {
         const uint32_t pack = lockstep_plan_pack(args.n_streams);
-        hipLaunchKernelGGL(fir_lockstep_chain_kernel, dim3((args.n_streams + pack - 1) / pack), dim3(64 * pack), 0, stream, args);
+        if (pchain) hipLaunchKernelGGL(fir_lockstep_chain_kernel<true>, dim3((args.n_streams + pack - 1) / pack), dim3(64 * pack), 0, stream, args);
+        else hipLaunchKernelGGL(fir_lockstep_chain_kernel<false>, dim3((args.n_streams + pack - 1) / pack), dim3(64 * pack), 0, stream, args);
         // (the replay: a wave per chunk of 64 calls for small batches, one wave per stream otherwise)
         const uint32_t chunks = (args.k + 63) / 64;
         const uint32_t wwaves = pack > 1 ? std::min<uint32_t>(kLsWrapWaves, chunks) : 1u;
