@@ -113,6 +113,8 @@ extern "C" {
     #[allow(dead_code)]
     fn rsmp_fir_lockstep_discard(ls: *mut rsmp_fir_lockstep);
     #[allow(dead_code)]
+    fn rsmp_fir_lockstep_rebind_buffers(ls: *mut rsmp_fir_lockstep, d_in: *const *const f32, d_out: *const *mut f32, stream: *mut c_void) -> c_int;
+    #[allow(dead_code)]
     fn rsmp_fir_batch_distinct_states(rs: *const *mut rsmp_fir, n: usize, distinct: *mut usize) -> c_int;
     fn rsmp_fir_lockstep_table_rebinds(ls: *const rsmp_fir_lockstep, rebinds: *mut usize) -> c_int;
     fn rsmp_fir_lockstep_run_bulk(ls: *mut rsmp_fir_lockstep, total_frames: usize, chunk_frames: usize, in_offset_frames: usize,

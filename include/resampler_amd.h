@@ -271,6 +271,11 @@ int rsmp_fir_lockstep_sync(rsmp_fir_lockstep* ls);
  * point since (its state and history buffer are what the batch last wrote back): a host that alternates between the batch and other
  * entries re-creates the batch when this says 0.  rsmp_fir_batch_distinct_states: how many different states n handles are in (what a
  * host-planned bulk launch has to plan: streams in one state and fed the same amount share a plan). */
+/* New buffers under a bound batch -- the same capacities, states and histories; what rsmp_fir_lockstep_bind does when only d_in / d_out
+ * change, without its waits: the table goes to the device in `stream` order, and a run planned ahead (rsmp_fir_lockstep_run: the next
+ * run of a caller that feeds run after run) survives if it starts at the front of the output -- the two pointers of its descriptors are
+ * patched when it is taken over.  A service that hands every launch fresh buffers keeps the planner off its critical path that way. */
+int rsmp_fir_lockstep_rebind_buffers(rsmp_fir_lockstep* ls, const float* const* d_in, float* const* d_out, void* stream);
 /* rsmp_fir_lockstep_free without the write-back: for a batch whose handles have been used through other entry points since its last
  * sync (the handles hold the newer state). */
 void rsmp_fir_lockstep_discard(rsmp_fir_lockstep* ls);

@@ -148,6 +148,7 @@ _SIGNATURES = [
     ("rsmp_fir_lockstep_split_workgroups", C.c_size_t, [C.c_void_p]),
     ("rsmp_fir_lockstep_sync", C.c_int, [C.c_void_p]),
     ("rsmp_fir_lockstep_discard", None, [C.c_void_p]),
+    ("rsmp_fir_lockstep_rebind_buffers", C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_void_p]),
     ("rsmp_fir_lockstep_sync_totals", C.c_int, [C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_uint32)]),
     ("rsmp_fir_lockstep_in_sync", C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     ("rsmp_fir_batch_distinct_states", C.c_int, [C.POINTER(C.c_void_p), C.c_size_t, C.POINTER(C.c_size_t)]),
@@ -558,6 +559,15 @@ class FirLockstep:
             self._out[i] = _dev_ptr(b)
             self._out_caps[i] = k
         _check(lib().rsmp_fir_lockstep_bind(self._h, self._in, self._out, self._out_caps))
+
+    def rebind(self, d_ins, d_outs, stream: Optional[int] = None) -> None:
+        """New buffers, same capacities (rsmp_fir_lockstep_rebind_buffers): a run planned ahead that starts at the front of the
+        output survives."""
+        self._keep = (list(d_ins), list(d_outs))
+        for i, (a, b) in enumerate(zip(d_ins, d_outs)):
+            self._in[i] = _dev_ptr(a)
+            self._out[i] = _dev_ptr(b)
+        _check(lib().rsmp_fir_lockstep_rebind_buffers(self._h, self._in, self._out, C.c_void_p(stream or 0)))
 
     def step(self, in_frames: int, in_offset_frames: int = 0, append: bool = False,
              stream: Optional[int] = None, d_in_frames=None) -> None:

@@ -1197,9 +1197,13 @@ static int batch_bulk_routed(rsmp_fir* const* rs, size_t n, const float* const* 
         if (trace) fprintf(stderr, "[rsmp] routed batch: %s\n", bound != rb.bound ? "bind" : "bound already");
     }
     if (bound != rb.bound) {
-        std::vector<size_t> caps(n);
-        for (size_t i = 0; i < n; ++i) caps[i] = rsmp_fir_buffer_size_output(rs[i]);   // per CALL, as the reference sizes a call's buffer
-        if (int rc = rsmp_fir_lockstep_bind(rb.ls, d_in, d_out, caps.data())) return fail_and_drop(rc);
+        if (rb.bound.empty()) {
+            std::vector<size_t> caps(n);
+            for (size_t i = 0; i < n; ++i) caps[i] = rsmp_fir_buffer_size_output(rs[i]);   // per CALL, as the reference sizes a call's buffer
+            if (int rc = rsmp_fir_lockstep_bind(rb.ls, d_in, d_out, caps.data())) return fail_and_drop(rc);
+        } else {   // (fresh buffers for this launch: the run planned ahead for it stays)
+            if (int rc = rsmp_fir_lockstep_rebind_buffers(rb.ls, d_in, d_out, stream)) return fail_and_drop(rc);
+        }
         rb.bound = bound;
     }
     if (int rc = rsmp_fir_lockstep_run_bulk(rb.ls, length / ch, frames, 0, 0, stream)) return fail_and_drop(rc);

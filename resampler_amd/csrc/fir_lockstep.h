@@ -224,6 +224,10 @@ hipError_t launch_fir_lockstep_patch_tables(const LsPatchArgs& args, hipStream_t
 // A run planned ahead (on a stream of its own, while the previous run computes) left its results in scratch copies:
 // states, append positions, the last call's counts, status flags -> the batch's own, when the run is really asked for.
 hipError_t launch_fir_lockstep_commit(const LsCommitArgs& args, hipStream_t stream);
+// A run planned ahead names the buffers the batch was bound to when it was planned: descs[gs].in / .out again from the stream table as
+// it is now (rsmp_fir_lockstep_rebind_buffers; a run that starts at the front of `out`: no `append`).
+hipError_t launch_fir_lockstep_rebase(FirStreamDesc* descs, const LockstepStream* streams, const LsRunStream* rs, uint64_t in_offset,
+                                      uint32_t n_streams, hipStream_t stream);
 hipError_t launch_fir_lockstep_gather_counts(const uint64_t* last_counts, const LsRunStream* rs, uint32_t* counts, uint32_t n,
                                              hipStream_t stream);
 

@@ -40,6 +40,7 @@ struct rsmp_fir_lockstep {
     uint32_t rec_stride = 0, epoch = 1, step = 0;   // plan-ahead records (fir_lockstep.h)
     uint32_t max_lds = 0;
     bool bound = false;
+    bool rebased = false;   // the buffers changed under a run planned ahead (rsmp_fir_lockstep_rebind_buffers): its descriptors are patched when it is taken over
     hipStream_t last_stream = nullptr;
     hipStream_t own_stream = nullptr;
     std::vector<uint64_t> h_counts;
@@ -729,6 +730,41 @@ extern "C" int rsmp_fir_lockstep_bind(rsmp_fir_lockstep* ls, const float* const*
     return RSMP_OK;
 }
 
+extern "C" int rsmp_fir_lockstep_rebind_buffers(rsmp_fir_lockstep* ls, const float* const* d_in, float* const* d_out, void* stream) {
+    if (!ls || !d_in || !d_out) return rsmp::fail(RSMP_ERR_INVALID_ARGUMENT, "rsmp_fir_lockstep_rebind_buffers: null argument");
+    if (!ls->bound) return rsmp::fail(RSMP_ERR_INVALID_ARGUMENT, "rsmp_fir_lockstep_rebind_buffers: the batch has not been bound yet");
+    DeviceGuard guard(ls->device);
+    const size_t n = ls->rs.size();
+    bool aligned8 = true;
+    for (size_t i = 0; i < n; ++i)
+        if (reinterpret_cast<uintptr_t>(d_in[i]) % 8 != 0) aligned8 = false;
+    if (aligned8 != ls->in_aligned8) {   // (another build of the step kernel's loads: a bind proper, with the capacities as they are)
+        std::vector<size_t> caps(n);
+        for (size_t k = 0; k < n; ++k) caps[ls->order[k]] = static_cast<size_t>(ls->streams[k].out_cap_frames) * ls->rs[ls->order[k]]->channels;
+        return rsmp_fir_lockstep_bind(ls, d_in, d_out, caps.data());
+    }
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : ls->own_stream;
+    if (ls->last_stream && ls->last_stream != s) RSMP_HIP_CHECK(hipStreamSynchronize(ls->last_stream));
+    // A run planned ahead survives if it starts at the front of `out` (nothing it computed depends on the buffers but the two pointers
+    // in its descriptors); one that appends behind what the old buffers hold does not.
+    const bool keep = ls->ahead_inflight && ls->ahead.valid && ls->ahead.append == 0;
+    if (!keep) {
+        if (int rc = drop_plan_ahead(ls, s)) return rc;
+    }
+    for (size_t k = 0; k < n; ++k) {
+        const uint32_t i = ls->order[k];
+        ls->streams[k].in = d_in[i];
+        ls->streams[k].out = d_out[i];
+    }
+    // (in stream order: steps and runs enqueued before this read the old table, those behind it the new one.  A planner already running
+    // on the plan stream may see either -- its descriptors are patched when the run is taken over.)
+    RSMP_HIP_CHECK(hipMemcpyAsync(ls->d_streams.get(), ls->streams.data(), n * sizeof(LockstepStream), hipMemcpyHostToDevice, s));
+    RSMP_HIP_CHECK(hipMemsetAsync(ls->d_cursor.get(), 0, n * sizeof(uint64_t), s));   // nothing has been appended to the new buffers
+    ls->rebased = keep;
+    ls->last_stream = s;
+    return RSMP_OK;
+}
+
 extern "C" int rsmp_fir_lockstep_step(rsmp_fir_lockstep* ls, size_t in_frames, size_t in_offset_frames,
                                       const uint32_t* d_in_frames, int append, void* stream) {
     if (!ls || !ls->bound)
@@ -1237,6 +1273,11 @@ extern "C" int rsmp_fir_lockstep_run(rsmp_fir_lockstep* ls, size_t k_steps, size
         ls->ahead_inflight = false;
         plan_taken_over = true;
         ++ls->stat_ahead_hits;
+        if (ls->rebased) {   // (planned when the batch was bound to other buffers: the two pointers of every descriptor again)
+            RSMP_HIP_CHECK(rsmp::launch_fir_lockstep_rebase(ls->slot[sl].descs.as<rsmp::FirStreamDesc>(), ls->d_streams.as<LockstepStream>(),
+                                                            ls->d_run_rs.as<rsmp::LsRunStream>(), key.in_offset, static_cast<uint32_t>(n), s));
+            ls->rebased = false;
+        }
         // (new tables: from the next plan on; this run was planned with the old ones, whose images nobody overwrites
         // before this run's kernels are through -- TableRefresher's guard event.  Behind the wait: the planner read
         // the stream table this may patch.)
@@ -1273,6 +1314,7 @@ extern "C" int rsmp_fir_lockstep_run(rsmp_fir_lockstep* ls, size_t k_steps, size
         }
     } else {
         ls->ahead_waited = false;
+        ls->rebased = false;   // (planned here, behind the new table)
         if (ls->ahead.valid) ++ls->stat_ahead_misses;
         if (int rc = drop_plan_ahead(ls, s)) return rc;   // (whatever the plan stream still does: finished before this stream goes on)
         if (int rc = poll_drift(ls, s)) return rc;

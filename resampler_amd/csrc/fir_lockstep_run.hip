@@ -821,6 +821,20 @@ hipError_t launch_fir_lockstep_patch_tables(const LsPatchArgs& args, hipStream_t
     return hipGetLastError();
 }
 
+__global__ __launch_bounds__(256) void fir_lockstep_rebase_kernel(FirStreamDesc* descs, const LockstepStream* streams, const LsRunStream* rs,
+                                                                  uint64_t in_offset, uint32_t n) {
+    const uint32_t gs = blockIdx.x * 256u + threadIdx.x;
+    if (gs >= n) return;
+    descs[gs].in = streams[gs].in + in_offset * rs[gs].channels;   // (as the chain kernel sets them: d->in = ls.in + in_offset * C)
+    descs[gs].out = streams[gs].out;
+}
+
+hipError_t launch_fir_lockstep_rebase(FirStreamDesc* descs, const LockstepStream* streams, const LsRunStream* rs, uint64_t in_offset,
+                                      uint32_t n_streams, hipStream_t stream) {
+    hipLaunchKernelGGL(fir_lockstep_rebase_kernel, dim3((n_streams + 255) / 256), dim3(256), 0, stream, descs, streams, rs, in_offset, n_streams);
+    return hipGetLastError();
+}
+
 hipError_t launch_fir_lockstep_commit(const LsCommitArgs& args, hipStream_t stream) {
     hipLaunchKernelGGL(fir_lockstep_commit_kernel, dim3((args.n_streams + 255) / 256), dim3(256), 0, stream, args);
     return hipGetLastError();

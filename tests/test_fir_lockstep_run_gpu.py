@@ -588,6 +588,53 @@ def test_long_runs_of_few_streams(calls, chunk, fresh):
     ls.close()
 
 
+def test_fresh_buffers_for_every_launch_keep_the_run_planned_ahead():
+    """rsmp_fir_lockstep_rebind_buffers: a service that hands every launch new input and output buffers -- the run planned ahead
+    for the launch survives (it starts at the front of the output; the two pointers of its descriptors are patched when it is
+    taken over): counts, samples and states as the reference's, and plan-ahead hits from the fourth launch on.  A bind proper
+    in between (other capacities would drop the plan) and an appending run after a rebind (which must not survive)."""
+    import torch
+    dev = torch.device("cuda:0")
+    n, k, frames = 14, 40, 128
+    specs = sharding.mixed_rate_batch(n, 2, 512)
+    hs = [ra.ResamplerFir.new_from_hz(2, s.in_hz, s.out_hz, ra.Latency.Sample64, ra.Attenuation.Db90) for s in specs]
+    kind = o.CONVOLVE_AVX_FMA if o.have_avx_fma() else o.CONVOLVE_SCALAR
+    refs = [o.OracleFir(2, s.in_hz, s.out_hz, 128, 90, kind) for s in specs]
+    caps = [h.buffer_size_output() for h in hs]
+    rng = np.random.default_rng(3)
+    ls = ra.FirLockstep(hs, frames)
+    st = torch.cuda.Stream()
+    hits0 = 0
+    for launch in range(9):
+        xs = [(rng.random(2 * k * frames, dtype=np.float32) * 2 - 1).astype(np.float32) for _ in range(n)]
+        d_in = [torch.from_numpy(x).to(dev) for x in xs]
+        d_out = [torch.zeros(k * c, device=dev) for c in caps]
+        if launch in (0, 6):
+            ls.bind_caps(d_in, d_out, caps)
+        else:
+            ls.rebind(d_in, d_out, st.cuda_stream)
+        if launch == 4:
+            hits0 = ls.stats()["plan_ahead_hits"]
+        ls.run(k, frames, 0, append=(launch == 7), stream=st.cuda_stream)
+        st.synchronize()
+        cons, prod = ls.run_counts()
+        for i, r in enumerate(refs):
+            out = np.zeros(caps[i], np.float32)
+            ys = []
+            for c in range(k):
+                rc, cc, pp = r.resample(xs[i][c * 2 * frames:(c + 1) * 2 * frames], out)
+                assert rc == 0 and (cc, pp) == (int(cons[c][i]), int(prod[c][i])), (launch, i, c)
+                ys.append(out[:pp].copy())
+            want = np.concatenate(ys)
+            assert rms(d_out[i][:want.size].cpu().numpy(), want) <= RMS_TOL, (launch, i)
+        if launch == 5:
+            assert ls.stats()["plan_ahead_hits"] >= hits0 + 2, (hits0, ls.stats())   # (launches 4 and 5: planned ahead, buffers new)
+    ls.sync()
+    for h, r in zip(hs, refs):
+        assert h.state() == r.state()
+    ls.close()
+
+
 def test_bulk_calls_a_stream_cannot_accept_whole_are_refused():
     """The driver loop offers a call's remainder again when the call accepts less than its offer (resample/src/main.rs:
     226-254); a run's calls read at fixed offsets -- so rsmp_fir_lockstep_run_bulk takes only calls every stream accepts whole

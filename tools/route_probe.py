@@ -13,9 +13,14 @@ base = torch.from_numpy(synth.sweep(N, 2, 44100.0)).to(dev)
 d_in = [base.clone() for _ in range(S)]
 d_out = [torch.empty(h.bulk_output_bound(2 * N, chunk), device=dev) for h in hs]
 b = ra.FirBatch(hs); b.bind(d_in, d_out)
+fresh = os.environ.get("PROBE_FRESH")   # other buffers for every launch (two sets, in turn): the library re-binds its batch without losing the run planned ahead
+if fresh:
+    sets = [(d_in, d_out), ([t.clone() for t in d_in], [torch.empty_like(t) for t in d_out])]
 st = torch.cuda.Stream()
 ts, tc = [], []
 for rep in range(10):
+    if fresh:
+        b.bind(*sets[rep % 2])
     torch.cuda.synchronize(); t0 = time.perf_counter()
     b.resample_bulk_device(chunk, st.cuda_stream)
     t1 = time.perf_counter()
