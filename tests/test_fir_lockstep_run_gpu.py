@@ -627,7 +627,7 @@ def test_fresh_buffers_for_every_launch_keep_the_run_planned_ahead():
                 ys.append(out[:pp].copy())
             want = np.concatenate(ys)
             assert rms(d_out[i][:want.size].cpu().numpy(), want) <= RMS_TOL, (launch, i)
-        if launch == 5:
+        if launch == 5 and os.environ.get("RSMP_LS_AHEAD") != "0":   # (tests/test_knobs_gpu.py runs this without the plan stream as well)
             assert ls.stats()["plan_ahead_hits"] >= hits0 + 2, (hits0, ls.stats())   # (launches 4 and 5: planned ahead, buffers new)
     ls.sync()
     for h, r in zip(hs, refs):
